@@ -1,0 +1,82 @@
+"""Synthetic inputs shared by bench.py, the tests and the golden-vector generator.
+
+NumPy only (no torch, no reference, no oracle).  Definitions follow SURVEY.md section 8(d):
+ground truth = clipped sum of 6 random cosines + 8 random rectangles, PSF = 15x15 Gaussian
+(sigma 5), observation = circular blur + N(0, (2/255)^2) noise, all from one
+``numpy.random.RandomState`` (draw order matters).
+"""
+import numpy as np
+
+
+def fspecial_gaussian(hsize=15, sigma=5.0):
+    """MATLAB fspecial('gaussian') -- restates reference dprox/contrib/restoration.py:34-45 (float64)."""
+    r = (hsize - 1.0) / 2.0
+    ax = np.arange(-r, r + 1)
+    xx, yy = np.meshgrid(ax, ax)
+    h = np.exp(-(xx * xx + yy * yy) / (2.0 * sigma * sigma))
+    h[h < np.finfo(float).eps * h.max()] = 0
+    s = h.sum()
+    return h / s if s != 0 else h
+
+
+def point_spread_function(ksize=15, sigma=5.0):
+    """HxWx1 float32 PSF -- reference dprox/contrib/restoration.py:21-22."""
+    return fspecial_gaussian(ksize, sigma)[:, :, None].astype("float32")
+
+
+def synth(rng, B, C, H, W):
+    """SURVEY.md Appendix B ground-truth generator, NCHW float32 in [0, 1]."""
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    out = np.zeros((B, C, H, W), np.float32)
+    for b in range(B):
+        for c in range(C):
+            img = np.zeros((H, W))
+            for _ in range(6):
+                f, g = rng.randint(0, 9), rng.randint(0, 9)
+                a = rng.rand()
+                ph = rng.rand() * 2 * np.pi
+                img += a * np.cos(2 * np.pi * (f * yy / H + g * xx / W) + ph)
+            img = img / 3 + 0.5
+            for _ in range(8):
+                y0, x0 = rng.randint(0, H), rng.randint(0, W)
+                h, w = rng.randint(H // 16, H // 3), rng.randint(W // 16, W // 3)
+                img[y0:y0 + h, x0:x0 + w] += rng.uniform(-0.3, 0.3)
+            out[b, c] = np.clip(img, 0, 1)
+    return out
+
+
+def circular_blur(img, psf2d):
+    """Circular (wrap-around) convolution of NCHW ``img`` with a centred 2-D PSF, float64 FFT internally.
+    Equivalent to scipy.ndimage.convolve(mode='wrap') as used by the reference's ``blurring``
+    (dprox/contrib/restoration.py:25-31)."""
+    H, W = img.shape[-2:]
+    kh, kw = psf2d.shape
+    pad = np.zeros((H, W))
+    pad[:kh, :kw] = psf2d
+    pad = np.roll(pad, (-(kh // 2), -(kw // 2)), axis=(0, 1))
+    otf = np.fft.rfft2(pad)
+    return np.fft.irfft2(np.fft.rfft2(img.astype(np.float64), axes=(-2, -1)) * otf, s=(H, W), axes=(-2, -1))
+
+
+def deconv_case(B, C, H, W, seed=2023, noise=2.0 / 255.0, ksize=15, ksigma=5.0):
+    """(gt, b, psf): the config-1/2 deconvolution inputs; ``x0 = b``."""
+    rng = np.random.RandomState(seed)
+    gt = synth(rng, B, C, H, W)
+    psf = point_spread_function(ksize, ksigma)
+    b = circular_blur(gt, psf[:, :, 0].astype(np.float64))
+    b = (b + rng.randn(B, C, H, W) * noise).astype(np.float32)
+    return gt, b, psf
+
+
+def csmri_case(B, H, W, seed=2023, rate=0.25, center=32, noise=0.01):
+    """(gt, mask, y): config-4 style CS-MRI inputs.  gt real NCHW (C=1), mask {0,1} float32 [1,1,H,W],
+    y = mask * centred-orthonormal-FFT(gt) + complex noise (complex64)."""
+    rng = np.random.RandomState(seed)
+    gt = synth(rng, B, 1, H, W)
+    mask = (rng.rand(H, W) < rate).astype(np.float32)
+    c0, c1 = H // 2 - center // 2, W // 2 - center // 2
+    mask[c0:c0 + center, c1:c1 + center] = 1.0
+    k = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(gt.astype(np.float64), axes=(-2, -1)), norm="ortho"), axes=(-2, -1))
+    nz = (rng.randn(B, 1, H, W) + 1j * rng.randn(B, 1, H, W)) * noise
+    y = (mask[None, None] * (k + nz)).astype(np.complex64)
+    return gt, mask[None, None], y

@@ -1,0 +1,421 @@
+#!/usr/bin/env python
+"""Golden-vector generator -- runs ONLY in the build container (needs /root/reference).
+
+Imports the real Delta-Prox reference (PyTorch-CPU path) through a stub for its
+non-arithmetic third-party imports and stores inputs + reference outputs as small
+``.npz`` fixtures next to this file.  Nothing here is
+reference source: the fixtures are data, the shim only mocks I/O / plotting / RL modules
+that are absent from the image, and every number is produced by the reference's own code
++ torch/numpy.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The pretrained FFDNet checkpoints cannot be downloaded (no network), so the denoiser
+cases use seeded random weights (``oracle.ffdnet_weights``) loaded into the reference's
+own ``FFDNet`` module.
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+from unittest.mock import MagicMock
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("DPROX_REFERENCE", "/root/reference")
+
+# ---- import shim: mock only non-arithmetic third-party modules ----
+_MISSING = ["imageio", "skimage", "cv2", "munch", "termcolor", "tensorboardX", "cvxpy", "proximal",
+            "torchlight", "torchlights", "tfpnp", "graphviz", "IPython"]
+
+
+class _Loader(importlib.abc.Loader):
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__name__, m.__path__, m.__spec__, m.__loader__ = spec.name, [], spec, self
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+class _Finder(importlib.abc.MetaPathFinder):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in _MISSING:
+            return importlib.machinery.ModuleSpec(fullname, _Loader(), is_package=True)
+
+
+sys.meta_path.insert(0, _Finder())
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+import scipy.misc  # noqa: E402
+
+_rng0 = np.random.RandomState(0)
+scipy.misc.face = lambda gray=False: (_rng0.rand(768, 1024, 3) * 255).astype("uint8")
+scipy.misc.ascent = lambda: (_rng0.rand(512, 512) * 255).astype("uint8")
+if not hasattr(scipy, "finfo"):
+    scipy.finfo = np.finfo
+for _n, _t in (("int", int), ("bool", bool), ("float", float)):
+    if not hasattr(np, _n):
+        setattr(np, _n, _t)
+
+sys.path.insert(0, REF)        # the reference's `dprox`
+sys.path.insert(1, ROOT)       # synthetic.py, oracle (weights generator only)
+import torch  # noqa: E402
+import dprox as dp  # noqa: E402   (the REFERENCE)
+from dprox.linalg import LinearSolveConfig  # noqa: E402
+from dprox.linalg.solve import cg as ref_cg  # noqa: E402
+from dprox.proxfn.pnp.denoisers.base import Denoiser, Denoiser2D  # noqa: E402
+from dprox.proxfn.pnp.denoisers.models.network_ffdnet import FFDNet  # noqa: E402
+from dprox.utils import fft2, ifft2  # noqa: E402
+from dprox.algo.tune.dpir import log_descent  # noqa: E402
+
+import synthetic  # noqa: E402
+from oracle.dprox_oracle import ffdnet_weights  # noqa: E402
+
+assert dp.__file__.startswith(REF), dp.__file__
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB  keys={list(out)}")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def gauss(k, s):
+    return synthetic.point_spread_function(k, s)
+
+
+# --------------------------------------------------------------------------------------
+# reference denoiser wrappers holding seeded weights
+# --------------------------------------------------------------------------------------
+def load_ffdnet(in_nc, out_nc, nc, nb, seed):
+    net = FFDNet(in_nc=in_nc, out_nc=out_nc, nc=nc, nb=nb, act_mode="R")
+    layers = ffdnet_weights(seed, in_nc, out_nc, nc, nb)
+    sd = {}
+    for i, (w, b) in enumerate(layers):
+        sd[f"model.{2 * i}.weight"] = T(w)
+        sd[f"model.{2 * i}.bias"] = T(b)
+    net.load_state_dict(sd, strict=True)
+    return net
+
+
+class ColorDen(Denoiser):
+    def __init__(self, seed=7):
+        super().__init__()
+        self.model = load_ffdnet(3, 3, 96, 12, seed)
+
+    def _denoise(self, x, sigma):
+        return self.model(x, sigma)
+
+
+class GrayDen(Denoiser2D):
+    def __init__(self, seed=11):
+        super().__init__()
+        self.model = load_ffdnet(1, 1, 64, 15, seed)
+
+    def _denoise(self, x, sigma):
+        return self.model(x, sigma)
+
+
+class MaskedFFT(dp.LinOp):
+    """Config-4 operator expressed through the reference's plugin surface (SURVEY 8(a) NB)."""
+
+    def __init__(self, arg, mask):
+        super().__init__([arg])
+        self.mask = mask
+
+    def forward(self, x, **kw):
+        return self.mask * fft2(x)
+
+    def adjoint(self, y, **kw):
+        return ifft2(self.mask * y).real
+
+
+# --------------------------------------------------------------------------------------
+def g1_linops():
+    rng = np.random.RandomState(101)
+    for tag, shape in (("a", (2, 3, 32, 48)), ("b", (1, 1, 15, 21)), ("c", (2, 3, 20, 24))):
+        x = T(rng.rand(*shape).astype("float32"))
+        y = T(rng.randn(*shape).astype("float32"))
+        psf = gauss(7, 2.0)
+        v = dp.Variable()
+        out = {"x": x, "y": y, "psf": psf}
+        c = dp.conv(v, psf)
+        out["conv_fwd"], out["conv_adj"], out["conv_diag"] = c.forward(x), c.adjoint(y), c.get_diag(x, freq=True)
+        dims = (0, 1, 2) if shape[1] == 3 else (0, 1)
+        for d in dims:
+            g = dp.grad(v, dim=d)
+            out[f"grad{d}_fwd"], out[f"grad{d}_adj"] = g.forward(x), g.adjoint(y)
+            out[f"grad{d}_diag"] = g.get_diag(x, freq=True)
+        save(f"g1_linops_{tag}", **out)
+
+
+def g2_psf2otf():
+    from dprox.utils.psf2otf import psf2otf
+    out = {}
+    k15 = gauss(15, 5.0)
+    out["k15"] = k15
+    o = psf2otf(k15, [64, 64, 1]); out["g15_64x64x1"] = o; out["g15_64x64x1_isreal"] = np.isrealobj(o)
+    o = psf2otf(k15, [32, 48, 3]); out["g15_32x48x3"] = o
+    o = psf2otf(k15, [33, 47, 3]); out["g15_33x47x3"] = o
+    rng = np.random.RandomState(5)
+    ka = rng.rand(5, 4, 1).astype("float32")          # asymmetric, even width
+    out["ka"] = ka
+    out["ka_24x20x3"] = psf2otf(ka, [24, 20, 3])
+    for d in (0, 1, 2):
+        D = dp.grad(dp.Variable(), dim=d).kernel
+        out[f"D{d}"] = D
+        out[f"D{d}_16x24x3"] = psf2otf(D, [16, 24, 3])
+    save("g2_psf2otf", **out)
+
+
+def g3_prox():
+    rng = np.random.RandomState(103)
+    v = T(rng.randn(2, 3, 16, 24).astype("float32"))
+    lam0 = torch.tensor(0.3)
+    lamB = torch.tensor([0.3, 0.05])
+    var = dp.Variable()
+    var.value = torch.zeros(2, 3, 16, 24)
+    out = {"v": v, "lamB": lamB}
+    from dprox.proxfn.norm import soft_threshold
+    out["soft_0p3"] = soft_threshold(v, 0.3)
+    out["norm1_scalar"] = dp.norm1(var).prox(v, lam0)
+    out["norm1_batch"] = dp.norm1(var).prox(v, lamB)
+    out["norm1_alpha2p5"] = (2.5 * dp.norm1(var)).prox(v, lamB)
+    c = T(rng.randn(2, 3, 16, 24).astype("float32"))
+    out["c"] = c
+    out["norm1_offset"] = dp.norm1(var - c).prox(v, lamB)
+    out["norm1_grad1_offset"] = dp.norm1(dp.grad(var, dim=1) - c).prox(v, lam0)
+    out["nonneg"] = dp.nonneg(var).prox(v, lam0)
+    out["nonneg_offset"] = dp.nonneg(var - c).prox(v, lam0)
+    out["sumsq_batch"] = dp.sum_squares(var).prox(v, lamB)
+    out["norm2_scalar"] = dp.norm2(var).prox(v, lam0)
+    fn = dp.norm1(var); fn.beta = 2.0
+    out["norm1_beta2"] = fn.prox(v, lam0)
+    save("g3_prox", **out)
+
+
+def _tv_problem(x, b, psf, dims=(0, 1)):
+    fns = dp.sum_squares(dp.conv(x, psf) - b)
+    for d in dims:
+        fns = fns + dp.norm1(dp.grad(x, dim=d))
+    return fns
+
+
+def g4_solve_direct():
+    rng = np.random.RandomState(104)
+    B, C, H, W = 2, 3, 24, 32
+    b = T(rng.rand(B, C, H, W).astype("float32"))
+    psf = gauss(9, 2.5)
+    x = dp.Variable()
+    fns = _tv_problem(x, b, psf)
+    solver = dp.compile(fns, method="admm", device="cpu")
+    solver.Kall.update_vars([b])
+    rhs = [T(rng.randn(B, C, H, W).astype("float32")) for _ in range(2)]
+    out = {"b": b, "psf": psf, "rhs0": rhs[0], "rhs1": rhs[1]}
+    out["x_rho_scalar"] = solver.least_square.solve(rhs, torch.tensor(0.7))
+    out["x_rho_batch"] = solver.least_square.solve(rhs, torch.tensor([0.7, 0.05]))
+    # identity Psi term: |H|^2 + rho*1
+    x2 = dp.Variable()
+    fns2 = dp.sum_squares(dp.conv(x2, psf) - b) + dp.nonneg(x2)
+    s2 = dp.compile(fns2, method="admm", device="cpu")
+    s2.Kall.update_vars([b])
+    out["x_identity"] = s2.least_square.solve([rhs[0]], torch.tensor(0.3))
+    save("g4_solve_direct", **out)
+
+
+def _sample(t):
+    return t[..., ::4, ::4]
+
+
+def g5_admm_tv():
+    # --- config 1 exactly: 1x1x256x256, rho 0.1, lam 0.005, 20 iterations
+    gt, b, psf = synthetic.deconv_case(1, 1, 256, 256, seed=2023)
+    x = dp.Variable()
+    fns = _tv_problem(x, T(b), psf)
+    snaps = {}
+
+    def cb(iter, state, rho, lam):
+        if iter + 1 in (1, 5, 20):
+            xs, vs, us = state
+            snaps[f"it{iter + 1}_x"] = _sample(xs).clone()
+            for i in range(2):
+                snaps[f"it{iter + 1}_v{i}"] = _sample(vs[i]).clone()
+                snaps[f"it{iter + 1}_u{i}"] = _sample(us[i]).clone()
+                snaps[f"it{iter + 1}_v{i}_sum"] = vs[i].double().sum()
+                snaps[f"it{iter + 1}_u{i}_l2"] = us[i].double().norm()
+            snaps[f"it{iter + 1}_x_sum"] = xs.double().sum()
+
+    out = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=0.1, lams=0.005, max_iter=20, callback=cb)
+    psnr = 10 * np.log10(1.0 / np.mean((out.numpy() - gt) ** 2))
+    save("g5_admm_tv_c1", gt=gt, b=b, psf=psf, x=out, psnr=psnr, value_after=x.value, **snaps)
+
+    # --- 2x3x64x64, 50 iterations, per-iteration rho schedule, full final state
+    gt, b, psf = synthetic.deconv_case(2, 3, 64, 64, seed=7)
+    x = dp.Variable()
+    fns = _tv_problem(x, T(b), psf)
+    rhos = torch.linspace(0.05, 0.3, 50)
+    st = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams=0.004, max_iter=50,
+                               return_full_states=True)
+    save("g5_admm_tv_small", gt=gt, b=b, psf=psf, rhos=rhos, x=st[0], v0=st[1][0], v1=st[1][1], u0=st[2][0], u1=st[2][1])
+
+    # --- defaults (rho=1, lam=0.02, 24 it), HWC numpy x0, three grad terms incl. channel dim, per-term lams
+    gt, b, psf = synthetic.deconv_case(1, 3, 32, 40, seed=9)
+    x = dp.Variable()
+    t_data = dp.sum_squares(dp.conv(x, psf) - T(b))
+    t0, t1, t2 = dp.norm1(dp.grad(x, dim=0)), 2.0 * dp.norm1(dp.grad(x, dim=1)), dp.norm1(dp.grad(x, dim=2))
+    out_def = dp.Problem(t_data + t0 + t1 + t2).solve(method="admm", device="cpu", x0=np.ascontiguousarray(b[0].transpose(1, 2, 0)))
+    out_lams = dp.Problem(t_data + t0 + t1 + t2).solve(
+        method="admm", device="cpu", x0=T(b), rhos=0.2, max_iter=6,
+        lams={t0: 0.01, t1: torch.linspace(0.01, 0.02, 6), t2: 0.003})
+    save("g5_admm_tv_misc", b=b, psf=psf, x_defaults=out_def, x_lams=out_lams)
+
+
+def _csmri(B, H, W, seed):
+    gt, mask, y = synthetic.csmri_case(B, H, W, seed=seed, center=8)
+    return gt, T(mask), T(y)
+
+
+def g6_cg():
+    out = {}
+    for B in (1, 4):
+        gt, mask, y = _csmri(B, 32, 32, seed=60 + B)
+        rho = 0.35
+
+        class A(torch.nn.Module):
+            def forward(self, x):
+                return ifft2(mask * (mask * fft2(x))).real + rho * x
+
+        rhs = ifft2(mask * y).real.float() + rho * T(gt)
+        iters = []
+        import dprox.linalg.solve.solver_cg as scg
+        orig = scg.torch.linalg.norm
+        xs = ref_cg(A(), rhs, rtol=1e-6, max_iters=100, verbose=False)
+        # iteration count at exit: re-run with verbose and parse
+        import io, contextlib
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ref_cg(A(), rhs, rtol=1e-6, max_iters=100, verbose=True)
+        txt = buf.getvalue()
+        n = int(txt.split("Converged at CG Iter")[1].split()[0]) if "Converged" in txt else 100
+        out[f"B{B}_mask"], out[f"B{B}_rhs"], out[f"B{B}_x"], out[f"B{B}_iters"] = mask, rhs, xs, n
+        xs10 = ref_cg(A(), rhs, rtol=0.0, max_iters=10)
+        out[f"B{B}_x_10it"] = xs10
+    out["rho"] = 0.35
+    save("g6_cg", **out)
+
+
+def g7_ladmm_cg():
+    B, H, W = 2, 32, 32
+    gt, mask, y = _csmri(B, H, W, seed=70)
+    x = dp.Variable()
+    A = MaskedFFT(x, mask)
+    den = GrayDen(seed=11)
+    fns = dp.sum_squares(A, y) + dp.nonneg(x) + dp.deep_prior(x, denoiser=den)
+    x0 = ifft2(y).real.float()
+    st = dp.Problem(fns, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100)).solve(
+        method="ladmm", device="cpu", x0=x0, rhos=0.5, lams=0.03, max_iter=5, return_full_states=True)
+    st_admm = dp.Problem(fns, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100)).solve(
+        method="admm", device="cpu", x0=x0, rhos=0.5, lams=0.03, max_iter=3)
+    save("g7_ladmm_cg", gt=gt, mask=mask, y=y, x0=x0, x=st[0], v0=st[1][0], v1=st[1][1], u0=st[2][0], u1=st[2][1],
+         x_admm=st_admm)
+
+
+def g8_ffdnet():
+    rng = np.random.RandomState(108)
+    out = {}
+    col = ColorDen(7).eval()
+    for tag, shape in (("odd", (1, 3, 33, 47)), ("even", (2, 3, 32, 40))):
+        x = T(rng.rand(*shape).astype("float32"))
+        out[f"{tag}_x"] = x
+        for s in (0.02, 0.2):
+            with torch.no_grad():
+                out[f"{tag}_s{s}"] = col.denoise(x, torch.tensor(s))
+    xb = T(rng.rand(2, 3, 16, 24).astype("float32"))
+    with torch.no_grad():
+        out["batch_sigma_x"] = xb
+        out["batch_sigma"] = col.denoise(xb, torch.tensor([0.05, 0.15]))
+    gray = GrayDen(11).eval()
+    xg = T(rng.rand(2, 2, 20, 26).astype("float32"))
+    with torch.no_grad():
+        out["gray_x"] = xg
+        out["gray_s0.1"] = gray.denoise(xg, torch.tensor(0.1))
+    save("g8_ffdnet", **out)
+
+
+def g9_admm_pnp():
+    gt, b, psf = synthetic.deconv_case(2, 3, 32, 40, seed=90)
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=ColorDen(7))
+    fns = dp.sum_squares(dp.conv(x, psf) - T(b)) + prior
+    rhos, sigmas = log_descent(35, 5, 3)
+    st = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams={prior: sigmas}, max_iter=3, return_full_states=True)
+    # + nonneg, like the reference's test_algorithms
+    x2 = dp.Variable()
+    prior2, nn2 = dp.deep_prior(x2, denoiser=ColorDen(7)), dp.nonneg(x2)
+    fns2 = dp.sum_squares(dp.conv(x2, psf) - T(b)) + prior2 + nn2
+    out2 = dp.Problem(fns2).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams={prior2: sigmas, nn2: 0.0}, max_iter=3)
+    save("g9_admm_pnp", gt=gt, b=b, psf=psf, rhos=rhos, sigmas=sigmas, x=st[0], v0=st[1][0], u0=st[2][0], x_nonneg=out2)
+
+
+def g10_pgd():
+    gt, b, psf = synthetic.deconv_case(2, 3, 32, 40, seed=100)
+    x = dp.Variable()
+    fns = dp.sum_squares(dp.conv(x, psf) - T(b)) + dp.norm1(x)
+    out = dp.Problem(fns).solve(method="pgd", device="cpu", x0=T(b), rhos=0.8, lams=0.01, max_iter=5)
+    x2 = dp.Variable()
+    fns2 = dp.sum_squares(dp.conv(x2, psf) - T(b)) + dp.nonneg(x2)
+    out2 = dp.Problem(fns2).solve(method="pgd", device="cpu", x0=T(b), rhos=torch.tensor([[0.8] * 5, [0.4] * 5]), lams=0.01, max_iter=5)
+    save("g10_pgd", b=b, psf=psf, x_norm1=out, x_nonneg_rhoB=out2)
+
+
+def g12_log_descent():
+    out = {}
+    for tag, kw in (("35_5_30", dict(upper=35, lower=5, iter=30)), ("49_7_24_s", dict(upper=49, lower=7, iter=24, sigma=7.65 / 255)),
+                    ("30_10_8_sqrt", dict(upper=30, lower=10, iter=8, sqrt=True, lam=0.1, w=0.7))):
+        r, s = log_descent(**kw)
+        out[f"rhos_{tag}"], out[f"sigmas_{tag}"] = r, s
+    save("g12_log_descent", **out)
+
+
+def g13_known_answers():
+    """The reference's own exact known-answer tests (tests/problem/test_ml_problems.py:5-44), device='cpu'."""
+    out = {}
+    x = dp.Variable((3, 3))
+    rhs = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]])
+    dp.Problem(dp.sum_squares(2 * x - rhs)).solve("admm", device="cpu", x0=np.zeros((3, 3)))
+    out["lsq"] = x.value
+    x = dp.Variable((3, 3))
+    dp.Problem(dp.sum_squares(2 * x, rhs)).solve("admm", device="cpu", x0=np.zeros((3, 3)))
+    out["lsq1"] = x.value
+    x = dp.Variable((3, 3, 1))
+    rhs3 = np.array([[[1, 2, 3], [4, 5, 6], [7, 8, 9]]])
+    kernel = np.array([[1, 1], [1, 1]]) / 4
+    dp.Problem(dp.sum_squares(dp.conv(x, kernel) - rhs3)).solve("admm", device="cpu", x0=np.zeros((3, 3, 1)))
+    out["lsq2_x"] = x.value
+    out["lsq2_res"] = dp.eval(dp.conv(x, kernel) - rhs3, x.value, zero_out_constant=False)
+    x = dp.Variable((3))
+    rhs1 = np.array([1, 2, 3])
+    dp.Problem(dp.sum_squares(2 * x - rhs1)).solve("admm", device="cpu", x0=np.zeros(3))
+    out["lsq3"] = x.value
+    save("g13_known_answers", **out)
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
+               g9_admm_pnp, g10_pgd, g12_log_descent, g13_known_answers):
+        if not only or any(fn.__name__.startswith(o) for o in only):
+            fn()

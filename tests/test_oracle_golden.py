@@ -1,0 +1,245 @@
+"""Pins the oracle (oracle/dprox_oracle.py) against golden vectors produced by the real
+reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import assert_close, load_golden, rel_l2
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+TIGHT = 2e-6     # same ops in the same order -> only thread-count / summation-order noise
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g1_linops(tag):
+    g = load_golden(f"g1_linops_{tag}")
+    x, y = T(g["x"]), T(g["y"])
+    c = O.lin_conv(g["psf"])
+    assert_close(c.fwd(x), g["conv_fwd"], TIGHT, "conv fwd")
+    assert_close(c.adj(y), g["conv_adj"], TIGHT, "conv adj")
+    assert_close(c.diag(x, True), g["conv_diag"], TIGHT, "conv diag")
+    for d in (0, 1, 2):
+        if f"grad{d}_fwd" not in g:
+            continue
+        l = O.lin_grad(d)
+        assert_close(l.fwd(x), g[f"grad{d}_fwd"], TIGHT, f"grad{d} fwd")
+        assert_close(l.adj(y), g[f"grad{d}_adj"], TIGHT, f"grad{d} adj")
+        assert_close(l.diag(x, True), g[f"grad{d}_diag"], TIGHT, f"grad{d} diag")
+        assert l.diag(x, True).dtype == torch.float64          # complex128 OTF
+
+
+def test_g1_grad_is_forward_difference():
+    """forward = x[n+1]-x[n] (circular), adjoint = y[n-1]-y[n]."""
+    g = load_golden("g1_linops_a")
+    x, y = g["x"], g["y"]
+    assert_close(np.roll(x, -1, axis=2) - x, g["grad0_fwd"], 2e-6)
+    assert_close(np.roll(x, -1, axis=3) - x, g["grad1_fwd"], 2e-6)
+    # dim=2 quirk: psf2otf FFTs over C as well, the result is used as a per-channel 2-D multiplier
+    # => a per-channel scale Re(exp(2*pi*i*c/3) - 1) = [0, -1.5, -1.5], not a channel difference.
+    sc = np.array([0.0, -1.5, -1.5], np.float32).reshape(1, 3, 1, 1)
+    assert_close(x * sc, g["grad2_fwd"], 2e-6)
+    assert_close(y * sc, g["grad2_adj"], 2e-6)
+    assert_close(np.broadcast_to(np.array([0.0, 3.0, 3.0]).reshape(1, 3, 1, 1), g["grad2_diag"].shape), g["grad2_diag"], 1e-6)
+    assert_close(np.roll(y, 1, axis=2) - y, g["grad0_adj"], 2e-6)
+    assert_close(np.roll(y, 1, axis=3) - y, g["grad1_adj"], 2e-6)
+
+
+def test_g2_psf2otf():
+    g = load_golden("g2_psf2otf")
+    k15 = g["k15"]
+    o = O.psf2otf(k15, [64, 64, 1])
+    assert np.isrealobj(o) == bool(g["g15_64x64x1_isreal"])
+    assert_close(o, g["g15_64x64x1"], 1e-6)
+    assert_close(O.psf2otf(k15, [32, 48, 3]), g["g15_32x48x3"], 1e-6)
+    assert_close(O.psf2otf(k15, [33, 47, 3]), g["g15_33x47x3"], 1e-6)
+    assert_close(O.psf2otf(g["ka"], [24, 20, 3]), g["ka_24x20x3"], 1e-6)
+    for d in (0, 1, 2):
+        D = O.grad_kernel(d).numpy()
+        assert np.array_equal(D, g[f"D{d}"])
+        assert_close(O.psf2otf(D, [16, 24, 3]), g[f"D{d}_16x24x3"], 1e-12)
+
+
+def test_g3_prox():
+    g = load_golden("g3_prox")
+    v, c = T(g["v"]), T(g["c"])
+    lam0, lamB = torch.tensor(0.3), T(g["lamB"])
+    xref = torch.zeros_like(v)
+    I = O.lin_identity()
+    assert_close(O.soft_threshold(v, 0.3), g["soft_0p3"], 1e-7)
+    assert_close(O.prox(O.norm1(I), v, lam0, xref), g["norm1_scalar"], 1e-7)
+    assert_close(O.prox(O.norm1(I), v, lamB, xref), g["norm1_batch"], 1e-7)
+    assert_close(O.prox(O.norm1(I, alpha=2.5), v, lamB, xref), g["norm1_alpha2p5"], 1e-7)
+    assert_close(O.prox(O.norm1(I.minus(c)), v, lamB, xref), g["norm1_offset"], 1e-7)
+    assert_close(O.prox(O.norm1(O.lin_grad(1).minus(c)), v, lam0, xref), g["norm1_grad1_offset"], 1e-6)
+    assert_close(O.prox(O.nonneg(I), v, lam0, xref), g["nonneg"], 1e-7)
+    assert_close(O.prox(O.nonneg(I.minus(c)), v, lam0, xref), g["nonneg_offset"], 1e-7)
+    assert_close(O.prox(O.sum_squares(I), v, lamB, xref), g["sumsq_batch"], 1e-7)
+    assert_close(O.prox(O.norm2(I), v, lam0, xref), g["norm2_scalar"], 1e-7)
+    t = O.norm1(I); t.beta = 2.0
+    assert_close(O.prox(t, v, lam0, xref), g["norm1_beta2"], 1e-7)
+
+
+def _tv_terms(b, psf, dims=(0, 1)):
+    return [O.sum_squares(O.lin_conv(psf).minus(b))] + [O.norm1(O.lin_grad(d)) for d in dims]
+
+
+def test_g4_solve_direct():
+    g = load_golden("g4_solve_direct")
+    b = T(g["b"])
+    terms = _tv_terms(b, g["psf"])
+    ls = O.LeastSquares([terms[0]], terms[1:])
+    assert ls.freq_diagonalizable and not ls.diagonalizable
+    rhs = [T(g["rhs0"]), T(g["rhs1"])]
+    assert_close(ls.solve(rhs, torch.tensor(0.7), xref=b), g["x_rho_scalar"], TIGHT)
+    assert_close(ls.solve(rhs, torch.tensor([0.7, 0.05]), xref=b), g["x_rho_batch"], TIGHT)
+    ls2 = O.LeastSquares([terms[0]], [O.nonneg(O.lin_identity())])
+    assert_close(ls2.solve([rhs[0]], torch.tensor(0.3), xref=b), g["x_identity"], TIGHT)
+
+
+def test_g5_admm_tv_config1():
+    g = load_golden("g5_admm_tv_c1")
+    b = T(g["b"])
+    snaps = {}
+
+    def cb(iter, state, rho, lam):
+        if iter + 1 in (1, 5, 20):
+            snaps[iter + 1] = (state[0].clone(), [e.clone() for e in state[1]], [e.clone() for e in state[2]])
+
+    x = O.solve(_tv_terms(b, g["psf"]), "admm", x0=b, rhos=0.1, lams=0.005, max_iter=20, callback=cb)
+    assert_close(x, g["x"], 5e-6, "final x")
+    for it, (xs, vs, us) in snaps.items():
+        assert_close(xs[..., ::4, ::4], g[f"it{it}_x"], 5e-6, f"x@{it}")
+        assert abs(float(xs.double().sum()) - float(g[f"it{it}_x_sum"])) <= 1e-5 * abs(float(g[f"it{it}_x_sum"]))
+        for i in range(2):
+            assert_close(vs[i][..., ::4, ::4], g[f"it{it}_v{i}"], 2e-5, f"v{i}@{it}")
+            assert_close(us[i][..., ::4, ::4], g[f"it{it}_u{i}"], 2e-5, f"u{i}@{it}")
+    psnr = float(O.psnr(x, T(g["gt"]))[0])
+    assert abs(psnr - float(g["psnr"])) < 1e-3
+    assert psnr > 31.0          # 24.77 dB -> 31.90 dB after 20 iterations
+
+
+def test_g5_admm_tv_small_and_misc():
+    g = load_golden("g5_admm_tv_small")
+    b = T(g["b"])
+    st = O.solve(_tv_terms(b, g["psf"]), "admm", x0=b, rhos=T(g["rhos"]), lams=0.004, max_iter=50, return_full_states=True)
+    assert_close(st[0], g["x"], 5e-6, "x")
+    for i in range(2):
+        assert_close(st[1][i], g[f"v{i}"], 5e-5, f"v{i}")
+        assert_close(st[2][i], g[f"u{i}"], 5e-5, f"u{i}")
+    g = load_golden("g5_admm_tv_misc")
+    b = T(g["b"])
+    terms = _tv_terms(b, g["psf"], dims=(0, 1, 2))
+    terms[2].alpha = 2.0
+    x = O.solve(terms, "admm", x0=np.ascontiguousarray(g["b"][0].transpose(1, 2, 0)))
+    assert_close(x, g["x_defaults"], 5e-6, "defaults")
+    x = O.solve(terms, "admm", x0=b, rhos=0.2, max_iter=6,
+                lams={terms[1]: 0.01, terms[2]: torch.linspace(0.01, 0.02, 6), terms[3]: 0.003})
+    assert_close(x, g["x_lams"], 5e-6, "per-term lams")
+
+
+def _masked(mask):
+    return O.lin_custom(lambda x: mask * O.fft2c(x), lambda y: O.ifft2c(mask * y).real)
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_g6_cg(B):
+    g = load_golden("g6_cg")
+    mask, rhs, rho = T(g[f"B{B}_mask"]), T(g[f"B{B}_rhs"]), float(g["rho"])
+    A = lambda x: O.ifft2c(mask * (mask * O.fft2c(x))).real + rho * x
+    x, n = O.cg(A, rhs, rtol=1e-6, max_iters=100, return_iters=True)
+    assert n == int(g[f"B{B}_iters"])
+    assert_close(x, g[f"B{B}_x"], 5e-6)
+    assert_close(O.cg(A, rhs, rtol=0.0, max_iters=10), g[f"B{B}_x_10it"], 5e-6)
+
+
+def test_g7_ladmm_cg():
+    g = load_golden("g7_ladmm_cg")
+    mask, y, x0 = T(g["mask"]), T(g["y"]), T(g["x0"])
+    den = O.FFDNetOracle(O.ffdnet_weights(11, 1, 1, 64, 15), per_band=True)
+    terms = [O.sum_squares(_masked(mask), b=y), O.nonneg(O.lin_identity()), O.deep_prior(O.lin_identity(), den)]
+    cfg = O.LinearSolveConfig(rtol=1e-6, max_iters=100)
+    with torch.no_grad():
+        st = O.solve(terms, "ladmm", x0=x0, rhos=0.5, lams=0.03, max_iter=5, return_full_states=True, linear_solve_config=cfg)
+        xa = O.solve(terms, "admm", x0=x0, rhos=0.5, lams=0.03, max_iter=3, linear_solve_config=cfg)
+    assert_close(st[0], g["x"], 2e-5, "ladmm x")
+    assert_close(st[1][0], g["v0"], 2e-5); assert_close(st[1][1], g["v1"], 2e-5)
+    assert_close(st[2][0], g["u0"], 5e-5); assert_close(st[2][1], g["u1"], 5e-5)
+    assert_close(xa, g["x_admm"], 2e-5, "admm+cg x")
+
+
+def test_g8_ffdnet():
+    g = load_golden("g8_ffdnet")
+    col = O.FFDNetOracle(O.ffdnet_weights(7))
+    with torch.no_grad():
+        for tag in ("odd", "even"):
+            for s in (0.02, 0.2):
+                assert_close(col(T(g[f"{tag}_x"]), torch.tensor(s)), g[f"{tag}_s{s}"], 5e-6, f"{tag} {s}")
+        assert_close(col(T(g["batch_sigma_x"]), torch.tensor([0.05, 0.15])), g["batch_sigma"], 5e-6)
+        gray = O.FFDNetOracle(O.ffdnet_weights(11, 1, 1, 64, 15), per_band=True)
+        assert_close(gray(T(g["gray_x"]), torch.tensor(0.1)), g["gray_s0.1"], 5e-6)
+    assert sum(w.size + b.size for w, b in O.ffdnet_weights(7)) == 852108
+
+
+def test_pixel_unshuffle_order():
+    """channel = c*4 + dy*2 + dx; PixelShuffle(2) is the exact inverse."""
+    x = torch.arange(16.0).view(1, 1, 4, 4)
+    u = O.pixel_unshuffle2(x)
+    assert u[0, :, :, :].flatten(1).tolist() == [[0, 2, 8, 10], [1, 3, 9, 11], [4, 6, 12, 14], [5, 7, 13, 15]]
+    assert torch.equal(torch.nn.functional.pixel_shuffle(u, 2), x)
+
+
+def test_g9_admm_pnp():
+    g = load_golden("g9_admm_pnp")
+    b = T(g["b"])
+    den = O.FFDNetOracle(O.ffdnet_weights(7))
+    prior = O.deep_prior(O.lin_identity(), den)
+    terms = [O.sum_squares(O.lin_conv(g["psf"]).minus(b)), prior]
+    rhos, sig = O.log_descent(35, 5, 3)
+    assert_close(rhos, g["rhos"], 1e-7); assert_close(sig, g["sigmas"], 1e-7)
+    with torch.no_grad():
+        st = O.solve(terms, "admm", x0=b, rhos=rhos, lams={prior: sig}, max_iter=3, return_full_states=True)
+    assert_close(st[0], g["x"], 1e-5); assert_close(st[1][0], g["v0"], 1e-5); assert_close(st[2][0], g["u0"], 5e-5)
+    nn = O.nonneg(O.lin_identity())
+    with torch.no_grad():
+        x2 = O.solve(terms + [nn], "admm", x0=b, rhos=rhos, lams={prior: sig, nn: 0.0}, max_iter=3)
+    assert_close(x2, g["x_nonneg"], 1e-5)
+
+
+def test_g10_pgd():
+    g = load_golden("g10_pgd")
+    b = T(g["b"])
+    data = O.sum_squares(O.lin_conv(g["psf"]).minus(b))
+    assert_close(O.solve([data, O.norm1(O.lin_identity())], "pgd", x0=b, rhos=0.8, lams=0.01, max_iter=5), g["x_norm1"], 5e-6)
+    rhoB = torch.tensor([[0.8] * 5, [0.4] * 5])
+    assert_close(O.solve([data, O.nonneg(O.lin_identity())], "pgd", x0=b, rhos=rhoB, lams=0.01, max_iter=5), g["x_nonneg_rhoB"], 5e-6)
+    with pytest.raises(ValueError):
+        O.solve([data], "pgd", x0=b)
+
+
+def test_g12_log_descent():
+    g = load_golden("g12_log_descent")
+    for tag, kw in (("35_5_30", dict(upper=35, lower=5, iter=30)), ("49_7_24_s", dict(upper=49, lower=7, iter=24, sigma=7.65 / 255)),
+                    ("30_10_8_sqrt", dict(upper=30, lower=10, iter=8, sqrt=True, lam=0.1, w=0.7))):
+        r, s = O.log_descent(**kw)
+        assert r.dtype == torch.float32 and s.dtype == torch.float32
+        assert np.array_equal(r.numpy(), g[f"rhos_{tag}"]) and np.array_equal(s.numpy(), g[f"sigmas_{tag}"])
+
+
+def test_g13_known_answers():
+    """The reference's exact known-answer tests (tests/problem/test_ml_problems.py:5-44)."""
+    g = load_golden("g13_known_answers")
+    rhs = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]])
+    I2 = O.lin_scale(2, O.lin_identity())
+    x = O.solve([O.sum_squares(I2.minus(rhs))], "admm", x0=np.zeros((3, 3)))
+    assert (x.numpy() == rhs / 2).all() and np.array_equal(x.numpy(), g["lsq"])
+    x = O.solve([O.sum_squares(I2, b=rhs)], "admm", x0=np.zeros((3, 3)))
+    assert (x.numpy() == rhs / 2).all() and np.array_equal(x.numpy(), g["lsq1"])
+    rhs3 = np.array([[[1, 2, 3], [4, 5, 6], [7, 8, 9]]])
+    kernel = np.array([[1, 1], [1, 1]]) / 4
+    lin = O.lin_conv(kernel).minus(rhs3)
+    x = O.solve([O.sum_squares(lin)], "admm", x0=np.zeros((3, 3, 1)))
+    assert_close(x, g["lsq2_x"], 1e-5)
+    assert (lin.value(x) < 1e-5).all()
+    x = O.solve([O.sum_squares(I2.minus(np.array([1, 2, 3])))], "admm", x0=np.zeros(3))
+    assert np.array_equal(x.numpy(), g["lsq3"])
