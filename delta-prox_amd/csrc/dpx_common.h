@@ -1,0 +1,92 @@
+// Internal helpers shared by the gfx950 kernels of libdpx_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/dpx.h"
+
+namespace dpx {
+
+// ---- error reporting (thread-local last error, int status across the ABI) -------------------
+void set_error(const char* fmt, ...);
+int launch_status(const char* what);   // hipGetLastError() -> DPX_OK / DPX_ERR_LAUNCH
+
+// ---- optional per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) -------
+void timing_begin(const char* name, hipStream_t s);
+void timing_end(hipStream_t s);
+#define DPX_LAUNCH(name, kernel, grid, block, shmem, stream, ...)              \
+  do {                                                                          \
+    ::dpx::timing_begin(name, stream);                                          \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);        \
+    ::dpx::timing_end(stream);                                                  \
+  } while (0)
+
+#define DPX_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::dpx::set_error(__VA_ARGS__);    \
+      return DPX_ERR_ARG;               \
+    }                                   \
+  } while (0)
+
+// ---- complex arithmetic on float2 ---------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {   // a * conj(b)
+  return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+// multiply by -i (DIR = -1, forward) or +i (DIR = +1, inverse)
+template <int DIR> __device__ __forceinline__ float2 cmul_i(float2 a) {
+  return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+// ---- mixed-radix plan for one 1-D complex transform (passed by value to kernels) -----------
+struct Plan1D {
+  int n;
+  int nf;
+  int radix[20];
+};
+Plan1D make_plan(int n);
+
+// half-spectrum geometry of an H x W real plane: Ws stored columns; for even W the Nyquist column
+// is packed into the imaginary part of column 0 (both are real-valued after the row transform).
+static inline int spec_cols(int W) { return (W + 1) / 2; }
+
+// ---- spectral tables ---------------------------------------------------------------------------
+// layout of a real or complex table: main [C][H][Ws] then side [C][H] (values on the Nyquist column
+// l = W/2, only meaningful for even W).
+static inline size_t table_elems(int C, int H, int W) { return (size_t)C * H * spec_cols(W) + (size_t)C * H; }
+
+// twiddle table: float2[W] (e^{-2 pi i t / W}) followed by float2[H]
+static inline const float2* tw_rows(const void* table) { return (const float2*)table; }
+static inline const float2* tw_cols(const void* table, int W) { return (const float2*)table + W; }
+
+// pointwise operator applied between the forward and inverse column transforms
+enum SpecOp { OP_MUL = 0, OP_MULCONJ = 1, OP_SOLVE = 2 };
+struct SpecArgs {
+  const float2* otf;   // OP_MUL / OP_MULCONJ
+  const float* d0;     // OP_SOLVE (nullable)
+  const float* d1;     // OP_SOLVE (nullable)
+  const float* rho;    // OP_SOLVE device [B]
+  float c0, c1, eps;
+  float scale;         // 1/(H*W)
+};
+
+int spectral_apply(const float* x, float* y, int op, const SpecArgs& a, int B, int C, int H, int W,
+                   const void* table, void* ws, hipStream_t stream);
+
+static inline int grid_for(long n, int block, int cap = 256 * 8) {
+  long g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace dpx

@@ -1,0 +1,371 @@
+// Streaming (HBM-bound) kernels of the ADMM/PGD iteration: stencils, proximal operators, the fused
+// z/dual update, the x-update right-hand side, AXPY-style linear combinations and batched dots.
+//
+// They replace the reference's chains of eager elementwise torch ops:
+//   * v_i = prox(K_i x + u_i), u_i += K_i x - v_i           dprox/algo/admm.py:54-57
+//   * Ktb + rho * sum_i K_i^T (v_i - u_i)                    dprox/proxfn/sum_square.py:126-135, algo/admm.py:51
+//   * soft-threshold / nonneg / v/(1+2 lam)                 dprox/proxfn/norm.py:6-27, nonneg.py:10-11, sum_square.py:26-27
+//   * grad forward/adjoint (a 2-tap circular stencil the reference evaluates with two full FFTs)
+//                                                           dprox/linop/grad.py:8-23, linop/conv.py:31-41
+//   * bdot and the CG AXPYs                                  dprox/linalg/solve/solver_cg.py:7-22,109-129
+// All of them are one coalesced float4 pass over each operand; halo values of the stencils come
+// from L2 (the neighbouring row/pixel was just streamed by the same or the adjacent workgroup).
+#include "dpx_common.h"
+
+namespace dpx {
+
+__device__ __forceinline__ float prox_eval(int kind, float d, float lam) {
+  switch (kind) {
+    case DPX_PROX_NORM1: {                                   // sign(d) * max(|d| - lam, 0)
+      const float m = fmaxf(fabsf(d) - lam, 0.f);
+      return d > 0.f ? m : (d < 0.f ? -m : 0.f * m);
+    }
+    case DPX_PROX_NONNEG: return fmaxf(d, 0.f);
+    case DPX_PROX_SUMSQ: return d / (1.f + 2.f * lam);
+    default: return d;
+  }
+}
+
+struct TermPack {
+  dpx_term t[DPX_MAX_TERMS];
+  int n;
+};
+
+// ---------------------------------------------------------------------------------------------
+// z / dual update.  One thread = 4 consecutive pixels of a row (VEC=4) or one pixel (VEC=1).
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void k_zupdate(const float* __restrict__ x, TermPack T, int B, int C, int H, int W) {
+  const int Wv = W / VEC;
+  const long total = (long)B * C * H * Wv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int wv = (int)(i % Wv);
+    const long row = i / Wv;                 // (b*C + c)*H + h
+    const int h = (int)(row % H);
+    const long plane = row / H;
+    const int b = (int)(plane / C);
+    const long off = row * W + (long)wv * VEC;
+    float xv[VEC + 1];
+    if constexpr (VEC == 4) {
+      const float4 q = *(const float4*)(x + off);
+      xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+    } else {
+      xv[0] = x[off];
+    }
+    bool need_w = false, need_h = false;
+    for (int t = 0; t < T.n; ++t) {
+      need_w |= T.t[t].linop == DPX_LIN_GRAD_W;
+      need_h |= T.t[t].linop == DPX_LIN_GRAD_H;
+    }
+    if (need_w) xv[VEC] = x[row * W + ((wv + 1) * VEC) % W];
+    float xd[VEC];
+    if (need_h) {
+      const long offd = (plane * H + (h + 1 == H ? 0 : h + 1)) * W + (long)wv * VEC;
+      if constexpr (VEC == 4) {
+        const float4 q = *(const float4*)(x + offd);
+        xd[0] = q.x; xd[1] = q.y; xd[2] = q.z; xd[3] = q.w;
+      } else {
+        xd[0] = x[offd];
+      }
+    }
+    for (int t = 0; t < T.n; ++t) {
+      const dpx_term tm = T.t[t];
+      const float lam = tm.lam ? tm.lam[b] * tm.alpha : 0.f;
+      float uu[VEC], vv[VEC];
+      if (tm.prox != DPX_PROX_EXTERNAL || true) {
+        if constexpr (VEC == 4) {
+          const float4 q = *(const float4*)(tm.u + off);
+          uu[0] = q.x; uu[1] = q.y; uu[2] = q.z; uu[3] = q.w;
+        } else {
+          uu[0] = tm.u[off];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float kx;
+        if (tm.linop == DPX_LIN_IDENTITY) kx = xv[e];
+        else if (tm.linop == DPX_LIN_GRAD_W) kx = xv[e + 1] - xv[e];
+        else kx = xd[e] - xv[e];
+        const float d = kx + uu[e];
+        if (tm.prox == DPX_PROX_EXTERNAL) {
+          vv[e] = d;                                         // the denoiser consumes d; u finished afterwards
+        } else {
+          vv[e] = prox_eval(tm.prox, d, lam);
+          uu[e] = d - vv[e];
+        }
+      }
+      if constexpr (VEC == 4) {
+        *(float4*)(tm.v + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (tm.prox != DPX_PROX_EXTERNAL) *(float4*)(tm.u + off) = make_float4(uu[0], uu[1], uu[2], uu[3]);
+      } else {
+        tm.v[off] = vv[0];
+        if (tm.prox != DPX_PROX_EXTERNAL) tm.u[off] = uu[0];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rhs = ktb + sum_i rho_b * K_i^T (v_i - u_i)
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void k_rhs(float* __restrict__ rhs, const float* __restrict__ ktb, const float* __restrict__ rho, TermPack T,
+                      int B, int C, int H, int W) {
+  const int Wv = W / VEC;
+  const long total = (long)B * C * H * Wv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int wv = (int)(i % Wv);
+    const long row = i / Wv;
+    const int h = (int)(row % H);
+    const long plane = row / H;
+    const int b = (int)(plane / C);
+    const long off = row * W + (long)wv * VEC;
+    const float r = rho[b];
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int t = 0; t < T.n; ++t) {
+      const dpx_term tm = T.t[t];
+      float y[VEC + 1];   // y[1..VEC] = (v-u) at this pixel group, y[0] = left neighbour
+      if constexpr (VEC == 4) {
+        const float4 a = *(const float4*)(tm.v + off), c = *(const float4*)(tm.u + off);
+        y[1] = a.x - c.x; y[2] = a.y - c.y; y[3] = a.z - c.z; y[4] = a.w - c.w;
+      } else {
+        y[1] = tm.v[off] - tm.u[off];
+      }
+      if (tm.linop == DPX_LIN_IDENTITY) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += y[e + 1];
+      } else if (tm.linop == DPX_LIN_GRAD_W) {
+        const long left = row * W + (wv == 0 ? W - 1 : wv * VEC - 1);
+        y[0] = tm.v[left] - tm.u[left];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += y[e] - y[e + 1];
+      } else {
+        const long offu = (plane * H + (h == 0 ? H - 1 : h - 1)) * W + (long)wv * VEC;
+        float yu[VEC];
+        if constexpr (VEC == 4) {
+          const float4 a = *(const float4*)(tm.v + offu), c = *(const float4*)(tm.u + offu);
+          yu[0] = a.x - c.x; yu[1] = a.y - c.y; yu[2] = a.z - c.z; yu[3] = a.w - c.w;
+        } else {
+          yu[0] = tm.v[offu] - tm.u[offu];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += yu[e] - y[e + 1];
+      }
+    }
+    if constexpr (VEC == 4) {
+      float4 k = ktb ? *(const float4*)(ktb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(rhs + off) = make_float4(fmaf(r, acc[0], k.x), fmaf(r, acc[1], k.y), fmaf(r, acc[2], k.z), fmaf(r, acc[3], k.w));
+    } else {
+      rhs[off] = fmaf(r, acc[0], ktb ? ktb[off] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone stencil, prox, linear combination
+// ---------------------------------------------------------------------------------------------
+__global__ void k_grad(const float* __restrict__ x, float* __restrict__ y, int dim, int adjoint, long planes, int H, int W) {
+  const long total = planes * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long row = i / W;
+    const int h = (int)(row % H);
+    long j;
+    if (dim == 1) {
+      const int wn = adjoint ? (w == 0 ? W - 1 : w - 1) : (w + 1 == W ? 0 : w + 1);
+      j = row * W + wn;
+    } else {
+      const int hn = adjoint ? (h == 0 ? H - 1 : h - 1) : (h + 1 == H ? 0 : h + 1);
+      j = (row - h + hn) * W + w;
+    }
+    y[i] = x[j] - x[i];
+  }
+}
+
+__global__ void k_prox(int kind, const float* __restrict__ v, float* __restrict__ out, const float* __restrict__ lam,
+                       float alpha, const float* __restrict__ off, int B, long npb) {
+  const long total = (long)B * npb;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / npb);
+    const float o = off ? off[i] : 0.f;
+    out[i] = prox_eval(kind, v[i] - o, (lam ? lam[b] : 0.f) * alpha) + o;
+  }
+}
+
+struct LinPack {
+  const float* x[4];
+  const float* cb[4];
+  float c[4];
+  int n;
+};
+__global__ void k_lincomb(float* __restrict__ out, LinPack L, int B, long npb) {
+  const long total = (long)B * npb;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / npb);
+    float acc = 0.f;
+    for (int t = 0; t < L.n; ++t) {
+      const float c = L.c[t] * (L.cb[t] ? L.cb[t][b] : 1.f);
+      acc = (t == 0) ? c * L.x[t][i] : fmaf(c, L.x[t][i], acc);
+    }
+    out[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched dot products: per-block partials (wave shuffles + one LDS hop), then a tiny finishing pass.
+// Deterministic (no atomics): the CG iterates must be reproducible run to run.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  const int nw = (blockDim.x + 63) >> 6;
+  float r = (threadIdx.x < nw) ? sh[threadIdx.x] : 0.f;
+  if (wid == 0) r = wave_sum(r);
+  return r;   // valid in wave 0
+}
+
+// grid (nblk, B, Bj): partial[(bi*Bj + bj)*nblk + blk] = sum over a slice of <x[bi], y[bj or bi]>
+__global__ void k_dot_partial(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ partial,
+                              long npb, int gram) {
+  __shared__ float sh[16];
+  const int bi = blockIdx.y, bj = gram ? blockIdx.z : bi;
+  const float* xa = x + (long)bi * npb;
+  const float* yb = y + (long)bj * npb;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npb; i += (long)gridDim.x * blockDim.x)
+    acc = fmaf(xa[i], yb[i], acc);
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[((long)bi * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = acc;
+}
+__global__ void k_dot_finish(const float* __restrict__ partial, float* __restrict__ out, int nblk) {
+  __shared__ float sh[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += partial[(long)blockIdx.x * nblk + i];
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+static int dot_blocks(long npb) {
+  long g = (npb + 256 * 8 - 1) / (256 * 8);
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static int pack_terms(TermPack& T, const dpx_term* terms, int n, const char* who, bool& vec_ok) {
+  if (n < 0 || n > DPX_MAX_TERMS || (n > 0 && !terms)) {
+    set_error("%s: nterms must be in [0, %d]", who, DPX_MAX_TERMS);
+    return DPX_ERR_ARG;
+  }
+  T.n = n;
+  for (int i = 0; i < n; ++i) {
+    T.t[i] = terms[i];
+    if (!terms[i].v || !terms[i].u) {
+      set_error("%s: term %d has a null state pointer", who, i);
+      return DPX_ERR_ARG;
+    }
+    if (terms[i].linop < DPX_LIN_IDENTITY || terms[i].linop > DPX_LIN_GRAD_W || terms[i].prox < 0 || terms[i].prox > DPX_PROX_EXTERNAL) {
+      set_error("%s: term %d has an unknown linop/prox code", who, i);
+      return DPX_ERR_ARG;
+    }
+    vec_ok &= aligned16(terms[i].v) && aligned16(terms[i].u);
+  }
+  return DPX_OK;
+}
+
+}  // namespace dpx
+
+using namespace dpx;
+
+extern "C" int dpx_admm_zupdate(const float* x, const dpx_term* terms, int nterms, int B, int C, int H, int W,
+                                dpx_stream_t stream) {
+  DPX_REQUIRE(x && B > 0 && C > 0 && H > 0 && W > 0, "dpx_admm_zupdate: bad arguments");
+  TermPack T;
+  bool vec = (W % 4 == 0) && aligned16(x);
+  int rc = pack_terms(T, terms, nterms, "dpx_admm_zupdate", vec);
+  if (rc) return rc;
+  if (nterms == 0) return DPX_OK;
+  const long n = (long)B * C * H * W;
+  if (vec)
+    DPX_LAUNCH("k_zupdate", (k_zupdate<4>), dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, T, B, C, H, W);
+  else
+    DPX_LAUNCH("k_zupdate", (k_zupdate<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, T, B, C, H, W);
+  return launch_status("dpx_admm_zupdate");
+}
+
+extern "C" int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, const dpx_term* terms, int nterms, int B, int C,
+                            int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(rhs && rho && B > 0 && C > 0 && H > 0 && W > 0, "dpx_admm_rhs: bad arguments");
+  TermPack T;
+  bool vec = (W % 4 == 0) && aligned16(rhs) && (!ktb || aligned16(ktb));
+  int rc = pack_terms(T, terms, nterms, "dpx_admm_rhs", vec);
+  if (rc) return rc;
+  const long n = (long)B * C * H * W;
+  if (vec)
+    DPX_LAUNCH("k_rhs", (k_rhs<4>), dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, rho, T, B, C, H, W);
+  else
+    DPX_LAUNCH("k_rhs", (k_rhs<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, rho, T, B, C, H, W);
+  return launch_status("dpx_admm_rhs");
+}
+
+extern "C" int dpx_grad(const float* x, float* y, int dim, int adjoint, int B, int C, int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && x != y, "dpx_grad: null or aliased pointers");
+  DPX_REQUIRE(dim == 0 || dim == 1, "dpx_grad: dim must be 0 (H) or 1 (W)");
+  DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_grad: bad shape");
+  const long n = (long)B * C * H * W;
+  DPX_LAUNCH("k_grad", k_grad, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, dim, adjoint, (long)B * C, H, W);
+  return launch_status("dpx_grad");
+}
+
+extern "C" int dpx_prox(int kind, const float* v, float* out, const float* lam, float alpha, const float* off, int B,
+                        long n_per_batch, dpx_stream_t stream) {
+  DPX_REQUIRE(v && out && B > 0 && n_per_batch > 0, "dpx_prox: bad arguments");
+  DPX_REQUIRE(kind >= DPX_PROX_NORM1 && kind <= DPX_PROX_SUMSQ, "dpx_prox: unknown kind %d", kind);
+  DPX_LAUNCH("k_prox", k_prox, dim3(grid_for(B * n_per_batch, 256, 8192)), dim3(256), 0, (hipStream_t)stream, kind, v, out, lam,
+                     alpha, off, B, n_per_batch);
+  return launch_status("dpx_prox");
+}
+
+extern "C" int dpx_lincomb(float* out, int n, const float* const* x, const float* coef, const float* const* coef_b, int B,
+                           long n_per_batch, dpx_stream_t stream) {
+  DPX_REQUIRE(out && x && coef && n >= 1 && n <= 4 && B > 0 && n_per_batch > 0, "dpx_lincomb: bad arguments");
+  LinPack L;
+  L.n = n;
+  for (int i = 0; i < n; ++i) {
+    DPX_REQUIRE(x[i], "dpx_lincomb: operand %d is null", i);
+    L.x[i] = x[i];
+    L.c[i] = coef[i];
+    L.cb[i] = coef_b ? coef_b[i] : nullptr;
+  }
+  DPX_LAUNCH("k_lincomb", k_lincomb, dim3(grid_for(B * n_per_batch, 256, 8192)), dim3(256), 0, (hipStream_t)stream, out, L, B, n_per_batch);
+  return launch_status("dpx_lincomb");
+}
+
+extern "C" size_t dpx_bdot_ws_bytes(int B, long n_per_batch) { return (size_t)B * B * dot_blocks(n_per_batch) * sizeof(float); }
+
+extern "C" int dpx_bdot(const float* x, const float* y, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && out && ws && B > 0 && n_per_batch > 0, "dpx_bdot: bad arguments");
+  const int nblk = dot_blocks(n_per_batch);
+  DPX_LAUNCH("k_dot_partial", k_dot_partial, dim3(nblk, B, 1), dim3(256), 0, (hipStream_t)stream, x, y, (float*)ws, n_per_batch, 0);
+  DPX_LAUNCH("k_dot_finish", k_dot_finish, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, out, nblk);
+  return launch_status("dpx_bdot");
+}
+
+extern "C" int dpx_bgram(const float* r, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(r && out && ws && B > 0 && n_per_batch > 0, "dpx_bgram: bad arguments");
+  const int nblk = dot_blocks(n_per_batch);
+  DPX_LAUNCH("k_dot_partial", k_dot_partial, dim3(nblk, B, B), dim3(256), 0, (hipStream_t)stream, r, r, (float*)ws, n_per_batch, 1);
+  DPX_LAUNCH("k_dot_finish", k_dot_finish, dim3(B * B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, out, nblk);
+  return launch_status("dpx_bgram");
+}

@@ -1,0 +1,459 @@
+// Generic (any H, W) batched 2-D real FFT pipeline of the x-update and of conv/adjoint:
+//
+//   rows r2c  ->  [ columns c2c  ->  per-frequency operator  ->  columns c2c^-1 ]  ->  rows c2r
+//
+// Replaces the reference's eager `torch.fft.fftn -> (F + eps)/(diag + eps) -> ifftn -> real -> float`
+// (dprox/proxfn/sum_square.py:150-156) and `fftn -> FB * Fx -> ifftn -> real` (dprox/linop/conv.py:31-41).
+//
+// This file is the size-generic path: LDS-resident Stockham autosort passes with a run-time radix
+// list (2,3,4,5,7,8,11,13 in registers, any other prime by an O(p) per-output pass), half-length
+// complex transform for even row lengths, Nyquist column packed into column 0.  Power-of-two
+// planes take the register-radix kernels of dpx_fft_pow2.hip instead.
+#include "dpx_common.h"
+
+namespace dpx {
+
+// ---------------------------------------------------------------------------------------------
+// plans and tables
+// ---------------------------------------------------------------------------------------------
+Plan1D make_plan(int n) {
+  Plan1D p;
+  p.n = n;
+  p.nf = 0;
+  int m = n;
+  const int pref[] = {8, 4, 2, 3, 5, 7, 11, 13};
+  for (int r : pref)
+    while (m % r == 0 && m > 1) {
+      p.radix[p.nf++] = r;
+      m /= r;
+    }
+  for (int q = 17; m > 1; q += 2)
+    while (m % q == 0) {
+      p.radix[p.nf++] = q;
+      m /= q;
+    }
+  return p;
+}
+
+__global__ void k_twiddle_table(float2* tw, int n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double s, c;
+  sincospi(-2.0 * (double)t / (double)n, &s, &c);   // exact at multiples of 1/4 turn
+  tw[t] = make_float2((float)c, (float)s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-register butterflies
+// ---------------------------------------------------------------------------------------------
+template <int DIR> __device__ __forceinline__ void bfly2(float2& a, float2& b) {
+  float2 t = csub(a, b);
+  a = cadd(a, b);
+  b = t;
+}
+template <int DIR> __device__ __forceinline__ void bfly4(float2 (&v)[4]) {
+  float2 s0 = cadd(v[0], v[2]), d0 = csub(v[0], v[2]);
+  float2 s1 = cadd(v[1], v[3]), d1 = cmul_i<DIR>(csub(v[1], v[3]));
+  v[0] = cadd(s0, s1);
+  v[2] = csub(s0, s1);
+  v[1] = cadd(d0, d1);
+  v[3] = csub(d0, d1);
+}
+template <int DIR> __device__ __forceinline__ void bfly8(float2 (&v)[8]) {
+  const float h = 0.70710678118654752440f;
+  float2 e[4] = {v[0], v[2], v[4], v[6]};
+  float2 o[4] = {v[1], v[3], v[5], v[7]};
+  bfly4<DIR>(e);
+  bfly4<DIR>(o);
+  // o[m] *= W_8^m  (W_8 = exp(DIR * i*pi/4))
+  float2 t1 = DIR < 0 ? make_float2((o[1].x + o[1].y) * h, (o[1].y - o[1].x) * h)
+                      : make_float2((o[1].x - o[1].y) * h, (o[1].y + o[1].x) * h);
+  float2 t2 = cmul_i<DIR>(o[2]);
+  float2 t3 = DIR < 0 ? make_float2((o[3].y - o[3].x) * h, -(o[3].x + o[3].y) * h)
+                      : make_float2(-(o[3].x + o[3].y) * h, (o[3].x - o[3].y) * h);
+  v[0] = cadd(e[0], o[0]);
+  v[4] = csub(e[0], o[0]);
+  v[1] = cadd(e[1], t1);
+  v[5] = csub(e[1], t1);
+  v[2] = cadd(e[2], t2);
+  v[6] = csub(e[2], t2);
+  v[3] = cadd(e[3], t3);
+  v[7] = csub(e[3], t3);
+}
+// odd prime radix, O(R^2), roots of unity read from the transform's own table: W_R^t = tw[t * rstride]
+template <int R, int DIR> __device__ __forceinline__ void bfly_odd(float2 (&v)[R], const float2* __restrict__ tw, int rstride) {
+  float2 w[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    w[t] = tw[t * rstride];
+    if (DIR > 0) w[t].y = -w[t].y;
+  }
+  float2 o[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    float2 acc = v[0];
+#pragma unroll
+    for (int m = 1; m < R; ++m) acc = cadd(acc, cmul(v[m], w[(q * m) % R]));
+    o[q] = acc;
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) v[q] = o[q];
+}
+template <int R, int DIR> __device__ __forceinline__ void bfly(float2 (&v)[R], const float2* __restrict__ tw, int rstride) {
+  if constexpr (R == 2) bfly2<DIR>(v[0], v[1]);
+  else if constexpr (R == 4) bfly4<DIR>(v);
+  else if constexpr (R == 8) bfly8<DIR>(v);
+  else bfly_odd<R, DIR>(v, tw, rstride);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one Stockham autosort pass over `nseq` sequences held in LDS (sequence s at base + s*ld)
+//   out[(j/Ns)*Ns*R + k + m*Ns] = DFT_R_m( in[j + m'*N/R] * W_{Ns*R}^{k*m'} ),  k = j % Ns
+// tw is a table of length tlen = N * tscale with tw[t] = exp(-2 pi i t / tlen)
+// ---------------------------------------------------------------------------------------------
+template <int R, int DIR>
+__device__ void stockham_pass(const float2* __restrict__ in, float2* __restrict__ out, int N, int Ns,
+                              const float2* __restrict__ tw, int tscale, int nseq, int ld, int tid, int nthr) {
+  const int nb = N / R;
+  const int twm = (N / (Ns * R)) * tscale;
+  const int rstride = nb * tscale;
+  for (int i = tid; i < nseq * nb; i += nthr) {
+    const int s = i / nb, j = i - s * nb;
+    const int k = j % Ns;
+    const float2* src = in + s * ld;
+    float2* dst = out + s * ld;
+    float2 v[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = src[j + m * nb];
+    if (Ns > 1) {
+#pragma unroll
+      for (int m = 1; m < R; ++m) {
+        float2 w = tw[k * m * twm];
+        if (DIR > 0) w.y = -w.y;
+        v[m] = cmul(v[m], w);
+      }
+    }
+    bfly<R, DIR>(v, tw, rstride);
+    const int j0 = (j - k) * R + k;
+#pragma unroll
+    for (int m = 0; m < R; ++m) dst[j0 + m * Ns] = v[m];
+  }
+}
+
+// any radix: one output per work item, O(R) each
+template <int DIR>
+__device__ void stockham_pass_any(const float2* __restrict__ in, float2* __restrict__ out, int N, int Ns, int R,
+                                  const float2* __restrict__ tw, int tscale, int nseq, int ld, int tid, int nthr) {
+  const int nb = N / R;
+  const long long e1 = N / (Ns * R), e2 = nb;
+  for (int i = tid; i < nseq * N; i += nthr) {
+    const int s = i / N, r = i - s * N;
+    const int q = r / nb, j = r - q * nb;
+    const int k = j % Ns;
+    const float2* src = in + s * ld;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int m = 0; m < R; ++m) {
+      long long e = ((long long)k * m * e1 + (long long)q * m * e2) % N;
+      float2 w = tw[e * tscale];
+      if (DIR > 0) w.y = -w.y;
+      acc = cadd(acc, cmul(src[j + m * nb], w));
+    }
+    out[s * ld + (j - k) * R + k + q * Ns] = acc;
+  }
+}
+
+// full transform of nseq LDS-resident sequences, ping-ponging a <-> b; returns the buffer holding
+// the result (natural order).  Every thread of the block must call it.
+template <int DIR>
+__device__ float2* fft_lds(float2* a, float2* b, const Plan1D& plan, const float2* __restrict__ tw, int tscale,
+                           int nseq, int ld, int tid, int nthr) {
+  const int N = plan.n;
+  int Ns = 1;
+  for (int f = 0; f < plan.nf; ++f) {
+    const int R = plan.radix[f];
+    switch (R) {
+      case 2: stockham_pass<2, DIR>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 3: stockham_pass<3, DIR>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 4: stockham_pass<4, DIR>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 5: stockham_pass<5, DIR>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 7: stockham_pass<7, DIR>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 8: stockham_pass<8, DIR>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 11: stockham_pass<11, DIR>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 13: stockham_pass<13, DIR>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      default: stockham_pass_any<DIR>(a, b, N, Ns, R, tw, tscale, nseq, ld, tid, nthr); break;
+    }
+    __syncthreads();
+    float2* t = a;
+    a = b;
+    b = t;
+    Ns *= R;
+  }
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows: real -> half spectrum   (even W: length-W/2 complex transform of (x[2n], x[2n+1]) pairs)
+// ---------------------------------------------------------------------------------------------
+template <bool EVEN>
+__global__ void k_rows_r2c(const float* __restrict__ x, float2* __restrict__ spec, int W, int nrows, Plan1D plan,
+                           const float2* __restrict__ twW, int rpb) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  const int M = plan.n, ld = M + 1, Ws = (W + 1) / 2;
+  float2* a = smem;
+  float2* b = smem + rpb * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int row0 = blockIdx.x * rpb;
+  const int nseq = min(rpb, nrows - row0);
+  for (int i = tid; i < nseq * M; i += nthr) {
+    const int s = i / M, n = i - s * M;
+    const float* xr = x + (size_t)(row0 + s) * W;
+    a[s * ld + n] = EVEN ? make_float2(xr[2 * n], xr[2 * n + 1]) : make_float2(xr[n], 0.f);
+  }
+  __syncthreads();
+  const float2* z = fft_lds<-1>(a, b, plan, twW, EVEN ? 2 : 1, nseq, ld, tid, nthr);
+  for (int i = tid; i < nseq * Ws; i += nthr) {
+    const int s = i / Ws, k = i - s * Ws;
+    const float2* zs = z + s * ld;
+    float2 X;
+    if (!EVEN) {
+      X = zs[k];
+    } else if (k == 0) {
+      X = make_float2(zs[0].x + zs[0].y, zs[0].x - zs[0].y);   // (DC, Nyquist) packed
+    } else {
+      const float2 zk = zs[k], zm = cconj(zs[M - k]);
+      const float2 e = cscale(cadd(zk, zm), 0.5f);
+      const float2 d = cscale(csub(zk, zm), 0.5f);
+      const float2 o = make_float2(d.y, -d.x);                 // -i * d
+      X = cadd(e, cmul(o, twW[k]));
+    }
+    spec[(size_t)(row0 + s) * Ws + k] = X;
+  }
+}
+
+// rows: half spectrum -> real (unnormalised inverse times `scale`)
+template <bool EVEN>
+__global__ void k_rows_c2r(const float2* __restrict__ spec, float* __restrict__ y, int W, int nrows, Plan1D plan,
+                           const float2* __restrict__ twW, int rpb, float scale) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  const int M = plan.n, ld = M + 1, Ws = (W + 1) / 2;
+  float2* a = smem;
+  float2* b = smem + rpb * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int row0 = blockIdx.x * rpb;
+  const int nseq = min(rpb, nrows - row0);
+  for (int i = tid; i < nseq * Ws; i += nthr) {
+    const int s = i / Ws, k = i - s * Ws;
+    b[s * ld + k] = spec[(size_t)(row0 + s) * Ws + k];
+  }
+  __syncthreads();
+  if (EVEN) {
+    for (int i = tid; i < nseq * M; i += nthr) {
+      const int s = i / M, k = i - s * M;
+      const float2* X = b + s * ld;
+      float2 zp;
+      if (k == 0) {
+        zp = make_float2(X[0].x + X[0].y, X[0].x - X[0].y);
+      } else {
+        const float2 xk = X[k], xm = cconj(X[M - k]);
+        const float2 e = cadd(xk, xm);
+        const float2 d = cmulc(csub(xk, xm), twW[k]);          // * w^{-k}
+        zp = make_float2(e.x - d.y, e.y + d.x);                // e + i d
+      }
+      a[s * ld + k] = zp;
+    }
+  } else {
+    for (int i = tid; i < nseq * W; i += nthr) {
+      const int s = i / W, k = i - s * W;
+      const float2* X = b + s * ld;
+      a[s * ld + k] = (k < Ws) ? X[k] : cconj(X[W - k]);
+    }
+  }
+  __syncthreads();
+  const float2* z = fft_lds<+1>(a, b, plan, twW, EVEN ? 2 : 1, nseq, ld, tid, nthr);
+  for (int i = tid; i < nseq * M; i += nthr) {
+    const int s = i / M, n = i - s * M;
+    float* yr = y + (size_t)(row0 + s) * W;
+    const float2 v = z[s * ld + n];
+    if (EVEN) {
+      yr[2 * n] = v.x * scale;
+      yr[2 * n + 1] = v.y * scale;
+    } else {
+      yr[n] = v.x * scale;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the per-frequency operator
+// ---------------------------------------------------------------------------------------------
+template <int OP>
+__device__ __forceinline__ float2 spec_op(float2 z, const SpecArgs& A, size_t tix, float rho_b) {
+  if constexpr (OP == OP_MUL) {
+    return cscale(cmul(z, A.otf[tix]), A.scale);
+  } else if constexpr (OP == OP_MULCONJ) {
+    return cscale(cmulc(z, A.otf[tix]), A.scale);
+  } else {
+    const float d0 = (A.d0 ? A.d0[tix] : 0.f) + A.c0;
+    const float d1 = (A.d1 ? A.d1[tix] : 0.f) + A.c1;
+    const float den = fmaf(rho_b, d1, d0) + A.eps;
+    const float inv = A.scale / den;
+    return make_float2((z.x + A.eps) * inv, z.y * inv);
+  }
+}
+
+// columns: forward c2c, operator, inverse c2c, for a tile of CT columns of one plane
+template <int OP>
+__global__ void k_cols(float2* __restrict__ spec, SpecArgs A, int C, int H, int W, Plan1D plan,
+                       const float2* __restrict__ twH, int CT) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  const int Ws = (W + 1) / 2, ld = H + 1;
+  const bool packed = (W % 2 == 0);
+  float2* a = smem;
+  float2* b = smem + CT * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int p = blockIdx.y, l0 = blockIdx.x * CT;
+  const int nseq = min(CT, Ws - l0);
+  const int ch = p % C, bi = p / C;
+  float2* base = spec + (size_t)p * H * Ws;
+  for (int i = tid; i < H * nseq; i += nthr) {
+    const int r = i / nseq, c = i - r * nseq;
+    a[c * ld + r] = base[(size_t)r * Ws + l0 + c];
+  }
+  __syncthreads();
+  float2* z = fft_lds<-1>(a, b, plan, twH, 1, nseq, ld, tid, nthr);
+  float2* other = (z == a) ? b : a;
+  const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
+  const size_t tmain = (size_t)ch * H * Ws;
+  const size_t tside = (size_t)C * H * Ws + (size_t)ch * H;
+  for (int i = tid; i < H * nseq; i += nthr) {
+    const int k = i / nseq, c = i - k * nseq;
+    if (packed && l0 + c == 0) continue;
+    z[c * ld + k] = spec_op<OP>(z[c * ld + k], A, tmain + (size_t)k * Ws + l0 + c, rho_b);
+  }
+  if (packed && l0 == 0) {
+    // column 0 holds DC + i*Nyquist of real-valued columns: separate by Hermitian symmetry
+    for (int k = tid; k <= H / 2; k += nthr) {
+      const int k2 = (H - k) % H;
+      const float2 zk = z[k], zm = cconj(z[k2]);
+      const float2 Ak = cscale(cadd(zk, zm), 0.5f);
+      const float2 d = cscale(csub(zk, zm), 0.5f);
+      const float2 Bk = make_float2(d.y, -d.x);                       // d / i
+      const float2 A1 = spec_op<OP>(Ak, A, tmain + (size_t)k * Ws, rho_b);
+      const float2 B1 = spec_op<OP>(Bk, A, tside + k, rho_b);
+      const float2 A2 = spec_op<OP>(cconj(Ak), A, tmain + (size_t)k2 * Ws, rho_b);
+      const float2 B2 = spec_op<OP>(cconj(Bk), A, tside + k2, rho_b);
+      other[k] = make_float2(A1.x - B1.y, A1.y + B1.x);               // A' + i B'
+      other[k2] = make_float2(A2.x - B2.y, A2.y + B2.x);
+    }
+    __syncthreads();
+    for (int k = tid; k < H; k += nthr) z[k] = other[k];
+  }
+  __syncthreads();
+  const float2* r = fft_lds<+1>(z, other, plan, twH, 1, nseq, ld, tid, nthr);
+  for (int i = tid; i < H * nseq; i += nthr) {
+    const int row = i / nseq, c = i - row * nseq;
+    base[(size_t)row * Ws + l0 + c] = r[c * ld + row];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool pow2_path_available(int H, int W);
+int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& a, int B, int C, int H, int W,
+                        const void* table, void* ws, hipStream_t stream);
+
+static int rows_per_block(int M) {
+  int r = 4096 / (M + 1);
+  if (r < 1) r = 1;
+  if (r > 16) r = 16;
+  return r;
+}
+
+int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, int C, int H, int W,
+                   const void* table, void* ws, hipStream_t stream) {
+  if (pow2_path_available(H, W)) return spectral_apply_pow2(x, y, op, A, B, C, H, W, table, ws, stream);
+  const int P = B * C, Ws = spec_cols(W);
+  const bool even = (W % 2 == 0);
+  const int M = even ? W / 2 : W;
+  const Plan1D prow = make_plan(M), pcol = make_plan(H);
+  float2* spec = (float2*)ws;
+  const int nrows = P * H;
+  const int rpb = rows_per_block(M);
+  const size_t shrow = (size_t)2 * rpb * (M + 1) * sizeof(float2);
+  const dim3 grow((nrows + rpb - 1) / rpb);
+  if (shrow > 160 * 1024) {
+    set_error("row length %d too large for the LDS-resident generic FFT", W);
+    return DPX_ERR_UNSUPPORTED;
+  }
+  if (even)
+    DPX_LAUNCH("k_rows_r2c", (k_rows_r2c<true>), grow, dim3(256), shrow, stream, x, spec, W, nrows, prow, tw_rows(table), rpb);
+  else
+    DPX_LAUNCH("k_rows_r2c", (k_rows_r2c<false>), grow, dim3(256), shrow, stream, x, spec, W, nrows, prow, tw_rows(table), rpb);
+
+  int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
+  if (CT < 1) CT = 1;
+  if (CT > 16) CT = 16;
+  const size_t shcol = (size_t)2 * CT * (H + 1) * sizeof(float2);
+  if (shcol > 160 * 1024) {
+    set_error("column length %d too large for the LDS-resident generic FFT", H);
+    return DPX_ERR_UNSUPPORTED;
+  }
+  const dim3 gcol((Ws + CT - 1) / CT, P);
+  const float2* twH = tw_cols(table, W);
+  switch (op) {
+    case OP_MUL: DPX_LAUNCH("k_cols", (k_cols<OP_MUL>), gcol, dim3(256), shcol, stream, spec, A, C, H, W, pcol, twH, CT); break;
+    case OP_MULCONJ: DPX_LAUNCH("k_cols", (k_cols<OP_MULCONJ>), gcol, dim3(256), shcol, stream, spec, A, C, H, W, pcol, twH, CT); break;
+    default: DPX_LAUNCH("k_cols", (k_cols<OP_SOLVE>), gcol, dim3(256), shcol, stream, spec, A, C, H, W, pcol, twH, CT); break;
+  }
+  if (even)
+    DPX_LAUNCH("k_rows_c2r", (k_rows_c2r<true>), grow, dim3(256), shrow, stream, spec, y, W, nrows, prow, tw_rows(table), rpb, 1.0f);
+  else
+    DPX_LAUNCH("k_rows_c2r", (k_rows_c2r<false>), grow, dim3(256), shrow, stream, spec, y, W, nrows, prow, tw_rows(table), rpb, 1.0f);
+  return launch_status("spectral_apply");
+}
+
+}  // namespace dpx
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+using namespace dpx;
+
+extern "C" size_t dpx_fft_table_bytes(int H, int W) { return (size_t)(H + W) * sizeof(float2); }
+
+extern "C" int dpx_fft_table_init(void* table, int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(table && H > 0 && W > 0, "dpx_fft_table_init: bad arguments");
+  float2* t = (float2*)table;
+  DPX_LAUNCH("k_twiddle_table", k_twiddle_table, dim3((W + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, W);
+  DPX_LAUNCH("k_twiddle_table", k_twiddle_table, dim3((H + 255) / 256), dim3(256), 0, (hipStream_t)stream, t + W, H);
+  return launch_status("dpx_fft_table_init");
+}
+
+extern "C" size_t dpx_spectrum_bytes(int P, int H, int W) { return (size_t)P * H * spec_cols(W) * sizeof(float2); }
+
+extern "C" int dpx_fft_conv(const float* x, float* y, const void* otf, int conj_otf, int B, int C, int H, int W,
+                            const void* table, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && otf && table && ws, "dpx_fft_conv: null pointer");
+  DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_fft_conv: bad shape");
+  SpecArgs a{};
+  a.otf = (const float2*)otf;
+  a.scale = 1.0f / ((float)H * (float)W);
+  return spectral_apply(x, y, conj_otf ? OP_MULCONJ : OP_MUL, a, B, C, H, W, table, ws, (hipStream_t)stream);
+}
+
+extern "C" int dpx_fourier_solve(const float* rhs, float* x, const void* d0, const void* d1, float c0, float c1,
+                                 const float* rho, float eps, int B, int C, int H, int W, const void* table,
+                                 void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(rhs && x && table && ws && rho, "dpx_fourier_solve: null pointer");
+  DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_fourier_solve: bad shape");
+  SpecArgs a{};
+  a.d0 = (const float*)d0;
+  a.d1 = (const float*)d1;
+  a.rho = rho;
+  a.c0 = c0;
+  a.c1 = c1;
+  a.eps = eps;
+  a.scale = 1.0f / ((float)H * (float)W);
+  return spectral_apply(rhs, x, OP_SOLVE, a, B, C, H, W, table, ws, (hipStream_t)stream);
+}

@@ -1,0 +1,133 @@
+"""ctypes binding of ``libdpx_hip.so`` (C ABI declared in ``include/dpx.h``).
+
+The HIP library is the product: there is no CPU implementation behind these calls and no
+fallback.  ``lib()`` raises if the shared object has not been built (``python __graft_entry__.py``),
+and every op refuses tensors that do not live on a HIP device.
+
+``_inject_for_tests`` exists for ``tests/emul`` only: it swaps in the *same kernel sources*
+compiled for the host by the SIMT emulator so that indexing can be checked on a GPU-less box.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdpx_hip.so")
+
+PROX_NORM1, PROX_NONNEG, PROX_SUMSQ, PROX_EXTERNAL = 0, 1, 2, 3
+LIN_IDENTITY, LIN_GRAD_H, LIN_GRAD_W = 0, 1, 2
+MAX_TERMS = 4
+
+
+class DpxError(RuntimeError):
+    pass
+
+
+class Term(ctypes.Structure):
+    """``dpx_term`` of include/dpx.h."""
+    _fields_ = [("linop", c_int32), ("prox", c_int32), ("alpha", c_float), ("reserved", c_int32),
+                ("lam", c_void_p), ("v", c_void_p), ("u", c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/dpx.h declares
+SIGNATURES = {
+    "dpx_version": (c_int, []),
+    "dpx_last_error": (c_char_p, []),
+    "dpx_timing_enable": (c_int, [c_int]),
+    "dpx_timing_report": (c_int, [c_char_p, c_size_t]),
+    "dpx_fft_table_bytes": (c_size_t, [c_int, c_int]),
+    "dpx_fft_table_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "dpx_spectrum_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpx_otf_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpx_diag_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpx_psf2otf": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p]),
+    "dpx_fft_conv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dpx_fourier_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_float,
+                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dpx_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_lincomb": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_float), POINTER(c_void_p), c_int, c_long, c_void_p]),
+    "dpx_bdot": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "dpx_bdot_ws_bytes": (c_size_t, [c_int, c_long]),
+    "dpx_bgram": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "dpx_prox": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
+    "dpx_admm_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_admm_zupdate": (c_int, [c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_ffdnet_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpx_ffdnet_pack": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    "dpx_ffdnet_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dpx_ffdnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+
+class Library:
+    def __init__(self, path):
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)       # AttributeError = symbol missing from the build
+            fn.restype, fn.argtypes = res, args
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise DpxError(f"{name} failed ({rc}): {self.cdll.dpx_last_error().decode()}")
+
+    def query(self, name, *args):
+        return getattr(self.cdll, name)(*args)
+
+
+_lib = None
+_host_pointers = False      # True only under tests/emul
+
+
+def lib() -> Library:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DpxError(f"{LIB_PATH} is missing: build the HIP extension first (python __graft_entry__.py). "
+                           "This backend has no CPU or PyTorch fallback.")
+        _lib = Library(LIB_PATH)
+    return _lib
+
+
+def _inject_for_tests(library, host_pointers):
+    """tests/emul only."""
+    global _lib, _host_pointers
+    _lib, _host_pointers = library, host_pointers
+
+
+def host_mode():
+    return _host_pointers
+
+
+def stream():
+    if _host_pointers:
+        return None
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require(t: torch.Tensor, dtype=torch.float32, what="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise DpxError(f"{what}: expected a torch.Tensor, got {type(t)}")
+    if not _host_pointers and not t.is_cuda:
+        raise DpxError(f"{what} lives on {t.device}: the MI355X backend only runs on HIP devices "
+                       "(no CPU fallback); pass device='cuda'")
+    if dtype is not None and t.dtype != dtype:
+        raise DpxError(f"{what}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise DpxError(f"{what} must be contiguous")
+    return t
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def default_device():
+    if _host_pointers:
+        return torch.device("cpu")
+    if not torch.cuda.is_available():
+        raise DpxError("no HIP device visible: the MI355X backend has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())

@@ -1,0 +1,264 @@
+"""Tensor-level wrappers around the C ABI (device pointers + current stream from PyTorch-ROCm).
+
+PyTorch is used for device memory and streams only; every arithmetic pass below is a HIP kernel
+of ``libdpx_hip.so``.
+"""
+import ctypes
+from ctypes import c_float, c_void_p
+
+import numpy as np
+import torch
+
+from . import _backend as be
+from ._backend import Term, ptr, require
+
+EPS = 1e-7   # least_squares.solve default (reference dprox/proxfn/sum_square.py:115)
+
+
+# ----------------------------------------------------------------------------------------------
+# cached tables / workspaces
+# ----------------------------------------------------------------------------------------------
+_tables = {}
+_workspaces = {}
+
+
+def _bytes(n, device):
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=device)
+
+
+def fft_table(H, W, device):
+    key = (str(device), H, W)
+    t = _tables.get(key)
+    if t is None:
+        L = be.lib()
+        t = _bytes(L.query("dpx_fft_table_bytes", H, W), device)
+        L.call("dpx_fft_table_init", ptr(t), H, W, be.stream())
+        _tables[key] = t
+    return t
+
+
+def workspace(tag, nbytes, device):
+    key = (str(device), tag)
+    w = _workspaces.get(key)
+    if w is None or w.numel() < nbytes:
+        w = _bytes(nbytes, device)
+        _workspaces[key] = w
+    return w
+
+
+def spectrum_ws(P, H, W, device):
+    return workspace("spectrum", be.lib().query("dpx_spectrum_bytes", P, H, W), device)
+
+
+def clear_caches():
+    _tables.clear()
+    _workspaces.clear()
+
+
+def _shape4(x):
+    if x.ndim != 4:
+        raise be.DpxError(f"expected an NCHW tensor, got shape {tuple(x.shape)}")
+    return tuple(int(s) for s in x.shape)
+
+
+def as_batch_vec(v, B, device):
+    """scalar / 0-d / [B] / [B,1,1,1] -> contiguous float32 [B] on device."""
+    if not isinstance(v, torch.Tensor):
+        v = torch.tensor(float(v))
+    v = v.detach().to(device=device, dtype=torch.float32).reshape(-1)
+    if v.numel() == 1:
+        v = v.expand(B)
+    elif v.numel() != B:
+        raise be.DpxError(f"per-image scalar has {v.numel()} entries for a batch of {B}")
+    return v.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# OTF tables
+# ----------------------------------------------------------------------------------------------
+def psf_to_device(psf, device):
+    """kernel (2-D, or HWC 3-D) -> contiguous fp64 [kh,kw,kc] on device."""
+    k = np.asarray(psf, dtype=np.float64)
+    if k.ndim == 1:
+        k = k[None, :, None]
+    elif k.ndim == 2:
+        k = k[:, :, None]
+    elif k.ndim != 3:
+        raise ValueError(f"kernel must be 1-D, 2-D or HWC 3-D, got shape {k.shape}")
+    return torch.from_numpy(np.ascontiguousarray(k)).to(device), k.shape
+
+
+def make_otf(psf, C, H, W, device):
+    """complex OTF table for dpx_fft_conv (opaque layout)."""
+    L = be.lib()
+    kd, (kh, kw, kc) = psf_to_device(psf, device)
+    if kh > H or kw > W or kc > C:
+        raise ValueError(f"outsize {[H, W, C]} cannot be smaller than the PSF array size {[kh, kw, kc]} in any dimension.")
+    otf = _bytes(L.query("dpx_otf_bytes", C, H, W), device)
+    L.call("dpx_psf2otf", ptr(kd), kh, kw, kc, C, H, W, ptr(otf), None, c_float(1.0), 0, be.stream())
+    return otf
+
+
+def new_diag(C, H, W, device):
+    d = torch.zeros(max(be.lib().query("dpx_diag_bytes", C, H, W) // 4, 4), dtype=torch.float32, device=device)
+    return d
+
+
+def accumulate_diag(diag, psf, weight, C, H, W):
+    """diag += weight * |OTF(psf)|^2"""
+    L = be.lib()
+    kd, (kh, kw, kc) = psf_to_device(psf, diag.device)
+    L.call("dpx_psf2otf", ptr(kd), kh, kw, kc, C, H, W, None, ptr(diag), c_float(weight), 1, be.stream())
+    return diag
+
+
+def diag_to_full(diag, C, H, W):
+    """expand an opaque diag table to the full [1,C,H,W] |OTF|^2 array (host/numpy convenience, setup-time only)."""
+    Ws = (W + 1) // 2
+    d = diag.detach().cpu().numpy()
+    main = d[:C * H * Ws].reshape(C, H, Ws)
+    full = np.zeros((C, H, W), np.float32)
+    full[:, :, :Ws] = main
+    if W % 2 == 0:
+        full[:, :, W // 2] = d[C * H * Ws:C * H * Ws + C * H].reshape(C, H)
+    for l in range(Ws, W):
+        if W % 2 == 0 and l == W // 2:
+            continue
+        src = W - l
+        full[:, :, l] = np.roll(full[:, ::-1, src], 1, axis=1)     # |F(-k,-l)| = |F(k,l)| for real kernels
+    return torch.from_numpy(full[None])
+
+
+# ----------------------------------------------------------------------------------------------
+# Fourier-domain operators
+# ----------------------------------------------------------------------------------------------
+def fft_conv(x, otf, conj=False, out=None):
+    require(x, what="fft_conv input")
+    B, C, H, W = _shape4(x)
+    y = torch.empty_like(x) if out is None else out
+    be.lib().call("dpx_fft_conv", ptr(x), ptr(y), ptr(otf), int(bool(conj)), B, C, H, W,
+                  ptr(fft_table(H, W, x.device)), ptr(spectrum_ws(B * C, H, W, x.device)), be.stream())
+    return y
+
+
+def fourier_solve(rhs, d0, d1, c0, c1, rho, eps=EPS, out=None):
+    require(rhs, what="fourier_solve rhs")
+    B, C, H, W = _shape4(rhs)
+    rho = as_batch_vec(rho, B, rhs.device)
+    x = torch.empty_like(rhs) if out is None else out
+    be.lib().call("dpx_fourier_solve", ptr(rhs), ptr(x), ptr(d0), ptr(d1), c_float(c0), c_float(c1), ptr(rho),
+                  c_float(eps), B, C, H, W, ptr(fft_table(H, W, rhs.device)),
+                  ptr(spectrum_ws(B * C, H, W, rhs.device)), be.stream())
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# spatial / elementwise
+# ----------------------------------------------------------------------------------------------
+def grad(x, dim, adjoint=False):
+    require(x, what="grad input")
+    B, C, H, W = _shape4(x)
+    y = torch.empty_like(x)
+    be.lib().call("dpx_grad", ptr(x), ptr(y), int(dim), int(bool(adjoint)), B, C, H, W, be.stream())
+    return y
+
+
+def _flat_real(t):
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
+def lincomb(terms, out=None):
+    """out = sum_i coef_i * x_i, terms = [(coef, x)] with coef a python float or a per-image [B] tensor.
+    Real fp32 tensors, or complex64 tensors with real coefficients (handled as interleaved floats)."""
+    xs = [t[1] for t in terms]
+    ref = xs[0]
+    cplx = ref.is_complex()
+    for x in xs:
+        require(x, dtype=torch.complex64 if cplx else torch.float32, what="lincomb operand")
+        if x.shape != ref.shape:
+            raise be.DpxError(f"lincomb: shape mismatch {tuple(x.shape)} vs {tuple(ref.shape)}")
+    res = torch.empty_like(ref) if out is None else out
+    B = int(ref.shape[0]) if ref.ndim > 0 else 1
+    npb = (ref.numel() // max(B, 1)) * (2 if cplx else 1)
+    if ref.numel() == 0:
+        return res
+    i, first = 0, True
+    while i < len(terms):
+        take = 4 if first else 3
+        ops = ([] if first else [(1.0, res)]) + list(terms[i:i + take])
+        i += take
+        first = False
+        n = len(ops)
+        px = (c_void_p * n)(*[_flat_real(o[1]).data_ptr() for o in ops])
+        cf = (c_float * n)()
+        pb = (c_void_p * n)()
+        keep = []
+        for j, (c, _) in enumerate(ops):
+            if isinstance(c, torch.Tensor) and c.numel() > 1:
+                cb = as_batch_vec(c, B, ref.device)
+                keep.append(cb)
+                cf[j] = 1.0
+                pb[j] = cb.data_ptr()
+            else:
+                cf[j] = float(c)
+                pb[j] = None
+        be.lib().call("dpx_lincomb", ptr(_flat_real(res)), n, px, cf, pb, B, npb, be.stream())
+    return res
+
+
+def bdot(x, y):
+    require(x, what="bdot x"), require(y, what="bdot y")
+    B = int(x.shape[0])
+    npb = x.numel() // B
+    L = be.lib()
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    ws = workspace("dot", L.query("dpx_bdot_ws_bytes", B, npb), x.device)
+    L.call("dpx_bdot", ptr(x), ptr(y), ptr(out), B, npb, ptr(ws), be.stream())
+    return out
+
+
+def bgram(r):
+    require(r, what="bgram r")
+    B = int(r.shape[0])
+    npb = r.numel() // B
+    L = be.lib()
+    out = torch.empty(B, B, dtype=torch.float32, device=r.device)
+    ws = workspace("dot", L.query("dpx_bdot_ws_bytes", B, npb), r.device)
+    L.call("dpx_bgram", ptr(r), ptr(out), B, npb, ptr(ws), be.stream())
+    return out
+
+
+def prox(kind, v, lam, alpha=1.0, off=None, out=None):
+    require(v, what="prox input")
+    B = int(v.shape[0])
+    npb = v.numel() // B
+    lam_v = None if lam is None else as_batch_vec(lam, B, v.device)
+    if off is not None:
+        off = require(off.expand_as(v).contiguous(), what="prox offset")
+    res = torch.empty_like(v) if out is None else out
+    be.lib().call("dpx_prox", int(kind), ptr(v), ptr(res), ptr(lam_v), c_float(alpha), ptr(off), B, npb, be.stream())
+    return res
+
+
+def make_terms(specs):
+    """specs: list of dict(linop, prox, alpha, lam[B] tensor or None, v, u) -> (ctypes array, keepalive)."""
+    n = len(specs)
+    if n > be.MAX_TERMS:
+        raise be.DpxError(f"at most {be.MAX_TERMS} fused terms")
+    arr = (Term * max(n, 1))()
+    for i, s in enumerate(specs):
+        arr[i].linop, arr[i].prox, arr[i].alpha = s["linop"], s["prox"], float(s.get("alpha", 1.0))
+        arr[i].lam = None if s.get("lam") is None else s["lam"].data_ptr()
+        arr[i].v, arr[i].u = s["v"].data_ptr(), s["u"].data_ptr()
+    return arr
+
+
+def admm_rhs(rhs, ktb, rho, term_arr, nterms):
+    B, C, H, W = _shape4(rhs)
+    be.lib().call("dpx_admm_rhs", ptr(rhs), ptr(ktb), ptr(rho), term_arr, nterms, B, C, H, W, be.stream())
+    return rhs
+
+
+def admm_zupdate(x, term_arr, nterms):
+    B, C, H, W = _shape4(x)
+    be.lib().call("dpx_admm_zupdate", ptr(x), term_arr, nterms, B, C, H, W, be.stream())

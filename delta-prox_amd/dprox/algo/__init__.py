@@ -1,0 +1,5 @@
+from .api import SOLVERS, Problem, UnrolledSolver, build_unrolled_solver, compile, specialize
+from .driver import Algorithm
+from .gradient import ProximalGradientDescent
+from .splitting import ADMM, HQS, ADMM_vxu, LinearizedADMM, PockChambolle
+from .tune.dpir import log_descent

@@ -1,0 +1,115 @@
+"""User-facing entry points: ``compile``, ``specialize``, ``Problem``
+(reference dprox/algo/primitives.py:24-95, dprox/algo/problem.py:13-55, specialization/unroll.py:14-58)."""
+import copy
+from functools import partial
+from typing import List, Union
+
+import torch
+import torch.nn as nn
+
+from .. import _backend as be
+from ..linalg import LinearSolveConfig
+from ..proxfn import ProxFn
+from .driver import Algorithm
+from .gradient import ProximalGradientDescent
+from .splitting import ADMM, HQS, ADMM_vxu, LinearizedADMM, PockChambolle
+
+SOLVERS = {
+    "admm": ADMM,
+    "admm_vxu": ADMM_vxu,
+    "ladmm": LinearizedADMM,
+    "hqs": HQS,
+    "pc": PockChambolle,
+    "pgd": ProximalGradientDescent,
+}
+
+
+def _default_device():
+    return "cuda"
+
+
+def _resolve_device(device):
+    device = torch.device(device) if isinstance(device, str) else device
+    if device.type != "cuda" and not be.host_mode():
+        raise be.DpxError(f"device={device}: this is the MI355X backend of Delta-Prox -- solvers run on HIP devices only "
+                          "(no CPU path). Use device='cuda'.")
+    if be.host_mode():
+        return torch.device("cpu")
+    return device
+
+
+def compile(prox_fns: List[ProxFn], method: str = "admm", device: Union[str, torch.device] = "cuda", **kwargs):
+    """Compile an objective (a list / sum of proxable functions) into a proximal solver."""
+    if method not in SOLVERS:
+        raise KeyError(f"unknown method {method!r}; valid methods are {sorted(SOLVERS)}")
+    algorithm = SOLVERS[method]
+    if isinstance(prox_fns, ProxFn):
+        prox_fns = [prox_fns]
+    psi_fns, omega_fns = algorithm.partition(prox_fns)
+    solver = algorithm.create(psi_fns, omega_fns, **kwargs)
+    return solver.to(_resolve_device(device))
+
+
+class UnrolledSolver(nn.Module):
+    """one (deep-copied) solver per unrolled step -- specialization/unroll.py:21-58"""
+
+    def __init__(self, solver: Algorithm, max_iter, share=False, learned_params=False):
+        super().__init__()
+        self.solvers = nn.ModuleList([solver] + [copy.deepcopy(solver) for _ in range(max_iter - 1)]) if not share \
+            else nn.ModuleList([solver])
+        self.max_iter, self.share = max_iter, share
+
+    def solve(self, x0, rhos, lams, **kwargs):
+        from .driver import to_tensor
+        first = self.solvers[0]
+        x0 = to_tensor(x0, batch=True)
+        x0, rhos, lams, _ = first.defaults(x0, to_tensor(rhos), to_tensor(lams) if lams is not None else None, self.max_iter)
+        dev = first.device
+        x0 = x0.to(dev).float().contiguous()
+        state = first.initialize(x0)
+        for it in range(self.max_iter):
+            solver = self.solvers[0 if self.share else it]
+            rho = rhos[..., it].to(dev)
+            lam = {k: v[..., it].to(dev) for k, v in lams.items()}
+            solver._notify_all_op_current_step(it)
+            state = solver.iter(state, rho, lam)
+        return state[0]
+
+
+def build_unrolled_solver(solver, share=True, **kwargs):
+    if share:
+        solver.solve = partial(solver.solve, **kwargs)
+        return solver
+    return UnrolledSolver(solver, share=share, **kwargs)
+
+
+SPECAILIZATIONS = {"unroll": build_unrolled_solver}
+
+
+def specialize(solver: Algorithm, method: str = "unroll", device: Union[str, torch.device] = "cuda", **kwargs):
+    if method not in SPECAILIZATIONS:
+        raise NotImplementedError(f"specialization {method!r} (training strategy) is outside the MI355X hot-path backend; "
+                                  f"available: {sorted(SPECAILIZATIONS)}")
+    solver = SPECAILIZATIONS[method](solver, **kwargs)
+    return solver.to(_resolve_device(device))
+
+
+class Problem:
+    def __init__(self, prox_fns: Union[ProxFn, List[ProxFn]], constraints=[], absorb=True, merge=True,
+                 try_diagonalize=True, try_freq_diagonalize=True, linear_solve_config=LinearSolveConfig()):
+        if isinstance(prox_fns, ProxFn):
+            prox_fns = [prox_fns]
+        self.prox_fns = prox_fns
+        self.absorb, self.merge = absorb, merge
+        self.solver_args = dict(try_diagonalize=try_diagonalize, try_freq_diagonalize=try_freq_diagonalize,
+                                linear_solve_config=linear_solve_config)
+        self.solver = None
+
+    @property
+    def objective(self):
+        return self.prox_fns
+
+    def solve(self, method="admm", device="cuda", **kwargs):
+        args = self.solver_args if method != "pgd" else {}
+        self.solver = compile(self.prox_fns, method=method, device=device, **args)
+        return self.solver.solve(**kwargs)

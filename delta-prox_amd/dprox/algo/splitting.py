@@ -1,0 +1,174 @@
+"""Operator-splitting solvers: ``ADMM``, ``LinearizedADMM``, ``ADMM_vxu``, ``HQS``, ``PockChambolle``
+(reference dprox/algo/admm.py:25-120, hqs.py:4-20, pc.py:6-40, invert.py:5-14).
+
+Variable splitting follows the reference: exact-type ``sum_squares`` terms (and the first
+``ext_sum_squares``) form Omega and share x; every other term gets its own split variable.
+``ADMM`` problems whose graph is recognised by ``fused.plan_admm`` run the fused HIP iteration
+(3 kernel stages per iteration); everything else, including user plugins, runs op-by-op on the
+same HIP primitives through ``_iter``.
+"""
+from typing import List
+
+import torch
+
+from .. import _ops as ops
+from ..linalg import LinearSolveConfig
+from ..linop import Variable, adjoint, eval
+from ..proxfn import ProxFn, ext_sum_squares, least_squares, sum_squares
+from .driver import Algorithm, expand
+from . import fused
+
+
+def get_least_square_solver(psi_fns, omega_fns, try_diagonalize, try_freq_diagonalize, linear_solve_config):
+    prox_fns = list(psi_fns) + list(omega_fns)
+    ext_sq = [fn for fn in omega_fns if isinstance(fn, ext_sum_squares)]
+    for fn in ext_sq:
+        other = [f for f in prox_fns if f is not fn]
+        if all(isinstance(f.linop, Variable) for f in other):
+            return ext_sq[0].setup([f.b for f in omega_fns if f is not fn and f not in ext_sq])
+    return least_squares(omega_fns, psi_fns, try_diagonalize, try_freq_diagonalize, linear_solve_config=linear_solve_config)
+
+
+def _add(*terms):
+    return ops.lincomb([(c, t.contiguous()) for c, t in terms])
+
+
+class ADMM(Algorithm):
+    @classmethod
+    def partition(cls, prox_fns: List[ProxFn]):
+        omega_fns, taken = [], False
+        for fn in prox_fns:
+            if not taken and isinstance(fn, ext_sum_squares):
+                omega_fns.append(fn)
+                taken = True
+            elif type(fn) == sum_squares:
+                omega_fns.append(fn)
+        psi_fns = [fn for fn in prox_fns if not any(fn is o for o in omega_fns)]
+        return psi_fns, omega_fns
+
+    def __init__(self, psi_fns, omega_fns, try_diagonalize=True, try_freq_diagonalize=True,
+                 linear_solve_config=LinearSolveConfig()):
+        super().__init__(psi_fns, omega_fns)
+        self.least_square = get_least_square_solver(psi_fns, omega_fns, try_diagonalize, try_freq_diagonalize,
+                                                    linear_solve_config)
+        self.use_fused = True
+        self.last_path = None           # "fused" | "generic": which engine ran the last solve
+
+    def initialize(self, x0, v=None):
+        x = x0
+        self.Kall.update_vars([x])
+        if v is None:
+            v = self.K.forward(x, return_list=True)
+            if v is None:
+                v = []
+        v = [e if e is not x else e.clone() for e in v]
+        u = [torch.zeros_like(e) for e in v]
+        return x, v, u
+
+    def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
+        plan = fused.plan_admm(self, state) if (self.use_fused and type(self) is ADMM) else None
+        if plan is not None:
+            self.last_path = "fused"
+            return plan.run(state, rhos, lams, max_iter, pbar, callback)
+        self.last_path = "generic"
+        return super().iters(state, rhos, lams, max_iter, pbar, callback)
+
+    def _prox_dual(self, Kx, v, u, lam):
+        for i, fn in enumerate(self.psi_fns):
+            t = _add((1.0, Kx[i]), (1.0, u[i]))
+            v[i] = fn.prox(t, lam=lam[fn])
+            u[i] = _add((1.0, t), (-1.0, v[i]))
+
+    def _iter(self, state, rho, lam):
+        x, v, u = state
+        b = [_add((1.0, v[i]), (-1.0, u[i])) for i in range(len(self.psi_fns))]
+        x = self.least_square.solve(b, rho)
+        Kx = self.K.forward(x, return_list=True)
+        self._prox_dual(Kx, v, u, lam)
+        return x, v, u
+
+    @property
+    def nparams(self):
+        return len(self.psi_fns) + 1
+
+    @property
+    def state_split(self):
+        return [1, [len(self.psi_fns)], [len(self.psi_fns)]]
+
+
+class LinearizedADMM(ADMM):
+    def _iter(self, state, rho, lam):
+        x, v, u = state
+        b = []
+        for i, fn in enumerate(self.psi_fns):
+            tmp = _add((1.0, eval(fn.linop, x)), (-1.0, v[i]), (1.0, u[i]))
+            tmp = adjoint(fn.linop, tmp)
+            b.append(_add((1.0, x), (-1.0, tmp)))          # the reference fixes the step coefficient to 1 (admm.py:87)
+        x = self.least_square.solve(b, rho)
+        Kx = self.K.forward(x, return_list=True)
+        self._prox_dual(Kx, v, u, lam)
+        return x, v, u
+
+
+class ADMM_vxu(ADMM):
+    """update order v, x, u"""
+
+    def _iter(self, state, rho, lam):
+        z, x, u = state
+        Kz = self.K.forward(z, return_list=True)
+        for i, fn in enumerate(self.psi_fns):
+            x[i] = fn.prox(_add((1.0, Kz[i]), (-1.0, u[i])), lam=lam[fn])
+        b = [_add((1.0, x[i]), (1.0, u[i])) for i in range(len(self.psi_fns))]
+        z = self.least_square.solve(b, rho)
+        for i, fn in enumerate(self.psi_fns):
+            u[i] = _add((1.0, u[i]), (1.0, x[i]), (-1.0, z))
+        return z, x, u
+
+
+class HQS(ADMM):
+    def initialize(self, x0):
+        x = x0
+        self.Kall.update_vars([x])
+        z = self.K.forward(x, return_list=True)
+        return x, [e if e is not x else e.clone() for e in z]
+
+    def _iter(self, state, rho, lam):
+        x, z = state
+        x = self.least_square.solve(z, rho)
+        Kx = self.K.forward(x, return_list=True)
+        for i, fn in enumerate(self.psi_fns):
+            z[i] = fn.prox(Kx[i].contiguous(), lam=lam[fn])
+        return x, z
+
+    @property
+    def state_split(self):
+        return [1, [len(self.psi_fns)]]
+
+
+class PockChambolle(ADMM):
+    def initialize(self, x0):
+        x = x0
+        self.Kall.update_vars([x])
+        xbar = x.clone()
+        z = self.K.forward(x, return_list=True)
+        return x, [e if e is not x else e.clone() for e in z], xbar
+
+    def _iter(self, state, rho, lam):
+        x, z, xbar = state
+        Kxbar = self.K.forward(xbar, return_list=True)
+        for i, fn in enumerate(self.psi_fns):
+            r = lam[fn]
+            z[i] = _add((1.0, z[i]), (r, Kxbar[i]))
+            z[i] = _add((1.0, z[i]), (-r if isinstance(r, torch.Tensor) else -float(r), fn.prox(z[i], lam=r)))
+        Ktz = [adjoint(fn.linop, z[i]) for i, fn in enumerate(self.psi_fns)]
+        x_next = [_add((1.0, x), (-1.0, k)) for k in Ktz]
+        if len(self.omega_fns) > 0:
+            x_next = self.least_square.solve(x_next, rho)
+        else:
+            x_next = _add(*[(1.0, t) for t in x_next])
+        xbar = _add((2.0, x_next), (-1.0, x))
+        return x_next, z, xbar
+
+    @property
+    def state_split(self):
+        return [1, [len(self.psi_fns)], 1]

@@ -1,0 +1,25 @@
+"""Small helpers of the reference's ``dprox.contrib`` that the hot-path examples use
+(reference dprox/contrib/restoration.py:14-45)."""
+import numpy as np
+
+
+def fspecial_gaussian(hsize, sigma):
+    """MATLAB fspecial('gaussian', hsize, sigma)"""
+    r = (hsize - 1.0) / 2.0
+    ax = np.arange(-r, r + 1)
+    xx, yy = np.meshgrid(ax, ax)
+    h = np.exp(-(xx * xx + yy * yy) / (2.0 * sigma * sigma))
+    h[h < np.finfo(float).eps * h.max()] = 0
+    s = h.sum()
+    return h / s if s != 0 else h
+
+
+def point_spread_function(ksize, sigma):
+    return np.expand_dims(fspecial_gaussian(ksize, sigma), axis=2).astype("float32")
+
+
+def blurring(img, psf):
+    """circular blur of an NCHW tensor with ``psf`` through the backend's own conv operator"""
+    from ..linop import Variable, conv
+    op = conv(Variable(), psf).to(img.device)
+    return op.forward(img.contiguous().float())

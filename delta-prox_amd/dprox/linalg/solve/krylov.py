@@ -1,0 +1,79 @@
+"""Matrix-free conjugate gradients on the HIP primitives (reference dprox/linalg/solve/solver_cg.py:7-136).
+
+Per iteration: one operator application, one fused B x B residual Gram pass (its diagonal is
+gamma = <r_i, r_i>; its largest eigenvalue gives the reference's stop rule, which uses the *spectral*
+norm of the [B, N] residual matrix and therefore couples the images of a batch -- solver_cg.py:103-104),
+one batched dot <p, Ap> and three fused AXPY passes with per-image coefficients.  Dots are reduced with
+wavefront shuffles and are deterministic (no atomics)."""
+import numpy as np
+import torch
+
+from ... import _ops as ops
+
+
+def bdot(x: torch.Tensor, y: torch.Tensor):
+    """batched dot over all non-leading dims -> [B]  (a plain dot for 1-D inputs)"""
+    if x.ndim != y.ndim:
+        raise ValueError("The input of `bdot` should have the same shape.")
+    if x.ndim == 1:
+        return ops.bdot(x.reshape(1, -1).contiguous(), y.reshape(1, -1).contiguous())[0]
+    return ops.bdot(x.contiguous(), y.contiguous())
+
+
+def expand(x: torch.Tensor, ref: torch.Tensor):
+    while x.ndim < ref.ndim:
+        x = x.unsqueeze(-1)
+    return x
+
+
+def ravel(x: torch.Tensor):
+    return x if x.ndim == 1 else x.reshape(x.shape[0], -1)
+
+
+def _as_batch(t):
+    return (t.reshape(1, -1), True) if t.ndim == 1 else (t, False)
+
+
+def cg(A, b, x0=None, rtol=1e-6, max_iters=100, verbose=False, return_iters=False):
+    """Solve A x = b for symmetric positive definite A given as a callable."""
+    b = b.contiguous()
+    if b.dtype != torch.float32:
+        b = b.float()
+    bb, flat = _as_batch(b)
+    B = bb.shape[0]
+    apply = (lambda t: A(t.reshape(b.shape)).reshape(bb.shape).contiguous())
+    if x0 is None:
+        x = torch.zeros_like(bb)
+        r = bb.clone()                      # b - A(0): A is linear, skip the wasted operator application
+    else:
+        x = x0.reshape(bb.shape).contiguous().float()
+        r = ops.lincomb([(1.0, bb), (-1.0, apply(x))])
+    cg_tol = rtol * np.sqrt(np.maximum(ops.bdot(bb, bb).cpu().numpy().astype(np.float64), 0.0))   # rtol * ||b_i||
+    n_it = int(min(max_iters, b.numel()))
+    p = gamma_1 = None
+    done = n_it
+    normr = None
+    for it in range(n_it):
+        G = ops.bgram(r)                                     # [B,B] on device
+        Gh = G.cpu().numpy().astype(np.float64)
+        normr = float(np.sqrt(max(np.linalg.eigvalsh((Gh + Gh.T) * 0.5)[-1], 0.0))) if B > 1 else float(np.sqrt(max(Gh[0, 0], 0.0)))
+        if np.all(normr <= cg_tol):
+            if verbose:
+                print("Converged at CG Iter %03d" % it)
+            done = it
+            break
+        gamma = G.diagonal().contiguous()                    # <r_i, r_i>
+        if it > 0:
+            p = ops.lincomb([(1.0, r), (gamma / gamma_1, p)])
+        else:
+            p = r.clone()
+        Ap = apply(p)
+        alpha = gamma / ops.bdot(p, Ap)
+        x = ops.lincomb([(1.0, x), (alpha, p)])
+        r = ops.lincomb([(1.0, r), (-alpha, Ap)])
+        gamma_1 = gamma
+    else:
+        if verbose:
+            print(f"Not converged, r norm={normr}")
+    x = x.reshape(b.shape)
+    return (x, done) if return_iters else x

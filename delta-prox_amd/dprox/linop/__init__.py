@@ -1,0 +1,6 @@
+from .arith import copy, scale, split, sum, vstack
+from .blackbox import BlackBox, LinOpFactory
+from .fourier import conv, grad
+from .graph import CompGraph, adjoint, eval, gram, validate
+from .leaf import Constant, Placeholder, Variable
+from .node import LinOp

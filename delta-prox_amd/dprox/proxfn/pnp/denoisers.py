@@ -1,0 +1,134 @@
+"""Denoiser protocol + the FFDNet denoisers of the plug-and-play prior
+(reference dprox/proxfn/pnp/denoisers/base.py:5-25, wrapper.py:25-48, models/network_ffdnet.py:27-68).
+
+``FFDNet`` here is not an ``nn.Sequential`` of cuDNN/MIOpen convolutions: its forward is the
+hand-written gfx950 kernel stack behind ``dpx_ffdnet_forward`` (exact-fp32 MFMA implicit GEMM,
+pixel-(un)shuffle, sigma map, bias and ReLU fused).  Checkpoints in the reference's format
+(``model.{0,2,...}.weight/bias``) load unchanged.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _backend as be
+from ... import _ops as ops
+
+
+class Denoiser(nn.Module):
+    def denoise(self, input: torch.Tensor, sigma: torch.Tensor):
+        """input: [N,C,H,W]; sigma: 0-d or [N]"""
+        sigma = sigma.view(-1, 1, 1, 1)
+        return self._denoise(input, sigma)
+
+    def _denoise(self, x, sigma):
+        raise NotImplementedError
+
+
+class Denoiser2D(Denoiser):
+    """applies a single-channel denoiser band by band"""
+
+    def denoise(self, input: torch.Tensor, sigma: torch.Tensor):
+        sigma = sigma.view(-1, 1, 1, 1)
+        return torch.cat([self._denoise(band.contiguous(), sigma) for band in input.split(1, dim=1)], dim=1)
+
+
+class FFDNet(nn.Module):
+    """FFDNet(in_nc, out_nc, nc, nb): conv3x3(in_nc*4+1 -> nc) + (nb-2) x conv3x3(nc -> nc) + conv3x3(nc -> out_nc*4)"""
+
+    def __init__(self, in_nc=1, out_nc=1, nc=64, nb=15, act_mode="R"):
+        super().__init__()
+        assert "R" in act_mode, "only the ReLU FFDNet variants are built for the HIP path"
+        assert in_nc == out_nc
+        self.in_nc, self.out_nc, self.nc, self.nb = in_nc, out_nc, nc, nb
+        chans = [in_nc * 4 + 1] + [nc] * (nb - 1) + [out_nc * 4]
+        self.weights = nn.ParameterList([nn.Parameter(torch.zeros(co, ci, 3, 3)) for ci, co in zip(chans[:-1], chans[1:])])
+        self.biases = nn.ParameterList([nn.Parameter(torch.zeros(co)) for co in chans[1:]])
+        self._packed = None
+
+    # reference checkpoint layout: Conv2d modules at the even indices of `model`
+    def load_reference_state_dict(self, sd):
+        for i in range(self.nb):
+            self.weights[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.weight"]))
+            self.biases[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.bias"]))
+        self._packed = None
+        return self
+
+    def load_layers(self, layers):
+        """layers: [(weight[co,ci,3,3], bias[co])] numpy/torch"""
+        assert len(layers) == self.nb
+        for i, (w, b) in enumerate(layers):
+            self.weights[i].data.copy_(torch.as_tensor(w))
+            self.biases[i].data.copy_(torch.as_tensor(b))
+        self._packed = None
+        return self
+
+    def reference_state_dict(self):
+        sd = {}
+        for i in range(self.nb):
+            sd[f"model.{2 * i}.weight"] = self.weights[i].detach().cpu()
+            sd[f"model.{2 * i}.bias"] = self.biases[i].detach().cpu()
+        return sd
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def packed(self):
+        dev = self.weights[0].device
+        if self._packed is None or self._packed.device != dev:
+            L = be.lib()
+            blob = torch.empty(max(L.query("dpx_ffdnet_packed_bytes", self.in_nc, self.nc, self.nb), 16), dtype=torch.uint8, device=dev)
+            ws = [w.detach().float().contiguous() for w in self.weights]
+            bs = [b.detach().float().contiguous() for b in self.biases]
+            pw = (ctypes.c_void_p * self.nb)(*[w.data_ptr() for w in ws])
+            pb = (ctypes.c_void_p * self.nb)(*[b.data_ptr() for b in bs])
+            L.call("dpx_ffdnet_pack", be.ptr(blob), pw, pb, self.in_nc, self.nc, self.nb, be.stream())
+            self._packed = blob
+        return self._packed
+
+    def forward(self, x, sigma):
+        be.require(x, what="FFDNet input")
+        B, C, H, W = x.shape
+        assert C == self.in_nc, f"FFDNet built for {self.in_nc} channels, got {C}"
+        sig = ops.as_batch_vec(sigma, B, x.device)
+        L = be.lib()
+        y = torch.empty_like(x)
+        ws = ops.workspace("ffdnet", L.query("dpx_ffdnet_ws_bytes", B, self.in_nc, self.nc, H, W), x.device)
+        L.call("dpx_ffdnet_forward", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(self.packed()), self.in_nc, self.nc,
+               self.nb, B, H, W, be.ptr(ws), be.stream())
+        return y
+
+
+def _load_checkpoint(model, model_path):
+    if model_path is None:
+        return model
+    if isinstance(model_path, (list, tuple)):
+        return model.load_layers(model_path)
+    if isinstance(model_path, dict):
+        return model.load_reference_state_dict(model_path)
+    return model.load_reference_state_dict(torch.load(model_path, map_location="cpu"))
+
+
+class FFDNetDenoiser(Denoiser2D):
+    """gray FFDNet (nc=64, nb=15) applied per band -- wrapper.py:25-35"""
+
+    def __init__(self, model_path=None):
+        super().__init__()
+        self.model = _load_checkpoint(FFDNet(in_nc=1, out_nc=1, nc=64, nb=15, act_mode="R"), model_path)
+
+    def _denoise(self, x, sigma):
+        return self.model(x, sigma)
+
+
+class FFDNetColorDenoiser(Denoiser):
+    """color FFDNet (nc=96, nb=12) -- wrapper.py:38-48"""
+
+    def __init__(self, model_path=None):
+        super().__init__()
+        self.model = _load_checkpoint(FFDNet(in_nc=3, out_nc=3, nc=96, nb=12, act_mode="R"), model_path)
+
+    def _denoise(self, x, sigma):
+        return self.model(x, sigma)

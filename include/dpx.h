@@ -1,0 +1,157 @@
+/*
+ * dpx.h -- C ABI of the MI355X (gfx950) proximal-solver backend for Delta-Prox.
+ *
+ * The reference (princeton-computational-imaging/Delta-Prox @ v2) is pure Python/PyTorch and has
+ * no FFI of its own: its ADMM/PGD hot path is the eager torch-op sequences cited next to every
+ * entry point below (paths relative to the reference checkout).  This header is the boundary a
+ * maintainer would bind instead (INTEGRATION.md shows the ctypes stub): plain device pointers and
+ * sizes, a hipStream_t, int status codes; no torch types, no allocation, no exceptions.
+ *
+ * Conventions
+ *   - every image tensor is contiguous NCHW fp32 in device memory, owned by the caller;
+ *   - every call is asynchronous on `stream`; workspaces are caller-owned and sized by the
+ *     *_bytes() queries; tables (twiddles, OTFs, denominators) are immutable after creation and
+ *     may be shared by concurrent calls on different streams;
+ *   - return value 0 = ok, <0 = error, text via dpx_last_error() (thread-local);
+ *   - per-image scalars (rho, lambda, sigma) are device arrays of length B so that a whole
+ *     iteration can be replayed from a hipGraph while the schedule advances.
+ *   - spectral tables use an opaque internal half-spectrum layout; always size/produce them
+ *     through this API.
+ */
+#ifndef DPX_H
+#define DPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dpx_stream_t; /* hipStream_t */
+
+#define DPX_OK 0
+#define DPX_ERR_ARG (-1)
+#define DPX_ERR_LAUNCH (-2)
+#define DPX_ERR_UNSUPPORTED (-3)
+
+int dpx_version(void);
+const char* dpx_last_error(void);
+/* optional per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg):
+ * enable, run, then dpx_timing_report writes "kernel_name launches total_ms" lines and resets the log. */
+int dpx_timing_enable(int on);
+int dpx_timing_report(char* buf, size_t cap);
+
+/* ------------------------------------------------------------------------------------------ */
+/* spectral plans                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+/* Twiddle tables for H x W planes (fp64-accurate, stored fp32).  Replaces the per-call planning
+ * inside torch.fft.fftn / ifftn (reference dprox/linop/conv.py:33-34, proxfn/sum_square.py:150-152). */
+size_t dpx_fft_table_bytes(int H, int W);
+int dpx_fft_table_init(void* table, int H, int W, dpx_stream_t stream);
+/* workspace holding the half spectrum of P = B*C planes */
+size_t dpx_spectrum_bytes(int P, int H, int W);
+
+/* ------------------------------------------------------------------------------------------ */
+/* PSF -> OTF (setup time)                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+/* psf2otf: reference dprox/utils/psf2otf.py:11-40 as called by conv._FB (linop/conv.py:23-29):
+ * zero-pad, shift the centre floor(k/2) to the origin, DFT over (H, W, C).  Evaluated directly
+ * in fp64 on the device (no FFT round-off).  `psf` is device fp64 [kh][kw][kc].
+ *   otf  (nullable): complex table used by dpx_fft_conv  (dpx_otf_bytes)
+ *   diag (nullable): real |OTF|^2 table = conv.get_diag (linop/conv.py:46-53)  (dpx_diag_bytes);
+ *                    diag = (accumulate ? diag : 0) + weight * |OTF|^2                         */
+size_t dpx_otf_bytes(int C, int H, int W);
+size_t dpx_diag_bytes(int C, int H, int W);
+int dpx_psf2otf(const double* psf, int kh, int kw, int kc, int C, int H, int W,
+                void* otf, void* diag, float weight, int accumulate, dpx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Fourier-domain operators                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* y = real(ifft2(OTF * fft2(x)))  (conj_otf=0: conv.forward, linop/conv.py:31-35)
+ * y = real(ifft2(conj(OTF) * fft2(x)))  (conj_otf=1: conv.adjoint, linop/conv.py:37-41)         */
+int dpx_fft_conv(const float* x, float* y, const void* otf, int conj_otf, int B, int C, int H, int W,
+                 const void* table, void* spectrum_ws, dpx_stream_t stream);
+
+/* x = real(ifft2((fft2(rhs) + eps) / (d0 + c0 + rho_b*(d1 + c1) + eps)))
+ * least_squares.solve_direct, frequency branch -- proxfn/sum_square.py:137-152.
+ * d0/d1 are diag tables (nullable = 0); c0/c1 add the constant diagonals of identity linops
+ * (Variable.get_diag, linop/variable.py:47-59, and the `+ rho` of :147-148); rho is device [B]. */
+int dpx_fourier_solve(const float* rhs, float* x, const void* d0, const void* d1, float c0, float c1,
+                      const float* rho, float eps, int B, int C, int H, int W,
+                      const void* table, void* spectrum_ws, dpx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* spatial operators and fused ADMM steps                                                      */
+/* ------------------------------------------------------------------------------------------ */
+/* grad(x, dim) forward = x[n+1]-x[n] (circular), adjoint = y[n-1]-y[n]; dim 0 = H, 1 = W.
+ * Equal (to fp32 rounding) to the reference's FFT evaluation -- linop/grad.py:8-23 + conv.py:31-41. */
+int dpx_grad(const float* x, float* y, int dim, int adjoint, int B, int C, int H, int W, dpx_stream_t stream);
+
+/* out = sum_i coef[i] * (coef_b[i] ? coef_b[i][b] : 1) * x[i]   (n <= 4; x[i] may alias out).
+ * The AXPY family of the reference's eager ops: sum.forward (linop/sum.py:13-19), scale
+ * (linop/scale.py:20-31), `v - u`, `u + Kx - v` (algo/admm.py:51,57), CG updates
+ * (linalg/solve/solver_cg.py:114-129).  n_per_batch = C*H*W.                                   */
+int dpx_lincomb(float* out, int n, const float* const* x, const float* coef, const float* const* coef_b,
+                int B, long n_per_batch, dpx_stream_t stream);
+
+/* batched dot: out[b] = <x[b], y[b]>  -- bdot, linalg/solve/solver_cg.py:7-22 */
+int dpx_bdot(const float* x, const float* y, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream);
+size_t dpx_bdot_ws_bytes(int B, long n_per_batch);
+/* B x B Gram matrix of the rows of r ([B, n]) -- for the spectral-norm stop rule of cg()
+ * (torch.linalg.norm(ravel(r), 2), solver_cg.py:103-104)                                       */
+int dpx_bgram(const float* r, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream);
+
+/* proximal operators, ProxFn.prox with the scaled/translated wrappers (proxfn/base.py:12-27,55-64):
+ *   out = P(v - off, lam_b * alpha) + off      off nullable
+ * kinds: norm1 soft-threshold (proxfn/norm.py:6-19), nonneg (proxfn/nonneg.py:10-11),
+ *        sum_squares / norm2  v/(1+2 lam) (proxfn/sum_square.py:26-27, norm.py:26-27)          */
+#define DPX_PROX_NORM1 0
+#define DPX_PROX_NONNEG 1
+#define DPX_PROX_SUMSQ 2
+#define DPX_PROX_EXTERNAL 3 /* z-update only: v <- K x + u (the denoiser runs next), u untouched */
+int dpx_prox(int kind, const float* v, float* out, const float* lam, float alpha, const float* off,
+             int B, long n_per_batch, dpx_stream_t stream);
+
+/* one Psi term of the ADMM splitting (algo/admm.py:26-36): linop K_i and prox of g_i */
+#define DPX_LIN_IDENTITY 0
+#define DPX_LIN_GRAD_H 1
+#define DPX_LIN_GRAD_W 2
+typedef struct dpx_term {
+  int32_t linop;    /* DPX_LIN_* */
+  int32_t prox;     /* DPX_PROX_* */
+  float alpha;      /* lam multiplier (`alpha * fn`, proxfn/base.py:78-82) */
+  int32_t reserved;
+  const float* lam; /* device [B] */
+  float* v;         /* state v_i [B,C,H,W] */
+  float* u;         /* state u_i [B,C,H,W] */
+} dpx_term;
+#define DPX_MAX_TERMS 4
+
+/* rhs = ktb + sum_i rho_b * K_i^T (v_i - u_i)   -- proxfn/sum_square.py:126-135 with
+ * b_i = v_i - u_i from algo/admm.py:51.  ktb = sum over Omega of K^T offset (constant per solve). */
+int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, const dpx_term* terms, int nterms,
+                 int B, int C, int H, int W, dpx_stream_t stream);
+
+/* for every term: d = K_i x + u_i ; v_i = prox_i(d) ; u_i = d - v_i   -- algo/admm.py:54-57 */
+int dpx_admm_zupdate(const float* x, const dpx_term* terms, int nterms,
+                     int B, int C, int H, int W, dpx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* FFDNet denoiser (deep_prior z-update)                                                       */
+/* ------------------------------------------------------------------------------------------ */
+/* FFDNet.forward -- proxfn/pnp/denoisers/models/network_ffdnet.py:54-68 (+ basicblock.py:61-126):
+ * replicate-pad to even, pixel-unshuffle(2), append sigma map, nb x conv3x3(+ReLU), pixel-shuffle,
+ * crop.  `weights` is the packed blob made by dpx_ffdnet_pack (exact fp32, MFMA f32 path).       */
+size_t dpx_ffdnet_packed_bytes(int in_nc, int nc, int nb);
+int dpx_ffdnet_pack(void* packed, const float* const* w, const float* const* b, int in_nc, int nc, int nb,
+                    dpx_stream_t stream);
+size_t dpx_ffdnet_ws_bytes(int B, int in_nc, int nc, int H, int W);
+int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void* packed,
+                       int in_nc, int nc, int nb, int B, int H, int W, void* ws, dpx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPX_H */

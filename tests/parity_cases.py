@@ -1,0 +1,195 @@
+"""Parity cases shared by the GPU tests (-m gpu, real MI355X through the C ABI) and the emulated-kernel
+tests (CPU, same kernel sources under the SIMT emulator).  Every case rebuilds a golden fixture's problem
+with the drop-in `dprox` API on `device` and compares with the reference's stored outputs.
+
+Tolerance (north_star): rel-L2 <= 1e-5 on the iterate x.  The split variables v/u are
+non-smooth functions of x (soft threshold / clip at lam) so their error is compared on the scale of x.
+"""
+import numpy as np
+import torch
+
+import dprox as dp
+from conftest import assert_close, load_golden, rel_l2
+
+TOL = 1e-5
+
+
+def T(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def close_on_scale(a, b, scale_ref, tol, what=""):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    err = np.linalg.norm((a - b).ravel()) / np.linalg.norm(np.asarray(scale_ref, dtype=np.float64).ravel())
+    assert err <= tol, f"{what}: error {err:.3e} relative to the iterate's norm > {tol:.1e}"
+
+
+def tv_problem(b, psf, dims=(0, 1)):
+    x = dp.Variable()
+    fns = dp.sum_squares(dp.conv(x, psf) - b)
+    regs = [dp.norm1(dp.grad(x, dim=d)) for d in dims]
+    for r in regs:
+        fns = fns + r
+    return x, fns, regs
+
+
+def case_linops(device, tag):
+    g = load_golden(f"g1_linops_{tag}")
+    x, y = T(g["x"], device), T(g["y"], device)
+    v = dp.Variable()
+    c = dp.conv(v, g["psf"]).to(device)
+    assert_close(c.forward(x).cpu(), g["conv_fwd"], TOL, "conv fwd")
+    assert_close(c.adjoint(y).cpu(), g["conv_adj"], TOL, "conv adj")
+    assert_close(c.get_diag(x, freq=True).cpu(), g["conv_diag"], TOL, "conv diag")
+    for d in (0, 1, 2):
+        if f"grad{d}_fwd" not in g:
+            continue
+        gr = dp.grad(v, dim=d).to(device)
+        assert_close(gr.forward(x).cpu(), g[f"grad{d}_fwd"], TOL, f"grad{d} fwd")
+        assert_close(gr.adjoint(y).cpu(), g[f"grad{d}_adj"], TOL, f"grad{d} adj")
+        assert_close(gr.get_diag(x, freq=True).cpu(), g[f"grad{d}_diag"], TOL, f"grad{d} diag")
+
+
+def case_prox(device):
+    g = load_golden("g3_prox")
+    v, c = T(g["v"], device), T(g["c"], device)
+    lam0, lamB = torch.tensor(0.3, device=device), T(g["lamB"], device)
+    var = dp.Variable()
+    var.value = torch.zeros_like(v)
+    mk = lambda fn: fn.to(device)
+    assert_close(dp.soft_threshold(v, 0.3).cpu(), g["soft_0p3"], 1e-6)
+    assert_close(mk(dp.norm1(var)).prox(v, lam0).cpu(), g["norm1_scalar"], 1e-6)
+    assert_close(mk(dp.norm1(var)).prox(v, lamB).cpu(), g["norm1_batch"], 1e-6)
+    assert_close(mk(2.5 * dp.norm1(var)).prox(v, lamB).cpu(), g["norm1_alpha2p5"], 1e-6)
+    assert_close(mk(dp.norm1(var - c)).prox(v, lamB).cpu(), g["norm1_offset"], 1e-6)
+    assert_close(mk(dp.norm1(dp.grad(var, dim=1) - c)).prox(v, lam0).cpu(), g["norm1_grad1_offset"], 1e-6)
+    assert_close(mk(dp.nonneg(var)).prox(v, lam0).cpu(), g["nonneg"], 1e-6)
+    assert_close(mk(dp.nonneg(var - c)).prox(v, lam0).cpu(), g["nonneg_offset"], 1e-6)
+    assert_close(mk(dp.sum_squares(var)).prox(v, lamB).cpu(), g["sumsq_batch"], 1e-6)
+    assert_close(mk(dp.norm2(var)).prox(v, lam0).cpu(), g["norm2_scalar"], 1e-6)
+    fn = mk(dp.norm1(var))
+    fn.beta = 2.0
+    assert_close(fn.prox(v, lam0).cpu(), g["norm1_beta2"], 1e-6)
+
+
+def case_solve_direct(device):
+    g = load_golden("g4_solve_direct")
+    b = T(g["b"], device)
+    x, fns, _ = tv_problem(b, g["psf"])
+    s = dp.compile(fns, method="admm", device=device)
+    s.Kall.update_vars([b])
+    rhs = [T(g["rhs0"], device), T(g["rhs1"], device)]
+    assert s.least_square.freq_diagonalizable and not s.least_square.diagonalizable
+    assert_close(s.least_square.solve(rhs, torch.tensor(0.7, device=device)).cpu(), g["x_rho_scalar"], TOL)
+    assert_close(s.least_square.solve(rhs, torch.tensor([0.7, 0.05], device=device)).cpu(), g["x_rho_batch"], TOL)
+    x2 = dp.Variable()
+    s2 = dp.compile(dp.sum_squares(dp.conv(x2, g["psf"]) - b) + dp.nonneg(x2), method="admm", device=device)
+    s2.Kall.update_vars([b])
+    assert_close(s2.least_square.solve([rhs[0]], torch.tensor(0.3, device=device)).cpu(), g["x_identity"], TOL)
+
+
+def case_admm_tv_small(device, fused=True):
+    g = load_golden("g5_admm_tv_small")
+    b = T(g["b"], device)
+    x, fns, _ = tv_problem(b, g["psf"])
+    s = dp.compile(fns, method="admm", device=device)
+    s.use_fused = fused
+    st = s.solve(x0=b, rhos=T(g["rhos"], device), lams=0.004, max_iter=50, return_full_states=True)
+    assert s.last_path == ("fused" if fused else "generic")
+    assert_close(st[0].cpu(), g["x"], TOL, "x")
+    assert x.value is st[0] or torch.equal(x.value, st[0])
+    for i in range(2):
+        close_on_scale(st[1][i], g[f"v{i}"], g["x"], TOL, f"v{i}")
+        close_on_scale(st[2][i], g[f"u{i}"], g["x"], TOL, f"u{i}")
+
+
+def case_admm_tv_config1(device):
+    g = load_golden("g5_admm_tv_c1")
+    b = T(g["b"], device)
+    x, fns, _ = tv_problem(b, g["psf"])
+    snaps = {}
+
+    def cb(iter, state, rho, lam):
+        if iter + 1 in (1, 5, 20):
+            snaps[iter + 1] = (state[0].clone(), [e.clone() for e in state[1]], [e.clone() for e in state[2]])
+
+    out = dp.Problem(fns).solve(method="admm", device=device, x0=b, rhos=0.1, lams=0.005, max_iter=20, callback=cb)
+    assert_close(out.cpu(), g["x"], TOL, "final x")
+    for it, (xs, vs, us) in snaps.items():
+        assert_close(xs[..., ::4, ::4].cpu(), g[f"it{it}_x"], TOL, f"x@{it}")
+        for i in range(2):
+            close_on_scale(vs[i][..., ::4, ::4], g[f"it{it}_v{i}"], g[f"it{it}_x"], TOL, f"v{i}@{it}")
+            close_on_scale(us[i][..., ::4, ::4], g[f"it{it}_u{i}"], g[f"it{it}_x"], TOL, f"u{i}@{it}")
+    psnr = 10 * np.log10(1.0 / np.mean((out.cpu().numpy() - g["gt"]) ** 2))
+    assert abs(psnr - float(g["psnr"])) < 1e-3 and psnr > 31.0
+
+
+def case_admm_tv_misc(device):
+    g = load_golden("g5_admm_tv_misc")
+    b = T(g["b"], device)
+    x = dp.Variable()
+    data = dp.sum_squares(dp.conv(x, g["psf"]) - b)
+    t0, t1, t2 = dp.norm1(dp.grad(x, dim=0)), 2.0 * dp.norm1(dp.grad(x, dim=1)), dp.norm1(dp.grad(x, dim=2))
+    out = dp.Problem(data + t0 + t1 + t2).solve(method="admm", device=device, x0=np.ascontiguousarray(g["b"][0].transpose(1, 2, 0)))
+    assert_close(out.cpu(), g["x_defaults"], TOL, "defaults (rho=1, lam=0.02, 24 it, HWC numpy x0)")
+    out = dp.Problem(data + t0 + t1 + t2).solve(method="admm", device=device, x0=b, rhos=0.2, max_iter=6,
+                                                lams={t0: 0.01, t1: torch.linspace(0.01, 0.02, 6), t2: 0.003})
+    assert_close(out.cpu(), g["x_lams"], TOL, "per-term lams")
+
+
+def case_pgd(device):
+    g = load_golden("g10_pgd")
+    b = T(g["b"], device)
+    x = dp.Variable()
+    out = dp.Problem(dp.sum_squares(dp.conv(x, g["psf"]) - b) + dp.norm1(x)).solve(
+        method="pgd", device=device, x0=b, rhos=0.8, lams=0.01, max_iter=5)
+    assert_close(out.cpu(), g["x_norm1"], TOL)
+    x2 = dp.Variable()
+    out = dp.Problem(dp.sum_squares(dp.conv(x2, g["psf"]) - b) + dp.nonneg(x2)).solve(
+        method="pgd", device=device, x0=b, rhos=torch.tensor([[0.8] * 5, [0.4] * 5]), lams=0.01, max_iter=5)
+    assert_close(out.cpu(), g["x_nonneg_rhoB"], TOL)
+
+
+def case_known_answers(device):
+    """the reference's own exact tests, tests/problem/test_ml_problems.py:5-44"""
+    g = load_golden("g13_known_answers")
+    rhs = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]])
+    x = dp.Variable((3, 3))
+    dp.Problem(dp.sum_squares(2 * x - rhs)).solve("admm", device=device, x0=np.zeros((3, 3)))
+    assert (x.value.cpu().numpy() == rhs / 2).all()
+    x = dp.Variable((3, 3))
+    dp.Problem(dp.sum_squares(2 * x, rhs)).solve("admm", device=device, x0=np.zeros((3, 3)))
+    assert (x.value.cpu().numpy() == rhs / 2).all()
+    x = dp.Variable((3, 3, 1))
+    rhs3 = np.array([[[1, 2, 3], [4, 5, 6], [7, 8, 9]]])
+    kernel = np.array([[1, 1], [1, 1]]) / 4
+    dp.Problem(dp.sum_squares(dp.conv(x, kernel) - rhs3)).solve("admm", device=device, x0=np.zeros((3, 3, 1)))
+    out = dp.eval(dp.conv(x, kernel).to(device) - rhs3, x.value, zero_out_constant=False)
+    assert (out.cpu() < 1e-5).all()
+    assert_close(x.value.cpu(), g["lsq2_x"], 2e-5)
+    x = dp.Variable((3))
+    dp.Problem(dp.sum_squares(2 * x - np.array([1, 2, 3]))).solve("admm", device=device, x0=np.zeros(3))
+    assert (x.value.cpu().numpy() == np.array([1, 2, 3]) / 2).all()
+
+
+def case_cg(device, B):
+    from dprox.linalg.solve import cg
+    from dprox.utils import fft2, ifft2
+    g = load_golden("g6_cg")
+    mask, rhs, rho = T(g[f"B{B}_mask"], device), T(g[f"B{B}_rhs"], device), float(g["rho"])
+    A = lambda x: (ifft2(mask * (mask * fft2(x))).real + rho * x).contiguous()
+    x, n = cg(A, rhs, rtol=1e-6, max_iters=100, return_iters=True)
+    assert abs(n - int(g[f"B{B}_iters"])) <= 1, (n, int(g[f"B{B}_iters"]))
+    assert_close(x.cpu(), g[f"B{B}_x"], TOL)
+    assert_close(cg(A, rhs, rtol=0.0, max_iters=10).cpu(), g[f"B{B}_x_10it"], TOL)
+
+
+def case_adjoint_dot(device, shape=(2, 3, 96, 80)):
+    """CompGraph.sanity_check dot-product test (reference comp_graph.py:342-371, tests/test_linop.py)"""
+    import synthetic
+    x = dp.Variable()
+    psf = synthetic.point_spread_function(15, 5.0)
+    for op in (dp.conv(x, psf), dp.grad(x, dim=0), dp.grad(x, dim=1), dp.vstack([dp.conv(x, psf), dp.grad(x, dim=1), x]),
+               2.0 * dp.conv(x, psf) - 0.5 * dp.grad(x, dim=0)):
+        assert dp.CompGraph(op.to(device)).sanity_check(eps=1e-4, shape=shape), str(op)

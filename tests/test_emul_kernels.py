@@ -1,0 +1,55 @@
+"""CPU-only: the unchanged HIP kernel sources compiled for the host by the SIMT emulator (tests/emul)
+run the same parity cases as the GPU tests (small fixtures only).  Catches indexing / barrier / layout
+bugs without a GPU; the authoritative numerics check is tests/test_gpu_parity.py on a real MI355X."""
+import pytest
+
+import emul_util
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emulated():
+    emul_util.use_emulator()
+    yield
+
+
+import parity_cases as pc  # noqa: E402
+
+DEV = "cpu"
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_linops(tag):
+    pc.case_linops(DEV, tag)
+
+
+def test_prox():
+    pc.case_prox(DEV)
+
+
+def test_solve_direct():
+    pc.case_solve_direct(DEV)
+
+
+def test_admm_tv_small_fused():
+    pc.case_admm_tv_small(DEV, True)
+
+
+def test_admm_tv_misc():
+    pc.case_admm_tv_misc(DEV)
+
+
+def test_pgd():
+    pc.case_pgd(DEV)
+
+
+def test_known_answers():
+    pc.case_known_answers(DEV)
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_cg(B):
+    pc.case_cg(DEV, B)
+
+
+def test_adjoint_dot_product():
+    pc.case_adjoint_dot(DEV, shape=(1, 3, 24, 20))

@@ -1,0 +1,113 @@
+"""-m gpu: parity of the HIP path (through the C ABI, via the drop-in dprox API) against the golden
+vectors of the reference, and size-independent properties at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _hip_lib_loaded():
+    from dprox import _backend as be
+    assert torch.cuda.is_available()
+    assert not be.host_mode()
+    lib = be.lib()                      # raises if libdpx_hip.so is missing: no fallback
+    assert "libdpx_hip.so" in lib.path
+    yield
+
+
+import parity_cases as pc  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_linops(tag):
+    pc.case_linops(DEV, tag)
+
+
+def test_prox():
+    pc.case_prox(DEV)
+
+
+def test_solve_direct():
+    pc.case_solve_direct(DEV)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_admm_tv_small(fused):
+    pc.case_admm_tv_small(DEV, fused)
+
+
+def test_admm_tv_config1():
+    pc.case_admm_tv_config1(DEV)
+
+
+def test_admm_tv_misc():
+    pc.case_admm_tv_misc(DEV)
+
+
+def test_pgd():
+    pc.case_pgd(DEV)
+
+
+def test_known_answers():
+    pc.case_known_answers(DEV)
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_cg(B):
+    pc.case_cg(DEV, B)
+
+
+def test_adjoint_dot_product():
+    pc.case_adjoint_dot(DEV)
+
+
+def test_cpu_device_is_refused():
+    import dprox as dp
+    from dprox._backend import DpxError
+    x = dp.Variable()
+    with pytest.raises(DpxError):
+        dp.Problem(dp.sum_squares(x - torch.zeros(1, 1, 8, 8)) + dp.nonneg(x)).solve(device="cpu", x0=torch.zeros(1, 1, 8, 8))
+
+
+# ---- full-size properties (config 2 shape, 8x3x1024x1024) -------------------------------------------
+def test_full_size_properties():
+    import dprox as dp
+    import synthetic
+    from dprox import _ops as ops
+    torch.manual_seed(0)
+    B, C, H, W = 8, 3, 1024, 1024
+    psf = synthetic.point_spread_function(15, 5.0)
+    x = torch.rand(B, C, H, W, device=DEV)
+    y = torch.randn(B, C, H, W, device=DEV)
+    v = dp.Variable()
+    op = dp.conv(v, psf).to(DEV)
+    Kx, Kty = op.forward(x), op.adjoint(y)
+    # adjointness <Kx, y> == <x, K^T y>
+    lhs, rhs = float(ops.bdot(Kx, y).sum()), float(ops.bdot(x, Kty).sum())
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs) + 1e-2
+    # a normalised PSF preserves the mean; blurring twice == blurring with the self-convolved PSF is linear:
+    assert abs(float(Kx.mean()) - float(x.mean())) < 1e-5
+    a = 0.37
+    lin = op.forward((a * x + y).contiguous())
+    assert float((lin - (a * Kx + op.forward(y))).abs().max()) < 2e-5
+    # identity OTF round trip
+    delta = np.zeros((3, 3, 1), np.float32); delta[1, 1, 0] = 1
+    assert float((dp.conv(v, delta).to(DEV).forward(x) - x).abs().max()) < 2e-6
+    # Fourier solve inverts (|H|^2 + rho) in the least-squares sense: residual of the normal equations
+    d0 = ops.new_diag(C, H, W, x.device); ops.accumulate_diag(d0, psf, 1.0, C, H, W)
+    rho = torch.full((B,), 0.3, device=DEV)
+    sol = ops.fourier_solve(y, d0, None, 0.0, 1.0, rho, eps=0.0)
+    res = op.adjoint(op.forward(sol)) + 0.3 * sol - y
+    assert float(res.norm() / y.norm()) < 2e-5
+    # ADMM on the config-2 objective improves PSNR and keeps x finite
+    gt, b, _ = synthetic.deconv_case(1, 3, H, W, seed=5)
+    bt = torch.from_numpy(b).to(DEV).repeat(2, 1, 1, 1)
+    xv = dp.Variable()
+    fns = dp.sum_squares(dp.conv(xv, psf) - bt) + dp.norm1(dp.grad(xv, dim=0)) + dp.norm1(dp.grad(xv, dim=1))
+    out = dp.Problem(fns).solve(method="admm", device=DEV, x0=bt, rhos=0.1, lams=0.005, max_iter=20)
+    ps = lambda t: 10 * np.log10(1.0 / np.mean((t.cpu().numpy()[0] - gt[0]) ** 2))
+    assert torch.isfinite(out).all() and ps(out) > ps(bt) + 3.0
+    assert torch.equal(out[0], out[1])           # images of a batch never interact

@@ -1,0 +1,115 @@
+"""CPU-only: host-side logic of the drop-in layer (no kernel launches) + the C-ABI library loads and
+exports every symbol include/dpx.h declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dprox as dp
+from conftest import ROOT, load_golden
+from dprox import _backend as be
+from dprox.algo.driver import Algorithm
+from dprox.utils import to_ndarray, to_torch_tensor
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dpx.h")).read()
+    declared = set(re.findall(r"\b(dpx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(be.SIGNATURES), declared ^ set(be.SIGNATURES)
+    if not os.path.exists(be.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = be.Library(be.LIB_PATH)          # AttributeError if a symbol is missing
+    assert lib.query("dpx_version") >= 100
+    assert lib.query("dpx_fft_table_bytes", 1024, 1024) == 2048 * 8
+    assert lib.query("dpx_spectrum_bytes", 24, 1024, 1024) == 24 * 1024 * 512 * 8      # packed half spectrum = input bytes
+    assert lib.query("dpx_spectrum_bytes", 1, 15, 21) == 15 * 11 * 8
+
+
+def test_to_torch_tensor_and_ndarray():
+    a = np.zeros((5, 7, 3), np.float32)
+    assert tuple(to_torch_tensor(a, batch=True).shape) == (1, 3, 5, 7)          # HWC -> NCHW
+    assert tuple(to_torch_tensor(np.zeros((5, 7, 1)), batch=True).shape) == (1, 1, 5, 7)
+    assert tuple(to_torch_tensor(np.zeros((5, 7, 2)), batch=True).shape) == (1, 5, 7, 2)   # C not in {1,3}: untouched
+    assert tuple(to_torch_tensor(np.zeros((5, 7)), batch=True).shape) == (1, 5, 7)
+    t = dp.tensor(np.zeros((5, 7, 3)))
+    assert to_torch_tensor(t, batch=True) is t                                  # tagged tensors are never re-batchified
+    assert to_ndarray(torch.zeros(1, 3, 4, 5), debatch=True).shape == (4, 5, 3)
+    assert to_ndarray(np.zeros((2, 2), np.float64)).dtype == np.float32
+
+
+def test_partition_and_defaults():
+    x = dp.Variable()
+    data = dp.sum_squares(dp.conv(x, np.ones((3, 3, 1)) / 9) - torch.zeros(1, 1, 8, 8))
+    r0, r1, nn = dp.norm1(dp.grad(x, dim=0)), 2.0 * dp.norm1(dp.grad(x, dim=1)), dp.nonneg(x)
+    fns = data + r0 + r1 + nn
+    assert isinstance(fns, list) and len(fns) == 4 and r1.alpha == 2.0
+    psi, omega = dp.ADMM.partition(fns)
+    assert omega == [data] and psi == [r0, r1, nn]
+
+    class weighted(dp.sum_squares):          # subclasses of sum_squares stay in Psi (exact-type test, admm.py:33)
+        pass
+    psi, omega = dp.ADMM.partition([weighted(x), data])
+    assert len(omega) == 1 and omega[0] is data
+    with pytest.raises(ValueError):
+        dp.ProximalGradientDescent.partition([data])
+    with pytest.raises(ValueError):
+        dp.ProximalGradientDescent.partition([r0, nn])
+    psi, omega = dp.ProximalGradientDescent.partition([nn, data])
+    assert omega == [data] and psi == [nn]
+
+    solver = dp.ADMM(*dp.ADMM.partition(fns))
+    _, rhos, lams, T = solver.defaults(None, None, None, 24)
+    assert T == 24 and torch.equal(rhos, torch.full((24,), 1.0)) and set(lams) == {r0, r1, nn}
+    assert all(torch.allclose(v, torch.full((24,), 0.02)) for v in lams.values())
+    _, rhos, lams, _ = solver.defaults(None, 0.3, {r0: 0.1, r1: torch.arange(5.0)}, 5)
+    assert torch.allclose(lams[r0], torch.full((5,), 0.1)) and torch.equal(lams[r1], torch.arange(5.0))
+    assert solver.least_square.freq_diagonalizable and not solver.least_square.diagonalizable
+    assert solver.nparams == 4 and solver.state_split == [1, [3], [3]]
+
+
+def test_errors_and_quirks():
+    x = dp.Variable()
+    with pytest.raises(ValueError):
+        dp.grad(x, dim=3)
+    with pytest.raises(TypeError):
+        x * np.ones(3)
+    with pytest.raises(KeyError):
+        dp.compile([dp.nonneg(x)], method="nope", device="cuda")
+    if not be.host_mode():
+        with pytest.raises(be.DpxError):
+            dp.compile([dp.nonneg(x), dp.sum_squares(x)], method="admm", device="cpu")   # no CPU path
+    with pytest.raises(NotImplementedError):
+        dp.specialize(None, method="deq")
+    ph = dp.Placeholder()
+    seen = []
+    ph.change(seen.append)
+    ph.value = torch.ones(2)
+    ph.value = torch.nn.Parameter(torch.zeros(2))       # the reference silently skips watchers here
+    assert len(seen) == 2
+    e = 2 * x - 3.0
+    assert type(e).__name__ == "sum" and len(e.input_nodes) == 2 and e.variables == [x]
+    assert (x + 1 + 2).__class__.__name__ == "sum" and len((x + 1 + 2).input_nodes) == 3   # sums are flattened
+
+
+def test_log_descent_matches_reference_tables():
+    g = load_golden("g12_log_descent")
+    r, s = dp.log_descent(35, 5, 30)
+    assert np.array_equal(r.numpy(), g["rhos_35_5_30"]) and np.array_equal(s.numpy(), g["sigmas_35_5_30"])
+    r, s = dp.log_descent(upper=30, lower=10, iter=8, sqrt=True, lam=0.1, w=0.7)
+    assert np.array_equal(r.numpy(), g["rhos_30_10_8_sqrt"]) and np.array_equal(s.numpy(), g["sigmas_30_10_8_sqrt"])
+
+
+def test_product_does_not_import_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0]=[%r, %r]; import dprox, dprox.algo.fused, dprox.proxfn.pnp; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle leaked into the product'"
+            % (ROOT, os.path.join(ROOT, "delta-prox_amd")))
+    subprocess.run([sys.executable, "-c", code], check=True)
+    src = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "delta-prox_amd", "dprox")):
+        src += [open(os.path.join(dirpath, f)).read() for f in files if f.endswith(".py")]
+    assert not any(re.search(r"^\s*(import|from)\s+oracle", s, re.M) for s in src)
