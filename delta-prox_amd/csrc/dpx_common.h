@@ -75,6 +75,7 @@ struct SpecArgs {
   const float* d0;     // OP_SOLVE (nullable)
   const float* d1;     // OP_SOLVE (nullable)
   const float* rho;    // OP_SOLVE device [B]
+  const float2* add;   // OP_SOLVE (nullable): per-plane spectrum added before the division
   float c0, c1, eps;
   float scale;         // 1/(H*W)
 };

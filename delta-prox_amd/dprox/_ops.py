@@ -141,12 +141,25 @@ def fft_conv(x, otf, conj=False, out=None):
     return y
 
 
-def fourier_solve(rhs, d0, d1, c0, c1, rho, eps=EPS, out=None):
+def data_spectrum(b, otf=None, conj=True, out=None, accumulate=False):
+    """packed fp32 half spectrum of op(OTF) * F(b), transform evaluated in fp64 (once per solve)"""
+    require(b, what="data_spectrum input")
+    B, C, H, W = _shape4(b)
+    L = be.lib()
+    if out is None:
+        out = _bytes(L.query("dpx_spectrum_bytes", B * C, H, W), b.device)
+        accumulate = False
+    ws = workspace("data_spectrum", L.query("dpx_data_spectrum_ws_bytes", B * C, H, W), b.device)
+    L.call("dpx_data_spectrum", ptr(b), ptr(otf), int(bool(conj)), ptr(out), int(bool(accumulate)), B, C, H, W, ptr(ws), be.stream())
+    return out
+
+
+def fourier_solve(rhs, d0, d1, c0, c1, rho, eps=EPS, out=None, spec_add=None):
     require(rhs, what="fourier_solve rhs")
     B, C, H, W = _shape4(rhs)
     rho = as_batch_vec(rho, B, rhs.device)
     x = torch.empty_like(rhs) if out is None else out
-    be.lib().call("dpx_fourier_solve", ptr(rhs), ptr(x), ptr(d0), ptr(d1), c_float(c0), c_float(c1), ptr(rho),
+    be.lib().call("dpx_fourier_solve", ptr(rhs), ptr(x), ptr(spec_add), ptr(d0), ptr(d1), c_float(c0), c_float(c1), ptr(rho),
                   c_float(eps), B, C, H, W, ptr(fft_table(H, W, rhs.device)),
                   ptr(spectrum_ws(B * C, H, W, rhs.device)), be.stream())
     return x

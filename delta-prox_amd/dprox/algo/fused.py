@@ -10,8 +10,9 @@ proxfn/sum_square.py:123-156 -> linop/comp_graph.py:198-282; 18 full complex FFT
 per TV-deconvolution iteration) by three stages of hand-written kernels working in place on
 HBM-resident state:
 
-    1. rhs   = K^T b + rho * sum_i K_i^T (v_i - u_i)                 (dpx_admm_rhs: spatial stencils)
-    2. x     = irFFT2[(rFFT2(rhs) + eps) / (|H|^2 + rho sum|G_i|^2 + eps)]   (dpx_fourier_solve)
+    0. FK    = F(sum_Omega K^T b)  once per solve, fp64 transform       (dpx_data_spectrum)
+    1. rhs   = rho * sum_i K_i^T (v_i - u_i)                           (dpx_admm_rhs: spatial stencils)
+    2. x     = irFFT2[(rFFT2(rhs) + FK + eps) / (|H|^2 + rho sum|G_i|^2 + eps)]   (dpx_fourier_solve)
     3. v_i   = prox_i(K_i x + u_i) ; u_i += K_i x - v_i               (dpx_admm_zupdate [+ FFDNet])
 
 K^T b and the denominators are computed once per solve; rho / lambda schedules are uploaded once as
@@ -47,6 +48,14 @@ def _omega_ok(fn):
     if _is_var(op):
         return True
     return type(op) is conv and _is_var(op.input_nodes[0])
+
+
+def _omega_conv(fn):
+    """the conv node of a recognised Omega term (None for the identity)"""
+    op = fn.linop
+    if isinstance(op, lin_sum):
+        op = [k for k in op.input_nodes if not isinstance(k, Constant)][0]
+    return op if type(op) is conv else None
 
 
 def _psi_linop_code(op):
@@ -127,9 +136,16 @@ class FusedADMM:
             if isinstance(fn, deep_prior) and fn.sqrt:
                 lt = torch.sqrt(torch.clamp(lt, min=1e-8))           # safe_sqrt(lam), prior.py:77
             lam_tab.append(lt)
-        ktb = ls.quad_rhs()
-        if ktb is not None and ktb.shape != x0.shape:
-            ktb = ktb.expand_as(x0).contiguous()
+        # data spectrum F(sum_Omega K^T b), once per solve, fp64 transform (kept in the Fourier domain)
+        FK = None
+        for fn in s.omega_fns:
+            off = fn.offset
+            if off is None:
+                continue
+            off = off.expand_as(x0).contiguous() if off.shape != x0.shape else off.contiguous()
+            cv = _omega_conv(fn)
+            otf = cv._tables(x0.shape, dev) if cv is not None else None
+            FK = ops.data_spectrum(off, otf, conj=True, out=FK, accumulate=FK is not None)
         (t0, c0), (t1, c1) = ls.diag_tables(x0.shape, dev, True)
 
         v = [t.contiguous() for t in v]
@@ -146,8 +162,8 @@ class FusedADMM:
         for it in tqdm(range(T), disable=not pbar):
             for i in range(n):
                 terms[i].lam = lam_tab[i][it].data_ptr()
-            ops.admm_rhs(rhs, ktb, rho_tab[it], terms, n)
-            ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x)
+            ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
+            ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x, spec_add=FK)
             ops.admm_zupdate(x, terms, n)
             for i in ext:                                            # v_i holds d = x + u_i
                 fn = psi[i]

@@ -74,11 +74,21 @@ int dpx_psf2otf(const double* psf, int kh, int kw, int kc, int C, int H, int W,
 int dpx_fft_conv(const float* x, float* y, const void* otf, int conj_otf, int B, int C, int H, int W,
                  const void* table, void* spectrum_ws, dpx_stream_t stream);
 
-/* x = real(ifft2((fft2(rhs) + eps) / (d0 + c0 + rho_b*(d1 + c1) + eps)))
+/* spec (+)= op(OTF) * fft2(b), evaluated once per solve in fp64 and stored as a packed fp32 half spectrum
+ * (dpx_spectrum_bytes).  This is the Fourier transform of the constant part of the x-update's
+ * right-hand side, sum over Omega of K^T b (proxfn/sum_square.py:126-132, where the reference
+ * re-evaluates it with two fp32 FFTs every iteration); otf nullable = identity.                    */
+size_t dpx_data_spectrum_ws_bytes(int P, int H, int W);
+int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, void* spec_out, int accumulate,
+                      int B, int C, int H, int W, void* ws, dpx_stream_t stream);
+
+/* x = real(ifft2((fft2(rhs) + spec_add + eps) / (d0 + c0 + rho_b*(d1 + c1) + eps)))
  * least_squares.solve_direct, frequency branch -- proxfn/sum_square.py:137-152.
+ * spec_add (nullable) is a dpx_data_spectrum result: the data part of the right-hand side kept in the
+ * Fourier domain, so that rhs only carries rho * sum_i K_i^T (v_i - u_i).
  * d0/d1 are diag tables (nullable = 0); c0/c1 add the constant diagonals of identity linops
  * (Variable.get_diag, linop/variable.py:47-59, and the `+ rho` of :147-148); rho is device [B]. */
-int dpx_fourier_solve(const float* rhs, float* x, const void* d0, const void* d1, float c0, float c1,
+int dpx_fourier_solve(const float* rhs, float* x, const void* spec_add, const void* d0, const void* d1, float c0, float c1,
                       const float* rho, float eps, int B, int C, int H, int W,
                       const void* table, void* spectrum_ws, dpx_stream_t stream);
 
