@@ -1,11 +1,233 @@
-// Register-radix kernels for power-of-two planes (256/512/1024/2048): placeholder until the tuned
-// kernels land; the generic LDS path of dpx_fft.hip serves every size meanwhile.
-#include "dpx_common.h"
+// Power-of-two planes (H in {256,512,1024}, W in {256,...,2048}): the rFFT2 -> operator -> irFFT2 pipeline on
+// the register-radix transform of dpx_fft_reg.h.
+//
+//   k_rows_r2c_p2 : one wave (or part of one) per image row: row read as (x[2n], x[2n+1]) complex pairs with
+//                   coalesced 8-byte loads, length-W/2 transform in registers, real-input untangling with
+//                   in-wave shuffles, half spectrum written with coalesced stores (Nyquist packed into DC).
+//   k_cols_p2     : a tile of COLS adjacent spectrum columns of one plane per workgroup: forward column
+//                   transform, per-frequency operator on registers, inverse column transform, in place.
+//   k_rows_c2r_p2 : inverse of the first.
+// Every element crosses HBM once per kernel (8 B/element algorithmic traffic each) and LDS twice per 1-D
+// transform.
+#include "dpx_fft_reg.h"
 
 namespace dpx {
-bool pow2_path_available(int H, int W) { (void)H; (void)W; return false; }
-int spectral_apply_pow2(const float*, float*, int, const SpecArgs&, int, int, int, int, const void*, void*, hipStream_t) {
-  set_error("pow2 path not built");
-  return DPX_ERR_UNSUPPORTED;
+
+// ---------------------------------------------------------------------------------------------
+// rows
+// ---------------------------------------------------------------------------------------------
+template <int M, int T>
+__global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x, float2* __restrict__ spec, int nrows,
+                                                      const float2* __restrict__ twW) {
+  constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
+  __shared__ float2 lds[SPB * S];
+  const int tid = threadIdx.x, seq = tid / T, t = tid % T;
+  const int row = blockIdx.x * SPB + seq;
+  const bool live = row < nrows;
+  const float2* xr = (const float2*)(x + (size_t)(live ? row : 0) * (2 * M));
+  float2 v[V];
+#pragma unroll
+  for (int m = 0; m < V; ++m) v[m] = xr[t + m * T];
+  fft_reg<M, T, -1>(v, lds + seq * S, t, twW, 2, WaveSync());
+  // real-input untangling: X[k] = E[k] + w^k O[k], E = (Z[k] + conj Z[M-k])/2, O = -i (Z[k] - conj Z[M-k])/2
+  const int lane = tid & 63;
+  const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
+  float2* out = spec + (size_t)(live ? row : 0) * M;
+#pragma unroll
+  for (int m = 0; m < V; ++m) {
+    const float2 got = make_float2(__shfl(v[V - 1 - m].x, plane), __shfl(v[V - 1 - m].y, plane));
+    const float2 zm = cconj(t == 0 ? v[(V - m) % V] : got);
+    const int k = t + m * T;
+    const float2 zk = v[m];
+    float2 X;
+    if (k == 0) {
+      X = make_float2(zk.x + zk.y, zk.x - zk.y);
+    } else {
+      const float2 e = cscale(cadd(zk, zm), 0.5f);
+      const float2 d = cscale(csub(zk, zm), 0.5f);
+      X = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
+    }
+    if (live) out[k] = X;
+  }
 }
+
+template <int M, int T>
+__global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ spec, float* __restrict__ y, int nrows,
+                                                      const float2* __restrict__ twW, float scale) {
+  constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
+  __shared__ float2 lds[SPB * S];
+  const int tid = threadIdx.x, seq = tid / T, t = tid % T;
+  const int row = blockIdx.x * SPB + seq;
+  const bool live = row < nrows;
+  const float2* in = spec + (size_t)(live ? row : 0) * M;
+  float2 X[V], v[V];
+#pragma unroll
+  for (int m = 0; m < V; ++m) X[m] = in[t + m * T];
+  const int lane = tid & 63;
+  const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
+#pragma unroll
+  for (int m = 0; m < V; ++m) {
+    const float2 got = make_float2(__shfl(X[V - 1 - m].x, plane), __shfl(X[V - 1 - m].y, plane));
+    const float2 xm = cconj(t == 0 ? X[(V - m) % V] : got);
+    const int k = t + m * T;
+    const float2 xk = X[m];
+    if (k == 0) {
+      v[m] = make_float2(xk.x + xk.y, xk.x - xk.y);
+    } else {
+      const float2 e = cadd(xk, xm);
+      const float2 d = cmulc(csub(xk, xm), twW[k]);
+      v[m] = make_float2(e.x - d.y, e.y + d.x);
+    }
+  }
+  fft_reg<M, T, +1>(v, lds + seq * S, t, twW, 2, WaveSync());
+  float2* yr = (float2*)(y + (size_t)(live ? row : 0) * (2 * M));
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < V; ++m) yr[t + m * T] = make_float2(v[m].x * scale, v[m].y * scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-frequency operator (same semantics as dpx_fft.hip::spec_op)
+// ---------------------------------------------------------------------------------------------
+template <int OP>
+__device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, size_t tix, float rho_b) {
+  if constexpr (OP == OP_MUL) {
+    return cscale(cmul(z, A.otf[tix]), A.scale);
+  } else if constexpr (OP == OP_MULCONJ) {
+    return cscale(cmulc(z, A.otf[tix]), A.scale);
+  } else {
+    const float d0 = (A.d0 ? A.d0[tix] : 0.f) + A.c0;
+    const float d1 = (A.d1 ? A.d1[tix] : 0.f) + A.c1;
+    const float den = fmaf(rho_b, d1, d0) + A.eps;
+    const float inv = A.scale / den;
+    return make_float2((z.x + A.eps) * inv, z.y * inv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// columns
+// ---------------------------------------------------------------------------------------------
+template <int H, int T, int COLS, int OP>
+__global__ void __launch_bounds__(T* COLS) k_cols_p2(float2* __restrict__ spec, SpecArgs A, int C, int Ws,
+                                                      const float2* __restrict__ twH) {
+  constexpr int V = H / T;
+  constexpr int S0 = LdsSeq<H>::SLOTS;
+  constexpr int S = S0 + ((36 - S0 % 32) % 32);     // S % 32 == 4: adjacent columns start 8 banks apart
+  HIP_DYNAMIC_SHARED(float2, smem_p2)
+  const int tid = threadIdx.x, c = tid % COLS, t = tid / COLS;
+  const int p = blockIdx.y, l0 = blockIdx.x * COLS;
+  const int ch = p % C, bi = p / C;
+  float2* base = spec + (size_t)p * H * Ws + l0 + c;
+  float2* lds = smem_p2 + c * S;
+  float2 v[V];
+#pragma unroll
+  for (int m = 0; m < V; ++m) v[m] = base[(size_t)(t + m * T) * Ws];
+  fft_reg<H, T, -1>(v, lds, t, twH, 1, BlockSync());
+  const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
+  const size_t tmain = (size_t)ch * H * Ws + l0 + c;
+  if (OP == OP_SOLVE && A.add) {
+    const float2* add = A.add + (size_t)p * H * Ws + l0 + c;
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[m] = cadd(v[m], add[(size_t)(t + m * T) * Ws]);
+  }
+  if (l0 == 0) {
+    // column 0 carries DC + i*Nyquist of two real-valued columns: separate them through Z[k], Z[H-k]
+    __syncthreads();
+    if (c == 0) {
+#pragma unroll
+      for (int m = 0; m < V; ++m) lds[lds_slot(t + m * T)] = v[m];
+    }
+    __syncthreads();
+    if (c == 0) {
+      const size_t tside = (size_t)C * H * Ws + (size_t)ch * H;
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const int k = t + m * T, k2 = (H - k) % H;
+        const float2 zk = v[m], zm = cconj(lds[lds_slot(k2)]);
+        const float2 Ak = cscale(cadd(zk, zm), 0.5f);
+        const float2 d = cscale(csub(zk, zm), 0.5f);
+        const float2 Bk = make_float2(d.y, -d.x);
+        const float2 A1 = spec_op_p2<OP>(Ak, A, tmain + (size_t)k * Ws, rho_b);
+        const float2 B1 = spec_op_p2<OP>(Bk, A, tside + k, rho_b);
+        v[m] = make_float2(A1.x - B1.y, A1.y + B1.x);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < V; ++m) v[m] = spec_op_p2<OP>(v[m], A, tmain + (size_t)(t + m * T) * Ws, rho_b);
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[m] = spec_op_p2<OP>(v[m], A, tmain + (size_t)(t + m * T) * Ws, rho_b);
+  }
+  __syncthreads();
+  fft_reg<H, T, +1>(v, lds, t, twH, 1, BlockSync());
+#pragma unroll
+  for (int m = 0; m < V; ++m) base[(size_t)(t + m * T) * Ws] = v[m];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host dispatch
+// ---------------------------------------------------------------------------------------------
+bool pow2_path_available(int H, int W) {
+  const bool hok = (H == 256 || H == 512 || H == 1024);
+  const bool wok = (W == 256 || W == 512 || W == 1024 || W == 2048);
+  return hok && wok;
+}
+
+template <int M, int T>
+static void launch_rows(bool fwd, const float* x, float2* spec, float* y, int nrows, const float2* twW, float scale, hipStream_t s) {
+  constexpr int SPB = 256 / T;
+  const dim3 grid((nrows + SPB - 1) / SPB);
+  if (fwd)
+    DPX_LAUNCH("k_rows_r2c_p2", (k_rows_r2c_p2<M, T>), grid, dim3(256), 0, s, x, spec, nrows, twW);
+  else
+    DPX_LAUNCH("k_rows_c2r_p2", (k_rows_c2r_p2<M, T>), grid, dim3(256), 0, s, (const float2*)spec, y, nrows, twW, scale);
+}
+
+static void rows_dispatch(bool fwd, int W, const float* x, float2* spec, float* y, int nrows, const float2* twW, float scale, hipStream_t s) {
+  switch (W) {
+    case 256: launch_rows<128, 16>(fwd, x, spec, y, nrows, twW, scale, s); break;
+    case 512: launch_rows<256, 32>(fwd, x, spec, y, nrows, twW, scale, s); break;
+    case 1024: launch_rows<512, 64>(fwd, x, spec, y, nrows, twW, scale, s); break;
+    default: launch_rows<1024, 64>(fwd, x, spec, y, nrows, twW, scale, s); break;
+  }
+}
+
+template <int H, int T, int COLS, int OP>
+static void launch_cols(float2* spec, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
+  constexpr int S0 = LdsSeq<H>::SLOTS;
+  constexpr int S = S0 + ((36 - S0 % 32) % 32);
+  const size_t sh = (size_t)COLS * S * sizeof(float2);
+  static bool attr_done = false;
+  if (!attr_done && sh > 48 * 1024) {
+    hipFuncSetAttribute((const void*)k_cols_p2<H, T, COLS, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    attr_done = true;
+  }
+  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP>), dim3(Ws / COLS, P), dim3(T * COLS), sh, s, spec, A, C, Ws, twH);
+}
+
+template <int OP>
+static void cols_dispatch(int H, float2* spec, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
+  switch (H) {
+    case 256: launch_cols<256, 32, 8, OP>(spec, A, P, C, Ws, twH, s); break;
+    case 512: launch_cols<512, 64, 8, OP>(spec, A, P, C, Ws, twH, s); break;
+    default: launch_cols<1024, 64, 8, OP>(spec, A, P, C, Ws, twH, s); break;
+  }
+}
+
+int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& A, int B, int C, int H, int W,
+                        const void* table, void* ws, hipStream_t stream) {
+  const int P = B * C, Ws = W / 2;
+  float2* spec = (float2*)ws;
+  rows_dispatch(true, W, x, spec, nullptr, P * H, tw_rows(table), 1.0f, stream);
+  switch (op) {
+    case OP_MUL: cols_dispatch<OP_MUL>(H, spec, A, P, C, Ws, tw_cols(table, W), stream); break;
+    case OP_MULCONJ: cols_dispatch<OP_MULCONJ>(H, spec, A, P, C, Ws, tw_cols(table, W), stream); break;
+    default: cols_dispatch<OP_SOLVE>(H, spec, A, P, C, Ws, tw_cols(table, W), stream); break;
+  }
+  rows_dispatch(false, W, nullptr, spec, y, P * H, tw_rows(table), 1.0f, stream);
+  return launch_status("spectral_apply_pow2");
+}
+
 }  // namespace dpx

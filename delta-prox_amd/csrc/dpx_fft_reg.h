@@ -1,0 +1,138 @@
+// Register-resident radix passes for power-of-two transforms (gfx950).
+//
+// A length-N complex transform is carried by T threads holding V = N/T values each.  Three Stockham
+// passes: radix V in registers -> (LDS) -> radix RM = N/V^2 -> (LDS) -> radix V in registers, so an
+// element crosses LDS twice per transform (2 writes + 2 reads) instead of once per radix-2/4/8 pass.
+// On entry v[m] = x[t + m*T]; on exit v[m] = X[t + m*T] -- the same striding, so a forward transform's
+// output registers feed the inverse transform's first pass directly (the per-frequency operator of the
+// x-update runs on registers between the two).
+//
+// LDS image of one sequence: element i lives at slot i + (i >> 4) (one pad slot per 16) which keeps the
+// "thread t writes V consecutive elements" pattern of the first pass off a single bank.
+#pragma once
+#include "dpx_common.h"
+
+namespace dpx {
+
+__device__ __forceinline__ int lds_slot(int i) { return i + (i >> 4); }
+template <int N> struct LdsSeq { static constexpr int SLOTS = N + N / 16; };
+
+// ---- small in-register DFTs, natural order in and out ------------------------------------------------
+template <int DIR> __device__ __forceinline__ void rdft2(float2& a, float2& b) {
+  const float2 t = csub(a, b);
+  a = cadd(a, b);
+  b = t;
+}
+template <int DIR> __device__ __forceinline__ void rdft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+  const float2 s0 = cadd(a0, a2), d0 = csub(a0, a2);
+  const float2 s1 = cadd(a1, a3), d1 = cmul_i<DIR>(csub(a1, a3));
+  a0 = cadd(s0, s1);
+  a2 = csub(s0, s1);
+  a1 = cadd(d0, d1);
+  a3 = csub(d0, d1);
+}
+// multiply by exp(DIR * i * pi * q / 8), q = 1..7, constants folded
+template <int DIR, int Q> __device__ __forceinline__ float2 rot16(float2 a) {
+  constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+  constexpr float cr = (Q == 1) ? c1 : (Q == 2) ? h : (Q == 3) ? s1 : (Q == 4) ? 0.f : (Q == 5) ? -s1 : (Q == 6) ? -h : -c1;
+  constexpr float sr = (Q == 1) ? s1 : (Q == 2) ? h : (Q == 3) ? c1 : (Q == 4) ? 1.f : (Q == 5) ? c1 : (Q == 6) ? h : s1;
+  constexpr float si = DIR < 0 ? -sr : sr;
+  return make_float2(a.x * cr - a.y * si, a.x * si + a.y * cr);
+}
+template <int DIR> __device__ __forceinline__ void rdft8(float2 (&v)[8]) {
+  rdft4<DIR>(v[0], v[2], v[4], v[6]);     // even samples -> E[0..3] in v[0],v[2],v[4],v[6]
+  rdft4<DIR>(v[1], v[3], v[5], v[7]);     // odd samples  -> O[0..3] in v[1],v[3],v[5],v[7]
+  const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  const float2 o0 = v[1], o1 = rot16<DIR, 2>(v[3]), o2 = cmul_i<DIR>(v[5]), o3 = rot16<DIR, 6>(v[7]);
+  v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+template <int DIR> __device__ __forceinline__ void rdft16(float2 (&v)[16]) {
+  float2 e[8] = {v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14]};
+  float2 o[8] = {v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15]};
+  rdft8<DIR>(e);
+  rdft8<DIR>(o);
+  o[1] = rot16<DIR, 1>(o[1]);
+  o[2] = rot16<DIR, 2>(o[2]);
+  o[3] = rot16<DIR, 3>(o[3]);
+  o[4] = cmul_i<DIR>(o[4]);
+  o[5] = rot16<DIR, 5>(o[5]);
+  o[6] = rot16<DIR, 6>(o[6]);
+  o[7] = rot16<DIR, 7>(o[7]);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = cadd(e[k], o[k]);
+    v[k + 8] = csub(e[k], o[k]);
+  }
+}
+template <int R, int DIR> __device__ __forceinline__ void rdft(float2 (&v)[R]) {
+  if constexpr (R == 2) rdft2<DIR>(v[0], v[1]);
+  else if constexpr (R == 4) rdft4<DIR>(v[0], v[1], v[2], v[3]);
+  else if constexpr (R == 8) rdft8<DIR>(v);
+  else rdft16<DIR>(v);
+}
+
+template <int DIR> __device__ __forceinline__ float2 twmul(float2 a, float2 w) {
+  return DIR < 0 ? cmul(a, w) : cmulc(a, w);
+}
+
+// ---- the three-pass transform -------------------------------------------------------------------------
+// lds: this sequence's LdsSeq<N>::SLOTS float2 slots; tw: exp(-2 pi i k / (N*TWS)) table, stride TWS;
+// sync(): barrier over (at least) the T threads of the sequence.  Ends with all LDS reads done but NOT
+// synchronised: call sync() before the same LDS region is written again.
+template <int N, int T, int DIR, class Sync>
+__device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__ lds, int t, const float2* __restrict__ tw,
+                                        int tws, Sync sync) {
+  constexpr int V = N / T;
+  constexpr int RM = N / (V * V);
+  static_assert(V * V * RM == N && (RM == 1 || RM == 2 || RM == 4 || RM == 8), "unsupported N/T split");
+  static_assert(RM <= V, "middle radix must fit the per-thread registers");
+  // pass A: radix V, stride 1, no twiddles
+  rdft<V, DIR>(v);
+#pragma unroll
+  for (int m = 0; m < V; ++m) lds[lds_slot(t * V + m)] = v[m];
+  sync();
+  if constexpr (RM > 1) {
+    // pass B: radix RM, Ns = V; this thread owns butterflies jb = t + i*T
+    constexpr int NB = V / RM;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int jb = t + i * T;
+#pragma unroll
+      for (int mm = 0; mm < RM; ++mm) v[i * RM + mm] = lds[lds_slot(jb + mm * (N / RM))];
+    }
+    sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int jb = t + i * T;
+      const int k = jb % V;
+      float2 a[RM];
+#pragma unroll
+      for (int mm = 0; mm < RM; ++mm) a[mm] = v[i * RM + mm];
+#pragma unroll
+      for (int mm = 1; mm < RM; ++mm) a[mm] = twmul<DIR>(a[mm], tw[(k * mm * V) * tws]);   // W_{V*RM}^{k*mm}
+      rdft<RM, DIR>(a);
+      const int j0 = (jb - k) * RM + k;
+#pragma unroll
+      for (int mm = 0; mm < RM; ++mm) lds[lds_slot(j0 + mm * V)] = a[mm];
+    }
+    sync();
+  }
+  // pass C: radix V, Ns = N/V = T
+#pragma unroll
+  for (int m = 0; m < V; ++m) v[m] = lds[lds_slot(t + m * T)];
+#pragma unroll
+  for (int m = 1; m < V; ++m) v[m] = twmul<DIR>(v[m], tw[(t * m) * tws]);
+  rdft<V, DIR>(v);
+}
+
+struct BlockSync {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+struct WaveSync {
+  __device__ __forceinline__ void operator()() const { __builtin_amdgcn_wave_barrier(); }
+};
+
+}  // namespace dpx

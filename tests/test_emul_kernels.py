@@ -34,6 +34,10 @@ def test_admm_tv_small_fused():
     pc.case_admm_tv_small(DEV, True)
 
 
+def test_admm_tv_config1_pow2_path():
+    pc.case_admm_tv_config1(DEV)          # 256x256: register-radix power-of-two kernels
+
+
 def test_admm_tv_misc():
     pc.case_admm_tv_misc(DEV)
 
