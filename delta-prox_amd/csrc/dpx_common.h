@@ -7,6 +7,14 @@
 
 #include "../../include/dpx.h"
 
+// Hides a value's provenance from the optimiser (zero instructions): used where common-subexpression
+// elimination across kernel phases would keep dozens of addresses alive and spill them.
+#ifdef DPX_EMULATED
+#define DPX_OPAQUE(x) ((void)(x))
+#else
+#define DPX_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 namespace dpx {
 
 // ---- error reporting (thread-local last error, int status across the ABI) -------------------

@@ -427,7 +427,7 @@ __global__ void k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict_
 
 // columns of the unpacked fp64 half spectrum (Wh = W/2+1 columns) -> packed fp32 spectrum times the OTF
 __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restrict__ out, const float2* __restrict__ otf,
-                               int conj_otf, int accumulate, int C, int H, int W, Plan1D plan) {
+                               int conj_otf, int accumulate, int C, int H, int W, Plan1D plan, int side_layout, int P) {
   HIP_DYNAMIC_SHARED(double2, smem64)
   const int Wh = W / 2 + 1, Ws = (W + 1) / 2, ld = H + 1;
   const bool packed = (W % 2 == 0);
@@ -461,7 +461,17 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
         const double tr = t.x, ti = conj_otf ? -(double)t.y : (double)t.y;
         n = make_double2(n.x * tr - n.y * ti, n.x * ti + n.y * tr);
       }
-      v = make_double2(v.x - n.y, v.y + n.x);          // A + i B
+      if (side_layout) {                                // Nyquist column -> side array [P][H]
+        float2* sd = out + (size_t)P * H * Ws + (size_t)p * H + k;
+        if (accumulate) {
+          const float2 old = *sd;
+          *sd = make_float2((float)((double)old.x + n.x), (float)((double)old.y + n.y));
+        } else {
+          *sd = make_float2((float)n.x, (float)n.y);
+        }
+      } else {
+        v = make_double2(v.x - n.y, v.y + n.x);        // packed: A + i B
+      }
     }
     float2* dst = o + (size_t)k * Ws + l;
     if (accumulate) {
@@ -477,6 +487,7 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
 // host side
 // ---------------------------------------------------------------------------------------------
 bool pow2_path_available(int H, int W);
+size_t pow2_spec_elems(int P, int H, int W);
 int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& a, int B, int C, int H, int W,
                         const void* table, void* ws, hipStream_t stream);
 
@@ -547,7 +558,12 @@ extern "C" int dpx_fft_table_init(void* table, int H, int W, dpx_stream_t stream
   return launch_status("dpx_fft_table_init");
 }
 
-extern "C" size_t dpx_spectrum_bytes(int P, int H, int W) { return (size_t)P * H * spec_cols(W) * sizeof(float2); }
+// two half-spectrum buffers (the power-of-two column pass works out of place); power-of-two planes keep the
+// Nyquist bins in a side array [P][H] behind the main [P][H][W/2] array instead of packing them into column 0
+extern "C" size_t dpx_spectrum_bytes(int P, int H, int W) {
+  const size_t one = pow2_path_available(H, W) ? pow2_spec_elems(P, H, W) : (size_t)P * H * spec_cols(W);
+  return 2 * one * sizeof(float2);
+}
 
 extern "C" int dpx_fft_conv(const float* x, float* y, const void* otf, int conj_otf, int B, int C, int H, int W,
                             const void* table, void* ws, dpx_stream_t stream) {
@@ -575,7 +591,8 @@ extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, 
   if (shcol > 48 * 1024) hipFuncSetAttribute((const void*)k_cols_fwd_f64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
   DPX_LAUNCH("k_rows_r2c_f64", k_rows_r2c_f64, dim3(P * H), dim3(256), shrow, (hipStream_t)stream, b, (double2*)ws, W, P * H, make_plan(W));
   DPX_LAUNCH("k_cols_fwd_f64", k_cols_fwd_f64, dim3(Ws, P), dim3(256), shcol, (hipStream_t)stream, (const double2*)ws,
-             (float2*)spec_out, (const float2*)otf, conj_otf, accumulate, C, H, W, make_plan(H));
+             (float2*)spec_out, (const float2*)otf, conj_otf, accumulate, C, H, W, make_plan(H),
+             pow2_path_available(H, W) ? 1 : 0, P);
   return launch_status("dpx_data_spectrum");
 }
 

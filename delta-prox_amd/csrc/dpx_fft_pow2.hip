@@ -3,7 +3,9 @@
 //
 //   k_rows_r2c_p2 : one wave (or part of one) per image row: row read as (x[2n], x[2n+1]) complex pairs with
 //                   coalesced 8-byte loads, length-W/2 transform in registers, real-input untangling with
-//                   in-wave shuffles, half spectrum written with coalesced stores (Nyquist packed into DC).
+//                   in-wave shuffles, half spectrum written with coalesced stores; the (real) Nyquist bins go
+//                   to a small side array [P][H] so that every column of the main array is an ordinary
+//                   complex column (no packed DC/Nyquist special case in the column kernel).
 //   k_cols_p2     : a tile of COLS adjacent spectrum columns of one plane per workgroup: forward column
 //                   transform, per-frequency operator on registers, inverse column transform, in place.
 //   k_rows_c2r_p2 : inverse of the first.
@@ -17,8 +19,8 @@ namespace dpx {
 // rows
 // ---------------------------------------------------------------------------------------------
 template <int M, int T>
-__global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x, float2* __restrict__ spec, int nrows,
-                                                      const float2* __restrict__ twW) {
+__global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x, float2* __restrict__ spec, float2* __restrict__ side,
+                                                      int nrows, const float2* __restrict__ twW) {
   constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
   __shared__ float2 lds[SPB * S];
   const int tid = threadIdx.x, seq = tid / T, t = tid % T;
@@ -41,7 +43,8 @@ __global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x
     const float2 zk = v[m];
     float2 X;
     if (k == 0) {
-      X = make_float2(zk.x + zk.y, zk.x - zk.y);
+      X = make_float2(zk.x + zk.y, 0.f);                                  // DC (real)
+      if (live) side[row] = make_float2(zk.x - zk.y, 0.f);                // Nyquist (real)
     } else {
       const float2 e = cscale(cadd(zk, zm), 0.5f);
       const float2 d = cscale(csub(zk, zm), 0.5f);
@@ -52,8 +55,8 @@ __global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x
 }
 
 template <int M, int T>
-__global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ spec, float* __restrict__ y, int nrows,
-                                                      const float2* __restrict__ twW, float scale) {
+__global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ spec, const float2* __restrict__ side,
+                                                      float* __restrict__ y, int nrows, const float2* __restrict__ twW, float scale) {
   constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
   __shared__ float2 lds[SPB * S];
   const int tid = threadIdx.x, seq = tid / T, t = tid % T;
@@ -72,7 +75,8 @@ __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ 
     const int k = t + m * T;
     const float2 xk = X[m];
     if (k == 0) {
-      v[m] = make_float2(xk.x + xk.y, xk.x - xk.y);
+      const float xn = side[live ? row : 0].x;      // DC and Nyquist bins of a real row are real: imaginary round-off dropped
+      v[m] = make_float2(xk.x + xn, xk.x - xn);
     } else {
       const float2 e = cadd(xk, xm);
       const float2 d = cmulc(csub(xk, xm), twW[k]);
@@ -91,7 +95,7 @@ __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ 
 // per-frequency operator (same semantics as dpx_fft.hip::spec_op)
 // ---------------------------------------------------------------------------------------------
 template <int OP>
-__device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, size_t tix, float rho_b) {
+__device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsigned tix, float rho_b) {
   if constexpr (OP == OP_MUL) {
     return cscale(cmul(z, A.otf[tix]), A.scale);
   } else if constexpr (OP == OP_MULCONJ) {
@@ -109,66 +113,68 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, size_t
 // columns
 // ---------------------------------------------------------------------------------------------
 template <int H, int T, int COLS, int OP>
-__global__ void __launch_bounds__(T* COLS) k_cols_p2(float2* __restrict__ spec, SpecArgs A, int C, int Ws,
-                                                      const float2* __restrict__ twH) {
+__global__ void __launch_bounds__(T* COLS) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
+                                                      int C, int Ws, int P, const float2* __restrict__ twH) {
   constexpr int V = H / T;
   constexpr int S0 = LdsSeq<H>::SLOTS;
   constexpr int S = S0 + ((36 - S0 % 32) % 32);     // S % 32 == 4: adjacent columns start 8 banks apart
   HIP_DYNAMIC_SHARED(float2, smem_p2)
   const int tid = threadIdx.x, c = tid % COLS, t = tid / COLS;
-  const int p = blockIdx.y, l0 = blockIdx.x * COLS;
-  const int ch = p % C, bi = p / C;
-  float2* base = spec + (size_t)p * H * Ws + l0 + c;
+  const int tiles = Ws / COLS, nmain = P * tiles;
+  const int bid = blockIdx.x;
+  // main tiles: COLS adjacent columns of plane p.  side tiles: the Nyquist columns of COLS consecutive planes.
+  const bool is_side = bid >= nmain;                  // block-uniform
+  // uniform (scalar) bases + 32-bit per-thread element offsets: one address VGPR per access
+  size_t ubase;                                       // element offset of the tile's plane / of the side array
+  unsigned off0, step, toff0, tbase;                  // data offset of row t, row step, table offset of row t, table base
+  int p;
+  if (!is_side) {
+    p = bid / tiles;
+    const int l = (bid - p * tiles) * COLS + c;
+    ubase = (size_t)p * H * Ws;
+    off0 = (unsigned)(t * Ws + l);
+    step = (unsigned)(T * Ws);
+    toff0 = off0;
+    tbase = (unsigned)(p % C) * H * Ws;
+  } else {
+    p = (bid - nmain) * COLS + c;
+    if (p >= P) p = P - 1;                            // (P not a multiple of COLS: duplicate work, identical values)
+    ubase = (size_t)P * H * Ws;
+    off0 = (unsigned)(p * H + t);
+    step = (unsigned)T;
+    toff0 = (unsigned)((p % C) * H + t);
+    tbase = (unsigned)C * H * Ws;
+  }
+  const int bi = p / C;
+  const char* pin = (const char*)(spec_in + ubase);
+  char* pout = (char*)(spec_out + ubase);
   float2* lds = smem_p2 + c * S;
   float2 v[V];
 #pragma unroll
-  for (int m = 0; m < V; ++m) v[m] = base[(size_t)(t + m * T) * Ws];
+  for (int m = 0; m < V; ++m) v[m] = *(const float2*)(pin + (off0 + step * m) * 8u);
   fft_reg<H, T, -1>(v, lds, t, twH, 1, BlockSync());
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
-  const size_t tmain = (size_t)ch * H * Ws + l0 + c;
-  if (OP == OP_SOLVE && A.add) {
-    const float2* add = A.add + (size_t)p * H * Ws + l0 + c;
+  const char* add = (OP == OP_SOLVE && A.add) ? (const char*)(A.add + ubase) : nullptr;
 #pragma unroll
-    for (int m = 0; m < V; ++m) v[m] = cadd(v[m], add[(size_t)(t + m * T) * Ws]);
-  }
-  if (l0 == 0) {
-    // column 0 carries DC + i*Nyquist of two real-valued columns: separate them through Z[k], Z[H-k]
-    __syncthreads();
-    if (c == 0) {
-#pragma unroll
-      for (int m = 0; m < V; ++m) lds[lds_slot(t + m * T)] = v[m];
-    }
-    __syncthreads();
-    if (c == 0) {
-      const size_t tside = (size_t)C * H * Ws + (size_t)ch * H;
-#pragma unroll
-      for (int m = 0; m < V; ++m) {
-        const int k = t + m * T, k2 = (H - k) % H;
-        const float2 zk = v[m], zm = cconj(lds[lds_slot(k2)]);
-        const float2 Ak = cscale(cadd(zk, zm), 0.5f);
-        const float2 d = cscale(csub(zk, zm), 0.5f);
-        const float2 Bk = make_float2(d.y, -d.x);
-        const float2 A1 = spec_op_p2<OP>(Ak, A, tmain + (size_t)k * Ws, rho_b);
-        const float2 B1 = spec_op_p2<OP>(Bk, A, tside + k, rho_b);
-        v[m] = make_float2(A1.x - B1.y, A1.y + B1.x);
-      }
-    } else {
-#pragma unroll
-      for (int m = 0; m < V; ++m) v[m] = spec_op_p2<OP>(v[m], A, tmain + (size_t)(t + m * T) * Ws, rho_b);
-    }
-  } else {
-#pragma unroll
-    for (int m = 0; m < V; ++m) v[m] = spec_op_p2<OP>(v[m], A, tmain + (size_t)(t + m * T) * Ws, rho_b);
+  for (int m = 0; m < V; ++m) {
+    float2 z = v[m];
+    if (add) z = cadd(z, *(const float2*)(add + (off0 + step * m) * 8u));
+    v[m] = spec_op_p2<OP>(z, A, tbase + toff0 + step * m, rho_b);
+    if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
   fft_reg<H, T, +1>(v, lds, t, twH, 1, BlockSync());
+  unsigned off1 = off0;
+  DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores
 #pragma unroll
-  for (int m = 0; m < V; ++m) base[(size_t)(t + m * T) * Ws] = v[m];
+  for (int m = 0; m < V; ++m) *(float2*)(pout + (off1 + step * m) * 8u) = v[m];
 }
 
 // ---------------------------------------------------------------------------------------------
 // host dispatch
 // ---------------------------------------------------------------------------------------------
+size_t pow2_spec_elems(int P, int H, int W) { return (size_t)P * H * (W / 2) + (size_t)P * H; }
+
 bool pow2_path_available(int H, int W) {
   const bool hok = (H == 256 || H == 512 || H == 1024);
   const bool wok = (W == 256 || W == 512 || W == 1024 || W == 2048);
@@ -179,10 +185,11 @@ template <int M, int T>
 static void launch_rows(bool fwd, const float* x, float2* spec, float* y, int nrows, const float2* twW, float scale, hipStream_t s) {
   constexpr int SPB = 256 / T;
   const dim3 grid((nrows + SPB - 1) / SPB);
+  float2* side = spec + (size_t)nrows * M;           // [P][H] Nyquist bins behind the main [P][H][W/2] array
   if (fwd)
-    DPX_LAUNCH("k_rows_r2c_p2", (k_rows_r2c_p2<M, T>), grid, dim3(256), 0, s, x, spec, nrows, twW);
+    DPX_LAUNCH("k_rows_r2c_p2", (k_rows_r2c_p2<M, T>), grid, dim3(256), 0, s, x, spec, side, nrows, twW);
   else
-    DPX_LAUNCH("k_rows_c2r_p2", (k_rows_c2r_p2<M, T>), grid, dim3(256), 0, s, (const float2*)spec, y, nrows, twW, scale);
+    DPX_LAUNCH("k_rows_c2r_p2", (k_rows_c2r_p2<M, T>), grid, dim3(256), 0, s, (const float2*)spec, (const float2*)side, y, nrows, twW, scale);
 }
 
 static void rows_dispatch(bool fwd, int W, const float* x, float2* spec, float* y, int nrows, const float2* twW, float scale, hipStream_t s) {
@@ -195,7 +202,7 @@ static void rows_dispatch(bool fwd, int W, const float* x, float2* spec, float* 
 }
 
 template <int H, int T, int COLS, int OP>
-static void launch_cols(float2* spec, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
+static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
   constexpr int S0 = LdsSeq<H>::SLOTS;
   constexpr int S = S0 + ((36 - S0 % 32) % 32);
   const size_t sh = (size_t)COLS * S * sizeof(float2);
@@ -204,15 +211,16 @@ static void launch_cols(float2* spec, const SpecArgs& A, int P, int C, int Ws, c
     hipFuncSetAttribute((const void*)k_cols_p2<H, T, COLS, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr_done = true;
   }
-  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP>), dim3(Ws / COLS, P), dim3(T * COLS), sh, s, spec, A, C, Ws, twH);
+  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP>), dim3(P * (Ws / COLS) + (P + COLS - 1) / COLS), dim3(T * COLS), sh, s, spec,
+             spec_out, A, C, Ws, P, twH);
 }
 
 template <int OP>
-static void cols_dispatch(int H, float2* spec, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
+static void cols_dispatch(int H, const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
   switch (H) {
-    case 256: launch_cols<256, 32, 8, OP>(spec, A, P, C, Ws, twH, s); break;
-    case 512: launch_cols<512, 64, 8, OP>(spec, A, P, C, Ws, twH, s); break;
-    default: launch_cols<1024, 64, 8, OP>(spec, A, P, C, Ws, twH, s); break;
+    case 256: launch_cols<256, 32, 8, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 512: launch_cols<512, 64, 8, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    default: launch_cols<1024, 64, 8, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
   }
 }
 
@@ -220,13 +228,14 @@ int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& A, int
                         const void* table, void* ws, hipStream_t stream) {
   const int P = B * C, Ws = W / 2;
   float2* spec = (float2*)ws;
+  float2* spec2 = spec + pow2_spec_elems(P, H, W);     // the column pass is out of place
   rows_dispatch(true, W, x, spec, nullptr, P * H, tw_rows(table), 1.0f, stream);
   switch (op) {
-    case OP_MUL: cols_dispatch<OP_MUL>(H, spec, A, P, C, Ws, tw_cols(table, W), stream); break;
-    case OP_MULCONJ: cols_dispatch<OP_MULCONJ>(H, spec, A, P, C, Ws, tw_cols(table, W), stream); break;
-    default: cols_dispatch<OP_SOLVE>(H, spec, A, P, C, Ws, tw_cols(table, W), stream); break;
+    case OP_MUL: cols_dispatch<OP_MUL>(H, spec, spec2, A, P, C, Ws, tw_cols(table, W), stream); break;
+    case OP_MULCONJ: cols_dispatch<OP_MULCONJ>(H, spec, spec2, A, P, C, Ws, tw_cols(table, W), stream); break;
+    default: cols_dispatch<OP_SOLVE>(H, spec, spec2, A, P, C, Ws, tw_cols(table, W), stream); break;
   }
-  rows_dispatch(false, W, nullptr, spec, y, P * H, tw_rows(table), 1.0f, stream);
+  rows_dispatch(false, W, nullptr, spec2, y, P * H, tw_rows(table), 1.0f, stream);
   return launch_status("spectral_apply_pow2");
 }
 

@@ -85,6 +85,7 @@ template <int DIR> __device__ __forceinline__ float2 twmul(float2 a, float2 w) {
 template <int N, int T, int DIR, class Sync>
 __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__ lds, int t, const float2* __restrict__ tw,
                                         int tws, Sync sync) {
+  DPX_OPAQUE(t);      // every call re-derives its few index registers instead of keeping all of them alive
   constexpr int V = N / T;
   constexpr int RM = N / (V * V);
   static_assert(V * V * RM == N && (RM == 1 || RM == 2 || RM == 4 || RM == 8), "unsupported N/T split");
@@ -120,11 +121,16 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
     }
     sync();
   }
-  // pass C: radix V, Ns = N/V = T
+  // pass C: radix V, Ns = N/V = T.  Twiddles W_N^{t*m} are exact table values; they are applied in groups
+  // of four so that at most four of them are live at a time (register pressure at V = 16).
 #pragma unroll
   for (int m = 0; m < V; ++m) v[m] = lds[lds_slot(t + m * T)];
+  const unsigned tstep = (unsigned)(t * tws);
 #pragma unroll
-  for (int m = 1; m < V; ++m) v[m] = twmul<DIR>(v[m], tw[(t * m) * tws]);
+  for (int m = 1; m < V; ++m) {
+    v[m] = twmul<DIR>(v[m], tw[tstep * (unsigned)m]);
+    if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
   rdft<V, DIR>(v);
 }
 

@@ -147,7 +147,7 @@ def data_spectrum(b, otf=None, conj=True, out=None, accumulate=False):
     B, C, H, W = _shape4(b)
     L = be.lib()
     if out is None:
-        out = _bytes(L.query("dpx_spectrum_bytes", B * C, H, W), b.device)
+        out = _bytes(L.query("dpx_spectrum_bytes", B * C, H, W) // 2, b.device)
         accumulate = False
     ws = workspace("data_spectrum", L.query("dpx_data_spectrum_ws_bytes", B * C, H, W), b.device)
     L.call("dpx_data_spectrum", ptr(b), ptr(otf), int(bool(conj)), ptr(out), int(bool(accumulate)), B, C, H, W, ptr(ws), be.stream())

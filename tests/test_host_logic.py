@@ -24,8 +24,8 @@ def test_c_abi_exports_every_declared_symbol():
     lib = be.Library(be.LIB_PATH)          # AttributeError if a symbol is missing
     assert lib.query("dpx_version") >= 100
     assert lib.query("dpx_fft_table_bytes", 1024, 1024) == 2048 * 8
-    assert lib.query("dpx_spectrum_bytes", 24, 1024, 1024) == 24 * 1024 * 512 * 8      # packed half spectrum = input bytes
-    assert lib.query("dpx_spectrum_bytes", 1, 15, 21) == 15 * 11 * 8
+    assert lib.query("dpx_spectrum_bytes", 24, 1024, 1024) == 2 * (24 * 1024 * 512 + 24 * 1024) * 8  # 2 x (half spectrum + Nyquist side)
+    assert lib.query("dpx_spectrum_bytes", 1, 15, 21) == 2 * 15 * 11 * 8
 
 
 def test_to_torch_tensor_and_ndarray():
