@@ -67,9 +67,17 @@ Plan1D make_plan(int n);
 // is packed into the imaginary part of column 0 (both are real-valued after the row transform).
 static inline int spec_cols(int W) { return (W + 1) / 2; }
 
-// ---- spectral tables ---------------------------------------------------------------------------
-// layout of a real or complex table: main [C][H][Ws] then side [C][H] (values on the Nyquist column
-// l = W/2, only meaningful for even W).
+// ---- spectral layouts --------------------------------------------------------------------------
+// A half spectrum / spectral table of one plane has a main part of H x Ws entries and (even W) a side
+// part of H entries for the Nyquist column l = W/2.  Generic sizes: main is row-major [H][Ws] and the
+// transform packs the Nyquist bins into the imaginary part of column 0.  Power-of-two planes: main is
+// COLUMN-TILE-MAJOR, [Ws/8][H][8] -- each 8-column tile is contiguous, so every stream of the column
+// kernel is a linear 512-byte-per-wave-instruction access -- and the Nyquist bins live in the side part.
+bool pow2_path_available(int H, int W);
+__host__ __device__ __forceinline__ size_t spec_main_index(int tiled, int H, int Ws, int k, int l) {
+  return tiled ? ((size_t)(l >> 3) * H + k) * 8 + (l & 7) : (size_t)k * Ws + l;
+}
+// table = all planes' main parts [C][H*Ws] followed by all side parts [C][H]
 static inline size_t table_elems(int C, int H, int W) { return (size_t)C * H * spec_cols(W) + (size_t)C * H; }
 
 // twiddle table: float2[W] (e^{-2 pi i t / W}) followed by float2[H]
@@ -80,11 +88,10 @@ static inline const float2* tw_cols(const void* table, int W) { return (const fl
 enum SpecOp { OP_MUL = 0, OP_MULCONJ = 1, OP_SOLVE = 2 };
 struct SpecArgs {
   const float2* otf;   // OP_MUL / OP_MULCONJ
-  const float* d0;     // OP_SOLVE (nullable)
-  const float* d1;     // OP_SOLVE (nullable)
+  const float2* dd;    // OP_SOLVE: interleaved denominators (d0 + c0, d1 + c1); den = dd.x + rho_b * dd.y + eps
   const float* rho;    // OP_SOLVE device [B]
-  const float2* add;   // OP_SOLVE (nullable): per-plane spectrum added before the division
-  float c0, c1, eps;
+  const float2* add;   // OP_SOLVE (nullable): per-plane data spectrum added before the division
+  float eps;
   float scale;         // 1/(H*W)
 };
 

@@ -330,9 +330,8 @@ __device__ __forceinline__ float2 spec_op(float2 z, const SpecArgs& A, size_t ti
   } else if constexpr (OP == OP_MULCONJ) {
     return cscale(cmulc(z, A.otf[tix]), A.scale);
   } else {
-    const float d0 = (A.d0 ? A.d0[tix] : 0.f) + A.c0;
-    const float d1 = (A.d1 ? A.d1[tix] : 0.f) + A.c1;
-    const float den = fmaf(rho_b, d1, d0) + A.eps;
+    const float2 dd = A.dd[tix];
+    const float den = fmaf(rho_b, dd.y, dd.x) + A.eps;
     const float inv = A.scale / den;
     return make_float2((z.x + A.eps) * inv, z.y * inv);
   }
@@ -450,7 +449,7 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
   for (int k = tid; k < H; k += nthr) {
     double2 v = z[k];
     if (otf) {
-      const float2 t = otf[tmain + (size_t)k * Ws + l];
+      const float2 t = otf[tmain + spec_main_index(side_layout, H, Ws, k, l)];
       const double tr = t.x, ti = conj_otf ? -(double)t.y : (double)t.y;
       v = make_double2(v.x * tr - v.y * ti, v.x * ti + v.y * tr);
     }
@@ -473,7 +472,7 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
         v = make_double2(v.x - n.y, v.y + n.x);        // packed: A + i B
       }
     }
-    float2* dst = o + (size_t)k * Ws + l;
+    float2* dst = o + spec_main_index(side_layout, H, Ws, k, l);
     if (accumulate) {
       const float2 old = *dst;
       *dst = make_float2((float)((double)old.x + v.x), (float)((double)old.y + v.y));
@@ -486,7 +485,6 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-bool pow2_path_available(int H, int W);
 size_t pow2_spec_elems(int P, int H, int W);
 int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& a, int B, int C, int H, int W,
                         const void* table, void* ws, hipStream_t stream);
@@ -596,18 +594,14 @@ extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, 
   return launch_status("dpx_data_spectrum");
 }
 
-extern "C" int dpx_fourier_solve(const float* rhs, float* x, const void* spec_add, const void* d0, const void* d1, float c0,
-                                 float c1, const float* rho, float eps, int B, int C, int H, int W, const void* table,
-                                 void* ws, dpx_stream_t stream) {
-  DPX_REQUIRE(rhs && x && table && ws && rho, "dpx_fourier_solve: null pointer");
+extern "C" int dpx_fourier_solve(const float* rhs, float* x, const void* spec_add, const void* dd, const float* rho, float eps,
+                                 int B, int C, int H, int W, const void* table, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(rhs && x && table && ws && rho && dd, "dpx_fourier_solve: null pointer");
   DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_fourier_solve: bad shape");
   SpecArgs a{};
   a.add = (const float2*)spec_add;
-  a.d0 = (const float*)d0;
-  a.d1 = (const float*)d1;
+  a.dd = (const float2*)dd;
   a.rho = rho;
-  a.c0 = c0;
-  a.c1 = c1;
   a.eps = eps;
   a.scale = 1.0f / ((float)H * (float)W);
   return spectral_apply(rhs, x, OP_SOLVE, a, B, C, H, W, table, ws, (hipStream_t)stream);

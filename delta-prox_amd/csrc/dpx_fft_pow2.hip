@@ -13,6 +13,8 @@
 // transform.
 #include "dpx_fft_reg.h"
 
+#include <cstdlib>
+
 namespace dpx {
 
 // ---------------------------------------------------------------------------------------------
@@ -20,7 +22,7 @@ namespace dpx {
 // ---------------------------------------------------------------------------------------------
 template <int M, int T>
 __global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x, float2* __restrict__ spec, float2* __restrict__ side,
-                                                      int nrows, const float2* __restrict__ twW) {
+                                                      int nrows, int H, const float2* __restrict__ twW) {
   constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
   __shared__ float2 lds[SPB * S];
   const int tid = threadIdx.x, seq = tid / T, t = tid % T;
@@ -34,7 +36,9 @@ __global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x
   // real-input untangling: X[k] = E[k] + w^k O[k], E = (Z[k] + conj Z[M-k])/2, O = -i (Z[k] - conj Z[M-k])/2
   const int lane = tid & 63;
   const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
-  float2* out = spec + (size_t)(live ? row : 0) * M;
+  // column-tile-major spectrum: bin k of image row h of plane pl -> pl*H*M + ((k >> 3)*H + h)*8 + (k & 7)
+  const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H;
+  float2* out = spec + (size_t)pl * H * M + (size_t)hh * 8 + (t & 7) + (size_t)(t >> 3) * H * 8;
 #pragma unroll
   for (int m = 0; m < V; ++m) {
     const float2 got = make_float2(__shfl(v[V - 1 - m].x, plane), __shfl(v[V - 1 - m].y, plane));
@@ -50,22 +54,23 @@ __global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x
       const float2 d = cscale(csub(zk, zm), 0.5f);
       X = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
     }
-    if (live) out[k] = X;
+    if (live) out[(size_t)m * (T / 8) * H * 8] = X;     // k = t + m*T: tile index advances by T/8 per m
   }
 }
 
 template <int M, int T>
 __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ spec, const float2* __restrict__ side,
-                                                      float* __restrict__ y, int nrows, const float2* __restrict__ twW, float scale) {
+                                                      float* __restrict__ y, int nrows, int H, const float2* __restrict__ twW, float scale) {
   constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
   __shared__ float2 lds[SPB * S];
   const int tid = threadIdx.x, seq = tid / T, t = tid % T;
   const int row = blockIdx.x * SPB + seq;
   const bool live = row < nrows;
-  const float2* in = spec + (size_t)(live ? row : 0) * M;
+  const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H;
+  const float2* in = spec + (size_t)pl * H * M + (size_t)hh * 8 + (t & 7) + (size_t)(t >> 3) * H * 8;
   float2 X[V], v[V];
 #pragma unroll
-  for (int m = 0; m < V; ++m) X[m] = in[t + m * T];
+  for (int m = 0; m < V; ++m) X[m] = in[(size_t)m * (T / 8) * H * 8];
   const int lane = tid & 63;
   const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
 #pragma unroll
@@ -101,9 +106,8 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
   } else if constexpr (OP == OP_MULCONJ) {
     return cscale(cmulc(z, A.otf[tix]), A.scale);
   } else {
-    const float d0 = (A.d0 ? A.d0[tix] : 0.f) + A.c0;
-    const float d1 = (A.d1 ? A.d1[tix] : 0.f) + A.c1;
-    const float den = fmaf(rho_b, d1, d0) + A.eps;
+    const float2 dd = A.dd[tix];
+    const float den = fmaf(rho_b, dd.y, dd.x) + A.eps;
     const float inv = A.scale / den;
     return make_float2((z.x + A.eps) * inv, z.y * inv);
   }
@@ -112,7 +116,8 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
 // ---------------------------------------------------------------------------------------------
 // columns
 // ---------------------------------------------------------------------------------------------
-template <int H, int T, int COLS, int OP>
+// DBG (tuning experiments only, default 0): bit0 = skip both transforms, bit1 = skip the operator's table loads
+template <int H, int T, int COLS, int OP, int DBG = 0>
 __global__ void __launch_bounds__(T* COLS) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
                                                       int C, int Ws, int P, const float2* __restrict__ twH) {
   constexpr int V = H / T;
@@ -130,12 +135,12 @@ __global__ void __launch_bounds__(T* COLS) k_cols_p2(const float2* __restrict__ 
   int p;
   if (!is_side) {
     p = bid / tiles;
-    const int l = (bid - p * tiles) * COLS + c;
-    ubase = (size_t)p * H * Ws;
-    off0 = (unsigned)(t * Ws + l);
-    step = (unsigned)(T * Ws);
+    const int j = (bid - p * tiles) * (COLS / 8);     // first 8-column tile of this workgroup
+    ubase = (size_t)p * H * Ws + (size_t)j * H * 8;   // tile-major main part: element (row r, col c) of a tile at r*8 + c
+    off0 = (unsigned)((c >> 3) * H * 8 + t * 8 + (c & 7));
+    step = (unsigned)(T * 8);
     toff0 = off0;
-    tbase = (unsigned)(p % C) * H * Ws;
+    tbase = (unsigned)((p % C) * H * Ws + j * H * 8);
   } else {
     p = (bid - nmain) * COLS + c;
     if (p >= P) p = P - 1;                            // (P not a multiple of COLS: duplicate work, identical values)
@@ -152,18 +157,19 @@ __global__ void __launch_bounds__(T* COLS) k_cols_p2(const float2* __restrict__ 
   float2 v[V];
 #pragma unroll
   for (int m = 0; m < V; ++m) v[m] = *(const float2*)(pin + (off0 + step * m) * 8u);
-  fft_reg<H, T, -1>(v, lds, t, twH, 1, BlockSync());
+  if (!(DBG & 1)) fft_reg<H, T, -1>(v, lds, t, twH, 1, BlockSync());
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const char* add = (OP == OP_SOLVE && A.add) ? (const char*)(A.add + ubase) : nullptr;
 #pragma unroll
   for (int m = 0; m < V; ++m) {
     float2 z = v[m];
     if (add) z = cadd(z, *(const float2*)(add + (off0 + step * m) * 8u));
-    v[m] = spec_op_p2<OP>(z, A, tbase + toff0 + step * m, rho_b);
+    if (DBG & 2) v[m] = cscale(z, A.scale);
+    else v[m] = spec_op_p2<OP>(z, A, tbase + toff0 + step * m, rho_b);
     if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
-  fft_reg<H, T, +1>(v, lds, t, twH, 1, BlockSync());
+  if (!(DBG & 1)) fft_reg<H, T, +1>(v, lds, t, twH, 1, BlockSync());
   unsigned off1 = off0;
   DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores
 #pragma unroll
@@ -182,41 +188,61 @@ bool pow2_path_available(int H, int W) {
 }
 
 template <int M, int T>
-static void launch_rows(bool fwd, const float* x, float2* spec, float* y, int nrows, const float2* twW, float scale, hipStream_t s) {
+static void launch_rows(bool fwd, const float* x, float2* spec, float* y, int nrows, int H, const float2* twW, float scale, hipStream_t s) {
   constexpr int SPB = 256 / T;
   const dim3 grid((nrows + SPB - 1) / SPB);
   float2* side = spec + (size_t)nrows * M;           // [P][H] Nyquist bins behind the main [P][H][W/2] array
   if (fwd)
-    DPX_LAUNCH("k_rows_r2c_p2", (k_rows_r2c_p2<M, T>), grid, dim3(256), 0, s, x, spec, side, nrows, twW);
+    DPX_LAUNCH("k_rows_r2c_p2", (k_rows_r2c_p2<M, T>), grid, dim3(256), 0, s, x, spec, side, nrows, H, twW);
   else
-    DPX_LAUNCH("k_rows_c2r_p2", (k_rows_c2r_p2<M, T>), grid, dim3(256), 0, s, (const float2*)spec, (const float2*)side, y, nrows, twW, scale);
+    DPX_LAUNCH("k_rows_c2r_p2", (k_rows_c2r_p2<M, T>), grid, dim3(256), 0, s, (const float2*)spec, (const float2*)side, y, nrows, H, twW, scale);
 }
 
-static void rows_dispatch(bool fwd, int W, const float* x, float2* spec, float* y, int nrows, const float2* twW, float scale, hipStream_t s) {
+static void rows_dispatch(bool fwd, int W, int H, const float* x, float2* spec, float* y, int nrows, const float2* twW, float scale, hipStream_t s) {
   switch (W) {
-    case 256: launch_rows<128, 16>(fwd, x, spec, y, nrows, twW, scale, s); break;
-    case 512: launch_rows<256, 32>(fwd, x, spec, y, nrows, twW, scale, s); break;
-    case 1024: launch_rows<512, 64>(fwd, x, spec, y, nrows, twW, scale, s); break;
-    default: launch_rows<1024, 64>(fwd, x, spec, y, nrows, twW, scale, s); break;
+    case 256: launch_rows<128, 16>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
+    case 512: launch_rows<256, 32>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
+    case 1024: launch_rows<512, 64>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
+    default: launch_rows<1024, 64>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
   }
 }
 
-template <int H, int T, int COLS, int OP>
+template <int H, int T, int COLS, int OP, int DBG = 0>
 static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
   constexpr int S0 = LdsSeq<H>::SLOTS;
   constexpr int S = S0 + ((36 - S0 % 32) % 32);
   const size_t sh = (size_t)COLS * S * sizeof(float2);
   static bool attr_done = false;
   if (!attr_done && sh > 48 * 1024) {
-    hipFuncSetAttribute((const void*)k_cols_p2<H, T, COLS, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipFuncSetAttribute((const void*)k_cols_p2<H, T, COLS, OP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr_done = true;
   }
-  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP>), dim3(P * (Ws / COLS) + (P + COLS - 1) / COLS), dim3(T * COLS), sh, s, spec,
+  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP, DBG>), dim3(P * (Ws / COLS) + (P + COLS - 1) / COLS), dim3(T * COLS), sh, s, spec,
              spec_out, A, C, Ws, P, twH);
+}
+
+static int cols_per_tile() {           // tuning knob (default 8): DPX_COLS=16 selects 16-column tiles for H = 1024
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DPX_COLS");
+    v = (e && atoi(e) == 16) ? 16 : 8;
+  }
+  return v;
 }
 
 template <int OP>
 static void cols_dispatch(int H, const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
+  if (H == 1024 && cols_per_tile() == 16) {
+    launch_cols<1024, 64, 16, OP>(spec, spec_out, A, P, C, Ws, twH, s);
+    return;
+  }
+  if (H == 1024 && OP == OP_SOLVE) {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("DPX_DEBUG_COLS"); dbg = e ? atoi(e) : 0; }
+    if (dbg == 1) { launch_cols<1024, 64, 8, OP, 1>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 2) { launch_cols<1024, 64, 8, OP, 2>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 3) { launch_cols<1024, 64, 8, OP, 3>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+  }
   switch (H) {
     case 256: launch_cols<256, 32, 8, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
     case 512: launch_cols<512, 64, 8, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
@@ -229,13 +255,13 @@ int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& A, int
   const int P = B * C, Ws = W / 2;
   float2* spec = (float2*)ws;
   float2* spec2 = spec + pow2_spec_elems(P, H, W);     // the column pass is out of place
-  rows_dispatch(true, W, x, spec, nullptr, P * H, tw_rows(table), 1.0f, stream);
+  rows_dispatch(true, W, H, x, spec, nullptr, P * H, tw_rows(table), 1.0f, stream);
   switch (op) {
     case OP_MUL: cols_dispatch<OP_MUL>(H, spec, spec2, A, P, C, Ws, tw_cols(table, W), stream); break;
     case OP_MULCONJ: cols_dispatch<OP_MULCONJ>(H, spec, spec2, A, P, C, Ws, tw_cols(table, W), stream); break;
     default: cols_dispatch<OP_SOLVE>(H, spec, spec2, A, P, C, Ws, tw_cols(table, W), stream); break;
   }
-  rows_dispatch(false, W, nullptr, spec2, y, P * H, tw_rows(table), 1.0f, stream);
+  rows_dispatch(false, W, H, nullptr, spec2, y, P * H, tw_rows(table), 1.0f, stream);
   return launch_status("spectral_apply_pow2");
 }
 

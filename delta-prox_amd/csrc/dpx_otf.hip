@@ -12,7 +12,7 @@
 namespace dpx {
 
 __global__ void k_psf2otf(const double* __restrict__ psf, int kh, int kw, int kc, int C, int H, int W,
-                          float2* __restrict__ otf, float* __restrict__ diag, float weight, int accumulate) {
+                          float2* __restrict__ otf, float* __restrict__ diag, float weight, int accumulate, int tiled) {
   const int Ws = (W + 1) / 2;
   const bool even = (W % 2 == 0);
   const long nmain = (long)C * H * Ws, nside = (long)C * H;
@@ -62,17 +62,79 @@ __global__ void k_psf2otf(const double* __restrict__ psf, int kh, int kw, int kc
       hr += sr * cc;
       hi += si * cc;
     }
-    if (otf) otf[idx] = make_float2((float)hr, (float)hi);
+    const size_t pos = idx < nmain ? (size_t)c * H * Ws + spec_main_index(tiled, H, Ws, k, l) : (size_t)idx;
+    if (otf) otf[pos] = make_float2((float)hr, (float)hi);
     if (diag) {
       const double d = (double)weight * (fr * fr + fi * fi);
-      diag[idx] = accumulate ? (float)((double)diag[idx] + d) : (float)d;
+      diag[pos] = accumulate ? (float)((double)diag[pos] + d) : (float)d;
     }
   }
+}
+
+// real table <-> full [C][H][W] array (Hermitian-symmetric extension: T(-k,-l) = T(k,l))
+__global__ void k_table_to_full(const float* __restrict__ tab, float* __restrict__ full, int C, int H, int W, int tiled) {
+  const int Ws = (W + 1) / 2;
+  const long total = (long)C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int l0 = (int)(i % W);
+    const long r = i / W;
+    const int k0 = (int)(r % H), c = (int)(r / H);
+    int k = k0, l = l0;
+    if (2 * l0 > W) { l = W - l0; k = (H - k0) % H; }
+    float v;
+    if (W % 2 == 0 && l == W / 2) v = tab[(size_t)C * H * Ws + (size_t)c * H + k];
+    else v = tab[(size_t)c * H * Ws + spec_main_index(tiled, H, Ws, k, l)];
+    full[i] = v;
+  }
+}
+__global__ void k_table_from_full(const float* __restrict__ full, float* __restrict__ tab, int C, int H, int W, int tiled) {
+  const int Ws = (W + 1) / 2;
+  const long nmain = (long)C * H * Ws, total = nmain + ((W % 2 == 0) ? (long)C * H : 0);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i < nmain) {
+      const int l = (int)(i % Ws);
+      const long r = i / Ws;
+      const int k = (int)(r % H), c = (int)(r / H);
+      tab[(size_t)c * H * Ws + spec_main_index(tiled, H, Ws, k, l)] = full[((size_t)c * H + k) * W + l];
+    } else {
+      const long r = i - nmain;
+      const int k = (int)(r % H), c = (int)(r / H);
+      tab[i] = full[((size_t)c * H + k) * W + W / 2];
+    }
+  }
+}
+// dd = (d0 + c0, d1 + c1) interleaved; element order is irrelevant (same opaque layout in and out)
+__global__ void k_denominator_pack(const float* __restrict__ d0, float c0, const float* __restrict__ d1, float c1,
+                                   float2* __restrict__ dd, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dd[i] = make_float2((d0 ? d0[i] : 0.f) + c0, (d1 ? d1[i] : 0.f) + c1);
 }
 
 }  // namespace dpx
 
 using namespace dpx;
+
+extern "C" int dpx_table_to_full(const void* table, float* full, int C, int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(table && full && C > 0 && H > 0 && W > 0, "dpx_table_to_full: bad arguments");
+  DPX_LAUNCH("k_table_to_full", k_table_to_full, dim3(grid_for((long)C * H * W, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+             (const float*)table, full, C, H, W, pow2_path_available(H, W) ? 1 : 0);
+  return launch_status("dpx_table_to_full");
+}
+extern "C" int dpx_table_from_full(const float* full, void* table, int C, int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(table && full && C > 0 && H > 0 && W > 0, "dpx_table_from_full: bad arguments");
+  DPX_LAUNCH("k_table_from_full", k_table_from_full, dim3(grid_for((long)table_elems(C, H, W), 256, 4096)), dim3(256), 0,
+             (hipStream_t)stream, full, (float*)table, C, H, W, pow2_path_available(H, W) ? 1 : 0);
+  return launch_status("dpx_table_from_full");
+}
+extern "C" size_t dpx_denominator_bytes(int C, int H, int W) { return table_elems(C, H, W) * sizeof(float2); }
+extern "C" int dpx_denominator_pack(const void* d0, float c0, const void* d1, float c1, void* dd, int C, int H, int W,
+                                    dpx_stream_t stream) {
+  DPX_REQUIRE(dd && C > 0 && H > 0 && W > 0, "dpx_denominator_pack: bad arguments");
+  const long n = (long)table_elems(C, H, W);
+  DPX_LAUNCH("k_denominator_pack", k_denominator_pack, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+             (const float*)d0, c0, (const float*)d1, c1, (float2*)dd, n);
+  return launch_status("dpx_denominator_pack");
+}
 
 extern "C" size_t dpx_otf_bytes(int C, int H, int W) { return table_elems(C, H, W) * sizeof(float2); }
 extern "C" size_t dpx_diag_bytes(int C, int H, int W) { return table_elems(C, H, W) * sizeof(float); }
@@ -85,6 +147,6 @@ extern "C" int dpx_psf2otf(const double* psf, int kh, int kw, int kc, int C, int
               H, W, C, kh, kw, kc);   // psf2otf.py:53-54
   const long total = (long)table_elems(C, H, W);
   DPX_LAUNCH("k_psf2otf", k_psf2otf, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, psf, kh, kw, kc, C, H,
-                     W, (float2*)otf, (float*)diag, weight, accumulate);
+                     W, (float2*)otf, (float*)diag, weight, accumulate, pow2_path_available(H, W) ? 1 : 0);
   return launch_status("dpx_psf2otf");
 }

@@ -46,7 +46,11 @@ SIGNATURES = {
     "dpx_fft_conv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpx_data_spectrum_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_data_spectrum": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "dpx_fourier_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_float,
+    "dpx_table_to_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dpx_table_from_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dpx_denominator_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpx_denominator_pack": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dpx_fourier_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpx_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_lincomb": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_float), POINTER(c_void_p), c_int, c_long, c_void_p]),

@@ -53,6 +53,7 @@ def spectrum_ws(P, H, W, device):
 def clear_caches():
     _tables.clear()
     _workspaces.clear()
+    _dd_cache.clear()
 
 
 def _shape4(x):
@@ -113,20 +114,37 @@ def accumulate_diag(diag, psf, weight, C, H, W):
 
 
 def diag_to_full(diag, C, H, W):
-    """expand an opaque diag table to the full [1,C,H,W] |OTF|^2 array (host/numpy convenience, setup-time only)."""
-    Ws = (W + 1) // 2
-    d = diag.detach().cpu().numpy()
-    main = d[:C * H * Ws].reshape(C, H, Ws)
-    full = np.zeros((C, H, W), np.float32)
-    full[:, :, :Ws] = main
-    if W % 2 == 0:
-        full[:, :, W // 2] = d[C * H * Ws:C * H * Ws + C * H].reshape(C, H)
-    for l in range(Ws, W):
-        if W % 2 == 0 and l == W // 2:
-            continue
-        src = W - l
-        full[:, :, l] = np.roll(full[:, ::-1, src], 1, axis=1)     # |F(-k,-l)| = |F(k,l)| for real kernels
-    return torch.from_numpy(full[None])
+    """opaque diag table -> full [1,C,H,W] |OTF|^2 array on the table's device (setup-time interop)"""
+    full = torch.empty(1, C, H, W, dtype=torch.float32, device=diag.device)
+    be.lib().call("dpx_table_to_full", ptr(diag), ptr(full), C, H, W, be.stream())
+    return full
+
+
+def diag_from_full(full, C, H, W, device):
+    """full-spectrum real diagonal [.., C, H, W] -> opaque table (user-supplied BlackBox diagonals)"""
+    f = torch.as_tensor(full).real.float().reshape(-1, C, H, W)[0].contiguous().to(device)
+    tab = new_diag(C, H, W, device)
+    be.lib().call("dpx_table_from_full", ptr(f), ptr(tab), C, H, W, be.stream())
+    return tab
+
+
+_dd_cache = {}
+
+
+def denominator(d0, c0, d1, c1, C, H, W, device):
+    """interleaved (d0 + c0, d1 + c1) table for fourier_solve; cached on the identity of its inputs"""
+    key = (None if d0 is None else (d0.data_ptr(), d0._version), float(c0), None if d1 is None else (d1.data_ptr(), d1._version),
+           float(c1), C, H, W, str(device))
+    hit = _dd_cache.get(key)
+    if hit is None:
+        L = be.lib()
+        dd = _bytes(L.query("dpx_denominator_bytes", C, H, W), device)
+        L.call("dpx_denominator_pack", ptr(d0), c_float(c0), ptr(d1), c_float(c1), ptr(dd), C, H, W, be.stream())
+        if len(_dd_cache) > 64:
+            _dd_cache.clear()
+        hit = (dd, d0, d1)            # keep the sources alive so data_ptr keys stay unique
+        _dd_cache[key] = hit
+    return hit[0]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -159,7 +177,8 @@ def fourier_solve(rhs, d0, d1, c0, c1, rho, eps=EPS, out=None, spec_add=None):
     B, C, H, W = _shape4(rhs)
     rho = as_batch_vec(rho, B, rhs.device)
     x = torch.empty_like(rhs) if out is None else out
-    be.lib().call("dpx_fourier_solve", ptr(rhs), ptr(x), ptr(spec_add), ptr(d0), ptr(d1), c_float(c0), c_float(c1), ptr(rho),
+    dd = denominator(d0, c0, d1, c1, C, H, W, rhs.device)
+    be.lib().call("dpx_fourier_solve", ptr(rhs), ptr(x), ptr(spec_add), ptr(dd), ptr(rho),
                   c_float(eps), B, C, H, W, ptr(fft_table(H, W, rhs.device)),
                   ptr(spectrum_ws(B * C, H, W, rhs.device)), be.stream())
     return x

@@ -70,15 +70,6 @@ class ext_sum_squares(sum_squares):
 # ------------------------------------------------------------------------------------------------
 # Gram diagonals:  (opaque half-spectrum table | None, constant)
 # ------------------------------------------------------------------------------------------------
-def _full_to_table(full, C, H, W, device):
-    """[1|B, C, H, W] real full-spectrum diagonal -> opaque half-spectrum table"""
-    Ws = (W + 1) // 2
-    f = torch.as_tensor(full).real.float().reshape(-1, C, H, W)[0]
-    main = f[:, :, :Ws].reshape(-1)
-    side = f[:, :, W // 2].reshape(-1) if W % 2 == 0 else torch.zeros(C * H)
-    return torch.cat([main, side]).to(device).contiguous()
-
-
 def _gram_diag(linop, shape, device, freq):
     if isinstance(linop, Variable):
         return None, 1.0
@@ -100,7 +91,7 @@ def _gram_diag(linop, shape, device, freq):
     if not freq:
         return ("spatial", torch.as_tensor(d).float().to(device)), 0.0
     _, C, H, W = shape
-    return _full_to_table(d, C, H, W, device), 0.0
+    return ops.diag_from_full(d, C, H, W, device), 0.0
 
 
 class least_squares(ProxFn):

@@ -82,13 +82,24 @@ size_t dpx_data_spectrum_ws_bytes(int P, int H, int W);
 int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, void* spec_out, int accumulate,
                       int B, int C, int H, int W, void* ws, dpx_stream_t stream);
 
-/* x = real(ifft2((fft2(rhs) + spec_add + eps) / (d0 + c0 + rho_b*(d1 + c1) + eps)))
- * least_squares.solve_direct, frequency branch -- proxfn/sum_square.py:137-152.
+/* spectral table helpers (setup time).  Tables use an opaque per-(H,W) layout:
+ *   dpx_table_to_full / from_full : real diag table <-> full [C][H][W] array (get_diag interop, linop/conv.py:46-53,
+ *                                    user-supplied diagonals of BlackBox operators, linop/blackbox.py:74-75)
+ *   dpx_denominator_pack          : dd = interleaved (d0 + c0, d1 + c1) for dpx_fourier_solve               */
+int dpx_table_to_full(const void* table, float* full, int C, int H, int W, dpx_stream_t stream);
+int dpx_table_from_full(const float* full, void* table, int C, int H, int W, dpx_stream_t stream);
+size_t dpx_denominator_bytes(int C, int H, int W);
+int dpx_denominator_pack(const void* d0, float c0, const void* d1, float c1, void* dd, int C, int H, int W,
+                         dpx_stream_t stream);
+
+/* x = real(ifft2((fft2(rhs) + spec_add + eps) / (dd.x + rho_b*dd.y + eps)))
+ * least_squares.solve_direct, frequency branch -- proxfn/sum_square.py:137-152, with
+ *   dd.x = sum over Omega of |OTF|^2 (+ constant diagonals),  dd.y = the same over Psi (dpx_denominator_pack);
  * spec_add (nullable) is a dpx_data_spectrum result: the data part of the right-hand side kept in the
  * Fourier domain, so that rhs only carries rho * sum_i K_i^T (v_i - u_i).
- * d0/d1 are diag tables (nullable = 0); c0/c1 add the constant diagonals of identity linops
+ * c0/c1 of dpx_denominator_pack add the constant diagonals of identity linops
  * (Variable.get_diag, linop/variable.py:47-59, and the `+ rho` of :147-148); rho is device [B]. */
-int dpx_fourier_solve(const float* rhs, float* x, const void* spec_add, const void* d0, const void* d1, float c0, float c1,
+int dpx_fourier_solve(const float* rhs, float* x, const void* spec_add, const void* dd,
                       const float* rho, float eps, int B, int C, int H, int W,
                       const void* table, void* spectrum_ws, dpx_stream_t stream);
 
