@@ -250,6 +250,17 @@ static void cols_dispatch(int H, const float2* spec, float2* spec_out, const Spe
   }
 }
 
+int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table,
+                    hipStream_t stream) {
+  cols_dispatch<OP_SOLVE>(H, spec_in, spec_out, A, P, C, W / 2, tw_cols(table, W), stream);
+  return launch_status("cols_solve_pow2");
+}
+
+int rows_r2c_pow2(const float* x, float2* spec, int P, int H, int W, const void* table, hipStream_t stream) {
+  rows_dispatch(true, W, H, x, spec, nullptr, P * H, tw_rows(table), 1.0f, stream);
+  return launch_status("rows_r2c_pow2");
+}
+
 int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& A, int B, int C, int H, int W,
                         const void* table, void* ws, hipStream_t stream) {
   const int P = B * C, Ws = W / 2;

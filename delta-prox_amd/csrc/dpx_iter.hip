@@ -1,0 +1,310 @@
+// The fused ADMM iteration for power-of-two planes: TWO kernels per iteration.
+//
+//   k_iter_cols (= k_cols_p2<OP_SOLVE>, dpx_fft_pow2.hip): column FFT -> (+ data spectrum, / denominator) -> inverse
+//                 column FFT, spectrum in, spectrum out.
+//   k_iter_rows (this file): for a band of R image rows of one plane
+//        inverse row FFT (finishes the x-update)                     x = irFFT2[...]          sum_square.py:150-152
+//     -> z / dual update of every Psi term on the fresh rows          v = prox(Kx + u), u += Kx - v   admm.py:54-57
+//     -> right-hand side increment of the NEXT x-update               rho' * sum K_i^T (v_i - u_i)    sum_square.py:126-135
+//     -> forward row FFT of that increment                            first half of the next rFFT2
+//   The image x and the split variables v_i never touch HBM inside the loop (they are emitted on request: last
+//   iteration or a user callback); per iteration and element the loop moves one spectrum in, one spectrum
+//   out, u_i in and u_i out per term.  Reference: one iteration = dprox/algo/admm.py:49-59.
+//
+// Row dependencies (grad along H couples row h with h+1 in K and h-1 in K^T) are handled inside a workgroup:
+// its SPB row-sequences advance through the band in lock step, a ring of SPB+1 rows of x and of (v-u) lives in
+// LDS, and one halo row above / below the band is recomputed (R+2 inverse transforms for R rows).
+#include "dpx_fft_reg.h"
+
+namespace dpx {
+
+struct IterTerm {
+  int linop, prox;
+  float alpha;
+  const float* lam;
+  const float* u_in;
+  float* u_out;
+  float* v_out;
+};
+struct IterTerms {
+  IterTerm t[DPX_MAX_TERMS];
+  int n;
+};
+
+__device__ __forceinline__ float prox1(int kind, float d, float lam) {
+  if (kind == DPX_PROX_NORM1) {
+    const float m = fmaxf(fabsf(d) - lam, 0.f);
+    return d > 0.f ? m : (d < 0.f ? -m : 0.f * m);
+  }
+  if (kind == DPX_PROX_NONNEG) return fmaxf(d, 0.f);
+  return d / (1.f + 2.f * lam);
+}
+
+// M = W/2 complex points per row, T threads per row, SPB = 256/T rows in flight per workgroup
+template <int M, int T>
+__global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
+                                                    const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
+                                                    int C, int H, int R, int P, const float2* __restrict__ twW) {
+  constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS, RING = SPB + 1;
+  HIP_DYNAMIC_SHARED(float2, smem_it)
+  float2* fft_lds = smem_it;                          // SPB * S
+  float2* xring = smem_it + SPB * S;                  // RING rows of M float2 (pixel pairs)
+  float2* wring = xring + RING * M;                   // RING rows of (v-u) of the grad_H term
+  const int tid = threadIdx.x, j = tid / T, t = tid % T;
+  const int lane = tid & 63, lbase = lane & ~(T - 1);
+  const int bands = H / R;
+  const int pl = blockIdx.x / bands, r0 = (blockIdx.x - pl * bands) * R;
+  const int bi = pl / C;
+  const size_t plane_px = (size_t)pl * H * (2 * M);
+  const float2* sin_main = spec_in + (size_t)pl * H * M;
+  const float2* sin_side = spec_in + (size_t)P * H * M + (size_t)pl * H;
+  float2* sout_main = spec_out + (size_t)pl * H * M;
+  float2* sout_side = spec_out + (size_t)P * H * M + (size_t)pl * H;
+  const unsigned tile_off = (unsigned)((t & 7) + (t >> 3) * H * 8);   // bin t of a row in the tile-major spectrum
+  const unsigned tile_step = (unsigned)((T / 8) * H * 8);            // bin t + m*T
+  const float rho = rho_next ? rho_next[bi] : 0.f;
+  float2* myfft = fft_lds + j * S;
+  int hterm = -1;
+  for (int i = 0; i < TT.n; ++i)
+    if (TT.t[i].linop == DPX_LIN_GRAD_H) hterm = i;
+  const int nsteps = (R + 2 + SPB - 1) / SPB;
+
+  for (int s = 0; s < nsteps; ++s) {
+    // ---------------- phase A: inverse row transform of row q (relative to r0 - 1) ----------------
+    const int q = s * SPB + j;
+    const bool a_live = q <= R + 1;
+    float2 xa[V];
+    {
+      const int h = (r0 - 1 + q + H) % H;
+      const float2* in = sin_main + (unsigned)h * 8u + tile_off;
+      float2 X[V];
+#pragma unroll
+      for (int m = 0; m < V; ++m) X[m] = a_live ? in[tile_step * m] : make_float2(0.f, 0.f);
+      const float xn = a_live ? sin_side[h].x : 0.f;
+      const int plane = lbase | ((T - t) & (T - 1));
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 got = make_float2(__shfl(X[V - 1 - m].x, plane), __shfl(X[V - 1 - m].y, plane));
+        const float2 xm = cconj(t == 0 ? X[(V - m) % V] : got);
+        const int k = t + m * T;
+        const float2 xk = X[m];
+        if (k == 0) {
+          xa[m] = make_float2(xk.x + xn, xk.x - xn);
+        } else {
+          const float2 e = cadd(xk, xm);
+          const float2 d = cmulc(csub(xk, xm), twW[k]);
+          xa[m] = make_float2(e.x - d.y, e.y + d.x);
+        }
+      }
+      WaveSync()();
+      fft_reg<M, T, +1>(xa, myfft, t, twW, 2, WaveSync());    // xa[m] = (x[2n], x[2n+1]), n = t + m*T
+      if (a_live) {
+        float2* xr = xring + (q % RING) * M;
+#pragma unroll
+        for (int m = 0; m < V; ++m) xr[t + m * T] = xa[m];
+        if (x_out && q >= 1 && q <= R) {
+          float2* xo = (float2*)(x_out + plane_px + (size_t)h * (2 * M));
+#pragma unroll
+          for (int m = 0; m < V; ++m) xo[t + m * T] = xa[m];
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------- phase B: z / dual update of row qz = q - 1 (x[qz] from LDS, x[qz+1] = xa) ----
+    const int qz = q - 1;
+    const bool z_live = qz >= 0 && qz <= R;
+    const bool z_own = qz >= 1 && qz <= R;               // rows of this band (row qz = 0 is the halo above)
+    const int hz = (r0 - 1 + qz + 2 * H) % H;
+    float2 acc[V];                                        // K^T (v - u) accumulated over the terms (row-local parts)
+    float2 wh[V];                                         // (v - u) of the grad_H term on this row
+#pragma unroll
+    for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f), wh[m] = make_float2(0.f, 0.f);
+    {
+      // every lane runs the arithmetic (the shuffles need converged T-lane groups); only memory writes are predicated
+      const float2* xc_row = xring + ((qz + RING) % RING) * M;
+      float2 xc[V];
+#pragma unroll
+      for (int m = 0; m < V; ++m) xc[m] = xc_row[t + m * T];
+      for (int i = 0; i < TT.n; ++i) {
+        const IterTerm tm = TT.t[i];
+        const float lam = tm.lam ? tm.lam[bi] * tm.alpha : 0.f;
+        const float2* urow = (const float2*)(tm.u_in + plane_px + (size_t)hz * (2 * M));
+        float2 w[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+          const float2 uu = urow[t + m * T];
+          float2 kx;
+          if (tm.linop == DPX_LIN_IDENTITY) {
+            kx = xc[m];
+          } else if (tm.linop == DPX_LIN_GRAD_H) {
+            kx = make_float2(xa[m].x - xc[m].x, xa[m].y - xc[m].y);
+          } else {                                      // grad_W: x[w+1] - x[w]; pixel 2n+2 is the neighbour lane's .x
+            const float nx_same = __shfl(xc[m].x, lbase | ((t + 1) & (T - 1)));
+            const float nx_wrap = __shfl(xc[(m + 1) % V].x, lbase);
+            const float xr = (t == T - 1) ? nx_wrap : nx_same;
+            kx = make_float2(xc[m].y - xc[m].x, xr - xc[m].y);
+          }
+          const float dx = kx.x + uu.x, dy = kx.y + uu.y;
+          const float vx = prox1(tm.prox, dx, lam), vy = prox1(tm.prox, dy, lam);
+          const float ux = dx - vx, uy = dy - vy;
+          w[m] = make_float2(vx - ux, vy - uy);
+          if (z_own) {
+            ((float2*)(tm.u_out + plane_px + (size_t)hz * (2 * M)))[t + m * T] = make_float2(ux, uy);
+            if (emit_v) ((float2*)(tm.v_out + plane_px + (size_t)hz * (2 * M)))[t + m * T] = make_float2(vx, vy);
+          }
+        }
+        // this term's contribution to K^T (v - u) that needs no other row
+        if (tm.linop == DPX_LIN_IDENTITY) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) acc[m] = cadd(acc[m], w[m]);
+        } else if (tm.linop == DPX_LIN_GRAD_W) {          // adjoint: y[w-1] - y[w]; pixel 2n-1 is the left lane's .y
+#pragma unroll
+          for (int m = 0; m < V; ++m) {
+            const float l_same = __shfl(w[m].y, lbase | ((t + T - 1) & (T - 1)));
+            const float l_wrap = __shfl(w[(m + V - 1) % V].y, lbase | (T - 1));
+            const float wl = (t == 0) ? l_wrap : l_same;
+            acc[m] = make_float2(acc[m].x + (wl - w[m].x), acc[m].y + (w[m].x - w[m].y));
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < V; ++m) wh[m] = w[m];
+          if (z_live) {
+            float2* wr = wring + (qz % RING) * M;
+#pragma unroll
+            for (int m = 0; m < V; ++m) wr[t + m * T] = w[m];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------- phase C: right-hand-side increment of row qz and its forward row transform ----
+    if (rho_next) {
+      float2 z[V];
+      if (z_own) {
+        if (hterm >= 0) {                                  // grad_H adjoint: y[h-1] - y[h]
+          const float2* wp = wring + ((qz - 1 + RING) % RING) * M;
+#pragma unroll
+          for (int m = 0; m < V; ++m) {
+            const float2 up = wp[t + m * T];
+            acc[m] = make_float2(acc[m].x + (up.x - wh[m].x), acc[m].y + (up.y - wh[m].y));
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
+      } else {
+#pragma unroll
+        for (int m = 0; m < V; ++m) z[m] = make_float2(0.f, 0.f);
+      }
+      WaveSync()();
+      fft_reg<M, T, -1>(z, myfft, t, twW, 2, WaveSync());
+      const int plane = lbase | ((T - t) & (T - 1));
+      float2* out = sout_main + (unsigned)hz * 8u + tile_off;
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 got = make_float2(__shfl(z[V - 1 - m].x, plane), __shfl(z[V - 1 - m].y, plane));
+        const float2 zm = cconj(t == 0 ? z[(V - m) % V] : got);
+        const int k = t + m * T;
+        const float2 zk = z[m];
+        float2 X;
+        if (k == 0) {
+          X = make_float2(zk.x + zk.y, 0.f);
+          if (z_own) sout_side[hz] = make_float2(zk.x - zk.y, 0.f);
+        } else {
+          const float2 e = cscale(cadd(zk, zm), 0.5f);
+          const float2 d = cscale(csub(zk, zm), 0.5f);
+          X = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
+        }
+        if (z_own) out[tile_step * m] = X;
+      }
+    }
+    // the next phase A overwrites ring rows that phase B has finished with (barrier above) and its own
+    // transform scratch (wave-local, WaveSync at its start); ring rows read in phase C are rewritten in the
+    // next phase B, which sits behind the next phase-A barrier.
+  }
+}
+
+static size_t iter_rows_lds(int M, int T) {
+  const int SPB = 256 / T, S = M + M / 16;
+  return (size_t)(SPB * S + 2 * (SPB + 1) * M) * sizeof(float2);
+}
+
+template <int M, int T>
+static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
+                             int C, int H, int R, int P, const float2* twW, hipStream_t s) {
+  const size_t sh = iter_rows_lds(M, T);
+  static bool attr = false;
+  if (!attr && sh > 48 * 1024) {
+    hipFuncSetAttribute((const void*)k_iter_rows<M, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    attr = true;
+  }
+  DPX_LAUNCH("k_iter_rows", (k_iter_rows<M, T>), dim3(P * (H / R)), dim3(256), sh, s, sin, sout, TT, rho_next, x_out, emit_v, C, H,
+             R, P, twW);
+}
+
+size_t pow2_spec_elems(int P, int H, int W);
+int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table,
+                    hipStream_t stream);
+int rows_r2c_pow2(const float* x, float2* spec, int P, int H, int W, const void* table, hipStream_t stream);
+
+}  // namespace dpx
+
+using namespace dpx;
+
+static int terms_ok(const dpx_term* terms, int nterms) {
+  if (nterms < 1 || nterms > DPX_MAX_TERMS || !terms) return 0;
+  int nh = 0;
+  for (int i = 0; i < nterms; ++i) {
+    if (terms[i].linop < DPX_LIN_IDENTITY || terms[i].linop > DPX_LIN_GRAD_W) return 0;
+    if (terms[i].prox < DPX_PROX_NORM1 || terms[i].prox > DPX_PROX_SUMSQ) return 0;
+    nh += terms[i].linop == DPX_LIN_GRAD_H;
+  }
+  return nh <= 1;
+}
+
+extern "C" int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms) {
+  return pow2_path_available(H, W) && H % 16 == 0 && terms_ok(terms, nterms);
+}
+
+extern "C" int dpx_rfft_rows(const float* x, void* spec, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
+  DPX_REQUIRE(x && spec && table, "dpx_rfft_rows: null pointer");
+  DPX_REQUIRE(pow2_path_available(H, W), "dpx_rfft_rows: only power-of-two planes use the two-kernel iteration");
+  return rows_r2c_pow2(x, (float2*)spec, B * C, H, W, table, (hipStream_t)stream);
+}
+
+extern "C" int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const void* spec_add, const void* dd, const float* rho,
+                                  float eps, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
+  DPX_REQUIRE(spec_in && spec_out && dd && rho && table, "dpx_admm_iter_cols: null pointer");
+  DPX_REQUIRE(pow2_path_available(H, W), "dpx_admm_iter_cols: unsupported plane size %dx%d", H, W);
+  SpecArgs a{};
+  a.dd = (const float2*)dd;
+  a.add = (const float2*)spec_add;
+  a.rho = rho;
+  a.eps = eps;
+  a.scale = 1.0f / ((float)H * (float)W);
+  return cols_solve_pow2((const float2*)spec_in, (float2*)spec_out, a, B * C, C, H, W, table, (hipStream_t)stream);
+}
+
+extern "C" int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next,
+                                  float* x_out, int emit_v, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
+  DPX_REQUIRE(spec_in && table && (spec_out || !rho_next), "dpx_admm_iter_rows: null pointer");
+  DPX_REQUIRE(dpx_admm_iter_supported(H, W, terms, nterms), "dpx_admm_iter_rows: unsupported problem (plane %dx%d, %d terms)", H, W, nterms);
+  IterTerms TT;
+  TT.n = nterms;
+  for (int i = 0; i < nterms; ++i) {
+    DPX_REQUIRE(terms[i].u && (terms[i].u_out) && (!emit_v || terms[i].v), "dpx_admm_iter_rows: term %d lacks u / u_out / v", i);
+    DPX_REQUIRE(terms[i].u != terms[i].u_out, "dpx_admm_iter_rows: u must be double-buffered (u_out != u)");
+    TT.t[i] = IterTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].u, terms[i].u_out, terms[i].v};
+  }
+  const int P = B * C, R = 16;
+  const float2* tw = tw_rows(table);
+  hipStream_t s = (hipStream_t)stream;
+  const float2* sin = (const float2*)spec_in;
+  float2* sout = (float2*)spec_out;
+  switch (W) {
+    case 256: launch_iter_rows<128, 16>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
+    case 512: launch_iter_rows<256, 32>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
+    case 1024: launch_iter_rows<512, 64>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
+    default: launch_iter_rows<1024, 64>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
+  }
+  return launch_status("dpx_admm_iter_rows");
+}

@@ -28,7 +28,7 @@ class DpxError(RuntimeError):
 class Term(ctypes.Structure):
     """``dpx_term`` of include/dpx.h."""
     _fields_ = [("linop", c_int32), ("prox", c_int32), ("alpha", c_float), ("reserved", c_int32),
-                ("lam", c_void_p), ("v", c_void_p), ("u", c_void_p)]
+                ("lam", c_void_p), ("v", c_void_p), ("u", c_void_p), ("u_out", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/dpx.h declares
@@ -60,6 +60,11 @@ SIGNATURES = {
     "dpx_prox": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
     "dpx_admm_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_zupdate": (c_int, [c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_admm_iter_supported": (c_int, [c_int, c_int, POINTER(Term), c_int]),
+    "dpx_rfft_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_iter_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_iter_rows": (c_int, [c_void_p, c_void_p, POINTER(Term), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p]),
     "dpx_ffdnet_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_ffdnet_pack": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

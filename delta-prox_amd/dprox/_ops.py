@@ -282,6 +282,7 @@ def make_terms(specs):
         arr[i].linop, arr[i].prox, arr[i].alpha = s["linop"], s["prox"], float(s.get("alpha", 1.0))
         arr[i].lam = None if s.get("lam") is None else s["lam"].data_ptr()
         arr[i].v, arr[i].u = s["v"].data_ptr(), s["u"].data_ptr()
+        arr[i].u_out = None
     return arr
 
 
@@ -294,3 +295,32 @@ def admm_rhs(rhs, ktb, rho, term_arr, nterms):
 def admm_zupdate(x, term_arr, nterms):
     B, C, H, W = _shape4(x)
     be.lib().call("dpx_admm_zupdate", ptr(x), term_arr, nterms, B, C, H, W, be.stream())
+
+
+# ----------------------------------------------------------------------------------------------
+# two-kernel fused iteration (power-of-two planes)
+# ----------------------------------------------------------------------------------------------
+def iter_supported(H, W, term_arr, nterms):
+    return bool(be.lib().query("dpx_admm_iter_supported", H, W, term_arr, nterms))
+
+
+def spectrum_buffer(P, H, W, device):
+    """one half-spectrum buffer (dpx_spectrum_bytes covers two)"""
+    return _bytes(be.lib().query("dpx_spectrum_bytes", P, H, W) // 2, device)
+
+
+def rfft_rows(x, spec):
+    B, C, H, W = _shape4(x)
+    be.lib().call("dpx_rfft_rows", ptr(x), ptr(spec), B, C, H, W, ptr(fft_table(H, W, x.device)), be.stream())
+
+
+def iter_cols(spec_in, spec_out, spec_add, dd, rho, eps, shape, device):
+    B, C, H, W = shape
+    be.lib().call("dpx_admm_iter_cols", ptr(spec_in), ptr(spec_out), ptr(spec_add), ptr(dd), ptr(rho), c_float(eps),
+                  B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
+
+
+def iter_rows(spec_in, spec_out, term_arr, nterms, rho_next, x_out, emit_v, shape, device):
+    B, C, H, W = shape
+    be.lib().call("dpx_admm_iter_rows", ptr(spec_in), ptr(spec_out), term_arr, nterms, ptr(rho_next), ptr(x_out),
+                  int(bool(emit_v)), B, C, H, W, ptr(fft_table(H, W, device)), be.stream())

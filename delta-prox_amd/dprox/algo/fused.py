@@ -159,6 +159,10 @@ class FusedADMM:
         ext = [i for i, (_, pc) in enumerate(self.codes) if pc == be.PROX_EXTERNAL]
         var = s.Kall.variables[0]
 
+        if not ext and n > 0 and ops.iter_supported(H, W, terms, n):
+            return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
+                                        rhos, lams, pbar, callback)
+
         for it in tqdm(range(T), disable=not pbar):
             for i in range(n):
                 terms[i].lam = lam_tab[i][it].data_ptr()
@@ -183,6 +187,42 @@ class FusedADMM:
                 callback(iter=it, state=(x, v, u), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
         s.Kall.update_vars([x])
         return x, v, u
+
+
+    def _run_two_kernel(self, shape, dev, T, terms, n, v, u, x, rhs, FK, diag, rho_tab, lam_tab, rhos, lams, pbar, callback):
+        """power-of-two planes: cols -> rows, two kernels per iteration; x / v only leave the chip on request"""
+        s = self.solver
+        B, C, H, W = shape
+        t0, c0, t1, c1 = diag
+        dd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
+        SA, SB = ops.spectrum_buffer(B * C, H, W, dev), ops.spectrum_buffer(B * C, H, W, dev)
+        u_cur, u_nxt = list(u), [torch.empty_like(t) for t in u]
+        var = s.Kall.variables[0]
+        if T == 0:
+            return var.value, v, u
+        # seed: row transform of the first right-hand-side increment rho_0 * sum K_i^T (v_i - u_i)
+        for i in range(n):
+            terms[i].lam = lam_tab[i][0].data_ptr()
+        ops.admm_rhs(rhs, None, rho_tab[0], terms, n)
+        ops.rfft_rows(rhs, SA)
+        for it in tqdm(range(T), disable=not pbar):
+            last = it == T - 1
+            emit = last or callback is not None
+            ops.iter_cols(SA, SB, FK, dd, rho_tab[it], ls_eps(s.least_square), shape, dev)
+            for i in range(n):
+                terms[i].lam = lam_tab[i][it].data_ptr()
+                terms[i].u, terms[i].u_out = u_cur[i].data_ptr(), u_nxt[i].data_ptr()
+                terms[i].v = v[i].data_ptr()
+            ops.iter_rows(SB, None if last else SA, terms, n, None if last else rho_tab[it + 1], x if emit else None, emit,
+                          shape, dev)
+            u_cur, u_nxt = u_nxt, u_cur
+            if emit:
+                var.value = x
+            if callback is not None:
+                s._notify_all_op_current_step(it)
+                callback(iter=it, state=(x, v, u_cur), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+        s.Kall.update_vars([x])
+        return x, v, u_cur
 
 
 def ls_eps(ls):

@@ -147,6 +147,7 @@ typedef struct dpx_term {
   const float* lam; /* device [B] */
   float* v;         /* state v_i [B,C,H,W] */
   float* u;         /* state u_i [B,C,H,W] */
+  float* u_out;     /* dpx_admm_iter_rows only: updated u_i (double-buffered, must differ from u) */
 } dpx_term;
 #define DPX_MAX_TERMS 4
 
@@ -158,6 +159,23 @@ int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, const dpx_term*
 /* for every term: d = K_i x + u_i ; v_i = prox_i(d) ; u_i = d - v_i   -- algo/admm.py:54-57 */
 int dpx_admm_zupdate(const float* x, const dpx_term* terms, int nterms,
                      int B, int C, int H, int W, dpx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* two-kernel fused ADMM iteration (power-of-two planes)                                       */
+/* ------------------------------------------------------------------------------------------ */
+/* One iteration of algo/admm.py:49-59 as  cols -> rows :
+ *   dpx_admm_iter_cols : spectrum in -> column FFT -> (+ data spectrum) / denominator -> inverse column FFT -> spectrum out
+ *   dpx_admm_iter_rows : inverse row FFT (x of this iteration) -> z / dual update of every term (lam of this iteration)
+ *                        -> rho_next * sum_i K_i^T (v_i - u_i) -> forward row FFT -> spectrum out (input of the next cols)
+ * x and v_i are only written when requested (x_out non-null / emit_v), u_i is double-buffered (terms[i].u -> u_out);
+ * rho_next = NULL on the last iteration (no right-hand side is produced).  dpx_rfft_rows seeds the loop with the row
+ * transform of the first right-hand side (dpx_admm_rhs).  Spectrum buffers: dpx_spectrum_bytes / 2 each.            */
+int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms);
+int dpx_rfft_rows(const float* x, void* spec, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
+int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const void* spec_add, const void* dd, const float* rho, float eps,
+                       int B, int C, int H, int W, const void* table, dpx_stream_t stream);
+int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next,
+                       float* x_out, int emit_v, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* FFDNet denoiser (deep_prior z-update)                                                       */
