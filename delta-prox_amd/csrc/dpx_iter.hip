@@ -40,8 +40,10 @@ __device__ __forceinline__ float prox1(int kind, float d, float lam) {
   return d / (1.f + 2.f * lam);
 }
 
-// M = W/2 complex points per row, T threads per row, SPB = 256/T rows in flight per workgroup
-template <int M, int T>
+// M = W/2 complex points per row, T threads per row, SPB = 256/T rows in flight per workgroup, NT terms.
+// Global loads are issued one phase ahead of their use (u rows at the top of phase A, the next spectrum row at
+// the top of phase C) so that the transforms cover the HBM latency; 2 workgroups (8 waves) share a CU.
+template <int M, int T, int NT>
 __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
                                                     const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
                                                     int C, int H, int R, int P, const float2* __restrict__ twW) {
@@ -65,56 +67,69 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
   const float rho = rho_next ? rho_next[bi] : 0.f;
   float2* myfft = fft_lds + j * S;
   int hterm = -1;
-  for (int i = 0; i < TT.n; ++i)
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
     if (TT.t[i].linop == DPX_LIN_GRAD_H) hterm = i;
   const int nsteps = (R + 2 + SPB - 1) / SPB;
+  const int pair = lbase | ((T - t) & (T - 1));         // lane holding bin M-k for this lane's bin k
+
+  // prefetch the spectrum row of step 0
+  float2 X[V];
+  float xn;
+  {
+    const int h = (r0 - 1 + j + H) % H;
+    const float2* in = sin_main + (unsigned)h * 8u + tile_off;
+#pragma unroll
+    for (int m = 0; m < V; ++m) X[m] = in[tile_step * m];
+    xn = sin_side[h].x;
+  }
 
   for (int s = 0; s < nsteps; ++s) {
-    // ---------------- phase A: inverse row transform of row q (relative to r0 - 1) ----------------
-    const int q = s * SPB + j;
+    const int q = s * SPB + j;                          // row (relative to r0 - 1) this sequence transforms
     const bool a_live = q <= R + 1;
+    const int h = (r0 - 1 + q + H) % H;
+    const int qz = q - 1;                               // row this sequence updates (x[qz] from LDS, x[qz+1] own)
+    const bool z_live = qz >= 0 && qz <= R;
+    const bool z_own = qz >= 1 && qz <= R;              // rows of this band (row qz = 0 is the halo above)
+    const int hz = (r0 - 1 + qz + 2 * H) % H;
+    // ---- issue the u loads of phase B now: the inverse transform below covers their latency ----
+    float2 ureg[NT][V];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const float2* urow = (const float2*)(TT.t[i].u_in + plane_px + (size_t)hz * (2 * M));
+#pragma unroll
+      for (int m = 0; m < V; ++m) ureg[i][m] = urow[t + m * T];
+    }
+    // ---------------- phase A: inverse row transform of row q ----------------
     float2 xa[V];
-    {
-      const int h = (r0 - 1 + q + H) % H;
-      const float2* in = sin_main + (unsigned)h * 8u + tile_off;
-      float2 X[V];
 #pragma unroll
-      for (int m = 0; m < V; ++m) X[m] = a_live ? in[tile_step * m] : make_float2(0.f, 0.f);
-      const float xn = a_live ? sin_side[h].x : 0.f;
-      const int plane = lbase | ((T - t) & (T - 1));
-#pragma unroll
-      for (int m = 0; m < V; ++m) {
-        const float2 got = make_float2(__shfl(X[V - 1 - m].x, plane), __shfl(X[V - 1 - m].y, plane));
-        const float2 xm = cconj(t == 0 ? X[(V - m) % V] : got);
-        const int k = t + m * T;
-        const float2 xk = X[m];
-        if (k == 0) {
-          xa[m] = make_float2(xk.x + xn, xk.x - xn);
-        } else {
-          const float2 e = cadd(xk, xm);
-          const float2 d = cmulc(csub(xk, xm), twW[k]);
-          xa[m] = make_float2(e.x - d.y, e.y + d.x);
-        }
+    for (int m = 0; m < V; ++m) {
+      const float2 got = make_float2(__shfl(X[V - 1 - m].x, pair), __shfl(X[V - 1 - m].y, pair));
+      const float2 xm = cconj(t == 0 ? X[(V - m) % V] : got);
+      const int k = t + m * T;
+      const float2 xk = X[m];
+      if (k == 0) {
+        xa[m] = make_float2(xk.x + xn, xk.x - xn);
+      } else {
+        const float2 e = cadd(xk, xm);
+        const float2 d = cmulc(csub(xk, xm), twW[k]);
+        xa[m] = make_float2(e.x - d.y, e.y + d.x);
       }
-      WaveSync()();
-      fft_reg<M, T, +1>(xa, myfft, t, twW, 2, WaveSync());    // xa[m] = (x[2n], x[2n+1]), n = t + m*T
-      if (a_live) {
-        float2* xr = xring + (q % RING) * M;
+    }
+    WaveSync()();
+    fft_reg<M, T, +1>(xa, myfft, t, twW, 2, WaveSync());    // xa[m] = (x[2n], x[2n+1]), n = t + m*T
+    if (a_live) {
+      float2* xr = xring + (q % RING) * M;
 #pragma unroll
-        for (int m = 0; m < V; ++m) xr[t + m * T] = xa[m];
-        if (x_out && q >= 1 && q <= R) {
-          float2* xo = (float2*)(x_out + plane_px + (size_t)h * (2 * M));
+      for (int m = 0; m < V; ++m) xr[t + m * T] = xa[m];
+      if (x_out && q >= 1 && q <= R) {
+        float2* xo = (float2*)(x_out + plane_px + (size_t)h * (2 * M));
 #pragma unroll
-          for (int m = 0; m < V; ++m) xo[t + m * T] = xa[m];
-        }
+        for (int m = 0; m < V; ++m) xo[t + m * T] = xa[m];
       }
     }
     __syncthreads();
-    // ---------------- phase B: z / dual update of row qz = q - 1 (x[qz] from LDS, x[qz+1] = xa) ----
-    const int qz = q - 1;
-    const bool z_live = qz >= 0 && qz <= R;
-    const bool z_own = qz >= 1 && qz <= R;               // rows of this band (row qz = 0 is the halo above)
-    const int hz = (r0 - 1 + qz + 2 * H) % H;
+    // ---------------- phase B: z / dual update of row qz ----------------
     float2 acc[V];                                        // K^T (v - u) accumulated over the terms (row-local parts)
     float2 wh[V];                                         // (v - u) of the grad_H term on this row
 #pragma unroll
@@ -125,14 +140,14 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
       float2 xc[V];
 #pragma unroll
       for (int m = 0; m < V; ++m) xc[m] = xc_row[t + m * T];
-      for (int i = 0; i < TT.n; ++i) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
         const IterTerm tm = TT.t[i];
         const float lam = tm.lam ? tm.lam[bi] * tm.alpha : 0.f;
-        const float2* urow = (const float2*)(tm.u_in + plane_px + (size_t)hz * (2 * M));
         float2 w[V];
 #pragma unroll
         for (int m = 0; m < V; ++m) {
-          const float2 uu = urow[t + m * T];
+          const float2 uu = ureg[i][m];
           float2 kx;
           if (tm.linop == DPX_LIN_IDENTITY) {
             kx = xc[m];
@@ -177,49 +192,50 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
       }
     }
     __syncthreads();
+    // ---- issue the spectrum loads of the next step's phase A: the forward transform below covers them ----
+    if (s + 1 < nsteps) {
+      const int hn = (r0 - 1 + q + SPB + H) % H;
+      const float2* in = sin_main + (unsigned)hn * 8u + tile_off;
+#pragma unroll
+      for (int m = 0; m < V; ++m) X[m] = in[tile_step * m];
+      xn = sin_side[hn].x;
+    }
     // ---------------- phase C: right-hand-side increment of row qz and its forward row transform ----
     if (rho_next) {
       float2 z[V];
-      if (z_own) {
-        if (hterm >= 0) {                                  // grad_H adjoint: y[h-1] - y[h]
-          const float2* wp = wring + ((qz - 1 + RING) % RING) * M;
+      if (hterm >= 0) {                                    // grad_H adjoint: y[h-1] - y[h]
+        const float2* wp = wring + ((qz - 1 + RING) % RING) * M;
 #pragma unroll
-          for (int m = 0; m < V; ++m) {
-            const float2 up = wp[t + m * T];
-            acc[m] = make_float2(acc[m].x + (up.x - wh[m].x), acc[m].y + (up.y - wh[m].y));
-          }
+        for (int m = 0; m < V; ++m) {
+          const float2 up = wp[t + m * T];
+          acc[m] = make_float2(acc[m].x + (up.x - wh[m].x), acc[m].y + (up.y - wh[m].y));
         }
-#pragma unroll
-        for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
-      } else {
-#pragma unroll
-        for (int m = 0; m < V; ++m) z[m] = make_float2(0.f, 0.f);
       }
+#pragma unroll
+      for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
       WaveSync()();
       fft_reg<M, T, -1>(z, myfft, t, twW, 2, WaveSync());
-      const int plane = lbase | ((T - t) & (T - 1));
       float2* out = sout_main + (unsigned)hz * 8u + tile_off;
 #pragma unroll
       for (int m = 0; m < V; ++m) {
-        const float2 got = make_float2(__shfl(z[V - 1 - m].x, plane), __shfl(z[V - 1 - m].y, plane));
+        const float2 got = make_float2(__shfl(z[V - 1 - m].x, pair), __shfl(z[V - 1 - m].y, pair));
         const float2 zm = cconj(t == 0 ? z[(V - m) % V] : got);
         const int k = t + m * T;
         const float2 zk = z[m];
-        float2 X;
+        float2 Xo;
         if (k == 0) {
-          X = make_float2(zk.x + zk.y, 0.f);
+          Xo = make_float2(zk.x + zk.y, 0.f);
           if (z_own) sout_side[hz] = make_float2(zk.x - zk.y, 0.f);
         } else {
           const float2 e = cscale(cadd(zk, zm), 0.5f);
           const float2 d = cscale(csub(zk, zm), 0.5f);
-          X = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
+          Xo = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
         }
-        if (z_own) out[tile_step * m] = X;
+        if (z_own) out[tile_step * m] = Xo;
       }
     }
-    // the next phase A overwrites ring rows that phase B has finished with (barrier above) and its own
-    // transform scratch (wave-local, WaveSync at its start); ring rows read in phase C are rewritten in the
-    // next phase B, which sits behind the next phase-A barrier.
+    // ring rows read in phase B / C are rewritten by the next phase A / B, each behind a barrier; the transform
+    // scratch is wave-local (WaveSync before reuse).
   }
 }
 
@@ -228,17 +244,27 @@ static size_t iter_rows_lds(int M, int T) {
   return (size_t)(SPB * S + 2 * (SPB + 1) * M) * sizeof(float2);
 }
 
-template <int M, int T>
-static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
-                             int C, int H, int R, int P, const float2* twW, hipStream_t s) {
+template <int M, int T, int NT>
+static void launch_iter_rows_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
+                                int C, int H, int R, int P, const float2* twW, hipStream_t s) {
   const size_t sh = iter_rows_lds(M, T);
   static bool attr = false;
   if (!attr && sh > 48 * 1024) {
-    hipFuncSetAttribute((const void*)k_iter_rows<M, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipFuncSetAttribute((const void*)k_iter_rows<M, T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr = true;
   }
-  DPX_LAUNCH("k_iter_rows", (k_iter_rows<M, T>), dim3(P * (H / R)), dim3(256), sh, s, sin, sout, TT, rho_next, x_out, emit_v, C, H,
-             R, P, twW);
+  DPX_LAUNCH("k_iter_rows", (k_iter_rows<M, T, NT>), dim3(P * (H / R)), dim3(256), sh, s, sin, sout, TT, rho_next, x_out, emit_v, C,
+             H, R, P, twW);
+}
+template <int M, int T>
+static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
+                             int C, int H, int R, int P, const float2* twW, hipStream_t s) {
+  switch (TT.n) {
+    case 1: launch_iter_rows_nt<M, T, 1>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s); break;
+    case 2: launch_iter_rows_nt<M, T, 2>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s); break;
+    case 3: launch_iter_rows_nt<M, T, 3>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s); break;
+    default: launch_iter_rows_nt<M, T, 4>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s); break;
+  }
 }
 
 size_t pow2_spec_elems(int P, int H, int W);
