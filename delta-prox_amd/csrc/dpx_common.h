@@ -9,10 +9,15 @@
 
 // Hides a value's provenance from the optimiser (zero instructions): used where common-subexpression
 // elimination across kernel phases would keep dozens of addresses alive and spill them.
+// DPX_LDS_BARRIER: workgroup barrier that only waits for this wave's LDS traffic (lgkmcnt), not for its
+// outstanding global loads / stores (vmcnt) the way __syncthreads() does -- prefetched loads and posted stores
+// stay in flight across it.  Only LDS data may be exchanged through it.
 #ifdef DPX_EMULATED
 #define DPX_OPAQUE(x) ((void)(x))
+#define DPX_LDS_BARRIER() __syncthreads()
 #else
 #define DPX_OPAQUE(x) asm volatile("" : "+v"(x))
+#define DPX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
 namespace dpx {

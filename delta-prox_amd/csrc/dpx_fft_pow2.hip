@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(T* COLS) k_cols_p2(const float2* __restrict__ 
     else v[m] = spec_op_p2<OP>(z, A, tbase + toff0 + step * m, rho_b);
     if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();
+  DPX_LDS_BARRIER();
   if (!(DBG & 1)) fft_reg<H, T, +1>(v, lds, t, twH, 1, BlockSync());
   unsigned off1 = off0;
   DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores

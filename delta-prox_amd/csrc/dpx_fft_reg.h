@@ -135,7 +135,7 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
 }
 
 struct BlockSync {
-  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+  __device__ __forceinline__ void operator()() const { DPX_LDS_BARRIER(); }
 };
 struct WaveSync {
   __device__ __forceinline__ void operator()() const { __builtin_amdgcn_wave_barrier(); }

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
     for (int i = 0; i < NT; ++i) {
       const float2* urow = (const float2*)(TT.t[i].u_in + plane_px + (size_t)hz * (2 * M));
 #pragma unroll
-      for (int m = 0; m < V; ++m) ureg[i][m] = urow[t + m * T];
+      for (int m = 0; m < V; ++m) ureg[i][m] = z_live ? urow[t + m * T] : make_float2(0.f, 0.f);
     }
     // ---------------- phase A: inverse row transform of row q ----------------
     float2 xa[V];
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
         for (int m = 0; m < V; ++m) xo[t + m * T] = xa[m];
       }
     }
-    __syncthreads();
+    DPX_LDS_BARRIER();
     // ---------------- phase B: z / dual update of row qz ----------------
     float2 acc[V];                                        // K^T (v - u) accumulated over the terms (row-local parts)
     float2 wh[V];                                         // (v - u) of the grad_H term on this row
@@ -191,9 +191,9 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
         }
       }
     }
-    __syncthreads();
+    DPX_LDS_BARRIER();
     // ---- issue the spectrum loads of the next step's phase A: the forward transform below covers them ----
-    if (s + 1 < nsteps) {
+    if (s + 1 < nsteps && q + SPB <= R + 1) {
       const int hn = (r0 - 1 + q + SPB + H) % H;
       const float2* in = sin_main + (unsigned)hn * 8u + tile_off;
 #pragma unroll
@@ -333,4 +333,40 @@ extern "C" int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx
     default: launch_iter_rows<1024, 64>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
   }
   return launch_status("dpx_admm_iter_rows");
+}
+
+// Runs `n_iters` consecutive iterations (it0 .. it0 + n_iters - 1 of `total_iters`) without returning to the host
+// language: 2 kernel launches per iteration.  rho_tab is [total_iters][B], lam_tabs[i] is [total_iters][B] for term i.
+// spec_a holds the row-transformed right-hand side on entry (dpx_rfft_rows) and on exit (unless the solve ended);
+// u_i alternate between terms[i].u and terms[i].u_out: the return value (>= 0) is 0 if the current u_i are in
+// terms[i].u after the call, 1 if they are in terms[i].u_out.  x / v_i are written only by the final iteration of
+// the call when emit_last is set.
+extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, const void* dd, const dpx_term* terms, int nterms,
+                            const float* rho_tab, const float* const* lam_tabs, float eps, int it0, int n_iters, int total_iters,
+                            float* x_out, int emit_last, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
+  DPX_REQUIRE(spec_a && spec_b && dd && terms && rho_tab && lam_tabs && table, "dpx_admm_run: null pointer");
+  DPX_REQUIRE(n_iters >= 0 && it0 >= 0 && it0 + n_iters <= total_iters, "dpx_admm_run: bad iteration range");
+  DPX_REQUIRE(!emit_last || x_out, "dpx_admm_run: emit_last needs x_out");
+  dpx_term cur[DPX_MAX_TERMS];
+  DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS, "dpx_admm_run: nterms");
+  for (int i = 0; i < nterms; ++i) cur[i] = terms[i];
+  int parity = 0;
+  for (int k = 0; k < n_iters; ++k) {
+    const int it = it0 + k;
+    const bool last_of_solve = (it == total_iters - 1);
+    const bool emit = emit_last && (k == n_iters - 1);
+    int rc = dpx_admm_iter_cols(spec_a, spec_b, spec_add, dd, rho_tab + (size_t)it * B, eps, B, C, H, W, table, stream);
+    if (rc) return rc;
+    for (int i = 0; i < nterms; ++i) {
+      cur[i].lam = lam_tabs[i] ? lam_tabs[i] + (size_t)it * B : nullptr;
+      cur[i].u = parity ? terms[i].u_out : terms[i].u;
+      cur[i].u_out = parity ? terms[i].u : terms[i].u_out;
+    }
+    rc = dpx_admm_iter_rows(spec_b, last_of_solve ? nullptr : spec_a, cur, nterms,
+                            last_of_solve ? nullptr : rho_tab + (size_t)(it + 1) * B, emit ? x_out : nullptr, emit ? 1 : 0, B, C,
+                            H, W, table, stream);
+    if (rc) return rc;
+    parity ^= 1;
+  }
+  return parity;
 }

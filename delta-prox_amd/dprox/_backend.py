@@ -65,6 +65,8 @@ SIGNATURES = {
     "dpx_admm_iter_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_iter_rows": (c_int, [c_void_p, c_void_p, POINTER(Term), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p]),
+    "dpx_admm_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_void_p, POINTER(c_void_p), c_float,
+                             c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_ffdnet_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_ffdnet_pack": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

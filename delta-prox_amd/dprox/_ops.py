@@ -324,3 +324,17 @@ def iter_rows(spec_in, spec_out, term_arr, nterms, rho_next, x_out, emit_v, shap
     B, C, H, W = shape
     be.lib().call("dpx_admm_iter_rows", ptr(spec_in), ptr(spec_out), term_arr, nterms, ptr(rho_next), ptr(x_out),
                   int(bool(emit_v)), B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
+
+
+def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, eps, it0, n_iters, total, x_out, emit_last,
+             shape, device):
+    """n_iters fused iterations on the C side; returns the u-buffer parity (0: terms[i].u current, 1: u_out)"""
+    B, C, H, W = shape
+    lt = (c_void_p * nterms)(*[None if t is None else t.data_ptr() for t in lam_tabs])
+    L = be.lib()
+    rc = L.query("dpx_admm_run", ptr(spec_a), ptr(spec_b), ptr(spec_add), ptr(dd), term_arr, nterms, ptr(rho_tab), lt,
+                 c_float(eps), it0, n_iters, total, ptr(x_out), int(bool(emit_last)), B, C, H, W,
+                 ptr(fft_table(H, W, device)), be.stream())
+    if rc < 0:
+        raise be.DpxError(f"dpx_admm_run failed ({rc}): {L.cdll.dpx_last_error().decode()}")
+    return rc

@@ -136,16 +136,23 @@ class FusedADMM:
             if isinstance(fn, deep_prior) and fn.sqrt:
                 lt = torch.sqrt(torch.clamp(lt, min=1e-8))           # safe_sqrt(lam), prior.py:77
             lam_tab.append(lt)
-        # data spectrum F(sum_Omega K^T b), once per solve, fp64 transform (kept in the Fourier domain)
-        FK = None
-        for fn in s.omega_fns:
-            off = fn.offset
-            if off is None:
-                continue
-            off = off.expand_as(x0).contiguous() if off.shape != x0.shape else off.contiguous()
-            cv = _omega_conv(fn)
-            otf = cv._tables(x0.shape, dev) if cv is not None else None
-            FK = ops.data_spectrum(off, otf, conj=True, out=FK, accumulate=FK is not None)
+        # data spectrum F(sum_Omega K^T b): fp64 transform, kept in the Fourier domain, recomputed only when an
+        # offset (the observation b) changes
+        offs = [fn.offset for fn in s.omega_fns]
+        fk_key = (tuple(x0.shape), str(dev)) + tuple((id(o), o._version) if o is not None else None for o in offs)
+        cached = getattr(s, "_fk_cache", None)
+        if cached is not None and cached[0] == fk_key:
+            FK = cached[1]
+        else:
+            FK = None
+            for fn, off in zip(s.omega_fns, offs):
+                if off is None:
+                    continue
+                off = off.expand_as(x0).contiguous() if off.shape != x0.shape else off.contiguous()
+                cv = _omega_conv(fn)
+                otf = cv._tables(x0.shape, dev) if cv is not None else None
+                FK = ops.data_spectrum(off, otf, conj=True, out=FK, accumulate=FK is not None)
+            s._fk_cache = (fk_key, FK, offs)
         (t0, c0), (t1, c1) = ls.diag_tables(x0.shape, dev, True)
 
         v = [t.contiguous() for t in v]
@@ -205,22 +212,26 @@ class FusedADMM:
             terms[i].lam = lam_tab[i][0].data_ptr()
         ops.admm_rhs(rhs, None, rho_tab[0], terms, n)
         ops.rfft_rows(rhs, SA)
-        for it in tqdm(range(T), disable=not pbar):
-            last = it == T - 1
-            emit = last or callback is not None
-            ops.iter_cols(SA, SB, FK, dd, rho_tab[it], ls_eps(s.least_square), shape, dev)
-            for i in range(n):
-                terms[i].lam = lam_tab[i][it].data_ptr()
-                terms[i].u, terms[i].u_out = u_cur[i].data_ptr(), u_nxt[i].data_ptr()
-                terms[i].v = v[i].data_ptr()
-            ops.iter_rows(SB, None if last else SA, terms, n, None if last else rho_tab[it + 1], x if emit else None, emit,
-                          shape, dev)
-            u_cur, u_nxt = u_nxt, u_cur
-            if emit:
-                var.value = x
-            if callback is not None:
-                s._notify_all_op_current_step(it)
-                callback(iter=it, state=(x, v, u_cur), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+        for i in range(n):
+            terms[i].u, terms[i].u_out, terms[i].v = u_cur[i].data_ptr(), u_nxt[i].data_ptr(), v[i].data_ptr()
+        eps = ls_eps(s.least_square)
+        if callback is None and not pbar:
+            par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_tab, eps, 0, T, T, x, True, shape, dev)
+            if par:
+                u_cur, u_nxt = u_nxt, u_cur
+        else:
+            for it in tqdm(range(T), disable=not pbar):
+                emit = callback is not None or it == T - 1
+                par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_tab, eps, it, 1, T, x, emit, shape, dev)
+                if par:
+                    u_cur, u_nxt = u_nxt, u_cur
+                    for i in range(n):
+                        terms[i].u, terms[i].u_out = u_cur[i].data_ptr(), u_nxt[i].data_ptr()
+                if emit:
+                    var.value = x
+                if callback is not None:
+                    s._notify_all_op_current_step(it)
+                    callback(iter=it, state=(x, v, u_cur), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
         s.Kall.update_vars([x])
         return x, v, u_cur
 
