@@ -1,16 +1,238 @@
-// FFDNet conv stack (deep_prior z-update) -- reference dprox/proxfn/pnp/denoisers/models/network_ffdnet.py:54-68.
-// Placeholder entry points until the MFMA kernel lands: they fail loudly (no fallback).
+// FFDNet denoiser = the deep_prior z-update (reference dprox/proxfn/pnp/prior.py:73-86 ->
+// denoisers/models/network_ffdnet.py:54-68, conv stack built by basicblock.py:61-98, pixel-unshuffle :104-126).
+//
+//   k_ffd_pack_in   : replicate-pad to even size, pixel-unshuffle(2) (channel = c*4 + dy*2 + dx), append the
+//                     per-image sigma map as the last channel                      network_ffdnet.py:56-63
+//   k_conv3x3_mfma  : 3x3 / pad 1 convolution + bias (+ ReLU) as an implicit GEMM on the exact-fp32 matrix cores
+//                     (v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] B[2x32], bitwise an fmaf chain), one workgroup =
+//                     all output channels x (8 rows x 32 columns) pixels; K runs over (input-channel pair, tap).
+//   k_ffd_unpack_out: PixelShuffle(2) + crop                                      network_ffdnet.py:65-67
+//
+// GEMM view per layer: M = Cout (1..3 tiles of 32), N = pixels, K = 9 * Cin.  Per K-step of 2 (two input channels,
+// one tap) a wave reads MT weight fragments and 2 pixel fragments from LDS (one float per lane each, conflict-free:
+// weights are pre-packed [ci/2][tap][ci&1][cout] so cout is the fast axis, pixels are the fast axis of the staged
+// input tile) and issues 2*MT MFMAs.  FLOP roofline: 157.3 TFLOP/s fp32 MFMA.
 #include "dpx_common.h"
+
+namespace dpx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FFD_TW = 32;        // tile width  (pixels, = MFMA N)
+constexpr int FFD_TH = 8;         // tile height (rows): 4 waves x 2 rows
+constexpr int FFD_CK = 8;         // input channels staged per chunk
+constexpr int FFD_LDW = 36;       // LDS row pitch of the staged input tile (34 used)
+constexpr int FFD_ROWS = FFD_TH + 2;
+
+static inline int pad_even(int c) { return (c + 1) & ~1; }
+static inline int mtiles(int cout) { return (cout + 31) / 32; }
+
+// packed layer: weights [Cin_pad/2][9][2][MT*32] then bias [MT*32]
+static inline size_t layer_floats(int cin, int cout) { return (size_t)(pad_even(cin) / 2) * 9 * 2 * mtiles(cout) * 32 + (size_t)mtiles(cout) * 32; }
+
+__global__ void k_ffd_pack_weights(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ dst, int cin, int cout) {
+  const int MT32 = ((cout + 31) / 32) * 32, pairs = ((cin + 1) & ~1) / 2;
+  const long nw = (long)pairs * 9 * 2 * MT32;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + MT32; i += (long)gridDim.x * blockDim.x) {
+    if (i < nw) {
+      const int co = (int)(i % MT32);
+      long r = i / MT32;
+      const int half = (int)(r % 2);
+      r /= 2;
+      const int tap = (int)(r % 9), cp = (int)(r / 9);
+      const int ci = 2 * cp + half;
+      dst[i] = (co < cout && ci < cin) ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
+    } else {
+      const int co = (int)(i - nw);
+      dst[i] = co < cout ? b[co] : 0.f;
+    }
+  }
+}
+
+// x [B][C][H][W] -> a [B][Cp][H2][W2] with Cp = pad_even(4C+1); channel 4C = sigma, channel 4C+1 (if any) = 0
+__global__ void k_ffd_pack_in(const float* __restrict__ x, const float* __restrict__ sigma, float* __restrict__ a, int B, int C,
+                              int H, int W, int H2, int W2, int Cp) {
+  const long total = (long)B * Cp * H2 * W2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x2 = (int)(i % W2);
+    long r = i / W2;
+    const int y2 = (int)(r % H2);
+    r /= H2;
+    const int ch = (int)(r % Cp), b = (int)(r / Cp);
+    float v;
+    if (ch < 4 * C) {
+      const int c = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1;
+      const int yy = min(2 * y2 + dy, H - 1), xx = min(2 * x2 + dx, W - 1);       // ReplicationPad2d (bottom / right)
+      v = x[(((long)b * C + c) * H + yy) * W + xx];
+    } else {
+      v = (ch == 4 * C) ? sigma[b] : 0.f;
+    }
+    a[i] = v;
+  }
+}
+
+// o [B][4C][H2][W2] -> y [B][C][H][W]  (PixelShuffle(2): out[c][2y+dy][2x+dx] = in[c*4 + dy*2 + dx][y][x], then crop)
+__global__ void k_ffd_unpack_out(const float* __restrict__ o, float* __restrict__ y, int B, int C, int H, int W, int H2, int W2) {
+  const long total = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    long r = i / W;
+    const int yy = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    const int ch = c * 4 + (yy & 1) * 2 + (xx & 1);
+    y[i] = o[(((long)b * 4 * C + ch) * H2 + (yy >> 1)) * W2 + (xx >> 1)];
+  }
+}
+
+// in [B][Cin][H2][W2] (Cin even), out [B][Cout][H2][W2]; wpk = packed layer (see layer_floats)
+template <int MT, bool RELU>
+__global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
+                                                       const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x) {
+  constexpr int M32 = MT * 32;
+  __shared__ float s_in[FFD_CK * FFD_ROWS * FFD_LDW];          // [ch][row][col]
+  __shared__ float s_w[(FFD_CK / 2) * 9 * 2 * M32];            // [pair][tap][half][cout]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * FFD_TH, x0 = tx * FFD_TW;
+  const int j = lane & 31, half = lane >> 5;
+  const float* inb = in + (size_t)b * Cin * H2 * W2;
+  const float* bias = wpk + (size_t)(Cin / 2) * 9 * 2 * M32;
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  for (int c0 = 0; c0 < Cin; c0 += FFD_CK) {
+    const int nch = min(FFD_CK, Cin - c0);                     // even
+    // ---- stage the input tile (zero padding outside the image) ----
+    for (int i = tid; i < nch * FFD_ROWS * 34; i += 256) {
+      const int col = i % 34;
+      const int r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
+      const int yy = y0 + r - 1, xx = x0 + col - 1;
+      float v = 0.f;
+      if (yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = inb[((size_t)(c0 + ch) * H2 + yy) * W2 + xx];
+      s_in[(ch * FFD_ROWS + r) * FFD_LDW + col] = v;
+    }
+    // ---- stage the weight chunk (linear copy of the packed blob) ----
+    const float* wsrc = wpk + (size_t)(c0 / 2) * 9 * 2 * M32;
+    for (int i = tid; i < (nch / 2) * 9 * 2 * M32; i += 256) s_w[i] = wsrc[i];
+    __syncthreads();
+    // ---- MFMA: K-step = (channel pair, tap) ----
+    for (int cp = 0; cp < nch / 2; ++cp) {
+      const float* sin_c = s_in + ((2 * cp + half) * FFD_ROWS + 2 * wave) * FFD_LDW + j;
+      const float* sw_c = s_w + (cp * 9 * 2 + half) * M32 + j;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        const float b0 = sin_c[(dy + 0) * FFD_LDW + dx];       // output row 2*wave + 0
+        const float b1 = sin_c[(dy + 1) * FFD_LDW + dx];       // output row 2*wave + 1
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = sw_c[tap * 2 * M32 + mt * 32];
+          acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[mt][0], 0, 0, 0);
+          acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[mt][1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: bias, ReLU, store.  C/D layout: col = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cout) ----
+  float* outb = out + (size_t)b * Cout * H2 * W2;
+  const int xx = x0 + j;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int yy = y0 + 2 * wave + nt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[mt][nt][r] + bias[co];
+        if (RELU) v = fmaxf(v, 0.f);
+        if (co < Cout && yy < H2 && xx < W2) outb[((size_t)co * H2 + yy) * W2 + xx] = v;
+      }
+    }
+}
+
+template <int MT>
+static void launch_conv(bool relu, const float* in, float* out, const float* wpk, int Cin, int Cout, int B, int H2, int W2, hipStream_t s) {
+  const int tx = (W2 + FFD_TW - 1) / FFD_TW, ty = (H2 + FFD_TH - 1) / FFD_TH;
+  if (relu)
+    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, true>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx);
+  else
+    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, false>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx);
+}
+
+static int layer_cin(int l, int in_nc, int nc) { return l == 0 ? 4 * in_nc + 1 : nc; }
+static int layer_cout(int l, int in_nc, int nc, int nb) { return l == nb - 1 ? 4 * in_nc : nc; }
+
+}  // namespace dpx
+
 using namespace dpx;
 
-extern "C" size_t dpx_ffdnet_packed_bytes(int, int, int) { return 0; }
-extern "C" int dpx_ffdnet_pack(void*, const float* const*, const float* const*, int, int, int, dpx_stream_t) {
-  set_error("dpx_ffdnet_pack: FFDNet kernels not built yet");
-  return DPX_ERR_UNSUPPORTED;
+extern "C" size_t dpx_ffdnet_packed_bytes(int in_nc, int nc, int nb) {
+  size_t n = 0;
+  for (int l = 0; l < nb; ++l) n += layer_floats(layer_cin(l, in_nc, nc), layer_cout(l, in_nc, nc, nb));
+  return n * sizeof(float);
 }
-extern "C" size_t dpx_ffdnet_ws_bytes(int, int, int, int, int) { return 0; }
-extern "C" int dpx_ffdnet_forward(const float*, float*, const float*, const void*, int, int, int, int, int, int, void*,
-                                  dpx_stream_t) {
-  set_error("dpx_ffdnet_forward: FFDNet kernels not built yet");
-  return DPX_ERR_UNSUPPORTED;
+
+extern "C" int dpx_ffdnet_pack(void* packed, const float* const* w, const float* const* b, int in_nc, int nc, int nb,
+                               dpx_stream_t stream) {
+  DPX_REQUIRE(packed && w && b && in_nc > 0 && nc > 0 && nb >= 2, "dpx_ffdnet_pack: bad arguments");
+  DPX_REQUIRE(nc <= 96 && 4 * in_nc <= 96, "dpx_ffdnet_pack: at most 96 channels per layer are built");
+  float* dst = (float*)packed;
+  for (int l = 0; l < nb; ++l) {
+    const int cin = layer_cin(l, in_nc, nc), cout = layer_cout(l, in_nc, nc, nb);
+    DPX_REQUIRE(w[l] && b[l], "dpx_ffdnet_pack: layer %d has null weights", l);
+    const size_t n = layer_floats(cin, cout);
+    DPX_LAUNCH("k_ffd_pack_weights", k_ffd_pack_weights, dim3(grid_for((long)n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, w[l],
+               b[l], dst, cin, cout);
+    dst += n;
+  }
+  return launch_status("dpx_ffdnet_pack");
+}
+
+extern "C" size_t dpx_ffdnet_ws_bytes(int B, int in_nc, int nc, int H, int W) {
+  const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const size_t px = (size_t)B * H2 * W2;
+  return (px * pad_even(4 * in_nc + 1) + 2 * px * nc + px * 4 * in_nc) * sizeof(float);
+}
+
+extern "C" int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb,
+                                  int B, int H, int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && sigma && packed && ws, "dpx_ffdnet_forward: null pointer");
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96,
+              "dpx_ffdnet_forward: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, Cp = pad_even(4 * in_nc + 1);
+  const size_t px = (size_t)B * H2 * W2;
+  float* a0 = (float*)ws;
+  float* bufA = a0 + px * Cp;
+  float* bufB = bufA + px * nc;
+  float* last = bufB + px * nc;
+  DPX_LAUNCH("k_ffd_pack_in", k_ffd_pack_in, dim3(grid_for((long)(px * Cp), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W,
+             H2, W2, Cp);
+  const float* wl = (const float*)packed;
+  const float* cur = a0;
+  for (int l = 0; l < nb; ++l) {
+    const int cin = layer_cin(l, in_nc, nc), cout = layer_cout(l, in_nc, nc, nb);
+    float* dst = (l == nb - 1) ? last : ((l & 1) ? bufB : bufA);
+    const bool relu = l != nb - 1;
+    switch (mtiles(cout)) {
+      case 1: launch_conv<1>(relu, cur, dst, wl, pad_even(cin), cout, B, H2, W2, s); break;
+      case 2: launch_conv<2>(relu, cur, dst, wl, pad_even(cin), cout, B, H2, W2, s); break;
+      default: launch_conv<3>(relu, cur, dst, wl, pad_even(cin), cout, B, H2, W2, s); break;
+    }
+    wl += layer_floats(cin, cout);
+    cur = dst;
+  }
+  DPX_LAUNCH("k_ffd_unpack_out", k_ffd_unpack_out, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, last, y, B,
+             in_nc, H, W, H2, W2);
+  return launch_status("dpx_ffdnet_forward");
 }

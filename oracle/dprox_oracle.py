@@ -30,7 +30,7 @@ __all__ = [
     "Term", "sum_squares", "norm1", "norm2", "nonneg", "deep_prior",
     "soft_threshold", "prox", "LeastSquares", "cg", "bdot", "LinearSolveConfig",
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
-    "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr",
+    "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
 ]
 
 
@@ -606,3 +606,64 @@ def psnr(out, gt):
     """utils/metrics.py:68-70 restated for data range 1: 10*log10(1/MSE), per image."""
     mse = ((out - gt) ** 2).reshape(out.shape[0], -1).mean(dim=1)
     return 10.0 * torch.log10(1.0 / mse)
+
+
+# --------------------------------------------------------------------------- #
+# float64 evaluation of the same ADMM iteration ("exact iterate")             #
+# --------------------------------------------------------------------------- #
+def admm_f64(b, psf, psi, rhos, lams, max_iter, ffdnet_layers=None):
+    """The ADMM iteration of algo/admm.py:49-59 for  sum_squares(conv(x, psf) - b) + sum_i g_i(K_i x)  evaluated in
+    float64 with exact OTFs: the iterate both the reference's fp32 path and the HIP path approximate.
+
+    Used to put parity numbers in context: when rho * |G|^2 + |H|^2 gets tiny (PnP schedules reach 1e-5) the x-update
+    amplifies fp32 round-off by 1/min(den), and the reference's own output is then 1e-4..1e-3 away from this iterate.
+
+    psi: list of (linop, prox, alpha) with linop in {"id", "grad0", "grad1"}, prox in {"norm1", "nonneg", "ffdnet"};
+    rhos: [T]; lams: list (one per psi term) of [T] arrays; x0 = b.  Returns (x, [v_i], [u_i]) float64 tensors."""
+    bb = torch.as_tensor(b).double()
+    B, C, H, W = bb.shape
+
+    def otf(k):
+        return torch.from_numpy(np.transpose(psf2otf(np.asarray(k, dtype=np.float64), [H, W, C]), (2, 0, 1))[None])
+
+    Hf = otf(_kernel_ndarray(psf).astype(np.float64))
+    G = {"grad0": otf(grad_kernel(0).numpy()), "grad1": otf(grad_kernel(1).numpy())}
+    F2 = lambda a: torch.fft.fftn(a, dim=[-2, -1])
+    Fi = lambda a: torch.real(torch.fft.ifftn(a, dim=[-2, -1]))
+    K = lambda name, a: a if name == "id" else Fi(G[name] * F2(a))
+    Kt = lambda name, a: a if name == "id" else Fi(torch.conj(G[name]) * F2(a))
+    gram = lambda name: torch.ones_like(Hf.real) if name == "id" else torch.abs(G[name]) ** 2
+
+    def den64(x, sigma):
+        l64 = [(torch.as_tensor(w).double(), torch.as_tensor(bs).double()) for w, bs in ffdnet_layers]
+        h, w = x.shape[-2:]
+        xx = F.pad(x, (0, w % 2, 0, h % 2), mode="replicate")
+        xx = pixel_unshuffle2(xx)
+        m = torch.ones((xx.shape[0], 1, xx.shape[2], xx.shape[3]), dtype=torch.float64) * sigma.view(-1, 1, 1, 1)
+        xx = torch.cat((xx, m), 1)
+        for i, (wt, bs) in enumerate(l64):
+            xx = F.conv2d(xx, wt, bs, padding=1)
+            if i < len(l64) - 1:
+                xx = F.relu(xx)
+        return F.pixel_shuffle(xx, 2)[..., :h, :w]
+
+    x = bb.clone()
+    v = [K(name, x) for name, _, _ in psi]
+    u = [torch.zeros_like(e) for e in v]
+    Ktb = Fi(torch.conj(Hf) * F2(bb))
+    for it in range(max_iter):
+        rho = float(np.float32(rhos[it]))
+        rhs = Ktb + rho * sum(Kt(name, v[i] - u[i]) for i, (name, _, _) in enumerate(psi))
+        den = torch.abs(Hf) ** 2 + rho * sum(gram(name) for name, _, _ in psi)
+        x = Fi((F2(rhs) + 1e-7) / (den + 1e-7))
+        for i, (name, prox_kind, alpha) in enumerate(psi):
+            lam = float(np.float32(lams[i][it])) * alpha
+            d = K(name, x) + u[i]
+            if prox_kind == "norm1":
+                v[i] = torch.sign(d) * torch.clamp(d.abs() - lam, min=0)
+            elif prox_kind == "nonneg":
+                v[i] = torch.clamp(d, min=0)
+            else:
+                v[i] = den64(d, torch.full((B,), lam, dtype=torch.float64))
+            u[i] = d - v[i]
+    return x, v, u

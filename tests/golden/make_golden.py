@@ -71,7 +71,7 @@ from dprox.utils import fft2, ifft2  # noqa: E402
 from dprox.algo.tune.dpir import log_descent  # noqa: E402
 
 import synthetic  # noqa: E402
-from oracle.dprox_oracle import ffdnet_weights  # noqa: E402
+from oracle.dprox_oracle import admm_f64, ffdnet_weights  # noqa: E402
 
 assert dp.__file__.startswith(REF), dp.__file__
 torch.manual_seed(0)
@@ -260,7 +260,9 @@ def g5_admm_tv():
 
     out = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=0.1, lams=0.005, max_iter=20, callback=cb)
     psnr = 10 * np.log10(1.0 / np.mean((out.numpy() - gt) ** 2))
-    save("g5_admm_tv_c1", gt=gt, b=b, psf=psf, x=out, psnr=psnr, value_after=x.value, **snaps)
+    lam20 = np.full(20, 0.005, np.float32)
+    x64, _, _ = admm_f64(b, psf, [("grad0", "norm1", 1.0), ("grad1", "norm1", 1.0)], np.full(20, 0.1, np.float32), [lam20, lam20], 20)
+    save("g5_admm_tv_c1", gt=gt, b=b, psf=psf, x=out, psnr=psnr, value_after=x.value, x_f64=x64, **snaps)
 
     # --- 2x3x64x64, 50 iterations, per-iteration rho schedule, full final state
     gt, b, psf = synthetic.deconv_case(2, 3, 64, 64, seed=7)
@@ -367,7 +369,12 @@ def g9_admm_pnp():
     prior2, nn2 = dp.deep_prior(x2, denoiser=ColorDen(7)), dp.nonneg(x2)
     fns2 = dp.sum_squares(dp.conv(x2, psf) - T(b)) + prior2 + nn2
     out2 = dp.Problem(fns2).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams={prior2: sigmas, nn2: 0.0}, max_iter=3)
-    save("g9_admm_pnp", gt=gt, b=b, psf=psf, rhos=rhos, sigmas=sigmas, x=st[0], v0=st[1][0], u0=st[2][0], x_nonneg=out2)
+    # the exact (float64) iterates of the same algorithm: context for the fp32 round-off of ill-conditioned x-updates
+    x64, v64, u64 = admm_f64(b, psf, [("id", "ffdnet", 1.0)], rhos.numpy(), [sigmas.numpy()], 3, ffdnet_weights(7))
+    x64n, _, _ = admm_f64(b, psf, [("id", "ffdnet", 1.0), ("id", "nonneg", 1.0)], rhos.numpy(), [sigmas.numpy(), np.zeros(3)], 3,
+                          ffdnet_weights(7))
+    save("g9_admm_pnp", gt=gt, b=b, psf=psf, rhos=rhos, sigmas=sigmas, x=st[0], v0=st[1][0], u0=st[2][0], x_nonneg=out2,
+         x_f64=x64, v0_f64=v64[0], x_nonneg_f64=x64n)
 
 
 def g10_pgd():

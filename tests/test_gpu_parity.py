@@ -60,6 +60,18 @@ def test_cg(B):
     pc.case_cg(DEV, B)
 
 
+def test_ffdnet():
+    pc.case_ffdnet(DEV)
+
+
+def test_admm_pnp():
+    pc.case_admm_pnp(DEV)
+
+
+def test_ladmm_cg():
+    pc.case_ladmm_cg(DEV)
+
+
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV)
 
