@@ -134,6 +134,74 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
   rdft<V, DIR>(v);
 }
 
+// The twiddles a thread needs depend only on its index t: kernels that transform many sequences with the same
+// thread mapping (one row after another) load them once into registers and reuse them for every transform.
+template <int N, int T, bool KEEPB = true> struct TwRegs {
+  static constexpr int V = N / T, RM = N / (V * V), NB = (RM > 1) ? V / RM : 0;
+  float2 b[(RM > 1 && KEEPB) ? NB * (RM - 1) : 1];
+  float2 c[V - 1];
+  const float2* tw_;
+  int tws_;
+  __device__ __forceinline__ void load(int t, const float2* __restrict__ tw, int tws) {
+    tw_ = tw;
+    tws_ = tws;
+    if constexpr (RM > 1 && KEEPB) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int k = (t + i * T) % V;
+#pragma unroll
+        for (int mm = 1; mm < RM; ++mm) b[i * (RM - 1) + mm - 1] = tw[(k * mm * V) * tws];
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < V; ++m) c[m - 1] = tw[(t * m) * tws];
+  }
+};
+
+// fft_reg with preloaded twiddles (same passes, same LDS image)
+template <int N, int T, int DIR, bool KEEPB, class Sync>
+__device__ __forceinline__ void fft_reg_tw(float2 (&v)[N / T], float2* __restrict__ lds, int t, const TwRegs<N, T, KEEPB>& W, Sync sync) {
+  constexpr int V = N / T;
+  constexpr int RM = N / (V * V);
+  rdft<V, DIR>(v);
+#pragma unroll
+  for (int m = 0; m < V; ++m) lds[lds_slot(t * V + m)] = v[m];
+  sync();
+  if constexpr (RM > 1) {
+    constexpr int NB = V / RM;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int jb = t + i * T;
+#pragma unroll
+      for (int mm = 0; mm < RM; ++mm) v[i * RM + mm] = lds[lds_slot(jb + mm * (N / RM))];
+    }
+    sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int jb = t + i * T;
+      const int k = jb % V;
+      float2 a[RM];
+#pragma unroll
+      for (int mm = 0; mm < RM; ++mm) a[mm] = v[i * RM + mm];
+#pragma unroll
+      for (int mm = 1; mm < RM; ++mm) {
+        if constexpr (KEEPB) a[mm] = twmul<DIR>(a[mm], W.b[i * (RM - 1) + mm - 1]);
+        else a[mm] = twmul<DIR>(a[mm], W.tw_[(k * mm * V) * W.tws_]);
+      }
+      rdft<RM, DIR>(a);
+      const int j0 = (jb - k) * RM + k;
+#pragma unroll
+      for (int mm = 0; mm < RM; ++mm) lds[lds_slot(j0 + mm * V)] = a[mm];
+    }
+    sync();
+  }
+#pragma unroll
+  for (int m = 0; m < V; ++m) v[m] = lds[lds_slot(t + m * T)];
+#pragma unroll
+  for (int m = 1; m < V; ++m) v[m] = twmul<DIR>(v[m], W.c[m - 1]);
+  rdft<V, DIR>(v);
+}
+
 struct BlockSync {
   __device__ __forceinline__ void operator()() const { DPX_LDS_BARRIER(); }
 };

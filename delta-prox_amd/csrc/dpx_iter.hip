@@ -44,7 +44,7 @@ __device__ __forceinline__ float prox1(int kind, float d, float lam) {
 // Global loads are issued one phase ahead of their use (u rows at the top of phase A, the next spectrum row at
 // the top of phase C) so that the transforms cover the HBM latency; 2 workgroups (8 waves) share a CU.
 template <int M, int T, int NT>
-__global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
+__global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
                                                     const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
                                                     int C, int H, int R, int P, const float2* __restrict__ twW) {
   constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS, RING = SPB + 1;
@@ -73,6 +73,10 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
   const int nsteps = (R + 2 + SPB - 1) / SPB;
   const int pair = lbase | ((T - t) & (T - 1));         // lane holding bin M-k for this lane's bin k
 
+  // the last-pass transform twiddles depend on t only: loaded once for the whole band
+  TwRegs<M, T, false> twr;
+  twr.load(t, twW, 2);
+
   // prefetch the spectrum row of step 0
   float2 X[V];
   float xn;
@@ -87,11 +91,13 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
   for (int s = 0; s < nsteps; ++s) {
     const int q = s * SPB + j;                          // row (relative to r0 - 1) this sequence transforms
     const bool a_live = q <= R + 1;
-    const int h = (r0 - 1 + q + H) % H;
+    int h = r0 - 1 + q;                                 // circular rows: at most one wrap either way
+    h = h < 0 ? h + H : (h >= H ? h - H : h);
     const int qz = q - 1;                               // row this sequence updates (x[qz] from LDS, x[qz+1] own)
     const bool z_live = qz >= 0 && qz <= R;
     const bool z_own = qz >= 1 && qz <= R;              // rows of this band (row qz = 0 is the halo above)
-    const int hz = (r0 - 1 + qz + 2 * H) % H;
+    int hz = r0 - 1 + qz;
+    hz = hz < 0 ? hz + H : (hz >= H ? hz - H : hz);
     // ---- issue the u loads of phase B now: the inverse transform below covers their latency ----
     float2 ureg[NT][V];
 #pragma unroll
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
       }
     }
     WaveSync()();
-    fft_reg<M, T, +1>(xa, myfft, t, twW, 2, WaveSync());    // xa[m] = (x[2n], x[2n+1]), n = t + m*T
+    fft_reg_tw<M, T, +1, false>(xa, myfft, t, twr, WaveSync());   // xa[m] = (x[2n], x[2n+1]), n = t + m*T
     if (a_live) {
       float2* xr = xring + (q % RING) * M;
 #pragma unroll
@@ -131,9 +137,8 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
     DPX_LDS_BARRIER();
     // ---------------- phase B: z / dual update of row qz ----------------
     float2 acc[V];                                        // K^T (v - u) accumulated over the terms (row-local parts)
-    float2 wh[V];                                         // (v - u) of the grad_H term on this row
 #pragma unroll
-    for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f), wh[m] = make_float2(0.f, 0.f);
+    for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f);
     {
       // every lane runs the arithmetic (the shuffles need converged T-lane groups); only memory writes are predicated
       const float2* xc_row = xring + ((qz + RING) % RING) * M;
@@ -180,9 +185,7 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
             const float wl = (t == 0) ? l_wrap : l_same;
             acc[m] = make_float2(acc[m].x + (wl - w[m].x), acc[m].y + (w[m].x - w[m].y));
           }
-        } else {
-#pragma unroll
-          for (int m = 0; m < V; ++m) wh[m] = w[m];
+        } else {                                          // grad_H: (v - u) goes to the ring, its adjoint is formed in phase C
           if (z_live) {
             float2* wr = wring + (qz % RING) * M;
 #pragma unroll
@@ -194,7 +197,8 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
     DPX_LDS_BARRIER();
     // ---- issue the spectrum loads of the next step's phase A: the forward transform below covers them ----
     if (s + 1 < nsteps && q + SPB <= R + 1) {
-      const int hn = (r0 - 1 + q + SPB + H) % H;
+      int hn = r0 - 1 + q + SPB;
+      hn = hn >= H ? hn - H : hn;
       const float2* in = sin_main + (unsigned)hn * 8u + tile_off;
 #pragma unroll
       for (int m = 0; m < V; ++m) X[m] = in[tile_step * m];
@@ -205,16 +209,17 @@ __global__ void __launch_bounds__(256) k_iter_rows(const float2* __restrict__ sp
       float2 z[V];
       if (hterm >= 0) {                                    // grad_H adjoint: y[h-1] - y[h]
         const float2* wp = wring + ((qz - 1 + RING) % RING) * M;
+        const float2* wc = wring + ((qz + RING) % RING) * M;
 #pragma unroll
         for (int m = 0; m < V; ++m) {
-          const float2 up = wp[t + m * T];
-          acc[m] = make_float2(acc[m].x + (up.x - wh[m].x), acc[m].y + (up.y - wh[m].y));
+          const float2 up = wp[t + m * T], cu = wc[t + m * T];
+          acc[m] = make_float2(acc[m].x + (up.x - cu.x), acc[m].y + (up.y - cu.y));
         }
       }
 #pragma unroll
       for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
       WaveSync()();
-      fft_reg<M, T, -1>(z, myfft, t, twW, 2, WaveSync());
+      fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
       float2* out = sout_main + (unsigned)hz * 8u + tile_off;
 #pragma unroll
       for (int m = 0; m < V; ++m) {
