@@ -176,6 +176,14 @@ def main():
                    "GBps": KERNEL_BYTES_PER_ELEM.get(k, 0.0) * n_elem / (1e-3 * t / c) / 1e9}
                for k, (c, t) in rep.items()}
     dom = max(rep, key=lambda k: rep[k][1])
+    # HBM traffic of the dominant kernel from the PMC counters: rocprofv3 cannot be run from inside this process, so the
+    # figure comes from the committed separate --pmc passes of this same command (tools/pmc_summary.py, profiles/)
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")
+    if os.path.exists(pmc_file):
+        for name, e in json.load(open(pmc_file)).items():
+            if name.split("<")[0] == dom and "hbm_traffic_bytes" in e:
+                traffic, traffic_src = e["hbm_traffic_bytes"], "profiles/r1_pmc_hbm.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
     dom_bytes = KERNEL_BYTES_PER_ELEM.get(dom, 0.0) * n_elem
     dom_avg_s = 1e-3 * rep[dom][1] / rep[dom][0]
     achieved = dom_bytes / dom_avg_s
@@ -189,7 +197,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "shape": [C, H, W], "parallelism": f"batch-shard x{world}"},
         "psnr_db": {"input_mean": float(np.mean(psnr_in)), "admm50_mean": float(np.mean(psnr_out)), "admm50_per_image": psnr_out},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "frac_of_measured_copy": achieved / HBM_COPY, "traffic": None,
+                     "frac": achieved / HBM_PEAK, "frac_of_measured_copy": achieved / HBM_COPY, "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_avg_s * 1e6},
         "roofline_iteration": {"algorithmic_bytes_per_iter": ITER_BYTES_PER_ELEM * n_elem,
                                "achieved_GBps": (it_per_s / world) * ITER_BYTES_PER_ELEM * n_elem / 1e9,

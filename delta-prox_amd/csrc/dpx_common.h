@@ -79,8 +79,12 @@ static inline int spec_cols(int W) { return (W + 1) / 2; }
 // COLUMN-TILE-MAJOR, [Ws/8][H][8] -- each 8-column tile is contiguous, so every stream of the column
 // kernel is a linear 512-byte-per-wave-instruction access -- and the Nyquist bins live in the side part.
 bool pow2_path_available(int H, int W);
+#ifndef DPX_SPEC_TILE
+#define DPX_SPEC_TILE 8            // columns per spectrum tile of the power-of-two layout (4 or 8)
+#endif
+constexpr int SPEC_TILE = DPX_SPEC_TILE;
 __host__ __device__ __forceinline__ size_t spec_main_index(int tiled, int H, int Ws, int k, int l) {
-  return tiled ? ((size_t)(l >> 3) * H + k) * 8 + (l & 7) : (size_t)k * Ws + l;
+  return tiled ? ((size_t)(l / SPEC_TILE) * H + k) * SPEC_TILE + (l % SPEC_TILE) : (size_t)k * Ws + l;
 }
 // table = all planes' main parts [C][H*Ws] followed by all side parts [C][H]
 static inline size_t table_elems(int C, int H, int W) { return (size_t)C * H * spec_cols(W) + (size_t)C * H; }

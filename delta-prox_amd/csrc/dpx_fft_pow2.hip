@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x
   const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
   // column-tile-major spectrum: bin k of image row h of plane pl -> pl*H*M + ((k >> 3)*H + h)*8 + (k & 7)
   const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H;
-  float2* out = spec + (size_t)pl * H * M + (size_t)hh * 8 + (t & 7) + (size_t)(t >> 3) * H * 8;
+  float2* out = spec + (size_t)pl * H * M + (size_t)hh * SPEC_TILE + (t % SPEC_TILE) + (size_t)(t / SPEC_TILE) * H * SPEC_TILE;
 #pragma unroll
   for (int m = 0; m < V; ++m) {
     const float2 got = make_float2(__shfl(v[V - 1 - m].x, plane), __shfl(v[V - 1 - m].y, plane));
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x
       const float2 d = cscale(csub(zk, zm), 0.5f);
       X = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
     }
-    if (live) out[(size_t)m * (T / 8) * H * 8] = X;     // k = t + m*T: tile index advances by T/8 per m
+    if (live) out[(size_t)m * (T / SPEC_TILE) * H * SPEC_TILE] = X;     // k = t + m*T: tile index advances by T/SPEC_TILE per m
   }
 }
 
@@ -67,10 +67,10 @@ __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ 
   const int row = blockIdx.x * SPB + seq;
   const bool live = row < nrows;
   const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H;
-  const float2* in = spec + (size_t)pl * H * M + (size_t)hh * 8 + (t & 7) + (size_t)(t >> 3) * H * 8;
+  const float2* in = spec + (size_t)pl * H * M + (size_t)hh * SPEC_TILE + (t % SPEC_TILE) + (size_t)(t / SPEC_TILE) * H * SPEC_TILE;
   float2 X[V], v[V];
 #pragma unroll
-  for (int m = 0; m < V; ++m) X[m] = in[(size_t)m * (T / 8) * H * 8];
+  for (int m = 0; m < V; ++m) X[m] = in[(size_t)m * (T / SPEC_TILE) * H * SPEC_TILE];
   const int lane = tid & 63;
   const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
 #pragma unroll
@@ -135,12 +135,12 @@ __global__ void __launch_bounds__(T* COLS) k_cols_p2(const float2* __restrict__ 
   int p;
   if (!is_side) {
     p = bid / tiles;
-    const int j = (bid - p * tiles) * (COLS / 8);     // first 8-column tile of this workgroup
-    ubase = (size_t)p * H * Ws + (size_t)j * H * 8;   // tile-major main part: element (row r, col c) of a tile at r*8 + c
-    off0 = (unsigned)((c >> 3) * H * 8 + t * 8 + (c & 7));
-    step = (unsigned)(T * 8);
+    const int j = (bid - p * tiles) * (COLS / SPEC_TILE);     // first spectrum tile of this workgroup
+    ubase = (size_t)p * H * Ws + (size_t)j * H * SPEC_TILE;   // tile-major main part: element (row r, col c) of a tile at r*TILE + c
+    off0 = (unsigned)((c / SPEC_TILE) * H * SPEC_TILE + t * SPEC_TILE + (c % SPEC_TILE));
+    step = (unsigned)(T * SPEC_TILE);
     toff0 = off0;
-    tbase = (unsigned)((p % C) * H * Ws + j * H * 8);
+    tbase = (unsigned)((p % C) * H * Ws + j * H * SPEC_TILE);
   } else {
     p = (bid - nmain) * COLS + c;
     if (p >= P) p = P - 1;                            // (P not a multiple of COLS: duplicate work, identical values)
@@ -221,32 +221,19 @@ static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A,
              spec_out, A, C, Ws, P, twH);
 }
 
-static int cols_per_tile() {           // tuning knob (default 8): DPX_COLS=16 selects 16-column tiles for H = 1024
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DPX_COLS");
-    v = (e && atoi(e) == 16) ? 16 : 8;
-  }
-  return v;
-}
-
 template <int OP>
 static void cols_dispatch(int H, const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
-  if (H == 1024 && cols_per_tile() == 16) {
-    launch_cols<1024, 64, 16, OP>(spec, spec_out, A, P, C, Ws, twH, s);
-    return;
-  }
   if (H == 1024 && OP == OP_SOLVE) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("DPX_DEBUG_COLS"); dbg = e ? atoi(e) : 0; }
-    if (dbg == 1) { launch_cols<1024, 64, 8, OP, 1>(spec, spec_out, A, P, C, Ws, twH, s); return; }
-    if (dbg == 2) { launch_cols<1024, 64, 8, OP, 2>(spec, spec_out, A, P, C, Ws, twH, s); return; }
-    if (dbg == 3) { launch_cols<1024, 64, 8, OP, 3>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 1) { launch_cols<1024, 64, SPEC_TILE, OP, 1>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 2) { launch_cols<1024, 64, SPEC_TILE, OP, 2>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 3) { launch_cols<1024, 64, SPEC_TILE, OP, 3>(spec, spec_out, A, P, C, Ws, twH, s); return; }
   }
   switch (H) {
-    case 256: launch_cols<256, 32, 8, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
-    case 512: launch_cols<512, 64, 8, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
-    default: launch_cols<1024, 64, 8, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 256: launch_cols<256, 32, SPEC_TILE, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 512: launch_cols<512, 64, SPEC_TILE, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    default: launch_cols<1024, 64, SPEC_TILE, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
   }
 }
 

@@ -62,8 +62,8 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
   const float2* sin_side = spec_in + (size_t)P * H * M + (size_t)pl * H;
   float2* sout_main = spec_out + (size_t)pl * H * M;
   float2* sout_side = spec_out + (size_t)P * H * M + (size_t)pl * H;
-  const unsigned tile_off = (unsigned)((t & 7) + (t >> 3) * H * 8);   // bin t of a row in the tile-major spectrum
-  const unsigned tile_step = (unsigned)((T / 8) * H * 8);            // bin t + m*T
+  const unsigned tile_off = (unsigned)((t % SPEC_TILE) + (t / SPEC_TILE) * H * SPEC_TILE);   // bin t of a row in the tile-major spectrum
+  const unsigned tile_step = (unsigned)((T / SPEC_TILE) * H * SPEC_TILE);            // bin t + m*T
   const float rho = rho_next ? rho_next[bi] : 0.f;
   float2* myfft = fft_lds + j * S;
   int hterm = -1;
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
   float xn;
   {
     const int h = (r0 - 1 + j + H) % H;
-    const float2* in = sin_main + (unsigned)h * 8u + tile_off;
+    const float2* in = sin_main + (unsigned)h * SPEC_TILE + tile_off;
 #pragma unroll
     for (int m = 0; m < V; ++m) X[m] = in[tile_step * m];
     xn = sin_side[h].x;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
     if (s + 1 < nsteps && q + SPB <= R + 1) {
       int hn = r0 - 1 + q + SPB;
       hn = hn >= H ? hn - H : hn;
-      const float2* in = sin_main + (unsigned)hn * 8u + tile_off;
+      const float2* in = sin_main + (unsigned)hn * SPEC_TILE + tile_off;
 #pragma unroll
       for (int m = 0; m < V; ++m) X[m] = in[tile_step * m];
       xn = sin_side[hn].x;
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
       for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
       WaveSync()();
       fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
-      float2* out = sout_main + (unsigned)hz * 8u + tile_off;
+      float2* out = sout_main + (unsigned)hz * SPEC_TILE + tile_off;
 #pragma unroll
       for (int m = 0; m < V; ++m) {
         const float2 got = make_float2(__shfl(z[V - 1 - m].x, pair), __shfl(z[V - 1 - m].y, pair));

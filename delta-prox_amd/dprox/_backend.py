@@ -14,7 +14,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_long,
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdpx_hip.so")
+# DPX_LIB selects another *HIP* build of the same library (kernel tuning experiments); never a non-HIP substitute
+LIB_PATH = os.environ.get("DPX_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdpx_hip.so")
 
 PROX_NORM1, PROX_NONNEG, PROX_SUMSQ, PROX_EXTERNAL = 0, 1, 2, 3
 LIN_IDENTITY, LIN_GRAD_H, LIN_GRAD_W = 0, 1, 2
