@@ -85,13 +85,46 @@ __global__ void k_ffd_unpack_out(const float* __restrict__ o, float* __restrict_
   }
 }
 
+// NP channel pairs x 9 taps, fully unrolled; the LDS fragments of step k+1 are fetched while step k multiplies
+template <int MT, int NP>
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __restrict__ sin_b, const float* __restrict__ sw_b) {
+  constexpr int M32 = MT * 32, NS = NP * 9;
+  float a_cur[MT], b_cur[2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) a_cur[mt] = sw_b[mt * 32];
+  b_cur[0] = sin_b[0];
+  b_cur[1] = sin_b[FFD_LDW];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    float a_nxt[MT], b_nxt[2];
+    if (k + 1 < NS) {
+      const int cp = (k + 1) / 9, tap = (k + 1) % 9, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = sw_b[(cp * 9 + tap) * 2 * M32 + mt * 32];
+      b_nxt[0] = sin_b[(2 * cp * FFD_ROWS + dy) * FFD_LDW + dx];
+      b_nxt[1] = sin_b[(2 * cp * FFD_ROWS + dy + 1) * FFD_LDW + dx];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[0], acc[mt][0], 0, 0, 0);
+      acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[1], acc[mt][1], 0, 0, 0);
+    }
+    if (k + 1 < NS) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+      b_cur[0] = b_nxt[0];
+      b_cur[1] = b_nxt[1];
+    }
+  }
+}
+
 // in [B][Cin][H2][W2] (Cin even), out [B][Cout][H2][W2]; wpk = packed layer (see layer_floats)
 template <int MT, bool RELU>
 __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x) {
   constexpr int M32 = MT * 32;
-  __shared__ float s_in[FFD_CK * FFD_ROWS * FFD_LDW];          // [ch][row][col]
-  __shared__ float s_w[(FFD_CK / 2) * 9 * 2 * M32];            // [pair][tap][half][cout]
+  __shared__ float s_in[2 * FFD_CK * FFD_ROWS * FFD_LDW];                              // 2 x [ch][row][col]
+  __shared__ __attribute__((aligned(16))) float s_w[2 * (FFD_CK / 2) * 9 * 2 * M32];  // 2 x [pair][tap][half][cout]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -108,38 +141,59 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  for (int c0 = 0; c0 < Cin; c0 += FFD_CK) {
-    const int nch = min(FFD_CK, Cin - c0);                     // even
-    // ---- stage the input tile (zero padding outside the image) ----
-    for (int i = tid; i < nch * FFD_ROWS * 34; i += 256) {
-      const int col = i % 34;
-      const int r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
+  // Software pipeline over chunks of FFD_CK input channels: while the matrix cores work on chunk c (LDS buffer c&1) the
+  // global loads of chunk c+1 are in flight into registers; they are written to the other LDS buffer after the MFMAs and
+  // one barrier per chunk hands the buffers over.
+  constexpr int NI = (FFD_CK * FFD_ROWS * 34 + 255) / 256;                 // input-tile elements per thread
+  constexpr int NW4 = ((FFD_CK / 2) * 9 * 2 * M32 / 4 + 255) / 256;        // weight float4s per thread
+  float in_reg[NI];
+  float4 w_reg[NW4];
+  auto fetch = [&](int c0) {
+    const int nch = min(FFD_CK, Cin - c0);
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      const int i = tid + 256 * e;
+      const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
       const int yy = y0 + r - 1, xx = x0 + col - 1;
       float v = 0.f;
-      if (yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = inb[((size_t)(c0 + ch) * H2 + yy) * W2 + xx];
-      s_in[(ch * FFD_ROWS + r) * FFD_LDW + col] = v;
+      if (ch < nch && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = inb[((size_t)(c0 + ch) * H2 + yy) * W2 + xx];
+      in_reg[e] = v;
     }
-    // ---- stage the weight chunk (linear copy of the packed blob) ----
-    const float* wsrc = wpk + (size_t)(c0 / 2) * 9 * 2 * M32;
-    for (int i = tid; i < (nch / 2) * 9 * 2 * M32; i += 256) s_w[i] = wsrc[i];
-    __syncthreads();
-    // ---- MFMA: K-step = (channel pair, tap) ----
-    for (int cp = 0; cp < nch / 2; ++cp) {
-      const float* sin_c = s_in + ((2 * cp + half) * FFD_ROWS + 2 * wave) * FFD_LDW + j;
-      const float* sw_c = s_w + (cp * 9 * 2 + half) * M32 + j;
+    const float4* wsrc = (const float4*)(wpk + (size_t)(c0 / 2) * 9 * 2 * M32);
+    const int n4 = (nch / 2) * 9 * 2 * M32 / 4;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
-        const float b0 = sin_c[(dy + 0) * FFD_LDW + dx];       // output row 2*wave + 0
-        const float b1 = sin_c[(dy + 1) * FFD_LDW + dx];       // output row 2*wave + 1
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float a = sw_c[tap * 2 * M32 + mt * 32];
-          acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[mt][0], 0, 0, 0);
-          acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[mt][1], 0, 0, 0);
-        }
-      }
+    for (int e = 0; e < NW4; ++e) {
+      const int i = tid + 256 * e;
+      w_reg[e] = i < n4 ? wsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto commit = [&](int buf) {
+    float* si = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW);
+    float4* sw = (float4*)(s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32));
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      const int i = tid + 256 * e;
+      const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
+      if (ch < FFD_CK) si[(ch * FFD_ROWS + r) * FFD_LDW + col] = in_reg[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NW4; ++e) {
+      const int i = tid + 256 * e;
+      if (i < (FFD_CK / 2) * 9 * 2 * M32 / 4) sw[i] = w_reg[e];
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int c0 = 0; c0 < Cin; c0 += FFD_CK, buf ^= 1) {
+    const int nch = min(FFD_CK, Cin - c0);                     // even
+    const bool more = c0 + FFD_CK < Cin;
+    if (more) fetch(c0 + FFD_CK);
+    const float* sin_b = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW) + (half * FFD_ROWS + 2 * wave) * FFD_LDW + j;
+    const float* sw_b = s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32) + half * M32 + j;
+    for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * 9 * 2 * M32);
+    if (more) commit(buf ^ 1);
     __syncthreads();
   }
   // ---- epilogue: bias, ReLU, store.  C/D layout: col = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cout) ----
