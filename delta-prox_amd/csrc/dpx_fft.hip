@@ -483,6 +483,67 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// complex 2-D transform with the centring shifts fused (utils.fft2 / ifft2 of the reference:
+// ifftshift -> fft2(norm='ortho') -> fftshift, dprox/utils/misc.py:164-193) -- the building block of
+// user-defined CS-MRI operators (mask * fft2(x)).  Any size (same Stockham core as above).
+//   centred: input index (i + N/2) % N is read at position i, output bin k is stored at (k + N/2) % N
+// ---------------------------------------------------------------------------------------------
+template <int DIR>
+__global__ void k_crows(const float2* __restrict__ in, float2* __restrict__ out, int W, int nrows, Plan1D plan,
+                        const float2* __restrict__ twW, int rpb, int centred, float scale) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  const int ld = W + 1, hs = centred ? W / 2 : 0;
+  float2* a = smem;
+  float2* b = smem + rpb * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int row0 = blockIdx.x * rpb;
+  const int nseq = min(rpb, nrows - row0);
+  for (int i = tid; i < nseq * W; i += nthr) {
+    const int s = i / W, n = i - s * W;
+    int src = n + hs;
+    if (src >= W) src -= W;
+    a[s * ld + n] = in[(size_t)(row0 + s) * W + src];
+  }
+  __syncthreads();
+  const Twid<float2> twd{twW, W};
+  const float2* z = fft_lds<DIR, float2>(a, b, plan, twd, 1, nseq, ld, tid, nthr);
+  for (int i = tid; i < nseq * W; i += nthr) {
+    const int s = i / W, k = i - s * W;
+    int dst = k + hs;
+    if (dst >= W) dst -= W;
+    out[(size_t)(row0 + s) * W + dst] = cscale(z[s * ld + k], scale);
+  }
+}
+
+template <int DIR>
+__global__ void k_ccols(float2* __restrict__ data, int H, int W, Plan1D plan, const float2* __restrict__ twH, int CT, int centred) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  const int ld = H + 1, hs = centred ? H / 2 : 0;
+  float2* a = smem;
+  float2* b = smem + CT * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int p = blockIdx.y, l0 = blockIdx.x * CT;
+  const int nseq = min(CT, W - l0);
+  float2* base = data + (size_t)p * H * W;
+  for (int i = tid; i < H * nseq; i += nthr) {
+    const int r = i / nseq, c = i - r * nseq;
+    int src = r + hs;
+    if (src >= H) src -= H;
+    a[c * ld + r] = base[(size_t)src * W + l0 + c];
+  }
+  __syncthreads();
+  const Twid<float2> twd{twH, H};
+  const float2* z = fft_lds<DIR, float2>(a, b, plan, twd, 1, nseq, ld, tid, nthr);
+  __syncthreads();      // (all loads of this tile happened before the first pass; stores below are in place)
+  for (int i = tid; i < H * nseq; i += nthr) {
+    const int k = i / nseq, c = i - k * nseq;
+    int dst = k + hs;
+    if (dst >= H) dst -= H;
+    base[(size_t)dst * W + l0 + c] = z[c * ld + k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 size_t pow2_spec_elems(int P, int H, int W);
@@ -605,4 +666,31 @@ extern "C" int dpx_fourier_solve(const float* rhs, float* x, const void* spec_ad
   a.eps = eps;
   a.scale = 1.0f / ((float)H * (float)W);
   return spectral_apply(rhs, x, OP_SOLVE, a, B, C, H, W, table, ws, (hipStream_t)stream);
+}
+
+extern "C" int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, int P, int H, int W, const void* table,
+                         dpx_stream_t stream) {
+  DPX_REQUIRE(in && out && table && in != out, "dpx_cfft2: null or aliased pointers");
+  DPX_REQUIRE(P > 0 && H > 0 && W > 0, "dpx_cfft2: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const Plan1D prow = make_plan(W), pcol = make_plan(H);
+  const int rpb = rows_per_block(W);
+  const size_t shrow = (size_t)2 * rpb * (W + 1) * sizeof(float2);
+  int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
+  CT = CT < 1 ? 1 : (CT > 16 ? 16 : CT);
+  const size_t shcol = (size_t)2 * CT * (H + 1) * sizeof(float2);
+  if (shrow > 64 * 1024 || shcol > 64 * 1024) {
+    set_error("dpx_cfft2: plane %dx%d too large for the LDS-resident transform", H, W);
+    return DPX_ERR_UNSUPPORTED;
+  }
+  const float scale = ortho ? 1.0f / sqrtf((float)H * (float)W) : (inverse ? 1.0f / ((float)H * (float)W) : 1.0f);
+  const dim3 grow((P * H + rpb - 1) / rpb), gcol((W + CT - 1) / CT, P);
+  if (!inverse) {
+    DPX_LAUNCH("k_crows", (k_crows<-1>), grow, dim3(256), shrow, s, (const float2*)in, (float2*)out, W, P * H, prow, tw_rows(table), rpb, centred, scale);
+    DPX_LAUNCH("k_ccols", (k_ccols<-1>), gcol, dim3(256), shcol, s, (float2*)out, H, W, pcol, tw_cols(table, W), CT, centred);
+  } else {
+    DPX_LAUNCH("k_crows", (k_crows<+1>), grow, dim3(256), shrow, s, (const float2*)in, (float2*)out, W, P * H, prow, tw_rows(table), rpb, centred, scale);
+    DPX_LAUNCH("k_ccols", (k_ccols<+1>), gcol, dim3(256), shcol, s, (float2*)out, H, W, pcol, tw_cols(table, W), CT, centred);
+  }
+  return launch_status("dpx_cfft2");
 }

@@ -338,3 +338,17 @@ def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, 
     if rc < 0:
         raise be.DpxError(f"dpx_admm_run failed ({rc}): {L.cdll.dpx_last_error().decode()}")
     return rc
+
+
+def cfft2(x, inverse=False, centred=True, ortho=True):
+    """complex64 2-D FFT over the last two dims (hand-written kernels; centring shifts and normalisation fused)"""
+    if not x.is_complex():
+        x = torch.complex(x.float(), torch.zeros_like(x, dtype=torch.float32))
+    x = x.to(torch.complex64).contiguous()
+    require(x, dtype=torch.complex64, what="cfft2 input")
+    H, W = int(x.shape[-2]), int(x.shape[-1])
+    P = x.numel() // (H * W)
+    out = torch.empty_like(x)
+    be.lib().call("dpx_cfft2", ptr(x), ptr(out), int(bool(inverse)), int(bool(centred)), int(bool(ortho)), P, H, W,
+                  ptr(fft_table(H, W, x.device)), be.stream())
+    return out

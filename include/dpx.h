@@ -103,6 +103,11 @@ int dpx_fourier_solve(const float* rhs, float* x, const void* spec_add, const vo
                       const float* rho, float eps, int B, int C, int H, int W,
                       const void* table, void* spectrum_ws, dpx_stream_t stream);
 
+/* complex64 2-D FFT of P planes, optionally centred (ifftshift -> fft2 -> fftshift) and orthonormal: utils.fft2 / ifft2,
+ * dprox/utils/misc.py:164-193 (used by CS-MRI style operators mask * fft2(x)).  Out of place, any size.        */
+int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, int P, int H, int W, const void* table,
+              dpx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* spatial operators and fused ADMM steps                                                      */
 /* ------------------------------------------------------------------------------------------ */

@@ -388,6 +388,17 @@ def g10_pgd():
     save("g10_pgd", b=b, psf=psf, x_norm1=out, x_nonneg_rhoB=out2)
 
 
+def g14_other_algorithms():
+    """the remaining splitting algorithms on the same kernels (ADMM_vxu, HQS, Pock-Chambolle)."""
+    gt, b, psf = synthetic.deconv_case(2, 3, 32, 40, seed=140)
+    out = {"b": b, "psf": psf}
+    for method in ("admm_vxu", "hqs", "pc"):
+        x = dp.Variable()
+        fns = dp.sum_squares(dp.conv(x, psf) - T(b)) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
+        out[method] = dp.Problem(fns).solve(method=method, device="cpu", x0=T(b), rhos=0.3, lams=0.01, max_iter=6)
+    save("g14_other_algorithms", **out)
+
+
 def g12_log_descent():
     out = {}
     for tag, kw in (("35_5_30", dict(upper=35, lower=5, iter=30)), ("49_7_24_s", dict(upper=49, lower=7, iter=24, sigma=7.65 / 255)),
@@ -423,6 +434,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g12_log_descent, g13_known_answers):
+               g9_admm_pnp, g10_pgd, g12_log_descent, g13_known_answers, g14_other_algorithms):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -284,3 +284,14 @@ def case_ladmm_cg(device):
     close_on_scale(st[1][1], g["v1"], g["x"], 2 * TOL, "v1")
     close_on_scale(st[2][0], g["u0"], g["x"], 5 * TOL, "u0")
     assert_close(xa.cpu(), g["x_admm"], 2 * TOL, "admm+cg x")
+
+
+def case_other_algorithms(device):
+    """G14: ADMM_vxu / HQS / Pock-Chambolle through the generic path (same HIP primitives, different update order)"""
+    g = load_golden("g14_other_algorithms")
+    b = T(g["b"], device)
+    for method in ("admm_vxu", "hqs", "pc"):
+        x = dp.Variable()
+        fns = dp.sum_squares(dp.conv(x, g["psf"]) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
+        out = dp.Problem(fns).solve(method=method, device=device, x0=b, rhos=0.3, lams=0.01, max_iter=6)
+        assert_close(out.cpu(), g[method], TOL, method)

@@ -59,5 +59,9 @@ def test_ffdnet_mfma_layout():
     pc.case_ffdnet(DEV, which=("batch",))       # 2x3x16x24: the f32 MFMA lane layouts + pack / unpack, emulated
 
 
+def test_other_algorithms():
+    pc.case_other_algorithms(DEV)
+
+
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV, shape=(1, 3, 24, 20))

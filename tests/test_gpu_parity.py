@@ -72,6 +72,10 @@ def test_ladmm_cg():
     pc.case_ladmm_cg(DEV)
 
 
+def test_other_algorithms():
+    pc.case_other_algorithms(DEV)
+
+
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV)
 
