@@ -20,6 +20,38 @@
 #define DPX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// ---- LDS-DMA (global -> LDS without touching VGPRs) and hand-counted waits -----------------------------
+// dpx_glds16 / dpx_glds4: every lane names its own 16 / 4 source bytes; the wave's 64 pieces land lane-linearly at
+// lds_wave_base (+ lane * size).  hipcc does not see these loads: the kernel counts them itself with
+// dpx_wait_vm<N>() ("all but the N most recent vector-memory operations of this wave have completed"; loads,
+// LDS-DMA and stores retire in issue order on gfx9-family vmcnt) before it reads the landed bytes, and calls
+// dpx_wait_lds() (this wave's LDS reads have returned) before it re-targets a staging area.
+#ifdef DPX_EMULATED
+#include <cstring>
+__device__ inline void dpx_glds16(const void* g, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, g, 16); }
+__device__ inline void dpx_glds4(const void* g, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 4, g, 4); }
+template <int N> __device__ inline void dpx_wait_vm() { __builtin_amdgcn_wave_barrier(); }
+__device__ inline void dpx_wait_lds() { __builtin_amdgcn_wave_barrier(); }
+#else
+__device__ __forceinline__ void dpx_glds16(const void* g, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void dpx_glds4(const void* g, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void dpx_wait_vm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void dpx_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
+
 namespace dpx {
 
 // ---- error reporting (thread-local last error, int status across the ABI) -------------------

@@ -118,7 +118,10 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
 // ---------------------------------------------------------------------------------------------
 // DBG (tuning experiments only, default 0): bit0 = skip both transforms, bit1 = skip the operator's table loads
 template <int H, int T, int COLS, int OP, int DBG = 0>
-__global__ void __launch_bounds__(T* COLS) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
+#ifndef DPX_COLS_WPE
+#define DPX_COLS_WPE ((T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for
+#endif
+__global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
                                                       int C, int Ws, int P, const float2* __restrict__ twH) {
   constexpr int V = H / T;
   constexpr int S0 = LdsSeq<H>::SLOTS;
@@ -154,22 +157,82 @@ __global__ void __launch_bounds__(T* COLS) k_cols_p2(const float2* __restrict__ 
   const char* pin = (const char*)(spec_in + ubase);
   char* pout = (char*)(spec_out + ubase);
   float2* lds = smem_p2 + c * S;
+  float2* twl = smem_p2 + COLS * S;                   // the H column twiddles, shared by the workgroup
   float2 v[V];
 #pragma unroll
   for (int m = 0; m < V; ++m) v[m] = *(const float2*)(pin + (off0 + step * m) * 8u);
-  if (!(DBG & 1)) fft_reg<H, T, -1>(v, lds, t, twH, 1, BlockSync());
+  for (int i = tid; i < H; i += T * COLS) twl[i] = twH[i];
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const char* add = (OP == OP_SOLVE && A.add) ? (const char*)(A.add + ubase) : nullptr;
-#pragma unroll
-  for (int m = 0; m < V; ++m) {
-    float2 z = v[m];
-    if (add) z = cadd(z, *(const float2*)(add + (off0 + step * m) * 8u));
-    if (DBG & 2) v[m] = cscale(z, A.scale);
-    else v[m] = spec_op_p2<OP>(z, A, tbase + toff0 + step * m, rho_b);
-    if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-  }
   DPX_LDS_BARRIER();
-  if (!(DBG & 1)) fft_reg<H, T, +1>(v, lds, t, twH, 1, BlockSync());
+
+  // The operator's table values of the tile (SOLVE: the interleaved denominators) are fetched by LDS-DMA into the
+  // transform's exchange buffer while it is idle -- between the forward transform's last LDS read and the inverse
+  // transform's first write -- so that they cost no registers; each wave fetches exactly the rows its own lanes use
+  // (lane-linear image: float2 index m*64 + lane of the wave's 8 KB), so its own vmcnt wait is all the
+  // synchronisation the data needs.  The data-spectrum values (HBM) are requested in one batch right behind them:
+  // ONE memory round trip between the two transforms.
+  constexpr bool DMA_TABLE = (OP == OP_SOLVE) && (COLS == 8) && (V % 2 == 0) && !(DBG & 2);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float2* tstage = smem_p2 + wave * (64 * V);
+  auto fetch_table = [&]() {
+    if (DMA_TABLE && !is_side) {
+      DPX_LDS_BARRIER();                                // every wave has read its last-pass inputs
+      // piece j: rows T*(2j + half) + 8*wave + li/4 (half = lane / 32, li = lane % 32), columns 2*(li % 4), +1
+      int ln = lane;
+      DPX_OPAQUE(ln);                                   // derive the source address here, not at kernel entry
+      const int half = ln >> 5, li = ln & 31;
+      const float2* src = A.dd + tbase + (unsigned)((T * half + 8 * wave + (li >> 2)) * SPEC_TILE + (li & 3) * 2);
+#pragma unroll
+      for (int j = 0; j < V / 2; ++j) dpx_glds16(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
+    }
+  };
+  if (!(DBG & 1)) {
+    fft_reg<H, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (OP == OP_SOLVE) {
+    float2 av[V];
+    unsigned offa = off0;
+    DPX_OPAQUE(offa);
+    if (add) {
+#pragma unroll
+      for (int m = 0; m < V; ++m) av[m] = *(const float2*)(add + (offa + step * m) * 8u);
+    } else {
+#pragma unroll
+      for (int m = 0; m < V; ++m) av[m] = make_float2(0.f, 0.f);
+    }
+    if (DMA_TABLE && !is_side) {
+      if (add) dpx_wait_vm<V>();                        // the V data-spectrum loads above may stay in flight
+      else dpx_wait_vm<0>();
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 dv = tstage[m * 64 + (offa & 0) + lane];
+        const float2 z = cadd(v[m], av[m]);
+        const float den = fmaf(rho_b, dv.y, dv.x) + A.eps;
+        const float inv = A.scale / den;
+        v[m] = make_float2((z.x + A.eps) * inv, z.y * inv);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 z = cadd(v[m], av[m]);
+        if (DBG & 2) v[m] = cscale(z, A.scale);
+        else v[m] = spec_op_p2<OP>(z, A, tbase + toff0 + step * m, rho_b);
+        if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+      v[m] = spec_op_p2<OP>(v[m], A, tbase + toff0 + step * m, rho_b);
+      if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  DPX_LDS_BARRIER();
+  if (!(DBG & 1)) fft_reg<H, T, +1>(v, lds, t, twl, 1, BlockSync());
   unsigned off1 = off0;
   DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores
 #pragma unroll
@@ -211,7 +274,7 @@ template <int H, int T, int COLS, int OP, int DBG = 0>
 static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
   constexpr int S0 = LdsSeq<H>::SLOTS;
   constexpr int S = S0 + ((36 - S0 % 32) % 32);
-  const size_t sh = (size_t)COLS * S * sizeof(float2);
+  const size_t sh = (size_t)(COLS * S + H) * sizeof(float2);
   static bool attr_done = false;
   if (!attr_done && sh > 48 * 1024) {
     hipFuncSetAttribute((const void*)k_cols_p2<H, T, COLS, OP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

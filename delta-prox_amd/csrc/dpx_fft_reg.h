@@ -82,9 +82,14 @@ template <int DIR> __device__ __forceinline__ float2 twmul(float2 a, float2 w) {
 // lds: this sequence's LdsSeq<N>::SLOTS float2 slots; tw: exp(-2 pi i k / (N*TWS)) table, stride TWS;
 // sync(): barrier over (at least) the T threads of the sequence.  Ends with all LDS reads done but NOT
 // synchronised: call sync() before the same LDS region is written again.
-template <int N, int T, int DIR, class Sync>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_reads(): called once, right after the last LDS read of the transform has been issued and before the last
+// pass's arithmetic -- the place to start memory traffic that should overlap that arithmetic.
+template <int N, int T, int DIR, class Sync, class Hook = NoHook>
 __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__ lds, int t, const float2* __restrict__ tw,
-                                        int tws, Sync sync) {
+                                        int tws, Sync sync, Hook after_reads = Hook()) {
   DPX_OPAQUE(t);      // every call re-derives its few index registers instead of keeping all of them alive
   constexpr int V = N / T;
   constexpr int RM = N / (V * V);
@@ -125,6 +130,7 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
   // of four so that at most four of them are live at a time (register pressure at V = 16).
 #pragma unroll
   for (int m = 0; m < V; ++m) v[m] = lds[lds_slot(t + m * T)];
+  after_reads();
   const unsigned tstep = (unsigned)(t * tws);
 #pragma unroll
   for (int m = 1; m < V; ++m) {
@@ -140,11 +146,11 @@ template <int N, int T, bool KEEPB = true> struct TwRegs {
   static constexpr int V = N / T, RM = N / (V * V), NB = (RM > 1) ? V / RM : 0;
   float2 b[(RM > 1 && KEEPB) ? NB * (RM - 1) : 1];
   float2 c[V - 1];
-  const float2* tw_;
-  int tws_;
+  const float2* twb_;      // pass-B twiddles W_{V*RM}^j at twb_[j * bstride_] (the global table, or a 64-entry LDS copy)
+  int bstride_;
   __device__ __forceinline__ void load(int t, const float2* __restrict__ tw, int tws) {
-    tw_ = tw;
-    tws_ = tws;
+    twb_ = tw;
+    bstride_ = V * tws;
     if constexpr (RM > 1 && KEEPB) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -186,7 +192,7 @@ __device__ __forceinline__ void fft_reg_tw(float2 (&v)[N / T], float2* __restric
 #pragma unroll
       for (int mm = 1; mm < RM; ++mm) {
         if constexpr (KEEPB) a[mm] = twmul<DIR>(a[mm], W.b[i * (RM - 1) + mm - 1]);
-        else a[mm] = twmul<DIR>(a[mm], W.tw_[(k * mm * V) * W.tws_]);
+        else a[mm] = twmul<DIR>(a[mm], W.twb_[(k * mm) * W.bstride_]);
       }
       rdft<RM, DIR>(a);
       const int j0 = (jb - k) * RM + k;

@@ -14,6 +14,9 @@
 // Row dependencies (grad along H couples row h with h+1 in K and h-1 in K^T) are handled inside a workgroup:
 // its SPB row-sequences advance through the band in lock step, a ring of SPB+1 rows of x and of (v-u) lives in
 // LDS, and one halo row above / below the band is recomputed (R+2 inverse transforms for R rows).
+#include <cstdlib>
+#include <cstring>
+
 #include "dpx_fft_reg.h"
 
 namespace dpx {
@@ -272,6 +275,284 @@ static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& T
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// k_iter_rows_seq: the same band update as k_iter_rows, organised so that HBM streams continuously.
+//
+// One T-lane group (a whole wave when T = 64) owns a band of R rows and walks down it row by row:
+//   * the neighbouring rows the stencils need (x[h] for grad_H, (v-u)[h-1] for its adjoint) are simply the
+//     previous step's registers -- no LDS rings, no workgroup barriers, waves never wait for each other;
+//   * the next spectrum row and the next u rows are fetched by LDS-DMA (global_load_lds, no VGPRs) one full step
+//     ahead into a wave-private staging area, so every wave always has ~(1 + NT) rows in flight while it
+//     computes; the waits are hand-counted vmcnt values (loads, LDS-DMA and stores retire in issue order), never 0
+//     in the steady state, so posted stores and the prefetch stay in flight across them;
+//   * the inverse untangling reads bin k and bin M-k straight from the staging area (no cross-lane shuffles).
+// Per band: R+2 inverse transforms, R+1 z-updates, R forward transforms (halo = one row above, one below).
+// The loop contains no compiler-visible global load (twiddles live in LDS / registers, per-image scalars are
+// read before the loop): hipcc therefore never inserts a vmcnt wait of its own that would drain the prefetch.
+template <int M, int T, int NT>
+__global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
+                                                        const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
+                                                        int C, int H, int bands, int P, const float2* __restrict__ twW) {
+  constexpr int V = M / T, G = 64 / T, S = LdsSeq<M>::SLOTS, D = V / 2, RM = M / (V * V);
+  constexpr int STG = 64 * V;                           // float2 per staged row set of one wave (G rows)
+  constexpr int PERWAVE = G * S + STG + 32 + NT * STG;
+  HIP_DYNAMIC_SHARED(float2, smem_sq)
+  float2* twl = smem_sq;                                // untangling twiddles exp(-i pi k / M), k < M
+  float2* twb = smem_sq + M;                            // pass-B twiddles W_{V*RM}^j, j < 64
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane / T, t = lane % T, lbase = lane & ~(T - 1);
+  float2* wl = twb + 64 + wave * PERWAVE;
+  float2* myfft = wl + g * S;
+  float2* stX = wl + G * S;
+  float* stN = (float*)(stX + STG);
+  float2* stU = stX + STG + 32;
+  for (int i = tid; i < M; i += 256) twl[i] = twW[i];
+  if (tid < 64) twb[tid] = twW[(tid * (M / (V * RM)) * 2) % (2 * M)];   // W_{2M}^{2 j M/(V RM)} = W_{V RM}^j  (j < 64 = V*RM)
+  TwRegs<M, T, false> twr;
+  twr.load(t, twW, 2);
+  twr.twb_ = twb;
+  twr.bstride_ = 1;
+
+  // `bands` bands per plane; the first H % bands of them are one row longer
+  const int band = (blockIdx.x * 4 + wave) * G + g;
+  const int pl = band / bands, bb = band - pl * bands;
+  const int rbase = H / bands, rrem = H - rbase * bands;
+  const int r0 = bb * rbase + (bb < rrem ? bb : rrem);
+  const int R = rbase + (bb < rrem ? 1 : 0);
+  const int Rmax = rbase + (rrem ? 1 : 0);            // loop bound of the whole wave (its groups differ by at most one row)
+  const int bi = pl / C;
+  const float rho = rho_next ? rho_next[bi] : 0.f;
+  float lamv[NT];
+  int hterm = -1;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    lamv[i] = TT.t[i].lam ? TT.t[i].lam[bi] * TT.t[i].alpha : 0.f;
+    if (TT.t[i].linop == DPX_LIN_GRAD_H) hterm = i;
+  }
+  __syncthreads();                                      // the only workgroup barrier: the twiddle copies
+
+  // per-lane element offsets (float2 units)
+  const unsigned e0 = 2u * t;                           // first of the two elements this lane fetches per DMA piece
+  const unsigned xoff = (unsigned)pl * H * M + (e0 / SPEC_TILE) * H * SPEC_TILE + (e0 % SPEC_TILE);
+  const unsigned xstep = (unsigned)(2 * T / SPEC_TILE) * H * SPEC_TILE;   // elements e0 + 2T*i
+  const unsigned noff = (unsigned)P * H * M + (unsigned)pl * H;
+  const unsigned uoff = (unsigned)pl * H * M + e0;      // row-major image rows: M float2 per row
+  const unsigned tile_off = (unsigned)pl * H * M + (unsigned)((t % SPEC_TILE) + (t / SPEC_TILE) * H * SPEC_TILE);
+  const unsigned tile_step = (unsigned)((T / SPEC_TILE) * H * SPEC_TILE);
+  const int pair = lbase | ((T - t) & (T - 1));
+  auto rowof = [&](int q) { int h = r0 - 1 + q; return h < 0 ? h + H : (h >= H ? h - H : h); };
+  auto stage_idx = [&](int e) { return ((e >> 1) / T) * 128 + g * 2 * T + ((e >> 1) % T) * 2 + (e & 1); };
+  auto issue_x = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) dpx_glds16(spec_in + xoff + (unsigned)h * SPEC_TILE + xstep * i, stX + i * 128);
+    dpx_glds4(spec_in + noff + h, stN);
+  };
+  auto issue_u = [&](int h) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const float2* urow = (const float2*)TT.t[n].u_in + uoff + (unsigned)h * M;
+#pragma unroll
+      for (int i = 0; i < D; ++i) dpx_glds16(urow + 2 * T * i, stU + n * STG + i * 128);
+    }
+  };
+  constexpr int NX_STEADY = (NT * (D + V) + V) > 63 ? 63 : (NT * (D + V) + V);
+  constexpr int NU_LAST = (NT * V + V) > 63 ? 63 : (NT * V + V);
+  constexpr int NU_STEADY = (NT * V + V + D + 1) > 63 ? 63 : (NT * V + V + D + 1);
+
+  issue_x(rowof(0));
+  issue_u(rowof(0));
+  float2 xprev[V], wprev[V];
+#pragma unroll
+  for (int m = 0; m < V; ++m) xprev[m] = wprev[m] = make_float2(0.f, 0.f);
+
+  for (int q = 0; q <= Rmax + 1; ++q) {
+    // ---------------- phase A: inverse row transform of row q ----------------
+    if (q >= 3) dpx_wait_vm<NX_STEADY>();
+    else if (q == 1) dpx_wait_vm<0>();
+    else dpx_wait_vm<NT * D>();
+    float2 xa[V];
+    {
+      float2 Xk[V], Xm[V];
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const int k = t + m * T;
+        Xk[m] = stX[stage_idx(k)];
+        Xm[m] = stX[stage_idx((M - k) & (M - 1))];
+      }
+      const float xn = stN[g * T];
+      dpx_wait_lds();
+      if (q <= Rmax) issue_x(rowof(q + 1));
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const int k = t + m * T;
+        const float2 xk = Xk[m], xm = cconj(Xm[m]);
+        if (k == 0) {
+          xa[m] = make_float2(xk.x + xn, xk.x - xn);
+        } else {
+          const float2 e = cadd(xk, xm);
+          const float2 d = cmulc(csub(xk, xm), twl[k]);
+          xa[m] = make_float2(e.x - d.y, e.y + d.x);
+        }
+      }
+    }
+    WaveSync()();
+    fft_reg_tw<M, T, +1, false>(xa, myfft, t, twr, WaveSync());   // xa[m] = (x[2n], x[2n+1]), n = t + m*T
+    if (x_out && q >= 1 && q <= R) {
+      float2* xo = (float2*)x_out + (unsigned)pl * H * M + (unsigned)rowof(q) * M;
+#pragma unroll
+      for (int m = 0; m < V; ++m) xo[t + m * T] = xa[m];
+    }
+    if (q >= 1) {
+      // ---------------- phase B: z / dual update of row qz = q - 1 (x[qz] = xprev, x[qz+1] = xa) ----------------
+      const int qz = q - 1;
+      const bool own = qz >= 1 && qz <= R;
+      const unsigned hz = (unsigned)rowof(qz);
+      if (q >= 3) {
+        if (q <= Rmax) dpx_wait_vm<NU_STEADY>();
+        else dpx_wait_vm<NU_LAST>();
+      } else {
+        dpx_wait_vm<D + 1>();
+      }
+      float2 ureg[NT][V];
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < V; ++m) ureg[n][m] = stU[n * STG + stage_idx(t + m * T)];
+      dpx_wait_lds();
+      if (qz < Rmax) issue_u(rowof(qz + 1));
+      float2 acc[V];
+#pragma unroll
+      for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const IterTerm tm = TT.t[n];
+        const float lam = lamv[n];
+        // d = K x + u   (the operator / prox codes are wave-uniform: one branch per term, not per element)
+        float2 d[V];
+        if (tm.linop == DPX_LIN_IDENTITY) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) d[m] = cadd(xprev[m], ureg[n][m]);
+        } else if (tm.linop == DPX_LIN_GRAD_H) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) d[m] = cadd(csub(xa[m], xprev[m]), ureg[n][m]);
+        } else {                                        // grad_W: x[w+1] - x[w]; pixel 2n+2 is the neighbour lane's .x
+#pragma unroll
+          for (int m = 0; m < V; ++m) {
+            const float nx_same = __shfl(xprev[m].x, lbase | ((t + 1) & (T - 1)));
+            const float nx_wrap = __shfl(xprev[(m + 1) % V].x, lbase);
+            const float xr = (t == T - 1) ? nx_wrap : nx_same;
+            d[m] = make_float2(xprev[m].y - xprev[m].x + ureg[n][m].x, xr - xprev[m].y + ureg[n][m].y);
+          }
+        }
+        float2 v[V];
+        if (tm.prox == DPX_PROX_NORM1) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) v[m] = make_float2(prox1(DPX_PROX_NORM1, d[m].x, lam), prox1(DPX_PROX_NORM1, d[m].y, lam));
+        } else if (tm.prox == DPX_PROX_NONNEG) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) v[m] = make_float2(fmaxf(d[m].x, 0.f), fmaxf(d[m].y, 0.f));
+        } else {
+#pragma unroll
+          for (int m = 0; m < V; ++m) v[m] = make_float2(prox1(DPX_PROX_SUMSQ, d[m].x, lam), prox1(DPX_PROX_SUMSQ, d[m].y, lam));
+        }
+        float2 w[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+          const float2 un = csub(d[m], v[m]);
+          w[m] = csub(v[m], un);
+          d[m] = un;
+        }
+        if (own) {
+          float2* uo = (float2*)tm.u_out + (unsigned)pl * H * M + hz * M + t;
+#pragma unroll
+          for (int m = 0; m < V; ++m) uo[m * T] = d[m];
+          if (emit_v) {
+            float2* vo = (float2*)tm.v_out + (unsigned)pl * H * M + hz * M + t;
+#pragma unroll
+            for (int m = 0; m < V; ++m) vo[m * T] = v[m];
+          }
+        }
+        if (tm.linop == DPX_LIN_IDENTITY) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) acc[m] = cadd(acc[m], w[m]);
+        } else if (tm.linop == DPX_LIN_GRAD_W) {          // adjoint: y[w-1] - y[w]; pixel 2n-1 is the left lane's .y
+#pragma unroll
+          for (int m = 0; m < V; ++m) {
+            const float l_same = __shfl(w[m].y, lbase | ((t + T - 1) & (T - 1)));
+            const float l_wrap = __shfl(w[(m + V - 1) % V].y, lbase | (T - 1));
+            const float wlft = (t == 0) ? l_wrap : l_same;
+            acc[m] = make_float2(acc[m].x + (wlft - w[m].x), acc[m].y + (w[m].x - w[m].y));
+          }
+        } else {                                          // grad_H adjoint: y[h-1] - y[h], the row above is last step's w
+#pragma unroll
+          for (int m = 0; m < V; ++m) {
+            acc[m] = make_float2(acc[m].x + (wprev[m].x - w[m].x), acc[m].y + (wprev[m].y - w[m].y));
+            wprev[m] = w[m];
+          }
+        }
+      }
+      // ---------------- phase C: right-hand-side increment of row qz and its forward row transform ----------------
+      if (own && rho_next) {
+        float2 z[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
+        WaveSync()();
+        fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
+        float2* out = spec_out + tile_off + hz * SPEC_TILE;
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+          const float2 got = make_float2(__shfl(z[V - 1 - m].x, pair), __shfl(z[V - 1 - m].y, pair));
+          const float2 zm = cconj(t == 0 ? z[(V - m) % V] : got);
+          const int k = t + m * T;
+          const float2 zk = z[m];
+          float2 Xo;
+          if (k == 0) {
+            Xo = make_float2(zk.x + zk.y, 0.f);
+            spec_out[noff + hz] = make_float2(zk.x - zk.y, 0.f);
+          } else {
+            const float2 e = cscale(cadd(zk, zm), 0.5f);
+            const float2 d = cscale(csub(zk, zm), 0.5f);
+            Xo = cadd(e, cmul(make_float2(d.y, -d.x), twl[k]));
+          }
+          out[tile_step * m] = Xo;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < V; ++m) xprev[m] = xa[m];
+  }
+}
+
+static size_t iter_rows_seq_lds(int M, int T, int NT) {
+  const int V = M / T, G = 64 / T, S = M + M / 16, STG = 64 * V;
+  return (size_t)(M + 64 + 4 * (G * S + STG + 32 + NT * STG)) * sizeof(float2);
+}
+template <int M, int T, int NT>
+static void launch_iter_rows_seq_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
+                                    int C, int H, int R, int P, const float2* twW, hipStream_t s) {
+  const size_t sh = iter_rows_seq_lds(M, T, NT);
+  static bool attr = false;
+  if (!attr && sh > 48 * 1024) {
+    hipFuncSetAttribute((const void*)k_iter_rows_seq<M, T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    attr = true;
+  }
+  const int groups = P * R, per_block = 4 * (64 / T);   // R = bands per plane here
+  DPX_LAUNCH("k_iter_rows_seq", (k_iter_rows_seq<M, T, NT>), dim3(groups / per_block), dim3(256), sh, s, sin, sout, TT, rho_next, x_out,
+             emit_v, C, H, R, P, twW);
+}
+template <int M, int T>
+static void launch_iter_rows_seq(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
+                                 int C, int H, int R, int P, const float2* twW, hipStream_t s) {
+  switch (TT.n) {
+    case 1: launch_iter_rows_seq_nt<M, T, 1>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s); break;
+    case 2: launch_iter_rows_seq_nt<M, T, 2>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s); break;
+    case 3: launch_iter_rows_seq_nt<M, T, 3>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s); break;
+    default: launch_iter_rows_seq_nt<M, T, 4>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s); break;
+  }
+}
+
 size_t pow2_spec_elems(int P, int H, int W);
 int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table,
                     hipStream_t stream);
@@ -326,11 +607,33 @@ extern "C" int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx
     DPX_REQUIRE(terms[i].u != terms[i].u_out, "dpx_admm_iter_rows: u must be double-buffered (u_out != u)");
     TT.t[i] = IterTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].u, terms[i].u_out, terms[i].v};
   }
-  const int P = B * C, R = 16;
+  const int P = B * C;
   const float2* tw = tw_rows(table);
   hipStream_t s = (hipStream_t)stream;
   const float2* sin = (const float2*)spec_in;
   float2* sout = (float2*)spec_out;
+  // Streaming kernel (one T-lane group per band): bands as long as possible while still >= ~2 waves per SIMD-pair
+  // of the chip; DPX_ITER_ROWS=lockstep keeps the ring-buffer kernel (A/B timing), DPX_ITER_BAND overrides the number of bands per plane.
+  static const char* mode = getenv("DPX_ITER_ROWS");
+  static const int band_env = getenv("DPX_ITER_BAND") ? atoi(getenv("DPX_ITER_BAND")) : 0;
+  if (!(mode && !strcmp(mode, "lockstep")) && W <= 1024) {
+    // as many bands per plane as keep every T-lane group of the launch resident at once (2 workgroups of 4 waves per
+    // CU), rounded so that the groups fill whole workgroups; bands are >= 4 rows (halo = 2 extra inverse transforms)
+    const int T = W / 16, G = 64 / T, per_block = 4 * G;
+    int nb = (256 * 2 * 4 * G) / P;
+    if (band_env) nb = band_env;
+    if (nb > H / 4) nb = H / 4;
+    while (nb > 1 && (P * nb) % per_block) --nb;
+    if (nb >= 1 && (P * nb) % per_block == 0) {
+      switch (W) {
+        case 256: launch_iter_rows_seq<128, 16>(sin, sout, TT, rho_next, x_out, emit_v, C, H, nb, P, tw, s); break;
+        case 512: launch_iter_rows_seq<256, 32>(sin, sout, TT, rho_next, x_out, emit_v, C, H, nb, P, tw, s); break;
+        default: launch_iter_rows_seq<512, 64>(sin, sout, TT, rho_next, x_out, emit_v, C, H, nb, P, tw, s); break;
+      }
+      return launch_status("dpx_admm_iter_rows");
+    }
+  }
+  const int R = 16;
   switch (W) {
     case 256: launch_iter_rows<128, 16>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
     case 512: launch_iter_rows<256, 32>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
