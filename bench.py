@@ -44,6 +44,7 @@ KERNEL_BYTES_PER_ELEM = {
     "k_cols": 8.0,            # reads + writes half spectrum
     "k_rows_c2r": 8.0,        # reads half spectrum ; writes x
     "k_zupdate": 28.0,        # reads x,u0,u1 ; writes v0,v1,u0,u1
+    "k_iter_rows_seq": 24.0,  # streaming fused rows (wave per band): same algorithmic traffic as k_iter_rows
     "k_iter_rows": 24.0,      # fused rows: reads spectrum, u0, u1 ; writes u0, u1, spectrum (x, v stay on chip)
     "k_cols_p2": 12.0,        # column solve: reads spectrum + data spectrum ; writes spectrum (denominators are L2-resident)
     "k_rows_r2c_p2": 8.0,

@@ -173,6 +173,13 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   // synchronisation the data needs.  The data-spectrum values (HBM) are requested in one batch right behind them:
   // ONE memory round trip between the two transforms.
   constexpr bool DMA_TABLE = (OP == OP_SOLVE) && (COLS == 8) && (V % 2 == 0) && !(DBG & 2);
+#ifndef DPX_COLS_EARLY_ADD
+#define DPX_COLS_EARLY_ADD 0
+#endif
+  constexpr bool EARLY_ADD = DPX_COLS_EARLY_ADD;        // request the data spectrum before the last pass's arithmetic
+  float2 av[OP == OP_SOLVE ? V : 1];
+#pragma unroll
+  for (int m = 0; m < (OP == OP_SOLVE ? V : 1); ++m) av[m] = make_float2(0.f, 0.f);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float2* tstage = smem_p2 + wave * (64 * V);
@@ -187,21 +194,25 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
 #pragma unroll
       for (int j = 0; j < V / 2; ++j) dpx_glds16(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
     }
+    if constexpr (OP == OP_SOLVE && EARLY_ADD) {
+      unsigned offa = off0;
+      DPX_OPAQUE(offa);
+      if (add) {
+#pragma unroll
+        for (int m = 0; m < V; ++m) av[m] = *(const float2*)(add + (offa + step * m) * 8u);
+      }
+    }
   };
   if (!(DBG & 1)) {
     fft_reg<H, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
   }
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (OP == OP_SOLVE) {
-    float2 av[V];
     unsigned offa = off0;
     DPX_OPAQUE(offa);
-    if (add) {
+    if (!EARLY_ADD && add) {
 #pragma unroll
       for (int m = 0; m < V; ++m) av[m] = *(const float2*)(add + (offa + step * m) * 8u);
-    } else {
-#pragma unroll
-      for (int m = 0; m < V; ++m) av[m] = make_float2(0.f, 0.f);
     }
     if (DMA_TABLE && !is_side) {
       if (add) dpx_wait_vm<V>();                        // the V data-spectrum loads above may stay in flight
@@ -237,6 +248,32 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores
 #pragma unroll
   for (int m = 0; m < V; ++m) *(float2*)(pout + (off1 + step * m) * 8u) = v[m];
+}
+
+// Tuning probe (DPX_DEBUG_COLS=4, wrong results by design): the column kernel's HBM traffic with 16-byte accesses and
+// no arithmetic -- the ceiling a wide-access version of k_cols_p2 could reach at the same occupancy.
+template <int H, int T, int COLS>
+__global__ void __launch_bounds__(T* COLS, 4) k_cols_probe_wide(const float4* __restrict__ spec_in, float4* __restrict__ spec_out,
+                                                                const float4* __restrict__ add, int n_tiles) {
+  HIP_DYNAMIC_SHARED(float2, smem_probe)
+  constexpr int V = H / T;
+  const size_t base = (size_t)blockIdx.x * (H * COLS / 2);      // float4 units per tile
+  if (blockIdx.x >= n_tiles) return;
+  const int tid = threadIdx.x;
+  float4 v[V / 2], a[V / 2];
+#pragma unroll
+  for (int m = 0; m < V / 2; ++m) v[m] = spec_in[base + tid + m * (T * COLS)];
+  if (tid == 100000) smem_probe[0] = make_float2(v[0].x, 0.f);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < V / 2; ++m) a[m] = add[base + tid + m * (T * COLS)];
+#pragma unroll
+  for (int m = 0; m < V / 2; ++m) v[m] = make_float4(v[m].x + a[m].x, v[m].y + a[m].y, v[m].z + a[m].z, v[m].w + a[m].w);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < V / 2; ++m) spec_out[base + tid + m * (T * COLS)] = v[m];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -292,6 +329,15 @@ static void cols_dispatch(int H, const float2* spec, float2* spec_out, const Spe
     if (dbg == 1) { launch_cols<1024, 64, SPEC_TILE, OP, 1>(spec, spec_out, A, P, C, Ws, twH, s); return; }
     if (dbg == 2) { launch_cols<1024, 64, SPEC_TILE, OP, 2>(spec, spec_out, A, P, C, Ws, twH, s); return; }
     if (dbg == 3) { launch_cols<1024, 64, SPEC_TILE, OP, 3>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 4) {
+      const size_t sh = (size_t)(SPEC_TILE * 1092 + 1024) * sizeof(float2);
+      static bool once = false;
+      if (!once) { hipFuncSetAttribute((const void*)k_cols_probe_wide<1024, 64, SPEC_TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); once = true; }
+      const int nt = P * (Ws / SPEC_TILE);
+      DPX_LAUNCH("k_cols_p2", (k_cols_probe_wide<1024, 64, SPEC_TILE>), dim3(nt), dim3(512), sh, s, (const float4*)spec, (float4*)spec_out,
+                 (const float4*)A.add, nt);
+      return;
+    }
   }
   switch (H) {
     case 256: launch_cols<256, 32, SPEC_TILE, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
