@@ -352,6 +352,76 @@ extern "C" int dpx_lincomb(float* out, int n, const float* const* x, const float
   return launch_status("dpx_lincomb");
 }
 
+// ---- complex-iterate arithmetic of the CS-MRI solver (contrib/csmri.py:156-171, proxfn/fast/csmri.py:14-25) ----
+struct CplxPack {
+  const void* x[4];
+  float c[4];
+  int cx[4];
+  int n;
+};
+template <bool OUT_COMPLEX>
+__global__ void __launch_bounds__(256) k_cplx_lincomb(void* __restrict__ out, CplxPack L, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    float re = 0.f, im = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < L.n) {
+        if (L.cx[k]) {
+          const float2 v = ((const float2*)L.x[k])[i];
+          re = fmaf(L.c[k], v.x, re);
+          im = fmaf(L.c[k], v.y, im);
+        } else {
+          re = fmaf(L.c[k], ((const float*)L.x[k])[i], re);
+        }
+      }
+    }
+    if (OUT_COMPLEX) ((float2*)out)[i] = make_float2(re, im);
+    else ((float*)out)[i] = re;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_csmri_update(float2* __restrict__ z, const float2* __restrict__ y, const unsigned char* __restrict__ mask,
+                                                       int mask_images, const float* __restrict__ lam, float num_psi, long n_per_image) {
+  const int b = blockIdx.y;
+  const float l = lam[b];
+  const float den = 1.f + l * num_psi;
+  const unsigned char* mk = mask + (mask_images > 1 ? (long)b * n_per_image : 0L);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n_per_image; i += (long)gridDim.x * 256L) {
+    if (mk[i]) {
+      const long j = (long)b * n_per_image + i;
+      const float2 zz = z[j], yy = y[j];
+      z[j] = make_float2((l * zz.x + yy.x) / den, (l * zz.y + yy.y) / den);
+    }
+  }
+}
+
+extern "C" int dpx_csmri_update(void* z, const void* y, const unsigned char* mask, int mask_images, const float* lam, float num_psi, int B,
+                                long n_per_image, dpx_stream_t stream) {
+  DPX_REQUIRE(z && y && mask && lam && B > 0 && n_per_image > 0, "dpx_csmri_update: bad arguments");
+  DPX_REQUIRE(mask_images == 1 || mask_images == B, "dpx_csmri_update: mask must hold 1 or B=%d images (got %d)", B, mask_images);
+  DPX_LAUNCH("k_csmri_update", k_csmri_update, dim3(grid_for(n_per_image, 256, 2048), B, 1), dim3(256), 0, (hipStream_t)stream, (float2*)z,
+             (const float2*)y, mask, mask_images, lam, num_psi, n_per_image);
+  return launch_status("dpx_csmri_update");
+}
+
+extern "C" int dpx_cplx_lincomb(void* out, int out_complex, int n, const void* const* x, const int* x_complex, const float* coef,
+                                long n_elems, dpx_stream_t stream) {
+  DPX_REQUIRE(out && x && x_complex && coef && n >= 1 && n <= 4 && n_elems > 0, "dpx_cplx_lincomb: bad arguments");
+  CplxPack L;
+  L.n = n;
+  for (int i = 0; i < 4; ++i) {
+    L.x[i] = i < n ? x[i] : nullptr;
+    L.c[i] = i < n ? coef[i] : 0.f;
+    L.cx[i] = i < n ? (x_complex[i] != 0) : 0;
+    DPX_REQUIRE(i >= n || x[i], "dpx_cplx_lincomb: operand %d is null", i);
+  }
+  if (out_complex)
+    DPX_LAUNCH("k_cplx_lincomb", k_cplx_lincomb<true>, dim3(grid_for(n_elems, 256, 8192)), dim3(256), 0, (hipStream_t)stream, out, L, n_elems);
+  else
+    DPX_LAUNCH("k_cplx_lincomb", k_cplx_lincomb<false>, dim3(grid_for(n_elems, 256, 8192)), dim3(256), 0, (hipStream_t)stream, out, L, n_elems);
+  return launch_status("dpx_cplx_lincomb");
+}
+
 extern "C" size_t dpx_bdot_ws_bytes(int B, long n_per_batch) { return (size_t)B * B * dot_blocks(n_per_batch) * sizeof(float); }
 
 extern "C" int dpx_bdot(const float* x, const float* y, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream) {

@@ -340,10 +340,54 @@ def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, 
     return rc
 
 
+def clincomb(terms, out_complex=True):
+    """sum_i coef_i * x_i over up to 4 real-fp32 / complex64 tensors of one shape; complex64 result, or its real part
+    as fp32 (out_complex=False).  coef_i are python floats."""
+    xs = [t[1].contiguous() for t in terms]
+    ref = xs[0]
+    if not 1 <= len(xs) <= 4:
+        raise be.DpxError("clincomb: 1..4 operands")
+    for x in xs:
+        if x.dtype not in (torch.float32, torch.complex64):
+            raise be.DpxError(f"clincomb operand must be float32 or complex64, got {x.dtype}")
+        require(x, dtype=None, what="clincomb operand")
+        if x.shape != ref.shape:
+            raise be.DpxError(f"clincomb: shape mismatch {tuple(x.shape)} vs {tuple(ref.shape)}")
+    res = torch.empty(ref.shape, dtype=torch.complex64 if out_complex else torch.float32, device=ref.device)
+    if ref.numel() == 0:
+        return res
+    n = len(xs)
+    px = (c_void_p * n)(*[x.data_ptr() for x in xs])
+    cx = (ctypes.c_int * n)(*[int(x.is_complex()) for x in xs])
+    cf = (c_float * n)(*[float(t[0]) for t in terms])
+    be.lib().call("dpx_cplx_lincomb", ptr(res), int(bool(out_complex)), n, px, cx, cf, ref.numel(), be.stream())
+    return res
+
+
+def csmri_update(z, y, mask, lam, num_psi):
+    """in place on the complex64 spectrum z [B,C,H,W]: z[mask] = ((lam z + y) / (1 + lam num_psi))[mask]"""
+    require(z, dtype=torch.complex64, what="csmri spectrum")
+    B = int(z.shape[0])
+    npi = z.numel() // B
+    y = y.to(torch.complex64).contiguous()
+    if y.shape != z.shape:
+        raise be.DpxError(f"csmri: y {tuple(y.shape)} does not match the iterate {tuple(z.shape)}")
+    mk = (mask != 0).to(torch.uint8).contiguous()
+    if mk.numel() == z.numel():
+        mimg = B
+    elif mk.numel() == npi:
+        mimg = 1
+    else:
+        raise be.DpxError(f"csmri: mask {tuple(mask.shape)} matches neither one image nor the batch {tuple(z.shape)}")
+    lam_v = as_batch_vec(lam, B, z.device)
+    be.lib().call("dpx_csmri_update", ptr(z), ptr(y), ptr(mk), mimg, ptr(lam_v), float(num_psi), B, npi, be.stream())
+    return z
+
+
 def cfft2(x, inverse=False, centred=True, ortho=True):
     """complex64 2-D FFT over the last two dims (hand-written kernels; centring shifts and normalisation fused)"""
     if not x.is_complex():
-        x = torch.complex(x.float(), torch.zeros_like(x, dtype=torch.float32))
+        x = clincomb([(1.0, x.float())], out_complex=True)
     x = x.to(torch.complex64).contiguous()
     require(x, dtype=torch.complex64, what="cfft2 input")
     H, W = int(x.shape[-2]), int(x.shape[-1])

@@ -1,0 +1,2 @@
+"""Closed-form data terms (reference dprox/proxfn/fast/): the ones on the hot path of the reference's own pipelines."""
+from .csmri import csmri

@@ -6,6 +6,7 @@ import os
 import torch
 import torch.nn as nn
 
+from ... import _ops as ops
 from ...utils import safe_sqrt
 from ..core import ProxFn
 from .denoisers import FFDNetColorDenoiser, FFDNetDenoiser
@@ -53,7 +54,7 @@ class deep_prior(ProxFn):
         if self.clamp:
             v = v.clamp(0, 1)
         if torch.is_complex(v):
-            v = v.real
+            v = ops.clincomb([(1.0, v)], out_complex=False)          # v.real (prior.py:79)
         inp = v.unsqueeze(1) if v.ndim == 3 else v
         den = self.denoisers[self.step] if self.unroll else self.denoiser
         out = den.denoise(inp.contiguous(), sigma)

@@ -63,7 +63,10 @@ class ext_sum_squares(sum_squares):
         return self
 
     def solve(self, b, rho, eps=1e-6):
-        xtilde = ops.lincomb([(1.0, t) for t in b])
+        if any(t.is_complex() for t in b) and not all(t.is_complex() for t in b):
+            xtilde = ops.clincomb([(1.0, t) for t in b], out_complex=True)
+        else:
+            xtilde = ops.lincomb([(1.0, t) for t in b]) if len(b) > 1 else b[0]
         return self._prox(xtilde, rho, len(b))
 
 

@@ -108,6 +108,21 @@ int dpx_fourier_solve(const float* rhs, float* x, const void* spec_add, const vo
 int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, int P, int H, int W, const void* table,
               dpx_stream_t stream);
 
+/* Closed-form CS-MRI data-term update in the (centred) Fourier domain, in place:
+ *   z[f] <- (lam_b * z[f] + y[f]) / (1 + lam_b * num_psi)   where mask[f] != 0,      z[f] unchanged elsewhere
+ * = the body of csmri._prox between its two transforms (dprox/proxfn/fast/csmri.py:14-25).  z, y: complex64
+ * [B, n_per_image]; mask: one byte per element, [B, n_per_image] (mask_images = B) or [1, n_per_image]
+ * (mask_images = 1, shared by the batch); lam: [B].                                                          */
+int dpx_csmri_update(void* z, const void* y, const unsigned char* mask, int mask_images, const float* lam, float num_psi, int B,
+                     long n_per_image, dpx_stream_t stream);
+
+/* out = sum_i coef[i] * x[i] over n <= 4 operands that are each real (float32) or complex (complex64) arrays of
+ * `n_elems` elements; out is complex64 (out_complex = 1) or the REAL PART of the sum as float32 (out_complex = 0).
+ * The complex-iterate arithmetic of the CS-MRI solver: `z - u`, `x + u`, `u + x - z` (dprox/contrib/csmri.py:161-169)
+ * and deep_prior's `v.real` (dprox/proxfn/pnp/prior.py:79).  x[i] may alias out when both have the same type.        */
+int dpx_cplx_lincomb(void* out, int out_complex, int n, const void* const* x, const int* x_complex, const float* coef,
+                     long n_elems, dpx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* spatial operators and fused ADMM steps                                                      */
 /* ------------------------------------------------------------------------------------------ */

@@ -31,6 +31,7 @@ __all__ = [
     "soft_threshold", "prox", "LeastSquares", "cg", "bdot", "LinearSolveConfig",
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
     "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
+    "csmri_prox", "custom_admm_csmri",
 ]
 
 
@@ -600,6 +601,39 @@ class FFDNetOracle:
         if not self.per_band:
             return ffdnet_forward(x, sigma, self.layers)
         return torch.cat([ffdnet_forward(band, sigma, self.layers) for band in x.split(1, dim=1)], dim=1)
+
+
+# --------------------------------------------------------------------------- #
+# CS-MRI pipeline: closed-form data term + CustomADMM                         #
+# --------------------------------------------------------------------------- #
+def csmri_prox(v, lam, num_psi, mask, y):
+    """proxfn/fast/csmri.py:14-25: z = fft2(v); z[mask] = ((lam z + y)/(1 + lam num_psi))[mask]; ifft2(z)."""
+    lam = torch.as_tensor(lam, dtype=torch.float32)
+    if lam.ndim == 1:
+        lam = lam.view(lam.shape[0], 1, 1, 1)
+    mask = mask.bool()
+    z = fft2c(v)
+    temp = ((lam * z.clone()) + y) / (1 + lam * num_psi)
+    z[mask] = temp[mask]
+    return ifft2c(z)
+
+
+def custom_admm_csmri(x0, y, mask, rhos, sigmas, max_iter, denoise):
+    """contrib/csmri.py:156-171 (CustomADMM._iter) driven by algo/base.py:128-156 with one deep_prior Psi term and the
+    csmri data term routed through ext_sum_squares.solve (sum_square.py:35-48, invert.py:8-12); state initialised by
+    admm.py:61-67 (z = [x0], u = [0]).  deep_prior takes the real part of a complex iterate (pnp/prior.py:79).
+    Returns (x, z, u) after max_iter iterations."""
+    x, z, u = x0, x0.clone(), torch.zeros_like(x0)
+    for i in range(max_iter):
+        rho, sigma = rhos[..., i], sigmas[..., i]
+        v = z - u
+        if torch.is_complex(v):
+            v = v.real
+        x = denoise(v.contiguous(), torch.as_tensor(sigma, dtype=torch.float32).reshape(-1)).type_as(v)
+        b = x + u
+        z = csmri_prox(b, rho, 1, mask, y)
+        u = u + x - z
+    return x, z, u
 
 
 def psnr(out, gt):

@@ -377,6 +377,40 @@ def g9_admm_pnp():
          x_f64=x64, v0_f64=v64[0], x_nonneg_f64=x64n)
 
 
+def g15_csmri():
+    """CS-MRI pipeline of the reference's examples (csmri closed-form data term + CustomADMM + gray FFDNet prior):
+    dprox/proxfn/fast/csmri.py:8-25, dprox/contrib/csmri.py:156-171, ext_sum_squares routing invert.py:8-12."""
+    from dprox.contrib.csmri import CustomADMM
+    from dprox.proxfn.fast.csmri import csmri
+    parts = [synthetic.csmri_case(1, 32, 40, seed=150 + i, center=8) for i in range(2)]   # per-image masks, like the datasets
+    gt, mask, y = (np.concatenate([p[k] for p in parts], axis=0) for k in range(3))
+    rng = np.random.RandomState(151)
+    out = {"gt": gt, "mask": mask, "y": y}
+    # (1) the closed-form prox on its own: complex and real inputs, scalar and per-image lam
+    x = dp.Variable()
+    yp, mp = dp.Placeholder(), dp.Placeholder()
+    yp.value, mp.value = T(y), T(mask)
+    fn = csmri(x, mp, yp)
+    vc = (rng.randn(2, 1, 32, 40) + 1j * rng.randn(2, 1, 32, 40)).astype("complex64")
+    out["prox_v"] = vc
+    out["prox_lam_scalar"] = fn._prox(T(vc), torch.tensor(0.7), 1)
+    out["prox_lam_B"] = fn._prox(T(vc), torch.tensor([0.3, 1.9]), 2)
+    # (2) the full solver, 4 iterations
+    x2 = dp.Variable()
+    y2, m2 = dp.Placeholder(), dp.Placeholder()
+    data = csmri(x2, m2, y2)
+    reg = dp.deep_prior(x2, denoiser=GrayDen(11))
+    solver = CustomADMM([reg], [data])
+    y2.value, m2.value = T(y), T(mask)
+    x0 = ifft2(T(y))
+    rhos, sigmas = log_descent(80, 40, 4)
+    rhos, _ = log_descent(10, 0.1, 4)
+    with torch.no_grad():
+        st = solver.solve(x0=x0, rhos=rhos, lams={reg: sigmas}, max_iter=4, return_full_states=True)
+    out.update(x0=x0, rhos=rhos, sigmas=sigmas, x=st[0], z=st[1][0], u=st[2][0])
+    save("g15_csmri", **out)
+
+
 def g10_pgd():
     gt, b, psf = synthetic.deconv_case(2, 3, 32, 40, seed=100)
     x = dp.Variable()
@@ -434,6 +468,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g12_log_descent, g13_known_answers, g14_other_algorithms):
+               g9_admm_pnp, g10_pgd, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

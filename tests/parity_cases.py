@@ -286,6 +286,33 @@ def case_ladmm_cg(device):
     assert_close(xa.cpu(), g["x_admm"], 2 * TOL, "admm+cg x")
 
 
+def case_csmri(device):
+    """G15: closed-form csmri data term (native complex FFT + masked update) and CustomADMM on a complex iterate"""
+    from dprox.contrib.csmri import CustomADMM
+    g = load_golden("g15_csmri")
+    y, mask = T(g["y"], device), T(g["mask"], device)
+    x = dp.Variable()
+    yp, mp = dp.Placeholder(), dp.Placeholder()
+    yp.value, mp.value = y, mask
+    fn = dp.csmri(x, mp, yp).to(device)
+    v = T(g["prox_v"], device)
+    assert_close(fn._prox(v, torch.tensor(0.7, device=device), 1).cpu(), g["prox_lam_scalar"], TOL, "csmri prox scalar lam")
+    assert_close(fn._prox(v, torch.tensor([0.3, 1.9], device=device), 2).cpu(), g["prox_lam_B"], TOL, "csmri prox per-image lam")
+    x2 = dp.Variable()
+    y2, m2 = dp.Placeholder(), dp.Placeholder()
+    data = dp.csmri(x2, m2, y2)
+    reg = dp.deep_prior(x2, denoiser=_ffdnet("gray", device))
+    solver = CustomADMM([reg], [data]).to(device)
+    y2.value, m2.value = y, mask
+    with torch.no_grad():
+        st = solver.solve(x0=T(g["x0"], device), rhos=torch.from_numpy(g["rhos"]), lams={reg: torch.from_numpy(g["sigmas"])}, max_iter=4,
+                          return_full_states=True)
+    assert solver.last_path == "generic"
+    assert_close(st[0].cpu(), g["x"], TOL, "CustomADMM x (prior output)")
+    assert_close(st[1][0].cpu(), g["z"], TOL, "CustomADMM z (data-term output)")
+    assert_close(st[2][0].cpu(), g["u"], 2 * TOL, "CustomADMM u")
+
+
 def case_other_algorithms(device):
     """G14: ADMM_vxu / HQS / Pock-Chambolle through the generic path (same HIP primitives, different update order)"""
     g = load_golden("g14_other_algorithms")

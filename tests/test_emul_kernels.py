@@ -63,5 +63,9 @@ def test_other_algorithms():
     pc.case_other_algorithms(DEV)
 
 
+def test_csmri_custom_admm():
+    pc.case_csmri(DEV)
+
+
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV, shape=(1, 3, 24, 20))

@@ -76,6 +76,10 @@ def test_other_algorithms():
     pc.case_other_algorithms(DEV)
 
 
+def test_csmri_custom_admm():
+    pc.case_csmri(DEV)
+
+
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV)
 

@@ -206,6 +206,19 @@ def test_g9_admm_pnp():
     assert_close(x2, g["x_nonneg"], 1e-5)
 
 
+def test_g15_csmri():
+    """csmri closed-form prox + CustomADMM with the gray FFDNet prior (complex iterate)."""
+    g = load_golden("g15_csmri")
+    y, mask = T(g["y"]), T(g["mask"])
+    v = T(g["prox_v"])
+    assert_close(O.csmri_prox(v, 0.7, 1, mask, y), g["prox_lam_scalar"], 2e-6)
+    assert_close(O.csmri_prox(v, torch.tensor([0.3, 1.9]), 2, mask, y), g["prox_lam_B"], 2e-6)
+    den = O.FFDNetOracle(O.ffdnet_weights(11, 1, 1, 64, 15), per_band=True)
+    with torch.no_grad():
+        x, z, u = O.custom_admm_csmri(T(g["x0"]), y, mask, T(g["rhos"]), T(g["sigmas"]), 4, den)
+    assert_close(x, g["x"], 1e-5); assert_close(z, g["z"], 1e-5); assert_close(u, g["u"], 1e-5)
+
+
 def test_g10_pgd():
     g = load_golden("g10_pgd")
     b = T(g["b"])
