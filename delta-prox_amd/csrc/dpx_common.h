@@ -133,6 +133,7 @@ struct SpecArgs {
   const float* rho;    // OP_SOLVE device [B]
   const float2* add;   // OP_SOLVE (nullable): per-plane data spectrum added before the division
   float eps;
+  float eps_num;       // OP_SOLVE: added to the numerator's real part (= eps in the x-update, 0 in its adjoint / backward)
   float scale;         // 1/(H*W)
 };
 

@@ -337,6 +337,45 @@ extern "C" int dpx_prox(int kind, const float* v, float* out, const float* lam, 
   return launch_status("dpx_prox");
 }
 
+// backward of k_prox at the point d (t = d - offset, l = lam_b * alpha):
+//   soft-threshold: J = [|t| > l],  dprox/dl = -sign(t) [|t| > l]
+//   nonneg        : J = [t > 0],    dprox/dl = 0
+//   sum-squares   : J = 1/(1 + 2l), dprox/dl = -2 t / (1 + 2l)^2
+__global__ void k_prox_bwd(int kind, const float* __restrict__ d, const float* __restrict__ g, float* __restrict__ gd,
+                           float* __restrict__ dlam, const float* __restrict__ lam, float alpha, const float* __restrict__ off, int B,
+                           long npb) {
+  const long total = (long)B * npb;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / npb);
+    const float t = d[i] - (off ? off[i] : 0.f);
+    const float l = (lam ? lam[b] : 0.f) * alpha;
+    float J, dl;
+    if (kind == DPX_PROX_NORM1) {
+      const bool pass = fabsf(t) > l;
+      J = pass ? 1.f : 0.f;
+      dl = pass ? (t > 0.f ? -1.f : 1.f) : 0.f;
+    } else if (kind == DPX_PROX_NONNEG) {
+      J = t > 0.f ? 1.f : 0.f;
+      dl = 0.f;
+    } else {
+      const float s = 1.f / (1.f + 2.f * l);
+      J = s;
+      dl = -2.f * t * s * s;
+    }
+    if (gd) gd[i] = J * (g ? g[i] : 1.f);
+    if (dlam) dlam[i] = dl;
+  }
+}
+
+extern "C" int dpx_prox_bwd(int kind, const float* d, const float* g, float* gd, float* dlam, const float* lam, float alpha,
+                            const float* offset, int B, long n_per_batch, dpx_stream_t stream) {
+  DPX_REQUIRE(d && (gd || dlam) && (g || !gd) && B > 0 && n_per_batch > 0, "dpx_prox_bwd: bad arguments");
+  DPX_REQUIRE(kind >= DPX_PROX_NORM1 && kind <= DPX_PROX_SUMSQ, "dpx_prox_bwd: unknown kind %d", kind);
+  DPX_LAUNCH("k_prox_bwd", k_prox_bwd, dim3(grid_for(B * n_per_batch, 256, 8192)), dim3(256), 0, (hipStream_t)stream, kind, d, g, gd, dlam,
+             lam, alpha, offset, B, n_per_batch);
+  return launch_status("dpx_prox_bwd");
+}
+
 extern "C" int dpx_lincomb(float* out, int n, const float* const* x, const float* coef, const float* const* coef_b, int B,
                            long n_per_batch, dpx_stream_t stream) {
   DPX_REQUIRE(out && x && coef && n >= 1 && n <= 4 && B > 0 && n_per_batch > 0, "dpx_lincomb: bad arguments");

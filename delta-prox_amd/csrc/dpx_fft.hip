@@ -333,7 +333,7 @@ __device__ __forceinline__ float2 spec_op(float2 z, const SpecArgs& A, size_t ti
     const float2 dd = A.dd[tix];
     const float den = fmaf(rho_b, dd.y, dd.x) + A.eps;
     const float inv = A.scale / den;
-    return make_float2((z.x + A.eps) * inv, z.y * inv);
+    return make_float2((z.x + A.eps_num) * inv, z.y * inv);
   }
 }
 
@@ -664,8 +664,22 @@ extern "C" int dpx_fourier_solve(const float* rhs, float* x, const void* spec_ad
   a.dd = (const float2*)dd;
   a.rho = rho;
   a.eps = eps;
+  a.eps_num = eps;
   a.scale = 1.0f / ((float)H * (float)W);
   return spectral_apply(rhs, x, OP_SOLVE, a, B, C, H, W, table, ws, (hipStream_t)stream);
+}
+
+extern "C" int dpx_fourier_apply_inv(const float* g, float* out, const void* dd, const float* rho, float eps, int B, int C, int H, int W,
+                                     const void* table, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(g && out && table && ws && rho && dd, "dpx_fourier_apply_inv: null pointer");
+  DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_fourier_apply_inv: bad shape");
+  SpecArgs a{};
+  a.dd = (const float2*)dd;
+  a.rho = rho;
+  a.eps = eps;
+  a.eps_num = 0.f;
+  a.scale = 1.0f / ((float)H * (float)W);
+  return spectral_apply(g, out, OP_SOLVE, a, B, C, H, W, table, ws, (hipStream_t)stream);
 }
 
 extern "C" int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, int P, int H, int W, const void* table,

@@ -109,7 +109,7 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
     const float2 dd = A.dd[tix];
     const float den = fmaf(rho_b, dd.y, dd.x) + A.eps;
     const float inv = A.scale / den;
-    return make_float2((z.x + A.eps) * inv, z.y * inv);
+    return make_float2((z.x + A.eps_num) * inv, z.y * inv);
   }
 }
 
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
         const float2 z = cadd(v[m], av[m]);
         const float den = fmaf(rho_b, dv.y, dv.x) + A.eps;
         const float inv = A.scale / den;
-        v[m] = make_float2((z.x + A.eps) * inv, z.y * inv);
+        v[m] = make_float2((z.x + A.eps_num) * inv, z.y * inv);
       }
     } else {
 #pragma unroll

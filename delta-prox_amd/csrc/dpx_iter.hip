@@ -592,6 +592,7 @@ extern "C" int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const voi
   a.add = (const float2*)spec_add;
   a.rho = rho;
   a.eps = eps;
+  a.eps_num = eps;
   a.scale = 1.0f / ((float)H * (float)W);
   return cols_solve_pow2((const float2*)spec_in, (float2*)spec_out, a, B * C, C, H, W, table, (hipStream_t)stream);
 }

@@ -62,6 +62,8 @@ SIGNATURES = {
     "dpx_bdot_ws_bytes": (c_size_t, [c_int, c_long]),
     "dpx_bgram": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "dpx_prox": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
+    "dpx_prox_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
+    "dpx_fourier_apply_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpx_admm_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_zupdate": (c_int, [c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_iter_supported": (c_int, [c_int, c_int, POINTER(Term), c_int]),

@@ -184,6 +184,31 @@ def fourier_solve(rhs, d0, d1, c0, c1, rho, eps=EPS, out=None, spec_add=None):
     return x
 
 
+def fourier_apply_inv(g, d0, d1, c0, c1, rho, eps=EPS):
+    """irFFT2[rFFT2(g) / (d0 + c0 + rho (d1 + c1) + eps)]: the self-adjoint linear part of fourier_solve (its backward)"""
+    require(g, what="fourier_apply_inv input")
+    B, C, H, W = _shape4(g)
+    rho = as_batch_vec(rho, B, g.device)
+    out = torch.empty_like(g)
+    dd = denominator(d0, c0, d1, c1, C, H, W, g.device)
+    be.lib().call("dpx_fourier_apply_inv", ptr(g), ptr(out), ptr(dd), ptr(rho), c_float(eps), B, C, H, W,
+                  ptr(fft_table(H, W, g.device)), ptr(spectrum_ws(B * C, H, W, g.device)), be.stream())
+    return out
+
+
+def prox_bwd(kind, d, g, lam, alpha=1.0, off=None, want_dlam=True):
+    """(J(d)^T g, d prox / d lam at d) of ops.prox -- see dpx_prox_bwd"""
+    require(d, what="prox_bwd point")
+    require(g, what="prox_bwd gradient")
+    B = int(d.shape[0])
+    npb = d.numel() // max(B, 1)
+    lam_v = as_batch_vec(lam, B, d.device)
+    gd = torch.empty_like(d)
+    dl = torch.empty_like(d) if want_dlam else None
+    be.lib().call("dpx_prox_bwd", int(kind), ptr(d), ptr(g), ptr(gd), ptr(dl), ptr(lam_v), c_float(alpha), ptr(off), B, npb, be.stream())
+    return gd, dl
+
+
 # ----------------------------------------------------------------------------------------------
 # spatial / elementwise
 # ----------------------------------------------------------------------------------------------

@@ -51,28 +51,46 @@ def compile(prox_fns: List[ProxFn], method: str = "admm", device: Union[str, tor
 
 
 class UnrolledSolver(nn.Module):
-    """one (deep-copied) solver per unrolled step -- specialization/unroll.py:21-58"""
+    """one (deep-copied) solver per unrolled step, optionally with learnable rho / lambda schedules --
+    specialization/unroll.py:21-58"""
 
     def __init__(self, solver: Algorithm, max_iter, share=False, learned_params=False):
         super().__init__()
-        self.solvers = nn.ModuleList([solver] + [copy.deepcopy(solver) for _ in range(max_iter - 1)]) if not share \
-            else nn.ModuleList([solver])
+        if not share:
+            self.solvers = nn.ModuleList([solver] + [copy.deepcopy(solver) for _ in range(max_iter - 1)])
+        else:
+            self.solver = solver
+            self.solvers = [solver for _ in range(max_iter)]
         self.max_iter, self.share = max_iter, share
+        self.learned_params = learned_params
+        if learned_params:
+            self.rhos = nn.Parameter(torch.ones(max_iter))
+            self.lams = {}
+            for fn in solver.psi_fns:
+                lam = nn.Parameter(torch.ones(max_iter))
+                setattr(self, "lam_" + str(len(self.lams)), lam)
+                self.lams[fn] = lam
 
-    def solve(self, x0, rhos, lams, **kwargs):
+    def solve(self, x0=None, rhos=None, lams=None, max_iter=None, **kwargs):
         from .driver import to_tensor
         first = self.solvers[0]
+        max_iter = self.max_iter if max_iter is None else max_iter
         x0 = to_tensor(x0, batch=True)
-        x0, rhos, lams, _ = first.defaults(x0, to_tensor(rhos), to_tensor(lams) if lams is not None else None, self.max_iter)
+        if self.learned_params:
+            rhos, lams = self.rhos, self.lams
+        else:
+            _, rhos, lams, _ = first.defaults(x0, to_tensor(rhos) if rhos is not None else None,
+                                              to_tensor(lams) if lams is not None else None, max_iter)
         dev = first.device
         x0 = x0.to(dev).float().contiguous()
         state = first.initialize(x0)
-        for it in range(self.max_iter):
-            solver = self.solvers[0 if self.share else it]
-            rho = rhos[..., it].to(dev)
-            lam = {k: v[..., it].to(dev) for k, v in lams.items()}
+        for it in range(max_iter):
+            solver = self.solvers[it]
+            rho = rhos[..., it:it + 1].to(dev)
+            # schedules are keyed by the FIRST solver's Psi terms; step `it` uses its own clone of each term
+            lam = {fn_i: lams[fn_0][..., it:it + 1].to(dev) for fn_0, fn_i in zip(first.psi_fns, solver.psi_fns)}
             solver._notify_all_op_current_step(it)
-            state = solver.iter(state, rho, lam)
+            state = solver.iters(state, rho, lam, 1, False)
         return state[0]
 
 

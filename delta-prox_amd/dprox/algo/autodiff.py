@@ -1,0 +1,184 @@
+"""Reverse-mode differentiation of the fused ADMM iteration (config 5: unrolled training).
+
+The reference differentiates its solvers with plain PyTorch autograd through every eager op of the iteration
+(dprox/algo/admm.py:49-59 under specialization/unroll.py:14-58; README.md:93-116 trains the rho / lambda schedules).
+Here the iteration is three hand-written stages; each gets a hand-written backward built from the same HIP primitives:
+
+    rhs = rho * sum_i K_i^T (v_i - u_i)           linear:      g_v_i = rho K_i g,  g_u_i = -g_v_i,  g_rho = <g, rhs> / rho
+    x   = S_rho(rhs + sum_Omega K^T b)            self-adjoint Fourier solve M = F^-1 diag(1/den) F:
+                                                  g_rhs = M g,  g_b = K g_rhs,  g_rho = -<g_rhs, (sum_Psi K_i^T K_i) x>
+    d_i = K_i x + u_i ; v_i = prox(d_i, lam_i) ;  u_i' = d_i - v_i
+                                                  g_d = J_prox^T (g_v - g_u') + g_u',  g_x += K_i^T g_d,  g_u = g_d,
+                                                  g_lam = alpha <g_v - g_u', d prox / d lam>
+
+(K_i in {I, grad_H, grad_W}; prox in {soft-threshold, nonneg, v/(1+2 lam)}.)  torch.autograd only chains these
+Functions and carries the [B]-sized schedule entries; every image-sized pass runs in libdpx_hip.so.
+"""
+import torch
+
+from .. import _backend as be
+from .. import _ops as ops
+
+_DIM = {be.LIN_GRAD_H: 0, be.LIN_GRAD_W: 1}
+
+
+def _K(code, x):
+    return x if code == be.LIN_IDENTITY else ops.grad(x, _DIM[code], adjoint=False)
+
+
+def _KT(code, y):
+    return y if code == be.LIN_IDENTITY else ops.grad(y, _DIM[code], adjoint=True)
+
+
+def _scaled(coef_b, x, sign=1.0):
+    """sign * coef[b] * x[b]"""
+    return ops.lincomb([(coef_b if sign == 1.0 else coef_b * sign, x)])
+
+
+class _LinApply(torch.autograd.Function):
+    """y = K x for K in {I, grad_H, grad_W} (the initial split variables v_i = K_i x0, admm.py:61-67)"""
+
+    @staticmethod
+    def forward(ctx, code, x):
+        ctx.code = code
+        return _K(code, x.contiguous()).clone() if code == be.LIN_IDENTITY else _K(code, x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, _KT(ctx.code, g.contiguous())
+
+
+class _Rhs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, codes, rho, *vu):
+        n = len(codes)
+        v, u = vu[:n], vu[n:]
+        rhs = torch.empty_like(v[0])
+        specs = [dict(linop=lc, prox=pc if pc != be.PROX_EXTERNAL else be.PROX_NORM1, alpha=1.0, lam=None, v=v[i].contiguous(),
+                      u=u[i].contiguous()) for i, (lc, pc) in enumerate(codes)]
+        ctx.keep = specs
+        ops.admm_rhs(rhs, None, rho.contiguous(), ops.make_terms(specs), n)
+        ctx.codes = codes
+        ctx.save_for_backward(rho, rhs)
+        return rhs
+
+    @staticmethod
+    def backward(ctx, g):
+        rho, rhs = ctx.saved_tensors
+        g = g.contiguous()
+        gv = [_scaled(rho, _K(lc, g)) for lc, _ in ctx.codes]
+        gu = [ops.lincomb([(-1.0, t)]) for t in gv]
+        g_rho = ops.bdot(g, rhs) / rho
+        return (None, g_rho, *gv, *gu)
+
+
+class _Solve(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, rhs, rho, *offsets):
+        t0, c0, t1, c1 = plan.diag
+        x = ops.fourier_solve(rhs.contiguous(), t0, t1, c0, c1, rho, plan.eps, spec_add=plan.FK)
+        ctx.plan = plan
+        ctx.save_for_backward(x, rho)
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        plan = ctx.plan
+        x, rho = ctx.saved_tensors
+        t0, c0, t1, c1 = plan.diag
+        g_rhs = ops.fourier_apply_inv(gx.contiguous(), t0, t1, c0, c1, rho, plan.eps)
+        # d x / d rho = -M (sum_Psi K_i^T K_i) x
+        Gx = None
+        for lc, _ in plan.codes:
+            t = _KT(lc, _K(lc, x))
+            Gx = t if Gx is None else ops.lincomb([(1.0, Gx), (1.0, t)])
+        g_rho = -ops.bdot(g_rhs, Gx) if Gx is not None else torch.zeros_like(rho)
+        g_offs = []
+        for need, otf in zip(ctx.needs_input_grad[3:], plan.omega_otfs):
+            if not need:
+                g_offs.append(None)
+            else:
+                g_offs.append(g_rhs if otf is None else ops.fft_conv(g_rhs, otf, conj=False))
+        return (None, g_rhs, g_rho, *g_offs)
+
+
+class _ZUpdate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, x, *lam_u):
+        n = len(plan.codes)
+        lams, us = lam_u[:n], lam_u[n:]
+        x = x.contiguous()
+        ds, vs, uos = [], [], []
+        for (lc, pc), fn, lam, u in zip(plan.codes, plan.psi, lams, us):
+            d = ops.lincomb([(1.0, _K(lc, x)), (1.0, u.contiguous())])
+            v = ops.prox(pc, d, lam, float(fn.alpha), None)
+            ds.append(d)
+            vs.append(v)
+            uos.append(ops.lincomb([(1.0, d), (-1.0, v)]))
+        ctx.plan = plan
+        ctx.save_for_backward(*lams, *ds)
+        return (*vs, *uos)
+
+    @staticmethod
+    def backward(ctx, *g):
+        plan = ctx.plan
+        n = len(plan.codes)
+        saved = ctx.saved_tensors
+        lams, ds = saved[:n], saved[n:]
+        gvs, guos = g[:n], g[n:]
+        gx, glams, gus = None, [], []
+        for i, ((lc, pc), fn) in enumerate(zip(plan.codes, plan.psi)):
+            gv = gvs[i] if gvs[i] is not None else torch.zeros_like(ds[i])
+            gu = guos[i] if guos[i] is not None else torch.zeros_like(ds[i])
+            diff = ops.lincomb([(1.0, gv.contiguous()), (-1.0, gu.contiguous())])
+            jd, dl = ops.prox_bwd(pc, ds[i], diff, lams[i], float(fn.alpha), None, want_dlam=True)
+            gd = ops.lincomb([(1.0, jd), (1.0, gu.contiguous())])
+            glams.append(ops.bdot(diff, dl) * float(fn.alpha))
+            gus.append(gd)
+            t = _KT(lc, gd)
+            gx = t if gx is None else ops.lincomb([(1.0, gx), (1.0, t)])
+        return (None, gx, *glams, *gus)
+
+
+def needs_grad(x0, rhos, lams, offsets, state_tensors=()):
+    if not torch.is_grad_enabled():
+        return False
+    ts = [x0, rhos] + list(lams.values()) + [o for o in offsets if o is not None] + list(state_tensors)
+    return any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+class DiffPlan:
+    """what the three Functions need from a recognised problem (built by FusedADMM.run_differentiable)"""
+
+    def __init__(self, codes, psi, diag, FK, omega_otfs, eps):
+        self.codes, self.psi, self.diag, self.FK, self.omega_otfs, self.eps = codes, psi, diag, FK, omega_otfs, eps
+
+
+def _sched(vals, it, B, dev):
+    """entry `it` of a 0-d / [T] / [B,T] schedule as a [B] device tensor, differentiably (tiny torch ops: plumbing)"""
+    v = vals if isinstance(vals, torch.Tensor) else torch.as_tensor(vals, dtype=torch.float32)
+    v = v.to(device=dev, dtype=torch.float32)
+    if v.ndim >= 1:
+        v = v[..., it]
+    return v.reshape(-1).expand(B).contiguous() if v.numel() in (1, B) else v
+
+
+def run(plan: DiffPlan, state, rhos, lams, max_iter, diff_offsets):
+    """max_iter differentiable ADMM iterations from `state` = (x, [v_i], [u_i]); returns the new state.
+    When x requires grad but the split variables are not connected to it (the state came straight from
+    ``initialize``), v_i = K_i x is rebuilt differentiably."""
+    x, v, u = state
+    B, dev = int(x.shape[0]), x.device
+    n = len(plan.codes)
+    codes = tuple(plan.codes)
+    v, u = list(v), list(u)
+    if x.requires_grad:
+        v = [_LinApply.apply(lc, x) if (t.grad_fn is None and not t.requires_grad) else t for (lc, _), t in zip(codes, v)]
+    for it in range(max_iter):
+        rho = _sched(rhos, it, B, dev)
+        lam = [_sched(lams[fn], it, B, dev) for fn in plan.psi]
+        rhs = _Rhs.apply(codes, rho, *v, *u)
+        x = _Solve.apply(plan, rhs, rho, *diff_offsets)
+        out = _ZUpdate.apply(plan, x, *lam, *u)
+        v, u = list(out[:n]), list(out[n:])
+    return x, v, u

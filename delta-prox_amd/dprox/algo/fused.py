@@ -24,6 +24,7 @@ from tqdm import tqdm
 
 from .. import _backend as be
 from .. import _ops as ops
+from . import autodiff
 from ..linop import Constant, Variable, conv, grad
 from ..linop import sum as lin_sum
 from ..proxfn import deep_prior, least_squares, nonneg, norm1, norm2, sum_squares
@@ -155,6 +156,21 @@ class FusedADMM:
             s._fk_cache = (fk_key, FK, offs)
         (t0, c0), (t1, c1) = ls.diag_tables(x0.shape, dev, True)
 
+        # ---- differentiable (unrolled-training) mode: hand-written backward stages, autodiff.py -------------------
+        raw_offs = [self._offset_autograd(fn, x0) for fn in s.omega_fns]
+        if autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u)):
+            if any(pc == be.PROX_EXTERNAL for _, pc in self.codes):
+                raise NotImplementedError("gradients through deep_prior / FFDNet are not built yet (unrolled TV-type problems are)")
+            otfs = []
+            for fn in s.omega_fns:
+                cv = _omega_conv(fn)
+                otfs.append(cv._tables(x0.shape, dev) if cv is not None else None)
+            plan = autodiff.DiffPlan(self.codes, psi, (t0, c0, t1, c1), FK, otfs, ls_eps(ls))
+            diff_offs = [o if o is not None else torch.zeros((), device=dev) for o in raw_offs]
+            x, v, u = autodiff.run(plan, (x0, v, u), rhos, {fn: lams[fn] for fn in psi}, T, diff_offs)
+            s.Kall.update_vars([x.detach()])
+            return x, v, u
+
         v = [t.contiguous() for t in v]
         u = [t.contiguous() for t in u]
         x = torch.empty_like(x0)
@@ -195,6 +211,20 @@ class FusedADMM:
         s.Kall.update_vars([x])
         return x, v, u
 
+
+    @staticmethod
+    def _offset_autograd(fn, x0):
+        """The offset b of a recognised Omega term as an autograd-connected tensor when one of its constants requires
+        grad (offset = -sum of the constant leaves of  K x + c_1 + ...), else None.  Only routes gradients: the forward
+        pass uses the data spectrum built from the native offset."""
+        consts = [c for c in fn.linop.constants if isinstance(c._value, torch.Tensor) and c._value.requires_grad]
+        if not consts or not torch.is_grad_enabled():
+            return None
+        tot = None
+        for c in fn.linop.constants:
+            val = c._value.to(x0.device)
+            tot = val if tot is None else tot + val
+        return (-tot).expand_as(x0)
 
     def _run_two_kernel(self, shape, dev, T, terms, n, v, u, x, rhs, FK, diag, rho_tab, lam_tab, rhos, lams, pbar, callback):
         """power-of-two planes: cols -> rows, two kernels per iteration; x / v only leave the chip on request"""

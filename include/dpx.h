@@ -103,6 +103,13 @@ int dpx_fourier_solve(const float* rhs, float* x, const void* spec_add, const vo
                       const float* rho, float eps, int B, int C, int H, int W,
                       const void* table, void* spectrum_ws, dpx_stream_t stream);
 
+/* out = irFFT2[ rFFT2(g) / (d0 + c0 + rho_b (d1 + c1) + eps) ]: the (self-adjoint) linear part of the x-update, i.e.
+ * dpx_fourier_solve without data spectrum and without eps in the numerator.  It is the vector-Jacobian product of
+ * least_squares.solve_direct w.r.t. its right-hand side (backward of proxfn/sum_square.py:123-156; the reference gets it
+ * from PyTorch autograd through fftn / division / ifftn).                                                            */
+int dpx_fourier_apply_inv(const float* g, float* out, const void* dd, const float* rho, float eps, int B, int C, int H, int W,
+                          const void* table, void* ws, dpx_stream_t stream);
+
 /* complex64 2-D FFT of P planes, optionally centred (ifftshift -> fft2 -> fftshift) and orthonormal: utils.fft2 / ifft2,
  * dprox/utils/misc.py:164-193 (used by CS-MRI style operators mask * fft2(x)).  Out of place, any size.        */
 int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, int P, int H, int W, const void* table,
@@ -154,6 +161,13 @@ int dpx_bgram(const float* r, float* out, int B, long n_per_batch, void* ws, dpx
 #define DPX_PROX_EXTERNAL 3 /* z-update only: v <- K x + u (the denoiser runs next), u untouched */
 int dpx_prox(int kind, const float* v, float* out, const float* lam, float alpha, const float* off,
              int B, long n_per_batch, dpx_stream_t stream);
+
+/* Backward of dpx_prox for v = prox(d): gd = J(d)^T g (soft-threshold / nonneg: a mask; sum-squares: a scale) and
+ * dlam = d prox / d lam evaluated at d (soft-threshold: -sign(d) on the pass band; nonneg: 0; sum-squares:
+ * -2 (d - offset) / (1 + 2 lam)^2), so that grad_lam[b] = alpha * <g_b, dlam_b>.  Same argument meaning as dpx_prox;
+ * gd and / or dlam may be NULL.  (Reference: autograd through proxfn/norm.py:6-27, nonneg.py:10-11, sum_square.py:26-27.) */
+int dpx_prox_bwd(int kind, const float* d, const float* g, float* gd, float* dlam, const float* lam, float alpha, const float* offset,
+                 int B, long n_per_batch, dpx_stream_t stream);
 
 /* one Psi term of the ADMM splitting (algo/admm.py:26-36): linop K_i and prox of g_i */
 #define DPX_LIN_IDENTITY 0

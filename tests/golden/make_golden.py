@@ -377,6 +377,56 @@ def g9_admm_pnp():
          x_f64=x64, v0_f64=v64[0], x_nonneg_f64=x64n)
 
 
+def g11_unrolled_grads():
+    """Config-5 shape of problem at fixture size: unrolled ADMM (specialize method='unroll', shared solver), MSE loss,
+    gradients w.r.t. the per-iteration rho / lambda schedules and the observation (README.md:93-116,
+    specialization/unroll.py:14-18)."""
+    gt, b, psf = synthetic.deconv_case(2, 3, 32, 40, seed=110)
+    K = 3
+    out = {"gt": gt, "b": b, "psf": psf}
+    for tag, with_nonneg in (("tv", False), ("tvnn", True)):
+        x = dp.Variable()
+        bt = T(b).clone().requires_grad_(True)
+        n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+        fns = dp.sum_squares(dp.conv(x, psf) - bt) + n0 + n1
+        if with_nonneg:
+            nn_ = dp.nonneg(x)
+            fns = fns + nn_
+        solver = dp.compile(fns, method="admm", device="cpu")
+        solver = dp.specialize(solver, method="unroll", device="cpu", max_iter=K)
+        rhos = torch.tensor([0.3, 0.2, 0.1], requires_grad=True)
+        l0 = torch.tensor([0.02, 0.015, 0.01], requires_grad=True)
+        l1 = torch.tensor([0.03, 0.02, 0.012], requires_grad=True)
+        lams = {n0: l0, n1: l1}
+        if with_nonneg:
+            lams[nn_] = torch.zeros(K)
+        x0 = T(b).clone().requires_grad_(True)
+        xo = solver.solve(x0=x0, rhos=rhos, lams=lams)
+        loss = ((xo - T(gt)) ** 2).mean()
+        loss.backward()
+        out.update({f"{tag}_x": xo, f"{tag}_loss": loss, f"{tag}_g_rhos": rhos.grad, f"{tag}_g_l0": l0.grad, f"{tag}_g_l1": l1.grad,
+                    f"{tag}_g_b": bt.grad, f"{tag}_g_x0": x0.grad if x0.grad is not None else torch.zeros_like(x0)})
+        print(tag, float(loss), rhos.grad, l0.grad, l1.grad, float(bt.grad.abs().max()), None if x0.grad is None else float(x0.grad.abs().max()))
+    # UnrolledSolver proper (share=False: one solver clone per step, learned rho / lambda parameters); the reference's
+    # per-step lam dict is keyed by psi_fns[0] only (unroll.py:54), i.e. it serves single-Psi problems
+    # (norm1(x): |H|^2 + rho >= rho keeps the x-update well conditioned; a single grad term leaves a whole line of
+    #  frequencies with denominator ~eps, where fp32 round-off, not the algorithm, decides the output)
+    x = dp.Variable()
+    n1 = dp.norm1(x)
+    solver = dp.compile(dp.sum_squares(dp.conv(x, psf) - T(b)) + n1, method="admm", device="cpu")
+    us = dp.specialize(solver, method="unroll", device="cpu", max_iter=K, share=False, learned_params=True)
+    with torch.no_grad():
+        us.rhos.copy_(torch.tensor([0.3, 0.2, 0.1]))
+        list(us.lams.values())[0].copy_(torch.tensor([0.03, 0.02, 0.012]))
+    xo = us.solve(x0=T(b))
+    loss = ((xo - T(gt)) ** 2).mean()
+    loss.backward()
+    out.update(us_x=xo, us_loss=loss, us_g_rhos=us.rhos.grad, us_g_lam=list(us.lams.values())[0].grad)
+    print("us", float(loss.detach()), us.rhos.grad, list(us.lams.values())[0].grad)
+    out["rhos"], out["l0"], out["l1"] = np.array([0.3, 0.2, 0.1], "float32"), np.array([0.02, 0.015, 0.01], "float32"), np.array([0.03, 0.02, 0.012], "float32")
+    save("g11_unrolled_grads", **out)
+
+
 def g15_csmri():
     """CS-MRI pipeline of the reference's examples (csmri closed-form data term + CustomADMM + gray FFDNet prior):
     dprox/proxfn/fast/csmri.py:8-25, dprox/contrib/csmri.py:156-171, ext_sum_squares routing invert.py:8-12."""
@@ -468,6 +518,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri):
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -286,6 +286,62 @@ def case_ladmm_cg(device):
     assert_close(xa.cpu(), g["x_admm"], 2 * TOL, "admm+cg x")
 
 
+def case_unrolled_grads(device):
+    """G11 (config 5 at fixture size): loss and gradients of 3 unrolled ADMM iterations w.r.t. the rho / lambda schedules,
+    the observation b and x0 -- hand-written backward stages vs the reference's PyTorch autograd.
+    Tolerances: forward 1e-5; gradients 1e-4 (measured ~2e-6; the reference's own gradient tests use rtol 1e-2..1e-3,
+    tests/linalg/test_linear_solver_grad.py:101-123: soft-threshold masks make them piecewise constant in x)."""
+    g = load_golden("g11_unrolled_grads")
+    gt = T(g["gt"], device)
+    for tag, with_nn in (("tv", False), ("tvnn", True)):
+        x = dp.Variable()
+        bt = T(g["b"], device).clone().requires_grad_(True)
+        n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+        fns = dp.sum_squares(dp.conv(x, g["psf"]) - bt) + n0 + n1
+        if with_nn:
+            nn_ = dp.nonneg(x)
+            fns = fns + nn_
+        solver = dp.compile(fns, method="admm", device=device)
+        solver = dp.specialize(solver, method="unroll", device=device, max_iter=3)
+        rhos = torch.tensor(g["rhos"], requires_grad=True)
+        l0, l1 = torch.tensor(g["l0"], requires_grad=True), torch.tensor(g["l1"], requires_grad=True)
+        lams = {n0: l0, n1: l1}
+        if with_nn:
+            lams[nn_] = torch.zeros(3)
+        x0 = T(g["b"], device).clone().requires_grad_(True)
+        xo = solver.solve(x0=x0, rhos=rhos, lams=lams)
+        loss = ((xo - gt) ** 2).mean()
+        loss.backward()
+        assert_close(xo.detach().cpu(), g[f"{tag}_x"], TOL, f"{tag} unrolled x")
+        lv = float(loss.detach())
+        assert abs(lv - float(g[f"{tag}_loss"])) <= 1e-5 * abs(float(g[f"{tag}_loss"])), (lv, float(g[f"{tag}_loss"]))
+        for name, got in (("g_rhos", rhos.grad), ("g_l0", l0.grad), ("g_l1", l1.grad), ("g_b", bt.grad), ("g_x0", x0.grad)):
+            assert got is not None, f"{tag} {name}: no gradient"
+            assert_close(got.detach().cpu(), g[f"{tag}_{name}"], 1e-4, f"{tag} {name}")
+
+
+def case_unrolled_solver(device):
+    """G11 (second half): UnrolledSolver with one solver clone per step and learned rho / lambda parameters
+    (specialization/unroll.py:21-58)"""
+    g = load_golden("g11_unrolled_grads")
+    x = dp.Variable()
+    n1 = dp.norm1(x)
+    b = T(g["b"], device)
+    solver = dp.compile(dp.sum_squares(dp.conv(x, g["psf"]) - b) + n1, method="admm", device=device)
+    us = dp.specialize(solver, method="unroll", device=device, max_iter=3, share=False, learned_params=True)
+    assert len(us.solvers) == 3 and us.solvers[1] is not us.solvers[0]
+    assert sorted(n for n, _ in us.named_parameters() if "rhos" in n or "lam_" in n) == ["lam_0", "rhos"]
+    with torch.no_grad():
+        us.rhos.copy_(torch.tensor([0.3, 0.2, 0.1]))
+        list(us.lams.values())[0].copy_(torch.tensor([0.03, 0.02, 0.012]))
+    xo = us.solve(x0=b)
+    loss = ((xo - T(g["gt"], device)) ** 2).mean()
+    loss.backward()
+    assert_close(xo.detach().cpu(), g["us_x"], TOL, "UnrolledSolver x")
+    assert_close(us.rhos.grad.cpu(), g["us_g_rhos"], 1e-4, "UnrolledSolver d loss / d rhos")
+    assert_close(list(us.lams.values())[0].grad.cpu(), g["us_g_lam"], 1e-4, "UnrolledSolver d loss / d lams")
+
+
 def case_csmri(device):
     """G15: closed-form csmri data term (native complex FFT + masked update) and CustomADMM on a complex iterate"""
     from dprox.contrib.csmri import CustomADMM

@@ -80,6 +80,14 @@ def test_csmri_custom_admm():
     pc.case_csmri(DEV)
 
 
+def test_unrolled_gradients():
+    pc.case_unrolled_grads(DEV)
+
+
+def test_unrolled_solver_learned_params():
+    pc.case_unrolled_solver(DEV)
+
+
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV)
 

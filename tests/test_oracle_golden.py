@@ -206,6 +206,30 @@ def test_g9_admm_pnp():
     assert_close(x2, g["x_nonneg"], 1e-5)
 
 
+def test_g11_unrolled_grads():
+    """The oracle is plain torch: autograd through it must reproduce the reference's gradients (config 5)."""
+    g = load_golden("g11_unrolled_grads")
+    b, gt = T(g["b"]), T(g["gt"])
+    for tag, with_nn in (("tv", False), ("tvnn", True)):
+        bt = b.clone().requires_grad_(True)
+        n0, n1 = O.norm1(O.lin_grad(0)), O.norm1(O.lin_grad(1))
+        terms = [O.sum_squares(O.lin_conv(g["psf"]).minus(bt)), n0, n1]
+        rhos = torch.tensor(g["rhos"], requires_grad=True)
+        l0, l1 = torch.tensor(g["l0"], requires_grad=True), torch.tensor(g["l1"], requires_grad=True)
+        lams = {n0: l0, n1: l1}
+        if with_nn:
+            nn_ = O.nonneg(O.lin_identity())
+            terms.append(nn_)
+            lams[nn_] = torch.zeros(3)
+        x0 = b.clone().requires_grad_(True)
+        xo = O.solve(terms, "admm", x0=x0, rhos=rhos, lams=lams, max_iter=3)
+        loss = ((xo - gt) ** 2).mean()
+        loss.backward()
+        assert_close(xo.detach(), g[f"{tag}_x"], 1e-6)
+        for name, got in (("g_rhos", rhos.grad), ("g_l0", l0.grad), ("g_l1", l1.grad), ("g_b", bt.grad), ("g_x0", x0.grad)):
+            assert_close(got, g[f"{tag}_{name}"], 1e-5, f"{tag} {name}")
+
+
 def test_g15_csmri():
     """csmri closed-form prox + CustomADMM with the gray FFDNet prior (complex iterate)."""
     g = load_golden("g15_csmri")

@@ -61,3 +61,26 @@ if "c4" in which:
         dt, out = timed(lambda: s.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=10), 1)
     print(f"config4 32x1x320x320 CS-MRI LADMM+CG(<=100) + nonneg + FFDNet-gray, 10 outer it: {dt/10*1e3:.1f} ms/outer it, CG its {s.least_square.cg_iters[-10:]}, "
           f"PSNR {psnr(x0.cpu(), torch.from_numpy(gt)):.2f} -> {psnr(out.cpu(), torch.from_numpy(gt)):.2f} dB")
+
+if "c5" in which:
+    # config 5: unrolled ADMM (10 iterations) training step on 4x3x512x512 -- forward + backward w.r.t. the rho / lambda schedules
+    gt, b, psf = synthetic.deconv_case(4, 3, 512, 512, seed=2023)
+    bt, gtt = torch.from_numpy(b).to(dev), torch.from_numpy(gt).to(dev)
+    x = dp.Variable()
+    n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+    s = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + n0 + n1, method="admm", device=dev)
+    s = dp.specialize(s, method="unroll", device=dev, max_iter=10)
+    rhos = torch.full((10,), 0.1, requires_grad=True)
+    l0, l1 = torch.full((10,), 0.005, requires_grad=True), torch.full((10,), 0.005, requires_grad=True)
+    def step():
+        for p in (rhos, l0, l1):
+            p.grad = None
+        out = s.solve(x0=bt, rhos=rhos, lams={n0: l0, n1: l1})
+        loss = ((out - gtt) ** 2).mean()
+        loss.backward()
+        return loss
+    dt, loss = timed(step, 5)
+    with torch.no_grad():
+        dtf, _ = timed(lambda: s.solve(x0=bt, rhos=rhos.detach(), lams={n0: l0.detach(), n1: l1.detach()}), 5)
+    print(f"config5 4x3x512x512 unrolled ADMM x10, MSE loss: fwd+bwd {dt*1e3:.2f} ms/step ({1/dt:.1f} steps/s), inference-only forward {dtf*1e3:.2f} ms; "
+          f"loss {float(loss.detach()):.5f}, |g_rho| {float(rhos.grad.abs().sum()):.3e}, |g_lam| {float(l0.grad.abs().sum() + l1.grad.abs().sum()):.3e}")
