@@ -57,7 +57,7 @@ DESIGN_BYTES_PER_ELEM = 36.0        # what the two-kernel iteration actually has
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()

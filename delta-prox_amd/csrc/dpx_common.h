@@ -112,7 +112,7 @@ static inline int spec_cols(int W) { return (W + 1) / 2; }
 // kernel is a linear 512-byte-per-wave-instruction access -- and the Nyquist bins live in the side part.
 bool pow2_path_available(int H, int W);
 #ifndef DPX_SPEC_TILE
-#define DPX_SPEC_TILE 8            // columns per spectrum tile of the power-of-two layout (4 or 8)
+#define DPX_SPEC_TILE 16           // columns per spectrum tile of the power-of-two layout (4, 8 or 16): 16 = one 128-byte line per row
 #endif
 constexpr int SPEC_TILE = DPX_SPEC_TILE;
 __host__ __device__ __forceinline__ size_t spec_main_index(int tiled, int H, int Ws, int k, int l) {

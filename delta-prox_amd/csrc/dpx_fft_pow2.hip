@@ -136,11 +136,23 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   size_t ubase;                                       // element offset of the tile's plane / of the side array
   unsigned off0, step, toff0, tbase;                  // data offset of row t, row step, table offset of row t, table base
   int p;
+  unsigned sub_off = 0;                               // column offset of this workgroup inside a wider spectrum tile
   if (!is_side) {
     p = bid / tiles;
-    const int j = (bid - p * tiles) * (COLS / SPEC_TILE);     // first spectrum tile of this workgroup
+    int j;                                              // first spectrum tile of this workgroup
+    if constexpr (COLS >= SPEC_TILE) {
+      j = (bid - p * tiles) * (COLS / SPEC_TILE);
+    } else {
+      // SPEC_TILE / COLS workgroups share a tile (and its 128-byte lines): they are placed 8 block ids apart so that
+      // the round-robin block -> XCD assignment puts them on the same XCD, i.e. behind the same L2
+      constexpr int SUB = SPEC_TILE / COLS;
+      static_assert(SUB == 2, "sub-tile workgroups: only two per tile are laid out");
+      const int q = bid - p * tiles;
+      j = (q / 16) * 8 + (q % 8);
+      sub_off = (unsigned)(((q % 16) / 8) * COLS);
+    }
     ubase = (size_t)p * H * Ws + (size_t)j * H * SPEC_TILE;   // tile-major main part: element (row r, col c) of a tile at r*TILE + c
-    off0 = (unsigned)((c / SPEC_TILE) * H * SPEC_TILE + t * SPEC_TILE + (c % SPEC_TILE));
+    off0 = (unsigned)((c / SPEC_TILE) * H * SPEC_TILE + t * SPEC_TILE + (c % SPEC_TILE)) + sub_off;
     step = (unsigned)(T * SPEC_TILE);
     toff0 = off0;
     tbase = (unsigned)((p % C) * H * Ws + j * H * SPEC_TILE);
@@ -190,7 +202,7 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
       int ln = lane;
       DPX_OPAQUE(ln);                                   // derive the source address here, not at kernel entry
       const int half = ln >> 5, li = ln & 31;
-      const float2* src = A.dd + tbase + (unsigned)((T * half + 8 * wave + (li >> 2)) * SPEC_TILE + (li & 3) * 2);
+      const float2* src = A.dd + tbase + (unsigned)((T * half + 8 * wave + (li >> 2)) * SPEC_TILE + (li & 3) * 2) + sub_off;
 #pragma unroll
       for (int j = 0; j < V / 2; ++j) dpx_glds16(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
     }
@@ -321,28 +333,30 @@ static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A,
              spec_out, A, C, Ws, P, twH);
 }
 
+constexpr int COLS_WG = SPEC_TILE > 8 ? 8 : SPEC_TILE;   // columns per workgroup of the column kernel
+
 template <int OP>
 static void cols_dispatch(int H, const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
   if (H == 1024 && OP == OP_SOLVE) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("DPX_DEBUG_COLS"); dbg = e ? atoi(e) : 0; }
-    if (dbg == 1) { launch_cols<1024, 64, SPEC_TILE, OP, 1>(spec, spec_out, A, P, C, Ws, twH, s); return; }
-    if (dbg == 2) { launch_cols<1024, 64, SPEC_TILE, OP, 2>(spec, spec_out, A, P, C, Ws, twH, s); return; }
-    if (dbg == 3) { launch_cols<1024, 64, SPEC_TILE, OP, 3>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 1) { launch_cols<1024, 64, COLS_WG, OP, 1>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 2) { launch_cols<1024, 64, COLS_WG, OP, 2>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+    if (dbg == 3) { launch_cols<1024, 64, COLS_WG, OP, 3>(spec, spec_out, A, P, C, Ws, twH, s); return; }
     if (dbg == 4) {
-      const size_t sh = (size_t)(SPEC_TILE * 1092 + 1024) * sizeof(float2);
+      const size_t sh = (size_t)(COLS_WG * 1092 + 1024) * sizeof(float2);
       static bool once = false;
-      if (!once) { hipFuncSetAttribute((const void*)k_cols_probe_wide<1024, 64, SPEC_TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); once = true; }
-      const int nt = P * (Ws / SPEC_TILE);
-      DPX_LAUNCH("k_cols_p2", (k_cols_probe_wide<1024, 64, SPEC_TILE>), dim3(nt), dim3(512), sh, s, (const float4*)spec, (float4*)spec_out,
+      if (!once) { hipFuncSetAttribute((const void*)k_cols_probe_wide<1024, 64, COLS_WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); once = true; }
+      const int nt = P * (Ws / COLS_WG);
+      DPX_LAUNCH("k_cols_p2", (k_cols_probe_wide<1024, 64, COLS_WG>), dim3(nt), dim3(512), sh, s, (const float4*)spec, (float4*)spec_out,
                  (const float4*)A.add, nt);
       return;
     }
   }
   switch (H) {
-    case 256: launch_cols<256, 32, SPEC_TILE, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
-    case 512: launch_cols<512, 64, SPEC_TILE, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
-    default: launch_cols<1024, 64, SPEC_TILE, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 256: launch_cols<256, 32, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 512: launch_cols<512, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    default: launch_cols<1024, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
   }
 }
 
