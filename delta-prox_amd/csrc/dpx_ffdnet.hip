@@ -30,7 +30,10 @@ static inline int mtiles(int cout) { return (cout + 31) / 32; }
 // packed layer: weights [Cin_pad/2][9][2][MT*32] then bias [MT*32]
 static inline size_t layer_floats(int cin, int cout) { return (size_t)(pad_even(cin) / 2) * 9 * 2 * mtiles(cout) * 32 + (size_t)mtiles(cout) * 32; }
 
-__global__ void k_ffd_pack_weights(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ dst, int cin, int cout) {
+// transposed != 0: the layer of the backward-data pass, conv with W'[co'][ci'][tap] = W[ci'][co'][8 - tap] (w is still the
+// forward tensor [cout' ... ] = [cin][cout]-swapped view: w has shape [cin][cout][3][3] in the primed names), zero bias
+__global__ void k_ffd_pack_weights(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ dst, int cin, int cout,
+                                   int transposed) {
   const int MT32 = ((cout + 31) / 32) * 32, pairs = ((cin + 1) & ~1) / 2;
   const long nw = (long)pairs * 9 * 2 * MT32;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + MT32; i += (long)gridDim.x * blockDim.x) {
@@ -41,10 +44,11 @@ __global__ void k_ffd_pack_weights(const float* __restrict__ w, const float* __r
       r /= 2;
       const int tap = (int)(r % 9), cp = (int)(r / 9);
       const int ci = 2 * cp + half;
-      dst[i] = (co < cout && ci < cin) ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
+      if (!transposed) dst[i] = (co < cout && ci < cin) ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
+      else dst[i] = (co < cout && ci < cin) ? w[((long)ci * cout + co) * 9 + (8 - tap)] : 0.f;
     } else {
       const int co = (int)(i - nw);
-      dst[i] = co < cout ? b[co] : 0.f;
+      dst[i] = (co < cout && !transposed) ? b[co] : 0.f;
     }
   }
 }
@@ -85,6 +89,59 @@ __global__ void k_ffd_unpack_out(const float* __restrict__ o, float* __restrict_
   }
 }
 
+// ---- backward helpers ------------------------------------------------------------------------------------------
+// adjoint of k_ffd_unpack_out: g_o[b][c*4 + dy*2 + dx][y2][x2] = gy[b][c][2 y2 + dy][2 x2 + dx] (0 outside the crop)
+__global__ void k_ffd_pack_gout(const float* __restrict__ gy, float* __restrict__ go, int B, int C, int H, int W, int H2, int W2) {
+  const long total = (long)B * 4 * C * H2 * W2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x2 = (int)(i % W2);
+    long r = i / W2;
+    const int y2 = (int)(r % H2);
+    r /= H2;
+    const int ch = (int)(r % (4 * C)), b = (int)(r / (4 * C));
+    const int c = ch >> 2, yy = 2 * y2 + ((ch >> 1) & 1), xx = 2 * x2 + (ch & 1);
+    go[i] = (yy < H && xx < W) ? gy[(((long)b * C + c) * H + yy) * W + xx] : 0.f;
+  }
+}
+
+// adjoint of k_ffd_pack_in w.r.t. x: the replicate padding of an odd size makes the last row / column receive two terms
+__global__ void k_ffd_unpack_gin(const float* __restrict__ ga, float* __restrict__ gx, int B, int C, int H, int W, int H2, int W2, int Cp) {
+  const long total = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    long r = i / W;
+    const int yy = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    const int y2 = yy >> 1, x2 = xx >> 1;
+    const int dy0 = yy & 1, dx0 = xx & 1;
+    const int ndy = (yy == H - 1 && (H & 1)) ? 2 : 1, ndx = (xx == W - 1 && (W & 1)) ? 2 : 1;   // padded duplicates
+    float acc = 0.f;
+    for (int a = 0; a < ndy; ++a)
+      for (int e = 0; e < ndx; ++e) {
+        const int dy = ndy == 2 ? a : dy0, dx = ndx == 2 ? e : dx0;
+        acc += ga[(((long)b * Cp + c * 4 + dy * 2 + dx) * H2 + y2) * W2 + x2];
+      }
+    gx[i] = acc;
+  }
+}
+
+// gsigma[b] = sum over the sigma-map channel of g_a0 (one block per image, fixed summation order)
+__global__ void __launch_bounds__(256) k_ffd_sigma_grad(const float* __restrict__ ga, float* __restrict__ gs, int C, int H2, int W2, int Cp) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x;
+  const float* pl = ga + ((size_t)b * Cp + 4 * C) * H2 * W2;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < (long)H2 * W2; i += 256) acc += pl[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gs[b] = sh[0];
+}
+
 // NP channel pairs x 9 taps, fully unrolled; the LDS fragments of step k+1 are fetched while step k multiplies
 template <int MT, int NP>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __restrict__ sin_b, const float* __restrict__ sw_b) {
@@ -119,9 +176,11 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __
 }
 
 // in [B][Cin][H2][W2] (Cin even), out [B][Cout][H2][W2]; wpk = packed layer (see layer_floats)
-template <int MT, bool RELU>
+// MASKED: the staged input is in[.] * [mask[.] > 0] (backward through the ReLU that produced `mask`, fused into the load)
+template <int MT, bool RELU, bool MASKED = false>
 __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
-                                                       const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x) {
+                                                       const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x,
+                                                       const float* __restrict__ mask) {
   constexpr int M32 = MT * 32;
   __shared__ float s_in[2 * FFD_CK * FFD_ROWS * FFD_LDW];                              // 2 x [ch][row][col]
   __shared__ __attribute__((aligned(16))) float s_w[2 * (FFD_CK / 2) * 9 * 2 * M32];  // 2 x [pair][tap][half][cout]
@@ -131,6 +190,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
   const int y0 = ty * FFD_TH, x0 = tx * FFD_TW;
   const int j = lane & 31, half = lane >> 5;
   const float* inb = in + (size_t)b * Cin * H2 * W2;
+  const float* maskb = MASKED ? mask + (size_t)b * Cin * H2 * W2 : nullptr;
   const float* bias = wpk + (size_t)(Cin / 2) * 9 * 2 * M32;
 
   f32x16 acc[MT][2];
@@ -156,7 +216,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
       const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
       const int yy = y0 + r - 1, xx = x0 + col - 1;
       float v = 0.f;
-      if (ch < nch && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = inb[((size_t)(c0 + ch) * H2 + yy) * W2 + xx];
+      if (ch < nch && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) {
+        const size_t idx = ((size_t)(c0 + ch) * H2 + yy) * W2 + xx;
+        v = inb[idx];
+        if (MASKED) v = maskb[idx] > 0.f ? v : 0.f;
+      }
       in_reg[e] = v;
     }
     const float4* wsrc = (const float4*)(wpk + (size_t)(c0 / 2) * 9 * 2 * M32);
@@ -215,12 +279,17 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
 }
 
 template <int MT>
-static void launch_conv(bool relu, const float* in, float* out, const float* wpk, int Cin, int Cout, int B, int H2, int W2, hipStream_t s) {
+static void launch_conv(bool relu, const float* in, float* out, const float* wpk, int Cin, int Cout, int B, int H2, int W2, hipStream_t s,
+                        const float* mask = nullptr) {
   const int tx = (W2 + FFD_TW - 1) / FFD_TW, ty = (H2 + FFD_TH - 1) / FFD_TH;
+  if (mask) {
+    DPX_LAUNCH("k_conv3x3_mfma_bwd", (k_conv3x3_mfma<MT, false, true>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx, mask);
+    return;
+  }
   if (relu)
-    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, true>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx);
+    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, true>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx, (const float*)nullptr);
   else
-    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, false>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx);
+    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, false>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx, (const float*)nullptr);
 }
 
 static int layer_cin(int l, int in_nc, int nc) { return l == 0 ? 4 * in_nc + 1 : nc; }
@@ -246,7 +315,7 @@ extern "C" int dpx_ffdnet_pack(void* packed, const float* const* w, const float*
     DPX_REQUIRE(w[l] && b[l], "dpx_ffdnet_pack: layer %d has null weights", l);
     const size_t n = layer_floats(cin, cout);
     DPX_LAUNCH("k_ffd_pack_weights", k_ffd_pack_weights, dim3(grid_for((long)n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, w[l],
-               b[l], dst, cin, cout);
+               b[l], dst, cin, cout, 0);
     dst += n;
   }
   return launch_status("dpx_ffdnet_pack");
@@ -289,4 +358,116 @@ extern "C" int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, 
   DPX_LAUNCH("k_ffd_unpack_out", k_ffd_unpack_out, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, last, y, B,
              in_nc, H, W, H2, W2);
   return launch_status("dpx_ffdnet_forward");
+}
+
+// ---- training variants: forward that keeps every layer's output, backward-data through the whole stack ----------------
+extern "C" size_t dpx_ffdnet_acts_bytes(int B, int in_nc, int nc, int nb, int H, int W) {
+  const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
+  return (px * pad_even(4 * in_nc + 1) + (size_t)(nb - 1) * px * nc + px * 4 * in_nc) * sizeof(float);
+}
+
+extern "C" int dpx_ffdnet_forward_save(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb,
+                                       int B, int H, int W, void* acts, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && sigma && packed && acts, "dpx_ffdnet_forward_save: null pointer");
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96,
+              "dpx_ffdnet_forward_save: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, Cp = pad_even(4 * in_nc + 1);
+  const size_t px = (size_t)B * H2 * W2;
+  float* a0 = (float*)acts;
+  float* hidden = a0 + px * Cp;                          // nb-1 buffers of px*nc
+  float* last = hidden + (size_t)(nb - 1) * px * nc;
+  DPX_LAUNCH("k_ffd_pack_in", k_ffd_pack_in, dim3(grid_for((long)(px * Cp), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W,
+             H2, W2, Cp);
+  const float* wl = (const float*)packed;
+  const float* cur = a0;
+  for (int l = 0; l < nb; ++l) {
+    const int cin = layer_cin(l, in_nc, nc), cout = layer_cout(l, in_nc, nc, nb);
+    float* dst = (l == nb - 1) ? last : hidden + (size_t)l * px * nc;
+    const bool relu = l != nb - 1;
+    switch (mtiles(cout)) {
+      case 1: launch_conv<1>(relu, cur, dst, wl, pad_even(cin), cout, B, H2, W2, s); break;
+      case 2: launch_conv<2>(relu, cur, dst, wl, pad_even(cin), cout, B, H2, W2, s); break;
+      default: launch_conv<3>(relu, cur, dst, wl, pad_even(cin), cout, B, H2, W2, s); break;
+    }
+    wl += layer_floats(cin, cout);
+    cur = dst;
+  }
+  DPX_LAUNCH("k_ffd_unpack_out", k_ffd_unpack_out, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, last, y, B,
+             in_nc, H, W, H2, W2);
+  return launch_status("dpx_ffdnet_forward_save");
+}
+
+// transposed layer l: input channels = forward cout (padded even), output channels = forward cin
+static size_t layer_floats_T(int l, int in_nc, int nc, int nb) { return layer_floats(layer_cout(l, in_nc, nc, nb), layer_cin(l, in_nc, nc)); }
+
+extern "C" size_t dpx_ffdnet_packed_T_bytes(int in_nc, int nc, int nb) {
+  size_t n = 0;
+  for (int l = 0; l < nb; ++l) n += layer_floats_T(l, in_nc, nc, nb);
+  return n * sizeof(float);
+}
+
+extern "C" int dpx_ffdnet_pack_T(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream) {
+  DPX_REQUIRE(packed_T && w && in_nc > 0 && nc > 0 && nb >= 2, "dpx_ffdnet_pack_T: bad arguments");
+  DPX_REQUIRE(nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96 && (4 * in_nc) % 2 == 0, "dpx_ffdnet_pack_T: unsupported channel counts");
+  float* dst = (float*)packed_T;
+  for (int l = 0; l < nb; ++l) {
+    const int cin_f = layer_cin(l, in_nc, nc), cout_f = layer_cout(l, in_nc, nc, nb);
+    DPX_REQUIRE(w[l], "dpx_ffdnet_pack_T: layer %d has null weights", l);
+    const size_t n = layer_floats(cout_f, cin_f);
+    DPX_LAUNCH("k_ffd_pack_weights", k_ffd_pack_weights, dim3(grid_for((long)n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, w[l],
+               (const float*)nullptr, dst, cout_f, cin_f, 1);
+    dst += n;
+  }
+  return launch_status("dpx_ffdnet_pack_T");
+}
+
+extern "C" size_t dpx_ffdnet_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W) {
+  const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
+  return (px * 4 * in_nc + 2 * px * nc + px * pad_even(4 * in_nc + 1)) * sizeof(float);
+}
+
+extern "C" int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, const void* packed_T, const void* acts, int in_nc, int nc,
+                                   int nb, int B, int H, int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(gy && packed_T && acts && ws && (gx || gsigma), "dpx_ffdnet_backward: null pointer");
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96,
+              "dpx_ffdnet_backward: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, Cp = pad_even(4 * in_nc + 1);
+  const size_t px = (size_t)B * H2 * W2;
+  const float* a0 = (const float*)acts;
+  const float* hidden = a0 + px * Cp;
+  float* g_last = (float*)ws;
+  float* gA = g_last + px * 4 * in_nc;
+  float* gB = gA + px * nc;
+  float* g_a0 = gB + px * nc;
+  DPX_LAUNCH("k_ffd_pack_gout", k_ffd_pack_gout, dim3(grid_for((long)(px * 4 * in_nc), 256, 8192)), dim3(256), 0, s, gy, g_last, B, in_nc,
+             H, W, H2, W2);
+  // offsets of the transposed layers inside packed_T (stored in forward order)
+  const float* wt = (const float*)packed_T;
+  size_t off[64];
+  DPX_REQUIRE(nb <= 64, "dpx_ffdnet_backward: at most 64 layers");
+  size_t o = 0;
+  for (int l = 0; l < nb; ++l) { off[l] = o; o += layer_floats_T(l, in_nc, nc, nb); }
+  const float* cur = g_last;
+  for (int l = nb - 1; l >= 0; --l) {
+    const int cin_t = layer_cout(l, in_nc, nc, nb), cout_t = layer_cin(l, in_nc, nc);   // transposed layer: cin_t -> cout_t channels
+    float* dst = (l == 0) ? g_a0 : (((nb - 1 - l) & 1) ? gB : gA);
+    // the input of transposed layer l is the gradient w.r.t. forward layer l's output; for l < nb-1 that output went
+    // through a ReLU: mask with the saved activation hidden[l]
+    const float* mask = (l < nb - 1) ? hidden + (size_t)l * px * nc : nullptr;
+    // layer 0 writes Cp channels (13 -> 14 padded: the pad channel's packed weights are zero)
+    const int cout_w = (l == 0) ? Cp : cout_t;
+    switch (mtiles(cout_t)) {
+      case 1: launch_conv<1>(false, cur, dst, wt + off[l], pad_even(cin_t), cout_w, B, H2, W2, s, mask); break;
+      case 2: launch_conv<2>(false, cur, dst, wt + off[l], pad_even(cin_t), cout_w, B, H2, W2, s, mask); break;
+      default: launch_conv<3>(false, cur, dst, wt + off[l], pad_even(cin_t), cout_w, B, H2, W2, s, mask); break;
+    }
+    cur = dst;
+  }
+  if (gx)
+    DPX_LAUNCH("k_ffd_unpack_gin", k_ffd_unpack_gin, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, g_a0, gx, B,
+               in_nc, H, W, H2, W2, Cp);
+  if (gsigma) DPX_LAUNCH("k_ffd_sigma_grad", k_ffd_sigma_grad, dim3(B), dim3(256), 0, s, g_a0, gsigma, in_nc, H2, W2, Cp);
+  return launch_status("dpx_ffdnet_backward");
 }

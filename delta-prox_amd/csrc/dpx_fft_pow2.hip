@@ -146,10 +146,9 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
       // SPEC_TILE / COLS workgroups share a tile (and its 128-byte lines): they are placed 8 block ids apart so that
       // the round-robin block -> XCD assignment puts them on the same XCD, i.e. behind the same L2
       constexpr int SUB = SPEC_TILE / COLS;
-      static_assert(SUB == 2, "sub-tile workgroups: only two per tile are laid out");
       const int q = bid - p * tiles;
-      j = (q / 16) * 8 + (q % 8);
-      sub_off = (unsigned)(((q % 16) / 8) * COLS);
+      j = (q / (8 * SUB)) * 8 + (q % 8);
+      sub_off = (unsigned)(((q % (8 * SUB)) / 8) * COLS);
     }
     ubase = (size_t)p * H * Ws + (size_t)j * H * SPEC_TILE;   // tile-major main part: element (row r, col c) of a tile at r*TILE + c
     off0 = (unsigned)((c / SPEC_TILE) * H * SPEC_TILE + t * SPEC_TILE + (c % SPEC_TILE)) + sub_off;
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   // (lane-linear image: float2 index m*64 + lane of the wave's 8 KB), so its own vmcnt wait is all the
   // synchronisation the data needs.  The data-spectrum values (HBM) are requested in one batch right behind them:
   // ONE memory round trip between the two transforms.
-  constexpr bool DMA_TABLE = (OP == OP_SOLVE) && (COLS == 8) && (V % 2 == 0) && !(DBG & 2);
+  constexpr bool DMA_TABLE = (OP == OP_SOLVE) && (COLS == 8 || COLS == 4) && (V % 2 == 0) && !(DBG & 2);
 #ifndef DPX_COLS_EARLY_ADD
 #define DPX_COLS_EARLY_ADD 0
 #endif
@@ -198,11 +197,12 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   auto fetch_table = [&]() {
     if (DMA_TABLE && !is_side) {
       DPX_LDS_BARRIER();                                // every wave has read its last-pass inputs
-      // piece j: rows T*(2j + half) + 8*wave + li/4 (half = lane / 32, li = lane % 32), columns 2*(li % 4), +1
+      // piece j: rows T*(2j + half) + RPW*wave + li/LPR (half = lane / 32, li = lane % 32), columns 2*(li % LPR), +1
+      constexpr int RPW = 64 / COLS, LPR = COLS / 2;      // rows per wave and 16-byte lanes per row
       int ln = lane;
       DPX_OPAQUE(ln);                                   // derive the source address here, not at kernel entry
       const int half = ln >> 5, li = ln & 31;
-      const float2* src = A.dd + tbase + (unsigned)((T * half + 8 * wave + (li >> 2)) * SPEC_TILE + (li & 3) * 2) + sub_off;
+      const float2* src = A.dd + tbase + (unsigned)((T * half + RPW * wave + li / LPR) * SPEC_TILE + (li % LPR) * 2) + sub_off;
 #pragma unroll
       for (int j = 0; j < V / 2; ++j) dpx_glds16(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
     }
@@ -333,7 +333,10 @@ static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A,
              spec_out, A, C, Ws, P, twH);
 }
 
-constexpr int COLS_WG = SPEC_TILE > 8 ? 8 : SPEC_TILE;   // columns per workgroup of the column kernel
+#ifndef DPX_COLS_WG
+#define DPX_COLS_WG (SPEC_TILE > 8 ? 8 : SPEC_TILE)
+#endif
+constexpr int COLS_WG = DPX_COLS_WG;   // columns per workgroup of the column kernel
 
 template <int OP>
 static void cols_dispatch(int H, const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {

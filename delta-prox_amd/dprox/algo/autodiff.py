@@ -48,6 +48,20 @@ class _LinApply(torch.autograd.Function):
         return None, _KT(ctx.code, g.contiguous())
 
 
+class _LinComb(torch.autograd.Function):
+    """sum_i c_i x_i with python-float coefficients"""
+
+    @staticmethod
+    def forward(ctx, coefs, *xs):
+        ctx.coefs = coefs
+        return ops.lincomb([(float(c), x.contiguous()) for c, x in zip(coefs, xs)])
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (None, *[g if c == 1.0 else ops.lincomb([(float(c), g)]) for c in ctx.coefs])
+
+
 class _Rhs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, codes, rho, *vu):
@@ -103,13 +117,17 @@ class _Solve(torch.autograd.Function):
 
 
 class _ZUpdate(torch.autograd.Function):
+    """the closed-form prox terms `idx` of the plan (deep priors are chained separately, see run())"""
+
     @staticmethod
-    def forward(ctx, plan, x, *lam_u):
-        n = len(plan.codes)
+    def forward(ctx, plan, idx, x, *lam_u):
+        n = len(idx)
         lams, us = lam_u[:n], lam_u[n:]
         x = x.contiguous()
         ds, vs, uos = [], [], []
-        for (lc, pc), fn, lam, u in zip(plan.codes, plan.psi, lams, us):
+        ctx.idx = idx
+        for i, lam, u in zip(idx, lams, us):
+            (lc, pc), fn = plan.codes[i], plan.psi[i]
             d = ops.lincomb([(1.0, _K(lc, x)), (1.0, u.contiguous())])
             v = ops.prox(pc, d, lam, float(fn.alpha), None)
             ds.append(d)
@@ -122,12 +140,13 @@ class _ZUpdate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *g):
         plan = ctx.plan
-        n = len(plan.codes)
+        n = len(ctx.idx)
         saved = ctx.saved_tensors
         lams, ds = saved[:n], saved[n:]
         gvs, guos = g[:n], g[n:]
         gx, glams, gus = None, [], []
-        for i, ((lc, pc), fn) in enumerate(zip(plan.codes, plan.psi)):
+        for i, k in enumerate(ctx.idx):
+            (lc, pc), fn = plan.codes[k], plan.psi[k]
             gv = gvs[i] if gvs[i] is not None else torch.zeros_like(ds[i])
             gu = guos[i] if guos[i] is not None else torch.zeros_like(ds[i])
             diff = ops.lincomb([(1.0, gv.contiguous()), (-1.0, gu.contiguous())])
@@ -137,7 +156,7 @@ class _ZUpdate(torch.autograd.Function):
             gus.append(gd)
             t = _KT(lc, gd)
             gx = t if gx is None else ops.lincomb([(1.0, gx), (1.0, t)])
-        return (None, gx, *glams, *gus)
+        return (None, None, gx, *glams, *gus)
 
 
 def needs_grad(x0, rhos, lams, offsets, state_tensors=()):
@@ -174,11 +193,23 @@ def run(plan: DiffPlan, state, rhos, lams, max_iter, diff_offsets):
     v, u = list(v), list(u)
     if x.requires_grad:
         v = [_LinApply.apply(lc, x) if (t.grad_fn is None and not t.requires_grad) else t for (lc, _), t in zip(codes, v)]
+    closed = tuple(i for i, (_, pc) in enumerate(codes) if pc != be.PROX_EXTERNAL)
+    ext = [i for i, (_, pc) in enumerate(codes) if pc == be.PROX_EXTERNAL]
     for it in range(max_iter):
         rho = _sched(rhos, it, B, dev)
         lam = [_sched(lams[fn], it, B, dev) for fn in plan.psi]
         rhs = _Rhs.apply(codes, rho, *v, *u)
         x = _Solve.apply(plan, rhs, rho, *diff_offsets)
-        out = _ZUpdate.apply(plan, x, *lam, *u)
-        v, u = list(out[:n]), list(out[n:])
+        nv, nu = list(v), list(u)
+        if closed:
+            out = _ZUpdate.apply(plan, closed, x, *[lam[i] for i in closed], *[u[i] for i in closed])
+            for k, i in enumerate(closed):
+                nv[i], nu[i] = out[k], out[len(closed) + k]
+        for i in ext:                                   # deep prior on the identity: v = D(x + u, sigma), u' = x + u - v
+            fn = plan.psi[i]
+            d = _LinComb.apply((1.0, 1.0), x, u[i])
+            fn.step = it
+            nv[i] = fn._prox(d, lam[i] * float(fn.alpha))
+            nu[i] = _LinComb.apply((1.0, -1.0), d, nv[i])
+        v, u = nv, nu
     return x, v, u

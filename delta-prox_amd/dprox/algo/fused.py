@@ -159,8 +159,6 @@ class FusedADMM:
         # ---- differentiable (unrolled-training) mode: hand-written backward stages, autodiff.py -------------------
         raw_offs = [self._offset_autograd(fn, x0) for fn in s.omega_fns]
         if autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u)):
-            if any(pc == be.PROX_EXTERNAL for _, pc in self.codes):
-                raise NotImplementedError("gradients through deep_prior / FFDNet are not built yet (unrolled TV-type problems are)")
             otfs = []
             for fn in s.omega_fns:
                 cv = _omega_conv(fn)

@@ -76,8 +76,26 @@ class FFDNet(nn.Module):
         self._packed = None
         return super()._apply(fn, *a, **k)
 
+    def _weights_version(self):
+        return tuple(p._version for p in list(self.weights) + list(self.biases))
+
+    def packed_T(self):
+        """flipped / transposed weights of the backward-data convolutions (dpx_ffdnet_pack_T), cached per weight version"""
+        dev = self.weights[0].device
+        key = (self._weights_version(), str(dev))
+        if getattr(self, "_packed_T", None) is None or self._packed_T[0] != key:
+            L = be.lib()
+            blob = torch.empty(max(L.query("dpx_ffdnet_packed_T_bytes", self.in_nc, self.nc, self.nb), 16), dtype=torch.uint8, device=dev)
+            ws = [w.detach().float().contiguous() for w in self.weights]
+            pw = (ctypes.c_void_p * self.nb)(*[w.data_ptr() for w in ws])
+            L.call("dpx_ffdnet_pack_T", be.ptr(blob), pw, self.in_nc, self.nc, self.nb, be.stream())
+            self._packed_T = (key, blob)
+        return self._packed_T[1]
+
     def packed(self):
         dev = self.weights[0].device
+        if self._packed is not None and getattr(self, "_packed_version", None) != self._weights_version():
+            self._packed = None                           # weights were updated in place (optimizer step)
         if self._packed is None or self._packed.device != dev:
             L = be.lib()
             blob = torch.empty(max(L.query("dpx_ffdnet_packed_bytes", self.in_nc, self.nc, self.nb), 16), dtype=torch.uint8, device=dev)
@@ -87,12 +105,21 @@ class FFDNet(nn.Module):
             pb = (ctypes.c_void_p * self.nb)(*[b.data_ptr() for b in bs])
             L.call("dpx_ffdnet_pack", be.ptr(blob), pw, pb, self.in_nc, self.nc, self.nb, be.stream())
             self._packed = blob
+            self._packed_version = self._weights_version()
         return self._packed
 
     def forward(self, x, sigma):
         be.require(x, what="FFDNet input")
         B, C, H, W = x.shape
         assert C == self.in_nc, f"FFDNet built for {self.in_nc} channels, got {C}"
+        if torch.is_grad_enabled() and (x.requires_grad or (isinstance(sigma, torch.Tensor) and sigma.requires_grad)):
+            if any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError("weight gradients of FFDNet are not built yet: freeze the denoiser "
+                                          "(deep_prior(..., trainable=False)); gradients w.r.t. the image and sigma are available")
+            sig_t = sigma if isinstance(sigma, torch.Tensor) else torch.as_tensor(sigma, dtype=torch.float32)
+            sig_t = sig_t.to(device=x.device, dtype=torch.float32).reshape(-1)
+            sig_t = sig_t.expand(B).contiguous() if sig_t.numel() == 1 else sig_t.contiguous()
+            return _FFDNetFn.apply(self, x, sig_t)
         sig = ops.as_batch_vec(sigma, B, x.device)
         L = be.lib()
         y = torch.empty_like(x)
@@ -100,6 +127,37 @@ class FFDNet(nn.Module):
         L.call("dpx_ffdnet_forward", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(self.packed()), self.in_nc, self.nc,
                self.nb, B, H, W, be.ptr(ws), be.stream())
         return y
+
+
+class _FFDNetFn(torch.autograd.Function):
+    """FFDNet forward that keeps the layer outputs + hand-written backward-data pass (dpx_ffdnet_backward)"""
+
+    @staticmethod
+    def forward(ctx, net, x, sig):
+        B, C, H, W = x.shape
+        L = be.lib()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        acts = torch.empty(L.query("dpx_ffdnet_acts_bytes", B, net.in_nc, net.nc, net.nb, H, W), dtype=torch.uint8, device=x.device)
+        L.call("dpx_ffdnet_forward_save", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(net.packed()), net.in_nc, net.nc, net.nb,
+               B, H, W, be.ptr(acts), be.stream())
+        ctx.net, ctx.shape = net, (B, C, H, W)
+        ctx.save_for_backward(acts)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        net = ctx.net
+        B, C, H, W = ctx.shape
+        (acts,) = ctx.saved_tensors
+        L = be.lib()
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy) if ctx.needs_input_grad[1] else None
+        gs = torch.empty(B, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[2] else None
+        ws = ops.workspace("ffdnet_bwd", L.query("dpx_ffdnet_bwd_ws_bytes", B, net.in_nc, net.nc, H, W), gy.device)
+        L.call("dpx_ffdnet_backward", be.ptr(gy), be.ptr(gx), be.ptr(gs), be.ptr(net.packed_T()), be.ptr(acts), net.in_nc, net.nc,
+               net.nb, B, H, W, be.ptr(ws), be.stream())
+        return None, gx, gs
 
 
 def _load_checkpoint(model, model_path):

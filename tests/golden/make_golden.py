@@ -427,6 +427,49 @@ def g11_unrolled_grads():
     save("g11_unrolled_grads", **out)
 
 
+def g16_ffdnet_grads():
+    """Backward through the FFDNet stack (PyTorch autograd of the reference's network_ffdnet.py:54-68): gradients w.r.t.
+    the image and the per-image noise level, odd sizes included (adjoint of the replicate padding); and 2 unrolled
+    plug-and-play ADMM iterations with gradients w.r.t. rho_t, sigma_t and x0."""
+    rng = np.random.RandomState(160)
+    out = {}
+    col = ColorDen(7).eval()
+    for p in col.parameters():
+        p.requires_grad_(False)
+    for tag, shape in (("odd", (2, 3, 33, 47)), ("even", (1, 3, 32, 40))):
+        x = T(rng.rand(*shape).astype("float32")).requires_grad_(True)
+        sig = torch.tensor([0.05, 0.2][: shape[0]], requires_grad=True)
+        w = T(rng.randn(*shape).astype("float32"))
+        y = col.denoise(x, sig)
+        (y * w).sum().backward()
+        out.update({f"{tag}_x": x.detach(), f"{tag}_sigma": sig.detach(), f"{tag}_w": w, f"{tag}_y": y.detach(), f"{tag}_gx": x.grad, f"{tag}_gsigma": sig.grad})
+    gray = GrayDen(11).eval()
+    for p in gray.parameters():
+        p.requires_grad_(False)
+    xg = T(rng.rand(2, 2, 21, 26).astype("float32")).requires_grad_(True)
+    sg = torch.tensor(0.1, requires_grad=True)
+    wg = T(rng.randn(2, 2, 21, 26).astype("float32"))
+    yg = gray.denoise(xg, sg)
+    (yg * wg).sum().backward()
+    out.update(gray_x=xg.detach(), gray_w=wg, gray_y=yg.detach(), gray_gx=xg.grad, gray_gsigma=sg.grad)
+    # unrolled PnP
+    gt, b, psf = synthetic.deconv_case(2, 3, 32, 40, seed=161)
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=ColorDen(7))
+    solver = dp.compile(dp.sum_squares(dp.conv(x, psf) - T(b)) + prior, method="admm", device="cpu")
+    solver = dp.specialize(solver, method="unroll", device="cpu", max_iter=2)
+    rhos = torch.tensor([0.4, 0.2], requires_grad=True)
+    sigmas = torch.tensor([0.08, 0.04], requires_grad=True)
+    x0 = T(b).clone().requires_grad_(True)
+    xo = solver.solve(x0=x0, rhos=rhos, lams={prior: sigmas})
+    loss = ((xo - T(gt)) ** 2).mean()
+    loss.backward()
+    out.update(pnp_gt=gt, pnp_b=b, pnp_psf=psf, pnp_x=xo.detach(), pnp_loss=loss.detach(), pnp_g_rhos=rhos.grad, pnp_g_sigmas=sigmas.grad,
+               pnp_g_x0=x0.grad)
+    print("pnp", float(loss.detach()), rhos.grad, sigmas.grad, float(x0.grad.abs().max()))
+    save("g16_ffdnet_grads", **out)
+
+
 def g15_csmri():
     """CS-MRI pipeline of the reference's examples (csmri closed-form data term + CustomADMM + gray FFDNet prior):
     dprox/proxfn/fast/csmri.py:8-25, dprox/contrib/csmri.py:156-171, ext_sum_squares routing invert.py:8-12."""
@@ -518,6 +561,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri):
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

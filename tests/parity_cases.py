@@ -342,6 +342,73 @@ def case_unrolled_solver(device):
     assert_close(list(us.lams.values())[0].grad.cpu(), g["us_g_lam"], 1e-4, "UnrolledSolver d loss / d lams")
 
 
+def _assert_grad_close(got, ref, what, tol=1e-4, flip_frac=0.08, flip_rel=5e-2):
+    """Gradients through ReLU stacks are piecewise constant in the forward activations: an activation that rounds to the
+    other side of 0 (fp32 summation order) flips one mask entry and changes the gradient on one receptive field
+    (~10x10 pixels x C = 3 % of a 33x47 fixture) -- in the reference as much as here.  Accept: rel-L2 <= tol, or at most `flip_frac` of the entries
+    off by more than tol * max|ref| with the total still within `flip_rel`."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    r = rel_l2(got, ref)
+    if r <= tol:
+        return
+    bad = np.abs(got - ref) > tol * np.abs(ref).max()
+    assert bad.mean() <= flip_frac and r <= flip_rel, f"{what}: rel-L2 {r:.3e}, {bad.mean():.2%} of entries off"
+
+
+def case_ffdnet_grads(device, which=("odd", "even", "gray")):
+    """G16: backward-data through the FFDNet stack (transposed MFMA convolutions, fused ReLU masks, adjoint of the
+    pixel-unshuffle / replicate padding) vs the reference's autograd; gradients w.r.t. image and sigma.  Tolerance 1e-4
+    (ReLU masks make the gradient piecewise constant in the forward activations)."""
+    g = load_golden("g16_ffdnet_grads")
+    col = _ffdnet("color", device)
+    col.requires_grad_(False)
+    for tag in ("odd", "even"):
+        if tag not in which:
+            continue
+        x = T(g[f"{tag}_x"], device).requires_grad_(True)
+        sig = T(g[f"{tag}_sigma"], device).requires_grad_(True)
+        y = col.denoise(x, sig)
+        (y * T(g[f"{tag}_w"], device)).sum().backward()
+        assert_close(y.detach().cpu(), g[f"{tag}_y"], TOL, f"ffdnet {tag} y (training forward)")
+        _assert_grad_close(x.grad.cpu(), g[f"{tag}_gx"], f"ffdnet {tag} d/dx")
+        _assert_grad_close(sig.grad.cpu(), g[f"{tag}_gsigma"], f"ffdnet {tag} d/dsigma", tol=1e-2)   # a sum over the image: one mask flip moves it by ~1e-3
+    if "gray" not in which:
+        return
+    gray = _ffdnet("gray", device)
+    gray.requires_grad_(False)
+    xg = T(g["gray_x"], device).requires_grad_(True)
+    sg = torch.tensor(0.1, device=device, requires_grad=True)
+    yg = gray.denoise(xg, sg)
+    (yg * T(g["gray_w"], device)).sum().backward()
+    assert_close(yg.detach().cpu(), g["gray_y"], TOL, "gray y")
+    _assert_grad_close(xg.grad.cpu(), g["gray_gx"], "gray d/dx")
+    _assert_grad_close(sg.grad.cpu(), g["gray_gsigma"], "gray d/dsigma (summed over bands and images)", tol=1e-2)
+
+
+def case_unrolled_pnp_grads(device):
+    """G16 (second half): 2 unrolled plug-and-play ADMM iterations, gradients w.r.t. rho_t, sigma_t, x0"""
+    g = load_golden("g16_ffdnet_grads")
+    b = T(g["pnp_b"], device)
+    x = dp.Variable()
+    den = _ffdnet("color", device)
+    den.requires_grad_(False)
+    prior = dp.deep_prior(x, denoiser=den)
+    solver = dp.compile(dp.sum_squares(dp.conv(x, g["pnp_psf"]) - b) + prior, method="admm", device=device)
+    solver = dp.specialize(solver, method="unroll", device=device, max_iter=2)
+    rhos = torch.tensor([0.4, 0.2], requires_grad=True)
+    sigmas = torch.tensor([0.08, 0.04], requires_grad=True)
+    x0 = b.clone().requires_grad_(True)
+    xo = solver.solve(x0=x0, rhos=rhos, lams={prior: sigmas})
+    loss = ((xo - T(g["pnp_gt"], device)) ** 2).mean()
+    loss.backward()
+    assert_close(xo.detach().cpu(), g["pnp_x"], TOL, "unrolled PnP x")
+    _assert_grad_close(rhos.grad.cpu(), g["pnp_g_rhos"], "unrolled PnP d/d rhos", tol=1e-2)
+    _assert_grad_close(x0.grad.cpu(), g["pnp_g_x0"], "unrolled PnP d/d x0")
+    gs, rs = sigmas.grad.cpu().numpy(), g["pnp_g_sigmas"]
+    assert abs(gs[1]) <= 1e-12 and abs(gs[0] - rs[0]) <= 1e-3 * abs(rs[0]) + 1e-9, (gs, rs)   # tiny: 5e-7 (random weights)
+
+
 def case_csmri(device):
     """G15: closed-form csmri data term (native complex FFT + masked update) and CustomADMM on a complex iterate"""
     from dprox.contrib.csmri import CustomADMM

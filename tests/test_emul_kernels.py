@@ -75,5 +75,9 @@ def test_unrolled_solver_learned_params():
     pc.case_unrolled_solver(DEV)
 
 
+def test_ffdnet_backward():
+    pc.case_ffdnet_grads(DEV, which=("even",))      # one small image: the emulator runs MFMA layers at ~1 s each
+
+
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV, shape=(1, 3, 24, 20))

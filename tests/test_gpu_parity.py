@@ -88,6 +88,14 @@ def test_unrolled_solver_learned_params():
     pc.case_unrolled_solver(DEV)
 
 
+def test_ffdnet_backward():
+    pc.case_ffdnet_grads(DEV)
+
+
+def test_unrolled_pnp_gradients():
+    pc.case_unrolled_pnp_grads(DEV)
+
+
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV)
 

@@ -230,6 +230,19 @@ def test_g11_unrolled_grads():
             assert_close(got, g[f"{tag}_{name}"], 1e-5, f"{tag} {name}")
 
 
+def test_g16_ffdnet_grads():
+    """autograd through the oracle's FFDNet restatement reproduces the reference's input / sigma gradients"""
+    g = load_golden("g16_ffdnet_grads")
+    den = O.FFDNetOracle(O.ffdnet_weights(7))
+    for tag in ("odd", "even"):
+        x = T(g[f"{tag}_x"]).requires_grad_(True)
+        sig = T(g[f"{tag}_sigma"]).requires_grad_(True)
+        y = den(x, sig)
+        (y * T(g[f"{tag}_w"])).sum().backward()
+        assert_close(y.detach(), g[f"{tag}_y"], 2e-6)
+        assert_close(x.grad, g[f"{tag}_gx"], 1e-5); assert_close(sig.grad, g[f"{tag}_gsigma"], 1e-5)
+
+
 def test_g15_csmri():
     """csmri closed-form prox + CustomADMM with the gray FFDNet prior (complex iterate)."""
     g = load_golden("g15_csmri")
