@@ -401,25 +401,25 @@ extern "C" int dpx_ffdnet_forward_save(const float* x, float* y, const float* si
 // transposed layer l: input channels = forward cout (padded even), output channels = forward cin
 static size_t layer_floats_T(int l, int in_nc, int nc, int nb) { return layer_floats(layer_cout(l, in_nc, nc, nb), layer_cin(l, in_nc, nc)); }
 
-extern "C" size_t dpx_ffdnet_packed_T_bytes(int in_nc, int nc, int nb) {
+extern "C" size_t dpx_ffdnet_packed_transposed_bytes(int in_nc, int nc, int nb) {
   size_t n = 0;
   for (int l = 0; l < nb; ++l) n += layer_floats_T(l, in_nc, nc, nb);
   return n * sizeof(float);
 }
 
-extern "C" int dpx_ffdnet_pack_T(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream) {
-  DPX_REQUIRE(packed_T && w && in_nc > 0 && nc > 0 && nb >= 2, "dpx_ffdnet_pack_T: bad arguments");
-  DPX_REQUIRE(nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96 && (4 * in_nc) % 2 == 0, "dpx_ffdnet_pack_T: unsupported channel counts");
+extern "C" int dpx_ffdnet_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream) {
+  DPX_REQUIRE(packed_T && w && in_nc > 0 && nc > 0 && nb >= 2, "dpx_ffdnet_pack_transposed: bad arguments");
+  DPX_REQUIRE(nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96 && (4 * in_nc) % 2 == 0, "dpx_ffdnet_pack_transposed: unsupported channel counts");
   float* dst = (float*)packed_T;
   for (int l = 0; l < nb; ++l) {
     const int cin_f = layer_cin(l, in_nc, nc), cout_f = layer_cout(l, in_nc, nc, nb);
-    DPX_REQUIRE(w[l], "dpx_ffdnet_pack_T: layer %d has null weights", l);
+    DPX_REQUIRE(w[l], "dpx_ffdnet_pack_transposed: layer %d has null weights", l);
     const size_t n = layer_floats(cout_f, cin_f);
     DPX_LAUNCH("k_ffd_pack_weights", k_ffd_pack_weights, dim3(grid_for((long)n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, w[l],
                (const float*)nullptr, dst, cout_f, cin_f, 1);
     dst += n;
   }
-  return launch_status("dpx_ffdnet_pack_T");
+  return launch_status("dpx_ffdnet_pack_transposed");
 }
 
 extern "C" size_t dpx_ffdnet_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W) {

@@ -80,15 +80,15 @@ class FFDNet(nn.Module):
         return tuple(p._version for p in list(self.weights) + list(self.biases))
 
     def packed_T(self):
-        """flipped / transposed weights of the backward-data convolutions (dpx_ffdnet_pack_T), cached per weight version"""
+        """flipped / transposed weights of the backward-data convolutions (dpx_ffdnet_pack_transposed), cached per weight version"""
         dev = self.weights[0].device
         key = (self._weights_version(), str(dev))
         if getattr(self, "_packed_T", None) is None or self._packed_T[0] != key:
             L = be.lib()
-            blob = torch.empty(max(L.query("dpx_ffdnet_packed_T_bytes", self.in_nc, self.nc, self.nb), 16), dtype=torch.uint8, device=dev)
+            blob = torch.empty(max(L.query("dpx_ffdnet_packed_transposed_bytes", self.in_nc, self.nc, self.nb), 16), dtype=torch.uint8, device=dev)
             ws = [w.detach().float().contiguous() for w in self.weights]
             pw = (ctypes.c_void_p * self.nb)(*[w.data_ptr() for w in ws])
-            L.call("dpx_ffdnet_pack_T", be.ptr(blob), pw, self.in_nc, self.nc, self.nb, be.stream())
+            L.call("dpx_ffdnet_pack_transposed", be.ptr(blob), pw, self.in_nc, self.nc, self.nb, be.stream())
             self._packed_T = (key, blob)
         return self._packed_T[1]
 

@@ -233,13 +233,13 @@ int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void*
 /* Training variants.  dpx_ffdnet_forward_save = dpx_ffdnet_forward that keeps every layer's output in `acts`
  * (dpx_ffdnet_acts_bytes) for the backward pass.  dpx_ffdnet_backward: gradient of the network output w.r.t. its image
  * input (gx, nullable) and w.r.t. the per-image noise level (gsigma[B], nullable) given gy -- the chain of transposed
- * 3x3 convolutions (same MFMA kernel, weights flipped / transposed once by dpx_ffdnet_pack_T, the ReLU masks fused into
+ * 3x3 convolutions (same MFMA kernel, weights flipped / transposed once by dpx_ffdnet_pack_transposed, the ReLU masks fused into
  * the loads), i.e. what PyTorch autograd does for network_ffdnet.py:54-68 in the reference's unrolled / DEQ training.  */
 size_t dpx_ffdnet_acts_bytes(int B, int in_nc, int nc, int nb, int H, int W);
 int dpx_ffdnet_forward_save(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb,
                             int B, int H, int W, void* acts, dpx_stream_t stream);
-size_t dpx_ffdnet_packed_T_bytes(int in_nc, int nc, int nb);
-int dpx_ffdnet_pack_T(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream);
+size_t dpx_ffdnet_packed_transposed_bytes(int in_nc, int nc, int nb);
+int dpx_ffdnet_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream);
 size_t dpx_ffdnet_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W);
 int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, const void* packed_T, const void* acts, int in_nc, int nc,
                         int nb, int B, int H, int W, void* ws, dpx_stream_t stream);
