@@ -391,6 +391,20 @@ extern "C" int dpx_lincomb(float* out, int n, const float* const* x, const float
   return launch_status("dpx_lincomb");
 }
 
+__global__ void __launch_bounds__(256) k_mul(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, long npb,
+                                             int w_images) {
+  const int b = blockIdx.y;
+  const float* wb = w + (w_images > 1 ? (long)b * npb : 0L);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < npb; i += (long)gridDim.x * 256L) out[(long)b * npb + i] = x[(long)b * npb + i] * wb[i];
+}
+
+extern "C" int dpx_mul(const float* x, const float* w, float* out, int B, long n_per_image, int w_images, dpx_stream_t stream) {
+  DPX_REQUIRE(x && w && out && B > 0 && n_per_image > 0, "dpx_mul: bad arguments");
+  DPX_REQUIRE(w_images == 1 || w_images == B, "dpx_mul: the weight must hold 1 or B=%d images (got %d)", B, w_images);
+  DPX_LAUNCH("k_mul", k_mul, dim3(grid_for(n_per_image, 256, 2048), B, 1), dim3(256), 0, (hipStream_t)stream, x, w, out, n_per_image, w_images);
+  return launch_status("dpx_mul");
+}
+
 // ---- complex-iterate arithmetic of the CS-MRI solver (contrib/csmri.py:156-171, proxfn/fast/csmri.py:14-25) ----
 struct CplxPack {
   const void* x[4];

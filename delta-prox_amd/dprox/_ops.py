@@ -365,6 +365,23 @@ def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, 
     return rc
 
 
+def mul(x, w):
+    """x * w with w one image ([1,C,H,W] or [C,H,W]) or a batch of them"""
+    require(x, what="mul input")
+    B = int(x.shape[0])
+    npb = x.numel() // B
+    w = w.to(device=x.device, dtype=torch.float32).contiguous()
+    if w.numel() == npb:
+        wimg = 1
+    elif w.numel() == x.numel():
+        wimg = B
+    else:
+        raise be.DpxError(f"mul: weight {tuple(w.shape)} matches neither one image nor the batch {tuple(x.shape)}")
+    out = torch.empty_like(x)
+    be.lib().call("dpx_mul", ptr(x), ptr(w), ptr(out), B, npb, wimg, be.stream())
+    return out
+
+
 def clincomb(terms, out_complex=True):
     """sum_i coef_i * x_i over up to 4 real-fp32 / complex64 tensors of one shape; complex64 result, or its real part
     as fp32 (out_complex=False).  coef_i are python floats."""

@@ -23,3 +23,11 @@ def blurring(img, psf):
     from ..linop import Variable, conv
     op = conv(Variable(), psf).to(img.device)
     return op.forward(img.contiguous().float())
+
+
+def mosaicing(img):
+    """Bayer (RGGB) mosaic of an NCHW RGB tensor through the backend's own mask multiply (reference
+    dprox/contrib/restoration.py:71-97)"""
+    from ..linop import Variable, mosaic
+    op = mosaic(Variable())
+    return op.forward(img.contiguous().float())

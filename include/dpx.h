@@ -123,6 +123,10 @@ int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, in
 int dpx_csmri_update(void* z, const void* y, const unsigned char* mask, int mask_images, const float* lam, float num_psi, int B,
                      long n_per_image, dpx_stream_t stream);
 
+/* out[b, i] = x[b, i] * w[(w_images > 1 ? b : 0), i]: diagonal operators in the image domain -- mosaic's Bayer mask
+ * (dprox/linop/subsample.py:17-31) and mul_elementwise (dprox/linop/mul.py:46-73); forward == adjoint.          */
+int dpx_mul(const float* x, const float* w, float* out, int B, long n_per_image, int w_images, dpx_stream_t stream);
+
 /* out = sum_i coef[i] * x[i] over n <= 4 operands that are each real (float32) or complex (complex64) arrays of
  * `n_elems` elements; out is complex64 (out_complex = 1) or the REAL PART of the sum as float32 (out_complex = 0).
  * The complex-iterate arithmetic of the CS-MRI solver: `z - u`, `x + u`, `u + x - z` (dprox/contrib/csmri.py:161-169)

@@ -31,7 +31,7 @@ __all__ = [
     "soft_threshold", "prox", "LeastSquares", "cg", "bdot", "LinearSolveConfig",
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
     "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
-    "csmri_prox", "custom_admm_csmri",
+    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic",
 ]
 
 
@@ -207,6 +207,26 @@ def lin_scale(s: float, inner: Lin) -> Lin:
         return d * torch.conj(d)
     return Lin(lambda x: inner.fwd(x) * s, lambda y: inner.adj(y * s), diag,
                inner.gram_diag_space, inner.gram_diag_freq)
+
+
+def bayer_mask(H, W) -> torch.Tensor:
+    """linop/subsample.py:33-46: RGGB colour-filter-array mask as [1,3,H,W] float32."""
+    m = np.zeros((3, H, W), dtype=np.float32)
+    for ch, (y, x) in zip((0, 1, 1, 2), [(0, 0), (0, 1), (1, 0), (1, 1)]):
+        m[ch, y::2, x::2] = 1
+    return torch.from_numpy(m)[None]
+
+
+def lin_mosaic(inner: "Lin") -> "Lin":
+    """mosaic(inner) -- subsample.py:17-31: y = mask * inner(x), adjoint = inner^T(mask * y); not diagonalisable once
+    composed with a convolution, so the x-update goes through CG."""
+    def fwd(x):
+        y = inner.fwd(x)
+        return bayer_mask(*y.shape[-2:]) * y
+
+    def adj(y):
+        return inner.adj(bayer_mask(*y.shape[-2:]) * y)
+    return lin_custom(fwd, adj)
 
 
 def lin_custom(forward, adjoint, diag=None) -> Lin:

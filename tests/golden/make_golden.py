@@ -470,6 +470,35 @@ def g16_ffdnet_grads():
     save("g16_ffdnet_grads", **out)
 
 
+def g17_mosaic_jd():
+    """mosaic / mul_elementwise linops and the joint demosaic + deconvolution problem of tests/problem/test_jd23.py
+    (sum_squares(mosaic(conv(x, psf)) - b) + deep_prior, ADMM with the CG x-update) at fixture size."""
+    from dprox.contrib import mosaicing
+    rng = np.random.RandomState(170)
+    out = {}
+    x = T(rng.rand(2, 3, 12, 14).astype("float32"))
+    m = dp.mosaic(dp.Variable())
+    out.update(lin_x=x, mosaic_fwd=m.forward(x), mosaic_adj=m.adjoint(x), mosaic_diag=m.get_diag(x).detach())
+    w = rng.rand(1, 3, 12, 14).astype("float32")
+    me = dp.mul_elementwise(dp.Variable(), w)
+    out.update(mul_w=w, mul_fwd=me.forward(x), mul_adj=me.adjoint(x))
+    gt, blur, psf = synthetic.deconv_case(2, 3, 32, 40, seed=171)
+    b = mosaicing(T(blur[0].transpose(1, 2, 0)))            # the reference helper takes one HWC image
+    b = torch.cat([b, mosaicing(T(blur[1].transpose(1, 2, 0)))], dim=0).float()
+    xv = dp.Variable()
+    data = dp.sum_squares(dp.mosaic(dp.conv(xv, psf)) - b)
+    reg = dp.deep_prior(xv, denoiser=ColorDen(7))
+    prob = dp.Problem(data + reg, linear_solve_config=LinearSolveConfig(max_iters=50))
+    # rho large enough for CG to converge (rtol 1e-6) well inside its 50 iterations: with the test's log_descent(35, 30)
+    # schedule (rho ~ 1e-4) the x-update is the 50th iterate of an unconverged CG, which amplifies fp32 round-off to 1e-3
+    _, sigmas = log_descent(35, 30, 3)
+    rhos = torch.tensor([0.5, 0.4, 0.3])
+    with torch.no_grad():
+        st = prob.solve(method="admm", device="cpu", x0=b, rhos=rhos, lams={reg: sigmas}, max_iter=3, return_full_states=True)
+    out.update(jd_b=b, jd_psf=psf, jd_rhos=rhos, jd_sigmas=sigmas, jd_x=st[0], jd_v=st[1][0], jd_u=st[2][0])
+    save("g17_mosaic_jd", **out)
+
+
 def g15_csmri():
     """CS-MRI pipeline of the reference's examples (csmri closed-form data term + CustomADMM + gray FFDNet prior):
     dprox/proxfn/fast/csmri.py:8-25, dprox/contrib/csmri.py:156-171, ext_sum_squares routing invert.py:8-12."""
@@ -561,6 +590,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads):
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

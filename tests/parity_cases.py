@@ -409,7 +409,35 @@ def case_unrolled_pnp_grads(device):
     assert abs(gs[1]) <= 1e-12 and abs(gs[0] - rs[0]) <= 1e-3 * abs(rs[0]) + 1e-9, (gs, rs)   # tiny: 5e-7 (random weights)
 
 
-def case_csmri(device):
+def case_mosaic_jd(device, solve=True):
+    """G17: mosaic / mul_elementwise (dpx_mul) and joint demosaic + deconvolution: ADMM whose x-update is CG on
+    (conv^T mosaic conv + rho I) with the FFDNet prior (tests/problem/test_jd23.py at fixture size)"""
+    from dprox.linalg import LinearSolveConfig
+    g = load_golden("g17_mosaic_jd")
+    x = T(g["lin_x"], device)
+    m = dp.mosaic(dp.Variable()).to(device)
+    assert_close(m.forward(x).cpu(), g["mosaic_fwd"], 1e-7, "mosaic forward")
+    assert_close(m.adjoint(x).cpu(), g["mosaic_adj"], 1e-7, "mosaic adjoint")
+    assert np.array_equal(m.get_diag(x).cpu().numpy(), g["mosaic_diag"])
+    me = dp.mul_elementwise(dp.Variable(), g["mul_w"]).to(device)
+    assert_close(me.forward(x).cpu(), g["mul_fwd"], 1e-7, "mul_elementwise forward")
+    assert_close(me.adjoint(x).cpu(), g["mul_adj"], 1e-7, "mul_elementwise adjoint")
+    if not solve:
+        return
+    b = T(g["jd_b"], device)
+    xv = dp.Variable()
+    data = dp.sum_squares(dp.mosaic(dp.conv(xv, g["jd_psf"])) - b)
+    reg = dp.deep_prior(xv, denoiser=_ffdnet("color", device))
+    prob = dp.Problem(data + reg, linear_solve_config=LinearSolveConfig(max_iters=50))
+    with torch.no_grad():
+        st = prob.solve(method="admm", device=device, x0=b, rhos=torch.from_numpy(g["jd_rhos"]), lams={reg: torch.from_numpy(g["jd_sigmas"])},
+                        max_iter=3, return_full_states=True)
+    assert prob.solver.last_path == "generic"
+    assert_close(st[0].cpu(), g["jd_x"], 2 * TOL, "JD x (CG x-update)")
+    assert_close(st[1][0].cpu(), g["jd_v"], 2 * TOL, "JD v")
+
+
+def case_csmri(device, solve=True):
     """G15: closed-form csmri data term (native complex FFT + masked update) and CustomADMM on a complex iterate"""
     from dprox.contrib.csmri import CustomADMM
     g = load_golden("g15_csmri")
@@ -421,6 +449,8 @@ def case_csmri(device):
     v = T(g["prox_v"], device)
     assert_close(fn._prox(v, torch.tensor(0.7, device=device), 1).cpu(), g["prox_lam_scalar"], TOL, "csmri prox scalar lam")
     assert_close(fn._prox(v, torch.tensor([0.3, 1.9], device=device), 2).cpu(), g["prox_lam_B"], TOL, "csmri prox per-image lam")
+    if not solve:
+        return
     x2 = dp.Variable()
     y2, m2 = dp.Placeholder(), dp.Placeholder()
     data = dp.csmri(x2, m2, y2)

@@ -80,6 +80,10 @@ def test_csmri_custom_admm():
     pc.case_csmri(DEV)
 
 
+def test_mosaic_joint_demosaic_deconv():
+    pc.case_mosaic_jd(DEV)
+
+
 def test_unrolled_gradients():
     pc.case_unrolled_grads(DEV)
 

@@ -243,6 +243,23 @@ def test_g16_ffdnet_grads():
         assert_close(x.grad, g[f"{tag}_gx"], 1e-5); assert_close(sig.grad, g[f"{tag}_gsigma"], 1e-5)
 
 
+def test_g17_mosaic_jd():
+    g = load_golden("g17_mosaic_jd")
+    x = T(g["lin_x"])
+    m = O.bayer_mask(12, 14)
+    assert_close(m * x, g["mosaic_fwd"], 0.0 + 1e-12); assert_close(m * x, g["mosaic_adj"], 1e-12)
+    assert np.array_equal(m.numpy(), g["mosaic_diag"])
+    assert_close(T(g["mul_w"]) * x, g["mul_fwd"], 1e-12)
+    b = T(g["jd_b"])
+    den = O.FFDNetOracle(O.ffdnet_weights(7))
+    prior = O.deep_prior(O.lin_identity(), den)
+    terms = [O.sum_squares(O.lin_mosaic(O.lin_conv(g["jd_psf"])).minus(b)), prior]
+    with torch.no_grad():
+        st = O.solve(terms, "admm", x0=b, rhos=T(g["jd_rhos"]), lams={prior: T(g["jd_sigmas"])}, max_iter=3, return_full_states=True,
+                     linear_solve_config=O.LinearSolveConfig(max_iters=50))
+    assert_close(st[0], g["jd_x"], 1e-5); assert_close(st[1][0], g["jd_v"], 1e-5); assert_close(st[2][0], g["jd_u"], 5e-5)
+
+
 def test_g15_csmri():
     """csmri closed-form prox + CustomADMM with the gray FFDNet prior (complex iterate)."""
     g = load_golden("g15_csmri")
