@@ -27,8 +27,12 @@ constexpr int FFD_ROWS = FFD_TH + 2;
 static inline int pad_even(int c) { return (c + 1) & ~1; }
 static inline int mtiles(int cout) { return (cout + 31) / 32; }
 
-// packed layer: weights [Cin_pad/2][9][2][MT*32] then bias [MT*32]
-static inline size_t layer_floats(int cin, int cout) { return (size_t)(pad_even(cin) / 2) * 9 * 2 * mtiles(cout) * 32 + (size_t)mtiles(cout) * 32; }
+// packed layer: weights [Cin_pad/2][9][2][MT*32], bias [MT*32], then FFD_ZPAD zero floats (the "zero word" LDS-DMA lanes
+// outside the image read from)
+constexpr int FFD_ZPAD = 4;
+static inline size_t layer_floats(int cin, int cout) {
+  return (size_t)(pad_even(cin) / 2) * 9 * 2 * mtiles(cout) * 32 + (size_t)mtiles(cout) * 32 + FFD_ZPAD;
+}
 
 // transposed != 0: the layer of the backward-data pass, conv with W'[co'][ci'][tap] = W[ci'][co'][8 - tap] (w is still the
 // forward tensor [cout' ... ] = [cin][cout]-swapped view: w has shape [cin][cout][3][3] in the primed names), zero bias
@@ -36,8 +40,10 @@ __global__ void k_ffd_pack_weights(const float* __restrict__ w, const float* __r
                                    int transposed) {
   const int MT32 = ((cout + 31) / 32) * 32, pairs = ((cin + 1) & ~1) / 2;
   const long nw = (long)pairs * 9 * 2 * MT32;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + MT32; i += (long)gridDim.x * blockDim.x) {
-    if (i < nw) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + MT32 + FFD_ZPAD; i += (long)gridDim.x * blockDim.x) {
+    if (i >= nw + MT32) {
+      dst[i] = 0.f;
+    } else if (i < nw) {
       const int co = (int)(i % MT32);
       long r = i / MT32;
       const int half = (int)(r % 2);
@@ -201,63 +207,118 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  // Software pipeline over chunks of FFD_CK input channels: while the matrix cores work on chunk c (LDS buffer c&1) the
-  // global loads of chunk c+1 are in flight into registers; they are written to the other LDS buffer after the MFMAs and
-  // one barrier per chunk hands the buffers over.
-  constexpr int NI = (FFD_CK * FFD_ROWS * 34 + 255) / 256;                 // input-tile elements per thread
-  constexpr int NW4 = ((FFD_CK / 2) * 9 * 2 * M32 / 4 + 255) / 256;        // weight float4s per thread
-  float in_reg[NI];
-  float4 w_reg[NW4];
-  auto fetch = [&](int c0) {
-    const int nch = min(FFD_CK, Cin - c0);
+  // Software pipeline over chunks of FFD_CK input channels, two LDS buffers, one barrier per chunk.
+  //  * forward layers: the next chunk is fetched by LDS-DMA (no VGPRs, no LDS-write pass, ~20 issue slots per wave and
+  //    chunk instead of ~450 staging instructions that competed with the MFMA issue: 63 % -> 8x % of the MFMA peak).
+  //    The weight chunk is a contiguous block of the packed layer (1 KB pieces, 16 B per lane); the input tile is
+  //    fetched dword-wise (rows start at arbitrary alignments), lanes outside the image read the layer's zero word.
+  //  * masked (backward) layers keep the register path: the ReLU mask is applied between load and LDS write.
+  constexpr bool DMA = !MASKED;
+  constexpr int NPI = (FFD_CK * FFD_ROWS * FFD_LDW + 63) / 64;             // dword pieces of one input chunk (45)
+  constexpr int NPW = (NPI + 3) / 4;                                       // per wave
+  constexpr int NWP = ((FFD_CK / 2) * 9 * 2 * M32) / 256;                  // 1 KB pieces of one weight chunk (27 / 18 / 9)
+  static_assert(((FFD_CK / 2) * 9 * 2 * M32) % 256 == 0, "weight chunk must be whole 1 KB pieces");
+  constexpr int NI = (FFD_CK * FFD_ROWS * 34 + 255) / 256;                 // input-tile elements per thread (register path)
+  constexpr int NW4 = ((FFD_CK / 2) * 9 * 2 * M32 / 4 + 255) / 256;        // weight float4s per thread (register path)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  unsigned ioff[DMA ? NPW : 1];            // (channel << 28) | element offset inside the chunk's channel block; ~0u = zero word
+  if constexpr (DMA) {
 #pragma unroll
-    for (int e = 0; e < NI; ++e) {
-      const int i = tid + 256 * e;
-      const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
+    for (int k = 0; k < NPW; ++k) {
+      const int e = (wv + 4 * k) * 64 + lane;
+      const int ch = e / (FFD_ROWS * FFD_LDW), r = (e / FFD_LDW) % FFD_ROWS, col = e % FFD_LDW;
       const int yy = y0 + r - 1, xx = x0 + col - 1;
-      float v = 0.f;
-      if (ch < nch && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) {
-        const size_t idx = ((size_t)(c0 + ch) * H2 + yy) * W2 + xx;
-        v = inb[idx];
-        if (MASKED) v = maskb[idx] > 0.f ? v : 0.f;
-      }
-      in_reg[e] = v;
+      const bool ok = (wv + 4 * k) < NPI && ch < FFD_CK && col < 34 && yy >= 0 && yy < H2 && xx >= 0 && xx < W2;
+      ioff[k] = ok ? (((unsigned)ch << 28) | (unsigned)((ch * H2 + yy) * W2 + xx)) : ~0u;
     }
-    const float4* wsrc = (const float4*)(wpk + (size_t)(c0 / 2) * 9 * 2 * M32);
-    const int n4 = (nch / 2) * 9 * 2 * M32 / 4;
+  }
+  const float* zero_word = bias + M32;
+  auto issue = [&](int c0, int buf) {
+    if constexpr (DMA) {
+      const int nch = min(FFD_CK, Cin - c0);
+      const float* cb = inb + (size_t)c0 * H2 * W2;
+      float* si = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW);
 #pragma unroll
-    for (int e = 0; e < NW4; ++e) {
-      const int i = tid + 256 * e;
-      w_reg[e] = i < n4 ? wsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < NPW; ++k) {
+        if (wv + 4 * k < NPI) {
+          const unsigned pk = ioff[k];
+          const bool ok = pk != ~0u && (int)(pk >> 28) < nch;
+          const float* src = ok ? cb + (pk & 0x0fffffffu) : zero_word;
+          dpx_glds4(src, si + (wv + 4 * k) * 64);
+        }
+      }
+      const float* wsrc = wpk + (size_t)(c0 / 2) * 9 * 2 * M32 + lane * 4;
+      float* sw = s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32);
+      for (int i = wv; i < NWP; i += 4) dpx_glds16(wsrc + i * 256, sw + i * 256);
+    }
+  };
+  float in_reg[DMA ? 1 : NI];
+  float4 w_reg[DMA ? 1 : NW4];
+  auto fetch = [&](int c0) {
+    if constexpr (!DMA) {
+      const int nch = min(FFD_CK, Cin - c0);
+#pragma unroll
+      for (int e = 0; e < NI; ++e) {
+        const int i = tid + 256 * e;
+        const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
+        const int yy = y0 + r - 1, xx = x0 + col - 1;
+        float v = 0.f;
+        if (ch < nch && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) {
+          const size_t idx = ((size_t)(c0 + ch) * H2 + yy) * W2 + xx;
+          v = inb[idx];
+          if (MASKED) v = maskb[idx] > 0.f ? v : 0.f;
+        }
+        in_reg[e] = v;
+      }
+      const float4* wsrc = (const float4*)(wpk + (size_t)(c0 / 2) * 9 * 2 * M32);
+      const int n4 = (nch / 2) * 9 * 2 * M32 / 4;
+#pragma unroll
+      for (int e = 0; e < NW4; ++e) {
+        const int i = tid + 256 * e;
+        w_reg[e] = i < n4 ? wsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   auto commit = [&](int buf) {
-    float* si = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW);
-    float4* sw = (float4*)(s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32));
+    if constexpr (!DMA) {
+      float* si = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW);
+      float4* sw = (float4*)(s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32));
 #pragma unroll
-    for (int e = 0; e < NI; ++e) {
-      const int i = tid + 256 * e;
-      const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
-      if (ch < FFD_CK) si[(ch * FFD_ROWS + r) * FFD_LDW + col] = in_reg[e];
-    }
+      for (int e = 0; e < NI; ++e) {
+        const int i = tid + 256 * e;
+        const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
+        if (ch < FFD_CK) si[(ch * FFD_ROWS + r) * FFD_LDW + col] = in_reg[e];
+      }
 #pragma unroll
-    for (int e = 0; e < NW4; ++e) {
-      const int i = tid + 256 * e;
-      if (i < (FFD_CK / 2) * 9 * 2 * M32 / 4) sw[i] = w_reg[e];
+      for (int e = 0; e < NW4; ++e) {
+        const int i = tid + 256 * e;
+        if (i < (FFD_CK / 2) * 9 * 2 * M32 / 4) sw[i] = w_reg[e];
+      }
     }
   };
-  fetch(0);
-  commit(0);
+  if constexpr (DMA) {
+    issue(0, 0);
+    dpx_wait_vm<0>();
+  } else {
+    fetch(0);
+    commit(0);
+  }
   __syncthreads();
   int buf = 0;
   for (int c0 = 0; c0 < Cin; c0 += FFD_CK, buf ^= 1) {
     const int nch = min(FFD_CK, Cin - c0);                     // even
     const bool more = c0 + FFD_CK < Cin;
-    if (more) fetch(c0 + FFD_CK);
+    if (more) {
+      if constexpr (DMA) issue(c0 + FFD_CK, buf ^ 1);
+      else fetch(c0 + FFD_CK);
+    }
     const float* sin_b = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW) + (half * FFD_ROWS + 2 * wave) * FFD_LDW + j;
     const float* sw_b = s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32) + half * M32 + j;
     for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * 9 * 2 * M32);
-    if (more) commit(buf ^ 1);
+    if (more) {
+      if constexpr (DMA) dpx_wait_vm<0>();
+      else commit(buf ^ 1);
+    }
     __syncthreads();
   }
   // ---- epilogue: bias, ReLU, store.  C/D layout: col = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cout) ----
@@ -302,7 +363,7 @@ using namespace dpx;
 extern "C" size_t dpx_ffdnet_packed_bytes(int in_nc, int nc, int nb) {
   size_t n = 0;
   for (int l = 0; l < nb; ++l) n += layer_floats(layer_cin(l, in_nc, nc), layer_cout(l, in_nc, nc, nb));
-  return n * sizeof(float);
+  return n * sizeof(float) + 1024;       // slack: the last 1 KB LDS-DMA piece of a partial channel chunk may over-read
 }
 
 extern "C" int dpx_ffdnet_pack(void* packed, const float* const* w, const float* const* b, int in_nc, int nc, int nb,
@@ -404,7 +465,7 @@ static size_t layer_floats_T(int l, int in_nc, int nc, int nb) { return layer_fl
 extern "C" size_t dpx_ffdnet_packed_transposed_bytes(int in_nc, int nc, int nb) {
   size_t n = 0;
   for (int l = 0; l < nb; ++l) n += layer_floats_T(l, in_nc, nc, nb);
-  return n * sizeof(float);
+  return n * sizeof(float) + 1024;
 }
 
 extern "C" int dpx_ffdnet_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream) {
