@@ -182,7 +182,8 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __
 }
 
 // in [B][Cin][H2][W2] (Cin even), out [B][Cout][H2][W2]; wpk = packed layer (see layer_floats)
-// MASKED: the staged input is in[.] * [mask[.] > 0] (backward through the ReLU that produced `mask`, fused into the load)
+// MASKED: the result is stored as out[.] * [mask[.] > 0] (backward through the ReLU that produced `mask`, the activation
+// at the OUTPUT position of this transposed layer, fused into the epilogue)
 template <int MT, bool RELU, bool MASKED = false>
 __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x,
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
   const int y0 = ty * FFD_TH, x0 = tx * FFD_TW;
   const int j = lane & 31, half = lane >> 5;
   const float* inb = in + (size_t)b * Cin * H2 * W2;
-  const float* maskb = MASKED ? mask + (size_t)b * Cin * H2 * W2 : nullptr;
+  const float* maskb = MASKED ? mask + (size_t)b * Cout * H2 * W2 : nullptr;
   const float* bias = wpk + (size_t)(Cin / 2) * 9 * 2 * M32;
 
   f32x16 acc[MT][2];
@@ -212,8 +213,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
   //    chunk instead of ~450 staging instructions that competed with the MFMA issue: 63 % -> 8x % of the MFMA peak).
   //    The weight chunk is a contiguous block of the packed layer (1 KB pieces, 16 B per lane); the input tile is
   //    fetched dword-wise (rows start at arbitrary alignments), lanes outside the image read the layer's zero word.
-  //  * masked (backward) layers keep the register path: the ReLU mask is applied between load and LDS write.
-  constexpr bool DMA = !MASKED;
+  //  (the register-staged variant is kept behind DMA = false for A/B timing)
+  constexpr bool DMA = true;
   constexpr int NPI = (FFD_CK * FFD_ROWS * FFD_LDW + 63) / 64;             // dword pieces of one input chunk (45)
   constexpr int NPW = (NPI + 3) / 4;                                       // per wave
   constexpr int NWP = ((FFD_CK / 2) * 9 * 2 * M32) / 256;                  // 1 KB pieces of one weight chunk (27 / 18 / 9)
@@ -266,7 +267,6 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
         if (ch < nch && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) {
           const size_t idx = ((size_t)(c0 + ch) * H2 + yy) * W2 + xx;
           v = inb[idx];
-          if (MASKED) v = maskb[idx] > 0.f ? v : 0.f;
         }
         in_reg[e] = v;
       }
@@ -334,7 +334,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
         const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[mt][nt][r] + bias[co];
         if (RELU) v = fmaxf(v, 0.f);
-        if (co < Cout && yy < H2 && xx < W2) outb[((size_t)co * H2 + yy) * W2 + xx] = v;
+        if (co < Cout && yy < H2 && xx < W2) {
+          const size_t idx = ((size_t)co * H2 + yy) * W2 + xx;
+          if (MASKED) v = maskb[idx] > 0.f ? v : 0.f;
+          outb[idx] = v;
+        }
       }
     }
 }
@@ -514,9 +518,9 @@ extern "C" int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, co
   for (int l = nb - 1; l >= 0; --l) {
     const int cin_t = layer_cout(l, in_nc, nc, nb), cout_t = layer_cin(l, in_nc, nc);   // transposed layer: cin_t -> cout_t channels
     float* dst = (l == 0) ? g_a0 : (((nb - 1 - l) & 1) ? gB : gA);
-    // the input of transposed layer l is the gradient w.r.t. forward layer l's output; for l < nb-1 that output went
-    // through a ReLU: mask with the saved activation hidden[l]
-    const float* mask = (l < nb - 1) ? hidden + (size_t)l * px * nc : nullptr;
+    // the output of transposed layer l is the gradient w.r.t. a_l, the (post-ReLU) output of forward layer l-1: it is
+    // stored already multiplied by [a_l > 0] (saved activation hidden[l-1]), ready to be the next layer's plain input
+    const float* mask = (l >= 1) ? hidden + (size_t)(l - 1) * px * nc : nullptr;
     // layer 0 writes Cp channels (13 -> 14 padded: the pad channel's packed weights are zero)
     const int cout_w = (l == 0) ? Cp : cout_t;
     switch (mtiles(cout_t)) {

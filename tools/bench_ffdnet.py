@@ -22,3 +22,18 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 be.lib().call("dpx_timing_report", buf, len(buf)); print(buf.value.decode())
 flop = 2 * 9 * (13 * 96 + 10 * 96 * 96 + 96 * 12) * 512 * 512 * B
 print(f"FFDNet-color B={B}: {dt*1e3:.2f} ms  {flop/dt/1e12:.1f} TFLOP/s  ({flop/dt/157.3e12*100:.1f}% of fp32 MFMA peak)")
+# training forward (keeps activations) + backward-data pass (gradients w.r.t. image and sigma), frozen weights
+den.requires_grad_(False)
+Bt = min(B, 4)
+xt = torch.rand(Bt, 3, 512, 512, device=dev, requires_grad=True)
+st = torch.full((Bt,), 0.05, device=dev, requires_grad=True)
+def step():
+    xt.grad = None; st.grad = None
+    y = den.denoise(xt, st)
+    y.sum().backward()
+for _ in range(2): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): step()
+torch.cuda.synchronize(); dtb = (time.perf_counter() - t0) / 5
+flop_t = 2 * 9 * (13 * 96 + 10 * 96 * 96 + 96 * 12) * 256 * 256 * Bt
+print(f"FFDNet-color train fwd+bwd-data B={Bt} 512x512: {dtb*1e3:.2f} ms  {2*flop_t/dtb/1e12:.1f} TFLOP/s over the two passes")
