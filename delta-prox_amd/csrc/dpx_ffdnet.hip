@@ -425,6 +425,124 @@ extern "C" int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, 
   return launch_status("dpx_ffdnet_forward");
 }
 
+// ---- weight gradients -------------------------------------------------------------------------------------------------
+// dW[co][ci][tap] = sum_{b,y,x} G[b][co][y][x] * A[b][ci][y+dy-1][x+dx-1]  (tap = dy*3+dx),  db[co] = sum G[b][co][y][x]
+// as a GEMM on the exact-fp32 matrix cores with the pixels as the K dimension: per MFMA (32x32x2) the D rows are 32 output
+// channels, the D columns 32 input channels, K = 2 pixels; one wave owns one 32-channel slice of Cout, all 9 taps
+// (9 accumulators) and the workgroup's block of 32 input channels.  A workgroup (MT waves) walks over pixel tiles
+// (4 rows x 32 columns) in a fixed order and keeps the accumulators in registers; per-workgroup partial sums go to a
+// workspace and a second kernel adds them in a fixed order (deterministic, no atomics).
+// LDS: G tile [pixel][co] pitch 97 and activation tile [(row, col)][ci] pitch 33 -- the MFMA operands (lanes = channels)
+// and the transposing stores (lanes = pixels) are both bank-conflict free with these odd pitches.
+constexpr int WG_TH = 4, WG_TW = 32, WG_PX = WG_TH * WG_TW, WG_GP = 97, WG_AP = 33, WG_AW = WG_TW + 2, WG_AH = WG_TH + 2;
+
+template <int MT>
+__global__ void __launch_bounds__(MT * 64) k_conv3x3_wgrad(const float* __restrict__ G, const float* __restrict__ A, float* __restrict__ part,
+                                                            float* __restrict__ part_b, int Cout, int Cin, int B, int H2, int W2,
+                                                            int tiles_x, int tiles_y) {
+  __shared__ float s_g[WG_PX * WG_GP];
+  __shared__ float s_a[WG_AH * WG_AW * WG_AP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = MT * 64;
+  const int j = lane & 31, kk = lane >> 5;
+  const int cb = blockIdx.y;                            // block of 32 input channels
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  const int ntiles = B * tiles_x * tiles_y;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y), tr = tile - b * tiles_x * tiles_y;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+    __syncthreads();                                    // previous tile's operands are no longer needed
+    // G tile: [pixel][co], zero outside the image / beyond Cout
+    for (int i = tid; i < MT * 32 * WG_PX; i += nthr) {
+      const int x = i % WG_TW, y = (i / WG_TW) % WG_TH, co = i / WG_PX;
+      const int yy = y0 + y, xx = x0 + x;
+      float v = 0.f;
+      if (co < Cout && yy < H2 && xx < W2) v = G[(((size_t)b * Cout + co) * H2 + yy) * W2 + xx];
+      s_g[(y * WG_TW + x) * WG_GP + co] = v;
+    }
+    // activation tile with a 1-pixel apron: [(row, col)][ci]
+    for (int i = tid; i < 32 * WG_AH * WG_AW; i += nthr) {
+      const int x = i % WG_AW, y = (i / WG_AW) % WG_AH, c = i / (WG_AH * WG_AW);
+      const int yy = y0 + y - 1, xx = x0 + x - 1, ci = cb * 32 + c;
+      float v = 0.f;
+      if (ci < Cin && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = A[(((size_t)b * Cin + ci) * H2 + yy) * W2 + xx];
+      s_a[(y * WG_AW + x) * WG_AP + c] = v;
+    }
+    __syncthreads();
+    const float* ga = s_g + wave * 32 + j;
+#pragma unroll 4
+    for (int s = 0; s < WG_PX / 2; ++s) {
+      const int p = 2 * s + kk, py = p / WG_TW, px = p % WG_TW;
+      const float av = ga[p * WG_GP];
+      bsum += av;
+      const float* ap = s_a + (py * WG_AW + px) * WG_AP + j;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float bv = ap[((t / 3) * WG_AW + (t % 3)) * WG_AP];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // partial sums: part[blockIdx.x][co][ci][tap] over the padded channel counts (MT*32 x gridDim.y*32)
+  const int CiP = gridDim.y * 32, CoP = MT * 32;
+  float* pp = part + (size_t)blockIdx.x * CoP * CiP * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = cb * 32 + j;
+      pp[((size_t)co * CiP + ci) * 9 + t] = acc[t][r];
+    }
+  if (cb == 0) part_b[((size_t)blockIdx.x * CoP + wave * 32 + j) * 2 + kk] = bsum;
+}
+
+__global__ void k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ gw, float* __restrict__ gb,
+                               int NG, int Cout, int Cin, int CoP, int CiP) {
+  const long nw = (long)Cout * Cin * 9;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + Cout; i += (long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    if (i < nw) {
+      const int t = (int)(i % 9), ci = (int)((i / 9) % Cin), co = (int)(i / (9L * Cin));
+      for (int g = 0; g < NG; ++g) acc += part[(((size_t)g * CoP + co) * CiP + ci) * 9 + t];
+      if (gw) gw[i] = acc;
+    } else if (gb) {
+      const int co = (int)(i - nw);
+      for (int g = 0; g < NG; ++g) acc += part_b[((size_t)g * CoP + co) * 2] + part_b[((size_t)g * CoP + co) * 2 + 1];
+      gb[co] = acc;
+    }
+  }
+}
+
+constexpr int WGRAD_NG = 128;      // persistent workgroups per input-channel block
+static size_t wgrad_ws_floats(int nc, int in_nc) {
+  const int cop = mtiles(nc > 4 * in_nc ? nc : 4 * in_nc) * 32, cip = ((pad_even(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1) + 31) / 32) * 32;
+  return (size_t)WGRAD_NG * cop * cip * 9 + (size_t)WGRAD_NG * cop * 2;
+}
+
+// G: [B][Cout][H2][W2] gradient w.r.t. the layer's pre-activation output; A: [B][Cin_a][H2][W2] the layer's input
+static void launch_wgrad(const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Cin_a, int B, int H2, int W2,
+                         float* ws, hipStream_t s) {
+  const int tx = (W2 + WG_TW - 1) / WG_TW, ty = (H2 + WG_TH - 1) / WG_TH;
+  const int MT = mtiles(Cout), CB = (Cin_w + 31) / 32, CoP = MT * 32, CiP = CB * 32;
+  int NG = WGRAD_NG;
+  if (NG > B * tx * ty) NG = B * tx * ty;
+  float* part = ws;
+  float* part_b = ws + (size_t)WGRAD_NG * CoP * CiP * 9;
+  (void)Cin_w;
+  switch (MT) {
+    case 1: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<1>), dim3(NG, CB), dim3(64), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
+    case 2: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<2>), dim3(NG, CB), dim3(128), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
+    default: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<3>), dim3(NG, CB), dim3(192), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
+  }
+  DPX_LAUNCH("k_wgrad_reduce", k_wgrad_reduce, dim3(grid_for((long)Cout * Cin_w * 9 + Cout, 256, 1024)), dim3(256), 0, s, (const float*)part,
+             (const float*)part_b, gw, gb, NG, Cout, Cin_w, CoP, CiP);
+}
+
 // ---- training variants: forward that keeps every layer's output, backward-data through the whole stack ----------------
 extern "C" size_t dpx_ffdnet_acts_bytes(int B, int in_nc, int nc, int nb, int H, int W) {
   const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
@@ -489,12 +607,13 @@ extern "C" int dpx_ffdnet_pack_transposed(void* packed_T, const float* const* w,
 
 extern "C" size_t dpx_ffdnet_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W) {
   const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
-  return (px * 4 * in_nc + 2 * px * nc + px * pad_even(4 * in_nc + 1)) * sizeof(float);
+  return (px * 4 * in_nc + 2 * px * nc + px * pad_even(4 * in_nc + 1) + wgrad_ws_floats(nc, in_nc)) * sizeof(float);
 }
 
-extern "C" int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, const void* packed_T, const void* acts, int in_nc, int nc,
-                                   int nb, int B, int H, int W, void* ws, dpx_stream_t stream) {
-  DPX_REQUIRE(gy && packed_T && acts && ws && (gx || gsigma), "dpx_ffdnet_backward: null pointer");
+extern "C" int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, float* const* gw, float* const* gb, const void* packed_T,
+                                   const void* acts, int in_nc, int nc, int nb, int B, int H, int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(gy && packed_T && acts && ws && (gx || gsigma || gw), "dpx_ffdnet_backward: null pointer");
+  DPX_REQUIRE(!gw == !gb, "dpx_ffdnet_backward: weight and bias gradients come together");
   DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96,
               "dpx_ffdnet_backward: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
   hipStream_t s = (hipStream_t)stream;
@@ -506,6 +625,7 @@ extern "C" int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, co
   float* gA = g_last + px * 4 * in_nc;
   float* gB = gA + px * nc;
   float* g_a0 = gB + px * nc;
+  float* wg_ws = g_a0 + px * Cp;
   DPX_LAUNCH("k_ffd_pack_gout", k_ffd_pack_gout, dim3(grid_for((long)(px * 4 * in_nc), 256, 8192)), dim3(256), 0, s, gy, g_last, B, in_nc,
              H, W, H2, W2);
   // offsets of the transposed layers inside packed_T (stored in forward order)
@@ -515,8 +635,16 @@ extern "C" int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, co
   size_t o = 0;
   for (int l = 0; l < nb; ++l) { off[l] = o; o += layer_floats_T(l, in_nc, nc, nb); }
   const float* cur = g_last;
+  const bool need_data = gx || gsigma;
   for (int l = nb - 1; l >= 0; --l) {
     const int cin_t = layer_cout(l, in_nc, nc, nb), cout_t = layer_cin(l, in_nc, nc);   // transposed layer: cin_t -> cout_t channels
+    if (gw && gw[l]) {
+      // `cur` is the gradient w.r.t. forward layer l's pre-activation output (ReLU mask already applied by the epilogue
+      // of transposed layer l+1); the layer's input is a_l
+      const float* a_l = (l == 0) ? a0 : hidden + (size_t)(l - 1) * px * nc;
+      launch_wgrad(cur, a_l, gw[l], gb[l], cin_t, cout_t, (l == 0) ? Cp : cout_t, B, H2, W2, wg_ws, s);
+    }
+    if (l == 0 && !need_data) break;
     float* dst = (l == 0) ? g_a0 : (((nb - 1 - l) & 1) ? gB : gA);
     // the output of transposed layer l is the gradient w.r.t. a_l, the (post-ReLU) output of forward layer l-1: it is
     // stored already multiplied by [a_l > 0] (saved activation hidden[l-1]), ready to be the next layer's plain input

@@ -82,7 +82,7 @@ SIGNATURES = {
     "dpx_ffdnet_packed_transposed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_ffdnet_pack_transposed": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "dpx_ffdnet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_ffdnet_backward": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_ffdnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 

@@ -112,14 +112,13 @@ class FFDNet(nn.Module):
         be.require(x, what="FFDNet input")
         B, C, H, W = x.shape
         assert C == self.in_nc, f"FFDNet built for {self.in_nc} channels, got {C}"
-        if torch.is_grad_enabled() and (x.requires_grad or (isinstance(sigma, torch.Tensor) and sigma.requires_grad)):
-            if any(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError("weight gradients of FFDNet are not built yet: freeze the denoiser "
-                                          "(deep_prior(..., trainable=False)); gradients w.r.t. the image and sigma are available")
+        train_w = any(p.requires_grad for p in self.parameters())
+        if torch.is_grad_enabled() and (train_w or x.requires_grad or (isinstance(sigma, torch.Tensor) and sigma.requires_grad)):
             sig_t = sigma if isinstance(sigma, torch.Tensor) else torch.as_tensor(sigma, dtype=torch.float32)
             sig_t = sig_t.to(device=x.device, dtype=torch.float32).reshape(-1)
             sig_t = sig_t.expand(B).contiguous() if sig_t.numel() == 1 else sig_t.contiguous()
-            return _FFDNetFn.apply(self, x, sig_t)
+            params = (list(self.weights) + list(self.biases)) if train_w else []
+            return _FFDNetFn.apply(self, x, sig_t, *params)
         sig = ops.as_batch_vec(sigma, B, x.device)
         L = be.lib()
         y = torch.empty_like(x)
@@ -133,7 +132,7 @@ class _FFDNetFn(torch.autograd.Function):
     """FFDNet forward that keeps the layer outputs + hand-written backward-data pass (dpx_ffdnet_backward)"""
 
     @staticmethod
-    def forward(ctx, net, x, sig):
+    def forward(ctx, net, x, sig, *params):
         B, C, H, W = x.shape
         L = be.lib()
         x = x.contiguous()
@@ -154,10 +153,20 @@ class _FFDNetFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(gy) if ctx.needs_input_grad[1] else None
         gs = torch.empty(B, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[2] else None
+        nb = net.nb
+        gws, gbs, pw, pb = [], [], None, None
+        if len(ctx.needs_input_grad) > 3:                 # weights / biases were passed: fill their gradients
+            need = ctx.needs_input_grad[3:]
+            gws = [torch.empty_like(net.weights[i], dtype=torch.float32) if (need[i] or need[nb + i]) else None for i in range(nb)]
+            gbs = [torch.empty_like(net.biases[i], dtype=torch.float32) if gws[i] is not None else None for i in range(nb)]
+            pw = (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in gws])
+            pb = (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in gbs])
+        if gx is None and gs is None and pw is None:
+            return (None, None, None) + (None,) * (2 * nb if gws else 0)
         ws = ops.workspace("ffdnet_bwd", L.query("dpx_ffdnet_bwd_ws_bytes", B, net.in_nc, net.nc, H, W), gy.device)
-        L.call("dpx_ffdnet_backward", be.ptr(gy), be.ptr(gx), be.ptr(gs), be.ptr(net.packed_T()), be.ptr(acts), net.in_nc, net.nc,
-               net.nb, B, H, W, be.ptr(ws), be.stream())
-        return None, gx, gs
+        L.call("dpx_ffdnet_backward", be.ptr(gy), be.ptr(gx), be.ptr(gs), pw, pb, be.ptr(net.packed_T()), be.ptr(acts), net.in_nc,
+               net.nc, nb, B, H, W, be.ptr(ws), be.stream())
+        return (None, gx, gs, *gws, *gbs)
 
 
 def _load_checkpoint(model, model_path):

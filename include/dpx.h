@@ -238,15 +238,18 @@ int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void*
  * (dpx_ffdnet_acts_bytes) for the backward pass.  dpx_ffdnet_backward: gradient of the network output w.r.t. its image
  * input (gx, nullable) and w.r.t. the per-image noise level (gsigma[B], nullable) given gy -- the chain of transposed
  * 3x3 convolutions (same MFMA kernel, weights flipped / transposed once by dpx_ffdnet_pack_transposed, the ReLU masks fused into
- * the loads), i.e. what PyTorch autograd does for network_ffdnet.py:54-68 in the reference's unrolled / DEQ training.  */
+ * the epilogues), i.e. what PyTorch autograd does for network_ffdnet.py:54-68 in the reference's unrolled / DEQ training.
+ * gw / gb (nullable, together): per-layer device pointers [nb] receiving d/dW [cout][cin][3][3] and d/db [cout]
+ * (entries may be NULL to skip a layer) -- a pixels-as-K GEMM on the fp32 matrix cores with a deterministic two-stage
+ * reduction.                                                                                                           */
 size_t dpx_ffdnet_acts_bytes(int B, int in_nc, int nc, int nb, int H, int W);
 int dpx_ffdnet_forward_save(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb,
                             int B, int H, int W, void* acts, dpx_stream_t stream);
 size_t dpx_ffdnet_packed_transposed_bytes(int in_nc, int nc, int nb);
 int dpx_ffdnet_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream);
 size_t dpx_ffdnet_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W);
-int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, const void* packed_T, const void* acts, int in_nc, int nc,
-                        int nb, int B, int H, int W, void* ws, dpx_stream_t stream);
+int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, float* const* gw, float* const* gb, const void* packed_T,
+                        const void* acts, int in_nc, int nc, int nb, int B, int H, int W, void* ws, dpx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -452,6 +452,15 @@ def g16_ffdnet_grads():
     yg = gray.denoise(xg, sg)
     (yg * wg).sum().backward()
     out.update(gray_x=xg.detach(), gray_w=wg, gray_y=yg.detach(), gray_gx=xg.grad, gray_gsigma=sg.grad)
+    # weight / bias gradients (trainable prior): first, one middle and last layer of the colour net, all of the gray net's
+    colt = ColorDen(7).train()
+    xw = T(rng.rand(2, 3, 24, 38).astype("float32"))
+    ww = T(rng.randn(2, 3, 24, 38).astype("float32"))
+    (colt.denoise(xw, torch.tensor([0.05, 0.2])) * ww).sum().backward()
+    convs = [m for m in colt.model.model if isinstance(m, torch.nn.Conv2d)]
+    out.update(wg_x=xw, wg_w=ww)
+    for li in (0, 5, 11):
+        out[f"wg_dw{li}"], out[f"wg_db{li}"] = convs[li].weight.grad, convs[li].bias.grad
     # unrolled PnP
     gt, b, psf = synthetic.deconv_case(2, 3, 32, 40, seed=161)
     x = dp.Variable()

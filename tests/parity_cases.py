@@ -386,6 +386,24 @@ def case_ffdnet_grads(device, which=("odd", "even", "gray")):
     _assert_grad_close(sg.grad.cpu(), g["gray_gsigma"], "gray d/dsigma (summed over bands and images)", tol=1e-2)
 
 
+def case_ffdnet_weight_grads(device):
+    """G16 (third part): d/dW, d/db of the FFDNet stack (pixels-as-K MFMA GEMM + deterministic reduction) vs the
+    reference's autograd -- first, a middle and the last layer."""
+    g = load_golden("g16_ffdnet_grads")
+    col = _ffdnet("color", device)
+    col.train()
+    x = T(g["wg_x"], device)
+    (col.denoise(x, torch.tensor([0.05, 0.2], device=device)) * T(g["wg_w"], device)).sum().backward()
+    for li in (0, 5, 11):
+        _assert_grad_close(col.model.weights[li].grad.cpu(), g[f"wg_dw{li}"], f"dW layer {li}", tol=1e-4, flip_frac=0.02)
+        _assert_grad_close(col.model.biases[li].grad.cpu(), g[f"wg_db{li}"], f"db layer {li}", tol=1e-4, flip_frac=0.05)
+    # run-to-run determinism of the two-stage reduction
+    g1 = col.model.weights[5].grad.clone()
+    col.zero_grad()
+    (col.denoise(x, torch.tensor([0.05, 0.2], device=device)) * T(g["wg_w"], device)).sum().backward()
+    assert torch.equal(g1, col.model.weights[5].grad)
+
+
 def case_unrolled_pnp_grads(device):
     """G16 (second half): 2 unrolled plug-and-play ADMM iterations, gradients w.r.t. rho_t, sigma_t, x0"""
     g = load_golden("g16_ffdnet_grads")

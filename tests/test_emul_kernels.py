@@ -79,6 +79,11 @@ def test_unrolled_solver_learned_params():
     pc.case_unrolled_solver(DEV)
 
 
+@pytest.mark.skipif(not __import__("os").environ.get("DPX_EMUL_SLOW"), reason="~4 min on the emulator (runs on the GPU in test_gpu_parity); DPX_EMUL_SLOW=1 enables it")
+def test_ffdnet_weight_gradients():
+    pc.case_ffdnet_weight_grads(DEV)
+
+
 def test_ffdnet_backward():
     pc.case_ffdnet_grads(DEV, which=("even",))      # one small image: the emulator runs MFMA layers at ~1 s each
 

@@ -92,6 +92,10 @@ def test_unrolled_solver_learned_params():
     pc.case_unrolled_solver(DEV)
 
 
+def test_ffdnet_weight_gradients():
+    pc.case_ffdnet_weight_grads(DEV)
+
+
 def test_ffdnet_backward():
     pc.case_ffdnet_grads(DEV)
 

@@ -37,3 +37,13 @@ for _ in range(5): step()
 torch.cuda.synchronize(); dtb = (time.perf_counter() - t0) / 5
 flop_t = 2 * 9 * (13 * 96 + 10 * 96 * 96 + 96 * 12) * 256 * 256 * Bt
 print(f"FFDNet-color train fwd+bwd-data B={Bt} 512x512: {dtb*1e3:.2f} ms  {2*flop_t/dtb/1e12:.1f} TFLOP/s over the two passes")
+den.requires_grad_(True)
+def step_w():
+    den.zero_grad()
+    y = den.denoise(xt.detach(), st.detach())
+    y.sum().backward()
+for _ in range(2): step_w()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): step_w()
+torch.cuda.synchronize(); dtw = (time.perf_counter() - t0) / 5
+print(f"FFDNet-color train fwd + bwd-data + weight grads B={Bt} 512x512: {dtw*1e3:.2f} ms  {3*flop_t/dtw/1e12:.1f} TFLOP/s over the three passes")
