@@ -1,0 +1,261 @@
+// Fused backward stages of the ADMM iteration (config 5: unrolled training).  The reference differentiates
+// dprox/algo/admm.py:49-59 with PyTorch autograd through ~80 eager ops per iteration; here each of the three forward
+// stages (dpx_admm_rhs, dpx_fourier_solve, dpx_admm_zupdate) has one backward kernel (+ the transforms of
+// dpx_fourier_apply_inv), with the per-image scalar gradients (d/d rho, d/d lambda) reduced deterministically:
+// per-block partial sums (wave shuffles + one LDS hop) and a fixed-order finishing pass, no atomics.
+//
+//   z/dual stage  d = K x + u, v = prox(d, lam), u' = d - v:
+//       g_d = J^T (g_v - g_u') + g_u',  g_u = g_d,  g_x = sum_i K_i^T g_d,  g_lam = alpha <g_v - g_u', dprox/dlam>
+//       (J and dprox/dlam are recovered from the saved OUTPUT v: soft-threshold passes where v != 0, nonneg where v > 0)
+//   x stage       g_rho = -<g_rhs, sum_i K_i^T K_i x>            (g_rhs = M g_x comes from dpx_fourier_apply_inv)
+//   rhs stage     g_v_i = rho K_i g, g_u_i = -g_v_i, g_rho = <g, rhs> / rho
+#include "dpx_common.h"
+
+namespace dpx {
+
+__device__ __forceinline__ float ad_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float ad_block_sum(float v, float* sh) {
+  v = ad_wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (wid == 0) {
+    r = lane < (int)(blockDim.x >> 6) ? sh[lane] : 0.f;
+    r = ad_wave_sum(r);
+  }
+  return r;                                              // valid in thread 0
+}
+
+struct BwdTerm {
+  int linop, prox;
+  float alpha;
+  const float* lam;
+  const float* v;       // saved forward output of the prox
+  const float* gv;      // incoming gradients (nullable = 0)
+  const float* gun;     //   ... w.r.t. the updated dual u'
+  float* gu;            // outgoing gradient w.r.t. the incoming dual u
+};
+struct BwdPack {
+  BwdTerm t[DPX_MAX_TERMS];
+  int n;
+};
+
+// g_d of one term at one pixel (offset i), and dprox/dlam * (g_v - g_u') for the lambda gradient
+__device__ __forceinline__ float zb_gd(const BwdTerm& tm, long i, float lam, float& lam_term) {
+  const float gv = tm.gv ? tm.gv[i] : 0.f, gu = tm.gun ? tm.gun[i] : 0.f;
+  const float diff = gv - gu, v = tm.v[i];
+  float J, dl;
+  if (tm.prox == DPX_PROX_NORM1) {
+    J = v != 0.f ? 1.f : 0.f;
+    dl = v > 0.f ? -1.f : (v < 0.f ? 1.f : 0.f);
+  } else if (tm.prox == DPX_PROX_NONNEG) {
+    J = v > 0.f ? 1.f : 0.f;
+    dl = 0.f;
+  } else {
+    const float s = 1.f / (1.f + 2.f * lam);
+    J = s;
+    dl = -2.f * v * s;                                   // d = v (1 + 2 lam):  -2 d s^2 = -2 v s
+  }
+  lam_term = diff * dl;
+  return fmaf(J, diff, gu);
+}
+
+// grid (blocks, B): one image per blockIdx.y so that the lambda partial sums stay per image
+__global__ void __launch_bounds__(256) k_zupdate_bwd(float* __restrict__ gx, BwdPack T, float* __restrict__ part, int C, int H, int W) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y;
+  const long npb = (long)C * H * W, base = (long)b * npb;
+  float lsum[DPX_MAX_TERMS];
+#pragma unroll
+  for (int t = 0; t < DPX_MAX_TERMS; ++t) lsum[t] = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npb; p += (long)gridDim.x * 256) {
+    const int w = (int)(p % W);
+    const long row = p / W;
+    const int h = (int)(row % H);
+    const long i = base + p;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < DPX_MAX_TERMS; ++t) {
+      if (t < T.n) {
+        const BwdTerm& tm = T.t[t];
+        const float lam = tm.lam ? tm.lam[b] * tm.alpha : 0.f;
+        float lt, dummy;
+        const float gd = zb_gd(tm, i, lam, lt);
+        lsum[t] += lt;
+        tm.gu[i] = gd;
+        if (tm.linop == DPX_LIN_IDENTITY) {
+          acc += gd;
+        } else if (tm.linop == DPX_LIN_GRAD_W) {           // adjoint: y[w-1] - y[w]
+          const long il = base + row * W + (w == 0 ? W - 1 : w - 1);
+          acc += zb_gd(tm, il, lam, dummy) - gd;
+        } else {                                            // grad_H adjoint: y[h-1] - y[h]
+          const long iu = i + (long)((h == 0 ? H - 1 : h - 1) - h) * W;
+          acc += zb_gd(tm, iu, lam, dummy) - gd;
+        }
+      }
+    }
+    gx[i] = acc;
+  }
+  for (int t = 0; t < T.n; ++t) {
+    const float s = ad_block_sum(lsum[t], sh);
+    if (threadIdx.x == 0) part[((long)t * gridDim.y + b) * gridDim.x + blockIdx.x] = s * T.t[t].alpha;
+  }
+}
+
+struct LinCodes {
+  int linop[DPX_MAX_TERMS];
+  int n;
+};
+
+// part[b][blk] = - sum_p g[p] * (sum_i K_i^T K_i x)[p]
+__global__ void __launch_bounds__(256) k_solve_rho_grad(const float* __restrict__ g, const float* __restrict__ x, LinCodes L,
+                                                         float* __restrict__ part, int C, int H, int W) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y;
+  const long npb = (long)C * H * W, base = (long)b * npb;
+  float cI = 0.f;
+  bool hasW = false, hasH = false;
+  int nW = 0, nH = 0;
+  for (int t = 0; t < L.n; ++t) {
+    if (L.linop[t] == DPX_LIN_IDENTITY) cI += 1.f;
+    else if (L.linop[t] == DPX_LIN_GRAD_W) { hasW = true; ++nW; }
+    else { hasH = true; ++nH; }
+  }
+  float acc = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npb; p += (long)gridDim.x * 256) {
+    const int w = (int)(p % W);
+    const long row = p / W;
+    const int h = (int)(row % H);
+    const long i = base + p;
+    const float xc = x[i];
+    float lx = cI * xc;
+    if (hasW) {
+      const float xl = x[base + row * W + (w == 0 ? W - 1 : w - 1)], xr = x[base + row * W + (w + 1 == W ? 0 : w + 1)];
+      lx += (float)nW * (2.f * xc - xl - xr);             // K^T K of the circular forward difference
+    }
+    if (hasH) {
+      const float xu = x[i + (long)((h == 0 ? H - 1 : h - 1) - h) * W], xd = x[i + (long)((h + 1 == H ? 0 : h + 1) - h) * W];
+      lx += (float)nH * (2.f * xc - xu - xd);
+    }
+    acc = fmaf(g[i], lx, acc);
+  }
+  const float s = ad_block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(long)b * gridDim.x + blockIdx.x] = -s;
+}
+
+struct RhsBwdPack {
+  int linop[DPX_MAX_TERMS];
+  float* gv[DPX_MAX_TERMS];
+  float* gu[DPX_MAX_TERMS];
+  int n;
+};
+
+// g_v_i = rho_b K_i g, g_u_i = -g_v_i; part[b][blk] = sum g * rhs  (the host divides by rho)
+__global__ void __launch_bounds__(256) k_rhs_bwd(const float* __restrict__ g, const float* __restrict__ rhs, const float* __restrict__ rho,
+                                                  RhsBwdPack T, float* __restrict__ part, int C, int H, int W) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y;
+  const long npb = (long)C * H * W, base = (long)b * npb;
+  const float r = rho[b];
+  float acc = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npb; p += (long)gridDim.x * 256) {
+    const int w = (int)(p % W);
+    const long row = p / W;
+    const int h = (int)(row % H);
+    const long i = base + p;
+    const float gc = g[i];
+    acc = fmaf(gc, rhs[i], acc);
+#pragma unroll
+    for (int t = 0; t < DPX_MAX_TERMS; ++t) {
+      if (t < T.n) {
+        float kg;
+        if (T.linop[t] == DPX_LIN_IDENTITY) kg = gc;
+        else if (T.linop[t] == DPX_LIN_GRAD_W) kg = g[base + row * W + (w + 1 == W ? 0 : w + 1)] - gc;
+        else kg = g[i + (long)((h + 1 == H ? 0 : h + 1) - h) * W] - gc;
+        kg *= r;
+        if (T.gv[t]) T.gv[t][i] = kg;
+        if (T.gu[t]) T.gu[t][i] = -kg;
+      }
+    }
+  }
+  const float s = ad_block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(long)b * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void k_ad_finish(const float* __restrict__ part, float* __restrict__ out, int nblk, const float* __restrict__ div) {
+  __shared__ float sh[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += part[(long)blockIdx.x * nblk + i];
+  acc = ad_block_sum(acc, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = div ? acc / div[blockIdx.x] : acc;
+}
+
+static int ad_blocks(long npb) {
+  long g = (npb + 256 * 8 - 1) / (256 * 8);
+  return (int)(g > 512 ? 512 : (g < 1 ? 1 : g));
+}
+
+}  // namespace dpx
+
+using namespace dpx;
+
+extern "C" size_t dpx_admm_bwd_ws_bytes(int B, int C, int H, int W) {
+  return (size_t)DPX_MAX_TERMS * B * ad_blocks((long)C * H * W) * sizeof(float);
+}
+
+extern "C" int dpx_admm_zupdate_bwd(float* gx, const dpx_bwd_term* terms, int nterms, float* glam, int B, int C, int H, int W, void* ws,
+                                    dpx_stream_t stream) {
+  DPX_REQUIRE(gx && terms && glam && ws && nterms >= 1 && nterms <= DPX_MAX_TERMS && B > 0 && C > 0 && H > 0 && W > 0,
+              "dpx_admm_zupdate_bwd: bad arguments");
+  BwdPack T;
+  T.n = nterms;
+  for (int i = 0; i < nterms; ++i) {
+    DPX_REQUIRE(terms[i].v && terms[i].gu, "dpx_admm_zupdate_bwd: term %d lacks v / gu", i);
+    DPX_REQUIRE(terms[i].linop >= DPX_LIN_IDENTITY && terms[i].linop <= DPX_LIN_GRAD_W && terms[i].prox >= DPX_PROX_NORM1 &&
+                    terms[i].prox <= DPX_PROX_SUMSQ, "dpx_admm_zupdate_bwd: term %d has an unknown linop / prox code", i);
+    T.t[i] = BwdTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].v, terms[i].gv, terms[i].gu_new, terms[i].gu};
+  }
+  const int nblk = ad_blocks((long)C * H * W);
+  hipStream_t s = (hipStream_t)stream;
+  DPX_LAUNCH("k_zupdate_bwd", k_zupdate_bwd, dim3(nblk, B), dim3(256), 0, s, gx, T, (float*)ws, C, H, W);
+  DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(nterms * B), dim3(256), 0, s, (const float*)ws, glam, nblk, (const float*)nullptr);
+  return launch_status("dpx_admm_zupdate_bwd");
+}
+
+extern "C" int dpx_admm_solve_rho_grad(const float* g_rhs, const float* x, const int* linops, int nterms, float* grho, int B, int C, int H,
+                                       int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(g_rhs && x && grho && ws && (linops || nterms == 0) && nterms >= 0 && nterms <= DPX_MAX_TERMS,
+              "dpx_admm_solve_rho_grad: bad arguments");
+  LinCodes L;
+  L.n = nterms;
+  for (int i = 0; i < nterms; ++i) L.linop[i] = linops[i];
+  const int nblk = ad_blocks((long)C * H * W);
+  hipStream_t s = (hipStream_t)stream;
+  DPX_LAUNCH("k_solve_rho_grad", k_solve_rho_grad, dim3(nblk, B), dim3(256), 0, s, g_rhs, x, L, (float*)ws, C, H, W);
+  DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(B), dim3(256), 0, s, (const float*)ws, grho, nblk, (const float*)nullptr);
+  return launch_status("dpx_admm_solve_rho_grad");
+}
+
+extern "C" int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv,
+                                float* const* gu, float* grho, int B, int C, int H, int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(g && rhs && rho && linops && gv && gu && grho && ws && nterms >= 1 && nterms <= DPX_MAX_TERMS,
+              "dpx_admm_rhs_bwd: bad arguments");
+  RhsBwdPack T;
+  T.n = nterms;
+  for (int i = 0; i < nterms; ++i) {
+    T.linop[i] = linops[i];
+    T.gv[i] = gv[i];
+    T.gu[i] = gu[i];
+  }
+  const int nblk = ad_blocks((long)C * H * W);
+  hipStream_t s = (hipStream_t)stream;
+  DPX_LAUNCH("k_rhs_bwd", k_rhs_bwd, dim3(nblk, B), dim3(256), 0, s, g, rhs, rho, T, (float*)ws, C, H, W);
+  DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(B), dim3(256), 0, s, (const float*)ws, grho, nblk, rho);
+  return launch_status("dpx_admm_rhs_bwd");
+}

@@ -94,12 +94,13 @@ __global__ void k_zupdate(const float* __restrict__ x, TermPack T, int B, int C,
           uu[e] = d - vv[e];
         }
       }
+      float* uo = tm.u_out ? tm.u_out : tm.u;            // out-of-place dual (differentiable mode keeps u_in)
       if constexpr (VEC == 4) {
         *(float4*)(tm.v + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        if (tm.prox != DPX_PROX_EXTERNAL) *(float4*)(tm.u + off) = make_float4(uu[0], uu[1], uu[2], uu[3]);
+        if (tm.prox != DPX_PROX_EXTERNAL) *(float4*)(uo + off) = make_float4(uu[0], uu[1], uu[2], uu[3]);
       } else {
         tm.v[off] = vv[0];
-        if (tm.prox != DPX_PROX_EXTERNAL) tm.u[off] = uu[0];
+        if (tm.prox != DPX_PROX_EXTERNAL) uo[off] = uu[0];
       }
     }
   }
@@ -279,7 +280,7 @@ static int pack_terms(TermPack& T, const dpx_term* terms, int n, const char* who
       set_error("%s: term %d has an unknown linop/prox code", who, i);
       return DPX_ERR_ARG;
     }
-    vec_ok &= aligned16(terms[i].v) && aligned16(terms[i].u);
+    vec_ok &= aligned16(terms[i].v) && aligned16(terms[i].u) && aligned16(terms[i].u_out);
   }
   return DPX_OK;
 }

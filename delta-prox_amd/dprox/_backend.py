@@ -32,6 +32,12 @@ class Term(ctypes.Structure):
                 ("lam", c_void_p), ("v", c_void_p), ("u", c_void_p), ("u_out", c_void_p)]
 
 
+class BwdTerm(ctypes.Structure):
+    """``dpx_bwd_term`` of include/dpx.h."""
+    _fields_ = [("linop", c_int32), ("prox", c_int32), ("alpha", c_float), ("reserved", c_int32),
+                ("lam", c_void_p), ("v", c_void_p), ("gv", c_void_p), ("gu_new", c_void_p), ("gu", c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/dpx.h declares
 SIGNATURES = {
     "dpx_version": (c_int, []),
@@ -67,6 +73,11 @@ SIGNATURES = {
     "dpx_fourier_apply_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpx_admm_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_zupdate": (c_int, [c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_admm_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dpx_admm_zupdate_bwd": (c_int, [c_void_p, POINTER(BwdTerm), c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_solve_rho_grad": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_rhs_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int), c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
+                                 c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_iter_supported": (c_int, [c_int, c_int, POINTER(Term), c_int]),
     "dpx_rfft_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_iter_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -297,6 +297,56 @@ def prox(kind, v, lam, alpha=1.0, off=None, out=None):
     return res
 
 
+def _bwd_ws(B, C, H, W, device):
+    return workspace("admm_bwd", be.lib().query("dpx_admm_bwd_ws_bytes", B, C, H, W), device)
+
+
+def admm_zupdate_bwd(specs, shape, device):
+    """specs: dict(linop, prox, alpha, lam[B], v, gv|None, gu_new|None) per term -> (gx, [gu_i], [glam_i [B]])"""
+    B, C, H, W = shape
+    n = len(specs)
+    arr = (be.BwdTerm * n)()
+    gus = [torch.empty(shape, dtype=torch.float32, device=device) for _ in specs]
+    keep = []
+    for i, s_ in enumerate(specs):
+        arr[i].linop, arr[i].prox, arr[i].alpha = s_["linop"], s_["prox"], float(s_.get("alpha", 1.0))
+        for name in ("lam", "v", "gv", "gu_new"):
+            t = s_.get(name)
+            if t is not None:
+                t = t.contiguous()
+                keep.append(t)
+            setattr(arr[i], name, None if t is None else t.data_ptr())
+        arr[i].gu = gus[i].data_ptr()
+    gx = torch.empty(shape, dtype=torch.float32, device=device)
+    glam = torch.empty(n, B, dtype=torch.float32, device=device)
+    be.lib().call("dpx_admm_zupdate_bwd", ptr(gx), arr, n, ptr(glam), B, C, H, W, ptr(_bwd_ws(B, C, H, W, device)), be.stream())
+    return gx, gus, [glam[i] for i in range(n)]
+
+
+def admm_solve_rho_grad(g_rhs, x, linops):
+    B, C, H, W = _shape4(x)
+    n = len(linops)
+    codes = (ctypes.c_int * max(n, 1))(*linops)
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    be.lib().call("dpx_admm_solve_rho_grad", ptr(g_rhs.contiguous()), ptr(x.contiguous()), codes, n, ptr(out), B, C, H, W,
+                  ptr(_bwd_ws(B, C, H, W, x.device)), be.stream())
+    return out
+
+
+def admm_rhs_bwd(g, rhs, rho, linops, want_v=True, want_u=True):
+    B, C, H, W = _shape4(g)
+    n = len(linops)
+    codes = (ctypes.c_int * n)(*linops)
+    gv = [torch.empty_like(g) if want_v else None for _ in range(n)]
+    gu = [torch.empty_like(g) if want_u else None for _ in range(n)]
+    pv = (c_void_p * n)(*[None if t is None else t.data_ptr() for t in gv])
+    pu = (c_void_p * n)(*[None if t is None else t.data_ptr() for t in gu])
+    grho = torch.empty(B, dtype=torch.float32, device=g.device)
+    be.lib().call("dpx_admm_rhs_bwd", ptr(g.contiguous()), ptr(rhs), ptr(rho.contiguous()), codes, n, pv, pu, ptr(grho), B, C, H, W,
+                  ptr(_bwd_ws(B, C, H, W, g.device)), be.stream())
+    return gv, gu, grho
+
+
 def make_terms(specs):
     """specs: list of dict(linop, prox, alpha, lam[B] tensor or None, v, u) -> (ctypes array, keepalive)."""
     n = len(specs)
@@ -307,7 +357,7 @@ def make_terms(specs):
         arr[i].linop, arr[i].prox, arr[i].alpha = s["linop"], s["prox"], float(s.get("alpha", 1.0))
         arr[i].lam = None if s.get("lam") is None else s["lam"].data_ptr()
         arr[i].v, arr[i].u = s["v"].data_ptr(), s["u"].data_ptr()
-        arr[i].u_out = None
+        arr[i].u_out = None if s.get("u_out") is None else s["u_out"].data_ptr()
     return arr
 
 

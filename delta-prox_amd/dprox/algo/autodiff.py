@@ -79,10 +79,7 @@ class _Rhs(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         rho, rhs = ctx.saved_tensors
-        g = g.contiguous()
-        gv = [_scaled(rho, _K(lc, g)) for lc, _ in ctx.codes]
-        gu = [ops.lincomb([(-1.0, t)]) for t in gv]
-        g_rho = ops.bdot(g, rhs) / rho
+        gv, gu, g_rho = ops.admm_rhs_bwd(g.contiguous(), rhs, rho, [lc for lc, _ in ctx.codes])
         return (None, g_rho, *gv, *gu)
 
 
@@ -101,12 +98,8 @@ class _Solve(torch.autograd.Function):
         x, rho = ctx.saved_tensors
         t0, c0, t1, c1 = plan.diag
         g_rhs = ops.fourier_apply_inv(gx.contiguous(), t0, t1, c0, c1, rho, plan.eps)
-        # d x / d rho = -M (sum_Psi K_i^T K_i) x
-        Gx = None
-        for lc, _ in plan.codes:
-            t = _KT(lc, _K(lc, x))
-            Gx = t if Gx is None else ops.lincomb([(1.0, Gx), (1.0, t)])
-        g_rho = -ops.bdot(g_rhs, Gx) if Gx is not None else torch.zeros_like(rho)
+        # d x / d rho = -M (sum_Psi K_i^T K_i) x : one stencil + reduction pass
+        g_rho = ops.admm_solve_rho_grad(g_rhs, x, [lc for lc, _ in plan.codes])
         g_offs = []
         for need, otf in zip(ctx.needs_input_grad[3:], plan.omega_otfs):
             if not need:
@@ -124,17 +117,14 @@ class _ZUpdate(torch.autograd.Function):
         n = len(idx)
         lams, us = lam_u[:n], lam_u[n:]
         x = x.contiguous()
-        ds, vs, uos = [], [], []
-        ctx.idx = idx
-        for i, lam, u in zip(idx, lams, us):
-            (lc, pc), fn = plan.codes[i], plan.psi[i]
-            d = ops.lincomb([(1.0, _K(lc, x)), (1.0, u.contiguous())])
-            v = ops.prox(pc, d, lam, float(fn.alpha), None)
-            ds.append(d)
-            vs.append(v)
-            uos.append(ops.lincomb([(1.0, d), (-1.0, v)]))
-        ctx.plan = plan
-        ctx.save_for_backward(*lams, *ds)
+        vs = [torch.empty_like(x) for _ in idx]
+        uos = [torch.empty_like(x) for _ in idx]
+        specs = [dict(linop=plan.codes[i][0], prox=plan.codes[i][1], alpha=float(plan.psi[i].alpha), lam=lam.contiguous(), v=v,
+                      u=u.contiguous(), u_out=uo) for i, lam, u, v, uo in zip(idx, lams, us, vs, uos)]
+        ctx.keep = specs
+        ops.admm_zupdate(x, ops.make_terms(specs), n)
+        ctx.plan, ctx.idx = plan, idx
+        ctx.save_for_backward(*lams, *vs)
         return (*vs, *uos)
 
     @staticmethod
@@ -142,20 +132,11 @@ class _ZUpdate(torch.autograd.Function):
         plan = ctx.plan
         n = len(ctx.idx)
         saved = ctx.saved_tensors
-        lams, ds = saved[:n], saved[n:]
+        lams, vs = saved[:n], saved[n:]
         gvs, guos = g[:n], g[n:]
-        gx, glams, gus = None, [], []
-        for i, k in enumerate(ctx.idx):
-            (lc, pc), fn = plan.codes[k], plan.psi[k]
-            gv = gvs[i] if gvs[i] is not None else torch.zeros_like(ds[i])
-            gu = guos[i] if guos[i] is not None else torch.zeros_like(ds[i])
-            diff = ops.lincomb([(1.0, gv.contiguous()), (-1.0, gu.contiguous())])
-            jd, dl = ops.prox_bwd(pc, ds[i], diff, lams[i], float(fn.alpha), None, want_dlam=True)
-            gd = ops.lincomb([(1.0, jd), (1.0, gu.contiguous())])
-            glams.append(ops.bdot(diff, dl) * float(fn.alpha))
-            gus.append(gd)
-            t = _KT(lc, gd)
-            gx = t if gx is None else ops.lincomb([(1.0, gx), (1.0, t)])
+        specs = [dict(linop=plan.codes[k][0], prox=plan.codes[k][1], alpha=float(plan.psi[k].alpha), lam=lams[i], v=vs[i], gv=gvs[i],
+                      gu_new=guos[i]) for i, k in enumerate(ctx.idx)]
+        gx, gus, glams = ops.admm_zupdate_bwd(specs, tuple(vs[0].shape), vs[0].device)
         return (None, None, gx, *glams, *gus)
 
 
@@ -173,13 +154,16 @@ class DiffPlan:
         self.codes, self.psi, self.diag, self.FK, self.omega_otfs, self.eps = codes, psi, diag, FK, omega_otfs, eps
 
 
-def _sched(vals, it, B, dev):
-    """entry `it` of a 0-d / [T] / [B,T] schedule as a [B] device tensor, differentiably (tiny torch ops: plumbing)"""
+def _sched_table(vals, T, B, dev):
+    """0-d / [T] / [B,T] schedule -> [T,B] device tensor, differentiably, in ONE set of tiny torch ops per solve (row `it`
+    is then a contiguous view: no per-iteration kernels)"""
     v = vals if isinstance(vals, torch.Tensor) else torch.as_tensor(vals, dtype=torch.float32)
     v = v.to(device=dev, dtype=torch.float32)
-    if v.ndim >= 1:
-        v = v[..., it]
-    return v.reshape(-1).expand(B).contiguous() if v.numel() in (1, B) else v
+    if v.ndim == 0:
+        return v.reshape(1, 1).expand(T, B).contiguous()
+    if v.ndim == 1:
+        return v[:T].reshape(T, 1).expand(T, B).contiguous()
+    return v[:, :T].t().expand(T, B).contiguous()
 
 
 def run(plan: DiffPlan, state, rhos, lams, max_iter, diff_offsets):
@@ -195,9 +179,11 @@ def run(plan: DiffPlan, state, rhos, lams, max_iter, diff_offsets):
         v = [_LinApply.apply(lc, x) if (t.grad_fn is None and not t.requires_grad) else t for (lc, _), t in zip(codes, v)]
     closed = tuple(i for i, (_, pc) in enumerate(codes) if pc != be.PROX_EXTERNAL)
     ext = [i for i, (_, pc) in enumerate(codes) if pc == be.PROX_EXTERNAL]
+    rho_tab = _sched_table(rhos, max_iter, B, dev)
+    lam_tabs = [_sched_table(lams[fn], max_iter, B, dev) for fn in plan.psi]
     for it in range(max_iter):
-        rho = _sched(rhos, it, B, dev)
-        lam = [_sched(lams[fn], it, B, dev) for fn in plan.psi]
+        rho = rho_tab[it]
+        lam = [lt[it] for lt in lam_tabs]
         rhs = _Rhs.apply(codes, rho, *v, *u)
         x = _Solve.apply(plan, rhs, rho, *diff_offsets)
         nv, nu = list(v), list(u)

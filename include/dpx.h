@@ -198,6 +198,30 @@ int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, const dpx_term*
 int dpx_admm_zupdate(const float* x, const dpx_term* terms, int nterms,
                      int B, int C, int H, int W, dpx_stream_t stream);
 
+/* ---- fused backward stages of the iteration (config 5, unrolled training; the reference uses PyTorch autograd through
+ * the eager ops of algo/admm.py:49-59).  Per-image scalar gradients are reduced deterministically; `ws` has
+ * dpx_admm_bwd_ws_bytes.                                                                                              */
+typedef struct dpx_bwd_term {
+  int32_t linop, prox;
+  float alpha;
+  int32_t reserved;
+  const float* lam;    /* [B] */
+  const float* v;      /* saved forward output v_i = prox(K_i x + u_i)                                  */
+  const float* gv;     /* incoming gradient w.r.t. v_i (nullable = 0)                                     */
+  const float* gu_new; /* incoming gradient w.r.t. the updated dual u_i' = K_i x + u_i - v_i (nullable)   */
+  float* gu;           /* out: gradient w.r.t. the incoming dual u_i                                       */
+} dpx_bwd_term;
+size_t dpx_admm_bwd_ws_bytes(int B, int C, int H, int W);
+/* z/dual stage: gx = sum_i K_i^T g_d_i, terms[i].gu = g_d_i, glam[i*B + b] = d loss / d lam_i[b]               */
+int dpx_admm_zupdate_bwd(float* gx, const dpx_bwd_term* terms, int nterms, float* glam, int B, int C, int H, int W, void* ws,
+                         dpx_stream_t stream);
+/* x stage: grho[b] = -<g_rhs_b, (sum_i K_i^T K_i) x_b> with g_rhs = dpx_fourier_apply_inv(gx)                   */
+int dpx_admm_solve_rho_grad(const float* g_rhs, const float* x, const int* linops, int nterms, float* grho, int B, int C, int H, int W,
+                            void* ws, dpx_stream_t stream);
+/* rhs stage: gv[i] = rho_b K_i g, gu[i] = -gv[i] (either may be NULL), grho[b] = <g_b, rhs_b> / rho_b            */
+int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv,
+                     float* const* gu, float* grho, int B, int C, int H, int W, void* ws, dpx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* two-kernel fused ADMM iteration (power-of-two planes)                                       */
 /* ------------------------------------------------------------------------------------------ */
