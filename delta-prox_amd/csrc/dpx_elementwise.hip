@@ -406,6 +406,94 @@ extern "C" int dpx_mul(const float* x, const float* w, float* out, int B, long n
   return launch_status("dpx_mul");
 }
 
+// ---- closed-form super-resolution data term (proxfn/fast/sr.py:45-126) -------------------------------------------------
+__global__ void __launch_bounds__(256) k_upsample_zero(const float* __restrict__ y, float* __restrict__ out, int sf, long planes, int h, int w) {
+  const int H = h * sf, W = w * sf;
+  const long total = planes * H * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int xx = (int)(i % W);
+    const long r = i / W;
+    const int yy = (int)(r % H);
+    const long p = r / H;
+    out[i] = (yy % sf == 0 && xx % sf == 0) ? y[(p * h + yy / sf) * w + xx / sf] : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_cplx_mul(float2* __restrict__ out, const float2* __restrict__ a, const float2* __restrict__ bb,
+                                                  int conj_a, long npb, int a_images) {
+  const int b = blockIdx.y;
+  const float2* ab = a + (a_images > 1 ? (long)b * npb : 0L);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < npb; i += (long)gridDim.x * 256L) {
+    float2 av = ab[i];
+    if (conj_a) av.y = -av.y;
+    const float2 bv = bb[(long)b * npb + i];
+    out[(long)b * npb + i] = make_float2(av.x * bv.x - av.y * bv.y, av.x * bv.y + av.y * bv.x);
+  }
+}
+
+// one thread per output frequency; the sf*sf aliases of its block are gathered from L2
+__global__ void __launch_bounds__(256) k_sisr_update(const float2* __restrict__ FRin, float2* __restrict__ FX, const float2* __restrict__ FB,
+                                                     int fb_planes, const float* __restrict__ lam, float I, int sf, int C, int H, int W) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int h = H / sf, w = W / sf;
+  const long plane = ((long)b * C + c) * H * W;
+  const float2* fb = FB + (fb_planes == 1 ? 0L : (fb_planes == C ? (long)c : ((long)b * C + c))) * H * W;
+  const float il = I * lam[b];
+  const float inv_n = 1.f / (float)(sf * sf);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)H * W; i += (long)gridDim.x * 256L) {
+    const int v = (int)(i % W), u = (int)(i / W);
+    const int u0 = u % h, v0 = v % w;
+    float2 fbr = make_float2(0.f, 0.f);
+    float invw = 0.f;
+    for (int a = 0; a < sf; ++a)
+      for (int e = 0; e < sf; ++e) {
+        const long k = (long)(u0 + a * h) * W + (v0 + e * w);
+        const float2 B2 = fb[k], R = FRin[plane + k];
+        fbr.x += B2.x * R.x - B2.y * R.y;
+        fbr.y += B2.x * R.y + B2.y * R.x;
+        invw += B2.x * B2.x + B2.y * B2.y;
+      }
+    fbr.x *= inv_n;
+    fbr.y *= inv_n;
+    invw *= inv_n;
+    const float d = invw + il;
+    const float2 q = make_float2(fbr.x / d, fbr.y / d);            // invWBR
+    const float2 Bc = fb[i], R = FRin[plane + i];
+    // FBC * invWBR = conj(B) * q
+    const float2 t = make_float2(Bc.x * q.x + Bc.y * q.y, Bc.x * q.y - Bc.y * q.x);
+    const float den = il + 1e-9f;
+    FX[plane + i] = make_float2((R.x - t.x) / den, (R.y - t.y) / den);
+  }
+}
+
+extern "C" int dpx_upsample_zero(const float* y, float* out, int sf, long planes, int h, int w, dpx_stream_t stream) {
+  DPX_REQUIRE(y && out && sf >= 1 && planes > 0 && h > 0 && w > 0, "dpx_upsample_zero: bad arguments");
+  DPX_LAUNCH("k_upsample_zero", k_upsample_zero, dim3(grid_for(planes * h * sf * w * sf, 256, 8192)), dim3(256), 0, (hipStream_t)stream, y, out,
+             sf, planes, h, w);
+  return launch_status("dpx_upsample_zero");
+}
+
+extern "C" int dpx_cplx_mul(void* out, const void* a, const void* bb, int conj_a, int B, long n_per_image, int a_images,
+                            dpx_stream_t stream) {
+  DPX_REQUIRE(out && a && bb && B > 0 && n_per_image > 0 && (a_images == 1 || a_images == B), "dpx_cplx_mul: bad arguments");
+  DPX_LAUNCH("k_cplx_mul", k_cplx_mul, dim3(grid_for(n_per_image, 256, 2048), B, 1), dim3(256), 0, (hipStream_t)stream, (float2*)out,
+             (const float2*)a, (const float2*)bb, conj_a, n_per_image, a_images);
+  return launch_status("dpx_cplx_mul");
+}
+
+extern "C" int dpx_sisr_update(void* FR, const void* FB, int fb_planes, const float* lam, float I, int sf, int B, int C, int H, int W,
+                               dpx_stream_t stream) {
+  DPX_REQUIRE(FR && FB && lam && sf >= 1 && B > 0 && C > 0 && H > 0 && W > 0, "dpx_sisr_update: bad arguments");
+  DPX_REQUIRE(H % sf == 0 && W % sf == 0, "dpx_sisr_update: the scale factor %d must divide the image size %dx%d", sf, H, W);
+  DPX_REQUIRE(fb_planes == 1 || fb_planes == C || fb_planes == B * C, "dpx_sisr_update: FB must have 1, C or B*C planes (got %d)", fb_planes);
+  // out of place inside: aliases of other frequencies are read while this one is written -> use a second buffer view:
+  // FR is [2][B][C][H][W]: the first half is the input, the second half receives FX (the caller passes both)
+  const long n = (long)B * C * H * W;
+  DPX_LAUNCH("k_sisr_update", k_sisr_update, dim3(grid_for((long)H * W, 256, 1024), C, B), dim3(256), 0, (hipStream_t)stream,
+             (const float2*)FR, (float2*)FR + n, (const float2*)FB, fb_planes, lam, I, sf, C, H, W);
+  return launch_status("dpx_sisr_update");
+}
+
 // ---- complex-iterate arithmetic of the CS-MRI solver (contrib/csmri.py:156-171, proxfn/fast/csmri.py:14-25) ----
 struct CplxPack {
   const void* x[4];

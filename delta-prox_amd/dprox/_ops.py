@@ -432,6 +432,49 @@ def mul(x, w):
     return out
 
 
+def upsample_zero(y, sf):
+    require(y, what="upsample input")
+    B, C, h, w = _shape4(y)
+    out = torch.empty(B, C, h * sf, w * sf, dtype=torch.float32, device=y.device)
+    be.lib().call("dpx_upsample_zero", ptr(y), ptr(out), int(sf), B * C, h, w, be.stream())
+    return out
+
+
+def cplx_mul(a, b, conj_a=False):
+    """(conj) a * b, complex64; a is one image [1,...] shared by the batch or a batch like b"""
+    require(b, dtype=torch.complex64, what="cplx_mul b")
+    a = a.to(torch.complex64).contiguous()
+    B = int(b.shape[0])
+    npb = b.numel() // B
+    a = a.expand(*([1] * (b.ndim - a.ndim)), *a.shape) if a.ndim < b.ndim else a
+    if a.numel() == npb:
+        aimg = 1
+    elif a.numel() == b.numel():
+        aimg = B
+    else:
+        a = a.expand_as(b).contiguous()
+        aimg = B
+    out = torch.empty_like(b)
+    be.lib().call("dpx_cplx_mul", ptr(out), ptr(a), ptr(b), int(bool(conj_a)), B, npb, aimg, be.stream())
+    return out
+
+
+def sisr_update(FR, FB, lam, I, sf):
+    """FX of sr.py:66-72 from FR [B,C,H,W] and the kernel spectrum FB ([1|B, 1|C, H, W])"""
+    require(FR, dtype=torch.complex64, what="sisr FR")
+    B, C, H, W = _shape4(FR)
+    FB = FB.to(torch.complex64).contiguous()
+    planes = FB.numel() // (H * W)
+    if planes not in (1, C, B * C):
+        FB = FB.expand(B, C, H, W).contiguous()
+        planes = B * C
+    buf = torch.empty(2, B, C, H, W, dtype=torch.complex64, device=FR.device)
+    buf[0].copy_(FR)
+    be.lib().call("dpx_sisr_update", ptr(buf), ptr(FB), planes, ptr(as_batch_vec(lam, B, FR.device)), float(I), int(sf), B, C, H, W,
+                  be.stream())
+    return buf[1]
+
+
 def clincomb(terms, out_complex=True):
     """sum_i coef_i * x_i over up to 4 real-fp32 / complex64 tensors of one shape; complex64 result, or its real part
     as fp32 (out_complex=False).  coef_i are python floats."""

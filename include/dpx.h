@@ -123,6 +123,18 @@ int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, in
 int dpx_csmri_update(void* z, const void* y, const unsigned char* mask, int mask_images, const float* lam, float num_psi, int B,
                      long n_per_image, dpx_stream_t stream);
 
+/* Building blocks of the closed-form single-image super-resolution data term `sisr` (dprox/proxfn/fast/sr.py:45-77):
+ *   dpx_upsample_zero : s-fold zero-filling upsampler (sr.py:117-126), planes x h x w -> planes x (h sf) x (w sf)
+ *   dpx_cplx_mul      : out[b,i] = (conj_a ? conj(a) : a)[(a_images > 1 ? b : 0), i] * bb[b, i]  (complex64; FBC * F(STy))
+ *   dpx_sisr_update   : FR is a [2][B][C][H][W] complex64 buffer: half 0 = FR (input), half 1 receives FX (sr.py:66-72):
+ *         FBR  = mean over the sf x sf aliases of FB * FR,   invW = mean over the aliases of |FB|^2
+ *         FX   = (FR - conj(FB) * FBR / (invW + I lam_b)) / (I lam_b + 1e-9)
+ *     FB holds fb_planes = 1, C or B*C planes.                                                                   */
+int dpx_upsample_zero(const float* y, float* out, int sf, long planes, int h, int w, dpx_stream_t stream);
+int dpx_cplx_mul(void* out, const void* a, const void* bb, int conj_a, int B, long n_per_image, int a_images, dpx_stream_t stream);
+int dpx_sisr_update(void* FR, const void* FB, int fb_planes, const float* lam, float I, int sf, int B, int C, int H, int W,
+                    dpx_stream_t stream);
+
 /* out[b, i] = x[b, i] * w[(w_images > 1 ? b : 0), i]: diagonal operators in the image domain -- mosaic's Bayer mask
  * (dprox/linop/subsample.py:17-31) and mul_elementwise (dprox/linop/mul.py:46-73); forward == adjoint.          */
 int dpx_mul(const float* x, const float* w, float* out, int B, long n_per_image, int w_images, dpx_stream_t stream);

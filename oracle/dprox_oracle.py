@@ -31,7 +31,7 @@ __all__ = [
     "soft_threshold", "prox", "LeastSquares", "cg", "bdot", "LinearSolveConfig",
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
     "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
-    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic",
+    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior",
 ]
 
 
@@ -654,6 +654,50 @@ def custom_admm_csmri(x0, y, mask, rhos, sigmas, max_iter, denoise):
         z = csmri_prox(b, rho, 1, mask, y)
         u = u + x - z
     return x, z, u
+
+
+# --------------------------------------------------------------------------- #
+# closed-form super-resolution data term                                      #
+# --------------------------------------------------------------------------- #
+def _sr_splits(a, sf):
+    """proxfn/fast/sr.py:83-93."""
+    b = torch.stack(torch.chunk(a, sf, dim=2), dim=4)
+    return torch.cat(torch.chunk(b, sf, dim=3), dim=4)
+
+
+def sisr_prox(v, lam, I, y, kernel, sf):
+    """proxfn/fast/sr.py:52-77 (reload + _prox): kernel [1,1,kh,kw] tensor, y [N,C,h,w]."""
+    h, w = y.shape[-2:]
+    STy = torch.zeros(y.shape[0], y.shape[1], h * sf, w * sf, dtype=y.dtype)              # upsample, sr.py:117-126
+    STy[..., 0::sf, 0::sf] = y
+    otf = torch.zeros(kernel.shape[:-2] + (h * sf, w * sf), dtype=kernel.dtype)           # p2o, sr.py:95-114
+    otf[..., :kernel.shape[2], :kernel.shape[3]] = kernel
+    for axis, axis_size in enumerate(kernel.shape[2:]):
+        otf = torch.roll(otf, -int(axis_size / 2), dims=axis + 2)
+    FB = torch.fft.fftn(otf, dim=(-2, -1))
+    FBC, F2B = torch.conj(FB), torch.pow(torch.abs(FB), 2)
+    FBFy = FBC * torch.fft.fftn(STy, dim=(-2, -1))
+    FR = FBFy + torch.fft.fftn(lam * v, dim=(-2, -1))
+    x1 = FB.mul(FR)
+    FBR = torch.mean(_sr_splits(x1, sf), dim=-1, keepdim=False)
+    invW = torch.mean(_sr_splits(F2B, sf), dim=-1, keepdim=False)
+    invWBR = FBR.div(invW + I * lam)
+    FCBinvWBR = FBC * invWBR.repeat(1, 1, sf, sf)
+    FX = (FR - FCBinvWBR) / (I * lam + 1e-9)
+    return torch.real(torch.fft.ifftn(FX, dim=(-2, -1)))
+
+
+def admm_ext_prior(x0, ext_prox, denoise, rhos, sigmas, max_iter):
+    """ADMM (algo/admm.py:49-67) for  ext_sum_squares data term + one deep prior on x: the x-update is the data term's
+    own closed form (sum_square.py:44-48 via invert.py:8-12).  Returns (x, v, u)."""
+    x, v, u = x0, x0.clone(), torch.zeros_like(x0)
+    for i in range(max_iter):
+        rho, sigma = rhos[..., i], sigmas[..., i]
+        x = ext_prox(v - u, rho, 1)
+        d = x + u
+        v = denoise(d.contiguous(), torch.as_tensor(sigma, dtype=torch.float32).reshape(-1))
+        u = d - v
+    return x, v, u
 
 
 def psnr(out, gt):

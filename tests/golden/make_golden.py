@@ -508,6 +508,42 @@ def g17_mosaic_jd():
     save("g17_mosaic_jd", **out)
 
 
+def g18_sisr():
+    """sisr closed-form data term (proxfn/fast/sr.py:45-77): the prox alone (scalar and per-image lam, sf = 2 and 3) and the
+    super-resolution example (examples/applications/super_resolution.py) with the FFDNet prior, 3 ADMM iterations."""
+    import scipy.ndimage
+    rng = np.random.RandomState(180)
+    out = {}
+    psf = synthetic.point_spread_function(5, 3.0)                       # HxWx1
+    for sf, (h, w) in ((2, (12, 10)), (3, (8, 9))):
+        gt = synthetic.synth(rng, 2, 3, h * sf, w * sf)
+        blur = np.stack([np.stack([scipy.ndimage.convolve(gt[b, c], psf[..., 0], mode="wrap") for c in range(3)]) for b in range(2)])
+        y = blur[..., ::sf, ::sf].astype("float32")
+        x = dp.Variable()
+        fn = dp.sisr(x, T(y), kernel=psf, sf=sf)
+        v = T(rng.rand(2, 3, h * sf, w * sf).astype("float32"))
+        out.update({f"sf{sf}_y": y, f"sf{sf}_v": v, f"sf{sf}_prox_scalar": fn._prox(v, torch.tensor(0.4), 1),
+                    f"sf{sf}_prox_B": fn._prox(v, torch.tensor([0.2, 0.9]).view(2, 1, 1, 1), 2)})
+    out["psf"] = psf
+    # the example problem
+    gt = synthetic.synth(rng, 1, 3, 32, 40)
+    blur = np.stack([scipy.ndimage.convolve(gt[0, c], psf[..., 0], mode="wrap") for c in range(3)])[None]
+    y = blur[..., ::2, ::2].astype("float32")
+    x0 = np.repeat(np.repeat(y, 2, axis=-2), 2, axis=-1)                  # nearest-neighbour start (the example uses cv2 bicubic)
+    x = dp.Variable()
+    data = dp.sisr(x, T(y), kernel=psf, sf=2)
+    reg = dp.deep_prior(x, denoiser=ColorDen(7))
+    prob = dp.Problem(data + reg)
+    # (rho ~ 1e-4 of the example's log_descent(35, 35) schedule divides the spectrum by I rho: fp32 round-off of either
+    #  implementation is amplified 1e4x; the fixture keeps the x-update well conditioned)
+    _, sigmas = log_descent(35, 35, 3)
+    rhos = torch.tensor([0.6, 0.4, 0.3])
+    with torch.no_grad():
+        st = prob.solve(method="admm", device="cpu", x0=T(x0), rhos=rhos, lams={reg: sigmas}, max_iter=3, return_full_states=True)
+    out.update(sr_y=y, sr_x0=x0, sr_rhos=rhos, sr_sigmas=sigmas, sr_x=st[0], sr_v=st[1][0], sr_u=st[2][0])
+    save("g18_sisr", **out)
+
+
 def g15_csmri():
     """CS-MRI pipeline of the reference's examples (csmri closed-form data term + CustomADMM + gray FFDNet prior):
     dprox/proxfn/fast/csmri.py:8-25, dprox/contrib/csmri.py:156-171, ext_sum_squares routing invert.py:8-12."""
@@ -599,6 +635,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd):
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -455,6 +455,29 @@ def case_mosaic_jd(device, solve=True):
     assert_close(st[1][0].cpu(), g["jd_v"], 2 * TOL, "JD v")
 
 
+def case_sisr(device, solve=True):
+    """G18: closed-form super-resolution data term (dpx_cfft2 + dpx_sisr_update), sf = 2 and 3, and the reference's
+    super-resolution example (sisr + FFDNet prior, ADMM with the data term's own x-update)"""
+    g = load_golden("g18_sisr")
+    for sf in (2, 3):
+        x = dp.Variable()
+        fn = dp.sisr(x, T(g[f"sf{sf}_y"], device), kernel=g["psf"], sf=sf).to(device)
+        v = T(g[f"sf{sf}_v"], device)
+        assert_close(fn._prox(v, torch.tensor(0.4, device=device), 1).cpu(), g[f"sf{sf}_prox_scalar"], TOL, f"sisr sf={sf} scalar lam")
+        assert_close(fn._prox(v, torch.tensor([0.2, 0.9], device=device), 2).cpu(), g[f"sf{sf}_prox_B"], TOL, f"sisr sf={sf} per-image lam")
+    if not solve:
+        return
+    x = dp.Variable()
+    data = dp.sisr(x, T(g["sr_y"], device), kernel=g["psf"], sf=2)
+    reg = dp.deep_prior(x, denoiser=_ffdnet("color", device))
+    prob = dp.Problem(data + reg)
+    with torch.no_grad():
+        st = prob.solve(method="admm", device=device, x0=T(g["sr_x0"], device), rhos=torch.from_numpy(g["sr_rhos"]),
+                        lams={reg: torch.from_numpy(g["sr_sigmas"])}, max_iter=3, return_full_states=True)
+    assert_close(st[0].cpu(), g["sr_x"], TOL, "super-resolution x")
+    assert_close(st[1][0].cpu(), g["sr_v"], TOL, "super-resolution v")
+
+
 def case_csmri(device, solve=True):
     """G15: closed-form csmri data term (native complex FFT + masked update) and CustomADMM on a complex iterate"""
     from dprox.contrib.csmri import CustomADMM

@@ -67,6 +67,10 @@ def test_csmri_custom_admm():
     pc.case_csmri(DEV, solve=False)          # the 4-iteration solve with the 15-layer gray FFDNet runs on the GPU only
 
 
+def test_sisr_super_resolution():
+    pc.case_sisr(DEV, solve=False)
+
+
 def test_mosaic_joint_demosaic_deconv():
     pc.case_mosaic_jd(DEV, solve=False)      # the ADMM + CG + FFDNet solve runs on the GPU only
 

@@ -80,6 +80,10 @@ def test_csmri_custom_admm():
     pc.case_csmri(DEV)
 
 
+def test_sisr_super_resolution():
+    pc.case_sisr(DEV)
+
+
 def test_mosaic_joint_demosaic_deconv():
     pc.case_mosaic_jd(DEV)
 

@@ -260,6 +260,21 @@ def test_g17_mosaic_jd():
     assert_close(st[0], g["jd_x"], 1e-5); assert_close(st[1][0], g["jd_v"], 1e-5); assert_close(st[2][0], g["jd_u"], 5e-5)
 
 
+def test_g18_sisr():
+    g = load_golden("g18_sisr")
+    k = T(g["psf"][..., 0])[None, None]
+    for sf in (2, 3):
+        y, v = T(g[f"sf{sf}_y"]), T(g[f"sf{sf}_v"])
+        assert_close(O.sisr_prox(v, torch.tensor(0.4), 1, y, k, sf), g[f"sf{sf}_prox_scalar"], 2e-6)
+        assert_close(O.sisr_prox(v, torch.tensor([0.2, 0.9]).view(2, 1, 1, 1), 2, y, k, sf), g[f"sf{sf}_prox_B"], 2e-6)
+    den = O.FFDNetOracle(O.ffdnet_weights(7))
+    y = T(g["sr_y"])
+    with torch.no_grad():
+        x, v, u = O.admm_ext_prior(T(g["sr_x0"]), lambda b, rho, n: O.sisr_prox(b, rho, n, y, k, 2).float(), den, T(g["sr_rhos"]),
+                                   T(g["sr_sigmas"]), 3)
+    assert_close(x, g["sr_x"], 1e-5); assert_close(v, g["sr_v"], 1e-5); assert_close(u, g["sr_u"], 5e-5)
+
+
 def test_g15_csmri():
     """csmri closed-form prox + CustomADMM with the gray FFDNet prior (complex iterate)."""
     g = load_golden("g15_csmri")
