@@ -103,6 +103,23 @@ __global__ void k_table_from_full(const float* __restrict__ full, float* __restr
     }
   }
 }
+// complex OTF given on the full grid [C][H][W] (conv_doe: transform of a padded, centred PSF) -> half-spectrum table
+__global__ void k_otf_from_full(const float2* __restrict__ full, float2* __restrict__ tab, int C, int H, int W, int tiled) {
+  const int Ws = (W + 1) / 2;
+  const long nmain = (long)C * H * Ws, total = nmain + ((W % 2 == 0) ? (long)C * H : 0);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i < nmain) {
+      const int l = (int)(i % Ws);
+      const long r = i / Ws;
+      const int k = (int)(r % H), c = (int)(r / H);
+      tab[(size_t)c * H * Ws + spec_main_index(tiled, H, Ws, k, l)] = full[((size_t)c * H + k) * W + l];
+    } else {
+      const long r = i - nmain;
+      const int k = (int)(r % H), c = (int)(r / H);
+      tab[i] = full[((size_t)c * H + k) * W + W / 2];
+    }
+  }
+}
 // dd = (d0 + c0, d1 + c1) interleaved; element order is irrelevant (same opaque layout in and out)
 __global__ void k_denominator_pack(const float* __restrict__ d0, float c0, const float* __restrict__ d1, float c1,
                                    float2* __restrict__ dd, long n) {
@@ -125,6 +142,12 @@ extern "C" int dpx_table_from_full(const float* full, void* table, int C, int H,
   DPX_LAUNCH("k_table_from_full", k_table_from_full, dim3(grid_for((long)table_elems(C, H, W), 256, 4096)), dim3(256), 0,
              (hipStream_t)stream, full, (float*)table, C, H, W, pow2_path_available(H, W) ? 1 : 0);
   return launch_status("dpx_table_from_full");
+}
+extern "C" int dpx_otf_from_full(const void* full, void* otf, int C, int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(otf && full && C > 0 && H > 0 && W > 0, "dpx_otf_from_full: bad arguments");
+  DPX_LAUNCH("k_otf_from_full", k_otf_from_full, dim3(grid_for((long)table_elems(C, H, W), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+             (const float2*)full, (float2*)otf, C, H, W, pow2_path_available(H, W) ? 1 : 0);
+  return launch_status("dpx_otf_from_full");
 }
 extern "C" size_t dpx_denominator_bytes(int C, int H, int W) { return table_elems(C, H, W) * sizeof(float2); }
 extern "C" int dpx_denominator_pack(const void* d0, float c0, const void* d1, float c1, void* dd, int C, int H, int W,

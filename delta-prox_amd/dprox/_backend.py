@@ -55,6 +55,7 @@ SIGNATURES = {
     "dpx_data_spectrum": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_table_to_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dpx_table_from_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dpx_otf_from_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dpx_denominator_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_denominator_pack": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dpx_fourier_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

@@ -120,6 +120,15 @@ def diag_to_full(diag, C, H, W):
     return full
 
 
+def otf_from_full(full, C, H, W):
+    """complex64 OTF on the full grid [.., C, H, W] -> opaque half-spectrum OTF table for fft_conv"""
+    f = full.reshape(-1, C, H, W)[0].to(torch.complex64).contiguous()
+    require(f, dtype=torch.complex64, what="full OTF")
+    tab = _bytes(be.lib().query("dpx_otf_bytes", C, H, W), f.device)
+    be.lib().call("dpx_otf_from_full", ptr(f), ptr(tab), C, H, W, be.stream())
+    return tab
+
+
 def diag_from_full(full, C, H, W, device):
     """full-spectrum real diagonal [.., C, H, W] -> opaque table (user-supplied BlackBox diagonals)"""
     f = torch.as_tensor(full).real.float().reshape(-1, C, H, W)[0].contiguous().to(device)

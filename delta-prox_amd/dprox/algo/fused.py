@@ -25,7 +25,7 @@ from tqdm import tqdm
 from .. import _backend as be
 from .. import _ops as ops
 from . import autodiff
-from ..linop import Constant, Variable, conv, grad
+from ..linop import Constant, Variable, conv, conv_doe, grad
 from ..linop import sum as lin_sum
 from ..proxfn import deep_prior, least_squares, nonneg, norm1, norm2, sum_squares
 from ..proxfn.pnp.denoisers import Denoiser2D, FFDNetColorDenoiser, FFDNetDenoiser
@@ -48,7 +48,7 @@ def _omega_ok(fn):
         op = lin[0]
     if _is_var(op):
         return True
-    return type(op) is conv and _is_var(op.input_nodes[0])
+    return type(op) in (conv, conv_doe) and _is_var(op.input_nodes[0])
 
 
 def _omega_conv(fn):
@@ -56,7 +56,7 @@ def _omega_conv(fn):
     op = fn.linop
     if isinstance(op, lin_sum):
         op = [k for k in op.input_nodes if not isinstance(k, Constant)][0]
-    return op if type(op) is conv else None
+    return op if type(op) in (conv, conv_doe) else None
 
 
 def _psi_linop_code(op):
@@ -140,7 +140,8 @@ class FusedADMM:
         # data spectrum F(sum_Omega K^T b): fp64 transform, kept in the Fourier domain, recomputed only when an
         # offset (the observation b) changes
         offs = [fn.offset for fn in s.omega_fns]
-        fk_key = (tuple(x0.shape), str(dev)) + tuple((id(o), o._version) if o is not None else None for o in offs)
+        fk_key = (tuple(x0.shape), str(dev)) + tuple((id(o), o._version) if o is not None else None for o in offs) + \
+            tuple(fn.linop.tables_version() for fn in s.omega_fns)
         cached = getattr(s, "_fk_cache", None)
         if cached is not None and cached[0] == fk_key:
             FK = cached[1]

@@ -80,3 +80,85 @@ class grad(conv):
 
     def norm_bound(self, input_mags):
         return 2.0 * input_mags[0]
+
+
+def _doe_padded(psf, shape):
+    """psf2otf2's spatial part (conv.py:59-78): zero-pad the [1,C,fh,fw] PSF to the image size with the reference's
+    split of the padding (computed from the HEIGHT difference for both axes), then ifftshift over ALL dims -- which
+    also rotates the channel axis (C = 3: by one), a quirk kept for parity."""
+    import torch.nn.functional as F
+    _, _, fh, fw = psf.shape
+    H = shape[2]
+    if H != fh:
+        pad = (H - fh) / 2
+        if (H - fh) % 2 != 0:
+            pt = pl = int(np.ceil(pad))
+            pb = pr = int(np.floor(pad))
+        else:
+            pt = pl = int(pad) + 1
+            pb = pr = int(pad) - 1
+        psf = F.pad(psf, [pl, pr, pt, pb], mode="constant")
+    if tuple(psf.shape[-2:]) != tuple(shape[-2:]):
+        raise ValueError(f"conv_doe: a {fh}x{fw} PSF padded like the reference gives {tuple(psf.shape[-2:])}, not the image size "
+                         f"{tuple(shape[-2:])} (the reference needs H - fh == W - fw)")
+    return torch.fft.ifftshift(psf)
+
+
+class conv_doe(LinOp):
+    """Circular convolution with a PSF given as a tensor / Placeholder [1,C,fh,fw] whose OTF is rebuilt on the device
+    whenever the PSF changes (reference dprox/linop/conv.py:81-156; end-to-end optics, README.md:93-116).
+    The transform of the padded PSF is ``dpx_cfft2``; forward / adjoint are the same ``dpx_fft_conv`` pipeline as ``conv``."""
+
+    def __init__(self, arg, psf, circular=True):
+        super().__init__([arg])
+        if not circular:
+            raise NotImplementedError("conv_doe(circular=False) (linearised convolution by 2x padding) is not built for the HIP path")
+        from .leaf import Placeholder
+        self._psf = psf
+        self.circular = circular
+        self.cache = None
+        if isinstance(psf, Placeholder):
+            self.psf = None
+            self._psf.change(lambda val: setattr(self, "psf", val))
+        else:
+            from ..utils import to_torch_tensor
+            self.psf = to_torch_tensor(psf, batch=True).float()
+
+    def _full_otf(self, shape, device):
+        psf = self.psf
+        if psf is None:
+            raise ValueError("conv_doe: the PSF placeholder has no value yet")
+        key = (psf.data_ptr(), psf._version, tuple(shape[1:]), str(device))
+        if self.cache is None or self.cache[0] != key:
+            _, C, H, W = shape
+            P = _doe_padded(psf.detach().float().to(device), shape).expand(1, C, H, W).contiguous()
+            full = ops.cfft2(P, inverse=False, centred=False, ortho=False)
+            self.cache = (key, full, ops.otf_from_full(full, C, H, W))
+        return self.cache[1], self.cache[2]
+
+    def _tables(self, shape, device):
+        return self._full_otf(shape, device)[1]
+
+    def _own_tables_version(self):
+        return None if self.psf is None else (self.psf.data_ptr(), self.psf._version)
+
+    def forward(self, input, **kwargs):
+        return ops.fft_conv(input, self._tables(input.shape, input.device), conj=False)
+
+    def adjoint(self, input, **kwargs):
+        return ops.fft_conv(input, self._tables(input.shape, input.device), conj=True)
+
+    def is_diag(self, freq=False):
+        return freq and self.input_nodes[0].is_diag(freq)
+
+    def get_diag(self, x, freq=False):
+        assert freq
+        full, _ = self._full_otf(x.shape, x.device)
+        return ops.clincomb([(1.0, ops.cplx_mul(full, full, conj_a=True))], out_complex=False)      # |OTF|^2, [1,C,H,W]
+
+    def accumulate_diag(self, diag, weight, C, H, W):
+        tab = ops.diag_from_full(self.get_diag(torch.empty(1, C, H, W, device=diag.device), True), C, H, W, diag.device)
+        return ops.lincomb([(1.0, diag.reshape(1, -1)), (float(weight), tab.reshape(1, -1))]).reshape(-1)
+
+    def norm_bound(self, input_mags):
+        return float(self.psf.abs().max()) * input_mags[0]

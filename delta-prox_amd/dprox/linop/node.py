@@ -54,6 +54,15 @@ class LinOp(nn.Module):
     def norm_bound(self, input_mags):
         return NotImplemented
 
+    def tables_version(self):
+        """changes whenever a value this operator's cached tables depend on changes (conv_doe: the PSF); the solvers key
+        their denominator / data-spectrum caches on it"""
+        own = self._own_tables_version()
+        return (own,) + tuple(n.tables_version() for n in self.input_nodes)
+
+    def _own_tables_version(self):
+        return None
+
     # ---- graph queries ------------------------------------------------------------------------
     @property
     def device(self):

@@ -17,7 +17,7 @@ import torch.nn as nn
 from .. import _backend as be
 from .. import _ops as ops
 from ..linalg import LinearSolveConfig, linear_solve
-from ..linop import BlackBox, LinOp, Variable, adjoint, conv, eval, scale, vstack
+from ..linop import BlackBox, LinOp, Variable, adjoint, conv, conv_doe, eval, scale, vstack
 from ..linop import sum as lin_sum
 from .core import ProxFn
 
@@ -76,7 +76,7 @@ class ext_sum_squares(sum_squares):
 def _gram_diag(linop, shape, device, freq):
     if isinstance(linop, Variable):
         return None, 1.0
-    if isinstance(linop, conv):
+    if isinstance(linop, (conv, conv_doe)):
         if not freq:
             raise ValueError("conv is only diagonal in the frequency domain")
         _, C, H, W = shape
@@ -155,7 +155,7 @@ class least_squares(ProxFn):
 
     def diag_tables(self, shape, device, freq):
         dyn = any(isinstance(fn.linop, BlackBox) for fn in list(self.quad_fns) + list(self.other_fns))
-        key = (tuple(shape[1:]), str(device), freq)
+        key = (tuple(shape[1:]), str(device), freq) + tuple(fn.linop.tables_version() for fn in list(self.quad_fns) + list(self.other_fns))
         if self._diag_cache is not None and self._diag_cache[0] == key and not dyn:
             return self._diag_cache[1]
 

@@ -88,6 +88,9 @@ int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, void* spec_
  *   dpx_denominator_pack          : dd = interleaved (d0 + c0, d1 + c1) for dpx_fourier_solve               */
 int dpx_table_to_full(const void* table, float* full, int C, int H, int W, dpx_stream_t stream);
 int dpx_table_from_full(const float* full, void* table, int C, int H, int W, dpx_stream_t stream);
+/* OTF table from a complex OTF given on the full [C][H][W] grid (Hermitian: the transform of a real kernel image):
+ * conv_doe's per-call PSF -> OTF (dprox/linop/conv.py:59-80, psf2otf2), the transform itself being dpx_cfft2.   */
+int dpx_otf_from_full(const void* full, void* otf, int C, int H, int W, dpx_stream_t stream);
 size_t dpx_denominator_bytes(int C, int H, int W);
 int dpx_denominator_pack(const void* d0, float c0, const void* d1, float c1, void* dd, int C, int H, int W,
                          dpx_stream_t stream);

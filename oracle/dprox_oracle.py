@@ -31,7 +31,7 @@ __all__ = [
     "soft_threshold", "prox", "LeastSquares", "cg", "bdot", "LinearSolveConfig",
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
     "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
-    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior",
+    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior", "doe_otf", "lin_conv_doe",
 ]
 
 
@@ -207,6 +207,35 @@ def lin_scale(s: float, inner: Lin) -> Lin:
         return d * torch.conj(d)
     return Lin(lambda x: inner.fwd(x) * s, lambda y: inner.adj(y * s), diag,
                inner.gram_diag_space, inner.gram_diag_freq)
+
+
+def doe_otf(psf: torch.Tensor, shape) -> torch.Tensor:
+    """psf2otf2 -- linop/conv.py:59-78 (padding split from the height difference, ifftshift over all dims, fft2)."""
+    _, _, fh, fw = psf.shape
+    if shape[2] != fh:
+        pad = (shape[2] - fh) / 2
+        if (shape[2] - fh) % 2 != 0:
+            pt = pl = int(np.ceil(pad)); pb = pr = int(np.floor(pad))
+        else:
+            pt = pl = int(pad) + 1; pb = pr = int(pad) - 1
+        psf = torch.nn.functional.pad(psf, [pl, pr, pt, pb], mode="constant")
+    return torch.fft.fft2(torch.fft.ifftshift(psf))
+
+
+def lin_conv_doe(psf) -> "Lin":
+    """conv_doe -- linop/conv.py:81-148: forward real(ifftn(otf * fftn(x))), adjoint with conj(otf), diag |otf|^2."""
+    psf = torch.as_tensor(psf).float()
+
+    def fwd(x):
+        return torch.real(torch.fft.ifftn(doe_otf(psf, x.shape) * torch.fft.fftn(x, dim=[-2, -1]), dim=[-2, -1])).float()
+
+    def adj(x):
+        return torch.real(torch.fft.ifftn(torch.conj(doe_otf(psf, x.shape)) * torch.fft.fftn(x, dim=[-2, -1]), dim=[-2, -1])).float()
+
+    def diag(x, freq):
+        o = doe_otf(psf, x.shape)
+        return torch.abs(torch.conj(o) * o)
+    return Lin(fwd, adj, diag, False, True)        # is_diag(freq=True) only: conv.py:136-137
 
 
 def bayer_mask(H, W) -> torch.Tensor:

@@ -544,6 +544,37 @@ def g18_sisr():
     save("g18_sisr", **out)
 
 
+def g19_conv_doe():
+    """conv_doe (linop/conv.py:81-156): PSF given as a tensor / Placeholder, OTF rebuilt per value through psf2otf2 (incl. its
+    padding split and the all-dims ifftshift); forward / adjoint / get_diag and an ADMM TV solve with the PSF in a Placeholder."""
+    from dprox.linop.conv import conv_doe
+    rng = np.random.RandomState(190)
+    out = {}
+    for tag, (C, H, W, f) in (("odd", (3, 24, 24, 9)), ("even", (1, 20, 24, 8))):
+        psf = rng.rand(1, C, f, f + (W - H)).astype("float32")
+        psf /= psf.sum(axis=(-2, -1), keepdims=True)
+        x = T(rng.rand(2, C, H, W).astype("float32"))
+        op = conv_doe(dp.Variable(), T(psf))
+        with torch.no_grad():
+            out.update({f"{tag}_psf": psf, f"{tag}_x": x, f"{tag}_fwd": op.forward(x), f"{tag}_adj": op.adjoint(x), f"{tag}_diag": op.get_diag(x, freq=True)})
+    gt, _, _ = synthetic.deconv_case(2, 3, 32, 32, seed=191)
+    psf = rng.rand(1, 3, 7, 7).astype("float32") ** 3
+    psf /= psf.sum(axis=(-2, -1), keepdims=True)
+    xv = dp.Variable()
+    P, Y = dp.Placeholder(), dp.Placeholder()
+    opb = conv_doe(dp.Variable(), T(psf))
+    with torch.no_grad():
+        y = opb.forward(T(gt)) + T((rng.randn(2, 3, 32, 32) * 0.01).astype("float32"))
+    n0, n1 = dp.norm1(dp.grad(xv, dim=0)), dp.norm1(dp.grad(xv, dim=1))
+    fns = dp.sum_squares(conv_doe(xv, P, circular=True), Y) + n0 + n1     # conv_doe registers its watcher on P here
+    P.value, Y.value = T(psf), y            # ... the values must exist before compile (CompGraph reads them)
+    solver = dp.compile(fns, method="admm", device="cpu")
+    with torch.no_grad():
+        st = solver.solve(x0=y, rhos=0.2, lams=0.01, max_iter=8, return_full_states=True)
+    out.update(tv_psf=psf, tv_y=y, tv_x=st[0], tv_v0=st[1][0], tv_u0=st[2][0])
+    save("g19_conv_doe", **out)
+
+
 def g15_csmri():
     """CS-MRI pipeline of the reference's examples (csmri closed-form data term + CustomADMM + gray FFDNet prior):
     dprox/proxfn/fast/csmri.py:8-25, dprox/contrib/csmri.py:156-171, ext_sum_squares routing invert.py:8-12."""
@@ -635,6 +666,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr):
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -455,6 +455,32 @@ def case_mosaic_jd(device, solve=True):
     assert_close(st[1][0].cpu(), g["jd_v"], 2 * TOL, "JD v")
 
 
+def case_conv_doe(device):
+    """G19: conv_doe -- OTF rebuilt on the device from the PSF value (dpx_cfft2 + dpx_otf_from_full), placeholder-driven,
+    through the fused ADMM path"""
+    g = load_golden("g19_conv_doe")
+    for tag in ("odd", "even"):
+        op = dp.conv_doe(dp.Variable(), T(g[f"{tag}_psf"], device)).to(device)
+        x = T(g[f"{tag}_x"], device)
+        assert_close(op.forward(x).cpu(), g[f"{tag}_fwd"], TOL, f"conv_doe {tag} forward")
+        assert_close(op.adjoint(x).cpu(), g[f"{tag}_adj"], TOL, f"conv_doe {tag} adjoint")
+        assert_close(op.get_diag(x, freq=True).cpu(), g[f"{tag}_diag"], TOL, f"conv_doe {tag} |OTF|^2")
+    xv = dp.Variable()
+    P, Y = dp.Placeholder(), dp.Placeholder()
+    n0, n1 = dp.norm1(dp.grad(xv, dim=0)), dp.norm1(dp.grad(xv, dim=1))
+    fns = dp.sum_squares(dp.conv_doe(xv, P, circular=True), Y) + n0 + n1
+    y = T(g["tv_y"], device)
+    P.value, Y.value = T(g["tv_psf"], device), y
+    solver = dp.compile(fns, method="admm", device=device)
+    st = solver.solve(x0=y, rhos=0.2, lams=0.01, max_iter=8, return_full_states=True)
+    assert solver.last_path == "fused"
+    assert_close(st[0].cpu(), g["tv_x"], TOL, "conv_doe TV x")
+    # a new PSF value invalidates the OTF
+    P.value = T(g["tv_psf"], device).flip(-1).contiguous()
+    x2 = solver.solve(x0=y, rhos=0.2, lams=0.01, max_iter=8)
+    assert rel_l2(x2.cpu(), g["tv_x"]) > 1e-3
+
+
 def case_sisr(device, solve=True):
     """G18: closed-form super-resolution data term (dpx_cfft2 + dpx_sisr_update), sf = 2 and 3, and the reference's
     super-resolution example (sisr + FFDNet prior, ADMM with the data term's own x-update)"""

@@ -80,6 +80,10 @@ def test_csmri_custom_admm():
     pc.case_csmri(DEV)
 
 
+def test_conv_doe():
+    pc.case_conv_doe(DEV)
+
+
 def test_sisr_super_resolution():
     pc.case_sisr(DEV)
 

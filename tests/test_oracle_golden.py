@@ -275,6 +275,19 @@ def test_g18_sisr():
     assert_close(x, g["sr_x"], 1e-5); assert_close(v, g["sr_v"], 1e-5); assert_close(u, g["sr_u"], 5e-5)
 
 
+def test_g19_conv_doe():
+    g = load_golden("g19_conv_doe")
+    for tag in ("odd", "even"):
+        lin = O.lin_conv_doe(g[f"{tag}_psf"])
+        x = T(g[f"{tag}_x"])
+        assert_close(lin.fwd(x), g[f"{tag}_fwd"], 1e-6); assert_close(lin.adj(x), g[f"{tag}_adj"], 1e-6)
+        assert_close(lin.diag(x, True), g[f"{tag}_diag"], 1e-6)
+    y = T(g["tv_y"])
+    n0, n1 = O.norm1(O.lin_grad(0)), O.norm1(O.lin_grad(1))
+    st = O.solve([O.sum_squares(O.lin_conv_doe(g["tv_psf"]), b=y), n0, n1], "admm", x0=y, rhos=0.2, lams=0.01, max_iter=8, return_full_states=True)
+    assert_close(st[0], g["tv_x"], 1e-5); assert_close(st[1][0], g["tv_v0"], 1e-5)
+
+
 def test_g15_csmri():
     """csmri closed-form prox + CustomADMM with the gray FFDNet prior (complex iterate)."""
     g = load_golden("g15_csmri")
