@@ -148,22 +148,24 @@ __global__ void __launch_bounds__(256) k_ffd_sigma_grad(const float* __restrict_
   if (threadIdx.x == 0) gs[b] = sh[0];
 }
 
-// NP channel pairs x 9 taps, fully unrolled; the LDS fragments of step k+1 are fetched while step k multiplies
-template <int MT, int NP>
+// NP channel pairs x NTAP taps (9: 3x3 kernel, 1: 1x1 kernel = centre tap only), fully unrolled; the LDS fragments of
+// step k+1 are fetched while step k multiplies
+template <int MT, int NP, int NTAP = 9>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __restrict__ sin_b, const float* __restrict__ sw_b) {
-  constexpr int M32 = MT * 32, NS = NP * 9;
+  constexpr int M32 = MT * 32, NS = NP * NTAP;
+  constexpr int T0 = NTAP == 9 ? 0 : 4;                       // first tap index in the 3x3 stencil (1x1: the centre)
   float a_cur[MT], b_cur[2];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) a_cur[mt] = sw_b[mt * 32];
-  b_cur[0] = sin_b[0];
-  b_cur[1] = sin_b[FFD_LDW];
+  b_cur[0] = sin_b[(T0 / 3) * FFD_LDW + T0 % 3];
+  b_cur[1] = sin_b[(T0 / 3 + 1) * FFD_LDW + T0 % 3];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     float a_nxt[MT], b_nxt[2];
     if (k + 1 < NS) {
-      const int cp = (k + 1) / 9, tap = (k + 1) % 9, dy = tap / 3, dx = tap % 3;
+      const int cp = (k + 1) / NTAP, tw = (k + 1) % NTAP, tap = T0 + tw, dy = tap / 3, dx = tap % 3;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = sw_b[(cp * 9 + tap) * 2 * M32 + mt * 32];
+      for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = sw_b[(cp * NTAP + tw) * 2 * M32 + mt * 32];
       b_nxt[0] = sin_b[(2 * cp * FFD_ROWS + dy) * FFD_LDW + dx];
       b_nxt[1] = sin_b[(2 * cp * FFD_ROWS + dy + 1) * FFD_LDW + dx];
     }
@@ -184,21 +186,26 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __
 // in [B][Cin][H2][W2] (Cin even), out [B][Cout][H2][W2]; wpk = packed layer (see layer_floats)
 // MASKED: the result is stored as out[.] * [mask[.] > 0] (backward through the ReLU that produced `mask`, the activation
 // at the OUTPUT position of this transposed layer, fused into the epilogue)
-template <int MT, bool RELU, bool MASKED = false>
+// NTAP = 9: 3x3 / pad 1; NTAP = 1: 1x1 (stride-2 and transposed 2x2 convolutions are 1x1 convolutions around a
+// space-to-depth / depth-to-space rearrangement).  blockIdx.z selects a block of MT*32 output channels (layers wider than
+// 96 channels: DRUNet), each with its own packed weight block.  RES: out = conv + res (residual blocks).
+template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false>
 __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x,
                                                        const float* __restrict__ mask) {
   constexpr int M32 = MT * 32;
   __shared__ float s_in[2 * FFD_CK * FFD_ROWS * FFD_LDW];                              // 2 x [ch][row][col]
-  __shared__ __attribute__((aligned(16))) float s_w[2 * (FFD_CK / 2) * 9 * 2 * M32];  // 2 x [pair][tap][half][cout]
+  __shared__ __attribute__((aligned(16))) float s_w[2 * (FFD_CK / 2) * NTAP * 2 * M32];  // 2 x [pair][tap][half][cout]
+  const int co0 = blockIdx.z * M32;                                                    // first output channel of this block
+  wpk += (size_t)blockIdx.z * ((size_t)(Cin / 2) * NTAP * 2 * M32 + M32 + FFD_ZPAD);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int y0 = ty * FFD_TH, x0 = tx * FFD_TW;
   const int j = lane & 31, half = lane >> 5;
   const float* inb = in + (size_t)b * Cin * H2 * W2;
-  const float* maskb = MASKED ? mask + (size_t)b * Cout * H2 * W2 : nullptr;
-  const float* bias = wpk + (size_t)(Cin / 2) * 9 * 2 * M32;
+  const float* maskb = (MASKED || RES) ? mask + (size_t)b * Cout * H2 * W2 : nullptr;   // RES: `mask` carries the residual input
+  const float* bias = wpk + (size_t)(Cin / 2) * NTAP * 2 * M32;
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -217,10 +224,10 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
   constexpr bool DMA = true;
   constexpr int NPI = (FFD_CK * FFD_ROWS * FFD_LDW + 63) / 64;             // dword pieces of one input chunk (45)
   constexpr int NPW = (NPI + 3) / 4;                                       // per wave
-  constexpr int NWP = ((FFD_CK / 2) * 9 * 2 * M32) / 256;                  // 1 KB pieces of one weight chunk (27 / 18 / 9)
-  static_assert(((FFD_CK / 2) * 9 * 2 * M32) % 256 == 0, "weight chunk must be whole 1 KB pieces");
+  constexpr int NWP = ((FFD_CK / 2) * NTAP * 2 * M32) / 256;               // 1 KB pieces of one weight chunk (27 / 18 / 9; 3 / 2 / 1)
+  static_assert(((FFD_CK / 2) * NTAP * 2 * M32) % 256 == 0, "weight chunk must be whole 1 KB pieces");
   constexpr int NI = (FFD_CK * FFD_ROWS * 34 + 255) / 256;                 // input-tile elements per thread (register path)
-  constexpr int NW4 = ((FFD_CK / 2) * 9 * 2 * M32 / 4 + 255) / 256;        // weight float4s per thread (register path)
+  constexpr int NW4 = ((FFD_CK / 2) * NTAP * 2 * M32 / 4 + 255) / 256;     // weight float4s per thread (register path)
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   unsigned ioff[DMA ? NPW : 1];            // (channel << 28) | element offset inside the chunk's channel block; ~0u = zero word
   if constexpr (DMA) {
@@ -248,8 +255,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
           dpx_glds4(src, si + (wv + 4 * k) * 64);
         }
       }
-      const float* wsrc = wpk + (size_t)(c0 / 2) * 9 * 2 * M32 + lane * 4;
-      float* sw = s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32);
+      const float* wsrc = wpk + (size_t)(c0 / 2) * NTAP * 2 * M32 + lane * 4;
+      float* sw = s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32);
       for (int i = wv; i < NWP; i += 4) dpx_glds16(wsrc + i * 256, sw + i * 256);
     }
   };
@@ -270,8 +277,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
         }
         in_reg[e] = v;
       }
-      const float4* wsrc = (const float4*)(wpk + (size_t)(c0 / 2) * 9 * 2 * M32);
-      const int n4 = (nch / 2) * 9 * 2 * M32 / 4;
+      const float4* wsrc = (const float4*)(wpk + (size_t)(c0 / 2) * NTAP * 2 * M32);
+      const int n4 = (nch / 2) * NTAP * 2 * M32 / 4;
 #pragma unroll
       for (int e = 0; e < NW4; ++e) {
         const int i = tid + 256 * e;
@@ -282,7 +289,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
   auto commit = [&](int buf) {
     if constexpr (!DMA) {
       float* si = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW);
-      float4* sw = (float4*)(s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32));
+      float4* sw = (float4*)(s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32));
 #pragma unroll
       for (int e = 0; e < NI; ++e) {
         const int i = tid + 256 * e;
@@ -292,7 +299,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
 #pragma unroll
       for (int e = 0; e < NW4; ++e) {
         const int i = tid + 256 * e;
-        if (i < (FFD_CK / 2) * 9 * 2 * M32 / 4) sw[i] = w_reg[e];
+        if (i < (FFD_CK / 2) * NTAP * 2 * M32 / 4) sw[i] = w_reg[e];
       }
     }
   };
@@ -313,8 +320,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
       else fetch(c0 + FFD_CK);
     }
     const float* sin_b = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW) + (half * FFD_ROWS + 2 * wave) * FFD_LDW + j;
-    const float* sw_b = s_w + buf * ((FFD_CK / 2) * 9 * 2 * M32) + half * M32 + j;
-    for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * 9 * 2 * M32);
+    const float* sw_b = s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32) + half * M32 + j;
+    for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1, NTAP>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * NTAP * 2 * M32);
     if (more) {
       if constexpr (DMA) dpx_wait_vm<0>();
       else commit(buf ^ 1);
@@ -331,12 +338,13 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
       const int yy = y0 + 2 * wave + nt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[mt][nt][r] + bias[co];
+        const int cl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, co = co0 + cl;
+        float v = acc[mt][nt][r] + bias[cl];
         if (RELU) v = fmaxf(v, 0.f);
         if (co < Cout && yy < H2 && xx < W2) {
           const size_t idx = ((size_t)co * H2 + yy) * W2 + xx;
           if (MASKED) v = maskb[idx] > 0.f ? v : 0.f;
+          if (RES) v += maskb[idx];
           outb[idx] = v;
         }
       }
@@ -663,4 +671,130 @@ extern "C" int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, fl
                in_nc, H, W, H2, W2, Cp);
   if (gsigma) DPX_LAUNCH("k_ffd_sigma_grad", k_ffd_sigma_grad, dim3(B), dim3(256), 0, s, g_a0, gsigma, in_nc, H2, W2, Cp);
   return launch_status("dpx_ffdnet_backward");
+}
+
+// ---- generic convolution layers on the same kernel (DRUNet-style residual U-Nets behind deep_prior) ----------------------
+namespace dpx {
+static int conv_block_width(int cout) {                  // output channels per workgroup (blockIdx.z blocks)
+  if (cout <= 96) return mtiles(cout) * 32;
+  return (cout % 64 == 0) ? 64 : 96;
+}
+static size_t conv_block_floats(int cin, int m32, int taps) { return (size_t)(pad_even(cin) / 2) * taps * 2 * m32 + m32 + FFD_ZPAD; }
+
+// w [cout][cin][taps] -> blocks of m32 output channels, each [cin/2][taps][2][m32] + bias[m32] + zero pad
+__global__ void k_conv_pack(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ dst, int cin, int cout, int taps,
+                            int m32, int nblk) {
+  const long per = (long)(((cin + 1) & ~1) / 2) * taps * 2 * m32, blk = per + m32 + FFD_ZPAD;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < blk * nblk; i += (long)gridDim.x * blockDim.x) {
+    const int kb = (int)(i / blk);
+    const long r0 = i - (long)kb * blk;
+    float v = 0.f;
+    if (r0 < per) {
+      const int cl = (int)(r0 % m32);
+      long r = r0 / m32;
+      const int half = (int)(r % 2);
+      r /= 2;
+      const int tap = (int)(r % taps), cp = (int)(r / taps);
+      const int ci = 2 * cp + half, co = kb * m32 + cl;
+      if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + tap];
+    } else if (r0 < per + m32) {
+      const int co = kb * m32 + (int)(r0 - per);
+      if (b && co < cout) v = b[co];
+    }
+    dst[i] = v;
+  }
+}
+
+__global__ void k_space_to_depth(const float* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W) {
+  const int H2 = H / 2, W2 = W / 2;
+  const long total = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x2 = (int)(i % W2);
+    long r = i / W2;
+    const int y2 = (int)(r % H2);
+    r /= H2;
+    const int ch = (int)(r % (4 * C)), b = (int)(r / (4 * C));
+    const int c = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1;
+    y[i] = x[(((long)b * C + c) * H + 2 * y2 + dy) * W + 2 * x2 + dx];
+  }
+}
+__global__ void k_depth_to_space(const float* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * C * Ho * Wo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % Wo);
+    long r = i / Wo;
+    const int yy = (int)(r % Ho);
+    r /= Ho;
+    const int c = (int)(r % C), b = (int)(r / C);
+    y[i] = x[(((long)b * 4 * C + c * 4 + (yy & 1) * 2 + (xx & 1)) * H + (yy >> 1)) * W + (xx >> 1)];
+  }
+}
+
+template <int MT, int NTAP>
+static void launch_conv_generic(int relu, const float* in, float* out, const float* wpk, const float* res, int Cin, int Cout, int nblk, int B,
+                                int H, int W, hipStream_t s) {
+  const int tx = (W + FFD_TW - 1) / FFD_TW, ty = (H + FFD_TH - 1) / FFD_TH;
+  const dim3 grid(tx * ty, B, nblk);
+  if (res)
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, true>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, res);
+  else if (relu)
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, true, false, NTAP, false>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+  else
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, false>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+}
+}  // namespace dpx
+
+extern "C" size_t dpx_conv_packed_bytes(int cin, int cout, int taps) {
+  if (cin <= 0 || cout <= 0 || (taps != 9 && taps != 1)) return 0;
+  const int m32 = conv_block_width(cout), nblk = (cout + m32 - 1) / m32;
+  return (conv_block_floats(cin, m32, taps) * nblk) * sizeof(float) + 1024;
+}
+
+extern "C" int dpx_conv_pack(void* packed, const float* w, const float* b, int cin, int cout, int taps, dpx_stream_t stream) {
+  DPX_REQUIRE(packed && w && cin > 0 && cout > 0 && (taps == 9 || taps == 1), "dpx_conv_pack: bad arguments (taps must be 9 or 1)");
+  const int m32 = conv_block_width(cout), nblk = (cout + m32 - 1) / m32;
+  const long n = (long)conv_block_floats(cin, m32, taps) * nblk;
+  DPX_LAUNCH("k_conv_pack", k_conv_pack, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, b, (float*)packed, cin, cout, taps,
+             m32, nblk);
+  return launch_status("dpx_conv_pack");
+}
+
+extern "C" int dpx_conv2d(const float* in, float* out, const void* packed, const float* res, int relu, int cin, int cout, int taps, int B,
+                          int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(in && out && packed && B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, "dpx_conv2d: bad arguments");
+  DPX_REQUIRE(taps == 9 || taps == 1, "dpx_conv2d: taps must be 9 (3x3, pad 1) or 1 (1x1)");
+  DPX_REQUIRE(cin % 2 == 0, "dpx_conv2d: the input must have an even number of channels (pad with a zero channel), got %d", cin);
+  DPX_REQUIRE(!(res && relu), "dpx_conv2d: residual add and ReLU are not combined (ResBlock: conv-ReLU-conv + x)");
+  const int m32 = conv_block_width(cout), nblk = (cout + m32 - 1) / m32;
+  hipStream_t s = (hipStream_t)stream;
+  const float* wp = (const float*)packed;
+  if (taps == 9) {
+    switch (m32 / 32) {
+      case 1: launch_conv_generic<1, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
+      case 2: launch_conv_generic<2, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
+      default: launch_conv_generic<3, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
+    }
+  } else {
+    switch (m32 / 32) {
+      case 1: launch_conv_generic<1, 1>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
+      case 2: launch_conv_generic<2, 1>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
+      default: launch_conv_generic<3, 1>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
+    }
+  }
+  return launch_status("dpx_conv2d");
+}
+
+extern "C" int dpx_space_to_depth(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "dpx_space_to_depth: even H, W required");
+  DPX_LAUNCH("k_space_to_depth", k_space_to_depth, dim3(grid_for((long)B * C * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, B, C,
+             H, W);
+  return launch_status("dpx_space_to_depth");
+}
+
+extern "C" int dpx_depth_to_space(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "dpx_depth_to_space: bad arguments");
+  DPX_LAUNCH("k_depth_to_space", k_depth_to_space, dim3(grid_for((long)B * C * 4 * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y,
+             B, C, H, W);
+  return launch_status("dpx_depth_to_space");
 }

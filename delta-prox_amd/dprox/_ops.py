@@ -484,6 +484,43 @@ def sisr_update(FR, FB, lam, I, sf):
     return buf[1]
 
 
+def conv_pack(w, b, taps):
+    """w [cout, cin, taps] float32 device tensor (+ optional bias) -> packed blob for conv2d"""
+    require(w, what="conv weight")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    L = be.lib()
+    blob = torch.empty(L.query("dpx_conv_packed_bytes", cin, cout, taps), dtype=torch.uint8, device=w.device)
+    L.call("dpx_conv_pack", ptr(blob), ptr(w), ptr(b), cin, cout, taps, be.stream())
+    return blob
+
+
+def conv2d(x, packed, cout, taps, relu=False, res=None):
+    """stride-1 3x3 (pad 1) / 1x1 convolution on the fp32 matrix cores; optional ReLU or residual add"""
+    require(x, what="conv input")
+    B, C, H, W = _shape4(x)
+    out = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    if res is not None:
+        require(res, what="conv residual")
+    be.lib().call("dpx_conv2d", ptr(x), ptr(out), ptr(packed), ptr(res), int(bool(relu)), C, cout, taps, B, H, W, be.stream())
+    return out
+
+
+def space_to_depth(x):
+    require(x, what="space_to_depth input")
+    B, C, H, W = _shape4(x)
+    y = torch.empty(B, 4 * C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    be.lib().call("dpx_space_to_depth", ptr(x), ptr(y), B, C, H, W, be.stream())
+    return y
+
+
+def depth_to_space(x):
+    require(x, what="depth_to_space input")
+    B, C4, H, W = _shape4(x)
+    y = torch.empty(B, C4 // 4, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    be.lib().call("dpx_depth_to_space", ptr(x), ptr(y), B, C4 // 4, H, W, be.stream())
+    return y
+
+
 def clincomb(terms, out_complex=True):
     """sum_i coef_i * x_i over up to 4 real-fp32 / complex64 tensors of one shape; complex64 result, or its real part
     as fp32 (out_complex=False).  coef_i are python floats."""

@@ -1,2 +1,2 @@
-from .denoisers import Denoiser, Denoiser2D, FFDNet, FFDNetColorDenoiser, FFDNetDenoiser
+from .denoisers import Denoiser, Denoiser2D, DRUNetDenoiser, FFDNet, FFDNetColorDenoiser, FFDNetDenoiser, UNetRes
 from .prior import deep_prior, get_denoiser

@@ -199,3 +199,136 @@ class FFDNetColorDenoiser(Denoiser):
 
     def _denoise(self, x, sigma):
         return self.model(x, sigma)
+
+
+class UNetRes(nn.Module):
+    """DRUNet body (reference models/network_unet.py:67-117): head conv, 3 x (nb ResBlocks + 2x2 stride-2 conv), nb ResBlocks,
+    3 x (2x2 stride-2 transposed conv + nb ResBlocks), tail conv; no biases.  Every convolution runs on the fp32-MFMA
+    kernel behind ``dpx_conv2d`` (ReLU / residual add fused into the epilogue); the strided / transposed 2x2 convolutions
+    are 1x1 convolutions around ``dpx_space_to_depth`` / ``dpx_depth_to_space``.  Parameters keep the reference's
+    state-dict names, so its checkpoints load unchanged.  Inference only (no autograd through this network yet)."""
+
+    def __init__(self, in_nc=1, out_nc=1, nc=(64, 128, 256, 512), nb=4, act_mode="R", downsample_mode="strideconv", upsample_mode="convtranspose"):
+        super().__init__()
+        assert act_mode == "R" and downsample_mode == "strideconv" and upsample_mode == "convtranspose", \
+            "only the DRUNet configuration (ReLU, strideconv, convtranspose) is built for the HIP path"
+        assert in_nc % 2 == 0, "dpx_conv2d needs an even number of input channels (DRUNet: image + sigma map = 4 or 2)"
+        self.in_nc, self.out_nc, self.nc, self.nb = in_nc, out_nc, tuple(nc), nb
+        shapes = {"m_head.weight": (nc[0], in_nc, 3, 3), "m_tail.weight": (out_nc, nc[0], 3, 3)}
+        for lvl in range(3):
+            for i in range(nb):
+                for k in (0, 2):
+                    shapes[f"m_down{lvl + 1}.{i}.res.{k}.weight"] = (nc[lvl], nc[lvl], 3, 3)
+            shapes[f"m_down{lvl + 1}.{nb}.weight"] = (nc[lvl + 1], nc[lvl], 2, 2)
+        for i in range(nb):
+            for k in (0, 2):
+                shapes[f"m_body.{i}.res.{k}.weight"] = (nc[3], nc[3], 3, 3)
+        for lvl in (3, 2, 1):
+            shapes[f"m_up{lvl}.0.weight"] = (nc[lvl], nc[lvl - 1], 2, 2)
+            for i in range(nb):
+                for k in (0, 2):
+                    shapes[f"m_up{lvl}.{i + 1}.res.{k}.weight"] = (nc[lvl - 1], nc[lvl - 1], 3, 3)
+        self._names = list(shapes)
+        self.params = nn.ParameterDict({n.replace(".", "/"): nn.Parameter(torch.zeros(*shp), requires_grad=False) for n, shp in shapes.items()})
+        self._packed = None
+
+    def load_state_dict(self, sd, strict=True):              # reference key names
+        missing = [n for n in self._names if n not in sd]
+        extra = [k for k in sd if k not in self._names]
+        if strict and (missing or extra):
+            raise RuntimeError(f"UNetRes.load_state_dict: missing {missing[:3]}..., unexpected {extra[:3]}...")
+        for n in self._names:
+            if n in sd:
+                self.params[n.replace(".", "/")].data.copy_(torch.as_tensor(sd[n]))
+        self._packed = None
+        return self
+
+    def state_dict(self, *a, **k):
+        return {n: self.params[n.replace(".", "/")].detach().cpu() for n in self._names}
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def _w(self, name):
+        return self.params[name.replace(".", "/")].detach().float()
+
+    def packed(self):
+        if self._packed is None:
+            pk = {}
+            for n in self._names:
+                w = self._w(n)
+                if w.shape[-1] == 3:
+                    pk[n] = (ops.conv_pack(w.reshape(w.shape[0], w.shape[1], 9).contiguous(), None, 9), int(w.shape[0]), 9)
+                elif n.startswith("m_down"):                 # Conv2d 2x2 / stride 2 = space_to_depth + 1x1 over (ci, dy, dx)
+                    co, ci = int(w.shape[0]), int(w.shape[1])
+                    pk[n] = (ops.conv_pack(w.reshape(co, ci * 4, 1).contiguous(), None, 1), co, 1)
+                else:                                        # ConvTranspose2d [ci, co, 2, 2] = 1x1 to (co, dy, dx) + depth_to_space
+                    ci, co = int(w.shape[0]), int(w.shape[1])
+                    pk[n] = (ops.conv_pack(w.permute(1, 2, 3, 0).reshape(co * 4, ci, 1).contiguous(), None, 1), co * 4, 1)
+            self._packed = pk
+        return self._packed
+
+    def _conv(self, x, name, relu=False, res=None):
+        blob, cout, taps = self.packed()[name]
+        return ops.conv2d(x, blob, cout, taps, relu=relu, res=res)
+
+    def _res(self, x, prefix, first):
+        for i in range(self.nb):
+            t = self._conv(x, f"{prefix}.{first + i}.res.0.weight", relu=True)
+            x = self._conv(t, f"{prefix}.{first + i}.res.2.weight", res=x)
+        return x
+
+    def forward(self, x0):
+        be.require(x0, what="UNetRes input")
+        if torch.is_grad_enabled() and x0.requires_grad:
+            raise NotImplementedError("gradients through DRUNet are not built for the HIP path (FFDNet priors are differentiable)")
+        nb = self.nb
+        x1 = self._conv(x0.contiguous(), "m_head.weight")
+        x2 = self._conv(ops.space_to_depth(self._res(x1, "m_down1", 0)), f"m_down1.{nb}.weight")
+        x3 = self._conv(ops.space_to_depth(self._res(x2, "m_down2", 0)), f"m_down2.{nb}.weight")
+        x4 = self._conv(ops.space_to_depth(self._res(x3, "m_down3", 0)), f"m_down3.{nb}.weight")
+        x = self._res(x4, "m_body", 0)
+        x = self._res(ops.depth_to_space(self._conv(ops.lincomb([(1.0, x), (1.0, x4)]), "m_up3.0.weight")), "m_up3", 1)
+        x = self._res(ops.depth_to_space(self._conv(ops.lincomb([(1.0, x), (1.0, x3)]), "m_up2.0.weight")), "m_up2", 1)
+        x = self._res(ops.depth_to_space(self._conv(ops.lincomb([(1.0, x), (1.0, x2)]), "m_up1.0.weight")), "m_up1", 1)
+        return self._conv(ops.lincomb([(1.0, x), (1.0, x1)]), "m_tail.weight")
+
+
+class DRUNetDenoiser(Denoiser):
+    """reference denoisers/wrapper.py:89-146: sigma map as an extra channel; images up to 256x256 are replicate-padded to a
+    multiple of 16 and denoised in one pass, larger ones as four overlapping quadrants (recursively).  The tensor
+    assembly (concat / pad / slices) is PyTorch memory plumbing, every convolution is HIP."""
+
+    def __init__(self, n_channels, model_path=None):
+        super().__init__()
+        self.model = UNetRes(in_nc=n_channels + 1, out_nc=n_channels, nc=(64, 128, 256, 512), nb=4)
+        if model_path is not None:
+            sd = model_path if isinstance(model_path, dict) else torch.load(model_path, map_location="cpu")
+            self.model.load_state_dict(sd, strict=True)
+
+    def _denoise(self, x, sigma):
+        if sigma.shape[0] != x.shape[0]:
+            sigma = sigma.repeat(x.shape[0], 1, 1, 1)
+        L = torch.cat((x, sigma.to(x.device, x.dtype).repeat(1, 1, x.shape[2], x.shape[3])), dim=1)
+        return self._run(L)
+
+    def _run(self, L, refield=32, min_size=256, modulo=16):
+        h, w = L.shape[-2:]
+        if h * w <= min_size ** 2:
+            Lp = torch.nn.functional.pad(L, (0, int(np.ceil(w / modulo) * modulo - w), 0, int(np.ceil(h / modulo) * modulo - h)), mode="replicate")
+            return self.model(Lp.contiguous())[..., :h, :w]
+        top, bottom = slice(0, (h // 2 // refield + 1) * refield), slice(h - (h // 2 // refield + 1) * refield, h)
+        left, right = slice(0, (w // 2 // refield + 1) * refield), slice(w - (w // 2 // refield + 1) * refield, w)
+        Ls = [L[..., top, left], L[..., top, right], L[..., bottom, left], L[..., bottom, right]]
+        if h * w <= 4 * (min_size ** 2):
+            Es = [self.model(q.contiguous()) for q in Ls]
+        else:
+            Es = [self._run(q, refield, min_size, modulo) for q in Ls]
+        b, c = Es[0].shape[:2]
+        E = torch.zeros(b, c, h, w, dtype=L.dtype, device=L.device)
+        E[..., :h // 2, :w // 2] = Es[0][..., :h // 2, :w // 2]
+        E[..., :h // 2, w // 2:] = Es[1][..., :h // 2, (-w + w // 2):]
+        E[..., h // 2:, :w // 2] = Es[2][..., (-h + h // 2):, :w // 2]
+        E[..., h // 2:, w // 2:] = Es[3][..., (-h + h // 2):, (-w + w // 2):]
+        return E

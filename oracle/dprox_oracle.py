@@ -31,7 +31,7 @@ __all__ = [
     "soft_threshold", "prox", "LeastSquares", "cg", "bdot", "LinearSolveConfig",
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
     "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
-    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior", "doe_otf", "lin_conv_doe",
+    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior", "doe_otf", "lin_conv_doe", "drunet_weights", "drunet_forward", "DRUNetOracle",
 ]
 
 
@@ -727,6 +727,93 @@ def admm_ext_prior(x0, ext_prox, denoise, rhos, sigmas, max_iter):
         v = denoise(d.contiguous(), torch.as_tensor(sigma, dtype=torch.float32).reshape(-1))
         u = d - v
     return x, v, u
+
+
+# --------------------------------------------------------------------------- #
+# DRUNet (UNetRes) denoiser                                                    #
+# --------------------------------------------------------------------------- #
+def drunet_weights(seed=21, in_nc=4, out_nc=3, nc=(64, 128, 256, 512), nb=4, gain=0.4):
+    """Seeded weights in the reference's state-dict layout (models/network_unet.py:67-104: no biases): He-normal x gain
+    (the checkpoints cannot be downloaded here)."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+
+    def conv_w(name, co, ci, k):
+        sd[name] = torch.from_numpy((rng.randn(co, ci, k, k) * gain * np.sqrt(2.0 / (ci * k * k))).astype(np.float32))
+
+    conv_w("m_head.weight", nc[0], in_nc, 3)
+    for lvl in range(3):
+        for i in range(nb):
+            conv_w(f"m_down{lvl + 1}.{i}.res.0.weight", nc[lvl], nc[lvl], 3)
+            conv_w(f"m_down{lvl + 1}.{i}.res.2.weight", nc[lvl], nc[lvl], 3)
+        conv_w(f"m_down{lvl + 1}.{nb}.weight", nc[lvl + 1], nc[lvl], 2)
+    for i in range(nb):
+        conv_w(f"m_body.{i}.res.0.weight", nc[3], nc[3], 3)
+        conv_w(f"m_body.{i}.res.2.weight", nc[3], nc[3], 3)
+    for lvl in (3, 2, 1):
+        w = (rng.randn(nc[lvl], nc[lvl - 1], 2, 2) * gain * np.sqrt(2.0 / (nc[lvl] * 4))).astype(np.float32)   # ConvTranspose2d: [in, out, 2, 2]
+        sd[f"m_up{lvl}.0.weight"] = torch.from_numpy(w)
+        for i in range(nb):
+            conv_w(f"m_up{lvl}.{i + 1}.res.0.weight", nc[lvl - 1], nc[lvl - 1], 3)
+            conv_w(f"m_up{lvl}.{i + 1}.res.2.weight", nc[lvl - 1], nc[lvl - 1], 3)
+    conv_w("m_tail.weight", out_nc, nc[0], 3)
+    return sd
+
+
+def drunet_forward(x0, sd, nb=4):
+    """UNetRes.forward -- models/network_unet.py:106-117 with ResBlock = x + conv(relu(conv(x))) (basicblock.py:211-223),
+    2x2 stride-2 convolutions down (:437-443) and 2x2 stride-2 transposed convolutions up (:413-419)."""
+    import torch.nn.functional as F
+
+    def res(x, pre):
+        for i in range(nb):
+            i0 = i if not pre.startswith("m_up") else i + 1
+            x = x + F.conv2d(F.relu(F.conv2d(x, sd[f"{pre}.{i0}.res.0.weight"], padding=1)), sd[f"{pre}.{i0}.res.2.weight"], padding=1)
+        return x
+    x1 = F.conv2d(x0, sd["m_head.weight"], padding=1)
+    x2 = F.conv2d(res(x1, "m_down1"), sd[f"m_down1.{nb}.weight"], stride=2)
+    x3 = F.conv2d(res(x2, "m_down2"), sd[f"m_down2.{nb}.weight"], stride=2)
+    x4 = F.conv2d(res(x3, "m_down3"), sd[f"m_down3.{nb}.weight"], stride=2)
+    x = res(x4, "m_body")
+    x = res(F.conv_transpose2d(x + x4, sd["m_up3.0.weight"], stride=2), "m_up3")
+    x = res(F.conv_transpose2d(x + x3, sd["m_up2.0.weight"], stride=2), "m_up2")
+    x = res(F.conv_transpose2d(x + x2, sd["m_up1.0.weight"], stride=2), "m_up1")
+    return F.conv2d(x + x1, sd["m_tail.weight"], padding=1)
+
+
+class DRUNetOracle:
+    """DRUNetDenoiser -- denoisers/wrapper.py:89-146: sigma map as an extra channel, replicate-pad to a multiple of 16 for
+    images up to 256x256, otherwise four overlapping quadrants (recursively), each denoised on its own."""
+
+    def __init__(self, sd):
+        self.sd = sd
+
+    def __call__(self, x, sigma):
+        sigma = sigma.view(-1, 1, 1, 1)
+        if sigma.shape[0] != x.shape[0]:
+            sigma = sigma.repeat(x.shape[0], 1, 1, 1)
+        L = torch.cat((x, sigma.repeat(1, 1, x.shape[2], x.shape[3])), dim=1)
+        return self._denoise(L)
+
+    def _denoise(self, L, refield=32, min_size=256, modulo=16):
+        h, w = L.shape[-2:]
+        if h * w <= min_size ** 2:
+            Lp = torch.nn.functional.pad(L, (0, int(np.ceil(w / modulo) * modulo - w), 0, int(np.ceil(h / modulo) * modulo - h)), mode="replicate")
+            return drunet_forward(Lp, self.sd)[..., :h, :w]
+        top, bottom = slice(0, (h // 2 // refield + 1) * refield), slice(h - (h // 2 // refield + 1) * refield, h)
+        left, right = slice(0, (w // 2 // refield + 1) * refield), slice(w - (w // 2 // refield + 1) * refield, w)
+        Ls = [L[..., top, left], L[..., top, right], L[..., bottom, left], L[..., bottom, right]]
+        if h * w <= 4 * (min_size ** 2):
+            Es = [drunet_forward(q, self.sd) for q in Ls]
+        else:
+            Es = [self._denoise(q, refield, min_size, modulo) for q in Ls]
+        b, c = Es[0].shape[:2]
+        E = torch.zeros(b, c, h, w, dtype=L.dtype)
+        E[..., :h // 2, :w // 2] = Es[0][..., :h // 2, :w // 2]
+        E[..., :h // 2, w // 2:] = Es[1][..., :h // 2, (-w + w // 2):]
+        E[..., h // 2:, :w // 2] = Es[2][..., (-h + h // 2):, :w // 2]
+        E[..., h // 2:, w // 2:] = Es[3][..., (-h + h // 2):, (-w + w // 2):]
+        return E
 
 
 def psnr(out, gt):

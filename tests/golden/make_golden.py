@@ -575,6 +575,34 @@ def g19_conv_doe():
     save("g19_conv_doe", **out)
 
 
+def g20_drunet():
+    """DRUNet (UNetRes, models/network_unet.py:67-117) behind DRUNetDenoiser (wrapper.py:89-146) with seeded weights:
+    the padded single-pass path (<= 256x256, size not a multiple of 16) and the four-quadrant path (> 256x256)."""
+    from oracle.dprox_oracle import drunet_weights
+    from dprox.proxfn.pnp.denoisers.models.network_unet import UNetRes
+    from dprox.proxfn.pnp.denoisers.wrapper import DRUNetDenoiser
+    rng = np.random.RandomState(200)
+    out = {}
+    for tag, n_ch, seed in (("color", 3, 21), ("gray", 1, 22)):
+        net = UNetRes(in_nc=n_ch + 1, out_nc=n_ch, nc=[64, 128, 256, 512], nb=4, act_mode="R", downsample_mode="strideconv",
+                      upsample_mode="convtranspose")
+        net.load_state_dict(drunet_weights(seed, n_ch + 1, n_ch), strict=True)
+        den = DRUNetDenoiser.__new__(DRUNetDenoiser)
+        Denoiser.__init__(den)
+        den.model = net.eval()
+        shapes = ((2, n_ch, 40, 52),) if tag == "color" else ((1, n_ch, 33, 47), (1, n_ch, 264, 260))
+        for i, shape in enumerate(shapes):
+            big = shape[-1] > 256
+            x = T((np.random.RandomState(201).rand(*shape) if big else rng.rand(*shape)).astype("float32"))
+            sig = torch.tensor([0.05, 0.2][: shape[0]])
+            with torch.no_grad():
+                y = den.denoise(x, sig)
+            if not big:                                       # the large input is regenerated from its seed (201) by the tests
+                out[f"{tag}{i}_x"] = x
+            out[f"{tag}{i}_y"], out[f"{tag}{i}_sigma"] = y, sig
+    save("g20_drunet", **out)
+
+
 def g15_csmri():
     """CS-MRI pipeline of the reference's examples (csmri closed-form data term + CustomADMM + gray FFDNet prior):
     dprox/proxfn/fast/csmri.py:8-25, dprox/contrib/csmri.py:156-171, ext_sum_squares routing invert.py:8-12."""
@@ -666,6 +694,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe):
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

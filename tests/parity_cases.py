@@ -455,6 +455,57 @@ def case_mosaic_jd(device, solve=True):
     assert_close(st[1][0].cpu(), g["jd_v"], 2 * TOL, "JD v")
 
 
+def case_conv2d_generic(device):
+    """dpx_conv2d / dpx_space_to_depth / dpx_depth_to_space against plain PyTorch fp32: 3x3 and 1x1, output-channel blocks
+    (Cout > 96), bias, fused ReLU, fused residual, odd spatial sizes; stride-2 conv and transposed conv built from them"""
+    import torch.nn.functional as F
+    from dprox import _ops as ops
+    rng = np.random.RandomState(5)
+    for (cin, cout, taps, H, W, relu, res, bias) in ((8, 128, 9, 9, 37, False, True, False), (6, 40, 9, 12, 20, True, False, True),
+                                                      (16, 200, 1, 10, 33, False, False, True), (4, 3, 9, 7, 5, False, False, False)):
+        k = 3 if taps == 9 else 1
+        w = torch.from_numpy((rng.randn(cout, cin, k, k) * 0.2).astype("float32")).to(device)
+        b = torch.from_numpy(rng.randn(cout).astype("float32")).to(device) if bias else None
+        x = torch.from_numpy(rng.randn(2, cin, H, W).astype("float32")).to(device)
+        r = torch.from_numpy(rng.randn(2, cout, H, W).astype("float32")).to(device) if res else None
+        y = ops.conv2d(x, ops.conv_pack(w.reshape(cout, cin, taps).contiguous(), b, taps), cout, taps, relu=relu, res=r)
+        ref = F.conv2d(x, w, b, padding=k // 2)
+        ref = F.relu(ref) if relu else ref
+        ref = ref + r if res else ref
+        assert_close(y.cpu(), ref.cpu(), 2e-6, f"conv2d cin={cin} cout={cout} taps={taps}")
+    x = torch.from_numpy(rng.randn(2, 6, 8, 10).astype("float32")).to(device)
+    assert torch.equal(ops.space_to_depth(x), F.pixel_unshuffle(x, 2))
+    assert torch.equal(ops.depth_to_space(F.pixel_unshuffle(x, 2)), x)
+    wd = torch.from_numpy((rng.randn(10, 6, 2, 2) * 0.3).astype("float32")).to(device)
+    y = ops.conv2d(ops.space_to_depth(x), ops.conv_pack(wd.reshape(10, 24, 1).contiguous(), None, 1), 10, 1)
+    assert_close(y.cpu(), F.conv2d(x, wd, stride=2).cpu(), 2e-6, "2x2 stride-2 conv = space_to_depth + 1x1")
+    wt = torch.from_numpy((rng.randn(6, 10, 2, 2) * 0.3).astype("float32")).to(device)
+    y = ops.depth_to_space(ops.conv2d(x, ops.conv_pack(wt.permute(1, 2, 3, 0).reshape(40, 6, 1).contiguous(), None, 1), 40, 1))
+    assert_close(y.cpu(), F.conv_transpose2d(x, wt, stride=2).cpu(), 2e-6, "2x2 stride-2 transposed conv = 1x1 + depth_to_space")
+
+
+def case_drunet(device):
+    """G20: DRUNet (UNetRes on dpx_conv2d: 3x3 / 1x1 MFMA convolutions with up to 512 channels in blocks of 64, fused ReLU and
+    residual adds, space-to-depth / depth-to-space around the strided / transposed 2x2 convolutions) behind
+    DRUNetDenoiser: padded single pass, odd sizes, the four-quadrant path, per-image sigma"""
+    import oracle as O          # seeded weight generator only
+    from dprox.proxfn.pnp.denoisers import DRUNetDenoiser
+    g = load_golden("g20_drunet")
+    with torch.no_grad():
+        den = DRUNetDenoiser(3, O.drunet_weights(21, 4, 3)).to(device)
+        y = den.denoise(T(g["color0_x"], device), T(g["color0_sigma"], device))
+        assert_close(y.cpu(), g["color0_y"], TOL, "DRUNet colour, 40x52 (padded to 48x64), per-image sigma")
+        deng = DRUNetDenoiser(1, O.drunet_weights(22, 2, 1)).to(device)
+        y = deng.denoise(T(g["gray0_x"], device), T(g["gray0_sigma"], device))
+        assert_close(y.cpu(), g["gray0_y"], TOL, "DRUNet gray, 33x47")
+        xb = torch.from_numpy(np.random.RandomState(201).rand(1, 1, 264, 260).astype("float32")).to(device)
+        y = deng.denoise(xb, T(g["gray1_sigma"], device))
+        assert_close(y.cpu(), g["gray1_y"], TOL, "DRUNet gray, 264x260 (four overlapping quadrants)")
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=den)
+    assert "deep_prior" in repr(prior)
+
+
 def case_conv_doe(device):
     """G19: conv_doe -- OTF rebuilt on the device from the PSF value (dpx_cfft2 + dpx_otf_from_full), placeholder-driven,
     through the fused ADMM path"""

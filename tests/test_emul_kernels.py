@@ -67,6 +67,10 @@ def test_csmri_custom_admm():
     pc.case_csmri(DEV, solve=False)          # the 4-iteration solve with the 15-layer gray FFDNet runs on the GPU only
 
 
+def test_conv2d_generic():
+    pc.case_conv2d_generic(DEV)
+
+
 def test_conv_doe():
     pc.case_conv_doe(DEV)
 

@@ -80,6 +80,14 @@ def test_csmri_custom_admm():
     pc.case_csmri(DEV)
 
 
+def test_drunet():
+    pc.case_drunet(DEV)
+
+
+def test_conv2d_generic():
+    pc.case_conv2d_generic(DEV)
+
+
 def test_conv_doe():
     pc.case_conv_doe(DEV)
 

@@ -288,6 +288,17 @@ def test_g19_conv_doe():
     assert_close(st[0], g["tv_x"], 1e-5); assert_close(st[1][0], g["tv_v0"], 1e-5)
 
 
+def test_g20_drunet():
+    g = load_golden("g20_drunet")
+    with torch.no_grad():
+        den = O.DRUNetOracle(O.drunet_weights(21, 4, 3))
+        assert_close(den(T(g["color0_x"]), T(g["color0_sigma"])), g["color0_y"], 2e-6)
+        deng = O.DRUNetOracle(O.drunet_weights(22, 2, 1))
+        assert_close(deng(T(g["gray0_x"]), T(g["gray0_sigma"])), g["gray0_y"], 2e-6)
+        xb = torch.from_numpy(np.random.RandomState(201).rand(1, 1, 264, 260).astype("float32"))
+        assert_close(deng(xb, T(g["gray1_sigma"])), g["gray1_y"], 2e-6)
+
+
 def test_g15_csmri():
     """csmri closed-form prox + CustomADMM with the gray FFDNet prior (complex iterate)."""
     g = load_golden("g15_csmri")
