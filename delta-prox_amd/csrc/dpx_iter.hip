@@ -357,9 +357,16 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       for (int i = 0; i < D; ++i) dpx_glds16(urow + 2 * T * i, stU + n * STG + i * 128);
     }
   };
+  // lower bounds of the vector-memory operations issued AFTER the awaited DMA (a wait count must never exceed the real
+  // number, or it could return early).  The V spectral stores of phase C only exist when a next right-hand side is
+  // produced (rho_next != NULL); the emit stores (x_out, v_out) are never counted.
   constexpr int NX_STEADY = (NT * (D + V) + V) > 63 ? 63 : (NT * (D + V) + V);
   constexpr int NU_LAST = (NT * V + V) > 63 ? 63 : (NT * V + V);
   constexpr int NU_STEADY = (NT * V + V + D + 1) > 63 ? 63 : (NT * V + V + D + 1);
+  constexpr int NX_STEADY_NS = (NT * (D + V)) > 63 ? 63 : (NT * (D + V));
+  constexpr int NU_LAST_NS = (NT * V) > 63 ? 63 : (NT * V);
+  constexpr int NU_STEADY_NS = (NT * V + D + 1) > 63 ? 63 : (NT * V + D + 1);
+  const bool has_spec = rho_next != nullptr;
 
   issue_x(rowof(0));
   issue_u(rowof(0));
@@ -369,7 +376,10 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
 
   for (int q = 0; q <= Rmax + 1; ++q) {
     // ---------------- phase A: inverse row transform of row q ----------------
-    if (q >= 3) dpx_wait_vm<NX_STEADY>();
+    if (q >= 3) {
+      if (has_spec) dpx_wait_vm<NX_STEADY>();
+      else dpx_wait_vm<NX_STEADY_NS>();
+    }
     else if (q == 1) dpx_wait_vm<0>();
     else dpx_wait_vm<NT * D>();
     float2 xa[V];
@@ -410,8 +420,13 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       const bool own = qz >= 1 && qz <= R;
       const unsigned hz = (unsigned)rowof(qz);
       if (q >= 3) {
-        if (q <= Rmax) dpx_wait_vm<NU_STEADY>();
-        else dpx_wait_vm<NU_LAST>();
+        if (has_spec) {
+          if (q <= Rmax) dpx_wait_vm<NU_STEADY>();
+          else dpx_wait_vm<NU_LAST>();
+        } else {
+          if (q <= Rmax) dpx_wait_vm<NU_STEADY_NS>();
+          else dpx_wait_vm<NU_LAST_NS>();
+        }
       } else {
         dpx_wait_vm<D + 1>();
       }
