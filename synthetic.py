@@ -6,6 +6,7 @@ ground truth = clipped sum of 6 random cosines + 8 random rectangles, PSF = 15x1
 ``numpy.random.RandomState`` (draw order matters).
 """
 import numpy as np
+import torch
 
 
 def fspecial_gaussian(hsize=15, sigma=5.0):
@@ -80,3 +81,48 @@ def csmri_case(B, H, W, seed=2023, rate=0.25, center=32, noise=0.01):
     nz = (rng.randn(B, 1, H, W) + 1j * rng.randn(B, 1, H, W)) * noise
     y = (mask[None, None] * (k + nz)).astype(np.complex64)
     return gt, mask[None, None], y
+
+
+# ---- seeded stand-ins for pretrained denoiser checkpoints (no network in the build / test environments) --------------------
+def ffdnet_weights(seed=7, in_nc=3, out_nc=3, nc=96, nb=12, gain=0.5):
+    """Seeded stand-in for the (un-downloadable) pretrained checkpoint: scaled He-normal weights,
+    small biases, drawn from ``numpy.random.RandomState(seed)`` (platform-stable).  Layer shapes are
+    FFDNet's -- reference network_ffdnet.py:43-47: (in_nc*4+1 -> nc), (nb-2) x (nc -> nc), (nc -> out_nc*4)."""
+    rng = np.random.RandomState(seed)
+    chans = [in_nc * 4 + 1] + [nc] * (nb - 1) + [out_nc * 4]
+    layers = []
+    for cin, cout in zip(chans[:-1], chans[1:]):
+        w = (rng.standard_normal((cout, cin, 3, 3)) * gain * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+        b = (rng.standard_normal((cout,)) * 0.01).astype(np.float32)
+        layers.append((w, b))
+    return layers
+
+
+def drunet_weights(seed=21, in_nc=4, out_nc=3, nc=(64, 128, 256, 512), nb=4, gain=0.4):
+    """Seeded weights in the reference's state-dict layout (models/network_unet.py:67-104: no biases): He-normal x gain
+    (the checkpoints cannot be downloaded here)."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+
+    def conv_w(name, co, ci, k):
+        sd[name] = torch.from_numpy((rng.randn(co, ci, k, k) * gain * np.sqrt(2.0 / (ci * k * k))).astype(np.float32))
+
+    conv_w("m_head.weight", nc[0], in_nc, 3)
+    for lvl in range(3):
+        for i in range(nb):
+            conv_w(f"m_down{lvl + 1}.{i}.res.0.weight", nc[lvl], nc[lvl], 3)
+            conv_w(f"m_down{lvl + 1}.{i}.res.2.weight", nc[lvl], nc[lvl], 3)
+        conv_w(f"m_down{lvl + 1}.{nb}.weight", nc[lvl + 1], nc[lvl], 2)
+    for i in range(nb):
+        conv_w(f"m_body.{i}.res.0.weight", nc[3], nc[3], 3)
+        conv_w(f"m_body.{i}.res.2.weight", nc[3], nc[3], 3)
+    for lvl in (3, 2, 1):
+        w = (rng.randn(nc[lvl], nc[lvl - 1], 2, 2) * gain * np.sqrt(2.0 / (nc[lvl] * 4))).astype(np.float32)   # ConvTranspose2d: [in, out, 2, 2]
+        sd[f"m_up{lvl}.0.weight"] = torch.from_numpy(w)
+        for i in range(nb):
+            conv_w(f"m_up{lvl}.{i + 1}.res.0.weight", nc[lvl - 1], nc[lvl - 1], 3)
+            conv_w(f"m_up{lvl}.{i + 1}.res.2.weight", nc[lvl - 1], nc[lvl - 1], 3)
+    conv_w("m_tail.weight", out_nc, nc[0], 3)
+    return sd
+
+

@@ -9,7 +9,7 @@ import dprox as dp
 from dprox.linalg import LinearSolveConfig
 from dprox.proxfn.pnp.denoisers import FFDNetColorDenoiser, FFDNetDenoiser
 from dprox.utils import fft2, ifft2
-import oracle as O          # seeded weight generator only
+import synthetic as O       # seeded weight generators
 import synthetic
 
 dev = torch.device("cuda")

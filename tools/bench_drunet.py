@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "delta-prox_amd")]
 import torch
 from dprox.proxfn.pnp.denoisers import DRUNetDenoiser
-import oracle as O
+import synthetic as O
 B, S = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), (int(sys.argv[2]) if len(sys.argv) > 2 else 256)
 dev = torch.device("cuda")
 den = DRUNetDenoiser(3, O.drunet_weights(21, 4, 3)).to(dev)

@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "delta-prox_amd")]
 import torch
 from dprox import _backend as be
 from dprox.proxfn.pnp.denoisers import FFDNetColorDenoiser
-import oracle as O
+import synthetic as O
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda")
 den = FFDNetColorDenoiser(O.ffdnet_weights(7)).to(dev)
