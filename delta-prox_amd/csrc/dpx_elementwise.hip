@@ -406,6 +406,30 @@ extern "C" int dpx_mul(const float* x, const float* w, float* out, int B, long n
   return launch_status("dpx_mul");
 }
 
+__global__ void __launch_bounds__(256) k_mul_color(const float* __restrict__ x, const float* __restrict__ srf, float* __restrict__ out,
+                                                   int transpose, int C, int C2, long hw) {
+  const int b = blockIdx.y;
+  const int cin = transpose ? C2 : C, cout = transpose ? C : C2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)cout * hw; i += (long)gridDim.x * 256L) {
+    const long p = i % hw;
+    const int co = (int)(i / hw);
+    float acc = 0.f;
+    for (int ci = 0; ci < cin; ++ci) {
+      const float s = transpose ? srf[(long)co * C2 + ci] : srf[(long)ci * C2 + co];
+      acc = fmaf(s, x[((long)b * cin + ci) * hw + p], acc);
+    }
+    out[((long)b * cout + co) * hw + p] = acc;
+  }
+}
+
+extern "C" int dpx_mul_color(const float* x, const float* srf, float* out, int transpose, int B, int C, int C2, long hw,
+                             dpx_stream_t stream) {
+  DPX_REQUIRE(x && srf && out && B > 0 && C > 0 && C2 > 0 && hw > 0, "dpx_mul_color: bad arguments");
+  const long n = (long)(transpose ? C : C2) * hw;
+  DPX_LAUNCH("k_mul_color", k_mul_color, dim3(grid_for(n, 256, 2048), B, 1), dim3(256), 0, (hipStream_t)stream, x, srf, out, transpose, C, C2, hw);
+  return launch_status("dpx_mul_color");
+}
+
 // ---- closed-form super-resolution data term (proxfn/fast/sr.py:45-126) -------------------------------------------------
 __global__ void __launch_bounds__(256) k_upsample_zero(const float* __restrict__ y, float* __restrict__ out, int sf, long planes, int h, int w) {
   const int H = h * sf, W = w * sf;

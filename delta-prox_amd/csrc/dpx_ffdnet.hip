@@ -257,7 +257,10 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
       }
       const float* wsrc = wpk + (size_t)(c0 / 2) * NTAP * 2 * M32 + lane * 4;
       float* sw = s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32);
-      for (int i = wv; i < NWP; i += 4) dpx_glds16(wsrc + i * 256, sw + i * 256);
+      // only the pieces this chunk's channels need (a partial chunk would otherwise read past the packed layer; the last
+      // piece may still over-read by < 1 KB: the blobs carry that much slack)
+      const int npieces = ((nch / 2) * NTAP * 2 * M32 + 255) / 256;
+      for (int i = wv; i < npieces; i += 4) dpx_glds16(wsrc + i * 256, sw + i * 256);
     }
   };
   float in_reg[DMA ? 1 : NI];

@@ -441,6 +441,19 @@ def mul(x, w):
     return out
 
 
+def mul_color(x, srf, transpose=False):
+    """channel mixing by srf [C, C2]: forward srf.T @ x (C -> C2 channels), adjoint srf @ x (C2 -> C)"""
+    require(x, what="mul_color input")
+    B, Cx, H, W = _shape4(x)
+    srf = srf.to(device=x.device, dtype=torch.float32).contiguous()
+    C, C2 = int(srf.shape[0]), int(srf.shape[1])
+    if Cx != (C2 if transpose else C):
+        raise be.DpxError(f"mul_color: input has {Cx} channels, srf is {C}x{C2} (transpose={transpose})")
+    out = torch.empty(B, C if transpose else C2, H, W, dtype=torch.float32, device=x.device)
+    be.lib().call("dpx_mul_color", ptr(x), ptr(srf), ptr(out), int(bool(transpose)), B, C, C2, H * W, be.stream())
+    return out
+
+
 def upsample_zero(y, sf):
     require(y, what="upsample input")
     B, C, h, w = _shape4(y)

@@ -76,3 +76,26 @@ class mul_elementwise(LinOp):
         if not freq:
             return self.w.to(x.device)
         return None
+
+
+class mul_color(LinOp):
+    """channel mixing by a spectral response function srf [C, C2] (reference dprox/linop/mul.py:13-43):
+    forward = srf.T @ x over the channel axis, adjoint = srf @ x (``dpx_mul_color``).  Like the reference, the SRF is a 2-D
+    tensor (given directly or through a Placeholder)."""
+
+    def __init__(self, arg, srf):
+        super().__init__([arg])
+        self._srf = srf
+        if isinstance(srf, Placeholder):
+            self.srf = None
+            self._srf.change(lambda val: setattr(self, "srf", val))
+        else:
+            self.srf = torch.as_tensor(srf).float()
+        if self.srf is not None and self.srf.ndim != 2:
+            raise ValueError("mul_color: srf must be a 2-D [C, C2] array")
+
+    def forward(self, x, **kwargs):
+        return ops.mul_color(x.contiguous(), self.srf, transpose=False)
+
+    def adjoint(self, x, **kwargs):
+        return ops.mul_color(x.contiguous(), self.srf, transpose=True)

@@ -126,6 +126,11 @@ int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, in
 int dpx_csmri_update(void* z, const void* y, const unsigned char* mask, int mask_images, const float* lam, float num_psi, int B,
                      long n_per_image, dpx_stream_t stream);
 
+/* mul_color (dprox/linop/mul.py:13-43): channel mixing by a spectral response srf [C][C2]:
+ *   forward  (transpose = 0): out[n][c2][p] = sum_c  srf[c][c2] x[n][c][p]      (= srf.T @ x), x has C  channels, out C2
+ *   adjoint  (transpose = 1): out[n][c][p]  = sum_c2 srf[c][c2] x[n][c2][p]     (= srf   @ x), x has C2 channels, out C   */
+int dpx_mul_color(const float* x, const float* srf, float* out, int transpose, int B, int C, int C2, long hw, dpx_stream_t stream);
+
 /* Building blocks of the closed-form single-image super-resolution data term `sisr` (dprox/proxfn/fast/sr.py:45-77):
  *   dpx_upsample_zero : s-fold zero-filling upsampler (sr.py:117-126), planes x h x w -> planes x (h sf) x (w sf)
  *   dpx_cplx_mul      : out[b,i] = (conj_a ? conj(a) : a)[(a_images > 1 ? b : 0), i] * bb[b, i]  (complex64; FBC * F(STy))

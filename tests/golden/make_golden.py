@@ -491,6 +491,12 @@ def g17_mosaic_jd():
     w = rng.rand(1, 3, 12, 14).astype("float32")
     me = dp.mul_elementwise(dp.Variable(), w)
     out.update(mul_w=w, mul_fwd=me.forward(x), mul_adj=me.adjoint(x))
+    P = dp.Placeholder()
+    mc = dp.mul_color(dp.Variable(), P)                      # the SRF must be a 2-D tensor (mul.py:36-42 uses srf.T)
+    srf = T(np.random.RandomState(172).rand(3, 5).astype("float32"))
+    P.value = srf
+    x5 = T(np.random.RandomState(173).rand(2, 5, 12, 14).astype("float32"))
+    out.update(srf=srf, mulc_fwd=mc.forward(x).detach(), mulc_x5=x5, mulc_adj=mc.adjoint(x5).detach())
     gt, blur, psf = synthetic.deconv_case(2, 3, 32, 40, seed=171)
     b = mosaicing(T(blur[0].transpose(1, 2, 0)))            # the reference helper takes one HWC image
     b = torch.cat([b, mosaicing(T(blur[1].transpose(1, 2, 0)))], dim=0).float()

@@ -440,6 +440,11 @@ def case_mosaic_jd(device, solve=True):
     me = dp.mul_elementwise(dp.Variable(), g["mul_w"]).to(device)
     assert_close(me.forward(x).cpu(), g["mul_fwd"], 1e-7, "mul_elementwise forward")
     assert_close(me.adjoint(x).cpu(), g["mul_adj"], 1e-7, "mul_elementwise adjoint")
+    P = dp.Placeholder()
+    mc = dp.mul_color(dp.Variable(), P).to(device)
+    P.value = T(g["srf"], device)
+    assert_close(mc.forward(x).cpu(), g["mulc_fwd"], 1e-6, "mul_color forward (3 -> 5 channels)")
+    assert_close(mc.adjoint(T(g["mulc_x5"], device)).cpu(), g["mulc_adj"], 1e-6, "mul_color adjoint (5 -> 3 channels)")
     if not solve:
         return
     b = T(g["jd_b"], device)
