@@ -1,0 +1,25 @@
+"""TEST INFRASTRUCTURE: parity cases against the ASan build of the emulated kernels (see run_asan.sh)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path[:0] = [os.path.join(ROOT, 'tests'), ROOT, os.path.join(ROOT, 'delta-prox_amd')]
+from dprox import _backend as be, _ops
+be._inject_for_tests(be.Library(os.environ["DPX_ASAN_LIB"]), host_pointers=True)
+_ops.clear_caches()
+import parity_cases as pc
+import torch
+which = sys.argv[1:]
+cases = {
+ "conv2d": lambda: pc.case_conv2d_generic("cpu"),
+ "ffdnet": lambda: pc.case_ffdnet("cpu", which=("odd","gray")),
+ "config1": lambda: pc.case_admm_tv_config1("cpu"),
+ "small": lambda: pc.case_admm_tv_small("cpu", True),
+ "linops": lambda: [pc.case_linops("cpu", t) for t in "abc"],
+ "csmri": lambda: pc.case_csmri("cpu", solve=False),
+ "sisr": lambda: pc.case_sisr("cpu", solve=False),
+ "doe": lambda: pc.case_conv_doe("cpu"),
+ "grads": lambda: pc.case_unrolled_grads("cpu"),
+ "cg": lambda: pc.case_cg("cpu", 4),
+ "ffbwd": lambda: pc.case_ffdnet_grads("cpu", which=("even",)),
+}
+for w in which:
+    cases[w](); print("OK", w, flush=True)
