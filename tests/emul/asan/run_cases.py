@@ -21,5 +21,23 @@ cases = {
  "cg": lambda: pc.case_cg("cpu", 4),
  "ffbwd": lambda: pc.case_ffdnet_grads("cpu", which=("even",)),
 }
+def pow2_terms():
+    """two-kernel iteration (LDS-DMA row / column kernels) at 256x256 with 1, 3 and 4 Psi terms, uneven band partition"""
+    import dprox as dp, synthetic
+    gt, b, psf = synthetic.deconv_case(2, 1, 256, 256, seed=9)
+    bt = torch.from_numpy(b)
+    for terms in ("h+l1", "hw+nn", "hw+nn+l1"):
+        x = dp.Variable()
+        fns = dp.sum_squares(dp.conv(x, psf) - bt)
+        if "h" in terms.split("+")[0]: fns = fns + dp.norm1(dp.grad(x, dim=0))
+        if "w" in terms.split("+")[0]: fns = fns + dp.norm1(dp.grad(x, dim=1))
+        if "nn" in terms: fns = fns + dp.nonneg(x)
+        if "l1" in terms: fns = fns + dp.norm1(x) * 0.5
+        s_ = dp.compile(fns, method="admm", device="cpu")
+        out = s_.solve(x0=bt, rhos=0.3, lams=0.01, max_iter=2)
+        assert s_.last_path == "fused" and torch.isfinite(out).all()
+
+
+cases["pow2"] = pow2_terms
 for w in which:
     cases[w](); print("OK", w, flush=True)
