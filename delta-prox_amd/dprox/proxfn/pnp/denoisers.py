@@ -201,12 +201,70 @@ class FFDNetColorDenoiser(Denoiser):
         return self.model(x, sigma)
 
 
+class _ConvFn(torch.autograd.Function):
+    """one dpx_conv2d layer (optional fused ReLU / residual) with a hand-written backward w.r.t. its inputs: the
+    transposed convolution is the same kernel on flipped / transposed weights (packed once per layer), the ReLU mask comes
+    from the saved output"""
+
+    @staticmethod
+    def forward(ctx, x, res, fwd, bwd, relu):
+        blob, cout, taps = fwd
+        y = ops.conv2d(x.contiguous(), blob, cout, taps, relu=relu, res=None if res is None else res.contiguous())
+        ctx.bwd, ctx.relu, ctx.has_res = bwd, relu, res is not None
+        ctx.save_for_backward(y if relu else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gp = g
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            gp, _ = ops.prox_bwd(be.PROX_NONNEG, y, g, torch.zeros((), device=g.device), 1.0, None, want_dlam=False)   # g * [y > 0]
+        blob_t, cin, taps = ctx.bwd
+        if gp.shape[1] % 2:
+            gp = torch.cat([gp, torch.zeros_like(gp[:, :1])], dim=1).contiguous()
+        gx = ops.conv2d(gp, blob_t, cin, taps) if ctx.needs_input_grad[0] else None
+        return gx, (g if ctx.has_res else None), None, None, None
+
+
+class _S2DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.space_to_depth(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.depth_to_space(g.contiguous())
+
+
+class _D2SFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.depth_to_space(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.space_to_depth(g.contiguous())
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.lincomb([(1.0, a.contiguous()), (1.0, b.contiguous())])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 class UNetRes(nn.Module):
     """DRUNet body (reference models/network_unet.py:67-117): head conv, 3 x (nb ResBlocks + 2x2 stride-2 conv), nb ResBlocks,
     3 x (2x2 stride-2 transposed conv + nb ResBlocks), tail conv; no biases.  Every convolution runs on the fp32-MFMA
     kernel behind ``dpx_conv2d`` (ReLU / residual add fused into the epilogue); the strided / transposed 2x2 convolutions
     are 1x1 convolutions around ``dpx_space_to_depth`` / ``dpx_depth_to_space``.  Parameters keep the reference's
-    state-dict names, so its checkpoints load unchanged.  Inference only (no autograd through this network yet)."""
+    state-dict names, so its checkpoints load unchanged.  Differentiable w.r.t. its input (frozen weights): every layer's
+    backward is the same kernel on transposed weights (``_ConvFn``)."""
 
     def __init__(self, in_nc=1, out_nc=1, nc=(64, 128, 256, 512), nb=4, act_mode="R", downsample_mode="strideconv", upsample_mode="convtranspose"):
         super().__init__()
@@ -229,6 +287,7 @@ class UNetRes(nn.Module):
                 for k in (0, 2):
                     shapes[f"m_up{lvl}.{i + 1}.res.{k}.weight"] = (nc[lvl - 1], nc[lvl - 1], 3, 3)
         self._names = list(shapes)
+        self._diff = False
         self.params = nn.ParameterDict({n.replace(".", "/"): nn.Parameter(torch.zeros(*shp), requires_grad=False) for n, shp in shapes.items()})
         self._packed = None
 
@@ -241,6 +300,7 @@ class UNetRes(nn.Module):
             if n in sd:
                 self.params[n.replace(".", "/")].data.copy_(torch.as_tensor(sd[n]))
         self._packed = None
+        self._packed_T = None
         return self
 
     def state_dict(self, *a, **k):
@@ -248,6 +308,7 @@ class UNetRes(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._packed_T = None
         return super()._apply(fn, *a, **k)
 
     def _w(self, name):
@@ -269,7 +330,29 @@ class UNetRes(nn.Module):
             self._packed = pk
         return self._packed
 
+    def packed_T(self):
+        """weights of the backward-data convolutions: 3x3 flipped and channel-transposed; the 1x1 forms transposed"""
+        if getattr(self, "_packed_T", None) is None:
+            pk = {}
+            for n in self._names:
+                w = self._w(n)
+                if w.shape[-1] == 3:
+                    wt = w.flip(-1, -2).permute(1, 0, 2, 3).reshape(w.shape[1], w.shape[0], 9)
+                    if wt.shape[1] % 2:                          # odd forward cout (tail conv): the gradient gets a zero channel
+                        wt = torch.cat([wt, torch.zeros_like(wt[:, :1])], dim=1)
+                    pk[n] = (ops.conv_pack(wt.contiguous(), None, 9), int(w.shape[1]), 9)
+                elif n.startswith("m_down"):
+                    co, ci = int(w.shape[0]), int(w.shape[1])
+                    pk[n] = (ops.conv_pack(w.reshape(co, ci * 4).t().reshape(ci * 4, co, 1).contiguous(), None, 1), ci * 4, 1)
+                else:
+                    ci, co = int(w.shape[0]), int(w.shape[1])
+                    pk[n] = (ops.conv_pack(w.permute(1, 2, 3, 0).reshape(co * 4, ci).t().reshape(ci, co * 4, 1).contiguous(), None, 1), ci, 1)
+            self._packed_T = pk
+        return self._packed_T
+
     def _conv(self, x, name, relu=False, res=None):
+        if self._diff:
+            return _ConvFn.apply(x, res, self.packed()[name], self.packed_T()[name], relu)
         blob, cout, taps = self.packed()[name]
         return ops.conv2d(x, blob, cout, taps, relu=relu, res=res)
 
@@ -281,18 +364,21 @@ class UNetRes(nn.Module):
 
     def forward(self, x0):
         be.require(x0, what="UNetRes input")
-        if torch.is_grad_enabled() and x0.requires_grad:
-            raise NotImplementedError("gradients through DRUNet are not built for the HIP path (FFDNet priors are differentiable)")
+        self._diff = torch.is_grad_enabled() and x0.requires_grad
+        if self._diff:
+            s2d, d2s, add = _S2DFn.apply, _D2SFn.apply, _AddFn.apply
+        else:
+            s2d, d2s, add = ops.space_to_depth, ops.depth_to_space, lambda a, b: ops.lincomb([(1.0, a), (1.0, b)])
         nb = self.nb
         x1 = self._conv(x0.contiguous(), "m_head.weight")
-        x2 = self._conv(ops.space_to_depth(self._res(x1, "m_down1", 0)), f"m_down1.{nb}.weight")
-        x3 = self._conv(ops.space_to_depth(self._res(x2, "m_down2", 0)), f"m_down2.{nb}.weight")
-        x4 = self._conv(ops.space_to_depth(self._res(x3, "m_down3", 0)), f"m_down3.{nb}.weight")
+        x2 = self._conv(s2d(self._res(x1, "m_down1", 0)), f"m_down1.{nb}.weight")
+        x3 = self._conv(s2d(self._res(x2, "m_down2", 0)), f"m_down2.{nb}.weight")
+        x4 = self._conv(s2d(self._res(x3, "m_down3", 0)), f"m_down3.{nb}.weight")
         x = self._res(x4, "m_body", 0)
-        x = self._res(ops.depth_to_space(self._conv(ops.lincomb([(1.0, x), (1.0, x4)]), "m_up3.0.weight")), "m_up3", 1)
-        x = self._res(ops.depth_to_space(self._conv(ops.lincomb([(1.0, x), (1.0, x3)]), "m_up2.0.weight")), "m_up2", 1)
-        x = self._res(ops.depth_to_space(self._conv(ops.lincomb([(1.0, x), (1.0, x2)]), "m_up1.0.weight")), "m_up1", 1)
-        return self._conv(ops.lincomb([(1.0, x), (1.0, x1)]), "m_tail.weight")
+        x = self._res(d2s(self._conv(add(x, x4), "m_up3.0.weight")), "m_up3", 1)
+        x = self._res(d2s(self._conv(add(x, x3), "m_up2.0.weight")), "m_up2", 1)
+        x = self._res(d2s(self._conv(add(x, x2), "m_up1.0.weight")), "m_up1", 1)
+        return self._conv(add(x, x1), "m_tail.weight")
 
 
 class DRUNetDenoiser(Denoiser):

@@ -606,6 +606,18 @@ def g20_drunet():
             if not big:                                       # the large input is regenerated from its seed (201) by the tests
                 out[f"{tag}{i}_x"] = x
             out[f"{tag}{i}_y"], out[f"{tag}{i}_sigma"] = y, sig
+    # gradients w.r.t. the image and sigma through the colour net (frozen weights), padded single-pass path
+    net = UNetRes(in_nc=4, out_nc=3, nc=[64, 128, 256, 512], nb=4, act_mode="R", downsample_mode="strideconv", upsample_mode="convtranspose")
+    net.load_state_dict(drunet_weights(21, 4, 3), strict=True)
+    net.requires_grad_(False)
+    den = DRUNetDenoiser.__new__(DRUNetDenoiser)
+    Denoiser.__init__(den)
+    den.model = net.eval()
+    xg = T(np.random.RandomState(202).rand(2, 3, 24, 40).astype("float32")).requires_grad_(True)
+    sg = torch.tensor([0.05, 0.2], requires_grad=True)
+    wg = T(np.random.RandomState(203).randn(2, 3, 24, 40).astype("float32"))
+    (den.denoise(xg, sg) * wg).sum().backward()
+    out.update(grad_x=xg.detach(), grad_w=wg, grad_gx=xg.grad, grad_gsigma=sg.grad)
     save("g20_drunet", **out)
 
 

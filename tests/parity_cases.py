@@ -506,6 +506,12 @@ def case_drunet(device):
         xb = torch.from_numpy(np.random.RandomState(201).rand(1, 1, 264, 260).astype("float32")).to(device)
         y = deng.denoise(xb, T(g["gray1_sigma"], device))
         assert_close(y.cpu(), g["gray1_y"], TOL, "DRUNet gray, 264x260 (four overlapping quadrants)")
+    # input / sigma gradients (frozen weights): per-layer transposed convolutions on the same kernel
+    xg = T(g["grad_x"], device).requires_grad_(True)
+    sg = torch.tensor([0.05, 0.2], device=device, requires_grad=True)
+    (den.denoise(xg, sg) * T(g["grad_w"], device)).sum().backward()
+    _assert_grad_close(xg.grad.cpu(), g["grad_gx"], "DRUNet d/dx")
+    _assert_grad_close(sg.grad.cpu(), g["grad_gsigma"], "DRUNet d/dsigma", tol=1e-2)
     x = dp.Variable()
     prior = dp.deep_prior(x, denoiser=den)
     assert "deep_prior" in repr(prior)
