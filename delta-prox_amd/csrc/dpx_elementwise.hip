@@ -406,6 +406,26 @@ extern "C" int dpx_mul(const float* x, const float* w, float* out, int B, long n
   return launch_status("dpx_mul");
 }
 
+__global__ void __launch_bounds__(256) k_wss_prox(const float* __restrict__ v, const float* __restrict__ ktb, int ktb_images,
+                                                  const float* __restrict__ diag, int diag_images, const float* __restrict__ lam,
+                                                  float* __restrict__ out, long npb) {
+  const int b = blockIdx.y;
+  const float l = lam[b];
+  const float* kb = ktb + (ktb_images > 1 ? (long)b * npb : 0L);
+  const float* db = diag + (diag_images > 1 ? (long)b * npb : 0L);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < npb; i += (long)gridDim.x * 256L)
+    out[(long)b * npb + i] = (kb[i] + l * v[(long)b * npb + i]) / (db[i] + l);
+}
+
+extern "C" int dpx_wss_prox(const float* v, const float* ktb, int ktb_images, const float* diag, int diag_images, const float* lam,
+                            float* out, int B, long n_per_image, dpx_stream_t stream) {
+  DPX_REQUIRE(v && ktb && diag && lam && out && B > 0 && n_per_image > 0, "dpx_wss_prox: bad arguments");
+  DPX_REQUIRE((ktb_images == 1 || ktb_images == B) && (diag_images == 1 || diag_images == B), "dpx_wss_prox: tables must hold 1 or B images");
+  DPX_LAUNCH("k_wss_prox", k_wss_prox, dim3(grid_for(n_per_image, 256, 2048), B, 1), dim3(256), 0, (hipStream_t)stream, v, ktb, ktb_images, diag,
+             diag_images, lam, out, n_per_image);
+  return launch_status("dpx_wss_prox");
+}
+
 __global__ void __launch_bounds__(256) k_mul_color(const float* __restrict__ x, const float* __restrict__ srf, float* __restrict__ out,
                                                    int transpose, int C, int C2, long hw) {
   const int b = blockIdx.y;

@@ -64,6 +64,7 @@ SIGNATURES = {
     "dpx_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_lincomb": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_float), POINTER(c_void_p), c_int, c_long, c_void_p]),
     "dpx_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "dpx_wss_prox": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "dpx_mul_color": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_void_p]),
     "dpx_upsample_zero": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
     "dpx_cplx_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),

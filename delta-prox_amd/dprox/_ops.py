@@ -441,6 +441,26 @@ def mul(x, w):
     return out
 
 
+def wss_prox(v, ktb, diag, lam):
+    """(ktb + lam v) / (diag + lam) with per-image lam; ktb / diag one image or a batch"""
+    require(v, what="wss_prox input")
+    B = int(v.shape[0])
+    npb = v.numel() // B
+    ktb = ktb.to(device=v.device, dtype=torch.float32).contiguous()
+    diag = diag.to(device=v.device, dtype=torch.float32).contiguous()
+
+    def images(t, what):
+        if t.numel() == npb:
+            return 1
+        if t.numel() == v.numel():
+            return B
+        raise be.DpxError(f"wss_prox: {what} {tuple(t.shape)} matches neither one image nor the batch {tuple(v.shape)}")
+    out = torch.empty_like(v)
+    be.lib().call("dpx_wss_prox", ptr(v), ptr(ktb), images(ktb, "Ktb"), ptr(diag), images(diag, "diag"), ptr(as_batch_vec(lam, B, v.device)),
+                  ptr(out), B, npb, be.stream())
+    return out
+
+
 def mul_color(x, srf, transpose=False):
     """channel mixing by srf [C, C2]: forward srf.T @ x (C -> C2 channels), adjoint srf @ x (C2 -> C)"""
     require(x, what="mul_color input")

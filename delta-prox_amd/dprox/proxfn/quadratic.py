@@ -70,6 +70,30 @@ class ext_sum_squares(sum_squares):
         return self._prox(xtilde, rho, len(b))
 
 
+class weighted_sum_squares(sum_squares):
+    """||W x - b||^2 with a diagonal weight operator W (reference sum_square.py:51-83): the prox is
+    (W^T b + lam v) / (diag(W) + lam), evaluated by ``dpx_wss_prox`` (spatially diagonal weights; the reference's frequency
+    branch transforms over the batch / channel axes and is not reproduced)."""
+
+    def __init__(self, linop, weight, b, eps=0):
+        super().__init__(linop, b, eps)
+        self.weight = weight
+        if not self.weight.is_diag():
+            raise ValueError("weight {} must be diagonalizable".format(weight))
+
+    @property
+    def Ktb(self):
+        return adjoint(self.weight, self.unwrap(self._b).to(self.weight.device).contiguous())
+
+    def prox(self, v, lam):
+        Ktb = self.Ktb
+        diag = self.weight.get_diag(Ktb)
+        return ops.wss_prox(v.contiguous(), Ktb, diag, lam)
+
+    def _prox(self, v, lam):
+        return self.prox(v, lam)
+
+
 # ------------------------------------------------------------------------------------------------
 # Gram diagonals:  (opaque half-spectrum table | None, constant)
 # ------------------------------------------------------------------------------------------------

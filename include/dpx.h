@@ -126,6 +126,11 @@ int dpx_cfft2(const void* in, void* out, int inverse, int centred, int ortho, in
 int dpx_csmri_update(void* z, const void* y, const unsigned char* mask, int mask_images, const float* lam, float num_psi, int B,
                      long n_per_image, dpx_stream_t stream);
 
+/* weighted_sum_squares._prox (dprox/proxfn/sum_square.py:70-75): out = (ktb + lam_b v) / (diag + lam_b), ktb / diag one image
+ * (ktb_images / diag_images = 1) or a batch.                                                                         */
+int dpx_wss_prox(const float* v, const float* ktb, int ktb_images, const float* diag, int diag_images, const float* lam, float* out,
+                 int B, long n_per_image, dpx_stream_t stream);
+
 /* mul_color (dprox/linop/mul.py:13-43): channel mixing by a spectral response srf [C][C2]:
  *   forward  (transpose = 0): out[n][c2][p] = sum_c  srf[c][c2] x[n][c][p]      (= srf.T @ x), x has C  channels, out C2
  *   adjoint  (transpose = 1): out[n][c][p]  = sum_c2 srf[c][c2] x[n][c2][p]     (= srf   @ x), x has C2 channels, out C   */

@@ -497,6 +497,10 @@ def g17_mosaic_jd():
     P.value = srf
     x5 = T(np.random.RandomState(173).rand(2, 5, 12, 14).astype("float32"))
     out.update(srf=srf, mulc_fwd=mc.forward(x).detach(), mulc_x5=x5, mulc_adj=mc.adjoint(x5).detach())
+    # weighted_sum_squares with a mul_elementwise weight (sum_square.py:51-75): a Psi-side prox
+    bw = T(np.random.RandomState(174).rand(2, 3, 12, 14).astype("float32"))
+    wss = dp.weighted_sum_squares(dp.Variable(), dp.mul_elementwise(dp.Variable(), w), bw)
+    out.update(wss_b=bw, wss_prox=wss.prox(x, torch.tensor([0.3, 1.2])).detach())
     gt, blur, psf = synthetic.deconv_case(2, 3, 32, 40, seed=171)
     b = mosaicing(T(blur[0].transpose(1, 2, 0)))            # the reference helper takes one HWC image
     b = torch.cat([b, mosaicing(T(blur[1].transpose(1, 2, 0)))], dim=0).float()

@@ -445,6 +445,8 @@ def case_mosaic_jd(device, solve=True):
     P.value = T(g["srf"], device)
     assert_close(mc.forward(x).cpu(), g["mulc_fwd"], 1e-6, "mul_color forward (3 -> 5 channels)")
     assert_close(mc.adjoint(T(g["mulc_x5"], device)).cpu(), g["mulc_adj"], 1e-6, "mul_color adjoint (5 -> 3 channels)")
+    wss = dp.weighted_sum_squares(dp.Variable(), dp.mul_elementwise(dp.Variable(), g["mul_w"]), T(g["wss_b"], device)).to(device)
+    assert_close(wss.prox(x, torch.tensor([0.3, 1.2], device=device)).cpu(), g["wss_prox"], TOL, "weighted_sum_squares prox")
     if not solve:
         return
     b = T(g["jd_b"], device)
