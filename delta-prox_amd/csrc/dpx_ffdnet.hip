@@ -21,8 +21,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int FFD_TW = 32;        // tile width  (pixels, = MFMA N)
 constexpr int FFD_TH = 8;         // tile height (rows): 4 waves x 2 rows
 constexpr int FFD_CK = 8;         // input channels staged per chunk
-constexpr int FFD_LDW = 36;       // LDS row pitch of the staged input tile (34 used)
-constexpr int FFD_ROWS = FFD_TH + 2;
+// staged input tile of a dilation-DIL 3x3 convolution: apron of DIL pixels on every side
+template <int DIL> struct FfdTile {
+  static constexpr int ROWS = FFD_TH + 2 * DIL;                       // 10 / 12 / 14 / 16
+  static constexpr int USED = FFD_TW + 2 * DIL;                       // 34 / 36 / 38 / 40 columns read
+  static constexpr int LDW = DIL == 1 ? 36 : (DIL == 4 ? 42 : 40);       // row pitch: ROWS * LDW mod 64 = 40 / 32 / 48 / 32 keeps the
+                                                                      // two channel halves of a K-step on (mostly) different banks
+};
 
 static inline int pad_even(int c) { return (c + 1) & ~1; }
 static inline int mtiles(int cout) { return (cout + 31) / 32; }
@@ -150,15 +155,16 @@ __global__ void __launch_bounds__(256) k_ffd_sigma_grad(const float* __restrict_
 
 // NP channel pairs x NTAP taps (9: 3x3 kernel, 1: 1x1 kernel = centre tap only), fully unrolled; the LDS fragments of
 // step k+1 are fetched while step k multiplies
-template <int MT, int NP, int NTAP = 9>
+template <int MT, int NP, int NTAP = 9, int DIL = 1>
 __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __restrict__ sin_b, const float* __restrict__ sw_b) {
   constexpr int M32 = MT * 32, NS = NP * NTAP;
+  constexpr int FFD_LDW = FfdTile<DIL>::LDW, FFD_ROWS = FfdTile<DIL>::ROWS;
   constexpr int T0 = NTAP == 9 ? 0 : 4;                       // first tap index in the 3x3 stencil (1x1: the centre)
   float a_cur[MT], b_cur[2];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) a_cur[mt] = sw_b[mt * 32];
-  b_cur[0] = sin_b[(T0 / 3) * FFD_LDW + T0 % 3];
-  b_cur[1] = sin_b[(T0 / 3 + 1) * FFD_LDW + T0 % 3];
+  b_cur[0] = sin_b[(T0 / 3) * DIL * FFD_LDW + (T0 % 3) * DIL];
+  b_cur[1] = sin_b[((T0 / 3) * DIL + 1) * FFD_LDW + (T0 % 3) * DIL];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     float a_nxt[MT], b_nxt[2];
@@ -166,8 +172,8 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __
       const int cp = (k + 1) / NTAP, tw = (k + 1) % NTAP, tap = T0 + tw, dy = tap / 3, dx = tap % 3;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = sw_b[(cp * NTAP + tw) * 2 * M32 + mt * 32];
-      b_nxt[0] = sin_b[(2 * cp * FFD_ROWS + dy) * FFD_LDW + dx];
-      b_nxt[1] = sin_b[(2 * cp * FFD_ROWS + dy + 1) * FFD_LDW + dx];
+      b_nxt[0] = sin_b[(2 * cp * FFD_ROWS + dy * DIL) * FFD_LDW + dx * DIL];
+      b_nxt[1] = sin_b[(2 * cp * FFD_ROWS + dy * DIL + 1) * FFD_LDW + dx * DIL];
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -189,11 +195,12 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __
 // NTAP = 9: 3x3 / pad 1; NTAP = 1: 1x1 (stride-2 and transposed 2x2 convolutions are 1x1 convolutions around a
 // space-to-depth / depth-to-space rearrangement).  blockIdx.z selects a block of MT*32 output channels (layers wider than
 // 96 channels: DRUNet), each with its own packed weight block.  RES: out = conv + res (residual blocks).
-template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false>
+template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false, int DIL = 1>
 __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x,
                                                        const float* __restrict__ mask) {
   constexpr int M32 = MT * 32;
+  constexpr int FFD_LDW = FfdTile<DIL>::LDW, FFD_ROWS = FfdTile<DIL>::ROWS, FFD_USED = FfdTile<DIL>::USED;
   __shared__ float s_in[2 * FFD_CK * FFD_ROWS * FFD_LDW];                              // 2 x [ch][row][col]
   __shared__ __attribute__((aligned(16))) float s_w[2 * (FFD_CK / 2) * NTAP * 2 * M32];  // 2 x [pair][tap][half][cout]
   const int co0 = blockIdx.z * M32;                                                    // first output channel of this block
@@ -220,29 +227,25 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
   //    chunk instead of ~450 staging instructions that competed with the MFMA issue: 63 % -> 8x % of the MFMA peak).
   //    The weight chunk is a contiguous block of the packed layer (1 KB pieces, 16 B per lane); the input tile is
   //    fetched dword-wise (rows start at arbitrary alignments), lanes outside the image read the layer's zero word.
-  //  (the register-staged variant is kept behind DMA = false for A/B timing)
-  constexpr bool DMA = true;
   constexpr int NPI = (FFD_CK * FFD_ROWS * FFD_LDW + 63) / 64;             // dword pieces of one input chunk (45)
   constexpr int NPW = (NPI + 3) / 4;                                       // per wave
   constexpr int NWP = ((FFD_CK / 2) * NTAP * 2 * M32) / 256;               // 1 KB pieces of one weight chunk (27 / 18 / 9; 3 / 2 / 1)
   static_assert(((FFD_CK / 2) * NTAP * 2 * M32) % 256 == 0, "weight chunk must be whole 1 KB pieces");
-  constexpr int NI = (FFD_CK * FFD_ROWS * 34 + 255) / 256;                 // input-tile elements per thread (register path)
-  constexpr int NW4 = ((FFD_CK / 2) * NTAP * 2 * M32 / 4 + 255) / 256;     // weight float4s per thread (register path)
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  unsigned ioff[DMA ? NPW : 1];            // (channel << 28) | element offset inside the chunk's channel block; ~0u = zero word
-  if constexpr (DMA) {
+  unsigned ioff[NPW];                      // (channel << 28) | element offset inside the chunk's channel block; ~0u = zero word
+  {
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
       const int e = (wv + 4 * k) * 64 + lane;
       const int ch = e / (FFD_ROWS * FFD_LDW), r = (e / FFD_LDW) % FFD_ROWS, col = e % FFD_LDW;
-      const int yy = y0 + r - 1, xx = x0 + col - 1;
-      const bool ok = (wv + 4 * k) < NPI && ch < FFD_CK && col < 34 && yy >= 0 && yy < H2 && xx >= 0 && xx < W2;
+      const int yy = y0 + r - DIL, xx = x0 + col - DIL;
+      const bool ok = (wv + 4 * k) < NPI && ch < FFD_CK && col < FFD_USED && yy >= 0 && yy < H2 && xx >= 0 && xx < W2;
       ioff[k] = ok ? (((unsigned)ch << 28) | (unsigned)((ch * H2 + yy) * W2 + xx)) : ~0u;
     }
   }
   const float* zero_word = bias + M32;
   auto issue = [&](int c0, int buf) {
-    if constexpr (DMA) {
+    {
       const int nch = min(FFD_CK, Cin - c0);
       const float* cb = inb + (size_t)c0 * H2 * W2;
       float* si = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW);
@@ -263,72 +266,18 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
       for (int i = wv; i < npieces; i += 4) dpx_glds16(wsrc + i * 256, sw + i * 256);
     }
   };
-  float in_reg[DMA ? 1 : NI];
-  float4 w_reg[DMA ? 1 : NW4];
-  auto fetch = [&](int c0) {
-    if constexpr (!DMA) {
-      const int nch = min(FFD_CK, Cin - c0);
-#pragma unroll
-      for (int e = 0; e < NI; ++e) {
-        const int i = tid + 256 * e;
-        const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
-        const int yy = y0 + r - 1, xx = x0 + col - 1;
-        float v = 0.f;
-        if (ch < nch && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) {
-          const size_t idx = ((size_t)(c0 + ch) * H2 + yy) * W2 + xx;
-          v = inb[idx];
-        }
-        in_reg[e] = v;
-      }
-      const float4* wsrc = (const float4*)(wpk + (size_t)(c0 / 2) * NTAP * 2 * M32);
-      const int n4 = (nch / 2) * NTAP * 2 * M32 / 4;
-#pragma unroll
-      for (int e = 0; e < NW4; ++e) {
-        const int i = tid + 256 * e;
-        w_reg[e] = i < n4 ? wsrc[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  };
-  auto commit = [&](int buf) {
-    if constexpr (!DMA) {
-      float* si = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW);
-      float4* sw = (float4*)(s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32));
-#pragma unroll
-      for (int e = 0; e < NI; ++e) {
-        const int i = tid + 256 * e;
-        const int col = i % 34, r = (i / 34) % FFD_ROWS, ch = i / (34 * FFD_ROWS);
-        if (ch < FFD_CK) si[(ch * FFD_ROWS + r) * FFD_LDW + col] = in_reg[e];
-      }
-#pragma unroll
-      for (int e = 0; e < NW4; ++e) {
-        const int i = tid + 256 * e;
-        if (i < (FFD_CK / 2) * NTAP * 2 * M32 / 4) sw[i] = w_reg[e];
-      }
-    }
-  };
-  if constexpr (DMA) {
-    issue(0, 0);
-    dpx_wait_vm<0>();
-  } else {
-    fetch(0);
-    commit(0);
-  }
+  issue(0, 0);
+  dpx_wait_vm<0>();
   __syncthreads();
   int buf = 0;
   for (int c0 = 0; c0 < Cin; c0 += FFD_CK, buf ^= 1) {
     const int nch = min(FFD_CK, Cin - c0);                     // even
     const bool more = c0 + FFD_CK < Cin;
-    if (more) {
-      if constexpr (DMA) issue(c0 + FFD_CK, buf ^ 1);
-      else fetch(c0 + FFD_CK);
-    }
+    if (more) issue(c0 + FFD_CK, buf ^ 1);
     const float* sin_b = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW) + (half * FFD_ROWS + 2 * wave) * FFD_LDW + j;
     const float* sw_b = s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32) + half * M32 + j;
-    for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1, NTAP>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * NTAP * 2 * M32);
-    if (more) {
-      if constexpr (DMA) dpx_wait_vm<0>();
-      else commit(buf ^ 1);
-    }
+    for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1, NTAP, DIL>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * NTAP * 2 * M32);
+    if (more) dpx_wait_vm<0>();
     __syncthreads();
   }
   // ---- epilogue: bias, ReLU, store.  C/D layout: col = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cout) ----
@@ -734,17 +683,30 @@ __global__ void k_depth_to_space(const float* __restrict__ x, float* __restrict_
   }
 }
 
-template <int MT, int NTAP>
+template <int MT, int NTAP, int DIL = 1>
 static void launch_conv_generic(int relu, const float* in, float* out, const float* wpk, const float* res, int Cin, int Cout, int nblk, int B,
                                 int H, int W, hipStream_t s) {
   const int tx = (W + FFD_TW - 1) / FFD_TW, ty = (H + FFD_TH - 1) / FFD_TH;
   const dim3 grid(tx * ty, B, nblk);
-  if (res)
-    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, true>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, res);
-  else if (relu)
-    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, true, false, NTAP, false>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+  if constexpr (DIL == 1) {
+    if (res) {
+      DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, true>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, res);
+      return;
+    }
+  }
+  if (relu)
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, true, false, NTAP, false, DIL>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
   else
-    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, false>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, false, DIL>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+}
+template <int MT>
+static void launch_conv_dilated(int dil, int relu, const float* in, float* out, const float* wpk, int Cin, int Cout, int nblk, int B, int H,
+                                int W, hipStream_t s) {
+  switch (dil) {
+    case 2: launch_conv_generic<MT, 9, 2>(relu, in, out, wpk, nullptr, Cin, Cout, nblk, B, H, W, s); break;
+    case 3: launch_conv_generic<MT, 9, 3>(relu, in, out, wpk, nullptr, Cin, Cout, nblk, B, H, W, s); break;
+    default: launch_conv_generic<MT, 9, 4>(relu, in, out, wpk, nullptr, Cin, Cout, nblk, B, H, W, s); break;
+  }
 }
 }  // namespace dpx
 
@@ -763,16 +725,24 @@ extern "C" int dpx_conv_pack(void* packed, const float* w, const float* b, int c
   return launch_status("dpx_conv_pack");
 }
 
-extern "C" int dpx_conv2d(const float* in, float* out, const void* packed, const float* res, int relu, int cin, int cout, int taps, int B,
-                          int H, int W, dpx_stream_t stream) {
+extern "C" int dpx_conv2d(const float* in, float* out, const void* packed, const float* res, int relu, int cin, int cout, int taps,
+                          int dilation, int B, int H, int W, dpx_stream_t stream) {
   DPX_REQUIRE(in && out && packed && B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, "dpx_conv2d: bad arguments");
+  DPX_REQUIRE(dilation >= 1 && dilation <= 4, "dpx_conv2d: dilation must be 1..4 (padding = dilation), got %d", dilation);
+  DPX_REQUIRE(dilation == 1 || (taps == 9 && !res), "dpx_conv2d: dilated layers are 3x3 without a fused residual");
   DPX_REQUIRE(taps == 9 || taps == 1, "dpx_conv2d: taps must be 9 (3x3, pad 1) or 1 (1x1)");
   DPX_REQUIRE(cin % 2 == 0, "dpx_conv2d: the input must have an even number of channels (pad with a zero channel), got %d", cin);
   DPX_REQUIRE(!(res && relu), "dpx_conv2d: residual add and ReLU are not combined (ResBlock: conv-ReLU-conv + x)");
   const int m32 = conv_block_width(cout), nblk = (cout + m32 - 1) / m32;
   hipStream_t s = (hipStream_t)stream;
   const float* wp = (const float*)packed;
-  if (taps == 9) {
+  if (dilation > 1) {
+    switch (m32 / 32) {
+      case 1: launch_conv_dilated<1>(dilation, relu, in, out, wp, cin, cout, nblk, B, H, W, s); break;
+      case 2: launch_conv_dilated<2>(dilation, relu, in, out, wp, cin, cout, nblk, B, H, W, s); break;
+      default: launch_conv_dilated<3>(dilation, relu, in, out, wp, cin, cout, nblk, B, H, W, s); break;
+    }
+  } else if (taps == 9) {
     switch (m32 / 32) {
       case 1: launch_conv_generic<1, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
       case 2: launch_conv_generic<2, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;

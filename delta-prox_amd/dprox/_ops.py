@@ -527,14 +527,14 @@ def conv_pack(w, b, taps):
     return blob
 
 
-def conv2d(x, packed, cout, taps, relu=False, res=None):
-    """stride-1 3x3 (pad 1) / 1x1 convolution on the fp32 matrix cores; optional ReLU or residual add"""
+def conv2d(x, packed, cout, taps, relu=False, res=None, dilation=1):
+    """stride-1 3x3 (pad = dilation) / 1x1 convolution on the fp32 matrix cores; optional ReLU or residual add"""
     require(x, what="conv input")
     B, C, H, W = _shape4(x)
     out = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
     if res is not None:
         require(res, what="conv residual")
-    be.lib().call("dpx_conv2d", ptr(x), ptr(out), ptr(packed), ptr(res), int(bool(relu)), C, cout, taps, B, H, W, be.stream())
+    be.lib().call("dpx_conv2d", ptr(x), ptr(out), ptr(packed), ptr(res), int(bool(relu)), C, cout, taps, int(dilation), B, H, W, be.stream())
     return out
 
 

@@ -418,3 +418,71 @@ class DRUNetDenoiser(Denoiser):
         E[..., h // 2:, :w // 2] = Es[2][..., (-h + h // 2):, :w // 2]
         E[..., h // 2:, w // 2:] = Es[3][..., (-h + h // 2):, (-w + w // 2):]
         return E
+
+
+class IRCNN(nn.Module):
+    """IRCNN body (reference models/network_dncnn.py:74-113): x - net(x) with seven biased 3x3 convolutions of dilation
+    1,2,3,4,3,2,1 -- ``dpx_conv2d`` with the dilation-templated staging tile.  Reference state-dict names."""
+
+    DIL = (1, 2, 3, 4, 3, 2, 1)
+
+    def __init__(self, in_nc=1, out_nc=1, nc=64):
+        super().__init__()
+        chans = [in_nc] + [nc] * 6 + [out_nc]
+        self.in_nc, self.out_nc, self.nc = in_nc, out_nc, nc
+        self.weights = nn.ParameterList([nn.Parameter(torch.zeros(co, ci, 3, 3), requires_grad=False) for ci, co in zip(chans[:-1], chans[1:])])
+        self.biases = nn.ParameterList([nn.Parameter(torch.zeros(co), requires_grad=False) for co in chans[1:]])
+        self._packed = None
+
+    def load_state_dict(self, sd, strict=True):
+        for i in range(7):
+            self.weights[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.weight"]))
+            self.biases[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.bias"]))
+        self._packed = None
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def packed(self):
+        if self._packed is None:
+            pk = []
+            for w, b in zip(self.weights, self.biases):
+                w = w.detach().float()
+                if w.shape[1] % 2:                           # odd input channel count (gray input): zero weights for the pad channel
+                    w = torch.cat([w, torch.zeros_like(w[:, :1])], dim=1)
+                pk.append((ops.conv_pack(w.reshape(w.shape[0], w.shape[1], 9).contiguous(), b.detach().float().contiguous(), 9), int(w.shape[0])))
+            self._packed = pk
+        return self._packed
+
+    def forward(self, x):
+        be.require(x, what="IRCNN input")
+        n = x
+        if n.shape[1] % 2:
+            n = torch.cat([n, torch.zeros_like(n[:, :1])], dim=1).contiguous()
+        for i, ((blob, cout), d) in enumerate(zip(self.packed(), self.DIL)):
+            n = ops.conv2d(n, blob, cout, 9, relu=i < 6, dilation=d)
+            if i < 6 and n.shape[1] % 2:
+                n = torch.cat([n, torch.zeros_like(n[:, :1])], dim=1).contiguous()
+        return ops.lincomb([(1.0, x.contiguous()), (-1.0, n)])
+
+
+class IRCNNDenoiser(Denoiser2D):
+    """reference denoisers/wrapper.py:68-86: 25 IRCNN models, one per noise-level bin ceil(sigma * 255 / 2) - 1; applied band
+    by band.  ``model_path``: a path to (or the dict of) the 25 state dicts keyed "0".."24"."""
+
+    def __init__(self, n_channels, model_path):
+        super().__init__()
+        self.model = IRCNN(in_nc=n_channels, out_nc=n_channels, nc=64)
+        self.model25 = model_path if isinstance(model_path, dict) else torch.load(model_path, map_location="cpu")
+        self.former_idx = None
+
+    def _denoise(self, x, sigma):
+        current_idx = int(np.ceil(sigma.reshape(-1)[:1].cpu().numpy() * 255. / 2.)[0] - 1)      # float32 arithmetic, like the reference
+        if current_idx != self.former_idx:
+            dev = x.device
+            self.model.load_state_dict(self.model25[str(current_idx)], strict=True)
+            self.model = self.model.to(dev)
+        self.former_idx = current_idx
+        return self.model(x)

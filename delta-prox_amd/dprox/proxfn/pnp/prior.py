@@ -9,7 +9,7 @@ import torch.nn as nn
 from ... import _ops as ops
 from ...utils import safe_sqrt
 from ..core import ProxFn
-from .denoisers import DRUNetDenoiser, FFDNetColorDenoiser, FFDNetDenoiser
+from .denoisers import DRUNetDenoiser, FFDNetColorDenoiser, FFDNetDenoiser, IRCNNDenoiser
 
 CACHE_DIR = os.path.join(os.path.expanduser("~"), ".cache", "dprox")
 
@@ -18,7 +18,8 @@ def get_denoiser(type):
     """pretrained weights are read from the reference's cache layout (~/.cache/dprox/pnp_denoisers/*.pth);
     nothing is downloaded."""
     table = {"ffdnet": ("ffdnet_gray.pth", FFDNetDenoiser), "ffdnet_color": ("ffdnet_color.pth", FFDNetColorDenoiser),
-             "drunet": ("drunet_gray.pth", lambda p: DRUNetDenoiser(1, p)), "drunet_color": ("drunet_color.pth", lambda p: DRUNetDenoiser(3, p))}
+             "drunet": ("drunet_gray.pth", lambda p: DRUNetDenoiser(1, p)), "drunet_color": ("drunet_color.pth", lambda p: DRUNetDenoiser(3, p)),
+             "ircnn": ("ircnn_gray.pth", lambda p: IRCNNDenoiser(1, p))}
     if type not in table:
         raise ValueError(f"denoiser {type!r} is not built for the MI355X backend (have {sorted(table)}); "
                          "pass a Denoiser instance instead")

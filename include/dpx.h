@@ -286,14 +286,15 @@ int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void*
 /* Generic convolution layers on the same MFMA kernel (residual U-Net denoisers behind deep_prior: DRUNet,
  * dprox/proxfn/pnp/denoisers/models/network_unet.py:67-117, basicblock.py).  NCHW fp32, stride 1.
  *   dpx_conv_pack  : w [cout][cin][taps] (taps = 9: 3x3 pad 1, taps = 1: 1x1), b nullable -> packed blob (dpx_conv_packed_bytes)
- *   dpx_conv2d     : out = conv(in) [+ b] ; relu != 0: ReLU ; res != NULL: out += res (ResBlock skip); cin must be even
+ *   dpx_conv2d     : out = conv(in) [+ b] ; relu != 0: ReLU ; res != NULL: out += res (ResBlock skip); cin must be even;
+ *                    dilation 1..4 with padding = dilation (3x3 only: IRCNN, models/network_dncnn.py:94-109)
  *   dpx_space_to_depth / dpx_depth_to_space : [B,C,H,W] <-> [B,4C,H/2,W/2], channel c*4 + dy*2 + dx (PixelUnshuffle /
  *     PixelShuffle order): a 2x2 stride-2 convolution is space_to_depth + 1x1 conv, a 2x2 stride-2 transposed
  *     convolution is 1x1 conv + depth_to_space.                                                                       */
 size_t dpx_conv_packed_bytes(int cin, int cout, int taps);
 int dpx_conv_pack(void* packed, const float* w, const float* b, int cin, int cout, int taps, dpx_stream_t stream);
-int dpx_conv2d(const float* in, float* out, const void* packed, const float* res, int relu, int cin, int cout, int taps, int B, int H,
-               int W, dpx_stream_t stream);
+int dpx_conv2d(const float* in, float* out, const void* packed, const float* res, int relu, int cin, int cout, int taps, int dilation,
+               int B, int H, int W, dpx_stream_t stream);
 int dpx_space_to_depth(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
 int dpx_depth_to_space(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
 

@@ -23,7 +23,7 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 import torch
 
-from synthetic import drunet_weights, ffdnet_weights  # seeded stand-ins for the un-downloadable checkpoints (shared with tools/)
+from synthetic import drunet_weights, ffdnet_weights, ircnn_weights  # seeded stand-ins for the un-downloadable checkpoints (shared with tools/)
 import torch.nn.functional as F
 
 __all__ = [
@@ -33,7 +33,7 @@ __all__ = [
     "soft_threshold", "prox", "LeastSquares", "cg", "bdot", "LinearSolveConfig",
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
     "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
-    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior", "doe_otf", "lin_conv_doe", "drunet_weights", "drunet_forward", "DRUNetOracle",
+    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior", "doe_otf", "lin_conv_doe", "drunet_weights", "drunet_forward", "DRUNetOracle", "ircnn_weights", "ircnn_forward", "IRCNNOracle",
 ]
 
 
@@ -774,6 +774,31 @@ class DRUNetOracle:
         E[..., h // 2:, :w // 2] = Es[2][..., (-h + h // 2):, :w // 2]
         E[..., h // 2:, w // 2:] = Es[3][..., (-h + h // 2):, (-w + w // 2):]
         return E
+
+
+def ircnn_forward(x, sd):
+    """IRCNN.forward -- models/network_dncnn.py:94-113: x - model(x), seven 3x3 convolutions with dilations 1,2,3,4,3,2,1
+    (padding = dilation), ReLU between them."""
+    import torch.nn.functional as F
+    n = x
+    for i, d in enumerate((1, 2, 3, 4, 3, 2, 1)):
+        n = F.conv2d(n, sd[f"model.{2 * i}.weight"], sd[f"model.{2 * i}.bias"], padding=d, dilation=d)
+        if i < 6:
+            n = F.relu(n)
+    return x - n
+
+
+class IRCNNOracle:
+    """IRCNNDenoiser -- denoisers/wrapper.py:68-86 (Denoiser2D: band by band): one of 25 models chosen by
+    ceil(sigma * 255 / 2) - 1."""
+
+    def __init__(self, model25):
+        self.model25 = model25
+
+    def __call__(self, x, sigma):
+        idx = int(np.ceil(sigma.reshape(-1)[:1].cpu().numpy() * 255. / 2.)[0] - 1)      # float32 arithmetic, like the reference
+        sd = self.model25[str(idx)]
+        return torch.cat([ircnn_forward(band, sd) for band in x.split(1, dim=1)], dim=1)
 
 
 def psnr(out, gt):

@@ -126,3 +126,13 @@ def drunet_weights(seed=21, in_nc=4, out_nc=3, nc=(64, 128, 256, 512), nb=4, gai
     return sd
 
 
+def ircnn_weights(seed=31, in_nc=1, out_nc=1, nc=64, gain=0.5):
+    """Seeded IRCNN state dict (reference models/network_dncnn.py:94-109: seven biased 3x3 convolutions, dilations
+    1,2,3,4,3,2,1; Conv2d modules at the even indices of `model`)."""
+    rng = np.random.RandomState(seed)
+    chans = [in_nc] + [nc] * 6 + [out_nc]
+    sd = {}
+    for i, (ci, co) in enumerate(zip(chans[:-1], chans[1:])):
+        sd[f"model.{2 * i}.weight"] = torch.from_numpy((rng.randn(co, ci, 3, 3) * gain * np.sqrt(2.0 / (ci * 9))).astype(np.float32))
+        sd[f"model.{2 * i}.bias"] = torch.from_numpy((rng.randn(co) * 0.01).astype(np.float32))
+    return sd

@@ -622,6 +622,18 @@ def g20_drunet():
     wg = T(np.random.RandomState(203).randn(2, 3, 24, 40).astype("float32"))
     (den.denoise(xg, sg) * wg).sum().backward()
     out.update(grad_x=xg.detach(), grad_w=wg, grad_gx=xg.grad, grad_gsigma=sg.grad)
+    # IRCNN (dilated convolutions) behind IRCNNDenoiser: two noise-level bins, two bands
+    from synthetic import ircnn_weights
+    from dprox.proxfn.pnp.denoisers.wrapper import IRCNNDenoiser
+    from dprox.proxfn.pnp.denoisers.models.network_dncnn import IRCNN
+    ird = IRCNNDenoiser.__new__(IRCNNDenoiser)
+    Denoiser2D.__init__(ird)
+    ird.model = IRCNN(in_nc=1, out_nc=1, nc=64)
+    ird.model25 = {str(k): ircnn_weights(31 + k) for k in (3, 12)}
+    ird.former_idx = -1
+    xi = T(np.random.RandomState(204).rand(2, 2, 29, 37).astype("float32"))
+    with torch.no_grad():
+        out.update(ircnn_x=xi, ircnn_y3=ird.denoise(xi, torch.tensor(8 / 255.0)), ircnn_y12=ird.denoise(xi, torch.tensor(25.5 / 255.0)))
     save("g20_drunet", **out)
 
 

@@ -480,6 +480,13 @@ def case_conv2d_generic(device):
         ref = F.relu(ref) if relu else ref
         ref = ref + r if res else ref
         assert_close(y.cpu(), ref.cpu(), 2e-6, f"conv2d cin={cin} cout={cout} taps={taps}")
+    for dil, (cin, cout, H, W, relu) in ((2, (8, 64, 11, 37, True)), (3, (6, 40, 9, 20, False)), (4, (8, 100, 12, 33, True))):
+        w = torch.from_numpy((rng.randn(cout, cin, 3, 3) * 0.2).astype("float32")).to(device)
+        b = torch.from_numpy(rng.randn(cout).astype("float32")).to(device)
+        x = torch.from_numpy(rng.randn(2, cin, H, W).astype("float32")).to(device)
+        y = ops.conv2d(x, ops.conv_pack(w.reshape(cout, cin, 9).contiguous(), b, 9), cout, 9, relu=relu, dilation=dil)
+        ref = F.conv2d(x, w, b, padding=dil, dilation=dil)
+        assert_close(y.cpu(), (F.relu(ref) if relu else ref).cpu(), 2e-6, f"dilated conv2d d={dil}")
     x = torch.from_numpy(rng.randn(2, 6, 8, 10).astype("float32")).to(device)
     assert torch.equal(ops.space_to_depth(x), F.pixel_unshuffle(x, 2))
     assert torch.equal(ops.depth_to_space(F.pixel_unshuffle(x, 2)), x)
@@ -514,6 +521,14 @@ def case_drunet(device):
     (den.denoise(xg, sg) * T(g["grad_w"], device)).sum().backward()
     _assert_grad_close(xg.grad.cpu(), g["grad_gx"], "DRUNet d/dx")
     _assert_grad_close(sg.grad.cpu(), g["grad_gsigma"], "DRUNet d/dsigma", tol=1e-2)
+    # IRCNN: seven dilated 3x3 convolutions (dilation 1,2,3,4,3,2,1), model chosen by the noise-level bin, per band
+    import synthetic
+    from dprox.proxfn.pnp.denoisers import IRCNNDenoiser
+    ird = IRCNNDenoiser(1, {str(k): synthetic.ircnn_weights(31 + k) for k in (3, 12)}).to(device)
+    xi = T(g["ircnn_x"], device)
+    with torch.no_grad():
+        assert_close(ird.denoise(xi, torch.tensor(8 / 255.0, device=device)).cpu(), g["ircnn_y3"], TOL, "IRCNN bin 3")
+        assert_close(ird.denoise(xi, torch.tensor(25.5 / 255.0, device=device)).cpu(), g["ircnn_y12"], TOL, "IRCNN bin 12")
     x = dp.Variable()
     prior = dp.deep_prior(x, denoiser=den)
     assert "deep_prior" in repr(prior)

@@ -297,6 +297,9 @@ def test_g20_drunet():
         assert_close(deng(T(g["gray0_x"]), T(g["gray0_sigma"])), g["gray0_y"], 2e-6)
         xb = torch.from_numpy(np.random.RandomState(201).rand(1, 1, 264, 260).astype("float32"))
         assert_close(deng(xb, T(g["gray1_sigma"])), g["gray1_y"], 2e-6)
+        ir = O.IRCNNOracle({str(k): O.ircnn_weights(31 + k) for k in (3, 12)})
+        assert_close(ir(T(g["ircnn_x"]), torch.tensor(8 / 255.0)), g["ircnn_y3"], 2e-6)
+        assert_close(ir(T(g["ircnn_x"]), torch.tensor(25.5 / 255.0)), g["ircnn_y12"], 2e-6)
 
 
 def test_g15_csmri():
