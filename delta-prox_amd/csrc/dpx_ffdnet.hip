@@ -396,18 +396,21 @@ extern "C" int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, 
 // and the transposing stores (lanes = pixels) are both bank-conflict free with these odd pitches.
 constexpr int WG_TH = 4, WG_TW = 32, WG_PX = WG_TH * WG_TW, WG_GP = 97, WG_AP = 33, WG_AW = WG_TW + 2, WG_AH = WG_TH + 2;
 
+// 2*MT waves per workgroup: wave w owns output-channel slice w % MT and taps [0,5) (w < MT) or [5,9) (w >= MT), so that
+// twice as many waves overlap the (register-staged, transposing) tile loads with the matrix-core work.
 template <int MT>
-__global__ void __launch_bounds__(MT * 64) k_conv3x3_wgrad(const float* __restrict__ G, const float* __restrict__ A, float* __restrict__ part,
-                                                            float* __restrict__ part_b, int Cout, int Cin, int B, int H2, int W2,
-                                                            int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(MT * 128) k_conv3x3_wgrad(const float* __restrict__ G, const float* __restrict__ A, float* __restrict__ part,
+                                                             float* __restrict__ part_b, int Cout, int Cin, int B, int H2, int W2,
+                                                             int tiles_x, int tiles_y) {
   __shared__ float s_g[WG_PX * WG_GP];
   __shared__ float s_a[WG_AH * WG_AW * WG_AP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = MT * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = MT * 128;
   const int j = lane & 31, kk = lane >> 5;
+  const int mtile = wave % MT, t0 = (wave < MT) ? 0 : 5, nt = (wave < MT) ? 5 : 4;
   const int cb = blockIdx.y;                            // block of 32 input channels
-  f32x16 acc[9];
+  f32x16 acc[5];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 5; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
@@ -417,24 +420,44 @@ __global__ void __launch_bounds__(MT * 64) k_conv3x3_wgrad(const float* __restri
     const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
     const int y0 = ty * WG_TH, x0 = tx * WG_TW;
     __syncthreads();                                    // previous tile's operands are no longer needed
-    // G tile: [pixel][co], zero outside the image / beyond Cout
-    for (int i = tid; i < MT * 32 * WG_PX; i += nthr) {
-      const int x = i % WG_TW, y = (i / WG_TW) % WG_TH, co = i / WG_PX;
-      const int yy = y0 + y, xx = x0 + x;
-      float v = 0.f;
-      if (co < Cout && yy < H2 && xx < W2) v = G[(((size_t)b * Cout + co) * H2 + yy) * W2 + xx];
-      s_g[(y * WG_TW + x) * WG_GP + co] = v;
+    // G tile: [pixel][co], zero outside the image / beyond Cout.  Loads are issued in batches of 8 before their LDS
+    // writes so that each batch costs one memory round trip, not eight.
+    constexpr int NG_E = MT * 32 * WG_PX, NA_E = 32 * WG_AH * WG_AW, BATCH = 16;
+    for (int i0 = tid; i0 < NG_E; i0 += nthr * BATCH) {
+      float vals[BATCH];
+#pragma unroll
+      for (int e = 0; e < BATCH; ++e) {
+        const int i = i0 + e * nthr;
+        const int x = i % WG_TW, y = (i / WG_TW) % WG_TH, co = i / WG_PX;
+        const int yy = y0 + y, xx = x0 + x;
+        vals[e] = (i < NG_E && co < Cout && yy < H2 && xx < W2) ? G[(((size_t)b * Cout + co) * H2 + yy) * W2 + xx] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < BATCH; ++e) {
+        const int i = i0 + e * nthr;
+        const int x = i % WG_TW, y = (i / WG_TW) % WG_TH, co = i / WG_PX;
+        if (i < NG_E) s_g[(y * WG_TW + x) * WG_GP + co] = vals[e];
+      }
     }
     // activation tile with a 1-pixel apron: [(row, col)][ci]
-    for (int i = tid; i < 32 * WG_AH * WG_AW; i += nthr) {
-      const int x = i % WG_AW, y = (i / WG_AW) % WG_AH, c = i / (WG_AH * WG_AW);
-      const int yy = y0 + y - 1, xx = x0 + x - 1, ci = cb * 32 + c;
-      float v = 0.f;
-      if (ci < Cin && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) v = A[(((size_t)b * Cin + ci) * H2 + yy) * W2 + xx];
-      s_a[(y * WG_AW + x) * WG_AP + c] = v;
+    for (int i0 = tid; i0 < NA_E; i0 += nthr * BATCH) {
+      float vals[BATCH];
+#pragma unroll
+      for (int e = 0; e < BATCH; ++e) {
+        const int i = i0 + e * nthr;
+        const int x = i % WG_AW, y = (i / WG_AW) % WG_AH, c = i / (WG_AH * WG_AW);
+        const int yy = y0 + y - 1, xx = x0 + x - 1, ci = cb * 32 + c;
+        vals[e] = (i < NA_E && ci < Cin && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) ? A[(((size_t)b * Cin + ci) * H2 + yy) * W2 + xx] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < BATCH; ++e) {
+        const int i = i0 + e * nthr;
+        const int x = i % WG_AW, y = (i / WG_AW) % WG_AH, c = i / (WG_AH * WG_AW);
+        if (i < NA_E) s_a[(y * WG_AW + x) * WG_AP + c] = vals[e];
+      }
     }
     __syncthreads();
-    const float* ga = s_g + wave * 32 + j;
+    const float* ga = s_g + mtile * 32 + j;
 #pragma unroll 4
     for (int s = 0; s < WG_PX / 2; ++s) {
       const int p = 2 * s + kk, py = p / WG_TW, px = p % WG_TW;
@@ -442,9 +465,12 @@ __global__ void __launch_bounds__(MT * 64) k_conv3x3_wgrad(const float* __restri
       bsum += av;
       const float* ap = s_a + (py * WG_AW + px) * WG_AP + j;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float bv = ap[((t / 3) * WG_AW + (t % 3)) * WG_AP];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      for (int t = 0; t < 5; ++t) {
+        if (t < nt) {
+          const int tap = t0 + t;
+          const float bv = ap[((tap / 3) * WG_AW + (tap % 3)) * WG_AP];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
       }
     }
   }
@@ -452,13 +478,15 @@ __global__ void __launch_bounds__(MT * 64) k_conv3x3_wgrad(const float* __restri
   const int CiP = gridDim.y * 32, CoP = MT * 32;
   float* pp = part + (size_t)blockIdx.x * CoP * CiP * 9;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 5; ++t)
+    if (t < nt) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = cb * 32 + j;
-      pp[((size_t)co * CiP + ci) * 9 + t] = acc[t][r];
+      for (int r = 0; r < 16; ++r) {
+        const int co = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = cb * 32 + j;
+        pp[((size_t)co * CiP + ci) * 9 + t0 + t] = acc[t][r];
+      }
     }
-  if (cb == 0) part_b[((size_t)blockIdx.x * CoP + wave * 32 + j) * 2 + kk] = bsum;
+  if (cb == 0 && wave < MT) part_b[((size_t)blockIdx.x * CoP + mtile * 32 + j) * 2 + kk] = bsum;
 }
 
 __global__ void k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ gw, float* __restrict__ gb,
@@ -478,7 +506,7 @@ __global__ void k_wgrad_reduce(const float* __restrict__ part, const float* __re
   }
 }
 
-constexpr int WGRAD_NG = 128;      // persistent workgroups per input-channel block
+constexpr int WGRAD_NG = 168;      // persistent workgroups per input-channel block
 static size_t wgrad_ws_floats(int nc, int in_nc) {
   const int cop = mtiles(nc > 4 * in_nc ? nc : 4 * in_nc) * 32, cip = ((pad_even(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1) + 31) / 32) * 32;
   return (size_t)WGRAD_NG * cop * cip * 9 + (size_t)WGRAD_NG * cop * 2;
@@ -495,9 +523,9 @@ static void launch_wgrad(const float* G, const float* A, float* gw, float* gb, i
   float* part_b = ws + (size_t)WGRAD_NG * CoP * CiP * 9;
   (void)Cin_w;
   switch (MT) {
-    case 1: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<1>), dim3(NG, CB), dim3(64), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
-    case 2: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<2>), dim3(NG, CB), dim3(128), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
-    default: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<3>), dim3(NG, CB), dim3(192), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
+    case 1: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<1>), dim3(NG, CB), dim3(128), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
+    case 2: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<2>), dim3(NG, CB), dim3(256), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
+    default: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<3>), dim3(NG, CB), dim3(384), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
   }
   DPX_LAUNCH("k_wgrad_reduce", k_wgrad_reduce, dim3(grid_for((long)Cout * Cin_w * 9 + Cout, 256, 1024)), dim3(256), 0, s, (const float*)part,
              (const float*)part_b, gw, gb, NG, Cout, Cin_w, CoP, CiP);
