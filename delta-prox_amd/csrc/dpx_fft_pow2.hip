@@ -108,7 +108,7 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
   } else {
     const float2 dd = A.dd[tix];
     const float den = fmaf(rho_b, dd.y, dd.x) + A.eps;
-    const float inv = A.scale / den;
+    const float inv = A.scale * DPX_RCP(den);
     return make_float2((z.x + A.eps_num) * inv, z.y * inv);
   }
 }
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
         const float2 dv = tstage[m * 64 + (offa & 0) + lane];
         const float2 z = cadd(v[m], av[m]);
         const float den = fmaf(rho_b, dv.y, dv.x) + A.eps;
-        const float inv = A.scale / den;
+        const float inv = A.scale * DPX_RCP(den);
         v[m] = make_float2((z.x + A.eps_num) * inv, z.y * inv);
       }
     } else {
