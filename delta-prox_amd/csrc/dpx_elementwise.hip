@@ -538,6 +538,24 @@ extern "C" int dpx_sisr_update(void* FR, const void* FB, int fb_planes, const fl
   return launch_status("dpx_sisr_update");
 }
 
+__global__ void __launch_bounds__(256) k_cplx_scale(float2* __restrict__ out, const float2* __restrict__ a, const float* __restrict__ w,
+                                                    long npb, int w_images) {
+  const int b = blockIdx.y;
+  const float* wb = w + (w_images > 1 ? (long)b * npb : 0L);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < npb; i += (long)gridDim.x * 256L) {
+    const float2 v = a[(long)b * npb + i];
+    const float s = wb[i];
+    out[(long)b * npb + i] = make_float2(s * v.x, s * v.y);
+  }
+}
+
+extern "C" int dpx_cplx_scale(void* out, const void* a, const float* w, int B, long n_per_image, int w_images, dpx_stream_t stream) {
+  DPX_REQUIRE(out && a && w && B > 0 && n_per_image > 0 && (w_images == 1 || w_images == B), "dpx_cplx_scale: bad arguments");
+  DPX_LAUNCH("k_cplx_scale", k_cplx_scale, dim3(grid_for(n_per_image, 256, 2048), B, 1), dim3(256), 0, (hipStream_t)stream, (float2*)out,
+             (const float2*)a, w, n_per_image, w_images);
+  return launch_status("dpx_cplx_scale");
+}
+
 // ---- complex-iterate arithmetic of the CS-MRI solver (contrib/csmri.py:156-171, proxfn/fast/csmri.py:14-25) ----
 struct CplxPack {
   const void* x[4];

@@ -69,6 +69,7 @@ SIGNATURES = {
     "dpx_upsample_zero": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]),
     "dpx_cplx_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
     "dpx_sisr_update": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_cplx_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
     "dpx_csmri_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_int, c_long, c_void_p]),
     "dpx_cplx_lincomb": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_float), c_long, c_void_p]),
     "dpx_bdot": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),

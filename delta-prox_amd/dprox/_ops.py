@@ -554,6 +554,23 @@ def depth_to_space(x):
     return y
 
 
+def cplx_scale(a, w):
+    """w * a with a complex64 and w a real weight (one image or a batch)"""
+    require(a, dtype=torch.complex64, what="cplx_scale input")
+    B = int(a.shape[0])
+    npb = a.numel() // B
+    w = w.to(device=a.device, dtype=torch.float32).contiguous()
+    if w.numel() == npb:
+        wimg = 1
+    elif w.numel() == a.numel():
+        wimg = B
+    else:
+        raise be.DpxError(f"cplx_scale: weight {tuple(w.shape)} matches neither one image nor the batch {tuple(a.shape)}")
+    out = torch.empty_like(a)
+    be.lib().call("dpx_cplx_scale", ptr(out), ptr(a), ptr(w), B, npb, wimg, be.stream())
+    return out
+
+
 def clincomb(terms, out_complex=True):
     """sum_i coef_i * x_i over up to 4 real-fp32 / complex64 tensors of one shape; complex64 result, or its real part
     as fp32 (out_complex=False).  coef_i are python floats."""

@@ -31,3 +31,26 @@ def mosaicing(img):
     from ..linop import Variable, mosaic
     op = mosaic(Variable())
     return op.forward(img.contiguous().float())
+
+
+def masked_fft(arg, mask):
+    """Subsampled centred orthonormal Fourier operator  A x = mask * fft2(x)  with adjoint  A^H y = real(ifft2(mask * y))
+    as a LinOp whose every pass is a HIP kernel (``dpx_cfft2`` + ``dpx_cplx_scale``): the CS-MRI forward model of
+    config 4.  The reference has no such class -- its users write it with eager torch ops through the LinOp plugin
+    protocol (``class MaskedFFT(LinOp)`` in the tests); this is the same operator without PyTorch arithmetic."""
+    from .. import _ops as ops
+    from ..linop import LinOp
+
+    class _MaskedFFT(LinOp):
+        def __init__(self, a, m):
+            super().__init__([a])
+            self.mask = m
+
+        def forward(self, x, **kw):
+            return ops.cplx_scale(ops.cfft2(x, inverse=False, centred=True, ortho=True), self.mask)
+
+        def adjoint(self, y, **kw):
+            z = ops.cfft2(ops.cplx_scale(y.contiguous(), self.mask), inverse=True, centred=True, ortho=True)
+            return ops.clincomb([(1.0, z)], out_complex=False)
+
+    return _MaskedFFT(arg, mask)

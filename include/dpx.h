@@ -152,6 +152,11 @@ int dpx_sisr_update(void* FR, const void* FB, int fb_planes, const float* lam, f
  * (dprox/linop/subsample.py:17-31) and mul_elementwise (dprox/linop/mul.py:46-73); forward == adjoint.          */
 int dpx_mul(const float* x, const float* w, float* out, int B, long n_per_image, int w_images, dpx_stream_t stream);
 
+/* out[b, i] = w[(w_images > 1 ? b : 0), i] * a[b, i] with a, out complex64 and w real fp32: the k-space mask of a
+ * subsampled Fourier operator  A x = mask * fft2(x),  A^H y = ifft2(mask * y)  (the CS-MRI forward model the reference
+ * writes with eager ops, dprox/proxfn/fast/csmri.py:19-23; config 4's operator through the LinOp plugin surface).   */
+int dpx_cplx_scale(void* out, const void* a, const float* w, int B, long n_per_image, int w_images, dpx_stream_t stream);
+
 /* out = sum_i coef[i] * x[i] over n <= 4 operands that are each real (float32) or complex (complex64) arrays of
  * `n_elems` elements; out is complex64 (out_complex = 1) or the REAL PART of the sum as float32 (out_complex = 0).
  * The complex-iterate arithmetic of the CS-MRI solver: `z - u`, `x + u`, `u + x - z` (dprox/contrib/csmri.py:161-169)

@@ -284,6 +284,13 @@ def case_ladmm_cg(device):
     close_on_scale(st[1][1], g["v1"], g["x"], 2 * TOL, "v1")
     close_on_scale(st[2][0], g["u0"], g["x"], 5 * TOL, "u0")
     assert_close(xa.cpu(), g["x_admm"], 2 * TOL, "admm+cg x")
+    # the same operator from the backend's own building blocks (no PyTorch arithmetic in the CG matvec)
+    from dprox.contrib import masked_fft
+    x2 = dp.Variable()
+    fns2 = dp.sum_squares(masked_fft(x2, mask), y) + dp.nonneg(x2) + dp.deep_prior(x2, denoiser=_ffdnet("gray", device))
+    with torch.no_grad():
+        x_native = dp.Problem(fns2, linear_solve_config=cfg).solve(method="ladmm", device=device, x0=x0, rhos=0.5, lams=0.03, max_iter=5)
+    assert_close(x_native.cpu(), g["x"], 2 * TOL, "ladmm x with contrib.masked_fft")
 
 
 def case_unrolled_grads(device):

@@ -53,8 +53,9 @@ if "c4" in which:
         def __init__(self, arg, mask): super().__init__([arg]); self.mask = mask
         def forward(self, x, **kw): return (self.mask * fft2(x)).contiguous()
         def adjoint(self, v, **kw): return ifft2(self.mask * v).real.contiguous()
+    from dprox.contrib import masked_fft
     x = dp.Variable()
-    fns = dp.sum_squares(MaskedFFT(x, mask_d), y_d) + dp.nonneg(x) + dp.deep_prior(x, denoiser=FFDNetDenoiser(O.ffdnet_weights(11, 1, 1, 64, 15)))
+    fns = dp.sum_squares(masked_fft(x, mask_d), y_d) + dp.nonneg(x) + dp.deep_prior(x, denoiser=FFDNetDenoiser(O.ffdnet_weights(11, 1, 1, 64, 15)))
     s = dp.compile(fns, method="ladmm", device=dev, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100))
     x0 = ifft2(y_d).real.contiguous()
     with torch.no_grad():
