@@ -19,11 +19,12 @@ namespace dpx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int FFD_TW = 32;        // tile width  (pixels, = MFMA N)
-constexpr int FFD_TH = 8;         // tile height (rows): 4 waves x 2 rows
+constexpr int FFD_TH = 8;         // default tile height (rows): 4 waves x NR = 2 rows (NR = 4: 16 rows)
 constexpr int FFD_CK = 8;         // input channels staged per chunk
 // staged input tile of a dilation-DIL 3x3 convolution: apron of DIL pixels on every side
-template <int DIL> struct FfdTile {
-  static constexpr int ROWS = FFD_TH + 2 * DIL;                       // 10 / 12 / 14 / 16
+template <int DIL, int NR = 2> struct FfdTile {
+  static constexpr int TH = 4 * NR;                                    // output rows per workgroup
+  static constexpr int ROWS = TH + 2 * DIL;                           // 10 / 12 / 14 / 16 (NR = 2)
   static constexpr int USED = FFD_TW + 2 * DIL;                       // 34 / 36 / 38 / 40 columns read
   static constexpr int LDW = DIL == 1 ? 36 : (DIL == 4 ? 42 : 40);       // row pitch: ROWS * LDW mod 64 = 40 / 32 / 48 / 32 keeps the
                                                                       // two channel halves of a K-step on (mostly) different banks
@@ -155,36 +156,36 @@ __global__ void __launch_bounds__(256) k_ffd_sigma_grad(const float* __restrict_
 
 // NP channel pairs x NTAP taps (9: 3x3 kernel, 1: 1x1 kernel = centre tap only), fully unrolled; the LDS fragments of
 // step k+1 are fetched while step k multiplies
-template <int MT, int NP, int NTAP = 9, int DIL = 1>
-__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __restrict__ sin_b, const float* __restrict__ sw_b) {
+template <int MT, int NP, int NTAP = 9, int DIL = 1, int NR = 2>
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NR], const float* __restrict__ sin_b, const float* __restrict__ sw_b) {
   constexpr int M32 = MT * 32, NS = NP * NTAP;
-  constexpr int FFD_LDW = FfdTile<DIL>::LDW, FFD_ROWS = FfdTile<DIL>::ROWS;
+  constexpr int FFD_LDW = FfdTile<DIL, NR>::LDW, FFD_ROWS = FfdTile<DIL, NR>::ROWS;
   constexpr int T0 = NTAP == 9 ? 0 : 4;                       // first tap index in the 3x3 stencil (1x1: the centre)
-  float a_cur[MT], b_cur[2];
+  float a_cur[MT], b_cur[NR];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) a_cur[mt] = sw_b[mt * 32];
-  b_cur[0] = sin_b[(T0 / 3) * DIL * FFD_LDW + (T0 % 3) * DIL];
-  b_cur[1] = sin_b[((T0 / 3) * DIL + 1) * FFD_LDW + (T0 % 3) * DIL];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) b_cur[r] = sin_b[((T0 / 3) * DIL + r) * FFD_LDW + (T0 % 3) * DIL];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-    float a_nxt[MT], b_nxt[2];
+    float a_nxt[MT], b_nxt[NR];
     if (k + 1 < NS) {
       const int cp = (k + 1) / NTAP, tw = (k + 1) % NTAP, tap = T0 + tw, dy = tap / 3, dx = tap % 3;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a_nxt[mt] = sw_b[(cp * NTAP + tw) * 2 * M32 + mt * 32];
-      b_nxt[0] = sin_b[(2 * cp * FFD_ROWS + dy * DIL) * FFD_LDW + dx * DIL];
-      b_nxt[1] = sin_b[(2 * cp * FFD_ROWS + dy * DIL + 1) * FFD_LDW + dx * DIL];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) b_nxt[r] = sin_b[(2 * cp * FFD_ROWS + dy * DIL + r) * FFD_LDW + dx * DIL];
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[0], acc[mt][0], 0, 0, 0);
-      acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[1], acc[mt][1], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt], b_cur[r], acc[mt][r], 0, 0, 0);
     }
     if (k + 1 < NS) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
-      b_cur[0] = b_nxt[0];
-      b_cur[1] = b_nxt[1];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) b_cur[r] = b_nxt[r];
     }
   }
 }
@@ -195,12 +196,15 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][2], const float* __
 // NTAP = 9: 3x3 / pad 1; NTAP = 1: 1x1 (stride-2 and transposed 2x2 convolutions are 1x1 convolutions around a
 // space-to-depth / depth-to-space rearrangement).  blockIdx.z selects a block of MT*32 output channels (layers wider than
 // 96 channels: DRUNet), each with its own packed weight block.  RES: out = conv + res (residual blocks).
-template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false, int DIL = 1>
-__global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
+// NR = output rows per wave (2 or 4): with 2 output-channel tiles (64-channel layers: gray FFDNet, DRUNet blocks) NR = 4
+// doubles the matrix-core work per weight fragment read and per staged halo row.
+template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false, int DIL = 1, int NR = 2>
+__global__ void __launch_bounds__(256, 2) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x,
                                                        const float* __restrict__ mask) {
   constexpr int M32 = MT * 32;
-  constexpr int FFD_LDW = FfdTile<DIL>::LDW, FFD_ROWS = FfdTile<DIL>::ROWS, FFD_USED = FfdTile<DIL>::USED;
+  constexpr int FFD_LDW = FfdTile<DIL, NR>::LDW, FFD_ROWS = FfdTile<DIL, NR>::ROWS, FFD_USED = FfdTile<DIL, NR>::USED;
+  constexpr int FFD_TH = FfdTile<DIL, NR>::TH;
   __shared__ float s_in[2 * FFD_CK * FFD_ROWS * FFD_LDW];                              // 2 x [ch][row][col]
   __shared__ __attribute__((aligned(16))) float s_w[2 * (FFD_CK / 2) * NTAP * 2 * M32];  // 2 x [pair][tap][half][cout]
   const int co0 = blockIdx.z * M32;                                                    // first output channel of this block
@@ -214,11 +218,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
   const float* maskb = (MASKED || RES) ? mask + (size_t)b * Cout * H2 * W2 : nullptr;   // RES: `mask` carries the residual input
   const float* bias = wpk + (size_t)(Cin / 2) * NTAP * 2 * M32;
 
-  f32x16 acc[MT][2];
+  f32x16 acc[MT][NR];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NR; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
@@ -274,9 +278,9 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
     const int nch = min(FFD_CK, Cin - c0);                     // even
     const bool more = c0 + FFD_CK < Cin;
     if (more) issue(c0 + FFD_CK, buf ^ 1);
-    const float* sin_b = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW) + (half * FFD_ROWS + 2 * wave) * FFD_LDW + j;
+    const float* sin_b = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW) + (half * FFD_ROWS + NR * wave) * FFD_LDW + j;
     const float* sw_b = s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32) + half * M32 + j;
-    for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1, NTAP, DIL>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * NTAP * 2 * M32);
+    for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1, NTAP, DIL, NR>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * NTAP * 2 * M32);
     if (more) dpx_wait_vm<0>();
     __syncthreads();
   }
@@ -286,8 +290,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int yy = y0 + 2 * wave + nt;
+    for (int nt = 0; nt < NR; ++nt) {
+      const int yy = y0 + NR * wave + nt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, co = co0 + cl;
@@ -306,15 +310,19 @@ __global__ void __launch_bounds__(256) k_conv3x3_mfma(const float* __restrict__ 
 template <int MT>
 static void launch_conv(bool relu, const float* in, float* out, const float* wpk, int Cin, int Cout, int B, int H2, int W2, hipStream_t s,
                         const float* mask = nullptr) {
-  const int tx = (W2 + FFD_TW - 1) / FFD_TW, ty = (H2 + FFD_TH - 1) / FFD_TH;
+  constexpr int NR = 2;        // rows per wave (NR = 4 measured: +2 % on 1024^2 gray planes, -5..-13 % on 320^2 planes and DRUNet's deep levels)
+  const int tx = (W2 + FFD_TW - 1) / FFD_TW, ty = (H2 + 4 * NR - 1) / (4 * NR);
   if (mask) {
-    DPX_LAUNCH("k_conv3x3_mfma_bwd", (k_conv3x3_mfma<MT, false, true>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx, mask);
+    DPX_LAUNCH("k_conv3x3_mfma_bwd", (k_conv3x3_mfma<MT, false, true, 9, false, 1, NR>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin,
+               Cout, H2, W2, tx, mask);
     return;
   }
   if (relu)
-    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, true>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx, (const float*)nullptr);
+    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, true, false, 9, false, 1, NR>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout,
+               H2, W2, tx, (const float*)nullptr);
   else
-    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, false>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout, H2, W2, tx, (const float*)nullptr);
+    DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, false, false, 9, false, 1, NR>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout,
+               H2, W2, tx, (const float*)nullptr);
 }
 
 static int layer_cin(int l, int in_nc, int nc) { return l == 0 ? 4 * in_nc + 1 : nc; }
@@ -714,18 +722,19 @@ __global__ void k_depth_to_space(const float* __restrict__ x, float* __restrict_
 template <int MT, int NTAP, int DIL = 1>
 static void launch_conv_generic(int relu, const float* in, float* out, const float* wpk, const float* res, int Cin, int Cout, int nblk, int B,
                                 int H, int W, hipStream_t s) {
-  const int tx = (W + FFD_TW - 1) / FFD_TW, ty = (H + FFD_TH - 1) / FFD_TH;
+  constexpr int NR = 2;
+  const int tx = (W + FFD_TW - 1) / FFD_TW, ty = (H + 4 * NR - 1) / (4 * NR);
   const dim3 grid(tx * ty, B, nblk);
   if constexpr (DIL == 1) {
     if (res) {
-      DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, true>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, res);
+      DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, true, 1, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, res);
       return;
     }
   }
   if (relu)
-    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, true, false, NTAP, false, DIL>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, true, false, NTAP, false, DIL, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
   else
-    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, false, DIL>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, false, DIL, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
 }
 template <int MT>
 static void launch_conv_dilated(int dil, int relu, const float* in, float* out, const float* wpk, int Cin, int Cout, int nblk, int B, int H,
