@@ -32,35 +32,55 @@ def get_denoiser(type):
 
 
 class deep_prior(ProxFn):
+    """Plug-and-play prior ``g(K x)`` whose proximal operator is one call of a denoiser at noise level ``sigma = lam``
+    (``sqrt=True``: ``sigma = sqrt(lam)``).
+
+    Same constructor as the reference (prior.py:40-63).  Behavioural notes for the HIP backend: ``x8`` test-time augmentation
+    is not built; a complex iterate is reduced to its real part by ``dpx_cplx_lincomb`` (prior.py:79); with
+    ``unroll_step=k`` the prior owns k independent copies of the denoiser and uses copy ``self.step`` (set by the solver
+    before every iteration)."""
+
     def __init__(self, linop, denoiser="ffdnet", x8=False, clamp=False, trainable=False, unroll_step=None, sqrt=False):
         super().__init__(linop)
-        self.name = denoiser
-        self.denoiser = get_denoiser(denoiser) if isinstance(denoiser, str) else denoiser
         if x8:
             raise NotImplementedError("x8 test-time augmentation is outside the MI355X hot path")
-        self.x8, self.clamp, self.sqrt = x8, clamp, sqrt
-        if not trainable:
-            self.denoiser.eval()
-            self.denoiser.requires_grad_(False)
+        self.name = denoiser
+        self.x8, self.clamp, self.sqrt = False, bool(clamp), bool(sqrt)
+        self.denoiser = self._resolve(denoiser, trainable)
         self.unroll = unroll_step is not None
         if self.unroll:
-            self.denoisers = nn.ModuleList([copy.deepcopy(self.denoiser) for _ in range(unroll_step)])
+            self.denoisers = nn.ModuleList(copy.deepcopy(self.denoiser) for _ in range(int(unroll_step)))
+
+    @staticmethod
+    def _resolve(denoiser, trainable):
+        """a registry name or a ready ``Denoiser``; frozen (eval mode, no parameter gradients) unless ``trainable``"""
+        net = get_denoiser(denoiser) if isinstance(denoiser, str) else denoiser
+        if not trainable:
+            net.eval()
+            net.requires_grad_(False)
+        return net
+
+    def _active_denoiser(self):
+        return self.denoisers[self.step] if self.unroll else self.denoiser
+
+    def _noise_level(self, lam):
+        return safe_sqrt(lam) if self.sqrt else lam
 
     def eval(self, v=None):
-        if v is None:
-            return super().eval()
-        raise NotImplementedError("deep prior cannot be explictly evaluated")
+        if v is not None:
+            raise NotImplementedError("deep prior cannot be explictly evaluated")
+        return super().eval()                            # nn.Module.eval()
 
     def _prox(self, v: torch.Tensor, lam: torch.Tensor):
-        sigma = safe_sqrt(lam) if self.sqrt else lam
+        """v: [N, C, H, W] or [N, H, W] (treated as one channel); lam: 0-d or [N]"""
+        shape = tuple(v.shape)
+        if torch.is_complex(v):
+            v = ops.clincomb([(1.0, v)], out_complex=False)
         if self.clamp:
             v = v.clamp(0, 1)
-        if torch.is_complex(v):
-            v = ops.clincomb([(1.0, v)], out_complex=False)          # v.real (prior.py:79)
-        inp = v.unsqueeze(1) if v.ndim == 3 else v
-        den = self.denoisers[self.step] if self.unroll else self.denoiser
-        out = den.denoise(inp.contiguous(), sigma)
-        return out.type_as(v).reshape(*v.shape)
+        batch = v if v.ndim == 4 else v.unsqueeze(1)
+        cleaned = self._active_denoiser().denoise(batch.contiguous(), self._noise_level(lam))
+        return cleaned.type_as(v).reshape(shape)
 
     def __repr__(self):
         return f'deep_prior(denoiser="{self.name}", unroll={self.unroll})'
