@@ -23,25 +23,28 @@ from ..utils import to_torch_tensor
 
 
 def expand(r):
-    if len(r.shape) == 1:
-        r = r.view(r.shape[0], 1, 1, 1)
-    return r
+    """[B] -> [B,1,1,1] (broadcast against NCHW); anything else unchanged"""
+    return r.reshape(-1, 1, 1, 1) if r.ndim == 1 else r
+
+
+def _map_leaves(fn, obj):
+    """apply fn to a tensor-like or to every value of a {ProxFn: schedule} dict; None passes through"""
+    if obj is None:
+        return None
+    if isinstance(obj, dict):
+        return {key: _map_leaves(fn, val) for key, val in obj.items()}
+    return fn(obj)
 
 
 def to_tensor(x, batch=False):
-    if isinstance(x, dict):
-        return {k: to_tensor(v, batch) for k, v in x.items()}
-    return to_torch_tensor(x, batch)
+    return _map_leaves(lambda leaf: to_torch_tensor(leaf, batch), x)
 
 
 def to_device(x, device):
-    if x is None:
-        return None
-    if isinstance(x, dict):
-        return {k: to_device(v, device) for k, v in x.items()}
-    if x.is_complex():
-        return x.to(device=device, dtype=torch.complex64)
-    return x.to(device=device, dtype=torch.float32)       # the backend computes in fp32
+    """onto the solver's device in the backend's compute types: fp32, or complex64 for complex iterates"""
+    def place(t):
+        return t.to(device=device, dtype=torch.complex64 if t.is_complex() else torch.float32)
+    return _map_leaves(place, x)
 
 
 def move(*args, device):
@@ -49,19 +52,25 @@ def move(*args, device):
 
 
 def auto_convert_to_tensor(names: List[str], batchify: List[str]):
-    """converts the *keyword* arguments listed in ``names`` (positional ones are left alone, like the reference)"""
-    def outer(fn):
-        def wrapper(*args, **kwargs):
-            for k, v in kwargs.items():
-                if k in names and v is not None:
-                    kwargs[k] = to_tensor(v, batch=k in batchify)
-            return fn(*args, **kwargs)
-        return wrapper
-    return outer
+    """Decorator: the *keyword* arguments listed in ``names`` become tensors (those in ``batchify`` also get the NCHW
+    treatment of ``to_torch_tensor(batch=True)``).  Positional arguments are deliberately left alone -- the reference
+    behaves the same way (base.py:20-33), so ``solve(x0=img)`` and ``solve(img)`` differ for HWC arrays."""
+    wanted, batched = frozenset(names), frozenset(batchify)
+
+    def decorate(fn):
+        def call(*args, **kwargs):
+            converted = {k: (to_tensor(v, batch=k in batched) if (k in wanted and v is not None) else v) for k, v in kwargs.items()}
+            return fn(*args, **converted)
+        return call
+    return decorate
 
 
 def isscalar(x):
-    return np.isscalar(x) or (isinstance(x, torch.Tensor) and len(x.shape) == 0)
+    return np.isscalar(x) or (isinstance(x, torch.Tensor) and x.ndim == 0)
+
+
+def _constant_schedule(value, steps):
+    return to_tensor([float(value)] * steps)
 
 
 class Algorithm(nn.Module):
@@ -130,42 +139,39 @@ class Algorithm(nn.Module):
             visit(fn.linop)
 
     def defaults(self, x0=None, rhos=None, lams=None, max_iter=24):
-        if rhos is None:
-            rhos = 1.0
-        if lams is None:
-            lams = 0.02
+        """rho = 1.0 and lam = 0.02 when absent; scalars become constant schedules of length max_iter; a scalar ``lams``
+        applies to every Psi term, keyed by the ProxFn object (base.py:205-218)"""
+        rhos = 1.0 if rhos is None else rhos
+        lams = 0.02 if lams is None else lams
         if isscalar(rhos):
-            rhos = to_tensor([float(rhos)] * max_iter)
+            rhos = _constant_schedule(rhos, max_iter)
         if isscalar(lams):
-            lams = {fn: to_tensor([float(lams)] * max_iter) for fn in self.psi_fns}
-        lams = {k: to_tensor([float(v)] * max_iter) if isscalar(v) else v for k, v in lams.items()}
+            lams = {fn: lams for fn in self.psi_fns}
+        lams = {fn: (_constant_schedule(val, max_iter) if isscalar(val) else val) for fn, val in lams.items()}
         return x0, rhos, lams, max_iter
 
-    # ---- state packing helpers (used by learned step-size policies) -------------------------------
+    # ---- state <-> one [B, n*C, H, W] tensor (learned step-size policies look at the packed state) -----------
     def pack(self, state):
-        flat = []
-        for s in state:
-            flat += s if isinstance(s, list) else [s]
-        return torch.cat(flat, dim=1)
+        pieces = []
+        for entry in state:
+            pieces.extend(entry if isinstance(entry, (list, tuple)) else [entry])
+        return torch.cat(pieces, dim=1)
 
     def unpack(self, tensor):
-        parts = list(torch.split(tensor, tensor.shape[1] // self.state_dim, dim=1))
-        out, pos = [], 0
-        for d in self.state_split:
-            if d == 1:
-                out.append(parts[pos])
-                pos += 1
+        chunks = list(torch.split(tensor, tensor.shape[1] // self.state_dim, dim=1))
+        state, cursor = [], 0
+        for spec in self.state_split:
+            if isinstance(spec, (list, tuple)):
+                state.append(chunks[cursor:cursor + spec[0]])
+                cursor += spec[0]
             else:
-                out.append(parts[pos:pos + d[0]])
-                pos += d[0]
-        return out
+                state.append(chunks[cursor])
+                cursor += 1
+        return state
 
     @property
     def state_dim(self):
-        n = 0
-        for s in self.state_split:
-            n += sum(s) if isinstance(s, list) else s
-        return n
+        return sum(sum(spec) if isinstance(spec, (list, tuple)) else spec for spec in self.state_split)
 
     @property
     def nparams(self):

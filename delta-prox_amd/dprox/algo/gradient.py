@@ -1,41 +1,59 @@
-"""Proximal gradient descent (reference dprox/algo/pgd.py:8-54):
-x <- prox_psi(x - rho * K^T (K x - b), lam), exactly one smooth and one proxable term."""
-from typing import List
+"""Forward-backward splitting for  f(x) + g(x)  with f smooth and g proxable (reference dprox/algo/pgd.py:8-54):
+
+    x_{k+1} = prox_{lam_k g}( x_k - rho_k * grad f(x_k) )
+
+``grad f`` of a ``sum_squares`` term is two passes of hand-written kernels (K x - b, then K^T) and the forward step is one
+fused AXPY with a per-image step size (``dpx_lincomb``); the backward step is the proxable term's own HIP prox.
+"""
+from typing import List, Sequence
 
 from .. import _ops as ops
 from ..proxfn import ProxFn
 from .driver import Algorithm
 
 
+def _is_smooth(fn: ProxFn) -> bool:
+    """a term takes the gradient role when it exposes ``grad(x)`` (``sum_squares``: proxfn/sum_square.py:29-32)"""
+    return callable(getattr(fn, "grad", None))
+
+
+def forward_step(x, step, gradient):
+    """x - step * gradient with ``step`` a 0-d tensor (shared) or a [B] tensor (per image)"""
+    coef = -step if getattr(step, "ndim", 0) else -float(step)
+    return ops.lincomb([(1.0, x), (coef, gradient)])
+
+
 class ProximalGradientDescent(Algorithm):
+    """state = [x]; exactly two terms, at least one of them smooth (the reference's restriction and error messages)"""
+
     @classmethod
     def partition(cls, prox_fns: List[ProxFn]):
-        if len(prox_fns) != 2:
+        terms: Sequence[ProxFn] = list(prox_fns)
+        if len(terms) != 2:
             raise ValueError("Proximal gradient descent only supports two proximal functions for now.")
-        omega_fns = [fn for fn in prox_fns if hasattr(fn, "grad")]
-        psi_fns = [fn for fn in prox_fns if not any(fn is o for o in omega_fns)]
-        if len(omega_fns) == 0:
+        smooth = [fn for fn in terms if _is_smooth(fn)]
+        if not smooth:
             raise ValueError("Proximal gradient descent requires at least one proximal function is differentiable.")
-        return psi_fns, omega_fns
+        proxable = [fn for fn in terms if all(fn is not s for s in smooth)]
+        return proxable, smooth
 
-    def __init__(self, psi_fns, omega_fns, *args, **kwargs):
+    def __init__(self, psi_fns, omega_fns, *unused_args, **unused_kwargs):
         super().__init__(psi_fns, omega_fns)
-        self.diff_fn = omega_fns[0]
-        self.prox_fn = psi_fns[0]
+        self.diff_fn, self.prox_fn = omega_fns[0], psi_fns[0]      # names kept: user code inspects them on the reference
 
-    def _iter(self, state, rho, lam):
-        x = state[0]
-        g = self.diff_fn.grad(x)
-        v = ops.lincomb([(1.0, x), (-rho if rho.ndim else -float(rho), g)])
-        return [self.prox_fn.prox(v, lam[self.prox_fn])]
-
+    # ---- Algorithm protocol ---------------------------------------------------------------------------------
     def initialize(self, x0):
         return [x0]
+
+    def _iter(self, state, rho, lam):
+        (x,) = state
+        moved = forward_step(x, rho, self.diff_fn.grad(x))
+        return [self.prox_fn.prox(moved, lam[self.prox_fn])]
+
+    @property
+    def nparams(self):
+        return 1 + len(self.psi_fns)
 
     @property
     def state_split(self):
         return [1]
-
-    @property
-    def nparams(self):
-        return len(self.psi_fns) + 1
