@@ -92,7 +92,7 @@ def timing_report(be):
     return out
 
 
-def cpu_baseline(b_host, psf, n_iters=2, sample_b=2):
+def cpu_baseline(b_host, psf, n_iters=4, sample_b=2):
     """reference-schedule oracle on the host cores: `sample_b` of the 8 images, 1 warm-up + n timed iterations"""
     import oracle as O
     bs = b_host[:sample_b].contiguous()
