@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   for (int i = tid; i < H; i += T * COLS) twl[i] = twH[i];
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const char* add = (OP == OP_SOLVE && A.add) ? (const char*)(A.add + ubase) : nullptr;
-  DPX_LDS_BARRIER();
+  // (no barrier here: the twiddle copy is first read in the second pass, behind the first pass's barrier)
 
   // The operator's table values of the tile (SOLVE: the interleaved denominators) are fetched by LDS-DMA into the
   // transform's exchange buffer while it is idle -- between the forward transform's last LDS read and the inverse
