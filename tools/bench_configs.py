@@ -81,6 +81,10 @@ if "c5" in which:
         loss.backward()
         return loss
     dt, loss = timed(step, 5)
+    if os.environ.get("DPX_C5_PROFILE"):
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable(); step(); torch.cuda.synchronize(); pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(30)
     with torch.no_grad():
         dtf, _ = timed(lambda: s.solve(x0=bt, rhos=rhos.detach(), lams={n0: l0.detach(), n1: l1.detach()}), 5)
     print(f"config5 4x3x512x512 unrolled ADMM x10, MSE loss: fwd+bwd {dt*1e3:.2f} ms/step ({1/dt:.1f} steps/s), inference-only forward {dtf*1e3:.2f} ms; "
