@@ -117,6 +117,9 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
 // columns
 // ---------------------------------------------------------------------------------------------
 // DBG (tuning experiments only, default 0): bit0 = skip both transforms, bit1 = skip the operator's table loads
+#ifndef DPX_COLS_BATCH_INNER
+#define DPX_COLS_BATCH_INNER 1
+#endif
 template <int H, int T, int COLS, int OP, int DBG = 0>
 #ifndef DPX_COLS_WPE
 #define DPX_COLS_WPE ((T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for
@@ -146,9 +149,25 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
       // SPEC_TILE / COLS workgroups share a tile (and its 128-byte lines): they are placed 8 block ids apart so that
       // the round-robin block -> XCD assignment puts them on the same XCD, i.e. behind the same L2
       constexpr int SUB = SPEC_TILE / COLS;
-      const int q = bid - p * tiles;
-      j = (q / (8 * SUB)) * 8 + (q % 8);
-      sub_off = (unsigned)(((q % (8 * SUB)) / 8) * COLS);
+      const int tiles_w = Ws / SPEC_TILE, Bn = P / C;   // spectrum tiles per plane, images
+      if (DPX_COLS_BATCH_INNER && (C * tiles_w) % 8 == 0) {
+        // ... and so are the Bn images' workgroups of one (channel, tile): the operator's table (denominators / OTF) is
+        // shared by the batch, and with the images innermost on one XCD its lines are fetched from HBM once instead of
+        // once per image (the streams in between would evict them from the 4 MB L2).
+        // bid = 8 * ((g * Bn + b) * SUB + sub) + xcd,  (channel, tile) = g * 8 + xcd
+        const int GB = (DPX_COLS_BATCH_INNER > 1 && Bn % DPX_COLS_BATCH_INNER == 0) ? DPX_COLS_BATCH_INNER : Bn;   // images per inner group
+        const int per = 8 * GB * SUB, u = bid / per, r = bid - u * per, ng = (C * tiles_w) / 8;
+        const int bg = u / ng, g = u - bg * ng;
+        const int xs = r % 8, sidx = r / 8, ct = g * 8 + xs;
+        const int cch = ct / tiles_w;
+        j = ct - cch * tiles_w;
+        p = (bg * GB + sidx / SUB) * C + cch;
+        sub_off = (unsigned)((sidx % SUB) * COLS);
+      } else {
+        const int q = bid - p * tiles;
+        j = (q / (8 * SUB)) * 8 + (q % 8);
+        sub_off = (unsigned)(((q % (8 * SUB)) / 8) * COLS);
+      }
     }
     ubase = (size_t)p * H * Ws + (size_t)j * H * SPEC_TILE;   // tile-major main part: element (row r, col c) of a tile at r*TILE + c
     off0 = (unsigned)((c / SPEC_TILE) * H * SPEC_TILE + t * SPEC_TILE + (c % SPEC_TILE)) + sub_off;
