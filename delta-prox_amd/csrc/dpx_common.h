@@ -1,6 +1,9 @@
 // Internal helpers shared by the gfx950 kernels of libdpx_hip.so (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef DPX_EMULATED
+#include <hip/hip_ext.h>
+#endif
 
 #include <cstdarg>
 #include <cstdio>
@@ -67,14 +70,19 @@ namespace dpx {
 void set_error(const char* fmt, ...);
 int launch_status(const char* what);   // hipGetLastError() -> DPX_OK / DPX_ERR_LAUNCH
 
-// ---- optional per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) -------
-void timing_begin(const char* name, hipStream_t s);
-void timing_end(hipStream_t s);
-#define DPX_LAUNCH(name, kernel, grid, block, shmem, stream, ...)              \
-  do {                                                                          \
-    ::dpx::timing_begin(name, stream);                                          \
-    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);        \
-    ::dpx::timing_end(stream);                                                  \
+// ---- optional per-kernel timing (bench.py's roofline leg) ------------------------------------------------
+// With timing on, a launch goes through hipExtLaunchKernelGGL with a start / stop event pair attached to the kernel's
+// own dispatch packet: their elapsed time is the kernel's execution time (the dispatch timestamps rocprofv3's kernel
+// trace reports), not the stream-level interval between two separately recorded events, which also contains the
+// two event packets' own dispatch latency (~5-8 us per launch on this stack).
+bool timing_events(const char* name, hipEvent_t* start, hipEvent_t* stop);
+#define DPX_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                                         \
+  do {                                                                                                     \
+    hipEvent_t dpx_e0_, dpx_e1_;                                                                           \
+    if (::dpx::timing_events(name, &dpx_e0_, &dpx_e1_))                                                    \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, dpx_e0_, dpx_e1_, 0, __VA_ARGS__);         \
+    else                                                                                                   \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                 \
   } while (0)
 
 #define DPX_REQUIRE(cond, ...)          \

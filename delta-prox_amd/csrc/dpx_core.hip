@@ -31,7 +31,6 @@ static bool g_timing = false;
 static std::vector<std::string> g_names;
 static std::vector<TimedLaunch> g_launches;
 static std::vector<hipEvent_t> g_free;
-static hipEvent_t g_pending;
 
 static hipEvent_t get_event() {
   if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
@@ -39,18 +38,16 @@ static hipEvent_t get_event() {
   hipEventCreate(&e);
   return e;
 }
-void timing_begin(const char* name, hipStream_t s) {
-  if (!g_timing) return;
+bool timing_events(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_timing) return false;
   int id = -1;
   for (size_t i = 0; i < g_names.size(); ++i) if (g_names[i] == name) { id = (int)i; break; }
   if (id < 0) { g_names.push_back(name); id = (int)g_names.size() - 1; }
   TimedLaunch t{id, get_event(), get_event()};
-  hipEventRecord(t.a, s);
   g_launches.push_back(t);
-}
-void timing_end(hipStream_t s) {
-  if (!g_timing || g_launches.empty()) return;
-  hipEventRecord(g_launches.back().b, s);
+  *start = t.a;
+  *stop = t.b;
+  return true;
 }
 }  // namespace dpx
 

@@ -217,6 +217,8 @@ template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
 
 // ---- events (timing is meaningless under emulation) --------------------------------------------
 typedef int hipEvent_t;
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
+  hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
