@@ -173,12 +173,14 @@ def test_full_size_properties():
     assert torch.equal(out[0], out[1])           # images of a batch never interact
 
 
-@pytest.mark.parametrize("shape", [(2, 1, 256, 256), (1, 3, 512, 512), (2, 3, 256, 1024), (1, 2, 1024, 512), (3, 1, 512, 256)])
+@pytest.mark.parametrize("shape", [(2, 1, 256, 256), (1, 3, 512, 512), (2, 3, 256, 1024), (1, 2, 1024, 512), (3, 1, 512, 256),
+                                   (1, 1, 256, 2048), (5, 3, 1024, 1024)])
 @pytest.mark.parametrize("terms", ["hw", "h+l1", "w+nn", "hw+nn+l1"])
 def test_two_kernel_iteration_matches_stagewise_path(shape, terms):
     """Power-of-two planes run the two-kernel iteration (k_cols_p2 + k_iter_rows_seq: LDS-DMA prefetch, hand-counted
     waits, band partition); the same problem with the fused path switched off runs the independent op-by-op kernels
-    (generic FFT, stencil and prox kernels).  All plane widths (T = 16 / 32 / 64 lane groups), 1..4 Psi terms and
+    (generic FFT, stencil and prox kernels).  All plane widths (T = 16 / 32 / 64 lane groups; W = 2048 runs the ring-buffer row
+    kernel), a batch whose band count is not a power of two, 1..4 Psi terms and
     per-image rho are covered; both paths must agree to fp32 round-off."""
     import dprox as dp
     import synthetic
