@@ -402,23 +402,26 @@ extern "C" int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, 
 // workspace and a second kernel adds them in a fixed order (deterministic, no atomics).
 // LDS: G tile [pixel][co] pitch 97 and activation tile [(row, col)][ci] pitch 33 -- the MFMA operands (lanes = channels)
 // and the transposing stores (lanes = pixels) are both bank-conflict free with these odd pitches.
-constexpr int WG_TH = 4, WG_TW = 32, WG_PX = WG_TH * WG_TW, WG_GP = 97, WG_AP = 33, WG_AW = WG_TW + 2, WG_AH = WG_TH + 2;
+constexpr int WG_TH = 4, WG_TW = 32, WG_PX = WG_TH * WG_TW, WG_GP = 97, WG_AP = 33;
 
-// 2*MT waves per workgroup: wave w owns output-channel slice w % MT and taps [0,5) (w < MT) or [5,9) (w >= MT), so that
-// twice as many waves overlap the (register-staged, transposing) tile loads with the matrix-core work.
-template <int MT>
+// NTAP = 9: 3x3 stencil with dilation DIL (apron of DIL pixels), 2*MT waves per workgroup: wave w owns output-channel slice
+// w % MT and taps [0,5) (w < MT) or [5,9) (w >= MT), so that twice as many waves overlap the (register-staged, transposing)
+// tile loads with the matrix-core work.  NTAP = 1: 1x1 convolution (the strided / transposed 2x2 convolutions of the U-Net
+// around space-to-depth / depth-to-space), MT waves.  The launch covers output channels [co0, co0 + MT*32) of Cout.
+template <int MT, int NTAP = 9, int DIL = 1>
 __global__ void __launch_bounds__(MT * 128) k_conv3x3_wgrad(const float* __restrict__ G, const float* __restrict__ A, float* __restrict__ part,
-                                                             float* __restrict__ part_b, int Cout, int Cin, int B, int H2, int W2,
+                                                             float* __restrict__ part_b, int Cout, int co0, int Cin, int B, int H2, int W2,
                                                              int tiles_x, int tiles_y) {
+  constexpr int PAD = NTAP == 9 ? DIL : 0, AW = WG_TW + 2 * PAD, AH = WG_TH + 2 * PAD, NACC = NTAP == 9 ? 5 : 1;
   __shared__ float s_g[WG_PX * WG_GP];
-  __shared__ float s_a[WG_AH * WG_AW * WG_AP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = MT * 128;
+  __shared__ float s_a[AH * AW * WG_AP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = NTAP == 9 ? MT * 128 : MT * 64;
   const int j = lane & 31, kk = lane >> 5;
-  const int mtile = wave % MT, t0 = (wave < MT) ? 0 : 5, nt = (wave < MT) ? 5 : 4;
+  const int mtile = wave % MT, t0 = (wave < MT) ? 0 : 5, nt = NTAP == 9 ? ((wave < MT) ? 5 : 4) : 1;
   const int cb = blockIdx.y;                            // block of 32 input channels
-  f32x16 acc[5];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < 5; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
@@ -428,15 +431,15 @@ __global__ void __launch_bounds__(MT * 128) k_conv3x3_wgrad(const float* __restr
     const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
     const int y0 = ty * WG_TH, x0 = tx * WG_TW;
     __syncthreads();                                    // previous tile's operands are no longer needed
-    // G tile: [pixel][co], zero outside the image / beyond Cout.  Loads are issued in batches of 8 before their LDS
-    // writes so that each batch costs one memory round trip, not eight.
-    constexpr int NG_E = MT * 32 * WG_PX, NA_E = 32 * WG_AH * WG_AW, BATCH = 16;
+    // G tile: [pixel][co], zero outside the image / beyond Cout.  Loads are issued in batches before their LDS
+    // writes so that each batch costs one memory round trip.
+    constexpr int NG_E = MT * 32 * WG_PX, NA_E = 32 * AH * AW, BATCH = 16;
     for (int i0 = tid; i0 < NG_E; i0 += nthr * BATCH) {
       float vals[BATCH];
 #pragma unroll
       for (int e = 0; e < BATCH; ++e) {
         const int i = i0 + e * nthr;
-        const int x = i % WG_TW, y = (i / WG_TW) % WG_TH, co = i / WG_PX;
+        const int x = i % WG_TW, y = (i / WG_TW) % WG_TH, co = co0 + i / WG_PX;
         const int yy = y0 + y, xx = x0 + x;
         vals[e] = (i < NG_E && co < Cout && yy < H2 && xx < W2) ? G[(((size_t)b * Cout + co) * H2 + yy) * W2 + xx] : 0.f;
       }
@@ -447,21 +450,21 @@ __global__ void __launch_bounds__(MT * 128) k_conv3x3_wgrad(const float* __restr
         if (i < NG_E) s_g[(y * WG_TW + x) * WG_GP + co] = vals[e];
       }
     }
-    // activation tile with a 1-pixel apron: [(row, col)][ci]
+    // activation tile with a PAD-pixel apron: [(row, col)][ci]
     for (int i0 = tid; i0 < NA_E; i0 += nthr * BATCH) {
       float vals[BATCH];
 #pragma unroll
       for (int e = 0; e < BATCH; ++e) {
         const int i = i0 + e * nthr;
-        const int x = i % WG_AW, y = (i / WG_AW) % WG_AH, c = i / (WG_AH * WG_AW);
-        const int yy = y0 + y - 1, xx = x0 + x - 1, ci = cb * 32 + c;
+        const int x = i % AW, y = (i / AW) % AH, c = i / (AH * AW);
+        const int yy = y0 + y - PAD, xx = x0 + x - PAD, ci = cb * 32 + c;
         vals[e] = (i < NA_E && ci < Cin && yy >= 0 && yy < H2 && xx >= 0 && xx < W2) ? A[(((size_t)b * Cin + ci) * H2 + yy) * W2 + xx] : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < BATCH; ++e) {
         const int i = i0 + e * nthr;
-        const int x = i % WG_AW, y = (i / WG_AW) % WG_AH, c = i / (WG_AH * WG_AW);
-        if (i < NA_E) s_a[(y * WG_AW + x) * WG_AP + c] = vals[e];
+        const int x = i % AW, y = (i / AW) % AH, c = i / (AH * AW);
+        if (i < NA_E) s_a[(y * AW + x) * WG_AP + c] = vals[e];
       }
     }
     __syncthreads();
@@ -471,12 +474,12 @@ __global__ void __launch_bounds__(MT * 128) k_conv3x3_wgrad(const float* __restr
       const int p = 2 * s + kk, py = p / WG_TW, px = p % WG_TW;
       const float av = ga[p * WG_GP];
       bsum += av;
-      const float* ap = s_a + (py * WG_AW + px) * WG_AP + j;
+      const float* ap = s_a + (py * AW + px) * WG_AP + j;
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
+      for (int t = 0; t < NACC; ++t) {
         if (t < nt) {
           const int tap = t0 + t;
-          const float bv = ap[((tap / 3) * WG_AW + (tap % 3)) * WG_AP];
+          const float bv = NTAP == 9 ? ap[((tap / 3) * DIL * AW + (tap % 3) * DIL) * WG_AP] : ap[0];
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
         }
       }
@@ -484,59 +487,83 @@ __global__ void __launch_bounds__(MT * 128) k_conv3x3_wgrad(const float* __restr
   }
   // partial sums: part[blockIdx.x][co][ci][tap] over the padded channel counts (MT*32 x gridDim.y*32)
   const int CiP = gridDim.y * 32, CoP = MT * 32;
-  float* pp = part + (size_t)blockIdx.x * CoP * CiP * 9;
+  float* pp = part + (size_t)blockIdx.x * CoP * CiP * NTAP;
 #pragma unroll
-  for (int t = 0; t < 5; ++t)
+  for (int t = 0; t < NACC; ++t)
     if (t < nt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = cb * 32 + j;
-        pp[((size_t)co * CiP + ci) * 9 + t0 + t] = acc[t][r];
+        pp[((size_t)co * CiP + ci) * NTAP + t0 + t] = acc[t][r];
       }
     }
   if (cb == 0 && wave < MT) part_b[((size_t)blockIdx.x * CoP + mtile * 32 + j) * 2 + kk] = bsum;
 }
 
+// gw[co0 + co][ci][tap] (co < CoN) = sum over the NG partial slices, in a fixed order
 __global__ void k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ gw, float* __restrict__ gb,
-                               int NG, int Cout, int Cin, int CoP, int CiP) {
-  const long nw = (long)Cout * Cin * 9;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + Cout; i += (long)gridDim.x * blockDim.x) {
+                               int NG, int CoN, int co0, int Cin, int CoP, int CiP, int ntap) {
+  const long nw = (long)CoN * Cin * ntap;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + CoN; i += (long)gridDim.x * blockDim.x) {
     float acc = 0.f;
     if (i < nw) {
-      const int t = (int)(i % 9), ci = (int)((i / 9) % Cin), co = (int)(i / (9L * Cin));
-      for (int g = 0; g < NG; ++g) acc += part[(((size_t)g * CoP + co) * CiP + ci) * 9 + t];
-      if (gw) gw[i] = acc;
+      const int t = (int)(i % ntap), ci = (int)((i / ntap) % Cin), co = (int)(i / ((long)ntap * Cin));
+      for (int g = 0; g < NG; ++g) acc += part[(((size_t)g * CoP + co) * CiP + ci) * ntap + t];
+      if (gw) gw[(long)co0 * Cin * ntap + i] = acc;
     } else if (gb) {
       const int co = (int)(i - nw);
       for (int g = 0; g < NG; ++g) acc += part_b[((size_t)g * CoP + co) * 2] + part_b[((size_t)g * CoP + co) * 2 + 1];
-      gb[co] = acc;
+      gb[co0 + co] = acc;
     }
   }
 }
 
-constexpr int WGRAD_NG = 168;      // persistent workgroups per input-channel block
+constexpr int WGRAD_NG = 168;      // persistent workgroups per input-channel block (FFDNet layers)
 static size_t wgrad_ws_floats(int nc, int in_nc) {
   const int cop = mtiles(nc > 4 * in_nc ? nc : 4 * in_nc) * 32, cip = ((pad_even(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1) + 31) / 32) * 32;
   return (size_t)WGRAD_NG * cop * cip * 9 + (size_t)WGRAD_NG * cop * 2;
 }
 
-// G: [B][Cout][H2][W2] gradient w.r.t. the layer's pre-activation output; A: [B][Cin_a][H2][W2] the layer's input
-static void launch_wgrad(const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Cin_a, int B, int H2, int W2,
-                         float* ws, hipStream_t s) {
-  const int tx = (W2 + WG_TW - 1) / WG_TW, ty = (H2 + WG_TH - 1) / WG_TH;
-  const int MT = mtiles(Cout), CB = (Cin_w + 31) / 32, CoP = MT * 32, CiP = CB * 32;
-  int NG = WGRAD_NG;
-  if (NG > B * tx * ty) NG = B * tx * ty;
-  float* part = ws;
-  float* part_b = ws + (size_t)WGRAD_NG * CoP * CiP * 9;
-  (void)Cin_w;
+template <int NTAP, int DIL>
+static void launch_wgrad_mt(int MT, dim3 grid, hipStream_t s, const float* G, const float* A, float* part, float* part_b, int Cout, int co0,
+                            int Cin_a, int B, int H2, int W2, int tx, int ty) {
+  constexpr int TPW = NTAP == 9 ? 128 : 64;
   switch (MT) {
-    case 1: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<1>), dim3(NG, CB), dim3(128), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
-    case 2: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<2>), dim3(NG, CB), dim3(256), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
-    default: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<3>), dim3(NG, CB), dim3(384), 0, s, G, A, part, part_b, Cout, Cin_a, B, H2, W2, tx, ty); break;
+    case 1: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<1, NTAP, DIL>), grid, dim3(TPW), 0, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty); break;
+    case 2: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<2, NTAP, DIL>), grid, dim3(2 * TPW), 0, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty); break;
+    default: DPX_LAUNCH("k_conv3x3_wgrad", (k_conv3x3_wgrad<3, NTAP, DIL>), grid, dim3(3 * TPW), 0, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty); break;
   }
-  DPX_LAUNCH("k_wgrad_reduce", k_wgrad_reduce, dim3(grid_for((long)Cout * Cin_w * 9 + Cout, 256, 1024)), dim3(256), 0, s, (const float*)part,
-             (const float*)part_b, gw, gb, NG, Cout, Cin_w, CoP, CiP);
+}
+
+// persistent workgroups per input-channel block of the generic layer: about WGRAD_NG workgroups in total
+static int wgrad_ng(int cin, long ntiles) {
+  const int CB = (cin + 31) / 32;
+  int ng = WGRAD_NG / CB;
+  if (ng < 8) ng = 8;
+  return (long)ng > ntiles ? (int)ntiles : ng;
+}
+
+// G: [B][Cout][H2][W2] gradient w.r.t. the layer's pre-activation output; A: [B][Cin_a][H2][W2] the layer's input;
+// gw: [Cout][Cin_w][ntap].  Output channels are processed in blocks of <= 96 that reuse the workspace.
+static void launch_wgrad(const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Cin_a, int B, int H2, int W2,
+                         float* ws, hipStream_t s, int ntap = 9, int dil = 1, int ng_max = WGRAD_NG) {
+  const int tx = (W2 + WG_TW - 1) / WG_TW, ty = (H2 + WG_TH - 1) / WG_TH;
+  const int CB = (Cin_w + 31) / 32, CiP = CB * 32;
+  int NG = ng_max;
+  if (NG > B * tx * ty) NG = B * tx * ty;
+  for (int co0 = 0; co0 < Cout; co0 += 96) {
+    const int CoN = Cout - co0 < 96 ? Cout - co0 : 96, MT = mtiles(CoN), CoP = MT * 32;
+    float* part = ws;
+    float* part_b = ws + (size_t)NG * CoP * CiP * ntap;
+    const dim3 grid(NG, CB);
+    if (ntap == 1) launch_wgrad_mt<1, 1>(MT, grid, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty);
+    else if (dil == 1) launch_wgrad_mt<9, 1>(MT, grid, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty);
+    else if (dil == 2) launch_wgrad_mt<9, 2>(MT, grid, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty);
+    else if (dil == 3) launch_wgrad_mt<9, 3>(MT, grid, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty);
+    else launch_wgrad_mt<9, 4>(MT, grid, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty);
+    DPX_LAUNCH("k_wgrad_reduce", k_wgrad_reduce, dim3(grid_for((long)CoN * Cin_w * ntap + CoN, 256, 1024)), dim3(256), 0, s, (const float*)part,
+               (const float*)part_b, gw, gb, NG, CoN, co0, Cin_w, CoP, CiP, ntap);
+  }
 }
 
 // ---- training variants: forward that keeps every layer's output, backward-data through the whole stack ----------------
@@ -807,4 +834,24 @@ extern "C" int dpx_depth_to_space(const float* x, float* y, int B, int C, int H,
   DPX_LAUNCH("k_depth_to_space", k_depth_to_space, dim3(grid_for((long)B * C * 4 * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y,
              B, C, H, W);
   return launch_status("dpx_depth_to_space");
+}
+
+// ---- weight / bias gradients of one generic layer (trainable U-Net / IRCNN denoisers inside `unroll`) ----------------
+static size_t conv_wgrad_floats(int cin, int cout, int taps, int B, int H, int W) {
+  const long ntiles = (long)B * ((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH);
+  const int NG = wgrad_ng(cin, ntiles), CoP = mtiles(cout < 96 ? cout : 96) * 32, CiP = ((cin + 31) / 32) * 32;
+  return (size_t)NG * CoP * CiP * taps + (size_t)NG * CoP * 2;
+}
+extern "C" size_t dpx_conv2d_wgrad_ws_bytes(int cin, int cout, int taps, int B, int H, int W) {
+  return conv_wgrad_floats(cin, cout, taps, B, H, W) * sizeof(float);
+}
+
+extern "C" int dpx_conv2d_wgrad(const float* g, const float* a, float* gw, float* gb, int cin, int cout, int taps, int dilation, int B, int H,
+                                int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(g && a && ws && (gw || gb), "dpx_conv2d_wgrad: null pointer");
+  DPX_REQUIRE(cin > 0 && cout > 0 && B > 0 && H > 0 && W > 0 && (taps == 9 || taps == 1), "dpx_conv2d_wgrad: bad arguments");
+  DPX_REQUIRE(dilation >= 1 && dilation <= 4 && (taps == 9 || dilation == 1), "dpx_conv2d_wgrad: dilation 1..4 (3x3 only)");
+  const long ntiles = (long)B * ((W + WG_TW - 1) / WG_TW) * ((H + WG_TH - 1) / WG_TH);
+  launch_wgrad(g, a, gw, gb, cout, cin, cin, B, H, W, (float*)ws, (hipStream_t)stream, taps, dilation, wgrad_ng(cin, ntiles));
+  return launch_status("dpx_conv2d_wgrad");
 }

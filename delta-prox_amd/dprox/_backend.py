@@ -98,6 +98,8 @@ SIGNATURES = {
     "dpx_conv_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dpx_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_conv2d_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dpx_conv2d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_depth_to_space": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_acts_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

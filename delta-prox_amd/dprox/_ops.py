@@ -538,6 +538,21 @@ def conv2d(x, packed, cout, taps, relu=False, res=None, dilation=1):
     return out
 
 
+def conv2d_wgrad(g, a, taps, dilation=1, want_bias=False):
+    """weight (and bias) gradient of one conv2d layer: g [B,cout,H,W] gradient of the pre-activation output, a [B,cin,H,W] the
+    layer's input -> gw [cout, cin, taps] (, gb [cout])"""
+    require(g, what="conv output gradient")
+    require(a, what="conv input")
+    B, cout, H, W = _shape4(g)
+    cin = int(a.shape[1])
+    L = be.lib()
+    gw = torch.empty(cout, cin, taps, dtype=torch.float32, device=g.device)
+    gb = torch.empty(cout, dtype=torch.float32, device=g.device) if want_bias else None
+    ws = workspace("conv_wgrad", L.query("dpx_conv2d_wgrad_ws_bytes", cin, cout, taps, B, H, W), g.device)
+    L.call("dpx_conv2d_wgrad", ptr(g), ptr(a), ptr(gw), ptr(gb), cin, cout, taps, int(dilation), B, H, W, ptr(ws), be.stream())
+    return gw, gb
+
+
 def space_to_depth(x):
     require(x, what="space_to_depth input")
     B, C, H, W = _shape4(x)

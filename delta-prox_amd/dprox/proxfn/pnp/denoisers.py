@@ -202,30 +202,36 @@ class FFDNetColorDenoiser(Denoiser):
 
 
 class _ConvFn(torch.autograd.Function):
-    """one dpx_conv2d layer (optional fused ReLU / residual) with a hand-written backward w.r.t. its inputs: the
-    transposed convolution is the same kernel on flipped / transposed weights (packed once per layer), the ReLU mask comes
-    from the saved output"""
+    """one dpx_conv2d layer (optional fused ReLU / residual) with a hand-written backward: the transposed convolution is the
+    same kernel on flipped / transposed weights (packed once per weight version), the ReLU mask comes from the saved
+    output, and -- when ``weight`` (the layer's weights in kernel form [cout, cin, taps], an autograd view of the
+    parameter) is given -- the weight gradient is the pixels-as-K GEMM ``dpx_conv2d_wgrad`` on the saved input"""
 
     @staticmethod
-    def forward(ctx, x, res, fwd, bwd, relu):
+    def forward(ctx, x, res, weight, fwd, bwd, relu):
         blob, cout, taps = fwd
-        y = ops.conv2d(x.contiguous(), blob, cout, taps, relu=relu, res=None if res is None else res.contiguous())
-        ctx.bwd, ctx.relu, ctx.has_res = bwd, relu, res is not None
-        ctx.save_for_backward(y if relu else x.new_empty(0))
+        x = x.contiguous()
+        y = ops.conv2d(x, blob, cout, taps, relu=relu, res=None if res is None else res.contiguous())
+        ctx.bwd, ctx.relu, ctx.has_res, ctx.taps = bwd, relu, res is not None, taps
+        train_w = weight is not None and weight.requires_grad
+        ctx.save_for_backward(y if relu else x.new_empty(0), x if train_w else x.new_empty(0))
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         gp = g
+        y, x = ctx.saved_tensors
         if ctx.relu:
-            (y,) = ctx.saved_tensors
             gp, _ = ops.prox_bwd(be.PROX_NONNEG, y, g, torch.zeros((), device=g.device), 1.0, None, want_dlam=False)   # g * [y > 0]
+        gw = ops.conv2d_wgrad(gp, x, ctx.taps)[0] if ctx.needs_input_grad[2] else None
         blob_t, cin, taps = ctx.bwd
-        if gp.shape[1] % 2:
-            gp = torch.cat([gp, torch.zeros_like(gp[:, :1])], dim=1).contiguous()
-        gx = ops.conv2d(gp, blob_t, cin, taps) if ctx.needs_input_grad[0] else None
-        return gx, (g if ctx.has_res else None), None, None, None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if gp.shape[1] % 2:
+                gp = torch.cat([gp, torch.zeros_like(gp[:, :1])], dim=1).contiguous()
+            gx = ops.conv2d(gp, blob_t, cin, taps)
+        return gx, (g if ctx.has_res else None), gw, None, None, None
 
 
 class _S2DFn(torch.autograd.Function):
@@ -263,8 +269,9 @@ class UNetRes(nn.Module):
     3 x (2x2 stride-2 transposed conv + nb ResBlocks), tail conv; no biases.  Every convolution runs on the fp32-MFMA
     kernel behind ``dpx_conv2d`` (ReLU / residual add fused into the epilogue); the strided / transposed 2x2 convolutions
     are 1x1 convolutions around ``dpx_space_to_depth`` / ``dpx_depth_to_space``.  Parameters keep the reference's
-    state-dict names, so its checkpoints load unchanged.  Differentiable w.r.t. its input (frozen weights): every layer's
-    backward is the same kernel on transposed weights (``_ConvFn``)."""
+    state-dict names, so its checkpoints load unchanged.  Differentiable w.r.t. its input (every layer's backward is the same
+    kernel on transposed weights) and, after ``requires_grad_(True)`` / ``deep_prior(trainable=True)``, w.r.t. its weights
+    (``dpx_conv2d_wgrad``), see ``_ConvFn``."""
 
     def __init__(self, in_nc=1, out_nc=1, nc=(64, 128, 256, 512), nb=4, act_mode="R", downsample_mode="strideconv", upsample_mode="convtranspose"):
         super().__init__()
@@ -314,6 +321,21 @@ class UNetRes(nn.Module):
     def _w(self, name):
         return self.params[name.replace(".", "/")].detach().float()
 
+    def _check_version(self):
+        """the packed blobs follow the parameters (an optimizer step bumps their version counters)"""
+        ver = sum(p._version for p in self.params.values())
+        if ver != getattr(self, "_pack_version", None):
+            self._packed, self._packed_T, self._pack_version = None, None, ver
+
+    def _kernel_form(self, name):
+        """the parameter as the [cout, cin, taps] tensor dpx_conv2d sees (an autograd view: gradients flow back to it)"""
+        w = self.params[name.replace(".", "/")]
+        if w.shape[-1] == 3:
+            return w.reshape(w.shape[0], w.shape[1], 9)
+        if name.startswith("m_down"):
+            return w.reshape(w.shape[0], w.shape[1] * 4, 1)
+        return w.permute(1, 2, 3, 0).reshape(w.shape[1] * 4, w.shape[0], 1)
+
     def packed(self):
         if self._packed is None:
             pk = {}
@@ -352,7 +374,8 @@ class UNetRes(nn.Module):
 
     def _conv(self, x, name, relu=False, res=None):
         if self._diff:
-            return _ConvFn.apply(x, res, self.packed()[name], self.packed_T()[name], relu)
+            w = self._kernel_form(name) if self.params[name.replace(".", "/")].requires_grad else None
+            return _ConvFn.apply(x, res, w, self.packed()[name], self.packed_T()[name], relu)
         blob, cout, taps = self.packed()[name]
         return ops.conv2d(x, blob, cout, taps, relu=relu, res=res)
 
@@ -364,7 +387,8 @@ class UNetRes(nn.Module):
 
     def forward(self, x0):
         be.require(x0, what="UNetRes input")
-        self._diff = torch.is_grad_enabled() and x0.requires_grad
+        self._check_version()
+        self._diff = torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in self.params.values()))
         if self._diff:
             s2d, d2s, add = _S2DFn.apply, _D2SFn.apply, _AddFn.apply
         else:

@@ -53,11 +53,14 @@ class deep_prior(ProxFn):
 
     @staticmethod
     def _resolve(denoiser, trainable):
-        """a registry name or a ready ``Denoiser``; frozen (eval mode, no parameter gradients) unless ``trainable``"""
+        """a registry name or a ready ``Denoiser``; frozen (eval mode, no parameter gradients) unless ``trainable``
+        (prior.py:57-60)"""
         net = get_denoiser(denoiser) if isinstance(denoiser, str) else denoiser
         if not trainable:
             net.eval()
             net.requires_grad_(False)
+        else:
+            net.requires_grad_(True)                       # the HIP modules create their parameters frozen
         return net
 
     def _active_denoiser(self):

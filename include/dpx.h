@@ -300,6 +300,14 @@ size_t dpx_conv_packed_bytes(int cin, int cout, int taps);
 int dpx_conv_pack(void* packed, const float* w, const float* b, int cin, int cout, int taps, dpx_stream_t stream);
 int dpx_conv2d(const float* in, float* out, const void* packed, const float* res, int relu, int cin, int cout, int taps, int dilation,
                int B, int H, int W, dpx_stream_t stream);
+/* weight / bias gradients of one dpx_conv2d layer (autograd of nn.Conv2d / ConvTranspose2d in the reference's trainable
+ * denoisers, basicblock.py:61-98 under `specialize(..., 'unroll')` with deep_prior(trainable=True)):
+ *   gw[co][ci][tap] = sum_{b,y,x} g[b][co][y][x] * a[b][ci][y + (tap/3 - 1) d][x + (tap%3 - 1) d],  gb[co] = sum g[b][co]
+ * g = gradient w.r.t. the layer's pre-activation output, a = the layer's input; either of gw / gb may be NULL.
+ * Deterministic (fixed-order two-stage reduction, no atomics).                                                         */
+size_t dpx_conv2d_wgrad_ws_bytes(int cin, int cout, int taps, int B, int H, int W);
+int dpx_conv2d_wgrad(const float* g, const float* a, float* gw, float* gb, int cin, int cout, int taps, int dilation,
+                     int B, int H, int W, void* ws, dpx_stream_t stream);
 int dpx_space_to_depth(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
 int dpx_depth_to_space(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
 

@@ -622,6 +622,19 @@ def g20_drunet():
     wg = T(np.random.RandomState(203).randn(2, 3, 24, 40).astype("float32"))
     (den.denoise(xg, sg) * wg).sum().backward()
     out.update(grad_x=xg.detach(), grad_w=wg, grad_gx=xg.grad, grad_gsigma=sg.grad)
+    # weight gradients of the same loss (trainable denoiser under `unroll`): the two small layers in full, 8x8 corners of one
+    # layer of every kind (ResBlock conv at each level, strided 2x2, transposed 2x2) and the L2 norm of every parameter's gradient
+    net.requires_grad_(True)
+    (den.denoise(xg.detach(), sg.detach()) * wg).sum().backward()
+    sd_grads = {n: p.grad for n, p in net.named_parameters()}
+    out["wgrad_names"] = np.array(sorted(sd_grads))
+    out["wgrad_norms"] = np.array([float(sd_grads[n].norm()) for n in sorted(sd_grads)], dtype=np.float64)
+    for n in ("m_head.weight", "m_tail.weight"):
+        out["wgrad_full_" + n] = sd_grads[n]
+    for n in ("m_down1.0.res.0.weight", "m_down2.4.weight", "m_down3.2.res.2.weight", "m_body.1.res.2.weight", "m_up3.0.weight",
+              "m_up2.3.res.0.weight", "m_up1.0.weight"):
+        out["wgrad_corner_" + n] = sd_grads[n][:8, :8].contiguous()
+    net.requires_grad_(False)
     # IRCNN (dilated convolutions) behind IRCNNDenoiser: two noise-level bins, two bands
     from synthetic import ircnn_weights
     from dprox.proxfn.pnp.denoisers.wrapper import IRCNNDenoiser

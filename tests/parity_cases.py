@@ -494,6 +494,19 @@ def case_conv2d_generic(device):
         y = ops.conv2d(x, ops.conv_pack(w.reshape(cout, cin, 9).contiguous(), b, 9), cout, 9, relu=relu, dilation=dil)
         ref = F.conv2d(x, w, b, padding=dil, dilation=dil)
         assert_close(y.cpu(), (F.relu(ref) if relu else ref).cpu(), 2e-6, f"dilated conv2d d={dil}")
+    # weight / bias gradients (dpx_conv2d_wgrad) against PyTorch's autograd of the same fp32 convolution: 3x3 / 1x1, dilation,
+    # odd channel counts, more than 96 output channels (blocks), image sizes that are not multiples of the 4x32 pixel tile
+    for (cin, cout, taps, dil, H, W) in ((5, 7, 9, 1, 9, 37), (8, 130, 9, 1, 6, 40), (34, 20, 1, 1, 10, 33), (6, 12, 9, 2, 11, 21),
+                                         (4, 40, 9, 3, 13, 9), (3, 9, 9, 4, 12, 35)):
+        k = 3 if taps == 9 else 1
+        w = torch.from_numpy((rng.randn(cout, cin, k, k) * 0.2).astype("float32")).requires_grad_(True)
+        b = torch.from_numpy(rng.randn(cout).astype("float32")).requires_grad_(True)
+        a = torch.from_numpy(rng.randn(2, cin, H, W).astype("float32"))
+        gout = torch.from_numpy(rng.randn(2, cout, H, W).astype("float32"))
+        (F.conv2d(a, w, b, padding=(k // 2) * dil, dilation=dil) * gout).sum().backward()
+        gw, gb = ops.conv2d_wgrad(gout.to(device), a.to(device), taps, dilation=dil, want_bias=True)
+        assert_close(gw.cpu().reshape(cout, cin, k, k), w.grad, 5e-6, f"conv2d_wgrad cin={cin} cout={cout} taps={taps} d={dil}")
+        assert_close(gb.cpu(), b.grad, 5e-6, f"conv2d_wgrad bias cin={cin} cout={cout}")
     x = torch.from_numpy(rng.randn(2, 6, 8, 10).astype("float32")).to(device)
     assert torch.equal(ops.space_to_depth(x), F.pixel_unshuffle(x, 2))
     assert torch.equal(ops.depth_to_space(F.pixel_unshuffle(x, 2)), x)
@@ -528,6 +541,21 @@ def case_drunet(device):
     (den.denoise(xg, sg) * T(g["grad_w"], device)).sum().backward()
     _assert_grad_close(xg.grad.cpu(), g["grad_gx"], "DRUNet d/dx")
     _assert_grad_close(sg.grad.cpu(), g["grad_gsigma"], "DRUNet d/dsigma", tol=1e-2)
+    # weight gradients (trainable denoiser): dpx_conv2d_wgrad for every layer kind -- 3x3 with 64..512 channels (output
+    # channels in blocks of 96), the strided 2x2 (1x1 over space-to-depth) and transposed 2x2 (1x1 before depth-to-space)
+    den.model.requires_grad_(True)
+    (den.denoise(T(g["grad_x"], device), torch.tensor([0.05, 0.2], device=device)) * T(g["grad_w"], device)).sum().backward()
+    grads = {n: den.model.params[n.replace(".", "/")].grad.cpu() for n in den.model._names}
+    den.model.requires_grad_(False)
+    for n in ("m_head.weight", "m_tail.weight"):
+        _assert_grad_close(grads[n], g["wgrad_full_" + n], f"DRUNet dW {n}")
+    for key in g:
+        if key.startswith("wgrad_corner_"):
+            n = key[len("wgrad_corner_"):]
+            _assert_grad_close(grads[n][:8, :8], g[key], f"DRUNet dW {n} [:8,:8]")
+    norms = dict(zip([str(n) for n in g["wgrad_names"]], g["wgrad_norms"]))
+    for n, gr in grads.items():
+        assert abs(float(gr.norm()) - norms[n]) <= 2e-3 * norms[n], (n, float(gr.norm()), norms[n])
     # IRCNN: seven dilated 3x3 convolutions (dilation 1,2,3,4,3,2,1), model chosen by the noise-level bin, per band
     import synthetic
     from dprox.proxfn.pnp.denoisers import IRCNNDenoiser

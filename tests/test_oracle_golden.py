@@ -300,6 +300,14 @@ def test_g20_drunet():
         ir = O.IRCNNOracle({str(k): O.ircnn_weights(31 + k) for k in (3, 12)})
         assert_close(ir(T(g["ircnn_x"]), torch.tensor(8 / 255.0)), g["ircnn_y3"], 2e-6)
         assert_close(ir(T(g["ircnn_x"]), torch.tensor(25.5 / 255.0)), g["ircnn_y12"], 2e-6)
+    # weight gradients (reference autograd) through the restatement
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.drunet_weights(21, 4, 3).items()}
+    (O.DRUNetOracle(sd)(T(g["grad_x"]), torch.tensor([0.05, 0.2])) * T(g["grad_w"])).sum().backward()
+    for n in ("m_head.weight", "m_tail.weight"):
+        assert_close(sd[n].grad, g["wgrad_full_" + n], 2e-5)
+    norms = dict(zip([str(n) for n in g["wgrad_names"]], g["wgrad_norms"]))
+    for n, v in sd.items():
+        assert abs(float(v.grad.norm()) - norms[n]) <= 1e-4 * norms[n], n
 
 
 def test_g15_csmri():
