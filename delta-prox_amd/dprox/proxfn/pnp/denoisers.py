@@ -201,6 +201,36 @@ class FFDNetColorDenoiser(Denoiser):
         return self.model(x, sigma)
 
 
+class Augment(nn.Module):
+    """``deep_prior(..., x8=True)`` (reference denoisers/composite.py:6-46): call k of the wrapped denoiser sees the image
+    under dihedral transform k mod 8 (rotations by 90 degrees / a flip of the rows) and its output is mapped back, so that
+    consecutive iterations average out the denoiser's orientation bias.  Pure tensor plumbing around ``denoise``."""
+
+    # mode -> (quarter turns, flip rows afterwards); the inverse of 3 is 5 and vice versa, the other modes undo themselves
+    MODES = ((0, False), (1, True), (0, True), (3, False), (2, True), (1, False), (2, False), (3, True))
+    INVERSE = (0, 1, 2, 5, 4, 3, 6, 7)
+
+    def __init__(self, base_denoiser):
+        super().__init__()
+        self.base_denoiser = base_denoiser
+        self.iter = 0
+
+    def reset(self):
+        self.iter = 0
+
+    @classmethod
+    def augment(cls, img, mode=0):
+        turns, flip = cls.MODES[mode]
+        out = img.rot90(turns, [2, 3]) if turns else img
+        return out.flip([2]) if flip else out
+
+    def denoise(self, x, sigma):
+        mode = self.iter % 8
+        y = self.base_denoiser.denoise(self.augment(x, mode).contiguous(), sigma)
+        self.iter += 1
+        return self.augment(y, self.INVERSE[mode]).contiguous()
+
+
 class _ConvFn(torch.autograd.Function):
     """one dpx_conv2d layer (optional fused ReLU / residual) with a hand-written backward: the transposed convolution is the
     same kernel on flipped / transposed weights (packed once per weight version), the ReLU mask comes from the saved

@@ -9,7 +9,7 @@ import torch.nn as nn
 from ... import _ops as ops
 from ...utils import safe_sqrt
 from ..core import ProxFn
-from .denoisers import DRUNetDenoiser, FFDNetColorDenoiser, FFDNetDenoiser, IRCNNDenoiser
+from .denoisers import Augment, DRUNetDenoiser, FFDNetColorDenoiser, FFDNetDenoiser, IRCNNDenoiser
 
 CACHE_DIR = os.path.join(os.path.expanduser("~"), ".cache", "dprox")
 
@@ -35,33 +35,37 @@ class deep_prior(ProxFn):
     """Plug-and-play prior ``g(K x)`` whose proximal operator is one call of a denoiser at noise level ``sigma = lam``
     (``sqrt=True``: ``sigma = sqrt(lam)``).
 
-    Same constructor as the reference (prior.py:40-63).  Behavioural notes for the HIP backend: ``x8`` test-time augmentation
-    is not built; a complex iterate is reduced to its real part by ``dpx_cplx_lincomb`` (prior.py:79); with
+    Same constructor as the reference (prior.py:40-63).  Behavioural notes for the HIP backend: ``x8`` wraps the denoiser in
+    ``Augment`` (one dihedral transform per call, cycling); a complex iterate is reduced to its real part by ``dpx_cplx_lincomb`` (prior.py:79); with
     ``unroll_step=k`` the prior owns k independent copies of the denoiser and uses copy ``self.step`` (set by the solver
     before every iteration)."""
 
     def __init__(self, linop, denoiser="ffdnet", x8=False, clamp=False, trainable=False, unroll_step=None, sqrt=False):
         super().__init__(linop)
-        if x8:
-            raise NotImplementedError("x8 test-time augmentation is outside the MI355X hot path")
         self.name = denoiser
-        self.x8, self.clamp, self.sqrt = False, bool(clamp), bool(sqrt)
-        self.denoiser = self._resolve(denoiser, trainable)
+        self.x8, self.clamp, self.sqrt = bool(x8), bool(clamp), bool(sqrt)
+        self.denoiser = self._resolve(denoiser, trainable, self.x8)
         self.unroll = unroll_step is not None
         if self.unroll:
             self.denoisers = nn.ModuleList(copy.deepcopy(self.denoiser) for _ in range(int(unroll_step)))
 
     @staticmethod
-    def _resolve(denoiser, trainable):
+    def _resolve(denoiser, trainable, x8=False):
         """a registry name or a ready ``Denoiser``; frozen (eval mode, no parameter gradients) unless ``trainable``
         (prior.py:57-60)"""
         net = get_denoiser(denoiser) if isinstance(denoiser, str) else denoiser
+        if x8:
+            net = Augment(net)                               # prior.py:55-56
         if not trainable:
             net.eval()
             net.requires_grad_(False)
         else:
             net.requires_grad_(True)                       # the HIP modules create their parameters frozen
         return net
+
+    def _reload(self, shape=None):
+        if self.x8:
+            self.denoiser.reset()
 
     def _active_denoiser(self):
         return self.denoisers[self.step] if self.unroll else self.denoiser

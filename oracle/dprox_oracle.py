@@ -33,7 +33,7 @@ __all__ = [
     "soft_threshold", "prox", "LeastSquares", "cg", "bdot", "LinearSolveConfig",
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
     "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
-    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior", "doe_otf", "lin_conv_doe", "drunet_weights", "drunet_forward", "DRUNetOracle", "ircnn_weights", "ircnn_forward", "IRCNNOracle",
+    "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior", "doe_otf", "lin_conv_doe", "drunet_weights", "drunet_forward", "DRUNetOracle", "ircnn_weights", "ircnn_forward", "IRCNNOracle", "AugmentOracle",
 ]
 
 
@@ -638,6 +638,39 @@ class FFDNetOracle:
         if not self.per_band:
             return ffdnet_forward(x, sigma, self.layers)
         return torch.cat([ffdnet_forward(band, sigma, self.layers) for band in x.split(1, dim=1)], dim=1)
+
+
+class AugmentOracle:
+    """``Augment`` -- denoisers/composite.py:6-46 (``deep_prior(x8=True)``, prior.py:55-56): call number k applies the
+    dihedral transform k % 8 before the denoiser and its inverse afterwards (3 and 5 invert each other, :18-21)."""
+
+    def __init__(self, base):
+        self.base, self.iter = base, 0
+
+    @staticmethod
+    def augment(img, mode):
+        # composite.py:31-46, mode by mode
+        if mode == 0:
+            return img
+        if mode == 1:
+            return torch.flip(torch.rot90(img, 1, [2, 3]), [2])
+        if mode == 2:
+            return torch.flip(img, [2])
+        if mode == 3:
+            return torch.rot90(img, 3, [2, 3])
+        if mode == 4:
+            return torch.flip(torch.rot90(img, 2, [2, 3]), [2])
+        if mode == 5:
+            return torch.rot90(img, 1, [2, 3])
+        if mode == 6:
+            return torch.rot90(img, 2, [2, 3])
+        return torch.flip(torch.rot90(img, 3, [2, 3]), [2])
+
+    def __call__(self, x, sigma):
+        m = self.iter % 8
+        y = self.base(self.augment(x, m), sigma)
+        self.iter += 1
+        return self.augment(y, 8 - m if m in (3, 5) else m)
 
 
 # --------------------------------------------------------------------------- #

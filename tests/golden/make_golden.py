@@ -377,6 +377,18 @@ def g9_admm_pnp():
          x_f64=x64, v0_f64=v64[0], x_nonneg_f64=x64n)
 
 
+def g21_x8_augment():
+    """deep_prior(x8=True): denoisers/composite.py:6-46 -- nine consecutive prox calls (modes 0..7, 0) on a non-square image"""
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=ColorDen(7), x8=True)
+    v = T(np.random.RandomState(210).rand(2, 3, 26, 38).astype("float32"))
+    outs = []
+    with torch.no_grad():
+        for k in range(9):
+            outs.append(prior._prox(v, torch.tensor(0.02 + 0.01 * k)))
+    save("g21_x8_augment", v=v, outs=torch.stack(outs))
+
+
 def g11_unrolled_grads():
     """Config-5 shape of problem at fixture size: unrolled ADMM (specialize method='unroll', shared solver), MSE loss,
     gradients w.r.t. the per-iteration rho / lambda schedules and the observation (README.md:93-116,
@@ -741,6 +753,6 @@ def g13_known_answers():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet):
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

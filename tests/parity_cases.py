@@ -255,6 +255,20 @@ def case_admm_pnp(device):
     assert rel_l2(out.cpu(), g["x_nonneg_f64"]) <= ref_err + TOL, (rel_l2(out.cpu(), g["x_nonneg_f64"]), ref_err)
 
 
+def case_x8_augment(device):
+    """G21: deep_prior(x8=True) -- the dihedral transform cycles with the call count (non-square image: the denoiser sees
+    transposed shapes on the odd quarter turns)"""
+    g = load_golden("g21_x8_augment")
+    prior = dp.deep_prior(dp.Variable(), denoiser=_ffdnet("color", device), x8=True)
+    v = T(g["v"], device)
+    with torch.no_grad():
+        for k in range(9):
+            out = prior._prox(v, torch.tensor(0.02 + 0.01 * k, device=device))
+            assert_close(out.cpu(), g["outs"][k], TOL, f"x8 call {k} (mode {k % 8})")
+    prior._reload()
+    assert prior.denoiser.iter == 0
+
+
 def case_ladmm_cg(device):
     """G7: user-defined masked-FFT LinOp (plugin surface) + nonneg + deep_prior(gray FFDNet), LADMM / ADMM with CG x-update"""
     from dprox.linalg import LinearSolveConfig

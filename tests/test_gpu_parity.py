@@ -68,6 +68,10 @@ def test_admm_pnp():
     pc.case_admm_pnp(DEV)
 
 
+def test_x8_augment():
+    pc.case_x8_augment(DEV)
+
+
 def test_ladmm_cg():
     pc.case_ladmm_cg(DEV)
 

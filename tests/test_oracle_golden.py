@@ -189,6 +189,14 @@ def test_pixel_unshuffle_order():
     assert torch.equal(torch.nn.functional.pixel_shuffle(u, 2), x)
 
 
+def test_g21_x8_augment():
+    g = load_golden("g21_x8_augment")
+    den = O.AugmentOracle(O.FFDNetOracle(O.ffdnet_weights(7)))
+    with torch.no_grad():
+        for k in range(9):
+            assert_close(den(T(g["v"]), torch.tensor(0.02 + 0.01 * k)), g["outs"][k], 5e-6, f"x8 call {k}")
+
+
 def test_g9_admm_pnp():
     g = load_golden("g9_admm_pnp")
     b = T(g["b"])
