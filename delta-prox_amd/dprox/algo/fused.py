@@ -48,7 +48,8 @@ def _omega_ok(fn):
         op = lin[0]
     if _is_var(op):
         return True
-    return type(op) in (conv, conv_doe) and _is_var(op.input_nodes[0])
+    # (a linearised conv_doe pads / crops around its FFT product: only the op-by-op path reproduces that)
+    return type(op) in (conv, conv_doe) and getattr(op, "circular", True) and _is_var(op.input_nodes[0])
 
 
 def _omega_conv(fn):

@@ -107,16 +107,16 @@ def _doe_padded(psf, shape):
 class conv_doe(LinOp):
     """Circular convolution with a PSF given as a tensor / Placeholder [1,C,fh,fw] whose OTF is rebuilt on the device
     whenever the PSF changes (reference dprox/linop/conv.py:81-156; end-to-end optics, README.md:93-116).
-    The transform of the padded PSF is ``dpx_cfft2``; forward / adjoint are the same ``dpx_fft_conv`` pipeline as ``conv``."""
+    The transform of the padded PSF is ``dpx_cfft2``; forward / adjoint are the same ``dpx_fft_conv`` pipeline as ``conv``.
+    ``circular=False`` (conv.py:100-108,121-129): the image is zero-padded to 2H x 2H, convolved circularly at that size and
+    cropped back; ``get_diag`` stays the circular |OTF|^2 of the unpadded size, as in the reference."""
 
     def __init__(self, arg, psf, circular=True):
         super().__init__([arg])
-        if not circular:
-            raise NotImplementedError("conv_doe(circular=False) (linearised convolution by 2x padding) is not built for the HIP path")
         from .leaf import Placeholder
         self._psf = psf
-        self.circular = circular
-        self.cache = None
+        self.circular = bool(circular)
+        self.cache = {}
         if isinstance(psf, Placeholder):
             self.psf = None
             self._psf.change(lambda val: setattr(self, "psf", val))
@@ -128,13 +128,16 @@ class conv_doe(LinOp):
         psf = self.psf
         if psf is None:
             raise ValueError("conv_doe: the PSF placeholder has no value yet")
-        key = (psf.data_ptr(), psf._version, tuple(shape[1:]), str(device))
-        if self.cache is None or self.cache[0] != key:
+        ver = (psf.data_ptr(), psf._version)
+        if self.cache.get("version") != ver:
+            self.cache = {"version": ver}                    # a new PSF value invalidates every size's OTF
+        key = (tuple(shape[1:]), str(device))
+        if key not in self.cache:
             _, C, H, W = shape
             P = _doe_padded(psf.detach().float().to(device), shape).expand(1, C, H, W).contiguous()
             full = ops.cfft2(P, inverse=False, centred=False, ortho=False)
-            self.cache = (key, full, ops.otf_from_full(full, C, H, W))
-        return self.cache[1], self.cache[2]
+            self.cache[key] = (full, ops.otf_from_full(full, C, H, W))
+        return self.cache[key]
 
     def _tables(self, shape, device):
         return self._full_otf(shape, device)[1]
@@ -142,11 +145,25 @@ class conv_doe(LinOp):
     def _own_tables_version(self):
         return None if self.psf is None else (self.psf.data_ptr(), self.psf._version)
 
+    def _convolve(self, img, conj):
+        if self.circular:
+            return ops.fft_conv(img, self._tables(img.shape, img.device), conj=conj)
+        import torch.nn.functional as F
+        H, W = img.shape[-2:]
+        side = 2 * H                                         # both axes are padded to twice the HEIGHT (conv.py:102-104)
+        pt, pb = int(np.ceil((side - H) / 2)), int(np.floor((side - H) / 2))
+        pl, pr = int(np.ceil((side - W) / 2)), int(np.floor((side - W) / 2))
+        if min(pt, pb, pl, pr) < 1:
+            raise ValueError(f"conv_doe(circular=False): a {H}x{W} image cannot be padded to {side}x{side} on every side")
+        big = F.pad(img, [pl, pr, pt, pb], mode="constant").contiguous()
+        out = ops.fft_conv(big, self._tables(big.shape, big.device), conj=conj)
+        return out[:, :, pt:-pb, pl:-pr].contiguous()
+
     def forward(self, input, **kwargs):
-        return ops.fft_conv(input, self._tables(input.shape, input.device), conj=False)
+        return self._convolve(input, False)
 
     def adjoint(self, input, **kwargs):
-        return ops.fft_conv(input, self._tables(input.shape, input.device), conj=True)
+        return self._convolve(input, True)
 
     def is_diag(self, freq=False):
         return freq and self.input_nodes[0].is_diag(freq)

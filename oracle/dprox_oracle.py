@@ -224,20 +224,29 @@ def doe_otf(psf: torch.Tensor, shape) -> torch.Tensor:
     return torch.fft.fft2(torch.fft.ifftshift(psf))
 
 
-def lin_conv_doe(psf) -> "Lin":
-    """conv_doe -- linop/conv.py:81-148: forward real(ifftn(otf * fftn(x))), adjoint with conj(otf), diag |otf|^2."""
+def lin_conv_doe(psf, circular=True) -> "Lin":
+    """conv_doe -- linop/conv.py:81-148: forward real(ifftn(otf * fftn(x))), adjoint with conj(otf), diag |otf|^2.
+    ``circular=False`` (conv.py:100-108,121-129): zero-pad to 2H x 2H (both axes from the height), same product, crop."""
     psf = torch.as_tensor(psf).float()
 
-    def fwd(x):
-        return torch.real(torch.fft.ifftn(doe_otf(psf, x.shape) * torch.fft.fftn(x, dim=[-2, -1]), dim=[-2, -1])).float()
-
-    def adj(x):
-        return torch.real(torch.fft.ifftn(torch.conj(doe_otf(psf, x.shape)) * torch.fft.fftn(x, dim=[-2, -1]), dim=[-2, -1])).float()
+    def apply(x, conj):
+        crop = None
+        if not circular:
+            side = 2 * x.shape[2]
+            hp, wp = (side - x.shape[2]) / 2, (side - x.shape[3]) / 2
+            pt, pb, pl, pr = int(np.ceil(hp)), int(np.floor(hp)), int(np.ceil(wp)), int(np.floor(wp))
+            x = torch.nn.functional.pad(x, [pl, pr, pt, pb], mode="constant")
+            crop = (pt, pb, pl, pr)
+        otf = doe_otf(psf, x.shape)
+        out = torch.real(torch.fft.ifftn((torch.conj(otf) if conj else otf) * torch.fft.fftn(x, dim=[-2, -1]), dim=[-2, -1])).float()
+        if crop is not None:
+            out = out[:, :, crop[0]:-crop[1], crop[2]:-crop[3]]
+        return out
 
     def diag(x, freq):
         o = doe_otf(psf, x.shape)
         return torch.abs(torch.conj(o) * o)
-    return Lin(fwd, adj, diag, False, True)        # is_diag(freq=True) only: conv.py:136-137
+    return Lin(lambda x: apply(x, False), lambda x: apply(x, True), diag, False, True)        # is_diag(freq=True) only: conv.py:136-137
 
 
 def bayer_mask(H, W) -> torch.Tensor:

@@ -594,6 +594,20 @@ def g19_conv_doe():
     with torch.no_grad():
         st = solver.solve(x0=y, rhos=0.2, lams=0.01, max_iter=8, return_full_states=True)
     out.update(tv_psf=psf, tv_y=y, tv_x=st[0], tv_v0=st[1][0], tv_u0=st[2][0])
+    # circular=False: zero-pad to 2H x 2H, circular product, crop (conv.py:100-108); + an ADMM TV solve through it
+    psfl = rng.rand(1, 3, 7, 7).astype("float32") ** 2
+    psfl /= psfl.sum(axis=(-2, -1), keepdims=True)
+    xl = T(rng.rand(2, 3, 24, 24).astype("float32"))
+    opl = conv_doe(dp.Variable(), T(psfl), circular=False)
+    with torch.no_grad():
+        out.update(lin_psf=psfl, lin_x=xl, lin_fwd=opl.forward(xl), lin_adj=opl.adjoint(xl))
+    xv2 = dp.Variable()
+    with torch.no_grad():
+        yl = opl.forward(T(gt[:, :, :24, :24].copy())) + T((rng.randn(2, 3, 24, 24) * 0.01).astype("float32"))
+    fl = dp.sum_squares(conv_doe(xv2, T(psfl), circular=False), yl) + dp.norm1(dp.grad(xv2, dim=0)) + dp.norm1(dp.grad(xv2, dim=1))
+    with torch.no_grad():
+        xs = dp.compile(fl, method="admm", device="cpu").solve(x0=yl, rhos=0.3, lams=0.01, max_iter=6)
+    out.update(lin_y=yl, lin_tv_x=xs)
     save("g19_conv_doe", **out)
 
 

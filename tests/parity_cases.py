@@ -607,6 +607,18 @@ def case_conv_doe(device):
     P.value = T(g["tv_psf"], device).flip(-1).contiguous()
     x2 = solver.solve(x0=y, rhos=0.2, lams=0.01, max_iter=8)
     assert rel_l2(x2.cpu(), g["tv_x"]) > 1e-3
+    # circular=False: pad to 2H x 2H, circular product, crop; the solver takes the op-by-op path (adjoint is the padded one,
+    # the denominators the circular |OTF|^2 of the unpadded size, like the reference)
+    opl = dp.conv_doe(dp.Variable(), T(g["lin_psf"], device), circular=False).to(device)
+    xl = T(g["lin_x"], device)
+    assert_close(opl.forward(xl).cpu(), g["lin_fwd"], TOL, "conv_doe linear forward")
+    assert_close(opl.adjoint(xl).cpu(), g["lin_adj"], TOL, "conv_doe linear adjoint")
+    xv2, yl = dp.Variable(), T(g["lin_y"], device)
+    fl = dp.sum_squares(dp.conv_doe(xv2, T(g["lin_psf"], device), circular=False), yl) + dp.norm1(dp.grad(xv2, dim=0)) + dp.norm1(dp.grad(xv2, dim=1))
+    sl = dp.compile(fl, method="admm", device=device)
+    xs = sl.solve(x0=yl, rhos=0.3, lams=0.01, max_iter=6)
+    assert sl.last_path != "fused"
+    assert_close(xs.cpu(), g["lin_tv_x"], TOL, "conv_doe linear TV x")
 
 
 def case_sisr(device, solve=True):

@@ -294,6 +294,12 @@ def test_g19_conv_doe():
     n0, n1 = O.norm1(O.lin_grad(0)), O.norm1(O.lin_grad(1))
     st = O.solve([O.sum_squares(O.lin_conv_doe(g["tv_psf"]), b=y), n0, n1], "admm", x0=y, rhos=0.2, lams=0.01, max_iter=8, return_full_states=True)
     assert_close(st[0], g["tv_x"], 1e-5); assert_close(st[1][0], g["tv_v0"], 1e-5)
+    lin = O.lin_conv_doe(g["lin_psf"], circular=False)
+    assert_close(lin.fwd(T(g["lin_x"])), g["lin_fwd"], 1e-6); assert_close(lin.adj(T(g["lin_x"])), g["lin_adj"], 1e-6)
+    yl = T(g["lin_y"])
+    xs = O.solve([O.sum_squares(O.lin_conv_doe(g["lin_psf"], circular=False), b=yl), O.norm1(O.lin_grad(0)), O.norm1(O.lin_grad(1))], "admm",
+                 x0=yl, rhos=0.3, lams=0.01, max_iter=6)
+    assert_close(xs, g["lin_tv_x"], 1e-5)
 
 
 def test_g20_drunet():
