@@ -238,12 +238,12 @@ class _ConvFn(torch.autograd.Function):
     parameter) is given -- the weight gradient is the pixels-as-K GEMM ``dpx_conv2d_wgrad`` on the saved input"""
 
     @staticmethod
-    def forward(ctx, x, res, weight, fwd, bwd, relu):
+    def forward(ctx, x, res, weight, fwd, bwd, relu, dilation=1, bias=None):
         blob, cout, taps = fwd
         x = x.contiguous()
-        y = ops.conv2d(x, blob, cout, taps, relu=relu, res=None if res is None else res.contiguous())
-        ctx.bwd, ctx.relu, ctx.has_res, ctx.taps = bwd, relu, res is not None, taps
-        train_w = weight is not None and weight.requires_grad
+        y = ops.conv2d(x, blob, cout, taps, relu=relu, res=None if res is None else res.contiguous(), dilation=dilation)
+        ctx.bwd, ctx.relu, ctx.has_res, ctx.taps, ctx.dilation = bwd, relu, res is not None, taps, dilation
+        train_w = (weight is not None and weight.requires_grad) or (bias is not None and bias.requires_grad)
         ctx.save_for_backward(y if relu else x.new_empty(0), x if train_w else x.new_empty(0))
         return y
 
@@ -254,14 +254,19 @@ class _ConvFn(torch.autograd.Function):
         y, x = ctx.saved_tensors
         if ctx.relu:
             gp, _ = ops.prox_bwd(be.PROX_NONNEG, y, g, torch.zeros((), device=g.device), 1.0, None, want_dlam=False)   # g * [y > 0]
-        gw = ops.conv2d_wgrad(gp, x, ctx.taps)[0] if ctx.needs_input_grad[2] else None
+        need = ctx.needs_input_grad                          # as many entries as apply() got arguments (6 or 8)
+        need_b = len(need) > 7 and need[7]
+        gw = gb = None
+        if need[2] or need_b:
+            gw, gb = ops.conv2d_wgrad(gp, x, ctx.taps, dilation=ctx.dilation, want_bias=need_b)
+            gw = gw if need[2] else None
         blob_t, cin, taps = ctx.bwd
         gx = None
         if ctx.needs_input_grad[0]:
             if gp.shape[1] % 2:
                 gp = torch.cat([gp, torch.zeros_like(gp[:, :1])], dim=1).contiguous()
-            gx = ops.conv2d(gp, blob_t, cin, taps)
-        return gx, (g if ctx.has_res else None), gw, None, None, None
+            gx = ops.conv2d(gp, blob_t, cin, taps, dilation=ctx.dilation)
+        return (gx, (g if ctx.has_res else None), gw, None, None, None, None, gb)[:len(need)]
 
 
 class _S2DFn(torch.autograd.Function):
@@ -292,6 +297,16 @@ class _AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, g
+
+
+class _SubFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.lincomb([(1.0, a.contiguous()), (-1.0, b.contiguous())])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, ops.lincomb([(-1.0, g.contiguous())])
 
 
 class UNetRes(nn.Module):
@@ -476,7 +491,8 @@ class DRUNetDenoiser(Denoiser):
 
 class IRCNN(nn.Module):
     """IRCNN body (reference models/network_dncnn.py:74-113): x - net(x) with seven biased 3x3 convolutions of dilation
-    1,2,3,4,3,2,1 -- ``dpx_conv2d`` with the dilation-templated staging tile.  Reference state-dict names."""
+    1,2,3,4,3,2,1 -- ``dpx_conv2d`` with the dilation-templated staging tile.  Reference state-dict names.  Differentiable
+    w.r.t. its input and (``requires_grad_(True)``) its weights / biases through ``_ConvFn``."""
 
     DIL = (1, 2, 3, 4, 3, 2, 1)
 
@@ -492,11 +508,11 @@ class IRCNN(nn.Module):
         for i in range(7):
             self.weights[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.weight"]))
             self.biases[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.bias"]))
-        self._packed = None
+        self._packed = self._packed_T = None
         return self
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self._packed = self._packed_T = None
         return super()._apply(fn, *a, **k)
 
     def packed(self):
@@ -510,15 +526,52 @@ class IRCNN(nn.Module):
             self._packed = pk
         return self._packed
 
+    def packed_T(self):
+        """backward-data layers: weights flipped and channel-transposed (same dilation), no bias; the transposed layer's input
+        (the forward layer's output gradient) is padded to an even channel count"""
+        if getattr(self, "_packed_T", None) is None:
+            pk = []
+            for w in self.weights:
+                w = w.detach().float()
+                cin_pad = w.shape[1] + (w.shape[1] % 2)                   # the forward layer saw a zero pad channel
+                wt = w.flip(-1, -2).permute(1, 0, 2, 3).reshape(w.shape[1], w.shape[0], 9)
+                if wt.shape[0] != cin_pad:
+                    wt = torch.cat([wt, torch.zeros_like(wt[:1])], dim=0)
+                if wt.shape[1] % 2:
+                    wt = torch.cat([wt, torch.zeros_like(wt[:, :1])], dim=1)
+                pk.append((ops.conv_pack(wt.contiguous(), None, 9), int(cin_pad)))
+            self._packed_T = pk
+        return self._packed_T
+
+    def _check_version(self):
+        ver = sum(p._version for p in self.parameters())
+        if ver != getattr(self, "_pack_version", None):
+            self._packed, self._packed_T, self._pack_version = None, None, ver
+
     def forward(self, x):
         be.require(x, what="IRCNN input")
+        self._check_version()
+        train_w = any(p.requires_grad for p in self.parameters())
+        diff = torch.is_grad_enabled() and (x.requires_grad or train_w)
         n = x
         if n.shape[1] % 2:
             n = torch.cat([n, torch.zeros_like(n[:, :1])], dim=1).contiguous()
         for i, ((blob, cout), d) in enumerate(zip(self.packed(), self.DIL)):
-            n = ops.conv2d(n, blob, cout, 9, relu=i < 6, dilation=d)
+            if diff:
+                w, b = self.weights[i], self.biases[i]
+                wk = None
+                if w.requires_grad:                          # kernel form [cout, cin(+pad), 9] as an autograd view of the parameter
+                    wk = w.reshape(w.shape[0], w.shape[1], 9)
+                    if w.shape[1] % 2:
+                        wk = torch.cat([wk, torch.zeros_like(wk[:, :1])], dim=1)
+                blob_t, cin_t = self.packed_T()[i]
+                n = _ConvFn.apply(n, None, wk, (blob, cout, 9), (blob_t, cin_t, 9), i < 6, d, b if b.requires_grad else None)
+            else:
+                n = ops.conv2d(n, blob, cout, 9, relu=i < 6, dilation=d)
             if i < 6 and n.shape[1] % 2:
                 n = torch.cat([n, torch.zeros_like(n[:, :1])], dim=1).contiguous()
+        if diff:
+            return _SubFn.apply(x, n)
         return ops.lincomb([(1.0, x.contiguous()), (-1.0, n)])
 
 

@@ -673,6 +673,17 @@ def g20_drunet():
     xi = T(np.random.RandomState(204).rand(2, 2, 29, 37).astype("float32"))
     with torch.no_grad():
         out.update(ircnn_x=xi, ircnn_y3=ird.denoise(xi, torch.tensor(8 / 255.0)), ircnn_y12=ird.denoise(xi, torch.tensor(25.5 / 255.0)))
+    # IRCNN gradients (bin 3): image, and every weight / bias (full for the small first / last layers, 8x8 corner of the dilation-4 layer)
+    xig = xi.clone().requires_grad_(True)
+    wi = T(np.random.RandomState(205).randn(2, 2, 29, 37).astype("float32"))
+    ird.denoise(xig, torch.tensor(8 / 255.0))                      # loads the bin-3 weights
+    ird.model.requires_grad_(True)
+    (ird.denoise(xig, torch.tensor(8 / 255.0)) * wi).sum().backward()
+    gi = {n: p.grad for n, p in ird.model.named_parameters()}
+    out.update(ircnn_gw=wi, ircnn_gx=xig.grad, ircnn_gnames=np.array(sorted(gi)),
+               ircnn_gnorms=np.array([float(gi[n].norm()) for n in sorted(gi)], dtype=np.float64),
+               ircnn_g_w0=gi["model.0.weight"], ircnn_g_b0=gi["model.0.bias"], ircnn_g_w6_corner=gi["model.6.weight"][:8, :8].contiguous(),
+               ircnn_g_b6=gi["model.6.bias"], ircnn_g_w12=gi["model.12.weight"], ircnn_g_b12=gi["model.12.bias"])
     save("g20_drunet", **out)
 
 

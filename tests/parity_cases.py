@@ -578,6 +578,25 @@ def case_drunet(device):
     with torch.no_grad():
         assert_close(ird.denoise(xi, torch.tensor(8 / 255.0, device=device)).cpu(), g["ircnn_y3"], TOL, "IRCNN bin 3")
         assert_close(ird.denoise(xi, torch.tensor(25.5 / 255.0, device=device)).cpu(), g["ircnn_y12"], TOL, "IRCNN bin 12")
+    # IRCNN gradients: backward-data through the dilated layers (same kernel, flipped weights, same dilation), weight and
+    # bias gradients by dpx_conv2d_wgrad with the dilation-templated apron; accumulated over the two bands
+    xig = T(g["ircnn_x"], device).requires_grad_(True)
+    sig3 = torch.tensor(8 / 255.0, device=device)
+    with torch.no_grad():
+        ird.denoise(xig.detach(), sig3)                          # selects the bin-3 model
+    ird.model.requires_grad_(True)
+    (ird.denoise(xig, sig3) * T(g["ircnn_gw"], device)).sum().backward()
+    _assert_grad_close(xig.grad.cpu(), g["ircnn_gx"], "IRCNN d/dx")
+    gi = {f"model.{2 * i}.weight": ird.model.weights[i].grad.cpu() for i in range(7)}
+    gi.update({f"model.{2 * i}.bias": ird.model.biases[i].grad.cpu() for i in range(7)})
+    ird.model.requires_grad_(False)
+    for key, name in (("ircnn_g_w0", "model.0.weight"), ("ircnn_g_b0", "model.0.bias"), ("ircnn_g_b6", "model.6.bias"),
+                      ("ircnn_g_w12", "model.12.weight"), ("ircnn_g_b12", "model.12.bias")):
+        _assert_grad_close(gi[name], g[key], f"IRCNN grad {name}")
+    _assert_grad_close(gi["model.6.weight"][:8, :8], g["ircnn_g_w6_corner"], "IRCNN grad model.6.weight [:8,:8] (dilation 4)")
+    inorms = dict(zip([str(n) for n in g["ircnn_gnames"]], g["ircnn_gnorms"]))
+    for n, gr in gi.items():
+        assert abs(float(gr.norm()) - inorms[n]) <= 2e-3 * inorms[n], (n, float(gr.norm()), inorms[n])
     x = dp.Variable()
     prior = dp.deep_prior(x, denoiser=den)
     assert "deep_prior" in repr(prior)

@@ -314,6 +314,12 @@ def test_g20_drunet():
         ir = O.IRCNNOracle({str(k): O.ircnn_weights(31 + k) for k in (3, 12)})
         assert_close(ir(T(g["ircnn_x"]), torch.tensor(8 / 255.0)), g["ircnn_y3"], 2e-6)
         assert_close(ir(T(g["ircnn_x"]), torch.tensor(25.5 / 255.0)), g["ircnn_y12"], 2e-6)
+    # IRCNN gradients through the restatement
+    sdi = {k: torch.as_tensor(v).clone().requires_grad_(True) for k, v in O.ircnn_weights(34).items()}
+    xi = T(g["ircnn_x"]).requires_grad_(True)
+    (O.IRCNNOracle({"3": sdi})(xi, torch.tensor(8 / 255.0)) * T(g["ircnn_gw"])).sum().backward()
+    assert_close(xi.grad, g["ircnn_gx"], 2e-5)
+    assert_close(sdi["model.0.weight"].grad, g["ircnn_g_w0"], 2e-5); assert_close(sdi["model.12.bias"].grad, g["ircnn_g_b12"], 2e-5)
     # weight gradients (reference autograd) through the restatement
     sd = {k: v.clone().requires_grad_(True) for k, v in O.drunet_weights(21, 4, 3).items()}
     (O.DRUNetOracle(sd)(T(g["grad_x"]), torch.tensor([0.05, 0.2])) * T(g["grad_w"])).sum().backward()
