@@ -6,6 +6,7 @@ Tolerance (north_star): rel-L2 <= 1e-5 on the iterate x.  The split
 non-smooth functions of x (soft threshold / clip at lam) so their error is compared on the scale of x.
 """
 import numpy as np
+import pytest
 import torch
 
 import dprox as dp
@@ -701,3 +702,28 @@ def case_other_algorithms(device):
         fns = dp.sum_squares(dp.conv(x, g["psf"]) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
         out = dp.Problem(fns).solve(method=method, device=device, x0=b, rhos=0.3, lams=0.01, max_iter=6)
         assert_close(out.cpu(), g[method], TOL, method)
+
+
+def case_tiny_shapes(device):
+    """degenerate planes against the oracle: 2x3, 3x3, 17x2 (every stage at its smallest size, prime lengths), and the
+    reference's error for an axis shorter than the gradient stencil (utils/psf2otf.py:46-54 raises there too)"""
+    import oracle as O
+    for shape in ((1, 1, 2, 3), (1, 1, 3, 3), (2, 3, 4, 6), (1, 1, 17, 2)):
+        B, C, H, W = shape
+        rng = np.random.RandomState(sum(shape))
+        b = rng.rand(*shape).astype("float32")
+        psf = np.ones((1, 1), dtype="float32") if min(H, W) < 3 else rng.rand(3, 3).astype("float32")
+        psf /= psf.sum()
+        bt = torch.from_numpy(b).to(device)
+        x = dp.Variable()
+        fns = dp.sum_squares(dp.conv(x, psf) - bt) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
+        out = dp.compile(fns, method="admm", device=device).solve(x0=bt, rhos=0.5, lams=0.02, max_iter=4)
+        bc = torch.from_numpy(b)
+        ref = O.solve([O.sum_squares(O.lin_conv(psf).minus(bc)), O.norm1(O.lin_grad(0)), O.norm1(O.lin_grad(1))], "admm", x0=bc, rhos=0.5,
+                      lams=0.02, max_iter=4)
+        assert_close(out.cpu(), ref, TOL, f"tiny plane {shape}")
+    bt = torch.rand(2, 1, 5, 1).to(device)
+    x = dp.Variable()
+    with pytest.raises(Exception, match="cannot be smaller than the PSF"):
+        dp.compile(dp.sum_squares(x - bt) + dp.norm1(dp.grad(x, dim=1)), method="admm", device=device).solve(x0=bt, rhos=0.5, lams=0.02, max_iter=2)
+

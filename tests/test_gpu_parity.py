@@ -92,6 +92,10 @@ def test_conv2d_generic():
     pc.case_conv2d_generic(DEV)
 
 
+def test_tiny_shapes():
+    pc.case_tiny_shapes(DEV)
+
+
 def test_conv_doe():
     pc.case_conv_doe(DEV)
 
