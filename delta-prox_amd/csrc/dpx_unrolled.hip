@@ -1,0 +1,154 @@
+// Unrolled ADMM with closed-form proxes, forward and backward, as two C-side loops (config 5: specialize(method='unroll'),
+// reference dprox/algo/specialization/unroll.py:14-58 differentiating dprox/algo/admm.py:49-59 with PyTorch autograd).
+//
+// The per-stage entry points (dpx_admm_rhs / dpx_fourier_solve / dpx_admm_zupdate and their backward counterparts in
+// dpx_autodiff.hip) are unchanged; this file only sequences them without returning to the host language between stages:
+// a 10-iteration training step is ~170 kernel launches whose Python-side issue cost (~4 ms) exceeded their run time
+// (~2.3 ms).  No kernels of its own.
+//
+// History buffer (caller-owned): iteration `it` occupies (2 + 2 n) planes of px = B*C*H*W floats:
+//     [rhs][x][v_0 .. v_{n-1}][u_0 .. u_{n-1}]
+// the backward pass reads rhs, x and v_i of every iteration (u_i only as the forward's running state).
+#include "dpx_common.h"
+
+using namespace dpx;
+
+namespace {
+struct Hist {
+  float* base;
+  size_t px;
+  int n;
+  float* rhs(int it) const { return base + (size_t)it * (2 + 2 * n) * px; }
+  float* x(int it) const { return rhs(it) + px; }
+  float* v(int it, int i) const { return rhs(it) + (size_t)(2 + i) * px; }
+  float* u(int it, int i) const { return rhs(it) + (size_t)(2 + n + i) * px; }
+};
+}  // namespace
+
+#define DPX_TRY(call)            \
+  do {                           \
+    const int dpx_rc_ = (call);  \
+    if (dpx_rc_ != DPX_OK) return dpx_rc_; \
+  } while (0)
+
+extern "C" size_t dpx_admm_unrolled_hist_bytes(int nterms, int T, int B, int C, int H, int W) {
+  return (size_t)T * (2 + 2 * nterms) * B * C * H * W * sizeof(float);
+}
+
+extern "C" int dpx_admm_unrolled_forward(float* hist, const float* const* v0, const float* const* u0, const int* linops, const int* proxes,
+                                         const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
+                                         const void* spec_add, const void* dd, float eps, int B, int C, int H, int W, const void* table,
+                                         void* spectrum_ws, dpx_stream_t stream) {
+  DPX_REQUIRE(hist && v0 && u0 && linops && proxes && alphas && rho_tab && lam_tabs && dd && table && spectrum_ws,
+              "dpx_admm_unrolled_forward: null pointer");
+  DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && T >= 1 && B > 0 && C > 0 && H > 0 && W > 0, "dpx_admm_unrolled_forward: bad sizes");
+  const Hist h{hist, (size_t)B * C * H * W, nterms};
+  for (int it = 0; it < T; ++it) {
+    dpx_term rt[DPX_MAX_TERMS], zt[DPX_MAX_TERMS];
+    for (int i = 0; i < nterms; ++i) {
+      float* pv = it ? h.v(it - 1, i) : (float*)v0[i];
+      float* pu = it ? h.u(it - 1, i) : (float*)u0[i];
+      rt[i] = dpx_term{linops[i], proxes[i], 1.0f, 0, nullptr, pv, pu, nullptr};
+      zt[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, h.v(it, i), pu, h.u(it, i)};
+    }
+    const float* rho = rho_tab + (size_t)it * B;
+    DPX_TRY(dpx_admm_rhs(h.rhs(it), nullptr, rho, rt, nterms, B, C, H, W, stream));
+    DPX_TRY(dpx_fourier_solve(h.rhs(it), h.x(it), spec_add, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
+    DPX_TRY(dpx_admm_zupdate(h.x(it), zt, nterms, B, C, H, W, stream));
+  }
+  return DPX_OK;
+}
+
+// workspace: (4 + 6 n) planes + 2 B floats, followed by dpx_admm_bwd_ws_bytes
+extern "C" size_t dpx_admm_unrolled_bwd_ws_bytes(int nterms, int B, int C, int H, int W) {
+  return ((size_t)(4 + 6 * nterms) * B * C * H * W + 2 * (size_t)B + 64) * sizeof(float) + dpx_admm_bwd_ws_bytes(B, C, H, W);
+}
+
+// gx / gv_in[i] / gu_in[i]: gradients w.r.t. the final x, v_i, u_i (any may be NULL = 0).
+// Out: gv0[i], gu0[i] (w.r.t. the initial split / dual variables), grho [T][B], glam [T][n][B], goff[k] (w.r.t. the k-th
+// Omega offset: K g_rhs summed over the iterations; off_otf[k] = that term's OTF table or NULL for the identity; goff[k]
+// NULL = not wanted).
+extern "C" int dpx_admm_unrolled_backward(const float* hist, const float* gx, const float* const* gv_in, const float* const* gu_in,
+                                          float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
+                                          const void* const* off_otf, int n_off, const int* linops, const int* proxes, const float* alphas,
+                                          int nterms, const float* rho_tab, const float* const* lam_tabs, int T, const void* dd, float eps,
+                                          int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(hist && gv0 && gu0 && grho && glam && linops && proxes && alphas && rho_tab && lam_tabs && dd && table && spectrum_ws && ws,
+              "dpx_admm_unrolled_backward: null pointer");
+  DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && T >= 1 && B > 0 && n_off >= 0 && (n_off == 0 || (goff && off_otf)),
+              "dpx_admm_unrolled_backward: bad sizes");
+  const int n = nterms;
+  const size_t px = (size_t)B * C * H * W;
+  const Hist h{(float*)hist, px, n};
+  float* w = (float*)ws;
+  float* gxz = w;
+  float* gtot = w + px;
+  float* grhs = w + 2 * px;
+  float* tmp = w + 3 * px;
+  float* gu_a = w + 4 * px;                  // n planes
+  float* gu_b = gu_a + n * px;               // n planes
+  float* set[2] = {gu_b + n * px, gu_b + 3 * n * px};   // each: gv[n] then gu[n]
+  float* rho_a = set[1] + 2 * n * px;
+  float* rho_b = rho_a + B;
+  void* bws = (void*)(rho_a + ((2 * B + 63) / 64) * 64);
+  const float one2[2] = {1.f, 1.f};
+  const float* cur_gv[DPX_MAX_TERMS];
+  const float* cur_gu[DPX_MAX_TERMS];
+  for (int i = 0; i < n; ++i) {
+    cur_gv[i] = gv_in ? gv_in[i] : nullptr;
+    cur_gu[i] = gu_in ? gu_in[i] : nullptr;
+  }
+  bool off_started[DPX_MAX_TERMS] = {false, false, false, false};
+  DPX_REQUIRE(n_off <= DPX_MAX_TERMS, "dpx_admm_unrolled_backward: at most %d offsets", DPX_MAX_TERMS);
+  for (int it = T - 1; it >= 0; --it) {
+    const float* rho = rho_tab + (size_t)it * B;
+    dpx_bwd_term bt[DPX_MAX_TERMS];
+    for (int i = 0; i < n; ++i)
+      bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, h.v(it, i), cur_gv[i], cur_gu[i], gu_a + i * px};
+    DPX_TRY(dpx_admm_zupdate_bwd(gxz, bt, n, glam + (size_t)it * n * B, B, C, H, W, bws, stream));
+    const float* g = gxz;
+    if (it == T - 1 && gx) {
+      const float* xs[2] = {gx, gxz};
+      DPX_TRY(dpx_lincomb(gtot, 2, xs, one2, nullptr, B, (long)(px / B), stream));
+      g = gtot;
+    }
+    DPX_TRY(dpx_fourier_apply_inv(g, grhs, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
+    DPX_TRY(dpx_admm_solve_rho_grad(grhs, h.x(it), linops, n, rho_a, B, C, H, W, bws, stream));
+    for (int k = 0; k < n_off; ++k) {
+      if (!goff[k]) continue;
+      if (off_otf[k]) {
+        float* dst = off_started[k] ? tmp : goff[k];
+        DPX_TRY(dpx_fft_conv(grhs, dst, off_otf[k], 0, B, C, H, W, table, spectrum_ws, stream));
+        if (off_started[k]) {
+          const float* xs[2] = {goff[k], tmp};
+          DPX_TRY(dpx_lincomb(goff[k], 2, xs, one2, nullptr, B, (long)(px / B), stream));
+        }
+      } else {
+        const float* xs[2] = {grhs, goff[k]};
+        DPX_TRY(dpx_lincomb(goff[k], off_started[k] ? 2 : 1, xs, one2, nullptr, B, (long)(px / B), stream));
+      }
+      off_started[k] = true;
+    }
+    // gradients w.r.t. the previous iteration's v_i, u_i (the last step writes the caller's outputs directly)
+    float* nv[DPX_MAX_TERMS];
+    float* nu[DPX_MAX_TERMS];
+    float* gub[DPX_MAX_TERMS];
+    for (int i = 0; i < n; ++i) {
+      nv[i] = it ? set[it & 1] + (size_t)i * px : gv0[i];
+      nu[i] = it ? set[it & 1] + (size_t)(n + i) * px : gu0[i];
+      gub[i] = gu_b + (size_t)i * px;
+    }
+    DPX_TRY(dpx_admm_rhs_bwd(grhs, h.rhs(it), rho, linops, n, nv, gub, rho_b, B, C, H, W, bws, stream));
+    {
+      const float* xs[2] = {rho_a, rho_b};
+      DPX_TRY(dpx_lincomb(grho + (size_t)it * B, 2, xs, one2, nullptr, 1, (long)B, stream));
+    }
+    for (int i = 0; i < n; ++i) {
+      const float* xs[2] = {gu_a + (size_t)i * px, gub[i]};
+      DPX_TRY(dpx_lincomb(nu[i], 2, xs, one2, nullptr, B, (long)(px / B), stream));
+      cur_gv[i] = nv[i];
+      cur_gu[i] = nu[i];
+    }
+  }
+  return DPX_OK;
+}

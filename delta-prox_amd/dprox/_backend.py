@@ -92,6 +92,15 @@ SIGNATURES = {
                                    c_void_p, c_void_p]),
     "dpx_admm_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_void_p, POINTER(c_void_p), c_float,
                              c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_unrolled_hist_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "dpx_admm_unrolled_forward": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_float), c_int,
+                                          c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p]),
+    "dpx_admm_unrolled_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dpx_admm_unrolled_backward": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p,
+                                           c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float),
+                                           c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]),
     "dpx_ffdnet_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_ffdnet_pack": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

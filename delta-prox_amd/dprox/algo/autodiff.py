@@ -14,6 +14,8 @@ Here the iteration is three hand-written stages; each gets a hand-written backwa
 (K_i in {I, grad_H, grad_W}; prox in {soft-threshold, nonneg, v/(1+2 lam)}.)  torch.autograd only chains these
 Functions and carries the [B]-sized schedule entries; every image-sized pass runs in libdpx_hip.so.
 """
+import os
+
 import torch
 
 from .. import _backend as be
@@ -166,6 +168,80 @@ def _sched_table(vals, T, B, dev):
     return v[:, :T].t().expand(T, B).contiguous()
 
 
+class _UnrolledClosed(torch.autograd.Function):
+    """All `T` iterations of a problem whose Psi terms are closed-form proxes as ONE autograd node whose forward and backward
+    are single C calls (``dpx_admm_unrolled_forward`` / ``_backward``: the same three forward stages and three backward
+    kernels per iteration as _Rhs / _Solve / _ZUpdate, sequenced on the C side).  Config 5 is issue-bound from Python: ~170
+    launches, 2.3 ms of kernels in a 4.2 ms step.  Inputs: rho_tab [T,B], lam_tabs[i] [T,B], v_i, u_i, offsets; outputs:
+    x, v_i, u_i after T iterations (views of the saved history buffer)."""
+
+    @staticmethod
+    def _common(plan, dev, shape):
+        import ctypes
+        n = len(plan.codes)
+        B, C, H, W = shape
+        lin = (ctypes.c_int * n)(*[lc for lc, _ in plan.codes])
+        prx = (ctypes.c_int * n)(*[pc for _, pc in plan.codes])
+        alp = (ctypes.c_float * n)(*[float(fn.alpha) for fn in plan.psi])
+        t0, c0, t1, c1 = plan.diag
+        dd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
+        return lin, prx, alp, dd, ops.fft_table(H, W, dev), ops.spectrum_ws(B * C, H, W, dev)
+
+    @staticmethod
+    def forward(ctx, plan, T, rho_tab, *rest):
+        import ctypes
+        n = len(plan.codes)
+        lam_tabs, v, u, offs = rest[:n], rest[n:2 * n], rest[2 * n:3 * n], rest[3 * n:]
+        v = [t.contiguous() for t in v]
+        u = [t.contiguous() for t in u]
+        shape, dev = tuple(v[0].shape), v[0].device
+        B, C, H, W = shape
+        rho_tab = rho_tab.contiguous()
+        lam_tabs = [t.contiguous() for t in lam_tabs]
+        lin, prx, alp, dd, table, sws = _UnrolledClosed._common(plan, dev, shape)
+        hist = torch.empty((T, 2 + 2 * n) + shape, dtype=torch.float32, device=dev)
+        vp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in v])
+        up = (ctypes.c_void_p * n)(*[t.data_ptr() for t in u])
+        lp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lam_tabs])
+        be.lib().call("dpx_admm_unrolled_forward", be.ptr(hist), vp, up, lin, prx, alp, n, be.ptr(rho_tab), lp, T, be.ptr(plan.FK), be.ptr(dd),
+                      ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.stream())
+        ctx.plan, ctx.T, ctx.n_off, ctx.shape = plan, T, len(offs), shape
+        ctx.save_for_backward(rho_tab, *lam_tabs)
+        ctx.hist = hist
+        last = hist[T - 1]
+        return (last[1], *[last[2 + i] for i in range(n)], *[last[2 + n + i] for i in range(n)])
+
+    @staticmethod
+    def backward(ctx, gx, *gvu):
+        import ctypes
+        plan, T, hist, shape = ctx.plan, ctx.T, ctx.hist, ctx.shape
+        n = len(plan.codes)
+        B, C, H, W = shape
+        dev = hist.device
+        rho_tab, *lam_tabs = ctx.saved_tensors
+        lin, prx, alp, dd, table, sws = _UnrolledClosed._common(plan, dev, shape)
+        keep = [None if g is None else g.contiguous() for g in (gx, *gvu)]
+        gxp = keep[0]
+        gvi = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in keep[1:1 + n]])
+        gui = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in keep[1 + n:1 + 2 * n]])
+        gv0 = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(n)]
+        gu0 = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(n)]
+        g_rho = torch.empty(T, B, dtype=torch.float32, device=dev)
+        g_lam = torch.empty(T, n, B, dtype=torch.float32, device=dev)
+        need_off = ctx.needs_input_grad[3 + 3 * n:]
+        g_off = [torch.empty(shape, dtype=torch.float32, device=dev) if need else None for need in need_off]
+        n_off = ctx.n_off
+        gop = (ctypes.c_void_p * max(n_off, 1))(*[None if t is None else t.data_ptr() for t in g_off])
+        otf = (ctypes.c_void_p * max(n_off, 1))(*[None if o is None else o.data_ptr() for o in plan.omega_otfs[:n_off]])
+        lp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lam_tabs])
+        L = be.lib()
+        ws = ops.workspace("unrolled_bwd", L.query("dpx_admm_unrolled_bwd_ws_bytes", n, B, C, H, W), dev)
+        L.call("dpx_admm_unrolled_backward", be.ptr(hist), be.ptr(gxp), gvi, gui, (ctypes.c_void_p * n)(*[t.data_ptr() for t in gv0]),
+               (ctypes.c_void_p * n)(*[t.data_ptr() for t in gu0]), be.ptr(g_rho), be.ptr(g_lam), gop, otf, n_off, lin, prx, alp, n,
+               be.ptr(rho_tab), lp, T, be.ptr(dd), ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.ptr(ws), be.stream())
+        return (None, None, g_rho, *[g_lam[:, i] for i in range(n)], *gv0, *gu0, *g_off)
+
+
 def run(plan: DiffPlan, state, rhos, lams, max_iter, diff_offsets):
     """max_iter differentiable ADMM iterations from `state` = (x, [v_i], [u_i]); returns the new state.
     When x requires grad but the split variables are not connected to it (the state came straight from
@@ -181,6 +257,9 @@ def run(plan: DiffPlan, state, rhos, lams, max_iter, diff_offsets):
     ext = [i for i, (_, pc) in enumerate(codes) if pc == be.PROX_EXTERNAL]
     rho_tab = _sched_table(rhos, max_iter, B, dev)
     lam_tabs = [_sched_table(lams[fn], max_iter, B, dev) for fn in plan.psi]
+    if not ext and n > 0 and max_iter > 0 and not os.environ.get("DPX_UNROLL_CHAIN"):
+        out = _UnrolledClosed.apply(plan, max_iter, rho_tab, *lam_tabs, *v, *u, *diff_offsets)
+        return out[0], list(out[1:1 + n]), list(out[1 + n:1 + 2 * n])
     for it in range(max_iter):
         rho = rho_tab[it]
         lam = [lt[it] for lt in lam_tabs]

@@ -252,6 +252,25 @@ int dpx_admm_solve_rho_grad(const float* g_rhs, const float* x, const int* linop
 int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv,
                      float* const* gu, float* grho, int B, int C, int H, int W, void* ws, dpx_stream_t stream);
 
+/* ---- unrolled ADMM with closed-form proxes: T iterations forward / backward without returning to the host language
+ * (specialization/unroll.py:14-58 over algo/admm.py:49-59; the per-stage calls above, sequenced on the C side).
+ * hist (dpx_admm_unrolled_hist_bytes): per iteration [rhs][x][v_0..v_{n-1}][u_0..u_{n-1}] planes of B*C*H*W floats -- the
+ * forward's outputs are its last iteration's x / v_i / u_i planes.  rho_tab [T][B], lam_tabs[i] [T][B] (device).
+ * backward: gx / gv_in[i] / gu_in[i] = gradients w.r.t. the final x, v_i, u_i (NULL = 0); out: gv0[i], gu0[i] (initial split /
+ * dual variables), grho [T][B], glam [T][n][B], goff[k] = gradient w.r.t. the k-th Omega offset (off_otf[k]: its OTF table,
+ * NULL = identity; goff[k] NULL = not wanted).                                                                       */
+size_t dpx_admm_unrolled_hist_bytes(int nterms, int T, int B, int C, int H, int W);
+int dpx_admm_unrolled_forward(float* hist, const float* const* v0, const float* const* u0, const int* linops, const int* proxes,
+                              const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
+                              const void* spec_add, const void* dd, float eps, int B, int C, int H, int W, const void* table,
+                              void* spectrum_ws, dpx_stream_t stream);
+size_t dpx_admm_unrolled_bwd_ws_bytes(int nterms, int B, int C, int H, int W);
+int dpx_admm_unrolled_backward(const float* hist, const float* gx, const float* const* gv_in, const float* const* gu_in,
+                               float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
+                               const void* const* off_otf, int n_off, const int* linops, const int* proxes, const float* alphas,
+                               int nterms, const float* rho_tab, const float* const* lam_tabs, int T, const void* dd, float eps,
+                               int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* two-kernel fused ADMM iteration (power-of-two planes)                                       */
 /* ------------------------------------------------------------------------------------------ */
