@@ -71,8 +71,9 @@ if "c5" in which:
     n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
     s = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + n0 + n1, method="admm", device=dev)
     s = dp.specialize(s, method="unroll", device=dev, max_iter=10)
-    rhos = torch.full((10,), 0.1, requires_grad=True)
-    l0, l1 = torch.full((10,), 0.005, requires_grad=True), torch.full((10,), 0.005, requires_grad=True)
+    pdev = "cpu" if os.environ.get("DPX_C5_CPU_PARAMS") else dev      # the trained schedules live on the GPU (nn.Parameters of the unrolled solver)
+    rhos = torch.full((10,), 0.1, requires_grad=True, device=pdev)
+    l0, l1 = torch.full((10,), 0.005, requires_grad=True, device=pdev), torch.full((10,), 0.005, requires_grad=True, device=pdev)
     def step():
         for p in (rhos, l0, l1):
             p.grad = None
