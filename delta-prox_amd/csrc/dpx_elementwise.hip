@@ -255,14 +255,21 @@ __global__ void k_dot_finish(const float* __restrict__ partial, float* __restric
   if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
-// B x B Gram matrix, B <= 32: a workgroup stages a [B][GR_CH] slab of the residuals in LDS once and forms all B*B partial
-// dot products from it (k_dot_partial with a (nblk, B, B) grid re-reads every row B times: 38 us -> a few us at 32 x 320^2).
-// Lane (i, j4) of a 32 x 8 thread grid owns outputs (i, 4*j4 .. 4*j4+3); summation order inside a block is fixed.
+// B x B Gram matrix, B <= 32: a workgroup stages a [32][GR_CH] slab of the residuals in LDS and forms all B*B partial dot
+// products from it (k_dot_partial with a (nblk, B, B) grid re-reads every row B times).  64 threads cover the 32 x 32 outputs
+// with 4 x 4 register tiles (8 LDS reads per 16 FMAs), the 4 waves split the slab's columns; one slab per workgroup
+// iteration and up to 1024 workgroups, so that a 32 x 320^2 residual (800 slabs) fills the chip: 125 us -> ~10 us.
+// Summation order is fixed (per-wave partials are added in wave order, slabs by the finishing kernel).
 constexpr int GR_CH = 128, GR_P = GR_CH + 1;
 __global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, float* __restrict__ partial, int B, long npb, int nblk) {
   __shared__ float sx[32 * GR_P];
-  const int tid = threadIdx.x, i = tid >> 3, j0 = (tid & 7) * 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  __shared__ float red[3][64][16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ti = (lane >> 3) * 4, tj = (lane & 7) * 4;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
   for (long c0 = (long)blockIdx.x * GR_CH; c0 < npb; c0 += (long)gridDim.x * GR_CH) {
     __syncthreads();
     for (int e = tid; e < 32 * GR_CH; e += 256) {
@@ -271,16 +278,39 @@ __global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, 
     }
     __syncthreads();
 #pragma unroll 4
-    for (int k = 0; k < GR_CH; ++k) {
-      const float xi = sx[i * GR_P + k];
+    for (int k = wave * (GR_CH / 4); k < (wave + 1) * (GR_CH / 4); ++k) {
+      float xi[4], xj[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = fmaf(xi, sx[(j0 + q) * GR_P + k], acc[q]);
+      for (int a = 0; a < 4; ++a) { xi[a] = sx[(ti + a) * GR_P + k]; xj[a] = sx[(tj + a) * GR_P + k]; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][q] = fmaf(xi[a], xj[q], acc[a][q]);
     }
   }
-  if (i < B)
+  if (wave > 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (j0 + q < B) partial[((long)i * B + (j0 + q)) * nblk + blockIdx.x] = acc[q];
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[wave - 1][lane][a * 4 + q] = acc[a][q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = ((acc[a][q] + red[0][lane][a * 4 + q]) + red[1][lane][a * 4 + q]) + red[2][lane][a * 4 + q];
+        if (ti + a < B && tj + q < B) partial[((long)(ti + a) * B + (tj + q)) * nblk + blockIdx.x] = v;
+      }
+  }
+}
+
+static int gram_blocks(long npb) {
+  long g = (npb + GR_CH - 1) / GR_CH;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (int)g;
 }
 
 static int dot_blocks(long npb) {
@@ -654,7 +684,10 @@ extern "C" int dpx_cplx_lincomb(void* out, int out_complex, int n, const void* c
   return launch_status("dpx_cplx_lincomb");
 }
 
-extern "C" size_t dpx_bdot_ws_bytes(int B, long n_per_batch) { return (size_t)B * B * dot_blocks(n_per_batch) * sizeof(float); }
+extern "C" size_t dpx_bdot_ws_bytes(int B, long n_per_batch) {
+  const int nb = dot_blocks(n_per_batch) > gram_blocks(n_per_batch) ? dot_blocks(n_per_batch) : gram_blocks(n_per_batch);
+  return (size_t)B * B * nb * sizeof(float);
+}
 
 extern "C" int dpx_bdot(const float* x, const float* y, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(x && y && out && ws && B > 0 && n_per_batch > 0, "dpx_bdot: bad arguments");
@@ -666,7 +699,7 @@ extern "C" int dpx_bdot(const float* x, const float* y, float* out, int B, long 
 
 extern "C" int dpx_bgram(const float* r, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(r && out && ws && B > 0 && n_per_batch > 0, "dpx_bgram: bad arguments");
-  const int nblk = dot_blocks(n_per_batch);
+  const int nblk = B <= 32 ? gram_blocks(n_per_batch) : dot_blocks(n_per_batch);
   if (B <= 32)
     DPX_LAUNCH("k_gram_tile", k_gram_tile, dim3(nblk), dim3(256), 0, (hipStream_t)stream, r, (float*)ws, B, n_per_batch, nblk);
   else
