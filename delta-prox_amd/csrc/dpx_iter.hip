@@ -632,7 +632,10 @@ extern "C" int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx
   // of the chip; DPX_ITER_ROWS=lockstep keeps the ring-buffer kernel (A/B timing), DPX_ITER_BAND overrides the number of bands per plane.
   static const char* mode = getenv("DPX_ITER_ROWS");
   static const int band_env = getenv("DPX_ITER_BAND") ? atoi(getenv("DPX_ITER_BAND")) : 0;
-  if (!(mode && !strcmp(mode, "lockstep")) && W <= 1024) {
+  // (small launches -- a few 256-wide planes -- are latency-bound: the ring-buffer kernel's row-parallel bands finish ~10 %
+  //  sooner there than the streaming kernel's sequential ones; measured crossover between 256- and 512-wide planes)
+  const bool tiny = W <= 256 && (long)P * H <= 4096 && !(mode && !strcmp(mode, "seq"));
+  if (!(mode && !strcmp(mode, "lockstep")) && W <= 1024 && !tiny) {
     // as many bands per plane as keep every T-lane group of the launch resident at once (2 workgroups of 4 waves per
     // CU), rounded so that the groups fill whole workgroups; bands are >= 4 rows (halo = 2 extra inverse transforms)
     const int T = W / 16, G = 64 / T, per_block = 4 * G;

@@ -182,13 +182,14 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 256, 256), (1, 3, 512, 512), (2, 3, 256, 1024), (1, 2, 1024, 512), (3, 1, 512, 256),
-                                   (1, 1, 256, 2048), (5, 3, 1024, 1024)])
+                                   (1, 1, 256, 2048), (5, 3, 1024, 1024), (6, 3, 256, 256)])
 @pytest.mark.parametrize("terms", ["hw", "h+l1", "w+nn", "hw+nn+l1"])
 def test_two_kernel_iteration_matches_stagewise_path(shape, terms):
     """Power-of-two planes run the two-kernel iteration (k_cols_p2 + k_iter_rows_seq: LDS-DMA prefetch, hand-counted
     waits, band partition); the same problem with the fused path switched off runs the independent op-by-op kernels
     (generic FFT, stencil and prox kernels).  All plane widths (T = 16 / 32 / 64 lane groups; W = 2048 runs the ring-buffer row
-    kernel), a batch whose band count is not a power of two, 1..4 Psi terms and
+    kernel, and so do launches of a few 256-wide planes; 6x3x256x256 is large enough for the streaming kernel at T = 16), a batch
+    whose band count is not a power of two, 1..4 Psi terms and
     per-image rho are covered; both paths must agree to fp32 round-off."""
     import dprox as dp
     import synthetic
