@@ -121,11 +121,18 @@ class FusedADMM:
     def __init__(self, solver, codes):
         self.solver, self.codes = solver, codes
 
-    def run(self, state, rhos, lams, max_iter, pbar=False, callback=None):
+    def run(self, state, rhos, lams, max_iter, pbar=False, callback=None, dual=True):
+        """``dual=False``: half-quadratic splitting (hqs.py:4-20) = the same three stages with the dual variables pinned to
+        zero -- state (x, [z_i]); the z-stage's ``u_out`` goes to a scratch buffer and is never read."""
         s = self.solver
         ls = s.least_square
         psi = list(s.psi_fns)
-        x0, v, u = state
+        if dual:
+            x0, v, u = state
+        else:
+            x0, v = state
+            zero = torch.zeros_like(x0)
+            u = [zero for _ in v]
         B, C, H, W = x0.shape
         dev = x0.device
         T = max_iter
@@ -160,7 +167,7 @@ class FusedADMM:
 
         # ---- differentiable (unrolled-training) mode: hand-written backward stages, autodiff.py -------------------
         raw_offs = [self._offset_autograd(fn, x0) for fn in s.omega_fns]
-        if autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u)):
+        if dual and autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u)):
             otfs = []
             for fn in s.omega_fns:
                 cv = _omega_conv(fn)
@@ -182,7 +189,11 @@ class FusedADMM:
         ext = [i for i, (_, pc) in enumerate(self.codes) if pc == be.PROX_EXTERNAL]
         var = s.Kall.variables[0]
 
-        if not ext and n > 0 and ops.iter_supported(H, W, terms, n):
+        if not dual:
+            scratch = torch.empty_like(x0)
+            for i in range(n):
+                terms[i].u_out = scratch.data_ptr()
+        if dual and not ext and n > 0 and ops.iter_supported(H, W, terms, n):
             return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
                                         rhos, lams, pbar, callback)
 
@@ -207,9 +218,9 @@ class FusedADMM:
             var.value = x
             if callback is not None:
                 s._notify_all_op_current_step(it)
-                callback(iter=it, state=(x, v, u), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+                callback(iter=it, state=(x, v, u) if dual else (x, v), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
         s.Kall.update_vars([x])
-        return x, v, u
+        return (x, v, u) if dual else (x, v)
 
 
     @staticmethod

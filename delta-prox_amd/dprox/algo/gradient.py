@@ -47,7 +47,14 @@ class ProximalGradientDescent(Algorithm):
 
     def _iter(self, state, rho, lam):
         (x,) = state
-        moved = forward_step(x, rho, self.diff_fn.grad(x))
+        parts = getattr(self.diff_fn, "grad_parts", lambda t: None)(x)
+        if parts is not None:                       # x - rho (K^T K x - K^T b) as one fused AXPY
+            gram_x, ktb = parts
+            coef = rho if getattr(rho, "ndim", 0) else float(rho)
+            terms = [(1.0, x), (-coef, gram_x)] + ([] if ktb is None else [(coef, ktb)])
+            moved = ops.lincomb(terms)
+        else:
+            moved = forward_step(x, rho, self.diff_fn.grad(x))
         return [self.prox_fn.prox(moved, lam[self.prox_fn])]
 
     @property

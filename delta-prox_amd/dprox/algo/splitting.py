@@ -132,6 +132,18 @@ class HQS(ADMM):
         z = self.K.forward(x, return_list=True)
         return x, [e if e is not x else e.clone() for e in z]
 
+    def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
+        """recognised problems (the fused ADMM's criteria, closed-form proxes only, no gradients requested) run the fused
+        rhs / Fourier-solve / z stages with the dual variables pinned to zero; everything else op by op"""
+        plan = fused.plan_admm(self, state) if self.use_fused else None
+        closed = plan is not None and all(pc != fused.be.PROX_EXTERNAL for _, pc in plan.codes)
+        tensors = [state[0], rhos] + list(lams.values()) + list(state[1])
+        if closed and len(state[1]) > 0 and not (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)):
+            self.last_path = "fused"
+            return plan.run(state, rhos, lams, max_iter, pbar, callback, dual=False)
+        self.last_path = "generic"
+        return Algorithm.iters(self, state, rhos, lams, max_iter, pbar, callback)
+
     def _iter(self, state, rho, lam):
         x, z = state
         x = self.least_square.solve(z, rho)

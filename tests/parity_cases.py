@@ -694,14 +694,22 @@ def case_csmri(device, solve=True):
 
 
 def case_other_algorithms(device):
-    """G14: ADMM_vxu / HQS / Pock-Chambolle through the generic path (same HIP primitives, different update order)"""
+    """G14: ADMM_vxu / Pock-Chambolle through the generic path (same HIP primitives, different update order), HQS through the
+    fused stages (dual variables pinned to zero) and op by op"""
     g = load_golden("g14_other_algorithms")
     b = T(g["b"], device)
     for method in ("admm_vxu", "hqs", "pc"):
         x = dp.Variable()
         fns = dp.sum_squares(dp.conv(x, g["psf"]) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
-        out = dp.Problem(fns).solve(method=method, device=device, x0=b, rhos=0.3, lams=0.01, max_iter=6)
+        prob = dp.Problem(fns)
+        out = prob.solve(method=method, device=device, x0=b, rhos=0.3, lams=0.01, max_iter=6)
         assert_close(out.cpu(), g[method], TOL, method)
+        if method == "hqs":            # recognised problems: the fused rhs / solve / z stages with the duals pinned to zero ...
+            assert prob.solver.last_path == "fused"
+            prob.solver.use_fused = False                        # ... and the op-by-op iteration give the same answer
+            out2 = prob.solver.solve(x0=b, rhos=0.3, lams=0.01, max_iter=6)
+            assert prob.solver.last_path == "generic"
+            assert_close(out2.cpu(), g[method], TOL, "hqs (op by op)")
 
 
 def case_tiny_shapes(device):
