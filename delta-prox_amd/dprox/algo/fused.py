@@ -121,9 +121,11 @@ class FusedADMM:
     def __init__(self, solver, codes):
         self.solver, self.codes = solver, codes
 
-    def run(self, state, rhos, lams, max_iter, pbar=False, callback=None, dual=True):
+    def run(self, state, rhos, lams, max_iter, pbar=False, callback=None, dual=True, vxu=False):
         """``dual=False``: half-quadratic splitting (hqs.py:4-20) = the same three stages with the dual variables pinned to
-        zero -- state (x, [z_i]); the z-stage's ``u_out`` goes to a scratch buffer and is never read."""
+        zero -- state (x, [z_i]); the z-stage's ``u_out`` goes to a scratch buffer and is never read.
+        ``vxu=True``: ADMM in the order v, x, u (admm.py:103-120) on the same stages: with u' = -u the split update is
+        prox(K z + u') (z stage, its dual output discarded), the x-update sees v - u', and u' <- u' - v + z is one AXPY."""
         s = self.solver
         ls = s.least_square
         psi = list(s.psi_fns)
@@ -167,7 +169,7 @@ class FusedADMM:
 
         # ---- differentiable (unrolled-training) mode: hand-written backward stages, autodiff.py -------------------
         raw_offs = [self._offset_autograd(fn, x0) for fn in s.omega_fns]
-        if dual and autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u)):
+        if dual and not vxu and autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u)):
             otfs = []
             for fn in s.omega_fns:
                 cv = _omega_conv(fn)
@@ -189,10 +191,30 @@ class FusedADMM:
         ext = [i for i, (_, pc) in enumerate(self.codes) if pc == be.PROX_EXTERNAL]
         var = s.Kall.variables[0]
 
-        if not dual:
+        if not dual or vxu:
             scratch = torch.empty_like(x0)
             for i in range(n):
                 terms[i].u_out = scratch.data_ptr()
+        if vxu:
+            x.copy_(x0)
+            for i in range(n):                                   # u' = -u, kept in fresh buffers
+                u[i] = ops.lincomb([(-1.0, u[i])])
+                terms[i].u = u[i].data_ptr()
+            for it in tqdm(range(T), disable=not pbar):
+                for i in range(n):
+                    terms[i].lam = lam_tab[i][it].data_ptr()
+                ops.admm_zupdate(x, terms, n)
+                ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
+                ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x, spec_add=FK)
+                for i in range(n):
+                    ops.lincomb([(1.0, u[i]), (-1.0, v[i]), (1.0, x)], out=u[i])
+                var.value = x
+                if callback is not None:
+                    s._notify_all_op_current_step(it)
+                    callback(iter=it, state=(x, v, [ops.lincomb([(-1.0, t)]) for t in u]), rho=rhos[..., it],
+                             lam={k: val[..., it] for k, val in lams.items()})
+            s.Kall.update_vars([x])
+            return x, v, [ops.lincomb([(-1.0, t)]) for t in u]
         if dual and not ext and n > 0 and ops.iter_supported(H, W, terms, n):
             return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
                                         rhos, lams, pbar, callback)

@@ -110,8 +110,27 @@ class LinearizedADMM(ADMM):
         return x, v, u
 
 
+def _fused_closed_form(solver, state, rhos, lams):
+    """the fused ADMM's plan when every Psi prox is closed-form and no gradient is requested, else None"""
+    plan = fused.plan_admm(solver, state) if solver.use_fused else None
+    if plan is None or len(state[1]) == 0 or any(pc == fused.be.PROX_EXTERNAL for _, pc in plan.codes):
+        return None
+    tensors = [state[0], rhos] + list(lams.values()) + [t for part in state[1:] for t in (part if isinstance(part, (list, tuple)) else [part])]
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        return None
+    return plan
+
+
 class ADMM_vxu(ADMM):
     """update order v, x, u"""
+
+    def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
+        plan = _fused_closed_form(self, state, rhos, lams)
+        if plan is not None:
+            self.last_path = "fused"
+            return plan.run(state, rhos, lams, max_iter, pbar, callback, vxu=True)
+        self.last_path = "generic"
+        return Algorithm.iters(self, state, rhos, lams, max_iter, pbar, callback)
 
     def _iter(self, state, rho, lam):
         z, x, u = state
@@ -135,10 +154,8 @@ class HQS(ADMM):
     def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
         """recognised problems (the fused ADMM's criteria, closed-form proxes only, no gradients requested) run the fused
         rhs / Fourier-solve / z stages with the dual variables pinned to zero; everything else op by op"""
-        plan = fused.plan_admm(self, state) if self.use_fused else None
-        closed = plan is not None and all(pc != fused.be.PROX_EXTERNAL for _, pc in plan.codes)
-        tensors = [state[0], rhos] + list(lams.values()) + list(state[1])
-        if closed and len(state[1]) > 0 and not (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)):
+        plan = _fused_closed_form(self, state, rhos, lams)
+        if plan is not None:
             self.last_path = "fused"
             return plan.run(state, rhos, lams, max_iter, pbar, callback, dual=False)
         self.last_path = "generic"

@@ -704,12 +704,12 @@ def case_other_algorithms(device):
         prob = dp.Problem(fns)
         out = prob.solve(method=method, device=device, x0=b, rhos=0.3, lams=0.01, max_iter=6)
         assert_close(out.cpu(), g[method], TOL, method)
-        if method == "hqs":            # recognised problems: the fused rhs / solve / z stages with the duals pinned to zero ...
+        if method in ("hqs", "admm_vxu"):   # recognised problems: the fused rhs / solve / z stages (hqs: duals pinned to zero) ...
             assert prob.solver.last_path == "fused"
             prob.solver.use_fused = False                        # ... and the op-by-op iteration give the same answer
             out2 = prob.solver.solve(x0=b, rhos=0.3, lams=0.01, max_iter=6)
             assert prob.solver.last_path == "generic"
-            assert_close(out2.cpu(), g[method], TOL, "hqs (op by op)")
+            assert_close(out2.cpu(), g[method], TOL, f"{method} (op by op)")
 
 
 def case_tiny_shapes(device):
