@@ -255,3 +255,19 @@ def test_random_shapes_vs_oracle(seed):
     # single grad_H + nothing else on the identity leaves a line of tiny denominators: allow the conditioning-limited floor
     tol = 1e-5 if (use["l1"] or use["nn"] or not use["w"]) else 3e-5
     assert pc.rel_l2(out.cpu(), ref) <= tol, (B, C, H, W, k, use, pc.rel_l2(out.cpu(), ref))
+
+
+def test_backend_launches_on_the_current_stream():
+    """the C ABI is stream-asynchronous: the host layer must hand it the stream PyTorch would launch on, inside a
+    torch.cuda.stream() context too (the backend reads the raw handle, not a Stream object)"""
+    from dprox import _backend as be
+    from dprox import _ops as ops
+    side = torch.cuda.Stream()
+    assert be.stream().value in (None, 0) or be.stream().value == torch.cuda.current_stream().cuda_stream
+    with torch.cuda.stream(side):
+        assert be.stream().value == side.cuda_stream
+        a = torch.rand(2, 3, 64, 64, device=DEV)
+        y = ops.lincomb([(2.0, a), (1.0, a)])
+    side.synchronize()
+    assert torch.allclose(y, 3.0 * a)
+
