@@ -53,25 +53,44 @@ def cg(A, b, x0=None, rtol=1e-6, max_iters=100, verbose=False, return_iters=Fals
     p = gamma_1 = None
     done = n_it
     normr = None
+    # The stop test needs the residual Gram matrix on the host (spectral norm, eigvalsh).  On the GPU its read-back is
+    # asynchronous (pinned buffer + event) and the iteration's updates are enqueued BEFORE the host waits for it, so the
+    # device never idles behind the host round trip; if the test then says "converged", the speculative updates are simply
+    # dropped (they were written to fresh tensors) -- decisions and results are exactly those of the sequential loop.
+    on_gpu = r.is_cuda
+    pin = torch.empty((B, B), dtype=torch.float32, pin_memory=True) if on_gpu else None
+
+    def converged(Gh):
+        nonlocal normr
+        Gh = Gh.astype(np.float64)
+        normr = float(np.sqrt(max(np.linalg.eigvalsh((Gh + Gh.T) * 0.5)[-1], 0.0))) if B > 1 else float(np.sqrt(max(Gh[0, 0], 0.0)))
+        return bool(np.all(normr <= cg_tol))
+
     for it in range(n_it):
         G = ops.bgram(r)                                     # [B,B] on device
-        Gh = G.cpu().numpy().astype(np.float64)
-        normr = float(np.sqrt(max(np.linalg.eigvalsh((Gh + Gh.T) * 0.5)[-1], 0.0))) if B > 1 else float(np.sqrt(max(Gh[0, 0], 0.0)))
-        if np.all(normr <= cg_tol):
+        if on_gpu:
+            pin.copy_(G, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        elif converged(G.cpu().numpy()):
             if verbose:
                 print("Converged at CG Iter %03d" % it)
             done = it
             break
         gamma = G.diagonal().contiguous()                    # <r_i, r_i>
-        if it > 0:
-            p = ops.lincomb([(1.0, r), (gamma / gamma_1, p)])
-        else:
-            p = r.clone()
-        Ap = apply(p)
-        alpha = gamma / ops.bdot(p, Ap)
-        x = ops.lincomb([(1.0, x), (alpha, p)])
-        r = ops.lincomb([(1.0, r), (-alpha, Ap)])
-        gamma_1 = gamma
+        p_new = ops.lincomb([(1.0, r), (gamma / gamma_1, p)]) if it > 0 else r.clone()
+        Ap = apply(p_new)
+        alpha = gamma / ops.bdot(p_new, Ap)
+        x_new = ops.lincomb([(1.0, x), (alpha, p_new)])
+        r_new = ops.lincomb([(1.0, r), (-alpha, Ap)])
+        if on_gpu:
+            ev.synchronize()
+            if converged(pin.numpy()):
+                if verbose:
+                    print("Converged at CG Iter %03d" % it)
+                done = it
+                break
+        x, r, p, gamma_1 = x_new, r_new, p_new, gamma
     else:
         if verbose:
             print(f"Not converged, r norm={normr}")
