@@ -139,6 +139,8 @@ class FusedADMM:
         dev = x0.device
         T = max_iter
         s.Kall.update_vars([x0])
+        if T <= 0:                                           # nothing to do: the state is returned as it came
+            return state
 
         rho_tab = schedule_table(rhos, T, B, dev)
         lam_tab = []
