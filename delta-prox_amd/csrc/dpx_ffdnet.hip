@@ -198,7 +198,11 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NR], const float* _
 // 96 channels: DRUNet), each with its own packed weight block.  RES: out = conv + res (residual blocks).
 // NR = output rows per wave (2 or 4): with 2 output-channel tiles (64-channel layers: gray FFDNet, DRUNet blocks) NR = 4
 // doubles the matrix-core work per weight fragment read and per staged halo row.
-template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false, int DIL = 1, int NR = 2>
+// M16 (MT = 1, at most 16 output channels, Cin a multiple of 4: the denoisers' last layer): the 16x16x4 matrix-core tile --
+// 16 output channels x 16 pixels x 4 input channels per instruction at the same rate -- so that a 12- or 4-channel layer does
+// not pay for 32 output rows.  Lane = (pixel or channel lane & 15, input channel lane >> 4 of the 4-group).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false, int DIL = 1, int NR = 2, bool M16 = false>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x,
                                                        const float* __restrict__ mask) {
@@ -218,13 +222,21 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_mfma(const float* __restrict
   const float* maskb = (MASKED || RES) ? mask + (size_t)b * Cout * H2 * W2 : nullptr;   // RES: `mask` carries the residual input
   const float* bias = wpk + (size_t)(Cin / 2) * NTAP * 2 * M32;
 
-  f32x16 acc[MT][NR];
+  static_assert(!M16 || (MT == 1 && NTAP == 9 && !MASKED && !RES), "M16: plain 3x3 layers with one 32-channel weight block");
+  f32x16 acc[M16 ? 1 : MT][M16 ? 1 : NR];
+  f32x4 acc16[M16 ? NR : 1][2];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < (M16 ? 1 : MT); ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NR; ++nt)
+    for (int nt = 0; nt < (M16 ? 1 : NR); ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < (M16 ? NR : 1); ++nt)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc16[nt][h][r] = 0.f;
 
   // Software pipeline over chunks of FFD_CK input channels, two LDS buffers, one barrier per chunk.
   //  * forward layers: the next chunk is fetched by LDS-DMA (no VGPRs, no LDS-write pass, ~20 issue slots per wave and
@@ -280,12 +292,51 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_mfma(const float* __restrict
     if (more) issue(c0 + FFD_CK, buf ^ 1);
     const float* sin_b = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW) + (half * FFD_ROWS + NR * wave) * FFD_LDW + j;
     const float* sw_b = s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32) + half * M32 + j;
-    for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1, NTAP, DIL, NR>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * NTAP * 2 * M32);
+    if constexpr (M16) {
+      const int k4 = lane >> 4, i16 = lane & 15;
+      const float* sin16 = s_in + buf * (FFD_CK * FFD_ROWS * FFD_LDW) + (k4 * FFD_ROWS + NR * wave) * FFD_LDW + i16;
+      const float* sw16 = s_w + buf * ((FFD_CK / 2) * NTAP * 2 * M32) + ((k4 >> 1) * NTAP * 2 + (k4 & 1)) * M32 + i16;
+      for (int cp = 0; cp < nch / 2; cp += 2) {              // 4 input channels per step
+        const float* sb = sin16 + 2 * cp * FFD_ROWS * FFD_LDW;
+        const float* sa = sw16 + cp * NTAP * 2 * M32;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float av = sa[tap * 2 * M32];
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float bv = sb[((tap / 3) * DIL + r) * FFD_LDW + (tap % 3) * DIL + 16 * h];
+              acc16[r][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc16[r][h], 0, 0, 0);
+            }
+        }
+      }
+    } else {
+      for (int cp = 0; cp < nch / 2; ++cp) mfma_chunk<MT, 1, NTAP, DIL, NR>(acc, sin_b + 2 * cp * FFD_ROWS * FFD_LDW, sw_b + cp * NTAP * 2 * M32);
+    }
     if (more) dpx_wait_vm<0>();
     __syncthreads();
   }
   // ---- epilogue: bias, ReLU, store.  C/D layout: col = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (cout) ----
   float* outb = out + (size_t)b * Cout * H2 * W2;
+  if constexpr (M16) {                     // 16x16 C/D layout: col = lane & 15 (pixel), row = 4 * (lane >> 4) + r (cout)
+#pragma unroll
+    for (int nt = 0; nt < NR; ++nt) {
+      const int yy = y0 + NR * wave + nt;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int xq = x0 + 16 * h + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cl = 4 * (lane >> 4) + r, co = co0 + cl;
+          float v = acc16[nt][h][r] + bias[cl];
+          if (RELU) v = fmaxf(v, 0.f);
+          if (co < Cout && yy < H2 && xq < W2) outb[((size_t)co * H2 + yy) * W2 + xq] = v;
+        }
+      }
+    }
+    return;
+  }
   const int xx = x0 + j;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -316,6 +367,13 @@ static void launch_conv(bool relu, const float* in, float* out, const float* wpk
     DPX_LAUNCH("k_conv3x3_mfma_bwd", (k_conv3x3_mfma<MT, false, true, 9, false, 1, NR>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin,
                Cout, H2, W2, tx, mask);
     return;
+  }
+  if constexpr (MT == 1) {
+    if (!relu && Cout <= 16 && Cin % 4 == 0) {               // the last layer: 16-wide matrix-core tile
+      DPX_LAUNCH("k_conv3x3_mfma16", (k_conv3x3_mfma<1, false, false, 9, false, 1, NR, true>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk,
+                 Cin, Cout, H2, W2, tx, (const float*)nullptr);
+      return;
+    }
   }
   if (relu)
     DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, true, false, 9, false, 1, NR>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout,
