@@ -28,8 +28,40 @@ def rel_l2(a, b):
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
 
 
-def assert_close(a, b, rel=1e-5, what=""):
-    """SURVEY 8(a) acceptance: rel-L2 <= rel and max-abs <= rel * max|ref|."""
+ACHIEVED = []          # (test id, what, achieved rel-L2, bound, achieved max-abs / max|ref|): written out at session end
+
+
+def record(what, rel, bound, maxabs=None):
+    ACHIEVED.append({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": what, "rel_l2": float(rel),
+                     "bound": float(bound), "maxabs_over_max": None if maxabs is None else float(maxabs)})
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """achieved errors of every parity comparison of the run -> gpurun_out/parity_achieved_<gpu|cpu>.json (scratch; the
+    judged copy is committed under profiles/)"""
+    if not ACHIEVED:
+        return
+    import json
+    try:
+        import torch
+        tag = "gpu" if torch.cuda.is_available() else "cpu"
+    except Exception:
+        tag = "cpu"
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, f"parity_achieved_{tag}.json"), "w") as f:
+            json.dump(ACHIEVED, f, indent=0)
+    except OSError:
+        pass
+
+
+# max-abs multiplier of assert_close: SURVEY 8(a) asks for max-abs <= rel * max|ref| (x1).  A max over 1e5..1e7 entries of
+# fp32 round-off sits ~4-5 sigma above the RMS the rel-L2 bound speaks about, so x1 on the max is a (much) stricter
+# statement than rel-L2 <= rel; cases that meet x1 pass maxabs_mult=1 explicitly, the default keeps x4 (and the achieved
+# ratio of every comparison is recorded either way).
+def assert_close(a, b, rel=1e-5, what="", maxabs_mult=4.0):
+    """SURVEY 8(a) acceptance: rel-L2 <= rel and max-abs <= maxabs_mult * rel * max|ref|."""
     a = np.asarray(a)
     b = np.asarray(b)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
@@ -37,8 +69,9 @@ def assert_close(a, b, rel=1e-5, what=""):
     wide = np.complex128 if np.iscomplexobj(a) or np.iscomplexobj(b) else np.float64
     m = float(np.max(np.abs(a.astype(wide) - b.astype(wide)))) if a.size else 0.0
     scale = float(np.max(np.abs(b))) if b.size else 0.0
+    record(what, r, rel, m / max(scale, 1e-30))
     assert r <= rel, f"{what}: rel-L2 {r:.3e} > {rel:.1e}"
-    assert m <= rel * max(scale, 1e-30) * 4 + 1e-12, f"{what}: max-abs {m:.3e} vs {rel:.1e}*{scale:.3e}"
+    assert m <= rel * max(scale, 1e-30) * maxabs_mult + 1e-12, f"{what}: max-abs {m:.3e} vs {maxabs_mult:g}*{rel:.1e}*{scale:.3e}"
 
 
 @pytest.fixture

@@ -775,9 +775,129 @@ def g13_known_answers():
     save("g13_known_answers", **out)
 
 
+# --------------------------------------------------------------------------------------
+# BASELINE-size cases (configs 2..5 of BASELINE.json): the inputs are regenerated from their seeds by the tests, the
+# reference's outputs are stored as strided samples + per-image sums / L2 norms in float64.
+# --------------------------------------------------------------------------------------
+def _pack(out, key, t, stride):
+    t = t.detach()
+    out[key] = t[..., ::stride, ::stride].clone()
+    d = t.double().reshape(t.shape[0], -1)
+    out[key + "_sum"], out[key + "_l2"] = d.sum(1), d.norm(dim=1)
+
+
+def g30_full_c2():
+    """config 2 at its real plane size: 2 of the 8 images (3x1024x1024), ADMM TV-deconv, rho 0.1, lam 0.005, 10 iterations,
+    full state at iterations 1 / 5 / 10 (algo/admm.py:49-59, proxfn/sum_square.py:123-156)."""
+    gt, b, psf = synthetic.deconv_case(2, 3, 1024, 1024, seed=2302)
+    x = dp.Variable()
+    fns = _tv_problem(x, T(b), psf)
+    out = {"seed": 2302}
+
+    def cb(iter, state, rho, lam):
+        if iter + 1 in (1, 5, 10):
+            xs, vs, us = state
+            _pack(out, f"it{iter + 1}_x", xs, 8)
+            for i in range(2):
+                _pack(out, f"it{iter + 1}_v{i}", vs[i], 16)
+                _pack(out, f"it{iter + 1}_u{i}", us[i], 16)
+
+    xo = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=0.1, lams=0.005, max_iter=10, callback=cb)
+    lam10 = np.full(10, 0.005, np.float32)
+    x64, _, _ = admm_f64(b, psf, [("grad0", "norm1", 1.0), ("grad1", "norm1", 1.0)], np.full(10, 0.1, np.float32), [lam10, lam10], 10)
+    _pack(out, "x_f64", torch.from_numpy(np.asarray(x64)), 8)
+    out["psnr"] = np.array([10 * np.log10(1.0 / np.mean((xo[i].numpy() - gt[i]) ** 2)) for i in range(2)])
+    save("g30_full_c2", **out)
+
+
+def g31_full_c3():
+    """config 3 at its real plane size: one 3x1024x1024 image, ADMM with the FFDNet-colour prior (seeded weights), the first
+    3 iterations of the log_descent(35, 5, 30) schedule (proxfn/pnp/prior.py:42-89, algo/tune/dpir.py:13-39)."""
+    gt, b, psf = synthetic.deconv_case(1, 3, 1024, 1024, seed=2303)
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=ColorDen(7))
+    fns = dp.sum_squares(dp.conv(x, psf) - T(b)) + prior
+    rhos, sigmas = log_descent(35, 5, 30)
+    rhos, sigmas = rhos[:3], sigmas[:3]
+    out = {"seed": 2303, "rhos": rhos, "sigmas": sigmas}
+    with torch.no_grad():
+        st = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams={prior: sigmas}, max_iter=3, return_full_states=True)
+    _pack(out, "x", st[0], 8)
+    _pack(out, "v0", st[1][0], 8)
+    _pack(out, "u0", st[2][0], 8)
+    x64, v64, u64 = admm_f64(b, psf, [("id", "ffdnet", 1.0)], rhos.numpy(), [sigmas.numpy()], 3, ffdnet_weights(7))
+    _pack(out, "x_f64", torch.from_numpy(np.asarray(x64)), 8)
+    _pack(out, "v0_f64", torch.from_numpy(np.asarray(v64[0])), 8)
+    save("g31_full_c3", **out)
+
+
+def g32_full_c4():
+    """config 4, one GPU's shard: 4 x 1 x 320 x 320 CS-MRI, masked-FFT LinOp + nonneg + deep_prior(gray FFDNet), LADMM with the
+    CG x-update (rtol 1e-6, <= 100 iterations), 2 outer iterations; the CG exit counts are recorded from the reference's own
+    loop (two bdot calls per CG iteration, linalg/solve/solver_cg.py:107-125)."""
+    import dprox.linalg.solve.solver_cg as scg
+    import dprox.proxfn.sum_square as ssq
+    gt, mask, y = synthetic.csmri_case(4, 320, 320, seed=2304, center=32)
+    mask, y = T(mask), T(y)
+    x = dp.Variable()
+    fns = dp.sum_squares(MaskedFFT(x, mask), y) + dp.nonneg(x) + dp.deep_prior(x, denoiser=GrayDen(seed=11))
+    x0 = ifft2(y).real.float()
+    calls = {"bdot": 0}
+    counts = []
+    orig_bdot, orig_ls = scg.bdot, ssq.linear_solve
+
+    def bdot(*a, **k):
+        calls["bdot"] += 1
+        return orig_bdot(*a, **k)
+
+    def linear_solve(*a, **k):
+        n0 = calls["bdot"]
+        r = orig_ls(*a, **k)
+        counts.append((calls["bdot"] - n0) // 2)
+        return r
+
+    scg.bdot, ssq.linear_solve = bdot, linear_solve
+    try:
+        with torch.no_grad():
+            st = dp.Problem(fns, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100)).solve(
+                method="ladmm", device="cpu", x0=x0, rhos=0.5, lams=0.03, max_iter=2, return_full_states=True)
+    finally:
+        scg.bdot, ssq.linear_solve = orig_bdot, orig_ls
+    out = {"seed": 2304, "cg_iters": np.array(counts)}
+    print("config-4 shard: CG exit counts", counts)
+    _pack(out, "x", st[0], 4)
+    for i in range(2):
+        _pack(out, f"v{i}", st[1][i], 4)
+        _pack(out, f"u{i}", st[2][i], 4)
+    save("g32_full_c4", **out)
+
+
+def g33_full_c5():
+    """config 5 at its real size: 4 x 3 x 512 x 512, ADMM unrolled 10 times (specialize method='unroll'), MSE loss, gradients
+    w.r.t. the rho / lambda schedules and the observation through the reference's autograd (specialization/unroll.py:14-58)."""
+    gt, b, psf = synthetic.deconv_case(4, 3, 512, 512, seed=2305)
+    K = 10
+    x = dp.Variable()
+    bt = T(b).clone().requires_grad_(True)
+    n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+    solver = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + n0 + n1, method="admm", device="cpu")
+    solver = dp.specialize(solver, method="unroll", device="cpu", max_iter=K)
+    r0, a0, a1 = np.linspace(0.3, 0.1, K).astype("float32"), np.linspace(0.02, 0.005, K).astype("float32"), np.linspace(0.015, 0.006, K).astype("float32")
+    rhos, l0, l1 = (torch.tensor(t, requires_grad=True) for t in (r0, a0, a1))
+    xo = solver.solve(x0=T(b), rhos=rhos, lams={n0: l0, n1: l1})
+    loss = ((xo - T(gt)) ** 2).mean()
+    loss.backward()
+    out = {"seed": 2305, "rhos": r0, "l0": a0, "l1": a1, "loss": loss.detach().double(), "g_rhos": rhos.grad, "g_l0": l0.grad, "g_l1": l1.grad}
+    _pack(out, "x", xo, 8)
+    _pack(out, "g_b", bt.grad, 8)
+    print("config 5:", float(loss), rhos.grad, l0.grad, l1.grad)
+    save("g33_full_c5", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment):
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment,
+               g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

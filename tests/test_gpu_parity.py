@@ -132,6 +132,23 @@ def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV)
 
 
+# ---- BASELINE-size fixtures (configs 2..5 at their real plane sizes) -----------------------------------
+def test_full_size_config2_trajectory():
+    pc.case_full_c2(DEV)
+
+
+def test_full_size_config3_pnp():
+    pc.case_full_c3(DEV)
+
+
+def test_full_size_config4_shard_ladmm_cg():
+    pc.case_full_c4(DEV)
+
+
+def test_full_size_config5_unrolled_grads():
+    pc.case_full_c5(DEV)
+
+
 def test_cpu_device_is_refused():
     import dprox as dp
     from dprox._backend import DpxError
