@@ -14,8 +14,14 @@ The JSON line also carries
   roofline     : dominant kernel's algorithmic bytes per launch / its average duration measured with
                  HIP events on the launch stream (second pass of K iterations with the library's
                  per-kernel timers on), against 8 TB/s HBM3E;
+  roofline_iteration : the whole iteration against HBM peak on the 36 B/element the two-kernel schedule
+                 really moves (`frac`); SURVEY 8(d)'s 64 B/element un-fused accounting is kept as a labelled
+                 comparison only (`survey_accounting_frac`);
   cpu_baseline : the reference-schedule CPU oracle (oracle/, a port of the reference's PyTorch-CPU
-                 path pinned on its golden vectors) timed on this box's host cores on a bounded sample.
+                 path pinned on its golden vectors) timed on this box's host cores on a bounded sample;
+  parity_rel_l2: rel-L2 between the GPU iterate and that same oracle run (same images, same iteration count);
+  configs      : short timed runs of BASELINE.json's other configurations (1, 3, 4, 5) through the same API
+                 with their own roofline figures (N=1 only, `--no-extra-configs` skips them).
 """
 import argparse
 import ctypes
@@ -60,6 +66,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true")
     return ap.parse_args()
 
 
@@ -98,14 +105,107 @@ def cpu_baseline(b_host, psf, n_iters=4, sample_b=2):
     bs = b_host[:sample_b].contiguous()
     terms = [O.sum_squares(O.lin_conv(psf).minus(bs)), O.norm1(O.lin_grad(0)), O.norm1(O.lin_grad(1))]
     stamps = []
-    O.solve(terms, "admm", x0=bs, rhos=RHO, lams=LAM, max_iter=1 + n_iters,
-            callback=lambda **kw: stamps.append(time.perf_counter()))
+    x_ref = O.solve(terms, "admm", x0=bs, rhos=RHO, lams=LAM, max_iter=1 + n_iters,
+                    callback=lambda **kw: stamps.append(time.perf_counter()))
     per_iter = (stamps[-1] - stamps[0]) / n_iters            # first iteration = warm-up (OTF build, caches)
     its_batch8 = (sample_b / B) / per_iter                   # iterations/s of a batch-8 problem
-    return {"value": its_batch8, "unit": "it/s (batch of 8x3x1024x1024)", "cores": torch.get_num_threads(),
+    return x_ref, {"value": its_batch8, "unit": "it/s (batch of 8x3x1024x1024)", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"{sample_b} of the {B} images, 1 warm-up + {n_iters} timed ADMM iterations of the reference-schedule "
                       f"oracle ({per_iter:.2f} s/iter), scaled x{sample_b}/{B} to the batch-8 rate"}
+
+
+def _timed(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, out
+
+
+def extra_configs(dp, synthetic, device):
+    """BASELINE.json configurations 1, 3, 4 (one GPU's shard), 5 through the same drop-in API: wall-clock per iteration /
+    step with the roofline figure SURVEY 8(d) names for each.  Short runs (a few seconds in total)."""
+    from dprox.linalg import LinearSolveConfig
+    from dprox.proxfn.pnp.denoisers import FFDNetColorDenoiser, FFDNetDenoiser
+    from dprox.contrib import masked_fft
+    from dprox.utils import ifft2
+    out = {}
+    psnr = lambda a_, b_: float(10 * torch.log10(1.0 / ((a_ - b_) ** 2).mean()))
+    # ---- config 1: 1x1x256x256 TV deconvolution, 20 iterations (launch-latency-bound)
+    gt, b1, psf = synthetic.deconv_case(1, 1, 256, 256, seed=2023)
+    bt, x = torch.from_numpy(b1).to(device), dp.Variable()
+    s = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device=device)
+    dt, o = _timed(lambda: s.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=20), 20)
+    out["config1"] = {"workload": "1x1x256x256 TV-deconv, ADMM 20 it", "ms_per_solve": dt * 1e3, "it_per_s": 20 / dt,
+                      "psnr_db": [psnr(bt.cpu(), torch.from_numpy(gt)), psnr(o.cpu(), torch.from_numpy(gt))],
+                      "roofline": {"bound": "hbm", "bytes_per_iter": 36.0 * 65536, "frac": 20 / dt * 36.0 * 65536 / HBM_PEAK,
+                                   "note": "2.4 MB per iteration is cache resident: launch-latency-bound, reported only"}}
+    # ---- config 3: config 2's data term + deep_prior(FFDNet-colour, seeded weights), 30 iterations
+    rng = np.random.RandomState(2023)
+    gt3 = torch.from_numpy(synthetic.synth(rng, B, C, H, W)).to(device)
+    b3 = (dp.conv(dp.Variable(), psf).to(device).forward(gt3) + torch.from_numpy((rng.randn(B, C, H, W) * 2 / 255).astype(np.float32)).to(device)).contiguous()
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=FFDNetColorDenoiser(synthetic.ffdnet_weights(7)))
+    s = dp.compile(dp.sum_squares(dp.conv(x, psf) - b3) + prior, method="admm", device=device)
+    rhos, sig = dp.log_descent(35, 5, 30)
+    with torch.no_grad():
+        dt, _ = _timed(lambda: s.solve(x0=b3, rhos=rhos, lams={prior: sig}, max_iter=30), 1)
+    flop = 3.5695e12                                   # SURVEY 8(d): denoiser FLOP per iteration at B = 8
+    out["config3"] = {"workload": "8x3x1024x1024 PnP ADMM, FFDNet-colour z-update (seeded weights), 30 it", "ms_per_iter": dt / 30 * 1e3,
+                      "it_per_s": 30 / dt, "path": s.last_path, "dtype": getattr(prior.denoiser, "compute_mode", "f32"),
+                      "roofline": {"bound": "mfma", "unit": "TFLOP/s", "achieved": flop * 30 / dt / 1e12, "peak": 157.3,
+                                   "frac": flop * 30 / dt / 157.3e12, "note": "denoiser FLOP / whole-iteration time vs the dense fp32 MFMA peak"}}
+    del s, prior, b3, gt3
+    # ---- config 4: one GPU's shard (4 of the 32 images) and the whole batch on one GPU
+    for tag, nb in (("config4_shard4", 4), ("config4_batch32", 32)):
+        gt4, mask, y = synthetic.csmri_case(nb, 320, 320, seed=2023)
+        mask_d, y_d = torch.from_numpy(mask).to(device), torch.from_numpy(y).to(device)
+        x = dp.Variable()
+        fns = dp.sum_squares(masked_fft(x, mask_d), y_d) + dp.nonneg(x) + dp.deep_prior(x, denoiser=FFDNetDenoiser(synthetic.ffdnet_weights(11, 1, 1, 64, 15)))
+        s = dp.compile(fns, method="ladmm", device=device, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100))
+        x0 = ifft2(y_d).real.contiguous()
+        with torch.no_grad():
+            dt, _ = _timed(lambda: s.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=10), 2)
+        cg = [int(n) for n in s.least_square.cg_iters[-10:]]
+        flop4 = 2.480e10 * nb
+        out[tag] = {"workload": f"{nb}x1x320x320 CS-MRI, LADMM + CG(rtol 1e-6, <=100) + nonneg + FFDNet-gray, 10 outer it",
+                    "ms_per_outer_iter": dt / 10 * 1e3, "cg_iters": cg,
+                    "roofline": {"bound": "mfma", "unit": "TFLOP/s", "achieved": flop4 * 10 / dt / 1e12, "peak": 157.3,
+                                 "frac": flop4 * 10 / dt / 157.3e12,
+                                 "cg_bytes_per_iter": 80.0 * nb * 320 * 320,
+                                 "note": "denoiser FLOP / whole outer-iteration time; the CG part is latency-bound (SURVEY 8(d): 80 B per "
+                                         "element and CG iteration)"}}
+        del s
+    # ---- config 5: unrolled ADMM x10 training step, 4x3x512x512
+    gt5, b5, psf = synthetic.deconv_case(4, 3, 512, 512, seed=2023)
+    bt, gtt = torch.from_numpy(b5).to(device), torch.from_numpy(gt5).to(device)
+    for mode in ("f32", "bf16"):
+        x = dp.Variable()
+        n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+        s = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + n0 + n1, method="admm", device=device)
+        if mode == "bf16" and not getattr(dp, "UNROLL_BF16", False):
+            continue
+        s = dp.specialize(s, method="unroll", device=device, max_iter=10, **({} if mode == "f32" else {"dtype": "bf16"}))
+        prm = [torch.full((10,), v, requires_grad=True, device=device) for v in (0.1, 0.005, 0.005)]
+
+        def step():
+            for p_ in prm:
+                p_.grad = None
+            o = s.solve(x0=bt, rhos=prm[0], lams={n0: prm[1], n1: prm[2]})
+            loss = ((o - gtt) ** 2).mean()
+            loss.backward()
+            return loss
+        dt, loss = _timed(step, 5)
+        n5 = 4 * 3 * 512 * 512
+        out["config5_" + mode] = {"workload": "4x3x512x512 unrolled ADMM x10 (specialize 'unroll'), MSE loss, fwd + bwd w.r.t. rho_t, lam_t",
+                                  "dtype": mode, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "loss": float(loss.detach()),
+                                  "roofline": {"bound": "hbm", "note": "forward 10 x 36 B/element + history writes, backward ~3x: launch-bound at "
+                                                                       "this size (12.6 MB per tensor)",
+                                               "frac_forward_bytes_only": 10 * 36.0 * n5 / dt / HBM_PEAK}}
+    return out
 
 
 def main():
@@ -180,11 +280,13 @@ def main():
     # HBM traffic of the dominant kernel from the PMC counters: rocprofv3 cannot be run from inside this process, so the
     # figure comes from the committed separate --pmc passes of this same command (tools/pmc_summary.py, profiles/)
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")
-    if os.path.exists(pmc_file):
-        for name, e in json.load(open(pmc_file)).items():
+    import glob
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    if pmc_files:
+        for name, e in json.load(open(pmc_files[-1])).items():
             if name.split("<")[0] == dom and "hbm_traffic_bytes" in e:
-                traffic, traffic_src = e["hbm_traffic_bytes"], "profiles/r1_pmc_hbm.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
+                traffic = e["hbm_traffic_bytes"]
+                traffic_src = f"profiles/{os.path.basename(pmc_files[-1])} (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
     dom_bytes = KERNEL_BYTES_PER_ELEM.get(dom, 0.0) * n_elem
     dom_avg_s = 1e-3 * rep[dom][1] / rep[dom][0]
     achieved = dom_bytes / dom_avg_s
@@ -201,18 +303,29 @@ def main():
                      "frac": achieved / HBM_PEAK, "frac_of_measured_copy": achieved / HBM_COPY, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_us": dom_avg_s * 1e6},
-        "roofline_iteration": {"algorithmic_bytes_per_iter": ITER_BYTES_PER_ELEM * n_elem,
-                               "achieved_GBps": (it_per_s / world) * ITER_BYTES_PER_ELEM * n_elem / 1e9,
-                               "frac": (it_per_s / world) * ITER_BYTES_PER_ELEM * n_elem / HBM_PEAK,
-                               "note": "SURVEY 8(d) accounting (64 B/element/iteration); the fused two-kernel schedule moves "
-                                       "36 B/element, see design_bytes_*",
-                               "design_bytes_per_iter": DESIGN_BYTES_PER_ELEM * n_elem,
-                               "design_achieved_GBps": (it_per_s / world) * DESIGN_BYTES_PER_ELEM * n_elem / 1e9,
-                               "design_frac": (it_per_s / world) * DESIGN_BYTES_PER_ELEM * n_elem / HBM_PEAK},
+        "roofline_iteration": {"bound": "hbm", "bytes_per_element": DESIGN_BYTES_PER_ELEM,
+                               "algorithmic_bytes_per_iter": DESIGN_BYTES_PER_ELEM * n_elem,
+                               "achieved_GBps": (it_per_s / world) * DESIGN_BYTES_PER_ELEM * n_elem / 1e9,
+                               "frac": (it_per_s / world) * DESIGN_BYTES_PER_ELEM * n_elem / HBM_PEAK,
+                               "frac_of_measured_copy": (it_per_s / world) * DESIGN_BYTES_PER_ELEM * n_elem / HBM_COPY,
+                               "kernel_time_share_of_step": 1e-3 * total_ms / K / (dt / K) if K else None,
+                               "note": "whole iteration (wall clock incl. launch gaps) on the 36 B/element the two-kernel schedule "
+                                       "moves: k_cols_p2 12 + k_iter_rows 24",
+                               "survey_accounting_bytes_per_iter": ITER_BYTES_PER_ELEM * n_elem,
+                               "survey_accounting_frac": (it_per_s / world) * ITER_BYTES_PER_ELEM * n_elem / HBM_PEAK,
+                               "survey_accounting_note": "comparison only: SURVEY 8(d) budgets 64 B/element for an un-fused 5-kernel "
+                                                         "schedule; this schedule does not move those bytes"},
         "kernels": kernels,
     }
     if world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(b.cpu(), psf)
+        n_it, sb = 4, 2
+        x_ref, res["cpu_baseline"] = cpu_baseline(b.cpu(), psf, n_iters=n_it, sample_b=sb)
+        x_gpu = solver.solve(x0=b, rhos=RHO, lams=LAM, max_iter=1 + n_it)[:sb].cpu()
+        res["parity_rel_l2"] = float((x_gpu - x_ref).double().norm() / x_ref.double().norm())
+        res["parity_note"] = (f"GPU iterate (images 0..{sb - 1} of the batch-8 solve, {1 + n_it} ADMM iterations) vs the CPU oracle run "
+                              f"timed above on the same images; bar 1e-5")
+    if world == 1 and not a.no_extra_configs:
+        res["configs"] = extra_configs(dp, synthetic, device)
     print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

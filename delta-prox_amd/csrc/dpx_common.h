@@ -31,22 +31,33 @@
 // dpx_wait_lds() (this wave's LDS reads have returned) before it re-targets a staging area.
 #ifdef DPX_EMULATED
 #include <cstring>
-__device__ inline void dpx_glds16(const void* g, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, g, 16); }
-__device__ inline void dpx_glds4(const void* g, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 4, g, 4); }
+template <int NT = 0> __device__ inline void dpx_glds16(const void* g, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, g, 16); }
+template <int NT = 0> __device__ inline void dpx_glds4(const void* g, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 4, g, 4); }
 template <int N> __device__ inline void dpx_wait_vm() { __builtin_amdgcn_wave_barrier(); }
 __device__ inline void dpx_wait_lds() { __builtin_amdgcn_wave_barrier(); }
 #else
-__device__ __forceinline__ void dpx_glds16(const void* g, void* lds_wave_base) {
+// Cache policy of streamed accesses.  NT = 1 marks a load `nt` (data read once by one CU: do not keep it in L2 ahead of
+// lines that are re-read); stores: ST = 0 plain, 1 `sc1` (write-through), 2 `nt`.  Measured on the config-2 iteration
+// (DESIGN.md section 3): `nt` on the row kernel's LDS-DMA streams -11 %, `nt` on the column kernel's stores -7 %.
+template <int NT = 0> __device__ __forceinline__ void dpx_glds16(const void* g, void* lds_wave_base) {
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
-__device__ __forceinline__ void dpx_glds4(const void* g, void* lds_wave_base) {
+template <int NT = 0> __device__ __forceinline__ void dpx_glds4(const void* g, void* lds_wave_base) {
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void dpx_wait_vm() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
@@ -92,6 +103,29 @@ bool timing_events(const char* name, hipEvent_t* start, hipEvent_t* stop);
       return DPX_ERR_ARG;               \
     }                                   \
   } while (0)
+
+// ---- streamed global accesses (data written once for the NEXT kernel / read once) -----------------------------------
+typedef float dpx_v2f __attribute__((ext_vector_type(2)));
+template <int ST> __device__ __forceinline__ void st_stream(float2* p, float2 v) {
+#ifdef DPX_EMULATED
+  *p = v;
+#else
+  if constexpr (ST == 1)
+    __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if constexpr (ST == 2)
+    __builtin_nontemporal_store(__builtin_bit_cast(dpx_v2f, v), (dpx_v2f*)p);
+  else
+    *p = v;
+#endif
+}
+template <int NT> __device__ __forceinline__ float2 ld_stream(const float2* p) {
+#ifdef DPX_EMULATED
+  return *p;
+#else
+  if constexpr (NT) return __builtin_bit_cast(float2, __builtin_nontemporal_load((const dpx_v2f*)p));
+  else return *p;
+#endif
+}
 
 // ---- complex arithmetic on float2 ---------------------------------------------------------------
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {

@@ -205,7 +205,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false, int DIL = 1, int NR = 2, bool M16 = false>
 __global__ void __launch_bounds__(256, 2) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x,
-                                                       const float* __restrict__ mask) {
+                                                       const float* __restrict__ mask, float slope) {
+  // RELU epilogue: max(v, 0) + slope * min(v, 0) -- slope = 0: ReLU, 0.2: the U-Net's LeakyReLU (exact for either sign)
   constexpr int M32 = MT * 32;
   constexpr int FFD_LDW = FfdTile<DIL, NR>::LDW, FFD_ROWS = FfdTile<DIL, NR>::ROWS, FFD_USED = FfdTile<DIL, NR>::USED;
   constexpr int FFD_TH = FfdTile<DIL, NR>::TH;
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_mfma(const float* __restrict
         for (int r = 0; r < 4; ++r) {
           const int cl = 4 * (lane >> 4) + r, co = co0 + cl;
           float v = acc16[nt][h][r] + bias[cl];
-          if (RELU) v = fmaxf(v, 0.f);
+          if (RELU) v = fmaxf(v, 0.f) + slope * fminf(v, 0.f);
           if (co < Cout && yy < H2 && xq < W2) outb[((size_t)co * H2 + yy) * W2 + xq] = v;
         }
       }
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_mfma(const float* __restrict
       for (int r = 0; r < 16; ++r) {
         const int cl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, co = co0 + cl;
         float v = acc[mt][nt][r] + bias[cl];
-        if (RELU) v = fmaxf(v, 0.f);
+        if (RELU) v = fmaxf(v, 0.f) + slope * fminf(v, 0.f);
         if (co < Cout && yy < H2 && xx < W2) {
           const size_t idx = ((size_t)co * H2 + yy) * W2 + xx;
           if (MASKED) v = maskb[idx] > 0.f ? v : 0.f;
@@ -365,22 +366,22 @@ static void launch_conv(bool relu, const float* in, float* out, const float* wpk
   const int tx = (W2 + FFD_TW - 1) / FFD_TW, ty = (H2 + 4 * NR - 1) / (4 * NR);
   if (mask) {
     DPX_LAUNCH("k_conv3x3_mfma_bwd", (k_conv3x3_mfma<MT, false, true, 9, false, 1, NR>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin,
-               Cout, H2, W2, tx, mask);
+               Cout, H2, W2, tx, mask, 0.f);
     return;
   }
   if constexpr (MT == 1) {
     if (!relu && Cout <= 16 && Cin % 4 == 0) {               // the last layer: 16-wide matrix-core tile
       DPX_LAUNCH("k_conv3x3_mfma16", (k_conv3x3_mfma<1, false, false, 9, false, 1, NR, true>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk,
-                 Cin, Cout, H2, W2, tx, (const float*)nullptr);
+                 Cin, Cout, H2, W2, tx, (const float*)nullptr, 0.f);
       return;
     }
   }
   if (relu)
     DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, true, false, 9, false, 1, NR>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout,
-               H2, W2, tx, (const float*)nullptr);
+               H2, W2, tx, (const float*)nullptr, 0.f);
   else
     DPX_LAUNCH("k_conv3x3_mfma", (k_conv3x3_mfma<MT, false, false, 9, false, 1, NR>), dim3(tx * ty, B), dim3(256), 0, s, in, out, wpk, Cin, Cout,
-               H2, W2, tx, (const float*)nullptr);
+               H2, W2, tx, (const float*)nullptr, 0.f);
 }
 
 static int layer_cin(int l, int in_nc, int nc) { return l == 0 ? 4 * in_nc + 1 : nc; }
@@ -806,20 +807,20 @@ __global__ void k_depth_to_space(const float* __restrict__ x, float* __restrict_
 
 template <int MT, int NTAP, int DIL = 1>
 static void launch_conv_generic(int relu, const float* in, float* out, const float* wpk, const float* res, int Cin, int Cout, int nblk, int B,
-                                int H, int W, hipStream_t s) {
+                                int H, int W, hipStream_t s, float slope = 0.f) {
   constexpr int NR = 2;
   const int tx = (W + FFD_TW - 1) / FFD_TW, ty = (H + 4 * NR - 1) / (4 * NR);
   const dim3 grid(tx * ty, B, nblk);
   if constexpr (DIL == 1) {
     if (res) {
-      DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, true, 1, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, res);
+      DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, true, 1, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, res, 0.f);
       return;
     }
   }
   if (relu)
-    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, true, false, NTAP, false, DIL, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, true, false, NTAP, false, DIL, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr, slope);
   else
-    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, false, DIL, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr);
+    DPX_LAUNCH("k_conv_mfma", (k_conv3x3_mfma<MT, false, false, NTAP, false, DIL, NR>), grid, dim3(256), 0, s, in, out, wpk, Cin, Cout, H, W, tx, (const float*)nullptr, 0.f);
 }
 template <int MT>
 static void launch_conv_dilated(int dil, int relu, const float* in, float* out, const float* wpk, int Cin, int Cout, int nblk, int B, int H,
@@ -847,14 +848,15 @@ extern "C" int dpx_conv_pack(void* packed, const float* w, const float* b, int c
   return launch_status("dpx_conv_pack");
 }
 
-extern "C" int dpx_conv2d(const float* in, float* out, const void* packed, const float* res, int relu, int cin, int cout, int taps,
-                          int dilation, int B, int H, int W, dpx_stream_t stream) {
+static int conv2d_impl(const float* in, float* out, const void* packed, const float* res, int relu, float slope, int cin, int cout, int taps,
+                       int dilation, int B, int H, int W, dpx_stream_t stream) {
   DPX_REQUIRE(in && out && packed && B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, "dpx_conv2d: bad arguments");
   DPX_REQUIRE(dilation >= 1 && dilation <= 4, "dpx_conv2d: dilation must be 1..4 (padding = dilation), got %d", dilation);
   DPX_REQUIRE(dilation == 1 || (taps == 9 && !res), "dpx_conv2d: dilated layers are 3x3 without a fused residual");
   DPX_REQUIRE(taps == 9 || taps == 1, "dpx_conv2d: taps must be 9 (3x3, pad 1) or 1 (1x1)");
   DPX_REQUIRE(cin % 2 == 0, "dpx_conv2d: the input must have an even number of channels (pad with a zero channel), got %d", cin);
   DPX_REQUIRE(!(res && relu), "dpx_conv2d: residual add and ReLU are not combined (ResBlock: conv-ReLU-conv + x)");
+  DPX_REQUIRE((size_t)FFD_CK * H * W < ((size_t)1 << 28), "dpx_conv2d: plane %dx%d too large for the 28-bit staging offsets", H, W);
   const int m32 = conv_block_width(cout), nblk = (cout + m32 - 1) / m32;
   hipStream_t s = (hipStream_t)stream;
   const float* wp = (const float*)packed;
@@ -866,9 +868,9 @@ extern "C" int dpx_conv2d(const float* in, float* out, const void* packed, const
     }
   } else if (taps == 9) {
     switch (m32 / 32) {
-      case 1: launch_conv_generic<1, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
-      case 2: launch_conv_generic<2, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
-      default: launch_conv_generic<3, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s); break;
+      case 1: launch_conv_generic<1, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s, slope); break;
+      case 2: launch_conv_generic<2, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s, slope); break;
+      default: launch_conv_generic<3, 9>(relu, in, out, wp, res, cin, cout, nblk, B, H, W, s, slope); break;
     }
   } else {
     switch (m32 / 32) {
@@ -878,6 +880,17 @@ extern "C" int dpx_conv2d(const float* in, float* out, const void* packed, const
     }
   }
   return launch_status("dpx_conv2d");
+}
+
+extern "C" int dpx_conv2d(const float* in, float* out, const void* packed, const float* res, int relu, int cin, int cout, int taps,
+                          int dilation, int B, int H, int W, dpx_stream_t stream) {
+  return conv2d_impl(in, out, packed, res, relu, 0.f, cin, cout, taps, dilation, B, H, W, stream);
+}
+
+extern "C" int dpx_conv2d_leaky(const float* in, float* out, const void* packed, float neg_slope, int cin, int cout, int taps, int B, int H,
+                                int W, dpx_stream_t stream) {
+  DPX_REQUIRE(taps == 9, "dpx_conv2d_leaky: 3x3 layers only");
+  return conv2d_impl(in, out, packed, nullptr, 1, neg_slope, cin, cout, taps, 1, B, H, W, stream);
 }
 
 extern "C" int dpx_space_to_depth(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream) {

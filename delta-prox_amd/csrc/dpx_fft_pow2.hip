@@ -117,6 +117,19 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
 // columns
 // ---------------------------------------------------------------------------------------------
 // DBG (tuning experiments only, default 0): bit0 = skip both transforms, bit1 = skip the operator's table loads
+#ifndef DPX_COLS_LD_NT
+#define DPX_COLS_LD_NT 0
+#endif
+#ifndef DPX_COLS_ADD_NT
+#define DPX_COLS_ADD_NT 1       // the data spectrum is re-read once per iteration, ~1 GB of other traffic later: stream it (see dpx_iter.hip)
+#endif
+#ifndef DPX_COLS_ST
+#define DPX_COLS_ST 0
+#endif
+#ifndef DPX_COLS_TBL_NT
+#define DPX_COLS_TBL_NT 0
+#endif
+constexpr int COLS_LD_NT = DPX_COLS_LD_NT, COLS_ADD_NT = DPX_COLS_ADD_NT, COLS_ST = DPX_COLS_ST;   // cache policy (dpx_common.h)
 #ifndef DPX_COLS_BATCH_INNER
 #define DPX_COLS_BATCH_INNER 1
 #endif
@@ -190,7 +203,7 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   float2* twl = smem_p2 + COLS * S;                   // the H column twiddles, shared by the workgroup
   float2 v[V];
 #pragma unroll
-  for (int m = 0; m < V; ++m) v[m] = *(const float2*)(pin + (off0 + step * m) * 8u);
+  for (int m = 0; m < V; ++m) v[m] = ld_stream<COLS_LD_NT>((const float2*)(pin + (off0 + step * m) * 8u));
   for (int i = tid; i < H; i += T * COLS) twl[i] = twH[i];
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const char* add = (OP == OP_SOLVE && A.add) ? (const char*)(A.add + ubase) : nullptr;
@@ -223,14 +236,14 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
       const int half = ln >> 5, li = ln & 31;
       const float2* src = A.dd + tbase + (unsigned)((T * half + RPW * wave + li / LPR) * SPEC_TILE + (li % LPR) * 2) + sub_off;
 #pragma unroll
-      for (int j = 0; j < V / 2; ++j) dpx_glds16(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
+      for (int j = 0; j < V / 2; ++j) dpx_glds16<DPX_COLS_TBL_NT>(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
     }
     if constexpr (OP == OP_SOLVE && EARLY_ADD) {
       unsigned offa = off0;
       DPX_OPAQUE(offa);
       if (add) {
 #pragma unroll
-        for (int m = 0; m < V; ++m) av[m] = *(const float2*)(add + (offa + step * m) * 8u);
+        for (int m = 0; m < V; ++m) av[m] = ld_stream<COLS_ADD_NT>((const float2*)(add + (offa + step * m) * 8u));
       }
     }
   };
@@ -243,7 +256,7 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
     DPX_OPAQUE(offa);
     if (!EARLY_ADD && add) {
 #pragma unroll
-      for (int m = 0; m < V; ++m) av[m] = *(const float2*)(add + (offa + step * m) * 8u);
+      for (int m = 0; m < V; ++m) av[m] = ld_stream<COLS_ADD_NT>((const float2*)(add + (offa + step * m) * 8u));
     }
     if (DMA_TABLE && !is_side) {
       if (add) dpx_wait_vm<V>();                        // the V data-spectrum loads above may stay in flight
@@ -278,7 +291,7 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   unsigned off1 = off0;
   DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores
 #pragma unroll
-  for (int m = 0; m < V; ++m) *(float2*)(pout + (off1 + step * m) * 8u) = v[m];
+  for (int m = 0; m < V; ++m) st_stream<COLS_ST>((float2*)(pout + (off1 + step * m) * 8u), v[m]);
 }
 
 // Tuning probe (DPX_DEBUG_COLS=4, wrong results by design): the column kernel's HBM traffic with 16-byte accesses and

@@ -290,6 +290,24 @@ static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& T
 // Per band: R+2 inverse transforms, R+1 z-updates, R forward transforms (halo = one row above, one below).
 // The loop contains no compiler-visible global load (twiddles live in LDS / registers, per-image scalars are
 // read before the loop): hipcc therefore never inserts a vmcnt wait of its own that would drain the prefetch.
+// Cache policy of the row kernel's four streams (dpx_common.h): spectrum in / u in (loads, 1 = nt), u out / spectrum out
+// (stores, 2 = nt).  The two spectra are the hand-over between the two kernels of an iteration (written by one, read by the
+// next: 2 x 100 MB at 8x3x1024^2, which the 256 MB Infinity Cache can hold); the dual variables come back a whole iteration
+// later and the data spectrum is re-read once per iteration -- streaming those past the caches (`nt`) leaves the cache to the
+// spectra.  Measured (12-variant matrix, gpurun_out/ab3.log): all plain 4692 it/s, this setting 5147 it/s.
+#ifndef DPX_R_LDX
+#define DPX_R_LDX 0
+#endif
+#ifndef DPX_R_LDU
+#define DPX_R_LDU 1
+#endif
+#ifndef DPX_R_STU
+#define DPX_R_STU 2
+#endif
+#ifndef DPX_R_STX
+#define DPX_R_STX 0
+#endif
+constexpr int R_LDX = DPX_R_LDX, R_LDU = DPX_R_LDU, R_STU = DPX_R_STU, R_STX = DPX_R_STX;
 template <int M, int T, int NT>
 __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
                                                         const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
@@ -346,15 +364,15 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   auto stage_idx = [&](int e) { return ((e >> 1) / T) * 128 + g * 2 * T + ((e >> 1) % T) * 2 + (e & 1); };
   auto issue_x = [&](int h) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) dpx_glds16(spec_in + xoff + (unsigned)h * SPEC_TILE + xstep * i, stX + i * 128);
-    dpx_glds4(spec_in + noff + h, stN);
+    for (int i = 0; i < D; ++i) dpx_glds16<R_LDX>(spec_in + xoff + (unsigned)h * SPEC_TILE + xstep * i, stX + i * 128);
+    dpx_glds4<R_LDX>(spec_in + noff + h, stN);
   };
   auto issue_u = [&](int h) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const float2* urow = (const float2*)TT.t[n].u_in + uoff + (unsigned)h * M;
 #pragma unroll
-      for (int i = 0; i < D; ++i) dpx_glds16(urow + 2 * T * i, stU + n * STG + i * 128);
+      for (int i = 0; i < D; ++i) dpx_glds16<R_LDU>(urow + 2 * T * i, stU + n * STG + i * 128);
     }
   };
   // lower bounds of the vector-memory operations issued AFTER the awaited DMA (a wait count must never exceed the real
@@ -482,7 +500,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
         if (own) {
           float2* uo = (float2*)tm.u_out + (unsigned)pl * H * M + hz * M + t;
 #pragma unroll
-          for (int m = 0; m < V; ++m) uo[m * T] = d[m];
+          for (int m = 0; m < V; ++m) st_stream<R_STU>(uo + m * T, d[m]);
           if (emit_v) {
             float2* vo = (float2*)tm.v_out + (unsigned)pl * H * M + hz * M + t;
 #pragma unroll
@@ -525,13 +543,13 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
           float2 Xo;
           if (k == 0) {
             Xo = make_float2(zk.x + zk.y, 0.f);
-            spec_out[noff + hz] = make_float2(zk.x - zk.y, 0.f);
+            st_stream<R_STX>(spec_out + noff + hz, make_float2(zk.x - zk.y, 0.f));
           } else {
             const float2 e = cscale(cadd(zk, zm), 0.5f);
             const float2 d = cscale(csub(zk, zm), 0.5f);
             Xo = cadd(e, cmul(make_float2(d.y, -d.x), twl[k]));
           }
-          out[tile_step * m] = Xo;
+          st_stream<R_STX>(out + tile_step * m, Xo);
         }
       }
     }
@@ -678,11 +696,18 @@ extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, co
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS, "dpx_admm_run: nterms");
   for (int i = 0; i < nterms; ++i) cur[i] = terms[i];
   int parity = 0;
+  static const bool cols_inplace = getenv("DPX_COLS_INPLACE") != nullptr;    // tuning experiment
   for (int k = 0; k < n_iters; ++k) {
     const int it = it0 + k;
     const bool last_of_solve = (it == total_iters - 1);
     const bool emit = emit_last && (k == n_iters - 1);
-    int rc = dpx_admm_iter_cols(spec_a, spec_b, spec_add, dd, rho_tab + (size_t)it * B, eps, B, C, H, W, table, stream);
+    if (cols_inplace) {
+      // column pass in place (every workgroup reads its whole tile before it writes it); the row pass then needs the other buffer
+      void* t = spec_a; spec_a = spec_b; spec_b = t;
+      int rc0 = dpx_admm_iter_cols(spec_b, spec_b, spec_add, dd, rho_tab + (size_t)it * B, eps, B, C, H, W, table, stream);
+      if (rc0) return rc0;
+    }
+    int rc = cols_inplace ? 0 : dpx_admm_iter_cols(spec_a, spec_b, spec_add, dd, rho_tab + (size_t)it * B, eps, B, C, H, W, table, stream);
     if (rc) return rc;
     for (int i = 0; i < nterms; ++i) {
       cur[i].lam = lam_tabs[i] ? lam_tabs[i] + (size_t)it * B : nullptr;

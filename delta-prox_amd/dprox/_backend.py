@@ -109,6 +109,13 @@ SIGNATURES = {
     "dpx_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_conv2d_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "dpx_conv2d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_conv2d_leaky": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_maxpool2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_maxpool2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_copy_channels": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_upsample2_into": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_upsample2_into_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_leaky_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
     "dpx_space_to_depth": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_depth_to_space": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_acts_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -175,12 +182,25 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def device_guard(device):
+    """context manager making `device` the current HIP device (no-op under tests/emul and for an unspecific / CPU device)"""
+    import contextlib
+    device = torch.device(device) if not isinstance(device, torch.device) else device
+    if _host_pointers or device.type != "cuda":
+        return contextlib.nullcontext()
+    return torch.cuda.device(device)
+
+
 def require(t: torch.Tensor, dtype=torch.float32, what="tensor"):
     if not isinstance(t, torch.Tensor):
         raise DpxError(f"{what}: expected a torch.Tensor, got {type(t)}")
     if not _host_pointers and not t.is_cuda:
         raise DpxError(f"{what} lives on {t.device}: the MI355X backend only runs on HIP devices "
                        "(no CPU fallback); pass device='cuda'")
+    if not _host_pointers and t.device.index != torch.cuda.current_device():
+        raise DpxError(f"{what} lives on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: the backend "
+                       f"launches on the current device's stream -- wrap the call in `with torch.cuda.device({t.device.index}):` "
+                       "(Algorithm.solve does this for its own device)")
     if dtype is not None and t.dtype != dtype:
         raise DpxError(f"{what}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():

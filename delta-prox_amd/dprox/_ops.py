@@ -538,6 +538,69 @@ def conv2d(x, packed, cout, taps, relu=False, res=None, dilation=1):
     return out
 
 
+def conv2d_leaky(x, packed, cout, neg_slope=0.2):
+    """3x3 / pad 1 convolution + bias + LeakyReLU(neg_slope) fused (the U-Net denoiser's ConvLayer)"""
+    require(x, what="conv input")
+    B, C, H, W = _shape4(x)
+    out = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    be.lib().call("dpx_conv2d_leaky", ptr(x), ptr(out), ptr(packed), float(neg_slope), C, cout, 9, B, H, W, be.stream())
+    return out
+
+
+def leaky_relu_bwd(y, g, neg_slope=0.2):
+    """g * (y > 0 ? 1 : neg_slope): backward of the fused LeakyReLU from the layer's saved output"""
+    require(y, what="activation")
+    require(g, what="gradient")
+    out = torch.empty_like(g)
+    be.lib().call("dpx_leaky_relu_bwd", ptr(y), ptr(g), ptr(out), y.numel(), float(neg_slope), be.stream())
+    return out
+
+
+def maxpool2(x):
+    """MaxPool2d(2) (floor)"""
+    require(x, what="maxpool input")
+    B, C, H, W = _shape4(x)
+    y = torch.empty(B, C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    be.lib().call("dpx_maxpool2", ptr(x), ptr(y), B, C, H, W, be.stream())
+    return y
+
+
+def maxpool2_bwd(x, gy):
+    require(x, what="maxpool input")
+    require(gy, what="maxpool output gradient")
+    B, C, H, W = _shape4(x)
+    gx = torch.empty_like(x)
+    be.lib().call("dpx_maxpool2_bwd", ptr(x), ptr(gy), ptr(gx), B, C, H, W, be.stream())
+    return gx
+
+
+def concat_skip_upsampled(skip, low):
+    """torch.cat([skip, pad(upsample_x2_bilinear_align_corners(low))], dim=1) without the intermediates: the interpolated,
+    zero-padded tensor is written straight into its channel slice (reference models/unet/unet.py:96-117)"""
+    require(skip, what="skip tensor")
+    require(low, what="low-resolution tensor")
+    B, C2, H, W = _shape4(skip)
+    _, C1, h, w = _shape4(low)
+    out = torch.empty(B, C2 + C1, H, W, dtype=torch.float32, device=skip.device)
+    L = be.lib()
+    L.call("dpx_copy_channels", ptr(skip), ptr(out), 1, B, C2, H, W, C2 + C1, 0, be.stream())
+    L.call("dpx_upsample2_into", ptr(low), ptr(out), B, C1, h, w, C2 + C1, C2, H, W, be.stream())
+    return out
+
+
+def concat_skip_upsampled_bwd(g, C2, low_shape):
+    """gradients of concat_skip_upsampled w.r.t. (skip, low)"""
+    require(g, what="concat gradient")
+    B, Ct, H, W = _shape4(g)
+    C1, (h, w) = Ct - C2, low_shape
+    gskip = torch.empty(B, C2, H, W, dtype=torch.float32, device=g.device)
+    glow = torch.empty(B, C1, h, w, dtype=torch.float32, device=g.device)
+    L = be.lib()
+    L.call("dpx_copy_channels", ptr(g), ptr(gskip), 0, B, C2, H, W, Ct, 0, be.stream())
+    L.call("dpx_upsample2_into_bwd", ptr(g), ptr(glow), B, C1, h, w, Ct, C2, H, W, be.stream())
+    return gskip, glow
+
+
 def conv2d_wgrad(g, a, taps, dilation=1, want_bias=False):
     """weight (and bias) gradient of one conv2d layer: g [B,cout,H,W] gradient of the pre-activation output, a [B,cin,H,W] the
     layer's input -> gw [cout, cin, taps] (, gb [cout])"""

@@ -66,9 +66,14 @@ class UnrolledSolver(nn.Module):
         if learned_params:
             self.rhos = nn.Parameter(torch.ones(max_iter))
             self.lams = {}
-            for fn in solver.psi_fns:
+            # parameter names follow the reference (setattr(self, str(fn), lam), unroll.py:35-38: the class name of the term), so
+            # that its checkpoints load; there a second term of the same class silently takes the name over -- here the earlier
+            # one keeps a suffixed name instead of dropping out of parameters() / state_dict()
+            names = [str(fn) for fn in solver.psi_fns]
+            for i, fn in enumerate(solver.psi_fns):
                 lam = nn.Parameter(torch.ones(max_iter))
-                setattr(self, "lam_" + str(len(self.lams)), lam)
+                last = i == max(j for j, n in enumerate(names) if n == names[i])
+                setattr(self, names[i] if last else f"{names[i]}#{i}", lam)
                 self.lams[fn] = lam
 
     def solve(self, x0=None, rhos=None, lams=None, max_iter=None, **kwargs):

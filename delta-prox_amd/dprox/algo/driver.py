@@ -103,10 +103,13 @@ class Algorithm(nn.Module):
             raise be.DpxError(f"solver lives on {device}: the MI355X backend has no CPU path; "
                               "compile(..., device='cuda') / Problem.solve(device='cuda')")
         x0, rhos, lams, max_iter = self.defaults(x0, rhos, lams, max_iter)
-        x0, rhos, lams = move(x0, rhos, lams, device=device)
-        x0 = x0.contiguous()
-        state = self.initialize(x0, **kwargs)
-        state = self.iters(state, rhos, lams, max_iter, pbar, callback=callback)
+        # every kernel of the solve is issued on the current stream of the SOLVER's GPU (the C ABI takes a raw stream handle:
+        # launching with another device current would run GPU-k pointers on GPU-0's stream)
+        with be.device_guard(device):
+            x0, rhos, lams = move(x0, rhos, lams, device=device)
+            x0 = x0.contiguous()
+            state = self.initialize(x0, **kwargs)
+            state = self.iters(state, rhos, lams, max_iter, pbar, callback=callback)
         return state if return_full_states else state[0]
 
     def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):

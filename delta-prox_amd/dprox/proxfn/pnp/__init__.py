@@ -1,2 +1,2 @@
-from .denoisers import Denoiser, Denoiser2D, DRUNetDenoiser, FFDNet, FFDNetColorDenoiser, FFDNetDenoiser, IRCNN, IRCNNDenoiser, UNetRes
+from .denoisers import Denoiser, Denoiser2D, DRUNetDenoiser, FFDNet, FFDNetColorDenoiser, FFDNetDenoiser, IRCNN, IRCNNDenoiser, UNet, UNetDenoiser, UNetRes
 from .prior import deep_prior, get_denoiser

@@ -35,7 +35,64 @@ class Denoiser2D(Denoiser):
         return torch.cat([self._denoise(band.contiguous(), sigma) for band in input.split(1, dim=1)], dim=1)
 
 
-class FFDNet(nn.Module):
+class RefKeyed(nn.Module):
+    """Base of the hand-written networks: parameters are plain ``nn.Parameter``s of THIS module, registered under attribute
+    names without dots, and saved / loaded under the reference model's dotted state-dict keys (``model.0.weight``,
+    ``m_down1.0.res.0.weight``, ``inc.conv.conv-0.conv2d.weight`` ...) through nn.Module's own recursive protocol
+    (``_save_to_state_dict`` / ``_load_from_state_dict``): a parent module's ``state_dict()`` / ``load_state_dict()`` and the
+    reference's checkpoints both work unchanged."""
+
+    def __init__(self):
+        super().__init__()
+        self._ref_attr = {}                   # reference key -> attribute name (insertion order = reference order)
+
+    def add_ref_param(self, key, shape, requires_grad=True):
+        attr = "p__" + key.replace(".", "__")
+        self.register_parameter(attr, nn.Parameter(torch.zeros(*shape), requires_grad=requires_grad))
+        self._ref_attr[key] = attr
+
+    def ref_param(self, key):
+        return getattr(self, self._ref_attr[key])
+
+    @property
+    def ref_keys(self):
+        return list(self._ref_attr)
+
+    def _weights_changed(self):
+        """drop the packed-weight caches"""
+        self._packed = None
+        self._packed_T = None
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for key, attr in self._ref_attr.items():
+            p = getattr(self, attr)
+            destination[prefix + key] = p if keep_vars else p.detach()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for key, attr in self._ref_attr.items():
+            full = prefix + key
+            if full not in state_dict:
+                missing_keys.append(full)
+                continue
+            p, v = getattr(self, attr), torch.as_tensor(state_dict[full])
+            if tuple(v.shape) != tuple(p.shape):
+                error_msgs.append(f"size mismatch for {full}: checkpoint {tuple(v.shape)} vs model {tuple(p.shape)}")
+                continue
+            with torch.no_grad():
+                p.copy_(v)
+        if strict:
+            unexpected_keys.extend(k for k in state_dict if k.startswith(prefix) and k[len(prefix):] not in self._ref_attr)
+        self._weights_changed()
+
+    def _apply(self, fn, *a, **k):
+        self._weights_changed()
+        return super()._apply(fn, *a, **k)
+
+    def _weights_version(self):
+        return tuple(getattr(self, a)._version for a in self._ref_attr.values())
+
+
+class FFDNet(RefKeyed):
     """FFDNet(in_nc, out_nc, nc, nb): conv3x3(in_nc*4+1 -> nc) + (nb-2) x conv3x3(nc -> nc) + conv3x3(nc -> out_nc*4)"""
 
     def __init__(self, in_nc=1, out_nc=1, nc=64, nb=15, act_mode="R"):
@@ -44,40 +101,34 @@ class FFDNet(nn.Module):
         assert in_nc == out_nc
         self.in_nc, self.out_nc, self.nc, self.nb = in_nc, out_nc, nc, nb
         chans = [in_nc * 4 + 1] + [nc] * (nb - 1) + [out_nc * 4]
-        self.weights = nn.ParameterList([nn.Parameter(torch.zeros(co, ci, 3, 3)) for ci, co in zip(chans[:-1], chans[1:])])
-        self.biases = nn.ParameterList([nn.Parameter(torch.zeros(co)) for co in chans[1:]])
+        for i, (ci, co) in enumerate(zip(chans[:-1], chans[1:])):        # reference layout: Conv2d at the even indices of `model`
+            self.add_ref_param(f"model.{2 * i}.weight", (co, ci, 3, 3))
+            self.add_ref_param(f"model.{2 * i}.bias", (co,))
         self._packed = None
 
-    # reference checkpoint layout: Conv2d modules at the even indices of `model`
+    @property
+    def weights(self):
+        return [self.ref_param(f"model.{2 * i}.weight") for i in range(self.nb)]
+
+    @property
+    def biases(self):
+        return [self.ref_param(f"model.{2 * i}.bias") for i in range(self.nb)]
+
     def load_reference_state_dict(self, sd):
-        for i in range(self.nb):
-            self.weights[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.weight"]))
-            self.biases[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.bias"]))
-        self._packed = None
+        self.load_state_dict(sd, strict=True)
         return self
 
     def load_layers(self, layers):
         """layers: [(weight[co,ci,3,3], bias[co])] numpy/torch"""
         assert len(layers) == self.nb
-        for i, (w, b) in enumerate(layers):
-            self.weights[i].data.copy_(torch.as_tensor(w))
-            self.biases[i].data.copy_(torch.as_tensor(b))
-        self._packed = None
+        for (w, b), pw, pb in zip(layers, self.weights, self.biases):
+            pw.data.copy_(torch.as_tensor(w))
+            pb.data.copy_(torch.as_tensor(b))
+        self._weights_changed()
         return self
 
     def reference_state_dict(self):
-        sd = {}
-        for i in range(self.nb):
-            sd[f"model.{2 * i}.weight"] = self.weights[i].detach().cpu()
-            sd[f"model.{2 * i}.bias"] = self.biases[i].detach().cpu()
-        return sd
-
-    def _apply(self, fn, *a, **k):
-        self._packed = None
-        return super()._apply(fn, *a, **k)
-
-    def _weights_version(self):
-        return tuple(p._version for p in list(self.weights) + list(self.biases))
+        return {k: v.detach().cpu() for k, v in self.state_dict().items()}
 
     def packed_T(self):
         """flipped / transposed weights of the backward-data convolutions (dpx_ffdnet_pack_transposed), cached per weight version"""
@@ -117,7 +168,7 @@ class FFDNet(nn.Module):
             sig_t = sigma if isinstance(sigma, torch.Tensor) else torch.as_tensor(sigma, dtype=torch.float32)
             sig_t = sig_t.to(device=x.device, dtype=torch.float32).reshape(-1)
             sig_t = sig_t.expand(B).contiguous() if sig_t.numel() == 1 else sig_t.contiguous()
-            params = (list(self.weights) + list(self.biases)) if train_w else []
+            params = (self.weights + self.biases) if train_w else []
             return _FFDNetFn.apply(self, x, sig_t, *params)
         sig = ops.as_batch_vec(sigma, B, x.device)
         L = be.lib()
@@ -238,11 +289,14 @@ class _ConvFn(torch.autograd.Function):
     parameter) is given -- the weight gradient is the pixels-as-K GEMM ``dpx_conv2d_wgrad`` on the saved input"""
 
     @staticmethod
-    def forward(ctx, x, res, weight, fwd, bwd, relu, dilation=1, bias=None):
+    def forward(ctx, x, res, weight, fwd, bwd, relu, dilation=1, bias=None, slope=0.0):
         blob, cout, taps = fwd
         x = x.contiguous()
-        y = ops.conv2d(x, blob, cout, taps, relu=relu, res=None if res is None else res.contiguous(), dilation=dilation)
-        ctx.bwd, ctx.relu, ctx.has_res, ctx.taps, ctx.dilation = bwd, relu, res is not None, taps, dilation
+        if slope:                                            # LeakyReLU(slope) epilogue (U-Net); relu is implied
+            y, relu = ops.conv2d_leaky(x, blob, cout, slope), True
+        else:
+            y = ops.conv2d(x, blob, cout, taps, relu=relu, res=None if res is None else res.contiguous(), dilation=dilation)
+        ctx.bwd, ctx.relu, ctx.has_res, ctx.taps, ctx.dilation, ctx.slope = bwd, relu, res is not None, taps, dilation, slope
         train_w = (weight is not None and weight.requires_grad) or (bias is not None and bias.requires_grad)
         ctx.save_for_backward(y if relu else x.new_empty(0), x if train_w else x.new_empty(0))
         return y
@@ -252,9 +306,11 @@ class _ConvFn(torch.autograd.Function):
         g = g.contiguous()
         gp = g
         y, x = ctx.saved_tensors
-        if ctx.relu:
+        if ctx.slope:
+            gp = ops.leaky_relu_bwd(y, g, ctx.slope)                                                                    # g * (y > 0 ? 1 : slope)
+        elif ctx.relu:
             gp, _ = ops.prox_bwd(be.PROX_NONNEG, y, g, torch.zeros((), device=g.device), 1.0, None, want_dlam=False)   # g * [y > 0]
-        need = ctx.needs_input_grad                          # as many entries as apply() got arguments (6 or 8)
+        need = ctx.needs_input_grad                          # as many entries as apply() got arguments (6 .. 9)
         need_b = len(need) > 7 and need[7]
         gw = gb = None
         if need[2] or need_b:
@@ -266,7 +322,7 @@ class _ConvFn(torch.autograd.Function):
             if gp.shape[1] % 2:
                 gp = torch.cat([gp, torch.zeros_like(gp[:, :1])], dim=1).contiguous()
             gx = ops.conv2d(gp, blob_t, cin, taps, dilation=ctx.dilation)
-        return (gx, (g if ctx.has_res else None), gw, None, None, None, None, gb)[:len(need)]
+        return (gx, (g if ctx.has_res else None), gw, None, None, None, None, gb, None)[:len(need)]
 
 
 class _S2DFn(torch.autograd.Function):
@@ -309,7 +365,7 @@ class _SubFn(torch.autograd.Function):
         return g, ops.lincomb([(-1.0, g.contiguous())])
 
 
-class UNetRes(nn.Module):
+class UNetRes(RefKeyed):
     """DRUNet body (reference models/network_unet.py:67-117): head conv, 3 x (nb ResBlocks + 2x2 stride-2 conv), nb ResBlocks,
     3 x (2x2 stride-2 transposed conv + nb ResBlocks), tail conv; no biases.  Every convolution runs on the fp32-MFMA
     kernel behind ``dpx_conv2d`` (ReLU / residual add fused into the epilogue); the strided / transposed 2x2 convolutions
@@ -338,43 +394,27 @@ class UNetRes(nn.Module):
             for i in range(nb):
                 for k in (0, 2):
                     shapes[f"m_up{lvl}.{i + 1}.res.{k}.weight"] = (nc[lvl - 1], nc[lvl - 1], 3, 3)
-        self._names = list(shapes)
         self._diff = False
-        self.params = nn.ParameterDict({n.replace(".", "/"): nn.Parameter(torch.zeros(*shp), requires_grad=False) for n, shp in shapes.items()})
+        for key, shp in shapes.items():                      # the reference's state-dict keys (frozen until trained: requires_grad_())
+            self.add_ref_param(key, shp, requires_grad=False)
         self._packed = None
 
-    def load_state_dict(self, sd, strict=True):              # reference key names
-        missing = [n for n in self._names if n not in sd]
-        extra = [k for k in sd if k not in self._names]
-        if strict and (missing or extra):
-            raise RuntimeError(f"UNetRes.load_state_dict: missing {missing[:3]}..., unexpected {extra[:3]}...")
-        for n in self._names:
-            if n in sd:
-                self.params[n.replace(".", "/")].data.copy_(torch.as_tensor(sd[n]))
-        self._packed = None
-        self._packed_T = None
-        return self
-
-    def state_dict(self, *a, **k):
-        return {n: self.params[n.replace(".", "/")].detach().cpu() for n in self._names}
-
-    def _apply(self, fn, *a, **k):
-        self._packed = None
-        self._packed_T = None
-        return super()._apply(fn, *a, **k)
+    @property
+    def _names(self):
+        return self.ref_keys
 
     def _w(self, name):
-        return self.params[name.replace(".", "/")].detach().float()
+        return self.ref_param(name).detach().float()
 
     def _check_version(self):
         """the packed blobs follow the parameters (an optimizer step bumps their version counters)"""
-        ver = sum(p._version for p in self.params.values())
+        ver = sum(self._weights_version())
         if ver != getattr(self, "_pack_version", None):
             self._packed, self._packed_T, self._pack_version = None, None, ver
 
     def _kernel_form(self, name):
         """the parameter as the [cout, cin, taps] tensor dpx_conv2d sees (an autograd view: gradients flow back to it)"""
-        w = self.params[name.replace(".", "/")]
+        w = self.ref_param(name)
         if w.shape[-1] == 3:
             return w.reshape(w.shape[0], w.shape[1], 9)
         if name.startswith("m_down"):
@@ -419,7 +459,7 @@ class UNetRes(nn.Module):
 
     def _conv(self, x, name, relu=False, res=None):
         if self._diff:
-            w = self._kernel_form(name) if self.params[name.replace(".", "/")].requires_grad else None
+            w = self._kernel_form(name) if self.ref_param(name).requires_grad else None
             return _ConvFn.apply(x, res, w, self.packed()[name], self.packed_T()[name], relu)
         blob, cout, taps = self.packed()[name]
         return ops.conv2d(x, blob, cout, taps, relu=relu, res=res)
@@ -433,7 +473,7 @@ class UNetRes(nn.Module):
     def forward(self, x0):
         be.require(x0, what="UNetRes input")
         self._check_version()
-        self._diff = torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in self.params.values()))
+        self._diff = torch.is_grad_enabled() and (x0.requires_grad or any(p.requires_grad for p in self.parameters()))
         if self._diff:
             s2d, d2s, add = _S2DFn.apply, _D2SFn.apply, _AddFn.apply
         else:
@@ -468,28 +508,179 @@ class DRUNetDenoiser(Denoiser):
         L = torch.cat((x, sigma.to(x.device, x.dtype).repeat(1, 1, x.shape[2], x.shape[3])), dim=1)
         return self._run(L)
 
+    # Tiling policy of wrapper.py:112-146, expressed per axis: an axis of length n is covered by two overlapping windows of
+    # k = (n // 2 // refield + 1) * refield samples, [0, k) and [n - k, n); the first contributes the output samples [0, n // 2),
+    # the second [n // 2, n).  A plane is the product of its two axes' windows (four overlapping tiles); tiles are denoised
+    # directly while the plane has at most 4 * min_size^2 pixels and recursively otherwise.  Planes of at most min_size^2
+    # pixels are replicate-padded to a multiple of `modulo` (the three 2x down-samplings) and denoised in one pass.
+    @staticmethod
+    def _axis_windows(n, refield):
+        k = (n // 2 // refield + 1) * refield
+        half = n // 2
+        return ((slice(0, k), slice(0, half), slice(0, half)),                 # (input window, output range, range inside the tile)
+                (slice(n - k, n), slice(half, n), slice(k - (n - half), k)))
+
     def _run(self, L, refield=32, min_size=256, modulo=16):
         h, w = L.shape[-2:]
-        if h * w <= min_size ** 2:
-            Lp = torch.nn.functional.pad(L, (0, int(np.ceil(w / modulo) * modulo - w), 0, int(np.ceil(h / modulo) * modulo - h)), mode="replicate")
-            return self.model(Lp.contiguous())[..., :h, :w]
-        top, bottom = slice(0, (h // 2 // refield + 1) * refield), slice(h - (h // 2 // refield + 1) * refield, h)
-        left, right = slice(0, (w // 2 // refield + 1) * refield), slice(w - (w // 2 // refield + 1) * refield, w)
-        Ls = [L[..., top, left], L[..., top, right], L[..., bottom, left], L[..., bottom, right]]
-        if h * w <= 4 * (min_size ** 2):
-            Es = [self.model(q.contiguous()) for q in Ls]
-        else:
-            Es = [self._run(q, refield, min_size, modulo) for q in Ls]
-        b, c = Es[0].shape[:2]
-        E = torch.zeros(b, c, h, w, dtype=L.dtype, device=L.device)
-        E[..., :h // 2, :w // 2] = Es[0][..., :h // 2, :w // 2]
-        E[..., :h // 2, w // 2:] = Es[1][..., :h // 2, (-w + w // 2):]
-        E[..., h // 2:, :w // 2] = Es[2][..., (-h + h // 2):, :w // 2]
-        E[..., h // 2:, w // 2:] = Es[3][..., (-h + h // 2):, (-w + w // 2):]
-        return E
+        if h * w <= min_size * min_size:
+            pad_h, pad_w = -h % modulo, -w % modulo
+            padded = torch.nn.functional.pad(L, (0, pad_w, 0, pad_h), mode="replicate") if (pad_h or pad_w) else L
+            return self.model(padded.contiguous())[..., :h, :w]
+        direct = h * w <= 4 * min_size * min_size
+        out = None
+        for win_h, dst_h, src_h in self._axis_windows(h, refield):
+            for win_w, dst_w, src_w in self._axis_windows(w, refield):
+                tile = L[..., win_h, win_w].contiguous()
+                den = self.model(tile) if direct else self._run(tile, refield, min_size, modulo)
+                if out is None:
+                    out = torch.empty(den.shape[0], den.shape[1], h, w, dtype=L.dtype, device=L.device)
+                out[..., dst_h, dst_w] = den[..., src_h, src_w]
+        return out
 
 
-class IRCNN(nn.Module):
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.maxpool2(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2_bwd(x, g.contiguous())
+
+
+class _ConcatUpFn(torch.autograd.Function):
+    """cat([skip, zero-pad(bilinear x2 (low))], dim=1) as one pair of kernels, and its adjoint"""
+
+    @staticmethod
+    def forward(ctx, skip, low):
+        ctx.c2, ctx.low_hw = int(skip.shape[1]), (int(low.shape[2]), int(low.shape[3]))
+        return ops.concat_skip_upsampled(skip.contiguous(), low.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.concat_skip_upsampled_bwd(g.contiguous(), ctx.c2, ctx.low_hw)
+
+
+class UNet(RefKeyed):
+    """The U-Net denoiser body (reference models/unet/unet.py:34-135): inc / down1..4 / up1..4 are ConvBlocks of three biased 3x3
+    convolutions each followed by LeakyReLU(0.2) -- one ``dpx_conv2d_leaky`` launch per layer on the fp32 matrix-core kernel --
+    with MaxPool2d(2) on the way down (``dpx_maxpool2``) and, on the way up, bilinear x2 up-sampling (align_corners=True),
+    zero-padding to the skip tensor's size and channel concatenation fused into ``dpx_upsample2_into`` + ``dpx_copy_channels``;
+    outc is a 1x1 convolution and the network returns ``input[:, :out_channels] + residual``.  Reference state-dict keys.
+    Differentiable w.r.t. its input and (``requires_grad_(True)``) its weights / biases: every layer's backward is the same
+    kernel on transposed weights (``_ConvFn``), the pooling / up-sampling adjoints are ``dpx_maxpool2_bwd`` / ``dpx_upsample2_into_bwd``."""
+
+    WIDTHS = (32, 64, 128, 256, 512)
+    SLOPE = 0.2
+
+    def __init__(self, in_channels, out_channels, requires_grad=False):
+        super().__init__()
+        assert in_channels % 2 == 0, "dpx_conv2d needs an even number of input channels (UNetDenoiser: image + noise map = 2)"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        w = self.WIDTHS
+        self.blocks = {"inc.conv": (in_channels, w[0])}
+        for k in range(4):
+            self.blocks[f"down{k + 1}.mpconv.1"] = (w[k], w[k + 1])
+        for k in range(4):
+            self.blocks[f"up{k + 1}.conv"] = (w[4 - k] + w[3 - k], w[3 - k])
+        for prefix, (ci, co) in self.blocks.items():
+            for i in range(3):
+                self.add_ref_param(f"{prefix}.conv-{i}.conv2d.weight", (co, ci if i == 0 else co, 3, 3), requires_grad)
+                self.add_ref_param(f"{prefix}.conv-{i}.conv2d.bias", (co,), requires_grad)
+        self.add_ref_param("outc.conv.weight", (out_channels, w[0], 1, 1), requires_grad)
+        self.add_ref_param("outc.conv.bias", (out_channels,), requires_grad)
+        self._packed = self._packed_T = None
+
+    def _layers(self):
+        """(weight key, bias key) of every convolution, 3x3 layers first"""
+        return [(f"{p}.conv-{i}.conv2d.weight", f"{p}.conv-{i}.conv2d.bias") for p in self.blocks for i in range(3)] + [("outc.conv.weight", "outc.conv.bias")]
+
+    def _check_version(self):
+        ver = sum(self._weights_version())
+        if ver != getattr(self, "_pack_version", None):
+            self._packed, self._packed_T, self._pack_version = None, None, ver
+
+    def packed(self):
+        if self._packed is None:
+            pk = {}
+            for wk, bk in self._layers():
+                w, b = self.ref_param(wk).detach().float(), self.ref_param(bk).detach().float().contiguous()
+                taps = int(w.shape[-1]) ** 2
+                pk[wk] = (ops.conv_pack(w.reshape(w.shape[0], w.shape[1], taps).contiguous(), b, taps), int(w.shape[0]), taps)
+            self._packed = pk
+        return self._packed
+
+    def packed_T(self):
+        """backward-data layers: 3x3 weights flipped and channel-transposed, the 1x1 layer transposed; no bias; an odd number of
+        gradient channels (the 1-channel output) is padded with a zero channel"""
+        if self._packed_T is None:
+            pk = {}
+            for wk, _ in self._layers():
+                w = self.ref_param(wk).detach().float()
+                taps = int(w.shape[-1]) ** 2
+                wt = (w.flip(-1, -2) if taps == 9 else w).permute(1, 0, 2, 3).reshape(w.shape[1], w.shape[0], taps)
+                if wt.shape[1] % 2:
+                    wt = torch.cat([wt, torch.zeros_like(wt[:, :1])], dim=1)
+                pk[wk] = (ops.conv_pack(wt.contiguous(), None, taps), int(w.shape[1]), taps)
+            self._packed_T = pk
+        return self._packed_T
+
+    def _conv(self, x, wk, bk, slope):
+        blob, cout, taps = self.packed()[wk]
+        if not self._diff:
+            return ops.conv2d_leaky(x, blob, cout, slope) if slope else ops.conv2d(x, blob, cout, taps)
+        w, b = self.ref_param(wk), self.ref_param(bk)
+        wkf = w.reshape(w.shape[0], w.shape[1], taps) if w.requires_grad else None       # kernel form, an autograd view of the parameter
+        return _ConvFn.apply(x, None, wkf, (blob, cout, taps), self.packed_T()[wk], bool(slope), 1, b if b.requires_grad else None, slope)
+
+    def _block(self, x, prefix):
+        for i in range(3):
+            x = self._conv(x, f"{prefix}.conv-{i}.conv2d.weight", f"{prefix}.conv-{i}.conv2d.bias", self.SLOPE)
+        return x
+
+    def forward(self, x):
+        be.require(x, what="UNet input")
+        assert x.shape[1] == self.in_channels, f"UNet built for {self.in_channels} input channels, got {x.shape[1]}"
+        assert min(x.shape[-2:]) >= 16, "four 2x poolings need planes of at least 16 x 16"
+        self._check_version()
+        self._diff = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        pool = _MaxPoolFn.apply if self._diff else ops.maxpool2
+        cat_up = _ConcatUpFn.apply if self._diff else ops.concat_skip_upsampled
+        x = x.contiguous()
+        skips = [self._block(x, "inc.conv")]
+        for k in range(4):
+            skips.append(self._block(pool(skips[-1]), f"down{k + 1}.mpconv.1"))
+        t = skips[4]
+        for k in range(4):
+            t = self._block(cat_up(skips[3 - k], t), f"up{k + 1}.conv")
+        res = self._conv(t, "outc.conv.weight", "outc.conv.bias", 0.0)
+        head = x[:, :self.out_channels].contiguous()
+        if self._diff:
+            return _AddFn.apply(head, res)
+        return ops.lincomb([(1.0, head), (1.0, res)])
+
+
+class UNetDenoiser(Denoiser2D):
+    """reference denoisers/wrapper.py:206-221: single-band U-Net applied band by band; the noise level enters as a constant second
+    channel; the output is clamped to [0, 1]"""
+
+    def __init__(self, model_path=None):
+        super().__init__()
+        self.model = UNet(2, 1)
+        if model_path is not None:
+            sd = model_path if isinstance(model_path, dict) else torch.load(model_path, map_location="cpu")
+            self.model.load_state_dict(sd, strict=True)
+
+    def _denoise(self, x, sigma):
+        noise_map = torch.ones_like(x) * sigma.to(x.device, x.dtype).view(-1, 1, 1, 1)
+        out = self.model(torch.cat([x, noise_map], dim=1).contiguous())
+        return torch.clamp(out, 0, 1)
+
+
+class IRCNN(RefKeyed):
     """IRCNN body (reference models/network_dncnn.py:74-113): x - net(x) with seven biased 3x3 convolutions of dilation
     1,2,3,4,3,2,1 -- ``dpx_conv2d`` with the dilation-templated staging tile.  Reference state-dict names.  Differentiable
     w.r.t. its input and (``requires_grad_(True)``) its weights / biases through ``_ConvFn``."""
@@ -500,20 +691,18 @@ class IRCNN(nn.Module):
         super().__init__()
         chans = [in_nc] + [nc] * 6 + [out_nc]
         self.in_nc, self.out_nc, self.nc = in_nc, out_nc, nc
-        self.weights = nn.ParameterList([nn.Parameter(torch.zeros(co, ci, 3, 3), requires_grad=False) for ci, co in zip(chans[:-1], chans[1:])])
-        self.biases = nn.ParameterList([nn.Parameter(torch.zeros(co), requires_grad=False) for co in chans[1:]])
+        for i, (ci, co) in enumerate(zip(chans[:-1], chans[1:])):
+            self.add_ref_param(f"model.{2 * i}.weight", (co, ci, 3, 3), requires_grad=False)
+            self.add_ref_param(f"model.{2 * i}.bias", (co,), requires_grad=False)
         self._packed = None
 
-    def load_state_dict(self, sd, strict=True):
-        for i in range(7):
-            self.weights[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.weight"]))
-            self.biases[i].data.copy_(torch.as_tensor(sd[f"model.{2 * i}.bias"]))
-        self._packed = self._packed_T = None
-        return self
+    @property
+    def weights(self):
+        return [self.ref_param(f"model.{2 * i}.weight") for i in range(7)]
 
-    def _apply(self, fn, *a, **k):
-        self._packed = self._packed_T = None
-        return super()._apply(fn, *a, **k)
+    @property
+    def biases(self):
+        return [self.ref_param(f"model.{2 * i}.bias") for i in range(7)]
 
     def packed(self):
         if self._packed is None:

@@ -9,7 +9,7 @@ import torch.nn as nn
 from ... import _ops as ops
 from ...utils import safe_sqrt
 from ..core import ProxFn
-from .denoisers import Augment, DRUNetDenoiser, FFDNetColorDenoiser, FFDNetDenoiser, IRCNNDenoiser
+from .denoisers import Augment, DRUNetDenoiser, FFDNetColorDenoiser, FFDNetDenoiser, IRCNNDenoiser, UNetDenoiser
 
 CACHE_DIR = os.path.join(os.path.expanduser("~"), ".cache", "dprox")
 
@@ -19,7 +19,7 @@ def get_denoiser(type):
     nothing is downloaded."""
     table = {"ffdnet": ("ffdnet_gray.pth", FFDNetDenoiser), "ffdnet_color": ("ffdnet_color.pth", FFDNetColorDenoiser),
              "drunet": ("drunet_gray.pth", lambda p: DRUNetDenoiser(1, p)), "drunet_color": ("drunet_color.pth", lambda p: DRUNetDenoiser(3, p)),
-             "ircnn": ("ircnn_gray.pth", lambda p: IRCNNDenoiser(1, p))}
+             "ircnn": ("ircnn_gray.pth", lambda p: IRCNNDenoiser(1, p)), "unet": ("unet-nm.pt", UNetDenoiser)}
     if type not in table:
         raise ValueError(f"denoiser {type!r} is not built for the MI355X backend (have {sorted(table)}); "
                          "pass a Denoiser instance instead")

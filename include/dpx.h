@@ -330,6 +330,22 @@ int dpx_conv2d_wgrad(const float* g, const float* a, float* gw, float* gb, int c
 int dpx_space_to_depth(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
 int dpx_depth_to_space(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
 
+/* U-Net denoiser (UNetDenoiser, dprox/proxfn/pnp/denoisers/wrapper.py:206-221 -> models/unet/unet.py:34-135): every ConvLayer
+ * (Conv2d 3x3 pad 1 + bias + LeakyReLU(0.2), unet.py:8-31) is one dpx_conv2d_leaky launch on the matrix-core kernel; between them
+ *   dpx_maxpool2            nn.MaxPool2d(2), unet.py:80 (floor; ties -> first maximum, as ATen)         [B,C,H,W] -> [B,C,H/2,W/2]
+ *   dpx_copy_channels       to_slice != 0: dst[:, c0:c0+C] = src ; else dst = src[:, c0:c0+C]            (torch.cat / its gradient)
+ *   dpx_upsample2_into      nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) + F.pad to (Hd, Wd) (left/top =
+ *                           diff // 2, unet.py:103-109) written into channels [c0, c0+C) of the [B,Ctot,Hd,Wd] concat buffer (unet.py:115)
+ * and the adjoints used by the backward-data pass (*_bwd; dpx_leaky_relu_bwd: g * (y > 0 ? 1 : slope) from the saved output). */
+int dpx_conv2d_leaky(const float* in, float* out, const void* packed, float neg_slope, int cin, int cout, int taps, int B, int H, int W,
+                     dpx_stream_t stream);
+int dpx_maxpool2(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
+int dpx_maxpool2_bwd(const float* x, const float* gy, float* gx, int B, int C, int H, int W, dpx_stream_t stream);
+int dpx_copy_channels(const float* src, float* dst, int to_slice, int B, int C, int H, int W, int Ctot, int c0, dpx_stream_t stream);
+int dpx_upsample2_into(const float* src, float* dst, int B, int C, int h, int w, int Ctot, int c0, int Hd, int Wd, dpx_stream_t stream);
+int dpx_upsample2_into_bwd(const float* gdst, float* gsrc, int B, int C, int h, int w, int Ctot, int c0, int Hd, int Wd, dpx_stream_t stream);
+int dpx_leaky_relu_bwd(const float* y, const float* g, float* gin, long n, float neg_slope, dpx_stream_t stream);
+
 /* Training variants.  dpx_ffdnet_forward_save = dpx_ffdnet_forward that keeps every layer's output in `acts`
  * (dpx_ffdnet_acts_bytes) for the backward pass.  dpx_ffdnet_backward: gradient of the network output w.r.t. its image
  * input (gx, nullable) and w.r.t. the per-image noise level (gsigma[B], nullable) given gy -- the chain of transposed

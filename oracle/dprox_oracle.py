@@ -23,7 +23,7 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 import torch
 
-from synthetic import drunet_weights, ffdnet_weights, ircnn_weights  # seeded stand-ins for the un-downloadable checkpoints (shared with tools/)
+from synthetic import drunet_weights, ffdnet_weights, ircnn_weights, unet_weights  # seeded stand-ins for the un-downloadable checkpoints (shared with tools/)
 import torch.nn.functional as F
 
 __all__ = [
@@ -34,6 +34,7 @@ __all__ = [
     "solve", "partition_admm", "log_descent", "fft2c", "ifft2c",
     "ffdnet_weights", "ffdnet_forward", "FFDNetOracle", "pixel_unshuffle2", "psnr", "admm_f64",
     "csmri_prox", "custom_admm_csmri", "bayer_mask", "lin_mosaic", "sisr_prox", "admm_ext_prior", "doe_otf", "lin_conv_doe", "drunet_weights", "drunet_forward", "DRUNetOracle", "ircnn_weights", "ircnn_forward", "IRCNNOracle", "AugmentOracle",
+    "unet_weights", "unet_forward", "UNetOracle",
 ]
 
 
@@ -888,23 +889,71 @@ def admm_f64(b, psf, psi, rhos, lams, max_iter, ffdnet_layers=None):
                 xx = F.relu(xx)
         return F.pixel_shuffle(xx, 2)[..., :h, :w]
 
-    x = bb.clone()
+    x = bb.detach().clone()                  # x0 = b as a separate tensor (the reference's solve(x0=...) does not tie it to b)
     v = [K(name, x) for name, _, _ in psi]
     u = [torch.zeros_like(e) for e in v]
     Ktb = Fi(torch.conj(Hf) * F2(bb))
     for it in range(max_iter):
-        rho = float(np.float32(rhos[it]))
+        # (tensor schedules stay tensors so that torch.autograd can differentiate the float64 iteration w.r.t. them)
+        rho = rhos[it].double() if isinstance(rhos, torch.Tensor) else float(np.float32(rhos[it]))
         rhs = Ktb + rho * sum(Kt(name, v[i] - u[i]) for i, (name, _, _) in enumerate(psi))
         den = torch.abs(Hf) ** 2 + rho * sum(gram(name) for name, _, _ in psi)
         x = Fi((F2(rhs) + 1e-7) / (den + 1e-7))
         for i, (name, prox_kind, alpha) in enumerate(psi):
-            lam = float(np.float32(lams[i][it])) * alpha
+            lam = (lams[i][it].double() if isinstance(lams[i], torch.Tensor) else float(np.float32(lams[i][it]))) * alpha
             d = K(name, x) + u[i]
             if prox_kind == "norm1":
                 v[i] = torch.sign(d) * torch.clamp(d.abs() - lam, min=0)
             elif prox_kind == "nonneg":
                 v[i] = torch.clamp(d, min=0)
             else:
-                v[i] = den64(d, torch.full((B,), lam, dtype=torch.float64))
+                v[i] = den64(d, torch.full((B,), float(lam), dtype=torch.float64))
             u[i] = d - v[i]
     return x, v, u
+
+
+# --------------------------------------------------------------------------- #
+# U-Net denoiser                                          #
+# --------------------------------------------------------------------------- #
+def unet_forward(x, sd):
+    """``UNet.forward`` -- dprox/proxfn/pnp/denoisers/models/unet/unet.py:47-64 with its blocks: ConvBlock = 3 x (Conv2d 3x3
+    pad 1 + bias + LeakyReLU(0.2)) (:8-31), down = MaxPool2d(2) + ConvBlock (:76-84), up = bilinear x2 (align_corners=True),
+    zero-pad to the skip tensor's size (left/top = diff // 2), cat([skip, up]), ConvBlock (:89-117), outc = 1x1 conv (:121-128);
+    output = input[:, :C_out] + residual (:61-64).  ``sd``: the reference state dict."""
+    def block(t, prefix):
+        for i in range(3):
+            t = F.leaky_relu(F.conv2d(t, sd[f"{prefix}.conv-{i}.conv2d.weight"], sd[f"{prefix}.conv-{i}.conv2d.bias"], padding=1), 0.2)
+        return t
+
+    def up(lo, skip, prefix):
+        lo = F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=True)
+        dy, dx = skip.shape[2] - lo.shape[2], skip.shape[3] - lo.shape[3]
+        lo = F.pad(lo, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+        return block(torch.cat([skip, lo], dim=1), prefix)
+
+    x1 = block(x, "inc.conv")
+    x2 = block(F.max_pool2d(x1, 2), "down1.mpconv.1")
+    x3 = block(F.max_pool2d(x2, 2), "down2.mpconv.1")
+    x4 = block(F.max_pool2d(x3, 2), "down3.mpconv.1")
+    x5 = block(F.max_pool2d(x4, 2), "down4.mpconv.1")
+    t = up(x5, x4, "up1.conv")
+    t = up(t, x3, "up2.conv")
+    t = up(t, x2, "up3.conv")
+    t = up(t, x1, "up4.conv")
+    res = F.conv2d(t, sd["outc.conv.weight"], sd["outc.conv.bias"])
+    return x[:, :res.shape[1]] + res
+
+
+class UNetOracle:
+    """``UNetDenoiser`` -- denoisers/wrapper.py:206-221 (a Denoiser2D: band by band, noise map as second channel, clamp to [0, 1])"""
+
+    def __init__(self, sd):
+        self.sd = sd
+
+    def denoise(self, x, sigma):
+        sigma = sigma.view(-1, 1, 1, 1)
+        outs = []
+        for band in x.split(1, dim=1):
+            noise_map = torch.ones_like(band) * sigma
+            outs.append(torch.clamp(unet_forward(torch.cat([band, noise_map], dim=1), self.sd), 0, 1))
+        return torch.cat(outs, dim=1)

@@ -136,3 +136,25 @@ def ircnn_weights(seed=31, in_nc=1, out_nc=1, nc=64, gain=0.5):
         sd[f"model.{2 * i}.weight"] = torch.from_numpy((rng.randn(co, ci, 3, 3) * gain * np.sqrt(2.0 / (ci * 9))).astype(np.float32))
         sd[f"model.{2 * i}.bias"] = torch.from_numpy((rng.randn(co) * 0.01).astype(np.float32))
     return sd
+
+
+def unet_weights(seed=41, in_ch=2, out_ch=1, gain=0.7):
+    """Seeded state dict of the reference's U-Net denoiser (models/unet/unet.py:34-135: ConvBlocks of three biased 3x3
+    convolutions + LeakyReLU(0.2), widths 32..512, bilinear up-sampling, 1x1 output convolution), He-normal x gain."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+
+    def block(prefix, ci, co):
+        for i in range(3):
+            cin = ci if i == 0 else co
+            sd[f"{prefix}.conv-{i}.conv2d.weight"] = torch.from_numpy((rng.randn(co, cin, 3, 3) * gain * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
+            sd[f"{prefix}.conv-{i}.conv2d.bias"] = torch.from_numpy((rng.randn(co) * 0.01).astype(np.float32))
+
+    block("inc.conv", in_ch, 32)
+    for k, (ci, co) in enumerate(((32, 64), (64, 128), (128, 256), (256, 512))):
+        block(f"down{k + 1}.mpconv.1", ci, co)
+    for k, (ci, co) in enumerate(((512 + 256, 256), (256 + 128, 128), (128 + 64, 64), (64 + 32, 32))):
+        block(f"up{k + 1}.conv", ci, co)
+    sd["outc.conv.weight"] = torch.from_numpy((rng.randn(out_ch, 32, 1, 1) * gain * np.sqrt(2.0 / 32)).astype(np.float32))
+    sd["outc.conv.bias"] = torch.from_numpy((rng.randn(out_ch) * 0.01).astype(np.float32))
+    return sd

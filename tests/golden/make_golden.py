@@ -687,6 +687,47 @@ def g20_drunet():
     save("g20_drunet", **out)
 
 
+def g22_unet():
+    """UNetDenoiser (wrapper.py:206-221 -> models/unet/unet.py:34-135) with seeded weights: forward on an odd-sized two-band image
+    (MaxPool floors, the up path zero-pads back: 37x45 -> 18x22 -> 9x11 -> 4x5 -> 2x2) and on an even one with per-image sigma;
+    gradients w.r.t. the image and sigma (backward-data pass) through the reference's autograd."""
+    from synthetic import unet_weights
+    from dprox.proxfn.pnp.denoisers.models.unet import UNet
+    from dprox.proxfn.pnp.denoisers.wrapper import UNetDenoiser
+    net = UNet(2, 1)
+    net.load_state_dict(unet_weights(41), strict=True)
+    den = UNetDenoiser.__new__(UNetDenoiser)
+    Denoiser2D.__init__(den)
+    den.model = net.eval()
+    rng = np.random.RandomState(220)
+    out = {}
+    x_odd = T(rng.rand(1, 2, 37, 45).astype("float32"))
+    x_even = T(rng.rand(2, 1, 32, 48).astype("float32"))
+    with torch.no_grad():
+        out.update(odd_x=x_odd, odd_y=den.denoise(x_odd, torch.tensor(0.1)),
+                   even_x=x_even, even_sigma=np.array([0.05, 0.2], "float32"), even_y=den.denoise(x_even, torch.tensor([0.05, 0.2])))
+        # the raw network (no clamp) on the even input: pins the residual path separately from the clamp
+        nm = torch.ones_like(x_even) * torch.tensor([0.05, 0.2]).view(-1, 1, 1, 1)
+        out["even_raw"] = net(torch.cat([x_even, nm], dim=1))
+    net.requires_grad_(False)
+    xg = T(rng.rand(2, 1, 24, 40).astype("float32") * 0.6 + 0.2).requires_grad_(True)
+    sg = torch.tensor([0.05, 0.2], requires_grad=True)
+    wg = T(rng.randn(2, 1, 24, 40).astype("float32"))
+    (den.denoise(xg, sg) * wg).sum().backward()
+    out.update(grad_x=xg.detach(), grad_w=wg, grad_gx=xg.grad, grad_gsigma=sg.grad)
+    # weight gradients of the same loss: norms of all, the first / last layers in full
+    net.requires_grad_(True)
+    (den.denoise(xg.detach(), sg.detach()) * wg).sum().backward()
+    gr = {n: p.grad for n, p in net.named_parameters()}
+    out["wgrad_names"] = np.array(sorted(gr))
+    out["wgrad_norms"] = np.array([float(gr[n].norm()) for n in sorted(gr)], dtype=np.float64)
+    for n in ("inc.conv.conv-0.conv2d.weight", "inc.conv.conv-0.conv2d.bias", "outc.conv.weight", "outc.conv.bias", "up4.conv.conv-2.conv2d.bias"):
+        out["wgrad_full_" + n] = gr[n]
+    out["wgrad_corner_down4"] = gr["down4.mpconv.1.conv-1.conv2d.weight"][:8, :8].contiguous()
+    out["wgrad_corner_up1"] = gr["up1.conv.conv-0.conv2d.weight"][:8, :8].contiguous()
+    save("g22_unet", **out)
+
+
 def g15_csmri():
     """CS-MRI pipeline of the reference's examples (csmri closed-form data term + CustomADMM + gray FFDNet prior):
     dprox/proxfn/fast/csmri.py:8-25, dprox/contrib/csmri.py:156-171, ext_sum_squares routing invert.py:8-12."""
@@ -890,14 +931,24 @@ def g33_full_c5():
     out = {"seed": 2305, "rhos": r0, "l0": a0, "l1": a1, "loss": loss.detach().double(), "g_rhos": rhos.grad, "g_l0": l0.grad, "g_l1": l1.grad}
     _pack(out, "x", xo, 8)
     _pack(out, "g_b", bt.grad, 8)
+    # the same loss and schedule gradients in float64 (autograd through oracle.admm_f64): the gradients w.r.t. rho_t are sums of
+    # 3e6 signed products that cancel to ~1e-5 -- fp32 accumulation order alone moves them by ~1e-4 (relative)
+    r64, a64, b64 = (torch.tensor(t, dtype=torch.float64, requires_grad=True) for t in (r0, a0, a1))
+    bt64 = T(b).double().requires_grad_(True)
+    x64, _, _ = admm_f64(bt64, psf, [("grad0", "norm1", 1.0), ("grad1", "norm1", 1.0)], r64, [a64, b64], K)
+    loss64 = ((x64 - T(gt).double()) ** 2).mean()
+    loss64.backward()
+    out.update(loss_f64=loss64.detach(), g_rhos_f64=r64.grad, g_l0_f64=a64.grad, g_l1_f64=b64.grad)
+    _pack(out, "g_b_f64", bt64.grad, 8)
     print("config 5:", float(loss), rhos.grad, l0.grad, l1.grad)
+    print("config 5 f64:", float(loss64), r64.grad, a64.grad, b64.grad)
     save("g33_full_c5", **out)
 
 
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment,
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet,
                g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

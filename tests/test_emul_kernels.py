@@ -106,3 +106,47 @@ def test_ffdnet_backward():
 
 def test_adjoint_dot_product():
     pc.case_adjoint_dot(DEV, shape=(1, 3, 24, 20))
+
+
+def test_unet_layer_kernels_vs_torch():
+    """the U-Net's non-convolution layers (dpx_unet.hip) against ATen on the CPU: MaxPool2d(2) with odd sizes and ties,
+    bilinear x2 (align_corners=True) + zero pad + concat, their adjoints (dot-product test + autograd), LeakyReLU backward"""
+    import torch
+    import torch.nn.functional as F
+    from dprox import _ops as ops
+    torch.manual_seed(3)
+    x = torch.rand(2, 3, 9, 11)
+    x[0, 0, 0, 0] = x[0, 0, 0, 1] = 0.99                      # a tie: the gradient goes to the first maximum
+    assert torch.equal(ops.maxpool2(x), F.max_pool2d(x, 2))
+    xr = x.clone().requires_grad_(True)
+    gy = torch.randn(2, 3, 4, 5)
+    (F.max_pool2d(xr, 2) * gy).sum().backward()
+    assert torch.equal(ops.maxpool2_bwd(x, gy), xr.grad)
+    for (h, w), (H, W) in (((4, 5), (9, 11)), ((1, 3), (2, 6)), ((6, 6), (12, 13))):
+        low, skip = torch.rand(2, 3, h, w), torch.rand(2, 2, H, W)
+        up = F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=True)
+        dy, dx = H - 2 * h, W - 2 * w
+        ref = torch.cat([skip, F.pad(up, (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))], dim=1)
+        got = ops.concat_skip_upsampled(skip, low)
+        assert float((got - ref).abs().max()) <= 2e-7, float((got - ref).abs().max())
+        g = torch.randn_like(ref)
+        gskip, glow = ops.concat_skip_upsampled_bwd(g, 2, (h, w))
+        lr = low.clone().requires_grad_(True)
+        upr = F.pad(F.interpolate(lr, scale_factor=2, mode="bilinear", align_corners=True), (dx // 2, dx - dx // 2, dy // 2, dy - dy // 2))
+        (upr * g[:, 2:]).sum().backward()
+        assert torch.equal(gskip, g[:, :2]) and float((glow - lr.grad).abs().max()) <= 2e-6
+    y, g = torch.randn(2, 3, 5, 7), torch.randn(2, 3, 5, 7)
+    assert torch.equal(ops.leaky_relu_bwd(y, g, 0.2), torch.where(y > 0, g, 0.2 * g))
+
+
+def test_leaky_conv_layer_vs_torch():
+    """dpx_conv2d_leaky (bias + LeakyReLU(0.2) epilogue on the MFMA kernel) against F.conv2d on a small layer"""
+    import torch
+    import torch.nn.functional as F
+    from dprox import _ops as ops
+    torch.manual_seed(4)
+    x, w, b = torch.randn(1, 2, 9, 13), torch.randn(32, 2, 3, 3) * 0.3, torch.randn(32) * 0.1
+    blob = ops.conv_pack(w.reshape(32, 2, 9).contiguous(), b, 9)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    got = ops.conv2d_leaky(x, blob, 32, 0.2)
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

@@ -88,6 +88,10 @@ def test_drunet():
     pc.case_drunet(DEV)
 
 
+def test_unet_denoiser():
+    pc.case_unet(DEV)
+
+
 def test_conv2d_generic():
     pc.case_conv2d_generic(DEV)
 

@@ -102,6 +102,51 @@ def test_log_descent_matches_reference_tables():
     assert np.array_equal(r.numpy(), g["rhos_30_10_8_sqrt"]) and np.array_equal(s.numpy(), g["sigmas_30_10_8_sqrt"])
 
 
+def test_denoiser_state_dicts_follow_the_nn_module_protocol():
+    """checkpoints keep the reference's keys through nn.Module's own recursion: a parent's state_dict() holds every denoiser
+    weight under its reference name, round-trips through load_state_dict(), and the reference's solver-level layout
+    (psi_fns.<i>.denoiser.model.<key>) loads -- reference network_ffdnet.py:43-47, network_unet.py:67-104, models/unet/unet.py:34-46"""
+    import synthetic
+    from dprox.proxfn.pnp.denoisers import DRUNetDenoiser, FFDNetColorDenoiser, IRCNN, UNetDenoiser
+
+    class Parent(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ffd = FFDNetColorDenoiser(synthetic.ffdnet_weights(7))
+            self.dru = DRUNetDenoiser(1, synthetic.drunet_weights(22, 2, 1))
+            self.unet = UNetDenoiser(synthetic.unet_weights(41))
+            self.irc = IRCNN(1, 1, 64)
+
+    a, b = Parent(), Parent()
+    sd = a.state_dict()
+    assert "ffd.model.model.0.weight" in sd and "ffd.model.model.22.bias" in sd
+    assert "dru.model.m_down1.0.res.0.weight" in sd and "unet.model.up1.conv.conv-0.conv2d.weight" in sd and "irc.model.12.bias" in sd
+    assert len([k for k in sd if k.startswith("ffd.")]) == 24 and len([k for k in sd if k.startswith("unet.")]) == 56
+    for p in b.parameters():
+        p.data.zero_()
+    res = b.load_state_dict(sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in b.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # strict loading reports foreign / missing keys like any nn.Module
+    bad = dict(sd)
+    bad["ffd.model.model.99.weight"] = torch.zeros(1)
+    del bad["unet.model.outc.conv.bias"]
+    with pytest.raises(RuntimeError) as e:
+        b.load_state_dict(bad)
+    assert "model.99.weight" in str(e.value) and "outc.conv.bias" in str(e.value)
+    # a reference-format solver checkpoint (weights of the prior inside the solver's psi_fns) loads into the compiled solver
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=FFDNetColorDenoiser(None))
+    solver = dp.compile(dp.sum_squares(x - torch.zeros(1, 3, 8, 8)) + prior, method="admm", device="cuda" if torch.cuda.is_available() else "cpu") \
+        if (torch.cuda.is_available() or be.host_mode()) else None
+    if solver is not None:
+        ref_ckpt = {f"psi_fns.0.denoiser.model.{k}": torch.as_tensor(v) for k, v in a.ffd.model.state_dict().items()}
+        out = solver.load_state_dict(ref_ckpt, strict=False)
+        assert not [k for k in out.unexpected_keys if "denoiser" in k]
+        assert torch.equal(solver.psi_fns[0].denoiser.model.weights[3].cpu(), a.ffd.model.weights[3])
+
+
 def test_product_does_not_import_the_oracle():
     import subprocess
     import sys

@@ -330,6 +330,23 @@ def test_g20_drunet():
         assert abs(float(v.grad.norm()) - norms[n]) <= 1e-4 * norms[n], n
 
 
+def test_g22_unet():
+    """U-Net denoiser restatement against the reference's UNet / UNetDenoiser (seeded weights)"""
+    g = load_golden("g22_unet")
+    sd = O.unet_weights(41)
+    den = O.UNetOracle(sd)
+    with torch.no_grad():
+        assert_close(den.denoise(T(g["odd_x"]), torch.tensor(0.1)), g["odd_y"], 2e-6)
+        assert_close(den.denoise(T(g["even_x"]), T(g["even_sigma"])), g["even_y"], 2e-6)
+    xg = T(g["grad_x"]).requires_grad_(True)
+    sg = torch.tensor([0.05, 0.2], requires_grad=True)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (O.UNetOracle(sdg).denoise(xg, sg) * T(g["grad_w"])).sum().backward()
+    assert_close(xg.grad, g["grad_gx"], 2e-5)
+    assert_close(sg.grad, g["grad_gsigma"], 2e-5)
+    assert_close(sdg["outc.conv.weight"].grad, g["wgrad_full_outc.conv.weight"], 2e-5)
+
+
 def test_g15_csmri():
     """csmri closed-form prox + CustomADMM with the gray FFDNet prior (complex iterate)."""
     g = load_golden("g15_csmri")

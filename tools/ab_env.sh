@@ -3,5 +3,5 @@
 cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   echo "== $v"
-  env $v python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'psnr', round(d['psnr_db']['admm50_mean'],3), {k:round(v['avg_us'],1) for k,v in d['kernels'].items() if 'iter' in k or 'cols_p2' in k})"
+  env $v python bench.py --no-cpu-baseline --no-extra-configs 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), 'psnr', round(d['psnr_db']['admm50_mean'],3), {k:round(v['avg_us'],1) for k,v in d['kernels'].items() if 'iter' in k or 'cols_p2' in k})"
 done
