@@ -422,6 +422,7 @@ extern "C" size_t dpx_ffdnet_ws_bytes(int B, int in_nc, int nc, int H, int W) {
 extern "C" int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb,
                                   int B, int H, int W, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(x && y && sigma && packed && ws, "dpx_ffdnet_forward: null pointer");
+  DPX_REQUIRE((size_t)FFD_CK * ((H + 1) / 2) * ((W + 1) / 2) < ((size_t)1 << 28), "dpx_ffdnet_forward: plane %dx%d too large for the 28-bit staging offsets", H, W);
   DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96,
               "dpx_ffdnet_forward: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
   hipStream_t s = (hipStream_t)stream;
@@ -634,6 +635,7 @@ extern "C" size_t dpx_ffdnet_acts_bytes(int B, int in_nc, int nc, int nb, int H,
 extern "C" int dpx_ffdnet_forward_save(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb,
                                        int B, int H, int W, void* acts, dpx_stream_t stream) {
   DPX_REQUIRE(x && y && sigma && packed && acts, "dpx_ffdnet_forward_save: null pointer");
+  DPX_REQUIRE((size_t)FFD_CK * ((H + 1) / 2) * ((W + 1) / 2) < ((size_t)1 << 28), "dpx_ffdnet_forward_save: plane %dx%d too large for the 28-bit staging offsets", H, W);
   DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96,
               "dpx_ffdnet_forward_save: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
   hipStream_t s = (hipStream_t)stream;
@@ -696,6 +698,7 @@ extern "C" int dpx_ffdnet_backward(const float* gy, float* gx, float* gsigma, fl
                                    const void* acts, int in_nc, int nc, int nb, int B, int H, int W, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(gy && packed_T && acts && ws && (gx || gsigma || gw), "dpx_ffdnet_backward: null pointer");
   DPX_REQUIRE(!gw == !gb, "dpx_ffdnet_backward: weight and bias gradients come together");
+  DPX_REQUIRE((size_t)FFD_CK * ((H + 1) / 2) * ((W + 1) / 2) < ((size_t)1 << 28), "dpx_ffdnet_backward: plane %dx%d too large for the 28-bit staging offsets", H, W);
   DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 2 == 0 && nc <= 96 && 4 * in_nc <= 96,
               "dpx_ffdnet_backward: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
   hipStream_t s = (hipStream_t)stream;

@@ -147,7 +147,9 @@ class FusedADMM:
         for fn in psi:
             lt = schedule_table(lams[fn], T, B, dev)
             if isinstance(fn, deep_prior) and fn.sqrt:
-                lt = torch.sqrt(torch.clamp(lt, min=1e-8))           # safe_sqrt(lam), prior.py:77
+                # sigma = safe_sqrt(alpha * lam): the scaling of `c * deep_prior(...)` enters before the root (prior.py:77 behind
+                # ProxFn.prox, proxfn/base.py:55-64); the table then already holds sigma
+                lt = torch.sqrt(torch.clamp(lt * float(fn.alpha), min=1e-8))
             lam_tab.append(lt)
         # data spectrum F(sum_Omega K^T b): fp64 transform, kept in the Fourier domain, recomputed only when an
         # offset (the observation b) changes
@@ -230,7 +232,7 @@ class FusedADMM:
             for i in ext:                                            # v_i holds d = x + u_i
                 fn = psi[i]
                 d = v[i]
-                sig = lam_tab[i][it] * float(fn.alpha)
+                sig = lam_tab[i][it] if fn.sqrt else lam_tab[i][it] * float(fn.alpha)
                 den = fn.denoiser
                 if isinstance(den, Denoiser2D):
                     out = den.model(d.reshape(B * C, 1, H, W), sig.repeat_interleave(C)).reshape(B, C, H, W)

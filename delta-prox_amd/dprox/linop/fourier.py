@@ -117,9 +117,14 @@ class conv_doe(LinOp):
         self._psf = psf
         self.circular = bool(circular)
         self.cache = {}
-        if isinstance(psf, Placeholder):
+        self._psf_gen = 0                                    # counts assignments of the placeholder: (generation, tensor version)
+        if isinstance(psf, Placeholder):                     # identifies a PSF value (an address can be recycled by the allocator)
             self.psf = None
-            self._psf.change(lambda val: setattr(self, "psf", val))
+
+            def assign(val):
+                self.psf = val
+                self._psf_gen += 1
+            self._psf.change(assign)
         else:
             from ..utils import to_torch_tensor
             self.psf = to_torch_tensor(psf, batch=True).float()
@@ -128,7 +133,7 @@ class conv_doe(LinOp):
         psf = self.psf
         if psf is None:
             raise ValueError("conv_doe: the PSF placeholder has no value yet")
-        ver = (psf.data_ptr(), psf._version)
+        ver = (self._psf_gen, psf._version)
         if self.cache.get("version") != ver:
             self.cache = {"version": ver}                    # a new PSF value invalidates every size's OTF
         key = (tuple(shape[1:]), str(device))
@@ -143,7 +148,7 @@ class conv_doe(LinOp):
         return self._full_otf(shape, device)[1]
 
     def _own_tables_version(self):
-        return None if self.psf is None else (self.psf.data_ptr(), self.psf._version)
+        return None if self.psf is None else (self._psf_gen, self.psf._version)
 
     def _convolve(self, img, conj):
         if self.circular:

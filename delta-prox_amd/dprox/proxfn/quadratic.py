@@ -33,7 +33,11 @@ class sum_squares(ProxFn):
 
     def _offset_key(self):
         k = super()._offset_key()
-        return k + ((getattr(self._b, "_version", id(self._b)),) if self._b is not None else ())
+        if self._b is None:
+            return k
+        # a tensor's in-place edits bump its version counter; anything else (a numpy array) cannot be watched: a key that never
+        # compares equal makes every use re-read it, as the reference does
+        return k + ((id(self._b), self._b._version) if isinstance(self._b, torch.Tensor) else (object(),))
 
     def _compute_offset(self):
         if self._b is not None:

@@ -377,6 +377,20 @@ def g9_admm_pnp():
          x_f64=x64, v0_f64=v64[0], x_nonneg_f64=x64n)
 
 
+def g23_pnp_scaled_sqrt():
+    """`c * deep_prior(x, sqrt=True)` with c != 1: the noise level is sqrt(c * lam) (ProxFn.prox scales lam by alpha before
+    deep_prior._prox takes the root, proxfn/base.py:55-64, pnp/prior.py:77); well-conditioned rho so that 1e-5 parity is meaningful."""
+    gt, b, psf = synthetic.deconv_case(2, 3, 32, 40, seed=230)
+    x = dp.Variable()
+    prior = 0.6 * dp.deep_prior(x, denoiser=ColorDen(7), sqrt=True)
+    fns = dp.sum_squares(dp.conv(x, psf) - T(b)) + prior
+    rhos = torch.tensor([0.5, 0.4, 0.3])
+    lams = torch.tensor([0.004, 0.003, 0.002])
+    with torch.no_grad():
+        st = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams={prior: lams}, max_iter=3, return_full_states=True)
+    save("g23_pnp_scaled_sqrt", b=b, psf=psf, rhos=rhos, lams=lams, x=st[0], v0=st[1][0], u0=st[2][0])
+
+
 def g21_x8_augment():
     """deep_prior(x8=True): denoisers/composite.py:6-46 -- nine consecutive prox calls (modes 0..7, 0) on a non-square image"""
     x = dp.Variable()
@@ -948,7 +962,7 @@ def g33_full_c5():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet,
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt,
                g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

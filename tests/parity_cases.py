@@ -257,6 +257,23 @@ def case_admm_pnp(device):
     assert rel_l2(out.cpu(), g["x_nonneg_f64"]) <= ref_err + TOL, (rel_l2(out.cpu(), g["x_nonneg_f64"]), ref_err)
 
 
+def case_pnp_scaled_sqrt(device):
+    """G23: `0.6 * deep_prior(x, sqrt=True)` -- sigma = sqrt(alpha * lam) on the fused and on the op-by-op path"""
+    g = load_golden("g23_pnp_scaled_sqrt")
+    b = T(g["b"], device)
+    for fused in (True, False):
+        x = dp.Variable()
+        prior = 0.6 * dp.deep_prior(x, denoiser=_ffdnet("color", device), sqrt=True)
+        with torch.no_grad():
+            s = dp.compile(dp.sum_squares(dp.conv(x, g["psf"]) - b) + prior, method="admm", device=device)
+            s.use_fused = fused
+            st = s.solve(x0=b, rhos=T(g["rhos"], device), lams={prior: T(g["lams"], device)}, max_iter=3, return_full_states=True)
+        assert s.last_path == ("fused" if fused else "generic")
+        assert_close(st[0].cpu(), g["x"], TOL, f"x (fused={fused})")
+        close_on_scale(st[1][0], g["v0"], g["x"], TOL, f"v (fused={fused})")
+        close_on_scale(st[2][0], g["u0"], g["x"], TOL, f"u (fused={fused})")
+
+
 def case_x8_augment(device):
     """G21: deep_prior(x8=True) -- the dihedral transform cycles with the call count (non-square image: the denoiser sees
     transposed shapes on the odd quarter turns)"""

@@ -68,6 +68,10 @@ def test_admm_pnp():
     pc.case_admm_pnp(DEV)
 
 
+def test_pnp_scaled_sqrt_prior():
+    pc.case_pnp_scaled_sqrt(DEV)
+
+
 def test_x8_augment():
     pc.case_x8_augment(DEV)
 
