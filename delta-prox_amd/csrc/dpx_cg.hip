@@ -1,0 +1,211 @@
+// Device-side control of the conjugate-gradient loop (reference dprox/linalg/solve/solver_cg.py:95-129).
+//
+// The operator application A(p) stays a sequence of the caller's kernels (any LinOp graph); everything else of an iteration
+// -- the stop rule, beta, the direction update, alpha, the x / r updates -- is decided and executed on the GPU from a small
+// state block, so the host issues a whole CG solve without a single read-back:
+//
+//   dpx_bgram(r) -> dpx_cg_test -> dpx_cg_direction -> [A(p): caller's kernels] -> dpx_bdot(p, Ap -> state) -> dpx_cg_update
+//
+// Stop rule (solver_cg.py:103-104): torch.linalg.norm(ravel(r), 2) <= cg_tol_i for ALL images i, i.e. the spectral norm of the
+// [B, N] residual matrix against the smallest tolerance:  lambda_max(R R^T) <= tau^2, tau = min_i rtol * ||b_i||.  That is a
+// statement about the B x B Gram matrix G only, and it holds iff  tau^2 I - G  is positive semidefinite -- decided here by an
+// LDL^T factorisation in float64 on one wavefront (B <= 64; pivots >= 0), no eigen-solver needed.  Once the test succeeds
+// the state's `done` flag is set and every later control kernel of the solve returns immediately (the iterate is frozen at
+// exactly the reference's exit point; `n_done` = the iteration index the reference prints in "Converged at CG Iter").
+#include "dpx_common.h"
+
+namespace dpx {
+
+// state block: floats gamma[B], gamma_prev[B], beta[B], pAp[B], tol2[B]; then ints done, n_done, it, pad
+struct CgState {
+  float* f;
+  int B;
+  __host__ __device__ float* gamma() const { return f; }
+  __host__ __device__ float* gamma_prev() const { return f + B; }
+  __host__ __device__ float* beta() const { return f + 2 * B; }
+  __host__ __device__ float* pAp() const { return f + 3 * B; }
+  __host__ __device__ float* tol2() const { return f + 4 * B; }
+  __host__ __device__ int* flags() const { return (int*)(f + 5 * B); }     // done, n_done, it
+};
+
+__global__ void k_cg_init(CgState S, const float* __restrict__ bnorm2, float rtol) {
+  const int i = threadIdx.x;
+  if (i < S.B) {
+    const float nb = sqrtf(fmaxf(bnorm2[i], 0.f));          // ||b_i||  (torch.linalg.norm(ravel(b), 2, dim=-1))
+    const float t = rtol * nb;                              // cg_tol_i in float32 like the reference
+    S.tol2()[i] = t * t;
+    S.gamma()[i] = 0.f;
+    S.gamma_prev()[i] = 1.f;
+    S.beta()[i] = 0.f;
+    S.pAp()[i] = 1.f;
+  }
+  if (i == 0) {
+    S.flags()[0] = 0;
+    S.flags()[1] = -1;
+    S.flags()[2] = 0;
+    S.flags()[3] = 0;
+  }
+}
+
+// one wavefront: M = tau^2 I - sym(G) in LDS (float64), right-looking LDL^T without pivoting; PSD <=> every pivot >= 0 (a zero
+// pivot must come with a zero column).  A NaN anywhere fails the test (the reference's `normr <= tol` is False for NaN too).
+__global__ void __launch_bounds__(64) k_cg_test(CgState S, const float* __restrict__ G) {
+  __shared__ double M[64 * 65];
+  __shared__ int ok;
+  const int B = S.B, t = threadIdx.x;
+  int* fl = S.flags();
+  if (fl[0]) return;                                        // converged earlier: the solve is frozen
+  float tau2 = INFINITY;
+  for (int i = 0; i < B; ++i) tau2 = fminf(tau2, S.tol2()[i]);
+  for (int e = t; e < B * B; e += 64) {
+    const int i = e / B, j = e - i * B;
+    const double g = 0.5 * ((double)G[i * B + j] + (double)G[j * B + i]);
+    M[i * 65 + j] = (i == j ? (double)tau2 : 0.0) - g;
+  }
+  if (t == 0) ok = 1;
+  __syncthreads();
+  // scale-aware zero threshold: round-off of the fp32 Gram entries
+  double scale = 0.0;
+  for (int i = 0; i < B; ++i) scale = fmax(scale, fabs((double)G[i * B + i]));
+  const double tiny = 1e-12 * fmax(scale, (double)tau2);
+  for (int k = 0; k < B; ++k) {
+    const double d = M[k * 65 + k];
+    if (!(d >= 0.0)) {                                      // negative or NaN pivot (uniform: every lane reads the same value)
+      if (t == 0) ok = 0;
+      break;
+    }
+    if (d <= tiny) {                                        // zero pivot: PSD only if the rest of the column vanishes
+      int bad = 0;
+      for (int i = k + 1 + t; i < B; i += 64) bad |= fabs(M[i * 65 + k]) > tiny;
+      if (__any(bad)) {
+        if (t == 0) ok = 0;
+        break;
+      }
+      continue;
+    }
+    const double inv = 1.0 / d;
+    for (int i = k + 1 + t; i < B; i += 64) {               // lane i owns row i of the trailing block
+      const double l = M[i * 65 + k] * inv;
+      for (int j = k + 1; j <= i; ++j) M[i * 65 + j] -= l * M[j * 65 + k];
+    }
+    __syncthreads();
+    // mirror the updated lower triangle's column entries used as M[j][k'] for later pivots: rows read M[j*65+k] with j > k only
+    // from the lower triangle (j >= k' > ...), which is what the update above maintains -- nothing to mirror
+  }
+  __syncthreads();
+  if (ok) {
+    if (t == 0) {
+      fl[0] = 1;
+      fl[1] = fl[2];
+    }
+    return;
+  }
+  const bool first = fl[2] == 0;
+  __syncthreads();
+  if (t < B) {
+    const float g = G[t * B + t];                           // gamma_i = <r_i, r_i>
+    S.beta()[t] = first ? 0.f : g / S.gamma_prev()[t];      // beta = gamma / gamma_1   (solver_cg.py:112)
+    S.gamma()[t] = g;
+    S.gamma_prev()[t] = g;
+  }
+  if (t == 0) fl[2] += 1;
+}
+
+// p = r + beta_b * p        (solver_cg.py:111-115; beta = 0 in the first iteration)
+__global__ void k_cg_direction(float* __restrict__ p, const float* __restrict__ r, CgState S, long npb4) {
+  if (S.flags()[0]) return;
+  const int b = blockIdx.y;
+  const float beta = S.beta()[b];
+  float4* pb = (float4*)p + (long)b * npb4;
+  const float4* rb = (const float4*)r + (long)b * npb4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npb4; i += (long)gridDim.x * blockDim.x) {
+    const float4 rv = rb[i], pv = pb[i];
+    pb[i] = make_float4(fmaf(beta, pv.x, rv.x), fmaf(beta, pv.y, rv.y), fmaf(beta, pv.z, rv.z), fmaf(beta, pv.w, rv.w));
+  }
+}
+__global__ void k_cg_direction1(float* __restrict__ p, const float* __restrict__ r, CgState S, long npb) {
+  if (S.flags()[0]) return;
+  const int b = blockIdx.y;
+  const float beta = S.beta()[b];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npb; i += (long)gridDim.x * blockDim.x)
+    p[(long)b * npb + i] = fmaf(beta, p[(long)b * npb + i], r[(long)b * npb + i]);
+}
+
+// alpha_b = gamma_b / <p_b, A p_b>;  x += alpha p;  r -= alpha A p       (solver_cg.py:122-127)
+__global__ void k_cg_update(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ p, const float* __restrict__ Ap, CgState S,
+                            long npb4) {
+  if (S.flags()[0]) return;
+  const int b = blockIdx.y;
+  const float alpha = S.gamma()[b] / S.pAp()[b];
+  float4* xb = (float4*)x + (long)b * npb4;
+  float4* rb = (float4*)r + (long)b * npb4;
+  const float4* pb = (const float4*)p + (long)b * npb4;
+  const float4* qb = (const float4*)Ap + (long)b * npb4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npb4; i += (long)gridDim.x * blockDim.x) {
+    const float4 pv = pb[i], qv = qb[i], xv = xb[i], rv = rb[i];
+    xb[i] = make_float4(fmaf(alpha, pv.x, xv.x), fmaf(alpha, pv.y, xv.y), fmaf(alpha, pv.z, xv.z), fmaf(alpha, pv.w, xv.w));
+    rb[i] = make_float4(fmaf(-alpha, qv.x, rv.x), fmaf(-alpha, qv.y, rv.y), fmaf(-alpha, qv.z, rv.z), fmaf(-alpha, qv.w, rv.w));
+  }
+}
+__global__ void k_cg_update1(float* __restrict__ x, float* __restrict__ r, const float* __restrict__ p, const float* __restrict__ Ap, CgState S,
+                             long npb) {
+  if (S.flags()[0]) return;
+  const int b = blockIdx.y;
+  const float alpha = S.gamma()[b] / S.pAp()[b];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npb; i += (long)gridDim.x * blockDim.x) {
+    const long e = (long)b * npb + i;
+    x[e] = fmaf(alpha, p[e], x[e]);
+    r[e] = fmaf(-alpha, Ap[e], r[e]);
+  }
+}
+
+}  // namespace dpx
+
+using namespace dpx;
+
+extern "C" size_t dpx_cg_state_bytes(int B) { return B > 0 ? (size_t)(5 * B + 4) * sizeof(float) : 0; }
+
+extern "C" int dpx_cg_init(void* state, const float* bnorm2, float rtol, int B, dpx_stream_t stream) {
+  DPX_REQUIRE(state && bnorm2 && B >= 1 && B <= 64, "dpx_cg_init: the device-side stop rule handles 1..64 systems per solve, got %d", B);
+  DPX_LAUNCH("k_cg_init", k_cg_init, dim3(1), dim3(64), 0, (hipStream_t)stream, CgState{(float*)state, B}, bnorm2, rtol);
+  return launch_status("dpx_cg_init");
+}
+
+extern "C" int dpx_cg_test(void* state, const float* gram, int B, dpx_stream_t stream) {
+  DPX_REQUIRE(state && gram && B >= 1 && B <= 64, "dpx_cg_test: bad arguments");
+  DPX_LAUNCH("k_cg_test", k_cg_test, dim3(1), dim3(64), 0, (hipStream_t)stream, CgState{(float*)state, B}, gram);
+  return launch_status("dpx_cg_test");
+}
+
+extern "C" int dpx_cg_direction(float* p, const float* r, void* state, int B, long n_per_batch, dpx_stream_t stream) {
+  DPX_REQUIRE(p && r && state && B >= 1 && n_per_batch > 0, "dpx_cg_direction: bad arguments");
+  const CgState S{(float*)state, B};
+  if (n_per_batch % 4 == 0 && ((size_t)p % 16 == 0) && ((size_t)r % 16 == 0))
+    DPX_LAUNCH("k_cg_direction", k_cg_direction, dim3(grid_for(n_per_batch / 4, 256, 1024), B), dim3(256), 0, (hipStream_t)stream, p, r, S,
+               n_per_batch / 4);
+  else
+    DPX_LAUNCH("k_cg_direction", k_cg_direction1, dim3(grid_for(n_per_batch, 256, 1024), B), dim3(256), 0, (hipStream_t)stream, p, r, S, n_per_batch);
+  return launch_status("dpx_cg_direction");
+}
+
+extern "C" int dpx_cg_update(float* x, float* r, const float* p, const float* Ap, void* state, int B, long n_per_batch, dpx_stream_t stream) {
+  DPX_REQUIRE(x && r && p && Ap && state && B >= 1 && n_per_batch > 0, "dpx_cg_update: bad arguments");
+  const CgState S{(float*)state, B};
+  const bool al = ((size_t)x % 16 == 0) && ((size_t)r % 16 == 0) && ((size_t)p % 16 == 0) && ((size_t)Ap % 16 == 0);
+  if (n_per_batch % 4 == 0 && al)
+    DPX_LAUNCH("k_cg_update", k_cg_update, dim3(grid_for(n_per_batch / 4, 256, 1024), B), dim3(256), 0, (hipStream_t)stream, x, r, p, Ap, S,
+               n_per_batch / 4);
+  else
+    DPX_LAUNCH("k_cg_update", k_cg_update1, dim3(grid_for(n_per_batch, 256, 1024), B), dim3(256), 0, (hipStream_t)stream, x, r, p, Ap, S, n_per_batch);
+  return launch_status("dpx_cg_update");
+}
+
+/* zero-fill on the stream (hipMemsetAsync): the solver's fresh iterates / workspaces */
+extern "C" int dpx_zero(void* p, size_t bytes, dpx_stream_t stream) {
+  DPX_REQUIRE(p || bytes == 0, "dpx_zero: null pointer");
+  if (bytes && hipMemsetAsync(p, 0, bytes, (hipStream_t)stream) != hipSuccess) {
+    set_error("dpx_zero: hipMemsetAsync failed");
+    return DPX_ERR_LAUNCH;
+  }
+  return DPX_OK;
+}

@@ -75,6 +75,12 @@ SIGNATURES = {
     "dpx_bdot": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "dpx_bdot_ws_bytes": (c_size_t, [c_int, c_long]),
     "dpx_bgram": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "dpx_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "dpx_cg_state_bytes": (c_size_t, [c_int]),
+    "dpx_cg_init": (c_int, [c_void_p, c_void_p, c_float, c_int, c_void_p]),
+    "dpx_cg_test": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "dpx_cg_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "dpx_cg_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "dpx_prox": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
     "dpx_prox_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
     "dpx_fourier_apply_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -294,6 +294,48 @@ def bgram(r):
     return out
 
 
+def zeros_like(t):
+    """torch.zeros_like through the C ABI's stream memset"""
+    out = torch.empty_like(t)
+    if be.host_mode():
+        return out.zero_()
+    be.lib().call("dpx_zero", ptr(out), out.numel() * out.element_size(), be.stream())
+    return out
+
+
+class CgControl:
+    """device-resident control block of one cg() solve (dpx_cg_*): stop rule, beta / alpha and the iterate updates run on the
+    GPU; the host only issues kernels and polls the `done` flag without blocking"""
+
+    MAX_B = 64
+
+    def __init__(self, b, rtol):
+        L = be.lib()
+        self.B = int(b.shape[0])
+        self.npb = b.numel() // self.B
+        self.dev = b.device
+        self.state = torch.empty(L.query("dpx_cg_state_bytes", self.B) // 4, dtype=torch.float32, device=b.device)
+        self.flags = self.state[5 * self.B:].view(torch.int32)                  # done, n_done, it, pad
+        self.pAp = self.state[3 * self.B:4 * self.B]
+        self.gram = torch.empty(self.B, self.B, dtype=torch.float32, device=b.device)
+        self.ws = workspace("dot", L.query("dpx_bdot_ws_bytes", self.B, self.npb), b.device)
+        self.bnorm2 = bdot(b, b)                                                # <b_i, b_i> (kept alive: the call below is asynchronous)
+        L.call("dpx_cg_init", ptr(self.state), ptr(self.bnorm2), c_float(rtol), self.B, be.stream())
+
+    def test(self, r):
+        L = be.lib()
+        L.call("dpx_bgram", ptr(r), ptr(self.gram), self.B, self.npb, ptr(self.ws), be.stream())
+        L.call("dpx_cg_test", ptr(self.state), ptr(self.gram), self.B, be.stream())
+
+    def direction(self, p, r):
+        be.lib().call("dpx_cg_direction", ptr(p), ptr(r), ptr(self.state), self.B, self.npb, be.stream())
+
+    def update(self, x, r, p, Ap):
+        L = be.lib()
+        L.call("dpx_bdot", ptr(p), ptr(Ap), ptr(self.pAp), self.B, self.npb, ptr(self.ws), be.stream())
+        L.call("dpx_cg_update", ptr(x), ptr(r), ptr(p), ptr(Ap), ptr(self.state), self.B, self.npb, be.stream())
+
+
 def prox(kind, v, lam, alpha=1.0, off=None, out=None):
     require(v, what="prox input")
     B = int(v.shape[0])

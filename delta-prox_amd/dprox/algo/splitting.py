@@ -70,6 +70,11 @@ class ADMM(Algorithm):
         if plan is not None:
             self.last_path = "fused"
             return plan.run(state, rhos, lams, max_iter, pbar, callback)
+        if self.use_fused and type(self) in (ADMM, LinearizedADMM):
+            plan = fused.plan_split_cg(self, state, rhos, lams)     # CG x-update, every Psi term on x itself (config 4)
+            if plan is not None:
+                self.last_path = "fused-cg"
+                return plan.run(state, rhos, lams, max_iter, pbar, callback)
         self.last_path = "generic"
         return super().iters(state, rhos, lams, max_iter, pbar, callback)
 

@@ -250,12 +250,12 @@ class least_squares(ProxFn):
         d = (t0[1] if t0 is not None else 0.0) + c0 + rho_v.view(B, 1, 1, 1) * ((t1[1] if t1 is not None else 0.0) + c1)
         return (Ktb / (d + eps)).float()
 
-    def solve_cg(self, b, rho, v=None, linear_solve_config=LinearSolveConfig()):
+    def normal_operator(self, rho, with_identity=False):
+        """x -> sum_Omega K^T K x + rho sum_Psi K^T K x (+ rho x): the system matrix of the x-update as an nn.Module with the
+        protocol linear_solve expects (callable, .T, .clone()) -- sum_square.py:160-185"""
         quad, other = self.quad_fns, self.other_fns
 
         class KtK(nn.Module):
-            """x -> sum_Omega K^T K x + rho sum_Psi K^T K x (+ rho x)"""
-
             def __init__(self, rho):
                 super().__init__()
                 self.rho = rho
@@ -266,7 +266,7 @@ class least_squares(ProxFn):
                     terms.append((1.0, fn.dag.adjoint(fn.dag.forward(x))))
                 for fn in other:
                     terms.append((self.rho, fn.dag.adjoint(fn.dag.forward(x))))
-                if v is not None:
+                if with_identity:
                     terms.append((self.rho, x))
                 return ops.lincomb([(c, t.contiguous()) for c, t in terms])
 
@@ -277,15 +277,23 @@ class least_squares(ProxFn):
             def clone(self):
                 return KtK(self.rho)
 
-        Ktb = self.rhs(b, rho, v)
-        rho_v = ops.as_batch_vec(rho, Ktb.shape[0], Ktb.device)
-        cfg = linear_solve_config
+        return KtK(rho)
+
+    def solve_cg_rhs(self, Ktb, rho_v, with_identity=False, linear_solve_config=None):
+        """the CG x-update for an already assembled right-hand side ``Ktb``; records the exit iteration in ``cg_iters``"""
+        cfg = linear_solve_config or self.linear_solve_config
+        A = self.normal_operator(rho_v, with_identity)
         if cfg.solver_type == "cg" and not (torch.is_grad_enabled() and Ktb.requires_grad):
             from ..linalg.solve import cg
-            x, n = cg(KtK(rho_v), Ktb, rtol=cfg.rtol, max_iters=cfg.max_iters, verbose=cfg.verbose, return_iters=True)
+            x, n = cg(A, Ktb, rtol=cfg.rtol, max_iters=cfg.max_iters, verbose=cfg.verbose, return_iters=True)
             self.cg_iters.append(n)
             return x
-        return linear_solve(KtK(rho_v), Ktb, config=cfg)
+        return linear_solve(A, Ktb, config=cfg)
+
+    def solve_cg(self, b, rho, v=None, linear_solve_config=LinearSolveConfig()):
+        Ktb = self.rhs(b, rho, v)
+        rho_v = ops.as_batch_vec(rho, Ktb.shape[0], Ktb.device)
+        return self.solve_cg_rhs(Ktb, rho_v, with_identity=v is not None, linear_solve_config=linear_solve_config)
 
     def extra_repr(self) -> str:
         return f"diagonalizable: {self.diagonalizable}; freq_diagonalizable: {self.freq_diagonalizable}"

@@ -185,6 +185,22 @@ size_t dpx_bdot_ws_bytes(int B, long n_per_batch);
  * (torch.linalg.norm(ravel(r), 2), solver_cg.py:103-104)                                       */
 int dpx_bgram(const float* r, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream);
 
+/* Device-side control of cg() (linalg/solve/solver_cg.py:95-129): the host issues a whole solve without a read-back.
+ * `state` (dpx_cg_state_bytes) = float gamma[B], gamma_prev[B], beta[B], pAp[B], tol2[B]; int done, n_done, it, pad.
+ *   dpx_cg_init      tol2_i = (rtol * ||b_i||)^2 from bnorm2[i] = <b_i, b_i>; done = 0                        (:96, 1 <= B <= 64)
+ *   dpx_cg_test      stop rule :103-104 on the B x B residual Gram matrix (dpx_bgram): lambda_max(G) <= min_i tol2_i, decided
+ *                    by an LDL^T factorisation of  tau^2 I - G  in float64; converged -> done = 1, n_done = it (the iterate
+ *                    freezes: the kernels below return at once); else gamma = diag G, beta = gamma / gamma_prev (:112), ++it
+ *   dpx_cg_direction p = r + beta_b p                                                                          (:111-115)
+ *   [caller: Ap = A(p) with its own kernels;  dpx_bdot(p, Ap, state + 3B floats)]                             (:118-122)
+ *   dpx_cg_update    alpha_b = gamma_b / pAp_b ; x += alpha p ; r -= alpha Ap                                   (:123-127) */
+int dpx_zero(void* p, size_t bytes, dpx_stream_t stream);          /* torch.zeros_like of the solvers' fresh iterates (solver_cg.py:83-85) */
+size_t dpx_cg_state_bytes(int B);
+int dpx_cg_init(void* state, const float* bnorm2, float rtol, int B, dpx_stream_t stream);
+int dpx_cg_test(void* state, const float* gram, int B, dpx_stream_t stream);
+int dpx_cg_direction(float* p, const float* r, void* state, int B, long n_per_batch, dpx_stream_t stream);
+int dpx_cg_update(float* x, float* r, const float* p, const float* Ap, void* state, int B, long n_per_batch, dpx_stream_t stream);
+
 /* proximal operators, ProxFn.prox with the scaled/translated wrappers (proxfn/base.py:12-27,55-64):
  *   out = P(v - off, lam_b * alpha) + off      off nullable
  * kinds: norm1 soft-threshold (proxfn/norm.py:6-19), nonneg (proxfn/nonneg.py:10-11),

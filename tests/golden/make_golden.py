@@ -391,6 +391,41 @@ def g23_pnp_scaled_sqrt():
     save("g23_pnp_scaled_sqrt", b=b, psf=psf, rhos=rhos, lams=lams, x=st[0], v0=st[1][0], u0=st[2][0])
 
 
+def g24_linear_solve_grad():
+    """linear_solve with the implicit backward pass (linalg/custom.py:39-82) on the masked-Fourier normal operator
+    A_rho(x) = Re F^H M F x + rho x with a trainable per-image rho: x, dL/db (one transposed solve) and dL/drho (operator VJP at
+    the solution) for L = <x, w>; the reference's own tests of this rule: tests/linalg/test_linear_solver_grad.py:101-123,
+    tests/linalg/test_linear_solver_torch.py:51-95."""
+    from dprox.linalg import linear_solve
+    B, H, W = 2, 32, 32
+    gt, mask, y = _csmri(B, H, W, seed=240)
+    rng = np.random.RandomState(241)
+
+    class Normal(torch.nn.Module):
+        def __init__(self, rho):
+            super().__init__()
+            self.rho = torch.nn.Parameter(rho)
+
+        def forward(self, x):
+            return ifft2(mask * (mask * fft2(x))).real.float() + self.rho.view(-1, 1, 1, 1) * x
+
+        @property
+        def T(self):
+            return self
+
+        def clone(self):
+            return Normal(self.rho.detach().clone())
+
+    rho0 = torch.tensor([0.35, 0.6])
+    A = Normal(rho0.clone())
+    b = (ifft2(mask * y).real.float() + rho0.view(-1, 1, 1, 1) * T(gt)).clone().requires_grad_(True)
+    w = T(rng.randn(B, 1, H, W).astype("float32"))
+    x = linear_solve(A, b, LinearSolveConfig(rtol=1e-6, max_iters=100))
+    (x * w).sum().backward()
+    save("g24_linear_solve_grad", mask=mask, rho=rho0, b=b.detach(), w=w, x=x.detach(), g_b=b.grad, g_rho=A.rho.grad)
+    print("g24", A.rho.grad, float(b.grad.abs().max()))
+
+
 def g21_x8_augment():
     """deep_prior(x8=True): denoisers/composite.py:6-46 -- nine consecutive prox calls (modes 0..7, 0) on a non-square image"""
     x = dp.Variable()
@@ -962,7 +997,7 @@ def g33_full_c5():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt,
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad,
                g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

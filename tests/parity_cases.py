@@ -497,7 +497,7 @@ def case_mosaic_jd(device, solve=True):
     with torch.no_grad():
         st = prob.solve(method="admm", device=device, x0=b, rhos=torch.from_numpy(g["jd_rhos"]), lams={reg: torch.from_numpy(g["jd_sigmas"])},
                         max_iter=3, return_full_states=True)
-    assert prob.solver.last_path == "generic"
+    assert prob.solver.last_path == "fused-cg"           # CG x-update + a Psi term on x itself: the fused split-CG loop
     assert_close(st[0].cpu(), g["jd_x"], 2 * TOL, "JD x (CG x-update)")
     assert_close(st[1][0].cpu(), g["jd_v"], 2 * TOL, "JD v")
 
@@ -953,3 +953,39 @@ def case_unet(device, grads=True):
     # the state dict keeps the reference's keys, also inside a parent module
     sd = den.state_dict()
     assert "model.inc.conv.conv-0.conv2d.weight" in sd and "model.outc.conv.bias" in sd and len(sd) == 56
+
+
+def case_linear_solve_grad(device):
+    """G24: linear_solve's implicit backward (reference linalg/custom.py:39-82) on the masked-Fourier normal operator with a
+    trainable per-image rho: the solution, dL/db (one more CG solve with A^T) and dL/drho (operator VJP at the solution)."""
+    from dprox.linalg import LinearSolveConfig, linear_solve
+    from dprox.utils import fft2, ifft2
+    g = load_golden("g24_linear_solve_grad")
+    mask, w = T(g["mask"], device), T(g["w"], device)
+
+    class Normal(torch.nn.Module):
+        def __init__(self, rho):
+            super().__init__()
+            self.rho = torch.nn.Parameter(rho)
+
+        def forward(self, x):
+            return ifft2(mask * (mask * fft2(x.contiguous()))).real.float().contiguous() + self.rho.view(-1, 1, 1, 1) * x
+
+        @property
+        def T(self):
+            return self
+
+        def clone(self):
+            return Normal(self.rho.detach().clone())
+
+    A = Normal(T(g["rho"], device).clone()).to(device)
+    b = T(g["b"], device).clone().requires_grad_(True)
+    x = linear_solve(A, b, LinearSolveConfig(rtol=1e-6, max_iters=100))
+    (x * w).sum().backward()
+    assert_close(x.detach().cpu(), g["x"], TOL, "linear_solve x")
+    assert_close(b.grad.cpu(), g["g_b"], 1e-4, "linear_solve dL/db (transposed solve)")
+    assert_close(A.rho.grad.cpu(), g["g_rho"], 1e-4, "linear_solve dL/drho (operator VJP)")
+    # without anything to differentiate the solver is called directly
+    with torch.no_grad():
+        x2 = linear_solve(A, b.detach(), LinearSolveConfig(rtol=1e-6, max_iters=100))
+    assert_close(x2.cpu(), g["x"], TOL, "linear_solve x (no grad)")

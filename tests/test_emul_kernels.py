@@ -55,6 +55,10 @@ def test_cg(B):
     pc.case_cg(DEV, B)
 
 
+def test_linear_solve_implicit_backward():
+    pc.case_linear_solve_grad(DEV)
+
+
 def test_ffdnet_mfma_layout():
     pc.case_ffdnet(DEV, which=("batch",))       # 2x3x16x24: the f32 MFMA lane layouts + pack / unpack, emulated
 

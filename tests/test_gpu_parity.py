@@ -60,6 +60,10 @@ def test_cg(B):
     pc.case_cg(DEV, B)
 
 
+def test_linear_solve_implicit_backward():
+    pc.case_linear_solve_grad(DEV)
+
+
 def test_ffdnet():
     pc.case_ffdnet(DEV)
 
