@@ -208,6 +208,108 @@ def extra_configs(dp, synthetic, device):
     return out
 
 
+def sharded_runs(dp, synthetic, dist, rank, world, device):
+    """N > 1 only: the strong-scaling companions of the weak-scaling headline.  Rank 0 holds a whole batch in its HBM; the
+    images are dealt out over RCCL (dprox.distributed.solve_sharded: scatter in, per-rank solve, all-gather out -- no
+    collective inside the iteration), timed end to end (barrier + synchronize on both sides, max over ranks).
+      config2_batch8  : the 8 x 3 x 1024 x 1024 batch of the headline, 50 ADMM iterations, 8 / N images per GPU
+      config4_batch32 : BASELINE.json config 4, 32 x 1 x 320 x 320 CS-MRI, LADMM + CG + FFDNet-gray, 10 outer iterations, 32 / N per GPU
+    Shared constants (PSF, sampling mask, denoiser weights) are built on rank 0 and broadcast once (excluded from the timing, like
+    the compile step)."""
+    from dprox import distributed as dd
+    from dprox.contrib import masked_fft
+    from dprox.linalg import LinearSolveConfig
+    from dprox.proxfn.pnp.denoisers import FFDNetDenoiser
+    from dprox.utils import ifft2
+    comm = dd.Comm.from_process_group() if os.environ.get("DPX_COMM", "torch") == "abi" else None
+    out = {"transport": "dpx_comm_* (RCCL through the C ABI)" if comm is not None else "torch.distributed nccl backend (RCCL)", "world": world}
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    failed = []
+
+    def guarded(fn, out_shape):
+        """a rank whose local solve raises still takes part in the collectives (zeros), and reports the failure afterwards"""
+        def run(loc):
+            try:
+                return fn(loc)
+            except Exception as e:                         # noqa: BLE001
+                failed.append(f"rank {rank}: {type(e).__name__}: {e}")
+                n = next(iter(loc.values())).shape[0]
+                return torch.zeros((n,) + tuple(out_shape), dtype=torch.float32, device=device)
+        return run
+
+    def any_failed():
+        t = torch.tensor([float(len(failed))], device=device)
+        dist.all_reduce(t)
+        return float(t.item()) > 0
+
+    def timed(fn, inputs):
+        fn(inputs)                                         # warm-up: tables, workspaces, RCCL channels
+        barrier()
+        t0 = time.perf_counter()
+        res = fn(inputs)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), res
+
+    # ---- config 2, one batch of 8 split over the ranks
+    if rank == 0:
+        rng = np.random.RandomState(2023)
+        gt = torch.from_numpy(synthetic.synth(rng, B, C, H, W)).to(device)
+        psf0 = synthetic.point_spread_function(15, 5.0)
+        b = (dp.conv(dp.Variable(), psf0).to(device).forward(gt) + torch.from_numpy((rng.randn(B, C, H, W) * (2.0 / 255.0)).astype(np.float32)).to(device)).contiguous()
+        consts = {"psf": torch.from_numpy(psf0).to(device)}
+    consts = dd.broadcast_constants(consts if rank == 0 else None, src=0, device=device, comm=comm)
+    psf = consts["psf"].cpu().numpy()
+    def solve_c2(loc):
+        bb = loc["b"]
+        x = dp.Variable()
+        s = dp.compile(dp.sum_squares(dp.conv(x, psf) - bb) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device=device)
+        return s.solve(x0=bb, rhos=RHO, lams=LAM, max_iter=50)
+
+    g2 = guarded(solve_c2, (C, H, W))
+    dt, xs = timed(lambda inp: dd.solve_sharded(g2, inp, src=0, device=device, comm=comm), {"b": b} if rank == 0 else None)
+    if any_failed():
+        out["error"] = failed or ["a peer rank failed in config2_batch8"]
+        return out
+    out["config2_batch8"] = {"images_per_gpu": B / world, "iters": 50, "seconds": dt, "it_per_s": 50 / dt,
+                             "note": "scatter of the 100.7 MB observation + 50 iterations + all-gather of the result, end to end"}
+    if rank == 0:
+        out["config2_batch8"]["psnr_db_mean"] = float(np.mean(psnr_per_image(xs, gt)))
+    # ---- config 4, 32 images split over the ranks
+    nb = 32
+    if rank == 0:
+        gt4, mask, y = synthetic.csmri_case(nb, 320, 320, seed=2023)
+        consts4 = {"mask": torch.from_numpy(mask).to(device)}
+        y_d = torch.from_numpy(y).to(device)
+        y_ri = torch.view_as_real(y_d).contiguous()        # complex tensors travel as [.., 2] float32
+    consts4 = dd.broadcast_constants(consts4 if rank == 0 else None, src=0, device=device, comm=comm)
+    wts = synthetic.ffdnet_weights(11, 1, 1, 64, 15)       # seeded: identical on every rank (a real checkpoint would be broadcast like the mask)
+
+    def solve_c4(loc):
+        yy = torch.view_as_complex(loc["y"].contiguous())
+        x = dp.Variable()
+        fns = dp.sum_squares(masked_fft(x, consts4["mask"]), yy) + dp.nonneg(x) + dp.deep_prior(x, denoiser=FFDNetDenoiser(wts))
+        s = dp.compile(fns, method="ladmm", device=device, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100))
+        with torch.no_grad():
+            return s.solve(x0=ifft2(yy).real.contiguous(), rhos=0.5, lams=0.03, max_iter=10)
+
+    g4 = guarded(solve_c4, (1, 320, 320))
+    dt, _ = timed(lambda inp: dd.solve_sharded(g4, inp, src=0, device=device, comm=comm), {"y": y_ri} if rank == 0 else None)
+    if any_failed():
+        out["error"] = failed or ["a peer rank failed in config4_batch32"]
+        return out
+    out["config4_batch32"] = {"images_per_gpu": nb / world, "outer_iters": 10, "seconds": dt, "ms_per_outer_iter": dt / 10 * 1e3}
+    if comm is not None:
+        comm.close()
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,9 +319,11 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DPX_BENCH_FORCE_DIST"):     # (FORCE_DIST: exercise the N > 1 code path on a one-GPU box)
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     import dprox as dp
     import synthetic
@@ -266,6 +370,12 @@ def main():
     out = solver.solve(x0=b, rhos=RHO, lams=LAM, max_iter=50)
     psnr_in, psnr_out = psnr_per_image(b, gt), psnr_per_image(out, gt)
 
+    sharded = None
+    if dist is not None and not a.no_extra_configs:
+        try:
+            sharded = sharded_runs(dp, synthetic, dist, rank, world, device)
+        except Exception as e:                             # the headline line must survive a failure of the companion runs
+            sharded = {"error": f"{type(e).__name__}: {e}"}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -324,9 +434,16 @@ def main():
         res["parity_rel_l2"] = float((x_gpu - x_ref).double().norm() / x_ref.double().norm())
         res["parity_note"] = (f"GPU iterate (images 0..{sb - 1} of the batch-8 solve, {1 + n_it} ADMM iterations) vs the CPU oracle run "
                               f"timed above on the same images; bar 1e-5")
+    if sharded is not None:
+        res["sharded"] = sharded
     if world == 1 and not a.no_extra_configs:
         res["configs"] = extra_configs(dp, synthetic, device)
-    print(json.dumps(res))
+    # RCCL writes a version banner to the C stdout buffer, which would otherwise be flushed at exit BEHIND the JSON line: flush it
+    # first, print the one line, then close stdout for everything that follows
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.write(json.dumps(res) + "\n")
+    sys.stdout.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -75,6 +75,14 @@ SIGNATURES = {
     "dpx_bdot": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "dpx_bdot_ws_bytes": (c_size_t, [c_int, c_long]),
     "dpx_bgram": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "dpx_comm_unique_id": (c_int, [c_void_p]),
+    "dpx_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "dpx_comm_destroy": (c_int, [c_void_p]),
+    "dpx_comm_rank": (c_int, [c_void_p]),
+    "dpx_comm_world": (c_int, [c_void_p]),
+    "dpx_comm_broadcast": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "dpx_comm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dpx_comm_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "dpx_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
     "dpx_cg_state_bytes": (c_size_t, [c_int]),
     "dpx_cg_init": (c_int, [c_void_p, c_void_p, c_float, c_int, c_void_p]),

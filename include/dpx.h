@@ -346,6 +346,21 @@ int dpx_conv2d_wgrad(const float* g, const float* a, float* gw, float* gb, int c
 int dpx_space_to_depth(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
 int dpx_depth_to_space(const float* x, float* y, int B, int C, int H, int W, dpx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* multi-GPU: RCCL behind the C ABI (one process per GPU)                          */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference runs on one device (algo/base.py:118); a batch is sharded image-wise here.  Only three collectives exist, none of
+ * them inside an iteration: broadcast of shared constants, scatter of a batch held by one rank, all-gather of the results.
+ * librccl is loaded lazily; a communicator belongs to the HIP device current at dpx_comm_init.  Byte counts, in-order on `stream`. */
+int dpx_comm_unique_id(void* out128);                                   /* rank 0, then shipped to the others out of band */
+int dpx_comm_init(void** comm, const void* id128, int rank, int world);
+int dpx_comm_destroy(void* comm);
+int dpx_comm_rank(void* comm);
+int dpx_comm_world(void* comm);
+int dpx_comm_broadcast(void* comm, void* buf, size_t bytes, int root, dpx_stream_t stream);
+int dpx_comm_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, dpx_stream_t stream);
+int dpx_comm_scatter(void* comm, const void* send, void* recv, size_t bytes_per_rank, int root, dpx_stream_t stream);
+
 /* U-Net denoiser (UNetDenoiser, dprox/proxfn/pnp/denoisers/wrapper.py:206-221 -> models/unet/unet.py:34-135): every ConvLayer
  * (Conv2d 3x3 pad 1 + bias + LeakyReLU(0.2), unet.py:8-31) is one dpx_conv2d_leaky launch on the matrix-core kernel; between them
  *   dpx_maxpool2            nn.MaxPool2d(2), unet.py:80 (floor; ties -> first maximum, as ATen)         [B,C,H,W] -> [B,C,H/2,W/2]
