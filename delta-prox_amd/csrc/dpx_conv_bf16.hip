@@ -1,0 +1,380 @@
+// 3x3 convolution layers at fp32 accuracy on the bf16 matrix cores ("split-bf16": x = hi + mid + lo, three bf16 terms that
+// together hold all 24 mantissa bits of an fp32 value, split by truncation so that the decomposition is EXACT).
+//
+//   y = sum_k w_k a_k  with  w = wh + wm + wl,  a = ah + am + al   =>   six products of order <= 2 are accumulated in fp32 by
+//   v_mfma_f32_32x32x16_bf16:   wh ah | wh am | wm ah | wh al | wl ah | wm am        (dropped: wm al, wl am, wl al <= 2^-24 |w a|,
+//   the size of one fp32 rounding of the product itself).  6 x 32 cycles per 16 input channels and 32 x 32 outputs instead of
+//   8 x 64 cycles with v_mfma_f32_32x32x2_f32: 2.67x the fp32-matrix-core rate.   MODE = 1 keeps only  wh ah  (plain bf16).
+//
+// Data layout ("C8"): activations [B][C/8][H][W][8] fp32 -- eight channels of a pixel are 32 contiguous bytes, so that
+//   * the producing layer's D tile (lane = pixel, 4 consecutive output channels per register quad) is written with 16-byte
+//     stores, 1 KB contiguous per wave instruction,
+//   * a (pixel, 8-channel group) is exactly the B operand of one lane of the 32x32x16 MFMA.
+// Activations stay fp32 in HBM (4 B / element as before); the workgroup splits the staged tile once per 16-channel chunk.
+//
+// Workgroup = 512 threads = 8 waves, output tile 16 rows x 32 columns x all output channels (MT x 32); wave w owns rows 2w, 2w+1.
+// Per 16-channel chunk:  LDS-DMA landing buffer (fp32, next chunk in flight while this one multiplies) -> split pass -> bf16 tile
+// [plane][k-group][row][col][8];  weights arrive by LDS-DMA in slots of 3 taps, pre-split at pack time, ring of 2 slots, one
+// workgroup barrier per slot.  LDS: 39 + 57 + 54 KB (MT = 3): one workgroup per CU, two waves per SIMD.
+#include "dpx_common.h"
+
+namespace dpx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BX_TW = 32, BX_TH = 16, BX_ROWS = BX_TH + 2, BX_COLS = BX_TW + 2;
+constexpr int BX_UNITS = 2 * BX_ROWS * BX_COLS;                      // (k-group, row, col) units of 8 channels: 1224
+constexpr int BX_PIECES = 2 * BX_UNITS;                              // 16-byte LDS-DMA pieces of one fp32 chunk: 2448
+constexpr int BX_LAND_BYTES = ((BX_PIECES + 63) / 64) * 1024;        // 39936 (whole 1 KB instructions)
+constexpr int BX_PLANE_BYTES = BX_UNITS * 16;                        // one bf16 plane of the tile: 19584
+constexpr int BX_TILE_BYTES = 3 * BX_PLANE_BYTES;
+constexpr int BX_NPI = (BX_PIECES + 511) / 512;                      // DMA instructions per thread and chunk: 5
+__host__ __device__ constexpr int bx_tap_bytes(int MT) { return 3 * 2 * MT * 32 * 16; }     // [plane][k-group][cout][8] bf16
+__host__ __device__ constexpr int bx_slot_bytes(int MT) { return 3 * bx_tap_bytes(MT); }    // 3 taps
+
+// packed layer: [chunk][tap group 3][tap 3][plane 3][k-group 2][cout MT*32][8] bf16, then bias fp32 [MT*32], then 64 zero bytes
+static inline size_t bx_layer_bytes(int cin, int cout) {
+  const int chunks = (cin + 15) / 16, MT = (cout + 31) / 32;
+  return (size_t)chunks * 3 * bx_slot_bytes(MT) + (size_t)MT * 32 * 4 + 64;
+}
+
+// exact three-way split by truncation; every part is returned as fp32 bits whose low 16 bits are zero
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m)) & 0xffff0000u;
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo_elem, unsigned hi_elem) { return (hi_elem & 0xffff0000u) | (lo_elem >> 16); }
+// round-to-nearest-even bf16 (MODE = 1, plain bf16 operands), as fp32 bits with a zero low half
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+
+#ifdef DPX_EMULATED
+__device__ inline f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) { return emul_mfma_32x32x16_bf16(a, b, c); }
+#else
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+#endif
+
+// w [cout][cin][9] fp32, b [cout] (nullable) -> packed layer.  mode 6: three exact planes; mode 1: plane 0 = RNE bf16, others 0.
+__global__ void k_bx_pack_weights(const float* __restrict__ w, const float* __restrict__ b, unsigned short* __restrict__ dst, int cin, int cout,
+                                  int mode) {
+  const int chunks = (cin + 15) / 16, MT = (cout + 31) / 32, M32 = MT * 32;
+  const long nw = (long)chunks * 9 * 3 * 2 * M32 * 8;                  // bf16 elements
+  float* bias = (float*)(dst + nw);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + M32 + 16; i += (long)gridDim.x * blockDim.x) {
+    if (i >= nw) {
+      const int k = (int)(i - nw);
+      bias[k] = (k < M32 && k < cout && b) ? b[k] : 0.f;
+      continue;
+    }
+    const int j = (int)(i % 8);
+    long r = i / 8;
+    const int co = (int)(r % M32);
+    r /= M32;
+    const int kg = (int)(r % 2);
+    r /= 2;
+    const int plane = (int)(r % 3);
+    r /= 3;
+    const int tap = (int)(r % 9), chunk = (int)(r / 9);               // [chunk][tap group][tap in group] == [chunk][tap]
+    const int ci = chunk * 16 + kg * 8 + j;
+    const float v = (co < cout && ci < cin) ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
+    unsigned h, m, l;
+    if (mode == 1) {
+      h = bf16_rne(v);
+      m = l = 0u;
+    } else {
+      split3(v, h, m, l);
+    }
+    dst[i] = (unsigned short)((plane == 0 ? h : (plane == 1 ? m : l)) >> 16);
+  }
+}
+
+// FFDNet input stage into the C8 layout: replicate-pad to even size, pixel-unshuffle(2) (channel = c*4 + dy*2 + dx), sigma map as
+// channel 4C, zero fill up to a multiple of 16 channels               (network_ffdnet.py:56-63)
+__global__ void k_bx_pack_in(const float* __restrict__ x, const float* __restrict__ sigma, float* __restrict__ a, int B, int C, int H, int W,
+                             int H2, int W2, int G) {
+  const long total = (long)B * G * H2 * W2 * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    long r = i / 8;
+    const int x2 = (int)(r % W2);
+    r /= W2;
+    const int y2 = (int)(r % H2);
+    r /= H2;
+    const int g = (int)(r % G), b = (int)(r / G);
+    const int ch = g * 8 + j;
+    float v = 0.f;
+    if (ch < 4 * C) {
+      const int c = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1;
+      const int yy = min(2 * y2 + dy, H - 1), xx = min(2 * x2 + dx, W - 1);
+      v = x[(((long)b * C + c) * H + yy) * W + xx];
+    } else if (ch == 4 * C) {
+      v = sigma[b];
+    }
+    a[i] = v;
+  }
+}
+
+// C8 [B][G][H2][W2][8] (first 4C channels) -> y [B][C][H][W]: PixelShuffle(2) + crop      (network_ffdnet.py:65-67)
+__global__ void k_bx_unpack_out(const float* __restrict__ o, float* __restrict__ y, int B, int C, int H, int W, int H2, int W2, int G) {
+  const long total = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    long r = i / W;
+    const int yy = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    const int ch = c * 4 + (yy & 1) * 2 + (xx & 1);
+    y[i] = o[((((long)b * G + (ch >> 3)) * H2 + (yy >> 1)) * W2 + (xx >> 1)) * 8 + (ch & 7)];
+  }
+}
+
+// in / out: C8 fp32; Gin = input channel groups (even: chunks of 2), Gout = output groups actually stored.
+template <int MT, bool RELU, int MODE>
+__global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict__ in, float* __restrict__ out, const char* __restrict__ wpk, int Gin,
+                                                        int Gout, int H, int W, int tiles_x) {
+  constexpr int M32 = MT * 32, TAPB = bx_tap_bytes(MT), SLOTB = bx_slot_bytes(MT);
+  constexpr int NPL = MODE == 1 ? 1 : 3;                              // operand planes in use
+  HIP_DYNAMIC_SHARED(char, smem_bx)
+  char* land = smem_bx;
+  char* tile = smem_bx + BX_LAND_BYTES;
+  char* ring = tile + BX_TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * BX_TH, x0 = tx * BX_TW;
+  const int n = lane & 31, kg = lane >> 5;
+  const int chunks = Gin / 2;
+  const float* bias = (const float*)(wpk + (size_t)chunks * 3 * SLOTB);
+  const float* zero_block = bias + M32;                               // 64 zero bytes behind the bias
+  const float* inb = in + (size_t)b * Gin * H * W * 8;
+
+  // per-lane source offsets (floats, relative to the chunk's first group) of its DMA pieces; ~0u = outside the image
+  unsigned poff[BX_NPI];
+#pragma unroll
+  for (int k = 0; k < BX_NPI; ++k) {
+    const int q = k * 512 + tid;
+    const int u = q >> 1, half = q & 1;
+    const int g = u / (BX_ROWS * BX_COLS), rem = u - g * (BX_ROWS * BX_COLS);
+    const int row = rem / BX_COLS, col = rem - row * BX_COLS;
+    const int yy = y0 + row - 1, xx = x0 + col - 1;
+    const bool ok = q < BX_PIECES && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    poff[k] = ok ? (unsigned)(((size_t)g * H * W + (size_t)yy * W + xx) * 8 + half * 4) : ~0u;
+  }
+  auto issue_act = [&](int c) {
+    const float* cb = inb + (size_t)(2 * c) * H * W * 8;
+#pragma unroll
+    for (int k = 0; k < BX_NPI; ++k) {
+      if (k * 512 + wv * 64 < BX_PIECES) {                            // wave-uniform: whole 1 KB instructions
+        const float* src = poff[k] != ~0u ? cb + poff[k] : zero_block;
+        dpx_glds16(src, land + (k * 512 + wv * 64) * 16);
+      }
+    }
+  };
+  auto issue_w = [&](int slot_idx) {                                  // global slot index = chunk * 3 + tap group
+    const char* src = wpk + (size_t)slot_idx * SLOTB + lane * 16;
+    char* dst = ring + (slot_idx & 1) * SLOTB;
+    for (int i = wv; i < SLOTB / 1024; i += 8) dpx_glds16(src + i * 1024, dst + i * 1024);
+  };
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][r][i] = 0.f;
+
+  const int nslots = chunks * 3;
+  issue_act(0);
+  issue_w(0);
+  for (int c = 0; c < chunks; ++c) {
+    // ---- the chunk's activations: landed -> split into bf16 planes ------------------------------------------------------
+    dpx_wait_vm<0>();
+    __syncthreads();                                                  // landing buffer complete; everybody is done with the old tile
+    for (int u = tid; u < BX_UNITS; u += 512) {
+      const float4 lo4 = *(const float4*)(land + u * 32), hi4 = *(const float4*)(land + u * 32 + 16);
+      const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      unsigned h[8], m[8], l[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (MODE == 1) {
+          h[j] = bf16_rne(v[j]);
+          m[j] = l[j] = 0u;
+        } else {
+          split3(v[j], h[j], m[j], l[j]);
+        }
+      }
+      *(uint4*)(tile + u * 16) = make_uint4(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7]));
+      if constexpr (MODE != 1) {
+        *(uint4*)(tile + BX_PLANE_BYTES + u * 16) = make_uint4(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7]));
+        *(uint4*)(tile + 2 * BX_PLANE_BYTES + u * 16) = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
+      }
+    }
+    __syncthreads();                                                  // tile ready, landing buffer free
+    if (c + 1 < chunks) issue_act(c + 1);
+    // ---- three slots of three taps ----------------------------------------------------------------------------------------
+    for (int tg = 0; tg < 3; ++tg) {
+      const int s = c * 3 + tg;
+      if (tg > 0) {                                                    // (tg == 0: the barrier pair above already covered slot s)
+        dpx_wait_vm<0>();
+        __syncthreads();                                              // slot s landed; slot s - 1 no longer read by anybody
+      }
+      if (s + 1 < nslots) issue_w(s + 1);
+      const char* wslot = ring + (s & 1) * SLOTB;
+#pragma unroll
+      for (int t3 = 0; t3 < 3; ++t3) {
+        const int tap = tg * 3 + t3, dy = tap / 3, dx = tap - dy * 3;
+        uint4 bf[2][NPL];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int u = (kg * BX_ROWS + 2 * wv + r + dy) * BX_COLS + n + dx;
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) bf[r][p] = *(const uint4*)(tile + p * BX_PLANE_BYTES + u * 16);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          uint4 af[NPL];
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) af[p] = *(const uint4*)(wslot + t3 * TAPB + ((p * 2 + kg) * M32 + mt * 32 + n) * 16);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            if constexpr (MODE == 1) {
+              acc[mt][r] = mfma_bf16(af[0], bf[r][0], acc[mt][r]);
+            } else {
+              // small terms first, the leading product last
+              acc[mt][r] = mfma_bf16(af[1], bf[r][1], acc[mt][r]);    // wm am
+              acc[mt][r] = mfma_bf16(af[2], bf[r][0], acc[mt][r]);    // wl ah
+              acc[mt][r] = mfma_bf16(af[0], bf[r][2], acc[mt][r]);    // wh al
+              acc[mt][r] = mfma_bf16(af[1], bf[r][0], acc[mt][r]);    // wm ah
+              acc[mt][r] = mfma_bf16(af[0], bf[r][1], acc[mt][r]);    // wh am
+              acc[mt][r] = mfma_bf16(af[0], bf[r][0], acc[mt][r]);    // wh ah
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue: bias, ReLU, C8 store.  D layout: col = lane & 31 (pixel), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) (cout) ----
+  float* outb = out + (size_t)b * Gout * H * W * 8;
+  const int xx = x0 + n;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int yy = y0 + 2 * wv + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cg = mt * 4 + q;                                    // output channel group of this register quad
+        float4 v;
+        const int cl = mt * 32 + 8 * q + 4 * kg;
+        v.x = acc[mt][r][4 * q + 0] + bias[cl + 0];
+        v.y = acc[mt][r][4 * q + 1] + bias[cl + 1];
+        v.z = acc[mt][r][4 * q + 2] + bias[cl + 2];
+        v.w = acc[mt][r][4 * q + 3] + bias[cl + 3];
+        if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (cg < Gout && yy < H && xx < W) *(float4*)(outb + (((size_t)cg * H + yy) * W + xx) * 8 + 4 * kg) = v;
+      }
+    }
+}
+
+template <int MT, int MODE>
+static void launch_bx(bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s) {
+  const int tx = (W + BX_TW - 1) / BX_TW, ty = (H + BX_TH - 1) / BX_TH;
+  const size_t sh = (size_t)BX_LAND_BYTES + BX_TILE_BYTES + 2 * bx_slot_bytes(MT);
+  static bool attr[2] = {false, false};
+  if (!attr[relu]) {
+    if (relu) hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, true, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    else hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    attr[relu] = true;
+  }
+  if (relu)
+    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, true, MODE>), dim3(tx * ty, B), dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx);
+  else
+    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, false, MODE>), dim3(tx * ty, B), dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx);
+}
+template <int MODE>
+static void launch_bx_mt(int mt, bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s) {
+  switch (mt) {
+    case 1: launch_bx<1, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s); break;
+    case 2: launch_bx<2, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s); break;
+    default: launch_bx<3, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s); break;
+  }
+}
+
+static int bx_cin(int l, int in_nc, int nc) { return l == 0 ? 4 * in_nc + 1 : nc; }
+static int bx_cout(int l, int in_nc, int nc, int nb) { return l == nb - 1 ? 4 * in_nc : nc; }
+static int groups16(int c) { return 2 * ((c + 15) / 16); }           // channel groups of 8, rounded up to whole 16-channel chunks
+
+}  // namespace dpx
+
+using namespace dpx;
+
+// mode: 6 = split-bf16 (fp32-accurate), 1 = plain bf16 operands
+extern "C" size_t dpx_ffdnet_bf16_packed_bytes(int in_nc, int nc, int nb) {
+  size_t n = 0;
+  for (int l = 0; l < nb; ++l) n += bx_layer_bytes(bx_cin(l, in_nc, nc), bx_cout(l, in_nc, nc, nb));
+  return n + 1024;
+}
+
+extern "C" int dpx_ffdnet_bf16_pack(void* packed, const float* const* w, const float* const* b, int in_nc, int nc, int nb, int mode,
+                                    dpx_stream_t stream) {
+  DPX_REQUIRE(packed && w && b && in_nc > 0 && nc > 0 && nb >= 2 && (mode == 6 || mode == 1), "dpx_ffdnet_bf16_pack: bad arguments");
+  DPX_REQUIRE(nc <= 96 && nc % 16 == 0 && 4 * in_nc <= 96, "dpx_ffdnet_bf16_pack: layers of 16..96 channels (multiples of 16), got %d", nc);
+  char* dst = (char*)packed;
+  for (int l = 0; l < nb; ++l) {
+    const int cin = bx_cin(l, in_nc, nc), cout = bx_cout(l, in_nc, nc, nb);
+    DPX_REQUIRE(w[l] && b[l], "dpx_ffdnet_bf16_pack: layer %d has null weights", l);
+    const size_t n = bx_layer_bytes(cin, cout);
+    DPX_LAUNCH("k_bx_pack_weights", k_bx_pack_weights, dim3(grid_for((long)(n / 2), 256, 2048)), dim3(256), 0, (hipStream_t)stream, w[l], b[l],
+               (unsigned short*)dst, cin, cout, mode);
+    dst += n;
+  }
+  return launch_status("dpx_ffdnet_bf16_pack");
+}
+
+extern "C" size_t dpx_ffdnet_bf16_ws_bytes(int B, int in_nc, int nc, int H, int W) {
+  const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
+  return (px * 8 * groups16(4 * in_nc + 1) + 2 * px * 8 * groups16(nc) + px * 8 * groups16(4 * in_nc)) * sizeof(float);
+}
+
+extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode,
+                                       int B, int H, int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && sigma && packed && ws, "dpx_ffdnet_forward_bf16: null pointer");
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 && (mode == 6 || mode == 1),
+              "dpx_ffdnet_forward_bf16: unsupported configuration (in_nc=%d nc=%d nb=%d mode=%d)", in_nc, nc, nb, mode);
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  DPX_REQUIRE((size_t)2 * H2 * W2 * 8 < ((size_t)1 << 32), "dpx_ffdnet_forward_bf16: plane %dx%d too large", H, W);
+  const size_t px = (size_t)B * H2 * W2;
+  const int G0 = groups16(4 * in_nc + 1), Gc = groups16(nc), GL = groups16(4 * in_nc);
+  float* a0 = (float*)ws;
+  float* bufA = a0 + px * 8 * G0;
+  float* bufB = bufA + px * 8 * Gc;
+  float* last = bufB + px * 8 * Gc;
+  DPX_LAUNCH("k_bx_pack_in", k_bx_pack_in, dim3(grid_for((long)(px * 8 * G0), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W, H2, W2, G0);
+  const char* wl = (const char*)packed;
+  const float* cur = a0;
+  int gin = G0;
+  for (int l = 0; l < nb; ++l) {
+    const int cin = bx_cin(l, in_nc, nc), cout = bx_cout(l, in_nc, nc, nb);
+    const bool lastl = l == nb - 1;
+    float* dst = lastl ? last : ((l & 1) ? bufB : bufA);
+    const int gout = lastl ? GL : Gc;
+    if (mode == 1) launch_bx_mt<1>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    else launch_bx_mt<6>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    wl += bx_layer_bytes(cin, cout);
+    cur = dst;
+    gin = gout;
+  }
+  DPX_LAUNCH("k_bx_unpack_out", k_bx_unpack_out, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, last, y, B, in_nc, H, W, H2,
+             W2, GL);
+  return launch_status("dpx_ffdnet_forward_bf16");
+}

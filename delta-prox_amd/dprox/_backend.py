@@ -118,6 +118,10 @@ SIGNATURES = {
     "dpx_ffdnet_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_ffdnet_pack": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dpx_ffdnet_bf16_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dpx_ffdnet_bf16_pack": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_ffdnet_bf16_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dpx_ffdnet_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_conv_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dpx_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -105,6 +105,13 @@ class FFDNet(RefKeyed):
             self.add_ref_param(f"model.{2 * i}.weight", (co, ci, 3, 3))
             self.add_ref_param(f"model.{2 * i}.bias", (co,))
         self._packed = None
+        # arithmetic of the (non-differentiable) forward pass:
+        #   "bf16x3" -- fp32 accuracy on the bf16 matrix cores (weights / activations split into three bf16 terms, six products,
+        #               fp32 accumulation: dpx_conv_bf16.hip), the default wherever the layer widths are multiples of 16;
+        #   "f32"    -- the f32-input matrix instruction (bitwise an fmaf chain); also what the differentiable path uses;
+        #   "bf16"   -- plain bf16 operands, fp32 accumulation (bf16 training / inference mode, ~3e-3 relative).
+        self.compute_mode = os.environ.get("DPX_FFDNET_MODE", "bf16x3" if nc % 16 == 0 else "f32")
+        self._packed_bf16 = None
 
     @property
     def weights(self):
@@ -113,6 +120,25 @@ class FFDNet(RefKeyed):
     @property
     def biases(self):
         return [self.ref_param(f"model.{2 * i}.bias") for i in range(self.nb)]
+
+    def _weights_changed(self):
+        super()._weights_changed()
+        self._packed_bf16 = None
+
+    def packed_bf16(self, mode):
+        """weights pre-split for the bf16 matrix cores (mode 6: three exact bf16 planes; mode 1: one rounded plane)"""
+        dev = self.weights[0].device
+        key = (self._weights_version(), str(dev), mode)
+        if self._packed_bf16 is None or self._packed_bf16[0] != key:
+            L = be.lib()
+            blob = torch.empty(L.query("dpx_ffdnet_bf16_packed_bytes", self.in_nc, self.nc, self.nb), dtype=torch.uint8, device=dev)
+            ws = [w.detach().float().contiguous() for w in self.weights]
+            bs = [b.detach().float().contiguous() for b in self.biases]
+            pw = (ctypes.c_void_p * self.nb)(*[w.data_ptr() for w in ws])
+            pb = (ctypes.c_void_p * self.nb)(*[b.data_ptr() for b in bs])
+            L.call("dpx_ffdnet_bf16_pack", be.ptr(blob), pw, pb, self.in_nc, self.nc, self.nb, mode, be.stream())
+            self._packed_bf16 = (key, blob)
+        return self._packed_bf16[1]
 
     def load_reference_state_dict(self, sd):
         self.load_state_dict(sd, strict=True)
@@ -173,6 +199,12 @@ class FFDNet(RefKeyed):
         sig = ops.as_batch_vec(sigma, B, x.device)
         L = be.lib()
         y = torch.empty_like(x)
+        if self.compute_mode in ("bf16x3", "bf16"):
+            mode = 6 if self.compute_mode == "bf16x3" else 1
+            ws = ops.workspace("ffdnet_bf16", L.query("dpx_ffdnet_bf16_ws_bytes", B, self.in_nc, self.nc, H, W), x.device)
+            L.call("dpx_ffdnet_forward_bf16", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(self.packed_bf16(mode)), self.in_nc, self.nc,
+                   self.nb, mode, B, H, W, be.ptr(ws), be.stream())
+            return y
         ws = ops.workspace("ffdnet", L.query("dpx_ffdnet_ws_bytes", B, self.in_nc, self.nc, H, W), x.device)
         L.call("dpx_ffdnet_forward", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(self.packed()), self.in_nc, self.nc,
                self.nb, B, H, W, be.ptr(ws), be.stream())

@@ -323,6 +323,18 @@ size_t dpx_ffdnet_ws_bytes(int B, int in_nc, int nc, int H, int W);
 int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void* packed,
                        int in_nc, int nc, int nb, int B, int H, int W, void* ws, dpx_stream_t stream);
 
+/* The same network at fp32 accuracy on the bf16 matrix cores (csrc/dpx_conv_bf16.hip): weights and activations are split into
+ * three bf16 terms each (exact: 3 x 8 mantissa bits) and six products of order <= 2 are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16 -- 2.67x the rate of the f32-input matrix instruction at a dropped-term error of 2^-24, the size of one
+ * fp32 rounding.  mode = 6: that split (default inference path); mode = 1: plain bf16 operands, fp32 accumulation (bf16 training
+ * mode).  Activations travel between the layers as fp32 in the channel-group layout [B][C/8][H][W][8].  nc: multiple of 16.   */
+size_t dpx_ffdnet_bf16_packed_bytes(int in_nc, int nc, int nb);
+int dpx_ffdnet_bf16_pack(void* packed, const float* const* w, const float* const* b, int in_nc, int nc, int nb, int mode,
+                         dpx_stream_t stream);
+size_t dpx_ffdnet_bf16_ws_bytes(int B, int in_nc, int nc, int H, int W);
+int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode,
+                            int B, int H, int W, void* ws, dpx_stream_t stream);
+
 /* Generic convolution layers on the same MFMA kernel (residual U-Net denoisers behind deep_prior: DRUNet,
  * dprox/proxfn/pnp/denoisers/models/network_unet.py:67-117, basicblock.py).  NCHW fp32, stride 1.
  *   dpx_conv_pack  : w [cout][cin][taps] (taps = 9: 3x3 pad 1, taps = 1: 1x1), b nullable -> packed blob (dpx_conv_packed_bytes)

@@ -38,6 +38,7 @@ struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return {x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return {x, y}; }
 static inline int2 make_int2(int x, int y) { return {x, y}; }
 
@@ -181,12 +182,41 @@ static inline emul_f32x4 emul_mfma_16x16x4(float a, float b, emul_f32x4 c) {
   ::emul::sync_wave();
   return c;
 }
+// v_mfma_f32_32x32x16_bf16: lane l holds A[m = l % 32][k = 8 (l / 32) .. + 8) and B[k = 8 (l / 32) .. + 8)][n = l % 32] as 8 bf16
+// (4 dwords, element 2i in the low half of dword i); D as for 32x32x2.  Exchanged through the 8-byte wave slots in two rounds.
+static inline float emul_bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline emul_f32x16 emul_mfma_32x32x16_bf16(uint4 a, uint4 b, emul_f32x16 c) {
+  int l = ::emul::lane();
+  int j = l & 31, h = l >> 5;
+  const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  for (int round = 0; round < 2; ++round) {
+    memcpy(::emul::wave_slot(l, 0), &av[2 * round], 8);
+    memcpy(::emul::wave_slot(l, 1), &bv[2 * round], 8);
+    ::emul::sync_wave();
+    for (int r = 0; r < 16; ++r) {
+      int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float acc = c[r];
+      for (int kg = 0; kg < 2; ++kg) {
+        unsigned short ae[4], be[4];
+        memcpy(ae, ::emul::wave_slot(kg * 32 + i, 0), 8);
+        memcpy(be, ::emul::wave_slot(kg * 32 + j, 1), 8);
+        for (int e = 0; e < 4; ++e) acc = fmaf(emul_bf16_to_f32(ae[e]), emul_bf16_to_f32(be[e]), acc);
+      }
+      c[r] = acc;
+    }
+    ::emul::sync_wave();
+  }
+  return c;
+}
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emul_mfma_32x32x2(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emul_mfma_16x16x4(a, b, c)
 
 // ---- atomics (fibers are serial) ------------------------------------------------------------------
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 
 // ---- math ---------------------------------------------------------------------------------------
 static inline void sincospi(double x, double* s, double* c) {
