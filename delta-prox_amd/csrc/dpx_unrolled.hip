@@ -9,9 +9,36 @@
 // History buffer (caller-owned): iteration `it` occupies (2 + 2 n) planes of px = B*C*H*W floats:
 //     [rhs][x][v_0 .. v_{n-1}][u_0 .. u_{n-1}]
 // the backward pass reads rhs, x and v_i of every iteration (u_i only as the forward's running state).
+//
+// bf16 mode (BASELINE config 5 is quoted in bf16): the forward iteration, every transform and every reduction stay fp32 -- the
+// x-update divides by |H|^2 + rho sum|G|^2, which amplifies round-off by up to 1e5, bf16 state would lose
+// the iterate -- but what is KEPT for the backward pass is stored in bf16: per iteration rhs, x and v_i (u_i is not needed),
+// (2 + n) x 2 bytes per pixel instead of (2 + 2n) x 4.  The soft-threshold / clipping masks the backward reads from v_i survive
+// the rounding exactly (v = 0 stays 0); d loss / d rho_t (inner products with x and rhs) carry the bf16 rounding, ~1e-3 relative.
 #include "dpx_common.h"
 
 using namespace dpx;
+
+namespace dpx {
+// (2 + n) fp32 planes <-> one bf16 history slot, round-to-nearest-even
+struct PlanePack {
+  float* p[2 + DPX_MAX_TERMS];
+  int n;
+};
+__global__ void k_hist_pack_bf16(PlanePack P, unsigned short* __restrict__ slot, long px) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < px * P.n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / px);
+    const unsigned u = __float_as_uint(P.p[k][i - k * px]);
+    slot[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+}
+__global__ void k_hist_unpack_bf16(PlanePack P, const unsigned short* __restrict__ slot, long px) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < px * P.n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / px);
+    P.p[k][i - k * px] = __uint_as_float((unsigned)slot[i] << 16);
+  }
+}
+}  // namespace dpx
 
 namespace {
 struct Hist {
@@ -59,6 +86,59 @@ extern "C" int dpx_admm_unrolled_forward(float* hist, const float* const* v0, co
   return DPX_OK;
 }
 
+extern "C" size_t dpx_admm_unrolled_hist_bytes_bf16(int nterms, int T, int B, int C, int H, int W) {
+  return (size_t)T * (2 + nterms) * B * C * H * W * sizeof(unsigned short);
+}
+// fp32 working planes of the bf16-history forward: rhs, x, and two generations of v_i / u_i
+extern "C" size_t dpx_admm_unrolled_work_bytes_bf16(int nterms, int B, int C, int H, int W) {
+  return (size_t)(2 + 4 * nterms) * B * C * H * W * sizeof(float);
+}
+
+// Same iteration as dpx_admm_unrolled_forward in fp32 working planes; after every iteration rhs, x, v_i are rounded into the
+// bf16 history.  The final state is written to x_out, v_out[i], u_out[i] (fp32).
+extern "C" int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float* x_out, float* const* v_out, float* const* u_out,
+                                              const float* const* v0, const float* const* u0, const int* linops, const int* proxes,
+                                              const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
+                                              const void* spec_add, const void* dd, float eps, int B, int C, int H, int W,
+                                              const void* table, void* spectrum_ws, dpx_stream_t stream) {
+  DPX_REQUIRE(hist_bf16 && work && x_out && v_out && u_out && v0 && u0 && linops && proxes && alphas && rho_tab && lam_tabs && dd && table &&
+                  spectrum_ws, "dpx_admm_unrolled_forward_bf16: null pointer");
+  DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && T >= 1 && B > 0 && C > 0 && H > 0 && W > 0, "dpx_admm_unrolled_forward_bf16: bad sizes");
+  const int n = nterms;
+  const size_t px = (size_t)B * C * H * W;
+  float* w = (float*)work;
+  float* rhs_w = w;
+  float* x_w = w + px;
+  auto vw = [&](int gen, int i) { return w + (size_t)(2 + gen * 2 * n + i) * px; };
+  auto uw = [&](int gen, int i) { return w + (size_t)(2 + gen * 2 * n + n + i) * px; };
+  unsigned short* hist = (unsigned short*)hist_bf16;
+  for (int it = 0; it < T; ++it) {
+    const bool last = it == T - 1;
+    dpx_term rt[DPX_MAX_TERMS], zt[DPX_MAX_TERMS];
+    float* xo = last ? x_out : x_w;
+    PlanePack P;
+    P.n = 2 + n;
+    P.p[0] = rhs_w;
+    P.p[1] = xo;
+    for (int i = 0; i < n; ++i) {
+      float* pv = it ? vw((it - 1) & 1, i) : (float*)v0[i];
+      float* pu = it ? uw((it - 1) & 1, i) : (float*)u0[i];
+      float* nv = last ? v_out[i] : vw(it & 1, i);
+      float* nu = last ? u_out[i] : uw(it & 1, i);
+      rt[i] = dpx_term{linops[i], proxes[i], 1.0f, 0, nullptr, pv, pu, nullptr};
+      zt[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, nv, pu, nu};
+      P.p[2 + i] = nv;
+    }
+    const float* rho = rho_tab + (size_t)it * B;
+    DPX_TRY(dpx_admm_rhs(rhs_w, nullptr, rho, rt, n, B, C, H, W, stream));
+    DPX_TRY(dpx_fourier_solve(rhs_w, xo, spec_add, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
+    DPX_TRY(dpx_admm_zupdate(xo, zt, n, B, C, H, W, stream));
+    DPX_LAUNCH("k_hist_pack_bf16", k_hist_pack_bf16, dim3(grid_for((long)(px * (2 + n)), 256, 8192)), dim3(256), 0, (hipStream_t)stream, P,
+               hist + (size_t)it * (2 + n) * px, (long)px);
+  }
+  return launch_status("dpx_admm_unrolled_forward_bf16");
+}
+
 // workspace: (4 + 6 n) planes + 2 B floats, followed by dpx_admm_bwd_ws_bytes
 extern "C" size_t dpx_admm_unrolled_bwd_ws_bytes(int nterms, int B, int C, int H, int W) {
   return ((size_t)(4 + 6 * nterms) * B * C * H * W + 2 * (size_t)B + 64) * sizeof(float) + dpx_admm_bwd_ws_bytes(B, C, H, W);
@@ -68,18 +148,22 @@ extern "C" size_t dpx_admm_unrolled_bwd_ws_bytes(int nterms, int B, int C, int H
 // Out: gv0[i], gu0[i] (w.r.t. the initial split / dual variables), grho [T][B], glam [T][n][B], goff[k] (w.r.t. the k-th
 // Omega offset: K g_rhs summed over the iterations; off_otf[k] = that term's OTF table or NULL for the identity; goff[k]
 // NULL = not wanted).
-extern "C" int dpx_admm_unrolled_backward(const float* hist, const float* gx, const float* const* gv_in, const float* const* gu_in,
+static int unrolled_backward_impl(const float* hist, const unsigned short* hist16, float* stage, const float* gx, const float* const* gv_in, const float* const* gu_in,
                                           float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
                                           const void* const* off_otf, int n_off, const int* linops, const int* proxes, const float* alphas,
                                           int nterms, const float* rho_tab, const float* const* lam_tabs, int T, const void* dd, float eps,
                                           int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream) {
-  DPX_REQUIRE(hist && gv0 && gu0 && grho && glam && linops && proxes && alphas && rho_tab && lam_tabs && dd && table && spectrum_ws && ws,
-              "dpx_admm_unrolled_backward: null pointer");
+  DPX_REQUIRE((hist || (hist16 && stage)) && gv0 && gu0 && grho && glam && linops && proxes && alphas && rho_tab && lam_tabs && dd && table &&
+                  spectrum_ws && ws, "dpx_admm_unrolled_backward: null pointer");
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && T >= 1 && B > 0 && n_off >= 0 && (n_off == 0 || (goff && off_otf)),
               "dpx_admm_unrolled_backward: bad sizes");
   const int n = nterms;
   const size_t px = (size_t)B * C * H * W;
-  const Hist h{(float*)hist, px, n};
+  // fp32 history: pointers into it; bf16 history: iteration `it` is expanded into the (2 + n) staging planes first
+  const Hist h32{(float*)hist, px, n};
+  auto H_rhs = [&](int it) { return hist ? h32.rhs(it) : stage; };
+  auto H_x = [&](int it) { return hist ? h32.x(it) : stage + px; };
+  auto H_v = [&](int it, int i) { return hist ? h32.v(it, i) : stage + (size_t)(2 + i) * px; };
   float* w = (float*)ws;
   float* gxz = w;
   float* gtot = w + px;
@@ -102,9 +186,16 @@ extern "C" int dpx_admm_unrolled_backward(const float* hist, const float* gx, co
   DPX_REQUIRE(n_off <= DPX_MAX_TERMS, "dpx_admm_unrolled_backward: at most %d offsets", DPX_MAX_TERMS);
   for (int it = T - 1; it >= 0; --it) {
     const float* rho = rho_tab + (size_t)it * B;
+    if (!hist) {
+      PlanePack P;
+      P.n = 2 + n;
+      for (int k = 0; k < 2 + n; ++k) P.p[k] = stage + (size_t)k * px;
+      DPX_LAUNCH("k_hist_unpack_bf16", k_hist_unpack_bf16, dim3(grid_for((long)(px * (2 + n)), 256, 8192)), dim3(256), 0, (hipStream_t)stream, P,
+                 hist16 + (size_t)it * (2 + n) * px, (long)px);
+    }
     dpx_bwd_term bt[DPX_MAX_TERMS];
     for (int i = 0; i < n; ++i)
-      bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, h.v(it, i), cur_gv[i], cur_gu[i], gu_a + i * px};
+      bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, H_v(it, i), cur_gv[i], cur_gu[i], gu_a + i * px};
     DPX_TRY(dpx_admm_zupdate_bwd(gxz, bt, n, glam + (size_t)it * n * B, B, C, H, W, bws, stream));
     const float* g = gxz;
     if (it == T - 1 && gx) {
@@ -113,7 +204,7 @@ extern "C" int dpx_admm_unrolled_backward(const float* hist, const float* gx, co
       g = gtot;
     }
     DPX_TRY(dpx_fourier_apply_inv(g, grhs, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
-    DPX_TRY(dpx_admm_solve_rho_grad(grhs, h.x(it), linops, n, rho_a, B, C, H, W, bws, stream));
+    DPX_TRY(dpx_admm_solve_rho_grad(grhs, H_x(it), linops, n, rho_a, B, C, H, W, bws, stream));
     for (int k = 0; k < n_off; ++k) {
       if (!goff[k]) continue;
       if (off_otf[k]) {
@@ -138,7 +229,7 @@ extern "C" int dpx_admm_unrolled_backward(const float* hist, const float* gx, co
       nu[i] = it ? set[it & 1] + (size_t)(n + i) * px : gu0[i];
       gub[i] = gu_b + (size_t)i * px;
     }
-    DPX_TRY(dpx_admm_rhs_bwd(grhs, h.rhs(it), rho, linops, n, nv, gub, rho_b, B, C, H, W, bws, stream));
+    DPX_TRY(dpx_admm_rhs_bwd(grhs, H_rhs(it), rho, linops, n, nv, gub, rho_b, B, C, H, W, bws, stream));
     {
       const float* xs[2] = {rho_a, rho_b};
       DPX_TRY(dpx_lincomb(grho + (size_t)it * B, 2, xs, one2, nullptr, 1, (long)B, stream));
@@ -151,4 +242,30 @@ extern "C" int dpx_admm_unrolled_backward(const float* hist, const float* gx, co
     }
   }
   return DPX_OK;
+}
+
+extern "C" int dpx_admm_unrolled_backward(const float* hist, const float* gx, const float* const* gv_in, const float* const* gu_in,
+                                          float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
+                                          const void* const* off_otf, int n_off, const int* linops, const int* proxes, const float* alphas,
+                                          int nterms, const float* rho_tab, const float* const* lam_tabs, int T, const void* dd, float eps,
+                                          int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(hist, "dpx_admm_unrolled_backward: null history");
+  return unrolled_backward_impl(hist, nullptr, nullptr, gx, gv_in, gu_in, gv0, gu0, grho, glam, goff, off_otf, n_off, linops, proxes, alphas, nterms,
+                                rho_tab, lam_tabs, T, dd, eps, B, C, H, W, table, spectrum_ws, ws, stream);
+}
+
+// bf16 history: `ws` = dpx_admm_unrolled_bwd_ws_bytes + (2 + n) fp32 planes (dpx_admm_unrolled_bwd_ws_bytes_bf16)
+extern "C" size_t dpx_admm_unrolled_bwd_ws_bytes_bf16(int nterms, int B, int C, int H, int W) {
+  return dpx_admm_unrolled_bwd_ws_bytes(nterms, B, C, H, W) + (size_t)(2 + nterms) * B * C * H * W * sizeof(float);
+}
+extern "C" int dpx_admm_unrolled_backward_bf16(const void* hist_bf16, const float* gx, const float* const* gv_in, const float* const* gu_in,
+                                               float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
+                                               const void* const* off_otf, int n_off, const int* linops, const int* proxes,
+                                               const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
+                                               const void* dd, float eps, int B, int C, int H, int W, const void* table, void* spectrum_ws,
+                                               void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(hist_bf16 && ws, "dpx_admm_unrolled_backward_bf16: null pointer");
+  float* stage = (float*)((char*)ws + dpx_admm_unrolled_bwd_ws_bytes(nterms, B, C, H, W));
+  return unrolled_backward_impl(nullptr, (const unsigned short*)hist_bf16, stage, gx, gv_in, gu_in, gv0, gu0, grho, glam, goff, off_otf, n_off, linops,
+                                proxes, alphas, nterms, rho_tab, lam_tabs, T, dd, eps, B, C, H, W, table, spectrum_ws, ws, stream);
 }

@@ -152,8 +152,9 @@ def needs_grad(x0, rhos, lams, offsets, state_tensors=()):
 class DiffPlan:
     """what the three Functions need from a recognised problem (built by FusedADMM.run_differentiable)"""
 
-    def __init__(self, codes, psi, diag, FK, omega_otfs, eps):
+    def __init__(self, codes, psi, diag, FK, omega_otfs, eps, hist_bf16=False):
         self.codes, self.psi, self.diag, self.FK, self.omega_otfs, self.eps = codes, psi, diag, FK, omega_otfs, eps
+        self.hist_bf16 = hist_bf16        # keep the backward pass's history (rhs, x, v_i per iteration) in bf16
 
 
 def _sched_table(vals, T, B, dev):
@@ -199,10 +200,24 @@ class _UnrolledClosed(torch.autograd.Function):
         rho_tab = rho_tab.contiguous()
         lam_tabs = [t.contiguous() for t in lam_tabs]
         lin, prx, alp, dd, table, sws = _UnrolledClosed._common(plan, dev, shape)
-        hist = torch.empty((T, 2 + 2 * n) + shape, dtype=torch.float32, device=dev)
         vp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in v])
         up = (ctypes.c_void_p * n)(*[t.data_ptr() for t in u])
         lp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lam_tabs])
+        if plan.hist_bf16:
+            L = be.lib()
+            hist = torch.empty((T, 2 + n) + shape, dtype=torch.bfloat16, device=dev)
+            work = ops.workspace("unrolled_work", L.query("dpx_admm_unrolled_work_bytes_bf16", n, B, C, H, W), dev)
+            x_out = torch.empty(shape, dtype=torch.float32, device=dev)
+            v_out = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(n)]
+            u_out = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(n)]
+            L.call("dpx_admm_unrolled_forward_bf16", be.ptr(hist), be.ptr(work), be.ptr(x_out), (ctypes.c_void_p * n)(*[t.data_ptr() for t in v_out]),
+                   (ctypes.c_void_p * n)(*[t.data_ptr() for t in u_out]), vp, up, lin, prx, alp, n, be.ptr(rho_tab), lp, T, be.ptr(plan.FK), be.ptr(dd),
+                   ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.stream())
+            ctx.plan, ctx.T, ctx.n_off, ctx.shape = plan, T, len(offs), shape
+            ctx.save_for_backward(rho_tab, *lam_tabs)
+            ctx.hist = hist
+            return (x_out, *v_out, *u_out)
+        hist = torch.empty((T, 2 + 2 * n) + shape, dtype=torch.float32, device=dev)
         be.lib().call("dpx_admm_unrolled_forward", be.ptr(hist), vp, up, lin, prx, alp, n, be.ptr(rho_tab), lp, T, be.ptr(plan.FK), be.ptr(dd),
                       ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.stream())
         ctx.plan, ctx.T, ctx.n_off, ctx.shape = plan, T, len(offs), shape
@@ -235,8 +250,9 @@ class _UnrolledClosed(torch.autograd.Function):
         otf = (ctypes.c_void_p * max(n_off, 1))(*[None if o is None else o.data_ptr() for o in plan.omega_otfs[:n_off]])
         lp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lam_tabs])
         L = be.lib()
-        ws = ops.workspace("unrolled_bwd", L.query("dpx_admm_unrolled_bwd_ws_bytes", n, B, C, H, W), dev)
-        L.call("dpx_admm_unrolled_backward", be.ptr(hist), be.ptr(gxp), gvi, gui, (ctypes.c_void_p * n)(*[t.data_ptr() for t in gv0]),
+        bf16 = hist.dtype == torch.bfloat16
+        ws = ops.workspace("unrolled_bwd", L.query("dpx_admm_unrolled_bwd_ws_bytes_bf16" if bf16 else "dpx_admm_unrolled_bwd_ws_bytes", n, B, C, H, W), dev)
+        L.call("dpx_admm_unrolled_backward_bf16" if bf16 else "dpx_admm_unrolled_backward", be.ptr(hist), be.ptr(gxp), gvi, gui, (ctypes.c_void_p * n)(*[t.data_ptr() for t in gv0]),
                (ctypes.c_void_p * n)(*[t.data_ptr() for t in gu0]), be.ptr(g_rho), be.ptr(g_lam), gop, otf, n_off, lin, prx, alp, n,
                be.ptr(rho_tab), lp, T, be.ptr(dd), ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.ptr(ws), be.stream())
         return (None, None, g_rho, *[g_lam[:, i] for i in range(n)], *gv0, *gu0, *g_off)

@@ -277,7 +277,7 @@ class FusedADMM:
             for fn in s.omega_fns:
                 cv = _omega_conv(fn)
                 otfs.append(cv._tables(x0.shape, dev) if cv is not None else None)
-            plan = autodiff.DiffPlan(self.codes, psi, (t0, c0, t1, c1), FK, otfs, ls_eps(ls))
+            plan = autodiff.DiffPlan(self.codes, psi, (t0, c0, t1, c1), FK, otfs, ls_eps(ls), hist_bf16=getattr(s, "unroll_dtype", "f32") == "bf16")
             diff_offs = [o if o is not None else torch.zeros((), device=dev) for o in raw_offs]
             x, v, u = autodiff.run(plan, (x0, v, u), rhos, {fn: lams[fn] for fn in psi}, T, diff_offs)
             s.Kall.update_vars([x.detach()])

@@ -286,6 +286,23 @@ int dpx_admm_unrolled_backward(const float* hist, const float* gx, const float* 
                                const void* const* off_otf, int n_off, const int* linops, const int* proxes, const float* alphas,
                                int nterms, const float* rho_tab, const float* const* lam_tabs, int T, const void* dd, float eps,
                                int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream);
+/* bf16 mode of the same training step (BASELINE config 5; specialize(..., method='unroll', dtype='bf16')): the iteration runs in
+ * fp32 working planes (`work`, dpx_admm_unrolled_work_bytes_bf16) and what the backward pass needs -- rhs, x, v_i of every
+ * iteration -- is kept in a bf16 history, (2 + n) x 2 bytes per pixel and iteration instead of (2 + 2n) x 4.  The final state goes
+ * to x_out / v_out[i] / u_out[i] (fp32).  Backward: as above with ws sized by dpx_admm_unrolled_bwd_ws_bytes_bf16.            */
+size_t dpx_admm_unrolled_hist_bytes_bf16(int nterms, int T, int B, int C, int H, int W);
+size_t dpx_admm_unrolled_work_bytes_bf16(int nterms, int B, int C, int H, int W);
+int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float* x_out, float* const* v_out, float* const* u_out,
+                                   const float* const* v0, const float* const* u0, const int* linops, const int* proxes,
+                                   const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
+                                   const void* spec_add, const void* dd, float eps, int B, int C, int H, int W, const void* table,
+                                   void* spectrum_ws, dpx_stream_t stream);
+size_t dpx_admm_unrolled_bwd_ws_bytes_bf16(int nterms, int B, int C, int H, int W);
+int dpx_admm_unrolled_backward_bf16(const void* hist_bf16, const float* gx, const float* const* gv_in, const float* const* gu_in,
+                                    float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
+                                    const void* const* off_otf, int n_off, const int* linops, const int* proxes, const float* alphas,
+                                    int nterms, const float* rho_tab, const float* const* lam_tabs, int T, const void* dd, float eps,
+                                    int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* two-kernel fused ADMM iteration (power-of-two planes)                                       */

@@ -360,6 +360,32 @@ def case_unrolled_grads(device):
             assert_close(got.detach().cpu(), g[f"{tag}_{name}"], 1e-4, f"{tag} {name}")
 
 
+def case_unrolled_grads_bf16(device, fixture="g11_unrolled_grads", K=3):
+    """bf16 mode of the unrolled training step (BASELINE config 5): specialize(..., method='unroll', dtype='bf16').  The iteration
+    itself is fp32 (forward and loss within 1e-5 of the reference); the backward pass reads a bf16 history.  Stated tolerances
+    against the reference's fp32 autograd: d/d lambda_t and d/d b 1e-4 (threshold masks survive the rounding), d/d rho_t 1e-2
+    (inner products with bf16-rounded x / rhs; measured ~1e-3)."""
+    g = load_golden(fixture)
+    gt = T(g["gt"], device)
+    x = dp.Variable()
+    bt = T(g["b"], device).clone().requires_grad_(True)
+    n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+    solver = dp.compile(dp.sum_squares(dp.conv(x, g["psf"]) - bt) + n0 + n1, method="admm", device=device)
+    solver = dp.specialize(solver, method="unroll", device=device, max_iter=K, dtype="bf16")
+    rhos = torch.tensor(g["rhos"], requires_grad=True)
+    l0, l1 = torch.tensor(g["l0"], requires_grad=True), torch.tensor(g["l1"], requires_grad=True)
+    xo = solver.solve(x0=T(g["b"], device), rhos=rhos, lams={n0: l0, n1: l1})
+    loss = ((xo - gt) ** 2).mean()
+    loss.backward()
+    assert_close(xo.detach().cpu(), g["tv_x"], TOL, "bf16-history unrolled x (fp32 iteration)")
+    assert abs(float(loss.detach()) - float(g["tv_loss"])) <= 1e-5 * abs(float(g["tv_loss"]))
+    assert_close(l0.grad.cpu(), g["tv_g_l0"], 1e-4, "bf16 mode d loss / d lam0")
+    assert_close(l1.grad.cpu(), g["tv_g_l1"], 1e-4, "bf16 mode d loss / d lam1")
+    assert_close(bt.grad.cpu(), g["tv_g_b"], 1e-4, "bf16 mode d loss / d b")
+    assert_close(rhos.grad.cpu(), g["tv_g_rhos"], 1e-2, "bf16 mode d loss / d rho (bf16 history)")
+    assert rel_l2(rhos.grad.cpu().numpy(), g["tv_g_rhos"]) > 1e-6, "the history should really be bf16"
+
+
 def case_unrolled_solver(device):
     """G11 (second half): UnrolledSolver with one solver clone per step and learned rho / lambda parameters
     (specialization/unroll.py:21-58)"""
@@ -871,7 +897,7 @@ def case_full_c4(device):
         _check_packed(g, f"u{i}", st[2][i], 4, TOL, scale_key="x", what="c4 ")
 
 
-def case_full_c5(device):
+def case_full_c5(device, dtype="f32"):
     """G33 -- config 5 at its real size (4 x 3 x 512 x 512, ADMM unrolled 10 times, MSE loss): forward, loss and the gradients
     w.r.t. the rho / lambda schedules and the observation against the reference's autograd."""
     import synthetic
@@ -882,12 +908,25 @@ def case_full_c5(device):
     bt = T(b, device).clone().requires_grad_(True)
     n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
     solver = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + n0 + n1, method="admm", device=device)
-    solver = dp.specialize(solver, method="unroll", device=device, max_iter=K)
+    solver = dp.specialize(solver, method="unroll", device=device, max_iter=K, dtype=dtype)
     rhos, l0, l1 = (torch.tensor(g[k], requires_grad=True) for k in ("rhos", "l0", "l1"))
     xo = solver.solve(x0=T(b, device), rhos=rhos, lams={n0: l0, n1: l1})
     loss = ((xo - T(gt, device)) ** 2).mean()
     loss.backward()
     _check_packed(g, "x", xo, 8, TOL, what="c5 ")
+    if dtype == "bf16":
+        # bf16 history (the BASELINE's dtype for this config): fp32 forward as above; stated gradient tolerances vs the reference's
+        # fp32 autograd: lambda schedules 1e-3 (masks survive the rounding; the sums still see bf16 x through the rho-coupling),
+        # rho schedule 2e-2, observation gradient as in fp32 (decision flips dominate)
+        for name, got, tol in (("g_rhos", rhos.grad, 2e-2), ("g_l0", l0.grad, 1e-3), ("g_l1", l1.grad, 1e-3)):
+            r = rel_l2(got.detach().cpu().numpy(), g[name])
+            record(f"c5 bf16-history {name} vs the reference's fp32 autograd", r, tol)
+            assert r <= tol, (name, r)
+        gb = bt.grad[..., ::8, ::8].cpu().numpy()
+        r_64, ref_64 = rel_l2(gb, g["g_b_f64"]), rel_l2(g["g_b"], g["g_b_f64"])
+        record(f"c5 bf16-history g_b samples vs the float64 gradient (reference's own distance: {ref_64:.2e})", r_64, 1.5 * ref_64)
+        assert r_64 <= 1.5 * ref_64 + 1e-5
+        return
     lv, lr = float(loss.detach().double()), float(g["loss"])
     record("c5 loss", abs(lv - lr) / abs(lr), 1e-5)
     assert abs(lv - lr) <= 1e-5 * abs(lr), (lv, lr)

@@ -95,6 +95,10 @@ def test_unrolled_gradients():
     pc.case_unrolled_grads(DEV)
 
 
+def test_unrolled_gradients_bf16_history():
+    pc.case_unrolled_grads_bf16(DEV)
+
+
 def test_unrolled_solver_learned_params():
     pc.case_unrolled_solver(DEV)
 

@@ -124,6 +124,10 @@ def test_unrolled_gradients():
     pc.case_unrolled_grads(DEV)
 
 
+def test_unrolled_gradients_bf16_history():
+    pc.case_unrolled_grads_bf16(DEV)
+
+
 def test_unrolled_solver_learned_params():
     pc.case_unrolled_solver(DEV)
 
@@ -157,8 +161,9 @@ def test_full_size_config4_shard_ladmm_cg():
     pc.case_full_c4(DEV)
 
 
-def test_full_size_config5_unrolled_grads():
-    pc.case_full_c5(DEV)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_size_config5_unrolled_grads(dtype):
+    pc.case_full_c5(DEV, dtype)
 
 
 def test_cpu_device_is_refused():
