@@ -606,6 +606,16 @@ static int terms_ok(const dpx_term* terms, int nterms) {
   return nh <= 1;
 }
 
+// run-time overrides of the row-kernel choice (tests / tuning): rows_mode 0 = automatic, 1 = streaming kernel, 2 = lock-step
+// ring-buffer kernel; bands_per_plane 0 = automatic.  The environment variables DPX_ITER_ROWS / DPX_ITER_BAND set the defaults.
+static int g_rows_mode = -1, g_rows_band = -1;
+extern "C" int dpx_admm_iter_config(int rows_mode, int bands_per_plane) {
+  DPX_REQUIRE(rows_mode >= 0 && rows_mode <= 2 && bands_per_plane >= 0, "dpx_admm_iter_config: bad arguments");
+  g_rows_mode = rows_mode;
+  g_rows_band = bands_per_plane;
+  return DPX_OK;
+}
+
 extern "C" int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms) {
   return pow2_path_available(H, W) && H % 16 == 0 && terms_ok(terms, nterms);
 }
@@ -648,8 +658,10 @@ extern "C" int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx
   float2* sout = (float2*)spec_out;
   // Streaming kernel (one T-lane group per band): bands as long as possible while still >= ~2 waves per SIMD-pair
   // of the chip; DPX_ITER_ROWS=lockstep keeps the ring-buffer kernel (A/B timing), DPX_ITER_BAND overrides the number of bands per plane.
-  static const char* mode = getenv("DPX_ITER_ROWS");
-  static const int band_env = getenv("DPX_ITER_BAND") ? atoi(getenv("DPX_ITER_BAND")) : 0;
+  static const char* mode_env = getenv("DPX_ITER_ROWS");
+  static const int band_env0 = getenv("DPX_ITER_BAND") ? atoi(getenv("DPX_ITER_BAND")) : 0;
+  const char* mode = g_rows_mode > 0 ? (g_rows_mode == 1 ? "seq" : "lockstep") : (g_rows_mode == 0 ? nullptr : mode_env);
+  const int band_env = g_rows_band >= 0 ? g_rows_band : band_env0;
   // (small launches -- a few 256-wide planes -- are latency-bound: the ring-buffer kernel's row-parallel bands finish ~10 %
   //  sooner there than the streaming kernel's sequential ones; measured crossover between 256- and 512-wide planes)
   const bool tiny = W <= 256 && (long)P * H <= 4096 && !(mode && !strcmp(mode, "seq"));

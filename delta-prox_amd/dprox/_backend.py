@@ -99,6 +99,7 @@ SIGNATURES = {
     "dpx_admm_solve_rho_grad": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_rhs_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int), c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_iter_config": (c_int, [c_int, c_int]),
     "dpx_admm_iter_supported": (c_int, [c_int, c_int, POINTER(Term), c_int]),
     "dpx_rfft_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_iter_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

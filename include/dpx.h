@@ -323,6 +323,8 @@ int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* term
 /* the hot loop of Algorithm.iters (algo/base.py:149-156) for n_iters iterations, entirely on the C side:
  * rho_tab [total_iters][B], lam_tabs[i] [total_iters][B]; returns 0/1 = which of terms[i].u / u_out holds the
  * current u_i afterwards (<0 = error); x / v_i are written by the call's final iteration when emit_last is set. */
+/* test / tuning hook: rows_mode 0 automatic, 1 streaming row kernel, 2 lock-step row kernel; bands_per_plane 0 = automatic */
+int dpx_admm_iter_config(int rows_mode, int bands_per_plane);
 int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, const void* dd, const dpx_term* terms, int nterms,
                  const float* rho_tab, const float* const* lam_tabs, float eps, int it0, int n_iters, int total_iters,
                  float* x_out, int emit_last, int B, int C, int H, int W, const void* table, dpx_stream_t stream);

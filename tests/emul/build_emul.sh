@@ -12,7 +12,7 @@ OBJS=""
 for s in $SRCS "$HERE/emul.cpp"; do
   o="$HERE/obj_$(basename "$s").o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ -n "$(find "$ROOT"/delta-prox_amd/csrc/*.h "$ROOT"/include/*.h "$HERE"/hip/hip_runtime.h -newer "$o" 2>/dev/null)" ]; then
-    $CXX -x c++ -std=c++17 -O2 -g -fPIC -Wno-unused-value -I "$HERE" -c "$s" -o "$o" &
+    $CXX -x c++ -std=c++17 -O2 -g -fPIC -Wno-unused-value -Wno-psabi -I "$HERE" -c "$s" -o "$o" &
   fi
   OBJS="$OBJS $o"
 done

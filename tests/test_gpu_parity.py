@@ -328,3 +328,77 @@ def test_reordered_algorithms_fused_vs_op_by_op(method, shape):
     for a, c in zip(flat(outs[0]), flat(outs[1])):
         assert pc.rel_l2(a.cpu(), c.cpu()) <= 2e-5 or float((a - c).abs().max()) <= 2e-5 * float(outs[1][0].abs().max())
 
+
+
+@pytest.mark.parametrize("W", [256, 512, 1024])
+def test_streaming_row_kernel_wait_counts_stress(W):
+    """Hardware-only (the host emulator replaces LDS-DMA by memcpy and s_waitcnt by a wave barrier): the streaming row kernel's
+    hand-counted vmcnt waits under many band partitions and term sets, at T = 16 / 32 / 64 lanes per row.  A row's arithmetic
+    does not depend on how the plane is cut into bands, so every band count must give BIT-identical state (a wait that returned
+    early would read a stale or half-landed row in some partition); the lock-step ring-buffer kernel (no LDS-DMA, barriers
+    instead of wait counts) is the independent reference at fp32 round-off (1e-6: the two kernels order a few additions
+    differently and the compiler contracts different multiply-adds)."""
+    import ctypes
+    import dprox as dp
+    import synthetic
+    from dprox import _backend as be
+    L = be.lib()
+    rng = np.random.RandomState(W)
+    T_lanes = W // 16
+    per_block = 4 * (64 // T_lanes)
+
+    def timing_names():
+        buf = ctypes.create_string_buffer(1 << 16)
+        L.call("dpx_timing_report", buf, len(buf))
+        return {ln.split()[0] for ln in buf.value.decode().splitlines() if ln.split()}
+
+    try:
+        for trial in range(4):
+            B, C = int(rng.randint(1, 5)), int(rng.choice([1, 2, 3]))
+            H = int(rng.choice([256, 512]))
+            terms = ["h", "hw", "hw+nn", "hw+nn+l1", "w+l1", "h+nn"][int(rng.randint(0, 6))]
+            gt, b, psf = synthetic.deconv_case(B, C, H, W, seed=100 * W + trial)
+            bt = torch.from_numpy(b).to(DEV)
+            P = B * C
+            cands = [nb for nb in range(1, H // 4 + 1) if (P * nb) % per_block == 0]
+            picks = sorted(set(int(c) for c in rng.choice(cands, size=min(4, len(cands)), replace=False)) | {cands[0], cands[-1]})
+
+            def run(rows_mode, bands):
+                L.call("dpx_admm_iter_config", rows_mode, bands)
+                x = dp.Variable()
+                fns = dp.sum_squares(dp.conv(x, psf) - bt)
+                if "h" in terms.split("+")[0]:
+                    fns = fns + dp.norm1(dp.grad(x, dim=0))
+                if "w" in terms.split("+")[0]:
+                    fns = fns + dp.norm1(dp.grad(x, dim=1))
+                if "nn" in terms:
+                    fns = fns + dp.nonneg(x)
+                if "l1" in terms:
+                    fns = fns + dp.norm1(x) * 0.5
+                s = dp.compile(fns, method="admm", device=DEV)
+                rhos = torch.linspace(0.4, 0.2, 4).repeat(B, 1) * torch.linspace(1.0, 1.5, B).view(B, 1)
+                L.call("dpx_timing_enable", 1)
+                timing_names()
+                st = s.solve(x0=bt, rhos=rhos, lams=0.01, max_iter=4, return_full_states=True)
+                torch.cuda.synchronize()
+                names = timing_names()
+                L.call("dpx_timing_enable", 0)
+                assert s.last_path == "fused"
+                return [st[0]] + list(st[1]) + list(st[2]), names
+
+            base, names = run(1, picks[0])
+            assert "k_iter_rows_seq" in names, (names, picks[0])
+            for nb in picks[1:]:
+                other, names = run(1, nb)
+                assert "k_iter_rows_seq" in names
+                for a, c in zip(base, other):
+                    assert torch.equal(a, c), (W, H, B, C, terms, picks[0], nb)
+            lock, names = run(2, 0)
+            assert "k_iter_rows" in names and "k_iter_rows_seq" not in names
+            # (a single gradient term leaves a line of ~eps denominators in the x-update: round-off differences between two correct
+            #  kernels are amplified there, see DESIGN.md section 4)
+            tol = 2e-4 if terms in ("h", "w") else 1e-5
+            for a, c in zip(base, lock):
+                assert float((a - c).abs().max()) <= tol * max(float(c.abs().max()), 1.0), (W, H, B, C, terms, float((a - c).abs().max()))
+    finally:
+        L.call("dpx_admm_iter_config", 0, 0)
