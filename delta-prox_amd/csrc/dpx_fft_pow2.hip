@@ -124,7 +124,7 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
 #define DPX_COLS_ADD_NT 1       // the data spectrum is re-read once per iteration, ~1 GB of other traffic later: stream it (see dpx_iter.hip)
 #endif
 #ifndef DPX_COLS_ST
-#define DPX_COLS_ST 0
+#define DPX_COLS_ST 1           // write-through, as for the row kernel's spectrum
 #endif
 #ifndef DPX_COLS_TBL_NT
 #define DPX_COLS_TBL_NT 0
@@ -251,6 +251,9 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
     fft_reg<H, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
   }
   __builtin_amdgcn_sched_barrier(0);
+#ifdef DPX_COLS_PRIO
+  __builtin_amdgcn_s_setprio(DPX_COLS_PRIO);          // experiment: workgroups past their forward transform go first
+#endif
   if constexpr (OP == OP_SOLVE) {
     unsigned offa = off0;
     DPX_OPAQUE(offa);

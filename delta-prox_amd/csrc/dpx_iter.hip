@@ -305,7 +305,7 @@ static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& T
 #define DPX_R_STU 2
 #endif
 #ifndef DPX_R_STX
-#define DPX_R_STX 0
+#define DPX_R_STX 1       // the spectrum handed to the next kernel: write-through (`sc1`), nothing left dirty at the kernel boundary (+0.5 ... 1 %)
 #endif
 constexpr int R_LDX = DPX_R_LDX, R_LDU = DPX_R_LDU, R_STU = DPX_R_STU, R_STX = DPX_R_STX;
 template <int M, int T, int NT>
@@ -670,6 +670,14 @@ extern "C" int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx
     // CU), rounded so that the groups fill whole workgroups; bands are >= 4 rows (halo = 2 extra inverse transforms)
     const int T = W / 16, G = 64 / T, per_block = 4 * G;
     int nb = (256 * 2 * 4 * G) / P;
+    // ... rounded UP to a power of two (H is one): bands of equal length keep the waves of a workgroup in step, and ~1.5 rounds
+    // of resident groups beat one round of unequal bands (8x3x1024^2: 128 bands of 8 rows 106 us, 85 bands of 12-13 rows 109 us,
+    // 96 / 102 / 136 bands 127-133 us)
+    {
+      int p2 = 1;
+      while (p2 < nb) p2 <<= 1;
+      nb = p2;
+    }
     if (band_env) nb = band_env;
     if (nb > H / 4) nb = H / 4;
     while (nb > 1 && (P * nb) % per_block) --nb;
