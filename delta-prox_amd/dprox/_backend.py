@@ -99,6 +99,8 @@ SIGNATURES = {
     "dpx_admm_solve_rho_grad": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_rhs_bwd": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int), c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p,
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_split_rhs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_pc_dual": (c_int, [c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_iter_config": (c_int, [c_int, c_int]),
     "dpx_admm_iter_supported": (c_int, [c_int, c_int, POINTER(Term), c_int]),
     "dpx_rfft_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -418,6 +418,18 @@ def admm_rhs(rhs, ktb, rho, term_arr, nterms):
     return rhs
 
 
+def split_rhs(rhs, ktb, x, rho, term_arr, nterms, mode):
+    """rhs = ktb + rho sum_i K_i^T (x - K_i^T q_i): mode 0 Pock-Chambolle (q = z), 1 linearised ADMM (q = K x - v + u)"""
+    B, C, H, W = _shape4(rhs)
+    be.lib().call("dpx_split_rhs", ptr(rhs), ptr(ktb), ptr(x), ptr(rho), term_arr, nterms, int(mode), B, C, H, W, be.stream())
+    return rhs
+
+
+def pc_dual(xbar, term_arr, nterms):
+    B, C, H, W = _shape4(xbar)
+    be.lib().call("dpx_pc_dual", ptr(xbar), term_arr, nterms, B, C, H, W, be.stream())
+
+
 def admm_zupdate(x, term_arr, nterms):
     B, C, H, W = _shape4(x)
     be.lib().call("dpx_admm_zupdate", ptr(x), term_arr, nterms, B, C, H, W, be.stream())

@@ -252,22 +252,7 @@ class FusedADMM:
             lam_tab.append(_sigma_table(fn, lt) if isinstance(fn, deep_prior) else lt)     # deep priors: the table holds sigma
         # data spectrum F(sum_Omega K^T b): fp64 transform, kept in the Fourier domain, recomputed only when an
         # offset (the observation b) changes
-        offs = [fn.offset for fn in s.omega_fns]
-        fk_key = (tuple(x0.shape), str(dev)) + tuple((id(o), o._version) if o is not None else None for o in offs) + \
-            tuple(fn.linop.tables_version() for fn in s.omega_fns)
-        cached = getattr(s, "_fk_cache", None)
-        if cached is not None and cached[0] == fk_key:
-            FK = cached[1]
-        else:
-            FK = None
-            for fn, off in zip(s.omega_fns, offs):
-                if off is None:
-                    continue
-                off = off.expand_as(x0).contiguous() if off.shape != x0.shape else off.contiguous()
-                cv = _omega_conv(fn)
-                otf = cv._tables(x0.shape, dev) if cv is not None else None
-                FK = ops.data_spectrum(off, otf, conj=True, out=FK, accumulate=FK is not None)
-            s._fk_cache = (fk_key, FK, offs)
+        FK = self._data_spectrum(x0)
         (t0, c0), (t1, c1) = ls.diag_tables(x0.shape, dev, True)
 
         # ---- differentiable (unrolled-training) mode: hand-written backward stages, autodiff.py -------------------
@@ -341,6 +326,90 @@ class FusedADMM:
         s.Kall.update_vars([x])
         return (x, v, u) if dual else (x, v)
 
+
+    def run_stencil(self, state, rhos, lams, max_iter, method, pbar=False, callback=None):
+        """LinearizedADMM (``method='ladmm'``, admm.py:78-100) and PockChambolle (``'pc'``, pc.py:6-40) on fused stages: their
+        right-hand sides nest the Psi operators twice (b_i = x - K_i^T(...), then K_i^T b_i), which ``dpx_split_rhs`` evaluates as one
+        radius-2 gather pass; the x-update is the same Fourier solve with the fp64 data spectrum added in the Fourier domain, the
+        z / dual stage is ``dpx_admm_zupdate`` (LADMM) or ``dpx_pc_dual`` (PC).  Closed-form proxes only; 3-4 passes per iteration
+        instead of 10-15."""
+        s = self.solver
+        ls = s.least_square
+        psi = list(s.psi_fns)
+        x0 = state[0]
+        B, C, H, W = x0.shape
+        dev = x0.device
+        T = max_iter
+        s.Kall.update_vars([x0])
+        if T <= 0:
+            return state
+        rho_tab = schedule_table(rhos, T, B, dev)
+        lam_tab = [schedule_table(lams[fn], T, B, dev) for fn in psi]
+        FK = self._data_spectrum(x0)
+        (t0, c0), (t1, c1) = ls.diag_tables(x0.shape, dev, True)
+        n = len(psi)
+        var = s.Kall.variables[0]
+        rhs = torch.empty_like(x0)
+        if method == "ladmm":
+            _, v, u = state
+            x = x0.clone()
+            v, u = [t.contiguous() for t in v], [t.contiguous() for t in u]
+            specs = [dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=lam_tab[i][0], v=v[i], u=u[i]) for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))]
+            terms = ops.make_terms(specs)
+            for it in tqdm(range(T), disable=not pbar):
+                for i in range(n):
+                    terms[i].lam = lam_tab[i][it].data_ptr()
+                ops.split_rhs(rhs, None, x, rho_tab[it], terms, n, 1)
+                ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x, spec_add=FK)
+                ops.admm_zupdate(x, terms, n)
+                var.value = x
+                if callback is not None:
+                    s._notify_all_op_current_step(it)
+                    callback(iter=it, state=(x, v, u), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+            s.Kall.update_vars([x])
+            return x, v, u
+        # Pock-Chambolle: state (x, [z_i], xbar)
+        _, z, xbar = state
+        x, xn = x0.clone(), torch.empty_like(x0)
+        xbar = xbar.clone()
+        z = [t.contiguous() for t in z]
+        specs = [dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=lam_tab[i][0], v=z[i], u=z[i]) for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))]
+        terms = ops.make_terms(specs)
+        for it in tqdm(range(T), disable=not pbar):
+            for i in range(n):
+                terms[i].lam = lam_tab[i][it].data_ptr()
+            ops.pc_dual(xbar, terms, n)                                  # z += r K xbar ; z -= r prox(z, r)
+            ops.split_rhs(rhs, None, x, rho_tab[it], terms, n, 0)        # rho sum K^T (x - K^T z)
+            ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=xn, spec_add=FK)
+            ops.lincomb([(2.0, xn), (-1.0, x)], out=xbar)
+            x, xn = xn, x
+            var.value = x
+            if callback is not None:
+                s._notify_all_op_current_step(it)
+                callback(iter=it, state=(x, z, xbar), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+        s.Kall.update_vars([x])
+        return x, z, xbar
+
+    def _data_spectrum(self, x0):
+        """F(sum_Omega K^T b) in fp64, cached on the solver while the offsets and operator tables are unchanged"""
+        s = self.solver
+        dev = x0.device
+        offs = [fn.offset for fn in s.omega_fns]
+        fk_key = (tuple(x0.shape), str(dev)) + tuple((id(o), o._version) if o is not None else None for o in offs) + \
+            tuple(fn.linop.tables_version() for fn in s.omega_fns)
+        cached = getattr(s, "_fk_cache", None)
+        if cached is not None and cached[0] == fk_key:
+            return cached[1]
+        FK = None
+        for fn, off in zip(s.omega_fns, offs):
+            if off is None:
+                continue
+            off = off.expand_as(x0).contiguous() if off.shape != x0.shape else off.contiguous()
+            cv = _omega_conv(fn)
+            otf = cv._tables(x0.shape, dev) if cv is not None else None
+            FK = ops.data_spectrum(off, otf, conj=True, out=FK, accumulate=FK is not None)
+        s._fk_cache = (fk_key, FK, offs)
+        return FK
 
     @staticmethod
     def _offset_autograd(fn, x0):

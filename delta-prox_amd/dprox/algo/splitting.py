@@ -75,6 +75,11 @@ class ADMM(Algorithm):
             if plan is not None:
                 self.last_path = "fused-cg"
                 return plan.run(state, rhos, lams, max_iter, pbar, callback)
+        if type(self) is LinearizedADMM:
+            plan = _fused_closed_form(self, state, rhos, lams)      # Fourier x-update, Psi terms on x / grad x: nested-stencil rhs pass
+            if plan is not None:
+                self.last_path = "fused"
+                return plan.run_stencil(state, rhos, lams, max_iter, "ladmm", pbar, callback)
         self.last_path = "generic"
         return super().iters(state, rhos, lams, max_iter, pbar, callback)
 
@@ -186,6 +191,14 @@ class PockChambolle(ADMM):
         xbar = x.clone()
         z = self.K.forward(x, return_list=True)
         return x, [e if e is not x else e.clone() for e in z], xbar
+
+    def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
+        plan = _fused_closed_form(self, (state[0], state[1]), rhos, lams) if len(self.omega_fns) > 0 else None
+        if plan is not None:
+            self.last_path = "fused"
+            return plan.run_stencil(state, rhos, lams, max_iter, "pc", pbar, callback)
+        self.last_path = "generic"
+        return Algorithm.iters(self, state, rhos, lams, max_iter, pbar, callback)
 
     def _iter(self, state, rho, lam):
         x, z, xbar = state

@@ -323,6 +323,13 @@ int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* term
 /* the hot loop of Algorithm.iters (algo/base.py:149-156) for n_iters iterations, entirely on the C side:
  * rho_tab [total_iters][B], lam_tabs[i] [total_iters][B]; returns 0/1 = which of terms[i].u / u_out holds the
  * current u_i afterwards (<0 = error); x / v_i are written by the call's final iteration when emit_last is set. */
+/* Fused stages of LinearizedADMM (algo/admm.py:78-100) and PockChambolle (algo/pc.py:6-40) for K_i in {identity, grad_H, grad_W}:
+ *   dpx_split_rhs   rhs = ktb + rho_b sum_i K_i^T (x - K_i^T q_i),  q_i = z_i (mode 0, PC: terms[i].v) or (K_i x - v_i) + u_i (mode 1, LADMM)
+ *                   -- the right-hand side least_squares.rhs builds from the b_i of pc.py:24-25 / admm.py:84-88 (ktb nullable)
+ *   dpx_pc_dual     z_i += r K_i xbar ; z_i -= r prox_i(z_i, r alpha_i), r = terms[i].lam[b]        (pc.py:13-19), in place on terms[i].v */
+int dpx_split_rhs(float* rhs, const float* ktb, const float* x, const float* rho, const dpx_term* terms, int nterms, int mode,
+                  int B, int C, int H, int W, dpx_stream_t stream);
+int dpx_pc_dual(const float* xbar, const dpx_term* terms, int nterms, int B, int C, int H, int W, dpx_stream_t stream);
 /* test / tuning hook: rows_mode 0 automatic, 1 streaming row kernel, 2 lock-step row kernel; bands_per_plane 0 = automatic */
 int dpx_admm_iter_config(int rows_mode, int bands_per_plane);
 int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, const void* dd, const dpx_term* terms, int nterms,
