@@ -159,6 +159,21 @@ __global__ void k_cg_update1(float* __restrict__ x, float* __restrict__ r, const
   }
 }
 
+// Ap = Re(z) + c * rho_b * p        (last pass of the masked-Fourier normal operator: A^H A p + n rho p)
+__global__ void k_real_plus_rho(float* __restrict__ Ap, const float2* __restrict__ z, const float* __restrict__ p, const float* __restrict__ rho,
+                                float c, const int* __restrict__ done, long npb) {
+  if (done && done[0]) return;
+  const int b = blockIdx.y;
+  const float cr = c * rho[b];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npb; i += (long)gridDim.x * blockDim.x) {
+    const long e = (long)b * npb + i;
+    Ap[e] = fmaf(cr, p[e], z[e].x);
+  }
+}
+__global__ void k_square(float* __restrict__ out, const float* __restrict__ w, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = w[i] * w[i];
+}
+
 }  // namespace dpx
 
 using namespace dpx;
@@ -208,4 +223,102 @@ extern "C" int dpx_zero(void* p, size_t bytes, dpx_stream_t stream) {
     return DPX_ERR_LAUNCH;
   }
   return DPX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole CG solve of config 4's x-update in one call:  (A^H A + n_identity * rho_b I) x = b,  A = mask * fft2c (centred,
+// orthonormal), x0 = 0 -- least_squares.solve_cg (proxfn/sum_square.py:158-197) over linalg/solve/solver_cg.py:56-136 for the
+// masked-Fourier data term.  The operator application is dpx_cfft2 -> mask^2 -> dpx_cfft2^-1 -> real part + n rho p; the loop
+// control is the device-side state machine above; the host side of THIS function only issues kernels and looks at the `done`
+// flag LAG iterations late through a pinned buffer (never blocks on the newest work).  Returns the exit iteration (>= 0, the
+// number the reference prints in "Converged at CG Iter"; max_iters if it did not converge) or a negative status.
+// ws (dpx_cg_masked_fft_ws_bytes): r, p, Ap [B n] floats; two complex [B n] buffers; mask^2; state; Gram; dot workspace.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_images) {
+  const size_t n = (size_t)H * W;
+  return (3 * B * n + 4 * B * n + (size_t)mask_images * n + 5 * B + 4 + (size_t)B * B + 64) * sizeof(float) + dpx_bdot_ws_bytes(B, (long)n) + 256;
+}
+
+extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol,
+                                 int max_iters, int B, int H, int W, const void* table, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(x && b && mask && rho && table && ws && B >= 1 && B <= 64 && H > 0 && W > 0 && max_iters >= 0 && (mask_images == 1 || mask_images == B),
+              "dpx_cg_masked_fft: bad arguments (B = %d must be 1..64)", B);
+  hipStream_t s = (hipStream_t)stream;
+  const long n = (long)H * W;
+  float* w = (float*)ws;
+  float* r = w;
+  float* p = r + (size_t)B * n;
+  float* Ap = p + (size_t)B * n;
+  float2* z0 = (float2*)(Ap + (size_t)B * n);
+  float2* z1 = z0 + (size_t)B * n;
+  float* mask2 = (float*)(z1 + (size_t)B * n);
+  float* state = mask2 + (size_t)mask_images * n;
+  float* gram = state + 5 * B + 4;
+  float* dotws = gram + (((size_t)B * B + 63) / 64) * 64;
+  int* flags = (int*)(state + 5 * B);
+  float* pAp = state + 3 * B;
+
+  // pinned ring for the flag read-backs + its events: created once per process (host-side resources only)
+  static int* pin = nullptr;
+  static hipEvent_t ev[4];
+  if (!pin) {
+    if (hipHostMalloc((void**)&pin, 4 * 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+      set_error("dpx_cg_masked_fft: hipHostMalloc failed");
+      return DPX_ERR_LAUNCH;
+    }
+    for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+  }
+#define CG_TRY(call)                 \
+  do {                               \
+    const int rc_ = (call);          \
+    if (rc_ != DPX_OK) return rc_;   \
+  } while (0)
+  // r = b, x = p = 0, tolerances
+  hipMemcpyAsync(r, b, (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, s);
+  hipMemsetAsync(x, 0, (size_t)B * n * sizeof(float), s);
+  hipMemsetAsync(p, 0, (size_t)B * n * sizeof(float), s);
+  DPX_LAUNCH("k_square", k_square, dim3(grid_for((long)mask_images * n, 256, 1024)), dim3(256), 0, s, mask2, mask, (long)mask_images * n);
+  CG_TRY(dpx_bdot(b, b, gram, B, n, dotws, stream));                      // <b_i, b_i> (gram reused as scratch)
+  CG_TRY(dpx_cg_init(state, gram, rtol, B, stream));
+  const int n_it = max_iters < (int)((long)B * n) ? max_iters : (int)((long)B * n);
+  const int LAG = 2;
+  int done_it = n_it;
+  bool done = false;
+  int last = -1;
+  for (int it = 0; it < n_it; ++it) {
+    if (it >= LAG) {
+      hipEventSynchronize(ev[(it - LAG) & 3]);
+      if (pin[((it - LAG) & 3) * 4]) {
+        done = true;
+        done_it = pin[((it - LAG) & 3) * 4 + 1];
+        break;
+      }
+    }
+    CG_TRY(dpx_bgram(r, gram, B, n, dotws, stream));
+    CG_TRY(dpx_cg_test(state, gram, B, stream));
+    CG_TRY(dpx_cg_direction(p, r, state, B, n, stream));
+    {                                                                       // Ap = Re F^-1 mask^2 F p + n rho p
+      const void* xs[1] = {p};
+      const int cplx[1] = {0};
+      const float one[1] = {1.f};
+      CG_TRY(dpx_cplx_lincomb(z0, 1, 1, xs, cplx, one, (long)B * n, stream));
+      CG_TRY(dpx_cfft2(z0, z1, 0, 1, 1, B, H, W, table, stream));
+      CG_TRY(dpx_cplx_scale(z1, z1, mask2, B, n, mask_images, stream));
+      CG_TRY(dpx_cfft2(z1, z0, 1, 1, 1, B, H, W, table, stream));
+      DPX_LAUNCH("k_real_plus_rho", k_real_plus_rho, dim3(grid_for(n, 256, 1024), B), dim3(256), 0, s, Ap, (const float2*)z0, (const float*)p, rho,
+                 n_identity, (const int*)flags, n);
+    }
+    CG_TRY(dpx_bdot(p, Ap, pAp, B, n, dotws, stream));
+    CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));
+    hipMemcpyAsync(pin + (it & 3) * 4, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);
+    hipEventRecord(ev[it & 3], s);
+    last = it;
+  }
+  if (!done && last >= 0) {
+    hipEventSynchronize(ev[last & 3]);
+    if (pin[(last & 3) * 4]) done_it = pin[(last & 3) * 4 + 1];
+  }
+#undef CG_TRY
+  const int st = launch_status("dpx_cg_masked_fft");
+  return st != DPX_OK ? st : done_it;
 }

@@ -378,3 +378,36 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
              W2, GL);
   return launch_status("dpx_ffdnet_forward_bf16");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One plug-and-play ADMM iteration (config 3) without returning to the host language: algo/admm.py:49-59 with a deep_prior
+// z-update (proxfn/pnp/prior.py:73-86) --
+//   rhs = rho sum_i K_i^T (v_i - u_i)  ->  x = Fourier solve (+ fp64 data spectrum)  ->  closed-form terms: v_i, u_i;  the
+//   prior's term `ext`: d = x + u (left in terms[ext].v by the z stage), v = FFDNet(d, sigma), u = d - v.
+// The denoiser runs in `mode` 6 (split-bf16) / 1 (bf16) on dpx_ffdnet_forward_bf16 or 0 on the f32-input kernel; a gray network
+// (in_nc = 1) sees every band as an image ([B, C, H, W] -> [B C, 1, H, W]; sigma then has B C entries).  v_new: where the
+// denoised image goes (the caller swaps it with terms[ext].v for the next iteration).
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
+                                 const float* sigma, const void* spec_add, const void* dd, float eps, const void* packed, int in_nc, int nc,
+                                 int nb, int mode, int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ffd_ws,
+                                 dpx_stream_t stream) {
+  DPX_REQUIRE(x && rhs && terms && v_new && rho && sigma && dd && packed && table && spectrum_ws && ffd_ws, "dpx_admm_pnp_iter: null pointer");
+  DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && ext >= 0 && ext < nterms && terms[ext].linop == DPX_LIN_IDENTITY,
+              "dpx_admm_pnp_iter: the prior must be a term on x itself");
+  DPX_REQUIRE((in_nc == C) || (in_nc == 1), "dpx_admm_pnp_iter: a %d-channel network on %d-channel images", in_nc, C);
+  int rc = dpx_admm_rhs(rhs, nullptr, rho, terms, nterms, B, C, H, W, stream);
+  if (rc) return rc;
+  rc = dpx_fourier_solve(rhs, x, spec_add, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream);
+  if (rc) return rc;
+  rc = dpx_admm_zupdate(x, terms, nterms, B, C, H, W, stream);
+  if (rc) return rc;
+  const float* d = terms[ext].v;
+  const int Bn = in_nc == C ? B : B * C;
+  if (mode == 0) rc = dpx_ffdnet_forward(d, v_new, sigma, packed, in_nc, nc, nb, Bn, H, W, ffd_ws, stream);
+  else rc = dpx_ffdnet_forward_bf16(d, v_new, sigma, packed, in_nc, nc, nb, mode, Bn, H, W, ffd_ws, stream);
+  if (rc) return rc;
+  const float* xs[2] = {d, v_new};
+  const float cf[2] = {1.f, -1.f};
+  return dpx_lincomb(terms[ext].u, 2, xs, cf, nullptr, B, (long)C * H * W, stream);     // u = d - v
+}

@@ -89,6 +89,8 @@ SIGNATURES = {
     "dpx_cg_test": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "dpx_cg_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "dpx_cg_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "dpx_cg_masked_fft_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dpx_cg_masked_fft": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpx_prox": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
     "dpx_prox_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
     "dpx_fourier_apply_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -135,6 +137,8 @@ SIGNATURES = {
     "dpx_ffdnet_bf16_pack": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_bf16_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dpx_ffdnet_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_pnp_iter": (c_int, [c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpx_conv_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dpx_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -198,6 +202,11 @@ def _inject_for_tests(library, host_pointers):
 
 def host_mode():
     return _host_pointers
+
+
+def host_mode_skip_fast_cg():
+    """DPX_GENERIC_CG=1 keeps the x-update on the generic cg() loop (A/B timing and tests of both paths)"""
+    return bool(os.environ.get("DPX_GENERIC_CG"))
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

@@ -294,6 +294,25 @@ def bgram(r):
     return out
 
 
+def cg_masked_fft(b, mask, rho, n_identity, rtol, max_iters):
+    """the whole CG x-update of a masked-Fourier data term in one C call (dpx_cg_masked_fft); returns (x, exit iteration)"""
+    require(b, what="cg right-hand side")
+    B = int(b.shape[0])
+    H, W = int(b.shape[-2]), int(b.shape[-1])
+    assert b.numel() == B * H * W, "one plane per system"
+    mask = mask.to(device=b.device, dtype=torch.float32).contiguous()
+    mimg = B if mask.numel() == b.numel() else 1
+    assert mask.numel() == mimg * H * W
+    L = be.lib()
+    x = torch.empty_like(b)
+    ws = workspace("cg_masked_fft", L.query("dpx_cg_masked_fft_ws_bytes", B, H, W, mimg), b.device)
+    n = L.query("dpx_cg_masked_fft", ptr(x), ptr(b), ptr(mask), mimg, ptr(as_batch_vec(rho, B, b.device)), c_float(n_identity), c_float(rtol),
+                int(max_iters), B, H, W, ptr(fft_table(H, W, b.device)), ptr(ws), be.stream())
+    if n < 0:
+        raise be.DpxError(f"dpx_cg_masked_fft failed ({n}): {L.cdll.dpx_last_error().decode()}")
+    return x, int(n)
+
+
 def zeros_like(t):
     """torch.zeros_like through the C ABI's stream memset"""
     out = torch.empty_like(t)
@@ -428,6 +447,23 @@ def split_rhs(rhs, ktb, x, rho, term_arr, nterms, mode):
 def pc_dual(xbar, term_arr, nterms):
     B, C, H, W = _shape4(xbar)
     be.lib().call("dpx_pc_dual", ptr(xbar), term_arr, nterms, B, C, H, W, be.stream())
+
+
+def admm_pnp_iter(x, rhs, term_arr, nterms, ext, v_new, rho, sigma, spec_add, dd, eps, net):
+    """one plug-and-play ADMM iteration in one C call (dpx_admm_pnp_iter); `net`: the FFDNet module of term `ext`"""
+    B, C, H, W = _shape4(x)
+    L = be.lib()
+    mode = {"f32": 0, "bf16x3": 6, "bf16": 1}[net.compute_mode]
+    Bn = B if net.in_nc == C else B * C
+    if mode == 0:
+        packed = net.packed()
+        ws = workspace("ffdnet", L.query("dpx_ffdnet_ws_bytes", Bn, net.in_nc, net.nc, H, W), x.device)
+    else:
+        packed = net.packed_bf16(mode)
+        ws = workspace("ffdnet_bf16", L.query("dpx_ffdnet_bf16_ws_bytes", Bn, net.in_nc, net.nc, H, W), x.device)
+    L.call("dpx_admm_pnp_iter", ptr(x), ptr(rhs), term_arr, nterms, int(ext), ptr(v_new), ptr(rho), ptr(sigma), ptr(spec_add), ptr(dd),
+           c_float(eps), ptr(packed), net.in_nc, net.nc, net.nb, mode, B, C, H, W, ptr(fft_table(H, W, x.device)),
+           ptr(spectrum_ws(B * C, H, W, x.device)), ptr(ws), be.stream())
 
 
 def admm_zupdate(x, term_arr, nterms):

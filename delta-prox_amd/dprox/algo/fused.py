@@ -307,6 +307,29 @@ class FusedADMM:
             return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
                                         rhos, lams, pbar, callback)
 
+        # one FFDNet prior, everything else closed-form: the whole iteration is ONE C call (dpx_admm_pnp_iter)
+        one_call = (dual and len(ext) == 1 and isinstance(psi[ext[0]].denoiser, (FFDNetColorDenoiser, FFDNetDenoiser))
+                    and not torch.is_grad_enabled() and psi[ext[0]].denoiser.model.in_nc in (C, 1))
+        if one_call:
+            e = ext[0]
+            net = psi[e].denoiser.model
+            gray = net.in_nc != C
+            sig_tab = lam_tab[e].repeat_interleave(C, dim=1).contiguous() if (gray and C > 1) else lam_tab[e]
+            dd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
+            v_new = torch.empty_like(x0)
+            for it in tqdm(range(T), disable=not pbar):
+                for i in range(n):
+                    terms[i].lam = lam_tab[i][it].data_ptr()
+                ops.admm_pnp_iter(x, rhs, terms, n, e, v_new, rho_tab[it], sig_tab[it], FK, dd, ls_eps(ls), net)
+                v[e], v_new = v_new, v[e]                            # the denoised image becomes v; its old buffer is the next target
+                terms[e].v = v[e].data_ptr()
+                var.value = x
+                if callback is not None:
+                    s._notify_all_op_current_step(it)
+                    callback(iter=it, state=(x, v, u), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+            s.Kall.update_vars([x])
+            return x, v, u
+
         for it in tqdm(range(T), disable=not pbar):
             for i in range(n):
                 terms[i].lam = lam_tab[i][it].data_ptr()

@@ -42,6 +42,8 @@ def masked_fft(arg, mask):
     from ..linop import LinOp
 
     class _MaskedFFT(LinOp):
+        is_masked_fft = True            # lets least_squares route a CG x-update over this operator to dpx_cg_masked_fft
+
         def __init__(self, a, m):
             super().__init__([a])
             self.mask = m

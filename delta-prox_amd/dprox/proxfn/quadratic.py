@@ -279,9 +279,33 @@ class least_squares(ProxFn):
 
         return KtK(rho)
 
+    def _masked_fft_system(self, with_identity):
+        """(mask, number of rho * I terms) when the normal operator is  A^H A + n rho I  with A = masked_fft(x) -- one subsampled
+        Fourier data term and Psi terms acting on x itself (config 4) -- else None"""
+        from ..linop import sum as lin_sum
+        if len(self.quad_fns) != 1:
+            return None
+        op = self.quad_fns[0].linop
+        if isinstance(op, lin_sum):
+            lin = [k for k in op.input_nodes if not getattr(k, "is_constant", False) and type(k).__name__ != "Constant"]
+            if len(lin) != 1:
+                return None
+            op = lin[0]
+        if not getattr(op, "is_masked_fft", False) or not isinstance(op.input_nodes[0], Variable):
+            return None
+        if not all(isinstance(fn.linop, Variable) for fn in self.other_fns):
+            return None
+        return op.mask, float(len(self.other_fns) + (1 if with_identity else 0))
+
     def solve_cg_rhs(self, Ktb, rho_v, with_identity=False, linear_solve_config=None):
         """the CG x-update for an already assembled right-hand side ``Ktb``; records the exit iteration in ``cg_iters``"""
         cfg = linear_solve_config or self.linear_solve_config
+        plain = cfg.solver_type == "cg" and not cfg.verbose and not (torch.is_grad_enabled() and Ktb.requires_grad)
+        sysm = self._masked_fft_system(with_identity) if plain else None
+        if sysm is not None and Ktb.ndim == 4 and Ktb.shape[1] == 1 and Ktb.shape[0] <= 64 and not be.host_mode_skip_fast_cg():
+            x, n = ops.cg_masked_fft(Ktb.contiguous(), sysm[0], rho_v, sysm[1], cfg.rtol, cfg.max_iters)   # one C call per solve
+            self.cg_iters.append(n)
+            return x
         A = self.normal_operator(rho_v, with_identity)
         if cfg.solver_type == "cg" and not (torch.is_grad_enabled() and Ktb.requires_grad):
             from ..linalg.solve import cg

@@ -200,6 +200,13 @@ int dpx_cg_init(void* state, const float* bnorm2, float rtol, int B, dpx_stream_
 int dpx_cg_test(void* state, const float* gram, int B, dpx_stream_t stream);
 int dpx_cg_direction(float* p, const float* r, void* state, int B, long n_per_batch, dpx_stream_t stream);
 int dpx_cg_update(float* x, float* r, const float* p, const float* Ap, void* state, int B, long n_per_batch, dpx_stream_t stream);
+/* One call = one whole CG solve of config 4's x-update, (A^H A + n_identity rho_b I) x = b with A = mask * fft2 (centred,
+ * orthonormal), x0 = 0: least_squares.solve_cg (proxfn/sum_square.py:158-197) over cg() for the subsampled-Fourier data term.
+ * Kernels only (dpx_cfft2, mask^2, dpx_cg_*); the host side polls the device's `done` flag two iterations late through a pinned
+ * buffer.  Returns the exit iteration (>= 0; max_iters when not converged) or a negative status.  1 <= B <= 64.             */
+size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_images);
+int dpx_cg_masked_fft(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol,
+                      int max_iters, int B, int H, int W, const void* table, void* ws, dpx_stream_t stream);
 
 /* proximal operators, ProxFn.prox with the scaled/translated wrappers (proxfn/base.py:12-27,55-64):
  *   out = P(v - off, lam_b * alpha) + off      off nullable
@@ -360,6 +367,14 @@ int dpx_ffdnet_bf16_pack(void* packed, const float* const* w, const float* const
 size_t dpx_ffdnet_bf16_ws_bytes(int B, int in_nc, int nc, int H, int W);
 int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode,
                             int B, int H, int W, void* ws, dpx_stream_t stream);
+
+/* One plug-and-play ADMM iteration in one call (algo/admm.py:49-59 with deep_prior(FFDNet) as term `ext`): rhs stage, Fourier
+ * solve with the fp64 data spectrum, z / dual stage of the closed-form terms, denoiser (mode 0: f32-input MFMA, packed by
+ * dpx_ffdnet_pack; 6 / 1: dpx_ffdnet_bf16_pack) on d = x + u, u = d - v.  sigma: [B] (colour network) or [B C] (gray network per
+ * band).  v_new receives the denoised image.  ffd_ws: dpx_ffdnet_ws_bytes / dpx_ffdnet_bf16_ws_bytes of the denoiser's batch.  */
+int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
+                      const float* sigma, const void* spec_add, const void* dd, float eps, const void* packed, int in_nc, int nc, int nb,
+                      int mode, int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ffd_ws, dpx_stream_t stream);
 
 /* Generic convolution layers on the same MFMA kernel (residual U-Net denoisers behind deep_prior: DRUNet,
  * dprox/proxfn/pnp/denoisers/models/network_unet.py:67-117, basicblock.py).  NCHW fp32, stride 1.
