@@ -20,7 +20,28 @@ cases = {
  "grads": lambda: pc.case_unrolled_grads("cpu"),
  "cg": lambda: pc.case_cg("cpu", 4),
  "ffbwd": lambda: pc.case_ffdnet_grads("cpu", which=("even",)),
+ "ladmm": lambda: pc.case_ladmm_cg("cpu"),                    # device-side CG, dpx_cg_masked_fft, fused split-CG loop, gray bf16x3 denoiser
+ "other": lambda: pc.case_other_algorithms("cpu"),            # dpx_split_rhs / dpx_pc_dual
+ "bf16hist": lambda: pc.case_unrolled_grads_bf16("cpu"),
+ "lsolve": lambda: pc.case_linear_solve_grad("cpu"),
 }
+def unet_layers():
+    import test_emul_kernels as t
+    t.test_unet_layer_kernels_vs_torch(); t.test_leaky_conv_layer_vs_torch()
+cases["unet"] = unet_layers
+def ffd_modes():
+    """split-bf16 / bf16 convolution path on the odd-sized colour fixture (tile edges, zero-block DMA lanes)"""
+    from conftest import load_golden, rel_l2
+    import synthetic
+    from dprox.proxfn.pnp.denoisers import FFDNetColorDenoiser
+    g = load_golden("g8_ffdnet")
+    col = FFDNetColorDenoiser(synthetic.ffdnet_weights(7))
+    for mode, tol in (("bf16x3", 1e-5), ("bf16", 1e-2)):
+        col.model.compute_mode = mode
+        with torch.no_grad():
+            out = col.denoise(torch.from_numpy(g["odd_x"]), torch.tensor(0.02))
+        assert rel_l2(out.numpy(), g["odd_s0.02"]) <= tol
+cases["ffmodes"] = ffd_modes
 def pow2_terms():
     """two-kernel iteration (LDS-DMA row / column kernels) at 256x256 with 1, 3 and 4 Psi terms, uneven band partition"""
     import dprox as dp, synthetic
