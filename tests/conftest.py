@@ -56,11 +56,12 @@ def pytest_sessionfinish(session, exitstatus):
         pass
 
 
-# max-abs multiplier of assert_close: SURVEY 8(a) asks for max-abs <= rel * max|ref| (x1).  A max over 1e5..1e7 entries of
-# fp32 round-off sits ~4-5 sigma above the RMS the rel-L2 bound speaks about, so x1 on the max is a (much) stricter
-# statement than rel-L2 <= rel; cases that meet x1 pass maxabs_mult=1 explicitly, the default keeps x4 (and the achieved
-# ratio of every comparison is recorded either way).
-def assert_close(a, b, rel=1e-5, what="", maxabs_mult=4.0):
+# SURVEY 8(a) acceptance: rel-L2 <= rel AND max-abs <= rel * max|ref| (maxabs_mult = 1, the default).  The long ADMM trajectories
+# whose rel-L2 itself sits on the reference's fp32 noise floor (6e-6 .. 9e-6 against a 1e-5 bar: G5 at 20 / 50 iterations, G30 at
+# iteration 10) pass maxabs_mult = 4 explicitly: the maximum over 1e5 .. 1e7 entries of that noise is 4-5 sigma above its RMS
+# (measured 1.6e-5 .. 3.5e-5 of max|ref|; the backend itself is 3e-7 from the float64 iterate there).  Every comparison's achieved
+# rel-L2 and max-abs ratio is recorded (profiles/r2_parity_achieved_gpu.json: 6 of 186 comparisons exceed x1).
+def assert_close(a, b, rel=1e-5, what="", maxabs_mult=1.0):
     """SURVEY 8(a) acceptance: rel-L2 <= rel and max-abs <= maxabs_mult * rel * max|ref|."""
     a = np.asarray(a)
     b = np.asarray(b)
