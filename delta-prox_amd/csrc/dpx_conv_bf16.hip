@@ -18,6 +18,12 @@
 // workgroup barrier per slot.  LDS: 39 + 57 + 54 KB (MT = 3): one workgroup per CU, two waves per SIMD.
 #include "dpx_common.h"
 
+// Tuning probes (wrong results by design; DESIGN.md section 3 has what they measured): 1 tap-independent fragment reads,
+// 2 no split pass, 4 no DMA / waits / barriers, 8 no DMA (barriers stay), 16 DMA never waited for,
+// 32 / 64 every activation piece from one cached KB of zeros / of image data.
+#ifndef DPX_BX_DBG
+#define DPX_BX_DBG 0
+#endif
 namespace dpx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -169,16 +175,19 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
     poff[k] = ok ? (unsigned)(((size_t)g * H * W + (size_t)yy * W + xx) * 8 + half * 4) : ~0u;
   }
   auto issue_act = [&](int c) {
+    if (DPX_BX_DBG & 8) return;
     const float* cb = inb + (size_t)(2 * c) * H * W * 8;
 #pragma unroll
     for (int k = 0; k < BX_NPI; ++k) {
       if (k * 512 + wv * 64 < BX_PIECES) {                            // wave-uniform: whole 1 KB instructions
-        const float* src = poff[k] != ~0u ? cb + poff[k] : zero_block;
+        const float* src = (poff[k] != ~0u && !(DPX_BX_DBG & 32)) ? cb + poff[k] : zero_block;
+        if (DPX_BX_DBG & 64) src = inb + (tid & 63) * 4;
         dpx_glds16(src, land + (k * 512 + wv * 64) * 16);
       }
     }
   };
   auto issue_w = [&](int slot_idx) {                                  // global slot index = chunk * 3 + tap group
+    if (DPX_BX_DBG & 8) return;
     const char* src = wpk + (size_t)slot_idx * SLOTB + lane * 16;
     char* dst = ring + (slot_idx & 1) * SLOTB;
     for (int i = wv; i < SLOTB / 1024; i += 8) dpx_glds16(src + i * 1024, dst + i * 1024);
@@ -193,13 +202,17 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
       for (int i = 0; i < 16; ++i) acc[mt][r][i] = 0.f;
 
   const int nslots = chunks * 3;
-  issue_act(0);
-  issue_w(0);
+  if (!(DPX_BX_DBG & 4)) {
+    issue_act(0);
+    issue_w(0);
+  }
   for (int c = 0; c < chunks; ++c) {
     // ---- the chunk's activations: landed -> split into bf16 planes ------------------------------------------------------
-    dpx_wait_vm<0>();
-    __syncthreads();                                                  // landing buffer complete; everybody is done with the old tile
-    for (int u = tid; u < BX_UNITS; u += 512) {
+    if (!(DPX_BX_DBG & 4)) {
+    if (!(DPX_BX_DBG & 16)) dpx_wait_vm<0>();
+    DPX_LDS_BARRIER();                                                // landing buffer complete; everybody is done with the old tile
+    }
+    for (int u = tid; u < ((DPX_BX_DBG & 2) ? 0 : BX_UNITS); u += 512) {
       const float4 lo4 = *(const float4*)(land + u * 32), hi4 = *(const float4*)(land + u * 32 + 16);
       const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
       unsigned h[8], m[8], l[8];
@@ -218,16 +231,18 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
         *(uint4*)(tile + 2 * BX_PLANE_BYTES + u * 16) = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
       }
     }
-    __syncthreads();                                                  // tile ready, landing buffer free
+    if (!(DPX_BX_DBG & 4)) {
+    DPX_LDS_BARRIER();                                                // tile ready, landing buffer free
     if (c + 1 < chunks) issue_act(c + 1);
+    }
     // ---- three slots of three taps ----------------------------------------------------------------------------------------
     for (int tg = 0; tg < 3; ++tg) {
       const int s = c * 3 + tg;
-      if (tg > 0) {                                                    // (tg == 0: the barrier pair above already covered slot s)
-        dpx_wait_vm<0>();
-        __syncthreads();                                              // slot s landed; slot s - 1 no longer read by anybody
+      if (tg > 0 && !(DPX_BX_DBG & 4)) {                               // (tg == 0: the barrier pair above already covered slot s)
+        if (!(DPX_BX_DBG & 16)) dpx_wait_vm<0>();
+        DPX_LDS_BARRIER();                                            // slot s landed; slot s - 1 no longer read by anybody
       }
-      if (s + 1 < nslots) issue_w(s + 1);
+      if (s + 1 < nslots && !(DPX_BX_DBG & 4)) issue_w(s + 1);
       const char* wslot = ring + (s & 1) * SLOTB;
 #pragma unroll
       for (int t3 = 0; t3 < 3; ++t3) {
@@ -235,7 +250,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
         uint4 bf[2][NPL];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const int u = (kg * BX_ROWS + 2 * wv + r + dy) * BX_COLS + n + dx;
+          const int u = (DPX_BX_DBG & 1) ? (kg * BX_ROWS + 2 * wv + r) * BX_COLS + n : (kg * BX_ROWS + 2 * wv + r + dy) * BX_COLS + n + dx;
 #pragma unroll
           for (int p = 0; p < NPL; ++p) bf[r][p] = *(const uint4*)(tile + p * BX_PLANE_BYTES + u * 16);
         }
@@ -243,7 +258,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
         for (int mt = 0; mt < MT; ++mt) {
           uint4 af[NPL];
 #pragma unroll
-          for (int p = 0; p < NPL; ++p) af[p] = *(const uint4*)(wslot + t3 * TAPB + ((p * 2 + kg) * M32 + mt * 32 + n) * 16);
+          for (int p = 0; p < NPL; ++p) af[p] = *(const uint4*)(wslot + ((DPX_BX_DBG & 1) ? 0 : t3 * TAPB) + ((p * 2 + kg) * M32 + mt * 32 + n) * 16);
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             if constexpr (MODE == 1) {
