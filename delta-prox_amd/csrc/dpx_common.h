@@ -1,5 +1,8 @@
 // Internal helpers shared by the gfx950 kernels of libdpx_hip.so (not part of the C ABI).
 #pragma once
+#ifndef DPX_COLS_PACK0
+#define DPX_COLS_PACK0 1
+#endif
 #include <hip/hip_runtime.h>
 #ifndef DPX_EMULATED
 #include <hip/hip_ext.h>
@@ -17,9 +20,12 @@
 // stay in flight across it.  Only LDS data may be exchanged through it.
 #ifdef DPX_EMULATED
 #define DPX_OPAQUE(x) ((void)(x))
+#define DPX_OPAQUE_AFTER(x, dep) ((void)(x))
 #define DPX_LDS_BARRIER() __syncthreads()
 #else
 #define DPX_OPAQUE(x) asm volatile("" : "+v"(x))
+// ... and not before `dep` has been computed (an address derived from x cannot be hoisted across the code producing dep)
+#define DPX_OPAQUE_AFTER(x, dep) asm volatile("" : "+v"(x) : "v"(dep))
 #define DPX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
@@ -170,6 +176,10 @@ __host__ __device__ __forceinline__ size_t spec_main_index(int tiled, int H, int
   return tiled ? ((size_t)(l / SPEC_TILE) * H + k) * SPEC_TILE + (l % SPEC_TILE) : (size_t)k * Ws + l;
 }
 // table = all planes' main parts [C][H*Ws] followed by all side parts [C][H]
+// Power-of-two planes, DPX_COLS_PACK0 = 1: the column kernel carries a plane's Nyquist column through its transforms as the
+// imaginary part of the DC column (dpx_fft_pow2.hip); the iteration-invariant data spectrum (dpx_data_spectrum) is stored that
+// way already -- column 0 of its main part holds A + iB, its side part is unused.  Spectra handed between the row and column
+// kernels and the tables keep the side array.
 static inline size_t table_elems(int C, int H, int W) { return (size_t)C * H * spec_cols(W) + (size_t)C * H; }
 
 // twiddle table: float2[W] (e^{-2 pi i t / W}) followed by float2[H]

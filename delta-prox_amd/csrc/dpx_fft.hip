@@ -460,7 +460,7 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
         const double tr = t.x, ti = conj_otf ? -(double)t.y : (double)t.y;
         n = make_double2(n.x * tr - n.y * ti, n.x * ti + n.y * tr);
       }
-      if (side_layout) {                                // Nyquist column -> side array [P][H]
+      if (side_layout && !DPX_COLS_PACK0) {              // Nyquist column -> side array [P][H]
         float2* sd = out + (size_t)P * H * Ws + (size_t)p * H + k;
         if (accumulate) {
           const float2 old = *sd;
@@ -469,7 +469,7 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
           *sd = make_float2((float)n.x, (float)n.y);
         }
       } else {
-        v = make_double2(v.x - n.y, v.y + n.x);        // packed: A + i B
+        v = make_double2(v.x - n.y, v.y + n.x);        // packed: A + i B (power-of-two planes too, see dpx_common.h)
       }
     }
     float2* dst = o + spec_main_index(side_layout, H, Ws, k, l);

@@ -14,6 +14,7 @@
 #include "dpx_fft_reg.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace dpx {
 
@@ -133,55 +134,27 @@ constexpr int COLS_LD_NT = DPX_COLS_LD_NT, COLS_ADD_NT = DPX_COLS_ADD_NT, COLS_S
 #ifndef DPX_COLS_BATCH_INNER
 #define DPX_COLS_BATCH_INNER 1
 #endif
-template <int H, int T, int COLS, int OP, int DBG = 0>
-#ifndef DPX_COLS_WPE
-#define DPX_COLS_WPE ((T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for
-#endif
-__global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
-                                                      int C, int Ws, int P, const float2* __restrict__ twH) {
+// The Nyquist column of a plane (side array [P][H]) rides through the two transforms as the imaginary part of the plane's DC
+// column: both are spectra of real sequences, so z = dc + i ny is ONE complex column, separated by Hermitian symmetry around
+// the per-frequency operator (a = (Z[k] + conj Z[N-k]) / 2, i b = (Z[k] - conj Z[N-k]) / 2), as the generic path does
+// (dpx_fft.hip).  The HBM layout does not change: the lanes of the DC column read and write the side array themselves.
+// With separate workgroups for the Nyquist columns the launch had 3 x 512 + 3 workgroups at 8x3x1024^2 for 512 resident
+// ones, and the three extra ran alone in a fourth round: 75.7 -> 68.9 us without them.
+// The workgroup's work; PACK = its column c == 0 is the plane's packed (DC, Nyquist) column.  Two instantiations per kernel so that
+// the packed variant's extra live values (and spills) stay out of the register allocation of the other 63 workgroups in 64.
+template <int H, int T, int COLS, int OP, int DBG, bool PACK>
+__device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, const SpecArgs& A, int C, int Ws, int P,
+                                          const float2* __restrict__ twH, int bid, int nmain, bool is_side, int p, int j, unsigned sub_off) {
   constexpr int V = H / T;
   constexpr int S0 = LdsSeq<H>::SLOTS;
   constexpr int S = S0 + ((36 - S0 % 32) % 32);     // S % 32 == 4: adjacent columns start 8 banks apart
   HIP_DYNAMIC_SHARED(float2, smem_p2)
   const int tid = threadIdx.x, c = tid % COLS, t = tid / COLS;
-  const int tiles = Ws / COLS, nmain = P * tiles;
-  const int bid = blockIdx.x;
-  // main tiles: COLS adjacent columns of plane p.  side tiles: the Nyquist columns of COLS consecutive planes.
-  const bool is_side = bid >= nmain;                  // block-uniform
   // uniform (scalar) bases + 32-bit per-thread element offsets: one address VGPR per access
   size_t ubase;                                       // element offset of the tile's plane / of the side array
   unsigned off0, step, toff0, tbase;                  // data offset of row t, row step, table offset of row t, table base
-  int p;
-  unsigned sub_off = 0;                               // column offset of this workgroup inside a wider spectrum tile
+  constexpr bool pack0 = PACK;
   if (!is_side) {
-    p = bid / tiles;
-    int j;                                              // first spectrum tile of this workgroup
-    if constexpr (COLS >= SPEC_TILE) {
-      j = (bid - p * tiles) * (COLS / SPEC_TILE);
-    } else {
-      // SPEC_TILE / COLS workgroups share a tile (and its 128-byte lines): they are placed 8 block ids apart so that
-      // the round-robin block -> XCD assignment puts them on the same XCD, i.e. behind the same L2
-      constexpr int SUB = SPEC_TILE / COLS;
-      const int tiles_w = Ws / SPEC_TILE, Bn = P / C;   // spectrum tiles per plane, images
-      if (DPX_COLS_BATCH_INNER && (C * tiles_w) % 8 == 0) {
-        // ... and so are the Bn images' workgroups of one (channel, tile): the operator's table (denominators / OTF) is
-        // shared by the batch, and with the images innermost on one XCD its lines are fetched from HBM once instead of
-        // once per image (the streams in between would evict them from the 4 MB L2).
-        // bid = 8 * ((g * Bn + b) * SUB + sub) + xcd,  (channel, tile) = g * 8 + xcd
-        const int GB = (DPX_COLS_BATCH_INNER > 1 && Bn % DPX_COLS_BATCH_INNER == 0) ? DPX_COLS_BATCH_INNER : Bn;   // images per inner group
-        const int per = 8 * GB * SUB, u = bid / per, r = bid - u * per, ng = (C * tiles_w) / 8;
-        const int bg = u / ng, g = u - bg * ng;
-        const int xs = r % 8, sidx = r / 8, ct = g * 8 + xs;
-        const int cch = ct / tiles_w;
-        j = ct - cch * tiles_w;
-        p = (bg * GB + sidx / SUB) * C + cch;
-        sub_off = (unsigned)((sidx % SUB) * COLS);
-      } else {
-        const int q = bid - p * tiles;
-        j = (q / (8 * SUB)) * 8 + (q % 8);
-        sub_off = (unsigned)(((q % (8 * SUB)) / 8) * COLS);
-      }
-    }
     ubase = (size_t)p * H * Ws + (size_t)j * H * SPEC_TILE;   // tile-major main part: element (row r, col c) of a tile at r*TILE + c
     off0 = (unsigned)((c / SPEC_TILE) * H * SPEC_TILE + t * SPEC_TILE + (c % SPEC_TILE)) + sub_off;
     step = (unsigned)(T * SPEC_TILE);
@@ -204,6 +177,12 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   float2 v[V];
 #pragma unroll
   for (int m = 0; m < V; ++m) v[m] = ld_stream<COLS_LD_NT>((const float2*)(pin + (off0 + step * m) * 8u));
+  const bool dc_lane = PACK && c == 0;               // the lanes carrying the packed (DC, Nyquist) column
+  if (dc_lane) {                                      // (row spectra: both columns are real on entry)
+    const float* sidef = (const float*)(spec_in + (size_t)P * H * Ws + (size_t)p * H + t);
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[m].y = sidef[2 * m * T];
+  }
   for (int i = tid; i < H; i += T * COLS) twl[i] = twH[i];
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const char* add = (OP == OP_SOLVE && A.add) ? (const char*)(A.add + ubase) : nullptr;
@@ -220,9 +199,10 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
 #define DPX_COLS_EARLY_ADD 1       // with the spectra served from the Infinity Cache the data spectrum is the HBM stream: start it one pass earlier (78.8 -> 76.0 us)
 #endif
   constexpr bool EARLY_ADD = DPX_COLS_EARLY_ADD;        // request the data spectrum before the last pass's arithmetic
-  float2 av[OP == OP_SOLVE ? V : 1];
+  constexpr int NAV = (OP == OP_SOLVE || DPX_COLS_PACK0) ? V : 1;
+  float2 av[NAV];                                     // data spectrum (SOLVE); MUL: the packed column's correction
 #pragma unroll
-  for (int m = 0; m < (OP == OP_SOLVE ? V : 1); ++m) av[m] = make_float2(0.f, 0.f);
+  for (int m = 0; m < NAV; ++m) av[m] = make_float2(0.f, 0.f);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float2* tstage = smem_p2 + wave * (64 * V);
@@ -254,6 +234,39 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
 #ifdef DPX_COLS_PRIO
   __builtin_amdgcn_s_setprio(DPX_COLS_PRIO);          // experiment: workgroups past their forward transform go first
 #endif
+  // Packed column (its workgroup only, PACK): Z = A + iB is split into A = (Z + Zc)/2 and iB = (Z - Zc)/2, Zc[k] = conj Z[N-k], so
+  // that the operator's factors of the DC column (fA) and of the Nyquist column (fB) reach their own parts:
+  //     op(Z) = fA (A + eps) + fB (iB + i eps) = fA (Z + eps) + (fB - fA) iB + i fB eps.
+  // The partner bins live in other waves: one exchange through an LDS buffer of H bins -- the 8 (S - H) slots behind the table
+  // stage + the launch's extra bytes behind the twiddles.   pack_split: zval(m) -> Z[t + m T] of this lane, consume(m, iB).
+  constexpr int XSLACK = COLS * (S - H);
+  auto xslot = [&](int i) { return i < XSLACK ? smem_p2 + COLS * H + i : smem_p2 + COLS * S + H + (i - XSLACK); };
+  auto pack_split = [&](auto zval, auto consume) {
+    DPX_LDS_BARRIER();                                // (no table stage on this path: every wave's last-pass reads are done)
+    if (dc_lane) {
+#pragma unroll
+      for (int m = 0; m < V; ++m) xslot(t + m * T)[0] = zval(m);
+    }
+    DPX_LDS_BARRIER();
+    if (dc_lane) {
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const int k = t + m * T;
+        consume(m, cscale(csub(zval(m), cconj(xslot((H - k) & (H - 1))[0])), 0.5f));
+      }
+    }
+  };
+  const float2* tside = (OP == OP_SOLVE ? A.dd : A.otf) + (unsigned)C * H * Ws + (unsigned)(p % C) * H + t;    // Nyquist column's table values
+  if constexpr (PACK && OP != OP_SOLVE) {
+    // multiply: no division by the DC factor is possible, so the correction (oB - oA) iB is formed in front of the operator and added behind it
+    float2 dd[V];
+    if (dc_lane) {
+#pragma unroll
+      for (int m = 0; m < V; ++m) dd[m] = cscale(csub(tside[m * T], A.otf[tbase + toff0 + step * m]), A.scale);
+    }
+    pack_split([&](int m) { return v[m]; },
+               [&](int m, float2 ib) { av[m] = OP == OP_MULCONJ ? cmulc(ib, dd[m]) : cmul(ib, dd[m]); });
+  }
   if constexpr (OP == OP_SOLVE) {
     unsigned offa = off0;
     DPX_OPAQUE(offa);
@@ -285,7 +298,43 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
 #pragma unroll
     for (int m = 0; m < V; ++m) {
       v[m] = spec_op_p2<OP>(v[m], A, tbase + toff0 + step * m, rho_b);
+      if (DPX_COLS_PACK0) v[m] = cadd(v[m], av[m]);     // (zero except in the packed column)
       if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (PACK && OP == OP_SOLVE) {
+    // solve: the operator above produced fA (Z + eps); Z is recovered from it (fA > 0), split, and the Nyquist part re-weighted
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");                    // (keeps the loads below behind the operator: hoisted across it they spill)
+    const float iscale = 1.0f / A.scale;
+    float dnb[V], g[V];                               // the Nyquist column's and the DC column's denominators
+    if (!DMA_TABLE) DPX_LDS_BARRIER();                  // (with the table stage, its barrier already separates the last-pass reads from these writes)
+    if (dc_lane) {
+      int ts = t;
+      DPX_OPAQUE(ts);
+      const float2* tsd = A.dd + (unsigned)C * H * Ws + (unsigned)(p % C) * H + ts;
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 db = tsd[m * T];
+        dnb[m] = fmaf(rho_b, db.y, db.x) + A.eps;
+      }
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 da = (DMA_TABLE && !(DBG & 2)) ? tstage[m * 64 + lane] : A.dd[tbase + toff0 + step * m];
+        g[m] = fmaf(rho_b, da.y, da.x) + A.eps;
+        xslot(t + m * T)[0] = make_float2(fmaf(v[m].x, g[m] * iscale, -A.eps_num), v[m].y * (g[m] * iscale));
+      }
+    }
+    DPX_LDS_BARRIER();
+    if (dc_lane) {
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const int k = t + m * T;
+        const float2 z = make_float2(fmaf(v[m].x, g[m] * iscale, -A.eps_num), v[m].y * (g[m] * iscale));
+        const float2 ib = cscale(csub(z, cconj(xslot((H - k) & (H - 1))[0])), 0.5f);
+        const float fb = A.scale * DPX_RCP(dnb[m]), df = fb - A.scale * DPX_RCP(g[m]);
+        v[m] = make_float2(fmaf(df, ib.x, v[m].x), fmaf(df, ib.y, fmaf(fb, A.eps_num, v[m].y)));
+      }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -294,7 +343,64 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
   unsigned off1 = off0;
   DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores
 #pragma unroll
-  for (int m = 0; m < V; ++m) st_stream<COLS_ST>((float2*)(pout + (off1 + step * m) * 8u), v[m]);
+  for (int m = 0; m < V; ++m) st_stream<COLS_ST>((float2*)(pout + (off1 + step * m) * 8u), dc_lane ? make_float2(v[m].x, 0.f) : v[m]);
+  if (dc_lane) {                                      // both columns are real again: Re -> DC column, Im -> side array
+    int te = threadIdx.x;
+    DPX_OPAQUE(te);                                   // (address re-derived here instead of kept alive through the kernel)
+    float2* so = spec_out + (size_t)P * H * Ws + (size_t)p * H + te / COLS;
+#pragma unroll
+    for (int m = 0; m < V; ++m) st_stream<COLS_ST>(so + m * T, make_float2(v[m].y, 0.f));
+  }
+}
+
+
+template <int H, int T, int COLS, int OP, int DBG = 0>
+#ifndef DPX_COLS_WPE
+#define DPX_COLS_WPE ((T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for
+#endif
+__global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
+                                                      int C, int Ws, int P, const float2* __restrict__ twH) {
+  const int tiles = Ws / COLS, nmain = P * tiles;
+  const int bid = blockIdx.x;
+  // main tiles: COLS adjacent columns of plane p.  side tiles (DPX_COLS_PACK0 = 0 only): the Nyquist columns of COLS consecutive planes.
+  const bool is_side = bid >= nmain;                  // block-uniform
+  int p = 0, j = 0;                                   // plane and first spectrum tile of this workgroup
+  unsigned sub_off = 0;                               // column offset of this workgroup inside a wider spectrum tile
+  if (!is_side) {
+    p = bid / tiles;
+    if constexpr (COLS >= SPEC_TILE) {
+      j = (bid - p * tiles) * (COLS / SPEC_TILE);
+    } else {
+      // SPEC_TILE / COLS workgroups share a tile (and its 128-byte lines): they are placed 8 block ids apart so that
+      // the round-robin block -> XCD assignment puts them on the same XCD, i.e. behind the same L2
+      constexpr int SUB = SPEC_TILE / COLS;
+      const int tiles_w = Ws / SPEC_TILE, Bn = P / C;   // spectrum tiles per plane, images
+      if (DPX_COLS_BATCH_INNER && (C * tiles_w) % 8 == 0) {
+        // ... and so are the Bn images' workgroups of one (channel, tile): the operator's table (denominators / OTF) is
+        // shared by the batch, and with the images innermost on one XCD its lines are fetched from HBM once instead of
+        // once per image (the streams in between would evict them from the 4 MB L2).
+        // bid = 8 * ((g * Bn + b) * SUB + sub) + xcd,  (channel, tile) = g * 8 + xcd
+        const int GB = (DPX_COLS_BATCH_INNER > 1 && Bn % DPX_COLS_BATCH_INNER == 0) ? DPX_COLS_BATCH_INNER : Bn;   // images per inner group
+        const int per = 8 * GB * SUB, u = bid / per, r = bid - u * per, ng = (C * tiles_w) / 8;
+        const int bg = u / ng, g = u - bg * ng;
+        const int xs = r % 8, sidx = r / 8, ct = g * 8 + xs;
+        // (channel, tile) pairs in tile-major order: the workgroups holding a packed (DC, Nyquist) column -- tile 0 of every channel,
+        // a few microseconds longer than the rest -- are dispatched first instead of ending up in the launch's last round
+        const int cch = DPX_COLS_PACK0 ? ct % C : ct / tiles_w;
+        j = DPX_COLS_PACK0 ? ct / C : ct - cch * tiles_w;
+        p = (bg * GB + sidx / SUB) * C + cch;
+        sub_off = (unsigned)((sidx % SUB) * COLS);
+      } else {
+        const int q = bid - p * tiles;
+        j = (q / (8 * SUB)) * 8 + (q % 8);
+        sub_off = (unsigned)(((q % (8 * SUB)) / 8) * COLS);
+      }
+    }
+  }
+  if (DPX_COLS_PACK0 && !is_side && j == 0 && sub_off == 0)
+    cols_body<H, T, COLS, OP, DBG, true>(spec_in, spec_out, A, C, Ws, P, twH, bid, nmain, is_side, p, j, sub_off);
+  else
+    cols_body<H, T, COLS, OP, DBG, false>(spec_in, spec_out, A, C, Ws, P, twH, bid, nmain, is_side, p, j, sub_off);
 }
 
 // Tuning probe (DPX_DEBUG_COLS=4, wrong results by design): the column kernel's HBM traffic with 16-byte accesses and
@@ -358,13 +464,14 @@ template <int H, int T, int COLS, int OP, int DBG = 0>
 static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
   constexpr int S0 = LdsSeq<H>::SLOTS;
   constexpr int S = S0 + ((36 - S0 % 32) % 32);
-  const size_t sh = (size_t)(COLS * S + H) * sizeof(float2);
+  // + the rest of the packed column's H-bin exchange buffer (DPX_COLS_PACK0): 80 KB per workgroup at H = 1024, still two per CU
+  const size_t sh = (size_t)(COLS * S + H + (DPX_COLS_PACK0 && H > COLS * (S - H) ? H - COLS * (S - H) : 0)) * sizeof(float2);
   static bool attr_done = false;
   if (!attr_done && sh > 48 * 1024) {
     hipFuncSetAttribute((const void*)k_cols_p2<H, T, COLS, OP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr_done = true;
   }
-  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP, DBG>), dim3(P * (Ws / COLS) + (P + COLS - 1) / COLS), dim3(T * COLS), sh, s, spec,
+  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP, DBG>), dim3(P * (Ws / COLS) + (DPX_COLS_PACK0 ? 0 : (P + COLS - 1) / COLS)), dim3(T * COLS), sh, s, spec,
              spec_out, A, C, Ws, P, twH);
 }
 

@@ -989,6 +989,7 @@ def g33_full_c5():
     loss64.backward()
     out.update(loss_f64=loss64.detach(), g_rhos_f64=r64.grad, g_l0_f64=a64.grad, g_l1_f64=b64.grad)
     _pack(out, "g_b_f64", bt64.grad, 8)
+    _pack(out, "x_f64", x64, 8)         # (pointwise context: after 10 iterations single pixels sit next to threshold decisions)
     print("config 5:", float(loss), rhos.grad, l0.grad, l1.grad)
     print("config 5 f64:", float(loss64), r64.grad, a64.grad, b64.grad)
     save("g33_full_c5", **out)

@@ -788,7 +788,18 @@ def _check_packed(g, key, t, stride, tol, scale_key=None, what="", scale_sub=1, 
     t = t.detach()
     samp = t[..., ::stride, ::stride].cpu().numpy()
     ref = g[key]
-    if scale_key is None:
+    if scale_key is None and (key + "_f64") in g and not (np.abs(samp - ref).max() <= tol * np.abs(ref).max()):
+        # pointwise the reference itself sits ~1e-5 from the float64 result stored next to it (single pixels beside a threshold
+        # decision after many iterations): the L2 criterion against the reference stays; the pointwise one is "within tol of the
+        # reference, or at least as close to the float64 samples as the reference is"
+        f64 = g[key + "_f64"]
+        r = rel_l2(samp, ref)
+        e_got, e_ref = np.abs(samp - f64).max() / np.abs(f64).max(), np.abs(ref - f64).max() / np.abs(f64).max()
+        record(f"{what}{key} samples", r, tol, float(np.abs(samp - ref).max() / np.abs(ref).max()))
+        record(f"{what}{key} samples: max-abs distance from float64 (reference's own: {e_ref:.2e})", float(e_got), float(e_ref))
+        assert r <= tol, f"{what}{key} samples: rel-L2 {r:.3e}"
+        assert e_got <= e_ref, f"{what}{key} samples: max-abs {e_got:.3e} from float64, the reference is {e_ref:.3e} away"
+    elif scale_key is None:
         assert_close(samp, ref, tol, f"{what}{key} samples", maxabs_mult=maxabs_mult)
     else:
         close_on_scale(samp, ref, g[scale_key][..., ::scale_sub, ::scale_sub], tol, f"{what}{key} samples")
