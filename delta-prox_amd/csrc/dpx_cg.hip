@@ -159,17 +159,6 @@ __global__ void k_cg_update1(float* __restrict__ x, float* __restrict__ r, const
   }
 }
 
-// Ap = Re(z) + c * rho_b * p        (last pass of the masked-Fourier normal operator: A^H A p + n rho p)
-__global__ void k_real_plus_rho(float* __restrict__ Ap, const float2* __restrict__ z, const float* __restrict__ p, const float* __restrict__ rho,
-                                float c, const int* __restrict__ done, long npb) {
-  if (done && done[0]) return;
-  const int b = blockIdx.y;
-  const float cr = c * rho[b];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npb; i += (long)gridDim.x * blockDim.x) {
-    const long e = (long)b * npb + i;
-    Ap[e] = fmaf(cr, p[e], z[e].x);
-  }
-}
 __global__ void k_square(float* __restrict__ out, const float* __restrict__ w, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = w[i] * w[i];
 }
@@ -177,6 +166,11 @@ __global__ void k_square(float* __restrict__ out, const float* __restrict__ w, l
 }  // namespace dpx
 
 using namespace dpx;
+
+namespace dpx {
+int masked_normal_apply(const float* p, float* Ap, float2* z, const float* mask2, int mask_images, const float* rho, float c, const int* done,
+                        int B, int H, int W, const void* table, hipStream_t s);     // dpx_fft.hip
+}
 
 extern "C" size_t dpx_cg_state_bytes(int B) { return B > 0 ? (size_t)(5 * B + 4) * sizeof(float) : 0; }
 
@@ -232,7 +226,8 @@ extern "C" int dpx_zero(void* p, size_t bytes, dpx_stream_t stream) {
 // control is the device-side state machine above; the host side of THIS function only issues kernels and looks at the `done`
 // flag LAG iterations late through a pinned buffer (never blocks on the newest work).  Returns the exit iteration (>= 0, the
 // number the reference prints in "Converged at CG Iter"; max_iters if it did not converge) or a negative status.
-// ws (dpx_cg_masked_fft_ws_bytes): r, p, Ap [B n] floats; two complex [B n] buffers; mask^2; state; Gram; dot workspace.
+// ws (dpx_cg_masked_fft_ws_bytes): r, p, Ap [B n] floats; two complex [B n] buffers (the second one unused since the operator
+// became three fused launches); mask^2; state; Gram; dot workspace.
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_images) {
   const size_t n = (size_t)H * W;
@@ -297,17 +292,9 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
     CG_TRY(dpx_bgram(r, gram, B, n, dotws, stream));
     CG_TRY(dpx_cg_test(state, gram, B, stream));
     CG_TRY(dpx_cg_direction(p, r, state, B, n, stream));
-    {                                                                       // Ap = Re F^-1 mask^2 F p + n rho p
-      const void* xs[1] = {p};
-      const int cplx[1] = {0};
-      const float one[1] = {1.f};
-      CG_TRY(dpx_cplx_lincomb(z0, 1, 1, xs, cplx, one, (long)B * n, stream));
-      CG_TRY(dpx_cfft2(z0, z1, 0, 1, 1, B, H, W, table, stream));
-      CG_TRY(dpx_cplx_scale(z1, z1, mask2, B, n, mask_images, stream));
-      CG_TRY(dpx_cfft2(z1, z0, 1, 1, 1, B, H, W, table, stream));
-      DPX_LAUNCH("k_real_plus_rho", k_real_plus_rho, dim3(grid_for(n, 256, 1024), B), dim3(256), 0, s, Ap, (const float2*)z0, (const float*)p, rho,
-                 n_identity, (const int*)flags, n);
-    }
+    // Ap = Re F^-1 mask^2 F p + n rho p: three launches (row transform of the real p, column transform - mask - inverse column
+    // transform, inverse row transform + real part + rho p) instead of the seven of cfft2 / mask / cfft2^-1 around two copies
+    CG_TRY(masked_normal_apply(p, Ap, z0, mask2, mask_images, rho, n_identity, (const int*)flags, B, H, W, table, s));
     CG_TRY(dpx_bdot(p, Ap, pAp, B, n, dotws, stream));
     CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));
     hipMemcpyAsync(pin + (it & 3) * 4, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);

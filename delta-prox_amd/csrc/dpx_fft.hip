@@ -543,6 +543,105 @@ __global__ void k_ccols(float2* __restrict__ data, int H, int W, Plan1D plan, co
   }
 }
 
+// ---- the masked-Fourier normal operator  Ap = Re F^-1 (mask^2 . F p) + c rho_b p  in three launches (CG matvec of the CS-MRI data
+// term, dpx_cg_masked_fft): the same transforms, index shifts and scale factors as  dpx_cfft2 -> mask^2 -> dpx_cfft2^-1  with the
+// real -> complex copy, the mask pass and the real-part / rho pass folded into the neighbouring transform kernels.
+//   k_crows_real_in : rows of the real image p -> centred orthonormal row spectra (complex)
+//   k_ccols_mask    : forward column transform -> * mask^2 -> inverse column transform, in place (one LDS residency)
+//   k_crows_real_out: inverse row transform -> real part + c rho_b p -> Ap
+__global__ void k_crows_real_in(const float* __restrict__ in, float2* __restrict__ out, int W, int nrows, Plan1D plan,
+                                const float2* __restrict__ twW, int rpb, float scale) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  const int ld = W + 1, hs = W / 2;
+  float2* a = smem;
+  float2* b = smem + rpb * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int row0 = blockIdx.x * rpb;
+  const int nseq = min(rpb, nrows - row0);
+  for (int i = tid; i < nseq * W; i += nthr) {
+    const int s = i / W, n = i - s * W;
+    int src = n + hs;
+    if (src >= W) src -= W;
+    a[s * ld + n] = make_float2(in[(size_t)(row0 + s) * W + src], 0.f);
+  }
+  __syncthreads();
+  const Twid<float2> twd{twW, W};
+  const float2* z = fft_lds<-1, float2>(a, b, plan, twd, 1, nseq, ld, tid, nthr);
+  for (int i = tid; i < nseq * W; i += nthr) {
+    const int s = i / W, k = i - s * W;
+    int dst = k + hs;
+    if (dst >= W) dst -= W;
+    out[(size_t)(row0 + s) * W + dst] = cscale(z[s * ld + k], scale);
+  }
+}
+
+__global__ void k_ccols_mask(float2* __restrict__ data, const float* __restrict__ mask2, int mask_images, int H, int W, Plan1D plan,
+                             const float2* __restrict__ twH, int CT) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  const int ld = H + 1, hs = H / 2;
+  float2* a = smem;
+  float2* b = smem + CT * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int p = blockIdx.y, l0 = blockIdx.x * CT;
+  const int nseq = min(CT, W - l0);
+  float2* base = data + (size_t)p * H * W;
+  const float* mk = mask2 + (mask_images == 1 ? (size_t)0 : (size_t)p * H * W);
+  for (int i = tid; i < H * nseq; i += nthr) {
+    const int r = i / nseq, c = i - r * nseq;
+    int src = r + hs;
+    if (src >= H) src -= H;
+    a[c * ld + r] = base[(size_t)src * W + l0 + c];
+  }
+  __syncthreads();
+  const Twid<float2> twd{twH, H};
+  float2* z = fft_lds<-1, float2>(a, b, plan, twd, 1, nseq, ld, tid, nthr);
+  // bin k would be stored at centred row (k + hs) % H, which is where the inverse transform reads its input r = k from: the two
+  // shifts cancel, only the mask is indexed with the centred row
+  for (int i = tid; i < H * nseq; i += nthr) {
+    const int k = i / nseq, c = i - k * nseq;
+    int row = k + hs;
+    if (row >= H) row -= H;
+    z[c * ld + k] = cscale(z[c * ld + k], mk[(size_t)row * W + l0 + c]);
+  }
+  __syncthreads();
+  const float2* y = fft_lds<+1, float2>(z, z == a ? b : a, plan, twd, 1, nseq, ld, tid, nthr);
+  for (int i = tid; i < H * nseq; i += nthr) {
+    const int k = i / nseq, c = i - k * nseq;
+    int dst = k + hs;
+    if (dst >= H) dst -= H;
+    base[(size_t)dst * W + l0 + c] = y[c * ld + k];
+  }
+}
+
+__global__ void k_crows_real_out(const float2* __restrict__ in, float* __restrict__ out, const float* __restrict__ pin, const float* __restrict__ rho,
+                                 float c, const int* __restrict__ done, int rows_per_image, int W, int nrows, Plan1D plan,
+                                 const float2* __restrict__ twW, int rpb, float scale) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  if (done && done[0]) return;                          // (block-uniform: the solve has converged, this launch ran ahead)
+  const int ld = W + 1, hs = W / 2;
+  float2* a = smem;
+  float2* b = smem + rpb * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int row0 = blockIdx.x * rpb;
+  const int nseq = min(rpb, nrows - row0);
+  for (int i = tid; i < nseq * W; i += nthr) {
+    const int s = i / W, n = i - s * W;
+    int src = n + hs;
+    if (src >= W) src -= W;
+    a[s * ld + n] = in[(size_t)(row0 + s) * W + src];
+  }
+  __syncthreads();
+  const Twid<float2> twd{twW, W};
+  const float2* z = fft_lds<+1, float2>(a, b, plan, twd, 1, nseq, ld, tid, nthr);
+  for (int i = tid; i < nseq * W; i += nthr) {
+    const int s = i / W, k = i - s * W;
+    int dst = k + hs;
+    if (dst >= W) dst -= W;
+    const size_t e = (size_t)(row0 + s) * W + dst;
+    out[e] = fmaf(c * rho[(row0 + s) / rows_per_image], pin[e], z[s * ld + k].x * scale);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -598,6 +697,28 @@ int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, i
   else
     DPX_LAUNCH("k_rows_c2r", (k_rows_c2r<false>), grow, dim3(256), shrow, stream, spec, y, W, nrows, prow, tw_rows(table), rpb, 1.0f);
   return launch_status("spectral_apply");
+}
+
+// z: one complex [B][H][W] scratch plane set.  Returns DPX_ERR_UNSUPPORTED for planes beyond the LDS-resident transform.
+int masked_normal_apply(const float* p, float* Ap, float2* z, const float* mask2, int mask_images, const float* rho, float c, const int* done,
+                        int B, int H, int W, const void* table, hipStream_t s) {
+  const Plan1D prow = make_plan(W), pcol = make_plan(H);
+  const int rpb = rows_per_block(W);
+  const size_t shrow = (size_t)2 * rpb * (W + 1) * sizeof(float2);
+  int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
+  CT = CT < 1 ? 1 : (CT > 16 ? 16 : CT);
+  const size_t shcol = (size_t)2 * CT * (H + 1) * sizeof(float2);
+  if (shrow > 64 * 1024 || shcol > 64 * 1024) {
+    set_error("masked_normal_apply: plane %dx%d too large for the LDS-resident transform", H, W);
+    return DPX_ERR_UNSUPPORTED;
+  }
+  const float scale = 1.0f / sqrtf((float)H * (float)W);
+  const dim3 grow((B * H + rpb - 1) / rpb), gcol((W + CT - 1) / CT, B);
+  DPX_LAUNCH("k_crows_real_in", k_crows_real_in, grow, dim3(256), shrow, s, p, z, W, B * H, prow, tw_rows(table), rpb, scale);
+  DPX_LAUNCH("k_ccols_mask", k_ccols_mask, gcol, dim3(256), shcol, s, z, mask2, mask_images, H, W, pcol, tw_cols(table, W), CT);
+  DPX_LAUNCH("k_crows_real_out", k_crows_real_out, grow, dim3(256), shrow, s, (const float2*)z, Ap, p, rho, c, done, H, W, B * H, prow,
+             tw_rows(table), rpb, scale);
+  return launch_status("masked_normal_apply");
 }
 
 }  // namespace dpx

@@ -45,8 +45,8 @@ if "c3" in which:
     print(f"config3 8x3x1024x1024 PnP(FFDNet-color, random weights) ADMM 30 it: {dt/30*1e3:.2f} ms/it = {30/dt:.1f} it/s; "
           f"denoiser FLOP rate {flop*30/dt/1e12:.1f} TFLOP/s = {flop*30/dt/157.3e12*100:.0f}% of fp32 MFMA peak; path={s.last_path}")
 
-if "c4" in which:
-    B, H, W = 32, 320, 320
+if "c4" in which or "c4s" in which:
+    B, H, W = (4 if "c4s" in which else 32), 320, 320        # c4s: one GPU's shard of the batch
     gt, mask, y = synthetic.csmri_case(B, H, W, seed=2023)
     mask_d, y_d = torch.from_numpy(mask).to(dev), torch.from_numpy(y).to(dev)
     class MaskedFFT(dp.LinOp):
@@ -60,7 +60,7 @@ if "c4" in which:
     x0 = ifft2(y_d).real.contiguous()
     with torch.no_grad():
         dt, out = timed(lambda: s.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=10), 1)
-    print(f"config4 32x1x320x320 CS-MRI LADMM+CG(<=100) + nonneg + FFDNet-gray, 10 outer it: {dt/10*1e3:.1f} ms/outer it, CG its {s.least_square.cg_iters[-10:]}, "
+    print(f"config4 {B}x1x320x320 CS-MRI LADMM+CG(<=100) + nonneg + FFDNet-gray, 10 outer it: {dt/10*1e3:.3f} ms/outer it, CG its {s.least_square.cg_iters[-10:]}, "
           f"(the seeded random-weight 'denoiser' is not a denoiser: output quality is meaningless here; parity is pinned by fixture G7)")
 
 if "c5" in which:
