@@ -153,10 +153,11 @@ struct RhsBwdPack {
   int linop[DPX_MAX_TERMS];
   float* gv[DPX_MAX_TERMS];
   float* gu[DPX_MAX_TERMS];
+  const float* gu_add[DPX_MAX_TERMS];      // nullable: gu = gu_add - gv  (the z stage's share of the gradient w.r.t. the dual)
   int n;
 };
 
-// g_v_i = rho_b K_i g, g_u_i = -g_v_i; part[b][blk] = sum g * rhs  (the host divides by rho)
+// g_v_i = rho_b K_i g, g_u_i = (gu_add_i) - g_v_i; part[b][blk] = sum g * rhs  (the finishing pass divides by rho)
 __global__ void __launch_bounds__(256) k_rhs_bwd(const float* __restrict__ g, const float* __restrict__ rhs, const float* __restrict__ rho,
                                                   RhsBwdPack T, float* __restrict__ part, int C, int H, int W) {
   __shared__ float sh[16];
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(256) k_rhs_bwd(const float* __restrict__ g, co
         else kg = g[i + (long)((h + 1 == H ? 0 : h + 1) - h) * W] - gc;
         kg *= r;
         if (T.gv[t]) T.gv[t][i] = kg;
-        if (T.gu[t]) T.gu[t][i] = -kg;
+        if (T.gu[t]) T.gu[t][i] = (T.gu_add[t] ? T.gu_add[t][i] : 0.f) - kg;
       }
     }
   }
@@ -188,12 +189,36 @@ __global__ void __launch_bounds__(256) k_rhs_bwd(const float* __restrict__ g, co
   if (threadIdx.x == 0) part[(long)b * gridDim.x + blockIdx.x] = s;
 }
 
-__global__ void k_ad_finish(const float* __restrict__ part, float* __restrict__ out, int nblk, const float* __restrict__ div) {
+__global__ void k_ad_finish(const float* __restrict__ part, float* __restrict__ out, int nblk, const float* __restrict__ div,
+                            const float* __restrict__ add) {
   __shared__ float sh[16];
   float acc = 0.f;
   for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += part[(long)blockIdx.x * nblk + i];
   acc = ad_block_sum(acc, sh);
-  if (threadIdx.x == 0) out[blockIdx.x] = div ? acc / div[blockIdx.x] : acc;
+  if (threadIdx.x == 0) out[blockIdx.x] = (div ? acc / div[blockIdx.x] : acc) + (add ? add[blockIdx.x] : 0.f);
+}
+
+// the three reductions of one unrolled backward iteration in one launch: block j < n B: glam[j] = sum part_lam[j][*];
+// block n B + b: grho[b] = sum part_a[b][*] + (sum part_b[b][*]) / rho[b]     (same summation order as three k_ad_finish launches)
+__global__ void k_ad_finish_iter(const float* __restrict__ part_lam, const float* __restrict__ part_a, const float* __restrict__ part_b,
+                                 float* __restrict__ glam, float* __restrict__ grho, const float* __restrict__ rho, int nB, int nblk) {
+  __shared__ float sh[16];
+  const int j = blockIdx.x;
+  if (j < nB) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += part_lam[(long)j * nblk + i];
+    acc = ad_block_sum(acc, sh);
+    if (threadIdx.x == 0) glam[j] = acc;
+  } else {
+    const int b = j - nB;
+    float a = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) a += part_a[(long)b * nblk + i];
+    a = ad_block_sum(a, sh);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) c += part_b[(long)b * nblk + i];
+    c = ad_block_sum(c, sh);
+    if (threadIdx.x == 0) grho[b] = a + c / rho[b];
+  }
 }
 
 static int ad_blocks(long npb) {
@@ -208,6 +233,34 @@ using namespace dpx;
 extern "C" size_t dpx_admm_bwd_ws_bytes(int B, int C, int H, int W) {
   return (size_t)DPX_MAX_TERMS * B * ad_blocks((long)C * H * W) * sizeof(float);
 }
+
+namespace dpx {
+int ad_partial_blocks(int C, int H, int W) { return ad_blocks((long)C * H * W); }
+// the stage kernels of the unrolled backward pass without their finishing launches: partial sums [rows][nblk] into `part`
+int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float* part, int B, int C, int H, int W, hipStream_t s) {
+  BwdPack T;
+  T.n = nterms;
+  for (int i = 0; i < nterms; ++i) {
+    DPX_REQUIRE(terms[i].v && terms[i].gu, "dpx_admm_zupdate_bwd: term %d lacks v / gu", i);
+    T.t[i] = BwdTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].v, terms[i].gv, terms[i].gu_new, terms[i].gu};
+  }
+  DPX_LAUNCH("k_zupdate_bwd", k_zupdate_bwd, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, gx, T, part, C, H, W);
+  return launch_status("dpx_admm_zupdate_bwd");
+}
+int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int B, int C, int H, int W, hipStream_t s) {
+  LinCodes L;
+  L.n = nterms;
+  for (int i = 0; i < nterms; ++i) L.linop[i] = linops[i];
+  DPX_LAUNCH("k_solve_rho_grad", k_solve_rho_grad, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g_rhs, x, L, part, C, H, W);
+  return launch_status("dpx_admm_solve_rho_grad");
+}
+int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
+                int C, int H, int W, hipStream_t s) {
+  DPX_LAUNCH("k_ad_finish_iter", k_ad_finish_iter, dim3(nterms * B + B), dim3(256), 0, s, part_lam, part_a, part_b, glam, grho, rho, nterms * B,
+             ad_blocks((long)C * H * W));
+  return launch_status("dpx_admm_unrolled_backward");
+}
+}  // namespace dpx
 
 extern "C" int dpx_admm_zupdate_bwd(float* gx, const dpx_bwd_term* terms, int nterms, float* glam, int B, int C, int H, int W, void* ws,
                                     dpx_stream_t stream) {
@@ -224,7 +277,7 @@ extern "C" int dpx_admm_zupdate_bwd(float* gx, const dpx_bwd_term* terms, int nt
   const int nblk = ad_blocks((long)C * H * W);
   hipStream_t s = (hipStream_t)stream;
   DPX_LAUNCH("k_zupdate_bwd", k_zupdate_bwd, dim3(nblk, B), dim3(256), 0, s, gx, T, (float*)ws, C, H, W);
-  DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(nterms * B), dim3(256), 0, s, (const float*)ws, glam, nblk, (const float*)nullptr);
+  DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(nterms * B), dim3(256), 0, s, (const float*)ws, glam, nblk, (const float*)nullptr, (const float*)nullptr);
   return launch_status("dpx_admm_zupdate_bwd");
 }
 
@@ -238,24 +291,34 @@ extern "C" int dpx_admm_solve_rho_grad(const float* g_rhs, const float* x, const
   const int nblk = ad_blocks((long)C * H * W);
   hipStream_t s = (hipStream_t)stream;
   DPX_LAUNCH("k_solve_rho_grad", k_solve_rho_grad, dim3(nblk, B), dim3(256), 0, s, g_rhs, x, L, (float*)ws, C, H, W);
-  DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(B), dim3(256), 0, s, (const float*)ws, grho, nblk, (const float*)nullptr);
+  DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(B), dim3(256), 0, s, (const float*)ws, grho, nblk, (const float*)nullptr, (const float*)nullptr);
   return launch_status("dpx_admm_solve_rho_grad");
 }
 
-extern "C" int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv,
-                                float* const* gu, float* grho, int B, int C, int H, int W, void* ws, dpx_stream_t stream) {
-  DPX_REQUIRE(g && rhs && rho && linops && gv && gu && grho && ws && nterms >= 1 && nterms <= DPX_MAX_TERMS,
-              "dpx_admm_rhs_bwd: bad arguments");
+namespace dpx {
+// dpx_admm_rhs_bwd with the two sums that follow it in the unrolled backward pass folded in: gu[i] = gu_add[i] - gv[i] and
+// grho = <g, rhs> / rho + grho_add (both additions nullable)
+int rhs_bwd_impl(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv, float* const* gu,
+                 const float* const* gu_add, float* grho, const float* grho_add, int B, int C, int H, int W, void* ws, hipStream_t s) {
   RhsBwdPack T;
   T.n = nterms;
   for (int i = 0; i < nterms; ++i) {
     T.linop[i] = linops[i];
     T.gv[i] = gv[i];
     T.gu[i] = gu[i];
+    T.gu_add[i] = gu_add ? gu_add[i] : nullptr;
   }
   const int nblk = ad_blocks((long)C * H * W);
-  hipStream_t s = (hipStream_t)stream;
   DPX_LAUNCH("k_rhs_bwd", k_rhs_bwd, dim3(nblk, B), dim3(256), 0, s, g, rhs, rho, T, (float*)ws, C, H, W);
-  DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(B), dim3(256), 0, s, (const float*)ws, grho, nblk, rho);
+  if (grho)                                             // (NULL: the caller finishes the partial sums in `ws` itself)
+    DPX_LAUNCH("k_ad_finish", k_ad_finish, dim3(B), dim3(256), 0, s, (const float*)ws, grho, nblk, rho, grho_add);
   return launch_status("dpx_admm_rhs_bwd");
+}
+}  // namespace dpx
+
+extern "C" int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv,
+                                float* const* gu, float* grho, int B, int C, int H, int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(g && rhs && rho && linops && gv && gu && grho && ws && nterms >= 1 && nterms <= DPX_MAX_TERMS,
+              "dpx_admm_rhs_bwd: bad arguments");
+  return rhs_bwd_impl(g, rhs, rho, linops, nterms, gv, gu, nullptr, grho, nullptr, B, C, H, W, ws, (hipStream_t)stream);
 }

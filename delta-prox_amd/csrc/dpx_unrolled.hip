@@ -20,6 +20,13 @@
 using namespace dpx;
 
 namespace dpx {
+int ad_partial_blocks(int C, int H, int W);
+int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float* part, int B, int C, int H, int W, hipStream_t s);
+int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int B, int C, int H, int W, hipStream_t s);
+int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
+                int C, int H, int W, hipStream_t s);
+int rhs_bwd_impl(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv, float* const* gu,
+                 const float* const* gu_add, float* grho, const float* grho_add, int B, int C, int H, int W, void* ws, hipStream_t s);   // dpx_autodiff.hip
 // (2 + n) fp32 planes <-> one bf16 history slot, round-to-nearest-even
 struct PlanePack {
   float* p[2 + DPX_MAX_TERMS];
@@ -139,9 +146,10 @@ extern "C" int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float
   return launch_status("dpx_admm_unrolled_forward_bf16");
 }
 
-// workspace: (4 + 6 n) planes + 2 B floats, followed by dpx_admm_bwd_ws_bytes
+// workspace: (4 + 6 n) planes + 2 B floats, followed by the partial sums of one iteration's three reductions ((n + 2) B rows)
 extern "C" size_t dpx_admm_unrolled_bwd_ws_bytes(int nterms, int B, int C, int H, int W) {
-  return ((size_t)(4 + 6 * nterms) * B * C * H * W + 2 * (size_t)B + 64) * sizeof(float) + dpx_admm_bwd_ws_bytes(B, C, H, W);
+  return ((size_t)(4 + 6 * nterms) * B * C * H * W + 2 * (size_t)B + 64) * sizeof(float) +
+         (size_t)(DPX_MAX_TERMS + 2) * B * ad_partial_blocks(C, H, W) * sizeof(float);
 }
 
 // gx / gv_in[i] / gu_in[i]: gradients w.r.t. the final x, v_i, u_i (any may be NULL = 0).
@@ -173,8 +181,9 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
   float* gu_b = gu_a + n * px;               // n planes
   float* set[2] = {gu_b + n * px, gu_b + 3 * n * px};   // each: gv[n] then gu[n]
   float* rho_a = set[1] + 2 * n * px;
-  float* rho_b = rho_a + B;
-  void* bws = (void*)(rho_a + ((2 * B + 63) / 64) * 64);
+  float* part_lam = rho_a + ((2 * B + 63) / 64) * 64;      // partial sums: [n B][nblk], [B][nblk], [B][nblk]
+  float* part_a = part_lam + (size_t)DPX_MAX_TERMS * B * ad_partial_blocks(C, H, W);
+  float* part_b = part_a + (size_t)B * ad_partial_blocks(C, H, W);
   const float one2[2] = {1.f, 1.f};
   const float* cur_gv[DPX_MAX_TERMS];
   const float* cur_gu[DPX_MAX_TERMS];
@@ -196,7 +205,7 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
     dpx_bwd_term bt[DPX_MAX_TERMS];
     for (int i = 0; i < n; ++i)
       bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, H_v(it, i), cur_gv[i], cur_gu[i], gu_a + i * px};
-    DPX_TRY(dpx_admm_zupdate_bwd(gxz, bt, n, glam + (size_t)it * n * B, B, C, H, W, bws, stream));
+    DPX_TRY(zupdate_bwd_partials(gxz, bt, n, part_lam, B, C, H, W, (hipStream_t)stream));
     const float* g = gxz;
     if (it == T - 1 && gx) {
       const float* xs[2] = {gx, gxz};
@@ -204,7 +213,7 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
       g = gtot;
     }
     DPX_TRY(dpx_fourier_apply_inv(g, grhs, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
-    DPX_TRY(dpx_admm_solve_rho_grad(grhs, H_x(it), linops, n, rho_a, B, C, H, W, bws, stream));
+    DPX_TRY(solve_rho_grad_partials(grhs, H_x(it), linops, n, part_a, B, C, H, W, (hipStream_t)stream));
     for (int k = 0; k < n_off; ++k) {
       if (!goff[k]) continue;
       if (off_otf[k]) {
@@ -223,20 +232,17 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
     // gradients w.r.t. the previous iteration's v_i, u_i (the last step writes the caller's outputs directly)
     float* nv[DPX_MAX_TERMS];
     float* nu[DPX_MAX_TERMS];
-    float* gub[DPX_MAX_TERMS];
     for (int i = 0; i < n; ++i) {
       nv[i] = it ? set[it & 1] + (size_t)i * px : gv0[i];
       nu[i] = it ? set[it & 1] + (size_t)(n + i) * px : gu0[i];
-      gub[i] = gu_b + (size_t)i * px;
     }
-    DPX_TRY(dpx_admm_rhs_bwd(grhs, H_rhs(it), rho, linops, n, nv, gub, rho_b, B, C, H, W, bws, stream));
-    {
-      const float* xs[2] = {rho_a, rho_b};
-      DPX_TRY(dpx_lincomb(grho + (size_t)it * B, 2, xs, one2, nullptr, 1, (long)B, stream));
-    }
+    // rhs stage, with the sum of the two stages' shares of the dual gradient folded in: gu_prev_i = gu_a_i - gv_i
+    const float* gua[DPX_MAX_TERMS];
+    for (int i = 0; i < n; ++i) gua[i] = gu_a + (size_t)i * px;
+    DPX_TRY(rhs_bwd_impl(grhs, H_rhs(it), rho, linops, n, nv, nu, gua, nullptr, nullptr, B, C, H, W, part_b, (hipStream_t)stream));
+    // ... and the iteration's three reductions (d/d lam_i, the two shares of d/d rho) finished by one launch
+    DPX_TRY(finish_iter(part_lam, part_a, part_b, glam + (size_t)it * n * B, grho + (size_t)it * B, rho, n, B, C, H, W, (hipStream_t)stream));
     for (int i = 0; i < n; ++i) {
-      const float* xs[2] = {gu_a + (size_t)i * px, gub[i]};
-      DPX_TRY(dpx_lincomb(nu[i], 2, xs, one2, nullptr, B, (long)(px / B), stream));
       cur_gv[i] = nv[i];
       cur_gu[i] = nu[i];
     }
