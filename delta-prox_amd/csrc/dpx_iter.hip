@@ -32,6 +32,8 @@ struct IterTerm {
 struct IterTerms {
   IterTerm t[DPX_MAX_TERMS];
   int n;
+  float* rhs_out;      // nullable: the next x-update's right-hand-side increment rho' sum K_i^T (v_i - u_i) as an image (the unrolled
+                       // forward pass keeps it for the backward pass); like x_out / v_out an emit store, never counted in the waits
 };
 
 __device__ __forceinline__ float prox1(int kind, float d, float lam) {
@@ -221,6 +223,11 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
       }
 #pragma unroll
       for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
+      if (TT.rhs_out && z_own) {
+        float2* ro = (float2*)(TT.rhs_out + plane_px + (size_t)hz * (2 * M));
+#pragma unroll
+        for (int m = 0; m < V; ++m) ro[t + m * T] = z[m];
+      }
       WaveSync()();
       fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
       float2* out = sout_main + (unsigned)hz * SPEC_TILE + tile_off;
@@ -531,6 +538,11 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
         float2 z[V];
 #pragma unroll
         for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
+        if (TT.rhs_out) {
+          float2* ro = (float2*)TT.rhs_out + (unsigned)pl * H * M + hz * M;
+#pragma unroll
+          for (int m = 0; m < V; ++m) ro[t + m * T] = z[m];
+        }
         WaveSync()();
         fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
         float2* out = spec_out + tile_off + hz * SPEC_TILE;
@@ -594,6 +606,10 @@ int rows_r2c_pow2(const float* x, float2* spec, int P, int H, int W, const void*
 }  // namespace dpx
 
 using namespace dpx;
+namespace dpx {
+int iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
+                   float* rhs_out, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
+}
 
 static int terms_ok(const dpx_term* terms, int nterms) {
   if (nterms < 1 || nterms > DPX_MAX_TERMS || !terms) return 0;
@@ -642,10 +658,17 @@ extern "C" int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const voi
 
 extern "C" int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next,
                                   float* x_out, int emit_v, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
+  return dpx::iter_rows_impl(spec_in, spec_out, terms, nterms, rho_next, x_out, emit_v, nullptr, B, C, H, W, table, stream);
+}
+
+// + rhs_out (nullable): the right-hand-side increment handed to the next x-update, also written as an image
+int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
+                        float* rhs_out, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
   DPX_REQUIRE(spec_in && table && (spec_out || !rho_next), "dpx_admm_iter_rows: null pointer");
   DPX_REQUIRE(dpx_admm_iter_supported(H, W, terms, nterms), "dpx_admm_iter_rows: unsupported problem (plane %dx%d, %d terms)", H, W, nterms);
   IterTerms TT;
   TT.n = nterms;
+  TT.rhs_out = rho_next ? rhs_out : nullptr;
   for (int i = 0; i < nterms; ++i) {
     DPX_REQUIRE(terms[i].u && (terms[i].u_out) && (!emit_v || terms[i].v), "dpx_admm_iter_rows: term %d lacks u / u_out / v", i);
     DPX_REQUIRE(terms[i].u != terms[i].u_out, "dpx_admm_iter_rows: u must be double-buffered (u_out != u)");

@@ -25,6 +25,8 @@ int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float
 int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int B, int C, int H, int W, hipStream_t s);
 int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
                 int C, int H, int W, hipStream_t s);
+int iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
+                   float* rhs_out, int B, int C, int H, int W, const void* table, dpx_stream_t stream);   // dpx_iter.hip
 int rhs_bwd_impl(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv, float* const* gu,
                  const float* const* gu_add, float* grho, const float* grho_add, int B, int C, int H, int W, void* ws, hipStream_t s);   // dpx_autodiff.hip
 // (2 + n) fp32 planes <-> one bf16 history slot, round-to-nearest-even
@@ -77,6 +79,31 @@ extern "C" int dpx_admm_unrolled_forward(float* hist, const float* const* v0, co
               "dpx_admm_unrolled_forward: null pointer");
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && T >= 1 && B > 0 && C > 0 && H > 0 && W > 0, "dpx_admm_unrolled_forward: bad sizes");
   const Hist h{hist, (size_t)B * C * H * W, nterms};
+  {
+    // power-of-two planes with stencil terms: the two-kernel iteration of dpx_admm_run, its row kernel emitting the history (x, v_i,
+    // the next right-hand side; u_i are its outputs anyway) -- 2 launches per iteration instead of 5
+    dpx_term probe[DPX_MAX_TERMS];
+    for (int i = 0; i < nterms; ++i) probe[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i], h.v(0, i), (float*)u0[i], h.u(0, i)};
+    if (dpx_admm_iter_supported(H, W, probe, nterms) && dpx_spectrum_bytes(B * C, H, W) > 0) {
+      char* spec_a = (char*)spectrum_ws;
+      char* spec_b = spec_a + dpx_spectrum_bytes(B * C, H, W) / 2;
+      dpx_term rt[DPX_MAX_TERMS];
+      for (int i = 0; i < nterms; ++i) rt[i] = dpx_term{linops[i], proxes[i], 1.0f, 0, nullptr, (float*)v0[i], (float*)u0[i], nullptr};
+      DPX_TRY(dpx_admm_rhs(h.rhs(0), nullptr, rho_tab, rt, nterms, B, C, H, W, stream));
+      DPX_TRY(dpx_rfft_rows(h.rhs(0), spec_a, B, C, H, W, table, stream));
+      for (int it = 0; it < T; ++it) {
+        const float* rho = rho_tab + (size_t)it * B;
+        DPX_TRY(dpx_admm_iter_cols(spec_a, spec_b, spec_add, dd, rho, eps, B, C, H, W, table, stream));
+        dpx_term zt[DPX_MAX_TERMS];
+        for (int i = 0; i < nterms; ++i)
+          zt[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, h.v(it, i), it ? h.u(it - 1, i) : (float*)u0[i], h.u(it, i)};
+        const bool last = it == T - 1;
+        DPX_TRY(iter_rows_impl(spec_b, last ? nullptr : spec_a, zt, nterms, last ? nullptr : rho_tab + (size_t)(it + 1) * B, h.x(it), 1,
+                               last ? nullptr : h.rhs(it + 1), B, C, H, W, table, stream));
+      }
+      return DPX_OK;
+    }
+  }
   for (int it = 0; it < T; ++it) {
     dpx_term rt[DPX_MAX_TERMS], zt[DPX_MAX_TERMS];
     for (int i = 0; i < nterms; ++i) {
