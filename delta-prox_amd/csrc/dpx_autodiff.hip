@@ -44,12 +44,13 @@ struct BwdTerm {
 struct BwdPack {
   BwdTerm t[DPX_MAX_TERMS];
   int n;
+  int hist_bf16;        // the saved planes (v here, x / rhs in the other two stages) are bf16 history slots, not fp32
 };
 
 // g_d of one term at one pixel (offset i), and dprox/dlam * (g_v - g_u') for the lambda gradient
-__device__ __forceinline__ float zb_gd(const BwdTerm& tm, long i, float lam, float& lam_term) {
+__device__ __forceinline__ float zb_gd(const BwdTerm& tm, long i, float lam, float& lam_term, int hist_bf16) {
   const float gv = tm.gv ? tm.gv[i] : 0.f, gu = tm.gun ? tm.gun[i] : 0.f;
-  const float diff = gv - gu, v = tm.v[i];
+  const float diff = gv - gu, v = dpx_hist_load(tm.v, hist_bf16, i);
   float J, dl;
   if (tm.prox == DPX_PROX_NORM1) {
     J = v != 0.f ? 1.f : 0.f;
@@ -86,17 +87,17 @@ __global__ void __launch_bounds__(256) k_zupdate_bwd(float* __restrict__ gx, Bwd
         const BwdTerm& tm = T.t[t];
         const float lam = tm.lam ? tm.lam[b] * tm.alpha : 0.f;
         float lt, dummy;
-        const float gd = zb_gd(tm, i, lam, lt);
+        const float gd = zb_gd(tm, i, lam, lt, T.hist_bf16);
         lsum[t] += lt;
         tm.gu[i] = gd;
         if (tm.linop == DPX_LIN_IDENTITY) {
           acc += gd;
         } else if (tm.linop == DPX_LIN_GRAD_W) {           // adjoint: y[w-1] - y[w]
           const long il = base + row * W + (w == 0 ? W - 1 : w - 1);
-          acc += zb_gd(tm, il, lam, dummy) - gd;
+          acc += zb_gd(tm, il, lam, dummy, T.hist_bf16) - gd;
         } else {                                            // grad_H adjoint: y[h-1] - y[h]
           const long iu = i + (long)((h == 0 ? H - 1 : h - 1) - h) * W;
-          acc += zb_gd(tm, iu, lam, dummy) - gd;
+          acc += zb_gd(tm, iu, lam, dummy, T.hist_bf16) - gd;
         }
       }
     }
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(256) k_zupdate_bwd(float* __restrict__ gx, Bwd
 struct LinCodes {
   int linop[DPX_MAX_TERMS];
   int n;
+  int hist_bf16;
 };
 
 // part[b][blk] = - sum_p g[p] * (sum_i K_i^T K_i x)[p]
@@ -133,14 +135,14 @@ __global__ void __launch_bounds__(256) k_solve_rho_grad(const float* __restrict_
     const long row = p / W;
     const int h = (int)(row % H);
     const long i = base + p;
-    const float xc = x[i];
+    const float xc = dpx_hist_load(x, L.hist_bf16, i);
     float lx = cI * xc;
     if (hasW) {
-      const float xl = x[base + row * W + (w == 0 ? W - 1 : w - 1)], xr = x[base + row * W + (w + 1 == W ? 0 : w + 1)];
+      const float xl = dpx_hist_load(x, L.hist_bf16, base + row * W + (w == 0 ? W - 1 : w - 1)), xr = dpx_hist_load(x, L.hist_bf16, base + row * W + (w + 1 == W ? 0 : w + 1));
       lx += (float)nW * (2.f * xc - xl - xr);             // K^T K of the circular forward difference
     }
     if (hasH) {
-      const float xu = x[i + (long)((h == 0 ? H - 1 : h - 1) - h) * W], xd = x[i + (long)((h + 1 == H ? 0 : h + 1) - h) * W];
+      const float xu = dpx_hist_load(x, L.hist_bf16, i + (long)((h == 0 ? H - 1 : h - 1) - h) * W), xd = dpx_hist_load(x, L.hist_bf16, i + (long)((h + 1 == H ? 0 : h + 1) - h) * W);
       lx += (float)nH * (2.f * xc - xu - xd);
     }
     acc = fmaf(g[i], lx, acc);
@@ -155,6 +157,7 @@ struct RhsBwdPack {
   float* gu[DPX_MAX_TERMS];
   const float* gu_add[DPX_MAX_TERMS];      // nullable: gu = gu_add - gv  (the z stage's share of the gradient w.r.t. the dual)
   int n;
+  int hist_bf16;
 };
 
 // g_v_i = rho_b K_i g, g_u_i = (gu_add_i) - g_v_i; part[b][blk] = sum g * rhs  (the finishing pass divides by rho)
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(256) k_rhs_bwd(const float* __restrict__ g, co
     const int h = (int)(row % H);
     const long i = base + p;
     const float gc = g[i];
-    acc = fmaf(gc, rhs[i], acc);
+    acc = fmaf(gc, dpx_hist_load(rhs, T.hist_bf16, i), acc);
 #pragma unroll
     for (int t = 0; t < DPX_MAX_TERMS; ++t) {
       if (t < T.n) {
@@ -237,9 +240,10 @@ extern "C" size_t dpx_admm_bwd_ws_bytes(int B, int C, int H, int W) {
 namespace dpx {
 int ad_partial_blocks(int C, int H, int W) { return ad_blocks((long)C * H * W); }
 // the stage kernels of the unrolled backward pass without their finishing launches: partial sums [rows][nblk] into `part`
-int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float* part, int B, int C, int H, int W, hipStream_t s) {
+int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float* part, int hist_bf16, int B, int C, int H, int W, hipStream_t s) {
   BwdPack T;
   T.n = nterms;
+  T.hist_bf16 = hist_bf16;
   for (int i = 0; i < nterms; ++i) {
     DPX_REQUIRE(terms[i].v && terms[i].gu, "dpx_admm_zupdate_bwd: term %d lacks v / gu", i);
     T.t[i] = BwdTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].v, terms[i].gv, terms[i].gu_new, terms[i].gu};
@@ -247,9 +251,11 @@ int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float
   DPX_LAUNCH("k_zupdate_bwd", k_zupdate_bwd, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, gx, T, part, C, H, W);
   return launch_status("dpx_admm_zupdate_bwd");
 }
-int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int B, int C, int H, int W, hipStream_t s) {
+int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int hist_bf16, int B, int C, int H, int W,
+                            hipStream_t s) {
   LinCodes L;
   L.n = nterms;
+  L.hist_bf16 = hist_bf16;
   for (int i = 0; i < nterms; ++i) L.linop[i] = linops[i];
   DPX_LAUNCH("k_solve_rho_grad", k_solve_rho_grad, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g_rhs, x, L, part, C, H, W);
   return launch_status("dpx_admm_solve_rho_grad");
@@ -268,6 +274,7 @@ extern "C" int dpx_admm_zupdate_bwd(float* gx, const dpx_bwd_term* terms, int nt
               "dpx_admm_zupdate_bwd: bad arguments");
   BwdPack T;
   T.n = nterms;
+  T.hist_bf16 = 0;
   for (int i = 0; i < nterms; ++i) {
     DPX_REQUIRE(terms[i].v && terms[i].gu, "dpx_admm_zupdate_bwd: term %d lacks v / gu", i);
     DPX_REQUIRE(terms[i].linop >= DPX_LIN_IDENTITY && terms[i].linop <= DPX_LIN_GRAD_W && terms[i].prox >= DPX_PROX_NORM1 &&
@@ -287,6 +294,7 @@ extern "C" int dpx_admm_solve_rho_grad(const float* g_rhs, const float* x, const
               "dpx_admm_solve_rho_grad: bad arguments");
   LinCodes L;
   L.n = nterms;
+  L.hist_bf16 = 0;
   for (int i = 0; i < nterms; ++i) L.linop[i] = linops[i];
   const int nblk = ad_blocks((long)C * H * W);
   hipStream_t s = (hipStream_t)stream;
@@ -299,9 +307,10 @@ namespace dpx {
 // dpx_admm_rhs_bwd with the two sums that follow it in the unrolled backward pass folded in: gu[i] = gu_add[i] - gv[i] and
 // grho = <g, rhs> / rho + grho_add (both additions nullable)
 int rhs_bwd_impl(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv, float* const* gu,
-                 const float* const* gu_add, float* grho, const float* grho_add, int B, int C, int H, int W, void* ws, hipStream_t s) {
+                 const float* const* gu_add, float* grho, const float* grho_add, int hist_bf16, int B, int C, int H, int W, void* ws, hipStream_t s) {
   RhsBwdPack T;
   T.n = nterms;
+  T.hist_bf16 = hist_bf16;
   for (int i = 0; i < nterms; ++i) {
     T.linop[i] = linops[i];
     T.gv[i] = gv[i];
@@ -320,5 +329,5 @@ extern "C" int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* r
                                 float* const* gu, float* grho, int B, int C, int H, int W, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(g && rhs && rho && linops && gv && gu && grho && ws && nterms >= 1 && nterms <= DPX_MAX_TERMS,
               "dpx_admm_rhs_bwd: bad arguments");
-  return rhs_bwd_impl(g, rhs, rho, linops, nterms, gv, gu, nullptr, grho, nullptr, B, C, H, W, ws, (hipStream_t)stream);
+  return rhs_bwd_impl(g, rhs, rho, linops, nterms, gv, gu, nullptr, grho, nullptr, 0, B, C, H, W, ws, (hipStream_t)stream);
 }

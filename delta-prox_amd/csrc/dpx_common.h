@@ -133,6 +133,21 @@ template <int NT> __device__ __forceinline__ float2 ld_stream(const float2* p) {
 #endif
 }
 
+// ---- bf16 history planes of the unrolled iteration (round to nearest even on the way in, exact on the way out) --------------------
+__device__ __forceinline__ unsigned dpx_bf16_bits(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// element pair `idx` of a plane that is fp32 (float2) or bf16 (two 16-bit values in one dword)
+__device__ __forceinline__ void dpx_emit_pair(float* plane, int bf16, size_t idx, float2 v) {
+  if (bf16) ((unsigned*)plane)[idx] = dpx_bf16_bits(v.x) | (dpx_bf16_bits(v.y) << 16);
+  else ((float2*)plane)[idx] = v;
+}
+// element i of a saved plane that is fp32 or bf16
+__device__ __forceinline__ float dpx_hist_load(const float* plane, int bf16, long i) {
+  return bf16 ? __uint_as_float((unsigned)((const unsigned short*)plane)[i] << 16) : plane[i];
+}
+
 // ---- complex arithmetic on float2 ---------------------------------------------------------------
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));

@@ -32,6 +32,7 @@ struct IterTerm {
 struct IterTerms {
   IterTerm t[DPX_MAX_TERMS];
   int n;
+  int emit_bf16;       // x_out / v_out / rhs_out are bf16 planes (the bf16 history of the unrolled forward pass) instead of fp32
   float* rhs_out;      // nullable: the next x-update's right-hand-side increment rho' sum K_i^T (v_i - u_i) as an image (the unrolled
                        // forward pass keeps it for the backward pass); like x_out / v_out an emit store, never counted in the waits
 };
@@ -134,9 +135,9 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
 #pragma unroll
       for (int m = 0; m < V; ++m) xr[t + m * T] = xa[m];
       if (x_out && q >= 1 && q <= R) {
-        float2* xo = (float2*)(x_out + plane_px + (size_t)h * (2 * M));
+        const size_t xo = (plane_px + (size_t)h * (2 * M)) / 2 + t;
 #pragma unroll
-        for (int m = 0; m < V; ++m) xo[t + m * T] = xa[m];
+        for (int m = 0; m < V; ++m) dpx_emit_pair(x_out, TT.emit_bf16, xo + m * T, xa[m]);
       }
     }
     DPX_LDS_BARRIER();
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
           w[m] = make_float2(vx - ux, vy - uy);
           if (z_own) {
             ((float2*)(tm.u_out + plane_px + (size_t)hz * (2 * M)))[t + m * T] = make_float2(ux, uy);
-            if (emit_v) ((float2*)(tm.v_out + plane_px + (size_t)hz * (2 * M)))[t + m * T] = make_float2(vx, vy);
+            if (emit_v) dpx_emit_pair(tm.v_out, TT.emit_bf16, (plane_px + (size_t)hz * (2 * M)) / 2 + t + m * T, make_float2(vx, vy));
           }
         }
         // this term's contribution to K^T (v - u) that needs no other row
@@ -224,9 +225,9 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
 #pragma unroll
       for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
       if (TT.rhs_out && z_own) {
-        float2* ro = (float2*)(TT.rhs_out + plane_px + (size_t)hz * (2 * M));
+        const size_t ro = (plane_px + (size_t)hz * (2 * M)) / 2 + t;
 #pragma unroll
-        for (int m = 0; m < V; ++m) ro[t + m * T] = z[m];
+        for (int m = 0; m < V; ++m) dpx_emit_pair(TT.rhs_out, TT.emit_bf16, ro + m * T, z[m]);
       }
       WaveSync()();
       fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
@@ -435,9 +436,9 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
     WaveSync()();
     fft_reg_tw<M, T, +1, false>(xa, myfft, t, twr, WaveSync());   // xa[m] = (x[2n], x[2n+1]), n = t + m*T
     if (x_out && q >= 1 && q <= R) {
-      float2* xo = (float2*)x_out + (unsigned)pl * H * M + (unsigned)rowof(q) * M;
+      const size_t xo = (size_t)pl * H * M + (size_t)rowof(q) * M + t;
 #pragma unroll
-      for (int m = 0; m < V; ++m) xo[t + m * T] = xa[m];
+      for (int m = 0; m < V; ++m) dpx_emit_pair(x_out, TT.emit_bf16, xo + m * T, xa[m]);
     }
     if (q >= 1) {
       // ---------------- phase B: z / dual update of row qz = q - 1 (x[qz] = xprev, x[qz+1] = xa) ----------------
@@ -509,9 +510,9 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
 #pragma unroll
           for (int m = 0; m < V; ++m) st_stream<R_STU>(uo + m * T, d[m]);
           if (emit_v) {
-            float2* vo = (float2*)tm.v_out + (unsigned)pl * H * M + hz * M + t;
+            const size_t vo = (size_t)pl * H * M + (size_t)hz * M + t;
 #pragma unroll
-            for (int m = 0; m < V; ++m) vo[m * T] = v[m];
+            for (int m = 0; m < V; ++m) dpx_emit_pair(tm.v_out, TT.emit_bf16, vo + m * T, v[m]);
           }
         }
         if (tm.linop == DPX_LIN_IDENTITY) {
@@ -539,9 +540,9 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
 #pragma unroll
         for (int m = 0; m < V; ++m) z[m] = make_float2(rho * acc[m].x, rho * acc[m].y);
         if (TT.rhs_out) {
-          float2* ro = (float2*)TT.rhs_out + (unsigned)pl * H * M + hz * M;
+          const size_t ro = (size_t)pl * H * M + (size_t)hz * M + t;
 #pragma unroll
-          for (int m = 0; m < V; ++m) ro[t + m * T] = z[m];
+          for (int m = 0; m < V; ++m) dpx_emit_pair(TT.rhs_out, TT.emit_bf16, ro + m * T, z[m]);
         }
         WaveSync()();
         fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
@@ -608,7 +609,7 @@ int rows_r2c_pow2(const float* x, float2* spec, int P, int H, int W, const void*
 using namespace dpx;
 namespace dpx {
 int iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
-                   float* rhs_out, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
+                   float* rhs_out, int emit_bf16, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
 }
 
 static int terms_ok(const dpx_term* terms, int nterms) {
@@ -658,17 +659,19 @@ extern "C" int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const voi
 
 extern "C" int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next,
                                   float* x_out, int emit_v, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
-  return dpx::iter_rows_impl(spec_in, spec_out, terms, nterms, rho_next, x_out, emit_v, nullptr, B, C, H, W, table, stream);
+  return dpx::iter_rows_impl(spec_in, spec_out, terms, nterms, rho_next, x_out, emit_v, nullptr, 0, B, C, H, W, table, stream);
 }
 
-// + rhs_out (nullable): the right-hand-side increment handed to the next x-update, also written as an image
+// + rhs_out (nullable): the right-hand-side increment handed to the next x-update, also written as an image;
+// + emit_bf16: x_out, terms[i].v and rhs_out are bf16 planes (written with round-to-nearest-even)
 int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
-                        float* rhs_out, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
+                        float* rhs_out, int emit_bf16, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
   DPX_REQUIRE(spec_in && table && (spec_out || !rho_next), "dpx_admm_iter_rows: null pointer");
   DPX_REQUIRE(dpx_admm_iter_supported(H, W, terms, nterms), "dpx_admm_iter_rows: unsupported problem (plane %dx%d, %d terms)", H, W, nterms);
   IterTerms TT;
   TT.n = nterms;
   TT.rhs_out = rho_next ? rhs_out : nullptr;
+  TT.emit_bf16 = emit_bf16;
   for (int i = 0; i < nterms; ++i) {
     DPX_REQUIRE(terms[i].u && (terms[i].u_out) && (!emit_v || terms[i].v), "dpx_admm_iter_rows: term %d lacks u / u_out / v", i);
     DPX_REQUIRE(terms[i].u != terms[i].u_out, "dpx_admm_iter_rows: u must be double-buffered (u_out != u)");

@@ -21,15 +21,17 @@ using namespace dpx;
 
 namespace dpx {
 int ad_partial_blocks(int C, int H, int W);
-int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float* part, int B, int C, int H, int W, hipStream_t s);
-int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int B, int C, int H, int W, hipStream_t s);
+int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float* part, int hist_bf16, int B, int C, int H, int W, hipStream_t s);
+int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int hist_bf16, int B, int C, int H, int W,
+                            hipStream_t s);
 int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
                 int C, int H, int W, hipStream_t s);
 int iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
-                   float* rhs_out, int B, int C, int H, int W, const void* table, dpx_stream_t stream);   // dpx_iter.hip
+                   float* rhs_out, int emit_bf16, int B, int C, int H, int W, const void* table, dpx_stream_t stream);   // dpx_iter.hip
 int rhs_bwd_impl(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv, float* const* gu,
-                 const float* const* gu_add, float* grho, const float* grho_add, int B, int C, int H, int W, void* ws, hipStream_t s);   // dpx_autodiff.hip
-// (2 + n) fp32 planes <-> one bf16 history slot, round-to-nearest-even
+                 const float* const* gu_add, float* grho, const float* grho_add, int hist_bf16, int B, int C, int H, int W, void* ws,
+                 hipStream_t s);   // dpx_autodiff.hip
+// fp32 planes -> consecutive bf16 planes of a history slot, round-to-nearest-even
 struct PlanePack {
   float* p[2 + DPX_MAX_TERMS];
   int n;
@@ -39,12 +41,6 @@ __global__ void k_hist_pack_bf16(PlanePack P, unsigned short* __restrict__ slot,
     const int k = (int)(i / px);
     const unsigned u = __float_as_uint(P.p[k][i - k * px]);
     slot[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-  }
-}
-__global__ void k_hist_unpack_bf16(PlanePack P, const unsigned short* __restrict__ slot, long px) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < px * P.n; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i / px);
-    P.p[k][i - k * px] = __uint_as_float((unsigned)slot[i] << 16);
   }
 }
 }  // namespace dpx
@@ -99,7 +95,7 @@ extern "C" int dpx_admm_unrolled_forward(float* hist, const float* const* v0, co
           zt[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, h.v(it, i), it ? h.u(it - 1, i) : (float*)u0[i], h.u(it, i)};
         const bool last = it == T - 1;
         DPX_TRY(iter_rows_impl(spec_b, last ? nullptr : spec_a, zt, nterms, last ? nullptr : rho_tab + (size_t)(it + 1) * B, h.x(it), 1,
-                               last ? nullptr : h.rhs(it + 1), B, C, H, W, table, stream));
+                               last ? nullptr : h.rhs(it + 1), 0, B, C, H, W, table, stream));
       }
       return DPX_OK;
     }
@@ -146,6 +142,47 @@ extern "C" int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float
   auto vw = [&](int gen, int i) { return w + (size_t)(2 + gen * 2 * n + i) * px; };
   auto uw = [&](int gen, int i) { return w + (size_t)(2 + gen * 2 * n + n + i) * px; };
   unsigned short* hist = (unsigned short*)hist_bf16;
+  {
+    // power-of-two planes: the two-kernel iteration with the row kernel emitting x, v_i and the next right-hand side (see
+    // dpx_admm_unrolled_forward): 3 launches per iteration instead of 6
+    dpx_term probe[DPX_MAX_TERMS];
+    for (int i = 0; i < n; ++i) probe[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i], vw(0, i), (float*)u0[i], uw(0, i)};
+    if (dpx_admm_iter_supported(H, W, probe, n) && dpx_spectrum_bytes(B * C, H, W) > 0) {
+      // ... and it writes them as bf16 straight into the history slot [rhs][x][v_i] (nothing but u_i and the spectra is read back by
+      // the next iteration); only rhs(0) and the last iteration's fp32 outputs go through the packing kernel
+      auto slot = [&](int it) { return hist + (size_t)it * (2 + n) * px; };
+      char* spec_a = (char*)spectrum_ws;
+      char* spec_b = spec_a + dpx_spectrum_bytes(B * C, H, W) / 2;
+      dpx_term rt[DPX_MAX_TERMS];
+      for (int i = 0; i < n; ++i) rt[i] = dpx_term{linops[i], proxes[i], 1.0f, 0, nullptr, (float*)v0[i], (float*)u0[i], nullptr};
+      DPX_TRY(dpx_admm_rhs(rhs_w, nullptr, rho_tab, rt, n, B, C, H, W, stream));
+      DPX_TRY(dpx_rfft_rows(rhs_w, spec_a, B, C, H, W, table, stream));
+      PlanePack P;
+      P.n = 1;
+      P.p[0] = rhs_w;
+      DPX_LAUNCH("k_hist_pack_bf16", k_hist_pack_bf16, dim3(grid_for((long)px, 256, 8192)), dim3(256), 0, (hipStream_t)stream, P, slot(0), (long)px);
+      for (int it = 0; it < T; ++it) {
+        const bool last = it == T - 1;
+        dpx_term zt[DPX_MAX_TERMS];
+        for (int i = 0; i < n; ++i) {
+          float* pu = it ? uw((it - 1) & 1, i) : (float*)u0[i];
+          float* nv = last ? v_out[i] : (float*)(slot(it) + (size_t)(2 + i) * px);
+          float* nu = last ? u_out[i] : uw(it & 1, i);
+          zt[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, nv, pu, nu};
+        }
+        DPX_TRY(dpx_admm_iter_cols(spec_a, spec_b, spec_add, dd, rho_tab + (size_t)it * B, eps, B, C, H, W, table, stream));
+        DPX_TRY(iter_rows_impl(spec_b, last ? nullptr : spec_a, zt, n, last ? nullptr : rho_tab + (size_t)(it + 1) * B,
+                               last ? x_out : (float*)(slot(it) + px), 1, last ? nullptr : (float*)slot(it + 1), last ? 0 : 1, B, C, H, W, table,
+                               stream));
+      }
+      P.n = 1 + n;
+      P.p[0] = x_out;
+      for (int i = 0; i < n; ++i) P.p[1 + i] = v_out[i];
+      DPX_LAUNCH("k_hist_pack_bf16", k_hist_pack_bf16, dim3(grid_for((long)(px * (1 + n)), 256, 8192)), dim3(256), 0, (hipStream_t)stream, P,
+                 slot(T - 1) + px, (long)px);
+      return launch_status("dpx_admm_unrolled_forward_bf16");
+    }
+  }
   for (int it = 0; it < T; ++it) {
     const bool last = it == T - 1;
     dpx_term rt[DPX_MAX_TERMS], zt[DPX_MAX_TERMS];
@@ -183,12 +220,12 @@ extern "C" size_t dpx_admm_unrolled_bwd_ws_bytes(int nterms, int B, int C, int H
 // Out: gv0[i], gu0[i] (w.r.t. the initial split / dual variables), grho [T][B], glam [T][n][B], goff[k] (w.r.t. the k-th
 // Omega offset: K g_rhs summed over the iterations; off_otf[k] = that term's OTF table or NULL for the identity; goff[k]
 // NULL = not wanted).
-static int unrolled_backward_impl(const float* hist, const unsigned short* hist16, float* stage, const float* gx, const float* const* gv_in, const float* const* gu_in,
+static int unrolled_backward_impl(const float* hist, const unsigned short* hist16, const float* gx, const float* const* gv_in, const float* const* gu_in,
                                           float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
                                           const void* const* off_otf, int n_off, const int* linops, const int* proxes, const float* alphas,
                                           int nterms, const float* rho_tab, const float* const* lam_tabs, int T, const void* dd, float eps,
                                           int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream) {
-  DPX_REQUIRE((hist || (hist16 && stage)) && gv0 && gu0 && grho && glam && linops && proxes && alphas && rho_tab && lam_tabs && dd && table &&
+  DPX_REQUIRE((hist || hist16) && gv0 && gu0 && grho && glam && linops && proxes && alphas && rho_tab && lam_tabs && dd && table &&
                   spectrum_ws && ws, "dpx_admm_unrolled_backward: null pointer");
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && T >= 1 && B > 0 && n_off >= 0 && (n_off == 0 || (goff && off_otf)),
               "dpx_admm_unrolled_backward: bad sizes");
@@ -196,9 +233,12 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
   const size_t px = (size_t)B * C * H * W;
   // fp32 history: pointers into it; bf16 history: iteration `it` is expanded into the (2 + n) staging planes first
   const Hist h32{(float*)hist, px, n};
-  auto H_rhs = [&](int it) { return hist ? h32.rhs(it) : stage; };
-  auto H_x = [&](int it) { return hist ? h32.x(it) : stage + px; };
-  auto H_v = [&](int it, int i) { return hist ? h32.v(it, i) : stage + (size_t)(2 + i) * px; };
+  // (bf16 history: the stage kernels read the 16-bit slots themselves)
+  const int hb = hist ? 0 : 1;
+  auto slot16 = [&](int it) { return hist16 + (size_t)it * (2 + n) * px; };
+  auto H_rhs = [&](int it) { return hist ? h32.rhs(it) : (float*)slot16(it); };
+  auto H_x = [&](int it) { return hist ? h32.x(it) : (float*)(slot16(it) + px); };
+  auto H_v = [&](int it, int i) { return hist ? h32.v(it, i) : (float*)(slot16(it) + (size_t)(2 + i) * px); };
   float* w = (float*)ws;
   float* gxz = w;
   float* gtot = w + px;
@@ -222,17 +262,10 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
   DPX_REQUIRE(n_off <= DPX_MAX_TERMS, "dpx_admm_unrolled_backward: at most %d offsets", DPX_MAX_TERMS);
   for (int it = T - 1; it >= 0; --it) {
     const float* rho = rho_tab + (size_t)it * B;
-    if (!hist) {
-      PlanePack P;
-      P.n = 2 + n;
-      for (int k = 0; k < 2 + n; ++k) P.p[k] = stage + (size_t)k * px;
-      DPX_LAUNCH("k_hist_unpack_bf16", k_hist_unpack_bf16, dim3(grid_for((long)(px * (2 + n)), 256, 8192)), dim3(256), 0, (hipStream_t)stream, P,
-                 hist16 + (size_t)it * (2 + n) * px, (long)px);
-    }
     dpx_bwd_term bt[DPX_MAX_TERMS];
     for (int i = 0; i < n; ++i)
       bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, H_v(it, i), cur_gv[i], cur_gu[i], gu_a + i * px};
-    DPX_TRY(zupdate_bwd_partials(gxz, bt, n, part_lam, B, C, H, W, (hipStream_t)stream));
+    DPX_TRY(zupdate_bwd_partials(gxz, bt, n, part_lam, hb, B, C, H, W, (hipStream_t)stream));
     const float* g = gxz;
     if (it == T - 1 && gx) {
       const float* xs[2] = {gx, gxz};
@@ -240,7 +273,7 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
       g = gtot;
     }
     DPX_TRY(dpx_fourier_apply_inv(g, grhs, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
-    DPX_TRY(solve_rho_grad_partials(grhs, H_x(it), linops, n, part_a, B, C, H, W, (hipStream_t)stream));
+    DPX_TRY(solve_rho_grad_partials(grhs, H_x(it), linops, n, part_a, hb, B, C, H, W, (hipStream_t)stream));
     for (int k = 0; k < n_off; ++k) {
       if (!goff[k]) continue;
       if (off_otf[k]) {
@@ -266,7 +299,7 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
     // rhs stage, with the sum of the two stages' shares of the dual gradient folded in: gu_prev_i = gu_a_i - gv_i
     const float* gua[DPX_MAX_TERMS];
     for (int i = 0; i < n; ++i) gua[i] = gu_a + (size_t)i * px;
-    DPX_TRY(rhs_bwd_impl(grhs, H_rhs(it), rho, linops, n, nv, nu, gua, nullptr, nullptr, B, C, H, W, part_b, (hipStream_t)stream));
+    DPX_TRY(rhs_bwd_impl(grhs, H_rhs(it), rho, linops, n, nv, nu, gua, nullptr, nullptr, hb, B, C, H, W, part_b, (hipStream_t)stream));
     // ... and the iteration's three reductions (d/d lam_i, the two shares of d/d rho) finished by one launch
     DPX_TRY(finish_iter(part_lam, part_a, part_b, glam + (size_t)it * n * B, grho + (size_t)it * B, rho, n, B, C, H, W, (hipStream_t)stream));
     for (int i = 0; i < n; ++i) {
@@ -283,13 +316,13 @@ extern "C" int dpx_admm_unrolled_backward(const float* hist, const float* gx, co
                                           int nterms, const float* rho_tab, const float* const* lam_tabs, int T, const void* dd, float eps,
                                           int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(hist, "dpx_admm_unrolled_backward: null history");
-  return unrolled_backward_impl(hist, nullptr, nullptr, gx, gv_in, gu_in, gv0, gu0, grho, glam, goff, off_otf, n_off, linops, proxes, alphas, nterms,
+  return unrolled_backward_impl(hist, nullptr, gx, gv_in, gu_in, gv0, gu0, grho, glam, goff, off_otf, n_off, linops, proxes, alphas, nterms,
                                 rho_tab, lam_tabs, T, dd, eps, B, C, H, W, table, spectrum_ws, ws, stream);
 }
 
-// bf16 history: `ws` = dpx_admm_unrolled_bwd_ws_bytes + (2 + n) fp32 planes (dpx_admm_unrolled_bwd_ws_bytes_bf16)
+// bf16 history: the stage kernels read the 16-bit slots directly, the workspace is that of the fp32 pass
 extern "C" size_t dpx_admm_unrolled_bwd_ws_bytes_bf16(int nterms, int B, int C, int H, int W) {
-  return dpx_admm_unrolled_bwd_ws_bytes(nterms, B, C, H, W) + (size_t)(2 + nterms) * B * C * H * W * sizeof(float);
+  return dpx_admm_unrolled_bwd_ws_bytes(nterms, B, C, H, W);
 }
 extern "C" int dpx_admm_unrolled_backward_bf16(const void* hist_bf16, const float* gx, const float* const* gv_in, const float* const* gu_in,
                                                float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
@@ -298,7 +331,6 @@ extern "C" int dpx_admm_unrolled_backward_bf16(const void* hist_bf16, const floa
                                                const void* dd, float eps, int B, int C, int H, int W, const void* table, void* spectrum_ws,
                                                void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(hist_bf16 && ws, "dpx_admm_unrolled_backward_bf16: null pointer");
-  float* stage = (float*)((char*)ws + dpx_admm_unrolled_bwd_ws_bytes(nterms, B, C, H, W));
-  return unrolled_backward_impl(nullptr, (const unsigned short*)hist_bf16, stage, gx, gv_in, gu_in, gv0, gu0, grho, glam, goff, off_otf, n_off, linops,
+  return unrolled_backward_impl(nullptr, (const unsigned short*)hist_bf16, gx, gv_in, gu_in, gv0, gu0, grho, glam, goff, off_otf, n_off, linops,
                                 proxes, alphas, nterms, rho_tab, lam_tabs, T, dd, eps, B, C, H, W, table, spectrum_ws, ws, stream);
 }

@@ -295,8 +295,9 @@ int dpx_admm_unrolled_backward(const float* hist, const float* gx, const float* 
                                int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ws, dpx_stream_t stream);
 /* bf16 mode of the same training step (BASELINE config 5; specialize(..., method='unroll', dtype='bf16')): the iteration runs in
  * fp32 working planes (`work`, dpx_admm_unrolled_work_bytes_bf16) and what the backward pass needs -- rhs, x, v_i of every
- * iteration -- is kept in a bf16 history, (2 + n) x 2 bytes per pixel and iteration instead of (2 + 2n) x 4.  The final state goes
- * to x_out / v_out[i] / u_out[i] (fp32).  Backward: as above with ws sized by dpx_admm_unrolled_bwd_ws_bytes_bf16.            */
+ * iteration -- is kept in a bf16 history, (2 + n) x 2 bytes per pixel and iteration instead of (2 + 2n) x 4 (power-of-two planes: the
+ * row kernel of the two-kernel iteration writes the slots itself).  The final state goes to x_out / v_out[i] / u_out[i] (fp32).
+ * Backward: as above with ws sized by dpx_admm_unrolled_bwd_ws_bytes_bf16; its stage kernels read the 16-bit slots directly.   */
 size_t dpx_admm_unrolled_hist_bytes_bf16(int nterms, int T, int B, int C, int H, int W);
 size_t dpx_admm_unrolled_work_bytes_bf16(int nterms, int B, int C, int H, int W);
 int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float* x_out, float* const* v_out, float* const* u_out,
