@@ -189,6 +189,39 @@ def case_cg(device, B):
     assert_close(cg(A, rhs, rtol=0.0, max_iters=10).cpu(), g[f"B{B}_x_10it"], TOL)
 
 
+def case_cg_masked_fft_shapes(device):
+    """dpx_cg_masked_fft (device-controlled CG whose matvec is three fused launches: real row transform, column transform - mask^2 -
+    inverse column transform, inverse row transform + real part + rho p) on odd / non-square planes, broadcast and per-image masks:
+    against a float64 torch solve of the same normal equations  (Re F^-1 M^2 F + c rho) x = b  (reference utils/misc.py:164-193)."""
+    from dprox import _ops as ops
+    rng = np.random.RandomState(77)
+    for (B, H, W, per_image, c) in ((3, 20, 28, False, 1.0), (2, 33, 30, True, 2.0), (1, 64, 64, False, 1.0), (4, 27, 45, True, 1.0)):
+        mask = (rng.rand(B if per_image else 1, 1, H, W) < 0.4).astype(np.float32)
+        b = rng.randn(B, 1, H, W).astype(np.float32)
+        rho = (0.3 + 0.2 * rng.rand(B)).astype(np.float32)
+        x, n_it = ops.cg_masked_fft(T(b, device), T(mask, device), T(rho, device), c, 1e-7, 200)
+        # float64 reference: the operator is diagonal in the (centred, orthonormal) Fourier domain only up to the real part --
+        # solve by CG in float64 with the same operator built from torch.fft
+        m2 = torch.from_numpy(mask.astype(np.float64)) ** 2
+        bt, rt = torch.from_numpy(b.astype(np.float64)), torch.from_numpy(rho.astype(np.float64)).view(B, 1, 1, 1)
+        f2 = lambda z: torch.fft.fftshift(torch.fft.fft2(torch.fft.ifftshift(z, dim=(-2, -1)), norm="ortho"), dim=(-2, -1))
+        i2 = lambda z: torch.fft.fftshift(torch.fft.ifft2(torch.fft.ifftshift(z, dim=(-2, -1)), norm="ortho"), dim=(-2, -1))
+        A = lambda z: i2(m2 * f2(z)).real + c * rt * z
+        xr, r = torch.zeros_like(bt), bt.clone()
+        p, rs = r.clone(), (r * r).sum()
+        for _ in range(400):
+            Ap = A(p)
+            al = rs / (p * Ap).sum()
+            xr, r = xr + al * p, r - al * Ap
+            rs_new = (r * r).sum()
+            if rs_new.sqrt() < 1e-13 * bt.norm():
+                break
+            p, rs = r + (rs_new / rs) * p, rs_new
+        e = rel_l2(x.cpu().numpy(), xr.numpy())
+        record(f"cg_masked_fft {B}x1x{H}x{W} per-image-mask={per_image} vs float64 solve", e, 1e-5)
+        assert e <= 1e-5, (B, H, W, per_image, e, n_it)
+
+
 def case_adjoint_dot(device, shape=(2, 3, 96, 80)):
     """CompGraph.sanity_check dot-product test (reference comp_graph.py:342-371, tests/test_linop.py)"""
     import synthetic

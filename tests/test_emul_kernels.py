@@ -55,6 +55,10 @@ def test_cg(B):
     pc.case_cg(DEV, B)
 
 
+def test_cg_masked_fft_odd_and_per_image_masks():
+    pc.case_cg_masked_fft_shapes(DEV)
+
+
 def test_linear_solve_implicit_backward():
     pc.case_linear_solve_grad(DEV)
 
