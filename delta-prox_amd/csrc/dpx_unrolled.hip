@@ -1,10 +1,11 @@
 // Unrolled ADMM with closed-form proxes, forward and backward, as two C-side loops (config 5: specialize(method='unroll'),
 // reference dprox/algo/specialization/unroll.py:14-58 differentiating dprox/algo/admm.py:49-59 with PyTorch autograd).
 //
-// The per-stage entry points (dpx_admm_rhs / dpx_fourier_solve / dpx_admm_zupdate and their backward counterparts in
-// dpx_autodiff.hip) are unchanged; this file only sequences them without returning to the host language between stages:
-// a 10-iteration training step is ~170 kernel launches whose Python-side issue cost (~4 ms) exceeded their run time
-// (~2.3 ms).  No kernels of its own.
+// This file sequences stage kernels without returning to the host language between stages (issued from Python, a 10-iteration
+// training step's launches cost ~4 ms of issue time for ~2.3 ms of run time).  Forward: on power-of-two planes the two-kernel
+// iteration of dpx_admm_run (dpx_iter.hip) whose row kernel emits the history -- x, v_i, the next right-hand side; fp32 or bf16 --,
+// otherwise dpx_admm_rhs / dpx_fourier_solve / dpx_admm_zupdate.  Backward: the stage kernels of dpx_autodiff.hip with the sums
+// between the stages folded in and one finishing launch per iteration for its three reductions.
 //
 // History buffer (caller-owned): iteration `it` occupies (2 + 2 n) planes of px = B*C*H*W floats:
 //     [rhs][x][v_0 .. v_{n-1}][u_0 .. u_{n-1}]
