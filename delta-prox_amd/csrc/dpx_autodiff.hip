@@ -192,6 +192,59 @@ __global__ void __launch_bounds__(256) k_rhs_bwd(const float* __restrict__ g, co
   if (threadIdx.x == 0) part[(long)b * gridDim.x + blockIdx.x] = s;
 }
 
+// k_solve_rho_grad and k_rhs_bwd in one pass over g (the unrolled backward loop runs them back to back on the same g = M_rho g_x):
+// part_a[b][blk] = - sum g (sum K_i^T K_i x),  part_b[b][blk] = sum g rhs,  g_v_i = rho_b K_i g,  g_u_i = gu_add_i - g_v_i
+__global__ void __launch_bounds__(256) k_solve_rhs_bwd(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ rhs,
+                                                        const float* __restrict__ rho, RhsBwdPack T, float* __restrict__ part_a,
+                                                        float* __restrict__ part_b, int C, int H, int W) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y;
+  const long npb = (long)C * H * W, base = (long)b * npb;
+  const float r = rho[b];
+  float cI = 0.f;
+  int nW = 0, nH = 0;
+  for (int t = 0; t < T.n; ++t) {
+    if (T.linop[t] == DPX_LIN_IDENTITY) cI += 1.f;
+    else if (T.linop[t] == DPX_LIN_GRAD_W) ++nW;
+    else ++nH;
+  }
+  float acc_a = 0.f, acc_b = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npb; p += (long)gridDim.x * 256) {
+    const int w = (int)(p % W);
+    const long row = p / W;
+    const int h = (int)(row % H);
+    const long i = base + p;
+    const long il = base + row * W + (w == 0 ? W - 1 : w - 1), ir = base + row * W + (w + 1 == W ? 0 : w + 1);
+    const long iu = i + (long)((h == 0 ? H - 1 : h - 1) - h) * W, id = i + (long)((h + 1 == H ? 0 : h + 1) - h) * W;
+    const float gc = g[i];
+    const float xc = dpx_hist_load(x, T.hist_bf16, i);
+    float lx = cI * xc;
+    if (nW) lx += (float)nW * (2.f * xc - dpx_hist_load(x, T.hist_bf16, il) - dpx_hist_load(x, T.hist_bf16, ir));
+    if (nH) lx += (float)nH * (2.f * xc - dpx_hist_load(x, T.hist_bf16, iu) - dpx_hist_load(x, T.hist_bf16, id));
+    acc_a = fmaf(gc, lx, acc_a);
+    acc_b = fmaf(gc, dpx_hist_load(rhs, T.hist_bf16, i), acc_b);
+#pragma unroll
+    for (int t = 0; t < DPX_MAX_TERMS; ++t) {
+      if (t < T.n) {
+        float kg;
+        if (T.linop[t] == DPX_LIN_IDENTITY) kg = gc;
+        else if (T.linop[t] == DPX_LIN_GRAD_W) kg = g[ir] - gc;
+        else kg = g[id] - gc;
+        kg *= r;
+        if (T.gv[t]) T.gv[t][i] = kg;
+        if (T.gu[t]) T.gu[t][i] = (T.gu_add[t] ? T.gu_add[t][i] : 0.f) - kg;
+      }
+    }
+  }
+  const float sa = ad_block_sum(acc_a, sh);
+  __syncthreads();
+  const float sb = ad_block_sum(acc_b, sh);
+  if (threadIdx.x == 0) {
+    part_a[(long)b * gridDim.x + blockIdx.x] = -sa;
+    part_b[(long)b * gridDim.x + blockIdx.x] = sb;
+  }
+}
+
 __global__ void k_ad_finish(const float* __restrict__ part, float* __restrict__ out, int nblk, const float* __restrict__ div,
                             const float* __restrict__ add) {
   __shared__ float sh[16];
@@ -251,14 +304,20 @@ int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float
   DPX_LAUNCH("k_zupdate_bwd", k_zupdate_bwd, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, gx, T, part, C, H, W);
   return launch_status("dpx_admm_zupdate_bwd");
 }
-int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int hist_bf16, int B, int C, int H, int W,
-                            hipStream_t s) {
-  LinCodes L;
-  L.n = nterms;
-  L.hist_bf16 = hist_bf16;
-  for (int i = 0; i < nterms; ++i) L.linop[i] = linops[i];
-  DPX_LAUNCH("k_solve_rho_grad", k_solve_rho_grad, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g_rhs, x, L, part, C, H, W);
-  return launch_status("dpx_admm_solve_rho_grad");
+int solve_rhs_bwd_partials(const float* g, const float* x, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv,
+                           float* const* gu, const float* const* gu_add, float* part_a, float* part_b, int hist_bf16, int B, int C, int H, int W,
+                           hipStream_t s) {
+  RhsBwdPack T;
+  T.n = nterms;
+  T.hist_bf16 = hist_bf16;
+  for (int i = 0; i < nterms; ++i) {
+    T.linop[i] = linops[i];
+    T.gv[i] = gv[i];
+    T.gu[i] = gu[i];
+    T.gu_add[i] = gu_add ? gu_add[i] : nullptr;
+  }
+  DPX_LAUNCH("k_solve_rhs_bwd", k_solve_rhs_bwd, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, part_a, part_b, C, H, W);
+  return launch_status("dpx_admm_unrolled_backward");
 }
 int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
                 int C, int H, int W, hipStream_t s) {

@@ -23,8 +23,9 @@ using namespace dpx;
 namespace dpx {
 int ad_partial_blocks(int C, int H, int W);
 int zupdate_bwd_partials(float* gx, const dpx_bwd_term* terms, int nterms, float* part, int hist_bf16, int B, int C, int H, int W, hipStream_t s);
-int solve_rho_grad_partials(const float* g_rhs, const float* x, const int* linops, int nterms, float* part, int hist_bf16, int B, int C, int H, int W,
-                            hipStream_t s);
+int solve_rhs_bwd_partials(const float* g, const float* x, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv,
+                           float* const* gu, const float* const* gu_add, float* part_a, float* part_b, int hist_bf16, int B, int C, int H, int W,
+                           hipStream_t s);
 int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
                 int C, int H, int W, hipStream_t s);
 int iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
@@ -274,7 +275,6 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
       g = gtot;
     }
     DPX_TRY(dpx_fourier_apply_inv(g, grhs, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
-    DPX_TRY(solve_rho_grad_partials(grhs, H_x(it), linops, n, part_a, hb, B, C, H, W, (hipStream_t)stream));
     for (int k = 0; k < n_off; ++k) {
       if (!goff[k]) continue;
       if (off_otf[k]) {
@@ -297,10 +297,11 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
       nv[i] = it ? set[it & 1] + (size_t)i * px : gv0[i];
       nu[i] = it ? set[it & 1] + (size_t)(n + i) * px : gu0[i];
     }
-    // rhs stage, with the sum of the two stages' shares of the dual gradient folded in: gu_prev_i = gu_a_i - gv_i
+    // the x-update's rho gradient and the rhs stage in one pass over g_rhs, with the sum of the two stages' shares of the dual
+    // gradient folded in: gu_prev_i = gu_a_i - gv_i
     const float* gua[DPX_MAX_TERMS];
     for (int i = 0; i < n; ++i) gua[i] = gu_a + (size_t)i * px;
-    DPX_TRY(rhs_bwd_impl(grhs, H_rhs(it), rho, linops, n, nv, nu, gua, nullptr, nullptr, hb, B, C, H, W, part_b, (hipStream_t)stream));
+    DPX_TRY(solve_rhs_bwd_partials(grhs, H_x(it), H_rhs(it), rho, linops, n, nv, nu, gua, part_a, part_b, hb, B, C, H, W, (hipStream_t)stream));
     // ... and the iteration's three reductions (d/d lam_i, the two shares of d/d rho) finished by one launch
     DPX_TRY(finish_iter(part_lam, part_a, part_b, glam + (size_t)it * n * B, grho + (size_t)it * B, rho, n, B, C, H, W, (hipStream_t)stream));
     for (int i = 0; i < n; ++i) {
