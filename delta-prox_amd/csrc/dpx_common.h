@@ -148,6 +148,15 @@ __device__ __forceinline__ float dpx_hist_load(const float* plane, int bf16, lon
   return bf16 ? __uint_as_float((unsigned)((const unsigned short*)plane)[i] << 16) : plane[i];
 }
 
+// four consecutive elements (i a multiple of 4) of such a plane
+__device__ __forceinline__ float4 dpx_hist_load4(const float* plane, int bf16, long i) {
+  if (bf16) {
+    const uint2 u = *(const uint2*)((const unsigned short*)plane + i);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  }
+  return *(const float4*)(plane + i);
+}
+
 // ---- complex arithmetic on float2 ---------------------------------------------------------------
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
