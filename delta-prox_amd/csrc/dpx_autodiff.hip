@@ -319,6 +319,85 @@ __global__ void __launch_bounds__(256) k_solve_rhs_bwd(const float* __restrict__
   }
 }
 
+// ... four pixels of a row per thread (W % 4 == 0)
+__global__ void __launch_bounds__(256) k_solve_rhs_bwd4(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ rhs,
+                                                         const float* __restrict__ rho, RhsBwdPack T, float* __restrict__ part_a,
+                                                         float* __restrict__ part_b, int C, int H, int W) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y;
+  const long npb = (long)C * H * W, base = (long)b * npb;
+  const float r = rho[b];
+  float cI = 0.f;
+  int nW = 0, nH = 0;
+  for (int t = 0; t < T.n; ++t) {
+    if (T.linop[t] == DPX_LIN_IDENTITY) cI += 1.f;
+    else if (T.linop[t] == DPX_LIN_GRAD_W) ++nW;
+    else ++nH;
+  }
+  float acc_a = 0.f, acc_b = 0.f;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npb / 4; q += (long)gridDim.x * 256) {
+    const long p = q * 4;
+    const int w = (int)(p % W);
+    const long row = p / W;
+    const int h = (int)(row % H);
+    const long i = base + p, rowb = base + row * W;
+    const long up = (long)((h == 0 ? H - 1 : h - 1) - h) * W, dn = (long)((h + 1 == H ? 0 : h + 1) - h) * W;
+    const float4 g4 = *(const float4*)(g + i);
+    const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float4 x4 = dpx_hist_load4(x, T.hist_bf16, i), r4 = dpx_hist_load4(rhs, T.hist_bf16, i);
+    const float xa[4] = {x4.x, x4.y, x4.z, x4.w}, ra[4] = {r4.x, r4.y, r4.z, r4.w};
+    float lx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lx[k] = cI * xa[k];
+    if (nW) {
+      const float xl = dpx_hist_load(x, T.hist_bf16, rowb + (w == 0 ? W - 1 : w - 1)), xr = dpx_hist_load(x, T.hist_bf16, rowb + (w + 4 == W ? 0 : w + 4));
+      const float xe[6] = {xl, xa[0], xa[1], xa[2], xa[3], xr};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lx[k] += (float)nW * (2.f * xe[k + 1] - xe[k] - xe[k + 2]);
+    }
+    float gdn[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nH) {
+      const float4 xu = dpx_hist_load4(x, T.hist_bf16, i + up), xd = dpx_hist_load4(x, T.hist_bf16, i + dn);
+      const float xua[4] = {xu.x, xu.y, xu.z, xu.w}, xda[4] = {xd.x, xd.y, xd.z, xd.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lx[k] += (float)nH * (2.f * xa[k] - xua[k] - xda[k]);
+      const float4 gd4 = *(const float4*)(g + i + dn);
+      gdn[0] = gd4.x; gdn[1] = gd4.y; gdn[2] = gd4.z; gdn[3] = gd4.w;
+    }
+    const float gright = nW ? g[rowb + (w + 4 == W ? 0 : w + 4)] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc_a = fmaf(ga[k], lx[k], acc_a);
+      acc_b = fmaf(ga[k], ra[k], acc_b);
+    }
+#pragma unroll
+    for (int t = 0; t < DPX_MAX_TERMS; ++t) {
+      if (t < T.n) {
+        float kg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (T.linop[t] == DPX_LIN_IDENTITY) kg[k] = ga[k];
+          else if (T.linop[t] == DPX_LIN_GRAD_W) kg[k] = (k < 3 ? ga[(k + 1) & 3] : gright) - ga[k];
+          else kg[k] = gdn[k] - ga[k];
+          kg[k] *= r;
+        }
+        if (T.gv[t]) *(float4*)(T.gv[t] + i) = make_float4(kg[0], kg[1], kg[2], kg[3]);
+        if (T.gu[t]) {
+          const float4 a4 = T.gu_add[t] ? *(const float4*)(T.gu_add[t] + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+          *(float4*)(T.gu[t] + i) = make_float4(a4.x - kg[0], a4.y - kg[1], a4.z - kg[2], a4.w - kg[3]);
+        }
+      }
+    }
+  }
+  const float sa = ad_block_sum(acc_a, sh);
+  __syncthreads();
+  const float sb = ad_block_sum(acc_b, sh);
+  if (threadIdx.x == 0) {
+    part_a[(long)b * gridDim.x + blockIdx.x] = -sa;
+    part_b[(long)b * gridDim.x + blockIdx.x] = sb;
+  }
+}
+
 __global__ void k_ad_finish(const float* __restrict__ part, float* __restrict__ out, int nblk, const float* __restrict__ div,
                             const float* __restrict__ add) {
   __shared__ float sh[16];
@@ -391,7 +470,10 @@ int solve_rhs_bwd_partials(const float* g, const float* x, const float* rhs, con
     T.gu[i] = gu[i];
     T.gu_add[i] = gu_add ? gu_add[i] : nullptr;
   }
-  DPX_LAUNCH("k_solve_rhs_bwd", k_solve_rhs_bwd, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, part_a, part_b, C, H, W);
+  if (W % 4 == 0)
+    DPX_LAUNCH("k_solve_rhs_bwd", k_solve_rhs_bwd4, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, part_a, part_b, C, H, W);
+  else
+    DPX_LAUNCH("k_solve_rhs_bwd", k_solve_rhs_bwd, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, part_a, part_b, C, H, W);
   return launch_status("dpx_admm_unrolled_backward");
 }
 int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
