@@ -193,6 +193,7 @@ class _UnrolledClosed(torch.autograd.Function):
         import ctypes
         n = len(plan.codes)
         lam_tabs, v, u, offs = rest[:n], rest[n:2 * n], rest[2 * n:3 * n], rest[3 * n:]
+        ctx.set_materialize_grads(False)       # outputs the loss does not use (v_i, u_i) arrive as None in backward, not as zero planes
         v = [t.contiguous() for t in v]
         u = [t.contiguous() for t in u]
         shape, dev = tuple(v[0].shape), v[0].device
