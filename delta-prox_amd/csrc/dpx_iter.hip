@@ -716,7 +716,10 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
       return launch_status("dpx_admm_iter_rows");
     }
   }
-  const int R = 16;
+  static const int r_env = getenv("DPX_ITER_R") ? atoi(getenv("DPX_ITER_R")) : 0;   // tuning: rows per band of the ring-buffer kernel
+  // (256-wide planes: 16 rows are in flight per workgroup, so a band of 8 rows + its 2 halo rows is ONE step of the kernel instead
+  //  of two -- these launches are latency-bound: config 1 0.78 -> 0.62 ms per 20-iteration solve)
+  const int R = r_env ? r_env : (W <= 256 ? 8 : 16);
   switch (W) {
     case 256: launch_iter_rows<128, 16>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
     case 512: launch_iter_rows<256, 32>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
