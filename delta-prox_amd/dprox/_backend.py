@@ -75,6 +75,11 @@ SIGNATURES = {
     "dpx_bdot": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "dpx_bdot_ws_bytes": (c_size_t, [c_int, c_long]),
     "dpx_bgram": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "dpx_bdot_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "dpx_bdot_f64_ws_bytes": (c_size_t, [c_int, c_long]),
+    "dpx_bgram_f64": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "dpx_lincomb_f64": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_double), POINTER(c_void_p), c_int, c_long, c_void_p]),
+    "dpx_absmax": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "dpx_comm_unique_id": (c_int, [c_void_p]),
     "dpx_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
     "dpx_comm_destroy": (c_int, [c_void_p]),

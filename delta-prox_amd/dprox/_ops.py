@@ -4,7 +4,7 @@ PyTorch is used for device memory and streams only; every arithmetic pass below 
 of ``libdpx_hip.so``.
 """
 import ctypes
-from ctypes import c_float, c_void_p
+from ctypes import c_double, c_float, c_void_p
 
 import numpy as np
 import torch
@@ -238,6 +238,8 @@ def lincomb(terms, out=None):
     Real fp32 tensors, or complex64 tensors with real coefficients (handled as interleaved floats)."""
     xs = [t[1] for t in terms]
     ref = xs[0]
+    if ref.dtype == torch.float64:
+        return _lincomb_f64(terms, out)
     cplx = ref.is_complex()
     for x in xs:
         require(x, dtype=torch.complex64 if cplx else torch.float32, what="lincomb operand")
@@ -272,7 +274,60 @@ def lincomb(terms, out=None):
     return res
 
 
+def _lincomb_f64(terms, out=None):
+    """float64 operands (the Krylov solvers keep a float64 system in float64): dpx_lincomb_f64"""
+    ref = terms[0][1]
+    for _, x in terms:
+        require(x, dtype=torch.float64, what="lincomb operand")
+        if x.shape != ref.shape:
+            raise be.DpxError(f"lincomb: shape mismatch {tuple(x.shape)} vs {tuple(ref.shape)}")
+    res = torch.empty_like(ref) if out is None else out
+    if ref.numel() == 0:
+        return res
+    B = int(ref.shape[0]) if ref.ndim > 0 else 1
+    npb = ref.numel() // max(B, 1)
+    i, first = 0, True
+    while i < len(terms):
+        take = 4 if first else 3
+        grp = ([] if first else [(1.0, res)]) + list(terms[i:i + take])
+        i += take
+        first = False
+        n = len(grp)
+        px = (c_void_p * n)(*[o[1].data_ptr() for o in grp])
+        cf, pb, keep = (c_double * n)(), (c_void_p * n)(), []
+        for j, (c, _) in enumerate(grp):
+            if isinstance(c, torch.Tensor) and c.numel() > 1:
+                cb = c.detach().to(device=ref.device, dtype=torch.float64).reshape(-1).contiguous()
+                if cb.numel() != B:
+                    raise be.DpxError(f"per-image scalar has {cb.numel()} entries for a batch of {B}")
+                keep.append(cb)
+                cf[j], pb[j] = 1.0, cb.data_ptr()
+            else:
+                cf[j], pb[j] = float(c), None
+        be.lib().call("dpx_lincomb_f64", ptr(res), n, px, cf, pb, B, npb, be.stream())
+    return res
+
+
+def absmax(x):
+    """max |x| over all elements (float32 or float64) as a 0-d tensor on x's device -- pcg's stop rule"""
+    f64 = x.dtype == torch.float64
+    require(x, dtype=torch.float64 if f64 else torch.float32, what="absmax operand")
+    out = torch.empty((), dtype=x.dtype, device=x.device)
+    ws = workspace("absmax", 256 * 8, x.device)
+    be.lib().call("dpx_absmax", ptr(x), ptr(out), x.numel(), 1 if f64 else 0, ptr(ws), be.stream())
+    return out
+
+
 def bdot(x, y):
+    if x.dtype == torch.float64:
+        require(x, dtype=torch.float64, what="bdot x"), require(y, dtype=torch.float64, what="bdot y")
+        B = int(x.shape[0])
+        npb = x.numel() // B
+        L = be.lib()
+        out = torch.empty(B, dtype=torch.float64, device=x.device)
+        ws = workspace("dot64", L.query("dpx_bdot_f64_ws_bytes", B, npb), x.device)
+        L.call("dpx_bdot_f64", ptr(x), ptr(y), ptr(out), B, npb, ptr(ws), be.stream())
+        return out
     require(x, what="bdot x"), require(y, what="bdot y")
     B = int(x.shape[0])
     npb = x.numel() // B
@@ -284,6 +339,15 @@ def bdot(x, y):
 
 
 def bgram(r):
+    if r.dtype == torch.float64:
+        require(r, dtype=torch.float64, what="bgram r")
+        B = int(r.shape[0])
+        npb = r.numel() // B
+        L = be.lib()
+        out = torch.empty(B, B, dtype=torch.float64, device=r.device)
+        ws = workspace("dot64", L.query("dpx_bdot_f64_ws_bytes", B, npb), r.device)
+        L.call("dpx_bgram_f64", ptr(r), ptr(out), B, npb, ptr(ws), be.stream())
+        return out
     require(r, what="bgram r")
     B = int(r.shape[0])
     npb = r.numel() // B

@@ -184,6 +184,17 @@ size_t dpx_bdot_ws_bytes(int B, long n_per_batch);
 /* B x B Gram matrix of the rows of r ([B, n]) -- for the spectral-norm stop rule of cg()
  * (torch.linalg.norm(ravel(r), 2), solver_cg.py:103-104)                                       */
 int dpx_bgram(const float* r, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream);
+/* The same three primitives in float64: the reference's solvers are dtype-generic torch code and its tests solve float64 systems
+ * at rtol 1e-8 (tests/linalg/test_linear_solver.py:57-80) -- a float64 right-hand side stays float64 on the device
+ * (cg / cg2 / pcg of dprox.linalg.solve, solver_cg.py:56-233).  ws: dpx_bdot_f64_ws_bytes for both dpx_bdot_f64 and dpx_bgram_f64. */
+size_t dpx_bdot_f64_ws_bytes(int B, long n_per_batch);
+int dpx_bdot_f64(const double* x, const double* y, double* out, int B, long n_per_batch, void* ws, dpx_stream_t stream);
+int dpx_bgram_f64(const double* r, double* out, int B, long n_per_batch, void* ws, dpx_stream_t stream);
+int dpx_lincomb_f64(double* out, int n, const double* const* x, const double* coef, const double* const* coef_b, int B,
+                    long n_per_batch, dpx_stream_t stream);
+/* out[0] = max_i |x_i| -- the stop rule of pcg (torch.linalg.vector_norm(r, inf), solver_cg.py:207-228); is_f64 selects the element
+ * type of x, out and ws (256 elements)                                                                                          */
+int dpx_absmax(const void* x, void* out, long n, int is_f64, void* ws, dpx_stream_t stream);
 
 /* Device-side control of cg() (linalg/solve/solver_cg.py:95-129): the host issues a whole solve without a read-back.
  * `state` (dpx_cg_state_bytes) = float gamma[B], gamma_prev[B], beta[B], pAp[B], tol2[B]; int done, n_done, it, pad.

@@ -222,6 +222,56 @@ def case_cg_masked_fft_shapes(device):
         assert e <= 1e-5, (B, H, W, per_image, e, n_it)
 
 
+def case_dense_krylov(device):
+    """The reference's own solver tests restated (tests/linalg/test_linear_solver.py:57-80, test_linear_solver_batch.py:27-49,
+    test_linear_solver_torch.py:33-134): a 5 x 5 SPD matrix as the operator, 1-D vectors, cg / cg2 / pcg in float64 (kept in
+    float64 on the device: 1e-8 like the reference) and float32, and the gradients of the solution w.r.t. b and the matrix
+    against torch.linalg.solve's."""
+    from dprox.linalg import linear_solve
+    from dprox.linalg.solve import SOLVERS, cg, cg2, pcg
+    assert set(SOLVERS) >= {"cg", "cg2", "pcg"}
+    rng = np.random.RandomState(2023)
+    P = rng.rand(5, 5)
+    A64 = P.T @ P + 0.5 * np.eye(5)
+    x64 = rng.rand(5)
+    for dt, tol in ((torch.float64, 1e-8), (torch.float32, 2e-4)):          # (float32: rtol 1e-6 on the residual x the condition number)
+        At, xt = torch.from_numpy(A64).to(device=device, dtype=dt), torch.from_numpy(x64).to(device=device, dtype=dt)
+        bt = At @ xt
+        K = lambda v: At @ v
+        for name, fn, kw in (("cg", cg, dict(rtol=1e-10 if dt == torch.float64 else 1e-6)),
+                             ("cg2", cg2, dict(rtol=1e-20 if dt == torch.float64 else 1e-10)),
+                             ("pcg", pcg, dict(rtol=1e-10 if dt == torch.float64 else 1e-5))):
+            xh = fn(K, bt, **kw)
+            assert xh.dtype == dt and xh.shape == bt.shape
+            e = float((xh - xt).abs().max() / xt.abs().max())
+            record(f"{name} {dt} on a 5x5 SPD system", e, tol)
+            assert e <= tol, (name, dt, e)
+        jac = pcg(K, bt, rtol=1e-10 if dt == torch.float64 else 1e-5, Minv=lambda r: r / torch.diagonal(At))      # Jacobi preconditioner
+        assert float((jac - xt).abs().max() / xt.abs().max()) <= tol
+
+    class MatrixOp(dp.LinOp):                      # the plugin protocol of the reference's tests: parameters + forward / adjoint
+        def __init__(self, M):
+            super().__init__()
+            self.A = torch.nn.Parameter(M)
+
+        def forward(self, v):
+            return self.A @ v
+
+        def adjoint(self, v):
+            return self.A.T @ v
+
+    for solve in (lambda op, b: linear_solve(op, b), lambda op, b: cg(op, b, rtol=1e-7), lambda op, b: pcg(op, b, rtol=1e-6)):
+        op = MatrixOp(torch.from_numpy(A64).float().to(device))
+        b = (op.A.detach() @ torch.from_numpy(x64).float().to(device)).requires_grad_(True)
+        xh = solve(op, b)
+        xh.mean().backward()
+        Ar = torch.from_numpy(A64).float().requires_grad_(True)
+        br = b.detach().cpu().clone().requires_grad_(True)
+        torch.linalg.solve(Ar, br).mean().backward()
+        assert_close(b.grad.cpu(), br.grad, 1e-3, "implicit d/db of the solve")
+        assert_close(op.A.grad.cpu(), Ar.grad, 1e-3, "implicit d/dA of the solve")
+
+
 def case_adjoint_dot(device, shape=(2, 3, 96, 80)):
     """CompGraph.sanity_check dot-product test (reference comp_graph.py:342-371, tests/test_linop.py)"""
     import synthetic

@@ -65,6 +65,11 @@ def test_cg_masked_fft_odd_and_per_image_masks():
     pc.case_cg_masked_fft_shapes(DEV)
 
 
+@pytest.mark.gpu
+def test_dense_systems_cg_cg2_pcg_and_implicit_gradients():
+    pc.case_dense_krylov(DEV)
+
+
 def test_linear_solve_implicit_backward():
     pc.case_linear_solve_grad(DEV)
 
