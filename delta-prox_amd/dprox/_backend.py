@@ -80,6 +80,7 @@ SIGNATURES = {
     "dpx_bgram_f64": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "dpx_lincomb_f64": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_double), POINTER(c_void_p), c_int, c_long, c_void_p]),
     "dpx_absmax": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "dpx_otf_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_comm_unique_id": (c_int, [c_void_p]),
     "dpx_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
     "dpx_comm_destroy": (c_int, [c_void_p]),

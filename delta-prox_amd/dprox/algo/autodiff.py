@@ -85,30 +85,58 @@ class _Rhs(torch.autograd.Function):
         return (None, g_rho, *gv, *gu)
 
 
-class _Solve(torch.autograd.Function):
+class _FullOtf(torch.autograd.Function):
+    """O = fft2(P) of the padded, shifted PSF P [1,C,H,W] (unnormalised; conv_doe's psf2otf2, linop/conv.py:59-78) as an autograd
+    node: the x-updates of all iterations hand their dL/dO back to it, one adjoint transform turns the sum into dL/dP."""
+
     @staticmethod
-    def forward(ctx, plan, rhs, rho, *offsets):
+    def forward(ctx, P):
+        return ops.cfft2(P.contiguous(), inverse=False, centred=False, ortho=False)
+
+    @staticmethod
+    def backward(ctx, G):
+        H, W = int(G.shape[-2]), int(G.shape[-1])
+        # dL/dP[n] = Re sum_k G_k e^{+i theta_kn}  (G = dL/dRe O + i dL/dIm O): the unnormalised inverse transform
+        g = ops.cfft2(G.contiguous(), inverse=True, centred=False, ortho=False)
+        return ops.lincomb([(float(H * W), torch.view_as_real(g)[..., 0].contiguous())])
+
+
+class _Solve(torch.autograd.Function):
+    """inputs behind (plan, rhs, rho): the full OTFs of plan.doe (conv_doe terms whose PSF is being trained), then the offsets"""
+
+    @staticmethod
+    def forward(ctx, plan, rhs, rho, *rest):
         t0, c0, t1, c1 = plan.diag
         x = ops.fourier_solve(rhs.contiguous(), t0, t1, c0, c1, rho, plan.eps, spec_add=plan.FK)
         ctx.plan = plan
-        ctx.save_for_backward(x, rho)
+        nd = len(plan.doe)
+        ctx.save_for_backward(x, rho, *[o.detach() for o in rest[:nd]])
         return x
 
     @staticmethod
     def backward(ctx, gx):
         plan = ctx.plan
-        x, rho = ctx.saved_tensors
+        x, rho, *otfs = ctx.saved_tensors
+        nd = len(plan.doe)
         t0, c0, t1, c1 = plan.diag
         g_rhs = ops.fourier_apply_inv(gx.contiguous(), t0, t1, c0, c1, rho, plan.eps)
         # d x / d rho = -M (sum_Psi K_i^T K_i) x : one stencil + reduction pass
         g_rho = ops.admm_solve_rho_grad(g_rhs, x, [lc for lc, _ in plan.codes])
+        g_otfs = [None] * nd
+        if any(ctx.needs_input_grad[3:3 + nd]):
+            # dL/dO = (1/HW) sum_b [conj(A) Y - 2 Re(A conj X) O],  A = fft2(g_rhs), X = fft2(x)   (dpx_otf_grad)
+            A = ops.cfft2(g_rhs, inverse=False, centred=False, ortho=False)
+            X = ops.cfft2(x, inverse=False, centred=False, ortho=False)
+            for j, (need, (_, Yhat)) in enumerate(zip(ctx.needs_input_grad[3:3 + nd], plan.doe)):
+                if need:
+                    g_otfs[j] = ops.otf_grad(A, X, Yhat, otfs[j])
         g_offs = []
-        for need, otf in zip(ctx.needs_input_grad[3:], plan.omega_otfs):
+        for need, otf in zip(ctx.needs_input_grad[3 + nd:], plan.omega_otfs):
             if not need:
                 g_offs.append(None)
             else:
                 g_offs.append(g_rhs if otf is None else ops.fft_conv(g_rhs, otf, conj=False))
-        return (None, g_rhs, g_rho, *g_offs)
+        return (None, g_rhs, g_rho, *g_otfs, *g_offs)
 
 
 class _ZUpdate(torch.autograd.Function):
@@ -152,9 +180,11 @@ def needs_grad(x0, rhos, lams, offsets, state_tensors=()):
 class DiffPlan:
     """what the three Functions need from a recognised problem (built by FusedADMM.run_differentiable)"""
 
-    def __init__(self, codes, psi, diag, FK, omega_otfs, eps, hist_bf16=False):
+    def __init__(self, codes, psi, diag, FK, omega_otfs, eps, hist_bf16=False, doe=()):
         self.codes, self.psi, self.diag, self.FK, self.omega_otfs, self.eps = codes, psi, diag, FK, omega_otfs, eps
         self.hist_bf16 = hist_bf16        # keep the backward pass's history (rhs, x, v_i per iteration) in bf16
+        # conv_doe data terms whose PSF requires grad: [(full OTF as an autograd tensor (_FullOtf), fft2 of the term's offset or None)]
+        self.doe = list(doe)
 
 
 def _sched_table(vals, T, B, dev):
@@ -274,14 +304,15 @@ def run(plan: DiffPlan, state, rhos, lams, max_iter, diff_offsets):
     ext = [i for i, (_, pc) in enumerate(codes) if pc == be.PROX_EXTERNAL]
     rho_tab = _sched_table(rhos, max_iter, B, dev)
     lam_tabs = [_sched_table(lams[fn], max_iter, B, dev) for fn in plan.psi]
-    if not ext and n > 0 and max_iter > 0 and not os.environ.get("DPX_UNROLL_CHAIN"):
+    doe_otfs = [o for o, _ in plan.doe]
+    if not ext and n > 0 and max_iter > 0 and not doe_otfs and not os.environ.get("DPX_UNROLL_CHAIN"):
         out = _UnrolledClosed.apply(plan, max_iter, rho_tab, *lam_tabs, *v, *u, *diff_offsets)
         return out[0], list(out[1:1 + n]), list(out[1 + n:1 + 2 * n])
     for it in range(max_iter):
         rho = rho_tab[it]
         lam = [lt[it] for lt in lam_tabs]
         rhs = _Rhs.apply(codes, rho, *v, *u)
-        x = _Solve.apply(plan, rhs, rho, *diff_offsets)
+        x = _Solve.apply(plan, rhs, rho, *doe_otfs, *diff_offsets)
         nv, nu = list(v), list(u)
         if closed:
             out = _ZUpdate.apply(plan, closed, x, *[lam[i] for i in closed], *[u[i] for i in closed])

@@ -257,12 +257,22 @@ class FusedADMM:
 
         # ---- differentiable (unrolled-training) mode: hand-written backward stages, autodiff.py -------------------
         raw_offs = [self._offset_autograd(fn, x0) for fn in s.omega_fns]
-        if dual and not vxu and autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u)):
-            otfs = []
+        trained_psfs = [cv.psf for cv in map(_omega_conv, s.omega_fns)
+                        if isinstance(cv, conv_doe) and cv.circular and isinstance(cv.psf, torch.Tensor) and cv.psf.requires_grad]
+        if dual and not vxu and autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u) + trained_psfs):
+            otfs, doe = [], []
             for fn in s.omega_fns:
                 cv = _omega_conv(fn)
                 otfs.append(cv._tables(x0.shape, dev) if cv is not None else None)
-            plan = autodiff.DiffPlan(self.codes, psi, (t0, c0, t1, c1), FK, otfs, ls_eps(ls), hist_bf16=getattr(s, "unroll_dtype", "f32") == "bf16")
+                if isinstance(cv, conv_doe) and cv.circular and isinstance(cv.psf, torch.Tensor) and cv.psf.requires_grad and torch.is_grad_enabled():
+                    # end-to-end optics: the PSF is trained through the solver -- its OTF enters the x-updates as an autograd tensor
+                    from ..linop.fourier import _doe_padded
+                    P = _doe_padded(cv.psf.float().to(dev), x0.shape).expand(1, C, H, W).contiguous()
+                    off = fn.offset
+                    Yhat = None if off is None else ops.cfft2(off.detach().to(dev).expand_as(x0).contiguous(), inverse=False, centred=False, ortho=False)
+                    doe.append((autodiff._FullOtf.apply(P), Yhat))
+            plan = autodiff.DiffPlan(self.codes, psi, (t0, c0, t1, c1), FK, otfs, ls_eps(ls), hist_bf16=getattr(s, "unroll_dtype", "f32") == "bf16",
+                                     doe=doe)
             diff_offs = [o if o is not None else torch.zeros((), device=dev) for o in raw_offs]
             x, v, u = autodiff.run(plan, (x0, v, u), rhos, {fn: lams[fn] for fn in psi}, T, diff_offs)
             s.Kall.update_vars([x.detach()])
@@ -439,8 +449,14 @@ class FusedADMM:
         """The offset b of a recognised Omega term as an autograd-connected tensor when one of its constants requires
         grad (offset = -sum of the constant leaves of  K x + c_1 + ...), else None.  Only routes gradients: the forward
         pass uses the data spectrum built from the native offset."""
+        if not torch.is_grad_enabled():
+            return None
+        b = getattr(fn, "_b", None)                        # sum_squares(linop, b): the observation given as the second argument
+        if b is not None:
+            val = fn.unwrap(b)
+            return val.to(x0.device).expand_as(x0) if isinstance(val, torch.Tensor) and val.requires_grad else None
         consts = [c for c in fn.linop.constants if isinstance(c._value, torch.Tensor) and c._value.requires_grad]
-        if not consts or not torch.is_grad_enabled():
+        if not consts:
             return None
         tot = None
         for c in fn.linop.constants:

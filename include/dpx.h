@@ -286,6 +286,13 @@ int dpx_admm_solve_rho_grad(const float* g_rhs, const float* x, const int* linop
 int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv,
                      float* const* gu, float* grho, int B, int C, int H, int W, void* ws, dpx_stream_t stream);
 
+/* Gradient of the Fourier x-update w.r.t. the OTF of a convolutional data term whose PSF is trained through the solver
+ * (end-to-end optics, reference README.md:93-116 with conv_doe, linop/conv.py:81-156; there PyTorch autograd through fft2):
+ * G[c,k] (+)= (1/HW) sum_b [ conj(A) Y - 2 Re(A conj X) O ],  A = fft2(g_rhs), X = fft2(x), Y = fft2(offset) (nullable),
+ * O = the OTF; full complex spectra in natural order, unnormalised transforms (dpx_cfft2).  G = dL/dRe O + i dL/dIm O.          */
+int dpx_otf_grad(const void* A, const void* X, const void* Y, const void* O, void* G, int B, int C, int H, int W, int accumulate,
+                 dpx_stream_t stream);
+
 /* ---- unrolled ADMM with closed-form proxes: T iterations forward / backward without returning to the host language
  * (specialization/unroll.py:14-58 over algo/admm.py:49-59; the per-stage calls above, sequenced on the C side).
  * hist (dpx_admm_unrolled_hist_bytes): per iteration [rhs][x][v_0..v_{n-1}][u_0..u_{n-1}] planes of B*C*H*W floats -- the

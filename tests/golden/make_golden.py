@@ -660,6 +660,39 @@ def g19_conv_doe():
     save("g19_conv_doe", **out)
 
 
+def g25_doe_psf_grad():
+    """End-to-end optics (README.md:93-116): the PSF of a conv_doe data term sits in a Placeholder, the solver is unrolled, and the
+    loss is differentiated w.r.t. the PSF, the observation and the schedules by the reference's autograd (linop/conv.py:81-156:
+    the Placeholder's value is wrapped in an nn.Parameter whose .grad receives the PSF gradient)."""
+    from dprox.linop.conv import conv_doe
+    rng = np.random.RandomState(250)
+    out = {}
+    for tag, (B, C, H, W, f, K) in (("a", (2, 3, 32, 32, 7, 4)), ("b", (1, 1, 20, 24, 5, 3))):
+        gt = rng.rand(B, C, H, W).astype("float32")
+        psf = rng.rand(1, C, f, f + (W - H)).astype("float32") ** 2       # (psf2otf2 pads both axes by the height difference)
+        psf /= psf.sum(axis=(-2, -1), keepdims=True)
+        xv = dp.Variable()
+        P, Y = dp.Placeholder(), dp.Placeholder()
+        op = conv_doe(xv, P, circular=True)
+        with torch.no_grad():
+            y = conv_doe(dp.Variable(), T(psf)).forward(T(gt)) + T((rng.randn(B, C, H, W) * 0.01).astype("float32"))
+        n0, n1 = dp.norm1(dp.grad(xv, dim=0)), dp.norm1(dp.grad(xv, dim=1))
+        yt = y.clone().requires_grad_(True)
+        P.value, Y.value = T(psf), yt
+        solver = dp.compile(dp.sum_squares(op, Y) + n0 + n1, method="admm", device="cpu")
+        solver = dp.specialize(solver, method="unroll", device="cpu", max_iter=K)
+        rhos = torch.full((K,), 0.2, requires_grad=True)
+        lam = torch.full((K,), 0.01, requires_grad=True)
+        xo = solver.solve(x0=y, rhos=rhos, lams={n0: lam, n1: lam})
+        loss = ((xo - T(gt)) ** 2).mean()
+        loss.backward()
+        assert op.psf.grad is not None and yt.grad is not None
+        out.update({f"{tag}_gt": gt, f"{tag}_psf": psf, f"{tag}_y": y, f"{tag}_x": xo.detach(), f"{tag}_loss": loss.detach().double(),
+                    f"{tag}_g_psf": op.psf.grad, f"{tag}_g_y": yt.grad, f"{tag}_g_rhos": rhos.grad, f"{tag}_g_lam": lam.grad, f"{tag}_K": K})
+        print("g25", tag, float(loss), float(op.psf.grad.abs().max()), float(yt.grad.abs().max()))
+    save("g25_doe_psf_grad", **out)
+
+
 def g20_drunet():
     """DRUNet (UNetRes, models/network_unet.py:67-117) behind DRUNetDenoiser (wrapper.py:89-146) with seeded weights:
     the padded single-pass path (<= 256x256, size not a multiple of 16) and the four-quadrant path (> 256x256)."""
@@ -998,7 +1031,7 @@ def g33_full_c5():
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
-               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad,
+               g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
                g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -768,6 +768,38 @@ def case_conv_doe(device):
     assert_close(xs.cpu(), g["lin_tv_x"], TOL, "conv_doe linear TV x")
 
 
+def case_doe_psf_grad(device):
+    """G25 -- end-to-end optics (reference README.md:93-116): the PSF of a conv_doe data term is trained through the unrolled solver.
+    Loss, x and the gradients w.r.t. the PSF, the observation and the rho / lambda schedules against the reference's autograd
+    (there torch.fft ops; here dpx_otf_grad behind the Fourier x-update's backward + one adjoint transform)."""
+    g = load_golden("g25_doe_psf_grad")
+    for tag in ("a", "b"):
+        K = int(g[f"{tag}_K"])
+        gt, y0 = T(g[f"{tag}_gt"], device), T(g[f"{tag}_y"], device)
+        psf = T(g[f"{tag}_psf"], device).clone().requires_grad_(True)
+        y = y0.clone().requires_grad_(True)
+        xv = dp.Variable()
+        P, Y = dp.Placeholder(), dp.Placeholder()
+        n0, n1 = dp.norm1(dp.grad(xv, dim=0)), dp.norm1(dp.grad(xv, dim=1))
+        fns = dp.sum_squares(dp.conv_doe(xv, P, circular=True), Y) + n0 + n1
+        P.value, Y.value = psf, y
+        solver = dp.compile(fns, method="admm", device=device)
+        solver = dp.specialize(solver, method="unroll", device=device, max_iter=K)
+        rhos = torch.full((K,), 0.2, requires_grad=True, device=device)
+        lam = torch.full((K,), 0.01, requires_grad=True, device=device)
+        xo = solver.solve(x0=y0, rhos=rhos, lams={n0: lam, n1: lam})
+        loss = ((xo - gt) ** 2).mean()
+        loss.backward()
+        assert_close(xo.detach().cpu(), g[f"{tag}_x"], TOL, f"doe {tag} x")
+        lv, lr = float(loss.detach().double()), float(g[f"{tag}_loss"])
+        assert abs(lv - lr) <= 1e-5 * abs(lr), (lv, lr)
+        for name, got in (("g_psf", psf.grad), ("g_y", y.grad), ("g_rhos", rhos.grad), ("g_lam", lam.grad)):
+            assert got is not None, f"doe {tag}: no gradient reached {name}"
+            r = rel_l2(got.detach().cpu().numpy(), g[f"{tag}_{name}"])
+            record(f"doe {tag} {name} vs the reference's autograd", r, 1e-4)
+            assert r <= 1e-4, (tag, name, r)
+
+
 def case_sisr(device, solve=True):
     """G18: closed-form super-resolution data term (dpx_cfft2 + dpx_sisr_update), sf = 2 and 3, and the reference's
     super-resolution example (sisr + FFDNet prior, ADMM with the data term's own x-update)"""

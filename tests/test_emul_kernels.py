@@ -63,6 +63,10 @@ def test_dense_systems_cg_cg2_pcg_and_implicit_gradients():
     pc.case_dense_krylov(DEV)
 
 
+def test_doe_psf_gradient_through_the_unrolled_solver():
+    pc.case_doe_psf_grad(DEV)
+
+
 def test_linear_solve_implicit_backward():
     pc.case_linear_solve_grad(DEV)
 
