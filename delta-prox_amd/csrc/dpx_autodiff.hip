@@ -434,17 +434,22 @@ __global__ void k_ad_finish_iter(const float* __restrict__ part_lam, const float
 // trained through the unrolled solver, reference README.md:93-116, linop/conv.py:81-156).  With X = (R + conj(O) Y + eps) / D,
 // D = |O|^2 + rho sum|G_i|^2 + eps, A = F(g_rhs) = F(g_x) / D, all transforms unnormalised:
 //     dL/dO = (1 / HW) sum_b [ conj(A_b) Y_b - 2 Re(A_b conj(X_b)) O ]        (dL/dRe O + i dL/dIm O, O shared by the batch)
-// A, X, Y: [B][C][HW] complex (full spectra, natural order; Y nullable), O: [C][HW], G: [C][HW].
+// A, X, Y: [B][C][HW] complex (full spectra, natural order; X and Y nullable), O: [C][HW], G: [C][HW].  With X = NULL it is the
+// gradient of a plain product: y = F^-1(O F(x)) has dL/dO = (1/HW) sum_b conj(F(x)) F(g) (A = F(x), Y = F(g)), the adjoint
+// y = F^-1(conj(O) F(x)) has dL/dO = (1/HW) sum_b conj(F(g)) F(x) (A = F(g), Y = F(x)).
 __global__ void k_otf_grad(const float2* __restrict__ A, const float2* __restrict__ X, const float2* __restrict__ Y,
                            const float2* __restrict__ O, float2* __restrict__ G, int B, long chw, float scale, int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += (long)gridDim.x * blockDim.x) {
     const float2 o = O[i];
     float2 acc = make_float2(0.f, 0.f);
     for (int b = 0; b < B; ++b) {
-      const float2 a = A[(long)b * chw + i], x = X[(long)b * chw + i];
-      const float w = 2.f * (a.x * x.x + a.y * x.y);                 // 2 Re(A conj X)
-      acc.x -= w * o.x;
-      acc.y -= w * o.y;
+      const float2 a = A[(long)b * chw + i];
+      if (X) {
+        const float2 x = X[(long)b * chw + i];
+        const float w = 2.f * (a.x * x.x + a.y * x.y);               // 2 Re(A conj X)
+        acc.x -= w * o.x;
+        acc.y -= w * o.y;
+      }
       if (Y) {
         const float2 y = Y[(long)b * chw + i];
         acc.x += a.x * y.x + a.y * y.y;                               // conj(A) Y
@@ -578,7 +583,7 @@ extern "C" int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* r
 
 extern "C" int dpx_otf_grad(const void* A, const void* X, const void* Y, const void* O, void* G, int B, int C, int H, int W, int accumulate,
                             dpx_stream_t stream) {
-  DPX_REQUIRE(A && X && O && G && B > 0 && C > 0 && H > 0 && W > 0, "dpx_otf_grad: bad arguments");
+  DPX_REQUIRE(A && (X || Y) && O && G && B > 0 && C > 0 && H > 0 && W > 0, "dpx_otf_grad: bad arguments");
   const long chw = (long)C * H * W;
   DPX_LAUNCH("k_otf_grad", k_otf_grad, dim3(grid_for(chw, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const float2*)A, (const float2*)X,
              (const float2*)Y, (const float2*)O, (float2*)G, B, chw, 1.0f / ((float)H * (float)W), accumulate);

@@ -850,7 +850,7 @@ def csmri_update(z, y, mask, lam, num_psi):
 def otf_grad(A, X, Y, O):
     """dL/dO of the Fourier x-update (dpx_otf_grad): A, X, Y complex64 [B,C,H,W] (Y may be None), O complex64 [1,C,H,W] -> [1,C,H,W]"""
     B, C, H, W = (int(v) for v in A.shape)
-    for t, what in ((A, "A"), (X, "X"), (O, "O")) + (((Y, "Y"),) if Y is not None else ()):
+    for t, what in ((A, "A"), (O, "O")) + (((X, "X"),) if X is not None else ()) + (((Y, "Y"),) if Y is not None else ()):
         require(t, dtype=torch.complex64, what=f"otf_grad {what}")
     G = torch.empty_like(O)
     be.lib().call("dpx_otf_grad", ptr(A), ptr(X), ptr(Y), ptr(O), ptr(G), B, C, H, W, 0, be.stream())

@@ -20,6 +20,7 @@ import torch
 
 from .. import _backend as be
 from .. import _ops as ops
+from ..linop.fourier import _FullOtf
 
 _DIM = {be.LIN_GRAD_H: 0, be.LIN_GRAD_W: 1}
 
@@ -83,22 +84,6 @@ class _Rhs(torch.autograd.Function):
         rho, rhs = ctx.saved_tensors
         gv, gu, g_rho = ops.admm_rhs_bwd(g.contiguous(), rhs, rho, [lc for lc, _ in ctx.codes])
         return (None, g_rho, *gv, *gu)
-
-
-class _FullOtf(torch.autograd.Function):
-    """O = fft2(P) of the padded, shifted PSF P [1,C,H,W] (unnormalised; conv_doe's psf2otf2, linop/conv.py:59-78) as an autograd
-    node: the x-updates of all iterations hand their dL/dO back to it, one adjoint transform turns the sum into dL/dP."""
-
-    @staticmethod
-    def forward(ctx, P):
-        return ops.cfft2(P.contiguous(), inverse=False, centred=False, ortho=False)
-
-    @staticmethod
-    def backward(ctx, G):
-        H, W = int(G.shape[-2]), int(G.shape[-1])
-        # dL/dP[n] = Re sum_k G_k e^{+i theta_kn}  (G = dL/dRe O + i dL/dIm O): the unnormalised inverse transform
-        g = ops.cfft2(G.contiguous(), inverse=True, centred=False, ortho=False)
-        return ops.lincomb([(float(H * W), torch.view_as_real(g)[..., 0].contiguous())])
 
 
 class _Solve(torch.autograd.Function):

@@ -104,6 +104,46 @@ def _doe_padded(psf, shape):
     return torch.fft.ifftshift(psf)
 
 
+class _FullOtf(torch.autograd.Function):
+    """O = fft2(P) of the padded, shifted PSF P [1,C,H,W] (unnormalised; conv_doe's psf2otf2, linop/conv.py:59-78) as an autograd
+    node: the x-updates of all iterations hand their dL/dO back to it, one adjoint transform turns the sum into dL/dP."""
+
+    @staticmethod
+    def forward(ctx, P):
+        return ops.cfft2(P.contiguous(), inverse=False, centred=False, ortho=False)
+
+    @staticmethod
+    def backward(ctx, G):
+        H, W = int(G.shape[-2]), int(G.shape[-1])
+        # dL/dP[n] = Re sum_k G_k e^{+i theta_kn}  (G = dL/dRe O + i dL/dIm O): the unnormalised inverse transform
+        g = ops.cfft2(G.contiguous(), inverse=True, centred=False, ortho=False)
+        return ops.lincomb([(float(H * W), torch.view_as_real(g)[..., 0].contiguous())])
+
+
+
+class _DoeConv(torch.autograd.Function):
+    """y = F^-1(op(O) F(x)) through dpx_fft_conv with gradients w.r.t. the image and the (full) OTF -- conv_doe.forward / adjoint
+    when the PSF or the image takes part in autograd"""
+
+    @staticmethod
+    def forward(ctx, img, O, tables, conj):
+        ctx.tables, ctx.conj = tables, conj
+        ctx.save_for_backward(img, O)
+        return ops.fft_conv(img.contiguous(), tables, conj=conj)
+
+    @staticmethod
+    def backward(ctx, g):
+        img, O = ctx.saved_tensors
+        g = g.contiguous()
+        g_img = ops.fft_conv(g, ctx.tables, conj=not ctx.conj) if ctx.needs_input_grad[0] else None
+        g_O = None
+        if ctx.needs_input_grad[1]:
+            G = ops.cfft2(g, inverse=False, centred=False, ortho=False)
+            X = ops.cfft2(img.contiguous(), inverse=False, centred=False, ortho=False)
+            g_O = ops.otf_grad(G, None, X, O) if ctx.conj else ops.otf_grad(X, None, G, O)
+        return g_img, g_O, None, None
+
+
 class conv_doe(LinOp):
     """Circular convolution with a PSF given as a tensor / Placeholder [1,C,fh,fw] whose OTF is rebuilt on the device
     whenever the PSF changes (reference dprox/linop/conv.py:81-156; end-to-end optics, README.md:93-116).
@@ -152,7 +192,16 @@ class conv_doe(LinOp):
 
     def _convolve(self, img, conj):
         if self.circular:
-            return ops.fft_conv(img, self._tables(img.shape, img.device), conj=conj)
+            tables = self._tables(img.shape, img.device)
+            psf = self.psf
+            if torch.is_grad_enabled() and (img.requires_grad or (isinstance(psf, torch.Tensor) and psf.requires_grad)):
+                if isinstance(psf, torch.Tensor) and psf.requires_grad:
+                    C, H, W = img.shape[-3:]
+                    O = _FullOtf.apply(_doe_padded(psf.float().to(img.device), img.shape).expand(1, C, H, W).contiguous())
+                else:
+                    O = self._full_otf(img.shape, img.device)[0]
+                return _DoeConv.apply(img, O, tables, bool(conj))
+            return ops.fft_conv(img, tables, conj=conj)
         import torch.nn.functional as F
         H, W = img.shape[-2:]
         side = 2 * H                                         # both axes are padded to twice the HEIGHT (conv.py:102-104)

@@ -288,7 +288,8 @@ int dpx_admm_rhs_bwd(const float* g, const float* rhs, const float* rho, const i
 
 /* Gradient of the Fourier x-update w.r.t. the OTF of a convolutional data term whose PSF is trained through the solver
  * (end-to-end optics, reference README.md:93-116 with conv_doe, linop/conv.py:81-156; there PyTorch autograd through fft2):
- * G[c,k] (+)= (1/HW) sum_b [ conj(A) Y - 2 Re(A conj X) O ],  A = fft2(g_rhs), X = fft2(x), Y = fft2(offset) (nullable),
+ * G[c,k] (+)= (1/HW) sum_b [ conj(A) Y - 2 Re(A conj X) O ],  A = fft2(g_rhs), X = fft2(x), Y = fft2(offset) (X or Y may be NULL:
+ * with X = NULL it is the gradient of the plain product conv_doe.forward / adjoint -- A, Y = fft2 of input and output gradient),
  * O = the OTF; full complex spectra in natural order, unnormalised transforms (dpx_cfft2).  G = dL/dRe O + i dL/dIm O.          */
 int dpx_otf_grad(const void* A, const void* X, const void* Y, const void* O, void* G, int B, int C, int H, int W, int accumulate,
                  dpx_stream_t stream);

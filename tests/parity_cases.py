@@ -800,6 +800,29 @@ def case_doe_psf_grad(device):
             assert r <= 1e-4, (tag, name, r)
 
 
+def case_doe_op_autograd(device):
+    """conv_doe.forward / adjoint under autograd (the reference's are torch.fft ops, linop/conv.py:97-135): gradients w.r.t. the
+    image and the PSF against the same convolution written with torch.fft on the CPU (psf2otf2's padding and shift included)."""
+    from dprox.linop.fourier import _doe_padded
+    rng = np.random.RandomState(26)
+    for (B, C, H, W, f) in ((2, 3, 24, 24, 7), (1, 1, 20, 24, 5)):
+        psf0 = torch.from_numpy((rng.rand(1, C, f, f + (W - H)) ** 2).astype(np.float32))
+        x0 = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32))
+        w = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32))
+        for adj in (False, True):
+            psf, x = psf0.clone().to(device).requires_grad_(True), x0.clone().to(device).requires_grad_(True)
+            op = dp.conv_doe(dp.Variable(), psf).to(device)
+            y = op.adjoint(x) if adj else op.forward(x)
+            (y * w.to(device)).sum().backward()
+            pr, xr = psf0.clone().double().requires_grad_(True), x0.clone().double().requires_grad_(True)
+            O = torch.fft.fft2(_doe_padded(pr, x0.shape))
+            yr = torch.fft.ifft2((O.conj() if adj else O) * torch.fft.fft2(xr)).real
+            (yr * w.double()).sum().backward()
+            assert_close(y.detach().cpu(), yr.detach().float(), TOL, f"conv_doe {'adjoint' if adj else 'forward'} under autograd")
+            assert_close(x.grad.cpu(), xr.grad.float(), 1e-5, "conv_doe d/d image")
+            assert_close(psf.grad.cpu(), pr.grad.float(), 1e-5, "conv_doe d/d psf")
+
+
 def case_sisr(device, solve=True):
     """G18: closed-form super-resolution data term (dpx_cfft2 + dpx_sisr_update), sf = 2 and 3, and the reference's
     super-resolution example (sisr + FFDNet prior, ADMM with the data term's own x-update)"""

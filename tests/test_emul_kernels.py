@@ -65,6 +65,7 @@ def test_dense_systems_cg_cg2_pcg_and_implicit_gradients():
 
 def test_doe_psf_gradient_through_the_unrolled_solver():
     pc.case_doe_psf_grad(DEV)
+    pc.case_doe_op_autograd(DEV)
 
 
 def test_linear_solve_implicit_backward():
