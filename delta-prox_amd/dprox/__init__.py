@@ -5,7 +5,7 @@ nonneg, deep_prior, Problem, compile, specialize, LinOp, ProxFn, LinOpFactory, l
 per-iteration arithmetic pass executed by hand-written gfx950 HIP kernels (``lib/libdpx_hip.so``,
 C ABI in ``include/dpx.h``).  There is no CPU or PyTorch fallback.
 """
-from . import linalg
+from . import contrib, linalg, utils
 from .algo import *      # noqa: F401,F403
 from .linop import *     # noqa: F401,F403
 from .proxfn import *    # noqa: F401,F403

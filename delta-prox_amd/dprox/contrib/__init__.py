@@ -14,6 +14,25 @@ def fspecial_gaussian(hsize, sigma):
     return h / s if s != 0 else h
 
 
+def sample(name="face", return_tensor=True):
+    """the reference's sample images (contrib/restoration.py:8-18: SciPy's ``face`` / ``ascent``) as float [0, 1] data -- taken from
+    whichever SciPy entry point still ships them; this package bundles no image data"""
+    data = None
+    for mod in ("scipy.datasets", "scipy.misc"):
+        try:
+            data = getattr(__import__(mod, fromlist=[name]), name)()
+            break
+        except (ImportError, AttributeError, OSError):         # (scipy.datasets needs `pooch` and a download)
+            continue
+    if data is None:
+        raise FileNotFoundError(f"sample image {name!r}: neither scipy.datasets nor scipy.misc provides it in this environment")
+    s = np.asarray(data).astype("float32") / 255
+    if return_tensor:
+        from ..utils import to_torch_tensor
+        s = to_torch_tensor(s, batch=True).float()
+    return s
+
+
 def point_spread_function(ksize, sigma):
     return np.expand_dims(fspecial_gaussian(ksize, sigma), axis=2).astype("float32")
 
@@ -56,3 +75,6 @@ def masked_fft(arg, mask):
             return ops.clincomb([(1.0, z)], out_complex=False)
 
     return _MaskedFFT(arg, mask)
+
+
+from . import csmri                                                             # noqa: E402,F401  (contrib.csmri.*, reference contrib/csmri.py)

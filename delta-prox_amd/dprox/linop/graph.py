@@ -16,6 +16,44 @@ from .leaf import Constant, Variable
 from .node import LinOp
 
 
+class _LinNode(torch.autograd.Function):
+    """A built-in linear node (a fixed linear map evaluated by HIP kernels) as an autograd node: the backward of its forward is
+    its adjoint and vice versa.  In the reference these operators are eager torch ops and differentiable by construction
+    (tests/test_linop.py:64-80 back-propagates through ``sum``); nodes that bring their own autograd (conv_doe: the PSF) and
+    user-defined LinOps (whose forward / adjoint may hold parameters) are called directly."""
+
+    @staticmethod
+    def forward(ctx, node, transpose, *args):
+        out = (node.adjoint if transpose else node.forward)(*args)
+        ctx.node, ctx.transpose, ctx.n_in = node, transpose, len(args)
+        ctx.multi = isinstance(out, (list, tuple))
+        ctx.shapes = [(a.shape, a.dtype, a.device) for a in (out if ctx.multi else [out])]
+        return tuple(out) if ctx.multi else out
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [torch.zeros(sh, dtype=dt, device=dv) if g is None else g.contiguous() for g, (sh, dt, dv) in zip(gs, ctx.shapes)]
+        back = (ctx.node.forward if ctx.transpose else ctx.node.adjoint)(*gs)
+        back = list(back) if isinstance(back, (list, tuple)) else [back]
+        return (None, None, *back[:ctx.n_in], *([None] * (ctx.n_in - len(back))))
+
+
+def _native_types():
+    from .arith import copy, scale
+    from .diagonal import mosaic, mul_color, mul_elementwise
+    from .fourier import conv, grad
+    return (conv, grad, mosaic, mul_elementwise, mul_color, scale, _sum, copy)
+
+
+def _apply(node, args, transpose):
+    """node.forward(*args) (or adjoint), through _LinNode when something in `args` takes part in autograd"""
+    if torch.is_grad_enabled() and type(node) in _native_types() and \
+            any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
+        out = _LinNode.apply(node, transpose, *args)
+        return LinOp.MultOutput(out) if isinstance(out, tuple) else out
+    return (node.adjoint if transpose else node.forward)(*args)
+
+
 class CompGraph:
     def __init__(self, end, zero_out_constant=False):
         self.end = end
@@ -42,9 +80,12 @@ class CompGraph:
             if any(i is None for i in ins):      # mixed: materialise the zeros
                 ref = next(i for i in ins if i is not None)
                 ins = [torch.zeros_like(ref) if i is None else i for i in ins]
-        return node.forward(*ins)
+        return _apply(node, ins, False)
 
     def forward(self, *values, return_list=False):
+        # (integer images -- uint8 from an image file -- are promoted like torch.fft promotes them in the reference's operators)
+        values = [v.float() if isinstance(v, torch.Tensor) and not (v.is_floating_point() or v.is_complex()) else v for v in values]
+        values = [v.contiguous() if isinstance(v, torch.Tensor) else v for v in values]
         env = {v.uuid: val for v, val in zip(self.variables, values)}
         y = self._fwd(self.end, env)
         if y is None and values and len(self.end.input_nodes) > 0:
@@ -60,7 +101,7 @@ class CompGraph:
         if isinstance(node, Variable):
             acc[node.uuid] = y if node.uuid not in acc else ops.lincomb([(1.0, acc[node.uuid]), (1.0, y)])
             return
-        ins = node.adjoint(*y) if isinstance(y, LinOp.MultOutput) else node.adjoint(y)
+        ins = _apply(node, list(y) if isinstance(y, LinOp.MultOutput) else [y], True)
         kids = list(node.input_nodes)
         if len(kids) == 1:
             self._adj(kids[0], ins, acc)

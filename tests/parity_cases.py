@@ -800,6 +800,35 @@ def case_doe_psf_grad(device):
             assert r <= 1e-4, (tag, name, r)
 
 
+def case_linop_autograd(device):
+    """Built-in linear nodes under autograd (the reference's operators are eager torch ops: tests/test_linop.py:64-80 back-propagates
+    through ``sum``): d/dx of <w, K x> is K^T w for every built-in K, including expressions with a shared variable, and uint8 /
+    permuted inputs are accepted like the reference's operators accept them."""
+    import synthetic
+    rng = np.random.RandomState(31)
+    psf = synthetic.point_spread_function(9, 2.0)
+    x = dp.Variable()
+    exprs = [dp.conv(x, psf), dp.grad(x, dim=0) + dp.grad(x, dim=1), 2.0 * dp.conv(x, psf) - 0.5 * dp.grad(x, dim=1), dp.mosaic(x)]
+    for e in exprs:
+        K = dp.CompGraph(e.to(device))
+        xt = torch.from_numpy(rng.randn(2, 3, 24, 32).astype(np.float32)).to(device).requires_grad_(True)
+        w = torch.from_numpy(rng.randn(2, 3, 24, 32).astype(np.float32)).to(device)
+        y = K.forward(xt)
+        (y * w).sum().backward()
+        assert_close(xt.grad.cpu(), K.adjoint(w).cpu(), 1e-6, f"d/dx <w, Kx> = K^T w for {e}")
+    x1, x2 = dp.Variable(), dp.Variable()
+    K = dp.CompGraph((x1 + x2).to(device))
+    v1 = torch.randn(4, 4, device=device, requires_grad=True)
+    v2 = torch.randn(4, 4, device=device)
+    out = K.forward(v1, v2)
+    assert torch.allclose(out, v1 + v2)
+    out.mean().backward()
+    assert torch.allclose(v1.grad, torch.full_like(v1.grad, 1 / 16))
+    img8 = torch.from_numpy((rng.rand(24, 32, 3) * 255).astype(np.uint8)).permute(2, 0, 1)[None].to(device)     # HWC uint8 -> NCHW view
+    K = dp.CompGraph(dp.conv(dp.Variable(), psf).to(device))
+    assert_close(K.forward(img8).cpu(), K.forward(img8.float().contiguous()).cpu(), 1e-7, "uint8 / permuted input")
+
+
 def case_doe_op_autograd(device):
     """conv_doe.forward / adjoint under autograd (the reference's are torch.fft ops, linop/conv.py:97-135): gradients w.r.t. the
     image and the PSF against the same convolution written with torch.fft on the CPU (psf2otf2's padding and shift included)."""

@@ -68,6 +68,10 @@ def test_doe_psf_gradient_through_the_unrolled_solver():
     pc.case_doe_op_autograd(DEV)
 
 
+def test_builtin_linear_nodes_under_autograd():
+    pc.case_linop_autograd(DEV)
+
+
 def test_linear_solve_implicit_backward():
     pc.case_linear_solve_grad(DEV)
 
