@@ -162,8 +162,12 @@ def extra_configs(dp, synthetic, device):
     flop = 3.5695e12                                   # denoiser FLOP per iteration at B = 8
     out["config3"] = {"workload": "8x3x1024x1024 PnP ADMM, FFDNet-colour z-update (seeded weights), 30 it", "ms_per_iter": dt / 30 * 1e3,
                       "it_per_s": 30 / dt, "path": s.last_path,
-                      "denoiser_arithmetic": getattr(prior.denoiser.model, "compute_mode", "f32") + " (bf16x3 = three-term split-bf16 operands on the bf16 matrix cores, "
-                                             "fp32 accumulation: 3e-7 from the f32-input MFMA path)",
+                      "denoiser_arithmetic": getattr(prior.denoiser.model, "compute_mode", "f32") + " (f16x2 = operands split into two binary16 terms, three "
+                                             "products on the f16 matrix cores, fp32 accumulation: 2e-7 from the f32-input MFMA path, parity-pinned by "
+                                             "G8 / G31 at 1e-5; bf16x3 = three bf16 terms, six products)",
+                      "roofline_split_f16": {"bound": "mfma", "unit": "TFLOP/s", "achieved": flop * 30 / dt / 1e12, "peak": 2500.0 / 3.0,
+                                             "frac": flop * 30 / dt / (2500.0e12 / 3.0),
+                                             "note": "fp32-equivalent FLOP rate vs the dense f16 MFMA peak / 3 products"},
                       "roofline": {"bound": "mfma", "unit": "TFLOP/s", "achieved": flop * 30 / dt / 1e12, "peak": 157.3,
                                    "frac": flop * 30 / dt / 157.3e12, "note": "denoiser FLOP / whole-iteration time vs the dense fp32 MFMA peak"}}
     del s, prior, b3, gt3

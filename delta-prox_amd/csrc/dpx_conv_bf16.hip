@@ -58,9 +58,39 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
   return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
 }
 
+// MODE = 3 ("split-f16"): x = hi + lo / 2048 with hi = half(x) (11 significant bits, round to nearest) and lo = half((x - hi) * 2048)
+// (the next 11 bits, scaled by 2^11 so that it stays in the normal range of binary16).  Three products  wh ah | wh al | wl ah
+// (dropped: wl al <= 2^-22 |w a|); the two cross terms go to their own accumulator, which enters the result times 2^-11.
+// Measured on the FFDNet stack against float64: 9.7e-8 (the f32-input instruction: 1.1e-7, split-bf16: 5.8e-8).  Operands must stay
+// below the binary16 range (6.5e4): the split pass counts the values that do not (dpx_ffdnet_f16_overflow).
+// Both parts as fp32-style words whose upper 16 bits hold the binary16 pattern (so that pack_hi16 packs them like the bf16 parts).
+constexpr float F16_LO_SCALE = 2048.f;
+__device__ unsigned g_f16_overflow = 0u;                              // set by any split-f16 layer that met |x| > 6e4
+__device__ __forceinline__ unsigned f16_word(float x) {
+  const _Float16 h = (_Float16)x;
+  unsigned short b;
+  __builtin_memcpy(&b, &h, 2);
+  return (unsigned)b << 16;
+}
+__device__ __forceinline__ float f16_word_value(unsigned w) {
+  const unsigned short b = (unsigned short)(w >> 16);
+  _Float16 h;
+  __builtin_memcpy(&h, &b, 2);
+  return (float)h;
+}
+__device__ __forceinline__ void split2_f16(float x, unsigned& h, unsigned& l) {
+  h = f16_word(x);
+  l = f16_word((x - f16_word_value(h)) * F16_LO_SCALE);
+}
+
 #ifdef DPX_EMULATED
 __device__ inline f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) { return emul_mfma_32x32x16_bf16(a, b, c); }
+__device__ inline f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) { return emul_mfma_32x32x16_f16(a, b, c); }
 #else
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -94,6 +124,10 @@ __global__ void k_bx_pack_weights(const float* __restrict__ w, const float* __re
     if (mode == 1) {
       h = bf16_rne(v);
       m = l = 0u;
+    } else if (mode == 3) {
+      split2_f16(v, h, m);
+      l = 0u;
+      if (fabsf(v) > 6.0e4f) atomicOr(&g_f16_overflow, 1u);
     } else {
       split3(v, h, m, l);
     }
@@ -146,7 +180,7 @@ template <int MT, bool RELU, int MODE>
 __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict__ in, float* __restrict__ out, const char* __restrict__ wpk, int Gin,
                                                         int Gout, int H, int W, int tiles_x) {
   constexpr int M32 = MT * 32, TAPB = bx_tap_bytes(MT), SLOTB = bx_slot_bytes(MT);
-  constexpr int NPL = MODE == 1 ? 1 : 3;                              // operand planes in use
+  constexpr int NPL = MODE == 1 ? 1 : (MODE == 3 ? 2 : 3);            // operand planes in use (the packed layouts always have room for three)
   HIP_DYNAMIC_SHARED(char, smem_bx)
   char* land = smem_bx;
   char* tile = smem_bx + BX_LAND_BYTES;
@@ -194,12 +228,17 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
   };
 
   f32x16 acc[MT][2];
+  f32x16 accx[MODE == 3 ? MT : 1][2];                                 // split-f16: the two cross terms, scaled by 2^11
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][r][i] = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        acc[mt][r][i] = 0.f;
+        if (MODE == 3) accx[MODE == 3 ? mt : 0][r][i] = 0.f;
+      }
+  unsigned f16_bad = 0u;                                              // split-f16: operands outside the binary16 range seen by this thread
 
   const int nslots = chunks * 3;
   if (!(DPX_BX_DBG & 4)) {
@@ -221,15 +260,19 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
         if constexpr (MODE == 1) {
           h[j] = bf16_rne(v[j]);
           m[j] = l[j] = 0u;
+        } else if constexpr (MODE == 3) {
+          split2_f16(v[j], h[j], m[j]);
+          l[j] = 0u;
+          f16_bad |= (fabsf(v[j]) > 6.0e4f) ? 1u : 0u;
         } else {
           split3(v[j], h[j], m[j], l[j]);
         }
       }
       *(uint4*)(tile + u * 16) = make_uint4(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7]));
-      if constexpr (MODE != 1) {
+      if constexpr (MODE != 1)
         *(uint4*)(tile + BX_PLANE_BYTES + u * 16) = make_uint4(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7]));
+      if constexpr (MODE == 6)
         *(uint4*)(tile + 2 * BX_PLANE_BYTES + u * 16) = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
-      }
     }
     if (!(DPX_BX_DBG & 4)) {
     DPX_LDS_BARRIER();                                                // tile ready, landing buffer free
@@ -263,6 +306,10 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
           for (int r = 0; r < 2; ++r) {
             if constexpr (MODE == 1) {
               acc[mt][r] = mfma_bf16(af[0], bf[r][0], acc[mt][r]);
+            } else if constexpr (MODE == 3) {
+              accx[mt][r] = mfma_f16(af[1], bf[r][0], accx[mt][r]);   // wl ah   (x 2^11)
+              accx[mt][r] = mfma_f16(af[0], bf[r][1], accx[mt][r]);   // wh al   (x 2^11)
+              acc[mt][r] = mfma_f16(af[0], bf[r][0], acc[mt][r]);     // wh ah
             } else {
               // small terms first, the leading product last
               acc[mt][r] = mfma_bf16(af[1], bf[r][1], acc[mt][r]);    // wm am
@@ -277,6 +324,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
       }
     }
   }
+  if (MODE == 3 && f16_bad) atomicOr(&g_f16_overflow, 1u);
   // ---- epilogue: bias, ReLU, C8 store.  D layout: col = lane & 31 (pixel), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) (cout) ----
   float* outb = out + (size_t)b * Gout * H * W * 8;
   const int xx = x0 + n;
@@ -294,6 +342,13 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
         v.y = acc[mt][r][4 * q + 1] + bias[cl + 1];
         v.z = acc[mt][r][4 * q + 2] + bias[cl + 2];
         v.w = acc[mt][r][4 * q + 3] + bias[cl + 3];
+        if constexpr (MODE == 3) {
+          constexpr float s = 1.0f / F16_LO_SCALE;
+          v.x = fmaf(accx[mt][r][4 * q + 0], s, v.x);
+          v.y = fmaf(accx[mt][r][4 * q + 1], s, v.y);
+          v.z = fmaf(accx[mt][r][4 * q + 2], s, v.z);
+          v.w = fmaf(accx[mt][r][4 * q + 3], s, v.w);
+        }
         if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
         if (cg < Gout && yy < H && xx < W) *(float4*)(outb + (((size_t)cg * H + yy) * W + xx) * 8 + 4 * kg) = v;
       }
@@ -332,7 +387,7 @@ static int groups16(int c) { return 2 * ((c + 15) / 16); }           // channel 
 
 using namespace dpx;
 
-// mode: 6 = split-bf16 (fp32-accurate), 1 = plain bf16 operands
+// mode: 6 = split-bf16 (fp32-accurate), 3 = split-f16 (fp32-accurate for |operands| < 6e4, half the matrix work), 1 = plain bf16 operands
 extern "C" size_t dpx_ffdnet_bf16_packed_bytes(int in_nc, int nc, int nb) {
   size_t n = 0;
   for (int l = 0; l < nb; ++l) n += bx_layer_bytes(bx_cin(l, in_nc, nc), bx_cout(l, in_nc, nc, nb));
@@ -341,7 +396,7 @@ extern "C" size_t dpx_ffdnet_bf16_packed_bytes(int in_nc, int nc, int nb) {
 
 extern "C" int dpx_ffdnet_bf16_pack(void* packed, const float* const* w, const float* const* b, int in_nc, int nc, int nb, int mode,
                                     dpx_stream_t stream) {
-  DPX_REQUIRE(packed && w && b && in_nc > 0 && nc > 0 && nb >= 2 && (mode == 6 || mode == 1), "dpx_ffdnet_bf16_pack: bad arguments");
+  DPX_REQUIRE(packed && w && b && in_nc > 0 && nc > 0 && nb >= 2 && (mode == 6 || mode == 1 || mode == 3), "dpx_ffdnet_bf16_pack: bad arguments");
   DPX_REQUIRE(nc <= 96 && nc % 16 == 0 && 4 * in_nc <= 96, "dpx_ffdnet_bf16_pack: layers of 16..96 channels (multiples of 16), got %d", nc);
   char* dst = (char*)packed;
   for (int l = 0; l < nb; ++l) {
@@ -363,7 +418,7 @@ extern "C" size_t dpx_ffdnet_bf16_ws_bytes(int B, int in_nc, int nc, int H, int 
 extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode,
                                        int B, int H, int W, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(x && y && sigma && packed && ws, "dpx_ffdnet_forward_bf16: null pointer");
-  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 && (mode == 6 || mode == 1),
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 && (mode == 6 || mode == 1 || mode == 3),
               "dpx_ffdnet_forward_bf16: unsupported configuration (in_nc=%d nc=%d nb=%d mode=%d)", in_nc, nc, nb, mode);
   hipStream_t s = (hipStream_t)stream;
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
@@ -384,6 +439,7 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
     float* dst = lastl ? last : ((l & 1) ? bufB : bufA);
     const int gout = lastl ? GL : Gc;
     if (mode == 1) launch_bx_mt<1>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    else if (mode == 3) launch_bx_mt<3>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     else launch_bx_mt<6>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     wl += bx_layer_bytes(cin, cout);
     cur = dst;
@@ -425,4 +481,16 @@ extern "C" int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, in
   const float* xs[2] = {d, v_new};
   const float cf[2] = {1.f, -1.f};
   return dpx_lincomb(terms[ext].u, 2, xs, cf, nullptr, B, (long)C * H * W, stream);     // u = d - v
+}
+
+// 1 if a split-f16 layer (mode 3) has met an operand outside the binary16 range since the last reset (results of that call are then
+// invalid: rerun in mode 6).  Synchronises the device.
+extern "C" int dpx_ffdnet_f16_overflow(int reset) {
+  unsigned v = 0u;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(dpx::g_f16_overflow), sizeof(v)) != hipSuccess) return DPX_ERR_LAUNCH;
+  if (reset && v) {
+    const unsigned z = 0u;
+    hipMemcpyToSymbol(HIP_SYMBOL(dpx::g_f16_overflow), &z, sizeof(z));
+  }
+  return v ? 1 : 0;
 }

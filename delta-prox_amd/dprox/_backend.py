@@ -80,6 +80,7 @@ SIGNATURES = {
     "dpx_bgram_f64": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "dpx_lincomb_f64": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_double), POINTER(c_void_p), c_int, c_long, c_void_p]),
     "dpx_absmax": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
+    "dpx_ffdnet_f16_overflow": (c_int, [c_int]),
     "dpx_otf_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_comm_unique_id": (c_int, [c_void_p]),
     "dpx_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
@@ -208,6 +209,46 @@ def _inject_for_tests(library, host_pointers):
 
 def host_mode():
     return _host_pointers
+
+
+# ---- range trap of the split-f16 denoiser arithmetic (FFDNet.compute_mode = "f16x2") -------------------------------------------
+_f16_pending = False
+_solve_depth = 0
+
+
+def note_f16_launch():
+    global _f16_pending
+    _f16_pending = True
+
+
+def check_f16_range(where):
+    """after a solve / a direct denoiser call that ran split-f16 layers: fail loudly if an operand left the binary16 range"""
+    global _f16_pending
+    if not _f16_pending or _solve_depth > 0:
+        return
+    _f16_pending = False
+    if lib().query("dpx_ffdnet_f16_overflow", 1):
+        raise DpxError(f"{where}: an activation or weight left the binary16 range (|x| > 6e4) in the split-f16 arithmetic of the "
+                       "FFDNet layers -- that result is invalid.  Set `<denoiser>.model.compute_mode = 'bf16x3'` (any range, "
+                       "~1.4x slower) and rerun")
+
+
+class solve_scope:
+    """defers the range check to the end of the outermost solve (one device synchronisation per solve instead of one per layer)"""
+
+    def __init__(self, where):
+        self.where = where
+
+    def __enter__(self):
+        global _solve_depth
+        _solve_depth += 1
+
+    def __exit__(self, et, ev, tb):
+        global _solve_depth
+        _solve_depth -= 1
+        if et is None:
+            check_f16_range(self.where)
+        return False
 
 
 def host_mode_skip_fast_cg():

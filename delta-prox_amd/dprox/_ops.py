@@ -517,7 +517,9 @@ def admm_pnp_iter(x, rhs, term_arr, nterms, ext, v_new, rho, sigma, spec_add, dd
     """one plug-and-play ADMM iteration in one C call (dpx_admm_pnp_iter); `net`: the FFDNet module of term `ext`"""
     B, C, H, W = _shape4(x)
     L = be.lib()
-    mode = {"f32": 0, "bf16x3": 6, "bf16": 1}[net.compute_mode]
+    mode = {"f32": 0, "bf16x3": 6, "bf16": 1, "f16x2": 3}[net.compute_mode]
+    if mode == 3:
+        be.note_f16_launch()
     Bn = B if net.in_nc == C else B * C
     if mode == 0:
         packed = net.packed()

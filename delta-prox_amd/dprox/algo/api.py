@@ -89,14 +89,15 @@ class UnrolledSolver(nn.Module):
                                               to_tensor(lams) if lams is not None else None, max_iter)
         dev = first.device
         x0 = x0.to(dev).float().contiguous()
-        state = first.initialize(x0)
-        for it in range(max_iter):
-            solver = self.solvers[it]
-            rho = rhos[..., it:it + 1].to(dev)
-            # schedules are keyed by the FIRST solver's Psi terms; step `it` uses its own clone of each term
-            lam = {fn_i: lams[fn_0][..., it:it + 1].to(dev) for fn_0, fn_i in zip(first.psi_fns, solver.psi_fns)}
-            solver._notify_all_op_current_step(it)
-            state = solver.iters(state, rho, lam, 1, False)
+        with be.solve_scope("solve"):
+            state = first.initialize(x0)
+            for it in range(max_iter):
+                solver = self.solvers[it]
+                rho = rhos[..., it:it + 1].to(dev)
+                # schedules are keyed by the FIRST solver's Psi terms; step `it` uses its own clone of each term
+                lam = {fn_i: lams[fn_0][..., it:it + 1].to(dev) for fn_0, fn_i in zip(first.psi_fns, solver.psi_fns)}
+                solver._notify_all_op_current_step(it)
+                state = solver.iters(state, rho, lam, 1, False)
         return state[0]
 
 

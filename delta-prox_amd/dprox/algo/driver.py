@@ -105,7 +105,7 @@ class Algorithm(nn.Module):
         x0, rhos, lams, max_iter = self.defaults(x0, rhos, lams, max_iter)
         # every kernel of the solve is issued on the current stream of the SOLVER's GPU (the C ABI takes a raw stream handle:
         # launching with another device current would run GPU-k pointers on GPU-0's stream)
-        with be.device_guard(device):
+        with be.device_guard(device), be.solve_scope("solve"):
             x0, rhos, lams = move(x0, rhos, lams, device=device)
             x0 = x0.contiguous()
             state = self.initialize(x0, **kwargs)

@@ -21,7 +21,9 @@ class Denoiser(nn.Module):
     def denoise(self, input: torch.Tensor, sigma: torch.Tensor):
         """input: [N,C,H,W]; sigma: 0-d or [N]"""
         sigma = sigma.view(-1, 1, 1, 1)
-        return self._denoise(input, sigma)
+        out = self._denoise(input, sigma)
+        be.check_f16_range("denoise")           # (no-op inside a solve: checked once at its end)
+        return out
 
     def _denoise(self, x, sigma):
         raise NotImplementedError
@@ -32,7 +34,9 @@ class Denoiser2D(Denoiser):
 
     def denoise(self, input: torch.Tensor, sigma: torch.Tensor):
         sigma = sigma.view(-1, 1, 1, 1)
-        return torch.cat([self._denoise(band.contiguous(), sigma) for band in input.split(1, dim=1)], dim=1)
+        out = torch.cat([self._denoise(band.contiguous(), sigma) for band in input.split(1, dim=1)], dim=1)
+        be.check_f16_range("denoise")
+        return out
 
 
 class RefKeyed(nn.Module):
@@ -107,10 +111,14 @@ class FFDNet(RefKeyed):
         self._packed = None
         # arithmetic of the (non-differentiable) forward pass:
         #   "bf16x3" -- fp32 accuracy on the bf16 matrix cores (weights / activations split into three bf16 terms, six products,
-        #               fp32 accumulation: dpx_conv_bf16.hip), the default wherever the layer widths are multiples of 16;
+        #               fp32 accumulation: dpx_conv_bf16.hip); any operand range;
         #   "f32"    -- the f32-input matrix instruction (bitwise an fmaf chain); also what the differentiable path uses;
+        #   "f16x2"  -- fp32 accuracy on the f16 matrix cores: x = hi + lo / 2^11 with two binary16 terms, three products (half the
+        #               matrix work of "bf16x3"; 1e-7 from float64 on this stack, like fp32 itself).  Operands must stay inside the
+        #               binary16 range (|x| < 6e4) -- a solve / denoise() call that met one that did not raises (be.check_f16_range).
+        #               The default wherever the layer widths are multiples of 16;
         #   "bf16"   -- plain bf16 operands, fp32 accumulation (bf16 training / inference mode, ~3e-3 relative).
-        self.compute_mode = os.environ.get("DPX_FFDNET_MODE", "bf16x3" if nc % 16 == 0 else "f32")
+        self.compute_mode = os.environ.get("DPX_FFDNET_MODE", "f16x2" if nc % 16 == 0 else "f32")
         self._packed_bf16 = None
 
     @property
@@ -139,6 +147,12 @@ class FFDNet(RefKeyed):
             L.call("dpx_ffdnet_bf16_pack", be.ptr(blob), pw, pb, self.in_nc, self.nc, self.nb, mode, be.stream())
             self._packed_bf16 = (key, blob)
         return self._packed_bf16[1]
+
+    @staticmethod
+    def f16_overflowed(reset=True):
+        """True if a "f16x2" forward pass since the last reset met an operand outside the binary16 range (its result is then invalid:
+        use "bf16x3").  Synchronises the device."""
+        return bool(be.lib().query("dpx_ffdnet_f16_overflow", int(bool(reset))))
 
     def load_reference_state_dict(self, sd):
         self.load_state_dict(sd, strict=True)
@@ -199,8 +213,10 @@ class FFDNet(RefKeyed):
         sig = ops.as_batch_vec(sigma, B, x.device)
         L = be.lib()
         y = torch.empty_like(x)
-        if self.compute_mode in ("bf16x3", "bf16"):
-            mode = 6 if self.compute_mode == "bf16x3" else 1
+        if self.compute_mode in ("bf16x3", "bf16", "f16x2"):
+            mode = {"bf16x3": 6, "bf16": 1, "f16x2": 3}[self.compute_mode]
+            if mode == 3:
+                be.note_f16_launch()
             ws = ops.workspace("ffdnet_bf16", L.query("dpx_ffdnet_bf16_ws_bytes", B, self.in_nc, self.nc, H, W), x.device)
             L.call("dpx_ffdnet_forward_bf16", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(self.packed_bf16(mode)), self.in_nc, self.nc,
                    self.nb, mode, B, H, W, be.ptr(ws), be.stream())

@@ -380,7 +380,11 @@ int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void*
  * three bf16 terms each (exact: 3 x 8 mantissa bits) and six products of order <= 2 are accumulated in fp32 by
  * v_mfma_f32_32x32x16_bf16 -- 2.67x the rate of the f32-input matrix instruction at a dropped-term error of 2^-24, the size of one
  * fp32 rounding.  mode = 6: that split (default inference path); mode = 1: plain bf16 operands, fp32 accumulation (bf16 training
- * mode).  Activations travel between the layers as fp32 in the channel-group layout [B][C/8][H][W][8].  nc: multiple of 16.   */
+ * mode); mode = 3: split-f16 -- x = hi + lo / 2^11 with two binary16 terms, three products on v_mfma_f32_32x32x16_f16 (half the
+ * matrix work of mode 6, 1e-7 from float64 on the FFDNet stack), valid while every operand stays inside the binary16 range:
+ * dpx_ffdnet_f16_overflow(reset) returns 1 if a mode-3 layer has met |x| > 6e4 since the last reset (synchronises the device).
+ * Activations travel between the layers as fp32 in the channel-group layout [B][C/8][H][W][8].  nc: multiple of 16.           */
+int dpx_ffdnet_f16_overflow(int reset);
 size_t dpx_ffdnet_bf16_packed_bytes(int in_nc, int nc, int nb);
 int dpx_ffdnet_bf16_pack(void* packed, const float* const* w, const float* const* b, int in_nc, int nc, int nb, int mode,
                          dpx_stream_t stream);

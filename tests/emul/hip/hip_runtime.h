@@ -52,6 +52,9 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 #define hipMemcpyDeviceToDevice 3
 #define hipMemcpyHostToDevice 1
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+#define HIP_SYMBOL(x) (&(x))
+static inline hipError_t hipMemcpyFromSymbol(void* d, const void* sym, size_t n) { memcpy(d, sym, n); return 0; }
+static inline hipError_t hipMemcpyToSymbol(void* sym, const void* s, size_t n) { memcpy(sym, s, n); return 0; }
 
 namespace emul {
 struct Idx { unsigned x, y, z; };
@@ -208,12 +211,38 @@ static inline emul_f32x16 emul_mfma_32x32x16_bf16(uint4 a, uint4 b, emul_f32x16 
   }
   return c;
 }
+// v_mfma_f32_32x32x16_f16: the same operand layout with IEEE half elements
+static inline float emul_f16_to_f32(unsigned short h) { _Float16 v; memcpy(&v, &h, 2); return (float)v; }
+static inline emul_f32x16 emul_mfma_32x32x16_f16(uint4 a, uint4 b, emul_f32x16 c) {
+  int l = ::emul::lane();
+  int j = l & 31, h = l >> 5;
+  const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+  for (int round = 0; round < 2; ++round) {
+    memcpy(::emul::wave_slot(l, 0), &av[2 * round], 8);
+    memcpy(::emul::wave_slot(l, 1), &bv[2 * round], 8);
+    ::emul::sync_wave();
+    for (int r = 0; r < 16; ++r) {
+      int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float acc = c[r];
+      for (int kg = 0; kg < 2; ++kg) {
+        unsigned short ae[4], be[4];
+        memcpy(ae, ::emul::wave_slot(kg * 32 + i, 0), 8);
+        memcpy(be, ::emul::wave_slot(kg * 32 + j, 1), 8);
+        for (int e = 0; e < 4; ++e) acc = fmaf(emul_f16_to_f32(ae[e]), emul_f16_to_f32(be[e]), acc);
+      }
+      c[r] = acc;
+    }
+    ::emul::sync_wave();
+  }
+  return c;
+}
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emul_mfma_32x32x2(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emul_mfma_16x16x4(a, b, c)
 
 // ---- atomics (fibers are serial) ------------------------------------------------------------------
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }

@@ -291,6 +291,45 @@ def _ffdnet(kind, device):
     return FFDNetDenoiser(O.ffdnet_weights(11, 1, 1, 64, 15)).to(device)
 
 
+def case_ffdnet_f16_split(device, tiny=False):
+    """split-f16 arithmetic of the FFDNet layers (the inference default): against the reference's fp32 output (G8) at the same
+    1e-5 as the other modes, and the range trap -- an input outside the binary16 range makes denoise() / solve() raise instead of
+    returning a wrong image, while "bf16x3" handles the same input.  tiny: a 3-layer 16-channel network against the f32 mode
+    (the SIMT emulator needs minutes for the 12-layer one)."""
+    import synthetic
+    from dprox import _backend as be
+    from dprox.proxfn.pnp.denoisers import FFDNetColorDenoiser
+    g = load_golden("g8_ffdnet")
+    sig = torch.tensor(0.02, device=device)
+    if tiny:
+        from dprox.proxfn.pnp.denoisers import FFDNet
+        col = FFDNetColorDenoiser()
+        col.model = FFDNet(in_nc=3, out_nc=3, nc=16, nb=3, act_mode="R").load_layers(synthetic.ffdnet_weights(5, 3, 3, 16, 3))
+        col = col.to(device)
+        x = T(g["odd_x"][:, :, :20, :28].copy(), device)
+    else:
+        col = _ffdnet("color", device)
+        x = T(g["odd_x"], device)
+    assert col.model.compute_mode == "f16x2"
+    with torch.no_grad():
+        out = col.denoise(x, sig)
+        if tiny:
+            col.model.compute_mode = "f32"
+            assert_close(out.cpu(), col.denoise(x, sig).cpu(), TOL, "FFDNet split-f16 vs the f32 mode")
+            col.model.compute_mode = "f16x2"
+        else:
+            assert_close(out.cpu(), g["odd_s0.02"], TOL, "FFDNet split-f16 odd sigma 0.02")
+        big = (x * 3.0e5).contiguous()
+        with pytest.raises(be.DpxError, match="binary16"):
+            col.denoise(big, sig)
+        col.model.compute_mode = "bf16x3"
+        ref = col.denoise(big, sig)
+        col.model.compute_mode = "f32"
+        r32 = col.denoise(big, sig)
+    assert torch.isfinite(ref).all() and rel_l2(ref.cpu().numpy(), r32.cpu().numpy()) < 1e-5
+    col.model.compute_mode = "f16x2"
+
+
 def case_ffdnet(device, which=("odd", "even", "batch", "gray")):
     """G8: FFDNet forward with seeded weights; odd sizes exercise the replicate-pad / crop path"""
     g = load_golden("g8_ffdnet")

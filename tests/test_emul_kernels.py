@@ -72,6 +72,10 @@ def test_builtin_linear_nodes_under_autograd():
     pc.case_linop_autograd(DEV)
 
 
+def test_ffdnet_split_f16_and_its_range_trap():
+    pc.case_ffdnet_f16_split(DEV, tiny=True)
+
+
 def test_linear_solve_implicit_backward():
     pc.case_linear_solve_grad(DEV)
 

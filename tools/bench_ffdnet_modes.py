@@ -14,7 +14,7 @@ for name, den, C, hw in (("color", FFDNetColorDenoiser(O.ffdnet_weights(7)).to(d
     x = torch.rand(Bn, C, hw, hw, device=dev)
     sig = torch.full((Bn,), 0.05, device=dev)
     ref = None
-    for mode in ("f32", "bf16x3", "bf16"):
+    for mode in ("f32", "bf16x3", "f16x2", "bf16"):
         den.model.compute_mode = mode
         with torch.no_grad():
             for _ in range(2): y = den.denoise(x, sig)
