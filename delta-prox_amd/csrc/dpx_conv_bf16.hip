@@ -82,6 +82,17 @@ __device__ __forceinline__ void split2_f16(float x, unsigned& h, unsigned& l) {
   h = f16_word(x);
   l = f16_word((x - f16_word_value(h)) * F16_LO_SCALE);
 }
+// two neighbouring elements at once, as the packed dwords of the operand tile (element 0 in the low half): packed conversions
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_f16_pair(float a, float b, unsigned& hw, unsigned& lw) {
+  const f32x2_t x = {a, b};
+  const f16x2_t h = __builtin_convertvector(x, f16x2_t);
+  const f32x2_t r = (x - __builtin_convertvector(h, f32x2_t)) * F16_LO_SCALE;
+  const f16x2_t l = __builtin_convertvector(r, f16x2_t);
+  __builtin_memcpy(&hw, &h, 4);
+  __builtin_memcpy(&lw, &l, 4);
+}
 
 #ifdef DPX_EMULATED
 __device__ inline f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) { return emul_mfma_32x32x16_bf16(a, b, c); }
@@ -238,7 +249,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
         acc[mt][r][i] = 0.f;
         if (MODE == 3) accx[MODE == 3 ? mt : 0][r][i] = 0.f;
       }
-  unsigned f16_bad = 0u;                                              // split-f16: operands outside the binary16 range seen by this thread
+  float f16_max = 0.f;                                                // split-f16: largest |operand| this thread has split
 
   const int nslots = chunks * 3;
   if (!(DPX_BX_DBG & 4)) {
@@ -254,16 +265,23 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
     for (int u = tid; u < ((DPX_BX_DBG & 2) ? 0 : BX_UNITS); u += 512) {
       const float4 lo4 = *(const float4*)(land + u * 32), hi4 = *(const float4*)(land + u * 32 + 16);
       const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      if constexpr (MODE == 3) {
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2_f16_pair(v[2 * j], v[2 * j + 1], hw[j], lw[j]);
+        *(uint4*)(tile + u * 16) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        *(uint4*)(tile + BX_PLANE_BYTES + u * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        const float m8 = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                               fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+        f16_max = fmaxf(f16_max, m8);
+        continue;
+      }
       unsigned h[8], m[8], l[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if constexpr (MODE == 1) {
           h[j] = bf16_rne(v[j]);
           m[j] = l[j] = 0u;
-        } else if constexpr (MODE == 3) {
-          split2_f16(v[j], h[j], m[j]);
-          l[j] = 0u;
-          f16_bad |= (fabsf(v[j]) > 6.0e4f) ? 1u : 0u;
         } else {
           split3(v[j], h[j], m[j], l[j]);
         }
@@ -324,7 +342,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
       }
     }
   }
-  if (MODE == 3 && f16_bad) atomicOr(&g_f16_overflow, 1u);
+  if (MODE == 3 && !(f16_max <= 6.0e4f)) atomicOr(&g_f16_overflow, 1u);        // (NaN counts)
   // ---- epilogue: bias, ReLU, C8 store.  D layout: col = lane & 31 (pixel), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) (cout) ----
   float* outb = out + (size_t)b * Gout * H * W * 8;
   const int xx = x0 + n;
