@@ -320,23 +320,33 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
           uint4 af[NPL];
 #pragma unroll
           for (int p = 0; p < NPL; ++p) af[p] = *(const uint4*)(wslot + ((DPX_BX_DBG & 1) ? 0 : t3 * TAPB) + ((p * 2 + kg) * M32 + mt * 32 + n) * 16);
+          if constexpr (MODE == 3) {
+            // (an accumulator is written again four matrix instructions later: no wait for the previous result)
+            accx[mt][0] = mfma_f16(af[1], bf[0][0], accx[mt][0]);     // wl ah   (x 2^11)
+            accx[mt][1] = mfma_f16(af[1], bf[1][0], accx[mt][1]);
+            acc[mt][0] = mfma_f16(af[0], bf[0][0], acc[mt][0]);       // wh ah
+            acc[mt][1] = mfma_f16(af[0], bf[1][0], acc[mt][1]);
+            accx[mt][0] = mfma_f16(af[0], bf[0][1], accx[mt][0]);     // wh al   (x 2^11)
+            accx[mt][1] = mfma_f16(af[0], bf[1][1], accx[mt][1]);
+          }
+          if constexpr (MODE == 1) {
+            acc[mt][0] = mfma_bf16(af[0], bf[0][0], acc[mt][0]);
+            acc[mt][1] = mfma_bf16(af[0], bf[1][0], acc[mt][1]);
+          } else if constexpr (MODE == 6) {
+            // small terms first, the leading product last; the two rows alternate so that an accumulator is not written by two
+            // consecutive matrix instructions
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            if constexpr (MODE == 1) {
-              acc[mt][r] = mfma_bf16(af[0], bf[r][0], acc[mt][r]);
-            } else if constexpr (MODE == 3) {
-              accx[mt][r] = mfma_f16(af[1], bf[r][0], accx[mt][r]);   // wl ah   (x 2^11)
-              accx[mt][r] = mfma_f16(af[0], bf[r][1], accx[mt][r]);   // wh al   (x 2^11)
-              acc[mt][r] = mfma_f16(af[0], bf[r][0], acc[mt][r]);     // wh ah
-            } else {
-              // small terms first, the leading product last
-              acc[mt][r] = mfma_bf16(af[1], bf[r][1], acc[mt][r]);    // wm am
-              acc[mt][r] = mfma_bf16(af[2], bf[r][0], acc[mt][r]);    // wl ah
-              acc[mt][r] = mfma_bf16(af[0], bf[r][2], acc[mt][r]);    // wh al
-              acc[mt][r] = mfma_bf16(af[1], bf[r][0], acc[mt][r]);    // wm ah
-              acc[mt][r] = mfma_bf16(af[0], bf[r][1], acc[mt][r]);    // wh am
-              acc[mt][r] = mfma_bf16(af[0], bf[r][0], acc[mt][r]);    // wh ah
-            }
+            for (int r = 0; r < 2; ++r) acc[mt][r] = mfma_bf16(af[1], bf[r][1], acc[mt][r]);    // wm am
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[mt][r] = mfma_bf16(af[2], bf[r][0], acc[mt][r]);    // wl ah
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[mt][r] = mfma_bf16(af[0], bf[r][2], acc[mt][r]);    // wh al
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[mt][r] = mfma_bf16(af[1], bf[r][0], acc[mt][r]);    // wm ah
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[mt][r] = mfma_bf16(af[0], bf[r][1], acc[mt][r]);    // wh am
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[mt][r] = mfma_bf16(af[0], bf[r][0], acc[mt][r]);    // wh ah
           }
         }
       }
