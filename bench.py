@@ -116,11 +116,11 @@ def cpu_baseline(b_host, psf, n_iters=4, sample_b=2):
 
 
 def _timed(fn, n):
-    """seconds per call over n back-to-back calls after one warm-up call; the faster of two such rounds when n is small (one stall of
-    the caching allocator -- the 755 MB history of config 5 -- in a round of five would otherwise triple its figure)"""
+    """seconds per call over n back-to-back calls after one warm-up call; the faster of two such rounds (one stall of the caching
+    allocator -- the 755 MB history of config 5 -- or a clock ramp in a round would otherwise double or triple a small figure)"""
     fn()
     best, out = None, None
-    for _ in range(2 if n <= 5 else 1):
+    for _ in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
