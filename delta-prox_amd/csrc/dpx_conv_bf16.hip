@@ -35,13 +35,15 @@ constexpr int BX_LAND_BYTES = ((BX_PIECES + 63) / 64) * 1024;        // 39936 (w
 constexpr int BX_PLANE_BYTES = BX_UNITS * 16;                        // one bf16 plane of the tile: 19584
 constexpr int BX_TILE_BYTES = 3 * BX_PLANE_BYTES;
 constexpr int BX_NPI = (BX_PIECES + 511) / 512;                      // DMA instructions per thread and chunk: 5
-__host__ __device__ constexpr int bx_tap_bytes(int MT) { return 3 * 2 * MT * 32 * 16; }     // [plane][k-group][cout][8] bf16
-__host__ __device__ constexpr int bx_slot_bytes(int MT) { return 3 * bx_tap_bytes(MT); }    // 3 taps
+// weight planes of an arithmetic mode (1 plain bf16 and 6 split-bf16: three plane slots; 3 split-f16: two)
+__host__ __device__ constexpr int bx_planes(int mode) { return mode == 3 ? 2 : 3; }
+__host__ __device__ constexpr int bx_tap_bytes(int MT, int NPW) { return NPW * 2 * MT * 32 * 16; }     // [plane][k-group][cout][8] 16-bit
+__host__ __device__ constexpr int bx_slot_bytes(int MT, int NPW) { return 3 * bx_tap_bytes(MT, NPW); }  // 3 taps
 
-// packed layer: [chunk][tap group 3][tap 3][plane 3][k-group 2][cout MT*32][8] bf16, then bias fp32 [MT*32], then 64 zero bytes
-static inline size_t bx_layer_bytes(int cin, int cout) {
+// packed layer: [chunk][tap group 3][tap 3][plane NPW][k-group 2][cout MT*32][8] 16-bit, then bias fp32 [MT*32], then 64 zero bytes
+static inline size_t bx_layer_bytes(int cin, int cout, int NPW = 3) {
   const int chunks = (cin + 15) / 16, MT = (cout + 31) / 32;
-  return (size_t)chunks * 3 * bx_slot_bytes(MT) + (size_t)MT * 32 * 4 + 64;
+  return (size_t)chunks * 3 * bx_slot_bytes(MT, NPW) + (size_t)MT * 32 * 4 + 64;
 }
 
 // exact three-way split by truncation; every part is returned as fp32 bits whose low 16 bits are zero
@@ -111,8 +113,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
 // w [cout][cin][9] fp32, b [cout] (nullable) -> packed layer.  mode 6: three exact planes; mode 1: plane 0 = RNE bf16, others 0.
 __global__ void k_bx_pack_weights(const float* __restrict__ w, const float* __restrict__ b, unsigned short* __restrict__ dst, int cin, int cout,
                                   int mode) {
-  const int chunks = (cin + 15) / 16, MT = (cout + 31) / 32, M32 = MT * 32;
-  const long nw = (long)chunks * 9 * 3 * 2 * M32 * 8;                  // bf16 elements
+  const int chunks = (cin + 15) / 16, MT = (cout + 31) / 32, M32 = MT * 32, NPW = bx_planes(mode);
+  const long nw = (long)chunks * 9 * NPW * 2 * M32 * 8;                // 16-bit elements
   float* bias = (float*)(dst + nw);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + M32 + 16; i += (long)gridDim.x * blockDim.x) {
     if (i >= nw) {
@@ -126,8 +128,8 @@ __global__ void k_bx_pack_weights(const float* __restrict__ w, const float* __re
     r /= M32;
     const int kg = (int)(r % 2);
     r /= 2;
-    const int plane = (int)(r % 3);
-    r /= 3;
+    const int plane = (int)(r % NPW);
+    r /= NPW;
     const int tap = (int)(r % 9), chunk = (int)(r / 9);               // [chunk][tap group][tap in group] == [chunk][tap]
     const int ci = chunk * 16 + kg * 8 + j;
     const float v = (co < cout && ci < cin) ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
@@ -190,7 +192,7 @@ __global__ void k_bx_unpack_out(const float* __restrict__ o, float* __restrict__
 template <int MT, bool RELU, int MODE>
 __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict__ in, float* __restrict__ out, const char* __restrict__ wpk, int Gin,
                                                         int Gout, int H, int W, int tiles_x) {
-  constexpr int M32 = MT * 32, TAPB = bx_tap_bytes(MT), SLOTB = bx_slot_bytes(MT);
+  constexpr int M32 = MT * 32, NPW = bx_planes(MODE), TAPB = bx_tap_bytes(MT, NPW), SLOTB = bx_slot_bytes(MT, NPW);
   constexpr int NPL = MODE == 1 ? 1 : (MODE == 3 ? 2 : 3);            // operand planes in use (the packed layouts always have room for three)
   HIP_DYNAMIC_SHARED(char, smem_bx)
   char* land = smem_bx;
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
 template <int MT, int MODE>
 static void launch_bx(bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s) {
   const int tx = (W + BX_TW - 1) / BX_TW, ty = (H + BX_TH - 1) / BX_TH;
-  const size_t sh = (size_t)BX_LAND_BYTES + BX_TILE_BYTES + 2 * bx_slot_bytes(MT);
+  const size_t sh = (size_t)BX_LAND_BYTES + BX_TILE_BYTES + 2 * bx_slot_bytes(MT, bx_planes(MODE));
   static bool attr[2] = {false, false};
   if (!attr[relu]) {
     if (relu) hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, true, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -430,7 +432,7 @@ extern "C" int dpx_ffdnet_bf16_pack(void* packed, const float* const* w, const f
   for (int l = 0; l < nb; ++l) {
     const int cin = bx_cin(l, in_nc, nc), cout = bx_cout(l, in_nc, nc, nb);
     DPX_REQUIRE(w[l] && b[l], "dpx_ffdnet_bf16_pack: layer %d has null weights", l);
-    const size_t n = bx_layer_bytes(cin, cout);
+    const size_t n = bx_layer_bytes(cin, cout, bx_planes(mode));
     DPX_LAUNCH("k_bx_pack_weights", k_bx_pack_weights, dim3(grid_for((long)(n / 2), 256, 2048)), dim3(256), 0, (hipStream_t)stream, w[l], b[l],
                (unsigned short*)dst, cin, cout, mode);
     dst += n;
@@ -469,7 +471,7 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
     if (mode == 1) launch_bx_mt<1>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     else if (mode == 3) launch_bx_mt<3>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     else launch_bx_mt<6>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
-    wl += bx_layer_bytes(cin, cout);
+    wl += bx_layer_bytes(cin, cout, bx_planes(mode));
     cur = dst;
     gin = gout;
   }
