@@ -97,6 +97,102 @@ __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ 
   }
 }
 
+#ifndef DPX_PGD_LD_NT
+#define DPX_PGD_LD_NT 0
+#endif
+#ifndef DPX_PGD_ST
+#define DPX_PGD_ST 0
+#endif
+#ifndef DPX_PGD_XST
+#define DPX_PGD_XST 0
+#endif
+__device__ __forceinline__ float pgd_prox(int kind, float d, float lam) {     // (dpx_elementwise.hip::prox_eval, closed forms only)
+  if (kind == DPX_PROX_NORM1) {
+    const float m = fmaxf(fabsf(d) - lam, 0.f);
+    return d > 0.f ? m : (d < 0.f ? -m : 0.f * m);
+  }
+  if (kind == DPX_PROX_NONNEG) return fmaxf(d, 0.f);
+  return d / (1.f + 2.f * lam);
+}
+
+// One row pass of a proximal-gradient iteration (reference dprox/algo/pgd.py:26-54 with a circular-convolution data term):
+//   inverse row transform of the column-processed spectrum  (= K^T K x, the Gram operator is ONE multiply by |OTF|^2)
+//   -> y = x - rho_b (K^T K x - K^T b) -> x' = prox(y, alpha lam_b) -> forward row transform of x'  (the next iteration's input).
+// k_rows_c2r_p2 and k_rows_r2c_p2 back to back on one wave's row, with the forward step and the prox on registers in between:
+// with the column kernel that is 2 launches and 28 B / element per iteration instead of 5 launches and 56.
+template <int M, int T>
+__global__ void __launch_bounds__(256) k_pgd_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, float* __restrict__ x,
+                                                   const float* __restrict__ ktb, const float* __restrict__ rho, const float* __restrict__ lam,
+                                                   float alpha, int prox, int nrows, int H, int C, const float2* __restrict__ twW) {
+  constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
+  __shared__ float2 lds[SPB * S];
+  const int tid = threadIdx.x, seq = tid / T, t = tid % T;
+  const int row = blockIdx.x * SPB + seq;
+  const bool live = row < nrows;
+  const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H, bi = pl / C;
+  const size_t toff = (size_t)pl * H * M + (size_t)hh * SPEC_TILE + (t % SPEC_TILE) + (size_t)(t / SPEC_TILE) * H * SPEC_TILE;
+  const size_t tstep = (size_t)(T / SPEC_TILE) * H * SPEC_TILE;
+  const float2* side_in = spec_in + (size_t)nrows * M;
+  const int lane = tid & 63;
+  const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
+  float2 X[V], v[V], xo[V], kb[V];
+#pragma unroll
+  for (int m = 0; m < V; ++m) X[m] = ld_stream<DPX_PGD_LD_NT>(spec_in + toff + tstep * m);
+  const float xn0 = side_in[rr].x;
+  // the iterate and K^T b are requested with the spectrum: ONE memory round trip in front of the transform
+  float2* xr = (float2*)(x + (size_t)rr * (2 * M));
+  const float2* kr = ktb ? (const float2*)(ktb + (size_t)rr * (2 * M)) : nullptr;
+#pragma unroll
+  for (int m = 0; m < V; ++m) xo[m] = xr[t + m * T];
+#pragma unroll
+  for (int m = 0; m < V; ++m) kb[m] = kr ? ld_stream<1>(kr + t + m * T) : make_float2(0.f, 0.f);
+#pragma unroll
+  for (int m = 0; m < V; ++m) {
+    const float2 got = make_float2(__shfl(X[V - 1 - m].x, plane), __shfl(X[V - 1 - m].y, plane));
+    const float2 xm = cconj(t == 0 ? X[(V - m) % V] : got);
+    const int k = t + m * T;
+    const float2 xk = X[m];
+    if (k == 0) {
+      const float xn = xn0;
+      v[m] = make_float2(xk.x + xn, xk.x - xn);
+    } else {
+      const float2 e = cadd(xk, xm);
+      const float2 d = cmulc(csub(xk, xm), twW[k]);
+      v[m] = make_float2(e.x - d.y, e.y + d.x);
+    }
+  }
+  fft_reg<M, T, +1>(v, lds + seq * S, t, twW, 2, WaveSync());     // v[m] = ((K^T K x)[2n], [2n+1]), n = t + m T
+  const float r = rho[bi], th = lam ? lam[bi] * alpha : 0.f;
+#pragma unroll
+  for (int m = 0; m < V; ++m) {
+    float2 y = make_float2(xo[m].x - r * (v[m].x - kb[m].x), xo[m].y - r * (v[m].y - kb[m].y));
+    y = make_float2(pgd_prox(prox, y.x, th), pgd_prox(prox, y.y, th));
+    if (live) st_stream<DPX_PGD_XST>(xr + t + m * T, y);
+    v[m] = y;
+  }
+  if (!spec_out) return;                                              // (block-uniform: the last iteration needs no spectrum)
+  WaveSync()();
+  fft_reg<M, T, -1>(v, lds + seq * S, t, twW, 2, WaveSync());
+  float2* side_out = spec_out + (size_t)nrows * M;
+#pragma unroll
+  for (int m = 0; m < V; ++m) {
+    const float2 got = make_float2(__shfl(v[V - 1 - m].x, plane), __shfl(v[V - 1 - m].y, plane));
+    const float2 zm = cconj(t == 0 ? v[(V - m) % V] : got);
+    const int k = t + m * T;
+    const float2 zk = v[m];
+    float2 Xo;
+    if (k == 0) {
+      Xo = make_float2(zk.x + zk.y, 0.f);
+      if (live) side_out[row] = make_float2(zk.x - zk.y, 0.f);
+    } else {
+      const float2 e = cscale(cadd(zk, zm), 0.5f);
+      const float2 d = cscale(csub(zk, zm), 0.5f);
+      Xo = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
+    }
+    if (live) st_stream<DPX_PGD_ST>(spec_out + toff + tstep * m, Xo);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-frequency operator (same semantics as dpx_fft.hip::spec_op)
 // ---------------------------------------------------------------------------------------------
@@ -194,7 +290,10 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   // (lane-linear image: float2 index m*64 + lane of the wave's 8 KB), so its own vmcnt wait is all the
   // synchronisation the data needs.  The data-spectrum values (HBM) are requested in one batch right behind them:
   // ONE memory round trip between the two transforms.
-  constexpr bool DMA_TABLE = (OP == OP_SOLVE) && (COLS == 8 || COLS == 4) && (V % 2 == 0) && !(DBG & 2);
+#ifndef DPX_COLS_MUL_DMA
+#define DPX_COLS_MUL_DMA 1         // the multiply operators stage their OTF values the same way (direct loads at the operator: 81.5 us at 8x3x1024^2)
+#endif
+  constexpr bool DMA_TABLE = (OP == OP_SOLVE || DPX_COLS_MUL_DMA) && (COLS == 8 || COLS == 4) && (V % 2 == 0) && !(DBG & 2);
 #ifndef DPX_COLS_EARLY_ADD
 #define DPX_COLS_EARLY_ADD 1       // with the spectra served from the Infinity Cache the data spectrum is the HBM stream: start it one pass earlier (78.8 -> 76.0 us)
 #endif
@@ -214,7 +313,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
       int ln = lane;
       DPX_OPAQUE(ln);                                   // derive the source address here, not at kernel entry
       const int half = ln >> 5, li = ln & 31;
-      const float2* src = A.dd + tbase + (unsigned)((T * half + RPW * wave + li / LPR) * SPEC_TILE + (li % LPR) * 2) + sub_off;
+      const float2* src = (OP == OP_SOLVE ? A.dd : A.otf) + tbase + (unsigned)((T * half + RPW * wave + li / LPR) * SPEC_TILE + (li % LPR) * 2) + sub_off;
 #pragma unroll
       for (int j = 0; j < V / 2; ++j) dpx_glds16<DPX_COLS_TBL_NT>(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
     }
@@ -259,13 +358,12 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   const float2* tside = (OP == OP_SOLVE ? A.dd : A.otf) + (unsigned)C * H * Ws + (unsigned)(p % C) * H + t;    // Nyquist column's table values
   if constexpr (PACK && OP != OP_SOLVE) {
     // multiply: no division by the DC factor is possible, so the correction (oB - oA) iB is formed in front of the operator and added behind it
-    float2 dd[V];
-    if (dc_lane) {
-#pragma unroll
-      for (int m = 0; m < V; ++m) dd[m] = cscale(csub(tside[m * T], A.otf[tbase + toff0 + step * m]), A.scale);
-    }
+    // (its table values are loaded where they are used: three workgroups of the launch, and the registers matter more than their latency)
     pack_split([&](int m) { return v[m]; },
-               [&](int m, float2 ib) { av[m] = OP == OP_MULCONJ ? cmulc(ib, dd[m]) : cmul(ib, dd[m]); });
+               [&](int m, float2 ib) {
+                 const float2 dd = cscale(csub(tside[m * T], A.otf[tbase + toff0 + step * m]), A.scale);
+                 av[m] = OP == OP_MULCONJ ? cmulc(ib, dd) : cmul(ib, dd);
+               });
   }
   if constexpr (OP == OP_SOLVE) {
     unsigned offa = off0;
@@ -297,7 +395,13 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   } else {
 #pragma unroll
     for (int m = 0; m < V; ++m) {
-      v[m] = spec_op_p2<OP>(v[m], A, tbase + toff0 + step * m, rho_b);
+      if (DMA_TABLE && !is_side) {
+        if (m == 0) dpx_wait_vm<0>();
+        const float2 o = tstage[m * 64 + lane];
+        v[m] = cscale(OP == OP_MULCONJ ? cmulc(v[m], o) : cmul(v[m], o), A.scale);
+      } else {
+        v[m] = spec_op_p2<OP>(v[m], A, tbase + toff0 + step * m, rho_b);
+      }
       if (DPX_COLS_PACK0) v[m] = cadd(v[m], av[m]);     // (zero except in the packed column)
       if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -531,4 +635,52 @@ int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& A, int
   return launch_status("spectral_apply_pow2");
 }
 
+
+template <int M, int T>
+static void launch_pgd_rows(const float2* sin, float2* sout, float* x, const float* ktb, const float* rho, const float* lam, float alpha, int prox,
+                            int nrows, int H, int C, const float2* twW, hipStream_t s) {
+  constexpr int SPB = 256 / T;
+  DPX_LAUNCH("k_pgd_rows", (k_pgd_rows<M, T>), dim3((nrows + SPB - 1) / SPB), dim3(256), 0, s, sin, sout, x, ktb, rho, lam, alpha, prox, nrows, H,
+             C, twW);
+}
+
+int pgd_run_pow2(float* x, const float* ktb, const void* gram_otf, int prox, float alpha, const float* rho_tab, const float* lam_tab, int T,
+                 int B, int C, int H, int W, const void* table, void* ws, hipStream_t stream) {
+  const int P = B * C, Ws = W / 2;
+  float2* spec = (float2*)ws;
+  float2* spec2 = spec + pow2_spec_elems(P, H, W);
+  SpecArgs A{};
+  A.otf = (const float2*)gram_otf;
+  A.scale = 1.0f / ((float)H * (float)W);
+  rows_dispatch(true, W, H, x, spec, nullptr, P * H, tw_rows(table), 1.0f, stream);
+  for (int it = 0; it < T; ++it) {
+    cols_dispatch<OP_MUL>(H, spec, spec2, A, P, C, Ws, tw_cols(table, W), stream);
+    float2* sout = it + 1 < T ? spec : nullptr;
+    const float* rho = rho_tab + (size_t)it * B;
+    const float* lam = lam_tab ? lam_tab + (size_t)it * B : nullptr;
+    switch (W) {
+      case 256: launch_pgd_rows<128, 16>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
+      case 512: launch_pgd_rows<256, 32>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
+      case 1024: launch_pgd_rows<512, 64>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
+      default: launch_pgd_rows<1024, 64>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
+    }
+  }
+  return launch_status("dpx_pgd_run");
+}
+
 }  // namespace dpx
+
+using namespace dpx;
+
+// T proximal-gradient iterations  x <- prox(x - rho_t (K^T K x - K^T b), alpha lam_t)  in place, 2 launches per iteration
+// (reference dprox/algo/pgd.py:26-54; K a circular convolution: gram_otf = the |OTF|^2 table, ktb = K^T b or NULL).
+extern "C" int dpx_pgd_supported(int H, int W, int prox) {
+  return pow2_path_available(H, W) && (prox == DPX_PROX_NORM1 || prox == DPX_PROX_NONNEG || prox == DPX_PROX_SUMSQ);
+}
+extern "C" int dpx_pgd_run(float* x, const float* ktb, const void* gram_otf, int prox, float alpha, const float* rho_tab, const float* lam_tab,
+                           int T, int B, int C, int H, int W, const void* table, void* spectrum_ws, dpx_stream_t stream) {
+  DPX_REQUIRE(x && gram_otf && rho_tab && table && spectrum_ws && T >= 0 && B > 0 && C > 0, "dpx_pgd_run: bad arguments");
+  DPX_REQUIRE(dpx_pgd_supported(H, W, prox), "dpx_pgd_run: unsupported plane %dx%d / prox %d", H, W, prox);
+  if (T == 0) return DPX_OK;
+  return pgd_run_pow2(x, ktb, gram_otf, prox, alpha, rho_tab, lam_tab, T, B, C, H, W, table, spectrum_ws, (hipStream_t)stream);
+}

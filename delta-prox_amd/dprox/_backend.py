@@ -51,6 +51,9 @@ SIGNATURES = {
     "dpx_diag_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_psf2otf": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "dpx_fft_conv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dpx_pgd_supported": (c_int, [c_int, c_int, c_int]),
+    "dpx_pgd_run": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                            c_void_p, c_void_p]),
     "dpx_data_spectrum_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_data_spectrum": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_table_to_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

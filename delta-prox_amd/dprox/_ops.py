@@ -168,6 +168,19 @@ def fft_conv(x, otf, conj=False, out=None):
     return y
 
 
+def pgd_supported(H, W, kind):
+    return bool(be.lib().query("dpx_pgd_supported", int(H), int(W), int(kind)))
+
+
+def pgd_run(x, ktb, gram_otf, kind, alpha, rho_tab, lam_tab, T):
+    """T fused proximal-gradient iterations on x, in place (two kernels per iteration; rho_tab / lam_tab: [T, B] device tables)"""
+    require(x, what="pgd iterate")
+    B, C, H, W = _shape4(x)
+    be.lib().call("dpx_pgd_run", ptr(x), ptr(ktb), ptr(gram_otf), int(kind), c_float(alpha), ptr(rho_tab), ptr(lam_tab), int(T),
+                  B, C, H, W, ptr(fft_table(H, W, x.device)), ptr(spectrum_ws(B * C, H, W, x.device)), be.stream())
+    return x
+
+
 def data_spectrum(b, otf=None, conj=True, out=None, accumulate=False):
     """packed fp32 half spectrum of op(OTF) * F(b), transform evaluated in fp64 (once per solve)"""
     require(b, what="data_spectrum input")

@@ -45,6 +45,47 @@ class ProximalGradientDescent(Algorithm):
     def initialize(self, x0):
         return [x0]
 
+    def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
+        plan = None
+        if callback is None and not pbar and max_iter >= 1:
+            self.Kall.update_vars([state[0]])           # (the terms' constant offsets are evaluated around the variable's value)
+            plan = self._fused_plan(state[0], rhos, lams)
+        if plan is None:
+            return super().iters(state, rhos, lams, max_iter, pbar, callback=callback)
+        # the whole solve as ONE call: the iterate's spectrum stays resident, two kernels per iteration (dpx_pgd_run)
+        from .fused import schedule_table
+        kind, gram, ktb = plan
+        x = state[0].clone()
+        B = int(x.shape[0])
+        rho_tab = schedule_table(rhos, max_iter, B, x.device)
+        lam_tab = schedule_table(lams[self.prox_fn], max_iter, B, x.device)
+        self._notify_all_op_current_step(max_iter - 1)
+        ops.pgd_run(x, ktb, gram, kind, float(self.prox_fn.alpha), rho_tab, lam_tab, max_iter)
+        self.Kall.update_vars([x])
+        return [x]
+
+    def _fused_plan(self, x, rhos, lams):
+        """(prox code, |OTF|^2 table, K^T b) when the iteration is a circular-convolution least-squares term plus a closed-form
+        prox of the variable itself on a power-of-two plane, and nothing wants gradients; None = op by op"""
+        import torch
+        from ..proxfn.quadratic import sum_squares
+        from .fused import _psi_linop_code, _psi_prox_code
+        from .. import _backend as be
+        f, g = self.diff_fn, self.prox_fn
+        if type(f) is not sum_squares or f.alpha != 1 or f.beta != 1 or g not in lams:
+            return None
+        kind = _psi_prox_code(g)
+        if kind not in (be.PROX_NORM1, be.PROX_NONNEG, be.PROX_SUMSQ) or _psi_linop_code(g.linop) != be.LIN_IDENTITY or g.offset is not None:
+            return None
+        if x.ndim != 4 or x.dtype != torch.float32 or len(self.Kall.variables) != 1:
+            return None
+        if torch.is_grad_enabled() and any(t.requires_grad for t in [x, rhos] + list(lams.values())):
+            return None
+        if not ops.pgd_supported(x.shape[2], x.shape[3], kind):
+            return None
+        tables = f.gram_tables(x)
+        return None if tables is None else (kind, tables[0], tables[1])
+
     def _iter(self, state, rho, lam):
         (x,) = state
         parts = getattr(self.diff_fn, "grad_parts", lambda t: None)(x)

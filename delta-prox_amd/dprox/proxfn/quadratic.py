@@ -59,9 +59,9 @@ class sum_squares(ProxFn):
             r = ops.lincomb([(1.0, r), (-1.0, off.expand_as(r).contiguous())])
         return adjoint(self.linop, r)
 
-    def grad_parts(self, x):
-        """(K^T K x, K^T b) when K is a circular convolution of the variable: the Gram operator is ONE Fourier multiply by
-        |OTF|^2 (3 kernels instead of the 6 of forward + adjoint) and K^T b is constant while b is; None otherwise."""
+    def gram_tables(self, x):
+        """(|OTF|^2 table, K^T b) when K is a circular convolution of the variable (cached while the kernel and b are unchanged);
+        None otherwise"""
         cv = self.linop
         if isinstance(cv, lin_sum):
             lin = [k for k in cv.input_nodes if k.variables]
@@ -70,7 +70,7 @@ class sum_squares(ProxFn):
             return None
         if torch.is_grad_enabled() and x.requires_grad:
             return None
-        key = (tuple(x.shape[1:]), str(x.device), cv.tables_version(), self._offset_key())
+        key = (tuple(x.shape), str(x.device), cv.tables_version(), self._offset_key())
         cache = getattr(self, "_gram_cache", None)
         if cache is None or cache[0] != key:
             _, C, H, W = x.shape
@@ -80,7 +80,15 @@ class sum_squares(ProxFn):
             ktb = None if off is None else cv.adjoint(off.expand_as(x).contiguous())
             cache = (key, gram, ktb)
             self._gram_cache = cache
-        return ops.fft_conv(x.contiguous(), cache[1], conj=False), cache[2]
+        return cache[1], cache[2]
+
+    def grad_parts(self, x):
+        """(K^T K x, K^T b) when K is a circular convolution of the variable: the Gram operator is ONE Fourier multiply by
+        |OTF|^2 (3 kernels instead of the 6 of forward + adjoint) and K^T b is constant while b is; None otherwise."""
+        tables = self.gram_tables(x)
+        if tables is None:
+            return None
+        return ops.fft_conv(x.contiguous(), tables[0], conj=False), tables[1]
 
 
 class ext_sum_squares(sum_squares):

@@ -74,6 +74,17 @@ int dpx_psf2otf(const double* psf, int kh, int kw, int kc, int C, int H, int W,
 int dpx_fft_conv(const float* x, float* y, const void* otf, int conj_otf, int B, int C, int H, int W,
                  const void* table, void* spectrum_ws, dpx_stream_t stream);
 
+/* T proximal-gradient iterations in place (algo/pgd.py:26-54 with f = ||k (*) x - b||^2, g a closed-form prox):
+ *     x <- prox_g( x - rho_t[b] (K^T K x - K^T b),  alpha * lam_t[b] )
+ * gram_otf = the |OTF|^2 table (dpx_otf_bytes), ktb = K^T b (nullable = 0), rho_tab / lam_tab = [T][B] device arrays
+ * (lam_tab nullable = 0), prox in {DPX_PROX_NORM1, DPX_PROX_NONNEG, DPX_PROX_SUMSQ}.  The spectrum stays resident between
+ * iterations: one column kernel + one row kernel per iteration (the row kernel finishes the inverse transform, steps,
+ * applies the prox, and starts the next forward transform on registers).  Power-of-two planes only: ask dpx_pgd_supported. */
+int dpx_pgd_supported(int H, int W, int prox);
+int dpx_pgd_run(float* x, const float* ktb, const void* gram_otf, int prox, float alpha, const float* rho_tab,
+                const float* lam_tab, int T, int B, int C, int H, int W, const void* table, void* spectrum_ws,
+                dpx_stream_t stream);
+
 /* spec (+)= op(OTF) * fft2(b), evaluated once per solve in fp64 and stored as a packed fp32 half spectrum
  * (dpx_spectrum_bytes).  This is the Fourier transform of the constant part of the x-update's
  * right-hand side, sum over Omega of K^T b (proxfn/sum_square.py:126-132, where the reference

@@ -1028,10 +1028,25 @@ def g33_full_c5():
     save("g33_full_c5", **out)
 
 
+def g34_pgd_pow2():
+    """Proximal gradient descent (algo/pgd.py:26-54) on power-of-two planes, where the backend runs the whole solve as one fused
+    call: 2 x 3 x 256 x 512, 8 iterations, decaying per-image step sizes, the three closed-form proximal terms."""
+    gt, b, psf = synthetic.deconv_case(2, 3, 256, 512, seed=3401)
+    rhos = torch.stack([torch.linspace(0.9, 0.5, 8), torch.linspace(0.6, 0.3, 8)])
+    lams = torch.linspace(0.02, 0.005, 8)
+    out = {"seed": 3401, "rhos": rhos, "lams": lams}
+    for tag, mk in (("norm1", lambda x: 0.7 * dp.norm1(x)), ("nonneg", dp.nonneg), ("norm2", dp.norm2)):
+        x = dp.Variable()
+        g = mk(x)
+        xo = dp.Problem(dp.sum_squares(dp.conv(x, psf) - T(b)) + g).solve(method="pgd", device="cpu", x0=T(b), rhos=rhos, lams={g: lams}, max_iter=8)
+        _pack(out, "x_" + tag, xo, 4)
+    save("g34_pgd_pow2", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
                g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
-               g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5):
+               g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5, g34_pgd_pow2):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

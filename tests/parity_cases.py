@@ -155,6 +155,42 @@ def case_pgd(device):
     assert_close(out.cpu(), g["x_nonneg_rhoB"], TOL)
 
 
+def case_pgd_pow2(device, tiny=False):
+    """G34: proximal gradient descent on power-of-two planes = ONE fused call (dpx_pgd_run: column kernel + a row kernel that
+    finishes the inverse transform, steps, applies the prox and starts the next forward transform).  Against the reference's
+    iterates, and against the op-by-op path of the same backend (forced by passing a callback).  tiny (the SIMT emulator):
+    1 x 2 x 256 x 256, 3 iterations, fused against op by op only."""
+    import synthetic
+    from dprox import _ops as ops
+    g = load_golden("g34_pgd_pow2")
+    shape, K = ((1, 2, 256, 256), 3) if tiny else ((2, 3, 256, 512), 8)
+    gt, b0, psf = synthetic.deconv_case(*shape, seed=int(g["seed"]))
+    b = T(b0, device)
+    rhos, lams = torch.from_numpy(g["rhos"])[:shape[0], :K], torch.from_numpy(g["lams"])[:K]
+    calls = []
+    real = ops.pgd_run
+    ops.pgd_run = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        for tag, mk in (("norm1", lambda x: 0.7 * dp.norm1(x)), ("nonneg", dp.nonneg), ("norm2", dp.norm2)):
+            x = dp.Variable()
+            term = mk(x)
+            prob = dp.Problem(dp.sum_squares(dp.conv(x, psf) - b) + term)
+            out = prob.solve(method="pgd", device=device, x0=b, rhos=rhos, lams={term: lams}, max_iter=K)
+            assert len(calls) == 1, "the fused proximal-gradient path did not run"
+            calls.clear()
+            assert torch.equal(x.value, out)
+            if not tiny:
+                _check_packed(g, "x_" + tag, out, 4, TOL, what="pgd pow2 ")
+            steps = []
+            ref = prob.solve(method="pgd", device=device, x0=b, rhos=rhos, lams={term: lams}, max_iter=K,
+                             callback=lambda **kw: steps.append(kw["iter"]))
+            assert steps == list(range(K)) and not calls
+            assert_close(out.cpu(), ref.cpu(), TOL, f"pgd pow2 {tag}: fused vs op by op")
+            assert np.array_equal(b.cpu().numpy(), b0), "x0 / b modified in place"
+    finally:
+        ops.pgd_run = real
+
+
 def case_known_answers(device):
     """the reference's own exact tests, tests/problem/test_ml_problems.py:5-44"""
     g = load_golden("g13_known_answers")
