@@ -191,6 +191,23 @@ def case_pgd_pow2(device, tiny=False):
         ops.pgd_run = real
 
 
+def case_pgd_pow2_shapes(device):
+    """the fused proximal-gradient call on every row / column length of the power-of-two path against the op-by-op path (itself
+    pinned by G10 / G34), K^T b absent (sum_squares(conv(x))) and present"""
+    import synthetic
+    for (B, C, H, W), with_b in (((1, 1, 256, 2048), True), ((1, 2, 512, 256), False), ((2, 1, 1024, 512), True), ((1, 1, 512, 1024), True)):
+        gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=H + W)
+        b = T(b0, device)
+        x = dp.Variable()
+        term = dp.norm1(x)
+        data = dp.sum_squares(dp.conv(x, psf) - b) if with_b else dp.sum_squares(dp.conv(x, psf))
+        prob = dp.Problem(data + term)
+        kw = dict(method="pgd", device=device, x0=b, rhos=torch.linspace(0.9, 0.6, 4), lams={term: 0.01}, max_iter=4)
+        out = prob.solve(**kw)
+        ref = prob.solve(callback=lambda **k: None, **kw)
+        assert_close(out.cpu(), ref.cpu(), TOL, f"pgd fused vs op by op {B}x{C}x{H}x{W}")
+
+
 def case_known_answers(device):
     """the reference's own exact tests, tests/problem/test_ml_problems.py:5-44"""
     g = load_golden("g13_known_answers")

@@ -55,6 +55,10 @@ def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV)
 
 
+def test_pgd_pow2_shapes():
+    pc.case_pgd_pow2_shapes(DEV)
+
+
 def test_known_answers():
     pc.case_known_answers(DEV)
 
