@@ -244,24 +244,32 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   constexpr int V = H / T;
   constexpr int S0 = LdsSeq<H>::SLOTS;
   constexpr int S = S0 + ((36 - S0 % 32) % 32);     // S % 32 == 4: adjacent columns start 8 banks apart
+  // H = 3 * 2^k (fft_reg_x3): register m = r * V/3 + a holds image row 3 (t + a T) + r before / after the kernel and frequency row
+  // (t + a T) + r H/3 in between; power-of-two H: row t + m T on both sides.  hrow / krow: the part of those maps that does not depend on t.
+  constexpr bool R3 = (H % 3 == 0);
+  constexpr int VS = R3 ? V / 3 : V, TMUL = R3 ? 3 : 1;
+  auto hrow = [](int m) { return R3 ? 3 * (m % VS) * T + m / VS : m * T; };
+  auto krow = [](int m) { return R3 ? (m % VS) * T + (m / VS) * (H / 3) : m * T; };
   HIP_DYNAMIC_SHARED(float2, smem_p2)
   const int tid = threadIdx.x, c = tid % COLS, t = tid / COLS;
   // uniform (scalar) bases + 32-bit per-thread element offsets: one address VGPR per access
   size_t ubase;                                       // element offset of the tile's plane / of the side array
-  unsigned off0, step, toff0, tbase;                  // data offset of row t, row step, table offset of row t, table base
+  unsigned off0, off0k, step, toff0, tbase;           // data offset of image row t TMUL / of frequency row t, offset of one row, table offset of row t, table base
   constexpr bool pack0 = PACK;
   if (!is_side) {
     ubase = (size_t)p * H * Ws + (size_t)j * H * SPEC_TILE;   // tile-major main part: element (row r, col c) of a tile at r*TILE + c
-    off0 = (unsigned)((c / SPEC_TILE) * H * SPEC_TILE + t * SPEC_TILE + (c % SPEC_TILE)) + sub_off;
-    step = (unsigned)(T * SPEC_TILE);
-    toff0 = off0;
+    off0k = (unsigned)((c / SPEC_TILE) * H * SPEC_TILE + t * SPEC_TILE + (c % SPEC_TILE)) + sub_off;
+    off0 = off0k + (unsigned)((TMUL - 1) * t * SPEC_TILE);
+    step = (unsigned)SPEC_TILE;
+    toff0 = off0k;
     tbase = (unsigned)((p % C) * H * Ws + j * H * SPEC_TILE);
   } else {
     p = (bid - nmain) * COLS + c;
     if (p >= P) p = P - 1;                            // (P not a multiple of COLS: duplicate work, identical values)
     ubase = (size_t)P * H * Ws;
-    off0 = (unsigned)(p * H + t);
-    step = (unsigned)T;
+    off0k = (unsigned)(p * H + t);
+    off0 = off0k + (unsigned)((TMUL - 1) * t);
+    step = 1u;
     toff0 = (unsigned)((p % C) * H + t);
     tbase = (unsigned)C * H * Ws;
   }
@@ -272,12 +280,12 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   float2* twl = smem_p2 + COLS * S;                   // the H column twiddles, shared by the workgroup
   float2 v[V];
 #pragma unroll
-  for (int m = 0; m < V; ++m) v[m] = ld_stream<COLS_LD_NT>((const float2*)(pin + (off0 + step * m) * 8u));
+  for (int m = 0; m < V; ++m) v[m] = ld_stream<COLS_LD_NT>((const float2*)(pin + (off0 + step * hrow(m)) * 8u));
   const bool dc_lane = PACK && c == 0;               // the lanes carrying the packed (DC, Nyquist) column
   if (dc_lane) {                                      // (row spectra: both columns are real on entry)
-    const float* sidef = (const float*)(spec_in + (size_t)P * H * Ws + (size_t)p * H + t);
+    const float* sidef = (const float*)(spec_in + (size_t)P * H * Ws + (size_t)p * H + TMUL * t);
 #pragma unroll
-    for (int m = 0; m < V; ++m) v[m].y = sidef[2 * m * T];
+    for (int m = 0; m < V; ++m) v[m].y = sidef[2 * hrow(m)];
   }
   for (int i = tid; i < H; i += T * COLS) twl[i] = twH[i];
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
@@ -313,21 +321,28 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
       int ln = lane;
       DPX_OPAQUE(ln);                                   // derive the source address here, not at kernel entry
       const int half = ln >> 5, li = ln & 31;
-      const float2* src = (OP == OP_SOLVE ? A.dd : A.otf) + tbase + (unsigned)((T * half + RPW * wave + li / LPR) * SPEC_TILE + (li % LPR) * 2) + sub_off;
+      const float2* src = (OP == OP_SOLVE ? A.dd : A.otf) + tbase + (unsigned)((RPW * wave + li / LPR) * SPEC_TILE + (li % LPR) * 2) + sub_off;
+      if constexpr (R3) {                                 // (pieces 2j, 2j+1 are not a constant distance apart)
 #pragma unroll
-      for (int j = 0; j < V / 2; ++j) dpx_glds16<DPX_COLS_TBL_NT>(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
+        for (int j = 0; j < V / 2; ++j) dpx_glds16<DPX_COLS_TBL_NT>(src + (half ? krow(2 * j + 1) : krow(2 * j)) * SPEC_TILE, tstage + j * 128);
+      } else {
+        src += T * half * SPEC_TILE;
+#pragma unroll
+        for (int j = 0; j < V / 2; ++j) dpx_glds16<DPX_COLS_TBL_NT>(src + j * 2 * T * SPEC_TILE, tstage + j * 128);
+      }
     }
     if constexpr (OP == OP_SOLVE && EARLY_ADD) {
-      unsigned offa = off0;
+      unsigned offa = off0k;
       DPX_OPAQUE(offa);
       if (add) {
 #pragma unroll
-        for (int m = 0; m < V; ++m) av[m] = ld_stream<COLS_ADD_NT>((const float2*)(add + (offa + step * m) * 8u));
+        for (int m = 0; m < V; ++m) av[m] = ld_stream<COLS_ADD_NT>((const float2*)(add + (offa + step * krow(m)) * 8u));
       }
     }
   };
   if (!(DBG & 1)) {
-    fft_reg<H, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
+    if constexpr (R3) fft_reg_x3<H / 3, T, -1>(v, lds, t, twl, BlockSync(), fetch_table);
+    else fft_reg<H, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
   }
   __builtin_amdgcn_sched_barrier(0);
 #ifdef DPX_COLS_PRIO
@@ -344,14 +359,14 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
     DPX_LDS_BARRIER();                                // (no table stage on this path: every wave's last-pass reads are done)
     if (dc_lane) {
 #pragma unroll
-      for (int m = 0; m < V; ++m) xslot(t + m * T)[0] = zval(m);
+      for (int m = 0; m < V; ++m) xslot(t + krow(m))[0] = zval(m);
     }
     DPX_LDS_BARRIER();
     if (dc_lane) {
 #pragma unroll
       for (int m = 0; m < V; ++m) {
-        const int k = t + m * T;
-        consume(m, cscale(csub(zval(m), cconj(xslot((H - k) & (H - 1))[0])), 0.5f));
+        const int k = t + krow(m);
+        consume(m, cscale(csub(zval(m), cconj(xslot(k ? H - k : 0)[0])), 0.5f));
       }
     }
   };
@@ -361,16 +376,16 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
     // (its table values are loaded where they are used: three workgroups of the launch, and the registers matter more than their latency)
     pack_split([&](int m) { return v[m]; },
                [&](int m, float2 ib) {
-                 const float2 dd = cscale(csub(tside[m * T], A.otf[tbase + toff0 + step * m]), A.scale);
+                 const float2 dd = cscale(csub(tside[krow(m)], A.otf[tbase + toff0 + step * krow(m)]), A.scale);
                  av[m] = OP == OP_MULCONJ ? cmulc(ib, dd) : cmul(ib, dd);
                });
   }
   if constexpr (OP == OP_SOLVE) {
-    unsigned offa = off0;
+    unsigned offa = off0k;
     DPX_OPAQUE(offa);
     if (!EARLY_ADD && add) {
 #pragma unroll
-      for (int m = 0; m < V; ++m) av[m] = ld_stream<COLS_ADD_NT>((const float2*)(add + (offa + step * m) * 8u));
+      for (int m = 0; m < V; ++m) av[m] = ld_stream<COLS_ADD_NT>((const float2*)(add + (offa + step * krow(m)) * 8u));
     }
     if (DMA_TABLE && !is_side) {
       if (add) dpx_wait_vm<V>();                        // the V data-spectrum loads above may stay in flight
@@ -388,7 +403,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
       for (int m = 0; m < V; ++m) {
         const float2 z = cadd(v[m], av[m]);
         if (DBG & 2) v[m] = cscale(z, A.scale);
-        else v[m] = spec_op_p2<OP>(z, A, tbase + toff0 + step * m, rho_b);
+        else v[m] = spec_op_p2<OP>(z, A, tbase + toff0 + step * krow(m), rho_b);
         if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -400,7 +415,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
         const float2 o = tstage[m * 64 + lane];
         v[m] = cscale(OP == OP_MULCONJ ? cmulc(v[m], o) : cmul(v[m], o), A.scale);
       } else {
-        v[m] = spec_op_p2<OP>(v[m], A, tbase + toff0 + step * m, rho_b);
+        v[m] = spec_op_p2<OP>(v[m], A, tbase + toff0 + step * krow(m), rho_b);
       }
       if (DPX_COLS_PACK0) v[m] = cadd(v[m], av[m]);     // (zero except in the packed column)
       if (V > 8 && (m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -419,23 +434,23 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
       const float2* tsd = A.dd + (unsigned)C * H * Ws + (unsigned)(p % C) * H + ts;
 #pragma unroll
       for (int m = 0; m < V; ++m) {
-        const float2 db = tsd[m * T];
+        const float2 db = tsd[krow(m)];
         dnb[m] = fmaf(rho_b, db.y, db.x) + A.eps;
       }
 #pragma unroll
       for (int m = 0; m < V; ++m) {
-        const float2 da = (DMA_TABLE && !(DBG & 2)) ? tstage[m * 64 + lane] : A.dd[tbase + toff0 + step * m];
+        const float2 da = (DMA_TABLE && !(DBG & 2)) ? tstage[m * 64 + lane] : A.dd[tbase + toff0 + step * krow(m)];
         g[m] = fmaf(rho_b, da.y, da.x) + A.eps;
-        xslot(t + m * T)[0] = make_float2(fmaf(v[m].x, g[m] * iscale, -A.eps_num), v[m].y * (g[m] * iscale));
+        xslot(t + krow(m))[0] = make_float2(fmaf(v[m].x, g[m] * iscale, -A.eps_num), v[m].y * (g[m] * iscale));
       }
     }
     DPX_LDS_BARRIER();
     if (dc_lane) {
 #pragma unroll
       for (int m = 0; m < V; ++m) {
-        const int k = t + m * T;
+        const int k = t + krow(m);
         const float2 z = make_float2(fmaf(v[m].x, g[m] * iscale, -A.eps_num), v[m].y * (g[m] * iscale));
-        const float2 ib = cscale(csub(z, cconj(xslot((H - k) & (H - 1))[0])), 0.5f);
+        const float2 ib = cscale(csub(z, cconj(xslot(k ? H - k : 0)[0])), 0.5f);
         const float fb = A.scale * DPX_RCP(dnb[m]), df = fb - A.scale * DPX_RCP(g[m]);
         v[m] = make_float2(fmaf(df, ib.x, v[m].x), fmaf(df, ib.y, fmaf(fb, A.eps_num, v[m].y)));
       }
@@ -443,24 +458,27 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   }
   __builtin_amdgcn_sched_barrier(0);
   DPX_LDS_BARRIER();
-  if (!(DBG & 1)) fft_reg<H, T, +1>(v, lds, t, twl, 1, BlockSync());
+  if (!(DBG & 1)) {
+    if constexpr (R3) fft_reg_x3<H / 3, T, +1>(v, lds, t, twl, BlockSync());
+    else fft_reg<H, T, +1>(v, lds, t, twl, 1, BlockSync());
+  }
   unsigned off1 = off0;
   DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores
 #pragma unroll
-  for (int m = 0; m < V; ++m) st_stream<COLS_ST>((float2*)(pout + (off1 + step * m) * 8u), dc_lane ? make_float2(v[m].x, 0.f) : v[m]);
+  for (int m = 0; m < V; ++m) st_stream<COLS_ST>((float2*)(pout + (off1 + step * hrow(m)) * 8u), dc_lane ? make_float2(v[m].x, 0.f) : v[m]);
   if (dc_lane) {                                      // both columns are real again: Re -> DC column, Im -> side array
     int te = threadIdx.x;
     DPX_OPAQUE(te);                                   // (address re-derived here instead of kept alive through the kernel)
-    float2* so = spec_out + (size_t)P * H * Ws + (size_t)p * H + te / COLS;
+    float2* so = spec_out + (size_t)P * H * Ws + (size_t)p * H + TMUL * (te / COLS);
 #pragma unroll
-    for (int m = 0; m < V; ++m) st_stream<COLS_ST>(so + m * T, make_float2(v[m].y, 0.f));
+    for (int m = 0; m < V; ++m) st_stream<COLS_ST>(so + hrow(m), make_float2(v[m].y, 0.f));
   }
 }
 
 
 template <int H, int T, int COLS, int OP, int DBG = 0>
 #ifndef DPX_COLS_WPE
-#define DPX_COLS_WPE ((T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for
+#define DPX_COLS_WPE ((T * COLS) >= 512 ? 4 : (H % 3 == 0 ? 2 : 3))     // waves per SIMD the register budget is sized for (H = 768: 61 KB of LDS -> 2 workgroups of 4 waves per CU)
 #endif
 __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
                                                       int C, int Ws, int P, const float2* __restrict__ twH) {
@@ -539,7 +557,7 @@ __global__ void __launch_bounds__(T* COLS, 4) k_cols_probe_wide(const float4* __
 size_t pow2_spec_elems(int P, int H, int W) { return (size_t)P * H * (W / 2) + (size_t)P * H; }
 
 bool pow2_path_available(int H, int W) {
-  const bool hok = (H == 256 || H == 512 || H == 1024);
+  const bool hok = (H == 256 || H == 512 || H == 768 || H == 1024);
   const bool wok = (W == 256 || W == 512 || W == 1024 || W == 2048);
   return hok && wok;
 }
@@ -605,6 +623,7 @@ static void cols_dispatch(int H, const float2* spec, float2* spec_out, const Spe
   switch (H) {
     case 256: launch_cols<256, 32, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
     case 512: launch_cols<512, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 768: launch_cols<768, 32, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
     default: launch_cols<1024, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
   }
 }

@@ -140,6 +140,101 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
   rdft<V, DIR>(v);
 }
 
+// ---- length 3N: three interleaved length-N transforms + one radix-3 butterfly on registers -------------------------------------------
+// v[r * VS + a], VS = N / T:   on entry (DIR < 0) x[3 (t + a T) + r]          -> on exit X[(t + a T) + r N]
+//                              on entry (DIR > 0) X[(t + a T) + r N]          -> on exit x[3 (t + a T) + r]
+// (decimation in time forward, in frequency backward: the two index maps are each other's inverse, so the operator between a forward
+// and an inverse transform works on registers exactly as in the power-of-two case -- it only has to address its tables with the
+// frequency map).  The three sub-transforms run pass by pass in three LDS regions of LdsSeq<N>::SLOTS slots: the same number of
+// barriers as one power-of-two transform.  tw: exp(-2 pi i k / (3N)), k < 3N, stride 1.
+template <int DIR> __device__ __forceinline__ void rdft3(float2& a0, float2& a1, float2& a2) {
+  constexpr float h = 0.86602540378443864676f;
+  const float2 s = cadd(a1, a2), d = cmul_i<DIR>(cscale(csub(a1, a2), h));
+  const float2 m = make_float2(fmaf(-0.5f, s.x, a0.x), fmaf(-0.5f, s.y, a0.y));
+  a0 = cadd(a0, s);
+  a1 = cadd(m, d);
+  a2 = csub(m, d);
+}
+template <int N, int T, int DIR, class Sync, class Hook = NoHook>
+__device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __restrict__ lds, int t, const float2* __restrict__ tw, Sync sync,
+                                           Hook after_reads = Hook()) {
+  DPX_OPAQUE(t);
+  constexpr int V = N / T, RM = N / (V * V), SL = LdsSeq<N>::SLOTS;
+  static_assert(V * V * RM == N && (RM == 1 || RM == 2 || RM == 4 || RM == 8) && RM <= V, "unsupported N/T split");
+  if constexpr (DIR > 0) {                                   // X[k + q N] -> G_r[k] = conj(w^{r k}) sum_q w3^{+r q} X[k + q N]
+#pragma unroll
+    for (int a = 0; a < V; ++a) {
+      rdft3<DIR>(v[a], v[V + a], v[2 * V + a]);
+      const int k = t + a * T;
+      v[V + a] = twmul<DIR>(v[V + a], tw[k]);
+      v[2 * V + a] = twmul<DIR>(v[2 * V + a], tw[2 * k]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float2 a[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) a[m] = v[r * V + m];
+    rdft<V, DIR>(a);
+#pragma unroll
+    for (int m = 0; m < V; ++m) lds[r * SL + lds_slot(t * V + m)] = a[m];
+  }
+  sync();
+  if constexpr (RM > 1) {
+    constexpr int NB = V / RM;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int mm = 0; mm < RM; ++mm) v[r * V + i * RM + mm] = lds[r * SL + lds_slot(t + i * T + mm * (N / RM))];
+    sync();
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int jb = t + i * T;
+        const int k = jb % V;
+        float2 a[RM];
+#pragma unroll
+        for (int mm = 0; mm < RM; ++mm) a[mm] = v[r * V + i * RM + mm];
+#pragma unroll
+        for (int mm = 1; mm < RM; ++mm) a[mm] = twmul<DIR>(a[mm], tw[(k * mm * V) * 3]);   // W_{V*RM}^{k*mm}
+        rdft<RM, DIR>(a);
+        const int j0 = (jb - k) * RM + k;
+#pragma unroll
+        for (int mm = 0; mm < RM; ++mm) lds[r * SL + lds_slot(j0 + mm * V)] = a[mm];
+      }
+    sync();
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[r * V + m] = lds[r * SL + lds_slot(t + m * T)];
+  after_reads();
+  const unsigned tstep = (unsigned)(t * 3);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float2 a[V];
+    a[0] = v[r * V];
+#pragma unroll
+    for (int m = 1; m < V; ++m) a[m] = twmul<DIR>(v[r * V + m], tw[tstep * (unsigned)m]);
+    rdft<V, DIR>(a);
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[r * V + m] = a[m];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (DIR < 0) {                                   // F_r[k] -> X[k + q N] = sum_r w3^{r q} w^{r k} F_r[k]
+#pragma unroll
+    for (int a = 0; a < V; ++a) {
+      const int k = t + a * T;
+      v[V + a] = twmul<DIR>(v[V + a], tw[k]);
+      v[2 * V + a] = twmul<DIR>(v[2 * V + a], tw[2 * k]);
+      rdft3<DIR>(v[a], v[V + a], v[2 * V + a]);
+    }
+  }
+}
+
 // The twiddles a thread needs depend only on its index t: kernels that transform many sequences with the same
 // thread mapping (one row after another) load them once into registers and reuse them for every transform.
 template <int N, int T, bool KEEPB = true> struct TwRegs {

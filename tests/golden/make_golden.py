@@ -1043,10 +1043,38 @@ def g34_pgd_pow2():
     save("g34_pgd_pow2", **out)
 
 
+def g35_h768():
+    """Column length 768 = 3 * 256 (the height of the reference's own example image, scipy.misc.face 768 x 1024): 1 x 3 x 768 x 256,
+    ADMM TV-deconvolution (state after 4 and 10 iterations), the convolution and its adjoint, proximal gradient descent."""
+    gt, b, psf = synthetic.deconv_case(1, 3, 768, 256, seed=3501)
+    out = {"seed": 3501}
+    for K in (4, 10):
+        x = dp.Variable()
+        st = dp.Problem(_tv_problem(x, T(b), psf)).solve(method="admm", device="cpu", x0=T(b), rhos=0.1, lams=0.005, max_iter=K, return_full_states=True)
+        _pack(out, f"it{K}_x", st[0], 8)
+        for i in range(2):
+            _pack(out, f"it{K}_v{i}", st[1][i], 16)
+            _pack(out, f"it{K}_u{i}", st[2][i], 16)
+    lam10 = np.full(10, 0.005, np.float32)
+    x64, _, _ = admm_f64(b, psf, [("grad0", "norm1", 1.0), ("grad1", "norm1", 1.0)], np.full(10, 0.1, np.float32), [lam10, lam10], 10)
+    _pack(out, "it10_x_f64", torch.from_numpy(np.asarray(x64)), 8)
+    x = dp.Variable()
+    k2 = gauss(9, 2.5)
+    cv = dp.conv(x, k2)
+    out["k2"] = k2
+    _pack(out, "conv_fwd", cv.forward(T(b)), 8)
+    _pack(out, "conv_adj", cv.adjoint(T(b)), 8)
+    x = dp.Variable()
+    g = dp.norm1(x)
+    xo = dp.Problem(dp.sum_squares(dp.conv(x, psf) - T(b)) + g).solve(method="pgd", device="cpu", x0=T(b), rhos=0.8, lams=0.01, max_iter=4)
+    _pack(out, "pgd_x", xo, 8)
+    save("g35_h768", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
                g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
-               g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5, g34_pgd_pow2):
+               g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5, g34_pgd_pow2, g35_h768):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

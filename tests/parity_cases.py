@@ -208,6 +208,38 @@ def case_pgd_pow2_shapes(device):
         assert_close(out.cpu(), ref.cpu(), TOL, f"pgd fused vs op by op {B}x{C}x{H}x{W}")
 
 
+def case_h768(device, tiny=False):
+    """G35: column length 768 = 3 * 256 on the register-radix path (three interleaved 256-point transforms + one radix-3 butterfly on
+    registers, fft_reg_x3) -- the height of the reference's own example image (768 x 1024).  The convolution and its adjoint, the
+    two-kernel ADMM iteration (state after 4 / 10 iterations) and the fused proximal-gradient call against the reference.
+    tiny (the SIMT emulator): the 4-iteration state and the convolution only."""
+    import synthetic
+    from dprox import _ops as ops
+    g = load_golden("g35_h768")
+    gt, b0, psf = synthetic.deconv_case(1, 3, 768, 256, seed=int(g["seed"]))
+    b = T(b0, device)
+    assert ops.pgd_supported(768, 256, 1), "H = 768 is not on the register-radix path"
+    x = dp.Variable()
+    cv = dp.conv(x, g["k2"]).to(device)
+    _check_packed(g, "conv_fwd", cv.forward(b), 8, TOL, what="h768 ")
+    _check_packed(g, "conv_adj", cv.adjoint(b), 8, TOL, what="h768 ")
+    for K in ((4,) if tiny else (4, 10)):
+        x, fns, _ = tv_problem(b, psf)
+        prob = dp.Problem(fns)
+        xs, vs, us = prob.solve(method="admm", device=device, x0=b, rhos=0.1, lams=0.005, max_iter=K, return_full_states=True)
+        assert prob.solver.last_path == "fused"
+        _check_packed(g, f"it{K}_x", xs, 8, TOL, what="h768 ")
+        for i in range(2):
+            _check_packed(g, f"it{K}_v{i}", vs[i], 16, TOL, scale_key=f"it{K}_x", what="h768 ", scale_sub=2)
+            _check_packed(g, f"it{K}_u{i}", us[i], 16, TOL, scale_key=f"it{K}_x", what="h768 ", scale_sub=2)
+    if tiny:
+        return
+    x = dp.Variable()
+    term = dp.norm1(x)
+    out = dp.Problem(dp.sum_squares(dp.conv(x, psf) - b) + term).solve(method="pgd", device=device, x0=b, rhos=0.8, lams=0.01, max_iter=4)
+    _check_packed(g, "pgd_x", out, 8, TOL, what="h768 ")
+
+
 def case_known_answers(device):
     """the reference's own exact tests, tests/problem/test_ml_problems.py:5-44"""
     g = load_golden("g13_known_answers")

@@ -51,6 +51,10 @@ def test_pgd():
     pc.case_pgd(DEV)
 
 
+def test_column_length_768():
+    pc.case_h768(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV)
 
