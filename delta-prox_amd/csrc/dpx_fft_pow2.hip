@@ -478,7 +478,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
 
 template <int H, int T, int COLS, int OP, int DBG = 0>
 #ifndef DPX_COLS_WPE
-#define DPX_COLS_WPE ((T * COLS) >= 512 ? 4 : (H % 3 == 0 ? 2 : 3))     // waves per SIMD the register budget is sized for (H = 768: 61 KB of LDS -> 2 workgroups of 4 waves per CU)
+#define DPX_COLS_WPE ((H % 3 == 0 || H >= 2048) ? 2 : (T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for (H = 768: 61 KB of LDS -> 2 workgroups of 4 waves per CU)
 #endif
 __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
                                                       int C, int Ws, int P, const float2* __restrict__ twH) {
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(T* COLS, 4) k_cols_probe_wide(const float4* __
 size_t pow2_spec_elems(int P, int H, int W) { return (size_t)P * H * (W / 2) + (size_t)P * H; }
 
 bool pow2_path_available(int H, int W) {
-  const bool hok = (H == 256 || H == 512 || H == 768 || H == 1024);
+  const bool hok = (H == 256 || H == 384 || H == 512 || H == 768 || H == 1024 || H == 1536 || H == 2048);
   const bool wok = (W == 256 || W == 512 || W == 1024 || W == 2048);
   return hok && wok;
 }
@@ -623,7 +623,10 @@ static void cols_dispatch(int H, const float2* spec, float2* spec_out, const Spe
   switch (H) {
     case 256: launch_cols<256, 32, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
     case 512: launch_cols<512, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 384: launch_cols<384, 16, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
     case 768: launch_cols<768, 32, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 1536: launch_cols<1536, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
+    case 2048: launch_cols<2048, 128, 4, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;      // (4 columns: 98 KB of LDS per workgroup)
     default: launch_cols<1024, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
   }
 }

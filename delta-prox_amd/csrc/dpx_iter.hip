@@ -633,8 +633,11 @@ extern "C" int dpx_admm_iter_config(int rows_mode, int bands_per_plane) {
   return DPX_OK;
 }
 
+static const int g_iter_w2048 = getenv("DPX_ITER_W2048") ? atoi(getenv("DPX_ITER_W2048")) : 0;   // tuning: keep the two-kernel iteration on 2048-wide planes
 extern "C" int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms) {
-  return pow2_path_available(H, W) && H % 16 == 0 && terms_ok(terms, nterms);
+  // (2048-wide planes: 16 values per thread spill in the row kernel -- 33 ps per pixel and iteration against 14 on the staged
+  //  kernels, which the callers fall back to)
+  return pow2_path_available(H, W) && W <= (g_iter_w2048 ? 2048 : 1024) && H % 16 == 0 && terms_ok(terms, nterms);
 }
 
 extern "C" int dpx_rfft_rows(const float* x, void* spec, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {

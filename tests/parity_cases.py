@@ -240,6 +240,28 @@ def case_h768(device, tiny=False):
     _check_packed(g, "pgd_x", out, 8, TOL, what="h768 ")
 
 
+def case_other_column_lengths(device, lengths=(384, 1536, 2048)):
+    """the other column lengths of the register-radix path (3 * 2^k, and 2048 on 4-column workgroups) against the oracle (the fp32 CPU restatement of the reference,
+    pinned by the fixtures): convolution, adjoint, and the two-kernel ADMM iteration"""
+    import oracle as O
+    import synthetic
+    for H in lengths:
+        gt, b0, psf = synthetic.deconv_case(1, 3 if H < 1024 else 1, H, 256, seed=H)      # (the reference's conv takes 1 or 3 channels)
+        b, bt = T(b0, device), torch.from_numpy(b0)
+        x = dp.Variable()
+        cv = dp.conv(x, psf).to(device)
+        lin = O.lin_conv(psf)
+        assert_close(cv.forward(b).cpu(), lin.fwd(bt), TOL, f"conv forward, H = {H}")
+        assert_close(cv.adjoint(b).cpu(), lin.adj(bt), TOL, f"conv adjoint, H = {H}")
+        x, fns, _ = tv_problem(b, psf)
+        prob = dp.Problem(fns)
+        out = prob.solve(method="admm", device=device, x0=b, rhos=0.1, lams=0.005, max_iter=6)
+        assert prob.solver.last_path == "fused"
+        ref = O.solve([O.sum_squares(O.lin_conv(psf).minus(bt)), O.norm1(O.lin_grad(0)), O.norm1(O.lin_grad(1))],
+                      "admm", x0=bt, rhos=0.1, lams=0.005, max_iter=6)
+        assert_close(out.cpu(), ref, TOL, f"ADMM x 6, H = {H}", maxabs_mult=4.0)   # (pointwise at the fp32 noise floor, as config 1: conftest.assert_close)
+
+
 def case_known_answers(device):
     """the reference's own exact tests, tests/problem/test_ml_problems.py:5-44"""
     g = load_golden("g13_known_answers")

@@ -50,6 +50,10 @@ def test_column_length_768():
     pc.case_h768(DEV, tiny=True)
 
 
+def test_other_column_lengths():
+    pc.case_other_column_lengths(DEV, lengths=(384,))
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV, tiny=True)
 

@@ -55,6 +55,10 @@ def test_column_length_768():
     pc.case_h768(DEV)
 
 
+def test_other_column_lengths():
+    pc.case_other_column_lengths(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV)
 
