@@ -21,48 +21,141 @@ namespace dpx {
 // ---------------------------------------------------------------------------------------------
 // rows
 // ---------------------------------------------------------------------------------------------
+// Register <-> index maps of one row (M = W/2 complex points, T lanes, V = M/T values per lane).  Power-of-two M: register m holds
+// point t + m T before and after a transform.  M = 3 * 2^k (fft_reg_x3): register m = r VS + a holds point 3 (t + a T) + r in the
+// image domain and bin (t + a T) + r M/3 in the frequency domain.  krow: the part of the frequency map that does not depend on t;
+// the bin M - k that the real-input (un)tangling pairs with bin k sits in lane (T - t) % T, register pne(m) (t != 0) / peq(m) (t == 0).
+template <int M, int T> struct RowMap {
+  static constexpr bool R3 = (M % 3 == 0);
+  static constexpr int V = M / T, VS = R3 ? V / 3 : V, N = R3 ? M / 3 : M;
+  static constexpr int LDS_SLOTS = R3 ? 3 * LdsSeq<N>::SLOTS : LdsSeq<M>::SLOTS;
+  __device__ static constexpr int krow(int m) { return R3 ? (m % VS) * T + (m / VS) * N : m * T; }
+  __device__ static constexpr int pne(int m) { return R3 ? (2 - m / VS) * VS + (VS - 1 - m % VS) : V - 1 - m; }
+  __device__ static constexpr int peq(int m) {
+    return R3 ? ((m % VS) ? (2 - m / VS) * VS + (VS - m % VS) : ((3 - m / VS) % 3) * VS) : (V - m) % V;
+  }
+  // the lane's pixel pairs of one image row (row: the row's first pair).  M = 3 * 2^k: a lane owns 3 adjacent pairs per a -- 24 contiguous
+  // bytes, moved as 16 + 8 (pair-by-pair the three 24-byte-strided loads take 3.5x longer: 104 us instead of 30 for 8x3x768^2)
+  typedef float row_f4 __attribute__((ext_vector_type(4), aligned(8)));
+  typedef float row_f2 __attribute__((ext_vector_type(2), aligned(8)));
+  template <int NT = 0> __device__ static __forceinline__ void load_pairs(float2 (&v)[V], const float2* __restrict__ row, int t) {
+    if constexpr (R3) {
+#pragma unroll
+      for (int a = 0; a < VS; ++a) {
+        const float* p = (const float*)(row + 3 * (t + a * T));
+        const row_f4 q = NT ? __builtin_nontemporal_load((const row_f4*)p) : *(const row_f4*)p;
+        const row_f2 w = NT ? __builtin_nontemporal_load((const row_f2*)(p + 4)) : *(const row_f2*)(p + 4);
+        v[a] = make_float2(q.x, q.y);
+        v[VS + a] = make_float2(q.z, q.w);
+        v[2 * VS + a] = make_float2(w.x, w.y);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < V; ++m) v[m] = ld_stream<NT>(row + t + m * T);
+    }
+  }
+  template <class F> __device__ static __forceinline__ void store_pairs(float2* __restrict__ row, int t, F value) {
+    if constexpr (R3) {
+#pragma unroll
+      for (int a = 0; a < VS; ++a) {
+        float* p = (float*)(row + 3 * (t + a * T));
+        const float2 v0 = value(a), v1 = value(VS + a), v2 = value(2 * VS + a);
+        row_f4 q = {v0.x, v0.y, v1.x, v1.y};
+        row_f2 w = {v2.x, v2.y};
+        *(row_f4*)p = q;
+        *(row_f2*)(p + 4) = w;
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < V; ++m) row[t + m * T] = value(m);
+    }
+  }
+  // spectrum offset of bin krow(m) relative to the lane's bin t (column-tile-major: bin k of image row h at ((k >> 3) H + h) 8 + (k & 7))
+  __device__ static constexpr size_t koff(int m, int H) { return (size_t)(krow(m) / SPEC_TILE) * H * SPEC_TILE; }
+  template <int DIR> __device__ static __forceinline__ void fft(float2 (&v)[V], float2* lds, int t, const float2* __restrict__ twW) {
+    if constexpr (R3) fft_reg_x3<N, T, DIR>(v, lds, t, twW, 2, WaveSync());
+    else fft_reg<M, T, DIR>(v, lds, t, twW, 2, WaveSync());
+  }
+  // Z (the transform of the row read as complex pairs) -> X (the row's half spectrum); returns the (real) Nyquist bin in lane t = 0
+  //   X[k] = E[k] + w^k O[k], E = (Z[k] + conj Z[M-k])/2, O = -i (Z[k] - conj Z[M-k])/2
+  __device__ static __forceinline__ float untangle(const float2 (&v)[V], float2 (&X)[V], int t, int lane, const float2* __restrict__ twW) {
+    const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
+    float nyq = 0.f;
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+      const float2 got = make_float2(__shfl(v[pne(m)].x, plane), __shfl(v[pne(m)].y, plane));
+      float2 own = v[peq(m)];
+      if constexpr (R3) {     // (there the select between two elements of v becomes one dynamically indexed access: the array would live in scratch)
+        DPX_OPAQUE(own.x);
+        DPX_OPAQUE(own.y);
+      }
+      const float2 zm = cconj(t == 0 ? own : got);
+      const int k = t + krow(m);
+      const float2 zk = v[m];
+      if (k == 0) {
+        X[m] = make_float2(zk.x + zk.y, 0.f);                               // DC (real)
+        nyq = zk.x - zk.y;
+      } else {
+        const float2 e = cscale(cadd(zk, zm), 0.5f);
+        const float2 d = cscale(csub(zk, zm), 0.5f);
+        X[m] = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
+      }
+    }
+    return nyq;
+  }
+  // the inverse: X (+ the Nyquist bin xn) -> the complex sequence whose inverse transform is the row's pixel pairs
+  __device__ static __forceinline__ void tangle(const float2 (&X)[V], float2 (&v)[V], float xn, int t, int lane, const float2* __restrict__ twW) {
+    const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+      const float2 got = make_float2(__shfl(X[pne(m)].x, plane), __shfl(X[pne(m)].y, plane));
+      float2 own = X[peq(m)];
+      if constexpr (R3) {
+        DPX_OPAQUE(own.x);
+        DPX_OPAQUE(own.y);
+      }
+      const float2 xm = cconj(t == 0 ? own : got);
+      const int k = t + krow(m);
+      const float2 xk = X[m];
+      if (k == 0) {
+        v[m] = make_float2(xk.x + xn, xk.x - xn);       // DC and Nyquist bins of a real row are real: imaginary round-off dropped
+      } else {
+        const float2 e = cadd(xk, xm);
+        const float2 d = cmulc(csub(xk, xm), twW[k]);
+        v[m] = make_float2(e.x - d.y, e.y + d.x);
+      }
+    }
+  }
+};
+
 template <int M, int T>
 __global__ void __launch_bounds__(256) k_rows_r2c_p2(const float* __restrict__ x, float2* __restrict__ spec, float2* __restrict__ side,
                                                       int nrows, int H, const float2* __restrict__ twW) {
-  constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
+  using RM = RowMap<M, T>;
+  constexpr int V = M / T, SPB = 256 / T, S = RM::LDS_SLOTS;
   __shared__ float2 lds[SPB * S];
   const int tid = threadIdx.x, seq = tid / T, t = tid % T;
   const int row = blockIdx.x * SPB + seq;
   const bool live = row < nrows;
-  const float2* xr = (const float2*)(x + (size_t)(live ? row : 0) * (2 * M));
   float2 v[V];
-#pragma unroll
-  for (int m = 0; m < V; ++m) v[m] = xr[t + m * T];
-  fft_reg<M, T, -1>(v, lds + seq * S, t, twW, 2, WaveSync());
-  // real-input untangling: X[k] = E[k] + w^k O[k], E = (Z[k] + conj Z[M-k])/2, O = -i (Z[k] - conj Z[M-k])/2
-  const int lane = tid & 63;
-  const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
-  // column-tile-major spectrum: bin k of image row h of plane pl -> pl*H*M + ((k >> 3)*H + h)*8 + (k & 7)
+  RM::load_pairs(v, (const float2*)(x + (size_t)(live ? row : 0) * (2 * M)), t);
+  RM::template fft<-1>(v, lds + seq * S, t, twW);
+  float2 X[V];
+  const float nyq = RM::untangle(v, X, t, tid & 63, twW);
   const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H;
   float2* out = spec + (size_t)pl * H * M + (size_t)hh * SPEC_TILE + (t % SPEC_TILE) + (size_t)(t / SPEC_TILE) * H * SPEC_TILE;
+  if (live && t == 0) side[row] = make_float2(nyq, 0.f);
+  if (live) {
 #pragma unroll
-  for (int m = 0; m < V; ++m) {
-    const float2 got = make_float2(__shfl(v[V - 1 - m].x, plane), __shfl(v[V - 1 - m].y, plane));
-    const float2 zm = cconj(t == 0 ? v[(V - m) % V] : got);
-    const int k = t + m * T;
-    const float2 zk = v[m];
-    float2 X;
-    if (k == 0) {
-      X = make_float2(zk.x + zk.y, 0.f);                                  // DC (real)
-      if (live) side[row] = make_float2(zk.x - zk.y, 0.f);                // Nyquist (real)
-    } else {
-      const float2 e = cscale(cadd(zk, zm), 0.5f);
-      const float2 d = cscale(csub(zk, zm), 0.5f);
-      X = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
-    }
-    if (live) out[(size_t)m * (T / SPEC_TILE) * H * SPEC_TILE] = X;     // k = t + m*T: tile index advances by T/SPEC_TILE per m
+    for (int m = 0; m < V; ++m) out[RM::koff(m, H)] = X[m];
   }
 }
 
 template <int M, int T>
 __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ spec, const float2* __restrict__ side,
                                                       float* __restrict__ y, int nrows, int H, const float2* __restrict__ twW, float scale) {
-  constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
+  using RM = RowMap<M, T>;
+  constexpr int V = M / T, SPB = 256 / T, S = RM::LDS_SLOTS;
   __shared__ float2 lds[SPB * S];
   const int tid = threadIdx.x, seq = tid / T, t = tid % T;
   const int row = blockIdx.x * SPB + seq;
@@ -71,30 +164,10 @@ __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ 
   const float2* in = spec + (size_t)pl * H * M + (size_t)hh * SPEC_TILE + (t % SPEC_TILE) + (size_t)(t / SPEC_TILE) * H * SPEC_TILE;
   float2 X[V], v[V];
 #pragma unroll
-  for (int m = 0; m < V; ++m) X[m] = in[(size_t)m * (T / SPEC_TILE) * H * SPEC_TILE];
-  const int lane = tid & 63;
-  const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
-#pragma unroll
-  for (int m = 0; m < V; ++m) {
-    const float2 got = make_float2(__shfl(X[V - 1 - m].x, plane), __shfl(X[V - 1 - m].y, plane));
-    const float2 xm = cconj(t == 0 ? X[(V - m) % V] : got);
-    const int k = t + m * T;
-    const float2 xk = X[m];
-    if (k == 0) {
-      const float xn = side[live ? row : 0].x;      // DC and Nyquist bins of a real row are real: imaginary round-off dropped
-      v[m] = make_float2(xk.x + xn, xk.x - xn);
-    } else {
-      const float2 e = cadd(xk, xm);
-      const float2 d = cmulc(csub(xk, xm), twW[k]);
-      v[m] = make_float2(e.x - d.y, e.y + d.x);
-    }
-  }
-  fft_reg<M, T, +1>(v, lds + seq * S, t, twW, 2, WaveSync());
-  float2* yr = (float2*)(y + (size_t)(live ? row : 0) * (2 * M));
-  if (live) {
-#pragma unroll
-    for (int m = 0; m < V; ++m) yr[t + m * T] = make_float2(v[m].x * scale, v[m].y * scale);
-  }
+  for (int m = 0; m < V; ++m) X[m] = in[RM::koff(m, H)];
+  RM::tangle(X, v, side[rr].x, t, tid & 63, twW);
+  RM::template fft<+1>(v, lds + seq * S, t, twW);
+  if (live) RM::store_pairs((float2*)(y + (size_t)rr * (2 * M)), t, [&](int m) { return make_float2(v[m].x * scale, v[m].y * scale); });
 }
 
 #ifndef DPX_PGD_LD_NT
@@ -102,9 +175,6 @@ __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ 
 #endif
 #ifndef DPX_PGD_ST
 #define DPX_PGD_ST 0
-#endif
-#ifndef DPX_PGD_XST
-#define DPX_PGD_XST 0
 #endif
 __device__ __forceinline__ float pgd_prox(int kind, float d, float lam) {     // (dpx_elementwise.hip::prox_eval, closed forms only)
   if (kind == DPX_PROX_NORM1) {
@@ -124,72 +194,46 @@ template <int M, int T>
 __global__ void __launch_bounds__(256) k_pgd_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, float* __restrict__ x,
                                                    const float* __restrict__ ktb, const float* __restrict__ rho, const float* __restrict__ lam,
                                                    float alpha, int prox, int nrows, int H, int C, const float2* __restrict__ twW) {
-  constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS;
+  using RM = RowMap<M, T>;
+  constexpr int V = M / T, SPB = 256 / T, S = RM::LDS_SLOTS;
   __shared__ float2 lds[SPB * S];
   const int tid = threadIdx.x, seq = tid / T, t = tid % T;
   const int row = blockIdx.x * SPB + seq;
   const bool live = row < nrows;
   const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H, bi = pl / C;
   const size_t toff = (size_t)pl * H * M + (size_t)hh * SPEC_TILE + (t % SPEC_TILE) + (size_t)(t / SPEC_TILE) * H * SPEC_TILE;
-  const size_t tstep = (size_t)(T / SPEC_TILE) * H * SPEC_TILE;
   const float2* side_in = spec_in + (size_t)nrows * M;
-  const int lane = tid & 63;
-  const int plane = (lane & ~(T - 1)) | ((T - t) & (T - 1));
   float2 X[V], v[V], xo[V], kb[V];
 #pragma unroll
-  for (int m = 0; m < V; ++m) X[m] = ld_stream<DPX_PGD_LD_NT>(spec_in + toff + tstep * m);
+  for (int m = 0; m < V; ++m) X[m] = ld_stream<DPX_PGD_LD_NT>(spec_in + toff + RM::koff(m, H));
   const float xn0 = side_in[rr].x;
   // the iterate and K^T b are requested with the spectrum: ONE memory round trip in front of the transform
   float2* xr = (float2*)(x + (size_t)rr * (2 * M));
-  const float2* kr = ktb ? (const float2*)(ktb + (size_t)rr * (2 * M)) : nullptr;
+  RM::load_pairs(xo, xr, t);
+  if (ktb) {
+    RM::template load_pairs<1>(kb, (const float2*)(ktb + (size_t)rr * (2 * M)), t);
+  } else {
 #pragma unroll
-  for (int m = 0; m < V; ++m) xo[m] = xr[t + m * T];
-#pragma unroll
-  for (int m = 0; m < V; ++m) kb[m] = kr ? ld_stream<1>(kr + t + m * T) : make_float2(0.f, 0.f);
-#pragma unroll
-  for (int m = 0; m < V; ++m) {
-    const float2 got = make_float2(__shfl(X[V - 1 - m].x, plane), __shfl(X[V - 1 - m].y, plane));
-    const float2 xm = cconj(t == 0 ? X[(V - m) % V] : got);
-    const int k = t + m * T;
-    const float2 xk = X[m];
-    if (k == 0) {
-      const float xn = xn0;
-      v[m] = make_float2(xk.x + xn, xk.x - xn);
-    } else {
-      const float2 e = cadd(xk, xm);
-      const float2 d = cmulc(csub(xk, xm), twW[k]);
-      v[m] = make_float2(e.x - d.y, e.y + d.x);
-    }
+    for (int m = 0; m < V; ++m) kb[m] = make_float2(0.f, 0.f);
   }
-  fft_reg<M, T, +1>(v, lds + seq * S, t, twW, 2, WaveSync());     // v[m] = ((K^T K x)[2n], [2n+1]), n = t + m T
+  RM::tangle(X, v, xn0, t, tid & 63, twW);
+  RM::template fft<+1>(v, lds + seq * S, t, twW);     // v[m] = two adjacent pixels of K^T K x
   const float r = rho[bi], th = lam ? lam[bi] * alpha : 0.f;
 #pragma unroll
   for (int m = 0; m < V; ++m) {
     float2 y = make_float2(xo[m].x - r * (v[m].x - kb[m].x), xo[m].y - r * (v[m].y - kb[m].y));
-    y = make_float2(pgd_prox(prox, y.x, th), pgd_prox(prox, y.y, th));
-    if (live) st_stream<DPX_PGD_XST>(xr + t + m * T, y);
-    v[m] = y;
+    v[m] = make_float2(pgd_prox(prox, y.x, th), pgd_prox(prox, y.y, th));
   }
+  if (live) RM::store_pairs(xr, t, [&](int m) { return v[m]; });
   if (!spec_out) return;                                              // (block-uniform: the last iteration needs no spectrum)
   WaveSync()();
-  fft_reg<M, T, -1>(v, lds + seq * S, t, twW, 2, WaveSync());
+  RM::template fft<-1>(v, lds + seq * S, t, twW);
+  const float nyq = RM::untangle(v, X, t, tid & 63, twW);
   float2* side_out = spec_out + (size_t)nrows * M;
+  if (live && t == 0) side_out[row] = make_float2(nyq, 0.f);
+  if (live) {
 #pragma unroll
-  for (int m = 0; m < V; ++m) {
-    const float2 got = make_float2(__shfl(v[V - 1 - m].x, plane), __shfl(v[V - 1 - m].y, plane));
-    const float2 zm = cconj(t == 0 ? v[(V - m) % V] : got);
-    const int k = t + m * T;
-    const float2 zk = v[m];
-    float2 Xo;
-    if (k == 0) {
-      Xo = make_float2(zk.x + zk.y, 0.f);
-      if (live) side_out[row] = make_float2(zk.x - zk.y, 0.f);
-    } else {
-      const float2 e = cscale(cadd(zk, zm), 0.5f);
-      const float2 d = cscale(csub(zk, zm), 0.5f);
-      Xo = cadd(e, cmul(make_float2(d.y, -d.x), twW[k]));
-    }
-    if (live) st_stream<DPX_PGD_ST>(spec_out + toff + tstep * m, Xo);
+    for (int m = 0; m < V; ++m) st_stream<DPX_PGD_ST>(spec_out + toff + RM::koff(m, H), X[m]);
   }
 }
 
@@ -341,7 +385,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
     }
   };
   if (!(DBG & 1)) {
-    if constexpr (R3) fft_reg_x3<H / 3, T, -1>(v, lds, t, twl, BlockSync(), fetch_table);
+    if constexpr (R3) fft_reg_x3<H / 3, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
     else fft_reg<H, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -459,7 +503,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   __builtin_amdgcn_sched_barrier(0);
   DPX_LDS_BARRIER();
   if (!(DBG & 1)) {
-    if constexpr (R3) fft_reg_x3<H / 3, T, +1>(v, lds, t, twl, BlockSync());
+    if constexpr (R3) fft_reg_x3<H / 3, T, +1>(v, lds, t, twl, 1, BlockSync());
     else fft_reg<H, T, +1>(v, lds, t, twl, 1, BlockSync());
   }
   unsigned off1 = off0;
@@ -558,7 +602,7 @@ size_t pow2_spec_elems(int P, int H, int W) { return (size_t)P * H * (W / 2) + (
 
 bool pow2_path_available(int H, int W) {
   const bool hok = (H == 256 || H == 384 || H == 512 || H == 768 || H == 1024 || H == 1536 || H == 2048);
-  const bool wok = (W == 256 || W == 512 || W == 1024 || W == 2048);
+  const bool wok = (W == 256 || W == 512 || W == 768 || W == 1024 || W == 1536 || W == 2048);
   return hok && wok;
 }
 
@@ -577,6 +621,8 @@ static void rows_dispatch(bool fwd, int W, int H, const float* x, float2* spec, 
   switch (W) {
     case 256: launch_rows<128, 16>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
     case 512: launch_rows<256, 32>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
+    case 768: launch_rows<384, 16>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
+    case 1536: launch_rows<768, 32>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
     case 1024: launch_rows<512, 64>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
     default: launch_rows<1024, 64>(fwd, x, spec, y, nrows, H, twW, scale, s); break;
   }
@@ -683,6 +729,8 @@ int pgd_run_pow2(float* x, const float* ktb, const void* gram_otf, int prox, flo
     switch (W) {
       case 256: launch_pgd_rows<128, 16>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
       case 512: launch_pgd_rows<256, 32>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
+      case 768: launch_pgd_rows<384, 16>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
+      case 1536: launch_pgd_rows<768, 32>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
       case 1024: launch_pgd_rows<512, 64>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
       default: launch_pgd_rows<1024, 64>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
     }

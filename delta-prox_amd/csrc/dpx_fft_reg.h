@@ -146,7 +146,7 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
 // (decimation in time forward, in frequency backward: the two index maps are each other's inverse, so the operator between a forward
 // and an inverse transform works on registers exactly as in the power-of-two case -- it only has to address its tables with the
 // frequency map).  The three sub-transforms run pass by pass in three LDS regions of LdsSeq<N>::SLOTS slots: the same number of
-// barriers as one power-of-two transform.  tw: exp(-2 pi i k / (3N)), k < 3N, stride 1.
+// barriers as one power-of-two transform.  tw: exp(-2 pi i k / (3N * tws)) table, stride tws.
 template <int DIR> __device__ __forceinline__ void rdft3(float2& a0, float2& a1, float2& a2) {
   constexpr float h = 0.86602540378443864676f;
   const float2 s = cadd(a1, a2), d = cmul_i<DIR>(cscale(csub(a1, a2), h));
@@ -156,8 +156,8 @@ template <int DIR> __device__ __forceinline__ void rdft3(float2& a0, float2& a1,
   a2 = csub(m, d);
 }
 template <int N, int T, int DIR, class Sync, class Hook = NoHook>
-__device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __restrict__ lds, int t, const float2* __restrict__ tw, Sync sync,
-                                           Hook after_reads = Hook()) {
+__device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __restrict__ lds, int t, const float2* __restrict__ tw, int tws,
+                                           Sync sync, Hook after_reads = Hook()) {
   DPX_OPAQUE(t);
   constexpr int V = N / T, RM = N / (V * V), SL = LdsSeq<N>::SLOTS;
   static_assert(V * V * RM == N && (RM == 1 || RM == 2 || RM == 4 || RM == 8) && RM <= V, "unsupported N/T split");
@@ -166,8 +166,8 @@ __device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __res
     for (int a = 0; a < V; ++a) {
       rdft3<DIR>(v[a], v[V + a], v[2 * V + a]);
       const int k = t + a * T;
-      v[V + a] = twmul<DIR>(v[V + a], tw[k]);
-      v[2 * V + a] = twmul<DIR>(v[2 * V + a], tw[2 * k]);
+      v[V + a] = twmul<DIR>(v[V + a], tw[k * tws]);
+      v[2 * V + a] = twmul<DIR>(v[2 * V + a], tw[2 * k * tws]);
     }
   }
 #pragma unroll
@@ -199,7 +199,7 @@ __device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __res
 #pragma unroll
         for (int mm = 0; mm < RM; ++mm) a[mm] = v[r * V + i * RM + mm];
 #pragma unroll
-        for (int mm = 1; mm < RM; ++mm) a[mm] = twmul<DIR>(a[mm], tw[(k * mm * V) * 3]);   // W_{V*RM}^{k*mm}
+        for (int mm = 1; mm < RM; ++mm) a[mm] = twmul<DIR>(a[mm], tw[(k * mm * V) * 3 * tws]);   // W_{V*RM}^{k*mm}
         rdft<RM, DIR>(a);
         const int j0 = (jb - k) * RM + k;
 #pragma unroll
@@ -212,7 +212,7 @@ __device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __res
 #pragma unroll
     for (int m = 0; m < V; ++m) v[r * V + m] = lds[r * SL + lds_slot(t + m * T)];
   after_reads();
-  const unsigned tstep = (unsigned)(t * 3);
+  const unsigned tstep = (unsigned)(t * 3 * tws);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     float2 a[V];
@@ -228,8 +228,8 @@ __device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __res
 #pragma unroll
     for (int a = 0; a < V; ++a) {
       const int k = t + a * T;
-      v[V + a] = twmul<DIR>(v[V + a], tw[k]);
-      v[2 * V + a] = twmul<DIR>(v[2 * V + a], tw[2 * k]);
+      v[V + a] = twmul<DIR>(v[V + a], tw[k * tws]);
+      v[2 * V + a] = twmul<DIR>(v[2 * V + a], tw[2 * k * tws]);
       rdft3<DIR>(v[a], v[V + a], v[2 * V + a]);
     }
   }

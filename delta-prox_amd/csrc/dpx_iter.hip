@@ -637,7 +637,8 @@ static const int g_iter_w2048 = getenv("DPX_ITER_W2048") ? atoi(getenv("DPX_ITER
 extern "C" int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms) {
   // (2048-wide planes: 16 values per thread spill in the row kernel -- 33 ps per pixel and iteration against 14 on the staged
   //  kernels, which the callers fall back to)
-  return pow2_path_available(H, W) && W <= (g_iter_w2048 ? 2048 : 1024) && H % 16 == 0 && terms_ok(terms, nterms);
+  const bool wok = W == 256 || W == 512 || W == 1024 || (W == 2048 && g_iter_w2048);     // (768 / 1536: 24 values per thread, staged kernels only)
+  return pow2_path_available(H, W) && wok && H % 16 == 0 && terms_ok(terms, nterms);
 }
 
 extern "C" int dpx_rfft_rows(const float* x, void* spec, int B, int C, int H, int W, const void* table, dpx_stream_t stream) {

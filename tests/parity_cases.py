@@ -240,26 +240,34 @@ def case_h768(device, tiny=False):
     _check_packed(g, "pgd_x", out, 8, TOL, what="h768 ")
 
 
-def case_other_column_lengths(device, lengths=(384, 1536, 2048)):
-    """the other column lengths of the register-radix path (3 * 2^k, and 2048 on 4-column workgroups) against the oracle (the fp32 CPU restatement of the reference,
-    pinned by the fixtures): convolution, adjoint, and the two-kernel ADMM iteration"""
+def case_other_plane_sizes(device, sizes=((384, 256), (1536, 256), (2048, 256), (256, 768), (768, 768), (512, 1536)), channels=None):
+    """the other plane sizes of the register-radix path (3 * 2^k rows / columns: fft_reg_x3; 2048 rows on 4-column workgroups)
+    against the oracle (the fp32 CPU restatement of the reference, pinned by the fixtures): convolution, adjoint, the ADMM
+    iteration (two kernels, or the staged kernels for 768- and 1536-wide planes) and the fused proximal-gradient call"""
     import oracle as O
     import synthetic
-    for H in lengths:
-        gt, b0, psf = synthetic.deconv_case(1, 3 if H < 1024 else 1, H, 256, seed=H)      # (the reference's conv takes 1 or 3 channels)
+    from dprox import _ops as ops
+    for (H, W) in sizes:
+        assert ops.pgd_supported(H, W, 1), f"{H}x{W} is not on the register-radix path"
+        gt, b0, psf = synthetic.deconv_case(1, channels or (3 if H * W < 500000 else 1), H, W, seed=H + W)      # (the reference's conv takes 1 or 3 channels)
         b, bt = T(b0, device), torch.from_numpy(b0)
         x = dp.Variable()
         cv = dp.conv(x, psf).to(device)
         lin = O.lin_conv(psf)
-        assert_close(cv.forward(b).cpu(), lin.fwd(bt), TOL, f"conv forward, H = {H}")
-        assert_close(cv.adjoint(b).cpu(), lin.adj(bt), TOL, f"conv adjoint, H = {H}")
+        assert_close(cv.forward(b).cpu(), lin.fwd(bt), TOL, f"conv forward, {H}x{W}")
+        assert_close(cv.adjoint(b).cpu(), lin.adj(bt), TOL, f"conv adjoint, {H}x{W}")
         x, fns, _ = tv_problem(b, psf)
         prob = dp.Problem(fns)
         out = prob.solve(method="admm", device=device, x0=b, rhos=0.1, lams=0.005, max_iter=6)
         assert prob.solver.last_path == "fused"
         ref = O.solve([O.sum_squares(O.lin_conv(psf).minus(bt)), O.norm1(O.lin_grad(0)), O.norm1(O.lin_grad(1))],
                       "admm", x0=bt, rhos=0.1, lams=0.005, max_iter=6)
-        assert_close(out.cpu(), ref, TOL, f"ADMM x 6, H = {H}", maxabs_mult=4.0)   # (pointwise at the fp32 noise floor, as config 1: conftest.assert_close)
+        assert_close(out.cpu(), ref, TOL, f"ADMM x 6, {H}x{W}", maxabs_mult=4.0)   # (pointwise at the fp32 noise floor, as config 1: conftest.assert_close)
+        x = dp.Variable()
+        term = dp.norm1(x)
+        out = dp.Problem(dp.sum_squares(dp.conv(x, psf) - b) + term).solve(method="pgd", device=device, x0=b, rhos=0.8, lams=0.01, max_iter=3)
+        ref = O.solve([O.sum_squares(O.lin_conv(psf).minus(bt)), O.norm1(O.lin_identity())], "pgd", x0=bt, rhos=0.8, lams=0.01, max_iter=3)
+        assert_close(out.cpu(), ref, TOL, f"PGD x 3, {H}x{W}")
 
 
 def case_known_answers(device):

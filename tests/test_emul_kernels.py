@@ -50,8 +50,8 @@ def test_column_length_768():
     pc.case_h768(DEV, tiny=True)
 
 
-def test_other_column_lengths():
-    pc.case_other_column_lengths(DEV, lengths=(384,))
+def test_other_plane_sizes():
+    pc.case_other_plane_sizes(DEV, sizes=((384, 256), (256, 768)), channels=1)
 
 
 def test_pgd_pow2_fused():

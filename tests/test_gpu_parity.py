@@ -55,8 +55,8 @@ def test_column_length_768():
     pc.case_h768(DEV)
 
 
-def test_other_column_lengths():
-    pc.case_other_column_lengths(DEV)
+def test_other_plane_sizes():
+    pc.case_other_plane_sizes(DEV)
 
 
 def test_pgd_pow2_fused():
