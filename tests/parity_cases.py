@@ -270,6 +270,39 @@ def case_other_plane_sizes(device, sizes=((384, 256), (1536, 256), (2048, 256), 
         assert_close(out.cpu(), ref, TOL, f"PGD x 3, {H}x{W}")
 
 
+def case_unrolled_plane_sizes(device, shapes=((1, 3, 768, 1024), (1, 3, 768, 768))):
+    """unrolled ADMM x 4 (forward on the two-kernel iteration / the staged kernels, hand-written backward stages) on the 3 * 2^k planes
+    against float64 autograd through oracle.admm_f64: iterate and loss at 1e-5, gradients w.r.t. the rho / lambda schedules and
+    the observation at 1e-3 (measured 6e-6 ... 1.5e-4, the same as on 512 x 512)"""
+    import synthetic
+    from oracle.dprox_oracle import admm_f64
+    K = 4
+    for shape in shapes:
+        gt, b, psf = synthetic.deconv_case(*shape, seed=5)
+        r0, a0, a1 = (np.linspace(lo, hi, K).astype("float32") for lo, hi in ((0.3, 0.1), (0.02, 0.005), (0.015, 0.006)))
+        x = dp.Variable()
+        bt = T(b, device).clone().requires_grad_(True)
+        n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+        solver = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + n0 + n1, method="admm", device=device)
+        solver = dp.specialize(solver, method="unroll", device=device, max_iter=K)
+        rhos, l0, l1 = (torch.tensor(t, requires_grad=True) for t in (r0, a0, a1))
+        xo = solver.solve(x0=T(b, device), rhos=rhos, lams={n0: l0, n1: l1})
+        loss = ((xo - T(gt, device)) ** 2).mean()
+        loss.backward()
+        r64, a64, b64 = (torch.tensor(t, dtype=torch.float64, requires_grad=True) for t in (r0, a0, a1))
+        bt64 = torch.from_numpy(b).double().requires_grad_(True)
+        x64, _, _ = admm_f64(bt64, psf, [("grad0", "norm1", 1.0), ("grad1", "norm1", 1.0)], r64, [a64, b64], K)
+        loss64 = ((x64 - torch.from_numpy(gt).double()) ** 2).mean()
+        loss64.backward()
+        tag = "x".join(str(v) for v in shape)
+        for name, got, ref, tol in (("x", xo, x64, 1e-5), ("g_rhos", rhos.grad, r64.grad, 1e-3), ("g_l0", l0.grad, a64.grad, 1e-3),
+                                    ("g_l1", l1.grad, b64.grad, 1e-3), ("g_b", bt.grad, bt64.grad, 1e-3)):
+            r = rel_l2(got.detach().cpu().double().numpy(), ref.detach().numpy())
+            record(f"unrolled {tag} {name} vs float64 autograd", r, tol)
+            assert r <= tol, (tag, name, r)
+        assert abs(float(loss) - float(loss64)) <= 1e-5 * float(loss64)
+
+
 def case_known_answers(device):
     """the reference's own exact tests, tests/problem/test_ml_problems.py:5-44"""
     g = load_golden("g13_known_answers")

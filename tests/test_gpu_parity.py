@@ -59,6 +59,10 @@ def test_other_plane_sizes():
     pc.case_other_plane_sizes(DEV)
 
 
+def test_unrolled_plane_sizes():
+    pc.case_unrolled_plane_sizes(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV)
 
