@@ -32,6 +32,8 @@ struct IterTerm {
 struct IterTerms {
   IterTerm t[DPX_MAX_TERMS];
   int n;
+  float dual;          // 1: ADMM.  0: half-quadratic splitting (DPX_TERM_NO_DUAL) -- the incoming duals count as zero and the right-hand side
+                       // sees v_i alone; applied as fma(dual, u, K x) / fma(-dual, u', v): the same instructions, and exact for dual = 1
   int emit_bf16;       // x_out / v_out / rhs_out are bf16 planes (the bf16 history of the unrolled forward pass) instead of fp32
   float* rhs_out;      // nullable: the next x-update's right-hand-side increment rho' sum K_i^T (v_i - u_i) as an image (the unrolled
                        // forward pass keeps it for the backward pass); like x_out / v_out an emit store, never counted in the waits
@@ -170,10 +172,10 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
             const float xr = (t == T - 1) ? nx_wrap : nx_same;
             kx = make_float2(xc[m].y - xc[m].x, xr - xc[m].y);
           }
-          const float dx = kx.x + uu.x, dy = kx.y + uu.y;
+          const float dx = fmaf(TT.dual, uu.x, kx.x), dy = fmaf(TT.dual, uu.y, kx.y);
           const float vx = prox1(tm.prox, dx, lam), vy = prox1(tm.prox, dy, lam);
           const float ux = dx - vx, uy = dy - vy;
-          w[m] = make_float2(vx - ux, vy - uy);
+          w[m] = make_float2(fmaf(-TT.dual, ux, vx), fmaf(-TT.dual, uy, vy));
           if (z_own) {
             ((float2*)(tm.u_out + plane_px + (size_t)hz * (2 * M)))[t + m * T] = make_float2(ux, uy);
             if (emit_v) dpx_emit_pair(tm.v_out, TT.emit_bf16, (plane_px + (size_t)hz * (2 * M)) / 2 + t + m * T, make_float2(vx, vy));
@@ -457,6 +459,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
         dpx_wait_vm<D + 1>();
       }
       float2 ureg[NT][V];
+      const float dualf = TT.dual;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -474,17 +477,17 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
         float2 d[V];
         if (tm.linop == DPX_LIN_IDENTITY) {
 #pragma unroll
-          for (int m = 0; m < V; ++m) d[m] = cadd(xprev[m], ureg[n][m]);
+          for (int m = 0; m < V; ++m) d[m] = make_float2(fmaf(dualf, ureg[n][m].x, xprev[m].x), fmaf(dualf, ureg[n][m].y, xprev[m].y));
         } else if (tm.linop == DPX_LIN_GRAD_H) {
 #pragma unroll
-          for (int m = 0; m < V; ++m) d[m] = cadd(csub(xa[m], xprev[m]), ureg[n][m]);
+          for (int m = 0; m < V; ++m) d[m] = make_float2(fmaf(dualf, ureg[n][m].x, xa[m].x - xprev[m].x), fmaf(dualf, ureg[n][m].y, xa[m].y - xprev[m].y));
         } else {                                        // grad_W: x[w+1] - x[w]; pixel 2n+2 is the neighbour lane's .x
 #pragma unroll
           for (int m = 0; m < V; ++m) {
             const float nx_same = __shfl(xprev[m].x, lbase | ((t + 1) & (T - 1)));
             const float nx_wrap = __shfl(xprev[(m + 1) % V].x, lbase);
             const float xr = (t == T - 1) ? nx_wrap : nx_same;
-            d[m] = make_float2(xprev[m].y - xprev[m].x + ureg[n][m].x, xr - xprev[m].y + ureg[n][m].y);
+            d[m] = make_float2(fmaf(dualf, ureg[n][m].x, xprev[m].y - xprev[m].x), fmaf(dualf, ureg[n][m].y, xr - xprev[m].y));
           }
         }
         float2 v[V];
@@ -502,7 +505,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
 #pragma unroll
         for (int m = 0; m < V; ++m) {
           const float2 un = csub(d[m], v[m]);
-          w[m] = csub(v[m], un);
+          w[m] = make_float2(fmaf(-dualf, un.x, v[m].x), fmaf(-dualf, un.y, v[m].y));
           d[m] = un;
         }
         if (own) {
@@ -676,7 +679,9 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   TT.n = nterms;
   TT.rhs_out = rho_next ? rhs_out : nullptr;
   TT.emit_bf16 = emit_bf16;
+  TT.dual = (nterms > 0 && (terms[0].reserved & DPX_TERM_NO_DUAL)) ? 0.f : 1.f;
   for (int i = 0; i < nterms; ++i) {
+    DPX_REQUIRE(!(terms[i].reserved & DPX_TERM_NO_DUAL) == (TT.dual != 0.f), "dpx_admm_iter_rows: DPX_TERM_NO_DUAL must be set on every term or on none");
     DPX_REQUIRE(terms[i].u && (terms[i].u_out) && (!emit_v || terms[i].v), "dpx_admm_iter_rows: term %d lacks u / u_out / v", i);
     DPX_REQUIRE(terms[i].u != terms[i].u_out, "dpx_admm_iter_rows: u must be double-buffered (u_out != u)");
     TT.t[i] = IterTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].u, terms[i].u_out, terms[i].v};

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("DPX_LIB") or os.path.join(os.path.dirname(_HERE), "li
 
 PROX_NORM1, PROX_NONNEG, PROX_SUMSQ, PROX_EXTERNAL = 0, 1, 2, 3
 LIN_IDENTITY, LIN_GRAD_H, LIN_GRAD_W = 0, 1, 2
+TERM_NO_DUAL = 1          # dpx_term.reserved flag (include/dpx.h)
 MAX_TERMS = 4
 
 

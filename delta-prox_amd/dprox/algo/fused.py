@@ -313,9 +313,12 @@ class FusedADMM:
                              lam={k: val[..., it] for k, val in lams.items()})
             s.Kall.update_vars([x])
             return x, v, [ops.lincomb([(-1.0, t)]) for t in u]
-        if dual and not ext and n > 0 and ops.iter_supported(H, W, terms, n):
+        if not ext and n > 0 and ops.iter_supported(H, W, terms, n):
+            if not dual:                                         # half-quadratic splitting: the same two kernels with the duals counted as zero
+                for i in range(n):
+                    terms[i].reserved = be.TERM_NO_DUAL
             return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
-                                        rhos, lams, pbar, callback)
+                                        rhos, lams, pbar, callback, dual)
 
         # one FFDNet prior, everything else closed-form: the whole iteration is ONE C call (dpx_admm_pnp_iter)
         one_call = (dual and len(ext) == 1 and isinstance(psi[ext[0]].denoiser, (FFDNetColorDenoiser, FFDNetDenoiser))
@@ -464,17 +467,22 @@ class FusedADMM:
             tot = val if tot is None else tot + val
         return (-tot).expand_as(x0)
 
-    def _run_two_kernel(self, shape, dev, T, terms, n, v, u, x, rhs, FK, diag, rho_tab, lam_tab, rhos, lams, pbar, callback):
-        """power-of-two planes: cols -> rows, two kernels per iteration; x / v only leave the chip on request"""
+    def _run_two_kernel(self, shape, dev, T, terms, n, v, u, x, rhs, FK, diag, rho_tab, lam_tab, rhos, lams, pbar, callback, dual=True):
+        """power-of-two planes: cols -> rows, two kernels per iteration; x / v only leave the chip on request.
+        dual=False (half-quadratic splitting): u holds one shared all-zero buffer per term; the kernels' dual output goes to one
+        shared scratch buffer and is ignored when it comes back as input (DPX_TERM_NO_DUAL)"""
         s = self.solver
         B, C, H, W = shape
         t0, c0, t1, c1 = diag
         dd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
         SA, SB = ops.spectrum_buffer(B * C, H, W, dev), ops.spectrum_buffer(B * C, H, W, dev)
-        u_cur, u_nxt = list(u), [torch.empty_like(t) for t in u]
+        if dual:
+            u_cur, u_nxt = list(u), [torch.empty_like(t) for t in u]
+        else:
+            u_cur, u_nxt = list(u), [torch.zeros_like(u[0])] * n
         var = s.Kall.variables[0]
         if T == 0:
-            return var.value, v, u
+            return (var.value, v, u) if dual else (var.value, v)
         # seed: row transform of the first right-hand-side increment rho_0 * sum K_i^T (v_i - u_i)
         for i in range(n):
             terms[i].lam = lam_tab[i][0].data_ptr()
@@ -499,9 +507,9 @@ class FusedADMM:
                     var.value = x
                 if callback is not None:
                     s._notify_all_op_current_step(it)
-                    callback(iter=it, state=(x, v, u_cur), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+                    callback(iter=it, state=(x, v, u_cur) if dual else (x, v), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
         s.Kall.update_vars([x])
-        return x, v, u_cur
+        return (x, v, u_cur) if dual else (x, v)
 
 
 def ls_eps(ls):

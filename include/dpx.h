@@ -256,13 +256,17 @@ typedef struct dpx_term {
   int32_t linop;    /* DPX_LIN_* */
   int32_t prox;     /* DPX_PROX_* */
   float alpha;      /* lam multiplier (`alpha * fn`, proxfn/base.py:78-82) */
-  int32_t reserved;
+  int32_t reserved; /* flags: DPX_TERM_NO_DUAL (dpx_admm_iter_rows / dpx_admm_run only; 0 elsewhere) */
   const float* lam; /* device [B] */
   float* v;         /* state v_i [B,C,H,W] */
   float* u;         /* state u_i [B,C,H,W] */
   float* u_out;     /* dpx_admm_iter_rows only: updated u_i (double-buffered, must differ from u) */
 } dpx_term;
 #define DPX_MAX_TERMS 4
+/* half-quadratic splitting on the two-kernel iteration (algo/hqs.py:4-20 = the ADMM iteration with the duals pinned to zero): the
+ * contents of u are ignored (finite values required: start from zeros) and the next right-hand side is rho sum_i K_i^T v_i;
+ * u / u_out are still read / written (scratch).  Set on every term of the call or on none.                                      */
+#define DPX_TERM_NO_DUAL 1
 
 /* rhs = ktb + sum_i rho_b * K_i^T (v_i - u_i)   -- proxfn/sum_square.py:126-135 with
  * b_i = v_i - u_i from algo/admm.py:51.  ktb = sum over Omega of K^T offset (constant per solve). */

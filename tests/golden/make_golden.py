@@ -1071,10 +1071,25 @@ def g35_h768():
     save("g35_h768", **out)
 
 
+def g36_hqs_pow2():
+    """Half-quadratic splitting (algo/hqs.py:4-20) on a power-of-two plane, where the backend runs it on the two-kernel ADMM iteration
+    with the duals counted as zero: 1 x 3 x 256 x 256, TV + nonneg, 6 iterations, decaying rho; full state (x, v_i)."""
+    gt, b, psf = synthetic.deconv_case(1, 3, 256, 256, seed=3601)
+    x = dp.Variable()
+    fns = dp.sum_squares(dp.conv(x, psf) - T(b)) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
+    rhos = torch.linspace(0.4, 0.2, 6)
+    st = dp.Problem(fns).solve(method="hqs", device="cpu", x0=T(b), rhos=rhos, lams=0.01, max_iter=6, return_full_states=True)
+    out = {"seed": 3601, "rhos": rhos}
+    _pack(out, "x", st[0], 4)
+    for i in range(3):
+        _pack(out, f"v{i}", st[1][i], 8)
+    save("g36_hqs_pow2", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
                g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
-               g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5, g34_pgd_pow2, g35_h768):
+               g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

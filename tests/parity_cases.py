@@ -1110,6 +1110,35 @@ def case_other_algorithms(device):
             assert_close(out2.cpu(), g[method], TOL, f"{method} (op by op)")
 
 
+def case_hqs_pow2(device):
+    """G36: half-quadratic splitting on a power-of-two plane = the two-kernel ADMM iteration with DPX_TERM_NO_DUAL (duals counted as
+    zero, right-hand side rho sum K_i^T v_i) against the reference's state, and against the op-by-op iteration"""
+    import synthetic
+    from dprox import _ops as ops
+    g = load_golden("g36_hqs_pow2")
+    gt, b0, psf = synthetic.deconv_case(1, 3, 256, 256, seed=int(g["seed"]))
+    b = T(b0, device)
+    x = dp.Variable()
+    fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
+    prob = dp.Problem(fns)
+    rhos = torch.from_numpy(g["rhos"])
+    calls = []
+    real = ops.admm_run
+    ops.admm_run = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        xs, vs = prob.solve(method="hqs", device=device, x0=b, rhos=rhos, lams=0.01, max_iter=6, return_full_states=True)
+    finally:
+        ops.admm_run = real
+    assert calls and prob.solver.last_path == "fused", "half-quadratic splitting did not run on the two-kernel iteration"
+    _check_packed(g, "x", xs, 4, TOL, what="hqs pow2 ")
+    for i in range(3):
+        _check_packed(g, f"v{i}", vs[i], 8, TOL, scale_key="x", what="hqs pow2 ", scale_sub=2)
+    prob.solver.use_fused = False
+    out2 = prob.solver.solve(x0=b, rhos=rhos, lams=0.01, max_iter=6)
+    assert prob.solver.last_path == "generic"
+    assert_close(xs.cpu(), out2.cpu(), TOL, "hqs pow2: two-kernel vs op by op")
+
+
 def case_tiny_shapes(device):
     """degenerate planes against the oracle: 2x3, 3x3, 17x2 (every stage at its smallest size, prime lengths), and the
     reference's error for an axis shorter than the gradient stencil (utils/psf2otf.py:46-54 raises there too)"""

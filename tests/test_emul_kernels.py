@@ -54,6 +54,10 @@ def test_other_plane_sizes():
     pc.case_other_plane_sizes(DEV, sizes=((384, 256), (256, 768)), channels=1)
 
 
+def test_hqs_two_kernel():
+    pc.case_hqs_pow2(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV, tiny=True)
 

@@ -63,6 +63,10 @@ def test_unrolled_plane_sizes():
     pc.case_unrolled_plane_sizes(DEV)
 
 
+def test_hqs_two_kernel():
+    pc.case_hqs_pow2(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV)
 
