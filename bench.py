@@ -149,6 +149,27 @@ def extra_configs(dp, synthetic, device):
                       "psnr_db": [psnr(bt.cpu(), torch.from_numpy(gt)), psnr(o.cpu(), torch.from_numpy(gt))],
                       "roofline": {"bound": "hbm", "bytes_per_iter": 36.0 * 65536, "frac": 20 / dt * 36.0 * 65536 / HBM_PEAK,
                                    "note": "2.4 MB per iteration is cache resident: launch-latency-bound, reported only"}}
+    # ---- the same data term on the other fused solvers / plane sizes (not BASELINE configurations; steady-state ms per iteration from
+    #      the difference between a 10- and a 40-iteration solve)
+    def per_iter(solver, x0, **kw):
+        a, _ = _timed(lambda: solver.solve(x0=x0, max_iter=10, **kw), 2)
+        c, _ = _timed(lambda: solver.solve(x0=x0, max_iter=40, **kw), 2)
+        return (c - a) / 30
+    other = {}
+    for tag, shape, method in (("hqs_8x3x1024x1024", (B, C, H, W), "hqs"), ("pgd_8x3x1024x1024", (B, C, H, W), "pgd"),
+                               ("admm_8x3x768x1024", (B, C, 768, 1024), "admm"), ("admm_8x3x768x768", (B, C, 768, 768), "admm")):
+        gto, bo, psfo = synthetic.deconv_case(*shape, seed=2023)
+        bo, x = torch.from_numpy(bo).to(device), dp.Variable()
+        reg = dp.norm1(x) if method == "pgd" else dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
+        s = dp.compile(dp.sum_squares(dp.conv(x, psfo) - bo) + reg, method=method, device=device)
+        dt = per_iter(s, bo, rhos=0.8 if method == "pgd" else 0.1, lams=0.005)
+        npx = float(np.prod(shape))
+        other[tag] = {"ms_per_iter": dt * 1e3, "it_per_s": 1 / dt, "ps_per_pixel": dt * 1e12 / npx}
+        del s, bo
+    other["note"] = ("hqs: the two-kernel ADMM iteration with DPX_TERM_NO_DUAL; pgd: dpx_pgd_run (2 launches per iteration, 28 B per pixel); "
+                     "768 x 1024 (the reference's example image): column length 3 x 256 on the register-radix path (fft_reg_x3), two-kernel "
+                     "iteration; 768 x 768: staged kernels (5 launches, 64 B per pixel)")
+    out["other_paths"] = other
     # ---- config 3: config 2's data term + deep_prior(FFDNet-colour, seeded weights), 30 iterations
     rng = np.random.RandomState(2023)
     gt3 = torch.from_numpy(synthetic.synth(rng, B, C, H, W)).to(device)
