@@ -12,7 +12,7 @@ done
 wait
 $CXX -shared -fsanitize=address -shared-libasan -o "$OUT/libdpx_emul_asan.so" "$OUT"/*.o
 RT=$(dirname "$($CXX -print-file-name=libclang_rt.asan-x86_64.so)")/libclang_rt.asan-x86_64.so
-CASES=${@:-conv2d linops config1 small pow2 csmri sisr doe grads cg ffdnet ffbwd ladmm other bf16hist lsolve unet ffmodes}
+CASES=${@:-conv2d linops config1 small pow2 csmri sisr doe grads cg ffdnet ffbwd ladmm other bf16hist lsolve unet ffmodes pgd h768 sizes hqs}
 for c in $CASES; do
   LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:handle_segv=0 DPX_ASAN_LIB="$OUT/libdpx_emul_asan.so" \
     python "$HERE/run_cases.py" $c 2>&1 | grep -E "^OK|ERROR: AddressSanitizer|SUMMARY|^\s+#[0-9] " | head -12

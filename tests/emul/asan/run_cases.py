@@ -24,6 +24,10 @@ cases = {
  "other": lambda: pc.case_other_algorithms("cpu"),            # dpx_split_rhs / dpx_pc_dual
  "bf16hist": lambda: pc.case_unrolled_grads_bf16("cpu"),
  "lsolve": lambda: pc.case_linear_solve_grad("cpu"),
+ "pgd": lambda: pc.case_pgd_pow2("cpu", tiny=True),                                                      # dpx_pgd_run
+ "h768": lambda: pc.case_h768("cpu", tiny=True),                                                          # fft_reg_x3 columns
+ "sizes": lambda: pc.case_other_plane_sizes("cpu", sizes=((384, 256), (256, 768)), channels=1),          # ... and rows (RowMap)
+ "hqs": lambda: pc.case_hqs_pow2("cpu"),                                                                  # DPX_TERM_NO_DUAL
 }
 def unet_layers():
     import test_emul_kernels as t
