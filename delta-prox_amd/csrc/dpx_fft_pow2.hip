@@ -170,6 +170,70 @@ __global__ void __launch_bounds__(256) k_rows_c2r_p2(const float2* __restrict__ 
   if (live) RM::store_pairs((float2*)(y + (size_t)rr * (2 * M)), t, [&](int m) { return make_float2(v[m].x * scale, v[m].y * scale); });
 }
 
+// The seed of the two-kernel iteration in one pass: the row transform of  rho_b sum_i K_i^T (v_i - u_i)  (dpx_admm_rhs followed by
+// dpx_rfft_rows: 112 + 60 us at 8x3x1024^2, and the right-hand side image written and read back in between).  One wave per image
+// row; the stencils' neighbours come from the adjacent lane (grad_W) / from the row above, read again (grad_H).
+struct SeedTerms {
+  const float* v[DPX_MAX_TERMS];
+  const float* u[DPX_MAX_TERMS];
+  int linop[DPX_MAX_TERMS];
+  int n;
+};
+template <int M, int T>
+__global__ void __launch_bounds__(256) k_seed_rows(SeedTerms S_, const float* __restrict__ rho, float2* __restrict__ spec, float2* __restrict__ side,
+                                                    int nrows, int H, int C, const float2* __restrict__ twW) {
+  using RM = RowMap<M, T>;
+  static_assert(!RM::R3, "power-of-two rows only (the two-kernel iteration's widths)");
+  constexpr int V = M / T, SPB = 256 / T, S = RM::LDS_SLOTS;
+  __shared__ float2 lds[SPB * S];
+  const int tid = threadIdx.x, seq = tid / T, t = tid % T;
+  const int row = blockIdx.x * SPB + seq;
+  const bool live = row < nrows;
+  const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H;
+  const int lane = tid & 63, lbase = lane & ~(T - 1);
+  const size_t here = (size_t)rr * M, above = ((size_t)pl * H + (hh == 0 ? H - 1 : hh - 1)) * M;      // float2 offsets of the two rows
+  float2 acc[V];
+#pragma unroll
+  for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f);
+  for (int i = 0; i < S_.n; ++i) {
+    const float2* vr = (const float2*)S_.v[i];
+    const float2* ur = (const float2*)S_.u[i];
+    float2 y[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) y[m] = csub(vr[here + t + m * T], ur[here + t + m * T]);
+    if (S_.linop[i] == DPX_LIN_IDENTITY) {
+#pragma unroll
+      for (int m = 0; m < V; ++m) acc[m] = cadd(acc[m], y[m]);
+    } else if (S_.linop[i] == DPX_LIN_GRAD_W) {           // adjoint: y[w-1] - y[w]; pixel 2n-1 is the left lane's .y
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float l_same = __shfl(y[m].y, lbase | ((t + T - 1) & (T - 1)));
+        const float l_wrap = __shfl(y[(m + V - 1) % V].y, lbase | (T - 1));
+        const float left = (t == 0) ? l_wrap : l_same;
+        acc[m] = make_float2(acc[m].x + (left - y[m].x), acc[m].y + (y[m].x - y[m].y));
+      }
+    } else {                                              // grad_H adjoint: y[h-1] - y[h]
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 yu = csub(vr[above + t + m * T], ur[above + t + m * T]);
+        acc[m] = cadd(acc[m], csub(yu, y[m]));
+      }
+    }
+  }
+  const float r = rho[pl / C];
+  float2 v[V], X[V];
+#pragma unroll
+  for (int m = 0; m < V; ++m) v[m] = cscale(acc[m], r);
+  RM::template fft<-1>(v, lds + seq * S, t, twW);
+  const float nyq = RM::untangle(v, X, t, lane, twW);
+  float2* out = spec + (size_t)pl * H * M + (size_t)hh * SPEC_TILE + (t % SPEC_TILE) + (size_t)(t / SPEC_TILE) * H * SPEC_TILE;
+  if (live && t == 0) side[row] = make_float2(nyq, 0.f);
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < V; ++m) out[RM::koff(m, H)] = X[m];
+  }
+}
+
 #ifndef DPX_PGD_LD_NT
 #define DPX_PGD_LD_NT 0
 #endif
@@ -675,6 +739,30 @@ static void cols_dispatch(int H, const float2* spec, float2* spec_out, const Spe
     case 2048: launch_cols<2048, 128, 4, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;      // (4 columns: 98 KB of LDS per workgroup)
     default: launch_cols<1024, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
   }
+}
+
+template <int M, int T>
+static void launch_seed(const SeedTerms& S_, const float* rho, float2* spec, int nrows, int H, int C, const float2* twW, hipStream_t s) {
+  constexpr int SPB = 256 / T;
+  DPX_LAUNCH("k_seed_rows", (k_seed_rows<M, T>), dim3((nrows + SPB - 1) / SPB), dim3(256), 0, s, S_, rho, spec, spec + (size_t)nrows * M, nrows, H, C,
+             twW);
+}
+int seed_rows_pow2(const dpx_term* terms, int nterms, const float* rho, float2* spec, int B, int C, int H, int W, const void* table,
+                   hipStream_t stream) {
+  SeedTerms S_{};
+  S_.n = nterms;
+  for (int i = 0; i < nterms; ++i) {
+    S_.v[i] = terms[i].v;
+    S_.u[i] = terms[i].u;
+    S_.linop[i] = terms[i].linop;
+  }
+  const int nrows = B * C * H;
+  switch (W) {
+    case 256: launch_seed<128, 16>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;
+    case 512: launch_seed<256, 32>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;
+    default: launch_seed<512, 64>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;
+  }
+  return launch_status("dpx_admm_seed_rows");
 }
 
 int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table,

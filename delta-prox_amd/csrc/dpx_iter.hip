@@ -606,6 +606,8 @@ size_t pow2_spec_elems(int P, int H, int W);
 int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table,
                     hipStream_t stream);
 int rows_r2c_pow2(const float* x, float2* spec, int P, int H, int W, const void* table, hipStream_t stream);
+int seed_rows_pow2(const dpx_term* terms, int nterms, const float* rho, float2* spec, int B, int C, int H, int W, const void* table,
+                   hipStream_t stream);
 
 }  // namespace dpx
 
@@ -648,6 +650,15 @@ extern "C" int dpx_rfft_rows(const float* x, void* spec, int B, int C, int H, in
   DPX_REQUIRE(x && spec && table, "dpx_rfft_rows: null pointer");
   DPX_REQUIRE(pow2_path_available(H, W), "dpx_rfft_rows: only power-of-two planes use the two-kernel iteration");
   return rows_r2c_pow2(x, (float2*)spec, B * C, H, W, table, (hipStream_t)stream);
+}
+
+// spec = row transform of rho_b sum_i K_i^T (v_i - u_i): dpx_admm_rhs (ktb = NULL) + dpx_rfft_rows in one pass (the seed of dpx_admm_run)
+extern "C" int dpx_admm_seed_rows(void* spec, const float* rho, const dpx_term* terms, int nterms, int B, int C, int H, int W, const void* table,
+                                  dpx_stream_t stream) {
+  DPX_REQUIRE(spec && rho && terms && table, "dpx_admm_seed_rows: null pointer");
+  DPX_REQUIRE(dpx_admm_iter_supported(H, W, terms, nterms), "dpx_admm_seed_rows: unsupported problem (plane %dx%d, %d terms)", H, W, nterms);
+  for (int i = 0; i < nterms; ++i) DPX_REQUIRE(terms[i].v && terms[i].u, "dpx_admm_seed_rows: term %d lacks v / u", i);
+  return seed_rows_pow2(terms, nterms, rho, (float2*)spec, B, C, H, W, table, (hipStream_t)stream);
 }
 
 extern "C" int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const void* spec_add, const void* dd, const float* rho,

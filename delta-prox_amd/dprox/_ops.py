@@ -579,6 +579,13 @@ def iter_rows(spec_in, spec_out, term_arr, nterms, rho_next, x_out, emit_v, shap
                   int(bool(emit_v)), B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
 
 
+def admm_seed_rows(spec, rho, term_arr, nterms, shape, device):
+    """spec = row transform of rho_b sum_i K_i^T (v_i - u_i): the seed of admm_run in one pass"""
+    B, C, H, W = shape
+    be.lib().call("dpx_admm_seed_rows", ptr(spec), ptr(rho), term_arr, nterms, B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
+    return spec
+
+
 def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, eps, it0, n_iters, total, x_out, emit_last,
              shape, device):
     """n_iters fused iterations on the C side; returns the u-buffer parity (0: terms[i].u current, 1: u_out)"""

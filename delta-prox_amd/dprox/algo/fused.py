@@ -260,7 +260,7 @@ class FusedADMM:
             early = ops.make_terms([dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=None, v=v[i], u=u[i])
                                     for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))])
             if ops.iter_supported(H, W, early, len(psi)):
-                seeded = ops.admm_rhs(torch.empty_like(x0), None, rho_tab[0], early, len(psi))
+                seeded = ops.admm_seed_rows(ops.spectrum_buffer(B * C, H, W, dev), rho_tab[0], early, len(psi), x0.shape, dev)
         lam_tab = []
         for fn in psi:
             lt = schedule_table(lams[fn], T, B, dev)
@@ -293,7 +293,7 @@ class FusedADMM:
         v = [t.contiguous() for t in v]
         u = [t.contiguous() for t in u]
         x = torch.empty_like(x0)
-        rhs = seeded if seeded is not None else torch.empty_like(x0)
+        rhs = None if seeded is not None else torch.empty_like(x0)        # (the two-kernel iteration never forms the right-hand side as an image)
         specs = [dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=lam_tab[i][0], v=v[i], u=u[i])
                  for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))]
         terms = ops.make_terms(specs)
@@ -330,7 +330,7 @@ class FusedADMM:
                 for i in range(n):
                     terms[i].reserved = be.TERM_NO_DUAL
             return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
-                                        rhos, lams, pbar, callback, dual, seeded is not None)
+                                        rhos, lams, pbar, callback, dual, seeded)
 
         # one FFDNet prior, everything else closed-form: the whole iteration is ONE C call (dpx_admm_pnp_iter)
         one_call = (dual and len(ext) == 1 and isinstance(psi[ext[0]].denoiser, (FFDNetColorDenoiser, FFDNetDenoiser))
@@ -479,7 +479,7 @@ class FusedADMM:
             tot = val if tot is None else tot + val
         return (-tot).expand_as(x0)
 
-    def _run_two_kernel(self, shape, dev, T, terms, n, v, u, x, rhs, FK, diag, rho_tab, lam_tab, rhos, lams, pbar, callback, dual=True, seeded=False):
+    def _run_two_kernel(self, shape, dev, T, terms, n, v, u, x, rhs, FK, diag, rho_tab, lam_tab, rhos, lams, pbar, callback, dual=True, seeded=None):
         """power-of-two planes: cols -> rows, two kernels per iteration; x / v only leave the chip on request.
         dual=False (half-quadratic splitting): u holds one shared all-zero buffer per term; the kernels' dual output goes to one
         shared scratch buffer and is ignored when it comes back as input (DPX_TERM_NO_DUAL)"""
@@ -487,7 +487,8 @@ class FusedADMM:
         B, C, H, W = shape
         t0, c0, t1, c1 = diag
         dd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
-        SA, SB = ops.spectrum_buffer(B * C, H, W, dev), ops.spectrum_buffer(B * C, H, W, dev)
+        SA = seeded if seeded is not None else ops.spectrum_buffer(B * C, H, W, dev)     # (run() launches the seed pass first)
+        SB = ops.spectrum_buffer(B * C, H, W, dev)
         if dual:
             u_cur, u_nxt = list(u), [torch.empty_like(t) for t in u]
         else:
@@ -498,9 +499,8 @@ class FusedADMM:
         # seed: row transform of the first right-hand-side increment rho_0 * sum K_i^T (v_i - u_i)
         for i in range(n):
             terms[i].lam = lam_tab[i][0].data_ptr()
-        if not seeded:                                               # (run() launches it in front of its host-side preparation)
-            ops.admm_rhs(rhs, None, rho_tab[0], terms, n)
-        ops.rfft_rows(rhs, SA)
+        if seeded is None:
+            ops.admm_seed_rows(SA, rho_tab[0], terms, n, shape, dev)
         for i in range(n):
             terms[i].u, terms[i].u_out, terms[i].v = u_cur[i].data_ptr(), u_nxt[i].data_ptr(), v[i].data_ptr()
         eps = ls_eps(s.least_square)

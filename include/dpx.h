@@ -358,6 +358,10 @@ int dpx_admm_unrolled_backward_bf16(const void* hist_bf16, const float* gx, cons
  * transform of the first right-hand side (dpx_admm_rhs).  Spectrum buffers: dpx_spectrum_bytes / 2 each.            */
 int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms);
 int dpx_rfft_rows(const float* x, void* spec, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
+/* the seed in one pass: spec = row transform of rho_b sum_i K_i^T (v_i - u_i)  (= dpx_admm_rhs with ktb = NULL, then dpx_rfft_rows;
+ * algo/admm.py:51 + proxfn/sum_square.py:126-135 for the first x-update of a solve); same support as dpx_admm_iter_rows */
+int dpx_admm_seed_rows(void* spec, const float* rho, const dpx_term* terms, int nterms, int B, int C, int H, int W, const void* table,
+                       dpx_stream_t stream);
 int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const void* spec_add, const void* dd, const float* rho, float eps,
                        int B, int C, int H, int W, const void* table, dpx_stream_t stream);
 int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next,
