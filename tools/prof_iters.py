@@ -1,3 +1,5 @@
+"""Host-side cost of one 20-iteration solve of bench.py's problem: issue time vs GPU time, when the first kernel is launched,
+and a cProfile of Algorithm.iters (GPU only)."""
 import os, sys, time, cProfile, pstats
 ROOT = "/root/repo"
 sys.path[:0] = [ROOT, os.path.join(ROOT, "delta-prox_amd")]
@@ -28,7 +30,7 @@ pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
 # ---- where the host time goes before the first kernel of the solve is launched
 from dprox import _ops as ops
 marks = {}
-for name in ("admm_rhs", "rfft_rows", "admm_run"):
+for name in ("admm_seed_rows", "admm_run"):
     real = getattr(ops, name)
     def wrap(*a, _r=real, _n=name, **k):
         marks.setdefault(_n + "_in", time.perf_counter())
@@ -47,8 +49,6 @@ for rep in range(3):
     t2 = time.perf_counter()
     print("us since t0:", {k: round(1e6 * (v - t0)) for k, v in marks.items()}, "iters returns", round(1e6 * (t1 - t0)), "gpu done", round(1e6 * (t2 - t0)))
 
-for name in ("admm_rhs", "rfft_rows", "admm_run"):
-    pass
 state = solver.initialize(b)
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
