@@ -334,6 +334,9 @@ __device__ __forceinline__ float2 spec_op_p2(float2 z, const SpecArgs& A, unsign
 #ifndef DPX_COLS_TBL_NT
 #define DPX_COLS_TBL_NT 0
 #endif
+#ifndef DPX_COLS_TW_GLOBAL
+#define DPX_COLS_TW_GLOBAL 1
+#endif
 constexpr int COLS_LD_NT = DPX_COLS_LD_NT, COLS_ADD_NT = DPX_COLS_ADD_NT, COLS_ST = DPX_COLS_ST;   // cache policy (dpx_common.h)
 #ifndef DPX_COLS_BATCH_INNER
 #define DPX_COLS_BATCH_INNER 1
@@ -385,7 +388,10 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   const char* pin = (const char*)(spec_in + ubase);
   char* pout = (char*)(spec_out + ubase);
   float2* lds = smem_p2 + c * S;
-  float2* twl = smem_p2 + COLS * S;                   // the H column twiddles, shared by the workgroup
+  // the H column twiddles, shared by the workgroup: an LDS copy -- except for H = 2048, where the copy's 16 KB would leave room for
+  // one 4-column workgroup per CU instead of two (81920 B each without it): there they are read from the table (L1 / L2 resident)
+  constexpr bool TWG = DPX_COLS_TW_GLOBAL && (H >= 2048);
+  const float2* twl = TWG ? twH : smem_p2 + COLS * S;
   float2 v[V];
 #pragma unroll
   for (int m = 0; m < V; ++m) v[m] = ld_stream<COLS_LD_NT>((const float2*)(pin + (off0 + step * hrow(m)) * 8u));
@@ -395,7 +401,9 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
 #pragma unroll
     for (int m = 0; m < V; ++m) v[m].y = sidef[2 * hrow(m)];
   }
-  for (int i = tid; i < H; i += T * COLS) twl[i] = twH[i];
+  if constexpr (!TWG) {
+    for (int i = tid; i < H; i += T * COLS) smem_p2[COLS * S + i] = twH[i];
+  }
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const char* add = (OP == OP_SOLVE && A.add) ? (const char*)(A.add + ubase) : nullptr;
   // (no barrier here: the twiddle copy is first read in the second pass, behind the first pass's barrier)
@@ -462,7 +470,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   // The partner bins live in other waves: one exchange through an LDS buffer of H bins -- the 8 (S - H) slots behind the table
   // stage + the launch's extra bytes behind the twiddles.   pack_split: zval(m) -> Z[t + m T] of this lane, consume(m, iB).
   constexpr int XSLACK = COLS * (S - H);
-  auto xslot = [&](int i) { return i < XSLACK ? smem_p2 + COLS * H + i : smem_p2 + COLS * S + H + (i - XSLACK); };
+  auto xslot = [&](int i) { return i < XSLACK ? smem_p2 + COLS * H + i : smem_p2 + COLS * S + (TWG ? 0 : H) + (i - XSLACK); };
   auto pack_split = [&](auto zval, auto consume) {
     DPX_LDS_BARRIER();                                // (no table stage on this path: every wave's last-pass reads are done)
     if (dc_lane) {
@@ -586,7 +594,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
 
 template <int H, int T, int COLS, int OP, int DBG = 0>
 #ifndef DPX_COLS_WPE
-#define DPX_COLS_WPE ((H % 3 == 0 || H >= 2048) ? 2 : (T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for (H = 768: 61 KB of LDS -> 2 workgroups of 4 waves per CU)
+#define DPX_COLS_WPE ((H % 3 == 0 || (H >= 2048 && !DPX_COLS_TW_GLOBAL)) ? 2 : (T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for (H = 768: 61 KB of LDS -> 2 workgroups of 4 waves per CU)
 #endif
 __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
                                                       int C, int Ws, int P, const float2* __restrict__ twH) {
@@ -697,7 +705,8 @@ static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A,
   constexpr int S0 = LdsSeq<H>::SLOTS;
   constexpr int S = S0 + ((36 - S0 % 32) % 32);
   // + the rest of the packed column's H-bin exchange buffer (DPX_COLS_PACK0): 80 KB per workgroup at H = 1024, still two per CU
-  const size_t sh = (size_t)(COLS * S + H + (DPX_COLS_PACK0 && H > COLS * (S - H) ? H - COLS * (S - H) : 0)) * sizeof(float2);
+  constexpr bool TWG = DPX_COLS_TW_GLOBAL && (H >= 2048);      // (cols_body: no LDS copy of the twiddles)
+  const size_t sh = (size_t)(COLS * S + (TWG ? 0 : H) + (DPX_COLS_PACK0 && H > COLS * (S - H) ? H - COLS * (S - H) : 0)) * sizeof(float2);
   static bool attr_done = false;
   if (!attr_done && sh > 48 * 1024) {
     hipFuncSetAttribute((const void*)k_cols_p2<H, T, COLS, OP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
