@@ -68,9 +68,10 @@ template <> struct Twid<float2> {
   __device__ __forceinline__ float2 get(long long idx) const { return t[idx]; }
 };
 template <> struct Twid<double2> {
-  const float2* t;   // unused
+  const double2* t;  // fp64 table exp(-2 pi i idx / len) (k_twiddle_table_f64), or NULL: evaluated on the fly
   int len;           // table length the indices refer to
   __device__ __forceinline__ double2 get(long long idx) const {
+    if (t) return t[idx];
     double s, c;
     sincospi(-2.0 * (double)idx / (double)len, &s, &c);
     return make_double2(c, s);
@@ -408,53 +409,116 @@ __global__ void k_cols(float2* __restrict__ spec, SpecArgs A, int C, int H, int 
 // rho * sum K_i^T (v_i - u_i) goes through them), which is what holds the iterates within 1e-5 of the
 // reference's although the x-update amplifies transform round-off by up to 1/min(denominator).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict__ spec, int W, int nrows, Plan1D plan) {
-  HIP_DYNAMIC_SHARED(double2, smem64)
-  const int Wh = W / 2 + 1, ld = W + 1;
-  double2* a = smem64;
-  double2* b = smem64 + ld;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int row = blockIdx.x;
-  if (row >= nrows) return;
-  const float* xr = x + (size_t)row * W;
-  for (int n = tid; n < W; n += nthr) a[n] = make_double2((double)xr[n], 0.0);
-  __syncthreads();
-  const Twid<double2> twd{nullptr, W};
-  const double2* z = fft_lds<-1, double2>(a, b, plan, twd, 1, 1, ld, tid, nthr);
-  for (int k = tid; k < Wh; k += nthr) spec[(size_t)row * Wh + k] = z[k];
+// The fp64 twiddles come from a table (k_twiddle_table_f64, once per call, in the workspace): evaluated on the fly, every
+// sincospi's argument reduction went through scratch memory (4.0 GB of scratch writes for a 100 MB image at 8x3x1024^2).
+// Intermediate fp64 half spectrum: COLUMN-TILE-MAJOR [P][ceil(Wh/CT)][H][CT] (Wh = W/2+1 columns, CT = 4 or 2): the row kernel
+// writes RPB adjacent rows x CT columns = one contiguous RPB * CT * 16-byte piece per tile, the column kernel reads its tile as
+// ONE linear block (the row-major intermediate cost it one 16-byte element per 8 KB stride: 16x the algorithmic traffic).
+__global__ void k_twiddle_table_f64(double2* tw, int n) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double s, c;
+  sincospi(-2.0 * (double)t / (double)n, &s, &c);
+  tw[t] = make_double2(c, s);
 }
 
-// columns of the unpacked fp64 half spectrum (Wh = W/2+1 columns) -> packed fp32 spectrum times the OTF
-__global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restrict__ out, const float2* __restrict__ otf,
-                               int conj_otf, int accumulate, int C, int H, int W, Plan1D plan, int side_layout, int P) {
+// rows: RPB image rows per workgroup; even W: length-W/2 complex transform of the (x[2n], x[2n+1]) pairs + real-input untangling
+template <bool EVEN>
+__global__ void k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict__ spec, int W, int nrows, int H, Plan1D plan,
+                               const double2* __restrict__ tw64, int rpb, int CT) {
   HIP_DYNAMIC_SHARED(double2, smem64)
-  const int Wh = W / 2 + 1, Ws = (W + 1) / 2, ld = H + 1;
-  const bool packed = (W % 2 == 0);
+  const int M = plan.n, ld = M + 1, Wh = W / 2 + 1, NTL = (Wh + CT - 1) / CT;
   double2* a = smem64;
-  double2* b = smem64 + 2 * ld;
+  double2* b = smem64 + rpb * ld;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int p = blockIdx.y, l = blockIdx.x;          // l in [0, Ws)
-  const int ch = p % C;
-  const int nseq = (packed && l == 0) ? 2 : 1;       // column 0 also carries the Nyquist column
-  const double2* base = spec + (size_t)p * H * Wh;
-  for (int i = tid; i < H * nseq; i += nthr) {
-    const int s = i / H, r = i - s * H;
-    a[s * ld + r] = base[(size_t)r * Wh + (s == 0 ? l : W / 2)];
+  const int row0 = blockIdx.x * rpb;
+  const int nseq = min(rpb, nrows - row0);
+  for (int i = tid; i < nseq * M; i += nthr) {
+    const int s = i / M, n = i - s * M;
+    const float* xr = x + (size_t)(row0 + s) * W;
+    if (EVEN) {
+      const float2 v = ((const float2*)xr)[n];
+      a[s * ld + n] = make_double2((double)v.x, (double)v.y);
+    } else {
+      a[s * ld + n] = make_double2((double)xr[n], 0.0);
+    }
   }
   __syncthreads();
-  const Twid<double2> twd{nullptr, H};
-  const double2* z = fft_lds<-1, double2>(a, b, plan, twd, 1, nseq, ld, tid, nthr);
+  const Twid<double2> twd{tw64, W};
+  const double2* z = fft_lds<-1, double2>(a, b, plan, twd, EVEN ? 2 : 1, nseq, ld, tid, nthr);
+  // (tile, row, column-in-tile) order: the rows of a workgroup are adjacent in every tile
+  for (int i = tid; i < NTL * nseq * CT; i += nthr) {
+    const int kk = i % CT, s = (i / CT) % nseq, kt = i / (CT * nseq);
+    const int k = kt * CT + kk;
+    if (k >= Wh) continue;
+    const double2* zs = z + s * ld;
+    double2 X;
+    if (!EVEN) {
+      X = zs[k];
+    } else if (k == 0) {
+      X = make_double2(zs[0].x + zs[0].y, 0.0);
+    } else if (k == M) {
+      X = make_double2(zs[0].x - zs[0].y, 0.0);
+    } else {
+      const double2 zk = zs[k], zm = make_double2(zs[M - k].x, -zs[M - k].y);
+      const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y));
+      const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y - zm.y));
+      const double2 o = make_double2(d.y, -d.x);                 // -i * d
+      X = gadd(e, gmul(o, tw64[k]));
+    }
+    const int row = row0 + s, p = row / H, h = row - p * H;
+    spec[(((size_t)p * NTL + kt) * H + h) * CT + kk] = X;
+  }
+}
+
+// columns of the fp64 half spectrum, CT per workgroup -> packed fp32 spectrum times the OTF.  Even W: the Nyquist column
+// (l = W/2) has to meet the DC column (packed layouts carry it as the imaginary part of column 0), so workgroup 0 takes it in its
+// last slot and the workgroup that would have held it takes column CT-1 instead.
+__global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restrict__ out, const float2* __restrict__ otf,
+                               int conj_otf, int accumulate, int C, int H, int W, Plan1D plan, int side_layout, int P,
+                               const double2* __restrict__ tw64, int CT) {
+  HIP_DYNAMIC_SHARED(double2, smem64)
+  const int Wh = W / 2 + 1, Ws = (W + 1) / 2, ld = H + 1, NTL = (Wh + CT - 1) / CT;
+  const bool packed = (W % 2 == 0);
+  double2* a = smem64;
+  double2* b = smem64 + CT * ld;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int p = blockIdx.y, lt = blockIdx.x;
+  const int ch = p % C;
+  const int nyq = W / 2, tn = packed ? nyq / CT : 0;
+  auto col_of = [&](int c) {                              // spectrum column of slot c of this workgroup (-1: none)
+    int l = lt * CT + c;
+    if (packed && tn != 0) {
+      if (lt == 0 && c == CT - 1) l = nyq;
+      else if (lt == tn && c == nyq % CT) l = CT - 1;
+    }
+    return l < Wh ? l : -1;
+  };
+  const double2* base = spec + (size_t)p * NTL * H * CT;
+  for (int i = tid; i < H * CT; i += nthr) {
+    const int c = i % CT, r = i / CT;
+    const int l = col_of(c);
+    a[c * ld + r] = l >= 0 ? base[((size_t)(l / CT) * H + r) * CT + (l % CT)] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  const Twid<double2> twd{tw64, H};
+  const double2* z = fft_lds<-1, double2>(a, b, plan, twd, 1, CT, ld, tid, nthr);
   const size_t tmain = (size_t)ch * H * Ws, tside = (size_t)C * H * Ws + (size_t)ch * H;
   float2* o = out + (size_t)p * H * Ws;
-  for (int k = tid; k < H; k += nthr) {
-    double2 v = z[k];
+  int nyq_slot = -1;                                        // the slot holding the Nyquist column, if this workgroup has the DC column
+  if (packed && lt == 0) nyq_slot = tn != 0 ? CT - 1 : nyq % CT;
+  for (int i = tid; i < H * CT; i += nthr) {
+    const int c = i % CT, k = i / CT;
+    const int l = col_of(c);
+    if (l < 0 || (packed && l == nyq)) continue;           // (the Nyquist column is consumed by the DC column's lanes)
+    double2 v = z[c * ld + k];
     if (otf) {
       const float2 t = otf[tmain + spec_main_index(side_layout, H, Ws, k, l)];
       const double tr = t.x, ti = conj_otf ? -(double)t.y : (double)t.y;
       v = make_double2(v.x * tr - v.y * ti, v.x * ti + v.y * tr);
     }
-    if (nseq == 2) {
-      double2 n = z[ld + k];
+    if (l == 0 && nyq_slot >= 0) {
+      double2 n = z[nyq_slot * ld + k];
       if (otf) {
         const float2 t = otf[tside + k];
         const double tr = t.x, ti = conj_otf ? -(double)t.y : (double)t.y;
@@ -755,24 +819,55 @@ extern "C" int dpx_fft_conv(const float* x, float* y, const void* otf, int conj_
   return spectral_apply(x, y, conj_otf ? OP_MULCONJ : OP_MUL, a, B, C, H, W, table, ws, (hipStream_t)stream);
 }
 
-extern "C" size_t dpx_data_spectrum_ws_bytes(int P, int H, int W) { return (size_t)P * H * (W / 2 + 1) * sizeof(double2); }
+// geometry of the fp64 data-spectrum pass: CT columns per column workgroup (LDS: two images of CT sequences of H fp64 points),
+// RPB rows per row workgroup; 0 = the plane does not fit the LDS-resident transform
+static int ds_ct(int H) { return (size_t)4 * 2 * (H + 1) * sizeof(double2) <= 160 * 1024 ? 4 : ((size_t)2 * 2 * (H + 1) * sizeof(double2) <= 160 * 1024 ? 2 : 0); }
+static int ds_rpb(int W) {
+  const int M = (W % 2 == 0) ? W / 2 : W;
+  for (int r = 4; r >= 1; r >>= 1)
+    if ((size_t)r * 2 * (M + 1) * sizeof(double2) <= 72 * 1024) return r;
+  return (size_t)2 * (M + 1) * sizeof(double2) <= 160 * 1024 ? 1 : 0;
+}
+static size_t ds_spec_elems(int P, int H, int W) {
+  const int CT = ds_ct(H) ? ds_ct(H) : 4, Wh = W / 2 + 1;
+  return (size_t)P * ((Wh + CT - 1) / CT) * H * CT;
+}
+// workspace: the tile-major fp64 half spectrum + the two fp64 twiddle tables
+extern "C" size_t dpx_data_spectrum_ws_bytes(int P, int H, int W) { return (ds_spec_elems(P, H, W) + (size_t)W + (size_t)H) * sizeof(double2); }
 
 extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, void* spec_out, int accumulate, int B, int C,
                                  int H, int W, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(b && spec_out && ws, "dpx_data_spectrum: null pointer");
   DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_data_spectrum: bad shape");
-  const int P = B * C, Ws = spec_cols(W);
-  const size_t shrow = (size_t)2 * (W + 1) * sizeof(double2), shcol = (size_t)4 * (H + 1) * sizeof(double2);
-  if (shrow > 160 * 1024 || shcol > 160 * 1024) {
+  const int P = B * C, Wh = W / 2 + 1;
+  const int CT = ds_ct(H), rpb = ds_rpb(W);
+  if (!CT || !rpb) {
     set_error("dpx_data_spectrum: plane %dx%d too large for the LDS-resident fp64 transform", H, W);
     return DPX_ERR_UNSUPPORTED;
   }
-  if (shrow > 48 * 1024) hipFuncSetAttribute((const void*)k_rows_r2c_f64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shrow);
+  const bool even = (W % 2 == 0);
+  const int M = even ? W / 2 : W;
+  const size_t shrow = (size_t)rpb * 2 * (M + 1) * sizeof(double2), shcol = (size_t)CT * 2 * (H + 1) * sizeof(double2);
+  hipStream_t s = (hipStream_t)stream;
+  double2* spec64 = (double2*)ws;
+  double2* twW = spec64 + ds_spec_elems(P, H, W);
+  double2* twH = twW + W;
+  DPX_LAUNCH("k_twiddle_table_f64", k_twiddle_table_f64, dim3((W + 255) / 256), dim3(256), 0, s, twW, W);
+  DPX_LAUNCH("k_twiddle_table_f64", k_twiddle_table_f64, dim3((H + 255) / 256), dim3(256), 0, s, twH, H);
+  const int nrows = P * H;
+  if (even) {
+    if (shrow > 48 * 1024) hipFuncSetAttribute((const void*)k_rows_r2c_f64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shrow);
+    DPX_LAUNCH("k_rows_r2c_f64", k_rows_r2c_f64<true>, dim3((nrows + rpb - 1) / rpb), dim3(256), shrow, s, b, spec64, W, nrows, H, make_plan(M),
+               (const double2*)twW, rpb, CT);
+  } else {
+    if (shrow > 48 * 1024) hipFuncSetAttribute((const void*)k_rows_r2c_f64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shrow);
+    DPX_LAUNCH("k_rows_r2c_f64", k_rows_r2c_f64<false>, dim3((nrows + rpb - 1) / rpb), dim3(256), shrow, s, b, spec64, W, nrows, H, make_plan(M),
+               (const double2*)twW, rpb, CT);
+  }
   if (shcol > 48 * 1024) hipFuncSetAttribute((const void*)k_cols_fwd_f64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
-  DPX_LAUNCH("k_rows_r2c_f64", k_rows_r2c_f64, dim3(P * H), dim3(256), shrow, (hipStream_t)stream, b, (double2*)ws, W, P * H, make_plan(W));
-  DPX_LAUNCH("k_cols_fwd_f64", k_cols_fwd_f64, dim3(Ws, P), dim3(256), shcol, (hipStream_t)stream, (const double2*)ws,
+  DPX_LAUNCH("k_cols_fwd_f64", k_cols_fwd_f64, dim3((Wh + CT - 1) / CT, P), dim3(CT >= 4 ? 512 : 256), shcol, s, (const double2*)spec64,
              (float2*)spec_out, (const float2*)otf, conj_otf, accumulate, C, H, W, make_plan(H),
-             pow2_path_available(H, W) ? 1 : 0, P);
+             pow2_path_available(H, W) ? 1 : 0, P, (const double2*)twH, CT);
   return launch_status("dpx_data_spectrum");
 }
 

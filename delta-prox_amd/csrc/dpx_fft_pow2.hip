@@ -178,8 +178,11 @@ struct SeedTerms {
   const float* u[DPX_MAX_TERMS];
   int linop[DPX_MAX_TERMS];
   int n;
+  const float* x0;       // FRESH: the iterate the state was initialised from (v_i = K_i x0, u_i = 0: admm.py:61-67)
 };
-template <int M, int T>
+// FRESH: the state comes straight from ADMM.initialize -- v_i = K_i x0 and u_i = 0 -- so v_i - u_i is recomputed from x0's rows (the
+// same fp32 differences K.forward stored, minus an exact zero: bit-identical spectra) and the pass reads ONE image instead of 2 n.
+template <int M, int T, bool FRESH>
 __global__ void __launch_bounds__(256) k_seed_rows(SeedTerms S_, const float* __restrict__ rho, float2* __restrict__ spec, float2* __restrict__ side,
                                                     int nrows, int H, int C, const float2* __restrict__ twW) {
   using RM = RowMap<M, T>;
@@ -192,15 +195,41 @@ __global__ void __launch_bounds__(256) k_seed_rows(SeedTerms S_, const float* __
   const int rr = live ? row : 0, pl = rr / H, hh = rr - pl * H;
   const int lane = tid & 63, lbase = lane & ~(T - 1);
   const size_t here = (size_t)rr * M, above = ((size_t)pl * H + (hh == 0 ? H - 1 : hh - 1)) * M;      // float2 offsets of the two rows
+  const size_t below = ((size_t)pl * H + (hh == H - 1 ? 0 : hh + 1)) * M;
   float2 acc[V];
 #pragma unroll
   for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f);
+  float2 xh[V];
+  if constexpr (FRESH) {
+    const float2* xr = (const float2*)S_.x0;
+#pragma unroll
+    for (int m = 0; m < V; ++m) xh[m] = xr[here + t + m * T];
+  }
   for (int i = 0; i < S_.n; ++i) {
     const float2* vr = (const float2*)S_.v[i];
     const float2* ur = (const float2*)S_.u[i];
     float2 y[V];
+    if constexpr (FRESH) {
+      if (S_.linop[i] == DPX_LIN_IDENTITY) {
 #pragma unroll
-    for (int m = 0; m < V; ++m) y[m] = csub(vr[here + t + m * T], ur[here + t + m * T]);
+        for (int m = 0; m < V; ++m) y[m] = xh[m];
+      } else if (S_.linop[i] == DPX_LIN_GRAD_W) {           // x[w+1] - x[w]; pixel 2n+2 is the neighbour lane's .x
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+          const float nx_same = __shfl(xh[m].x, lbase | ((t + 1) & (T - 1)));
+          const float nx_wrap = __shfl(xh[(m + 1) % V].x, lbase);
+          const float xr_ = (t == T - 1) ? nx_wrap : nx_same;
+          y[m] = make_float2(xh[m].y - xh[m].x, xr_ - xh[m].y);
+        }
+      } else {                                              // x[h+1] - x[h]
+        const float2* xr = (const float2*)S_.x0;
+#pragma unroll
+        for (int m = 0; m < V; ++m) y[m] = csub(xr[below + t + m * T], xh[m]);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < V; ++m) y[m] = csub(vr[here + t + m * T], ur[here + t + m * T]);
+    }
     if (S_.linop[i] == DPX_LIN_IDENTITY) {
 #pragma unroll
       for (int m = 0; m < V; ++m) acc[m] = cadd(acc[m], y[m]);
@@ -215,7 +244,9 @@ __global__ void __launch_bounds__(256) k_seed_rows(SeedTerms S_, const float* __
     } else {                                              // grad_H adjoint: y[h-1] - y[h]
 #pragma unroll
       for (int m = 0; m < V; ++m) {
-        const float2 yu = csub(vr[above + t + m * T], ur[above + t + m * T]);
+        float2 yu;
+        if constexpr (FRESH) yu = csub(xh[m], ((const float2*)S_.x0)[above + t + m * T]);
+        else yu = csub(vr[above + t + m * T], ur[above + t + m * T]);
         acc[m] = cadd(acc[m], csub(yu, y[m]));
       }
     }
@@ -753,13 +784,18 @@ static void cols_dispatch(int H, const float2* spec, float2* spec_out, const Spe
 template <int M, int T>
 static void launch_seed(const SeedTerms& S_, const float* rho, float2* spec, int nrows, int H, int C, const float2* twW, hipStream_t s) {
   constexpr int SPB = 256 / T;
-  DPX_LAUNCH("k_seed_rows", (k_seed_rows<M, T>), dim3((nrows + SPB - 1) / SPB), dim3(256), 0, s, S_, rho, spec, spec + (size_t)nrows * M, nrows, H, C,
-             twW);
+  if (S_.x0)
+    DPX_LAUNCH("k_seed_rows", (k_seed_rows<M, T, true>), dim3((nrows + SPB - 1) / SPB), dim3(256), 0, s, S_, rho, spec, spec + (size_t)nrows * M, nrows, H,
+               C, twW);
+  else
+    DPX_LAUNCH("k_seed_rows", (k_seed_rows<M, T, false>), dim3((nrows + SPB - 1) / SPB), dim3(256), 0, s, S_, rho, spec, spec + (size_t)nrows * M, nrows, H,
+               C, twW);
 }
-int seed_rows_pow2(const dpx_term* terms, int nterms, const float* rho, float2* spec, int B, int C, int H, int W, const void* table,
+int seed_rows_pow2(const dpx_term* terms, int nterms, const float* rho, const float* x0, float2* spec, int B, int C, int H, int W, const void* table,
                    hipStream_t stream) {
   SeedTerms S_{};
   S_.n = nterms;
+  S_.x0 = x0;
   for (int i = 0; i < nterms; ++i) {
     S_.v[i] = terms[i].v;
     S_.u[i] = terms[i].u;

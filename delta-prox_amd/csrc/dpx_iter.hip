@@ -35,6 +35,8 @@ struct IterTerms {
   float dual;          // 1: ADMM.  0: half-quadratic splitting (DPX_TERM_NO_DUAL) -- the incoming duals count as zero and the right-hand side
                        // sees v_i alone; applied as fma(dual, u, K x) / fma(-dual, u', v): the same instructions, and exact for dual = 1
   int emit_bf16;       // x_out / v_out / rhs_out are bf16 planes (the bf16 history of the unrolled forward pass) instead of fp32
+  int u_live;          // 0: the incoming duals are all zero (DPX_TERM_U_ZERO, first iteration after ADMM.initialize) -- the streaming kernel then
+                       // fetches every u row from row 0 of plane 0 (cache hits) instead of streaming the planes from HBM
   float* rhs_out;      // nullable: the next x-update's right-hand-side increment rho' sum K_i^T (v_i - u_i) as an image (the unrolled
                        // forward pass keeps it for the backward pass); like x_out / v_out an emit store, never counted in the waits
 };
@@ -366,7 +368,8 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   const unsigned xoff = (unsigned)pl * H * M + (e0 / SPEC_TILE) * H * SPEC_TILE + (e0 % SPEC_TILE);
   const unsigned xstep = (unsigned)(2 * T / SPEC_TILE) * H * SPEC_TILE;   // elements e0 + 2T*i
   const unsigned noff = (unsigned)P * H * M + (unsigned)pl * H;
-  const unsigned uoff = (unsigned)pl * H * M + e0;      // row-major image rows: M float2 per row
+  const unsigned usc = (unsigned)TT.u_live;
+  const unsigned uoff = (unsigned)pl * H * M * usc + e0;      // row-major image rows: M float2 per row
   const unsigned tile_off = (unsigned)pl * H * M + (unsigned)((t % SPEC_TILE) + (t / SPEC_TILE) * H * SPEC_TILE);
   const unsigned tile_step = (unsigned)((T / SPEC_TILE) * H * SPEC_TILE);
   const int pair = lbase | ((T - t) & (T - 1));
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   auto issue_u = [&](int h) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const float2* urow = (const float2*)TT.t[n].u_in + uoff + (unsigned)h * M;
+      const float2* urow = (const float2*)TT.t[n].u_in + uoff + (unsigned)h * M * usc;
 #pragma unroll
       for (int i = 0; i < D; ++i) dpx_glds16<R_LDU>(urow + 2 * T * i, stU + n * STG + i * 128);
     }
@@ -606,7 +609,7 @@ size_t pow2_spec_elems(int P, int H, int W);
 int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table,
                     hipStream_t stream);
 int rows_r2c_pow2(const float* x, float2* spec, int P, int H, int W, const void* table, hipStream_t stream);
-int seed_rows_pow2(const dpx_term* terms, int nterms, const float* rho, float2* spec, int B, int C, int H, int W, const void* table,
+int seed_rows_pow2(const dpx_term* terms, int nterms, const float* rho, const float* x0, float2* spec, int B, int C, int H, int W, const void* table,
                    hipStream_t stream);
 
 }  // namespace dpx
@@ -658,7 +661,16 @@ extern "C" int dpx_admm_seed_rows(void* spec, const float* rho, const dpx_term* 
   DPX_REQUIRE(spec && rho && terms && table, "dpx_admm_seed_rows: null pointer");
   DPX_REQUIRE(dpx_admm_iter_supported(H, W, terms, nterms), "dpx_admm_seed_rows: unsupported problem (plane %dx%d, %d terms)", H, W, nterms);
   for (int i = 0; i < nterms; ++i) DPX_REQUIRE(terms[i].v && terms[i].u, "dpx_admm_seed_rows: term %d lacks v / u", i);
-  return seed_rows_pow2(terms, nterms, rho, (float2*)spec, B, C, H, W, table, (hipStream_t)stream);
+  return seed_rows_pow2(terms, nterms, rho, nullptr, (float2*)spec, B, C, H, W, table, (hipStream_t)stream);
+}
+
+// the same seed for a state that comes straight from ADMM.initialize (admm.py:61-67: v_i = K_i x0, u_i = 0): the pass recomputes
+// v_i - u_i from x0 (bit-identical: the same fp32 differences, minus an exact zero) and reads one image instead of 2 nterms
+extern "C" int dpx_admm_seed_rows_fresh(void* spec, const float* rho, const float* x0, const dpx_term* terms, int nterms, int B, int C, int H, int W,
+                                        const void* table, dpx_stream_t stream) {
+  DPX_REQUIRE(spec && rho && terms && table && x0, "dpx_admm_seed_rows_fresh: null pointer");
+  DPX_REQUIRE(dpx_admm_iter_supported(H, W, terms, nterms), "dpx_admm_seed_rows_fresh: unsupported problem (plane %dx%d, %d terms)", H, W, nterms);
+  return seed_rows_pow2(terms, nterms, rho, x0, (float2*)spec, B, C, H, W, table, (hipStream_t)stream);
 }
 
 extern "C" int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const void* spec_add, const void* dd, const float* rho,
@@ -691,8 +703,10 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   TT.rhs_out = rho_next ? rhs_out : nullptr;
   TT.emit_bf16 = emit_bf16;
   TT.dual = (nterms > 0 && (terms[0].reserved & DPX_TERM_NO_DUAL)) ? 0.f : 1.f;
+  TT.u_live = (nterms > 0 && (terms[0].reserved & DPX_TERM_U_ZERO)) ? 0 : 1;
   for (int i = 0; i < nterms; ++i) {
     DPX_REQUIRE(!(terms[i].reserved & DPX_TERM_NO_DUAL) == (TT.dual != 0.f), "dpx_admm_iter_rows: DPX_TERM_NO_DUAL must be set on every term or on none");
+    DPX_REQUIRE(!(terms[i].reserved & DPX_TERM_U_ZERO) == (TT.u_live != 0), "dpx_admm_iter_rows: DPX_TERM_U_ZERO must be set on every term or on none");
     DPX_REQUIRE(terms[i].u && (terms[i].u_out) && (!emit_v || terms[i].v), "dpx_admm_iter_rows: term %d lacks u / u_out / v", i);
     DPX_REQUIRE(terms[i].u != terms[i].u_out, "dpx_admm_iter_rows: u must be double-buffered (u_out != u)");
     TT.t[i] = IterTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].u, terms[i].u_out, terms[i].v};
@@ -780,6 +794,7 @@ extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, co
     if (rc) return rc;
     for (int i = 0; i < nterms; ++i) {
       cur[i].lam = lam_tabs[i] ? lam_tabs[i] + (size_t)it * B : nullptr;
+      if (k > 0) cur[i].reserved &= ~DPX_TERM_U_ZERO;      // (only the duals the call starts from can be the fresh zeros)
       cur[i].u = parity ? terms[i].u_out : terms[i].u;
       cur[i].u_out = parity ? terms[i].u : terms[i].u_out;
     }

@@ -19,7 +19,8 @@ LIB_PATH = os.environ.get("DPX_LIB") or os.path.join(os.path.dirname(_HERE), "li
 
 PROX_NORM1, PROX_NONNEG, PROX_SUMSQ, PROX_EXTERNAL = 0, 1, 2, 3
 LIN_IDENTITY, LIN_GRAD_H, LIN_GRAD_W = 0, 1, 2
-TERM_NO_DUAL = 1          # dpx_term.reserved flag (include/dpx.h)
+TERM_NO_DUAL = 1          # dpx_term.reserved flags (include/dpx.h)
+TERM_U_ZERO = 2
 MAX_TERMS = 4
 
 
@@ -117,6 +118,7 @@ SIGNATURES = {
     "dpx_admm_iter_config": (c_int, [c_int, c_int]),
     "dpx_admm_iter_supported": (c_int, [c_int, c_int, POINTER(Term), c_int]),
     "dpx_admm_seed_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_seed_rows_fresh": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_rfft_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_iter_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_iter_rows": (c_int, [c_void_p, c_void_p, POINTER(Term), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

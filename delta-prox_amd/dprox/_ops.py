@@ -579,9 +579,14 @@ def iter_rows(spec_in, spec_out, term_arr, nterms, rho_next, x_out, emit_v, shap
                   int(bool(emit_v)), B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
 
 
-def admm_seed_rows(spec, rho, term_arr, nterms, shape, device):
-    """spec = row transform of rho_b sum_i K_i^T (v_i - u_i): the seed of admm_run in one pass"""
+def admm_seed_rows(spec, rho, term_arr, nterms, shape, device, fresh_x=None):
+    """spec = row transform of rho_b sum_i K_i^T (v_i - u_i): the seed of admm_run in one pass.  ``fresh_x``: the state is
+    ADMM.initialize(fresh_x) untouched (v_i = K_i x0, u_i = 0) -- the pass then reads x0 alone (bit-identical result)"""
     B, C, H, W = shape
+    if fresh_x is not None:
+        be.lib().call("dpx_admm_seed_rows_fresh", ptr(spec), ptr(rho), ptr(fresh_x), term_arr, nterms, B, C, H, W, ptr(fft_table(H, W, device)),
+                      be.stream())
+        return spec
     be.lib().call("dpx_admm_seed_rows", ptr(spec), ptr(rho), term_arr, nterms, B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
     return spec
 

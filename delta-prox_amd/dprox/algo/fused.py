@@ -105,6 +105,21 @@ def plan_admm(solver, state):
     return FusedADMM(solver, codes)
 
 
+def fresh_state(solver, state):
+    """True when ``state`` is exactly what ``ADMM.initialize`` returned last (same tensors, never written since): v_i = K_i x0 and
+    u_i = 0, so the first right-hand side can be formed from x0 alone and the first iteration need not stream the (zero) duals"""
+    f = getattr(solver, "_fresh", None)
+    if f is None or len(state) != 3:
+        return False
+    x, v, u, vers = f
+    sx, sv, su = state
+    if sx is not x or len(sv) != len(v) or len(su) != len(u):
+        return False
+    if any(a is not b for a, b in zip(list(sv) + list(su), v + u)):
+        return False
+    return all(t._version == n and t.is_contiguous() for t, n in zip([x] + v + u, vers))
+
+
 def schedule_table(vals, T, B, device):
     """0-d / [T] / [B,T] -> contiguous [T,B] float32 on device"""
     v = vals.to(device=device, dtype=torch.float32)
@@ -254,13 +269,16 @@ class FusedADMM:
         # nothing but the state, so it is launched FIRST and the rest of the host-side preparation (schedule tables, data spectrum,
         # denominators, workspaces: ~0.1 ms) runs while the GPU is already busy instead of in front of it.
         seeded = None
+        fresh = dual and not vxu and fresh_state(s, state)
+        s._fresh = None                                        # (the state is about to be advanced in place)
         if not want_grad and not vxu and len(psi) > 0 and all(pc != be.PROX_EXTERNAL for _, pc in self.codes):
             v = [t.contiguous() for t in v]
             u = [t.contiguous() for t in u]
             early = ops.make_terms([dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=None, v=v[i], u=u[i])
                                     for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))])
             if ops.iter_supported(H, W, early, len(psi)):
-                seeded = ops.admm_seed_rows(ops.spectrum_buffer(B * C, H, W, dev), rho_tab[0], early, len(psi), x0.shape, dev)
+                seeded = ops.admm_seed_rows(ops.spectrum_buffer(B * C, H, W, dev), rho_tab[0], early, len(psi), x0.shape, dev,
+                                            fresh_x=x0 if fresh else None)
         lam_tab = []
         for fn in psi:
             lt = schedule_table(lams[fn], T, B, dev)
@@ -330,7 +348,7 @@ class FusedADMM:
                 for i in range(n):
                     terms[i].reserved = be.TERM_NO_DUAL
             return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
-                                        rhos, lams, pbar, callback, dual, seeded)
+                                        rhos, lams, pbar, callback, dual, seeded, fresh and seeded is not None)
 
         # one FFDNet prior, everything else closed-form: the whole iteration is ONE C call (dpx_admm_pnp_iter)
         one_call = (dual and len(ext) == 1 and isinstance(psi[ext[0]].denoiser, (FFDNetColorDenoiser, FFDNetDenoiser))
@@ -479,7 +497,8 @@ class FusedADMM:
             tot = val if tot is None else tot + val
         return (-tot).expand_as(x0)
 
-    def _run_two_kernel(self, shape, dev, T, terms, n, v, u, x, rhs, FK, diag, rho_tab, lam_tab, rhos, lams, pbar, callback, dual=True, seeded=None):
+    def _run_two_kernel(self, shape, dev, T, terms, n, v, u, x, rhs, FK, diag, rho_tab, lam_tab, rhos, lams, pbar, callback, dual=True, seeded=None,
+                        fresh=False):
         """power-of-two planes: cols -> rows, two kernels per iteration; x / v only leave the chip on request.
         dual=False (half-quadratic splitting): u holds one shared all-zero buffer per term; the kernels' dual output goes to one
         shared scratch buffer and is ignored when it comes back as input (DPX_TERM_NO_DUAL)"""
@@ -504,6 +523,9 @@ class FusedADMM:
         for i in range(n):
             terms[i].u, terms[i].u_out, terms[i].v = u_cur[i].data_ptr(), u_nxt[i].data_ptr(), v[i].data_ptr()
         eps = ls_eps(s.least_square)
+        if fresh:                                                # u_i = 0: the first iteration does not stream the duals (DPX_TERM_U_ZERO)
+            for i in range(n):
+                terms[i].reserved |= be.TERM_U_ZERO
         if callback is None and not pbar:
             par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_tab, eps, 0, T, T, x, True, shape, dev)
             if par:
@@ -512,6 +534,8 @@ class FusedADMM:
             for it in tqdm(range(T), disable=not pbar):
                 emit = callback is not None or it == T - 1
                 par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_tab, eps, it, 1, T, x, emit, shape, dev)
+                for i in range(n):
+                    terms[i].reserved &= ~be.TERM_U_ZERO
                 if par:
                     u_cur, u_nxt = u_nxt, u_cur
                     for i in range(n):

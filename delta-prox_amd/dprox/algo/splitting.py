@@ -57,12 +57,15 @@ class ADMM(Algorithm):
     def initialize(self, x0, v=None):
         x = x0
         self.Kall.update_vars([x])
+        derived = v is None
         if v is None:
             v = self.K.forward(x, return_list=True)
             if v is None:
                 v = []
         v = [e if e is not x else e.clone() for e in v]
         u = [torch.zeros_like(e) for e in v]
+        # the fused path recognises this state as long as nobody has written to it (fused.fresh_state): v_i = K_i x0, u_i = 0 exactly
+        self._fresh = (x, v, u, [t._version for t in [x] + v + u]) if derived and all(isinstance(t, torch.Tensor) for t in [x] + v) else None
         return x, v, u
 
     def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
@@ -81,6 +84,7 @@ class ADMM(Algorithm):
                 self.last_path = "fused"
                 return plan.run_stencil(state, rhos, lams, max_iter, "ladmm", pbar, callback)
         self.last_path = "generic"
+        self._fresh = None
         return super().iters(state, rhos, lams, max_iter, pbar, callback)
 
     def _prox_dual(self, Kx, v, u, lam):

@@ -267,6 +267,10 @@ typedef struct dpx_term {
  * contents of u are ignored (finite values required: start from zeros) and the next right-hand side is rho sum_i K_i^T v_i;
  * u / u_out are still read / written (scratch).  Set on every term of the call or on none.                                      */
 #define DPX_TERM_NO_DUAL 1
+/* the incoming duals u are all zero (the state comes straight from ADMM.initialize, algo/admm.py:61-67): dpx_admm_iter_rows /
+ * the FIRST iteration of a dpx_admm_run call need not stream them from HBM (the buffers must still hold zeros: row 0 is read).
+ * Set on every term of the call or on none.                                                                                 */
+#define DPX_TERM_U_ZERO 2
 
 /* rhs = ktb + sum_i rho_b * K_i^T (v_i - u_i)   -- proxfn/sum_square.py:126-135 with
  * b_i = v_i - u_i from algo/admm.py:51.  ktb = sum over Omega of K^T offset (constant per solve). */
@@ -362,6 +366,10 @@ int dpx_rfft_rows(const float* x, void* spec, int B, int C, int H, int W, const 
  * algo/admm.py:51 + proxfn/sum_square.py:126-135 for the first x-update of a solve); same support as dpx_admm_iter_rows */
 int dpx_admm_seed_rows(void* spec, const float* rho, const dpx_term* terms, int nterms, int B, int C, int H, int W, const void* table,
                        dpx_stream_t stream);
+/* the same seed for a state that comes straight from ADMM.initialize (algo/admm.py:61-67: v_i = K_i x0, u_i = 0): v_i - u_i is
+ * recomputed from x0 (bit-identical), one image read instead of 2 nterms; terms[i].v / .u are not dereferenced */
+int dpx_admm_seed_rows_fresh(void* spec, const float* rho, const float* x0, const dpx_term* terms, int nterms, int B, int C, int H, int W,
+                             const void* table, dpx_stream_t stream);
 int dpx_admm_iter_cols(const void* spec_in, void* spec_out, const void* spec_add, const void* dd, const float* rho, float eps,
                        int B, int C, int H, int W, const void* table, dpx_stream_t stream);
 int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next,

@@ -1139,6 +1139,42 @@ def case_hqs_pow2(device):
     assert_close(xs.cpu(), out2.cpu(), TOL, "hqs pow2: two-kernel vs op by op")
 
 
+def case_fresh_state(device, shapes=((2, 1, 256, 256),), iters=3):
+    """The fresh-state shortcut (state straight from ADMM.initialize: the first right-hand side formed from x0 alone --
+    dpx_admm_seed_rows_fresh -- and the zero duals not streamed in the first iteration -- DPX_TERM_U_ZERO) against the same solve
+    started from a state that has been touched (general seed pass, duals read): BIT-identical x, v_i, u_i, on both row kernels."""
+    import synthetic
+    from dprox import _backend as be
+    from dprox import _ops as ops
+    L = be.lib()
+    try:
+        for (B, C, H, W) in shapes:
+            for rows_mode in (1, 2):
+                L.call("dpx_admm_iter_config", rows_mode, 0)
+                gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=77 + H)
+                b = T(b0, device)
+                x = dp.Variable()
+                fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
+                s = dp.compile(fns, method="admm", device=device)
+                x0 = b.clone()
+                seeds = []
+                real = ops.admm_seed_rows
+                ops.admm_seed_rows = lambda *a, **k: (seeds.append(k.get("fresh_x") is not None), real(*a, **k))[1]
+                try:
+                    fresh = s.solve(x0=x0, rhos=0.3, lams=0.01, max_iter=iters, return_full_states=True)
+                    _, rhos, lams, _ = s.defaults(x0, 0.3, 0.01, iters)
+                    st = s.initialize(x0)
+                    st[2][0].add_(0.0)                       # a write: the state no longer counts as fresh
+                    touched = s.iters(st, rhos.to(device), {k: v.to(device) for k, v in lams.items()}, iters)
+                finally:
+                    ops.admm_seed_rows = real
+                assert seeds == [True, False], seeds
+                for a, c in zip([fresh[0]] + list(fresh[1]) + list(fresh[2]), [touched[0]] + list(touched[1]) + list(touched[2])):
+                    assert torch.equal(a, c), ("fresh-state shortcut differs", (B, C, H, W), rows_mode, float((a - c).abs().max()))
+    finally:
+        L.call("dpx_admm_iter_config", 0, 0)
+
+
 def case_tiny_shapes(device):
     """degenerate planes against the oracle: 2x3, 3x3, 17x2 (every stage at its smallest size, prime lengths), and the
     reference's error for an axis shorter than the gradient stencil (utils/psf2otf.py:46-54 raises there too)"""

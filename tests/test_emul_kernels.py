@@ -58,6 +58,10 @@ def test_hqs_two_kernel():
     pc.case_hqs_pow2(DEV)
 
 
+def test_fresh_state_shortcut_is_bit_identical():
+    pc.case_fresh_state(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV, tiny=True)
 
