@@ -142,12 +142,21 @@ template <int R, int DIR, class CT> __device__ __forceinline__ void bfly(CT (&v)
   else bfly_odd<R, DIR, CT>(v, tw, rstride);
 }
 
+// LDS index maps of a sequence: plain, or one pad slot per 8 elements (fp64 passes: the first pass stores element 8 j + m from lane j,
+// a 128-byte stride = every lane on the same banks; padded, lane j lands 144 bytes on)
+struct IdxPlain {
+  __device__ static __forceinline__ int at(int i) { return i; }
+};
+struct IdxPad8 {
+  __device__ static __forceinline__ int at(int i) { return i + (i >> 3); }
+};
+
 // ---------------------------------------------------------------------------------------------
 // one Stockham autosort pass over `nseq` sequences held in LDS (sequence s at base + s*ld)
 //   out[(j/Ns)*Ns*R + k + m*Ns] = DFT_R_m( in[j + m'*N/R] * W_{Ns*R}^{k*m'} ),  k = j % Ns
 // tw is a table of length tlen = N * tscale with tw[t] = exp(-2 pi i t / tlen)
 // ---------------------------------------------------------------------------------------------
-template <int R, int DIR, class CT>
+template <int R, int DIR, class CT, class IX = IdxPlain>
 __device__ void stockham_pass(const CT* __restrict__ in, CT* __restrict__ out, int N, int Ns,
                               const Twid<CT>& tw, int tscale, int nseq, int ld, int tid, int nthr) {
   const int nb = N / R;
@@ -160,7 +169,7 @@ __device__ void stockham_pass(const CT* __restrict__ in, CT* __restrict__ out, i
     CT* dst = out + s * ld;
     CT v[R];
 #pragma unroll
-    for (int m = 0; m < R; ++m) v[m] = src[j + m * nb];
+    for (int m = 0; m < R; ++m) v[m] = src[IX::at(j + m * nb)];
     if (Ns > 1) {
 #pragma unroll
       for (int m = 1; m < R; ++m) {
@@ -172,12 +181,12 @@ __device__ void stockham_pass(const CT* __restrict__ in, CT* __restrict__ out, i
     bfly<R, DIR, CT>(v, tw, rstride);
     const int j0 = (j - k) * R + k;
 #pragma unroll
-    for (int m = 0; m < R; ++m) dst[j0 + m * Ns] = v[m];
+    for (int m = 0; m < R; ++m) dst[IX::at(j0 + m * Ns)] = v[m];
   }
 }
 
 // any radix: one output per work item, O(R) each
-template <int DIR, class CT>
+template <int DIR, class CT, class IX = IdxPlain>
 __device__ void stockham_pass_any(const CT* __restrict__ in, CT* __restrict__ out, int N, int Ns, int R,
                                   const Twid<CT>& tw, int tscale, int nseq, int ld, int tid, int nthr) {
   const int nb = N / R;
@@ -192,15 +201,15 @@ __device__ void stockham_pass_any(const CT* __restrict__ in, CT* __restrict__ ou
       long long e = ((long long)k * m * e1 + (long long)q * m * e2) % N;
       CT w = tw.get(e * tscale);
       if (DIR > 0) w.y = -w.y;
-      acc = gadd(acc, gmul(src[j + m * nb], w));
+      acc = gadd(acc, gmul(src[IX::at(j + m * nb)], w));
     }
-    out[s * ld + (j - k) * R + k + q * Ns] = acc;
+    out[s * ld + IX::at((j - k) * R + k + q * Ns)] = acc;
   }
 }
 
 // full transform of nseq LDS-resident sequences, ping-ponging a <-> b; returns the buffer holding
 // the result (natural order).  Every thread of the block must call it.
-template <int DIR, class CT>
+template <int DIR, class CT, class IX = IdxPlain>
 __device__ CT* fft_lds(CT* a, CT* b, const Plan1D& plan, const Twid<CT>& tw, int tscale,
                        int nseq, int ld, int tid, int nthr) {
   const int N = plan.n;
@@ -208,15 +217,15 @@ __device__ CT* fft_lds(CT* a, CT* b, const Plan1D& plan, const Twid<CT>& tw, int
   for (int f = 0; f < plan.nf; ++f) {
     const int R = plan.radix[f];
     switch (R) {
-      case 2: stockham_pass<2, DIR, CT>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
-      case 3: stockham_pass<3, DIR, CT>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
-      case 4: stockham_pass<4, DIR, CT>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
-      case 5: stockham_pass<5, DIR, CT>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
-      case 7: stockham_pass<7, DIR, CT>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
-      case 8: stockham_pass<8, DIR, CT>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
-      case 11: stockham_pass<11, DIR, CT>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
-      case 13: stockham_pass<13, DIR, CT>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
-      default: stockham_pass_any<DIR, CT>(a, b, N, Ns, R, tw, tscale, nseq, ld, tid, nthr); break;
+      case 2: stockham_pass<2, DIR, CT, IX>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 3: stockham_pass<3, DIR, CT, IX>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 4: stockham_pass<4, DIR, CT, IX>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 5: stockham_pass<5, DIR, CT, IX>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 7: stockham_pass<7, DIR, CT, IX>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 8: stockham_pass<8, DIR, CT, IX>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 11: stockham_pass<11, DIR, CT, IX>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      case 13: stockham_pass<13, DIR, CT, IX>(a, b, N, Ns, tw, tscale, nseq, ld, tid, nthr); break;
+      default: stockham_pass_any<DIR, CT, IX>(a, b, N, Ns, R, tw, tscale, nseq, ld, tid, nthr); break;
     }
     __syncthreads();
     CT* t = a;
@@ -427,7 +436,7 @@ template <bool EVEN>
 __global__ void k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict__ spec, int W, int nrows, int H, Plan1D plan,
                                const double2* __restrict__ tw64, int rpb, int CT) {
   HIP_DYNAMIC_SHARED(double2, smem64)
-  const int M = plan.n, ld = M + 1, Wh = W / 2 + 1, NTL = (Wh + CT - 1) / CT;
+  const int M = plan.n, ld = M + M / 8 + 1, Wh = W / 2 + 1, NTL = (Wh + CT - 1) / CT;
   double2* a = smem64;
   double2* b = smem64 + rpb * ld;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -438,14 +447,14 @@ __global__ void k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict_
     const float* xr = x + (size_t)(row0 + s) * W;
     if (EVEN) {
       const float2 v = ((const float2*)xr)[n];
-      a[s * ld + n] = make_double2((double)v.x, (double)v.y);
+      a[s * ld + IdxPad8::at(n)] = make_double2((double)v.x, (double)v.y);
     } else {
-      a[s * ld + n] = make_double2((double)xr[n], 0.0);
+      a[s * ld + IdxPad8::at(n)] = make_double2((double)xr[n], 0.0);
     }
   }
   __syncthreads();
   const Twid<double2> twd{tw64, W};
-  const double2* z = fft_lds<-1, double2>(a, b, plan, twd, EVEN ? 2 : 1, nseq, ld, tid, nthr);
+  const double2* z = fft_lds<-1, double2, IdxPad8>(a, b, plan, twd, EVEN ? 2 : 1, nseq, ld, tid, nthr);
   // (tile, row, column-in-tile) order: the rows of a workgroup are adjacent in every tile
   for (int i = tid; i < NTL * nseq * CT; i += nthr) {
     const int kk = i % CT, s = (i / CT) % nseq, kt = i / (CT * nseq);
@@ -454,13 +463,13 @@ __global__ void k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict_
     const double2* zs = z + s * ld;
     double2 X;
     if (!EVEN) {
-      X = zs[k];
+      X = zs[IdxPad8::at(k)];
     } else if (k == 0) {
       X = make_double2(zs[0].x + zs[0].y, 0.0);
     } else if (k == M) {
       X = make_double2(zs[0].x - zs[0].y, 0.0);
     } else {
-      const double2 zk = zs[k], zm = make_double2(zs[M - k].x, -zs[M - k].y);
+      const double2 zk = zs[IdxPad8::at(k)], zmr = zs[IdxPad8::at(M - k)], zm = make_double2(zmr.x, -zmr.y);
       const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y));
       const double2 d = make_double2(0.5 * (zk.x - zm.x), 0.5 * (zk.y - zm.y));
       const double2 o = make_double2(d.y, -d.x);                 // -i * d
@@ -478,7 +487,7 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
                                int conj_otf, int accumulate, int C, int H, int W, Plan1D plan, int side_layout, int P,
                                const double2* __restrict__ tw64, int CT) {
   HIP_DYNAMIC_SHARED(double2, smem64)
-  const int Wh = W / 2 + 1, Ws = (W + 1) / 2, ld = H + 1, NTL = (Wh + CT - 1) / CT;
+  const int Wh = W / 2 + 1, Ws = (W + 1) / 2, ld = H + H / 8 + 1, NTL = (Wh + CT - 1) / CT;
   const bool packed = (W % 2 == 0);
   double2* a = smem64;
   double2* b = smem64 + CT * ld;
@@ -498,11 +507,11 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
   for (int i = tid; i < H * CT; i += nthr) {
     const int c = i % CT, r = i / CT;
     const int l = col_of(c);
-    a[c * ld + r] = l >= 0 ? base[((size_t)(l / CT) * H + r) * CT + (l % CT)] : make_double2(0.0, 0.0);
+    a[c * ld + IdxPad8::at(r)] = l >= 0 ? base[((size_t)(l / CT) * H + r) * CT + (l % CT)] : make_double2(0.0, 0.0);
   }
   __syncthreads();
   const Twid<double2> twd{tw64, H};
-  const double2* z = fft_lds<-1, double2>(a, b, plan, twd, 1, CT, ld, tid, nthr);
+  const double2* z = fft_lds<-1, double2, IdxPad8>(a, b, plan, twd, 1, CT, ld, tid, nthr);
   const size_t tmain = (size_t)ch * H * Ws, tside = (size_t)C * H * Ws + (size_t)ch * H;
   float2* o = out + (size_t)p * H * Ws;
   int nyq_slot = -1;                                        // the slot holding the Nyquist column, if this workgroup has the DC column
@@ -511,14 +520,14 @@ __global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restr
     const int c = i % CT, k = i / CT;
     const int l = col_of(c);
     if (l < 0 || (packed && l == nyq)) continue;           // (the Nyquist column is consumed by the DC column's lanes)
-    double2 v = z[c * ld + k];
+    double2 v = z[c * ld + IdxPad8::at(k)];
     if (otf) {
       const float2 t = otf[tmain + spec_main_index(side_layout, H, Ws, k, l)];
       const double tr = t.x, ti = conj_otf ? -(double)t.y : (double)t.y;
       v = make_double2(v.x * tr - v.y * ti, v.x * ti + v.y * tr);
     }
     if (l == 0 && nyq_slot >= 0) {
-      double2 n = z[nyq_slot * ld + k];
+      double2 n = z[nyq_slot * ld + IdxPad8::at(k)];
       if (otf) {
         const float2 t = otf[tside + k];
         const double tr = t.x, ti = conj_otf ? -(double)t.y : (double)t.y;
@@ -821,12 +830,13 @@ extern "C" int dpx_fft_conv(const float* x, float* y, const void* otf, int conj_
 
 // geometry of the fp64 data-spectrum pass: CT columns per column workgroup (LDS: two images of CT sequences of H fp64 points),
 // RPB rows per row workgroup; 0 = the plane does not fit the LDS-resident transform
-static int ds_ct(int H) { return (size_t)4 * 2 * (H + 1) * sizeof(double2) <= 160 * 1024 ? 4 : ((size_t)2 * 2 * (H + 1) * sizeof(double2) <= 160 * 1024 ? 2 : 0); }
+static size_t ds_ld(int n) { return (size_t)n + n / 8 + 1; }      // padded LDS length of one fp64 sequence (IdxPad8)
+static int ds_ct(int H) { return 4 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 4 : (2 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 2 : 0); }
 static int ds_rpb(int W) {
   const int M = (W % 2 == 0) ? W / 2 : W;
   for (int r = 4; r >= 1; r >>= 1)
-    if ((size_t)r * 2 * (M + 1) * sizeof(double2) <= 72 * 1024) return r;
-  return (size_t)2 * (M + 1) * sizeof(double2) <= 160 * 1024 ? 1 : 0;
+    if ((size_t)r * 2 * ds_ld(M) * sizeof(double2) <= 80 * 1024) return r;
+  return 2 * ds_ld(M) * sizeof(double2) <= 160 * 1024 ? 1 : 0;
 }
 static size_t ds_spec_elems(int P, int H, int W) {
   const int CT = ds_ct(H) ? ds_ct(H) : 4, Wh = W / 2 + 1;
@@ -847,7 +857,7 @@ extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, 
   }
   const bool even = (W % 2 == 0);
   const int M = even ? W / 2 : W;
-  const size_t shrow = (size_t)rpb * 2 * (M + 1) * sizeof(double2), shcol = (size_t)CT * 2 * (H + 1) * sizeof(double2);
+  const size_t shrow = (size_t)rpb * 2 * ds_ld(M) * sizeof(double2), shcol = (size_t)CT * 2 * ds_ld(H) * sizeof(double2);
   hipStream_t s = (hipStream_t)stream;
   double2* spec64 = (double2*)ws;
   double2* twW = spec64 + ds_spec_elems(P, H, W);

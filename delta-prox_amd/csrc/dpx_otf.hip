@@ -75,6 +75,7 @@ __global__ void k_psf2otf(const double* __restrict__ psf, int kh, int kw, int kc
 
 // The same table, evaluated separably: one workgroup = one tile of PT_K frequency rows x PT_L frequency columns of one channel.
 //   R[m][i][l] = sum_j psf[i,j,m] e^{-2 pi i l (j-cj)/W}   (kc kh PT_L values, kw sincospi each)      -- the column factor, once per tile
+//   (the column phases e^{-2 pi i l (j-cj)/W} themselves: PT_L kw sincospi per tile, shared by the kh kernel rows)
 //   E[k][i]    = e^{-2 pi i k (i-ci)/H}                    (PT_K kh values)                           -- the row factor, once per tile
 //   S_m[k,l]   = sum_i R[m][i][l] E[k][i]                  (kh complex fp64 products per entry instead of kh (1 + kw) sincospi)
 // Same operations in the same order as k_psf2otf on every entry (bit-identical tables); 15 x 15 PSF at 3 x 1024^2: 0.84 ms -> ~0.03 ms.
@@ -94,18 +95,24 @@ __global__ void __launch_bounds__(256) k_psf2otf_tiled(const double* __restrict_
   double2* Rt = smem_otf;                               // [kc][kh][PT_L]
   double2* Et = smem_otf + (size_t)kc * kh * PT_L;      // [PT_K][kh]
   const int ci = kh / 2, cj = kw / 2, cm = kc / 2;
+  double2* Ft = Et + (size_t)PT_K * kh;                 // [PT_L][kw]: the column phases, shared by the kh kernel rows
+  for (int e = threadIdx.x; e < PT_L * kw; e += blockDim.x) {
+    const int j = e % kw, l = l0 + e / kw;
+    long long pw = ((long long)l * (j - cj)) % W;
+    if (pw < 0) pw += W;
+    double sw, cw;
+    sincospi(-2.0 * (double)pw / (double)W, &sw, &cw);
+    Ft[e] = make_double2(cw, sw);
+  }
+  __syncthreads();
   for (int e = threadIdx.x; e < kc * kh * PT_L; e += blockDim.x) {
     const int ll = e % PT_L, i = (e / PT_L) % kh, m = e / (PT_L * kh);
-    const int l = l0 + ll;
     double rr = 0.0, ri = 0.0;
     for (int j = 0; j < kw; ++j) {
-      long long pw = ((long long)l * (j - cj)) % W;
-      if (pw < 0) pw += W;
-      double sw, cw;
-      sincospi(-2.0 * (double)pw / (double)W, &sw, &cw);
+      const double2 f = Ft[ll * kw + j];
       const double a = psf[((long)i * kw + j) * kc + m];
-      rr += a * cw;
-      ri += a * sw;
+      rr += a * f.x;
+      ri += a * f.y;
     }
     Rt[e] = make_double2(rr, ri);
   }
@@ -246,7 +253,7 @@ extern "C" int dpx_psf2otf(const double* psf, int kh, int kw, int kc, int C, int
   DPX_REQUIRE(kh <= H && kw <= W && kc <= C, "dpx_psf2otf: outsize [%d,%d,%d] cannot be smaller than the PSF [%d,%d,%d]",
               H, W, C, kh, kw, kc);   // psf2otf.py:53-54
   const long total = (long)table_elems(C, H, W);
-  const size_t sh = ((size_t)kc * kh * PT_L + (size_t)PT_K * kh) * sizeof(double2);
+  const size_t sh = ((size_t)kc * kh * PT_L + (size_t)PT_K * kh + (size_t)PT_L * kw) * sizeof(double2);
   static const bool direct = getenv("DPX_PSF2OTF_DIRECT") != nullptr;      // (A/B: the entry-by-entry kernel)
   if (sh <= 64 * 1024 && !direct) {
     const int Wl = (W % 2 == 0) ? W / 2 + 1 : (W + 1) / 2;

@@ -8,6 +8,17 @@ from .. import _ops as ops
 from .node import LinOp
 
 
+def _zero_preserving(node):
+    """a chain of built-in, shape-preserving linear nodes over one variable (exact types: a user subclass may do anything)"""
+    from .fourier import conv, grad
+    from .leaf import Variable
+    if type(node) is Variable:
+        return True
+    if type(node) in (conv, grad, scale) and getattr(node, "circular", True):
+        return all(_zero_preserving(k) for k in node.input_nodes)
+    return False
+
+
 def _expand_to(t, ref):
     return t if t.shape == ref.shape else t.expand_as(ref).contiguous()
 
@@ -22,6 +33,21 @@ class sum(LinOp):
     def adjoint(self, y, **kwargs):
         outs = LinOp.MultOutput([y for _ in self.input_nodes])
         return outs if len(outs) > 1 else outs[0]
+
+    @property
+    def offset(self):
+        """``K x + c_1 + ...`` with K a chain of the built-in shape-preserving linear nodes (the data term ``conv(x) - b``): the value
+        at x = 0 is the sum of the constants -- no transform of an all-zero image (linop/base.py:117-129 evaluates the whole graph;
+        a circular convolution / difference / scaling of zeros is exactly zero, so the result is the same tensor)"""
+        from .leaf import Constant
+        consts = [k for k in self.input_nodes if isinstance(k, Constant)]
+        others = [k for k in self.input_nodes if not isinstance(k, Constant)]
+        vs = self.variables
+        if consts and others and all(_zero_preserving(k) for k in others) and len(vs) == 1 and vs[0]._value is not None:
+            vals = [c.value for c in consts]
+            if all(v is not None and v.shape == vs[0]._value.shape for v in vals):
+                return vals[0] if len(vals) == 1 else ops.lincomb([(1.0, v) for v in vals])
+        return LinOp.offset.fget(self)
 
     def is_diag(self, freq=False):
         return all(a.is_diag(freq) for a in self.input_nodes)
