@@ -229,6 +229,11 @@ extern "C" int dpx_zero(void* p, size_t bytes, dpx_stream_t stream) {
 // ws (dpx_cg_masked_fft_ws_bytes): r, p, Ap [B n] floats; two complex [B n] buffers (the second one unused since the operator
 // became three fused launches); mask^2; state; Gram; dot workspace.
 // ---------------------------------------------------------------------------------------------------------------------
+namespace dpx { bool masked_normal_fits(int H, int W); }
+// 1 when dpx_cg_masked_fft takes this batch of planes (B <= 64 images, planes within its LDS-resident transforms): callers fall
+// back to the generic cg() loop on the same primitives otherwise
+extern "C" int dpx_cg_masked_fft_supported(int B, int H, int W) { return B >= 1 && B <= 64 && H > 0 && W > 0 && dpx::masked_normal_fits(H, W) ? 1 : 0; }
+constexpr int DPX_CG_MAX_DEVICES = 64;
 extern "C" size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_images) {
   const size_t n = (size_t)H * W;
   return (3 * B * n + 4 * B * n + (size_t)mask_images * n + 5 * B + 4 + (size_t)B * B + 64) * sizeof(float) + dpx_bdot_ws_bytes(B, (long)n) + 256;
@@ -244,7 +249,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   float* r = w;
   float* p = r + (size_t)B * n;
   float* Ap = p + (size_t)B * n;
-  float2* z0 = (float2*)(Ap + (size_t)B * n);
+  float2* z0 = (float2*)(Ap + (size_t)B * n + (((size_t)3 * B * n) & 1));      // (8-byte aligned also when 3 B n is odd; the slack is in ws_bytes)
   float2* z1 = z0 + (size_t)B * n;
   float* mask2 = (float*)(z1 + (size_t)B * n);
   float* state = mask2 + (size_t)mask_images * n;
@@ -253,25 +258,54 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   int* flags = (int*)(state + 5 * B);
   float* pAp = state + 3 * B;
 
-  // pinned ring for the flag read-backs + its events: created once per process (host-side resources only)
-  static int* pin = nullptr;
-  static hipEvent_t ev[4];
-  if (!pin) {
-    if (hipHostMalloc((void**)&pin, 4 * 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+  // pinned ring for the flag read-backs + its events: host-side resources, one set per (host thread, device) -- an event belongs to
+  // the device that was current when it was created, and two host threads solving at once must not share slots (this function
+  // returns only after it has waited for its own last event, so a thread has at most one solve in flight)
+  struct Ring {
+    int* pin = nullptr;
+    hipEvent_t ev[4];
+  };
+  static thread_local Ring rings[DPX_CG_MAX_DEVICES];
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= DPX_CG_MAX_DEVICES) {
+    set_error("dpx_cg_masked_fft: hipGetDevice failed / device id %d out of range", devid);
+    return DPX_ERR_LAUNCH;
+  }
+  Ring& R = rings[devid];
+  if (!R.pin) {
+    int* pnew = nullptr;
+    if (hipHostMalloc((void**)&pnew, 4 * 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
       set_error("dpx_cg_masked_fft: hipHostMalloc failed");
       return DPX_ERR_LAUNCH;
     }
-    for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    for (int i = 0; i < 4; ++i)
+      if (hipEventCreateWithFlags(&R.ev[i], hipEventDisableTiming) != hipSuccess) {
+        for (int k = 0; k < i; ++k) hipEventDestroy(R.ev[k]);
+        hipHostFree(pnew);
+        set_error("dpx_cg_masked_fft: hipEventCreate failed");
+        return DPX_ERR_LAUNCH;
+      }
+    R.pin = pnew;
   }
+  int* pin = R.pin;
+  hipEvent_t* ev = R.ev;
+  for (int i = 0; i < 16; ++i) pin[i] = 0;             // nothing left over from an earlier solve can read as "done"
+#define CG_HIP(call)                                                        \
+  do {                                                                      \
+    if ((call) != hipSuccess) {                                             \
+      set_error("dpx_cg_masked_fft: %s failed (%s)", #call, hipGetErrorString(hipGetLastError())); \
+      return DPX_ERR_LAUNCH;                                                \
+    }                                                                       \
+  } while (0)
 #define CG_TRY(call)                 \
   do {                               \
     const int rc_ = (call);          \
     if (rc_ != DPX_OK) return rc_;   \
   } while (0)
   // r = b, x = p = 0, tolerances
-  hipMemcpyAsync(r, b, (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, s);
-  hipMemsetAsync(x, 0, (size_t)B * n * sizeof(float), s);
-  hipMemsetAsync(p, 0, (size_t)B * n * sizeof(float), s);
+  CG_HIP(hipMemcpyAsync(r, b, (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  CG_HIP(hipMemsetAsync(x, 0, (size_t)B * n * sizeof(float), s));
+  CG_HIP(hipMemsetAsync(p, 0, (size_t)B * n * sizeof(float), s));
   DPX_LAUNCH("k_square", k_square, dim3(grid_for((long)mask_images * n, 256, 1024)), dim3(256), 0, s, mask2, mask, (long)mask_images * n);
   CG_TRY(dpx_bdot(b, b, gram, B, n, dotws, stream));                      // <b_i, b_i> (gram reused as scratch)
   CG_TRY(dpx_cg_init(state, gram, rtol, B, stream));
@@ -282,7 +316,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   int last = -1;
   for (int it = 0; it < n_it; ++it) {
     if (it >= LAG) {
-      hipEventSynchronize(ev[(it - LAG) & 3]);
+      CG_HIP(hipEventSynchronize(ev[(it - LAG) & 3]));
       if (pin[((it - LAG) & 3) * 4]) {
         done = true;
         done_it = pin[((it - LAG) & 3) * 4 + 1];
@@ -297,15 +331,16 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
     CG_TRY(masked_normal_apply(p, Ap, z0, mask2, mask_images, rho, n_identity, (const int*)flags, B, H, W, table, s));
     CG_TRY(dpx_bdot(p, Ap, pAp, B, n, dotws, stream));
     CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));
-    hipMemcpyAsync(pin + (it & 3) * 4, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);
-    hipEventRecord(ev[it & 3], s);
+    CG_HIP(hipMemcpyAsync(pin + (it & 3) * 4, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    CG_HIP(hipEventRecord(ev[it & 3], s));
     last = it;
   }
   if (!done && last >= 0) {
-    hipEventSynchronize(ev[last & 3]);
+    CG_HIP(hipEventSynchronize(ev[last & 3]));
     if (pin[(last & 3) * 4]) done_it = pin[(last & 3) * 4 + 1];
   }
 #undef CG_TRY
+#undef CG_HIP
   const int st = launch_status("dpx_cg_masked_fft");
   return st != DPX_OK ? st : done_it;
 }

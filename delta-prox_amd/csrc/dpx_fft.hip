@@ -9,6 +9,8 @@
 // list (2,3,4,5,7,8,11,13 in registers, any other prime by an O(p) per-output pass), half-length
 // complex transform for even row lengths, Nyquist column packed into column 0.  Power-of-two
 // planes take the register-radix kernels of dpx_fft_pow2.hip instead.
+#include <cstdlib>
+
 #include "dpx_common.h"
 
 namespace dpx {
@@ -68,14 +70,10 @@ template <> struct Twid<float2> {
   __device__ __forceinline__ float2 get(long long idx) const { return t[idx]; }
 };
 template <> struct Twid<double2> {
-  const double2* t;  // fp64 table exp(-2 pi i idx / len) (k_twiddle_table_f64), or NULL: evaluated on the fly
+  const double2* t;  // fp64 table exp(-2 pi i idx / len) (k_twiddle_table_f64); evaluating sincospi at every use instead put its
+                     // argument reduction into scratch memory: 4.0 GB of scratch writes per 100 MB image
   int len;           // table length the indices refer to
-  __device__ __forceinline__ double2 get(long long idx) const {
-    if (t) return t[idx];
-    double s, c;
-    sincospi(-2.0 * (double)idx / (double)len, &s, &c);
-    return make_double2(c, s);
-  }
+  __device__ __forceinline__ double2 get(long long idx) const { return t[idx]; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -433,7 +431,7 @@ __global__ void k_twiddle_table_f64(double2* tw, int n) {
 
 // rows: RPB image rows per workgroup; even W: length-W/2 complex transform of the (x[2n], x[2n+1]) pairs + real-input untangling
 template <bool EVEN>
-__global__ void k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict__ spec, int W, int nrows, int H, Plan1D plan,
+__global__ void __launch_bounds__(512) k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict__ spec, int W, int nrows, int H, Plan1D plan,
                                const double2* __restrict__ tw64, int rpb, int CT) {
   HIP_DYNAMIC_SHARED(double2, smem64)
   const int M = plan.n, ld = M + M / 8 + 1, Wh = W / 2 + 1, NTL = (Wh + CT - 1) / CT;
@@ -483,7 +481,7 @@ __global__ void k_rows_r2c_f64(const float* __restrict__ x, double2* __restrict_
 // columns of the fp64 half spectrum, CT per workgroup -> packed fp32 spectrum times the OTF.  Even W: the Nyquist column
 // (l = W/2) has to meet the DC column (packed layouts carry it as the imaginary part of column 0), so workgroup 0 takes it in its
 // last slot and the workgroup that would have held it takes column CT-1 instead.
-__global__ void k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restrict__ out, const float2* __restrict__ otf,
+__global__ void __launch_bounds__(512) k_cols_fwd_f64(const double2* __restrict__ spec, float2* __restrict__ out, const float2* __restrict__ otf,
                                int conj_otf, int accumulate, int C, int H, int W, Plan1D plan, int side_layout, int P,
                                const double2* __restrict__ tw64, int CT) {
   HIP_DYNAMIC_SHARED(double2, smem64)
@@ -772,6 +770,14 @@ int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, i
   return launch_status("spectral_apply");
 }
 
+// does a plane fit the LDS-resident transforms of masked_normal_apply?  (the same arithmetic as below)
+bool masked_normal_fits(int H, int W) {
+  const int rpb = rows_per_block(W);
+  int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
+  CT = CT < 1 ? 1 : (CT > 16 ? 16 : CT);
+  return (size_t)2 * rpb * (W + 1) * sizeof(float2) <= 64 * 1024 && (size_t)2 * CT * (H + 1) * sizeof(float2) <= 64 * 1024;
+}
+
 // z: one complex [B][H][W] scratch plane set.  Returns DPX_ERR_UNSUPPORTED for planes beyond the LDS-resident transform.
 int masked_normal_apply(const float* p, float* Ap, float2* z, const float* mask2, int mask_images, const float* rho, float c, const int* done,
                         int B, int H, int W, const void* table, hipStream_t s) {
@@ -834,8 +840,9 @@ static size_t ds_ld(int n) { return (size_t)n + n / 8 + 1; }      // padded LDS 
 static int ds_ct(int H) { return 4 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 4 : (2 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 2 : 0); }
 static int ds_rpb(int W) {
   const int M = (W % 2 == 0) ? W / 2 : W;
-  for (int r = 4; r >= 1; r >>= 1)
-    if ((size_t)r * 2 * ds_ld(M) * sizeof(double2) <= 80 * 1024) return r;
+  // (measured at 8x3x1024^2, 256 threads: 2 rows per workgroup -- 4 workgroups per CU -- 174 us, 4 rows 207 us, 1 row 225 us)
+  for (int r = 2; r >= 1; r >>= 1)
+    if ((size_t)r * 2 * ds_ld(M) * sizeof(double2) <= 40 * 1024) return r;
   return 2 * ds_ld(M) * sizeof(double2) <= 160 * 1024 ? 1 : 0;
 }
 static size_t ds_spec_elems(int P, int H, int W) {
@@ -850,7 +857,11 @@ extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, 
   DPX_REQUIRE(b && spec_out && ws, "dpx_data_spectrum: null pointer");
   DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_data_spectrum: bad shape");
   const int P = B * C, Wh = W / 2 + 1;
-  const int CT = ds_ct(H), rpb = ds_rpb(W);
+  static const int env_rpb = getenv("DPX_DS_RPB") ? atoi(getenv("DPX_DS_RPB")) : 0, env_rt = getenv("DPX_DS_ROW_THREADS") ? atoi(getenv("DPX_DS_ROW_THREADS")) : 0,
+                   env_ct = getenv("DPX_DS_COL_THREADS") ? atoi(getenv("DPX_DS_COL_THREADS")) : 0;     // tuning
+  const int CT = ds_ct(H);
+  int rpb = ds_rpb(W);
+  if (env_rpb && env_rpb <= rpb) rpb = env_rpb;
   if (!CT || !rpb) {
     set_error("dpx_data_spectrum: plane %dx%d too large for the LDS-resident fp64 transform", H, W);
     return DPX_ERR_UNSUPPORTED;
@@ -867,7 +878,7 @@ extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, 
   const int nrows = P * H;
   if (even) {
     if (shrow > 48 * 1024) hipFuncSetAttribute((const void*)k_rows_r2c_f64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shrow);
-    DPX_LAUNCH("k_rows_r2c_f64", k_rows_r2c_f64<true>, dim3((nrows + rpb - 1) / rpb), dim3(256), shrow, s, b, spec64, W, nrows, H, make_plan(M),
+    DPX_LAUNCH("k_rows_r2c_f64", k_rows_r2c_f64<true>, dim3((nrows + rpb - 1) / rpb), dim3(env_rt ? env_rt : 256), shrow, s, b, spec64, W, nrows, H, make_plan(M),
                (const double2*)twW, rpb, CT);
   } else {
     if (shrow > 48 * 1024) hipFuncSetAttribute((const void*)k_rows_r2c_f64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shrow);
@@ -875,7 +886,7 @@ extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, 
                (const double2*)twW, rpb, CT);
   }
   if (shcol > 48 * 1024) hipFuncSetAttribute((const void*)k_cols_fwd_f64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
-  DPX_LAUNCH("k_cols_fwd_f64", k_cols_fwd_f64, dim3((Wh + CT - 1) / CT, P), dim3(CT >= 4 ? 512 : 256), shcol, s, (const double2*)spec64,
+  DPX_LAUNCH("k_cols_fwd_f64", k_cols_fwd_f64, dim3((Wh + CT - 1) / CT, P), dim3(env_ct ? env_ct : (CT >= 4 ? 512 : 256)), shcol, s, (const double2*)spec64,
              (float2*)spec_out, (const float2*)otf, conj_otf, accumulate, C, H, W, make_plan(H),
              pow2_path_available(H, W) ? 1 : 0, P, (const double2*)twH, CT);
   return launch_status("dpx_data_spectrum");

@@ -28,6 +28,11 @@ class DpxError(RuntimeError):
     pass
 
 
+class F16RangeError(DpxError):
+    """an operand of the split-f16 FFDNet arithmetic left the binary16 range: the result of that solve / denoise() call is invalid
+    (the callers re-run on the split-bf16 arithmetic, see ``f16_fallback``)"""
+
+
 class Term(ctypes.Structure):
     """``dpx_term`` of include/dpx.h."""
     _fields_ = [("linop", c_int32), ("prox", c_int32), ("alpha", c_float), ("reserved", c_int32),
@@ -102,6 +107,7 @@ SIGNATURES = {
     "dpx_cg_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "dpx_cg_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "dpx_cg_masked_fft_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dpx_cg_masked_fft_supported": (c_int, [c_int, c_int, c_int]),
     "dpx_cg_masked_fft": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpx_prox": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
     "dpx_prox_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_long, c_void_p]),
@@ -235,9 +241,24 @@ def check_f16_range(where):
         return
     _f16_pending = False
     if lib().query("dpx_ffdnet_f16_overflow", 1):
-        raise DpxError(f"{where}: an activation or weight left the binary16 range (|x| > 6e4) in the split-f16 arithmetic of the "
-                       "FFDNet layers -- that result is invalid.  Set `<denoiser>.model.compute_mode = 'bf16x3'` (any range, "
-                       "~1.4x slower) and rerun")
+        raise F16RangeError(f"{where}: an activation or weight left the binary16 range (|x| > 6e4) in the split-f16 arithmetic of the "
+                            "FFDNet layers -- that result is invalid.  Set `<denoiser>.model.compute_mode = 'bf16x3'` (any range, "
+                            "~1.4x slower) and rerun")
+
+
+def f16_fallback(modules, where):
+    """The networks among ``modules`` that ran split-f16 are switched to split-bf16 (fp32's range, six products instead of three)
+    for good and the caller re-runs; returns False when there is nothing to switch (or a network asks to raise instead:
+    ``model.f16_fallback = 'raise'``), in which case the caller re-raises."""
+    import warnings
+    nets = [m for m in modules if getattr(m, "compute_mode", None) == "f16x2"]
+    if not nets or any(getattr(m, "f16_fallback", "bf16x3") == "raise" for m in nets):
+        return False
+    for m in nets:
+        m.compute_mode = "bf16x3"
+    warnings.warn(f"{where}: an operand left the binary16 range of the split-f16 FFDNet arithmetic; re-running on split-bf16 "
+                  "(compute_mode = 'bf16x3', any range, ~1.4x slower) -- the network keeps that mode", RuntimeWarning, stacklevel=3)
+    return True
 
 
 class solve_scope:

@@ -77,6 +77,17 @@ class UnrolledSolver(nn.Module):
                 setattr(self, names[i] if last else f"{names[i]}#{i}", lam)
                 self.lams[fn] = lam
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """A reference checkpoint holds ``rhos`` and ONE entry per term class (unroll.py:35-38): the suffixed names this class gives to
+        earlier terms of a repeated class (``norm1#0``) are optional on load -- absent, they start from the class's un-suffixed entry
+        (what the reference trained for the term that kept the name), so ``load_state_dict(strict=True)`` accepts its checkpoints."""
+        if self.learned_params:
+            for name, _ in list(self.named_parameters(recurse=False)):
+                if "#" in name and prefix + name not in state_dict and prefix + name.split("#")[0] in state_dict:
+                    state_dict = dict(state_dict) if not isinstance(state_dict, dict) or "#patched" not in state_dict else state_dict
+                    state_dict[prefix + name] = state_dict[prefix + name.split("#")[0]]
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     def solve(self, x0=None, rhos=None, lams=None, max_iter=None, **kwargs):
         from .driver import to_tensor
         first = self.solvers[0]

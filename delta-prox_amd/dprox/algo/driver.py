@@ -105,11 +105,21 @@ class Algorithm(nn.Module):
         x0, rhos, lams, max_iter = self.defaults(x0, rhos, lams, max_iter)
         # every kernel of the solve is issued on the current stream of the SOLVER's GPU (the C ABI takes a raw stream handle:
         # launching with another device current would run GPU-k pointers on GPU-0's stream)
-        with be.device_guard(device), be.solve_scope("solve"):
-            x0, rhos, lams = move(x0, rhos, lams, device=device)
-            x0 = x0.contiguous()
-            state = self.initialize(x0, **kwargs)
-            state = self.iters(state, rhos, lams, max_iter, pbar, callback=callback)
+        def run():
+            with be.device_guard(device), be.solve_scope("solve"):
+                xs, rs, ls = move(x0, rhos, lams, device=device)
+                state = self.initialize(xs.contiguous(), **kwargs)
+                return self.iters(state, rs, ls, max_iter, pbar, callback=callback)
+        try:
+            state = run()
+        except be.F16RangeError:
+            # a split-f16 denoiser layer met an operand outside the binary16 range: that solve is invalid -- run it again from x0 on
+            # the split-bf16 arithmetic (the networks keep that mode; the callback sees the iterations of both runs)
+            nets = [m for fn in list(self.psi_fns) + list(self.omega_fns) if isinstance(getattr(fn, "denoiser", None), torch.nn.Module)
+                    for m in fn.denoiser.modules()]
+            if not be.f16_fallback(nets, "solve"):
+                raise
+            state = run()
         return state if return_full_states else state[0]
 
     def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):

@@ -67,11 +67,22 @@ def masked_fft(arg, mask):
             super().__init__([a])
             self.mask = m
 
+        def _plane_mask(self, ref):
+            """the mask as one plane per image or per batch: a broadcastable mask (a column profile [1,1,1,W], a row profile) is
+            expanded once to [.., H, W] -- the kernels take whole planes"""
+            import torch
+            m = self.mask
+            H, W = int(ref.shape[-2]), int(ref.shape[-1])
+            if isinstance(m, torch.Tensor) and m.ndim >= 2 and tuple(m.shape[-2:]) != (H, W):
+                m = m.expand(*m.shape[:-2], H, W).contiguous()
+                self.mask = m
+            return m
+
         def forward(self, x, **kw):
-            return ops.cplx_scale(ops.cfft2(x, inverse=False, centred=True, ortho=True), self.mask)
+            return ops.cplx_scale(ops.cfft2(x, inverse=False, centred=True, ortho=True), self._plane_mask(x))
 
         def adjoint(self, y, **kw):
-            z = ops.cfft2(ops.cplx_scale(y.contiguous(), self.mask), inverse=True, centred=True, ortho=True)
+            z = ops.cfft2(ops.cplx_scale(y.contiguous(), self._plane_mask(y)), inverse=True, centred=True, ortho=True)
             return ops.clincomb([(1.0, z)], out_complex=False)
 
     return _MaskedFFT(arg, mask)

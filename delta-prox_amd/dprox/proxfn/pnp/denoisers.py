@@ -22,7 +22,12 @@ class Denoiser(nn.Module):
         """input: [N,C,H,W]; sigma: 0-d or [N]"""
         sigma = sigma.view(-1, 1, 1, 1)
         out = self._denoise(input, sigma)
-        be.check_f16_range("denoise")           # (no-op inside a solve: checked once at its end)
+        try:
+            be.check_f16_range("denoise")       # (no-op inside a solve: checked once at its end)
+        except be.F16RangeError:
+            if not be.f16_fallback(self.modules(), "denoise"):
+                raise
+            out = self._denoise(input, sigma)    # split-bf16: fp32's range
         return out
 
     def _denoise(self, x, sigma):
@@ -34,8 +39,14 @@ class Denoiser2D(Denoiser):
 
     def denoise(self, input: torch.Tensor, sigma: torch.Tensor):
         sigma = sigma.view(-1, 1, 1, 1)
-        out = torch.cat([self._denoise(band.contiguous(), sigma) for band in input.split(1, dim=1)], dim=1)
-        be.check_f16_range("denoise")
+        run = lambda: torch.cat([self._denoise(band.contiguous(), sigma) for band in input.split(1, dim=1)], dim=1)
+        out = run()
+        try:
+            be.check_f16_range("denoise")
+        except be.F16RangeError:
+            if not be.f16_fallback(self.modules(), "denoise"):
+                raise
+            out = run()
         return out
 
 
@@ -119,6 +130,10 @@ class FFDNet(RefKeyed):
         #               The default wherever the layer widths are multiples of 16;
         #   "bf16"   -- plain bf16 operands, fp32 accumulation (bf16 training / inference mode, ~3e-3 relative).
         self.compute_mode = os.environ.get("DPX_FFDNET_MODE", "f16x2" if nc % 16 == 0 else "f32")
+        # what happens when a "f16x2" forward meets an operand outside the binary16 range (a checkpoint with a large dynamic range):
+        # "bf16x3" -- the enclosing solve() / denoise() is re-run on the split-bf16 arithmetic and the network keeps that mode
+        # (a RuntimeWarning says so); "raise" -- be.F16RangeError
+        self.f16_fallback = os.environ.get("DPX_F16_FALLBACK", "bf16x3")
         self._packed_bf16 = None
 
     @property

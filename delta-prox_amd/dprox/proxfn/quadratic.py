@@ -11,6 +11,7 @@
 """
 from typing import List
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -29,6 +30,8 @@ class sum_squares(ProxFn):
     def __init__(self, linop, b=None, eps=1e-7):
         super().__init__(linop)
         self.eps = eps
+        if isinstance(b, np.ndarray):                      # converted once: a tensor's edits can be watched (version counter), an
+            b = torch.from_numpy(np.ascontiguousarray(b))   # array's cannot, and re-reading it on every use rebuilt every cache
         self._b = b
 
     def _offset_key(self):
@@ -305,12 +308,24 @@ class least_squares(ProxFn):
             return None
         return op.mask, float(len(self.other_fns) + (1 if with_identity else 0))
 
+    @staticmethod
+    def _masked_fft_fits(mask, Ktb):
+        """the fused CG call takes one mask per plane or per image, real, on planes its LDS-resident transforms hold; anything else
+        (a broadcastable [1,1,1,W] mask, a huge plane) goes down the generic cg() loop"""
+        B, _, H, W = Ktb.shape
+        if not isinstance(mask, torch.Tensor) or mask.is_complex() or mask.numel() not in (H * W, B * H * W):
+            return False
+        if tuple(mask.shape[-2:]) != (H, W):
+            return False
+        return bool(be.lib().query("dpx_cg_masked_fft_supported", B, H, W))
+
     def solve_cg_rhs(self, Ktb, rho_v, with_identity=False, linear_solve_config=None):
         """the CG x-update for an already assembled right-hand side ``Ktb``; records the exit iteration in ``cg_iters``"""
         cfg = linear_solve_config or self.linear_solve_config
         plain = cfg.solver_type == "cg" and not cfg.verbose and not (torch.is_grad_enabled() and Ktb.requires_grad)
         sysm = self._masked_fft_system(with_identity) if plain else None
-        if sysm is not None and Ktb.ndim == 4 and Ktb.shape[1] == 1 and Ktb.shape[0] <= 64 and not be.host_mode_skip_fast_cg():
+        if sysm is not None and Ktb.ndim == 4 and Ktb.shape[1] == 1 and Ktb.shape[0] <= 64 and not be.host_mode_skip_fast_cg() \
+                and self._masked_fft_fits(sysm[0], Ktb):
             x, n = ops.cg_masked_fft(Ktb.contiguous(), sysm[0], rho_v, sysm[1], cfg.rtol, cfg.max_iters)   # one C call per solve
             self.cg_iters.append(n)
             return x

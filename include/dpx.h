@@ -227,6 +227,8 @@ int dpx_cg_update(float* x, float* r, const float* p, const float* Ap, void* sta
  * Kernels only (dpx_cfft2, mask^2, dpx_cg_*); the host side polls the device's `done` flag two iterations late through a pinned
  * buffer.  Returns the exit iteration (>= 0; max_iters when not converged) or a negative status.  1 <= B <= 64.             */
 size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_images);
+/* 1 when dpx_cg_masked_fft takes this batch (B <= 64, planes within its LDS-resident transforms); else use dpx_cg_* step by step */
+int dpx_cg_masked_fft_supported(int B, int H, int W);
 int dpx_cg_masked_fft(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol,
                       int max_iters, int B, int H, int W, const void* table, void* ws, dpx_stream_t stream);
 

@@ -288,3 +288,5 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipHostFree(void* p) { free(p); return 0; }

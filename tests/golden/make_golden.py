@@ -100,9 +100,9 @@ def gauss(k, s):
 # --------------------------------------------------------------------------------------
 # reference denoiser wrappers holding seeded weights
 # --------------------------------------------------------------------------------------
-def load_ffdnet(in_nc, out_nc, nc, nb, seed):
+def load_ffdnet(in_nc, out_nc, nc, nb, seed, gain=0.5):
     net = FFDNet(in_nc=in_nc, out_nc=out_nc, nc=nc, nb=nb, act_mode="R")
-    layers = ffdnet_weights(seed, in_nc, out_nc, nc, nb)
+    layers = ffdnet_weights(seed, in_nc, out_nc, nc, nb, gain=gain)
     sd = {}
     for i, (w, b) in enumerate(layers):
         sd[f"model.{2 * i}.weight"] = T(w)
@@ -355,6 +355,21 @@ def g8_ffdnet():
         out["gray_x"] = xg
         out["gray_s0.1"] = gray.denoise(xg, torch.tensor(0.1))
     save("g8_ffdnet", **out)
+
+
+def g8b_ffdnet_wide_range():
+    """FFDNet-colour with LARGE-dynamic-range weights (He-normal x 8 instead of x 0.5: activations grow ~8x per layer and leave the
+    binary16 range after a few layers; fp32 carries them): the forward the split-f16 -> split-bf16 fallback is pinned on
+    (models/network_ffdnet.py:54-68)."""
+    rng = np.random.RandomState(1808)
+    col = ColorDen(7)
+    col.model = load_ffdnet(3, 3, 96, 12, 7, gain=8.0)
+    col = col.eval()
+    x = T(rng.rand(1, 3, 32, 40).astype("float32"))
+    with torch.no_grad():
+        y = col.denoise(x, torch.tensor(0.05))
+    assert torch.isfinite(y).all() and float(y.abs().max()) > 1e6
+    save("g8b_ffdnet_wide_range", x=x, y=y, gain=np.float32(8.0), sigma=np.float32(0.05))
 
 
 def g9_admm_pnp():
@@ -933,6 +948,28 @@ def g30_full_c2():
     save("g30_full_c2", **out)
 
 
+def g30b_full_c2_batch8():
+    """config 2 exactly as BASELINE.json states it: the whole batch of 8 x 3 x 1024 x 1024, ADMM TV-deconv, rho 0.1, lam 0.005,
+    50 iterations -- the final x (::8 samples + per-image sums / L2 norms) and the iterate after 25 iterations, with the float64
+    evaluation of the same 50 iterations next to them (algo/admm.py:49-59, proxfn/sum_square.py:123-156)."""
+    gt, b, psf = synthetic.deconv_case(8, 3, 1024, 1024, seed=2304)
+    x = dp.Variable()
+    fns = _tv_problem(x, T(b), psf)
+    out = {"seed": 2304}
+
+    def cb(iter, state, rho, lam):
+        if iter + 1 == 25:
+            _pack(out, "it25_x", state[0], 8)
+
+    xo = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=0.1, lams=0.005, max_iter=50, callback=cb)
+    _pack(out, "x", xo, 8)
+    out["psnr"] = np.array([10 * np.log10(1.0 / np.mean((xo[i].numpy() - gt[i]) ** 2)) for i in range(8)])
+    lam50 = np.full(50, 0.005, np.float32)
+    x64, _, _ = admm_f64(b, psf, [("grad0", "norm1", 1.0), ("grad1", "norm1", 1.0)], np.full(50, 0.1, np.float32), [lam50, lam50], 50)
+    _pack(out, "x_f64", torch.from_numpy(np.asarray(x64)), 8)
+    save("g30b_full_c2_batch8", **out)
+
+
 def g31_full_c3():
     """config 3 at its real plane size: one 3x1024x1024 image, ADMM with the FFDNet-colour prior (seeded weights), the first
     3 iterations of the log_descent(35, 5, 30) schedule (proxfn/pnp/prior.py:42-89, algo/tune/dpir.py:13-39)."""
@@ -1088,8 +1125,8 @@ def g36_hqs_pow2():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet,
+    for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet, g8b_ffdnet_wide_range,
                g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
-               g30_full_c2, g31_full_c3, g32_full_c4, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2):
+               g30_full_c2, g30b_full_c2_batch8, g31_full_c3, g32_full_c4, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -368,6 +368,22 @@ def case_cg_masked_fft_shapes(device):
         e = rel_l2(x.cpu().numpy(), xr.numpy())
         record(f"cg_masked_fft {B}x1x{H}x{W} per-image-mask={per_image} vs float64 solve", e, 1e-5)
         assert e <= 1e-5, (B, H, W, per_image, e, n_it)
+    # a mask the fused call does not take (one column profile, broadcast over the rows) must go down the generic cg() loop, not
+    # trip an assertion: LADMM through the public API, against the same problem with the mask expanded to the plane
+    from dprox.contrib import masked_fft
+    from dprox.linalg import LinearSolveConfig
+    B, H, W = 2, 24, 20
+    col = (rng.rand(1, 1, 1, W) < 0.5).astype(np.float32)
+    y = (rng.randn(B, 1, H, W) + 1j * rng.randn(B, 1, H, W)).astype(np.complex64)
+    outs = []
+    for m in (col, np.broadcast_to(col, (1, 1, H, W)).copy()):
+        mt = T(m, device)
+        yt = (torch.from_numpy(y).to(device) * mt).contiguous()
+        xv = dp.Variable()
+        s = dp.compile(dp.sum_squares(masked_fft(xv, mt), yt) + dp.nonneg(xv), method="ladmm", device=device,
+                       linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=50))
+        outs.append(s.solve(x0=torch.zeros(B, 1, H, W, device=device), rhos=0.5, lams=0.1, max_iter=2).cpu().numpy())
+    assert rel_l2(outs[0], outs[1]) <= 1e-5, rel_l2(outs[0], outs[1])
 
 
 def case_dense_krylov(device):
@@ -468,14 +484,56 @@ def case_ffdnet_f16_split(device, tiny=False):
         else:
             assert_close(out.cpu(), g["odd_s0.02"], TOL, "FFDNet split-f16 odd sigma 0.02")
         big = (x * 3.0e5).contiguous()
-        with pytest.raises(be.DpxError, match="binary16"):
+        col.model.f16_fallback = "raise"
+        with pytest.raises(be.F16RangeError, match="binary16"):
             col.denoise(big, sig)
-        col.model.compute_mode = "bf16x3"
+        col.model.f16_fallback = "bf16x3"                    # the default: re-run on split-bf16, the network keeps that mode
+        with pytest.warns(RuntimeWarning, match="split-bf16"):
+            auto = col.denoise(big, sig)
+        assert col.model.compute_mode == "bf16x3"
         ref = col.denoise(big, sig)
         col.model.compute_mode = "f32"
         r32 = col.denoise(big, sig)
     assert torch.isfinite(ref).all() and rel_l2(ref.cpu().numpy(), r32.cpu().numpy()) < 1e-5
+    assert torch.equal(auto, ref)
     col.model.compute_mode = "f16x2"
+
+
+def case_ffdnet_wide_range(device):
+    """G8b: a checkpoint with a large dynamic range (He-normal x 8: activations ~8x per layer, out of binary16 range after a few
+    layers).  denoise() on the default split-f16 arithmetic trips the range trap, is re-run on split-bf16 automatically and matches
+    the reference's fp32 forward at 1e-5; a solve() does the same (one re-run of the whole solve, same iterates as a solver that
+    started on split-bf16)."""
+    import synthetic
+    from dprox.proxfn.pnp.denoisers import FFDNetColorDenoiser
+    g = load_golden("g8b_ffdnet_wide_range")
+    wts = synthetic.ffdnet_weights(7, gain=float(g["gain"]))
+    col = FFDNetColorDenoiser(wts).to(device)
+    assert col.model.compute_mode == "f16x2"
+    x = T(g["x"], device)
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match="split-bf16"):
+            y = col.denoise(x, torch.tensor(float(g["sigma"]), device=device))
+    assert col.model.compute_mode == "bf16x3"
+    assert_close(y.cpu(), g["y"], TOL, "FFDNet wide-range weights: split-f16 -> split-bf16 fallback")
+    # the same through a solve: PnP ADMM, 2 iterations
+    gt, b0, psf = synthetic.deconv_case(1, 3, 32, 40, seed=88)
+    b = T(b0, device)
+
+    def solve(mode):
+        den = FFDNetColorDenoiser(wts).to(device)
+        den.model.compute_mode = mode
+        xv = dp.Variable()
+        prior = dp.deep_prior(xv, denoiser=den)
+        s = dp.compile(dp.sum_squares(dp.conv(xv, psf) - b) + prior, method="admm", device=device)
+        with torch.no_grad():
+            out = s.solve(x0=b, rhos=0.5, lams={prior: 0.05}, max_iter=2)
+        return out, den
+    with pytest.warns(RuntimeWarning, match="split-bf16"):
+        auto, den = solve("f16x2")
+    assert den.model.compute_mode == "bf16x3"
+    direct, _ = solve("bf16x3")
+    assert torch.isfinite(auto).all() and torch.equal(auto, direct)
 
 
 def case_ffdnet(device, which=("odd", "even", "batch", "gray")):
@@ -676,6 +734,17 @@ def case_unrolled_solver(device):
     assert_close(xo.detach().cpu(), g["us_x"], TOL, "UnrolledSolver x")
     assert_close(us.rhos.grad.cpu(), g["us_g_rhos"], 1e-5, "UnrolledSolver d loss / d rhos", maxabs_mult=4.0)
     assert_close(list(us.lams.values())[0].grad.cpu(), g["us_g_lam"], 5e-5, "UnrolledSolver d loss / d lams")   # (measured 2.4e-5: a sum over threshold masks)
+    # a checkpoint in the REFERENCE's format (unroll.py:35-38: `rhos` + one entry per term class, so two norm1 terms share "norm1")
+    # loads with strict=True: the suffixed name of the earlier term starts from the class's entry
+    xv = dp.Variable()
+    two = dp.compile(dp.sum_squares(dp.conv(xv, g["psf"] if "psf" in g else np.ones((3, 3), np.float32) / 9) - b)
+                     + dp.norm1(dp.grad(xv, dim=0)) + dp.norm1(dp.grad(xv, dim=1)), method="admm", device=device)
+    us2 = dp.specialize(two, method="unroll", device=device, max_iter=3, share=False, learned_params=True)
+    ref_ckpt = {k: v for k, v in us2.state_dict().items() if "#" not in k}
+    ref_ckpt["rhos"] = torch.tensor([0.3, 0.2, 0.1])
+    ref_ckpt["norm1"] = torch.tensor([0.03, 0.02, 0.012])
+    us2.load_state_dict(ref_ckpt, strict=True)
+    assert all(torch.equal(p.detach().cpu(), ref_ckpt["norm1"]) for p in us2.lams.values())
 
 
 def _assert_grad_close(got, ref, what, tol=1e-4, flip_frac=0.08, flip_rel=5e-2):

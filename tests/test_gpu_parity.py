@@ -114,6 +114,11 @@ def test_ffdnet_split_f16_and_its_range_trap():
     pc.case_ffdnet_f16_split(DEV)
 
 
+@pytest.mark.gpu
+def test_ffdnet_wide_range_weights_fall_back_to_split_bf16():
+    pc.case_ffdnet_wide_range(DEV)
+
+
 def test_linear_solve_implicit_backward():
     pc.case_linear_solve_grad(DEV)
 

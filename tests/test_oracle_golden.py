@@ -181,6 +181,14 @@ def test_g8_ffdnet():
     assert sum(w.size + b.size for w, b in O.ffdnet_weights(7)) == 852108
 
 
+def test_g8b_ffdnet_wide_range():
+    """the large-dynamic-range checkpoint stand-in (He-normal x 8) the split-f16 -> split-bf16 fallback is pinned on"""
+    g = load_golden("g8b_ffdnet_wide_range")
+    col = O.FFDNetOracle(O.ffdnet_weights(7, gain=float(g["gain"])))
+    with torch.no_grad():
+        assert_close(col(T(g["x"]), torch.tensor(float(g["sigma"]))), g["y"], 5e-6, "wide-range weights")
+
+
 def test_pixel_unshuffle_order():
     """channel = c*4 + dy*2 + dx; PixelShuffle(2) is the exact inverse."""
     x = torch.arange(16.0).view(1, 1, 4, 4)
