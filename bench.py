@@ -325,11 +325,17 @@ def sharded_runs(dp, synthetic, dist, rank, world, device):
         consts = {"psf": torch.from_numpy(psf0).to(device)}
     consts = dd.broadcast_constants(consts if rank == 0 else None, src=0, device=device, comm=comm)
     psf = consts["psf"].cpu().numpy()
+    # compiled ONCE per rank, outside the timed call: the observation is a Placeholder that every call fills with its slice; the
+    # OTF / denominator tables are built on rank 0 and broadcast (dprox.distributed.share_tables) instead of rebuilt per rank
+    obs2 = dp.Placeholder()
+    x2 = dp.Variable()
+    s2 = dp.compile(dp.sum_squares(dp.conv(x2, psf) - obs2) + dp.norm1(dp.grad(x2, dim=0)) + dp.norm1(dp.grad(x2, dim=1)), method="admm", device=device)
+    dd.share_tables(s2, (max(B // world, 1), C, H, W), src=0, device=device, comm=comm)
+
     def solve_c2(loc):
         bb = loc["b"]
-        x = dp.Variable()
-        s = dp.compile(dp.sum_squares(dp.conv(x, psf) - bb) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device=device)
-        return s.solve(x0=bb, rhos=RHO, lams=LAM, max_iter=50)
+        obs2.value = bb
+        return s2.solve(x0=bb, rhos=RHO, lams=LAM, max_iter=50)
 
     g2 = guarded(solve_c2, (C, H, W))
     dt, xs = timed(lambda inp: dd.solve_sharded(g2, inp, src=0, device=device, comm=comm), {"b": b} if rank == 0 else None)
@@ -348,15 +354,22 @@ def sharded_runs(dp, synthetic, dist, rank, world, device):
         y_d = torch.from_numpy(y).to(device)
         y_ri = torch.view_as_real(y_d).contiguous()        # complex tensors travel as [.., 2] float32
     consts4 = dd.broadcast_constants(consts4 if rank == 0 else None, src=0, device=device, comm=comm)
-    wts = synthetic.ffdnet_weights(11, 1, 1, 64, 15)       # seeded: identical on every rank (a real checkpoint would be broadcast like the mask)
+    # the denoiser's weights exist on rank 0 (a real checkpoint would be loaded there) and reach the others by broadcast; solver and
+    # denoiser are built ONCE per rank, outside the timed call; the k-space data is a Placeholder filled per call
+    den4 = FFDNetDenoiser(synthetic.ffdnet_weights(11, 1, 1, 64, 15) if rank == 0 else None).to(device)
+    sd = dd.broadcast_constants({k: v.detach() for k, v in den4.state_dict().items()} if rank == 0 else None, src=0, device=device, comm=comm)
+    if rank != 0:
+        den4.load_state_dict(sd, strict=True)
+    y4 = dp.Placeholder()
+    x4 = dp.Variable()
+    fns4 = dp.sum_squares(masked_fft(x4, consts4["mask"]), y4) + dp.nonneg(x4) + dp.deep_prior(x4, denoiser=den4)
+    s4 = dp.compile(fns4, method="ladmm", device=device, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100))
 
     def solve_c4(loc):
         yy = torch.view_as_complex(loc["y"].contiguous())
-        x = dp.Variable()
-        fns = dp.sum_squares(masked_fft(x, consts4["mask"]), yy) + dp.nonneg(x) + dp.deep_prior(x, denoiser=FFDNetDenoiser(wts))
-        s = dp.compile(fns, method="ladmm", device=device, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100))
+        y4.value = yy
         with torch.no_grad():
-            return s.solve(x0=ifft2(yy).real.contiguous(), rhos=0.5, lams=0.03, max_iter=10)
+            return s4.solve(x0=ifft2(yy).real.contiguous(), rhos=0.5, lams=0.03, max_iter=10)
 
     g4 = guarded(solve_c4, (1, 320, 320))
     dt, _ = timed(lambda inp: dd.solve_sharded(g4, inp, src=0, device=device, comm=comm), {"y": y_ri} if rank == 0 else None)
@@ -471,6 +484,22 @@ def main():
     psnr_in, psnr_out = psnr_per_image(b, gt), psnr_per_image(out, gt)
     del out
     setup = setup_profile(dp, be, b, psf, device) if rank == 0 else None
+    # ---- second quality leg: the same solver settings on a detail-scaled synthetic (synthetic.synth_detail: the SURVEY generator's
+    #      cosines have <= 8 cycles per IMAGE whatever the plane size, so at 1024 x 1024 the blur hardly hurts and the deconvolution
+    #      has nothing to win -- 36.8 dB in, 36.7 dB out; with the detail of a 256 x 256 image per 256 x 256 pixels it has)
+    quality_detail = None
+    if rank == 0 and not a.no_extra_configs:
+        rngd = np.random.RandomState(4023)
+        gtd = torch.from_numpy(synthetic.synth_detail(rngd, B, C, H, W)).to(device)
+        bd = (dp.conv(dp.Variable(), psf).to(device).forward(gtd) + torch.from_numpy((rngd.randn(B, C, H, W) * (2.0 / 255.0)).astype(np.float32)).to(device)).contiguous()
+        xd = dp.Variable()
+        sd_ = dp.compile(dp.sum_squares(dp.conv(xd, psf) - bd) + dp.norm1(dp.grad(xd, dim=0)) + dp.norm1(dp.grad(xd, dim=1)), method="admm", device=device)
+        outd = sd_.solve(x0=bd, rhos=RHO, lams=LAM, max_iter=50)
+        pin, pout = psnr_per_image(bd, gtd), psnr_per_image(outd, gtd)
+        quality_detail = {"generator": "synthetic.synth_detail (seed 4023): cosines up to 8 cycles per 256 pixels, 128 rectangles of 16..85 pixels per plane",
+                          "input_mean": float(np.mean(pin)), "admm50_mean": float(np.mean(pout)), "gain_db": float(np.mean(pout) - np.mean(pin)),
+                          "admm50_per_image": pout}
+        del gtd, bd, outd, sd_, xd
 
     # The strong-scaling companions run collectives; a rank that fails or stalls inside them must not take the headline line with
     # it: they run in a worker thread with a deadline, after which every rank goes on (and leaves through os._exit, see below).
@@ -549,7 +578,10 @@ def main():
                                "spectrum cached), wall clock incl. every table, the fp64 data spectrum, initialize(), seed and result "
                                "emission, in a warm process; warm = the same call on a solver that has solved before; first_solve_of_the_"
                                "process additionally pays code-object loading and ~1.5 GB of first-time device allocations"},
-        "psnr_db": {"input_mean": float(np.mean(psnr_in)), "admm50_mean": float(np.mean(psnr_out)), "admm50_per_image": psnr_out},
+        "psnr_db": {"input_mean": float(np.mean(psnr_in)), "admm50_mean": float(np.mean(psnr_out)), "admm50_per_image": psnr_out,
+                    "generator": "SURVEY 8(d) / Appendix B (synthetic.synth, seed 2023): <= 8 cycles per image, 8 rectangles -- at 1024 x 1024 the "
+                                 "blur barely degrades it, see psnr_db_detail"},
+        "psnr_db_detail": quality_detail,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_measured_copy": achieved / HBM_COPY, "traffic": traffic,
                      "traffic_source": traffic_src,

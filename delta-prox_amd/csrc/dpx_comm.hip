@@ -6,6 +6,7 @@
 // A communicator is tied to the HIP device that is current when dpx_comm_init is called (one process per GPU).
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "dpx_common.h"
@@ -118,13 +119,35 @@ extern "C" int dpx_comm_broadcast(void* comm, void* buf, size_t bytes, int root,
   return rc ? fail("dpx_comm_broadcast", rc) : DPX_OK;
 }
 
-// recv = [world][bytes_per_rank]; send may alias recv + rank * bytes_per_rank
+// recv = [world][bytes_per_rank]; send may alias recv + rank * bytes_per_rank.
+// xGMI is a point-to-point mesh (7 links per GPU): the gather is issued as world - 1 direct peer sends + receives in ONE group --
+// every link carries one slice each way at the same time -- instead of the library's ring, whose every step is bound by a single
+// link.  DPX_COMM_ALLGATHER=ring keeps ncclAllGather (A/B).
 extern "C" int dpx_comm_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, dpx_stream_t stream) {
   DPX_REQUIRE(comm && ((send && recv) || !bytes_per_rank), "dpx_comm_allgather: null pointer");
   Comm* C = (Comm*)comm;
   if (!bytes_per_rank) return DPX_OK;
-  const int rc = rccl()->AllGather(send, recv, bytes_per_rank, RCCL_INT8, C->c, (hipStream_t)stream);
-  return rc ? fail("dpx_comm_allgather", rc) : DPX_OK;
+  Rccl* R = rccl();
+  static const bool ring = getenv("DPX_COMM_ALLGATHER") && !strcmp(getenv("DPX_COMM_ALLGATHER"), "ring");
+  if (ring || C->world == 1) {
+    const int rc = R->AllGather(send, recv, bytes_per_rank, RCCL_INT8, C->c, (hipStream_t)stream);
+    return rc ? fail("dpx_comm_allgather", rc) : DPX_OK;
+  }
+  char* own = (char*)recv + (size_t)C->rank * bytes_per_rank;
+  if ((const void*)own != send && hipMemcpyAsync(own, send, bytes_per_rank, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    dpx::set_error("dpx_comm_allgather: local copy failed");
+    return DPX_ERR_LAUNCH;
+  }
+  int rc = R->GroupStart();
+  if (rc) return fail("dpx_comm_allgather", rc);
+  for (int d = 1; d < C->world && !rc; ++d) {                 // peer at distance d: every rank talks to a different peer per step
+    const int to = (C->rank + d) % C->world, from = (C->rank - d + C->world) % C->world;
+    rc = R->Send(send, bytes_per_rank, RCCL_INT8, to, C->c, (hipStream_t)stream);
+    if (!rc) rc = R->Recv((char*)recv + (size_t)from * bytes_per_rank, bytes_per_rank, RCCL_INT8, from, C->c, (hipStream_t)stream);
+  }
+  const int rc2 = R->GroupEnd();
+  if (rc || rc2) return fail("dpx_comm_allgather", rc ? rc : rc2);
+  return DPX_OK;
 }
 
 // root holds send = [world][bytes_per_rank]; every rank receives its slice: direct peer sends over the xGMI mesh (no ring)

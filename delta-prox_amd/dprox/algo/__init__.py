@@ -3,3 +3,4 @@ from .driver import Algorithm
 from .gradient import ProximalGradientDescent
 from .splitting import ADMM, HQS, ADMM_vxu, LinearizedADMM, PockChambolle
 from .tune.dpir import log_descent
+from .training import TrainLoop, train

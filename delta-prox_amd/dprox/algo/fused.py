@@ -35,6 +35,11 @@ def _is_var(op):
     return isinstance(op, Variable)
 
 
+def _is_const(op):
+    """a Constant / Placeholder, or a subtree over constants only (``- placeholder`` is ``scale(-1, Placeholder)``)"""
+    return isinstance(op, Constant) or len(op.variables) == 0
+
+
 def _omega_ok(fn):
     """sum_squares over  x | conv(x) , optionally minus constants"""
     if type(fn) is not sum_squares or fn.beta != 1:
@@ -42,7 +47,7 @@ def _omega_ok(fn):
     op = fn.linop
     if isinstance(op, lin_sum):
         kids = list(op.input_nodes)
-        lin = [k for k in kids if not isinstance(k, Constant)]
+        lin = [k for k in kids if not _is_const(k)]
         if len(lin) != 1:
             return False
         op = lin[0]
@@ -56,7 +61,7 @@ def _omega_conv(fn):
     """the conv node of a recognised Omega term (None for the identity)"""
     op = fn.linop
     if isinstance(op, lin_sum):
-        op = [k for k in op.input_nodes if not isinstance(k, Constant)][0]
+        op = [k for k in op.input_nodes if not _is_const(k)][0]
     return op if type(op) in (conv, conv_doe) else None
 
 
@@ -491,9 +496,29 @@ class FusedADMM:
         consts = [c for c in fn.linop.constants if isinstance(c._value, torch.Tensor) and c._value.requires_grad]
         if not consts:
             return None
+        from ..linop import scale as lin_scale
+
+        def walk(node, coef):                              # constant leaves with the factor their scale() chain gives them
+            if isinstance(node, Constant):
+                return [(coef, node)]
+            if type(node) is lin_scale:
+                return walk(node.input_nodes[0], coef * float(node.scalar))
+            if isinstance(node, lin_sum):
+                out = []
+                for k in node.input_nodes:
+                    if len(k.variables) == 0:
+                        sub = walk(k, coef)
+                        if sub is None:
+                            return None
+                        out += sub
+                return out
+            return None
+        leaves = walk(fn.linop, 1.0)
+        if leaves is None:
+            return None
         tot = None
-        for c in fn.linop.constants:
-            val = c._value.to(x0.device)
+        for coef, c in leaves:
+            val = c._value.to(x0.device) * coef if coef != 1.0 else c._value.to(x0.device)
             tot = val if tot is None else tot + val
         return (-tot).expand_as(x0)
 

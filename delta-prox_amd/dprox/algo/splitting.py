@@ -69,7 +69,17 @@ class ADMM(Algorithm):
         return x, v, u
 
     def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
-        plan = fused.plan_admm(self, state) if (self.use_fused and type(self) is ADMM) else None
+        plan = None
+        if self.use_fused and type(self) is ADMM:
+            # (the pattern match depends on the problem graph and on the iterate's shape / dtype only: done once per shape)
+            x = state[0]
+            key = (tuple(x.shape), x.dtype, x.ndim) if isinstance(x, torch.Tensor) else None
+            hit = getattr(self, "_plan_cache", None)
+            if key is not None and hit is not None and hit[0] == key:
+                plan = hit[1]
+            else:
+                plan = fused.plan_admm(self, state)
+                self._plan_cache = (key, plan)
         if plan is not None:
             self.last_path = "fused"
             return plan.run(state, rhos, lams, max_iter, pbar, callback)

@@ -118,6 +118,52 @@ def broadcast_constants(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0
     return out
 
 
+def export_tables(solver, shape, device) -> Dict[str, torch.Tensor]:
+    """The per-shape constants of a compiled solver whose x-update is a Fourier division -- OTF tables of the data terms'
+    convolutions and the two |OTF|^2 sums of the denominator (opaque half-spectrum layouts) -- built if they are not cached yet.
+    They depend on (C, H, W) only, so the rank that holds them can broadcast them (``share_tables``) instead of every rank
+    evaluating its own copies (dpx_psf2otf: a direct fp64 DFT per table)."""
+    from .linop.fourier import conv
+    from .algo.fused import _omega_conv
+    ls = solver.least_square
+    out = {}
+    for i, fn in enumerate(solver.omega_fns):
+        cv = _omega_conv(fn)
+        if type(cv) is conv:
+            out[f"otf{i}"] = cv._tables(shape, device)
+    (t0, c0), (t1, c1) = ls.diag_tables(shape, device, True)
+    for name, t in (("t0", t0), ("t1", t1)):
+        if isinstance(t, torch.Tensor):
+            out[name] = t
+    out["consts"] = torch.tensor([c0, c1], dtype=torch.float64, device=device)
+    return out
+
+
+def import_tables(solver, shape, device, tabs: Dict[str, torch.Tensor]):
+    """fills the solver's caches with tables received from another rank (same problem, same plane size)"""
+    from .linop.fourier import conv
+    from .algo.fused import _omega_conv
+    ls = solver.least_square
+    for i, fn in enumerate(solver.omega_fns):
+        cv = _omega_conv(fn)
+        if type(cv) is conv and f"otf{i}" in tabs:
+            cv.cache[(tuple(shape[1:]), str(device))] = tabs[f"otf{i}"]
+    c0, c1 = (float(v) for v in tabs["consts"].cpu())
+    key = (tuple(shape[1:]), str(device), True) + tuple(fn.linop.tables_version() for fn in list(ls.quad_fns) + list(ls.other_fns))
+    ls._diag_cache = (key, ((tabs.get("t0"), c0), (tabs.get("t1"), c1)))
+
+
+def share_tables(solver, shape, src: int = 0, group=None, device=None, comm: Optional[Comm] = None):
+    """rank `src` builds the solver's tables for `shape` (any batch size) and broadcasts them; every rank's solver ends up with
+    them cached.  One-time, outside any timed solve."""
+    rank = dist.get_rank(group)
+    device = device if device is not None else solver.device
+    tabs = broadcast_constants(export_tables(solver, shape, device) if rank == src else None, src, group, device, comm)
+    if rank != src:
+        import_tables(solver, shape, device, tabs)
+    return tabs
+
+
 def scatter_batch(full: Optional[torch.Tensor], src: int = 0, group=None, device=None, comm: Optional[Comm] = None) -> torch.Tensor:
     """rank `src` holds the full [B, ...] tensor; every rank receives its slice (possibly empty).  An evenly divisible batch is
     dealt out from views of `full` (no staging copies); a ragged one is padded to the longest slice."""

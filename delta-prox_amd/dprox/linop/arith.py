@@ -39,9 +39,8 @@ class sum(LinOp):
         """``K x + c_1 + ...`` with K a chain of the built-in shape-preserving linear nodes (the data term ``conv(x) - b``): the value
         at x = 0 is the sum of the constants -- no transform of an all-zero image (linop/base.py:117-129 evaluates the whole graph;
         a circular convolution / difference / scaling of zeros is exactly zero, so the result is the same tensor)"""
-        from .leaf import Constant
-        consts = [k for k in self.input_nodes if isinstance(k, Constant)]
-        others = [k for k in self.input_nodes if not isinstance(k, Constant)]
+        consts = [k for k in self.input_nodes if len(k.variables) == 0]       # Constant / Placeholder leaves and subtrees over them
+        others = [k for k in self.input_nodes if len(k.variables) > 0]
         vs = self.variables
         if consts and others and all(_zero_preserving(k) for k in others) and len(vs) == 1 and vs[0]._value is not None:
             vals = [c.value for c in consts]

@@ -25,7 +25,7 @@ class conv(LinOp):
         super().__init__([arg])
 
     def _tables(self, shape, device):
-        key = (tuple(shape), str(device))
+        key = (tuple(shape[1:]), str(device))              # (the table of a plane set: shared by every batch size)
         if key not in self.cache:
             _, C, H, W = shape
             otf = ops.make_otf(self.kernel, C, H, W, device)

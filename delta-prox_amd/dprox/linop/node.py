@@ -70,11 +70,19 @@ class LinOp(nn.Module):
 
     @property
     def variables(self):
+        # (the graph below a node is fixed once it is built: the walk is done once per node, keyed on the identity of its inputs --
+        #  the solvers ask for it a few dozen times per solve)
+        key = tuple(id(n) for n in self.input_nodes)
+        hit = self.__dict__.get("_vars_cache")
+        if hit is not None and hit[0] == key:
+            return list(hit[1])
         found = {}
         for node in self.input_nodes:
             for v in node.variables:
                 found[v.uuid] = v
-        return [found[k] for k in sorted(found)]
+        out = [found[k] for k in sorted(found)]
+        self.__dict__["_vars_cache"] = (key, out)
+        return list(out)
 
     @property
     def constants(self):

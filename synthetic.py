@@ -46,6 +46,32 @@ def synth(rng, B, C, H, W):
     return out
 
 
+def synth_detail(rng, B, C, H, W, base=256):
+    """The same generator with its detail scaled to the plane: ``synth`` draws cosines of at most 8 cycles per IMAGE and rectangles
+    of 1/16 .. 1/3 of the image whatever H is, so at 1024 x 1024 a 15 x 15 blur hardly touches it (blurred input 36.8 dB, nothing
+    for a deconvolution to win).  Here the cosines have up to 8 cycles per `base` pixels (frequencies x H/base) and the rectangles
+    keep their size in pixels (1/16 .. 1/3 of `base`, (H/base)(W/base) x 8 of them): the local statistics of a 256 x 256 `synth`
+    image at any plane size.  H = W = base draws the same kind of image as ``synth`` (not the same numbers)."""
+    sy, sx = max(H // base, 1), max(W // base, 1)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    out = np.zeros((B, C, H, W), np.float32)
+    for b in range(B):
+        for c in range(C):
+            img = np.zeros((H, W))
+            for _ in range(6):
+                f, g = rng.randint(0, 9) * sy, rng.randint(0, 9) * sx
+                a = rng.rand()
+                ph = rng.rand() * 2 * np.pi
+                img += a * np.cos(2 * np.pi * (f * yy / H + g * xx / W) + ph)
+            img = img / 3 + 0.5
+            for _ in range(8 * sy * sx):
+                y0, x0 = rng.randint(0, H), rng.randint(0, W)
+                h, w = rng.randint(base // 16, base // 3), rng.randint(base // 16, base // 3)
+                img[y0:y0 + h, x0:x0 + w] += rng.uniform(-0.3, 0.3)
+            out[b, c] = np.clip(img, 0, 1)
+    return out
+
+
 def circular_blur(img, psf2d):
     """Circular (wrap-around) convolution of NCHW ``img`` with a centred 2-D PSF, float64 FFT internally.
     Equivalent to scipy.ndimage.convolve(mode='wrap') as used by the reference's ``blurring``

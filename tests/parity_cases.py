@@ -5,6 +5,8 @@ with the drop-in `dprox` API on `device` and compares with the reference's store
 Tolerance (north_star): rel-L2 <= 1e-5 on the iterate x.  The split variables v/u are
 non-smooth functions of x (soft threshold / clip at lam) so their error is compared on the scale of x.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -747,6 +749,59 @@ def case_unrolled_solver(device):
     assert all(torch.equal(p.detach().cpu(), ref_ckpt["norm1"]) for p in us2.lams.values())
 
 
+def case_train(device, tmpdir):
+    """dp.train (primitives.py:112-205 restated): an unrolled TV-deconvolution solver with learned rho / lambda schedules trained for
+    a few AdamW steps through the solver's own backward pass -- the loss goes down, ``last.pth`` holds what a resumed run needs, and
+    resuming after epoch 2 reproduces an uninterrupted run's parameters (same shuffles: the generator is seeded by the epoch)."""
+    import synthetic
+    gt0, b0, psf = synthetic.deconv_case(4, 1, 32, 32, seed=31, ksize=5, ksigma=1.5)
+    data = torch.from_numpy(gt0)
+    blur = dp.conv(dp.Variable(), psf).to(device)
+
+    class Schedules(torch.nn.Module):                      # the trained part (README.md:93-116: parameters live in a separate model)
+        def __init__(self):
+            super().__init__()
+            self.rhos = torch.nn.Parameter(torch.full((3,), 0.5))
+            self.lam0 = torch.nn.Parameter(torch.full((3,), 0.05))
+            self.lam1 = torch.nn.Parameter(torch.full((3,), 0.05))
+
+    def make():
+        obs = dp.Placeholder()
+        x = dp.Variable()
+        n0, n1 = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+        base = dp.compile(dp.sum_squares(dp.conv(x, psf) - obs) + n0 + n1, method="admm", device=device)
+        solver = dp.specialize(base, method="unroll", device=device, max_iter=3)
+        m = Schedules().to(device)
+
+        def step_fn(batch):
+            g = batch.to(device)
+            with torch.no_grad():
+                inp = blur.forward(g.contiguous())
+            obs.value = inp
+            pred = solver.solve(x0=inp, rhos=m.rhos, lams={n0: m.lam0, n1: m.lam1})
+            assert base.last_path == "fused", "a Placeholder observation must stay on the fused (differentiable) iteration"
+            return g, inp, pred
+        return m, step_fn
+
+    us, step_fn = make()
+    hist = dp.train(model=us, step_fn=step_fn, dataset=data, savedir=os.path.join(tmpdir, "a"), epochs=3, bs=2, lr=2e-2, weight_decay=0.0)
+    assert [h["epoch"] for h in hist] == [0, 1, 2] and hist[-1]["loss"] < hist[0]["loss"], hist
+    ck = torch.load(os.path.join(tmpdir, "a", "last.pth"))
+    assert set(ck) == {"model", "optimizer", "epoch", "gstep", "psnr", "best_psnr"} and ck["epoch"] == 2 and ck["gstep"] == 6
+    # interrupted after 2 epochs, resumed for the third: same parameters as the uninterrupted run
+    us2, step2 = make()
+    dp.train(model=us2, step_fn=step2, dataset=data, savedir=os.path.join(tmpdir, "b"), epochs=2, bs=2, lr=2e-2, weight_decay=0.0)
+    us3, step3 = make()
+    hist3 = dp.train(model=us3, step_fn=step3, dataset=data, savedir=os.path.join(tmpdir, "b"), epochs=3, bs=2, lr=2e-2, weight_decay=0.0, resume="last.pth")
+    assert len(hist3) == 3
+    for (n1, p1), (n3, p3) in zip(us.named_parameters(), us3.named_parameters()):
+        assert n1 == n3 and torch.allclose(p1.detach().cpu(), p3.detach().cpu(), rtol=1e-5, atol=1e-7), (n1, p1, p3)
+    with pytest.raises(ValueError, match="not supported"):
+        dp.train(us)
+    with pytest.raises(ValueError, match="no network"):
+        dp.train(model=us, step_fn=step_fn, dataset="BSD500", savedir=os.path.join(tmpdir, "c"), epochs=1)
+
+
 def _assert_grad_close(got, ref, what, tol=1e-4, flip_frac=0.08, flip_rel=5e-2):
     """Gradients through ReLU stacks are piecewise constant in the forward activations: an activation that rounds to the
     other side of 0 (fp32 summation order) flips one mask entry and changes the gradient on one receptive field
@@ -1335,6 +1390,45 @@ def case_full_c2(device):
     assert got_err <= ref_err
     psnr = [10 * np.log10(1.0 / np.mean((out2[i].cpu().numpy() - gt[i]) ** 2)) for i in range(2)]
     assert np.allclose(psnr, g["psnr"], atol=2e-3), (psnr, g["psnr"])
+
+
+def case_full_c2_batch8(device):
+    """G30b -- config 2 exactly as BASELINE.json states it: the whole batch of 8 x 3 x 1024 x 1024 (the launch geometry bench.py
+    times: 24 planes, 128 bands of 8 rows), 50 iterations on the C-side loop, against the real reference's run.
+    After 50 iterations at this size the REFERENCE's own fp32 round-off has grown to 1.3e-5 of the float64 iterate of the same
+    algorithm (stored next to it; it grows like sqrt(iterations): 4.7e-6 at iteration 10, G30), so a 1e-5 bar against the
+    reference's samples cannot be met by anything that is not the reference's rounding sequence.  Acceptance here, stated:
+      * the iterate after 25 iterations against the reference: rel-L2 <= 1e-5 (the reference is still below the bar there);
+      * the final x against the float64 iterate: rel-L2 <= 1e-5 (measured ~3e-7) -- and therefore at most (the reference's own
+        distance + 1e-5) from the reference, which is recorded;
+      * per-image sums and L2 norms of the final x against the reference at 1e-5 (round-off averages out of them)."""
+    import synthetic
+    g = load_golden("g30b_full_c2_batch8")
+    gt, b, psf = synthetic.deconv_case(8, 3, 1024, 1024, seed=int(g["seed"]))
+    bt = T(b, device)
+    x, fns, _ = tv_problem(bt, psf)
+    s = dp.compile(fns, method="admm", device=device)
+    x25 = s.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=25)
+    assert s.last_path == "fused"
+    _check_packed(g, "it25_x", x25, 16, TOL, what="c2 batch 8 ", maxabs_mult=4.0)
+    out = s.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=50)
+    samp = out[..., ::8, ::8].cpu().numpy()
+    e_ref_f64 = rel_l2(g["x"], g["x_f64"])
+    e_f64 = rel_l2(samp, g["x_f64"])
+    e_ref = rel_l2(samp, g["x"])
+    record("c2 batch 8, 50 it: x samples vs the float64 iterate", e_f64, TOL)
+    record(f"c2 batch 8, 50 it: x samples vs the reference (the reference itself is {e_ref_f64:.2e} from float64)", e_ref, e_ref_f64 + TOL)
+    assert e_f64 <= TOL, f"final x: {e_f64:.3e} from the float64 iterate"
+    assert e_ref <= e_ref_f64 + TOL, (e_ref, e_ref_f64)
+    d = out.double().reshape(8, -1)
+    l2, sm = d.norm(dim=1).cpu().numpy(), d.sum(1).cpu().numpy()
+    e_l2 = float(np.max(np.abs(l2 - g["x_l2"]) / g["x_l2"]))
+    e_sum = float(np.max(np.abs(sm - g["x_sum"]) / (g["x_l2"] * np.sqrt(d.shape[1]))))
+    record("c2 batch 8, 50 it: per-image L2 norm vs the reference", e_l2, TOL)
+    record("c2 batch 8, 50 it: per-image sum / (sqrt(n) L2) vs the reference", e_sum, TOL)
+    assert e_l2 <= TOL and e_sum <= TOL, (e_l2, e_sum)
+    psnr = [float(10 * np.log10(1.0 / np.mean((out[i].cpu().numpy() - gt[i]) ** 2))) for i in range(8)]
+    assert np.allclose(psnr, g["psnr"], atol=1e-3), (psnr, g["psnr"])
 
 
 def case_full_c3(device):

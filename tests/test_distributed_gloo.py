@@ -90,6 +90,117 @@ def test_sharded_solve_matches_single_process(B):
     assert slices[0][0] == 0 and slices[-1][1] == B
 
 
+def _worker_c4(rank, world, port, B, q):
+    """config 4's path per shard: masked-Fourier data term + nonneg + gray FFDNet prior (a small seeded network: the 15-layer one
+    takes the emulator minutes), LinearizedADMM with the CG x-update.  The CG stop rule couples the images of a batch (SURVEY 8(e)
+    caveat), so every shard is checked against an ORACLE run on the same sub-batch, not against a single-process run of the whole
+    batch.  Also: the Fourier-path solver's tables built on rank 0 and shared (share_tables) give the same answer as local tables."""
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "delta-prox_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emul_util
+    emul_util.use_emulator()
+    import oracle as O
+    import synthetic
+    import dprox as dp
+    from dprox import distributed as dd
+    from dprox.contrib import masked_fft
+    from dprox.linalg import LinearSolveConfig
+    from dprox.proxfn.pnp.denoisers import FFDNet, FFDNetDenoiser
+    from dprox.utils import ifft2
+
+    H = W = 24
+    gt, mask0, y0 = synthetic.csmri_case(B, H, W, seed=5, center=8)
+    wts = synthetic.ffdnet_weights(13, 1, 1, 16, 3)
+    # constants live on rank 0: sampling mask and denoiser weights reach the others by broadcast
+    den = FFDNetDenoiser()
+    den.model = FFDNet(in_nc=1, out_nc=1, nc=16, nb=3, act_mode="R")
+    if rank == 0:
+        den.model.load_layers(wts)
+    consts = dd.broadcast_constants({"mask": torch.from_numpy(mask0)} if rank == 0 else None, src=0)
+    sd = dd.broadcast_constants({k: v.detach() for k, v in den.state_dict().items()} if rank == 0 else None, src=0)
+    if rank != 0:
+        den.load_state_dict(sd, strict=True)
+    yph, xv = dp.Placeholder(), dp.Variable()
+    fns = dp.sum_squares(masked_fft(xv, consts["mask"]), yph) + dp.nonneg(xv) + dp.deep_prior(xv, denoiser=den)
+    cfg = LinearSolveConfig(rtol=1e-6, max_iters=100)
+    s = dp.compile(fns, method="ladmm", device="cpu", linear_solve_config=cfg)      # compiled once, the data is a Placeholder
+
+    def local_solve(loc):
+        yy = torch.view_as_complex(loc["y"].contiguous())
+        yph.value = yy
+        with torch.no_grad():
+            out = s.solve(x0=ifft2(yy).real.contiguous(), rhos=0.5, lams=0.03, max_iter=3)
+        assert s.last_path == "fused-cg", s.last_path
+        return out
+
+    y_ri = torch.view_as_real(torch.from_numpy(y0)).contiguous()
+    out = dd.solve_sharded(local_solve, {"y": y_ri} if rank == 0 else None, src=0)
+    # per-shard oracle parity
+    a, b_ = dd.shard_slices(B, world)[rank]
+    shard_err = 0.0
+    if b_ > a:
+        ys = torch.from_numpy(y0[a:b_])
+        mk = torch.from_numpy(mask0)
+        op = O.lin_custom(lambda x: mk * O.fft2c(x), lambda yy: O.ifft2c(mk * yy).real)
+        terms = [O.sum_squares(op, b=ys), O.nonneg(O.lin_identity()), O.deep_prior(O.lin_identity(), O.FFDNetOracle(wts, per_band=True))]
+        with torch.no_grad():
+            ref = O.solve(terms, "ladmm", x0=O.ifft2c(ys).real, rhos=0.5, lams=0.03, max_iter=3, linear_solve_config=O.LinearSolveConfig(rtol=1e-6, max_iters=100))
+        shard_err = float((out[a:b_] - ref).norm() / ref.norm())
+    # shared tables on the Fourier path
+    gt2, b2, psf = synthetic.deconv_case(2, 1, 24, 32, seed=9, ksize=7, ksigma=2.0)
+    bt = torch.from_numpy(b2)
+
+    def tv(shared):
+        xx = dp.Variable()
+        sv = dp.compile(dp.sum_squares(dp.conv(xx, psf) - bt) + dp.norm1(dp.grad(xx, dim=0)) + dp.norm1(dp.grad(xx, dim=1)), method="admm", device="cpu")
+        if shared:
+            tabs = dd.share_tables(sv, (1, 1, 24, 32), src=0, device=torch.device("cpu"))
+            assert {"otf0", "t0", "t1", "consts"} <= set(tabs)
+            from dprox import _ops as ops
+            calls = []
+            real = ops.make_otf
+            ops.make_otf = lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1]
+            try:
+                o = sv.solve(x0=bt, rhos=0.2, lams=0.01, max_iter=3)
+            finally:
+                ops.make_otf = real
+            assert rank == 0 or not calls, "a rank that received the tables rebuilt them"
+            return o
+        return sv.solve(x0=bt, rhos=0.2, lams=0.01, max_iter=3)
+    tab_err = float((tv(True) - tv(False)).abs().max())
+    q.put({"rank": rank, "shape": tuple(out.shape), "shard_err": shard_err, "tab_err": tab_err})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world4_config4_shards_match_their_oracle_and_shared_tables():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    B, world = 6, 4                                  # ragged: shards of 2, 2, 1, 1
+    procs = [ctx.Process(target=_worker_c4, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=600) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    assert sorted(r["rank"] for r in res) == list(range(world))
+    for r in res:
+        assert r["shape"] == (B, 1, 24, 24)
+        assert r["shard_err"] <= 1e-5, r            # every shard is the oracle's answer on that sub-batch
+        assert r["tab_err"] == 0.0, r               # broadcast tables = locally built tables
+
+
 def test_shard_slices():
     from dprox.distributed import shard_slices
     assert shard_slices(8, 8) == [(i, i + 1) for i in range(8)]

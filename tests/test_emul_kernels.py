@@ -144,6 +144,10 @@ def test_unrolled_solver_learned_params():
     pc.case_unrolled_solver(DEV)
 
 
+def test_train_driver_and_resume(tmp_path):
+    pc.case_train(DEV, str(tmp_path))
+
+
 @pytest.mark.skipif(not __import__("os").environ.get("DPX_EMUL_SLOW"), reason="~4 min on the emulator (runs on the GPU in test_gpu_parity); DPX_EMUL_SLOW=1 enables it")
 def test_ffdnet_weight_gradients():
     pc.case_ffdnet_weight_grads(DEV)

@@ -212,6 +212,14 @@ def test_full_size_config2_trajectory():
     pc.case_full_c2(DEV)
 
 
+def test_train_driver_and_resume(tmp_path):
+    pc.case_train(DEV, str(tmp_path))
+
+
+def test_full_size_config2_batch8_50_iterations():
+    pc.case_full_c2_batch8(DEV)
+
+
 def test_full_size_config3_pnp():
     pc.case_full_c3(DEV)
 
