@@ -320,13 +320,17 @@ static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& T
 #define DPX_R_STX 1       // the spectrum handed to the next kernel: write-through (`sc1`), nothing left dirty at the kernel boundary (+0.5 ... 1 %)
 #endif
 constexpr int R_LDX = DPX_R_LDX, R_LDU = DPX_R_LDU, R_STU = DPX_R_STU, R_STX = DPX_R_STX;
-template <int M, int T, int NT>
+// DUAL = false: half-quadratic splitting (TT.dual == 0, DPX_TERM_NO_DUAL) -- the duals are neither fetched nor stored (the general
+// kernel streams 16 of its 24 B per element for planes nobody reads: 36 -> 20 B per element and iteration with the column kernel);
+// every wait count below is the general one with the dual streams' operations taken out (NU = 0 terms with a dual).
+template <int M, int T, int NT, bool DUAL>
 __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
                                                         const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
                                                         int C, int H, int bands, int P, const float2* __restrict__ twW) {
   constexpr int V = M / T, G = 64 / T, S = LdsSeq<M>::SLOTS, D = V / 2, RM = M / (V * V);
   constexpr int STG = 64 * V;                           // float2 per staged row set of one wave (G rows)
-  constexpr int PERWAVE = G * S + STG + 32 + NT * STG;
+  constexpr int NU = DUAL ? NT : 0;                   // terms whose dual is streamed
+  constexpr int PERWAVE = G * S + STG + 32 + NU * STG;
   HIP_DYNAMIC_SHARED(float2, smem_sq)
   float2* twl = smem_sq;                                // untangling twiddles exp(-i pi k / M), k < M
   float2* twb = smem_sq + M;                            // pass-B twiddles W_{V*RM}^j, j < 64
@@ -382,7 +386,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   };
   auto issue_u = [&](int h) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
+    for (int n = 0; n < NU; ++n) {
       const float2* urow = (const float2*)TT.t[n].u_in + uoff + (unsigned)h * M * usc;
 #pragma unroll
       for (int i = 0; i < D; ++i) dpx_glds16<R_LDU>(urow + 2 * T * i, stU + n * STG + i * 128);
@@ -391,12 +395,12 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   // lower bounds of the vector-memory operations issued AFTER the awaited DMA (a wait count must never exceed the real
   // number, or it could return early).  The V spectral stores of phase C only exist when a next right-hand side is
   // produced (rho_next != NULL); the emit stores (x_out, v_out) are never counted.
-  constexpr int NX_STEADY = (NT * (D + V) + V) > 63 ? 63 : (NT * (D + V) + V);
-  constexpr int NU_LAST = (NT * V + V) > 63 ? 63 : (NT * V + V);
-  constexpr int NU_STEADY = (NT * V + V + D + 1) > 63 ? 63 : (NT * V + V + D + 1);
-  constexpr int NX_STEADY_NS = (NT * (D + V)) > 63 ? 63 : (NT * (D + V));
-  constexpr int NU_LAST_NS = (NT * V) > 63 ? 63 : (NT * V);
-  constexpr int NU_STEADY_NS = (NT * V + D + 1) > 63 ? 63 : (NT * V + D + 1);
+  constexpr int NX_STEADY = (NU * (D + V) + V) > 63 ? 63 : (NU * (D + V) + V);
+  constexpr int NU_LAST = (NU * V + V) > 63 ? 63 : (NU * V + V);
+  constexpr int NU_STEADY = (NU * V + V + D + 1) > 63 ? 63 : (NU * V + V + D + 1);
+  constexpr int NX_STEADY_NS = (NU * (D + V)) > 63 ? 63 : (NU * (D + V));
+  constexpr int NU_LAST_NS = (NU * V) > 63 ? 63 : (NU * V);
+  constexpr int NU_STEADY_NS = (NU * V + D + 1) > 63 ? 63 : (NU * V + D + 1);
   const bool has_spec = rho_next != nullptr;
 
   issue_x(rowof(0));
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       else dpx_wait_vm<NX_STEADY_NS>();
     }
     else if (q == 1) dpx_wait_vm<0>();
-    else dpx_wait_vm<NT * D>();
+    else dpx_wait_vm<NU * D>();
     float2 xa[V];
     {
       float2 Xk[V], Xm[V];
@@ -450,25 +454,32 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       const int qz = q - 1;
       const bool own = qz >= 1 && qz <= R;
       const unsigned hz = (unsigned)rowof(qz);
-      if (q >= 3) {
-        if (has_spec) {
-          if (q <= Rmax) dpx_wait_vm<NU_STEADY>();
-          else dpx_wait_vm<NU_LAST>();
-        } else {
-          if (q <= Rmax) dpx_wait_vm<NU_STEADY_NS>();
-          else dpx_wait_vm<NU_LAST_NS>();
-        }
-      } else {
-        dpx_wait_vm<D + 1>();
-      }
       float2 ureg[NT][V];
-      const float dualf = TT.dual;
+      const float dualf = DUAL ? TT.dual : 0.f;
+      if constexpr (DUAL) {
+        if (q >= 3) {
+          if (has_spec) {
+            if (q <= Rmax) dpx_wait_vm<NU_STEADY>();
+            else dpx_wait_vm<NU_LAST>();
+          } else {
+            if (q <= Rmax) dpx_wait_vm<NU_STEADY_NS>();
+            else dpx_wait_vm<NU_LAST_NS>();
+          }
+        } else {
+          dpx_wait_vm<D + 1>();
+        }
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int m = 0; m < V; ++m) ureg[n][m] = stU[n * STG + stage_idx(t + m * T)];
-      dpx_wait_lds();
-      if (qz < Rmax) issue_u(rowof(qz + 1));
+          for (int m = 0; m < V; ++m) ureg[n][m] = stU[n * STG + stage_idx(t + m * T)];
+        dpx_wait_lds();
+        if (qz < Rmax) issue_u(rowof(qz + 1));
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int m = 0; m < V; ++m) ureg[n][m] = make_float2(0.f, 0.f);
+      }
       float2 acc[V];
 #pragma unroll
       for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f);
@@ -512,9 +523,11 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
           d[m] = un;
         }
         if (own) {
-          float2* uo = (float2*)tm.u_out + (unsigned)pl * H * M + hz * M + t;
+          if constexpr (DUAL) {
+            float2* uo = (float2*)tm.u_out + (unsigned)pl * H * M + hz * M + t;
 #pragma unroll
-          for (int m = 0; m < V; ++m) st_stream<R_STU>(uo + m * T, d[m]);
+            for (int m = 0; m < V; ++m) st_stream<R_STU>(uo + m * T, d[m]);
+          }
           if (emit_v) {
             const size_t vo = (size_t)pl * H * M + (size_t)hz * M + t;
 #pragma unroll
@@ -577,22 +590,29 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   }
 }
 
-static size_t iter_rows_seq_lds(int M, int T, int NT) {
+static size_t iter_rows_seq_lds(int M, int T, int NU) {
   const int V = M / T, G = 64 / T, S = M + M / 16, STG = 64 * V;
-  return (size_t)(M + 64 + 4 * (G * S + STG + 32 + NT * STG)) * sizeof(float2);
+  return (size_t)(M + 64 + 4 * (G * S + STG + 32 + NU * STG)) * sizeof(float2);
+}
+template <int M, int T, int NT, bool DUAL>
+static void launch_iter_rows_seq_d(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
+                                   int C, int H, int R, int P, const float2* twW, hipStream_t s) {
+  const size_t sh = iter_rows_seq_lds(M, T, DUAL ? NT : 0);
+  static bool attr = false;
+  if (!attr && sh > 48 * 1024) {
+    hipFuncSetAttribute((const void*)k_iter_rows_seq<M, T, NT, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    attr = true;
+  }
+  const int groups = P * R, per_block = 4 * (64 / T);   // R = bands per plane here
+  DPX_LAUNCH(DUAL ? "k_iter_rows_seq" : "k_iter_rows_seq_nodual", (k_iter_rows_seq<M, T, NT, DUAL>), dim3(groups / per_block), dim3(256), sh, s, sin, sout,
+             TT, rho_next, x_out, emit_v, C, H, R, P, twW);
 }
 template <int M, int T, int NT>
 static void launch_iter_rows_seq_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
                                     int C, int H, int R, int P, const float2* twW, hipStream_t s) {
-  const size_t sh = iter_rows_seq_lds(M, T, NT);
-  static bool attr = false;
-  if (!attr && sh > 48 * 1024) {
-    hipFuncSetAttribute((const void*)k_iter_rows_seq<M, T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    attr = true;
-  }
-  const int groups = P * R, per_block = 4 * (64 / T);   // R = bands per plane here
-  DPX_LAUNCH("k_iter_rows_seq", (k_iter_rows_seq<M, T, NT>), dim3(groups / per_block), dim3(256), sh, s, sin, sout, TT, rho_next, x_out,
-             emit_v, C, H, R, P, twW);
+  static const bool keep_dual = getenv("DPX_HQS_STREAM_DUALS") != nullptr;      // (A/B: half-quadratic splitting on the general kernel)
+  if (TT.dual == 0.f && !keep_dual) launch_iter_rows_seq_d<M, T, NT, false>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
+  else launch_iter_rows_seq_d<M, T, NT, true>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
 }
 template <int M, int T>
 static void launch_iter_rows_seq(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,

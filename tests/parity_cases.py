@@ -1299,6 +1299,44 @@ def case_fresh_state(device, shapes=((2, 1, 256, 256),), iters=3):
         L.call("dpx_admm_iter_config", 0, 0)
 
 
+def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4):
+    """Half-quadratic splitting on the streaming row kernel's no-dual variant (k_iter_rows_seq<..., DUAL = false>: the duals are
+    neither fetched nor stored, its wait counts are the general kernel's minus the dual streams) against the lock-step ring-buffer
+    kernel (no LDS-DMA, no hand-counted waits), for one to four terms; bit-identical across band partitions."""
+    import synthetic
+    from dprox import _backend as be
+    L = be.lib()
+    try:
+        for (B, C, H, W) in shapes:
+            gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=55 + W)
+            b = T(b0, device)
+            for nterms in (1, 2, 3, 4):
+                def run(mode, bands):
+                    L.call("dpx_admm_iter_config", mode, bands)
+                    x = dp.Variable()
+                    fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0))
+                    if nterms >= 2:
+                        fns = fns + dp.norm1(dp.grad(x, dim=1))
+                    if nterms >= 3:
+                        fns = fns + dp.nonneg(x)
+                    if nterms >= 4:
+                        fns = fns + dp.norm1(x) * 0.5
+                    s = dp.compile(fns, method="hqs", device=device)
+                    st = s.solve(x0=b, rhos=torch.linspace(0.4, 0.2, iters), lams=0.01, max_iter=iters, return_full_states=True)
+                    assert s.last_path == "fused"
+                    return [st[0]] + list(st[1])
+                seq = run(1, 0)
+                seq2 = run(1, 16)
+                lock = run(2, 0)
+                for a, c in zip(seq, seq2):
+                    assert torch.equal(a, c), ("no-dual kernel: band partitions differ", (B, C, H, W), nterms)
+                tol = 2e-4 if nterms == 1 else 1e-5          # (one gradient term: a line of ~eps denominators, DESIGN.md section 4)
+                for a, c in zip(seq, lock):
+                    assert float((a - c).abs().max()) <= tol * max(float(c.abs().max()), 1.0), ((B, C, H, W), nterms, float((a - c).abs().max()))
+    finally:
+        L.call("dpx_admm_iter_config", 0, 0)
+
+
 def case_tiny_shapes(device):
     """degenerate planes against the oracle: 2x3, 3x3, 17x2 (every stage at its smallest size, prime lengths), and the
     reference's error for an axis shorter than the gradient stencil (utils/psf2otf.py:46-54 raises there too)"""

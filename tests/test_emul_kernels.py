@@ -62,6 +62,10 @@ def test_fresh_state_shortcut_is_bit_identical():
     pc.case_fresh_state(DEV)
 
 
+def test_hqs_no_dual_row_kernel():
+    pc.case_hqs_nodual_kernel(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV, tiny=True)
 

@@ -8,7 +8,9 @@ cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 out=gpurun_out/prof_$tag; mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
 tail -c 600 $out/bench.json
-rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python bench.py --no-cpu-baseline --no-extra-configs > $out/bench_under_rocprof.json 2> $out/rocprof.err
+# the driver's command line (round-end BENCH): --steps 20 --warmup 5
+python bench.py --steps 20 --warmup 5 > $out/bench_steps20_warmup5.json 2>> $out/bench.err
+rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs > $out/bench_under_rocprof.json 2> $out/rocprof.err
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 head -8 $out/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
