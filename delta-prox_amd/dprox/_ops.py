@@ -53,6 +53,7 @@ def spectrum_ws(P, H, W, device):
 def clear_caches():
     _tables.clear()
     _workspaces.clear()
+    _psf_dev.clear()
     _dd_cache.clear()
 
 
@@ -77,6 +78,9 @@ def as_batch_vec(v, B, device):
 # ----------------------------------------------------------------------------------------------
 # OTF tables
 # ----------------------------------------------------------------------------------------------
+_psf_dev = {}           # (kernel bytes, shape, device) -> fp64 device copy: a kernel is uploaded once, not once per table built from it
+
+
 def psf_to_device(psf, device):
     """kernel (2-D, or HWC 3-D) -> contiguous fp64 [kh,kw,kc] on device."""
     k = np.asarray(psf, dtype=np.float64)
@@ -86,7 +90,16 @@ def psf_to_device(psf, device):
         k = k[:, :, None]
     elif k.ndim != 3:
         raise ValueError(f"kernel must be 1-D, 2-D or HWC 3-D, got shape {k.shape}")
-    return torch.from_numpy(np.ascontiguousarray(k)).to(device), k.shape
+    k = np.ascontiguousarray(k)
+    if k.nbytes <= 1 << 16:
+        key = (k.tobytes(), k.shape, str(device))
+        hit = _psf_dev.get(key)
+        if hit is None:
+            if len(_psf_dev) >= 64:
+                _psf_dev.pop(next(iter(_psf_dev)))
+            hit = _psf_dev[key] = torch.from_numpy(k).to(device)     # (a pageable upload blocks the host behind everything queued: once)
+        return hit, k.shape
+    return torch.from_numpy(k).to(device), k.shape
 
 
 def make_otf(psf, C, H, W, device):

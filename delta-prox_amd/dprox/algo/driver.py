@@ -108,7 +108,7 @@ class Algorithm(nn.Module):
         def run():
             with be.device_guard(device), be.solve_scope("solve"):
                 xs, rs, ls = move(x0, rhos, lams, device=device)
-                state = self.initialize(xs.contiguous(), **kwargs)
+                state = self._initial_state(xs.contiguous(), **kwargs)
                 return self.iters(state, rs, ls, max_iter, pbar, callback=callback)
         try:
             state = run()
@@ -121,6 +121,10 @@ class Algorithm(nn.Module):
                 raise
             state = run()
         return state if return_full_states else state[0]
+
+    def _initial_state(self, x0, **kwargs):
+        """solve()'s initial state (= initialize unless a solver knows a cheaper equivalent for its own iteration)"""
+        return self.initialize(x0, **kwargs)
 
     def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
         for it in tqdm(range(max_iter), disable=not pbar):

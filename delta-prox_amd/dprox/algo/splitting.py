@@ -68,21 +68,32 @@ class ADMM(Algorithm):
         self._fresh = (x, v, u, [t._version for t in [x] + v + u]) if derived and all(isinstance(t, torch.Tensor) for t in [x] + v) else None
         return x, v, u
 
+    def _plan_for(self, x):
+        """the fused plan of this problem for an iterate like ``x`` (the pattern match depends on the problem graph and on the
+        iterate's shape / dtype only: done once per shape)"""
+        key = (tuple(x.shape), x.dtype) if isinstance(x, torch.Tensor) else None
+        hit = getattr(self, "_plan_cache", None)
+        if key is not None and hit is not None and hit[0] == key:
+            return hit[1]
+        plan = fused.plan_admm(self, (x, [], []))
+        self._plan_cache = (key, plan)
+        return plan
+
+    def _initial_state(self, x0, **kwargs):
+        """solve()'s initial state: for problems the two-kernel iteration takes, the split variables are allocated but not computed
+        (fused.lazy_initial_state: v_i = K_i x0, u_i = 0 are implied and never read); ``initialize`` itself stays eager"""
+        if type(self) is ADMM and self.use_fused and not kwargs:
+            st = fused.lazy_initial_state(self, x0, self._plan_for(x0))
+            if st is not None:
+                return st
+        return self.initialize(x0, **kwargs)
+
     def iters(self, state, rhos, lams, max_iter, pbar=False, callback=None):
-        plan = None
-        if self.use_fused and type(self) is ADMM:
-            # (the pattern match depends on the problem graph and on the iterate's shape / dtype only: done once per shape)
-            x = state[0]
-            key = (tuple(x.shape), x.dtype, x.ndim) if isinstance(x, torch.Tensor) else None
-            hit = getattr(self, "_plan_cache", None)
-            if key is not None and hit is not None and hit[0] == key:
-                plan = hit[1]
-            else:
-                plan = fused.plan_admm(self, state)
-                self._plan_cache = (key, plan)
+        plan = self._plan_for(state[0]) if (self.use_fused and type(self) is ADMM) else None
         if plan is not None:
             self.last_path = "fused"
             return plan.run(state, rhos, lams, max_iter, pbar, callback)
+        fused.materialize_state(self, state)                   # (every other path reads the split variables)
         if self.use_fused and type(self) in (ADMM, LinearizedADMM):
             plan = fused.plan_split_cg(self, state, rhos, lams)     # CG x-update, every Psi term on x itself (config 4)
             if plan is not None:

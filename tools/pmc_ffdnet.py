@@ -30,7 +30,7 @@ for k, e in d.items():
     if c.get("SQ_INSTS_MFMA") and c.get("SQ_WAVES"):
         r["mfma_per_wave_sampled"] = c["SQ_INSTS_MFMA"] / c["SQ_WAVES"]
     if c.get("GRBM_GUI_ACTIVE") and ns:
-        r["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / ns
+        r["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / ns       # (the counter is summed over the 8 XCDs)
     if c.get("SQ_WAVE_CYCLES") and c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("SQ_WAVES"):
         # per sampled wave: matrix-pipe busy cycles / wave lifetime (SQ_WAVE_CYCLES ticks in quad-cycles: x4)
         r["mfma_busy_over_wave_lifetime"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_WAVE_CYCLES"])
