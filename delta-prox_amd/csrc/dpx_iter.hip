@@ -36,7 +36,8 @@ struct IterTerms {
                        // sees v_i alone; applied as fma(dual, u, K x) / fma(-dual, u', v): the same instructions, and exact for dual = 1
   int emit_bf16;       // x_out / v_out / rhs_out are bf16 planes (the bf16 history of the unrolled forward pass) instead of fp32
   int u_live;          // 0: the incoming duals are all zero (DPX_TERM_U_ZERO, first iteration after ADMM.initialize) -- the streaming kernel then
-                       // fetches every u row from row 0 of plane 0 (cache hits) instead of streaming the planes from HBM
+                       // fetches every u row from row 0 of plane 0 (cache hits) instead of streaming the planes from HBM, the lock-step
+                       // kernel does not load them at all
   float* rhs_out;      // nullable: the next x-update's right-hand-side increment rho' sum K_i^T (v_i - u_i) as an image (the unrolled
                        // forward pass keeps it for the backward pass); like x_out / v_out an emit store, never counted in the waits
 };
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
     for (int i = 0; i < NT; ++i) {
       const float2* urow = (const float2*)(TT.t[i].u_in + plane_px + (size_t)hz * (2 * M));
 #pragma unroll
-      for (int m = 0; m < V; ++m) ureg[i][m] = z_live ? urow[t + m * T] : make_float2(0.f, 0.f);
+      for (int m = 0; m < V; ++m) ureg[i][m] = (z_live && TT.u_live) ? urow[t + m * T] : make_float2(0.f, 0.f);    // (u_live = 0: the duals count as zero, DPX_TERM_U_ZERO)
     }
     // ---------------- phase A: inverse row transform of row q ----------------
     float2 xa[V];

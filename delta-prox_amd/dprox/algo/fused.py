@@ -166,16 +166,32 @@ def fresh_state(solver, state):
     return all(t._version == n and t.is_contiguous() for t, n in zip([x] + v + u, vers))
 
 
+_sched_cache = {}        # (data_ptr, shape, version, T, B, device) -> (source tensor, table): a schedule handed in again costs nothing
+
+
 def schedule_table(vals, T, B, device):
-    """0-d / [T] / [B,T] -> contiguous [T,B] float32 on device"""
+    """0-d / [T] / [B,T] -> contiguous [T,B] float32 on device (cached while the caller passes the same, unmodified tensor: a loop
+    that calls iters() / solve() with its own schedule tensors then launches no kernel for them)"""
+    key = None
+    if isinstance(vals, torch.Tensor) and not vals.requires_grad:
+        key = (vals.data_ptr(), tuple(vals.shape), tuple(vals.stride()), vals._version, vals.dtype, str(vals.device), T, B, str(device))
+        hit = _sched_cache.get(key)
+        if hit is not None:
+            return hit[1]
     v = vals.to(device=device, dtype=torch.float32)
     if v.ndim == 0:
         v = v.expand(T)
     if v.ndim == 1:
-        return v[:T].reshape(T, 1).expand(T, B).contiguous()
-    if v.ndim == 2 and v.shape[0] == B:
-        return v[:, :T].t().contiguous()
-    raise be.DpxError(f"schedule of shape {tuple(vals.shape)} does not fit batch {B} x {T} iterations")
+        tab = v[:T].reshape(T, 1).expand(T, B).contiguous()
+    elif v.ndim == 2 and v.shape[0] == B:
+        tab = v[:, :T].t().contiguous()
+    else:
+        raise be.DpxError(f"schedule of shape {tuple(vals.shape)} does not fit batch {B} x {T} iterations")
+    if key is not None:
+        if len(_sched_cache) >= 32:
+            _sched_cache.pop(next(iter(_sched_cache)))
+        _sched_cache[key] = (vals, tab)          # (the source is kept alive: its address cannot be handed to another tensor meanwhile)
+    return tab
 
 
 def _sigma_table(fn, lt):

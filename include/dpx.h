@@ -270,7 +270,7 @@ typedef struct dpx_term {
  * u / u_out are still read / written (scratch).  Set on every term of the call or on none.                                      */
 #define DPX_TERM_NO_DUAL 1
 /* the incoming duals u are all zero (the state comes straight from ADMM.initialize, algo/admm.py:61-67): dpx_admm_iter_rows /
- * the FIRST iteration of a dpx_admm_run call need not stream them from HBM (the buffers must still hold zeros: row 0 is read).
+ * the FIRST iteration of a dpx_admm_run call need not stream them from HBM (only row 0 of plane 0 of every u must hold zeros).
  * Set on every term of the call or on none.                                                                                 */
 #define DPX_TERM_U_ZERO 2
 
