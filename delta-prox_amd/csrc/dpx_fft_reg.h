@@ -17,6 +17,34 @@ namespace dpx {
 __device__ __forceinline__ int lds_slot(int i) { return i + (i >> 4); }
 template <int N> struct LdsSeq { static constexpr int SLOTS = N + N / 16; };
 
+// Experiment, OFF by default (-DDPX_FFT_BASEOFF=1 enables it): the slot of every LDS access of the three passes as  base(t) +
+// compile-time constant, so that the constant becomes the instruction's immediate offset (written as lds_slot(t-dependent index +
+// constant) the compiler re-derives `i + (i >> 4)` per access).  Valid for the splits the kernels use (checked exhaustively against
+// lds_slot on the host; the emulator tests pass with it).  Measured at 8x3x1024^2, alternating runs on one box: the column kernel's
+// static instruction count 5468 -> 4895 (v_ashrrev 153 -> 29, LDS instructions 400 -> 304: paired ds_read2 / ds_write2), and it got
+// SLOWER -- k_cols_p2 70.5 -> 73.5 us, k_iter_rows_seq 104.5 -> 105.0 us: the kernel is bound by its dependent chain, not by VALU
+// issue, and the paired LDS instructions lengthen that chain.
+#ifndef DPX_FFT_BASEOFF
+#define DPX_FFT_BASEOFF 0
+#endif
+template <int N, int T> struct LdsIdx {
+  static constexpr int V = N / T, RM = N / (V * V);
+  static constexpr bool FAST = DPX_FFT_BASEOFF && (T % 16 == 0) && (V == 8 || V == 16) && (T % V == 0) &&
+                               (RM == 1 || ((N / RM) % 16 == 0 && RM % 2 == 0));
+  // pass A writes element t V + m
+  __device__ static __forceinline__ int base_a(int t) { return V == 16 ? 17 * t : 8 * t + (t >> 1); }
+  // pass B reads element t + i T + mm N/RM; pass C reads element t + m T
+  __device__ static __forceinline__ int base_t(int t) { return t + (t >> 4); }
+  __device__ static constexpr int off_br(int i, int mm) { return (i * T + mm * (N / RM)) + (i * T + mm * (N / RM)) / 16; }
+  __device__ static constexpr int off_c(int m) { return m * T + (m * T) / 16; }
+  // pass B writes element (jb - k) RM + k + mm V,  jb = t + i T,  k = jb % V = t % V
+  __device__ static __forceinline__ int base_bw(int t) {
+    const int k = t % V, tb = t - k;
+    return RM * tb + k + (RM * tb) / 16;
+  }
+  __device__ static constexpr int off_bw(int i, int mm) { return RM * i * T + (RM * i * T) / 16 + mm * V + (V == 16 ? mm : (mm >> 1)); }
+};
+
 // ---- small in-register DFTs, natural order in and out ------------------------------------------------
 template <int DIR> __device__ __forceinline__ void rdft2(float2& a, float2& b) {
   const float2 t = csub(a, b);
@@ -95,21 +123,37 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
   constexpr int RM = N / (V * V);
   static_assert(V * V * RM == N && (RM == 1 || RM == 2 || RM == 4 || RM == 8), "unsupported N/T split");
   static_assert(RM <= V, "middle radix must fit the per-thread registers");
+  using IX = LdsIdx<N, T>;
   // pass A: radix V, stride 1, no twiddles
   rdft<V, DIR>(v);
+  if constexpr (IX::FAST) {
+    float2* pa = lds + IX::base_a(t);
 #pragma unroll
-  for (int m = 0; m < V; ++m) lds[lds_slot(t * V + m)] = v[m];
+    for (int m = 0; m < V; ++m) pa[m] = v[m];
+  } else {
+#pragma unroll
+    for (int m = 0; m < V; ++m) lds[lds_slot(t * V + m)] = v[m];
+  }
   sync();
   if constexpr (RM > 1) {
     // pass B: radix RM, Ns = V; this thread owns butterflies jb = t + i*T
     constexpr int NB = V / RM;
+    if constexpr (IX::FAST) {
+      const float2* pr = lds + IX::base_t(t);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int jb = t + i * T;
+      for (int i = 0; i < NB; ++i)
 #pragma unroll
-      for (int mm = 0; mm < RM; ++mm) v[i * RM + mm] = lds[lds_slot(jb + mm * (N / RM))];
+        for (int mm = 0; mm < RM; ++mm) v[i * RM + mm] = pr[IX::off_br(i, mm)];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int jb = t + i * T;
+#pragma unroll
+        for (int mm = 0; mm < RM; ++mm) v[i * RM + mm] = lds[lds_slot(jb + mm * (N / RM))];
+      }
     }
     sync();
+    float2* pw = lds + (IX::FAST ? IX::base_bw(t) : 0);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int jb = t + i * T;
@@ -120,16 +164,27 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
 #pragma unroll
       for (int mm = 1; mm < RM; ++mm) a[mm] = twmul<DIR>(a[mm], tw[(k * mm * V) * tws]);   // W_{V*RM}^{k*mm}
       rdft<RM, DIR>(a);
-      const int j0 = (jb - k) * RM + k;
+      if constexpr (IX::FAST) {
 #pragma unroll
-      for (int mm = 0; mm < RM; ++mm) lds[lds_slot(j0 + mm * V)] = a[mm];
+        for (int mm = 0; mm < RM; ++mm) pw[IX::off_bw(i, mm)] = a[mm];
+      } else {
+        const int j0 = (jb - k) * RM + k;
+#pragma unroll
+        for (int mm = 0; mm < RM; ++mm) lds[lds_slot(j0 + mm * V)] = a[mm];
+      }
     }
     sync();
   }
   // pass C: radix V, Ns = N/V = T.  Twiddles W_N^{t*m} are exact table values; they are applied in groups
   // of four so that at most four of them are live at a time (register pressure at V = 16).
+  if constexpr (IX::FAST) {
+    const float2* pc = lds + IX::base_t(t);
 #pragma unroll
-  for (int m = 0; m < V; ++m) v[m] = lds[lds_slot(t + m * T)];
+    for (int m = 0; m < V; ++m) v[m] = pc[IX::off_c(m)];
+  } else {
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[m] = lds[lds_slot(t + m * T)];
+  }
   after_reads();
   const unsigned tstep = (unsigned)(t * tws);
 #pragma unroll
@@ -264,19 +319,35 @@ template <int N, int T, int DIR, bool KEEPB, class Sync>
 __device__ __forceinline__ void fft_reg_tw(float2 (&v)[N / T], float2* __restrict__ lds, int t, const TwRegs<N, T, KEEPB>& W, Sync sync) {
   constexpr int V = N / T;
   constexpr int RM = N / (V * V);
+  using IX = LdsIdx<N, T>;
   rdft<V, DIR>(v);
+  if constexpr (IX::FAST) {
+    float2* pa = lds + IX::base_a(t);
 #pragma unroll
-  for (int m = 0; m < V; ++m) lds[lds_slot(t * V + m)] = v[m];
+    for (int m = 0; m < V; ++m) pa[m] = v[m];
+  } else {
+#pragma unroll
+    for (int m = 0; m < V; ++m) lds[lds_slot(t * V + m)] = v[m];
+  }
   sync();
   if constexpr (RM > 1) {
     constexpr int NB = V / RM;
+    if constexpr (IX::FAST) {
+      const float2* pr = lds + IX::base_t(t);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int jb = t + i * T;
+      for (int i = 0; i < NB; ++i)
 #pragma unroll
-      for (int mm = 0; mm < RM; ++mm) v[i * RM + mm] = lds[lds_slot(jb + mm * (N / RM))];
+        for (int mm = 0; mm < RM; ++mm) v[i * RM + mm] = pr[IX::off_br(i, mm)];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int jb = t + i * T;
+#pragma unroll
+        for (int mm = 0; mm < RM; ++mm) v[i * RM + mm] = lds[lds_slot(jb + mm * (N / RM))];
+      }
     }
     sync();
+    float2* pw = lds + (IX::FAST ? IX::base_bw(t) : 0);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int jb = t + i * T;
@@ -290,14 +361,25 @@ __device__ __forceinline__ void fft_reg_tw(float2 (&v)[N / T], float2* __restric
         else a[mm] = twmul<DIR>(a[mm], W.twb_[(k * mm) * W.bstride_]);
       }
       rdft<RM, DIR>(a);
-      const int j0 = (jb - k) * RM + k;
+      if constexpr (IX::FAST) {
 #pragma unroll
-      for (int mm = 0; mm < RM; ++mm) lds[lds_slot(j0 + mm * V)] = a[mm];
+        for (int mm = 0; mm < RM; ++mm) pw[IX::off_bw(i, mm)] = a[mm];
+      } else {
+        const int j0 = (jb - k) * RM + k;
+#pragma unroll
+        for (int mm = 0; mm < RM; ++mm) lds[lds_slot(j0 + mm * V)] = a[mm];
+      }
     }
     sync();
   }
+  if constexpr (IX::FAST) {
+    const float2* pc = lds + IX::base_t(t);
 #pragma unroll
-  for (int m = 0; m < V; ++m) v[m] = lds[lds_slot(t + m * T)];
+    for (int m = 0; m < V; ++m) v[m] = pc[IX::off_c(m)];
+  } else {
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[m] = lds[lds_slot(t + m * T)];
+  }
 #pragma unroll
   for (int m = 1; m < V; ++m) v[m] = twmul<DIR>(v[m], W.c[m - 1]);
   rdft<V, DIR>(v);
