@@ -448,19 +448,16 @@ def main():
     K_steady = 200
     # ---- leg 3, the headline: W warm-up steps, then exactly K timed steps.  It follows leg 2 directly (no host work in between), so
     #      the GPU has been under load for ~40 ms when the warm-up starts.  This GPU needs tens of milliseconds of sustained load to
-    #      reach its clocks and loses them within a few milliseconds of idling (tools/ramp_probe.py): leg 4 shows what the same
-    #      region measures when the GPU idled in front of the W warm-up steps.
+    #      reach its clocks and loses them within a few milliseconds of idling (tools/ramp_probe.py): the last leg shows what the
+    #      same region measures when the GPU idled in front of the W warm-up steps.
     dt = timed_region(K) if K != 200 else dt_steady
-    # ---- leg 4: the same region after the GPU idled for half a second (the clock ramp falls into the timed steps)
-    time.sleep(0.5)
-    dt_idle = timed_region(K)
-    # ---- a warm 50-iteration solve (tables and data spectrum cached): cold - warm = what a first solve pays for its setup
+    # ---- leg 4: a warm 50-iteration solve (tables and data spectrum cached): cold - warm = what a first solve pays for its setup
     barrier()
     t0 = time.perf_counter()
     solver.solve(x0=b, rhos=RHO, lams=LAM, max_iter=50)
     barrier()
     warm_ms = 1e3 * (time.perf_counter() - t0)
-    # ---- the same cold solve in a warm process: a NEW problem (fresh observation tensor, freshly compiled solver: no table, no data
+    # ---- leg 5: the same cold solve in a warm process: a NEW problem (fresh observation tensor, freshly compiled solver: no table, no data
     #      spectrum cached) while the allocator's pool, the code objects and the FFT twiddle tables of this process are warm -- what a
     #      long-running caller pays per new problem
     b2 = b.clone()
@@ -473,6 +470,9 @@ def main():
     barrier()
     cold2_ms = 1e3 * (time.perf_counter() - t0)
     del solver2, b2, x2
+    # ---- leg 6 (last): the same region after the GPU idled for half a second (the clock ramp falls into the timed steps)
+    time.sleep(0.5)
+    dt_idle = timed_region(K)
     rhos, lams = rhos[..., :K], {k: v[..., :K] for k, v in lams.items()}
 
     # ---- second pass with per-kernel HIP-event timers (roofline leg) -------------------------------------

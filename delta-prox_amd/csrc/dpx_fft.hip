@@ -160,9 +160,13 @@ __device__ void stockham_pass(const CT* __restrict__ in, CT* __restrict__ out, i
   const int nb = N / R;
   const int twm = (N / (Ns * R)) * tscale;
   const int rstride = nb * tscale;
+  // (power-of-two butterfly counts: shifts and masks instead of two integer divisions per butterfly -- a third of a pass's
+  //  instructions on the fp64 path, whose butterflies are one per thread and pass)
+  const bool p2 = (nb & (nb - 1)) == 0 && (Ns & (Ns - 1)) == 0;
+  const int lnb = 31 - __builtin_clz((unsigned)(nb > 0 ? nb : 1));
   for (int i = tid; i < nseq * nb; i += nthr) {
-    const int s = i / nb, j = i - s * nb;
-    const int k = j % Ns;
+    const int s = p2 ? (i >> lnb) : i / nb, j = i - s * nb;
+    const int k = p2 ? (j & (Ns - 1)) : j % Ns;
     const CT* src = in + s * ld;
     CT* dst = out + s * ld;
     CT v[R];
@@ -453,12 +457,14 @@ __global__ void __launch_bounds__(512) k_rows_r2c_f64(const float* __restrict__ 
   __syncthreads();
   const Twid<double2> twd{tw64, W};
   const double2* z = fft_lds<-1, double2, IdxPad8>(a, b, plan, twd, EVEN ? 2 : 1, nseq, ld, tid, nthr);
-  // (tile, row, column-in-tile) order: the rows of a workgroup are adjacent in every tile
-  for (int i = tid; i < NTL * nseq * CT; i += nthr) {
-    const int kk = i % CT, s = (i / CT) % nseq, kt = i / (CT * nseq);
+  // (tile, row, column-in-tile) order: the rows of a workgroup are adjacent in every tile.  nthr is a multiple of CT * rpb: a thread
+  // keeps its (row, column-in-tile) and walks the tiles -- no division in the loop
+  const int kk = tid % CT, s = (tid / CT) % rpb, kt0 = tid / (CT * rpb), kstep = nthr / (CT * rpb);
+  const int row = row0 + (s < nseq ? s : 0), p = row / H, h = row - p * H;
+  const double2* zs = z + s * ld;
+  for (int kt = kt0; kt < NTL && s < nseq; kt += kstep) {
     const int k = kt * CT + kk;
     if (k >= Wh) continue;
-    const double2* zs = z + s * ld;
     double2 X;
     if (!EVEN) {
       X = zs[IdxPad8::at(k)];
@@ -473,7 +479,6 @@ __global__ void __launch_bounds__(512) k_rows_r2c_f64(const float* __restrict__ 
       const double2 o = make_double2(d.y, -d.x);                 // -i * d
       X = gadd(e, gmul(o, tw64[k]));
     }
-    const int row = row0 + s, p = row / H, h = row - p * H;
     spec[(((size_t)p * NTL + kt) * H + h) * CT + kk] = X;
   }
 }
@@ -512,10 +517,13 @@ __global__ void __launch_bounds__(512) k_cols_fwd_f64(const double2* __restrict_
     return l < Wh ? l : -1;
   };
   const double2* base = spec + (size_t)p * NTL * H * CT;
-  for (int i = tid; i < H * CT; i += nthr) {
-    const int c = i % CT, r = i / CT;
-    const int l = col_of(c);
-    a[c * ld + IdxPad8::at(r)] = l >= 0 ? base[((size_t)(l / CT) * H + r) * CT + (l % CT)] : make_double2(0.0, 0.0);
+  // (nthr is a multiple of CT: a thread keeps its column, rows advance by nthr / CT -- no division in the loops)
+  const int c_own = tid % CT, r_own = tid / CT, r_step = nthr / CT;
+  const int l_own = col_of(c_own);
+  {
+    const double2* src = base + ((size_t)(l_own >= 0 ? l_own / CT : 0) * H) * CT + (l_own >= 0 ? l_own % CT : 0);
+    double2* dst = a + c_own * ld;
+    for (int r = r_own; r < H; r += r_step) dst[IdxPad8::at(r)] = l_own >= 0 ? src[(size_t)r * CT] : make_double2(0.0, 0.0);
   }
   __syncthreads();
   const Twid<double2> twd{tw64, H};
@@ -524,10 +532,9 @@ __global__ void __launch_bounds__(512) k_cols_fwd_f64(const double2* __restrict_
   float2* o = out + (size_t)p * H * Ws;
   int nyq_slot = -1;                                        // the slot holding the Nyquist column, if this workgroup has the DC column
   if (packed && lt == 0) nyq_slot = tn != 0 ? CT - 1 : nyq % CT;
-  for (int i = tid; i < H * CT; i += nthr) {
-    const int c = i % CT, k = i / CT;
-    const int l = col_of(c);
-    if (l < 0 || (packed && l == nyq)) continue;           // (the Nyquist column is consumed by the DC column's lanes)
+  for (int k = r_own; k < H; k += r_step) {
+    const int c = c_own, l = l_own;
+    if (l < 0 || (packed && l == nyq)) break;              // (the Nyquist column is consumed by the DC column's lanes)
     double2 v = z[c * ld + IdxPad8::at(k)];
     if (otf) {
       const float2 t = otf[tmain + spec_main_index(side_layout, H, Ws, k, l)];
@@ -847,7 +854,13 @@ extern "C" int dpx_fft_conv(const float* x, float* y, const void* otf, int conj_
 // geometry of the fp64 data-spectrum pass: CT columns per column workgroup (LDS: two images of CT sequences of H fp64 points),
 // RPB rows per row workgroup; 0 = the plane does not fit the LDS-resident transform
 static size_t ds_ld(int n) { return (size_t)n + n / 8 + 1; }      // padded LDS length of one fp64 sequence (IdxPad8)
-static int ds_ct(int H) { return 4 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 4 : (2 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 2 : 0); }
+static int ds_ct(int H) {
+  // two columns per workgroup (256 threads, two workgroups per CU: one loads while the other transforms) beat four (512 threads, one per
+  // CU) at 8x3x1024^2: column pass 234 vs 267 us, row pass 164 vs 156 us (64-byte instead of 128-byte pieces); DPX_DS_CT=4 forces four
+  static const int env = getenv("DPX_DS_CT") ? atoi(getenv("DPX_DS_CT")) : 0;
+  if (env == 4 && 4 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024) return 4;
+  return 2 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 2 : 0;
+}
 static int ds_rpb(int W) {
   const int M = (W % 2 == 0) ? W / 2 : W;
   // (measured at 8x3x1024^2, 256 threads: 2 rows per workgroup -- 4 workgroups per CU -- 174 us, 4 rows 207 us, 1 row 225 us)
