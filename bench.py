@@ -460,16 +460,19 @@ def main():
     # ---- leg 5: the same cold solve in a warm process: a NEW problem (fresh observation tensor, freshly compiled solver: no table, no data
     #      spectrum cached) while the allocator's pool, the code objects and the FFT twiddle tables of this process are warm -- what a
     #      long-running caller pays per new problem
-    b2 = b.clone()
-    x2 = dp.Variable()
-    solver2 = dp.compile(dp.sum_squares(dp.conv(x2, psf) - b2) + dp.norm1(dp.grad(x2, dim=0)) + dp.norm1(dp.grad(x2, dim=1)), method="admm", device=device)
-    solver.solve(x0=b, rhos=RHO, lams=LAM, max_iter=50)      # (load in front, as for the headline: clocks)
-    barrier()
-    t0 = time.perf_counter()
-    solver2.solve(x0=b2, rhos=RHO, lams=LAM, max_iter=50)
-    barrier()
-    cold2_ms = 1e3 * (time.perf_counter() - t0)
-    del solver2, b2, x2
+    cold_runs = []
+    for _ in range(2):          # (twice: the first new problem may still make the caching allocator grow its pool -- a hipMalloc of 100 MB
+        b2 = b.clone()          #  takes ~10 ms --, the second one is the steady per-problem cost)
+        x2 = dp.Variable()
+        solver2 = dp.compile(dp.sum_squares(dp.conv(x2, psf) - b2) + dp.norm1(dp.grad(x2, dim=0)) + dp.norm1(dp.grad(x2, dim=1)), method="admm", device=device)
+        solver.solve(x0=b, rhos=RHO, lams=LAM, max_iter=50)      # (load in front, as for the headline: clocks)
+        barrier()
+        t0 = time.perf_counter()
+        solver2.solve(x0=b2, rhos=RHO, lams=LAM, max_iter=50)
+        barrier()
+        cold_runs.append(1e3 * (time.perf_counter() - t0))
+        del solver2, b2, x2
+    cold2_ms = min(cold_runs)
     # ---- leg 6 (last): the same region after the GPU idled for half a second (the clock ramp falls into the timed steps)
     time.sleep(0.5)
     dt_idle = timed_region(K)
@@ -575,7 +578,7 @@ def main():
         "steady_state": {"steps": K_steady, "it_per_s": world * K_steady / dt_steady, "ms_per_step": 1e3 * dt_steady / K_steady,
                          "roofline_iteration_frac": (K_steady / dt_steady) * DESIGN_BYTES_PER_ELEM * n_elem / HBM_PEAK},
         "cold_solve": {"cold_solve50_ms": cold2_ms, "warm_solve50_ms": warm_ms, "setup_ms": cold2_ms - warm_ms,
-                       "first_solve_of_the_process_ms": cold_ms,
+                       "first_solve_of_the_process_ms": cold_ms, "cold_solve50_runs_ms": cold_runs,
                        "steady_50_iterations_ms": 50 * 1e3 * dt_steady / K_steady,
                        "cold_over_50_steady_iterations": cold2_ms / (50 * 1e3 * dt_steady / K_steady),
                        "setup_profile": setup,

@@ -12,21 +12,11 @@
 // LDL^T factorisation in float64 on one wavefront (B <= 64; pivots >= 0), no eigen-solver needed.  Once the test succeeds
 // the state's `done` flag is set and every later control kernel of the solve returns immediately (the iterate is frozen at
 // exactly the reference's exit point; `n_done` = the iteration index the reference prints in "Converged at CG Iter").
-#include "dpx_common.h"
+#include <cstdlib>
+
+#include "dpx_cg_dev.h"
 
 namespace dpx {
-
-// state block: floats gamma[B], gamma_prev[B], beta[B], pAp[B], tol2[B]; then ints done, n_done, it, pad
-struct CgState {
-  float* f;
-  int B;
-  __host__ __device__ float* gamma() const { return f; }
-  __host__ __device__ float* gamma_prev() const { return f + B; }
-  __host__ __device__ float* beta() const { return f + 2 * B; }
-  __host__ __device__ float* pAp() const { return f + 3 * B; }
-  __host__ __device__ float* tol2() const { return f + 4 * B; }
-  __host__ __device__ int* flags() const { return (int*)(f + 5 * B); }     // done, n_done, it
-};
 
 __global__ void k_cg_init(CgState S, const float* __restrict__ bnorm2, float rtol) {
   const int i = threadIdx.x;
@@ -47,68 +37,11 @@ __global__ void k_cg_init(CgState S, const float* __restrict__ bnorm2, float rto
   }
 }
 
-// one wavefront: M = tau^2 I - sym(G) in LDS (float64), right-looking LDL^T without pivoting; PSD <=> every pivot >= 0 (a zero
-// pivot must come with a zero column).  A NaN anywhere fails the test (the reference's `normr <= tol` is False for NaN too).
+// one wavefront: the stop rule and beta / gamma of the next iteration (cg_test_block, dpx_cg_dev.h)
 __global__ void __launch_bounds__(64) k_cg_test(CgState S, const float* __restrict__ G) {
   __shared__ double M[64 * 65];
-  __shared__ int ok;
-  const int B = S.B, t = threadIdx.x;
-  int* fl = S.flags();
-  if (fl[0]) return;                                        // converged earlier: the solve is frozen
-  float tau2 = INFINITY;
-  for (int i = 0; i < B; ++i) tau2 = fminf(tau2, S.tol2()[i]);
-  for (int e = t; e < B * B; e += 64) {
-    const int i = e / B, j = e - i * B;
-    const double g = 0.5 * ((double)G[i * B + j] + (double)G[j * B + i]);
-    M[i * 65 + j] = (i == j ? (double)tau2 : 0.0) - g;
-  }
-  if (t == 0) ok = 1;
-  __syncthreads();
-  // scale-aware zero threshold: round-off of the fp32 Gram entries
-  double scale = 0.0;
-  for (int i = 0; i < B; ++i) scale = fmax(scale, fabs((double)G[i * B + i]));
-  const double tiny = 1e-12 * fmax(scale, (double)tau2);
-  for (int k = 0; k < B; ++k) {
-    const double d = M[k * 65 + k];
-    if (!(d >= 0.0)) {                                      // negative or NaN pivot (uniform: every lane reads the same value)
-      if (t == 0) ok = 0;
-      break;
-    }
-    if (d <= tiny) {                                        // zero pivot: PSD only if the rest of the column vanishes
-      int bad = 0;
-      for (int i = k + 1 + t; i < B; i += 64) bad |= fabs(M[i * 65 + k]) > tiny;
-      if (__any(bad)) {
-        if (t == 0) ok = 0;
-        break;
-      }
-      continue;
-    }
-    const double inv = 1.0 / d;
-    for (int i = k + 1 + t; i < B; i += 64) {               // lane i owns row i of the trailing block
-      const double l = M[i * 65 + k] * inv;
-      for (int j = k + 1; j <= i; ++j) M[i * 65 + j] -= l * M[j * 65 + k];
-    }
-    __syncthreads();
-    // mirror the updated lower triangle's column entries used as M[j][k'] for later pivots: rows read M[j*65+k] with j > k only
-    // from the lower triangle (j >= k' > ...), which is what the update above maintains -- nothing to mirror
-  }
-  __syncthreads();
-  if (ok) {
-    if (t == 0) {
-      fl[0] = 1;
-      fl[1] = fl[2];
-    }
-    return;
-  }
-  const bool first = fl[2] == 0;
-  __syncthreads();
-  if (t < B) {
-    const float g = G[t * B + t];                           // gamma_i = <r_i, r_i>
-    S.beta()[t] = first ? 0.f : g / S.gamma_prev()[t];      // beta = gamma / gamma_1   (solver_cg.py:112)
-    S.gamma()[t] = g;
-    S.gamma_prev()[t] = g;
-  }
-  if (t == 0) fl[2] += 1;
+  __shared__ int sh[2];
+  cg_test_block(S, G, M, sh, -1.f);
 }
 
 // p = r + beta_b * p        (solver_cg.py:111-115; beta = 0 in the first iteration)
@@ -159,6 +92,25 @@ __global__ void k_cg_update1(float* __restrict__ x, float* __restrict__ r, const
   }
 }
 
+// start of a fused solve: r = b, x = p = 0, control flags and the two arrival counters cleared (one launch instead of a copy, two
+// fills and the state initialisation; the tolerances are set by the first stop test from the Gram diagonal)
+__global__ void k_cgm_start(float* __restrict__ x, float* __restrict__ r, float* __restrict__ p, const float* __restrict__ b, long n, int* __restrict__ flags,
+                            unsigned* __restrict__ counters) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    r[i] = b[i];
+    x[i] = 0.f;
+    p[i] = 0.f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    flags[0] = 0;
+    flags[1] = -1;
+    flags[2] = 0;
+    flags[3] = 0;
+    counters[0] = 0u;
+    counters[1] = 0u;
+  }
+}
+
 __global__ void k_square(float* __restrict__ out, const float* __restrict__ w, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = w[i] * w[i];
 }
@@ -170,6 +122,10 @@ using namespace dpx;
 namespace dpx {
 int masked_normal_apply(const float* p, float* Ap, float2* z, const float* mask2, int mask_images, const float* rho, float c, const int* done,
                         int B, int H, int W, const void* table, hipStream_t s);     // dpx_fft.hip
+int masked_normal_apply_fused(float* p, const float* r, float* Ap, float2* z, const float* mask, int mask_images, const float* rho, float c,
+                              float* state, float* dotws, unsigned* counter, int B, int H, int W, const void* table, hipStream_t s);
+size_t masked_normal_fused_ws_floats(int B, int H, int W);
+int gram_test_fused(const float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, hipStream_t s);   // dpx_elementwise.hip
 }
 
 extern "C" size_t dpx_cg_state_bytes(int B) { return B > 0 ? (size_t)(5 * B + 4) * sizeof(float) : 0; }
@@ -236,7 +192,8 @@ extern "C" int dpx_cg_masked_fft_supported(int B, int H, int W) { return B >= 1 
 constexpr int DPX_CG_MAX_DEVICES = 64;
 extern "C" size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_images) {
   const size_t n = (size_t)H * W;
-  return (3 * B * n + 4 * B * n + (size_t)mask_images * n + 5 * B + 4 + (size_t)B * B + 64) * sizeof(float) + dpx_bdot_ws_bytes(B, (long)n) + 256;
+  return (3 * B * n + 4 * B * n + (size_t)mask_images * n + 5 * B + 4 + (size_t)B * B + 64) * sizeof(float) + dpx_bdot_ws_bytes(B, (long)n) + 256 +
+         (dpx::masked_normal_fused_ws_floats(B, H, W) + 8) * sizeof(float);
 }
 
 extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol,
@@ -302,6 +259,43 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
     const int rc_ = (call);          \
     if (rc_ != DPX_OK) return rc_;   \
   } while (0)
+  const int n_it = max_iters < (int)((long)B * n) ? max_iters : (int)((long)B * n);
+  const int LAG = 2;
+  int done_it = n_it;
+  bool done = false;
+  int last = -1;
+  // ---- B <= 8: the fused iteration -- 5 launches (Gram pass + its finish + the stop rule; the operator's three kernels with the
+  //      direction update in the first one's load and <p, Ap> in the last one's store; the x / r update) instead of 10, and one
+  //      launch instead of seven in front of the loop.  The partial sums of a launch are finished by its LAST workgroup to arrive
+  //      (dpx_last_block: no workgroup waits for another); same state machine, same exit iteration.
+  static const bool unfused = getenv("DPX_CG_UNFUSED") != nullptr;      // (A/B and tests: the step-by-step sequence below)
+  if (B <= 8 && !unfused) {
+    float* fdot = (float*)((char*)dotws + dpx_bdot_ws_bytes(B, n));
+    unsigned* counters = (unsigned*)(fdot + dpx::masked_normal_fused_ws_floats(B, H, W));
+    DPX_LAUNCH("k_cgm_start", k_cgm_start, dim3(grid_for((long)B * n, 256, 1024)), dim3(256), 0, s, x, r, p, b, (long)B * n, flags, counters);
+    for (int it = 0; it < n_it; ++it) {
+      if (it >= LAG) {
+        CG_HIP(hipEventSynchronize(ev[(it - LAG) & 3]));
+        if (pin[((it - LAG) & 3) * 4]) {
+          done = true;
+          done_it = pin[((it - LAG) & 3) * 4 + 1];
+          break;
+        }
+      }
+      CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, s));
+      CG_TRY(dpx::masked_normal_apply_fused(p, r, Ap, z0, mask, mask_images, rho, n_identity, state, fdot, counters + 1, B, H, W, table, s));
+      CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));
+      CG_HIP(hipMemcpyAsync(pin + (it & 3) * 4, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+      CG_HIP(hipEventRecord(ev[it & 3], s));
+      last = it;
+    }
+    if (!done && last >= 0) {
+      CG_HIP(hipEventSynchronize(ev[last & 3]));
+      if (pin[(last & 3) * 4]) done_it = pin[(last & 3) * 4 + 1];
+    }
+    const int st = launch_status("dpx_cg_masked_fft");
+    return st != DPX_OK ? st : done_it;
+  }
   // r = b, x = p = 0, tolerances
   CG_HIP(hipMemcpyAsync(r, b, (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, s));
   CG_HIP(hipMemsetAsync(x, 0, (size_t)B * n * sizeof(float), s));
@@ -309,11 +303,6 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   DPX_LAUNCH("k_square", k_square, dim3(grid_for((long)mask_images * n, 256, 1024)), dim3(256), 0, s, mask2, mask, (long)mask_images * n);
   CG_TRY(dpx_bdot(b, b, gram, B, n, dotws, stream));                      // <b_i, b_i> (gram reused as scratch)
   CG_TRY(dpx_cg_init(state, gram, rtol, B, stream));
-  const int n_it = max_iters < (int)((long)B * n) ? max_iters : (int)((long)B * n);
-  const int LAG = 2;
-  int done_it = n_it;
-  bool done = false;
-  int last = -1;
   for (int it = 0; it < n_it; ++it) {
     if (it >= LAG) {
       CG_HIP(hipEventSynchronize(ev[(it - LAG) & 3]));

@@ -10,7 +10,7 @@
 //   * bdot and the CG AXPYs                                  dprox/linalg/solve/solver_cg.py:7-22,109-129
 // All of them are one coalesced float4 pass over each operand; halo values of the stencils come
 // from L2 (the neighbouring row/pixel was just streamed by the same or the adjacent workgroup).
-#include "dpx_common.h"
+#include "dpx_cg_dev.h"
 
 namespace dpx {
 
@@ -261,9 +261,9 @@ __global__ void k_dot_finish(const float* __restrict__ partial, float* __restric
 // iteration and up to 1024 workgroups, so that a 32 x 320^2 residual (800 slabs) fills the chip: 125 us -> ~10 us.
 // Summation order is fixed (per-wave partials are added in wave order, slabs by the finishing kernel).
 constexpr int GR_CH = 128, GR_P = GR_CH + 1;
-__global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, float* __restrict__ partial, int B, long npb, int nblk) {
-  __shared__ float sx[32 * GR_P];
-  __shared__ float red[3][64][16];
+// sx: 32 * GR_P floats, red: 3 * 64 * 16 floats of shared memory
+__device__ __forceinline__ void gram_tile_body(const float* __restrict__ r, float* __restrict__ partial, int B, long npb, int nblk, float* sx,
+                                               float* red) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ti = (lane >> 3) * 4, tj = (lane & 7) * 4;
   float acc[4][4];
 #pragma unroll
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, 
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) red[wave - 1][lane][a * 4 + q] = acc[a][q];
+      for (int q = 0; q < 4; ++q) red[((wave - 1) * 64 + lane) * 16 + a * 4 + q] = acc[a][q];
   }
   __syncthreads();
   if (wave == 0) {
@@ -300,10 +300,40 @@ __global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, 
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float v = ((acc[a][q] + red[0][lane][a * 4 + q]) + red[1][lane][a * 4 + q]) + red[2][lane][a * 4 + q];
+        const float v = ((acc[a][q] + red[(0 * 64 + lane) * 16 + a * 4 + q]) + red[(1 * 64 + lane) * 16 + a * 4 + q]) + red[(2 * 64 + lane) * 16 + a * 4 + q];
         if (ti + a < B && tj + q < B) partial[((long)(ti + a) * B + (tj + q)) * nblk + blockIdx.x] = v;
       }
   }
+}
+__global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, float* __restrict__ partial, int B, long npb, int nblk) {
+  __shared__ float sx[32 * GR_P];
+  __shared__ float red[3 * 64 * 16];
+  gram_tile_body(r, partial, B, npb, nblk, sx, red);
+}
+
+// The Gram pass of a device-controlled CG iteration with its two followers folded in: the LAST workgroup to arrive adds up the
+// slabs' partial products (one wave per entry, fixed order) and runs the stop rule / beta update on the finished matrix
+// (cg_test_block) -- k_gram_tile -> k_dot_finish -> k_cg_test in one launch.  B <= 8.
+__global__ void __launch_bounds__(256) k_gram_tile_test(const float* __restrict__ r, float* __restrict__ partial, float* __restrict__ G, CgState S,
+                                                        long npb, int nblk, unsigned* __restrict__ counter, float init_rtol) {
+  __shared__ double rawd[64 * 65];                        // the slabs' staging (28.8 KB), then the test's matrix (33.3 KB)
+  char* raw = (char*)rawd;
+  __shared__ int shf[3];
+  if (S.flags()[0]) return;                               // (uniform: the solve has converged, this launch ran ahead)
+  const int B = S.B;
+  float* sx = (float*)raw;
+  float* red = sx + 32 * GR_P;
+  gram_tile_body(r, partial, B, npb, nblk, sx, red);
+  if (!dpx_last_block(counter, (unsigned)nblk, &shf[2])) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int e = wave; e < B * B; e += 4) {
+    float acc = 0.f;
+    for (int i = lane; i < nblk; i += 64) acc += dpx_ld_agent(partial + (long)e * nblk + i);
+    acc = wave_sum(acc);
+    if (lane == 0) G[e] = acc;
+  }
+  __syncthreads();
+  cg_test_block(S, G, (double*)raw, shf, init_rtol);
 }
 
 static int gram_blocks(long npb) {
@@ -696,6 +726,16 @@ extern "C" int dpx_bdot(const float* x, const float* y, float* out, int B, long 
   DPX_LAUNCH("k_dot_finish", k_dot_finish, dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)ws, out, nblk);
   return launch_status("dpx_bdot");
 }
+
+namespace dpx {
+// Gram pass + finish + stop rule in one launch (dpx_cg_masked_fft's fused iteration, B <= 8); ws: B * B * gram_blocks floats
+int gram_test_fused(const float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, hipStream_t s) {
+  const int nblk = gram_blocks(n_per_batch);
+  DPX_LAUNCH("k_gram_tile_test", k_gram_tile_test, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch, nblk,
+             counter, init_rtol);
+  return launch_status("gram_test_fused");
+}
+}  // namespace dpx
 
 extern "C" int dpx_bgram(const float* r, float* out, int B, long n_per_batch, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(r && out && ws && B > 0 && n_per_batch > 0, "dpx_bgram: bad arguments");

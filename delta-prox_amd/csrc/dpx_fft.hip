@@ -11,7 +11,7 @@
 // planes take the register-radix kernels of dpx_fft_pow2.hip instead.
 #include <cstdlib>
 
-#include "dpx_common.h"
+#include "dpx_cg_dev.h"
 
 namespace dpx {
 
@@ -637,9 +637,13 @@ __global__ void k_ccols(float2* __restrict__ data, int H, int W, Plan1D plan, co
 //   k_crows_real_in : rows of the real image p -> centred orthonormal row spectra (complex)
 //   k_ccols_mask    : forward column transform -> * mask^2 -> inverse column transform, in place (one LDS residency)
 //   k_crows_real_out: inverse row transform -> real part + c rho_b p -> Ap
-__global__ void k_crows_real_in(const float* __restrict__ in, float2* __restrict__ out, int W, int nrows, Plan1D plan,
-                                const float2* __restrict__ twW, int rpb, float scale) {
+// dir_r != NULL: the CG direction update rides in the load -- p = r + beta_b p (solver_cg.py:111-115) is formed here, written back
+// to `in` (= p) and transformed, instead of a k_cg_direction launch in front
+__global__ void k_crows_real_in(float* __restrict__ in, float2* __restrict__ out, int W, int nrows, Plan1D plan,
+                                const float2* __restrict__ twW, int rpb, float scale, const float* __restrict__ dir_r,
+                                const float* __restrict__ beta, const int* __restrict__ done, int rows_per_image) {
   HIP_DYNAMIC_SHARED(float2, smem)
+  if (done && done[0]) return;                          // (block-uniform: the solve has converged, this launch ran ahead)
   const int ld = W + 1, hs = W / 2;
   float2* a = smem;
   float2* b = smem + rpb * ld;
@@ -650,7 +654,13 @@ __global__ void k_crows_real_in(const float* __restrict__ in, float2* __restrict
     const int s = i / W, n = i - s * W;
     int src = n + hs;
     if (src >= W) src -= W;
-    a[s * ld + n] = make_float2(in[(size_t)(row0 + s) * W + src], 0.f);
+    const size_t e = (size_t)(row0 + s) * W + src;
+    float v = in[e];
+    if (dir_r) {
+      v = fmaf(beta[(row0 + s) / rows_per_image], v, dir_r[e]);
+      in[e] = v;
+    }
+    a[s * ld + n] = make_float2(v, 0.f);
   }
   __syncthreads();
   const Twid<float2> twd{twW, W};
@@ -664,8 +674,9 @@ __global__ void k_crows_real_in(const float* __restrict__ in, float2* __restrict
 }
 
 __global__ void k_ccols_mask(float2* __restrict__ data, const float* __restrict__ mask2, int mask_images, int H, int W, Plan1D plan,
-                             const float2* __restrict__ twH, int CT) {
+                             const float2* __restrict__ twH, int CT, int square, const int* __restrict__ done) {
   HIP_DYNAMIC_SHARED(float2, smem)
+  if (done && done[0]) return;
   const int ld = H + 1, hs = H / 2;
   float2* a = smem;
   float2* b = smem + CT * ld;
@@ -689,7 +700,8 @@ __global__ void k_ccols_mask(float2* __restrict__ data, const float* __restrict_
     const int k = i / nseq, c = i - k * nseq;
     int row = k + hs;
     if (row >= H) row -= H;
-    z[c * ld + k] = cscale(z[c * ld + k], mk[(size_t)row * W + l0 + c]);
+    const float mv = mk[(size_t)row * W + l0 + c];
+    z[c * ld + k] = cscale(z[c * ld + k], square ? mv * mv : mv);     // (square: `mask2` holds the mask itself)
   }
   __syncthreads();
   const float2* y = fft_lds<+1, float2>(z, z == a ? b : a, plan, twd, 1, nseq, ld, tid, nthr);
@@ -701,10 +713,15 @@ __global__ void k_ccols_mask(float2* __restrict__ data, const float* __restrict_
   }
 }
 
+// dot_partial != NULL (rpb divides rows_per_image): <p_b, A p_b> rides in the store -- every workgroup leaves the sum over its rows,
+// the LAST one to arrive adds them up per image in a fixed order and writes pAp_b into the CG state (k_dot_partial + k_dot_finish)
 __global__ void k_crows_real_out(const float2* __restrict__ in, float* __restrict__ out, const float* __restrict__ pin, const float* __restrict__ rho,
                                  float c, const int* __restrict__ done, int rows_per_image, int W, int nrows, Plan1D plan,
-                                 const float2* __restrict__ twW, int rpb, float scale) {
+                                 const float2* __restrict__ twW, int rpb, float scale, float* __restrict__ dot_partial,
+                                 unsigned* __restrict__ counter, float* __restrict__ pAp, int B) {
   HIP_DYNAMIC_SHARED(float2, smem)
+  __shared__ float shred[16];
+  __shared__ int shlast;
   if (done && done[0]) return;                          // (block-uniform: the solve has converged, this launch ran ahead)
   const int ld = W + 1, hs = W / 2;
   float2* a = smem;
@@ -721,12 +738,38 @@ __global__ void k_crows_real_out(const float2* __restrict__ in, float* __restric
   __syncthreads();
   const Twid<float2> twd{twW, W};
   const float2* z = fft_lds<+1, float2>(a, b, plan, twd, 1, nseq, ld, tid, nthr);
+  float dacc = 0.f;
   for (int i = tid; i < nseq * W; i += nthr) {
     const int s = i / W, k = i - s * W;
     int dst = k + hs;
     if (dst >= W) dst -= W;
     const size_t e = (size_t)(row0 + s) * W + dst;
-    out[e] = fmaf(c * rho[(row0 + s) / rows_per_image], pin[e], z[s * ld + k].x * scale);
+    const float pv = pin[e];
+    const float av = fmaf(c * rho[(row0 + s) / rows_per_image], pv, z[s * ld + k].x * scale);
+    out[e] = av;
+    dacc = fmaf(pv, av, dacc);
+  }
+  if (!dot_partial) return;
+  {
+    // block sum (wave shuffles, then the waves' sums through LDS)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
+    if ((tid & 63) == 0) shred[tid >> 6] = dacc;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < (nthr + 63) / 64; ++w) t += shred[w];
+      dot_partial[blockIdx.x] = t;
+    }
+  }
+  if (!dpx_last_block(counter, gridDim.x, &shlast)) return;
+  const int bpi = rows_per_image / rpb, wave = tid >> 6, lane = tid & 63;          // workgroups per image
+  for (int bimg = wave; bimg < B; bimg += (nthr + 63) / 64) {
+    float t = 0.f;
+    for (int i = lane; i < bpi; i += 64) t += dpx_ld_agent(dot_partial + (size_t)bimg * bpi + i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) pAp[bimg] = t;
   }
 }
 
@@ -810,11 +853,44 @@ int masked_normal_apply(const float* p, float* Ap, float2* z, const float* mask2
   }
   const float scale = 1.0f / sqrtf((float)H * (float)W);
   const dim3 grow((B * H + rpb - 1) / rpb), gcol((W + CT - 1) / CT, B);
-  DPX_LAUNCH("k_crows_real_in", k_crows_real_in, grow, dim3(256), shrow, s, p, z, W, B * H, prow, tw_rows(table), rpb, scale);
-  DPX_LAUNCH("k_ccols_mask", k_ccols_mask, gcol, dim3(256), shcol, s, z, mask2, mask_images, H, W, pcol, tw_cols(table, W), CT);
+  DPX_LAUNCH("k_crows_real_in", k_crows_real_in, grow, dim3(256), shrow, s, (float*)p, z, W, B * H, prow, tw_rows(table), rpb, scale, (const float*)nullptr,
+             (const float*)nullptr, (const int*)nullptr, H);
+  DPX_LAUNCH("k_ccols_mask", k_ccols_mask, gcol, dim3(256), shcol, s, z, mask2, mask_images, H, W, pcol, tw_cols(table, W), CT, 0, (const int*)nullptr);
   DPX_LAUNCH("k_crows_real_out", k_crows_real_out, grow, dim3(256), shrow, s, (const float2*)z, Ap, p, rho, c, done, H, W, B * H, prow,
-             tw_rows(table), rpb, scale);
+             tw_rows(table), rpb, scale, (float*)nullptr, (unsigned*)nullptr, (float*)nullptr, B);
   return launch_status("masked_normal_apply");
+}
+
+// rows per row workgroup of the fused iteration: the largest divisor of H the LDS-resident transform holds (a workgroup's rows then
+// belong to one image: its <p, Ap> share is one number)
+static int fused_rpb(int H, int W) {
+  int r = rows_per_block(W);
+  while (r > 1 && H % r) --r;
+  return r;
+}
+size_t masked_normal_fused_ws_floats(int B, int H, int W) { return (size_t)B * (H / fused_rpb(H, W)) + 8; }
+
+// The matvec of dpx_cg_masked_fft's fused iteration: the three launches above with the CG direction update in front (p = r + beta p
+// formed in the first kernel's load) and <p, Ap> behind (partial sums in the last kernel's store, finished by its last workgroup
+// into the CG state).  `mask` is the mask itself (squared on the fly).  dotws: masked_normal_fused_ws_floats floats.
+int masked_normal_apply_fused(float* p, const float* r, float* Ap, float2* z, const float* mask, int mask_images, const float* rho, float c,
+                              float* state, float* dotws, unsigned* counter, int B, int H, int W, const void* table, hipStream_t s) {
+  const Plan1D prow = make_plan(W), pcol = make_plan(H);
+  const int rpb = fused_rpb(H, W);
+  const size_t shrow = (size_t)2 * rpb * (W + 1) * sizeof(float2);
+  int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
+  CT = CT < 1 ? 1 : (CT > 16 ? 16 : CT);
+  const size_t shcol = (size_t)2 * CT * (H + 1) * sizeof(float2);
+  const CgState S{state, B};
+  const int* done = S.flags();
+  const float scale = 1.0f / sqrtf((float)H * (float)W);
+  const dim3 grow(B * H / rpb), gcol((W + CT - 1) / CT, B);
+  DPX_LAUNCH("k_crows_real_in", k_crows_real_in, grow, dim3(256), shrow, s, p, z, W, B * H, prow, tw_rows(table), rpb, scale, r, (const float*)S.beta(), done,
+             H);
+  DPX_LAUNCH("k_ccols_mask", k_ccols_mask, gcol, dim3(256), shcol, s, z, mask, mask_images, H, W, pcol, tw_cols(table, W), CT, 1, done);
+  DPX_LAUNCH("k_crows_real_out", k_crows_real_out, grow, dim3(256), shrow, s, (const float2*)z, Ap, (const float*)p, rho, c, done, H, W, B * H, prow,
+             tw_rows(table), rpb, scale, dotws, counter, S.pAp(), B);
+  return launch_status("masked_normal_apply_fused");
 }
 
 }  // namespace dpx
