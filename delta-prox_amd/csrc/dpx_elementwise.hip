@@ -327,9 +327,17 @@ __global__ void __launch_bounds__(256) k_gram_tile_test(const float* __restrict_
   if (!dpx_last_block(counter, (unsigned)nblk, &shf[2])) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int e = wave; e < B * B; e += 4) {
-    float acc = 0.f;
-    for (int i = lane; i < nblk; i += 64) acc += dpx_ld_agent(partial + (long)e * nblk + i);
-    acc = wave_sum(acc);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // (four independent chains: the loads of a wave overlap)
+    const float* pe = partial + (long)e * nblk;
+    int i = lane;
+    for (; i + 192 < nblk; i += 256) {
+      a0 += dpx_ld_agent(pe + i);
+      a1 += dpx_ld_agent(pe + i + 64);
+      a2 += dpx_ld_agent(pe + i + 128);
+      a3 += dpx_ld_agent(pe + i + 192);
+    }
+    for (; i < nblk; i += 64) a0 += dpx_ld_agent(pe + i);
+    const float acc = wave_sum((a0 + a1) + (a2 + a3));
     if (lane == 0) G[e] = acc;
   }
   __syncthreads();
