@@ -10,6 +10,8 @@
 //   * bdot and the CG AXPYs                                  dprox/linalg/solve/solver_cg.py:7-22,109-129
 // All of them are one coalesced float4 pass over each operand; halo values of the stencils come
 // from L2 (the neighbouring row/pixel was just streamed by the same or the adjacent workgroup).
+#include <cstdlib>
+
 #include "dpx_cg_dev.h"
 
 namespace dpx {
@@ -262,6 +264,7 @@ __global__ void k_dot_finish(const float* __restrict__ partial, float* __restric
 // Summation order is fixed (per-wave partials are added in wave order, slabs by the finishing kernel).
 constexpr int GR_CH = 128, GR_P = GR_CH + 1;
 // sx: 32 * GR_P floats, red: 3 * 64 * 16 floats of shared memory
+template <bool AGENT_STORE>
 __device__ __forceinline__ void gram_tile_body(const float* __restrict__ r, float* __restrict__ partial, int B, long npb, int nblk, float* sx,
                                                float* red) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ti = (lane >> 3) * 4, tj = (lane & 7) * 4;
@@ -301,14 +304,18 @@ __device__ __forceinline__ void gram_tile_body(const float* __restrict__ r, floa
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float v = ((acc[a][q] + red[(0 * 64 + lane) * 16 + a * 4 + q]) + red[(1 * 64 + lane) * 16 + a * 4 + q]) + red[(2 * 64 + lane) * 16 + a * 4 + q];
-        if (ti + a < B && tj + q < B) partial[((long)(ti + a) * B + (tj + q)) * nblk + blockIdx.x] = v;
+        if (ti + a < B && tj + q < B) {
+          float* dst = partial + ((long)(ti + a) * B + (tj + q)) * nblk + blockIdx.x;
+          if (AGENT_STORE) dpx_st_agent(dst, v);
+          else *dst = v;
+        }
       }
   }
 }
 __global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, float* __restrict__ partial, int B, long npb, int nblk) {
   __shared__ float sx[32 * GR_P];
   __shared__ float red[3 * 64 * 16];
-  gram_tile_body(r, partial, B, npb, nblk, sx, red);
+  gram_tile_body<false>(r, partial, B, npb, nblk, sx, red);
 }
 
 // The Gram pass of a device-controlled CG iteration with its two followers folded in: the LAST workgroup to arrive adds up the
@@ -323,7 +330,7 @@ __global__ void __launch_bounds__(256) k_gram_tile_test(const float* __restrict_
   const int B = S.B;
   float* sx = (float*)raw;
   float* red = sx + 32 * GR_P;
-  gram_tile_body(r, partial, B, npb, nblk, sx, red);
+  gram_tile_body<true>(r, partial, B, npb, nblk, sx, red);
   if (!dpx_last_block(counter, (unsigned)nblk, &shf[2])) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int e = wave; e < B * B; e += 4) {
@@ -738,7 +745,9 @@ extern "C" int dpx_bdot(const float* x, const float* y, float* out, int B, long 
 namespace dpx {
 // Gram pass + finish + stop rule in one launch (dpx_cg_masked_fft's fused iteration, B <= 8); ws: B * B * gram_blocks floats
 int gram_test_fused(const float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, hipStream_t s) {
-  const int nblk = gram_blocks(n_per_batch);
+  static const int env_blk = getenv("DPX_CGF_GRAM_BLOCKS") ? atoi(getenv("DPX_CGF_GRAM_BLOCKS")) : 0;      // tuning
+  int nblk = gram_blocks(n_per_batch);
+  if (env_blk > 0 && env_blk < nblk) nblk = env_blk;
   DPX_LAUNCH("k_gram_tile_test", k_gram_tile_test, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch, nblk,
              counter, init_rtol);
   return launch_status("gram_test_fused");

@@ -759,7 +759,7 @@ __global__ void k_crows_real_out(const float2* __restrict__ in, float* __restric
     if (tid == 0) {
       float t = 0.f;
       for (int w = 0; w < (nthr + 63) / 64; ++w) t += shred[w];
-      dot_partial[blockIdx.x] = t;
+      dpx_st_agent(dot_partial + blockIdx.x, t);
     }
   }
   if (!dpx_last_block(counter, gridDim.x, &shlast)) return;
