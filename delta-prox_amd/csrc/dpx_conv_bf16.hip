@@ -111,8 +111,10 @@ __device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
 #endif
 
 // w [cout][cin][9] fp32, b [cout] (nullable) -> packed layer.  mode 6: three exact planes; mode 1: plane 0 = RNE bf16, others 0.
+// tr: the backward-data layer of w -- (cin, cout) are ITS channel counts (the forward layer's cout, cin), the tensor is the forward
+// layer's [cin][cout][9] and the taps are flipped: v = w[ci][co][8 - tap]
 __global__ void k_bx_pack_weights(const float* __restrict__ w, const float* __restrict__ b, unsigned short* __restrict__ dst, int cin, int cout,
-                                  int mode) {
+                                  int mode, int tr) {
   const int chunks = (cin + 15) / 16, MT = (cout + 31) / 32, M32 = MT * 32, NPW = bx_planes(mode);
   const long nw = (long)chunks * 9 * NPW * 2 * M32 * 8;                // 16-bit elements
   float* bias = (float*)(dst + nw);
@@ -132,7 +134,7 @@ __global__ void k_bx_pack_weights(const float* __restrict__ w, const float* __re
     r /= NPW;
     const int tap = (int)(r % 9), chunk = (int)(r / 9);               // [chunk][tap group][tap in group] == [chunk][tap]
     const int ci = chunk * 16 + kg * 8 + j;
-    const float v = (co < cout && ci < cin) ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
+    const float v = (co < cout && ci < cin) ? (tr ? w[((long)ci * cout + co) * 9 + (8 - tap)] : w[((long)co * cin + ci) * 9 + tap]) : 0.f;
     unsigned h, m, l;
     if (mode == 1) {
       h = bf16_rne(v);
@@ -190,8 +192,10 @@ __global__ void k_bx_unpack_out(const float* __restrict__ o, float* __restrict__
 
 // in / out: C8 fp32; Gin = input channel groups (even: chunks of 2), Gout = output groups actually stored.
 template <int MT, bool RELU, int MODE>
+// mask (nullable; C8, Gout groups): the stored value is zeroed where mask <= 0 -- the ReLU derivative of the backward-data pass
+// ([a_l > 0] from the saved forward activation), applied in the producing layer's epilogue.
 __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict__ in, float* __restrict__ out, const char* __restrict__ wpk, int Gin,
-                                                        int Gout, int H, int W, int tiles_x) {
+                                                        int Gout, int H, int W, int tiles_x, const float* __restrict__ mask) {
   constexpr int M32 = MT * 32, NPW = bx_planes(MODE), TAPB = bx_tap_bytes(MT, NPW), SLOTB = bx_slot_bytes(MT, NPW);
   constexpr int NPL = MODE == 1 ? 1 : (MODE == 3 ? 2 : 3);            // operand planes in use (the packed layouts always have room for three)
   HIP_DYNAMIC_SHARED(char, smem_bx)
@@ -356,7 +360,6 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
   }
   if (MODE == 3 && !(f16_max <= 6.0e4f)) atomicOr(&g_f16_overflow, 1u);        // (NaN counts)
   // ---- epilogue: bias, ReLU, C8 store.  D layout: col = lane & 31 (pixel), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) (cout) ----
-  float* outb = out + (size_t)b * Gout * H * W * 8;
   const int xx = x0 + n;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -380,13 +383,21 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
           v.w = fmaf(accx[mt][r][4 * q + 3], s, v.w);
         }
         if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        if (cg < Gout && yy < H && xx < W) *(float4*)(outb + (((size_t)cg * H + yy) * W + xx) * 8 + 4 * kg) = v;
+        if (cg < Gout && yy < H && xx < W) {
+          const size_t o = (size_t)b * Gout * H * W * 8 + (((size_t)cg * H + yy) * W + xx) * 8 + 4 * kg;
+          if (mask) {                                                 // (kernel-uniform)
+            const float4 m = *(const float4*)(mask + o);
+            v = make_float4(m.x > 0.f ? v.x : 0.f, m.y > 0.f ? v.y : 0.f, m.z > 0.f ? v.z : 0.f, m.w > 0.f ? v.w : 0.f);
+          }
+          *(float4*)(out + o) = v;
+        }
       }
     }
 }
 
 template <int MT, int MODE>
-static void launch_bx(bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s) {
+static void launch_bx(bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s,
+                      const float* mask = nullptr) {
   const int tx = (W + BX_TW - 1) / BX_TW, ty = (H + BX_TH - 1) / BX_TH;
   const size_t sh = (size_t)BX_LAND_BYTES + BX_TILE_BYTES + 2 * bx_slot_bytes(MT, bx_planes(MODE));
   static bool attr[2] = {false, false};
@@ -396,17 +407,76 @@ static void launch_bx(bool relu, const float* in, float* out, const char* wpk, i
     attr[relu] = true;
   }
   if (relu)
-    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, true, MODE>), dim3(tx * ty, B), dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx);
+    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, true, MODE>), dim3(tx * ty, B), dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx, mask);
   else
-    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, false, MODE>), dim3(tx * ty, B), dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx);
+    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, false, MODE>), dim3(tx * ty, B), dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx, mask);
 }
 template <int MODE>
-static void launch_bx_mt(int mt, bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s) {
+static void launch_bx_mt(int mt, bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s,
+                         const float* mask = nullptr) {
   switch (mt) {
-    case 1: launch_bx<1, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s); break;
-    case 2: launch_bx<2, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s); break;
-    default: launch_bx<3, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s); break;
+    case 1: launch_bx<1, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s, mask); break;
+    case 2: launch_bx<2, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s, mask); break;
+    default: launch_bx<3, MODE>(relu, in, out, wpk, Gin, Gout, B, H, W, s, mask); break;
   }
+}
+
+// ---- backward-data of the FFDNet stack on the split kernels: adjoints of the input / output stages in the C8 layout ----------------
+// adjoint of k_bx_unpack_out (PixelShuffle + crop): g_last[b][ch][y2][x2] = gy[b][c][2 y2 + dy][2 x2 + dx] inside the image, else 0
+__global__ void k_bx_pack_gout(const float* __restrict__ gy, float* __restrict__ g, int B, int C, int H, int W, int H2, int W2, int G) {
+  const long total = (long)B * G * H2 * W2 * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    long r = i / 8;
+    const int x2 = (int)(r % W2);
+    r /= W2;
+    const int y2 = (int)(r % H2);
+    r /= H2;
+    const int gq = (int)(r % G), b = (int)(r / G);
+    const int ch = gq * 8 + j;
+    float v = 0.f;
+    if (ch < 4 * C) {
+      const int c = ch >> 2, yy = 2 * y2 + ((ch >> 1) & 1), xx = 2 * x2 + (ch & 1);
+      if (yy < H && xx < W) v = gy[(((long)b * C + c) * H + yy) * W + xx];
+    }
+    g[i] = v;
+  }
+}
+// adjoint of k_bx_pack_in's image part (replicate-pad to even size + pixel-unshuffle): the padded row / column folds onto the last one
+__global__ void k_bx_unpack_gin(const float* __restrict__ ga, float* __restrict__ gx, int B, int C, int H, int W, int H2, int W2, int G) {
+  const long total = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    long r = i / W;
+    const int yy = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    auto at = [&](int py, int px) {                                    // padded position (py, px) of channel c
+      const int ch = c * 4 + (py & 1) * 2 + (px & 1);
+      return ga[((((long)b * G + (ch >> 3)) * H2 + (py >> 1)) * W2 + (px >> 1)) * 8 + (ch & 7)];
+    };
+    float v = at(yy, xx);
+    const bool fy = (H & 1) && yy == H - 1, fx = (W & 1) && xx == W - 1;      // the replicated row / column comes back to this pixel
+    if (fy) v += at(yy + 1, xx);
+    if (fx) v += at(yy, xx + 1);
+    if (fy && fx) v += at(yy + 1, xx + 1);
+    gx[i] = v;
+  }
+}
+// d / d sigma_b = sum over the sigma-map channel (4 C) of g_a0: one workgroup per image, fixed summation order
+__global__ void __launch_bounds__(256) k_bx_sigma_grad(const float* __restrict__ ga, float* __restrict__ gs, int C, int H2, int W2, int G) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x, ch = 4 * C;
+  const float* base = ga + (((long)b * G + (ch >> 3)) * H2 * W2) * 8 + (ch & 7);
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < (long)H2 * W2; i += 256) acc += base[i * 8];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gs[b] = sh[0];
 }
 
 static int bx_cin(int l, int in_nc, int nc) { return l == 0 ? 4 * in_nc + 1 : nc; }
@@ -434,7 +504,7 @@ extern "C" int dpx_ffdnet_bf16_pack(void* packed, const float* const* w, const f
     DPX_REQUIRE(w[l] && b[l], "dpx_ffdnet_bf16_pack: layer %d has null weights", l);
     const size_t n = bx_layer_bytes(cin, cout, bx_planes(mode));
     DPX_LAUNCH("k_bx_pack_weights", k_bx_pack_weights, dim3(grid_for((long)(n / 2), 256, 2048)), dim3(256), 0, (hipStream_t)stream, w[l], b[l],
-               (unsigned short*)dst, cin, cout, mode);
+               (unsigned short*)dst, cin, cout, mode, 0);
     dst += n;
   }
   return launch_status("dpx_ffdnet_bf16_pack");
@@ -478,6 +548,116 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
   DPX_LAUNCH("k_bx_unpack_out", k_bx_unpack_out, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, last, y, B, in_nc, H, W, H2,
              W2, GL);
   return launch_status("dpx_ffdnet_forward_bf16");
+}
+
+// ---- reverse mode on the split kernels (frozen weights: gradients w.r.t. the image and sigma; the reference differentiates
+// network_ffdnet.py:54-68 with autograd).  Forward pass that KEEPS every layer's output (C8, the backward pass's ReLU masks), weights
+// of the backward-data layers (flipped / transposed, split like the forward ones, no bias), and the backward pass: the same
+// k_conv3x3_bf16 on those weights with [a_l > 0] applied in the epilogue.  Gradients can be tiny (1e-7 of an MSE loss): the backward
+// pass always runs split-bf16 (mode 6, fp32's range); the forward pass may be any fp32-accurate mode.
+extern "C" size_t dpx_ffdnet_bf16_acts_bytes(int B, int in_nc, int nc, int nb, int H, int W) {
+  const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
+  return (px * 8 * groups16(4 * in_nc + 1) + (size_t)(nb - 1) * px * 8 * groups16(nc) + px * 8 * groups16(4 * in_nc)) * sizeof(float);
+}
+
+extern "C" int dpx_ffdnet_forward_bf16_save(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode,
+                                            int B, int H, int W, void* acts, dpx_stream_t stream) {
+  DPX_REQUIRE(x && y && sigma && packed && acts, "dpx_ffdnet_forward_bf16_save: null pointer");
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 && (mode == 6 || mode == 3),
+              "dpx_ffdnet_forward_bf16_save: unsupported configuration (in_nc=%d nc=%d nb=%d mode=%d)", in_nc, nc, nb, mode);
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  DPX_REQUIRE((size_t)2 * H2 * W2 * 8 < ((size_t)1 << 32), "dpx_ffdnet_forward_bf16_save: plane %dx%d too large", H, W);
+  const size_t px = (size_t)B * H2 * W2;
+  const int G0 = groups16(4 * in_nc + 1), Gc = groups16(nc), GL = groups16(4 * in_nc);
+  float* a0 = (float*)acts;
+  float* hidden = a0 + px * 8 * G0;                                   // layer l's output (l < nb - 1) at hidden + l px 8 Gc
+  float* last = hidden + (size_t)(nb - 1) * px * 8 * Gc;
+  DPX_LAUNCH("k_bx_pack_in", k_bx_pack_in, dim3(grid_for((long)(px * 8 * G0), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W, H2, W2, G0);
+  const char* wl = (const char*)packed;
+  const float* cur = a0;
+  int gin = G0;
+  for (int l = 0; l < nb; ++l) {
+    const int cin = bx_cin(l, in_nc, nc), cout = bx_cout(l, in_nc, nc, nb);
+    const bool lastl = l == nb - 1;
+    float* dst = lastl ? last : hidden + (size_t)l * px * 8 * Gc;
+    const int gout = lastl ? GL : Gc;
+    if (mode == 3) launch_bx_mt<3>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    else launch_bx_mt<6>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    wl += bx_layer_bytes(cin, cout, bx_planes(mode));
+    cur = dst;
+    gin = gout;
+  }
+  DPX_LAUNCH("k_bx_unpack_out", k_bx_unpack_out, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, last, y, B, in_nc, H, W, H2,
+             W2, GL);
+  return launch_status("dpx_ffdnet_forward_bf16_save");
+}
+
+extern "C" size_t dpx_ffdnet_bf16_packed_transposed_bytes(int in_nc, int nc, int nb) {
+  size_t n = 0;
+  for (int l = 0; l < nb; ++l) n += bx_layer_bytes(bx_cout(l, in_nc, nc, nb), bx_cin(l, in_nc, nc));
+  return n + 1024;
+}
+
+// packed_T: the nb backward-data layers in FORWARD order (layer l: bx_cout(l) -> bx_cin(l) channels), split-bf16 planes, zero bias
+extern "C" int dpx_ffdnet_bf16_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream) {
+  DPX_REQUIRE(packed_T && w && in_nc > 0 && nc > 0 && nb >= 2, "dpx_ffdnet_bf16_pack_transposed: bad arguments");
+  DPX_REQUIRE(nc <= 96 && nc % 16 == 0 && 4 * in_nc <= 96, "dpx_ffdnet_bf16_pack_transposed: layers of 16..96 channels (multiples of 16), got %d", nc);
+  char* dst = (char*)packed_T;
+  for (int l = 0; l < nb; ++l) {
+    const int cin_t = bx_cout(l, in_nc, nc, nb), cout_t = bx_cin(l, in_nc, nc);
+    DPX_REQUIRE(w[l], "dpx_ffdnet_bf16_pack_transposed: layer %d has null weights", l);
+    const size_t n = bx_layer_bytes(cin_t, cout_t, 3);
+    DPX_LAUNCH("k_bx_pack_weights", k_bx_pack_weights, dim3(grid_for((long)(n / 2), 256, 2048)), dim3(256), 0, (hipStream_t)stream, w[l],
+               (const float*)nullptr, (unsigned short*)dst, cin_t, cout_t, 6, 1);
+    dst += n;
+  }
+  return launch_status("dpx_ffdnet_bf16_pack_transposed");
+}
+
+extern "C" size_t dpx_ffdnet_bf16_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W) {
+  const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
+  return (px * 8 * groups16(4 * in_nc) + 2 * px * 8 * groups16(nc) + px * 8 * groups16(4 * in_nc + 1)) * sizeof(float);
+}
+
+// gx, gsigma: either may be NULL.  acts: dpx_ffdnet_forward_bf16_save's buffer.
+extern "C" int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigma, const void* packed_T, const void* acts, int in_nc, int nc, int nb,
+                                        int B, int H, int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(gy && packed_T && acts && ws && (gx || gsigma), "dpx_ffdnet_backward_bf16: null pointer");
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96,
+              "dpx_ffdnet_backward_bf16: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const size_t px = (size_t)B * H2 * W2;
+  const int G0 = groups16(4 * in_nc + 1), Gc = groups16(nc), GL = groups16(4 * in_nc);
+  const float* hidden = (const float*)acts + px * 8 * G0;
+  float* g_last = (float*)ws;
+  float* gA = g_last + px * 8 * GL;
+  float* gB = gA + px * 8 * Gc;
+  float* g_a0 = gB + px * 8 * Gc;
+  DPX_LAUNCH("k_bx_pack_gout", k_bx_pack_gout, dim3(grid_for((long)(px * 8 * GL), 256, 8192)), dim3(256), 0, s, gy, g_last, B, in_nc, H, W, H2, W2, GL);
+  size_t off[64];
+  DPX_REQUIRE(nb <= 64, "dpx_ffdnet_backward_bf16: at most 64 layers");
+  size_t o = 0;
+  for (int l = 0; l < nb; ++l) { off[l] = o; o += bx_layer_bytes(bx_cout(l, in_nc, nc, nb), bx_cin(l, in_nc, nc), 3); }
+  const float* cur = g_last;
+  int gin = GL;
+  for (int l = nb - 1; l >= 0; --l) {
+    const int cout_t = bx_cin(l, in_nc, nc);
+    float* dst = (l == 0) ? g_a0 : (((nb - 1 - l) & 1) ? gB : gA);
+    const int gout = (l == 0) ? G0 : Gc;
+    // the output of backward layer l is the gradient w.r.t. a_l, the (post-ReLU) output of forward layer l - 1: stored already
+    // multiplied by [a_l > 0], ready to be the next layer's plain input
+    const float* mask = (l >= 1) ? hidden + (size_t)(l - 1) * px * 8 * Gc : nullptr;
+    launch_bx_mt<6>((cout_t + 31) / 32, false, cur, dst, (const char*)packed_T + off[l], gin, gout, B, H2, W2, s, mask);
+    cur = dst;
+    gin = gout;
+  }
+  if (gx)
+    DPX_LAUNCH("k_bx_unpack_gin", k_bx_unpack_gin, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, (const float*)g_a0, gx, B, in_nc, H,
+               W, H2, W2, G0);
+  if (gsigma) DPX_LAUNCH("k_bx_sigma_grad", k_bx_sigma_grad, dim3(B), dim3(256), 0, s, (const float*)g_a0, gsigma, in_nc, H2, W2, G0);
+  return launch_status("dpx_ffdnet_backward_bf16");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

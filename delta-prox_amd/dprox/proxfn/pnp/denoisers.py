@@ -147,6 +147,7 @@ class FFDNet(RefKeyed):
     def _weights_changed(self):
         super()._weights_changed()
         self._packed_bf16 = None
+        self._packed_T_bf16 = None
 
     def packed_bf16(self, mode):
         """weights pre-split for the bf16 matrix cores (mode 6: three exact bf16 planes; mode 1: one rounded plane)"""
@@ -198,6 +199,19 @@ class FFDNet(RefKeyed):
             self._packed_T = (key, blob)
         return self._packed_T[1]
 
+    def packed_T_bf16(self):
+        """the backward-data layers' weights for the split kernels (dpx_ffdnet_bf16_pack_transposed), cached per weight version"""
+        dev = self.weights[0].device
+        key = (self._weights_version(), str(dev))
+        if getattr(self, "_packed_T_bf16", None) is None or self._packed_T_bf16[0] != key:
+            L = be.lib()
+            blob = torch.empty(L.query("dpx_ffdnet_bf16_packed_transposed_bytes", self.in_nc, self.nc, self.nb), dtype=torch.uint8, device=dev)
+            ws = [w.detach().float().contiguous() for w in self.weights]
+            pw = (ctypes.c_void_p * self.nb)(*[w.data_ptr() for w in ws])
+            L.call("dpx_ffdnet_bf16_pack_transposed", be.ptr(blob), pw, self.in_nc, self.nc, self.nb, be.stream())
+            self._packed_T_bf16 = (key, blob)
+        return self._packed_T_bf16[1]
+
     def packed(self):
         dev = self.weights[0].device
         if self._packed is not None and getattr(self, "_packed_version", None) != self._weights_version():
@@ -224,6 +238,10 @@ class FFDNet(RefKeyed):
             sig_t = sig_t.to(device=x.device, dtype=torch.float32).reshape(-1)
             sig_t = sig_t.expand(B).contiguous() if sig_t.numel() == 1 else sig_t.contiguous()
             params = (self.weights + self.biases) if train_w else []
+            if not train_w and self.compute_mode in ("bf16x3", "f16x2") and self.nc % 16 == 0:
+                # frozen weights (unrolled plug-and-play training of schedules / upstream parameters): forward and backward-data on the
+                # split kernels -- fp32-accurate, 2 - 3x the f32-input matrix instruction; weight gradients stay on the f32-input path
+                return _FFDNetSplitFn.apply(self, x, sig_t)
             return _FFDNetFn.apply(self, x, sig_t, *params)
         sig = ops.as_batch_vec(sigma, B, x.device)
         L = be.lib()
@@ -240,6 +258,45 @@ class FFDNet(RefKeyed):
         L.call("dpx_ffdnet_forward", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(self.packed()), self.in_nc, self.nc,
                self.nb, B, H, W, be.ptr(ws), be.stream())
         return y
+
+
+class _FFDNetSplitFn(torch.autograd.Function):
+    """FFDNet with frozen weights under autograd, on the split kernels: the forward pass keeps every layer's output (C8 layout),
+    the backward pass is the same convolution kernel on flipped / transposed split weights with the ReLU masks in its epilogue
+    (dpx_ffdnet_forward_bf16_save / dpx_ffdnet_backward_bf16).  The backward pass always runs split-bf16 (gradients of a mean
+    loss sit far below the binary16 range); a "f16x2" forward that meets an operand outside that range is caught by the range trap."""
+
+    @staticmethod
+    def forward(ctx, net, x, sig):
+        B, C, H, W = x.shape
+        L = be.lib()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mode = {"bf16x3": 6, "f16x2": 3}[net.compute_mode]
+        if mode == 3:
+            be.note_f16_launch()
+        acts = torch.empty(L.query("dpx_ffdnet_bf16_acts_bytes", B, net.in_nc, net.nc, net.nb, H, W), dtype=torch.uint8, device=x.device)
+        L.call("dpx_ffdnet_forward_bf16_save", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(net.packed_bf16(mode)), net.in_nc, net.nc, net.nb, mode,
+               B, H, W, be.ptr(acts), be.stream())
+        ctx.net, ctx.shape = net, (B, C, H, W)
+        ctx.save_for_backward(acts)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        net = ctx.net
+        B, C, H, W = ctx.shape
+        (acts,) = ctx.saved_tensors
+        L = be.lib()
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy) if ctx.needs_input_grad[1] else None
+        gs = torch.empty(B, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[2] else None
+        if gx is None and gs is None:
+            return None, None, None
+        ws = ops.workspace("ffdnet_bf16_bwd", L.query("dpx_ffdnet_bf16_bwd_ws_bytes", B, net.in_nc, net.nc, H, W), gy.device)
+        L.call("dpx_ffdnet_backward_bf16", be.ptr(gy), be.ptr(gx), be.ptr(gs), be.ptr(net.packed_T_bf16()), be.ptr(acts), net.in_nc, net.nc, net.nb,
+               B, H, W, be.ptr(ws), be.stream())
+        return None, gx, gs
 
 
 class _FFDNetFn(torch.autograd.Function):

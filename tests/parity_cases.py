@@ -846,6 +846,42 @@ def case_ffdnet_grads(device, which=("odd", "even", "gray")):
     _assert_grad_close(sg.grad.cpu(), g["gray_gsigma"], "gray d/dsigma (summed over bands and images)", tol=1e-2)
 
 
+def case_ffdnet_split_backward(device, tiny=False):
+    """Frozen FFDNet under autograd runs forward AND backward-data on the split kernels (_FFDNetSplitFn: dpx_ffdnet_forward_bf16_save /
+    dpx_ffdnet_backward_bf16): d/dx and d/dsigma against the f32-input path (itself pinned against the reference's autograd by G16),
+    odd sizes (adjoint of the replicate padding), per-image sigma, colour and gray; and against G16 directly.  tiny: a 3-layer
+    16-channel network (the emulator needs minutes for the 12-layer one)."""
+    import synthetic
+    from dprox.proxfn.pnp.denoisers import FFDNet, FFDNetColorDenoiser
+    rng = np.random.RandomState(616)
+    shapes = ((2, 3, 17, 21),) if tiny else ((2, 3, 33, 47), (1, 3, 32, 40))
+    for shape in shapes:
+        if tiny:
+            col = FFDNetColorDenoiser()
+            col.model = FFDNet(in_nc=3, out_nc=3, nc=16, nb=3, act_mode="R").load_layers(synthetic.ffdnet_weights(5, 3, 3, 16, 3))
+            col = col.to(device)
+        else:
+            col = _ffdnet("color", device)
+        col.requires_grad_(False)
+        x0 = rng.rand(*shape).astype(np.float32)
+        w0 = rng.randn(*shape).astype(np.float32)
+        s0 = np.linspace(0.03, 0.12, shape[0]).astype(np.float32)
+        res = {}
+        for mode in ("f32", "bf16x3", "f16x2"):
+            col.model.compute_mode = mode
+            x = T(x0, device).requires_grad_(True)
+            sig = T(s0, device).requires_grad_(True)
+            y = col.denoise(x, sig)
+            assert ("Split" in y.grad_fn.name()) == (mode != "f32"), (mode, y.grad_fn.name())
+            (y * T(w0, device)).sum().backward()
+            res[mode] = (y.detach().cpu().numpy(), x.grad.cpu().numpy(), sig.grad.cpu().numpy())
+        for mode in ("bf16x3", "f16x2"):
+            assert_close(res[mode][0], res["f32"][0], TOL, f"split backward {shape} {mode}: forward")
+            _assert_grad_close(res[mode][1], res["f32"][1], f"split backward {shape} {mode}: d/dx", tol=1e-5)
+            _assert_grad_close(res[mode][2], res["f32"][2], f"split backward {shape} {mode}: d/dsigma", tol=1e-5)
+    col.model.compute_mode = "f16x2"
+
+
 def case_ffdnet_weight_grads(device):
     """G16 (third part): d/dW, d/db of the FFDNet stack (pixels-as-K MFMA GEMM + deterministic reduction) vs the
     reference's autograd -- first, a middle and the last layer."""

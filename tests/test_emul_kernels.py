@@ -157,6 +157,10 @@ def test_ffdnet_weight_gradients():
     pc.case_ffdnet_weight_grads(DEV)
 
 
+def test_ffdnet_split_backward():
+    pc.case_ffdnet_split_backward(DEV, tiny=True)
+
+
 def test_ffdnet_backward():
     pc.case_ffdnet_grads(DEV, which=("even",))      # one small image: the emulator runs MFMA layers at ~1 s each
 

@@ -119,6 +119,11 @@ def test_ffdnet_split_f16_and_its_range_trap():
 
 
 @pytest.mark.gpu
+def test_ffdnet_split_backward():
+    pc.case_ffdnet_split_backward(DEV)
+
+
+@pytest.mark.gpu
 def test_ffdnet_wide_range_weights_fall_back_to_split_bf16():
     pc.case_ffdnet_wide_range(DEV)
 
