@@ -20,6 +20,11 @@ The JSON line also carries
   cpu_baseline : the reference-schedule CPU oracle (oracle/, a port of the reference's PyTorch-CPU
                  path pinned on its golden vectors) timed on this box's host cores on a bounded sample;
   parity_rel_l2: rel-L2 between the GPU iterate and that same oracle run (same images, same iteration count);
+  headline_protocol / steady_state / value_after_idle_gpu : which leg `value` is (W warm-up + K timed steps directly behind the
+                 200-step steady-state leg), the 200-step figure, and the same K-step region on a GPU that idled first;
+  cold_solve   : wall clock of solve(max_iter=50) on a freshly compiled solver (nothing cached) against a warm one and against 50
+                 steady iterations, with the per-kernel times of everything a cold solve launches besides its iterations;
+  psnr_db_detail : the quality leg on a detail-scaled synthetic (the SURVEY generator barely degrades under the blur at 1024^2);
   configs      : short timed runs of BASELINE.json's other configurations (1, 3, 4, 5) through the same API
                  with their own roofline figures (N=1 only, `--no-extra-configs` skips them).
 """
@@ -451,6 +456,17 @@ def main():
     #      reach its clocks and loses them within a few milliseconds of idling (tools/ramp_probe.py): the last leg shows what the
     #      same region measures when the GPU idled in front of the W warm-up steps.
     dt = timed_region(K) if K != 200 else dt_steady
+    # ---- roofline leg: the same K iterations once more with the library's per-kernel timers on (HIP events attached to the dispatch
+    #      packets), directly behind the headline region -- same clocks
+    rhos_k, lams_k = sched[K]
+    be.lib().call("dpx_timing_enable", 1)
+    state2 = solver.initialize(b)
+    timing_report(be)                                   # drop the initialize() launches
+    solver.iters(state2, rhos_k, lams_k, K)
+    torch.cuda.synchronize()
+    rep = timing_report(be)
+    be.lib().call("dpx_timing_enable", 0)
+    del state2
     # ---- leg 4: a warm 50-iteration solve (tables and data spectrum cached): cold - warm = what a first solve pays for its setup
     barrier()
     t0 = time.perf_counter()
@@ -476,16 +492,6 @@ def main():
     # ---- leg 6 (last): the same region after the GPU idled for half a second (the clock ramp falls into the timed steps)
     time.sleep(0.5)
     dt_idle = timed_region(K)
-    rhos, lams = rhos[..., :K], {k: v[..., :K] for k, v in lams.items()}
-
-    # ---- second pass with per-kernel HIP-event timers (roofline leg) -------------------------------------
-    be.lib().call("dpx_timing_enable", 1)
-    state2 = solver.initialize(b)
-    timing_report(be)                                   # drop the initialize() launches
-    solver.iters(state2, rhos, lams, K)
-    torch.cuda.synchronize()
-    rep = timing_report(be)
-    be.lib().call("dpx_timing_enable", 0)
 
     # ---- quality (of the cold 50-iteration solve) -------------------------------------
     psnr_in, psnr_out = psnr_per_image(b, gt), psnr_per_image(out, gt)
