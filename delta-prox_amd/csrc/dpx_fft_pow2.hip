@@ -199,11 +199,20 @@ __global__ void __launch_bounds__(256) k_seed_rows(SeedTerms S_, const float* __
   float2 acc[V];
 #pragma unroll
   for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f);
-  float2 xh[V];
+  float2 xh[V], xab[V], xbe[V];                           // FRESH: this row of x0 and its two neighbours, requested together (one round trip)
   if constexpr (FRESH) {
     const float2* xr = (const float2*)S_.x0;
+    bool has_h = false;
+    for (int i = 0; i < S_.n; ++i) has_h |= S_.linop[i] == DPX_LIN_GRAD_H;
 #pragma unroll
     for (int m = 0; m < V; ++m) xh[m] = xr[here + t + m * T];
+    if (has_h) {
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        xab[m] = xr[above + t + m * T];
+        xbe[m] = xr[below + t + m * T];
+      }
+    }
   }
   for (int i = 0; i < S_.n; ++i) {
     const float2* vr = (const float2*)S_.v[i];
@@ -222,9 +231,8 @@ __global__ void __launch_bounds__(256) k_seed_rows(SeedTerms S_, const float* __
           y[m] = make_float2(xh[m].y - xh[m].x, xr_ - xh[m].y);
         }
       } else {                                              // x[h+1] - x[h]
-        const float2* xr = (const float2*)S_.x0;
 #pragma unroll
-        for (int m = 0; m < V; ++m) y[m] = csub(xr[below + t + m * T], xh[m]);
+        for (int m = 0; m < V; ++m) y[m] = csub(xbe[m], xh[m]);
       }
     } else {
 #pragma unroll
@@ -245,7 +253,7 @@ __global__ void __launch_bounds__(256) k_seed_rows(SeedTerms S_, const float* __
 #pragma unroll
       for (int m = 0; m < V; ++m) {
         float2 yu;
-        if constexpr (FRESH) yu = csub(xh[m], ((const float2*)S_.x0)[above + t + m * T]);
+        if constexpr (FRESH) yu = csub(xh[m], xab[m]);
         else yu = csub(vr[above + t + m * T], ur[above + t + m * T]);
         acc[m] = cadd(acc[m], csub(yu, y[m]));
       }

@@ -50,6 +50,14 @@ class Variable(LinOp):
     def value(self, val):
         self._value = val
 
+    def __setattr__(self, name, val):
+        # (`_value` / `value` are plain attributes holding a tensor or None: nn.Module.__setattr__ walks its parameter / buffer / module
+        #  tables for every assignment -- the solvers assign the iterate to the variable twice per call)
+        if name == "_value" or name == "value":
+            object.__setattr__(self, "_value", val)
+        else:
+            super().__setattr__(name, val)
+
     def norm_bound(self, input_mags):
         return 1.0
 

@@ -57,8 +57,20 @@ class LinOp(nn.Module):
     def tables_version(self):
         """changes whenever a value this operator's cached tables depend on changes (conv_doe: the PSF); the solvers key
         their denominator / data-spectrum caches on it"""
+        if self.__dict__.get("_tables_static"):
+            return self.__dict__["_tables_static_value"]
         own = self._own_tables_version()
-        return (own,) + tuple(n.tables_version() for n in self.input_nodes)
+        out = (own,) + tuple(n.tables_version() for n in self.input_nodes)
+        if not self._tables_dynamic():                           # no node below overrides _own_tables_version: the value never changes
+            self.__dict__["_tables_static"], self.__dict__["_tables_static_value"] = True, out
+        return out
+
+    def _tables_dynamic(self):
+        hit = self.__dict__.get("_tables_dyn")
+        if hit is None:
+            hit = type(self)._own_tables_version is not LinOp._own_tables_version or any(n._tables_dynamic() for n in self.input_nodes)
+            self.__dict__["_tables_dyn"] = hit
+        return hit
 
     def _own_tables_version(self):
         return None
@@ -68,28 +80,31 @@ class LinOp(nn.Module):
     def device(self):
         return self.dummy.device
 
+    # (the graph below a node is fixed once it is built -- input_nodes is assigned in the constructor only --: the walks over it are done
+    #  once per node; the solvers ask for them a few dozen times per solve)
     @property
     def variables(self):
-        # (the graph below a node is fixed once it is built: the walk is done once per node, keyed on the identity of its inputs --
-        #  the solvers ask for it a few dozen times per solve)
-        key = tuple(id(n) for n in self.input_nodes)
         hit = self.__dict__.get("_vars_cache")
-        if hit is not None and hit[0] == key:
-            return list(hit[1])
+        if hit is not None:
+            return list(hit)
         found = {}
         for node in self.input_nodes:
             for v in node.variables:
                 found[v.uuid] = v
         out = [found[k] for k in sorted(found)]
-        self.__dict__["_vars_cache"] = (key, out)
+        self.__dict__["_vars_cache"] = out
         return list(out)
 
     @property
     def constants(self):
+        hit = self.__dict__.get("_consts_cache")
+        if hit is not None:
+            return list(hit)
         out = []
         for node in self.input_nodes:
             out += node.constants
-        return out
+        self.__dict__["_consts_cache"] = out
+        return list(out)
 
     def is_constant(self):
         return len(self.variables) == 0
