@@ -35,6 +35,8 @@ struct IterTerms {
   float dual;          // 1: ADMM.  0: half-quadratic splitting (DPX_TERM_NO_DUAL) -- the incoming duals count as zero and the right-hand side
                        // sees v_i alone; applied as fma(dual, u, K x) / fma(-dual, u', v): the same instructions, and exact for dual = 1
   int emit_bf16;       // x_out / v_out / rhs_out are bf16 planes (the bf16 history of the unrolled forward pass) instead of fp32
+  int vxu;             // 1: ADMM in the order v, x, u (DPX_TERM_VXU, algo/admm.py:103-120) -- the stream in `u` carries q = u' - v (u' = -u):
+                       // t = q + x, d = K x + t, v = prox(d), q' = t - v goes out, the next right-hand side sees v - t
   int u_live;          // 0: the incoming duals are all zero (DPX_TERM_U_ZERO, first iteration after ADMM.initialize) -- the streaming kernel then
                        // fetches every u row from row 0 of plane 0 (cache hits) instead of streaming the planes from HBM, the lock-step
                        // kernel does not load them at all
@@ -175,10 +177,19 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__
             const float xr = (t == T - 1) ? nx_wrap : nx_same;
             kx = make_float2(xc[m].y - xc[m].x, xr - xc[m].y);
           }
-          const float dx = fmaf(TT.dual, uu.x, kx.x), dy = fmaf(TT.dual, uu.y, kx.y);
-          const float vx = prox1(tm.prox, dx, lam), vy = prox1(tm.prox, dy, lam);
-          const float ux = dx - vx, uy = dy - vy;
-          w[m] = make_float2(fmaf(-TT.dual, ux, vx), fmaf(-TT.dual, uy, vy));
+          float dx, dy, vx, vy, ux, uy;
+          if (TT.vxu) {                                       // (kernel-uniform) t = q + x, d = K x + t, v = prox(d), q' = t - v, w = v - t
+            const float tx = uu.x + xc[m].x, ty = uu.y + xc[m].y;
+            dx = kx.x + tx, dy = kx.y + ty;
+            vx = prox1(tm.prox, dx, lam), vy = prox1(tm.prox, dy, lam);
+            ux = tx - vx, uy = ty - vy;
+            w[m] = make_float2(-ux, -uy);
+          } else {
+            dx = fmaf(TT.dual, uu.x, kx.x), dy = fmaf(TT.dual, uu.y, kx.y);
+            vx = prox1(tm.prox, dx, lam), vy = prox1(tm.prox, dy, lam);
+            ux = dx - vx, uy = dy - vy;
+            w[m] = make_float2(fmaf(-TT.dual, ux, vx), fmaf(-TT.dual, uy, vy));
+          }
           if (z_own) {
             ((float2*)(tm.u_out + plane_px + (size_t)hz * (2 * M)))[t + m * T] = make_float2(ux, uy);
             if (emit_v) dpx_emit_pair(tm.v_out, TT.emit_bf16, (plane_px + (size_t)hz * (2 * M)) / 2 + t + m * T, make_float2(vx, vy));
@@ -324,7 +335,9 @@ constexpr int R_LDX = DPX_R_LDX, R_LDU = DPX_R_LDU, R_STU = DPX_R_STU, R_STX = D
 // DUAL = false: half-quadratic splitting (TT.dual == 0, DPX_TERM_NO_DUAL) -- the duals are neither fetched nor stored (the general
 // kernel streams 16 of its 24 B per element for planes nobody reads: 36 -> 20 B per element and iteration with the column kernel);
 // every wait count below is the general one with the dual streams' operations taken out (NU = 0 terms with a dual).
-template <int M, int T, int NT, bool DUAL>
+// VXU = true (DUAL only): the update order v, x, u (see IterTerms::vxu) -- two more additions per element and term, its own instantiation
+// so that the headline kernel's instruction stream stays as it is.
+template <int M, int T, int NT, bool DUAL, bool VXU = false>
 __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
                                                         const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
                                                         int C, int H, int bands, int P, const float2* __restrict__ twW) {
@@ -505,6 +518,14 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
             d[m] = make_float2(fmaf(dualf, ureg[n][m].x, xprev[m].y - xprev[m].x), fmaf(dualf, ureg[n][m].y, xr - xprev[m].y));
           }
         }
+        float2 tq[VXU ? V : 1];                              // VXU: t = q + x (the dual in front of this v-update)
+        if constexpr (VXU) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) {
+            tq[m] = make_float2(ureg[n][m].x + xprev[m].x, ureg[n][m].y + xprev[m].y);
+            d[m] = make_float2(d[m].x + xprev[m].x, d[m].y + xprev[m].y);      // (d was K x + q: + x)
+          }
+        }
         float2 v[V];
         if (tm.prox == DPX_PROX_NORM1) {
 #pragma unroll
@@ -519,9 +540,15 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
         float2 w[V];
 #pragma unroll
         for (int m = 0; m < V; ++m) {
-          const float2 un = csub(d[m], v[m]);
-          w[m] = make_float2(fmaf(-dualf, un.x, v[m].x), fmaf(-dualf, un.y, v[m].y));
-          d[m] = un;
+          if constexpr (VXU) {
+            const float2 un = csub(tq[m], v[m]);                 // q' = t - v
+            w[m] = make_float2(-un.x, -un.y);                    // v - t
+            d[m] = un;
+          } else {
+            const float2 un = csub(d[m], v[m]);
+            w[m] = make_float2(fmaf(-dualf, un.x, v[m].x), fmaf(-dualf, un.y, v[m].y));
+            d[m] = un;
+          }
         }
         if (own) {
           if constexpr (DUAL) {
@@ -595,24 +622,25 @@ static size_t iter_rows_seq_lds(int M, int T, int NU) {
   const int V = M / T, G = 64 / T, S = M + M / 16, STG = 64 * V;
   return (size_t)(M + 64 + 4 * (G * S + STG + 32 + NU * STG)) * sizeof(float2);
 }
-template <int M, int T, int NT, bool DUAL>
+template <int M, int T, int NT, bool DUAL, bool VXU = false>
 static void launch_iter_rows_seq_d(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
                                    int C, int H, int R, int P, const float2* twW, hipStream_t s) {
   const size_t sh = iter_rows_seq_lds(M, T, DUAL ? NT : 0);
   static bool attr = false;
   if (!attr && sh > 48 * 1024) {
-    hipFuncSetAttribute((const void*)k_iter_rows_seq<M, T, NT, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipFuncSetAttribute((const void*)k_iter_rows_seq<M, T, NT, DUAL, VXU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr = true;
   }
   const int groups = P * R, per_block = 4 * (64 / T);   // R = bands per plane here
-  DPX_LAUNCH(DUAL ? "k_iter_rows_seq" : "k_iter_rows_seq_nodual", (k_iter_rows_seq<M, T, NT, DUAL>), dim3(groups / per_block), dim3(256), sh, s, sin, sout,
-             TT, rho_next, x_out, emit_v, C, H, R, P, twW);
+  DPX_LAUNCH(VXU ? "k_iter_rows_seq_vxu" : (DUAL ? "k_iter_rows_seq" : "k_iter_rows_seq_nodual"), (k_iter_rows_seq<M, T, NT, DUAL, VXU>), dim3(groups / per_block),
+             dim3(256), sh, s, sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW);
 }
 template <int M, int T, int NT>
 static void launch_iter_rows_seq_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
                                     int C, int H, int R, int P, const float2* twW, hipStream_t s) {
   static const bool keep_dual = getenv("DPX_HQS_STREAM_DUALS") != nullptr;      // (A/B: half-quadratic splitting on the general kernel)
-  if (TT.dual == 0.f && !keep_dual) launch_iter_rows_seq_d<M, T, NT, false>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
+  if (TT.vxu) launch_iter_rows_seq_d<M, T, NT, true, true>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
+  else if (TT.dual == 0.f && !keep_dual) launch_iter_rows_seq_d<M, T, NT, false>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
   else launch_iter_rows_seq_d<M, T, NT, true>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
 }
 template <int M, int T>
@@ -725,9 +753,12 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   TT.emit_bf16 = emit_bf16;
   TT.dual = (nterms > 0 && (terms[0].reserved & DPX_TERM_NO_DUAL)) ? 0.f : 1.f;
   TT.u_live = (nterms > 0 && (terms[0].reserved & DPX_TERM_U_ZERO)) ? 0 : 1;
+  TT.vxu = (nterms > 0 && (terms[0].reserved & DPX_TERM_VXU)) ? 1 : 0;
+  DPX_REQUIRE(!(TT.vxu && TT.dual == 0.f), "dpx_admm_iter_rows: DPX_TERM_VXU and DPX_TERM_NO_DUAL exclude each other");
   for (int i = 0; i < nterms; ++i) {
     DPX_REQUIRE(!(terms[i].reserved & DPX_TERM_NO_DUAL) == (TT.dual != 0.f), "dpx_admm_iter_rows: DPX_TERM_NO_DUAL must be set on every term or on none");
     DPX_REQUIRE(!(terms[i].reserved & DPX_TERM_U_ZERO) == (TT.u_live != 0), "dpx_admm_iter_rows: DPX_TERM_U_ZERO must be set on every term or on none");
+    DPX_REQUIRE(!(terms[i].reserved & DPX_TERM_VXU) == (TT.vxu == 0), "dpx_admm_iter_rows: DPX_TERM_VXU must be set on every term or on none");
     DPX_REQUIRE(terms[i].u && (terms[i].u_out) && (!emit_v || terms[i].v), "dpx_admm_iter_rows: term %d lacks u / u_out / v", i);
     DPX_REQUIRE(terms[i].u != terms[i].u_out, "dpx_admm_iter_rows: u must be double-buffered (u_out != u)");
     TT.t[i] = IterTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].u, terms[i].u_out, terms[i].v};

@@ -21,6 +21,7 @@ PROX_NORM1, PROX_NONNEG, PROX_SUMSQ, PROX_EXTERNAL = 0, 1, 2, 3
 LIN_IDENTITY, LIN_GRAD_H, LIN_GRAD_W = 0, 1, 2
 TERM_NO_DUAL = 1          # dpx_term.reserved flags (include/dpx.h)
 TERM_U_ZERO = 2
+TERM_VXU = 4
 MAX_TERMS = 4
 
 

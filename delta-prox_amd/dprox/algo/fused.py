@@ -400,6 +400,8 @@ class FusedADMM:
             for i in range(n):                                   # u' = -u, kept in fresh buffers
                 u[i] = ops.lincomb([(-1.0, u[i])])
                 terms[i].u = u[i].data_ptr()
+            if callback is None and not pbar and T >= 3 and not ext and n > 0 and ops.iter_supported(H, W, terms, n):
+                return self._run_vxu_two_kernel(x0.shape, dev, T, terms, n, v, u, x, FK, (t0, c0, t1, c1), rho_tab, lam_tab)
             for it in tqdm(range(T), disable=not pbar):
                 for i in range(n):
                     terms[i].lam = lam_tab[i][it].data_ptr()
@@ -464,6 +466,54 @@ class FusedADMM:
         s.Kall.update_vars([x])
         return (x, v, u) if dual else (x, v)
 
+
+    def _run_vxu_two_kernel(self, shape, dev, T, terms, n, v, up, x, FK, diag, rho_tab, lam_tab):
+        """ADMM in the order v, x, u (admm.py:103-120) on the two-kernel iteration (power-of-two planes, closed-form proxes, no callback).
+        Per iteration j the reference does  v_i = prox(K_i z_j - u_i);  z_{j+1} = solve(v_i + u_i);  u_i += v_i - z_{j+1}  (z itself,
+        not K_i z: the reference's dual, kept).  With u' = -u and q_i = u'_i - v_i the row pass behind solve j forms the dual
+        u'_i = q_i + z_{j+1}, the NEXT v-update v_i = prox(K_i z_{j+1} + u'_i), q'_i = u'_i - v_i and the next right-hand side
+        rho_{j+1} sum K_i^T (v_i - u'_i): one plane in, one plane out per term like ADMM (DPX_TERM_VXU).  The first v-update and the
+        last x-update / dual are the staged kernels (the loop is one v-update ahead of the reference's iteration boundaries).
+        up: the negated duals u'.  Returns (z, [v_i], [u_i])."""
+        s = self.solver
+        ls = s.least_square
+        B, C, H, W = shape
+        t0, c0, t1, c1 = diag
+        var = s.Kall.variables[0]
+        scratch = torch.empty_like(x)
+        # v-update of iteration 0 (dpx_admm_zupdate: v = prox(K x + u'); its dual output is not used)
+        for i in range(n):
+            terms[i].lam = lam_tab[i][0].data_ptr()
+            terms[i].u_out = scratch.data_ptr()
+        ops.admm_zupdate(x, terms, n)
+        # seed: row transform of rho_0 sum K^T (v - u'), then q = u' - v in place of u'
+        SA = ops.spectrum_buffer(B * C, H, W, dev)
+        SB = ops.spectrum_buffer(B * C, H, W, dev)
+        ops.admm_seed_rows(SA, rho_tab[0], terms, n, shape, dev)
+        q_cur = [ops.lincomb([(1.0, up[i]), (-1.0, v[i])]) for i in range(n)]
+        q_nxt = [torch.empty_like(t) for t in q_cur]
+        dd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
+        for i in range(n):
+            terms[i].u, terms[i].u_out, terms[i].v = q_cur[i].data_ptr(), q_nxt[i].data_ptr(), v[i].data_ptr()
+            terms[i].reserved = be.TERM_VXU
+        # fused passes behind solves 0 .. T-2: the pass behind solve j uses lambda_{j+1} and rho_{j+1} (tables shifted by one row);
+        # the last of them emits z_{T-1} and v of iteration T-1
+        lam_shift = [lt[1:] for lt in lam_tab]
+        par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_shift, ls_eps(ls), 0, T - 1, T, x, True, shape, dev)
+        q_fin = q_nxt if par else q_cur
+        for i in range(n):
+            terms[i].reserved = 0
+        # iteration T-1's x-update and dual on the staged kernels: u' = q + v; z_T = solve(rho sum K^T (v - u')); u' += z_T - v
+        upf = [ops.lincomb([(1.0, q_fin[i]), (1.0, v[i])]) for i in range(n)]
+        for i in range(n):
+            terms[i].u, terms[i].u_out, terms[i].v = upf[i].data_ptr(), scratch.data_ptr(), v[i].data_ptr()
+        rhs = torch.empty_like(x)
+        ops.admm_rhs(rhs, None, rho_tab[T - 1], terms, n)
+        ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[T - 1], ls_eps(ls), out=x, spec_add=FK)
+        u_out = [ops.lincomb([(-1.0, upf[i]), (1.0, v[i]), (-1.0, x)]) for i in range(n)]          # u = -(u' - v + z)
+        var.value = x
+        s.Kall.update_vars([x])
+        return x, v, u_out
 
     def run_stencil(self, state, rhos, lams, max_iter, method, pbar=False, callback=None):
         """LinearizedADMM (``method='ladmm'``, admm.py:78-100) and PockChambolle (``'pc'``, pc.py:6-40) on fused stages: their

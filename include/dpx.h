@@ -273,6 +273,11 @@ typedef struct dpx_term {
  * the FIRST iteration of a dpx_admm_run call need not stream them from HBM (only row 0 of plane 0 of every u must hold zeros).
  * Set on every term of the call or on none.                                                                                 */
 #define DPX_TERM_U_ZERO 2
+/* ADMM in the update order v, x, u (algo/admm.py:103-120, ADMM_vxu) on the two-kernel iteration: the planes passed as u / u_out carry
+ * q_i = -u_i - v_i; a row pass forms t = q + x (the dual update with the fresh x), v = prox(K x + t) (the NEXT iteration's
+ * v-update), writes q' = t - v and hands  rho' sum K_i^T (v - t)  to the next x-update.  Set on every term of the call or on none;
+ * excludes DPX_TERM_NO_DUAL.                                                                                                 */
+#define DPX_TERM_VXU 4
 
 /* rhs = ktb + sum_i rho_b * K_i^T (v_i - u_i)   -- proxfn/sum_square.py:126-135 with
  * b_i = v_i - u_i from algo/admm.py:51.  ktb = sum over Omega of K^T offset (constant per solve). */

@@ -1373,6 +1373,54 @@ def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4):
         L.call("dpx_admm_iter_config", 0, 0)
 
 
+def case_vxu_two_kernel(device, shapes=((1, 2, 256, 256),), iters=5):
+    """ADMM in the order v, x, u (admm.py:103-120) on the two-kernel iteration (DPX_TERM_VXU: the planes carry q = u' - v, the row pass
+    forms the dual with the fresh x and the next v-update) against the op-by-op iteration of the same solver -- full state (z, v_i,
+    u_i), one to four terms, both row kernels."""
+    import synthetic
+    from dprox import _backend as be
+    from dprox import _ops as ops
+    L = be.lib()
+    try:
+        for (B, C, H, W) in shapes:
+            gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=91 + W)
+            b = T(b0, device)
+            for nterms in (2, 3, 4):     # (a single gradient term leaves a line of ~eps denominators: two correct evaluation orders differ by 6e-3 there)
+                def build():
+                    x = dp.Variable()
+                    fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0))
+                    if nterms >= 2:
+                        fns = fns + dp.norm1(dp.grad(x, dim=1))
+                    if nterms >= 3:
+                        fns = fns + dp.nonneg(x)
+                    if nterms >= 4:
+                        fns = fns + dp.norm1(x) * 0.5
+                    return dp.compile(fns, method="admm_vxu", device=device)
+                rhos = torch.linspace(0.4, 0.2, iters)
+                s = build()
+                s.use_fused = False
+                ref = s.solve(x0=b, rhos=rhos, lams=0.01, max_iter=iters, return_full_states=True)
+                assert s.last_path == "generic"
+                for mode in (1, 2):
+                    L.call("dpx_admm_iter_config", mode, 0)
+                    calls = []
+                    real = ops.admm_run
+                    ops.admm_run = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+                    try:
+                        s2 = build()
+                        got = s2.solve(x0=b, rhos=rhos, lams=0.01, max_iter=iters, return_full_states=True)
+                    finally:
+                        ops.admm_run = real
+                    assert calls and s2.last_path == "fused", "admm_vxu did not run on the two-kernel iteration"
+                    tol = 1e-5
+                    assert_close(got[0].cpu(), ref[0].cpu(), tol, f"admm_vxu two-kernel z ({nterms} terms, rows mode {mode})", maxabs_mult=4.0)
+                    for i in range(nterms):
+                        close_on_scale(got[1][i], ref[1][i].cpu().numpy(), ref[0].cpu().numpy(), tol, f"admm_vxu v{i}")
+                        close_on_scale(got[2][i], ref[2][i].cpu().numpy(), ref[0].cpu().numpy(), tol, f"admm_vxu u{i}")
+    finally:
+        L.call("dpx_admm_iter_config", 0, 0)
+
+
 def case_tiny_shapes(device):
     """degenerate planes against the oracle: 2x3, 3x3, 17x2 (every stage at its smallest size, prime lengths), and the
     reference's error for an axis shorter than the gradient stencil (utils/psf2otf.py:46-54 raises there too)"""

@@ -66,6 +66,10 @@ def test_hqs_no_dual_row_kernel():
     pc.case_hqs_nodual_kernel(DEV)
 
 
+def test_admm_vxu_two_kernel():
+    pc.case_vxu_two_kernel(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV, tiny=True)
 
