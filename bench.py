@@ -186,7 +186,8 @@ def extra_configs(dp, synthetic, device):
         c, _ = _timed(lambda: solver.solve(x0=x0, max_iter=40, **kw), 2)
         return (c - a) / 30
     other = {}
-    for tag, shape, method in (("hqs_8x3x1024x1024", (B, C, H, W), "hqs"), ("pgd_8x3x1024x1024", (B, C, H, W), "pgd"),
+    for tag, shape, method in (("hqs_8x3x1024x1024", (B, C, H, W), "hqs"), ("admm_vxu_8x3x1024x1024", (B, C, H, W), "admm_vxu"),
+                               ("pgd_8x3x1024x1024", (B, C, H, W), "pgd"),
                                ("admm_8x3x768x1024", (B, C, 768, 1024), "admm"), ("admm_8x3x768x768", (B, C, 768, 768), "admm")):
         gto, bo, psfo = synthetic.deconv_case(*shape, seed=2023)
         bo, x = torch.from_numpy(bo).to(device), dp.Variable()
@@ -196,7 +197,8 @@ def extra_configs(dp, synthetic, device):
         npx = float(np.prod(shape))
         other[tag] = {"ms_per_iter": dt * 1e3, "it_per_s": 1 / dt, "ps_per_pixel": dt * 1e12 / npx}
         del s, bo
-    other["note"] = ("hqs: the two-kernel ADMM iteration with DPX_TERM_NO_DUAL; pgd: dpx_pgd_run (2 launches per iteration, 28 B per pixel); "
+    other["note"] = ("hqs: the two-kernel ADMM iteration with DPX_TERM_NO_DUAL (no-dual row kernel, 20 B per pixel); admm_vxu: the same two kernels "
+                     "with DPX_TERM_VXU (the planes carry q = u' - v); pgd: dpx_pgd_run (2 launches per iteration, 28 B per pixel); "
                      "768 x 1024 (the reference's example image): column length 3 x 256 on the register-radix path (fft_reg_x3), two-kernel "
                      "iteration; 768 x 768: staged kernels (5 launches, 64 B per pixel)")
     out["other_paths"] = other

@@ -495,17 +495,18 @@ __global__ void __launch_bounds__(512) k_cols_fwd_f64(const double2* __restrict_
   double2* a = smem64;
   double2* b = smem64 + CT * ld;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  // The four workgroups whose columns share the 128-byte lines of the fp32 output / OTF table (16 columns = 4 tiles of CT = 4) are
-  // given block ids 8 apart inside a group of 32: the round-robin block -> XCD assignment puts them behind the same L2 at nearly the
+  // The workgroups whose columns share the 128-byte lines of the fp32 output / OTF table (16 columns = 16 / CT tiles) are given block
+  // ids 8 apart inside a group of 8 * 16 / CT: the round-robin block -> XCD assignment puts them behind the same L2 at nearly the
   // same time, so a table line is fetched once instead of four times (measured: 609 MB of reads for 214 MB algorithmic before) and
   // the four 32-byte pieces of an output line meet in that L2.
   const int p = blockIdx.y;
   int lt;
   {
-    const int id = blockIdx.x, g = id >> 5, r = id & 31;
-    lt = 4 * (g * 8 + (r & 7)) + (r >> 3);
+    const int TPL = 16 / CT;                                // tiles per 128-byte line of the fp32 layouts (8 for CT = 2)
+    const int id = blockIdx.x, g = id / (8 * TPL), r = id - g * (8 * TPL);
+    lt = TPL * (g * 8 + (r & 7)) + (r >> 3);
   }
-  if (lt >= NTL) return;                                   // (block-uniform: the grid is padded to a multiple of 32)
+  if (lt >= NTL) return;                                   // (block-uniform: the grid is padded to a multiple of 8 * TPL)
   const int ch = p % C;
   const int nyq = W / 2, tn = packed ? nyq / CT : 0;
   auto col_of = [&](int c) {                              // spectrum column of slot c of this workgroup (-1: none)
@@ -985,7 +986,7 @@ extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, 
                (const double2*)twW, rpb, CT);
   }
   if (shcol > 48 * 1024) hipFuncSetAttribute((const void*)k_cols_fwd_f64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
-  DPX_LAUNCH("k_cols_fwd_f64", k_cols_fwd_f64, dim3((((Wh + CT - 1) / CT + 31) / 32) * 32, P), dim3(env_ct ? env_ct : (CT >= 4 ? 512 : 256)), shcol, s, (const double2*)spec64,
+  DPX_LAUNCH("k_cols_fwd_f64", k_cols_fwd_f64, dim3((((Wh + CT - 1) / CT + 8 * (16 / CT) - 1) / (8 * (16 / CT))) * (8 * (16 / CT)), P), dim3(env_ct ? env_ct : (CT >= 4 ? 512 : 256)), shcol, s, (const double2*)spec64,
              (float2*)spec_out, (const float2*)otf, conj_otf, accumulate, C, H, W, make_plan(H),
              pow2_path_available(H, W) ? 1 : 0, P, (const double2*)twH, CT);
   return launch_status("dpx_data_spectrum");
