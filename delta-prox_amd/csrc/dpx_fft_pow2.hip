@@ -853,6 +853,9 @@ static void launch_pgd_rows(const float2* sin, float2* sout, float* x, const flo
              C, twW);
 }
 
+bool pgd_rows_seq_pow2(const float2* sin, float2* sout, float* x, const float* ktb, const float* rho, const float* lam, float alpha, int prox, int P,
+                       int C, int H, int W, const void* table, hipStream_t s);        // dpx_iter.hip: the streaming row pass
+
 int pgd_run_pow2(float* x, const float* ktb, const void* gram_otf, int prox, float alpha, const float* rho_tab, const float* lam_tab, int T,
                  int B, int C, int H, int W, const void* table, void* ws, hipStream_t stream) {
   const int P = B * C, Ws = W / 2;
@@ -867,6 +870,7 @@ int pgd_run_pow2(float* x, const float* ktb, const void* gram_otf, int prox, flo
     float2* sout = it + 1 < T ? spec : nullptr;
     const float* rho = rho_tab + (size_t)it * B;
     const float* lam = lam_tab ? lam_tab + (size_t)it * B : nullptr;
+    if (pgd_rows_seq_pow2(spec2, sout, x, ktb, rho, lam, alpha, prox, P, C, H, W, table, stream)) continue;
     switch (W) {
       case 256: launch_pgd_rows<128, 16>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;
       case 512: launch_pgd_rows<256, 32>(spec2, sout, x, ktb, rho, lam, alpha, prox, P * H, H, C, tw_rows(table), stream); break;

@@ -654,6 +654,209 @@ static void launch_iter_rows_seq(const float2* sin, float2* sout, const IterTerm
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_pgd_rows_seq: the row pass of a proximal-gradient iteration (k_pgd_rows, dpx_fft_pow2.hip; reference dprox/algo/pgd.py:26-54) on
+// the streaming structure of k_iter_rows_seq: one T-lane group walks down a band of rows; the next row's spectrum, iterate and K^T b
+// arrive by LDS-DMA one step ahead (hand-counted vmcnt waits, never 0 in the steady state).  No row couples to its neighbours here
+// (the prox acts on x itself), so there is no halo: per row one inverse transform, the forward step and the prox on registers, one
+// forward transform.  20 B per pixel: spectrum in, x in, K^T b in, x out, spectrum out.
+//   after the awaited spectrum DMA of row q (issued in step q-1): NR D (row DMAs of q) + V (x stores) [+ V spectrum stores]
+//   after the awaited row DMAs of row q (issued in step q-1)    : V [+ V] stores of step q-1, + D + 1 (spectrum DMA of q+1) unless q is the last row
+template <int M, int T, bool KTB>
+__global__ void __launch_bounds__(256, 2) k_pgd_rows_seq(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, float* __restrict__ x,
+                                                       const float* __restrict__ ktb, const float* __restrict__ rho, const float* __restrict__ lam,
+                                                       float alpha, int prox, int C, int H, int bands, int P, const float2* __restrict__ twW) {
+  constexpr int V = M / T, G = 64 / T, S = LdsSeq<M>::SLOTS, D = V / 2, RM = M / (V * V);
+  constexpr int STG = 64 * V;
+  constexpr int NR = KTB ? 2 : 1;                       // image-row streams: x, K^T b
+  constexpr int PERWAVE = G * S + STG + 32 + NR * STG;
+  HIP_DYNAMIC_SHARED(float2, smem_pq)
+  float2* twl = smem_pq;
+  float2* twb = smem_pq + M;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane / T, t = lane % T, lbase = lane & ~(T - 1);
+  float2* wl = twb + 64 + wave * PERWAVE;
+  float2* myfft = wl + g * S;
+  float2* stX = wl + G * S;
+  float* stN = (float*)(stX + STG);
+  float2* stR = stX + STG + 32;
+  for (int i = tid; i < M; i += 256) twl[i] = twW[i];
+  if (tid < 64) twb[tid] = twW[(tid * (M / (V * RM)) * 2) % (2 * M)];
+  TwRegs<M, T, false> twr;
+  twr.load(t, twW, 2);
+  twr.twb_ = twb;
+  twr.bstride_ = 1;
+  const int band = (blockIdx.x * 4 + wave) * G + g;
+  const int pl = band / bands, bb = band - pl * bands;
+  const int R = H / bands, r0 = bb * R;                 // equal bands (H and bands are powers of two)
+  const int bi = pl / C;
+  const float rr = rho[bi], th = lam ? lam[bi] * alpha : 0.f;
+  __syncthreads();
+  const unsigned e0 = 2u * t;
+  const unsigned xoff = (unsigned)pl * H * M + (e0 / SPEC_TILE) * H * SPEC_TILE + (e0 % SPEC_TILE);
+  const unsigned xstep = (unsigned)(2 * T / SPEC_TILE) * H * SPEC_TILE;
+  const unsigned noff = (unsigned)P * H * M + (unsigned)pl * H;
+  const unsigned uoff = (unsigned)pl * H * M + e0;
+  const unsigned tile_off = (unsigned)pl * H * M + (unsigned)((t % SPEC_TILE) + (t / SPEC_TILE) * H * SPEC_TILE);
+  const unsigned tile_step = (unsigned)((T / SPEC_TILE) * H * SPEC_TILE);
+  const int pair = lbase | ((T - t) & (T - 1));
+  auto stage_idx = [&](int e) { return ((e >> 1) / T) * 128 + g * 2 * T + ((e >> 1) % T) * 2 + (e & 1); };
+  auto issue_x = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) dpx_glds16<R_LDX>(spec_in + xoff + (unsigned)h * SPEC_TILE + xstep * i, stX + i * 128);
+    dpx_glds4<R_LDX>(spec_in + noff + h, stN);
+  };
+  auto issue_r = [&](int h) {
+    const float2* xrow = (const float2*)x + uoff + (unsigned)h * M;
+#pragma unroll
+    for (int i = 0; i < D; ++i) dpx_glds16<0>(xrow + 2 * T * i, stR + i * 128);
+    if constexpr (KTB) {
+      const float2* krow = (const float2*)ktb + uoff + (unsigned)h * M;
+#pragma unroll
+      for (int i = 0; i < D; ++i) dpx_glds16<1>(krow + 2 * T * i, stR + STG + i * 128);
+    }
+  };
+  constexpr int NXS = NR * D + 2 * V, NXS_NS = NR * D + V;
+  constexpr int NRS = 2 * V + D + 1, NRS_LAST = 2 * V, NRS_NS = V + D + 1, NRS_LAST_NS = V;
+  static_assert(NXS <= 63 && NRS <= 63, "vmcnt is a 6-bit counter");
+  const bool has_spec = spec_out != nullptr;
+  issue_x(r0);
+  issue_r(r0);
+  for (int q = 0; q < R; ++q) {
+    const int h = r0 + q;
+    // ---------------- phase A: inverse row transform of row h ----------------
+    if (q == 0) dpx_wait_vm<NR * D>();
+    else if (has_spec) dpx_wait_vm<NXS>();
+    else dpx_wait_vm<NXS_NS>();
+    float2 xa[V];
+    {
+      float2 Xk[V], Xm[V];
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const int k = t + m * T;
+        Xk[m] = stX[stage_idx(k)];
+        Xm[m] = stX[stage_idx((M - k) & (M - 1))];
+      }
+      const float xn = stN[g * T];
+      dpx_wait_lds();
+      if (q + 1 < R) issue_x(h + 1);
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const int k = t + m * T;
+        const float2 xk = Xk[m], xm = cconj(Xm[m]);
+        if (k == 0) {
+          xa[m] = make_float2(xk.x + xn, xk.x - xn);
+        } else {
+          const float2 e = cadd(xk, xm);
+          const float2 d = cmulc(csub(xk, xm), twl[k]);
+          xa[m] = make_float2(e.x - d.y, e.y + d.x);
+        }
+      }
+    }
+    WaveSync()();
+    fft_reg_tw<M, T, +1, false>(xa, myfft, t, twr, WaveSync());   // xa[m] = two adjacent pixels of K^T K x
+    // ---------------- phase B: forward step + prox on the row, store x ----------------
+    if (q == 0) {
+      if (R > 1) dpx_wait_vm<D + 1>();
+      else dpx_wait_vm<0>();
+    } else if (has_spec) {
+      if (q + 1 < R) dpx_wait_vm<NRS>();
+      else dpx_wait_vm<NRS_LAST>();
+    } else {
+      if (q + 1 < R) dpx_wait_vm<NRS_NS>();
+      else dpx_wait_vm<NRS_LAST_NS>();
+    }
+    float2 xo[V], kb[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+      xo[m] = stR[stage_idx(t + m * T)];
+      kb[m] = KTB ? stR[STG + stage_idx(t + m * T)] : make_float2(0.f, 0.f);
+    }
+    dpx_wait_lds();
+    if (q + 1 < R) issue_r(h + 1);
+    float2 z[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+      const float2 y = make_float2(xo[m].x - rr * (xa[m].x - kb[m].x), xo[m].y - rr * (xa[m].y - kb[m].y));
+      z[m] = make_float2(prox1(prox, y.x, th), prox1(prox, y.y, th));
+    }
+    {
+      float2* xw = (float2*)x + (unsigned)pl * H * M + (unsigned)h * M + t;
+#pragma unroll
+      for (int m = 0; m < V; ++m) xw[m * T] = z[m];
+    }
+    // ---------------- phase C: forward row transform of the new row ----------------
+    if (has_spec) {
+      WaveSync()();
+      fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
+      float2* out = spec_out + tile_off + (unsigned)h * SPEC_TILE;
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 got = make_float2(__shfl(z[V - 1 - m].x, pair), __shfl(z[V - 1 - m].y, pair));
+        const float2 zm = cconj(t == 0 ? z[(V - m) % V] : got);
+        const int k = t + m * T;
+        const float2 zk = z[m];
+        float2 Xo;
+        if (k == 0) {
+          Xo = make_float2(zk.x + zk.y, 0.f);
+          spec_out[noff + h] = make_float2(zk.x - zk.y, 0.f);
+        } else {
+          const float2 e = cscale(cadd(zk, zm), 0.5f);
+          const float2 d = cscale(csub(zk, zm), 0.5f);
+          Xo = cadd(e, cmul(make_float2(d.y, -d.x), twl[k]));
+        }
+        out[tile_step * m] = Xo;
+      }
+    }
+  }
+}
+
+// run-time overrides shared with the ADMM row kernels (dpx_admm_iter_config): rows_mode 2 keeps the plain kernels, bands_per_plane > 0
+// fixes the band count
+extern int g_rows_mode_pgd, g_rows_band_pgd;
+template <int M, int T>
+static bool launch_pgd_rows_seq(const float2* sin, float2* sout, float* x, const float* ktb, const float* rho, const float* lam, float alpha, int prox,
+                                int C, int H, int P, const float2* twW, hipStream_t s) {
+  constexpr int V = M / T, G = 64 / T, S = M + M / 16, STG = 64 * V;
+  // as many bands per plane as keep ~every T-lane group of the launch resident at once (2 workgroups of 4 waves per CU), a power of two
+  int nb = (256 * 2 * 4 * G) / P;
+  int p2 = 1;
+  while (p2 < nb) p2 <<= 1;
+  nb = p2;
+  static const int band_env = getenv("DPX_PGD_BAND") ? atoi(getenv("DPX_PGD_BAND")) : 0;
+  if (band_env) nb = band_env;
+  if (g_rows_band_pgd > 0) nb = g_rows_band_pgd;
+  if (nb > H) nb = H;
+  const int per_block = 4 * G;
+  if (nb < 1 || H % nb || (P * nb) % per_block) return false;
+  const size_t sh1 = (size_t)(M + 64 + 4 * (G * S + STG + 32 + 1 * STG)) * sizeof(float2), sh2 = (size_t)(M + 64 + 4 * (G * S + STG + 32 + 2 * STG)) * sizeof(float2);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)k_pgd_rows_seq<M, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2);
+    hipFuncSetAttribute((const void*)k_pgd_rows_seq<M, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1);
+    attr = true;
+  }
+  const dim3 grid(P * nb / per_block);
+  if (ktb)
+    DPX_LAUNCH("k_pgd_rows_seq", (k_pgd_rows_seq<M, T, true>), grid, dim3(256), sh2, s, sin, sout, x, ktb, rho, lam, alpha, prox, C, H, nb, P, twW);
+  else
+    DPX_LAUNCH("k_pgd_rows_seq", (k_pgd_rows_seq<M, T, false>), grid, dim3(256), sh1, s, sin, sout, x, ktb, rho, lam, alpha, prox, C, H, nb, P, twW);
+  return true;
+}
+// false: the plane / batch does not fit the streaming kernel (the caller keeps k_pgd_rows)
+bool pgd_rows_seq_pow2(const float2* sin, float2* sout, float* x, const float* ktb, const float* rho, const float* lam, float alpha, int prox, int P,
+                       int C, int H, int W, const void* table, hipStream_t s) {
+  static const bool plain = getenv("DPX_PGD_ROWS") && !strcmp(getenv("DPX_PGD_ROWS"), "plain");      // (A/B and tests)
+  if (plain || g_rows_mode_pgd == 2) return false;
+  switch (W) {
+    case 256: return launch_pgd_rows_seq<128, 16>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
+    case 512: return launch_pgd_rows_seq<256, 32>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
+    case 1024: return launch_pgd_rows_seq<512, 64>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
+    default: return false;
+  }
+}
+
 size_t pow2_spec_elems(int P, int H, int W);
 int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table,
                     hipStream_t stream);
@@ -683,10 +886,13 @@ static int terms_ok(const dpx_term* terms, int nterms) {
 // run-time overrides of the row-kernel choice (tests / tuning): rows_mode 0 = automatic, 1 = streaming kernel, 2 = lock-step
 // ring-buffer kernel; bands_per_plane 0 = automatic.  The environment variables DPX_ITER_ROWS / DPX_ITER_BAND set the defaults.
 static int g_rows_mode = -1, g_rows_band = -1;
+namespace dpx { int g_rows_mode_pgd = 0, g_rows_band_pgd = 0; }
 extern "C" int dpx_admm_iter_config(int rows_mode, int bands_per_plane) {
   DPX_REQUIRE(rows_mode >= 0 && rows_mode <= 2 && bands_per_plane >= 0, "dpx_admm_iter_config: bad arguments");
   g_rows_mode = rows_mode;
   g_rows_band = bands_per_plane;
+  dpx::g_rows_mode_pgd = rows_mode;                      // (dpx_pgd_run's row pass follows the same switch: 2 = the plain kernel)
+  dpx::g_rows_band_pgd = bands_per_plane;
   return DPX_OK;
 }
 

@@ -1373,6 +1373,39 @@ def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4):
         L.call("dpx_admm_iter_config", 0, 0)
 
 
+def case_pgd_streaming_rows(device, shapes=((1, 2, 256, 256),), iters=4):
+    """dpx_pgd_run's streaming row pass (k_pgd_rows_seq: LDS-DMA prefetch one row ahead, hand-counted waits) against the plain
+    one-wave-per-row kernel (k_pgd_rows): the same arithmetic on the same table values, so the iterates agree to fp32 round-off of a few
+    differently contracted multiply-adds; and BIT-identical across band partitions (a wait that returned early would read a stale or
+    half-landed row in some partition).  With and without a K^T b term, three proxes."""
+    import synthetic
+    from dprox import _backend as be
+    L = be.lib()
+    try:
+        for (B, C, H, W) in shapes:
+            gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=73 + W)
+            b = T(b0, device)
+            T_lanes = W // 16
+            per_block = 4 * (64 // T_lanes)
+            cands = [nb for nb in (1, 2, 4, 8, 16, 32, 64, 128, 256) if nb <= H and (B * C * nb) % per_block == 0]
+            for reg in ("l1", "nonneg", "l2"):
+                def run(mode, bands):
+                    L.call("dpx_admm_iter_config", mode, bands)
+                    x = dp.Variable()
+                    g = {"l1": dp.norm1(x), "nonneg": dp.nonneg(x), "l2": dp.norm2(x) if hasattr(dp, "norm2") else dp.norm1(x)}[reg]
+                    s = dp.compile(dp.sum_squares(dp.conv(x, psf) - b) + g, method="pgd", device=device)
+                    return s.solve(x0=b, rhos=0.8, lams=0.01, max_iter=iters)
+                outs = [run(1, nb) for nb in (cands[0], cands[len(cands) // 2], cands[-1])]
+                for o in outs[1:]:
+                    assert torch.equal(outs[0], o), ("streaming PGD rows: band partitions differ", (B, C, H, W), reg)
+                plain = run(2, 0)
+                err = float((outs[0] - plain).abs().max()) / max(float(plain.abs().max()), 1e-30)
+                record(f"pgd streaming rows vs plain kernel {B}x{C}x{H}x{W} {reg}", err, 1e-6)
+                assert err <= 1e-6, ((B, C, H, W), reg, err)
+    finally:
+        L.call("dpx_admm_iter_config", 0, 0)
+
+
 def case_vxu_two_kernel(device, shapes=((1, 2, 256, 256),), iters=5):
     """ADMM in the order v, x, u (admm.py:103-120) on the two-kernel iteration (DPX_TERM_VXU: the planes carry q = u' - v, the row pass
     forms the dual with the fresh x and the next v-update) against the op-by-op iteration of the same solver -- full state (z, v_i,

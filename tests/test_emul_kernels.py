@@ -70,6 +70,10 @@ def test_admm_vxu_two_kernel():
     pc.case_vxu_two_kernel(DEV)
 
 
+def test_pgd_streaming_row_kernel():
+    pc.case_pgd_streaming_rows(DEV)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV, tiny=True)
 

@@ -79,6 +79,10 @@ def test_admm_vxu_two_kernel():
     pc.case_vxu_two_kernel(DEV, shapes=((1, 2, 256, 256), (2, 3, 512, 1024)), iters=6)
 
 
+def test_pgd_streaming_row_kernel():
+    pc.case_pgd_streaming_rows(DEV, shapes=((1, 2, 256, 256), (3, 1, 512, 512), (2, 3, 256, 1024), (8, 3, 1024, 1024)), iters=5)
+
+
 def test_pgd_pow2_fused():
     pc.case_pgd_pow2(DEV)
 
