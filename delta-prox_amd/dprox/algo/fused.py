@@ -173,7 +173,8 @@ def schedule_table(vals, T, B, device):
     """0-d / [T] / [B,T] -> contiguous [T,B] float32 on device (cached while the caller passes the same, unmodified tensor: a loop
     that calls iters() / solve() with its own schedule tensors then launches no kernel for them)"""
     key = None
-    if isinstance(vals, torch.Tensor) and not vals.requires_grad:
+    # (device tensors only: a CPU tensor may share its memory with a NumPy array, whose edits do not bump the version counter)
+    if isinstance(vals, torch.Tensor) and not vals.requires_grad and vals.is_cuda:
         key = (vals.data_ptr(), tuple(vals.shape), tuple(vals.stride()), vals._version, vals.dtype, str(vals.device), T, B, str(device))
         hit = _sched_cache.get(key)
         if hit is not None:
