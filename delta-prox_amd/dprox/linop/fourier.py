@@ -173,7 +173,7 @@ class conv_doe(LinOp):
         psf = self.psf
         if psf is None:
             raise ValueError("conv_doe: the PSF placeholder has no value yet")
-        ver = (self._psf_gen, psf._version)
+        ver = (self._psf_gen, id(psf), psf._version)       # (id: `op.psf = other_tensor` assigned directly, not through the Placeholder)
         if self.cache.get("version") != ver:
             self.cache = {"version": ver}                    # a new PSF value invalidates every size's OTF
         key = (tuple(shape[1:]), str(device))
@@ -188,7 +188,7 @@ class conv_doe(LinOp):
         return self._full_otf(shape, device)[1]
 
     def _own_tables_version(self):
-        return None if self.psf is None else (self._psf_gen, self.psf._version)
+        return None if self.psf is None else (self._psf_gen, id(self.psf), self.psf._version)
 
     def _convolve(self, img, conj):
         if self.circular:

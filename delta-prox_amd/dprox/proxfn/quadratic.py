@@ -40,7 +40,13 @@ class sum_squares(ProxFn):
             return k
         # a tensor's in-place edits bump its version counter; anything else (a numpy array) cannot be watched: a key that never
         # compares equal makes every use re-read it, as the reference does
-        return k + ((id(self._b), self._b._version) if isinstance(self._b, torch.Tensor) else (object(),))
+        if isinstance(self._b, torch.Tensor):
+            return k + ((id(self._b), self._b._version),)
+        ver = getattr(self._b, "_version", None)           # a Placeholder counts its assignments (linop/leaf.py)
+        val = getattr(self._b, "_value", None)
+        if isinstance(ver, int):
+            return k + ((id(self._b), ver, id(val), getattr(val, "_version", None)),)
+        return k + (object(),)
 
     def _compute_offset(self):
         if self._b is not None:
