@@ -16,6 +16,7 @@
 // LDS, and one halo row above / below the band is recomputed (R+2 inverse transforms for R rows).
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "dpx_fft_reg.h"
 
@@ -416,18 +417,35 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   constexpr int NU_LAST_NS = (NU * V) > 63 ? 63 : (NU * V);
   constexpr int NU_STEADY_NS = (NU * V + D + 1) > 63 ? 63 : (NU * V + D + 1);
   const bool has_spec = rho_next != nullptr;
+  // An emitting pass (the last one of a call; every one under a callback) also stores x (V per row, phase A, behind issue_x) and v
+  // (NT V per row, phase B, behind issue_u).  With bands of equal length every steady-state wait has them behind the awaited DMA
+  // as well, so they are added to its count -- without them the wave would also wait for its emit stores of the previous row
+  // (the pass took 1.8 x a plain one instead of the 1.33 x its bytes ask for).  emode: 0 none / unequal bands, 1 x, 2 x and v.
+  constexpr int EX = V, EV = NT * V;
+  // xonly (emit_v == 2, no-dual instantiation only): the last pass of a solve() that hands back x alone -- inverse transforms of
+  // the band's own rows and their x stores, nothing else (no halo rows, no z / dual update: 8 B per element)
+  const bool xonly = !DUAL && emit_v == 2;
+  const int qfirst = xonly ? 1 : 0, qlast = xonly ? Rmax : Rmax + 1;
+  const int emode = (x_out && rrem == 0) ? ((emit_v && !xonly) ? 2 : 1) : 0;
+  auto wait_emit = [&](auto nbase, auto with_x) {
+    constexpr int N0 = decltype(nbase)::value, WX = decltype(with_x)::value;
+    constexpr int N1 = (N0 + WX * EX) > 63 ? 63 : (N0 + WX * EX), N2 = (N0 + WX * EX + EV) > 63 ? 63 : (N0 + WX * EX + EV);
+    if (emode == 2) dpx_wait_vm<N2>();
+    else if (emode == 1) dpx_wait_vm<N1>();
+    else dpx_wait_vm<N0>();
+  };
 
-  issue_x(rowof(0));
+  issue_x(rowof(qfirst));
   issue_u(rowof(0));
   float2 xprev[V], wprev[V];
 #pragma unroll
   for (int m = 0; m < V; ++m) xprev[m] = wprev[m] = make_float2(0.f, 0.f);
 
-  for (int q = 0; q <= Rmax + 1; ++q) {
+  for (int q = qfirst; q <= qlast; ++q) {
     // ---------------- phase A: inverse row transform of row q ----------------
     if (q >= 3) {
-      if (has_spec) dpx_wait_vm<NX_STEADY>();
-      else dpx_wait_vm<NX_STEADY_NS>();
+      if (has_spec) wait_emit(std::integral_constant<int, NX_STEADY>(), std::integral_constant<int, 1>());
+      else wait_emit(std::integral_constant<int, NX_STEADY_NS>(), std::integral_constant<int, 1>());
     }
     else if (q == 1) dpx_wait_vm<0>();
     else dpx_wait_vm<NU * D>();
@@ -442,7 +460,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       }
       const float xn = stN[g * T];
       dpx_wait_lds();
-      if (q <= Rmax) issue_x(rowof(q + 1));
+      if (q < qlast) issue_x(rowof(q + 1));
 #pragma unroll
       for (int m = 0; m < V; ++m) {
         const int k = t + m * T;
@@ -463,7 +481,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
 #pragma unroll
       for (int m = 0; m < V; ++m) dpx_emit_pair(x_out, TT.emit_bf16, xo + m * T, xa[m]);
     }
-    if (q >= 1) {
+    if (q >= 1 && !xonly) {
       // ---------------- phase B: z / dual update of row qz = q - 1 (x[qz] = xprev, x[qz+1] = xa) ----------------
       const int qz = q - 1;
       const bool own = qz >= 1 && qz <= R;
@@ -473,11 +491,11 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       if constexpr (DUAL) {
         if (q >= 3) {
           if (has_spec) {
-            if (q <= Rmax) dpx_wait_vm<NU_STEADY>();
-            else dpx_wait_vm<NU_LAST>();
+            if (q <= Rmax) wait_emit(std::integral_constant<int, NU_STEADY>(), std::integral_constant<int, 1>());
+            else wait_emit(std::integral_constant<int, NU_LAST>(), std::integral_constant<int, 0>());      // (row Rmax + 1 is a halo row: no x store in its phase A)
           } else {
-            if (q <= Rmax) dpx_wait_vm<NU_STEADY_NS>();
-            else dpx_wait_vm<NU_LAST_NS>();
+            if (q <= Rmax) wait_emit(std::integral_constant<int, NU_STEADY_NS>(), std::integral_constant<int, 1>());
+            else wait_emit(std::integral_constant<int, NU_LAST_NS>(), std::integral_constant<int, 0>());
           }
         } else {
           dpx_wait_vm<D + 1>();
@@ -639,9 +657,11 @@ template <int M, int T, int NT>
 static void launch_iter_rows_seq_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
                                     int C, int H, int R, int P, const float2* twW, hipStream_t s) {
   static const bool keep_dual = getenv("DPX_HQS_STREAM_DUALS") != nullptr;      // (A/B: half-quadratic splitting on the general kernel)
-  if (TT.vxu) launch_iter_rows_seq_d<M, T, NT, true, true>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
-  else if (TT.dual == 0.f && !keep_dual) launch_iter_rows_seq_d<M, T, NT, false>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
-  else launch_iter_rows_seq_d<M, T, NT, true>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, twW, s);
+  // emit_v == 2 (x only: the last pass of a solve() that returns x alone) runs on the no-dual instantiation whatever the solver
+  if (emit_v == 2 && x_out && !rho_next) launch_iter_rows_seq_d<M, T, NT, false>(sin, sout, TT, rho_next, x_out, 2, C, H, R, P, twW, s);
+  else if (TT.vxu) launch_iter_rows_seq_d<M, T, NT, true, true>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, twW, s);
+  else if (TT.dual == 0.f && !keep_dual) launch_iter_rows_seq_d<M, T, NT, false>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, twW, s);
+  else launch_iter_rows_seq_d<M, T, NT, true>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, twW, s);
 }
 template <int M, int T>
 static void launch_iter_rows_seq(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
@@ -1014,10 +1034,10 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   //  of two -- these launches are latency-bound: config 1 0.78 -> 0.62 ms per 20-iteration solve)
   const int R = r_env ? r_env : (W <= 256 ? 8 : 16);
   switch (W) {
-    case 256: launch_iter_rows<128, 16>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
-    case 512: launch_iter_rows<256, 32>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
-    case 1024: launch_iter_rows<512, 64>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
-    default: launch_iter_rows<1024, 64>(sin, sout, TT, rho_next, x_out, emit_v, C, H, R, P, tw, s); break;
+    case 256: launch_iter_rows<128, 16>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
+    case 512: launch_iter_rows<256, 32>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
+    case 1024: launch_iter_rows<512, 64>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
+    default: launch_iter_rows<1024, 64>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
   }
   return launch_status("dpx_admm_iter_rows");
 }
@@ -1058,7 +1078,8 @@ extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, co
       cur[i].u_out = parity ? terms[i].u : terms[i].u_out;
     }
     rc = dpx_admm_iter_rows(spec_b, last_of_solve ? nullptr : spec_a, cur, nterms,
-                            last_of_solve ? nullptr : rho_tab + (size_t)(it + 1) * B, emit ? x_out : nullptr, emit ? 1 : 0, B, C,
+                            last_of_solve ? nullptr : rho_tab + (size_t)(it + 1) * B, emit ? x_out : nullptr,
+                            emit ? (emit_last == 2 && last_of_solve ? 2 : 1) : 0, B, C,
                             H, W, table, stream);
     if (rc) return rc;
     parity ^= 1;

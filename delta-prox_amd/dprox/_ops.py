@@ -606,12 +606,13 @@ def admm_seed_rows(spec, rho, term_arr, nterms, shape, device, fresh_x=None):
 
 def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, eps, it0, n_iters, total, x_out, emit_last,
              shape, device):
-    """n_iters fused iterations on the C side; returns the u-buffer parity (0: terms[i].u current, 1: u_out)"""
+    """n_iters fused iterations on the C side; returns the u-buffer parity (0: terms[i].u current, 1: u_out).
+    emit_last: 0 nothing / 1 x and v (and the duals) / 2 x alone when the call ends the solve (v and u are then NOT updated)"""
     B, C, H, W = shape
     lt = (c_void_p * nterms)(*[None if t is None else t.data_ptr() for t in lam_tabs])
     L = be.lib()
     rc = L.query("dpx_admm_run", ptr(spec_a), ptr(spec_b), ptr(spec_add), ptr(dd), term_arr, nterms, ptr(rho_tab), lt,
-                 c_float(eps), it0, n_iters, total, ptr(x_out), int(bool(emit_last)), B, C, H, W,
+                 c_float(eps), it0, n_iters, total, ptr(x_out), int(emit_last), B, C, H, W,
                  ptr(fft_table(H, W, device)), be.stream())
     if rc < 0:
         raise be.DpxError(f"dpx_admm_run failed ({rc}): {L.cdll.dpx_last_error().decode()}")

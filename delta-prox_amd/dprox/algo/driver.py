@@ -109,7 +109,13 @@ class Algorithm(nn.Module):
             with be.device_guard(device), be.solve_scope("solve"):
                 xs, rs, ls = move(x0, rhos, lams, device=device)
                 state = self._initial_state(xs.contiguous(), **kwargs)
-                return self.iters(state, rs, ls, max_iter, pbar, callback=callback)
+                # only x leaves solve(): a solver may skip whatever of its LAST iteration x does not depend on (fused.py: the final
+                # z / dual update of the two-kernel iteration); callbacks and return_full_states see complete states
+                self._x_only = callback is None and not return_full_states
+                try:
+                    return self.iters(state, rs, ls, max_iter, pbar, callback=callback)
+                finally:
+                    self._x_only = False
         try:
             state = run()
         except be.F16RangeError:

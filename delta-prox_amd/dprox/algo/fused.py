@@ -670,7 +670,8 @@ class FusedADMM:
             for i in range(n):
                 terms[i].reserved |= be.TERM_U_ZERO
         if callback is None and not pbar:
-            par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_tab, eps, 0, T, T, x, True, shape, dev)
+            # (solve() hands back x alone: the last pass then stores nothing else -- no v, no final dual update: emit mode 2)
+            par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_tab, eps, 0, T, T, x, 2 if getattr(s, "_x_only", False) else 1, shape, dev)
             if par:
                 u_cur, u_nxt = u_nxt, u_cur
         else:

@@ -365,7 +365,8 @@ int dpx_admm_unrolled_backward_bf16(const void* hist_bf16, const float* gx, cons
  *   dpx_admm_iter_rows : inverse row FFT (x of this iteration) -> z / dual update of every term (lam of this iteration)
  *                        -> rho_next * sum_i K_i^T (v_i - u_i) -> forward row FFT -> spectrum out (input of the next cols)
  * x and v_i are only written when requested (x_out non-null / emit_v), u_i is double-buffered (terms[i].u -> u_out);
- * rho_next = NULL on the last iteration (no right-hand side is produced).  dpx_rfft_rows seeds the loop with the row
+ * rho_next = NULL on the last iteration (no right-hand side is produced); there emit_v = 2 with x_out asks for x ALONE (no z / dual
+ * update at all: terms[i].v / u_out are not written).  dpx_rfft_rows seeds the loop with the row
  * transform of the first right-hand side (dpx_admm_rhs).  Spectrum buffers: dpx_spectrum_bytes / 2 each.            */
 int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms);
 int dpx_rfft_rows(const float* x, void* spec, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
@@ -383,7 +384,10 @@ int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* term
                        float* x_out, int emit_v, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
 /* the hot loop of Algorithm.iters (algo/base.py:149-156) for n_iters iterations, entirely on the C side:
  * rho_tab [total_iters][B], lam_tabs[i] [total_iters][B]; returns 0/1 = which of terms[i].u / u_out holds the
- * current u_i afterwards (<0 = error); x / v_i are written by the call's final iteration when emit_last is set. */
+ * current u_i afterwards (<0 = error); x / v_i are written by the call's final iteration when emit_last is 1.
+ * emit_last = 2: the caller wants x alone (Algorithm.solve returns state[0], algo/base.py:141): when the call ends the solve
+ * (it0 + n_iters == total_iters) its final row pass stores x and nothing else -- v_i and the duals stay those of the iteration
+ * before; when it does not end the solve, 2 means 1.                                                                             */
 /* Fused stages of LinearizedADMM (algo/admm.py:78-100) and PockChambolle (algo/pc.py:6-40) for K_i in {identity, grad_H, grad_W}:
  *   dpx_split_rhs   rhs = ktb + rho_b sum_i K_i^T (x - K_i^T q_i),  q_i = z_i (mode 0, PC: terms[i].v) or (K_i x - v_i) + u_i (mode 1, LADMM)
  *                   -- the right-hand side least_squares.rhs builds from the b_i of pc.py:24-25 / admm.py:84-88 (ktb nullable)

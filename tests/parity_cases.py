@@ -1335,6 +1335,46 @@ def case_fresh_state(device, shapes=((2, 1, 256, 256),), iters=3):
         L.call("dpx_admm_iter_config", 0, 0)
 
 
+def case_solve_x_only(device, shapes=((2, 1, 256, 256),), iters=4):
+    """solve() hands back x alone, so its last row pass stores x and skips the final z / dual update (emit mode 2: the no-dual
+    instantiation of the streaming row kernel in its x-only mode, own rows of each band, no halo).  Against the same solve with
+    return_full_states=True (the emitting pass: x, v and the duals, with its emit-aware wait counts) and against a callback run
+    (every pass emits): BIT-identical x; ADMM and half-quadratic splitting; equal bands and ragged ones (bands of 8 and 9 rows)."""
+    import synthetic
+    from dprox import _backend as be
+    L = be.lib()
+    try:
+        for (B, C, H, W) in shapes:
+            gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=91 + H)
+            b = T(b0, device)
+            for method in ("admm", "hqs"):
+                for bands in (0, H // 8, 30):
+                    L.call("dpx_admm_iter_config", 1, bands)
+                    x = dp.Variable()
+                    fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
+                    s = dp.compile(fns, method=method, device=device)
+                    kw = dict(x0=b, rhos=torch.linspace(0.4, 0.2, iters), lams=0.01, max_iter=iters)
+                    xa = s.solve(**kw)
+                    assert s.last_path == "fused"
+                    full = s.solve(return_full_states=True, **kw)
+                    seen = []
+                    xc = s.solve(callback=lambda **k: seen.append(k["state"][0].clone()), **kw)
+                    assert len(seen) == iters
+                    assert torch.equal(xa, full[0]), ("x-only pass differs from the emitting pass", method, bands, float((xa - full[0]).abs().max()))
+                    assert torch.equal(xa, xc) and torch.equal(xa, seen[-1]), ("callback run differs", method, bands)
+                    # the full state is a state: continuing from it equals a longer solve
+                    if method == "admm" and bands == 0:
+                        sched = torch.cat([torch.linspace(0.4, 0.2, iters), torch.tensor([0.15, 0.1])])
+                        _, rhos, lams, _ = s.defaults(b, sched, 0.01, iters + 2)
+                        rd, ld = rhos.to(device), {k: v.to(device) for k, v in lams.items()}
+                        longer = s.solve(x0=b, rhos=sched, lams=0.01, max_iter=iters + 2)
+                        cont = s.iters(tuple(full), rd[..., iters:].contiguous(), {k: v[..., iters:].contiguous() for k, v in ld.items()}, 2)
+                        rel = float((cont[0] - longer).norm() / longer.norm())
+                        assert rel < 2e-6, ("continuing from the emitted state", rel)
+    finally:
+        L.call("dpx_admm_iter_config", 0, 0)
+
+
 def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4):
     """Half-quadratic splitting on the streaming row kernel's no-dual variant (k_iter_rows_seq<..., DUAL = false>: the duals are
     neither fetched nor stored, its wait counts are the general kernel's minus the dual streams) against the lock-step ring-buffer

@@ -62,6 +62,10 @@ def test_fresh_state_shortcut_is_bit_identical():
     pc.case_fresh_state(DEV)
 
 
+def test_solve_returns_x_alone_from_an_x_only_last_pass():
+    pc.case_solve_x_only(DEV)
+
+
 def test_hqs_no_dual_row_kernel():
     pc.case_hqs_nodual_kernel(DEV)
 

@@ -71,6 +71,10 @@ def test_fresh_state_shortcut_is_bit_identical():
     pc.case_fresh_state(DEV, shapes=((2, 1, 256, 256), (3, 2, 512, 1024), (1, 3, 1024, 512)), iters=4)
 
 
+def test_solve_returns_x_alone_from_an_x_only_last_pass():
+    pc.case_solve_x_only(DEV, shapes=((2, 1, 256, 256), (3, 2, 512, 1024), (8, 3, 1024, 1024), (1, 3, 1024, 512)), iters=5)
+
+
 def test_hqs_no_dual_row_kernel():
     pc.case_hqs_nodual_kernel(DEV, shapes=((1, 2, 256, 256), (3, 1, 512, 512), (2, 3, 256, 1024)), iters=5)
 
