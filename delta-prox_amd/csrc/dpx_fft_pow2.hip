@@ -789,6 +789,8 @@ static void cols_dispatch(int H, const float2* spec, float2* spec_out, const Spe
   }
 }
 
+bool seed_rows_seq_pow2(const int* linops, int n, const float* rho, const float* x0, float2* spec, int P, int C, int H, int W, const void* table,
+                        hipStream_t s);
 template <int M, int T>
 static void launch_seed(const SeedTerms& S_, const float* rho, float2* spec, int nrows, int H, int C, const float2* twW, hipStream_t s) {
   constexpr int SPB = 256 / T;
@@ -810,6 +812,11 @@ int seed_rows_pow2(const dpx_term* terms, int nterms, const float* rho, const fl
     S_.linop[i] = terms[i].linop;
   }
   const int nrows = B * C * H;
+  if (x0) {                                             // the streaming form (dpx_iter.hip) where the plane fits it
+    int ops[DPX_MAX_TERMS];
+    for (int i = 0; i < nterms; ++i) ops[i] = terms[i].linop;
+    if (seed_rows_seq_pow2(ops, nterms, rho, x0, spec, B * C, C, H, W, table, stream)) return launch_status("dpx_admm_seed_rows");
+  }
   switch (W) {
     case 256: launch_seed<128, 16>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;
     case 512: launch_seed<256, 32>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;

@@ -878,6 +878,181 @@ bool pgd_rows_seq_pow2(const float2* sin, float2* sout, float* x, const float* k
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_seed_rows_seq: the seed pass of a solve that starts from ADMM.initialize's state (k_seed_rows<FRESH>, dpx_fft_pow2.hip: the row
+// transform of rho_0 sum_i K_i^T K_i x0, formed from x0's rows alone) on the streaming structure: one T-lane group walks down a band,
+// the next row of x0 arrives by LDS-DMA while the current one is transformed; the band's two halo rows (grad_H couples a row to
+// both neighbours) are read once per band instead of twice per row.  8 B per pixel + the halo: image in, spectrum out.  The stencil
+// arithmetic is k_seed_rows' (same differences, same order).
+//   after the awaited DMA of row q (issued in step q-1): the V (+1) spectrum stores of step q-1, when that step produced a row
+struct SeedOps {
+  int linop[DPX_MAX_TERMS];
+  int n;
+};
+template <int M, int T>
+__global__ void __launch_bounds__(256, 2) k_seed_rows_seq(SeedOps SO, const float* __restrict__ rho, const float* __restrict__ x0,
+                                                        float2* __restrict__ spec_out, int C, int H, int bands, int P, const float2* __restrict__ twW) {
+  constexpr int V = M / T, G = 64 / T, S = LdsSeq<M>::SLOTS, D = V / 2, RM = M / (V * V);
+  constexpr int STG = 64 * V;
+  constexpr int PERWAVE = G * S + STG;
+  HIP_DYNAMIC_SHARED(float2, smem_sd)
+  float2* twl = smem_sd;
+  float2* twb = smem_sd + M;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane / T, t = lane % T, lbase = lane & ~(T - 1);
+  float2* wl = twb + 64 + wave * PERWAVE;
+  float2* myfft = wl + g * S;
+  float2* stR = wl + G * S;
+  for (int i = tid; i < M; i += 256) twl[i] = twW[i];
+  if (tid < 64) twb[tid] = twW[(tid * (M / (V * RM)) * 2) % (2 * M)];
+  TwRegs<M, T, false> twr;
+  twr.load(t, twW, 2);
+  twr.twb_ = twb;
+  twr.bstride_ = 1;
+  const int band = (blockIdx.x * 4 + wave) * G + g;
+  const int pl = band / bands, bb = band - pl * bands;
+  const int R = H / bands, r0 = bb * R;                 // equal bands
+  const float rr = rho[pl / C];
+  bool has_h = false;
+  for (int i = 0; i < SO.n; ++i) has_h |= SO.linop[i] == DPX_LIN_GRAD_H;
+  __syncthreads();
+  const unsigned e0 = 2u * t;
+  const unsigned noff = (unsigned)P * H * M + (unsigned)pl * H;
+  const unsigned uoff = (unsigned)pl * H * M + e0;
+  const unsigned tile_off = (unsigned)pl * H * M + (unsigned)((t % SPEC_TILE) + (t / SPEC_TILE) * H * SPEC_TILE);
+  const unsigned tile_step = (unsigned)((T / SPEC_TILE) * H * SPEC_TILE);
+  const int pair = lbase | ((T - t) & (T - 1));
+  auto rowof = [&](int q) { int h = r0 - 1 + q; return h < 0 ? h + H : (h >= H ? h - H : h); };
+  auto stage_idx = [&](int e) { return ((e >> 1) / T) * 128 + g * 2 * T + ((e >> 1) % T) * 2 + (e & 1); };
+  auto issue_r = [&](int h) {
+    const float2* xrow = (const float2*)x0 + uoff + (unsigned)h * M;
+#pragma unroll
+    for (int i = 0; i < D; ++i) dpx_glds16<0>(xrow + 2 * T * i, stR + i * 128);
+  };
+  // rows r0 - 1 + q; with a grad_H term step q reads row q and produces row q - 1 (q = 0 and R + 1: the halo rows), without one it
+  // produces the row it reads
+  const int qfirst = has_h ? 0 : 1, qlast = has_h ? R + 1 : R;
+  issue_r(rowof(qfirst));
+  float2 xc[V], xp[V];
+#pragma unroll
+  for (int m = 0; m < V; ++m) xc[m] = xp[m] = make_float2(0.f, 0.f);
+  for (int q = qfirst; q <= qlast; ++q) {
+    const bool stored_prev = has_h ? q >= 3 : q >= 2;
+    if (stored_prev) dpx_wait_vm<V>();
+    else dpx_wait_vm<0>();
+    float2 xn[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) xn[m] = stR[stage_idx(t + m * T)];
+    dpx_wait_lds();
+    if (q < qlast) issue_r(rowof(q + 1));
+    if (has_h ? q >= 2 : true) {
+      float2 ce[V];
+#pragma unroll
+      for (int m = 0; m < V; ++m) ce[m] = has_h ? xc[m] : xn[m];
+      float2 acc[V];
+#pragma unroll
+      for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f);
+      for (int i = 0; i < SO.n; ++i) {
+        const int op = SO.linop[i];
+        if (op == DPX_LIN_IDENTITY) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) acc[m] = cadd(acc[m], ce[m]);
+        } else if (op == DPX_LIN_GRAD_W) {
+          float2 y[V];
+#pragma unroll
+          for (int m = 0; m < V; ++m) {                   // x[w+1] - x[w]; pixel 2n+2 is the neighbour lane's .x
+            const float nx_same = __shfl(ce[m].x, lbase | ((t + 1) & (T - 1)));
+            const float nx_wrap = __shfl(ce[(m + 1) % V].x, lbase);
+            const float xr_ = (t == T - 1) ? nx_wrap : nx_same;
+            y[m] = make_float2(ce[m].y - ce[m].x, xr_ - ce[m].y);
+          }
+#pragma unroll
+          for (int m = 0; m < V; ++m) {                   // adjoint: y[w-1] - y[w]; pixel 2n-1 is the left lane's .y
+            const float l_same = __shfl(y[m].y, lbase | ((t + T - 1) & (T - 1)));
+            const float l_wrap = __shfl(y[(m + V - 1) % V].y, lbase | (T - 1));
+            const float left = (t == 0) ? l_wrap : l_same;
+            acc[m] = make_float2(acc[m].x + (left - y[m].x), acc[m].y + (y[m].x - y[m].y));
+          }
+        } else {                                          // grad_H: (x[h] - x[h-1]) - (x[h+1] - x[h])
+#pragma unroll
+          for (int m = 0; m < V; ++m) {
+            const float2 y = csub(xn[m], ce[m]);
+            const float2 yu = csub(ce[m], xp[m]);
+            acc[m] = cadd(acc[m], csub(yu, y));
+          }
+        }
+      }
+      const unsigned hz = (unsigned)rowof(has_h ? q - 1 : q);
+      float2 z[V];
+#pragma unroll
+      for (int m = 0; m < V; ++m) z[m] = cscale(acc[m], rr);
+      WaveSync()();
+      fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
+      float2* out = spec_out + tile_off + hz * SPEC_TILE;
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 got = make_float2(__shfl(z[V - 1 - m].x, pair), __shfl(z[V - 1 - m].y, pair));
+        const float2 zm = cconj(t == 0 ? z[(V - m) % V] : got);
+        const int k = t + m * T;
+        const float2 zk = z[m];
+        float2 Xo;
+        if (k == 0) {
+          Xo = make_float2(zk.x + zk.y, 0.f);
+          st_stream<R_STX>(spec_out + noff + hz, make_float2(zk.x - zk.y, 0.f));
+        } else {
+          const float2 e = cscale(cadd(zk, zm), 0.5f);
+          const float2 d = cscale(csub(zk, zm), 0.5f);
+          Xo = cadd(e, cmul(make_float2(d.y, -d.x), twl[k]));
+        }
+        st_stream<R_STX>(out + tile_step * m, Xo);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+      xp[m] = xc[m];
+      xc[m] = xn[m];
+    }
+  }
+}
+
+template <int M, int T>
+static bool launch_seed_rows_seq(const SeedOps& SO, const float* rho, const float* x0, float2* spec, int C, int H, int P, const float2* twW, hipStream_t s) {
+  constexpr int V = M / T, G = 64 / T, S = M + M / 16, STG = 64 * V;
+  // bands per plane: the row kernel's rule (every T-lane group of the launch resident, rounded up to a power of two)
+  int nb = (256 * 2 * 4 * G) / P, p2 = 1;
+  while (p2 < nb) p2 <<= 1;
+  nb = p2;
+  static const int band_env = getenv("DPX_SEED_BAND") ? atoi(getenv("DPX_SEED_BAND")) : 0;
+  if (band_env) nb = band_env;
+  if (nb > H / 4) nb = H / 4;
+  const int per_block = 4 * G;
+  if (nb < 1 || H % nb || (P * nb) % per_block) return false;
+  const size_t sh = (size_t)(M + 64 + 4 * (G * S + STG)) * sizeof(float2);
+  static bool attr = false;
+  if (!attr && sh > 48 * 1024) {
+    hipFuncSetAttribute((const void*)k_seed_rows_seq<M, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    attr = true;
+  }
+  DPX_LAUNCH("k_seed_rows_seq", (k_seed_rows_seq<M, T>), dim3(P * nb / per_block), dim3(256), sh, s, SO, rho, x0, spec, C, H, nb, P, twW);
+  return true;
+}
+// false: the plane / batch does not fit the streaming kernel (the caller keeps k_seed_rows<FRESH>)
+bool seed_rows_seq_pow2(const int* linops, int n, const float* rho, const float* x0, float2* spec, int P, int C, int H, int W, const void* table,
+                        hipStream_t s) {
+  static const bool plain = getenv("DPX_SEED_ROWS") && !strcmp(getenv("DPX_SEED_ROWS"), "plain");      // (A/B and tests)
+  if (plain || g_rows_mode_pgd == 2) return false;                 // (dpx_admm_iter_config: 2 = the plain kernels)
+  SeedOps SO{};
+  SO.n = n;
+  for (int i = 0; i < n; ++i) SO.linop[i] = linops[i];
+  switch (W) {
+    case 256: return launch_seed_rows_seq<128, 16>(SO, rho, x0, spec, C, H, P, tw_rows(table), s);
+    case 512: return launch_seed_rows_seq<256, 32>(SO, rho, x0, spec, C, H, P, tw_rows(table), s);
+    case 1024: return launch_seed_rows_seq<512, 64>(SO, rho, x0, spec, C, H, P, tw_rows(table), s);
+    default: return false;
+  }
+}
+
 size_t pow2_spec_elems(int P, int H, int W);
 int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table,
                     hipStream_t stream);
