@@ -884,7 +884,9 @@ bool pgd_rows_seq_pow2(const float2* sin, float2* sout, float* x, const float* k
 // the next row of x0 arrives by LDS-DMA while the current one is transformed; the band's two halo rows (grad_H couples a row to
 // both neighbours) are read once per band instead of twice per row.  8 B per pixel + the halo: image in, spectrum out.  The stencil
 // arithmetic is k_seed_rows' (same differences, same order).
-//   after the awaited DMA of row q (issued in step q-1): the V (+1) spectrum stores of step q-1, when that step produced a row
+// Two rows are in flight per group (two staging areas): with one, a launch has ~8 MB outstanding, short of what 8 TB/s needs.
+//   after the awaited DMA of row q (issued in step q-2): the V (+1) spectrum stores of steps q-2 and q-1, where those steps produced
+//   a row, and the D pieces of row q+1 (issued in step q-1)
 struct SeedOps {
   int linop[DPX_MAX_TERMS];
   int n;
@@ -894,7 +896,7 @@ __global__ void __launch_bounds__(256, 2) k_seed_rows_seq(SeedOps SO, const floa
                                                         float2* __restrict__ spec_out, int C, int H, int bands, int P, const float2* __restrict__ twW) {
   constexpr int V = M / T, G = 64 / T, S = LdsSeq<M>::SLOTS, D = V / 2, RM = M / (V * V);
   constexpr int STG = 64 * V;
-  constexpr int PERWAVE = G * S + STG;
+  constexpr int PERWAVE = G * S + 2 * STG;
   HIP_DYNAMIC_SHARED(float2, smem_sd)
   float2* twl = smem_sd;
   float2* twb = smem_sd + M;
@@ -925,27 +927,33 @@ __global__ void __launch_bounds__(256, 2) k_seed_rows_seq(SeedOps SO, const floa
   const int pair = lbase | ((T - t) & (T - 1));
   auto rowof = [&](int q) { int h = r0 - 1 + q; return h < 0 ? h + H : (h >= H ? h - H : h); };
   auto stage_idx = [&](int e) { return ((e >> 1) / T) * 128 + g * 2 * T + ((e >> 1) % T) * 2 + (e & 1); };
-  auto issue_r = [&](int h) {
+  auto issue_r = [&](int h, int slot) {
     const float2* xrow = (const float2*)x0 + uoff + (unsigned)h * M;
 #pragma unroll
-    for (int i = 0; i < D; ++i) dpx_glds16<0>(xrow + 2 * T * i, stR + i * 128);
+    for (int i = 0; i < D; ++i) dpx_glds16<0>(xrow + 2 * T * i, stR + slot * STG + i * 128);
   };
   // rows r0 - 1 + q; with a grad_H term step q reads row q and produces row q - 1 (q = 0 and R + 1: the halo rows), without one it
   // produces the row it reads
   const int qfirst = has_h ? 0 : 1, qlast = has_h ? R + 1 : R;
-  issue_r(rowof(qfirst));
+  issue_r(rowof(qfirst), qfirst & 1);
+  issue_r(rowof(qfirst + 1), (qfirst + 1) & 1);         // (bands have >= 4 rows)
   float2 xc[V], xp[V];
 #pragma unroll
   for (int m = 0; m < V; ++m) xc[m] = xp[m] = make_float2(0.f, 0.f);
   for (int q = qfirst; q <= qlast; ++q) {
-    const bool stored_prev = has_h ? q >= 3 : q >= 2;
-    if (stored_prev) dpx_wait_vm<V>();
-    else dpx_wait_vm<0>();
+    // lower bounds of what was issued behind row q's DMA (steps produce a row from q = qfirst + 2 on at the latest)
+    const int qq = q - qfirst;
+    if (q == qlast) {
+      if (qq >= 4) dpx_wait_vm<2 * V>();
+      else dpx_wait_vm<0>();
+    } else if (qq >= 4) dpx_wait_vm<2 * V + D>();
+    else if (qq == 3) dpx_wait_vm<V + D>();
+    else dpx_wait_vm<D>();
     float2 xn[V];
 #pragma unroll
-    for (int m = 0; m < V; ++m) xn[m] = stR[stage_idx(t + m * T)];
+    for (int m = 0; m < V; ++m) xn[m] = stR[(q & 1) * STG + stage_idx(t + m * T)];
     dpx_wait_lds();
-    if (q < qlast) issue_r(rowof(q + 1));
+    if (q + 2 <= qlast) issue_r(rowof(q + 2), q & 1);
     if (has_h ? q >= 2 : true) {
       float2 ce[V];
 #pragma unroll
@@ -1028,7 +1036,7 @@ static bool launch_seed_rows_seq(const SeedOps& SO, const float* rho, const floa
   if (nb > H / 4) nb = H / 4;
   const int per_block = 4 * G;
   if (nb < 1 || H % nb || (P * nb) % per_block) return false;
-  const size_t sh = (size_t)(M + 64 + 4 * (G * S + STG)) * sizeof(float2);
+  const size_t sh = (size_t)(M + 64 + 4 * (G * S + 2 * STG)) * sizeof(float2);
   static bool attr = false;
   if (!attr && sh > 48 * 1024) {
     hipFuncSetAttribute((const void*)k_seed_rows_seq<M, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

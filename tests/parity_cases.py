@@ -1302,7 +1302,8 @@ def case_hqs_pow2(device):
 def case_fresh_state(device, shapes=((2, 1, 256, 256),), iters=3):
     """The fresh-state shortcut (state straight from ADMM.initialize: the first right-hand side formed from x0 alone --
     dpx_admm_seed_rows_fresh -- and the zero duals not streamed in the first iteration -- DPX_TERM_U_ZERO) against the same solve
-    started from a state that has been touched (general seed pass, duals read): BIT-identical x, v_i, u_i, on both row kernels."""
+    started from a state that has been touched (general seed pass, duals read): x, v_i, u_i bit-identical where both seeds run the same
+    transform code (plain kernels), within one transform's round-off where the fresh seed is the streaming kernel."""
     import synthetic
     from dprox import _backend as be
     from dprox import _ops as ops
@@ -1332,7 +1333,11 @@ def case_fresh_state(device, shapes=((2, 1, 256, 256),), iters=3):
                     ops.admm_seed_rows = real
                 assert seeds == [True, False], seeds
                 for a, c in zip([fresh[0]] + list(fresh[1]) + list(fresh[2]), [touched[0]] + list(touched[1]) + list(touched[2])):
-                    assert torch.equal(a, c), ("fresh-state shortcut differs", (B, C, H, W), rows_mode, float((a - c).abs().max()))
+                    if rows_mode == 2:          # both seeds on k_seed_rows (one transform, two instantiations): bit-identical
+                        assert torch.equal(a, c), ("fresh-state shortcut differs", (B, C, H, W), rows_mode, float((a - c).abs().max()))
+                    else:                       # streaming seed (k_seed_rows_seq: the row kernel's transform) against k_seed_rows: round-off of one transform
+                        err = float((a - c).abs().max()) / max(float(c.abs().max()), 1e-30)
+                        assert err <= 4e-6, ("fresh-state shortcut differs", (B, C, H, W), rows_mode, err)
     finally:
         L.call("dpx_admm_iter_config", 0, 0)
 

@@ -58,7 +58,7 @@ def test_hqs_two_kernel():
     pc.case_hqs_pow2(DEV)
 
 
-def test_fresh_state_shortcut_is_bit_identical():
+def test_fresh_state_shortcut_matches_the_general_seed():
     pc.case_fresh_state(DEV)
 
 

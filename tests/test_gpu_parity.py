@@ -67,7 +67,7 @@ def test_hqs_two_kernel():
     pc.case_hqs_pow2(DEV)
 
 
-def test_fresh_state_shortcut_is_bit_identical():
+def test_fresh_state_shortcut_matches_the_general_seed():
     pc.case_fresh_state(DEV, shapes=((2, 1, 256, 256), (3, 2, 512, 1024), (1, 3, 1024, 512)), iters=4)
 
 
