@@ -380,6 +380,9 @@ constexpr int COLS_LD_NT = DPX_COLS_LD_NT, COLS_ADD_NT = DPX_COLS_ADD_NT, COLS_S
 #ifndef DPX_COLS_BATCH_INNER
 #define DPX_COLS_BATCH_INNER 1
 #endif
+#ifndef DPX_COLS_PERSIST
+#define DPX_COLS_PERSIST 0       // > 0: persistent workgroups, that many per CU (tuning experiment)
+#endif
 // The Nyquist column of a plane (side array [P][H]) rides through the two transforms as the imaginary part of the plane's DC
 // column: both are spectra of real sequences, so z = dc + i ny is ONE complex column, separated by Hermitian symmetry around
 // the per-frequency operator (a = (Z[k] + conj Z[N-k]) / 2, i b = (Z[k] - conj Z[N-k]) / 2), as the generic path does
@@ -636,9 +639,15 @@ template <int H, int T, int COLS, int OP, int DBG = 0>
 #define DPX_COLS_WPE ((H % 3 == 0 || (H >= 2048 && !DPX_COLS_TW_GLOBAL)) ? 2 : (T * COLS) >= 512 ? 4 : 3)     // waves per SIMD the register budget is sized for (H = 768: 61 KB of LDS -> 2 workgroups of 4 waves per CU)
 #endif
 __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, SpecArgs A,
-                                                      int C, int Ws, int P, const float2* __restrict__ twH) {
+                                                      int C, int Ws, int P, const float2* __restrict__ twH, int total_blocks) {
   const int tiles = Ws / COLS, nmain = P * tiles;
+#if DPX_COLS_PERSIST
+  // persistent form: the launch has at most DPX_COLS_PERSIST workgroups per CU's worth of blocks; each walks block ids bid, bid + grid, ...
+  // (same XCD: the grid is a multiple of 8) -- the next tile's loads are issued while this tile's stores drain
+  for (int bid = blockIdx.x; bid < total_blocks; bid += gridDim.x) {
+#else
   const int bid = blockIdx.x;
+#endif
   // main tiles: COLS adjacent columns of plane p.  side tiles (DPX_COLS_PACK0 = 0 only): the Nyquist columns of COLS consecutive planes.
   const bool is_side = bid >= nmain;                  // block-uniform
   int p = 0, j = 0;                                   // plane and first spectrum tile of this workgroup
@@ -678,6 +687,10 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
     cols_body<H, T, COLS, OP, DBG, true>(spec_in, spec_out, A, C, Ws, P, twH, bid, nmain, is_side, p, j, sub_off);
   else
     cols_body<H, T, COLS, OP, DBG, false>(spec_in, spec_out, A, C, Ws, P, twH, bid, nmain, is_side, p, j, sub_off);
+#if DPX_COLS_PERSIST
+    __syncthreads();                                  // the inverse transform's last LDS reads / the next tile's first writes
+  }
+#endif
 }
 
 // Tuning probe (DPX_DEBUG_COLS=4, wrong results by design): the column kernel's HBM traffic with 16-byte accesses and
@@ -751,8 +764,16 @@ static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A,
     hipFuncSetAttribute((const void*)k_cols_p2<H, T, COLS, OP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr_done = true;
   }
-  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP, DBG>), dim3(P * (Ws / COLS) + (DPX_COLS_PACK0 ? 0 : (P + COLS - 1) / COLS)), dim3(T * COLS), sh, s, spec,
-             spec_out, A, C, Ws, P, twH);
+  const int total_blocks = P * (Ws / COLS) + (DPX_COLS_PACK0 ? 0 : (P + COLS - 1) / COLS);
+  int grid = total_blocks;
+#if DPX_COLS_PERSIST
+  {
+    static const int per_cu_env = getenv("DPX_COLS_PERSIST_WG") ? atoi(getenv("DPX_COLS_PERSIST_WG")) : 0;
+    const int cap = 256 * (per_cu_env ? per_cu_env : DPX_COLS_PERSIST);
+    if (grid > cap) grid = cap;
+  }
+#endif
+  DPX_LAUNCH("k_cols_p2", (k_cols_p2<H, T, COLS, OP, DBG>), dim3(grid), dim3(T * COLS), sh, s, spec, spec_out, A, C, Ws, P, twH, total_blocks);
 }
 
 #ifndef DPX_COLS_WG

@@ -1336,8 +1336,8 @@ def case_fresh_state(device, shapes=((2, 1, 256, 256),), iters=3):
                     if rows_mode == 2:          # both seeds on k_seed_rows (one transform, two instantiations): bit-identical
                         assert torch.equal(a, c), ("fresh-state shortcut differs", (B, C, H, W), rows_mode, float((a - c).abs().max()))
                     else:                       # streaming seed (k_seed_rows_seq: the row kernel's transform) against k_seed_rows: round-off of one transform
-                        err = float((a - c).abs().max()) / max(float(c.abs().max()), 1e-30)
-                        assert err <= 4e-6, ("fresh-state shortcut differs", (B, C, H, W), rows_mode, err)
+                        err = float((a - c).abs().max())          # (images of O(1); the duals are clamped to lam / rho ~ 0.03)
+                        assert err <= 2e-6, ("fresh-state shortcut differs", (B, C, H, W), rows_mode, err)
     finally:
         L.call("dpx_admm_iter_config", 0, 0)
 
