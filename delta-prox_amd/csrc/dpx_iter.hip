@@ -834,14 +834,14 @@ __global__ void __launch_bounds__(256, 2) k_pgd_rows_seq(const float2* __restric
 
 // run-time overrides shared with the ADMM row kernels (dpx_admm_iter_config): rows_mode 2 keeps the plain kernels, bands_per_plane > 0
 // fixes the band count
-extern int g_rows_mode_pgd, g_rows_band_pgd;
+extern int g_rows_mode_pgd, g_rows_band_pgd, g_chain_share;
 template <int M, int T>
 static bool launch_pgd_rows_seq(const float2* sin, float2* sout, float* x, const float* ktb, const float* rho, const float* lam, float alpha, int prox,
                                 int C, int H, int P, const float2* twW, hipStream_t s) {
   constexpr int V = M / T, G = 64 / T, S = M + M / 16, STG = 64 * V;
   // bands per plane: a power of two, ~3 rounds of the resident T-lane groups (2 workgroups of 4 waves per CU) -- there is no halo
   // to amortise here, and shorter bands even out the tail (8x3x1024^2: 64 / 128 / 256 bands 0.158 / 0.150 / 0.147 ms per iteration)
-  int nb = (256 * 2 * 4 * G) / P;
+  int nb = (256 * 2 * 4 * G) / (P * g_chain_share);
   int p2 = 1;
   while (p2 < nb) p2 <<= 1;
   nb = 2 * p2;
@@ -1028,7 +1028,7 @@ template <int M, int T>
 static bool launch_seed_rows_seq(const SeedOps& SO, const float* rho, const float* x0, float2* spec, int C, int H, int P, const float2* twW, hipStream_t s) {
   constexpr int V = M / T, G = 64 / T, S = M + M / 16, STG = 64 * V;
   // bands per plane: the row kernel's rule (every T-lane group of the launch resident, rounded up to a power of two)
-  int nb = (256 * 2 * 4 * G) / P, p2 = 1;
+  int nb = (256 * 2 * 4 * G) / (P * g_chain_share), p2 = 1;
   while (p2 < nb) p2 <<= 1;
   nb = p2;
   static const int band_env = getenv("DPX_SEED_BAND") ? atoi(getenv("DPX_SEED_BAND")) : 0;
@@ -1090,7 +1090,14 @@ static int terms_ok(const dpx_term* terms, int nterms) {
 // run-time overrides of the row-kernel choice (tests / tuning): rows_mode 0 = automatic, 1 = streaming kernel, 2 = lock-step
 // ring-buffer kernel; bands_per_plane 0 = automatic.  The environment variables DPX_ITER_ROWS / DPX_ITER_BAND set the defaults.
 static int g_rows_mode = -1, g_rows_band = -1;
-namespace dpx { int g_rows_mode_pgd = 0, g_rows_band_pgd = 0; }
+namespace dpx { int g_rows_mode_pgd = 0, g_rows_band_pgd = 0, g_chain_share = 1; }
+// Sub-batches of one solve running as independent chains on separate streams (dprox/algo/fused.py) share the GPU: the row kernels size
+// their bands for `chains` x the planes of one call.  A tuning hint only -- results do not depend on the band partition.
+extern "C" int dpx_admm_iter_share(int chains) {
+  DPX_REQUIRE(chains >= 1 && chains <= 16, "dpx_admm_iter_share: chains must be in [1, 16]");
+  dpx::g_chain_share = chains;
+  return DPX_OK;
+}
 extern "C" int dpx_admm_iter_config(int rows_mode, int bands_per_plane) {
   DPX_REQUIRE(rows_mode >= 0 && rows_mode <= 2 && bands_per_plane >= 0, "dpx_admm_iter_config: bad arguments");
   g_rows_mode = rows_mode;
@@ -1191,7 +1198,7 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
     // as many bands per plane as keep every T-lane group of the launch resident at once (2 workgroups of 4 waves per
     // CU), rounded so that the groups fill whole workgroups; bands are >= 4 rows (halo = 2 extra inverse transforms)
     const int T = W / 16, G = 64 / T, per_block = 4 * G;
-    int nb = (256 * 2 * 4 * G) / P;
+    int nb = (256 * 2 * 4 * G) / (P * dpx::g_chain_share);
     // ... rounded UP to a power of two (H is one): bands of equal length keep the waves of a workgroup in step, and ~1.5 rounds
     // of resident groups beat one round of unequal bands (8x3x1024^2: 128 bands of 8 rows 106 us, 85 bands of 12-13 rows 109 us,
     // 96 / 102 / 136 bands 127-133 us)

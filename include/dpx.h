@@ -397,6 +397,10 @@ int dpx_split_rhs(float* rhs, const float* ktb, const float* x, const float* rho
 int dpx_pc_dual(const float* xbar, const dpx_term* terms, int nterms, int B, int C, int H, int W, dpx_stream_t stream);
 /* test / tuning hook: rows_mode 0 automatic, 1 streaming row kernel, 2 lock-step row kernel; bands_per_plane 0 = automatic */
 int dpx_admm_iter_config(int rows_mode, int bands_per_plane);
+/* tuning hint: the following dpx_admm_* calls are one of `chains` sub-batch chains of a solve that run concurrently on separate
+ * streams (the images of a batch never exchange data, algo/admm.py:49-59 acts per image): band lengths are chosen for the planes
+ * of all chains together.  1 = a call has the GPU to itself (default).  Results never depend on it.                          */
+int dpx_admm_iter_share(int chains);
 int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, const void* dd, const dpx_term* terms, int nterms,
                  const float* rho_tab, const float* const* lam_tabs, float eps, int it0, int n_iters, int total_iters,
                  float* x_out, int emit_last, int B, int C, int H, int W, const void* table, dpx_stream_t stream);

@@ -1382,6 +1382,48 @@ def case_solve_x_only(device, shapes=((2, 1, 256, 256),), iters=4):
         L.call("dpx_admm_iter_config", 0, 0)
 
 
+def case_sub_batch_chains(device, shapes=((4, 1, 256, 256),), iters=13, methods=("admm", "hqs"), nchs=(2, 3, 4), twice=True):
+    """The two-kernel iteration run as independent sub-batch chains (FusedADMM._run_chains: own spectrum buffers and data spectrum per
+    chain, separate streams on the GPU, launches issued in turns of 10 iterations) against the one-chain run: BIT-identical full
+    states and x-only results, for 2 / 3 / 4 chains (uneven sub-batches included), ADMM and half-quadratic splitting, per-image rho."""
+    import os
+    import synthetic
+    old = os.environ.get("DPX_CHAINS")
+    try:
+        for (B, C, H, W) in shapes:
+            gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=17 + B + H)
+            b = T(b0, device)
+            rhos = torch.linspace(0.5, 0.2, iters)[None, :] * torch.linspace(1.0, 1.5, B)[:, None]     # [B, T]: every image its own schedule
+            for method in methods:
+                def run(nch, full):
+                    os.environ["DPX_CHAINS"] = str(nch)
+                    x = dp.Variable()
+                    fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
+                    s = dp.compile(fns, method=method, device=device)
+                    out = s.solve(x0=b, rhos=rhos, lams=0.01, max_iter=iters, return_full_states=full)
+                    assert s.last_path == "fused"
+                    flat = lambda st: [st] if torch.is_tensor(st) else [t for part in st for t in (part if isinstance(part, (list, tuple)) else [part])]
+                    if twice:
+                        again = s.solve(x0=b, rhos=rhos, lams=0.01, max_iter=iters, return_full_states=full)      # cached data spectra of the chains
+                        for p_, q_ in zip(flat(out), flat(again)):
+                            assert torch.equal(p_, q_)
+                    return flat(out)
+                ref_full, ref_x = run(1, True), run(1, False)
+                assert torch.equal(ref_full[0], ref_x[0])
+                for nch in nchs:
+                    if nch > B:
+                        continue
+                    for got, ref in ((run(nch, True), ref_full), (run(nch, False), ref_x)):
+                        assert len(got) == len(ref)
+                        for a, c in zip(got, ref):
+                            assert torch.equal(a, c), ("sub-batch chains differ from the one-chain run", (B, C, H, W), method, nch, float((a - c).abs().max()))
+    finally:
+        if old is None:
+            os.environ.pop("DPX_CHAINS", None)
+        else:
+            os.environ["DPX_CHAINS"] = old
+
+
 def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4):
     """Half-quadratic splitting on the streaming row kernel's no-dual variant (k_iter_rows_seq<..., DUAL = false>: the duals are
     neither fetched nor stored, its wait counts are the general kernel's minus the dual streams) against the lock-step ring-buffer

@@ -66,6 +66,10 @@ def test_solve_returns_x_alone_from_an_x_only_last_pass():
     pc.case_solve_x_only(DEV)
 
 
+def test_sub_batch_chains_are_bit_identical_to_one_chain():
+    pc.case_sub_batch_chains(DEV, shapes=((3, 1, 256, 256),), iters=11, methods=("admm",), nchs=(3,), twice=False)      # (1-, 1-, 1-image chains, two turns)
+
+
 def test_hqs_no_dual_row_kernel():
     pc.case_hqs_nodual_kernel(DEV)
 

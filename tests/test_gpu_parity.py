@@ -75,6 +75,10 @@ def test_solve_returns_x_alone_from_an_x_only_last_pass():
     pc.case_solve_x_only(DEV, shapes=((2, 1, 256, 256), (3, 2, 512, 1024), (8, 3, 1024, 1024), (1, 3, 1024, 512)), iters=5)
 
 
+def test_sub_batch_chains_are_bit_identical_to_one_chain():
+    pc.case_sub_batch_chains(DEV, shapes=((4, 1, 256, 256), (6, 2, 512, 512), (8, 3, 1024, 1024)), iters=23)
+
+
 def test_hqs_no_dual_row_kernel():
     pc.case_hqs_nodual_kernel(DEV, shapes=((1, 2, 256, 256), (3, 1, 512, 512), (2, 3, 256, 1024)), iters=5)
 
