@@ -116,7 +116,7 @@ def lazy_initial_state(solver, x0, plan):
     """ADMM.solve's private initial state for problems the two-kernel iteration takes: (x0, [v_i], [u_i]) whose split variables are
     ALLOCATED but not computed -- v_i = K_i x0 and u_i = 0 are implied (``solver._fresh`` says so) and the fresh-state path never
     reads them: the seed pass forms the first right-hand side from x0, the first iteration counts the duals as zero (only row 0 of
-    plane 0 of every u_i is zeroed: the rows it fetches), every v_i / u_i is fully written before the solve returns.  Saves the two
+    plane 0 of every image of every u_i is zeroed: the rows it fetches), every v_i / u_i is fully written before the solve returns.  Saves the two
     K_i x0 passes and the two zero fills of ``initialize`` (0.17 ms at 8 x 3 x 1024^2).  ``materialize_state`` turns it into the
     real thing for any path that does read the state.  None when the problem does not qualify."""
     if not (isinstance(x0, torch.Tensor) and x0.ndim == 4 and x0.dtype == torch.float32 and x0.is_contiguous()):
@@ -131,7 +131,7 @@ def lazy_initial_state(solver, x0, plan):
     v = [torch.empty_like(x0) for _ in range(n)]
     u = [torch.empty_like(x0) for _ in range(n)]
     for t in u:
-        t.view(-1)[:W].zero_()
+        t[:, 0, 0, :].zero_()                                  # (row 0 of plane 0 of every IMAGE: sub-batch chains start at any of them)
     solver._fresh = (x0, v, u, [t._version for t in [x0] + v + u])
     solver._fresh_lazy = True
     return x0, v, u
@@ -298,6 +298,23 @@ class FusedSplitCG:
                 callback(iter=it, state=(x, v, u), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
         s.Kall.update_vars([x])
         return x, v, u
+
+
+_CHAIN_STREAMS = {}          # device index -> side streams of the sub-batch chains
+_chain_tab_cache = {}        # (id(table), b0, b1) -> (table, version, contiguous [T, b1 - b0] copy): the schedule tables are cached objects themselves
+
+
+def _chain_table(tab, b0, b1):
+    """columns [b0, b1) of a [T, B] schedule table as a contiguous table of their own (cached while the source table lives unchanged)"""
+    key = (id(tab), b0, b1)
+    hit = _chain_tab_cache.get(key)
+    if hit is not None and hit[0] is tab and hit[1] == tab._version:
+        return hit[2]
+    out = tab[:, b0:b1].contiguous()
+    if len(_chain_tab_cache) > 64:
+        _chain_tab_cache.clear()
+    _chain_tab_cache[key] = (tab, tab._version, out)
+    return out
 
 
 def chain_bounds(B, chains, c):
@@ -701,9 +718,9 @@ class FusedADMM:
             main, streams = None, [None] * chains
         else:
             main = torch.cuda.current_stream(dev)
-            side = getattr(s, "_chain_streams", None)
-            if side is None or len(side) < chains - 1 or side[0].device != dev:
-                side = s._chain_streams = [torch.cuda.Stream(device=dev) for _ in range(chains - 1)]
+            side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
+            while len(side) < chains - 1:                         # (created once per process and device: a stream costs milliseconds)
+                side.append(torch.cuda.Stream(device=dev))
             streams = [main] + list(side[:chains - 1])
         on = (lambda st: contextlib.nullcontext()) if main is None else torch.cuda.stream
         psi = list(s.psi_fns)
@@ -719,7 +736,7 @@ class FusedADMM:
                 if fresh:
                     terms[i].reserved |= be.TERM_U_ZERO
             work.append(dict(b0=b0, b1=b1, shape=(b1 - b0, C, H, W), terms=terms,
-                             rho=rho_tab[:, b0:b1].contiguous(), lam=[lt[:, b0:b1].contiguous() for lt in lam_tab],
+                             rho=_chain_table(rho_tab, b0, b1), lam=[_chain_table(lt, b0, b1) for lt in lam_tab],
                              SA=ops.spectrum_buffer((b1 - b0) * C, H, W, dev), SB=ops.spectrum_buffer((b1 - b0) * C, H, W, dev)))
         L = be.lib()
         L.call("dpx_admm_iter_share", chains)
@@ -732,10 +749,9 @@ class FusedADMM:
                     for i in range(n):
                         wk["terms"][i].lam = wk["lam"][i][0].data_ptr()
                     ops.admm_seed_rows(wk["SA"], wk["rho"][0], wk["terms"], n, wk["shape"], dev, fresh_x=x0[wk["b0"]:wk["b1"]] if fresh else None)
-            CHUNK = 10                                               # (even: the duals are back in their first buffer after every turn)
-            par = 0
-            for it0 in range(0, T, CHUNK):
-                cnt = min(CHUNK, T - it0)
+            par, it0 = 0, 0
+            while it0 < T:
+                cnt = min(4 if it0 == 0 else 10, T - it0)            # (even turns: the duals are back in their first buffer; a short first one: every chain has work at once)
                 last = it0 + cnt == T
                 for wk, st, fk in zip(work, streams, FK):
                     with on(st):
@@ -744,6 +760,7 @@ class FusedADMM:
                     if it0 == 0 and fresh:
                         for i in range(n):
                             wk["terms"][i].reserved &= ~be.TERM_U_ZERO
+                it0 += cnt
             for st in streams[1:]:
                 if main is not None:
                     main.wait_stream(st)
