@@ -634,9 +634,11 @@ class FusedADMM:
         offs = [fn.offset for fn in s.omega_fns]
         fk_key = (tuple(x0.shape), str(dev), chains) + tuple((id(o), o._version) if o is not None else None for o in offs) + \
             tuple(fn.linop.tables_version() for fn in s.omega_fns)
-        cached = getattr(s, "_fk_cache", None)
-        if cached is not None and cached[0] == fk_key:
-            return cached[1]
+        cache = getattr(s, "_fk_cache", None)                  # {key: (spectrum, offsets)}: the newest two (one per chain layout in use)
+        if cache is None:
+            cache = s._fk_cache = {}
+        if fk_key in cache:
+            return cache[fk_key][0]
         B = int(x0.shape[0])
         parts = []
         for c in range(chains):
@@ -652,7 +654,9 @@ class FusedADMM:
                 FK = ops.data_spectrum(off, otf, conj=True, out=FK, accumulate=FK is not None)
             parts.append(FK)
         out = parts[0] if chains == 1 else parts
-        s._fk_cache = (fk_key, out, offs)
+        while len(cache) >= 2:
+            cache.pop(next(iter(cache)))
+        cache[fk_key] = (out, offs)                            # (the offsets are kept alive: their ids are part of the key)
         return out
 
     @staticmethod
