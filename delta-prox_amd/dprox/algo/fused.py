@@ -330,7 +330,7 @@ def sub_batch_chains(B, C, H, W):
     if env:
         n = max(1, int(env))
         return n if B >= n else 1
-    if B % 2 == 0 and W in (256, 512, 1024) and (B // 2) * C * H * W >= (1 << 22):
+    if B % 2 == 0 and W in (256, 512, 1024) and (B // 2) * C * H * W >= (3 << 20):
         return 2
     return 1
 
