@@ -1276,3 +1276,80 @@ extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, co
   }
   return parity;
 }
+
+// The same loop for `nchains` sub-batches of one solve, each on its own stream (the images of a batch never exchange data: one
+// chain's column pass can run beside another chain's row pass).  Launches are issued chain by chain within an iteration, and the column
+// passes are chained by events -- chain c's column pass of iteration k starts after chain c-1's of iteration k has finished, chain 0's of
+// iteration k+1 after the last chain's of iteration k -- so that no chain runs ahead of the others (left to the queues' arbitration one
+// chain of two finished ~2.5 iterations early and the other ran its last iterations alone) and a column pass always has another
+// chain's row pass beside it.  Returns the dual-buffer parity (the same for every chain), < 0 on error.
+extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const void* dd, int nterms, float eps, int it0, int n_iters,
+                                   int total_iters, int emit_last, int C, int H, int W, const void* table) {
+  DPX_REQUIRE(chains && nchains >= 1 && nchains <= DPX_MAX_CHAINS && dd && table, "dpx_admm_run_chains: bad arguments");
+  DPX_REQUIRE(n_iters >= 0 && it0 >= 0 && it0 + n_iters <= total_iters, "dpx_admm_run_chains: bad iteration range");
+  DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS, "dpx_admm_run_chains: nterms");
+  for (int c = 0; c < nchains; ++c) {
+    const dpx_chain& ch = chains[c];
+    DPX_REQUIRE(ch.spec_a && ch.spec_b && ch.terms && ch.rho_tab && ch.lam_tabs && ch.B >= 1, "dpx_admm_run_chains: chain %d: null pointer", c);
+    DPX_REQUIRE(!emit_last || ch.x_out, "dpx_admm_run_chains: emit_last needs x_out (chain %d)", c);
+  }
+  // events: host-side resources, one set per (host thread, device)
+  struct Evs {
+    hipEvent_t ev[DPX_MAX_CHAINS];
+    bool ok = false;
+  };
+  constexpr int MAXDEV = 16;
+  static thread_local Evs evs[MAXDEV];
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= MAXDEV) {
+    set_error("dpx_admm_run_chains: hipGetDevice failed / device id %d out of range", devid);
+    return DPX_ERR_LAUNCH;
+  }
+  Evs& E = evs[devid];
+  if (!E.ok) {
+    for (int i = 0; i < DPX_MAX_CHAINS; ++i)
+      if (hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming) != hipSuccess) {
+        for (int k = 0; k < i; ++k) hipEventDestroy(E.ev[k]);
+        set_error("dpx_admm_run_chains: hipEventCreate failed");
+        return DPX_ERR_LAUNCH;
+      }
+    E.ok = true;
+  }
+  dpx_term cur[DPX_MAX_CHAINS][DPX_MAX_TERMS];
+  for (int c = 0; c < nchains; ++c)
+    for (int i = 0; i < nterms; ++i) cur[c][i] = chains[c].terms[i];
+  int parity = 0;
+  for (int k = 0; k < n_iters; ++k) {
+    const int it = it0 + k;
+    const bool last_of_solve = (it == total_iters - 1);
+    const bool emit = emit_last && (k == n_iters - 1);
+    for (int c = 0; c < nchains; ++c) {
+      const dpx_chain& ch = chains[c];
+      hipStream_t s = (hipStream_t)ch.stream;
+      if (nchains > 1 && (k > 0 || c > 0)) {
+        if (hipStreamWaitEvent(s, E.ev[(c + nchains - 1) % nchains], 0) != hipSuccess) {
+          set_error("dpx_admm_run_chains: hipStreamWaitEvent failed");
+          return DPX_ERR_LAUNCH;
+        }
+      }
+      int rc = dpx_admm_iter_cols(ch.spec_a, ch.spec_b, ch.spec_add, dd, ch.rho_tab + (size_t)it * ch.B, eps, ch.B, C, H, W, table, ch.stream);
+      if (rc) return rc;
+      if (nchains > 1 && hipEventRecord(E.ev[c], s) != hipSuccess) {
+        set_error("dpx_admm_run_chains: hipEventRecord failed");
+        return DPX_ERR_LAUNCH;
+      }
+      for (int i = 0; i < nterms; ++i) {
+        cur[c][i].lam = ch.lam_tabs[i] ? ch.lam_tabs[i] + (size_t)it * ch.B : nullptr;
+        if (k > 0) cur[c][i].reserved &= ~DPX_TERM_U_ZERO;
+        cur[c][i].u = parity ? ch.terms[i].u_out : ch.terms[i].u;
+        cur[c][i].u_out = parity ? ch.terms[i].u : ch.terms[i].u_out;
+      }
+      rc = dpx_admm_iter_rows(ch.spec_b, last_of_solve ? nullptr : ch.spec_a, cur[c], nterms,
+                              last_of_solve ? nullptr : ch.rho_tab + (size_t)(it + 1) * ch.B, emit ? ch.x_out : nullptr,
+                              emit ? (emit_last == 2 && last_of_solve ? 2 : 1) : 0, ch.B, C, H, W, table, ch.stream);
+      if (rc) return rc;
+    }
+    parity ^= 1;
+  }
+  return parity;
+}

@@ -40,6 +40,12 @@ class Term(ctypes.Structure):
                 ("lam", c_void_p), ("v", c_void_p), ("u", c_void_p), ("u_out", c_void_p)]
 
 
+class Chain(ctypes.Structure):
+    """``dpx_chain`` of include/dpx.h."""
+    _fields_ = [("spec_a", c_void_p), ("spec_b", c_void_p), ("spec_add", c_void_p), ("terms", POINTER(Term)), ("rho_tab", c_void_p),
+                ("lam_tabs", POINTER(c_void_p)), ("x_out", c_void_p), ("B", c_int32), ("pad_", c_int32), ("stream", c_void_p)]
+
+
 class BwdTerm(ctypes.Structure):
     """``dpx_bwd_term`` of include/dpx.h."""
     _fields_ = [("linop", c_int32), ("prox", c_int32), ("alpha", c_float), ("reserved", c_int32),
@@ -133,6 +139,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p]),
     "dpx_admm_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_void_p, POINTER(c_void_p), c_float,
                              c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_admm_run_chains": (c_int, [POINTER(Chain), c_int, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_unrolled_hist_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "dpx_admm_unrolled_forward": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_float), c_int,
                                           c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p,

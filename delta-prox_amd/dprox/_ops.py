@@ -619,6 +619,31 @@ def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, 
     return rc
 
 
+def admm_run_chains(chains, dd, nterms, eps, it0, n_iters, total, emit_last, shape, device):
+    """dpx_admm_run for several sub-batch chains at once.  chains: dicts with spec_a, spec_b, spec_add (tensor / None), terms (ctypes
+    array), rho_tab, lam_tabs (tensors), x_out, B, stream (raw handle).  Returns the dual-buffer parity."""
+    _, C, H, W = shape
+    arr = (be.Chain * len(chains))()
+    keep = []
+    for i, ch in enumerate(chains):
+        lt = (c_void_p * nterms)(*[None if t is None else t.data_ptr() for t in ch["lam_tabs"]])
+        keep.append(lt)
+        arr[i].spec_a, arr[i].spec_b = ch["spec_a"].data_ptr(), ch["spec_b"].data_ptr()
+        arr[i].spec_add = None if ch["spec_add"] is None else ch["spec_add"].data_ptr()
+        arr[i].terms = ctypes.cast(ch["terms"], ctypes.POINTER(Term))
+        arr[i].rho_tab = ch["rho_tab"].data_ptr()
+        arr[i].lam_tabs = ctypes.cast(lt, ctypes.POINTER(c_void_p))
+        arr[i].x_out = ch["x_out"].data_ptr()
+        arr[i].B = int(ch["B"])
+        arr[i].stream = ch["stream"]
+    L = be.lib()
+    rc = L.query("dpx_admm_run_chains", arr, len(chains), ptr(dd), nterms, c_float(eps), it0, n_iters, total, int(emit_last), C, H, W,
+                 ptr(fft_table(H, W, device)))
+    if rc < 0:
+        raise be.DpxError(f"dpx_admm_run_chains failed ({rc}): {L.cdll.dpx_last_error().decode()}")
+    return rc
+
+
 def mul(x, w):
     """x * w with w one image ([1,C,H,W] or [C,H,W]) or a batch of them"""
     require(x, what="mul input")

@@ -704,8 +704,7 @@ class FusedADMM:
         (admm.py:49-59; every table is per channel), so the sub-batches never meet: without a common kernel boundary one chain's column
         pass (load - transform - store in step across its workgroups) runs beside another chain's streaming row pass and the memory
         system stays busy through both kernels' ramps and tails -- 8x3x1024^2: 0.181 -> 0.172 ms per iteration, bit-identical results.
-        Every chain has its own spectrum buffers and data spectrum; state, tables and schedules are sub-batch views.  The launches of
-        the chains are issued in turns of CHUNK iterations so that all chains start within a few dozen microseconds."""
+        Every chain has its own spectrum buffers and data spectrum; state, tables and schedules are sub-batch views."""
         s = self.solver
         B, C, H, W = x0.shape
         t0, c0, t1, c1 = diag
@@ -753,18 +752,16 @@ class FusedADMM:
                     for i in range(n):
                         wk["terms"][i].lam = wk["lam"][i][0].data_ptr()
                     ops.admm_seed_rows(wk["SA"], wk["rho"][0], wk["terms"], n, wk["shape"], dev, fresh_x=x0[wk["b0"]:wk["b1"]] if fresh else None)
-            par, it0 = 0, 0
-            while it0 < T:
-                cnt = min(4 if it0 == 0 else 10, T - it0)            # (even turns: the duals are back in their first buffer; a short first one: every chain has work at once)
-                last = it0 + cnt == T
-                for wk, st, fk in zip(work, streams, FK):
-                    with on(st):
-                        par = ops.admm_run(wk["SA"], wk["SB"], fk, dd, wk["terms"], n, wk["rho"], wk["lam"], eps, it0, cnt, T,
-                                           x[wk["b0"]:wk["b1"]], (2 if x_only else 1) if last else 0, wk["shape"], dev)
-                    if it0 == 0 and fresh:
-                        for i in range(n):
-                            wk["terms"][i].reserved &= ~be.TERM_U_ZERO
-                it0 += cnt
+            # one C call issues every iteration of every chain, chain by chain within an iteration (dpx_admm_run_chains: the column
+            # passes are ordered by events so that the chains advance together)
+            raw = []
+            for st in streams:
+                with on(st):
+                    h = be.stream()
+                    raw.append(None if h is None else h.value)
+            par = ops.admm_run_chains([dict(spec_a=wk["SA"], spec_b=wk["SB"], spec_add=fk, terms=wk["terms"], rho_tab=wk["rho"], lam_tabs=wk["lam"],
+                                            x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=h) for wk, fk, h in zip(work, FK, raw)],
+                                      dd, n, eps, 0, T, T, 2 if x_only else 1, x0.shape, dev)
             for st in streams[1:]:
                 if main is not None:
                     main.wait_stream(st)

@@ -404,6 +404,25 @@ int dpx_admm_iter_share(int chains);
 int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, const void* dd, const dpx_term* terms, int nterms,
                  const float* rho_tab, const float* const* lam_tabs, float eps, int it0, int n_iters, int total_iters,
                  float* x_out, int emit_last, int B, int C, int H, int W, const void* table, dpx_stream_t stream);
+/* dpx_admm_run for `nchains` sub-batches of one solve at once, each on its own stream with its own spectrum buffers, data spectrum,
+ * terms (state views) and [total_iters][B_chain] schedule tables; dd, the problem's tables and the iteration range are shared.
+ * The chains' launches are interleaved and their column passes ordered by events, so that the chains advance together.  Returns the
+ * dual-buffer parity (equal for all chains), < 0 on error.  (algo/admm.py:49-59 acts per image: splitting the batch changes nothing.) */
+#define DPX_MAX_CHAINS 8
+typedef struct dpx_chain {
+  void* spec_a;              /* holds the chain's seeded spectrum on entry */
+  void* spec_b;
+  const void* spec_add;      /* the chain's data spectrum (nullable) */
+  const dpx_term* terms;     /* nterms terms over the chain's images */
+  const float* rho_tab;      /* [total_iters][B] */
+  const float* const* lam_tabs; /* nterms pointers to [total_iters][B] */
+  float* x_out;              /* the chain's images of x */
+  int32_t B;                 /* images of this chain */
+  int32_t pad_;
+  dpx_stream_t stream;
+} dpx_chain;
+int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const void* dd, int nterms, float eps, int it0, int n_iters,
+                        int total_iters, int emit_last, int C, int H, int W, const void* table);
 
 /* ------------------------------------------------------------------------------------------ */
 /* FFDNet denoiser (deep_prior z-update)                                                       */

@@ -285,6 +285,7 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return 0; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = 0; return 0; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, int) { *p = malloc(n); return *p ? 0 : 1; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }

@@ -1,19 +1,29 @@
 #!/usr/bin/env python
-"""Timeline of the LAST `bench.py --steps K` timed region from a rocprofv3 kernel trace, chains included: when each of the region's first
-and last kernels starts / ends relative to the region's first kernel, and the busy time per stream.  usage: region_timeline.py <kernel_trace.csv> <K>"""
+"""Timeline of the `bench.py --steps K` timed regions from a rocprofv3 kernel trace, chains included: every run of the two-kernel
+iteration (seed launches, then column / row launches) with its kernel count and span; for the LAST run with K iterations, when its first
+and last kernels start / end relative to its first kernel.  usage: region_timeline.py <kernel_trace.csv> <K>"""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 K = int(sys.argv[2])
-dpx = [r for r in rows if "dpx::" in r["Kernel_Name"]]
-# the last region: walk back from the last k_iter_rows launch to the seed launches in front of it
-seeds = [i for i, r in enumerate(dpx) if "k_seed_rows" in r["Kernel_Name"]]
-last_rows = max(i for i, r in enumerate(dpx) if "k_iter_rows" in r["Kernel_Name"])
-first = max(i for i in seeds if i < last_rows)
-while first - 1 in seeds:
-    first -= 1
-sel = dpx[first:last_rows + 1]
-t0 = int(sel[0]["Start_Timestamp"])
-print(f"{len(sel)} kernels, span {(int(sel[-1]['End_Timestamp']) - t0) / 1e3:.1f} us = {(int(sel[-1]['End_Timestamp']) - t0) / 1e3 / K:.2f} us per step")
-key = "Queue_Id" if "Queue_Id" in sel[0] else ("Stream_Id" if "Stream_Id" in sel[0] else None)
-for r in sel[:10] + sel[-6:]:
-    print(f"  {(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:9.1f} us  q={r.get(key, '?') if key else '?'}  {r['Kernel_Name'].split('(')[0][-40:]}")
+it = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_seed_rows", "k_cols_p2<1024, 64, 8, 2", "k_iter_rows"))]
+runs, cur = [], []
+for r in it:
+    if "k_seed_rows" in r["Kernel_Name"] and cur and "k_seed_rows" not in cur[-1]["Kernel_Name"]:
+        runs.append(cur)
+        cur = []
+    cur.append(r)
+if cur:
+    runs.append(cur)
+pick = None
+for run in runs:
+    ns = sum("k_seed_rows" in r["Kernel_Name"] for r in run)
+    n_it = (len(run) - ns) // (2 * max(ns, 1))
+    span = (max(int(r["End_Timestamp"]) for r in run) - int(run[0]["Start_Timestamp"])) / 1e3
+    print(f"run: {ns} chain(s), {n_it:3d} iterations, span {span:9.1f} us = {span / max(n_it, 1):7.2f} us per iteration")
+    if n_it == K:
+        pick = run
+if pick:
+    t0 = int(pick[0]["Start_Timestamp"])
+    key = "Queue_Id" if "Queue_Id" in pick[0] else None
+    for r in pick[:12] + pick[-8:]:
+        print(f"  {(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:9.1f} us  q={r.get(key, '?') if key else '?'}  {r['Kernel_Name'].split('(')[0][-44:]}")
