@@ -125,7 +125,8 @@ int masked_normal_apply(const float* p, float* Ap, float2* z, const float* mask2
 int masked_normal_apply_fused(float* p, const float* r, float* Ap, float2* z, const float* mask, int mask_images, const float* rho, float c,
                               float* state, float* dotws, unsigned* counter, int B, int H, int W, const void* table, hipStream_t s);
 size_t masked_normal_fused_ws_floats(int B, int H, int W);
-int gram_test_fused(const float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, hipStream_t s);   // dpx_elementwise.hip
+int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, float* x, const float* p,
+                    const float* Ap, int* host_flags, hipStream_t s);   // dpx_elementwise.hip
 }
 
 extern "C" size_t dpx_cg_state_bytes(int B) { return B > 0 ? (size_t)(5 * B + 4) * sizeof(float) : 0; }
@@ -220,6 +221,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   // returns only after it has waited for its own last event, so a thread has at most one solve in flight)
   struct Ring {
     int* pin = nullptr;
+    int* pin_dev = nullptr;     // the same memory as the device addresses it
     hipEvent_t ev[4];
   };
   static thread_local Ring rings[DPX_CG_MAX_DEVICES];
@@ -242,9 +244,18 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
         set_error("dpx_cg_masked_fft: hipEventCreate failed");
         return DPX_ERR_LAUNCH;
       }
+    void* dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, pnew, 0) != hipSuccess || !dptr) {
+      for (int k = 0; k < 4; ++k) hipEventDestroy(R.ev[k]);
+      hipHostFree(pnew);
+      set_error("dpx_cg_masked_fft: hipHostGetDevicePointer failed");
+      return DPX_ERR_LAUNCH;
+    }
     R.pin = pnew;
+    R.pin_dev = (int*)dptr;
   }
   int* pin = R.pin;
+  int* pin_dev = R.pin_dev;
   hipEvent_t* ev = R.ev;
   for (int i = 0; i < 16; ++i) pin[i] = 0;             // nothing left over from an earlier solve can read as "done"
 #define CG_HIP(call)                                                        \
@@ -269,6 +280,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   //      launch instead of seven in front of the loop.  The partial sums of a launch are finished by its LAST workgroup to arrive
   //      (dpx_last_block: no workgroup waits for another); same state machine, same exit iteration.
   static const bool unfused = getenv("DPX_CG_UNFUSED") != nullptr;      // (A/B and tests: the step-by-step sequence below)
+  static const bool split_update = getenv("DPX_CG_SPLIT_UPDATE") != nullptr;      // (A/B: the 5-launch form with its own update kernel and a flag transfer)
   if (B <= 8 && !unfused) {
     float* fdot = (float*)((char*)dotws + dpx_bdot_ws_bytes(B, n));
     unsigned* counters = (unsigned*)(fdot + dpx::masked_normal_fused_ws_floats(B, H, W));
@@ -282,16 +294,29 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
           break;
         }
       }
-      CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, s));
+      // 4 launches: [x / r update of the previous iteration + Gram pass + stop rule, flags to the pinned slot] + the operator's three
+      if (split_update) {
+        CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, nullptr, nullptr, nullptr, nullptr, s));
+      } else {
+        CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, it > 0 ? x : nullptr, p, Ap, pin_dev + (it & 3) * 4, s));
+      }
       CG_TRY(dpx::masked_normal_apply_fused(p, r, Ap, z0, mask, mask_images, rho, n_identity, state, fdot, counters + 1, B, H, W, table, s));
-      CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));
-      CG_HIP(hipMemcpyAsync(pin + (it & 3) * 4, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+      if (split_update) {
+        CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));
+        CG_HIP(hipMemcpyAsync(pin + (it & 3) * 4, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+      }
       CG_HIP(hipEventRecord(ev[it & 3], s));
       last = it;
     }
+    if (!split_update && last >= 0) CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));     // the last iteration's update (a no-op once converged)
     if (!done && last >= 0) {
+      // the iterations the loop did not look at yet, oldest first (a launch behind the converged one leaves its slot untouched)
       CG_HIP(hipEventSynchronize(ev[last & 3]));
-      if (pin[(last & 3) * 4]) done_it = pin[(last & 3) * 4 + 1];
+      for (int j = (last - LAG + 1 > 0 ? last - LAG + 1 : 0); j <= last; ++j)
+        if (pin[(j & 3) * 4]) {
+          done_it = pin[(j & 3) * 4 + 1];
+          break;
+        }
     }
     const int st = launch_status("dpx_cg_masked_fft");
     return st != DPX_OK ? st : done_it;

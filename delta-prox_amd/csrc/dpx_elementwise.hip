@@ -264,9 +264,12 @@ __global__ void k_dot_finish(const float* __restrict__ partial, float* __restric
 // Summation order is fixed (per-wave partials are added in wave order, slabs by the finishing kernel).
 constexpr int GR_CH = 128, GR_P = GR_CH + 1;
 // sx: 32 * GR_P floats, red: 3 * 64 * 16 floats of shared memory
-template <bool AGENT_STORE>
+// UPDATE: the slab load also applies the pending CG update of the previous iteration, x += alpha_b p, r -= alpha_b A p (upd_*; every
+// element of r belongs to exactly one slab of one workgroup), and the Gram products are those of the updated residual.
+template <bool AGENT_STORE, bool UPDATE = false>
 __device__ __forceinline__ void gram_tile_body(const float* __restrict__ r, float* __restrict__ partial, int B, long npb, int nblk, float* sx,
-                                               float* red) {
+                                               float* red, float* upd_r = nullptr, float* upd_x = nullptr, const float* upd_p = nullptr,
+                                               const float* upd_Ap = nullptr, const float* alpha = nullptr) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ti = (lane >> 3) * 4, tj = (lane & 7) * 4;
   float acc[4][4];
 #pragma unroll
@@ -277,7 +280,18 @@ __device__ __forceinline__ void gram_tile_body(const float* __restrict__ r, floa
     __syncthreads();
     for (int e = tid; e < 32 * GR_CH; e += 256) {
       const int b = e / GR_CH, k = e % GR_CH;
-      sx[b * GR_P + k] = (b < B && c0 + k < npb) ? r[(long)b * npb + c0 + k] : 0.f;
+      float rv = 0.f;
+      if (b < B && c0 + k < npb) {
+        const long at = (long)b * npb + c0 + k;
+        rv = r[at];
+        if constexpr (UPDATE) {
+          const float al = alpha[b];
+          upd_x[at] = fmaf(al, upd_p[at], upd_x[at]);
+          rv = fmaf(-al, upd_Ap[at], rv);
+          upd_r[at] = rv;
+        }
+      }
+      sx[b * GR_P + k] = rv;
     }
     __syncthreads();
 #pragma unroll 4
@@ -321,16 +335,28 @@ __global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, 
 // The Gram pass of a device-controlled CG iteration with its two followers folded in: the LAST workgroup to arrive adds up the
 // slabs' partial products (one wave per entry, fixed order) and runs the stop rule / beta update on the finished matrix
 // (cg_test_block) -- k_gram_tile -> k_dot_finish -> k_cg_test in one launch.  B <= 8.
-__global__ void __launch_bounds__(256) k_gram_tile_test(const float* __restrict__ r, float* __restrict__ partial, float* __restrict__ G, CgState S,
-                                                        long npb, int nblk, unsigned* __restrict__ counter, float init_rtol) {
+// UPDATE: + the x / r update of the previous iteration in the slab load (k_cg_update folded in: alpha_b = gamma_b / <p_b, A p_b> from the
+// state the previous launches left).  host_flags (nullable): a host-mapped copy of (done, n_done) written by the finishing workgroup --
+// the host polls it behind an event instead of copying the flags back with a transfer per iteration.
+template <bool UPDATE>
+__global__ void __launch_bounds__(256) k_gram_tile_test(float* __restrict__ r, float* __restrict__ partial, float* __restrict__ G, CgState S,
+                                                        long npb, int nblk, unsigned* __restrict__ counter, float init_rtol, float* __restrict__ x,
+                                                        const float* __restrict__ p, const float* __restrict__ Ap, int* __restrict__ host_flags) {
   __shared__ double rawd[64 * 65];                        // the slabs' staging (28.8 KB), then the test's matrix (33.3 KB)
   char* raw = (char*)rawd;
   __shared__ int shf[3];
+  __shared__ float alpha_s[32];
   if (S.flags()[0]) return;                               // (uniform: the solve has converged, this launch ran ahead)
   const int B = S.B;
   float* sx = (float*)raw;
   float* red = sx + 32 * GR_P;
-  gram_tile_body<true>(r, partial, B, npb, nblk, sx, red);
+  if constexpr (UPDATE) {
+    if (threadIdx.x < B) alpha_s[threadIdx.x] = S.gamma()[threadIdx.x] / S.pAp()[threadIdx.x];
+    __syncthreads();
+    gram_tile_body<true, true>(r, partial, B, npb, nblk, sx, red, r, x, p, Ap, alpha_s);
+  } else {
+    gram_tile_body<true>(r, partial, B, npb, nblk, sx, red);
+  }
   if (!dpx_last_block(counter, (unsigned)nblk, &shf[2])) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int e = wave; e < B * B; e += 4) {
@@ -349,6 +375,15 @@ __global__ void __launch_bounds__(256) k_gram_tile_test(const float* __restrict_
   }
   __syncthreads();
   cg_test_block(S, G, (double*)raw, shf, init_rtol);
+  if (host_flags) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      host_flags[1] = S.flags()[1];
+      __threadfence_system();
+      host_flags[0] = S.flags()[0];
+      __threadfence_system();
+    }
+  }
 }
 
 static int gram_blocks(long npb) {
@@ -744,12 +779,18 @@ extern "C" int dpx_bdot(const float* x, const float* y, float* out, int B, long 
 
 namespace dpx {
 // Gram pass + finish + stop rule in one launch (dpx_cg_masked_fft's fused iteration, B <= 8); ws: B * B * gram_blocks floats
-int gram_test_fused(const float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, hipStream_t s) {
+// x / p / Ap non-null: the pending update x += alpha p, r -= alpha A p of the previous iteration is applied on the way (r is written)
+int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, float* x, const float* p,
+                    const float* Ap, int* host_flags, hipStream_t s) {
   static const int env_blk = getenv("DPX_CGF_GRAM_BLOCKS") ? atoi(getenv("DPX_CGF_GRAM_BLOCKS")) : 0;      // tuning
   int nblk = gram_blocks(n_per_batch);
   if (env_blk > 0 && env_blk < nblk) nblk = env_blk;
-  DPX_LAUNCH("k_gram_tile_test", k_gram_tile_test, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch, nblk,
-             counter, init_rtol);
+  if (x)
+    DPX_LAUNCH("k_gram_tile_test_upd", k_gram_tile_test<true>, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch,
+               nblk, counter, init_rtol, x, p, Ap, host_flags);
+  else
+    DPX_LAUNCH("k_gram_tile_test", k_gram_tile_test<false>, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch,
+               nblk, counter, init_rtol, x, p, Ap, host_flags);
   return launch_status("gram_test_fused");
 }
 }  // namespace dpx

@@ -105,6 +105,7 @@ inline unsigned long long ballot(int pred) {
 static inline void __syncthreads() { ::emul::sync_block(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() {}
 
 template <class T> static inline T __shfl(T v, int src, int width = 64) {
   int l = ::emul::lane();
@@ -291,3 +292,4 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
