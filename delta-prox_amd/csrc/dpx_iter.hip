@@ -1278,11 +1278,12 @@ extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, co
 }
 
 // The same loop for `nchains` sub-batches of one solve, each on its own stream (the images of a batch never exchange data: one
-// chain's column pass can run beside another chain's row pass).  Launches are issued chain by chain within an iteration, and the column
-// passes are chained by events -- chain c's column pass of iteration k starts after chain c-1's of iteration k has finished, chain 0's of
-// iteration k+1 after the last chain's of iteration k -- so that no chain runs ahead of the others (left to the queues' arbitration one
-// chain of two finished ~2.5 iterations early and the other ran its last iterations alone) and a column pass always has another
-// chain's row pass beside it.  Returns the dual-buffer parity (the same for every chain), < 0 on error.
+// chain's column pass can run beside another chain's row pass).  Launches are issued chain by chain within an iteration, so that every
+// chain has work queued from the first microseconds on; the chains then run freely.  (DPX_CHAIN_LOCKSTEP=1, measured and kept as a
+// switch: the column passes ordered by events -- chain c's of iteration k behind chain c-1's, chain 0's of iteration k+1 behind the last
+// chain's of iteration k.  It removes the drift between the chains -- left to the queues' arbitration one chain of two finishes ~12 %
+// earlier -- but also forbids column pass beside column pass and row pass beside row pass: 0.174 -> 0.202 ms per iteration at 8x3x1024^2.)
+// Returns the dual-buffer parity (the same for every chain), < 0 on error.
 extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const void* dd, int nterms, float eps, int it0, int n_iters,
                                    int total_iters, int emit_last, int C, int H, int W, const void* table) {
   DPX_REQUIRE(chains && nchains >= 1 && nchains <= DPX_MAX_CHAINS && dd && table, "dpx_admm_run_chains: bad arguments");
@@ -1315,6 +1316,8 @@ extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const v
       }
     E.ok = true;
   }
+  static const bool lockstep = getenv("DPX_CHAIN_LOCKSTEP") != nullptr;
+  const bool ordered = lockstep && nchains > 1;
   dpx_term cur[DPX_MAX_CHAINS][DPX_MAX_TERMS];
   for (int c = 0; c < nchains; ++c)
     for (int i = 0; i < nterms; ++i) cur[c][i] = chains[c].terms[i];
@@ -1326,7 +1329,7 @@ extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const v
     for (int c = 0; c < nchains; ++c) {
       const dpx_chain& ch = chains[c];
       hipStream_t s = (hipStream_t)ch.stream;
-      if (nchains > 1 && (k > 0 || c > 0)) {
+      if (ordered && (k > 0 || c > 0)) {
         if (hipStreamWaitEvent(s, E.ev[(c + nchains - 1) % nchains], 0) != hipSuccess) {
           set_error("dpx_admm_run_chains: hipStreamWaitEvent failed");
           return DPX_ERR_LAUNCH;
@@ -1334,7 +1337,7 @@ extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const v
       }
       int rc = dpx_admm_iter_cols(ch.spec_a, ch.spec_b, ch.spec_add, dd, ch.rho_tab + (size_t)it * ch.B, eps, ch.B, C, H, W, table, ch.stream);
       if (rc) return rc;
-      if (nchains > 1 && hipEventRecord(E.ev[c], s) != hipSuccess) {
+      if (ordered && hipEventRecord(E.ev[c], s) != hipSuccess) {
         set_error("dpx_admm_run_chains: hipEventRecord failed");
         return DPX_ERR_LAUNCH;
       }

@@ -722,9 +722,11 @@ class FusedADMM:
         else:
             main = torch.cuda.current_stream(dev)
             side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
-            while len(side) < chains - 1:                         # (created once per process and device: a stream costs milliseconds)
-                side.append(torch.cuda.Stream(device=dev))
-            streams = [main] + list(side[:chains - 1])
+            allside = bool(os.environ.get("DPX_CHAIN_ALLSIDE"))     # (tuning: no chain on the caller's stream)
+            need = chains if allside else chains - 1
+            while len(side) < need:                               # (created once per process and device: a stream costs milliseconds)
+                side.append(torch.cuda.Stream(device=dev, priority=int(os.environ.get("DPX_CHAIN_PRIO", "0"))))
+            streams = list(side[:chains]) if allside else [main] + list(side[:chains - 1])
         on = (lambda st: contextlib.nullcontext()) if main is None else torch.cuda.stream
         psi = list(s.psi_fns)
         work = []
@@ -744,8 +746,8 @@ class FusedADMM:
         L = be.lib()
         L.call("dpx_admm_iter_share", chains)
         try:
-            for st in streams[1:]:
-                if main is not None:
+            for st in streams:
+                if main is not None and st is not main:
                     st.wait_stream(main)
             for wk, st in zip(work, streams):
                 with on(st):
@@ -762,8 +764,8 @@ class FusedADMM:
             par = ops.admm_run_chains([dict(spec_a=wk["SA"], spec_b=wk["SB"], spec_add=fk, terms=wk["terms"], rho_tab=wk["rho"], lam_tabs=wk["lam"],
                                             x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=h) for wk, fk, h in zip(work, FK, raw)],
                                       dd, n, eps, 0, T, T, 2 if x_only else 1, x0.shape, dev)
-            for st in streams[1:]:
-                if main is not None:
+            for st in streams:
+                if main is not None and st is not main:
                     main.wait_stream(st)
         finally:
             L.call("dpx_admm_iter_share", 1)
