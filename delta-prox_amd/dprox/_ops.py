@@ -185,12 +185,15 @@ def pgd_supported(H, W, kind):
     return bool(be.lib().query("dpx_pgd_supported", int(H), int(W), int(kind)))
 
 
-def pgd_run(x, ktb, gram_otf, kind, alpha, rho_tab, lam_tab, T):
-    """T fused proximal-gradient iterations on x, in place (two kernels per iteration; rho_tab / lam_tab: [T, B] device tables)"""
+def pgd_run(x, ktb, gram_otf, kind, alpha, rho_tab, lam_tab, T, ws=None):
+    """T fused proximal-gradient iterations on x, in place (two kernels per iteration; rho_tab / lam_tab: [T, B] device tables).
+    ws: a spectrum workspace of the caller's (concurrent calls on different streams must not share the cached one)"""
     require(x, what="pgd iterate")
     B, C, H, W = _shape4(x)
+    if ws is None:
+        ws = spectrum_ws(B * C, H, W, x.device)
     be.lib().call("dpx_pgd_run", ptr(x), ptr(ktb), ptr(gram_otf), int(kind), c_float(alpha), ptr(rho_tab), ptr(lam_tab), int(T),
-                  B, C, H, W, ptr(fft_table(H, W, x.device)), ptr(spectrum_ws(B * C, H, W, x.device)), be.stream())
+                  B, C, H, W, ptr(fft_table(H, W, x.device)), ptr(ws), be.stream())
     return x
 
 

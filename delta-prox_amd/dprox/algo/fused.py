@@ -317,6 +317,15 @@ def _chain_table(tab, b0, b1):
     return out
 
 
+def chain_streams(dev, chains):
+    """(the caller's current stream, chains - 1 side streams) of a device; side streams are created once per process and device"""
+    main = torch.cuda.current_stream(dev)
+    side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
+    while len(side) < chains - 1:
+        side.append(torch.cuda.Stream(device=dev))
+    return main, list(side[:chains - 1])
+
+
 def chain_bounds(B, chains, c):
     """images [b0, b1) of sub-batch chain c"""
     return (c * B) // chains, ((c + 1) * B) // chains
@@ -720,13 +729,8 @@ class FusedADMM:
         if be.host_mode():                                       # (the CPU emulator runs the chains one after the other)
             main, streams = None, [None] * chains
         else:
-            main = torch.cuda.current_stream(dev)
-            side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
-            allside = bool(os.environ.get("DPX_CHAIN_ALLSIDE"))     # (tuning: no chain on the caller's stream)
-            need = chains if allside else chains - 1
-            while len(side) < need:                               # (created once per process and device: a stream costs milliseconds)
-                side.append(torch.cuda.Stream(device=dev, priority=int(os.environ.get("DPX_CHAIN_PRIO", "0"))))
-            streams = list(side[:chains]) if allside else [main] + list(side[:chains - 1])
+            main, side = chain_streams(dev, chains)               # (stream priorities / no chain on the caller's stream: measured, no difference)
+            streams = [main] + side
         on = (lambda st: contextlib.nullcontext()) if main is None else torch.cuda.stream
         psi = list(s.psi_fns)
         work = []

@@ -5,6 +5,7 @@
 ``grad f`` of a ``sum_squares`` term is two passes of hand-written kernels (K x - b, then K^T) and the forward step is one
 fused AXPY with a per-image step size (``dpx_lincomb``); the backward step is the proxable term's own HIP prox.
 """
+import torch
 from typing import List, Sequence
 
 from .. import _ops as ops
@@ -60,7 +61,31 @@ class ProximalGradientDescent(Algorithm):
         rho_tab = schedule_table(rhos, max_iter, B, x.device)
         lam_tab = schedule_table(lams[self.prox_fn], max_iter, B, x.device)
         self._notify_all_op_current_step(max_iter - 1)
-        ops.pgd_run(x, ktb, gram, kind, float(self.prox_fn.alpha), rho_tab, lam_tab, max_iter)
+        from . import fused
+        from .. import _backend as be
+        C, H, W = (int(d) for d in x.shape[1:])
+        chains = fused.sub_batch_chains(B, C, H, W) if (x.is_cuda and (ktb is None or ktb.shape == x.shape)) else 1
+        if chains <= 1:
+            ops.pgd_run(x, ktb, gram, kind, float(self.prox_fn.alpha), rho_tab, lam_tab, max_iter)
+        else:
+            # independent sub-batch chains on separate streams (fused.FusedADMM._run_chains: one chain's column pass beside the other's row pass)
+            main, side = fused.chain_streams(x.device, chains)
+            L = be.lib()
+            L.call("dpx_admm_iter_share", chains)
+            try:
+                for st in side:
+                    st.wait_stream(main)
+                for c, st in enumerate([main] + side):
+                    b0, b1 = fused.chain_bounds(B, chains, c)
+                    ws = ops._bytes(L.query("dpx_spectrum_bytes", (b1 - b0) * C, H, W), x.device)
+                    with torch.cuda.stream(st):
+                        ops.pgd_run(x[b0:b1], None if ktb is None else ktb[b0:b1], gram, kind, float(self.prox_fn.alpha),
+                                    fused._chain_table(rho_tab, b0, b1), fused._chain_table(lam_tab, b0, b1), max_iter, ws=ws)
+                    ws.record_stream(st)
+                for st in side:
+                    main.wait_stream(st)
+            finally:
+                L.call("dpx_admm_iter_share", 1)
         self.Kall.update_vars([x])
         return [x]
 

@@ -1417,6 +1417,17 @@ def case_sub_batch_chains(device, shapes=((4, 1, 256, 256),), iters=13, methods=
                         assert len(got) == len(ref)
                         for a, c in zip(got, ref):
                             assert torch.equal(a, c), ("sub-batch chains differ from the one-chain run", (B, C, H, W), method, nch, float((a - c).abs().max()))
+            if str(device) != "cpu":                            # proximal gradient descent: the same split of dpx_pgd_run (streams: GPU only)
+                def run_pgd(nch):
+                    os.environ["DPX_CHAINS"] = str(nch)
+                    x = dp.Variable()
+                    s = dp.compile(dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(x) * 0.5, method="pgd", device=device)
+                    return s.solve(x0=b, rhos=rhos * 0.5, lams=0.01, max_iter=iters)
+                ref = run_pgd(1)
+                for nch in nchs:
+                    if nch <= B:
+                        got = run_pgd(nch)
+                        assert torch.equal(got, ref), ("pgd sub-batch chains differ", (B, C, H, W), nch, float((got - ref).abs().max()))
     finally:
         if old is None:
             os.environ.pop("DPX_CHAINS", None)
