@@ -73,17 +73,19 @@ class ProximalGradientDescent(Algorithm):
             L = be.lib()
             L.call("dpx_admm_iter_share", chains)
             try:
+                bounds = [fused.chain_bounds(B, chains, c) for c in range(chains)]
+                # every chain's workspace lives until the caller's stream has waited for all chains (a block handed back earlier could be
+                # given to the next chain while the previous one still runs)
+                wss = [ops._bytes(L.query("dpx_spectrum_bytes", (b1 - b0) * C, H, W), x.device) for b0, b1 in bounds]
+                tabs = [(fused._chain_table(rho_tab, b0, b1), fused._chain_table(lam_tab, b0, b1)) for b0, b1 in bounds]
                 for st in side:
                     st.wait_stream(main)
-                for c, st in enumerate([main] + side):
-                    b0, b1 = fused.chain_bounds(B, chains, c)
-                    ws = ops._bytes(L.query("dpx_spectrum_bytes", (b1 - b0) * C, H, W), x.device)
+                for (b0, b1), ws, (rt, lt), st in zip(bounds, wss, tabs, [main] + side):
                     with torch.cuda.stream(st):
-                        ops.pgd_run(x[b0:b1], None if ktb is None else ktb[b0:b1], gram, kind, float(self.prox_fn.alpha),
-                                    fused._chain_table(rho_tab, b0, b1), fused._chain_table(lam_tab, b0, b1), max_iter, ws=ws)
-                    ws.record_stream(st)
+                        ops.pgd_run(x[b0:b1], None if ktb is None else ktb[b0:b1], gram, kind, float(self.prox_fn.alpha), rt, lt, max_iter, ws=ws)
                 for st in side:
                     main.wait_stream(st)
+                del wss
             finally:
                 L.call("dpx_admm_iter_share", 1)
         self.Kall.update_vars([x])
