@@ -322,7 +322,7 @@ def chain_streams(dev, chains):
     main = torch.cuda.current_stream(dev)
     side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
     while len(side) < chains - 1:
-        side.append(torch.cuda.Stream(device=dev))
+        side.append(torch.cuda.Stream(device=dev, priority=int(os.environ.get("DPX_CHAIN_PRIO", "0"))))      # (priority: tuning experiments only)
     return main, list(side[:chains - 1])
 
 

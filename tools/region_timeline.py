@@ -25,5 +25,10 @@ for run in runs:
 if pick:
     t0 = int(pick[0]["Start_Timestamp"])
     key = "Queue_Id" if "Queue_Id" in pick[0] else None
+    if key:
+        ends = {}
+        for r in pick:
+            ends[r[key]] = max(ends.get(r[key], 0), int(r["End_Timestamp"]))
+        print("  last kernel of each queue ends at", {q: round((e - t0) / 1e3, 1) for q, e in ends.items()}, "us")
     for r in pick[:12] + pick[-8:]:
         print(f"  {(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:9.1f} us  q={r.get(key, '?') if key else '?'}  {r['Kernel_Name'].split('(')[0][-44:]}")
