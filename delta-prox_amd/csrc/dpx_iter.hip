@@ -1321,6 +1321,17 @@ extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const v
   dpx_term cur[DPX_MAX_CHAINS][DPX_MAX_TERMS];
   for (int c = 0; c < nchains; ++c)
     for (int i = 0; i < nterms; ++i) cur[c][i] = chains[c].terms[i];
+  // the seed passes of all chains first (it0 == 0 only): issued back to back from here, nothing of the host language between them and the loop
+  for (int c = 0; c < nchains; ++c) {
+    const dpx_chain& ch = chains[c];
+    if (!ch.seed) continue;
+    DPX_REQUIRE(it0 == 0 && n_iters > 0, "dpx_admm_run_chains: a chain can only be seeded at the start of the solve (chain %d)", c);
+    DPX_REQUIRE(ch.seed == 1 || (ch.seed == 2 && ch.seed_x0), "dpx_admm_run_chains: chain %d: seed mode %d", c, ch.seed);
+    for (int i = 0; i < nterms; ++i) cur[c][i].lam = ch.lam_tabs[i];
+    const int rc = ch.seed == 2 ? dpx_admm_seed_rows_fresh(ch.spec_a, ch.rho_tab, ch.seed_x0, cur[c], nterms, ch.B, C, H, W, table, ch.stream)
+                                : dpx_admm_seed_rows(ch.spec_a, ch.rho_tab, cur[c], nterms, ch.B, C, H, W, table, ch.stream);
+    if (rc) return rc;
+  }
   int parity = 0;
   for (int k = 0; k < n_iters; ++k) {
     const int it = it0 + k;

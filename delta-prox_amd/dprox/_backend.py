@@ -43,7 +43,7 @@ class Term(ctypes.Structure):
 class Chain(ctypes.Structure):
     """``dpx_chain`` of include/dpx.h."""
     _fields_ = [("spec_a", c_void_p), ("spec_b", c_void_p), ("spec_add", c_void_p), ("terms", POINTER(Term)), ("rho_tab", c_void_p),
-                ("lam_tabs", POINTER(c_void_p)), ("x_out", c_void_p), ("B", c_int32), ("pad_", c_int32), ("stream", c_void_p)]
+                ("lam_tabs", POINTER(c_void_p)), ("x_out", c_void_p), ("B", c_int32), ("seed", c_int32), ("stream", c_void_p), ("seed_x0", c_void_p)]
 
 
 class BwdTerm(ctypes.Structure):

@@ -624,7 +624,7 @@ def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, 
 
 def admm_run_chains(chains, dd, nterms, eps, it0, n_iters, total, emit_last, shape, device):
     """dpx_admm_run for several sub-batch chains at once.  chains: dicts with spec_a, spec_b, spec_add (tensor / None), terms (ctypes
-    array), rho_tab, lam_tabs (tensors), x_out, B, stream (raw handle).  Returns the dual-buffer parity."""
+    array), rho_tab, lam_tabs (tensors), x_out, B, stream (raw handle), optionally seed (0 / 1 / 2) and seed_x0.  Returns the dual-buffer parity."""
     _, C, H, W = shape
     arr = (be.Chain * len(chains))()
     keep = []
@@ -639,6 +639,8 @@ def admm_run_chains(chains, dd, nterms, eps, it0, n_iters, total, emit_last, sha
         arr[i].x_out = ch["x_out"].data_ptr()
         arr[i].B = int(ch["B"])
         arr[i].stream = ch["stream"]
+        arr[i].seed = int(ch.get("seed", 0))
+        arr[i].seed_x0 = None if ch.get("seed_x0") is None else ch["seed_x0"].data_ptr()
     L = be.lib()
     rc = L.query("dpx_admm_run_chains", arr, len(chains), ptr(dd), nterms, c_float(eps), it0, n_iters, total, int(emit_last), C, H, W,
                  ptr(fft_table(H, W, device)))

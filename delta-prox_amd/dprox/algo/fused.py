@@ -753,20 +753,15 @@ class FusedADMM:
             for st in streams:
                 if main is not None and st is not main:
                     st.wait_stream(main)
-            for wk, st in zip(work, streams):
-                with on(st):
-                    for i in range(n):
-                        wk["terms"][i].lam = wk["lam"][i][0].data_ptr()
-                    ops.admm_seed_rows(wk["SA"], wk["rho"][0], wk["terms"], n, wk["shape"], dev, fresh_x=x0[wk["b0"]:wk["b1"]] if fresh else None)
-            # one C call issues every iteration of every chain, chain by chain within an iteration (dpx_admm_run_chains: the column
-            # passes are ordered by events so that the chains advance together)
+            # one C call issues the chains' seed passes and then every iteration of every chain, chain by chain within an iteration
             raw = []
             for st in streams:
                 with on(st):
                     h = be.stream()
                     raw.append(None if h is None else h.value)
             par = ops.admm_run_chains([dict(spec_a=wk["SA"], spec_b=wk["SB"], spec_add=fk, terms=wk["terms"], rho_tab=wk["rho"], lam_tabs=wk["lam"],
-                                            x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=h) for wk, fk, h in zip(work, FK, raw)],
+                                            x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=h, seed=2 if fresh else 1,
+                                            seed_x0=x0[wk["b0"]:wk["b1"]] if fresh else None) for wk, fk, h in zip(work, FK, raw)],
                                       dd, n, eps, 0, T, T, 2 if x_only else 1, x0.shape, dev)
             for st in streams:
                 if main is not None and st is not main:

@@ -410,7 +410,7 @@ int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, const void* d
  * dual-buffer parity (equal for all chains), < 0 on error.  (algo/admm.py:49-59 acts per image: splitting the batch changes nothing.) */
 #define DPX_MAX_CHAINS 8
 typedef struct dpx_chain {
-  void* spec_a;              /* holds the chain's seeded spectrum on entry */
+  void* spec_a;              /* holds the chain's seeded spectrum on entry (seed == 0) */
   void* spec_b;
   const void* spec_add;      /* the chain's data spectrum (nullable) */
   const dpx_term* terms;     /* nterms terms over the chain's images */
@@ -418,8 +418,9 @@ typedef struct dpx_chain {
   const float* const* lam_tabs; /* nterms pointers to [total_iters][B] */
   float* x_out;              /* the chain's images of x */
   int32_t B;                 /* images of this chain */
-  int32_t pad_;
+  int32_t seed;              /* 0: spec_a is seeded; 1: seed it first from the terms' v / u (dpx_admm_seed_rows); 2: from seed_x0 (dpx_admm_seed_rows_fresh) */
   dpx_stream_t stream;
+  const float* seed_x0;      /* seed == 2: the chain's images of the iterate the state was initialised from */
 } dpx_chain;
 int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const void* dd, int nterms, float eps, int it0, int n_iters,
                         int total_iters, int emit_last, int C, int H, int W, const void* table);

@@ -1342,7 +1342,7 @@ def case_fresh_state(device, shapes=((2, 1, 256, 256),), iters=3):
         L.call("dpx_admm_iter_config", 0, 0)
 
 
-def case_solve_x_only(device, shapes=((2, 1, 256, 256),), iters=4):
+def case_solve_x_only(device, shapes=((2, 1, 256, 256),), iters=4, configs=None):
     """solve() hands back x alone, so its last row pass stores x and skips the final z / dual update (emit mode 2: the no-dual
     instantiation of the streaming row kernel in its x-only mode, own rows of each band, no halo).  Against the same solve with
     return_full_states=True (the emitting pass: x, v and the duals, with its emit-aware wait counts) and against a callback run
@@ -1354,8 +1354,8 @@ def case_solve_x_only(device, shapes=((2, 1, 256, 256),), iters=4):
         for (B, C, H, W) in shapes:
             gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=91 + H)
             b = T(b0, device)
-            for method in ("admm", "hqs"):
-                for bands in (0, H // 8, 30):
+            for method, bands in (configs or [(m_, b_) for m_ in ("admm", "hqs") for b_ in (0, H // 8, 30)]):
+                if True:
                     L.call("dpx_admm_iter_config", 1, bands)
                     x = dp.Variable()
                     fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
@@ -1435,7 +1435,7 @@ def case_sub_batch_chains(device, shapes=((4, 1, 256, 256),), iters=13, methods=
             os.environ["DPX_CHAINS"] = old
 
 
-def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4):
+def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4, nterms_list=(1, 2, 3, 4)):
     """Half-quadratic splitting on the streaming row kernel's no-dual variant (k_iter_rows_seq<..., DUAL = false>: the duals are
     neither fetched nor stored, its wait counts are the general kernel's minus the dual streams) against the lock-step ring-buffer
     kernel (no LDS-DMA, no hand-counted waits), for one to four terms; bit-identical across band partitions."""
@@ -1446,7 +1446,7 @@ def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4):
         for (B, C, H, W) in shapes:
             gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=55 + W)
             b = T(b0, device)
-            for nterms in (1, 2, 3, 4):
+            for nterms in nterms_list:
                 def run(mode, bands):
                     L.call("dpx_admm_iter_config", mode, bands)
                     x = dp.Variable()
@@ -1506,7 +1506,7 @@ def case_pgd_streaming_rows(device, shapes=((1, 2, 256, 256),), iters=4):
         L.call("dpx_admm_iter_config", 0, 0)
 
 
-def case_vxu_two_kernel(device, shapes=((1, 2, 256, 256),), iters=5):
+def case_vxu_two_kernel(device, shapes=((1, 2, 256, 256),), iters=5, nterms_list=(2, 3, 4)):
     """ADMM in the order v, x, u (admm.py:103-120) on the two-kernel iteration (DPX_TERM_VXU: the planes carry q = u' - v, the row pass
     forms the dual with the fresh x and the next v-update) against the op-by-op iteration of the same solver -- full state (z, v_i,
     u_i), one to four terms, both row kernels."""
@@ -1518,7 +1518,7 @@ def case_vxu_two_kernel(device, shapes=((1, 2, 256, 256),), iters=5):
         for (B, C, H, W) in shapes:
             gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=91 + W)
             b = T(b0, device)
-            for nterms in (2, 3, 4):     # (a single gradient term leaves a line of ~eps denominators: two correct evaluation orders differ by 6e-3 there)
+            for nterms in nterms_list:     # (a single gradient term leaves a line of ~eps denominators: two correct evaluation orders differ by 6e-3 there)
                 def build():
                     x = dp.Variable()
                     fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0))

@@ -63,19 +63,19 @@ def test_fresh_state_shortcut_matches_the_general_seed():
 
 
 def test_solve_returns_x_alone_from_an_x_only_last_pass():
-    pc.case_solve_x_only(DEV)
+    pc.case_solve_x_only(DEV, iters=3, configs=(("admm", 0), ("admm", 30), ("hqs", 0)))
 
 
 def test_sub_batch_chains_are_bit_identical_to_one_chain():
-    pc.case_sub_batch_chains(DEV, shapes=((3, 1, 256, 256),), iters=11, methods=("admm",), nchs=(3,), twice=False)      # (1-, 1-, 1-image chains, two turns)
+    pc.case_sub_batch_chains(DEV, shapes=((3, 1, 256, 256),), iters=3, methods=("admm",), nchs=(2,), twice=False)      # (a 1- and a 2-image chain)
 
 
 def test_hqs_no_dual_row_kernel():
-    pc.case_hqs_nodual_kernel(DEV)
+    pc.case_hqs_nodual_kernel(DEV, iters=3, nterms_list=(2, 4))
 
 
 def test_admm_vxu_two_kernel():
-    pc.case_vxu_two_kernel(DEV)
+    pc.case_vxu_two_kernel(DEV, iters=4, nterms_list=(2, 4))
 
 
 def test_pgd_streaming_row_kernel():
