@@ -395,12 +395,12 @@ class FusedADMM:
             early = ops.make_terms([dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=None, v=v[i], u=u[i])
                                     for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))])
             if ops.iter_supported(H, W, early, len(psi)):
-                if chains > 1:
-                    seeded = "chains"                              # (every chain seeds its own spectrum buffer on its own stream)
+                if chains > 1:                                     # (every chain seeds its own spectrum buffer on its own stream, now)
+                    seeded = self._seed_chains(x0, v, u, rho_tab, fresh, chains, dev)
                 else:
                     seeded = ops.admm_seed_rows(ops.spectrum_buffer(B * C, H, W, dev), rho_tab[0], early, len(psi), x0.shape, dev,
                                                 fresh_x=x0 if fresh else None)
-        if not isinstance(seeded, str):
+        if not isinstance(seeded, dict):
             chains = 1
         if lazy and seeded is None:                           # (cannot happen for a state lazy_initial_state handed out; kept as a guard)
             s._fresh, s._fresh_lazy = (x0, list(v), list(u), [t._version for t in [x0] + list(v) + list(u)]), True
@@ -477,7 +477,7 @@ class FusedADMM:
                 for i in range(n):
                     terms[i].reserved = be.TERM_NO_DUAL
             if chains > 1:
-                return self._run_chains(x0, dev, T, n, v, u, x, FK, (t0, c0, t1, c1), rho_tab, lam_tab, dual, fresh, chains)
+                return self._run_chains(x0, dev, T, n, v, u, x, FK, (t0, c0, t1, c1), rho_tab, lam_tab, dual, fresh, chains, seeded)
             return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
                                         rhos, lams, pbar, callback, dual, seeded, fresh and seeded is not None)
 
@@ -708,12 +708,47 @@ class FusedADMM:
             tot = val if tot is None else tot + val
         return (-tot).expand_as(x0)
 
-    def _run_chains(self, x0, dev, T, n, v, u, x, FK, diag, rho_tab, lam_tab, dual, fresh, chains):
+    def _seed_chains(self, x0, v, u, rho_tab, fresh, chains, dev):
+        """Sub-batch chains, first half: per chain its spectrum buffers, terms (views of the state) and stream, and the seed passes
+        launched -- before the rest of the host-side preparation, which then runs while the GPU is busy (as the one-chain path does)."""
+        import contextlib
+        B, C, H, W = x0.shape
+        psi = list(self.solver.psi_fns)
+        if be.host_mode():                                       # (the CPU emulator runs the chains one after the other)
+            main, streams = None, [None] * chains
+        else:
+            main, side = chain_streams(dev, chains)               # (stream priorities / no chain on the caller's stream: measured, no difference)
+            streams = [main] + side
+        on = (lambda st: contextlib.nullcontext()) if main is None else torch.cuda.stream
+        work = []
+        for c in range(chains):
+            b0, b1 = chain_bounds(B, chains, c)
+            terms = ops.make_terms([dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=None, v=v[i][b0:b1], u=u[i][b0:b1])
+                                    for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))])
+            work.append(dict(b0=b0, b1=b1, shape=(b1 - b0, C, H, W), terms=terms, rho=_chain_table(rho_tab, b0, b1),
+                             SA=ops.spectrum_buffer((b1 - b0) * C, H, W, dev), SB=ops.spectrum_buffer((b1 - b0) * C, H, W, dev)))
+        L = be.lib()
+        L.call("dpx_admm_iter_share", chains)
+        try:
+            for st in streams:
+                if main is not None and st is not main:
+                    st.wait_stream(main)
+            for wk, st in zip(work, streams):
+                with on(st):
+                    ops.admm_seed_rows(wk["SA"], wk["rho"][0], wk["terms"], len(psi), wk["shape"], dev, fresh_x=x0[wk["b0"]:wk["b1"]] if fresh else None)
+                    h = be.stream()
+                    wk["stream"] = None if h is None else h.value
+        finally:
+            L.call("dpx_admm_iter_share", 1)
+        return dict(work=work, streams=streams, main=main)
+
+    def _run_chains(self, x0, dev, T, n, v, u, x, FK, diag, rho_tab, lam_tab, dual, fresh, chains, pre):
         """The two-kernel iteration as `chains` independent sub-batch chains on separate HIP streams.  The iteration acts per image
         (admm.py:49-59; every table is per channel), so the sub-batches never meet: without a common kernel boundary one chain's column
         pass (load - transform - store in step across its workgroups) runs beside another chain's streaming row pass and the memory
-        system stays busy through both kernels' ramps and tails -- 8x3x1024^2: 0.181 -> 0.172 ms per iteration, bit-identical results.
-        Every chain has its own spectrum buffers and data spectrum; state, tables and schedules are sub-batch views."""
+        system stays busy through both kernels' ramps and tails -- 8x3x1024^2: 0.182 -> 0.169 ms per iteration, bit-identical results.
+        Every chain has its own spectrum buffers and data spectrum; state, tables and schedules are sub-batch views.  pre: what
+        _seed_chains prepared (the seed passes are already running)."""
         s = self.solver
         B, C, H, W = x0.shape
         t0, c0, t1, c1 = diag
@@ -725,43 +760,20 @@ class FusedADMM:
             u_cur, u_nxt = list(u), [torch.empty_like(t) for t in u]
         else:
             u_cur, u_nxt = list(u), [torch.zeros_like(u[0])] * n
-        import contextlib
-        if be.host_mode():                                       # (the CPU emulator runs the chains one after the other)
-            main, streams = None, [None] * chains
-        else:
-            main, side = chain_streams(dev, chains)               # (stream priorities / no chain on the caller's stream: measured, no difference)
-            streams = [main] + side
-        on = (lambda st: contextlib.nullcontext()) if main is None else torch.cuda.stream
-        psi = list(s.psi_fns)
-        work = []
-        for c in range(chains):
-            b0, b1 = chain_bounds(B, chains, c)
-            specs = [dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=lam_tab[i][0, b0:b1], v=v[i][b0:b1], u=u_cur[i][b0:b1], u_out=u_nxt[i][b0:b1])
-                     for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))]
-            terms = ops.make_terms(specs)
+        work, streams, main = pre["work"], pre["streams"], pre["main"]
+        for wk in work:
+            b0, b1 = wk["b0"], wk["b1"]
             for i in range(n):
-                if not dual:
-                    terms[i].reserved = be.TERM_NO_DUAL
-                if fresh:
-                    terms[i].reserved |= be.TERM_U_ZERO
-            work.append(dict(b0=b0, b1=b1, shape=(b1 - b0, C, H, W), terms=terms,
-                             rho=_chain_table(rho_tab, b0, b1), lam=[_chain_table(lt, b0, b1) for lt in lam_tab],
-                             SA=ops.spectrum_buffer((b1 - b0) * C, H, W, dev), SB=ops.spectrum_buffer((b1 - b0) * C, H, W, dev)))
+                tm = wk["terms"][i]
+                tm.v, tm.u, tm.u_out = v[i][b0:b1].data_ptr(), u_cur[i][b0:b1].data_ptr(), u_nxt[i][b0:b1].data_ptr()
+                tm.reserved = (0 if dual else be.TERM_NO_DUAL) | (be.TERM_U_ZERO if fresh else 0)
+            wk["lam"] = [_chain_table(lt, b0, b1) for lt in lam_tab]
         L = be.lib()
         L.call("dpx_admm_iter_share", chains)
         try:
-            for st in streams:
-                if main is not None and st is not main:
-                    st.wait_stream(main)
-            # one C call issues the chains' seed passes and then every iteration of every chain, chain by chain within an iteration
-            raw = []
-            for st in streams:
-                with on(st):
-                    h = be.stream()
-                    raw.append(None if h is None else h.value)
+            # one C call issues every iteration of every chain, chain by chain within an iteration
             par = ops.admm_run_chains([dict(spec_a=wk["SA"], spec_b=wk["SB"], spec_add=fk, terms=wk["terms"], rho_tab=wk["rho"], lam_tabs=wk["lam"],
-                                            x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=h, seed=2 if fresh else 1,
-                                            seed_x0=x0[wk["b0"]:wk["b1"]] if fresh else None) for wk, fk, h in zip(work, FK, raw)],
+                                            x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=wk["stream"]) for wk, fk in zip(work, FK)],
                                       dd, n, eps, 0, T, T, 2 if x_only else 1, x0.shape, dev)
             for st in streams:
                 if main is not None and st is not main:
