@@ -771,6 +771,10 @@ class FusedADMM:
         L = be.lib()
         L.call("dpx_admm_iter_share", chains)
         try:
+            # what the caller's stream produced since the seeds were launched (data spectrum, denominators, table slices) is input of every chain
+            for st in streams:
+                if main is not None and st is not main:
+                    st.wait_stream(main)
             # one C call issues every iteration of every chain, chain by chain within an iteration
             par = ops.admm_run_chains([dict(spec_a=wk["SA"], spec_b=wk["SB"], spec_add=fk, terms=wk["terms"], rho_tab=wk["rho"], lam_tabs=wk["lam"],
                                             x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=wk["stream"]) for wk, fk in zip(work, FK)],
