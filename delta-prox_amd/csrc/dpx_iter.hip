@@ -1277,6 +1277,67 @@ extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, co
   return parity;
 }
 
+// Stream fork / join for the sub-batch chains, with events kept per (host thread, device): `to[i]` waits for everything issued on `from`
+// so far / `into` waits for everything issued on `from[i]` so far.  Streams equal to the other side are skipped.
+namespace {
+struct ChainEvents {
+  hipEvent_t ev[DPX_MAX_CHAINS + 1];
+  bool ok = false;
+};
+ChainEvents* chain_events(const char* who) {
+  constexpr int MAXDEV = 16;
+  static thread_local ChainEvents evs[MAXDEV];
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= MAXDEV) {
+    dpx::set_error("%s: hipGetDevice failed / device id %d out of range", who, devid);
+    return nullptr;
+  }
+  ChainEvents& E = evs[devid];
+  if (!E.ok) {
+    for (int i = 0; i <= DPX_MAX_CHAINS; ++i)
+      if (hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming) != hipSuccess) {
+        for (int k = 0; k < i; ++k) hipEventDestroy(E.ev[k]);
+        dpx::set_error("%s: hipEventCreate failed", who);
+        return nullptr;
+      }
+    E.ok = true;
+  }
+  return &E;
+}
+}  // namespace
+extern "C" int dpx_stream_fork(dpx_stream_t from, const dpx_stream_t* to, int n) {
+  DPX_REQUIRE(to && n >= 0 && n <= DPX_MAX_CHAINS, "dpx_stream_fork: bad arguments");
+  ChainEvents* E = chain_events("dpx_stream_fork");
+  if (!E) return DPX_ERR_LAUNCH;
+  bool recorded = false;
+  for (int i = 0; i < n; ++i) {
+    if (to[i] == from) continue;
+    if (!recorded && hipEventRecord(E->ev[DPX_MAX_CHAINS], (hipStream_t)from) != hipSuccess) {
+      set_error("dpx_stream_fork: hipEventRecord failed");
+      return DPX_ERR_LAUNCH;
+    }
+    recorded = true;
+    if (hipStreamWaitEvent((hipStream_t)to[i], E->ev[DPX_MAX_CHAINS], 0) != hipSuccess) {
+      set_error("dpx_stream_fork: hipStreamWaitEvent failed");
+      return DPX_ERR_LAUNCH;
+    }
+  }
+  return DPX_OK;
+}
+extern "C" int dpx_stream_join(dpx_stream_t into, const dpx_stream_t* from, int n) {
+  DPX_REQUIRE(from && n >= 0 && n <= DPX_MAX_CHAINS, "dpx_stream_join: bad arguments");
+  ChainEvents* E = chain_events("dpx_stream_join");
+  if (!E) return DPX_ERR_LAUNCH;
+  for (int i = 0; i < n; ++i) {
+    if (from[i] == into) continue;
+    if (hipEventRecord(E->ev[i], (hipStream_t)from[i]) != hipSuccess || hipStreamWaitEvent((hipStream_t)into, E->ev[i], 0) != hipSuccess) {
+      set_error("dpx_stream_join: event record / wait failed");
+      return DPX_ERR_LAUNCH;
+    }
+  }
+  return DPX_OK;
+}
+
 // The same loop for `nchains` sub-batches of one solve, each on its own stream (the images of a batch never exchange data: one
 // chain's column pass can run beside another chain's row pass).  Launches are issued chain by chain within an iteration, so that every
 // chain has work queued from the first microseconds on; the chains then run freely.  (DPX_CHAIN_LOCKSTEP=1, measured and kept as a
@@ -1294,28 +1355,9 @@ extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const v
     DPX_REQUIRE(ch.spec_a && ch.spec_b && ch.terms && ch.rho_tab && ch.lam_tabs && ch.B >= 1, "dpx_admm_run_chains: chain %d: null pointer", c);
     DPX_REQUIRE(!emit_last || ch.x_out, "dpx_admm_run_chains: emit_last needs x_out (chain %d)", c);
   }
-  // events: host-side resources, one set per (host thread, device)
-  struct Evs {
-    hipEvent_t ev[DPX_MAX_CHAINS];
-    bool ok = false;
-  };
-  constexpr int MAXDEV = 16;
-  static thread_local Evs evs[MAXDEV];
-  int devid = 0;
-  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= MAXDEV) {
-    set_error("dpx_admm_run_chains: hipGetDevice failed / device id %d out of range", devid);
-    return DPX_ERR_LAUNCH;
-  }
-  Evs& E = evs[devid];
-  if (!E.ok) {
-    for (int i = 0; i < DPX_MAX_CHAINS; ++i)
-      if (hipEventCreateWithFlags(&E.ev[i], hipEventDisableTiming) != hipSuccess) {
-        for (int k = 0; k < i; ++k) hipEventDestroy(E.ev[k]);
-        set_error("dpx_admm_run_chains: hipEventCreate failed");
-        return DPX_ERR_LAUNCH;
-      }
-    E.ok = true;
-  }
+  ChainEvents* Ep = chain_events("dpx_admm_run_chains");
+  if (!Ep) return DPX_ERR_LAUNCH;
+  ChainEvents& E = *Ep;
   static const bool lockstep = getenv("DPX_CHAIN_LOCKSTEP") != nullptr;
   const bool ordered = lockstep && nchains > 1;
   dpx_term cur[DPX_MAX_CHAINS][DPX_MAX_TERMS];

@@ -595,16 +595,33 @@ def iter_rows(spec_in, spec_out, term_arr, nterms, rho_next, x_out, emit_v, shap
                   int(bool(emit_v)), B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
 
 
-def admm_seed_rows(spec, rho, term_arr, nterms, shape, device, fresh_x=None):
+def admm_seed_rows(spec, rho, term_arr, nterms, shape, device, fresh_x=None, stream=None):
     """spec = row transform of rho_b sum_i K_i^T (v_i - u_i): the seed of admm_run in one pass.  ``fresh_x``: the state is
-    ADMM.initialize(fresh_x) untouched (v_i = K_i x0, u_i = 0) -- the pass then reads x0 alone (bit-identical result)"""
+    ADMM.initialize(fresh_x) untouched (v_i = K_i x0, u_i = 0) -- the pass then reads x0 alone (bit-identical result).
+    stream: a raw stream handle (default: the current stream)"""
     B, C, H, W = shape
+    st = be.stream() if stream is None else stream
     if fresh_x is not None:
-        be.lib().call("dpx_admm_seed_rows_fresh", ptr(spec), ptr(rho), ptr(fresh_x), term_arr, nterms, B, C, H, W, ptr(fft_table(H, W, device)),
-                      be.stream())
+        be.lib().call("dpx_admm_seed_rows_fresh", ptr(spec), ptr(rho), ptr(fresh_x), term_arr, nterms, B, C, H, W, ptr(fft_table(H, W, device)), st)
         return spec
-    be.lib().call("dpx_admm_seed_rows", ptr(spec), ptr(rho), term_arr, nterms, B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
+    be.lib().call("dpx_admm_seed_rows", ptr(spec), ptr(rho), term_arr, nterms, B, C, H, W, ptr(fft_table(H, W, device)), st)
     return spec
+
+
+def stream_fork(frm, to):
+    """every raw stream of ``to`` waits for what has been issued on ``frm`` (dpx_stream_fork; no-op on the CPU emulator)"""
+    if be.host_mode():
+        return
+    arr = (c_void_p * len(to))(*to)
+    be.lib().call("dpx_stream_fork", c_void_p(frm), arr, len(to))
+
+
+def stream_join(into, frm):
+    """``into`` waits for what has been issued on every raw stream of ``frm``"""
+    if be.host_mode():
+        return
+    arr = (c_void_p * len(frm))(*frm)
+    be.lib().call("dpx_stream_join", c_void_p(into), arr, len(frm))
 
 
 def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, eps, it0, n_iters, total, x_out, emit_last,

@@ -19,6 +19,7 @@ K^T b and the denominators are computed once per solve; rho / lambda schedules a
 [T, B] device arrays.  Anything that does not match returns ``None`` and the caller falls back to the
 op-by-op path on the same HIP primitives (never to PyTorch or the CPU).
 """
+import ctypes
 import os
 
 import torch
@@ -301,6 +302,7 @@ class FusedSplitCG:
 
 
 _CHAIN_STREAMS = {}          # device index -> side streams of the sub-batch chains
+_chain_spec_bytes = {}       # (B, C, H, W, chains) -> bytes of one spectrum buffer per chain
 _chain_tab_cache = {}        # (id(table), b0, b1) -> (table, version, contiguous [T, b1 - b0] copy): the schedule tables are cached objects themselves
 
 
@@ -322,8 +324,20 @@ def chain_streams(dev, chains):
     main = torch.cuda.current_stream(dev)
     side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
     while len(side) < chains - 1:
-        side.append(torch.cuda.Stream(device=dev, priority=int(os.environ.get("DPX_CHAIN_PRIO", "0"))))      # (priority: tuning experiments only)
+        side.append(torch.cuda.Stream(device=dev))
     return main, list(side[:chains - 1])
+
+
+def chain_stream_handles(dev, chains):
+    """raw handles [caller's current stream, side streams ...] for the C ABI; [None] * chains on the CPU emulator (the chains then
+    run one after the other)"""
+    if be.host_mode():
+        return [None] * chains
+    h = be.stream()
+    side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
+    while len(side) < chains - 1:                             # (created once per process and device: a stream costs milliseconds)
+        side.append(torch.cuda.Stream(device=dev))
+    return [h.value or 0] + [st.cuda_stream for st in side[:chains - 1]]      # (0: the null stream)
 
 
 def chain_bounds(B, chains, c):
@@ -710,37 +724,36 @@ class FusedADMM:
 
     def _seed_chains(self, x0, v, u, rho_tab, fresh, chains, dev):
         """Sub-batch chains, first half: per chain its spectrum buffers, terms (views of the state) and stream, and the seed passes
-        launched -- before the rest of the host-side preparation, which then runs while the GPU is busy (as the one-chain path does)."""
-        import contextlib
+        launched -- before the rest of the host-side preparation, which then runs while the GPU is busy (as the one-chain path does).
+        Streams are raw handles and forks / joins C calls: torch's stream context managers and wait_stream cost ~15 us each."""
         B, C, H, W = x0.shape
         psi = list(self.solver.psi_fns)
-        if be.host_mode():                                       # (the CPU emulator runs the chains one after the other)
-            main, streams = None, [None] * chains
-        else:
-            main, side = chain_streams(dev, chains)               # (stream priorities / no chain on the caller's stream: measured, no difference)
-            streams = [main] + side
-        on = (lambda st: contextlib.nullcontext()) if main is None else torch.cuda.stream
-        work = []
+        handles = chain_stream_handles(dev, chains)
+        L = be.lib()
+        key = (B, C, H, W, chains)
+        sizes = _chain_spec_bytes.get(key)
+        if sizes is None:
+            sizes = _chain_spec_bytes[key] = [L.query("dpx_spectrum_bytes", (chain_bounds(B, chains, c)[1] - chain_bounds(B, chains, c)[0]) * C, H, W) // 2
+                                             for c in range(chains)]
+        pad = [(sz + 255) // 256 * 256 for sz in sizes]
+        pool = ops._bytes(2 * sum(pad), dev)                    # the 2 x chains spectrum buffers in one allocation
+        work, off = [], 0
         for c in range(chains):
             b0, b1 = chain_bounds(B, chains, c)
             terms = ops.make_terms([dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=None, v=v[i][b0:b1], u=u[i][b0:b1])
                                     for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))])
             work.append(dict(b0=b0, b1=b1, shape=(b1 - b0, C, H, W), terms=terms, rho=_chain_table(rho_tab, b0, b1),
-                             SA=ops.spectrum_buffer((b1 - b0) * C, H, W, dev), SB=ops.spectrum_buffer((b1 - b0) * C, H, W, dev)))
-        L = be.lib()
+                             SA=pool[off:off + pad[c]], SB=pool[off + pad[c]:off + 2 * pad[c]], stream=handles[c]))
+            off += 2 * pad[c]
         L.call("dpx_admm_iter_share", chains)
         try:
-            for st in streams:
-                if main is not None and st is not main:
-                    st.wait_stream(main)
-            for wk, st in zip(work, streams):
-                with on(st):
-                    ops.admm_seed_rows(wk["SA"], wk["rho"][0], wk["terms"], len(psi), wk["shape"], dev, fresh_x=x0[wk["b0"]:wk["b1"]] if fresh else None)
-                    h = be.stream()
-                    wk["stream"] = None if h is None else h.value
+            ops.stream_fork(handles[0], handles)                 # (the chains read x0 / the state: produced on the caller's stream)
+            for wk in work:
+                ops.admm_seed_rows(wk["SA"], wk["rho"][0], wk["terms"], len(psi), wk["shape"], dev, fresh_x=x0[wk["b0"]:wk["b1"]] if fresh else None,
+                                   stream=None if wk["stream"] is None else ctypes.c_void_p(wk["stream"]))
         finally:
             L.call("dpx_admm_iter_share", 1)
-        return dict(work=work, streams=streams, main=main)
+        return dict(work=work, handles=handles, pool=pool)
 
     def _run_chains(self, x0, dev, T, n, v, u, x, FK, diag, rho_tab, lam_tab, dual, fresh, chains, pre):
         """The two-kernel iteration as `chains` independent sub-batch chains on separate HIP streams.  The iteration acts per image
@@ -760,7 +773,7 @@ class FusedADMM:
             u_cur, u_nxt = list(u), [torch.empty_like(t) for t in u]
         else:
             u_cur, u_nxt = list(u), [torch.zeros_like(u[0])] * n
-        work, streams, main = pre["work"], pre["streams"], pre["main"]
+        work, handles = pre["work"], pre["handles"]
         for wk in work:
             b0, b1 = wk["b0"], wk["b1"]
             for i in range(n):
@@ -772,16 +785,12 @@ class FusedADMM:
         L.call("dpx_admm_iter_share", chains)
         try:
             # what the caller's stream produced since the seeds were launched (data spectrum, denominators, table slices) is input of every chain
-            for st in streams:
-                if main is not None and st is not main:
-                    st.wait_stream(main)
+            ops.stream_fork(handles[0], handles)
             # one C call issues every iteration of every chain, chain by chain within an iteration
             par = ops.admm_run_chains([dict(spec_a=wk["SA"], spec_b=wk["SB"], spec_add=fk, terms=wk["terms"], rho_tab=wk["rho"], lam_tabs=wk["lam"],
                                             x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=wk["stream"]) for wk, fk in zip(work, FK)],
                                       dd, n, eps, 0, T, T, 2 if x_only else 1, x0.shape, dev)
-            for st in streams:
-                if main is not None and st is not main:
-                    main.wait_stream(st)
+            ops.stream_join(handles[0], handles)                 # (every buffer of the chains stays alive until here: pre["pool"], u_nxt)
         finally:
             L.call("dpx_admm_iter_share", 1)
         if par:

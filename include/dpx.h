@@ -424,6 +424,10 @@ typedef struct dpx_chain {
 } dpx_chain;
 int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const void* dd, int nterms, float eps, int it0, int n_iters,
                         int total_iters, int emit_last, int C, int H, int W, const void* table);
+/* fork / join of the chains' streams (events cached per host thread and device): every to[i] waits for what has been issued on `from` /
+ * `into` waits for what has been issued on every from[i]; entries equal to the other side are skipped */
+int dpx_stream_fork(dpx_stream_t from, const dpx_stream_t* to, int n);
+int dpx_stream_join(dpx_stream_t into, const dpx_stream_t* from, int n);
 
 /* ------------------------------------------------------------------------------------------ */
 /* FFDNet denoiser (deep_prior z-update)                                                       */

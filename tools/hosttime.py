@@ -10,8 +10,8 @@ x0, rhos, lams, _ = solver.defaults(b, 0.1, 0.005, 50)
 rhos=rhos.to(dev); lams={k:v.to(dev) for k,v in lams.items()}
 for rep in range(3):
     state=solver.initialize(b); torch.cuda.synchronize()
-    t0=time.perf_counter(); solver.iters(state, rhos, lams, 50); t1=time.perf_counter(); torch.cuda.synchronize(); t2=time.perf_counter()
+    t0=time.perf_counter(); solver.iters(state, rhos, lams, int(os.environ.get("K", "2"))); t1=time.perf_counter(); torch.cuda.synchronize(); t2=time.perf_counter()
     print(f"host return after {1e3*(t1-t0):.3f} ms, GPU done after {1e3*(t2-t0):.3f} ms")
 state=solver.initialize(b); torch.cuda.synchronize()
-pr=cProfile.Profile(); pr.enable(); solver.iters(state, rhos, lams, 50); pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pr=cProfile.Profile(); pr.enable(); solver.iters(state, rhos, lams, int(os.environ.get("K", "2"))); pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
