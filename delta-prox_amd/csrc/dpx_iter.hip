@@ -887,6 +887,10 @@ bool pgd_rows_seq_pow2(const float2* sin, float2* sout, float* x, const float* k
 // Two rows are in flight per group (two staging areas): with one, a launch has ~8 MB outstanding, short of what 8 TB/s needs.
 //   after the awaited DMA of row q (issued in step q-2): the V (+1) spectrum stores of steps q-2 and q-1, where those steps produced
 //   a row, and the D pieces of row q+1 (issued in step q-1)
+#ifndef DPX_SEED_STX
+#define DPX_SEED_STX DPX_R_STX
+#endif
+constexpr int SEED_STX = DPX_SEED_STX;        // cache policy of the seed pass's spectrum stores (0 plain, 1 write-through, 2 nt)
 struct SeedOps {
   int linop[DPX_MAX_TERMS];
   int n;
@@ -1007,13 +1011,13 @@ __global__ void __launch_bounds__(256, 2) k_seed_rows_seq(SeedOps SO, const floa
         float2 Xo;
         if (k == 0) {
           Xo = make_float2(zk.x + zk.y, 0.f);
-          st_stream<R_STX>(spec_out + noff + hz, make_float2(zk.x - zk.y, 0.f));
+          st_stream<SEED_STX>(spec_out + noff + hz, make_float2(zk.x - zk.y, 0.f));
         } else {
           const float2 e = cscale(cadd(zk, zm), 0.5f);
           const float2 d = cscale(csub(zk, zm), 0.5f);
           Xo = cadd(e, cmul(make_float2(d.y, -d.x), twl[k]));
         }
-        st_stream<R_STX>(out + tile_step * m, Xo);
+        st_stream<SEED_STX>(out + tile_step * m, Xo);
       }
     }
 #pragma unroll
