@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, 
 
 // The Gram pass of a device-controlled CG iteration with its two followers folded in: the LAST workgroup to arrive adds up the
 // slabs' partial products (one wave per entry, fixed order) and runs the stop rule / beta update on the finished matrix
-// (cg_test_block) -- k_gram_tile -> k_dot_finish -> k_cg_test in one launch.  B <= 8.
+// (cg_test_block) -- k_gram_tile -> k_dot_finish -> k_cg_test in one launch.  B <= 32.
 // UPDATE: + the x / r update of the previous iteration in the slab load (k_cg_update folded in: alpha_b = gamma_b / <p_b, A p_b> from the
 // state the previous launches left).  host_flags (nullable): a host-mapped copy of (done, n_done) written by the finishing workgroup --
 // the host polls it behind an event instead of copying the flags back with a transfer per iteration.
@@ -778,12 +778,18 @@ extern "C" int dpx_bdot(const float* x, const float* y, float* out, int B, long 
 }
 
 namespace dpx {
-// Gram pass + finish + stop rule in one launch (dpx_cg_masked_fft's fused iteration, B <= 8); ws: B * B * gram_blocks floats
+// Gram pass + finish + stop rule in one launch (dpx_cg_masked_fft's fused iteration, B <= 32); ws: B * B * gram_blocks floats
 // x / p / Ap non-null: the pending update x += alpha p, r -= alpha A p of the previous iteration is applied on the way (r is written)
 int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, float* x, const float* p,
                     const float* Ap, int* host_flags, hipStream_t s) {
   static const int env_blk = getenv("DPX_CGF_GRAM_BLOCKS") ? atoi(getenv("DPX_CGF_GRAM_BLOCKS")) : 0;      // tuning
   int nblk = gram_blocks(n_per_batch);
+  // the finishing workgroup adds up B * B * nblk partial products: for larger batches fewer, longer slab walks (B = 32: 64 workgroups)
+  if (B > 8) {
+    int cap = 65536 / (B * B);
+    cap = cap < 32 ? 32 : cap;
+    if (nblk > cap) nblk = cap;
+  }
   if (env_blk > 0 && env_blk < nblk) nblk = env_blk;
   if (x)
     DPX_LAUNCH("k_gram_tile_test_upd", k_gram_tile_test<true>, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch,
