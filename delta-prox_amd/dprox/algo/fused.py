@@ -558,19 +558,44 @@ class FusedADMM:
             terms[i].u_out = scratch.data_ptr()
         ops.admm_zupdate(x, terms, n)
         # seed: row transform of rho_0 sum K^T (v - u'), then q = u' - v in place of u'
-        SA = ops.spectrum_buffer(B * C, H, W, dev)
-        SB = ops.spectrum_buffer(B * C, H, W, dev)
-        ops.admm_seed_rows(SA, rho_tab[0], terms, n, shape, dev)
-        q_cur = [ops.lincomb([(1.0, up[i]), (-1.0, v[i])]) for i in range(n)]
-        q_nxt = [torch.empty_like(t) for t in q_cur]
+        chains = sub_batch_chains(B, C, H, W) if (x.is_cuda or be.host_mode()) else 1
         dd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
-        for i in range(n):
-            terms[i].u, terms[i].u_out, terms[i].v = q_cur[i].data_ptr(), q_nxt[i].data_ptr(), v[i].data_ptr()
-            terms[i].reserved = be.TERM_VXU
-        # fused passes behind solves 0 .. T-2: the pass behind solve j uses lambda_{j+1} and rho_{j+1} (tables shifted by one row);
-        # the last of them emits z_{T-1} and v of iteration T-1
-        lam_shift = [lt[1:] for lt in lam_tab]
-        par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_shift, ls_eps(ls), 0, T - 1, T, x, True, shape, dev)
+        if chains > 1:
+            # sub-batch chains (_run_chains): every chain seeds from its images of (v, u') and walks its own spectrum buffers
+            pre = self._seed_chains(x, v, up, rho_tab, False, chains, dev)
+            q_cur = [ops.lincomb([(1.0, up[i]), (-1.0, v[i])]) for i in range(n)]
+            q_nxt = [torch.empty_like(t) for t in q_cur]
+            FKc = self._data_spectrum(x, chains)
+            for wk in pre["work"]:
+                b0, b1 = wk["b0"], wk["b1"]
+                for i in range(n):
+                    tm = wk["terms"][i]
+                    tm.v, tm.u, tm.u_out = v[i][b0:b1].data_ptr(), q_cur[i][b0:b1].data_ptr(), q_nxt[i][b0:b1].data_ptr()
+                    tm.reserved = be.TERM_VXU
+                wk["lam"] = [_chain_table(lt, b0, b1)[1:] for lt in lam_tab]      # (shifted by one row, see below)
+            L = be.lib()
+            L.call("dpx_admm_iter_share", chains)
+            try:
+                ops.stream_fork(pre["handles"][0], pre["handles"])
+                par = ops.admm_run_chains([dict(spec_a=wk["SA"], spec_b=wk["SB"], spec_add=fk, terms=wk["terms"], rho_tab=wk["rho"], lam_tabs=wk["lam"],
+                                                x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=wk["stream"]) for wk, fk in zip(pre["work"], FKc)],
+                                          dd, n, ls_eps(ls), 0, T - 1, T, 1, shape, dev)
+                ops.stream_join(pre["handles"][0], pre["handles"])
+            finally:
+                L.call("dpx_admm_iter_share", 1)
+        else:
+            SA = ops.spectrum_buffer(B * C, H, W, dev)
+            SB = ops.spectrum_buffer(B * C, H, W, dev)
+            ops.admm_seed_rows(SA, rho_tab[0], terms, n, shape, dev)
+            q_cur = [ops.lincomb([(1.0, up[i]), (-1.0, v[i])]) for i in range(n)]
+            q_nxt = [torch.empty_like(t) for t in q_cur]
+            for i in range(n):
+                terms[i].u, terms[i].u_out, terms[i].v = q_cur[i].data_ptr(), q_nxt[i].data_ptr(), v[i].data_ptr()
+                terms[i].reserved = be.TERM_VXU
+            # fused passes behind solves 0 .. T-2: the pass behind solve j uses lambda_{j+1} and rho_{j+1} (tables shifted by one row);
+            # the last of them emits z_{T-1} and v of iteration T-1
+            lam_shift = [lt[1:] for lt in lam_tab]
+            par = ops.admm_run(SA, SB, FK, dd, terms, n, rho_tab, lam_shift, ls_eps(ls), 0, T - 1, T, x, True, shape, dev)
         q_fin = q_nxt if par else q_cur
         for i in range(n):
             terms[i].reserved = 0
