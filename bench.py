@@ -202,8 +202,8 @@ def extra_configs(dp, synthetic, device):
     other["note"] = ("hqs: the two-kernel ADMM iteration with DPX_TERM_NO_DUAL (no-dual row kernel, 20 B per pixel); admm_vxu: the same two kernels "
                      "with DPX_TERM_VXU (the planes carry q = u' - v); pgd: dpx_pgd_run (2 launches per iteration, 28 B per pixel); "
                      "768 x 1024 (the reference's example image): column length 3 x 256 on the register-radix path (fft_reg_x3), two-kernel "
-                     "iteration; 768 x 768: staged kernels (5 launches, 64 B per pixel).  hqs, pgd and the 768 x 1024 ADMM run as two sub-batch "
-                     "chains on two streams like the headline (admm_vxu and the staged kernels as one)")
+                     "iteration; 768 x 768: staged kernels (5 launches, 64 B per pixel).  hqs, admm_vxu, pgd and the 768 x 1024 ADMM run as two "
+                     "sub-batch chains on two streams like the headline (the staged kernels as one)")
     out["other_paths"] = other
     # ---- config 3: config 2's data term + deep_prior(FFDNet-colour, seeded weights), 30 iterations
     rng = np.random.RandomState(2023)
