@@ -75,7 +75,7 @@ def test_hqs_no_dual_row_kernel():
 
 
 def test_admm_vxu_two_kernel():
-    pc.case_vxu_two_kernel(DEV, iters=4, nterms_list=(2, 4))
+    pc.case_vxu_two_kernel(DEV, iters=3, nterms_list=(3,))
 
 
 def test_pgd_streaming_row_kernel():
@@ -177,6 +177,7 @@ def test_ffdnet_split_backward():
     pc.case_ffdnet_split_backward(DEV, tiny=True)
 
 
+@pytest.mark.skipif(not __import__("os").environ.get("DPX_EMUL_SLOW"), reason="~1 min on the emulator (runs on the GPU in test_gpu_parity; the split-kernel backward below stays); DPX_EMUL_SLOW=1 enables it")
 def test_ffdnet_backward():
     pc.case_ffdnet_grads(DEV, which=("even",))      # one small image: the emulator runs MFMA layers at ~1 s each
 
