@@ -321,8 +321,10 @@ def sharded_runs(dp, synthetic, dist, rank, world, device):
         barrier()
         t0 = time.perf_counter()
         res = fn(inputs)
+        torch.cuda.synchronize()                           # (clock stops at this rank's completion; MAX over ranks below = the job's time)
+        dt_local = time.perf_counter() - t0
         barrier()
-        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        t = torch.tensor([dt_local], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), res
 
@@ -437,8 +439,12 @@ def main():
         barrier()
         t0 = time.perf_counter()
         st = solver.iters(st, rs, ls, n_steps)
-        barrier()
+        # the region ends when this rank's GPU has finished its K steps: the clock stops behind the synchronize, the inter-rank barrier
+        # follows it, and the job's time is the MAX over the ranks' clocks (all ranks left the opening barrier together) -- the RCCL
+        # barrier's own latency (~1 ms, a fifth of a 20-step region) is not part of any step
+        torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
+        barrier()
         if dist is not None:
             t = torch.tensor([dt_], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -607,7 +613,10 @@ def main():
                                       "measurement without host work in between, i.e. on a GPU that has just been under load.  "
                                       "`value_after_idle_gpu`: the identical region after the GPU idled for 0.5 s in front of the warm-up -- this GPU "
                                       "needs tens of ms of load to reach its clocks, so a 5-step warm-up (1 ms) leaves the ramp inside the "
-                                      "timed steps.  `steady_state`: 200 timed steps."},
+                                      "timed steps.  `steady_state`: 200 timed steps.",
+                              "clock": "opening: torch.cuda.synchronize + inter-rank barrier + synchronize, then t0; closing: torch.cuda.synchronize, "
+                                       "then t1, then the inter-rank barrier; the job's time is the MAX of t1 - t0 over the ranks (N = 1: no barrier).  "
+                                       "The closing RCCL barrier itself (~1 ms with the nccl backend) is not inside any rank's clock"},
         "value_after_idle_gpu": world * K / dt_idle, "ms_per_step_after_idle_gpu": 1e3 * dt_idle / K,
         "steady_state": {"steps": K_steady, "it_per_s": world * K_steady / dt_steady, "ms_per_step": 1e3 * dt_steady / K_steady,
                          "roofline_iteration_frac": (K_steady / dt_steady) * DESIGN_BYTES_PER_ELEM * n_elem / HBM_PEAK},
