@@ -140,6 +140,7 @@ SIGNATURES = {
     "dpx_admm_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_void_p, POINTER(c_void_p), c_float,
                              c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_run_chains": (c_int, [POINTER(Chain), c_int, c_void_p, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_streams_concurrent": (c_int, [c_void_p, c_void_p]),
     "dpx_stream_fork": (c_int, [c_void_p, POINTER(c_void_p), c_int]),
     "dpx_stream_join": (c_int, [c_void_p, POINTER(c_void_p), c_int]),
     "dpx_admm_unrolled_hist_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -301,7 +301,8 @@ class FusedSplitCG:
         return x, v, u
 
 
-_CHAIN_STREAMS = {}          # device index -> side streams of the sub-batch chains
+_CHAIN_STREAMS = {}          # device index -> candidate side streams of the sub-batch chains
+_CHAIN_CHOICE = {}           # (device index, caller's stream, n) -> the n side streams that overlap with it (None: there are none)
 _chain_spec_bytes = {}       # (B, C, H, W, chains) -> bytes of one spectrum buffer per chain
 _chain_tab_cache = {}        # (id(table), b0, b1) -> (table, version, contiguous [T, b1 - b0] copy): the schedule tables are cached objects themselves
 
@@ -319,25 +320,48 @@ def _chain_table(tab, b0, b1):
     return out
 
 
+def _concurrent_side_streams(dev, main_handle, n):
+    """n streams of the device whose kernels overlap with the caller's stream and with each other, or None.  HIP multiplexes streams onto
+    a few hardware queues (GPU_MAX_HW_QUEUES, default 4) in creation order and streams on one queue run strictly one after the other:
+    whether a new stream shares the caller's queue depends on what else created streams before (with RCCL initialised the first side
+    stream did: the chains serialised, 5500 -> 4300 it/s).  So the streams are CHOSEN: candidates are probed with dpx_streams_concurrent
+    (~1 ms each, drains the streams) once per (device, caller's stream) and the choice is kept."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, main_handle, n)
+    if key in _CHAIN_CHOICE:
+        return _CHAIN_CHOICE[key]
+    pool = _CHAIN_STREAMS.setdefault(idx, [])
+    L = be.lib()
+    chosen = []
+    for k in range(8):                                        # (at most 8 candidates: twice the default number of hardware queues)
+        if k >= len(pool):
+            pool.append(torch.cuda.Stream(device=dev))
+        cand = pool[k]
+        others = [main_handle] + [c.cuda_stream for c in chosen]
+        if all(L.query("dpx_streams_concurrent", ctypes.c_void_p(o), ctypes.c_void_p(cand.cuda_stream)) == 1 for o in others):
+            chosen.append(cand)
+            if len(chosen) == n:
+                break
+    _CHAIN_CHOICE[key] = chosen if len(chosen) == n else None
+    return _CHAIN_CHOICE[key]
+
+
 def chain_streams(dev, chains):
-    """(the caller's current stream, chains - 1 side streams) of a device; side streams are created once per process and device"""
+    """(the caller's current stream, chains - 1 side streams that overlap with it) of a device, or None when the device has no such
+    streams left (the caller then runs one chain)"""
     main = torch.cuda.current_stream(dev)
-    side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
-    while len(side) < chains - 1:
-        side.append(torch.cuda.Stream(device=dev))
-    return main, list(side[:chains - 1])
+    side = _concurrent_side_streams(dev, main.cuda_stream, chains - 1)
+    return None if side is None else (main, list(side))
 
 
 def chain_stream_handles(dev, chains):
     """raw handles [caller's current stream, side streams ...] for the C ABI; [None] * chains on the CPU emulator (the chains then
-    run one after the other)"""
+    run one after the other); None when no overlapping side streams exist"""
     if be.host_mode():
         return [None] * chains
-    h = be.stream()
-    side = _CHAIN_STREAMS.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
-    while len(side) < chains - 1:                             # (created once per process and device: a stream costs milliseconds)
-        side.append(torch.cuda.Stream(device=dev))
-    return [h.value or 0] + [st.cuda_stream for st in side[:chains - 1]]      # (0: the null stream)
+    h = be.stream().value or 0                                # (0: the null stream)
+    side = _concurrent_side_streams(dev, h, chains - 1)
+    return None if side is None else [h] + [st.cuda_stream for st in side]
 
 
 def chain_bounds(B, chains, c):
@@ -396,6 +420,8 @@ class FusedADMM:
         chains = 1
         if callback is None and not pbar and not vxu and torch.is_tensor(x0) and (x0.is_cuda or be.host_mode()):
             chains = sub_batch_chains(B, C, H, W)
+            if chains > 1 and chain_stream_handles(dev, chains) is None:      # (no second hardware queue to run on)
+                chains = 1
         fresh = dual and not vxu and fresh_state(s, state)
         lazy = fresh and getattr(s, "_fresh_lazy", False)
         if lazy and (want_grad or T <= 0 or len(psi) == 0):     # (a path that reads the split variables)
@@ -559,6 +585,8 @@ class FusedADMM:
         ops.admm_zupdate(x, terms, n)
         # seed: row transform of rho_0 sum K^T (v - u'), then q = u' - v in place of u'
         chains = sub_batch_chains(B, C, H, W) if (x.is_cuda or be.host_mode()) else 1
+        if chains > 1 and chain_stream_handles(dev, chains) is None:
+            chains = 1
         dd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
         if chains > 1:
             # sub-batch chains (_run_chains): every chain seeds from its images of (v, u') and walks its own spectrum buffers

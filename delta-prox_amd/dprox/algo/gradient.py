@@ -65,11 +65,12 @@ class ProximalGradientDescent(Algorithm):
         from .. import _backend as be
         C, H, W = (int(d) for d in x.shape[1:])
         chains = fused.sub_batch_chains(B, C, H, W) if (x.is_cuda and (ktb is None or ktb.shape == x.shape)) else 1
-        if chains <= 1:
+        streams = fused.chain_streams(x.device, chains) if chains > 1 else None
+        if streams is None:
             ops.pgd_run(x, ktb, gram, kind, float(self.prox_fn.alpha), rho_tab, lam_tab, max_iter)
         else:
             # independent sub-batch chains on separate streams (fused.FusedADMM._run_chains: one chain's column pass beside the other's row pass)
-            main, side = fused.chain_streams(x.device, chains)
+            main, side = streams
             L = be.lib()
             L.call("dpx_admm_iter_share", chains)
             try:

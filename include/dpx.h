@@ -426,6 +426,9 @@ int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const void* dd, in
                         int total_iters, int emit_last, int C, int H, int W, const void* table);
 /* fork / join of the chains' streams (events cached per host thread and device): every to[i] waits for what has been issued on `from` /
  * `into` waits for what has been issued on every from[i]; entries equal to the other side are skipped */
+/* 1 if kernels on the two streams overlap, 0 if the streams share a hardware queue (HIP multiplexes streams onto GPU_MAX_HW_QUEUES
+ * queues: streams on one queue run strictly one after the other), < 0 on error.  A ~1 ms probe that drains both streams first. */
+int dpx_streams_concurrent(dpx_stream_t a, dpx_stream_t b);
 int dpx_stream_fork(dpx_stream_t from, const dpx_stream_t* to, int n);
 int dpx_stream_join(dpx_stream_t into, const dpx_stream_t* from, int n);
 
