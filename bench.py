@@ -484,6 +484,8 @@ def main():
     #      covers the whole batch and has the GPU to itself, which is what `roofline` and `kernels` describe.
     from dprox.algo import fused as _fused
     chains_used = _fused.sub_batch_chains(B, C, H, W)
+    if chains_used > 1 and _fused.chain_stream_handles(device, chains_used) is None:      # (no second hardware queue: the library runs one chain)
+        chains_used = 1
     rhos_k, lams_k = sched[K]
     chains_env = os.environ.get("DPX_CHAINS")
     os.environ["DPX_CHAINS"] = "1"
