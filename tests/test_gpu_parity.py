@@ -502,3 +502,37 @@ def test_streaming_row_kernel_wait_counts_stress(W):
                 assert float((a - c).abs().max()) <= tol * max(float(c.abs().max()), 1.0), (W, H, B, C, terms, float((a - c).abs().max()))
     finally:
         L.call("dpx_admm_iter_config", 0, 0)
+
+
+def test_chain_streams_are_probed_for_overlap_and_missing_ones_fall_back():
+    """dpx_streams_concurrent: a stream against itself is 0, the side stream chosen for the chains overlaps with the caller's stream (1);
+    with no overlapping stream available (patched) a chained problem runs as one chain with the same result."""
+    import ctypes
+    import synthetic
+    import dprox as dp
+    from dprox import _backend as be
+    from dprox.algo import fused
+    dev = torch.device("cuda", torch.cuda.current_device())
+    L = be.lib()
+    h = be.stream().value or 0
+    assert L.query("dpx_streams_concurrent", ctypes.c_void_p(h), ctypes.c_void_p(h)) == 0
+    handles = fused.chain_stream_handles(dev, 2)
+    assert handles is not None and handles[0] == h and handles[1] != h
+    assert L.query("dpx_streams_concurrent", ctypes.c_void_p(handles[0]), ctypes.c_void_p(handles[1])) == 1
+    gt, b0, psf = synthetic.deconv_case(4, 3, 512, 1024, seed=5)
+    b = torch.from_numpy(b0).to(dev)
+
+    def run():
+        x = dp.Variable()
+        s = dp.compile(dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device=dev)
+        return s.solve(x0=b, rhos=0.2, lams=0.01, max_iter=7)
+    assert fused.sub_batch_chains(4, 3, 512, 1024) == 2
+    ref = run()
+    real = fused._concurrent_side_streams
+    fused._concurrent_side_streams = lambda *a, **k: None
+    try:
+        assert fused.chain_stream_handles(dev, 2) is None
+        one = run()
+    finally:
+        fused._concurrent_side_streams = real
+    assert torch.equal(ref, one)
