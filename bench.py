@@ -504,6 +504,7 @@ def main():
             os.environ["DPX_CHAINS"] = chains_env
     del state2
     # ---- leg 4: a warm 50-iteration solve (tables and data spectrum cached): cold - warm = what a first solve pays for its setup
+    solver.solve(x0=b, rhos=RHO, lams=LAM, max_iter=50)      # (load in front, as for the cold runs of leg 5: the roofline leg's report left the GPU idle)
     barrier()
     t0 = time.perf_counter()
     solver.solve(x0=b, rhos=RHO, lams=LAM, max_iter=50)
