@@ -387,6 +387,23 @@ class FusedADMM:
         self.solver, self.codes = solver, codes
 
     def run(self, state, rhos, lams, max_iter, pbar=False, callback=None, dual=True, vxu=False):
+        """_run, and on an exception behind the chains' seed launches the caller's stream joins the side streams before the chains' buffers
+        are released (a block handed back to the allocator while a side stream still writes it would be given out again)"""
+        self._pending_chains = None
+        try:
+            return self._run(state, rhos, lams, max_iter, pbar, callback, dual, vxu)
+        except BaseException:
+            pre = self._pending_chains
+            if pre is not None:
+                try:
+                    ops.stream_join(pre["handles"][0], pre["handles"])
+                except Exception:
+                    pass
+            raise
+        finally:
+            self._pending_chains = None
+
+    def _run(self, state, rhos, lams, max_iter, pbar=False, callback=None, dual=True, vxu=False):
         """``dual=False``: half-quadratic splitting (hqs.py:4-20) = the same three stages with the dual variables pinned to
         zero -- state (x, [z_i]); the z-stage's ``u_out`` goes to a scratch buffer and is never read.
         ``vxu=True``: ADMM in the order v, x, u (admm.py:103-120) on the same stages: with u' = -u the split update is
@@ -798,6 +815,8 @@ class FusedADMM:
             work.append(dict(b0=b0, b1=b1, shape=(b1 - b0, C, H, W), terms=terms, rho=_chain_table(rho_tab, b0, b1),
                              SA=pool[off:off + pad[c]], SB=pool[off + pad[c]:off + 2 * pad[c]], stream=handles[c]))
             off += 2 * pad[c]
+        pre = dict(work=work, handles=handles, pool=pool)
+        self._pending_chains = pre                             # (run() joins the streams if anything below or behind raises)
         L.call("dpx_admm_iter_share", chains)
         try:
             ops.stream_fork(handles[0], handles)                 # (the chains read x0 / the state: produced on the caller's stream)
@@ -806,7 +825,7 @@ class FusedADMM:
                                    stream=None if wk["stream"] is None else ctypes.c_void_p(wk["stream"]))
         finally:
             L.call("dpx_admm_iter_share", 1)
-        return dict(work=work, handles=handles, pool=pool)
+        return pre
 
     def _run_chains(self, x0, dev, T, n, v, u, x, FK, diag, rho_tab, lam_tab, dual, fresh, chains, pre):
         """The two-kernel iteration as `chains` independent sub-batch chains on separate HIP streams.  The iteration acts per image
