@@ -639,6 +639,11 @@ def admm_run(spec_a, spec_b, spec_add, dd, term_arr, nterms, rho_tab, lam_tabs, 
     return rc
 
 
+def _addr(t):
+    """device address of a tensor, or the address itself"""
+    return t if isinstance(t, int) else t.data_ptr()
+
+
 def admm_run_chains(chains, dd, nterms, eps, it0, n_iters, total, emit_last, shape, device):
     """dpx_admm_run for several sub-batch chains at once.  chains: dicts with spec_a, spec_b, spec_add (tensor / None), terms (ctypes
     array), rho_tab, lam_tabs (tensors), x_out, B, stream (raw handle), optionally seed (0 / 1 / 2) and seed_x0.  Returns the dual-buffer parity."""
@@ -648,16 +653,16 @@ def admm_run_chains(chains, dd, nterms, eps, it0, n_iters, total, emit_last, sha
     for i, ch in enumerate(chains):
         lt = (c_void_p * nterms)(*[None if t is None else t.data_ptr() for t in ch["lam_tabs"]])
         keep.append(lt)
-        arr[i].spec_a, arr[i].spec_b = ch["spec_a"].data_ptr(), ch["spec_b"].data_ptr()
-        arr[i].spec_add = None if ch["spec_add"] is None else ch["spec_add"].data_ptr()
+        arr[i].spec_a, arr[i].spec_b = _addr(ch["spec_a"]), _addr(ch["spec_b"])
+        arr[i].spec_add = None if ch["spec_add"] is None else _addr(ch["spec_add"])
         arr[i].terms = ctypes.cast(ch["terms"], ctypes.POINTER(Term))
         arr[i].rho_tab = ch["rho_tab"].data_ptr()
         arr[i].lam_tabs = ctypes.cast(lt, ctypes.POINTER(c_void_p))
-        arr[i].x_out = ch["x_out"].data_ptr()
+        arr[i].x_out = _addr(ch["x_out"])
         arr[i].B = int(ch["B"])
         arr[i].stream = ch["stream"]
         arr[i].seed = int(ch.get("seed", 0))
-        arr[i].seed_x0 = None if ch.get("seed_x0") is None else ch["seed_x0"].data_ptr()
+        arr[i].seed_x0 = None if ch.get("seed_x0") is None else _addr(ch["seed_x0"])
     L = be.lib()
     rc = L.query("dpx_admm_run_chains", arr, len(chains), ptr(dd), nterms, c_float(eps), it0, n_iters, total, int(emit_last), C, H, W,
                  ptr(fft_table(H, W, device)))

@@ -301,6 +301,20 @@ class FusedSplitCG:
         return x, v, u
 
 
+_TRACE = bool(os.environ.get("DPX_TRACE_HOST"))      # tuning: host-side time stamps of run() (microseconds since entry) on stderr
+_trace_t0 = [0.0]
+
+
+def _tr(tag):
+    if _TRACE:
+        import sys
+        import time
+        now = time.perf_counter()
+        if tag == "enter":
+            _trace_t0[0] = now
+        sys.stderr.write(f"[dpx host] {tag:18s} {1e6 * (now - _trace_t0[0]):8.1f} us\n")
+
+
 _CHAIN_STREAMS = {}          # device index -> candidate side streams of the sub-batch chains
 _CHAIN_CHOICE = {}           # (device index, caller's stream, n) -> the n side streams that overlap with it (None: there are none)
 _chain_spec_bytes = {}       # (B, C, H, W, chains) -> bytes of one spectrum buffer per chain
@@ -408,6 +422,7 @@ class FusedADMM:
         zero -- state (x, [z_i]); the z-stage's ``u_out`` goes to a scratch buffer and is never read.
         ``vxu=True``: ADMM in the order v, x, u (admm.py:103-120) on the same stages: with u' = -u the split update is
         prox(K z + u') (z stage, its dual output discarded), the x-update sees v - u', and u' <- u' - v + z is one AXPY."""
+        _tr("enter")
         s = self.solver
         ls = s.least_square
         psi = list(s.psi_fns)
@@ -426,6 +441,7 @@ class FusedADMM:
             return state
 
         rho_tab = schedule_table(rhos, T, B, dev)
+        _tr("rho table")
         raw_offs = [self._offset_autograd(fn, x0) for fn in s.omega_fns]
         trained_psfs = [cv.psf for cv in map(_omega_conv, s.omega_fns)
                         if isinstance(cv, conv_doe) and cv.circular and isinstance(cv.psf, torch.Tensor) and cv.psf.requires_grad]
@@ -433,6 +449,7 @@ class FusedADMM:
         # The two-kernel iteration starts from the row-transformed right-hand side rho_0 sum K_i^T (v_i - u_i): that pass needs
         # nothing but the state, so it is launched FIRST and the rest of the host-side preparation (schedule tables, data spectrum,
         # denominators, workspaces: ~0.1 ms) runs while the GPU is already busy instead of in front of it.
+        _tr("grad checks")
         seeded = None
         chains = 1
         if callback is None and not pbar and not vxu and torch.is_tensor(x0) and (x0.is_cuda or be.host_mode()):
@@ -457,6 +474,7 @@ class FusedADMM:
                 else:
                     seeded = ops.admm_seed_rows(ops.spectrum_buffer(B * C, H, W, dev), rho_tab[0], early, len(psi), x0.shape, dev,
                                                 fresh_x=x0 if fresh else None)
+        _tr("seeds issued")
         if not isinstance(seeded, dict):
             chains = 1
         if lazy and seeded is None:                           # (cannot happen for a state lazy_initial_state handed out; kept as a guard)
@@ -469,8 +487,11 @@ class FusedADMM:
             lam_tab.append(_sigma_table(fn, lt) if isinstance(fn, deep_prior) else lt)     # deep priors: the table holds sigma
         # data spectrum F(sum_Omega K^T b): fp64 transform, kept in the Fourier domain, recomputed only when an
         # offset (the observation b) changes
+        _tr("lam tables")
         FK = self._data_spectrum(x0, chains)
+        _tr("data spectrum")
         (t0, c0), (t1, c1) = ls.diag_tables(x0.shape, dev, True)
+        _tr("diag tables")
 
         # ---- differentiable (unrolled-training) mode: hand-written backward stages, autodiff.py -------------------
         if want_grad:
@@ -533,6 +554,7 @@ class FusedADMM:
             if not dual:                                         # half-quadratic splitting: the same two kernels with the duals counted as zero
                 for i in range(n):
                     terms[i].reserved = be.TERM_NO_DUAL
+            _tr("terms built")
             if chains > 1:
                 return self._run_chains(x0, dev, T, n, v, u, x, FK, (t0, c0, t1, c1), rho_tab, lam_tab, dual, fresh, chains, seeded)
             return self._run_two_kernel(x0.shape, dev, T, terms, n, v, u, x, rhs, FK, (t0, c0, t1, c1), rho_tab, lam_tab,
@@ -807,22 +829,35 @@ class FusedADMM:
                                              for c in range(chains)]
         pad = [(sz + 255) // 256 * 256 for sz in sizes]
         pool = ops._bytes(2 * sum(pad), dev)                    # the 2 x chains spectrum buffers in one allocation
+        # (addresses by arithmetic: a tensor slice costs ~3 us of host time, and this runs in front of the first launch)
+        n = len(psi)
+        img = C * H * W * 4                                    # bytes per image of the fp32 state
+        pbase, x0p = pool.data_ptr(), x0.data_ptr()
+        vps, ups = [t.data_ptr() for t in v], [t.data_ptr() for t in u]
         work, off = [], 0
         for c in range(chains):
             b0, b1 = chain_bounds(B, chains, c)
-            terms = ops.make_terms([dict(linop=lc, prox=pc, alpha=float(fn.alpha), lam=None, v=v[i][b0:b1], u=u[i][b0:b1])
-                                    for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes))])
+            terms = (ops.Term * n)()
+            for i, (fn, (lc, pc)) in enumerate(zip(psi, self.codes)):
+                tm = terms[i]
+                tm.linop, tm.prox, tm.alpha = lc, pc, float(fn.alpha)
+                tm.v, tm.u = vps[i] + b0 * img, ups[i] + b0 * img
             work.append(dict(b0=b0, b1=b1, shape=(b1 - b0, C, H, W), terms=terms, rho=_chain_table(rho_tab, b0, b1),
-                             SA=pool[off:off + pad[c]], SB=pool[off + pad[c]:off + 2 * pad[c]], stream=handles[c]))
+                             SA=pbase + off, SB=pbase + off + pad[c], stream=handles[c]))
             off += 2 * pad[c]
         pre = dict(work=work, handles=handles, pool=pool)
         self._pending_chains = pre                             # (run() joins the streams if anything below or behind raises)
+        table = ops.ptr(ops.fft_table(H, W, dev))
         L.call("dpx_admm_iter_share", chains)
         try:
             ops.stream_fork(handles[0], handles)                 # (the chains read x0 / the state: produced on the caller's stream)
             for wk in work:
-                ops.admm_seed_rows(wk["SA"], wk["rho"][0], wk["terms"], len(psi), wk["shape"], dev, fresh_x=x0[wk["b0"]:wk["b1"]] if fresh else None,
-                                   stream=None if wk["stream"] is None else ctypes.c_void_p(wk["stream"]))
+                st = None if wk["stream"] is None else ctypes.c_void_p(wk["stream"])
+                if fresh:
+                    L.call("dpx_admm_seed_rows_fresh", ctypes.c_void_p(wk["SA"]), ops.ptr(wk["rho"]), ctypes.c_void_p(x0p + wk["b0"] * img), wk["terms"], n,
+                           wk["b1"] - wk["b0"], C, H, W, table, st)
+                else:
+                    L.call("dpx_admm_seed_rows", ctypes.c_void_p(wk["SA"]), ops.ptr(wk["rho"]), wk["terms"], n, wk["b1"] - wk["b0"], C, H, W, table, st)
         finally:
             L.call("dpx_admm_iter_share", 1)
         return pre
@@ -845,23 +880,30 @@ class FusedADMM:
             u_cur, u_nxt = list(u), [torch.empty_like(t) for t in u]
         else:
             u_cur, u_nxt = list(u), [torch.zeros_like(u[0])] * n
+        _tr("chains: dd, u_nxt")
         work, handles = pre["work"], pre["handles"]
+        img = C * H * W * 4
+        vps, ups, uns, xp = [t.data_ptr() for t in v], [t.data_ptr() for t in u_cur], [t.data_ptr() for t in u_nxt], x.data_ptr()
+        flags = (0 if dual else be.TERM_NO_DUAL) | (be.TERM_U_ZERO if fresh else 0)
         for wk in work:
             b0, b1 = wk["b0"], wk["b1"]
             for i in range(n):
                 tm = wk["terms"][i]
-                tm.v, tm.u, tm.u_out = v[i][b0:b1].data_ptr(), u_cur[i][b0:b1].data_ptr(), u_nxt[i][b0:b1].data_ptr()
-                tm.reserved = (0 if dual else be.TERM_NO_DUAL) | (be.TERM_U_ZERO if fresh else 0)
+                tm.v, tm.u, tm.u_out = vps[i] + b0 * img, ups[i] + b0 * img, uns[i] + b0 * img
+                tm.reserved = flags
             wk["lam"] = [_chain_table(lt, b0, b1) for lt in lam_tab]
+            wk["x_out"] = xp + b0 * img
         L = be.lib()
         L.call("dpx_admm_iter_share", chains)
         try:
             # what the caller's stream produced since the seeds were launched (data spectrum, denominators, table slices) is input of every chain
+            _tr("chains: terms")
             ops.stream_fork(handles[0], handles)
             # one C call issues every iteration of every chain, chain by chain within an iteration
             par = ops.admm_run_chains([dict(spec_a=wk["SA"], spec_b=wk["SB"], spec_add=fk, terms=wk["terms"], rho_tab=wk["rho"], lam_tabs=wk["lam"],
-                                            x_out=x[wk["b0"]:wk["b1"]], B=wk["b1"] - wk["b0"], stream=wk["stream"]) for wk, fk in zip(work, FK)],
+                                            x_out=wk["x_out"], B=wk["b1"] - wk["b0"], stream=wk["stream"]) for wk, fk in zip(work, FK)],
                                       dd, n, eps, 0, T, T, 2 if x_only else 1, x0.shape, dev)
+            _tr("chains: loop issued")
             ops.stream_join(handles[0], handles)                 # (every buffer of the chains stays alive until here: pre["pool"], u_nxt)
         finally:
             L.call("dpx_admm_iter_share", 1)
