@@ -385,13 +385,14 @@ def chain_bounds(B, chains, c):
 
 def sub_batch_chains(B, C, H, W):
     """how many independent sub-batch chains the two-kernel iteration of a [B,C,H,W] problem is run as (FusedADMM._run_chains): 2 when
-    each half still fills the GPU by itself (measured on 8x3x1024^2; small problems are latency-bound and stay one chain).
+    each half still fills the GPU by itself (measured on 2 ... 16 images of 1 ... 3 x 512^2 ... 1024^2, tools/concurrent_probe.py,
+    tools/odd_probe.py; small problems are latency-bound and stay one chain).
     DPX_CHAINS=n forces n (1 = off)."""
     env = os.environ.get("DPX_CHAINS")
     if env:
         n = max(1, int(env))
         return n if B >= n else 1
-    if B % 2 == 0 and W in (256, 512, 1024) and (B // 2) * C * H * W >= (3 << 20):
+    if B >= 2 and W in (256, 512, 1024) and (B // 2) * C * H * W >= (3 << 20):      # (odd batches split unevenly: 3 / 5 / 7 images of 3x1024^2 gain 10 - 13 % too)
         return 2
     return 1
 

@@ -1,0 +1,30 @@
+import os, sys, time
+sys.path[:0] = ["/root/repo", "/root/repo/delta-prox_amd"]
+import numpy as np, torch
+import dprox as dp, synthetic
+from dprox import _backend as be
+dev = torch.device("cuda", 0)
+psf = synthetic.point_spread_function(15, 5.0)
+N = 100
+def problem(B, C, H, W):
+    rng = np.random.RandomState(2023)
+    gt = torch.from_numpy(synthetic.synth(rng, B, C, H, W)).to(dev)
+    b = (dp.conv(dp.Variable(), psf).to(dev).forward(gt)).contiguous()
+    x = dp.Variable()
+    s = dp.compile(dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device=dev)
+    _, rhos, lams, _ = s.defaults(b, 0.1, 0.005, N)
+    return s, b, rhos.to(dev), {k: v.to(dev) for k, v in lams.items()}
+def run(s, b, rs, ls, chains):
+    os.environ["DPX_CHAINS"] = str(chains)
+    s.iters(s.initialize(b), rs[..., :4].contiguous(), {k: v[..., :4].contiguous() for k, v in ls.items()}, 4)
+    best = None
+    for rep in range(3):
+        st = s.initialize(b); torch.cuda.synchronize(); t0 = time.perf_counter()
+        s.iters(st, rs, ls, N); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return 1e3 * best / N
+for shape in ((3, 3, 1024, 1024), (5, 3, 1024, 1024), (7, 3, 1024, 1024), (9, 3, 1024, 1024), (5, 3, 512, 1024), (7, 1, 1024, 1024), (15, 3, 512, 512)):
+    s, b, rs, ls = problem(*shape)
+    a = run(s, b, rs, ls, 1); c = run(s, b, rs, ls, 2)
+    print(shape, f"1 chain {a:.4f}  2 chains {c:.4f}  ratio {c/a:.3f}", flush=True)
+    del s, b, rs, ls
