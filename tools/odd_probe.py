@@ -23,8 +23,11 @@ def run(s, b, rs, ls, chains):
         s.iters(st, rs, ls, N); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     return 1e3 * best / N
-for shape in ((3, 3, 1024, 1024), (5, 3, 1024, 1024), (7, 3, 1024, 1024), (9, 3, 1024, 1024), (5, 3, 512, 1024), (7, 1, 1024, 1024), (15, 3, 512, 512)):
+big = len(sys.argv) > 1 and sys.argv[1] == "big"
+shapes = ((12, 3, 1024, 1024), (16, 3, 1024, 1024), (32, 3, 512, 512), (24, 1, 1024, 1024)) if big else \
+    ((3, 3, 1024, 1024), (5, 3, 1024, 1024), (7, 3, 1024, 1024), (9, 3, 1024, 1024), (5, 3, 512, 1024), (7, 1, 1024, 1024), (15, 3, 512, 512))
+for shape in shapes:
     s, b, rs, ls = problem(*shape)
-    a = run(s, b, rs, ls, 1); c = run(s, b, rs, ls, 2)
-    print(shape, f"1 chain {a:.4f}  2 chains {c:.4f}  ratio {c/a:.3f}", flush=True)
+    res = {n: run(s, b, rs, ls, n) for n in ((1, 2, 3, 4) if big else (1, 2))}
+    print(shape, "  ".join(f"{n} chain(s) {v:.4f} ({v / res[1]:.3f})" for n, v in res.items()), flush=True)
     del s, b, rs, ls
