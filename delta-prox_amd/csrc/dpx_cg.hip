@@ -279,11 +279,11 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   //      direction update in the first one's load and <p, Ap> in the last one's store; the x / r update) instead of 10, and one
   //      launch instead of seven in front of the loop.  The partial sums of a launch are finished by its LAST workgroup to arrive
   //      (dpx_last_block: no workgroup waits for another); same state machine, same exit iteration.
-  static const bool unfused = getenv("DPX_CG_UNFUSED") != nullptr;      // (A/B and tests: the step-by-step sequence below)
-  static const bool split_update = getenv("DPX_CG_SPLIT_UPDATE") != nullptr;      // (A/B: the 5-launch form with its own update kernel and a flag transfer)
+  const bool unfused = tune(TUNE_CG_UNFUSED) != 0;      // (A/B and tests: the step-by-step sequence below)
+  const bool split_update = tune(TUNE_CG_SPLIT_UPDATE) != 0;      // (A/B: the 5-launch form with its own update kernel and a flag transfer)
   // (the kernels hold up to 32 residuals, DPX_CG_FUSED_MAX_B: measured at 16 / 32 images of 320^2: 2.28 / 4.64 ms per outer iteration
   //  against 2.25 / 4.08 on the step-by-step sequence -- the Gram pass with its finish in one workgroup stops paying beyond 8)
-  static const int fused_max_b = getenv("DPX_CG_FUSED_MAX_B") ? atoi(getenv("DPX_CG_FUSED_MAX_B")) : 8;
+  const int fused_max_b = tune(TUNE_CG_FUSED_MAX_B);
   if (B <= (fused_max_b > 32 ? 32 : fused_max_b) && !unfused) {
     float* fdot = (float*)((char*)dotws + dpx_bdot_ws_bytes(B, n));
     unsigned* counters = (unsigned*)(fdot + dpx::masked_normal_fused_ws_floats(B, H, W));

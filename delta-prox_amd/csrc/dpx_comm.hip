@@ -128,7 +128,7 @@ extern "C" int dpx_comm_allgather(void* comm, const void* send, void* recv, size
   Comm* C = (Comm*)comm;
   if (!bytes_per_rank) return DPX_OK;
   Rccl* R = rccl();
-  static const bool ring = getenv("DPX_COMM_ALLGATHER") && !strcmp(getenv("DPX_COMM_ALLGATHER"), "ring");
+  const bool ring = dpx::tune(dpx::TUNE_COMM_ALLGATHER_RING) != 0;
   if (ring || C->world == 1) {
     const int rc = R->AllGather(send, recv, bytes_per_rank, RCCL_INT8, C->c, (hipStream_t)stream);
     return rc ? fail("dpx_comm_allgather", rc) : DPX_OK;

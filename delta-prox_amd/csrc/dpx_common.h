@@ -87,6 +87,15 @@ namespace dpx {
 void set_error(const char* fmt, ...);
 int launch_status(const char* what);   // hipGetLastError() -> DPX_OK / DPX_ERR_LAUNCH
 
+// ---- tuning knobs (dpx_tune_set / dpx_tune_get of the C ABI; dpx_core.hip holds the table, include/dpx.h documents it) ----------
+enum Tune {
+  TUNE_CG_FUSED_MAX_B, TUNE_CG_SPLIT_UPDATE, TUNE_CG_UNFUSED, TUNE_CG_GRAM_BLOCKS, TUNE_PSF2OTF_DIRECT, TUNE_COMM_ALLGATHER_RING,
+  TUNE_HQS_STREAM_DUALS, TUNE_PGD_BAND, TUNE_PGD_ROWS_PLAIN, TUNE_SEED_BAND, TUNE_SEED_ROWS_PLAIN, TUNE_ITER_W2048, TUNE_ITER_ROWS,
+  TUNE_ITER_BAND, TUNE_ITER_R, TUNE_COLS_INPLACE, TUNE_CHAIN_LOCKSTEP, TUNE_DS_CT, TUNE_DS_RPB, TUNE_DS_ROW_THREADS,
+  TUNE_DS_COL_THREADS, TUNE_COLS_PERSIST_WG, TUNE_DEBUG_COLS, TUNE_COUNT
+};
+int tune(Tune k);
+
 // ---- optional per-kernel timing (bench.py's roofline leg) ------------------------------------------------
 // With timing on, a launch goes through hipExtLaunchKernelGGL with a start / stop event pair attached to the kernel's
 // own dispatch packet: their elapsed time is the kernel's execution time (the dispatch timestamps rocprofv3's kernel

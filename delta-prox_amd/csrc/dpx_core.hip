@@ -1,7 +1,11 @@
 // Error plumbing + version of libdpx_hip.so.
 #include "dpx_common.h"
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -125,5 +129,101 @@ extern "C" int dpx_streams_concurrent(dpx_stream_t a, dpx_stream_t b) {
 #endif
 }
 
-extern "C" int dpx_version(void) { return 100; }
+// ---- tuning knobs -----------------------------------------------------------------------------------------------------------
+// One registry for every switch that selects between kernel variants / launch geometries (A/B timing, tests that must reach a
+// particular branch).  Part of the C ABI (dpx_tune_set / dpx_tune_get / dpx_tune_name, include/dpx.h holds the table): settable per
+// process at run time, readable back, so a test can drive both branches of a dispatcher in one process.  The environment variable
+// named next to a knob only supplies its INITIAL value (read once, at the first access of the registry).
+namespace dpx {
+namespace {
+struct KnobDef { const char* name; const char* env; int def; const char* env_word; };   // env_word: a string value of `env` that means 1 / 2
+const KnobDef kKnobs[TUNE_COUNT] = {
+    {"cg_fused_max_b", "DPX_CG_FUSED_MAX_B", 8, nullptr},
+    {"cg_split_update", "DPX_CG_SPLIT_UPDATE", 0, nullptr},
+    {"cg_unfused", "DPX_CG_UNFUSED", 0, nullptr},
+    {"cg_gram_blocks", "DPX_CGF_GRAM_BLOCKS", 0, nullptr},
+    {"psf2otf_direct", "DPX_PSF2OTF_DIRECT", 0, nullptr},
+    {"comm_allgather_ring", "DPX_COMM_ALLGATHER", 0, "ring"},
+    {"hqs_stream_duals", "DPX_HQS_STREAM_DUALS", 0, nullptr},
+    {"pgd_band", "DPX_PGD_BAND", 0, nullptr},
+    {"pgd_rows_plain", "DPX_PGD_ROWS", 0, "plain"},
+    {"seed_band", "DPX_SEED_BAND", 0, nullptr},
+    {"seed_rows_plain", "DPX_SEED_ROWS", 0, "plain"},
+    {"iter_w2048", "DPX_ITER_W2048", 0, nullptr},
+    {"iter_rows", "DPX_ITER_ROWS", 0, "seq,lockstep"},
+    {"iter_band", "DPX_ITER_BAND", 0, nullptr},
+    {"iter_r", "DPX_ITER_R", 0, nullptr},
+    {"cols_inplace", "DPX_COLS_INPLACE", 0, nullptr},
+    {"chain_lockstep", "DPX_CHAIN_LOCKSTEP", 0, nullptr},
+    {"ds_ct", "DPX_DS_CT", 0, nullptr},
+    {"ds_rpb", "DPX_DS_RPB", 0, nullptr},
+    {"ds_row_threads", "DPX_DS_ROW_THREADS", 0, nullptr},
+    {"ds_col_threads", "DPX_DS_COL_THREADS", 0, nullptr},
+    {"cols_persist_wg", "DPX_COLS_PERSIST_WG", 0, nullptr},
+    {"debug_cols", "DPX_DEBUG_COLS", 0, nullptr},
+};
+std::atomic<int> g_knob[TUNE_COUNT];
+std::once_flag g_knob_once;
+void knobs_init() {
+  for (int i = 0; i < TUNE_COUNT; ++i) {
+    int v = kKnobs[i].def;
+    const char* e = getenv(kKnobs[i].env);
+    if (e) {
+      if (kKnobs[i].env_word) {                       // "word" -> 1, "w1,w2" -> 1 / 2
+        v = 0;
+        const char* w = kKnobs[i].env_word;
+        int idx = 1;
+        while (*w) {
+          const char* c = strchr(w, ',');
+          const size_t len = c ? (size_t)(c - w) : strlen(w);
+          if (strlen(e) == len && !strncmp(e, w, len)) v = idx;
+          ++idx;
+          w += len + (c ? 1 : 0);
+        }
+      } else {
+        v = *e ? atoi(e) : 1;                         // a flag-style variable set to the empty string counts as on
+        if (v == 0 && *e && (e[0] < '0' || e[0] > '9') && e[0] != '-') v = 1;
+      }
+    }
+    g_knob[i].store(v, std::memory_order_relaxed);
+  }
+}
+}  // namespace
+int tune(Tune k) {
+  std::call_once(g_knob_once, knobs_init);
+  return g_knob[k].load(std::memory_order_relaxed);
+}
+}  // namespace dpx
+
+extern "C" int dpx_tune_count(void) { return dpx::TUNE_COUNT; }
+extern "C" const char* dpx_tune_name(int i) { return i >= 0 && i < dpx::TUNE_COUNT ? dpx::kKnobs[i].name : nullptr; }
+static int knob_index(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < dpx::TUNE_COUNT; ++i)
+    if (!strcmp(name, dpx::kKnobs[i].name)) return i;
+  return -1;
+}
+extern "C" int dpx_tune_set(const char* name, int value) {
+  const int i = knob_index(name);
+  DPX_REQUIRE(i >= 0, "dpx_tune_set: unknown knob '%s'", name ? name : "(null)");
+  std::call_once(dpx::g_knob_once, dpx::knobs_init);
+  dpx::g_knob[i].store(value, std::memory_order_relaxed);
+  return DPX_OK;
+}
+extern "C" int dpx_tune_get(const char* name, int* value) {
+  const int i = knob_index(name);
+  DPX_REQUIRE(i >= 0 && value, "dpx_tune_get: unknown knob '%s'", name ? name : "(null)");
+  *value = dpx::tune((dpx::Tune)i);
+  return DPX_OK;
+}
+// the CG solver's switches as one typed call (a negative argument leaves that switch as it is)
+extern "C" int dpx_cg_config(int fused_max_b, int split_update, int unfused) {
+  DPX_REQUIRE(fused_max_b <= 32, "dpx_cg_config: the fused CG iteration holds at most 32 systems (got %d)", fused_max_b);
+  if (fused_max_b >= 0) dpx_tune_set("cg_fused_max_b", fused_max_b);
+  if (split_update >= 0) dpx_tune_set("cg_split_update", split_update ? 1 : 0);
+  if (unfused >= 0) dpx_tune_set("cg_unfused", unfused ? 1 : 0);
+  return DPX_OK;
+}
+
+extern "C" int dpx_version(void) { return 101; }
 extern "C" const char* dpx_last_error(void) { return dpx::g_err; }

@@ -934,7 +934,7 @@ static size_t ds_ld(int n) { return (size_t)n + n / 8 + 1; }      // padded LDS 
 static int ds_ct(int H) {
   // two columns per workgroup (256 threads, two workgroups per CU: one loads while the other transforms) beat four (512 threads, one per
   // CU) at 8x3x1024^2: column pass 234 vs 267 us, row pass 164 vs 156 us (64-byte instead of 128-byte pieces); DPX_DS_CT=4 forces four
-  static const int env = getenv("DPX_DS_CT") ? atoi(getenv("DPX_DS_CT")) : 0;
+  const int env = tune(TUNE_DS_CT);
   if (env == 4 && 4 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024) return 4;
   return 2 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 2 : 0;
 }
@@ -957,8 +957,7 @@ extern "C" int dpx_data_spectrum(const float* b, const void* otf, int conj_otf, 
   DPX_REQUIRE(b && spec_out && ws, "dpx_data_spectrum: null pointer");
   DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_data_spectrum: bad shape");
   const int P = B * C, Wh = W / 2 + 1;
-  static const int env_rpb = getenv("DPX_DS_RPB") ? atoi(getenv("DPX_DS_RPB")) : 0, env_rt = getenv("DPX_DS_ROW_THREADS") ? atoi(getenv("DPX_DS_ROW_THREADS")) : 0,
-                   env_ct = getenv("DPX_DS_COL_THREADS") ? atoi(getenv("DPX_DS_COL_THREADS")) : 0;     // tuning
+  const int env_rpb = tune(TUNE_DS_RPB), env_rt = tune(TUNE_DS_ROW_THREADS), env_ct = tune(TUNE_DS_COL_THREADS);     // tuning
   const int CT = ds_ct(H);
   int rpb = ds_rpb(W);
   if (env_rpb && env_rpb <= rpb) rpb = env_rpb;

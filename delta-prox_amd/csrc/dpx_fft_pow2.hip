@@ -768,7 +768,7 @@ static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A,
   int grid = total_blocks;
 #if DPX_COLS_PERSIST
   {
-    static const int per_cu_env = getenv("DPX_COLS_PERSIST_WG") ? atoi(getenv("DPX_COLS_PERSIST_WG")) : 0;
+    const int per_cu_env = tune(TUNE_COLS_PERSIST_WG);
     const int cap = 256 * (per_cu_env ? per_cu_env : DPX_COLS_PERSIST);
     if (grid > cap) grid = cap;
   }
@@ -784,8 +784,7 @@ constexpr int COLS_WG = DPX_COLS_WG;   // columns per workgroup of the column ke
 template <int OP>
 static void cols_dispatch(int H, const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
   if (H == 1024 && OP == OP_SOLVE) {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("DPX_DEBUG_COLS"); dbg = e ? atoi(e) : 0; }
+    const int dbg = tune(TUNE_DEBUG_COLS);
     if (dbg == 1) { launch_cols<1024, 64, COLS_WG, OP, 1>(spec, spec_out, A, P, C, Ws, twH, s); return; }
     if (dbg == 2) { launch_cols<1024, 64, COLS_WG, OP, 2>(spec, spec_out, A, P, C, Ws, twH, s); return; }
     if (dbg == 3) { launch_cols<1024, 64, COLS_WG, OP, 3>(spec, spec_out, A, P, C, Ws, twH, s); return; }

@@ -656,7 +656,7 @@ static void launch_iter_rows_seq_d(const float2* sin, float2* sout, const IterTe
 template <int M, int T, int NT>
 static void launch_iter_rows_seq_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
                                     int C, int H, int R, int P, const float2* twW, hipStream_t s) {
-  static const bool keep_dual = getenv("DPX_HQS_STREAM_DUALS") != nullptr;      // (A/B: half-quadratic splitting on the general kernel)
+  const bool keep_dual = tune(TUNE_HQS_STREAM_DUALS) != 0;      // (A/B: half-quadratic splitting on the general kernel)
   // emit_v == 2 (x only: the last pass of a solve() that returns x alone) runs on the no-dual instantiation whatever the solver
   if (emit_v == 2 && x_out && !rho_next) launch_iter_rows_seq_d<M, T, NT, false>(sin, sout, TT, rho_next, x_out, 2, C, H, R, P, twW, s);
   else if (TT.vxu) launch_iter_rows_seq_d<M, T, NT, true, true>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, twW, s);
@@ -845,7 +845,7 @@ static bool launch_pgd_rows_seq(const float2* sin, float2* sout, float* x, const
   int p2 = 1;
   while (p2 < nb) p2 <<= 1;
   nb = 2 * p2;
-  static const int band_env = getenv("DPX_PGD_BAND") ? atoi(getenv("DPX_PGD_BAND")) : 0;
+  const int band_env = tune(TUNE_PGD_BAND);
   if (band_env) nb = band_env;
   if (g_rows_band_pgd > 0) nb = g_rows_band_pgd;
   if (nb > H) nb = H;
@@ -868,7 +868,7 @@ static bool launch_pgd_rows_seq(const float2* sin, float2* sout, float* x, const
 // false: the plane / batch does not fit the streaming kernel (the caller keeps k_pgd_rows)
 bool pgd_rows_seq_pow2(const float2* sin, float2* sout, float* x, const float* ktb, const float* rho, const float* lam, float alpha, int prox, int P,
                        int C, int H, int W, const void* table, hipStream_t s) {
-  static const bool plain = getenv("DPX_PGD_ROWS") && !strcmp(getenv("DPX_PGD_ROWS"), "plain");      // (A/B and tests)
+  const bool plain = tune(TUNE_PGD_ROWS_PLAIN) != 0;      // (A/B and tests)
   if (plain || g_rows_mode_pgd == 2) return false;
   switch (W) {
     case 256: return launch_pgd_rows_seq<128, 16>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
@@ -1035,7 +1035,7 @@ static bool launch_seed_rows_seq(const SeedOps& SO, const float* rho, const floa
   int nb = (256 * 2 * 4 * G) / (P * g_chain_share), p2 = 1;
   while (p2 < nb) p2 <<= 1;
   nb = p2;
-  static const int band_env = getenv("DPX_SEED_BAND") ? atoi(getenv("DPX_SEED_BAND")) : 0;
+  const int band_env = tune(TUNE_SEED_BAND);
   if (band_env) nb = band_env;
   if (nb > H / 4) nb = H / 4;
   const int per_block = 4 * G;
@@ -1052,7 +1052,7 @@ static bool launch_seed_rows_seq(const SeedOps& SO, const float* rho, const floa
 // false: the plane / batch does not fit the streaming kernel (the caller keeps k_seed_rows<FRESH>)
 bool seed_rows_seq_pow2(const int* linops, int n, const float* rho, const float* x0, float2* spec, int P, int C, int H, int W, const void* table,
                         hipStream_t s) {
-  static const bool plain = getenv("DPX_SEED_ROWS") && !strcmp(getenv("DPX_SEED_ROWS"), "plain");      // (A/B and tests)
+  const bool plain = tune(TUNE_SEED_ROWS_PLAIN) != 0;      // (A/B and tests)
   if (plain || g_rows_mode_pgd == 2) return false;                 // (dpx_admm_iter_config: 2 = the plain kernels)
   SeedOps SO{};
   SO.n = n;
@@ -1111,11 +1111,10 @@ extern "C" int dpx_admm_iter_config(int rows_mode, int bands_per_plane) {
   return DPX_OK;
 }
 
-static const int g_iter_w2048 = getenv("DPX_ITER_W2048") ? atoi(getenv("DPX_ITER_W2048")) : 0;   // tuning: keep the two-kernel iteration on 2048-wide planes
 extern "C" int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms) {
   // (2048-wide planes: 16 values per thread spill in the row kernel -- 33 ps per pixel and iteration against 14 on the staged
   //  kernels, which the callers fall back to)
-  const bool wok = W == 256 || W == 512 || W == 1024 || (W == 2048 && g_iter_w2048);     // (768 / 1536: 24 values per thread, staged kernels only)
+  const bool wok = W == 256 || W == 512 || W == 1024 || (W == 2048 && tune(TUNE_ITER_W2048))     /* knob: keep the two-kernel iteration on 2048-wide planes */;     // (768 / 1536: 24 values per thread, staged kernels only)
   return pow2_path_available(H, W) && wok && H % 16 == 0 && terms_ok(terms, nterms);
 }
 
@@ -1191,8 +1190,8 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   float2* sout = (float2*)spec_out;
   // Streaming kernel (one T-lane group per band): bands as long as possible while still >= ~2 waves per SIMD-pair
   // of the chip; DPX_ITER_ROWS=lockstep keeps the ring-buffer kernel (A/B timing), DPX_ITER_BAND overrides the number of bands per plane.
-  static const char* mode_env = getenv("DPX_ITER_ROWS");
-  static const int band_env0 = getenv("DPX_ITER_BAND") ? atoi(getenv("DPX_ITER_BAND")) : 0;
+  const int mode_knob = tune(TUNE_ITER_ROWS), band_env0 = tune(TUNE_ITER_BAND);
+  const char* mode_env = mode_knob == 1 ? "seq" : (mode_knob == 2 ? "lockstep" : nullptr);
   const char* mode = g_rows_mode > 0 ? (g_rows_mode == 1 ? "seq" : "lockstep") : (g_rows_mode == 0 ? nullptr : mode_env);
   const int band_env = g_rows_band >= 0 ? g_rows_band : band_env0;
   // (small launches -- a few 256-wide planes -- are latency-bound: the ring-buffer kernel's row-parallel bands finish ~10 %
@@ -1223,7 +1222,7 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
       return launch_status("dpx_admm_iter_rows");
     }
   }
-  static const int r_env = getenv("DPX_ITER_R") ? atoi(getenv("DPX_ITER_R")) : 0;   // tuning: rows per band of the ring-buffer kernel
+  const int r_env = tune(TUNE_ITER_R);   // tuning: rows per band of the ring-buffer kernel
   // (256-wide planes: 16 rows are in flight per workgroup, so a band of 8 rows + its 2 halo rows is ONE step of the kernel instead
   //  of two -- these launches are latency-bound: config 1 0.78 -> 0.62 ms per 20-iteration solve)
   const int R = r_env ? r_env : (W <= 256 ? 8 : 16);
@@ -1252,7 +1251,7 @@ extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, co
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS, "dpx_admm_run: nterms");
   for (int i = 0; i < nterms; ++i) cur[i] = terms[i];
   int parity = 0;
-  static const bool cols_inplace = getenv("DPX_COLS_INPLACE") != nullptr;    // tuning experiment
+  const bool cols_inplace = tune(TUNE_COLS_INPLACE) != 0;    // tuning experiment
   for (int k = 0; k < n_iters; ++k) {
     const int it = it0 + k;
     const bool last_of_solve = (it == total_iters - 1);
@@ -1362,7 +1361,7 @@ extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const v
   ChainEvents* Ep = chain_events("dpx_admm_run_chains");
   if (!Ep) return DPX_ERR_LAUNCH;
   ChainEvents& E = *Ep;
-  static const bool lockstep = getenv("DPX_CHAIN_LOCKSTEP") != nullptr;
+  const bool lockstep = tune(TUNE_CHAIN_LOCKSTEP) != 0;
   const bool ordered = lockstep && nchains > 1;
   dpx_term cur[DPX_MAX_CHAINS][DPX_MAX_TERMS];
   for (int c = 0; c < nchains; ++c)

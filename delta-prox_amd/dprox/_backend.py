@@ -58,6 +58,11 @@ SIGNATURES = {
     "dpx_last_error": (c_char_p, []),
     "dpx_timing_enable": (c_int, [c_int]),
     "dpx_timing_report": (c_int, [c_char_p, c_size_t]),
+    "dpx_tune_count": (c_int, []),
+    "dpx_tune_name": (c_char_p, [c_int]),
+    "dpx_tune_set": (c_int, [c_char_p, c_int]),
+    "dpx_tune_get": (c_int, [c_char_p, POINTER(c_int)]),
+    "dpx_cg_config": (c_int, [c_int, c_int, c_int]),
     "dpx_fft_table_bytes": (c_size_t, [c_int, c_int]),
     "dpx_fft_table_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "dpx_spectrum_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -294,6 +299,41 @@ class solve_scope:
         _solve_depth -= 1
         if et is None:
             check_f16_range(self.where)
+        return False
+
+
+# ---- tuning knobs of the library (include/dpx.h "tuning knobs"): per process, take effect at the next call ---------------------
+def tune_get(name):
+    v = c_int(0)
+    lib().call("dpx_tune_get", name.encode(), ctypes.byref(v))
+    return v.value
+
+
+def tune_set(name, value):
+    lib().call("dpx_tune_set", name.encode(), int(value))
+
+
+def tune_names():
+    L = lib()
+    return [L.query("dpx_tune_name", i).decode() for i in range(L.query("dpx_tune_count"))]
+
+
+class tuned:
+    """``with tuned(cg_unfused=1): ...`` -- sets knobs for the block and restores the previous values (not thread-safe: the
+    registry is per process)"""
+
+    def __init__(self, **knobs):
+        self.knobs, self.old = knobs, {}
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            self.old[k] = tune_get(k)
+            tune_set(k, v)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        for k, v in self.old.items():
+            tune_set(k, v)
         return False
 
 

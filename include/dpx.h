@@ -43,6 +43,54 @@ int dpx_timing_enable(int on);
 int dpx_timing_report(char* buf, size_t cap);
 
 /* ------------------------------------------------------------------------------------------ */
+/* tuning knobs                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference has no counterpart (it has one eager code path per op).  Every dispatcher of this library that chooses between
+ * kernel variants or launch geometries reads an integer knob from ONE per-process registry; 0 always means "the library's own
+ * rule".  dpx_tune_set takes effect at the next call that reads the knob (no caching), so a test can drive both branches of a
+ * dispatcher inside one process; dpx_tune_get reads a knob back; dpx_tune_count / dpx_tune_name enumerate the registry.  The
+ * environment variable in the last column only supplies the knob's INITIAL value (read once per process).  Results are
+ * numerically equivalent under every setting (bit-identical where the table says so); the knobs trade speed only.
+ *
+ *   knob                 values                                                         initial value from
+ *   cg_fused_max_b       dpx_cg_masked_fft: batches up to this size take the fused        DPX_CG_FUSED_MAX_B (8)
+ *                        4-launch CG iteration, larger ones the step-by-step sequence
+ *                        (0 = always step by step; at most 32)
+ *   cg_split_update      1 = fused CG with its own x / r update launch + flag copy        DPX_CG_SPLIT_UPDATE
+ *   cg_unfused           1 = always the step-by-step CG sequence                          DPX_CG_UNFUSED
+ *   cg_gram_blocks       workgroups of the fused Gram pass (0 = by size)                  DPX_CGF_GRAM_BLOCKS
+ *   psf2otf_direct       1 = entry-by-entry dpx_psf2otf kernel (same sums, same order)    DPX_PSF2OTF_DIRECT
+ *   comm_allgather_ring  1 = ncclAllGather instead of world-1 direct sends                DPX_COMM_ALLGATHER=ring
+ *   hqs_stream_duals     1 = half-quadratic splitting on the general row kernel           DPX_HQS_STREAM_DUALS
+ *                        (bit-identical)
+ *   pgd_band, seed_band  bands per plane of dpx_pgd_run's / the seed pass's streaming      DPX_PGD_BAND, DPX_SEED_BAND
+ *                        row kernel (bit-identical across band counts)
+ *   pgd_rows_plain,      1 = the plain (non-streaming) row kernels                        DPX_PGD_ROWS=plain,
+ *   seed_rows_plain                                                                       DPX_SEED_ROWS=plain
+ *   iter_rows            1 = streaming row kernel, 2 = lock-step ring-buffer kernel       DPX_ITER_ROWS=seq|lockstep
+ *                        (dpx_admm_iter_config overrides)
+ *   iter_band, iter_r    bands per plane (streaming) / rows per band (lock-step)          DPX_ITER_BAND, DPX_ITER_R
+ *   iter_w2048           1 = keep 2048-wide planes on the two-kernel iteration            DPX_ITER_W2048
+ *   cols_inplace         1 = column pass in place                                         DPX_COLS_INPLACE
+ *   chain_lockstep       1 = sub-batch chains' column passes ordered by events            DPX_CHAIN_LOCKSTEP
+ *   ds_ct, ds_rpb,       geometry of the one-off fp64 data-spectrum pass                  DPX_DS_CT, DPX_DS_RPB,
+ *   ds_row_threads,                                                                       DPX_DS_ROW_THREADS,
+ *   ds_col_threads                                                                        DPX_DS_COL_THREADS
+ *   cols_persist_wg      workgroups per CU of the persistent column kernel (builds with   DPX_COLS_PERSIST_WG
+ *                        DPX_COLS_PERSIST only)
+ *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
+ *                        tools/ only)
+ */
+int dpx_tune_count(void);
+const char* dpx_tune_name(int i);                       /* NULL beyond dpx_tune_count() */
+int dpx_tune_set(const char* name, int value);          /* DPX_ERR_ARG for a name the registry does not hold */
+int dpx_tune_get(const char* name, int* value);
+/* The CG solver's three switches as one typed call (cg_fused_max_b <= 32, cg_split_update, cg_unfused); a negative argument
+ * leaves that switch unchanged.  Both branches of dpx_cg_masked_fft -- fused (B <= fused_max_b) and step by step -- compute the
+ * reference's cg() (linalg/solve/solver_cg.py:56-136) with the same stop rule and exit iteration.                            */
+int dpx_cg_config(int fused_max_b, int split_update, int unfused);
+
+/* ------------------------------------------------------------------------------------------ */
 /* spectral plans                                                                              */
 /* ------------------------------------------------------------------------------------------ */
 /* Twiddle tables for H x W planes (fp64-accurate, stored fp32).  Replaces the per-call planning

@@ -319,6 +319,34 @@ def g6_cg():
     save("g6_cg", **out)
 
 
+def g6b_cg_large_batches():
+    """cg() on the config-4 operator for batches beyond 8 systems (12 and 20 x 1 x 32 x 32; per-image rho): solution, exit iteration
+    and the iterate after 10 fixed iterations -- the spectral-norm stop rule couples all images of a batch
+    (linalg/solve/solver_cg.py:95-129).  Small enough for the SIMT emulator; pins both branches of dpx_cg_masked_fft."""
+    import contextlib
+    import io
+    out = {}
+    for B in (12, 20):
+        gt, mask, y = _csmri(B, 32, 32, seed=600 + B)
+        rho = torch.from_numpy((0.3 + 0.02 * np.arange(B)).astype(np.float32)).view(B, 1, 1, 1)
+
+        class A(torch.nn.Module):
+            def forward(self, x):
+                return ifft2(mask * (mask * fft2(x))).real + rho * x
+
+        rhs = ifft2(mask * y).real.float() + rho * T(gt)
+        xs = ref_cg(A(), rhs, rtol=1e-6, max_iters=100, verbose=False)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ref_cg(A(), rhs, rtol=1e-6, max_iters=100, verbose=True)
+        txt = buf.getvalue()
+        n = int(txt.split("Converged at CG Iter")[1].split()[0]) if "Converged" in txt else 100
+        print(f"g6b B={B}: reference exits at CG iteration {n}")
+        out[f"B{B}_mask"], out[f"B{B}_rhs"], out[f"B{B}_rho"], out[f"B{B}_x"], out[f"B{B}_iters"] = mask, rhs, rho.view(B), xs, n
+        out[f"B{B}_x_10it"] = ref_cg(A(), rhs, rtol=0.0, max_iters=10)
+    save("g6b_cg_large_batches", **out)
+
+
 def g7_ladmm_cg():
     B, H, W = 2, 32, 32
     gt, mask, y = _csmri(B, H, W, seed=70)
@@ -1033,6 +1061,50 @@ def g32_full_c4():
     save("g32_full_c4", **out)
 
 
+def g32b_full_c4_batches():
+    """config 4 at the batch sizes of its 2-GPU and 1-GPU runs: 16 x 1 x 320 x 320 and the full 32 x 1 x 320 x 320 (BASELINE.json
+    config 4), same problem and recording as G32 -- 2 outer LADMM iterations, the CG exit counts of the reference's own loop.  These
+    batches are beyond the fused CG iteration's size rule (B <= 8), i.e. they pin the step-by-step branch of dpx_cg_masked_fft
+    (linalg/solve/solver_cg.py:56-136, proxfn/sum_square.py:158-197)."""
+    import dprox.linalg.solve.solver_cg as scg
+    import dprox.proxfn.sum_square as ssq
+    out = {}
+    for B, seed in ((16, 2316), (32, 2332)):
+        gt, mask, y = synthetic.csmri_case(B, 320, 320, seed=seed, center=32)
+        mask, y = T(mask), T(y)
+        x = dp.Variable()
+        fns = dp.sum_squares(MaskedFFT(x, mask), y) + dp.nonneg(x) + dp.deep_prior(x, denoiser=GrayDen(seed=11))
+        x0 = ifft2(y).real.float()
+        calls = {"bdot": 0}
+        counts = []
+        orig_bdot, orig_ls = scg.bdot, ssq.linear_solve
+
+        def bdot(*a, **k):
+            calls["bdot"] += 1
+            return orig_bdot(*a, **k)
+
+        def linear_solve(*a, **k):
+            n0 = calls["bdot"]
+            r = orig_ls(*a, **k)
+            counts.append((calls["bdot"] - n0) // 2)
+            return r
+
+        scg.bdot, ssq.linear_solve = bdot, linear_solve
+        try:
+            with torch.no_grad():
+                st = dp.Problem(fns, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100)).solve(
+                    method="ladmm", device="cpu", x0=x0, rhos=0.5, lams=0.03, max_iter=2, return_full_states=True)
+        finally:
+            scg.bdot, ssq.linear_solve = orig_bdot, orig_ls
+        print(f"config 4, batch {B}: CG exit counts", counts)
+        out[f"B{B}_seed"], out[f"B{B}_cg_iters"] = seed, np.array(counts)
+        _pack(out, f"B{B}_x", st[0], 8)
+        for i in range(2):
+            _pack(out, f"B{B}_v{i}", st[1][i], 8)
+            _pack(out, f"B{B}_u{i}", st[2][i], 8)
+    save("g32b_full_c4_batches", **out)
+
+
 def g33_full_c5():
     """config 5 at its real size: 4 x 3 x 512 x 512, ADMM unrolled 10 times (specialize method='unroll'), MSE loss, gradients
     w.r.t. the rho / lambda schedules and the observation through the reference's autograd (specialization/unroll.py:14-58)."""
@@ -1126,8 +1198,8 @@ def g36_hqs_pow2():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g7_ladmm_cg, g8_ffdnet, g8b_ffdnet_wide_range,
+    for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g6b_cg_large_batches, g7_ladmm_cg, g8_ffdnet, g8b_ffdnet_wide_range,
                g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
-               g30_full_c2, g30b_full_c2_batch8, g31_full_c3, g32_full_c4, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2):
+               g30_full_c2, g30b_full_c2_batch8, g31_full_c3, g32_full_c4, g32b_full_c4_batches, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -339,6 +339,86 @@ def case_cg(device, B):
     assert_close(cg(A, rhs, rtol=0.0, max_iters=10).cpu(), g[f"B{B}_x_10it"], TOL)
 
 
+CG_BRANCHES = (("default", {}),
+               ("fused", dict(cg_fused_max_b=32, cg_split_update=0, cg_unfused=0)),
+               ("fused + split update", dict(cg_fused_max_b=32, cg_split_update=1, cg_unfused=0)),
+               ("step by step", dict(cg_fused_max_b=0)),
+               ("step by step (cg_unfused)", dict(cg_fused_max_b=32, cg_unfused=1)))
+
+
+def case_cg_branches(device):
+    """G6 / G6b -- BOTH branches of dpx_cg_masked_fft (the fused 4-launch iteration and the step-by-step sequence, selected through
+    dpx_tune_set / dpx_cg_config) against the real reference's cg() on batches of 1, 4, 12 and 20 systems: solution, exit iteration,
+    the iterate after 10 fixed iterations.  By default B <= 8 runs fused and B > 8 step by step, so without the switches the two
+    batch sizes above 8 would never reach the fused kernels and the two below never the step-by-step ones."""
+    from dprox import _backend as be
+    from dprox import _ops as ops
+    assert {"cg_fused_max_b", "cg_split_update", "cg_unfused"} <= set(be.tune_names())
+    g6, g6b = load_golden("g6_cg"), load_golden("g6b_cg_large_batches")
+    for B, g in ((1, g6), (4, g6), (12, g6b), (20, g6b)):
+        mask, rhs = T(g[f"B{B}_mask"], device), T(g[f"B{B}_rhs"], device).contiguous()
+        rho = T(g[f"B{B}_rho"], device) if f"B{B}_rho" in g else torch.full((B,), float(g["rho"]), device=device)
+        n_ref = int(g[f"B{B}_iters"])
+        outs = {}
+        for name, knobs in CG_BRANCHES:
+            with be.tuned(**knobs):
+                x, n = ops.cg_masked_fft(rhs, mask, rho, 1.0, 1e-6, 100)
+                x10, n10 = ops.cg_masked_fft(rhs, mask, rho, 1.0, 0.0, 10)
+            assert abs(n - n_ref) <= 1, (B, name, n, n_ref)
+            assert n10 == 10, (B, name, n10)
+            assert_close(x.cpu(), g[f"B{B}_x"], TOL, f"cg branch '{name}' B={B}")
+            assert_close(x10.cpu(), g[f"B{B}_x_10it"], TOL, f"cg branch '{name}' B={B}, 10 fixed iterations")
+            outs[name] = (x.cpu().numpy(), n)
+        # the branches run the same recurrences with differently ordered reductions: same exit iteration, solutions within round-off
+        ns = {n for _, n in outs.values()}
+        assert len(ns) == 1, (B, {k: v[1] for k, v in outs.items()})
+        for name, (xv, _) in outs.items():
+            e = rel_l2(xv, outs["step by step"][0])
+            record(f"cg branch '{name}' vs step by step, B={B}", e, 2e-6)
+            assert e <= 2e-6, (B, name, e)
+    # the typed entry sets the same registry; negative arguments leave a switch alone; the fused kernels hold at most 32 systems
+    L = be.lib()
+    old = [be.tune_get(k) for k in ("cg_fused_max_b", "cg_split_update", "cg_unfused")]
+    try:
+        L.call("dpx_cg_config", 16, 1, -1)
+        assert [be.tune_get(k) for k in ("cg_fused_max_b", "cg_split_update", "cg_unfused")] == [16, 1, old[2]]
+        assert L.query("dpx_cg_config", 33, -1, -1) < 0
+        assert L.query("dpx_tune_set", b"no_such_knob", 1) < 0
+    finally:
+        L.call("dpx_cg_config", old[0], old[1], old[2])
+
+
+def case_full_c4_batches(device, B):
+    """G32b -- config 4 at the batch sizes of its 2-GPU and 1-GPU runs (16 and 32 x 1 x 320 x 320): LADMM with the CG x-update on the
+    STEP-BY-STEP branch of dpx_cg_masked_fft (B > 8; what bench.py's config4_batch32 times), nonneg + gray FFDNet prior, 2 outer
+    iterations, CG exit counts included -- and the same solve on the fused branch (cg_fused_max_b = 32)."""
+    import synthetic
+    from dprox import _backend as be
+    from dprox.contrib import masked_fft
+    from dprox.linalg import LinearSolveConfig
+    from dprox.utils import ifft2
+    g = load_golden("g32b_full_c4_batches")
+    gt, mask, y = synthetic.csmri_case(B, 320, 320, seed=int(g[f"B{B}_seed"]), center=32)
+    mask, y = T(mask, device), T(y, device)
+    x0 = ifft2(y).real.float().contiguous()
+    gB = {k[len(f"B{B}_"):]: g[k] for k in g.files if k.startswith(f"B{B}_")}
+    for name, knobs in (("step by step", {}), ("fused", dict(cg_fused_max_b=32))):
+        x = dp.Variable()
+        fns = dp.sum_squares(masked_fft(x, mask), y) + dp.nonneg(x) + dp.deep_prior(x, denoiser=_ffdnet("gray", device))
+        with torch.no_grad(), be.tuned(**knobs):
+            assert be.tune_get("cg_fused_max_b") == (32 if knobs else 8) and not be.tune_get("cg_unfused")
+            s = dp.compile(fns, method="ladmm", device=device, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100))
+            st = s.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=2, return_full_states=True)
+        assert s.last_path == "fused-cg", s.last_path
+        its = list(s.least_square.cg_iters[-2:])
+        assert all(abs(int(a) - int(r)) <= 1 for a, r in zip(its, gB["cg_iters"])), (name, its, gB["cg_iters"])
+        what = f"c4 batch {B} ({name}) "
+        _check_packed(gB, "x", st[0], 8, TOL, what=what)
+        for i in range(2):
+            _check_packed(gB, f"v{i}", st[1][i], 8, TOL, scale_key="x", what=what)
+            _check_packed(gB, f"u{i}", st[2][i], 8, TOL, scale_key="x", what=what)
+
+
 def case_cg_masked_fft_shapes(device):
     """dpx_cg_masked_fft (device-controlled CG whose matvec is three fused launches: real row transform, column transform - mask^2 -
     inverse column transform, inverse row transform + real part + rho p) on odd / non-square planes, broadcast and per-image masks:

@@ -95,6 +95,10 @@ def test_cg(B):
     pc.case_cg(DEV, B)
 
 
+def test_cg_both_branches_of_the_fused_call():
+    pc.case_cg_branches(DEV)
+
+
 def test_cg_masked_fft_odd_and_per_image_masks():
     pc.case_cg_masked_fft_shapes(DEV)
 

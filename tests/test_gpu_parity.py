@@ -109,6 +109,10 @@ def test_cg(B):
 
 
 @pytest.mark.gpu
+def test_cg_both_branches_of_the_fused_call():
+    pc.case_cg_branches(DEV)
+
+
 def test_cg_masked_fft_odd_and_per_image_masks():
     pc.case_cg_masked_fft_shapes(DEV)
 
@@ -251,6 +255,11 @@ def test_full_size_config3_pnp():
 
 def test_full_size_config4_shard_ladmm_cg():
     pc.case_full_c4(DEV)
+
+
+@pytest.mark.parametrize("B", [16, 32])
+def test_full_size_config4_batch16_and_32_step_by_step_cg(B):
+    pc.case_full_c4_batches(DEV, B)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

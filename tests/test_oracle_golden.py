@@ -153,6 +153,17 @@ def test_g6_cg(B):
     assert_close(O.cg(A, rhs, rtol=0.0, max_iters=10), g[f"B{B}_x_10it"], 5e-6)
 
 
+@pytest.mark.parametrize("B", [12, 20])
+def test_g6b_cg_large_batches(B):
+    g = load_golden("g6b_cg_large_batches")
+    mask, rhs, rho = T(g[f"B{B}_mask"]), T(g[f"B{B}_rhs"]), T(g[f"B{B}_rho"]).view(B, 1, 1, 1)
+    A = lambda x: O.ifft2c(mask * (mask * O.fft2c(x))).real + rho * x
+    x, n = O.cg(A, rhs, rtol=1e-6, max_iters=100, return_iters=True)
+    assert n == int(g[f"B{B}_iters"])
+    assert_close(x, g[f"B{B}_x"], 5e-6)
+    assert_close(O.cg(A, rhs, rtol=0.0, max_iters=10), g[f"B{B}_x_10it"], 5e-6)
+
+
 def test_g7_ladmm_cg():
     g = load_golden("g7_ladmm_cg")
     mask, y, x0 = T(g["mask"]), T(g["y"]), T(g["x0"])
