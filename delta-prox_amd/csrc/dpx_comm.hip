@@ -31,14 +31,21 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
 };
 
+// the collective library: dpx_comm_use_library(path) or, as its initial value, the environment variable DPX_RCCL_LIB name a shared
+// object that is tried before the system's librccl (any library with the NCCL / RCCL C API: a site build of RCCL, or the
+// shared-memory stand-in of tests/emul that lets the multi-rank branches below run between CPU processes)
+char g_lib_path[1024] = "";
+bool g_lib_tried = false;
+
 Rccl* rccl() {
   static Rccl R;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  if (!g_lib_tried) {
+    g_lib_tried = true;
+    if (!g_lib_path[0] && getenv("DPX_RCCL_LIB")) snprintf(g_lib_path, sizeof(g_lib_path), "%s", getenv("DPX_RCCL_LIB"));
+    if (g_lib_path[0]) R.so = dlopen(g_lib_path, RTLD_NOW | RTLD_GLOBAL);
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      if (R.so || g_lib_path[0]) break;                  // (a named library that does not load is an error, not a reason to fall back)
       R.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (R.so) break;
     }
     if (R.so) {
 #define DPX_BIND(field, sym) *(void**)(&R.field) = dlsym(R.so, sym)
@@ -72,6 +79,14 @@ int fail(const char* what, int rc) {
 }
 
 }  // namespace
+
+extern "C" int dpx_comm_use_library(const char* path) {
+  DPX_REQUIRE(path && strlen(path) < sizeof(g_lib_path), "dpx_comm_use_library: bad path");
+  DPX_REQUIRE(!g_lib_tried || !strcmp(path, g_lib_path), "dpx_comm_use_library: the collective library is already loaded (%s)",
+              g_lib_path[0] ? g_lib_path : "librccl");
+  snprintf(g_lib_path, sizeof(g_lib_path), "%s", path);
+  return DPX_OK;
+}
 
 extern "C" int dpx_comm_unique_id(void* out128) {
   DPX_REQUIRE(out128, "dpx_comm_unique_id: null pointer");

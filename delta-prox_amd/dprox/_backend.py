@@ -104,6 +104,7 @@ SIGNATURES = {
     "dpx_absmax": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "dpx_ffdnet_f16_overflow": (c_int, [c_int]),
     "dpx_otf_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_comm_use_library": (c_int, [c_char_p]),
     "dpx_comm_unique_id": (c_int, [c_void_p]),
     "dpx_comm_init": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
     "dpx_comm_destroy": (c_int, [c_void_p]),

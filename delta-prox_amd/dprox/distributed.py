@@ -110,7 +110,7 @@ def broadcast_constants(tensors: Optional[Dict[str, torch.Tensor]], src: int = 0
             t = tensors[k].to(device if device is not None else tensors[k].device).contiguous()
         else:
             t = torch.empty(shape, dtype=dtype, device=device if device is not None else "cpu")
-        if comm is not None and t.is_cuda:
+        if comm is not None and (t.is_cuda or be.host_mode()):
             comm.broadcast(t, src)
         else:
             dist.broadcast(t, src=src, group=group)
@@ -181,7 +181,7 @@ def scatter_batch(full: Optional[torch.Tensor], src: int = 0, group=None, device
             for r, (a, b) in enumerate(sl):
                 padded[r * nmax:r * nmax + (b - a)] = full[a:b]
             full = padded
-    if comm is not None and torch.device(device).type == "cuda":
+    if comm is not None and (torch.device(device).type == "cuda" or be.host_mode()):
         recv = comm.scatter(full if rank == src else None, nmax, shape[1:], dtype, device, src)
     else:
         recv = torch.empty((nmax,) + tuple(shape[1:]), dtype=dtype, device=device)
@@ -201,7 +201,7 @@ def all_gather_batch(local: torch.Tensor, batch: int, group=None, comm: Optional
     else:
         send = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send[:local.shape[0]] = local
-    if comm is not None and send.is_cuda:
+    if comm is not None and (send.is_cuda or be.host_mode()):
         flat = comm.all_gather(send)
     else:
         flat = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -560,6 +560,9 @@ int dpx_depth_to_space(const float* x, float* y, int B, int C, int H, int W, dpx
 /* The reference runs on one device (algo/base.py:118); a batch is sharded image-wise here.  Only three collectives exist, none of
  * them inside an iteration: broadcast of shared constants, scatter of a batch held by one rank, all-gather of the results.
  * librccl is loaded lazily; a communicator belongs to the HIP device current at dpx_comm_init.  Byte counts, in-order on `stream`. */
+/* dpx_comm_use_library: the shared object with the NCCL / RCCL C API to bind instead of the system's librccl (before the first
+ * dpx_comm_unique_id / dpx_comm_init of the process; the environment variable DPX_RCCL_LIB supplies the initial value).        */
+int dpx_comm_use_library(const char* path);
 int dpx_comm_unique_id(void* out128);                                   /* rank 0, then shipped to the others out of band */
 int dpx_comm_init(void** comm, const void* id128, int rank, int world);
 int dpx_comm_destroy(void* comm);

@@ -401,7 +401,7 @@ def case_full_c4_batches(device, B):
     gt, mask, y = synthetic.csmri_case(B, 320, 320, seed=int(g[f"B{B}_seed"]), center=32)
     mask, y = T(mask, device), T(y, device)
     x0 = ifft2(y).real.float().contiguous()
-    gB = {k[len(f"B{B}_"):]: g[k] for k in g.files if k.startswith(f"B{B}_")}
+    gB = {k[len(f"B{B}_"):]: g[k] for k in g if k.startswith(f"B{B}_")}
     for name, knobs in (("step by step", {}), ("fused", dict(cg_fused_max_b=32))):
         x = dp.Variable()
         fns = dp.sum_squares(masked_fft(x, mask), y) + dp.nonneg(x) + dp.deep_prior(x, denoiser=_ffdnet("gray", device))

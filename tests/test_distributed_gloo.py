@@ -201,6 +201,112 @@ def test_world4_config4_shards_match_their_oracle_and_shared_tables():
         assert r["tab_err"] == 0.0, r               # broadcast tables = locally built tables
 
 
+def _worker_abi(rank, world, port, B, q):
+    """The C-ABI transport (dprox.distributed.Comm -> dpx_comm_* of csrc/dpx_comm.hip) with world > 1: the library binds the
+    shared-memory stand-in for librccl of tests/emul (dpx_comm_use_library), so the direct-send all-gather, the root's sends of the
+    scatter and the broadcast run between real processes -- slice offsets, non-zero roots, payloads larger than the transport's
+    ring, ragged and empty shards through solve_sharded, tables shared through the communicator."""
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "delta-prox_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # host side only: ships the unique id and the shapes
+    import emul_util
+    be = emul_util.use_emulator()
+    import synthetic
+    import dprox as dp
+    from dprox import distributed as dd
+    L = be.lib()
+    L.call("dpx_comm_use_library", os.path.join(emul_util.EMUL, "librccl_stub.so").encode())
+    comm = dd.Comm.from_process_group()
+    assert (comm.rank, comm.world) == (rank, world)
+    assert L.query("dpx_comm_rank", comm._h) == rank and L.query("dpx_comm_world", comm._h) == world
+    calls = {}
+    real_call = L.call
+
+    def counting_call(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return real_call(name, *a)
+    L.call = counting_call
+    res = {"rank": rank}
+    # ---- the three collectives themselves --------------------------------------------------------------------------------
+    n_big = 300_000                                      # 1.2 MB per rank: several turns of the transport's 256 KB rings
+    mine = (torch.arange(n_big, dtype=torch.float32) * (rank + 1) + rank).view(2, -1)
+    for ring in (0, 1):                                  # world - 1 direct sends (default) and ncclAllGather
+        with be.tuned(comm_allgather_ring=ring):
+            got = comm.all_gather(mine)
+        want = torch.cat([(torch.arange(n_big, dtype=torch.float32) * (r + 1) + r).view(2, -1) for r in range(world)], 0)
+        assert torch.equal(got, want), ("all_gather", ring)
+    for root in (0, world - 1):
+        t = torch.full((1000, 7), float(root + 5)) if rank == root else torch.zeros(1000, 7)
+        comm.broadcast(t, root)
+        assert bool((t == root + 5).all()), ("broadcast", root)
+        full = torch.arange(world * 3 * 50, dtype=torch.float32).view(world * 3, 50) + root if rank == root else None
+        part = comm.scatter(full, 3, (50,), torch.float32, torch.device("cpu"), root)
+        want = (torch.arange(world * 3 * 50, dtype=torch.float32).view(world * 3, 50) + root)[rank * 3:(rank + 1) * 3]
+        assert torch.equal(part, want), ("scatter", root)
+    assert L.query("dpx_comm_broadcast", comm._h, None, 16, world, None) < 0            # root out of range: an error, not a hang
+    # ---- the sharded solve over this transport (ragged / empty shards) ---------------------------------------------------
+    gt, b, psf0 = synthetic.deconv_case(B, 1, 24, 32, seed=3, ksize=7, ksigma=2.0)
+    consts = dd.broadcast_constants({"psf": torch.from_numpy(psf0)} if rank == 0 else None, src=0, comm=comm)
+    psf = consts["psf"].numpy()
+
+    def local_solve(loc):
+        x = dp.Variable()
+        fns = dp.sum_squares(dp.conv(x, psf) - loc["b"]) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
+        s = dp.compile(fns, method="admm", device="cpu")
+        return s.solve(x0=loc["b"], rhos=0.2, lams=0.01, max_iter=4)
+
+    n0 = dict(calls)
+    out = dd.solve_sharded(local_solve, {"b": torch.from_numpy(b)} if rank == 0 else None, src=0, comm=comm)
+    res["used_abi"] = (calls.get("dpx_comm_scatter", 0) > n0.get("dpx_comm_scatter", 0) and
+                       calls.get("dpx_comm_allgather", 0) > n0.get("dpx_comm_allgather", 0) and
+                       calls.get("dpx_comm_broadcast", 0) > 2)
+    full = local_solve({"b": torch.from_numpy(b)})
+    res["err"], res["shape"] = float((out - full).abs().max()), tuple(out.shape)
+    # ---- tables built on rank 0 reach the other ranks through the communicator -------------------------------------------
+    bt = torch.from_numpy(b[:1])
+    xx = dp.Variable()
+    sv = dp.compile(dp.sum_squares(dp.conv(xx, psf) - bt) + dp.norm1(dp.grad(xx, dim=0)) + dp.norm1(dp.grad(xx, dim=1)), method="admm", device="cpu")
+    tabs = dd.share_tables(sv, (1, 1, 24, 32), src=0, device=torch.device("cpu"), comm=comm)
+    res["tab_err"] = float((sv.solve(x0=bt, rhos=0.2, lams=0.01, max_iter=4) - full[:1]).abs().max())      # (full: tables built locally)
+    res["tabs"] = sorted(tabs)
+    comm.close()
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 5), (4, 6), (4, 3)])
+def test_c_abi_transport_runs_with_more_than_one_rank(world, B):
+    import emul_util
+    emul_util.build()                                    # (once, before the ranks race to build it)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_abi, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=600) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    assert sorted(r["rank"] for r in res) == list(range(world))
+    for r in res:
+        assert r["used_abi"], r                          # scatter, all-gather and broadcast went through dpx_comm_*
+        assert r["shape"] == (B, 1, 24, 32)
+        assert r["err"] == 0.0, r                        # sharding the direct (Fourier) path is exact
+        assert r["tab_err"] == 0.0, r                    # tables received through the communicator = tables built locally
+        assert {"otf0", "t0", "t1", "consts"} <= set(r["tabs"])
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("dpx_rccl_stub_")]      # the last rank to leave unlinks the segment
+
+
 def test_shard_slices():
     from dprox.distributed import shard_slices
     assert shard_slices(8, 8) == [(i, i + 1) for i in range(8)]
