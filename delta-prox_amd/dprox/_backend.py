@@ -251,6 +251,13 @@ def host_mode():
 # ---- range trap of the split-f16 denoiser arithmetic (FFDNet.compute_mode = "f16x2") -------------------------------------------
 _f16_pending = False
 _solve_depth = 0
+_solve_epoch = 0
+
+
+def solve_epoch():
+    """a number that identifies the outermost solve in progress, None outside of one (host-side caches of things that cannot be
+    watched -- a NumPy observation -- are re-validated once per solve, and on every use outside of a solve)"""
+    return _solve_epoch if _solve_depth > 0 else None
 
 
 def note_f16_launch():
@@ -270,7 +277,7 @@ def check_f16_range(where):
                             "~1.4x slower) and rerun")
 
 
-def f16_fallback(modules, where):
+def f16_fallback(modules, where, stacklevel=3):
     """The networks among ``modules`` that ran split-f16 are switched to split-bf16 (fp32's range, six products instead of three)
     for good and the caller re-runs; returns False when there is nothing to switch (or a network asks to raise instead:
     ``model.f16_fallback = 'raise'``), in which case the caller re-raises."""
@@ -281,7 +288,7 @@ def f16_fallback(modules, where):
     for m in nets:
         m.compute_mode = "bf16x3"
     warnings.warn(f"{where}: an operand left the binary16 range of the split-f16 FFDNet arithmetic; re-running on split-bf16 "
-                  "(compute_mode = 'bf16x3', any range, ~1.4x slower) -- the network keeps that mode", RuntimeWarning, stacklevel=3)
+                  "(compute_mode = 'bf16x3', any range, ~1.4x slower) -- the network keeps that mode", RuntimeWarning, stacklevel=stacklevel)
     return True
 
 
@@ -292,7 +299,9 @@ class solve_scope:
         self.where = where
 
     def __enter__(self):
-        global _solve_depth
+        global _solve_depth, _solve_epoch
+        if _solve_depth == 0:
+            _solve_epoch += 1
         _solve_depth += 1
 
     def __exit__(self, et, ev, tb):

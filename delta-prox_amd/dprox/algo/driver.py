@@ -73,6 +73,21 @@ def _constant_schedule(value, steps):
     return to_tensor([float(value)] * steps)
 
 
+def _restarted_callback(callback):
+    """the user's callback for the second run of a solve that was re-run (split-f16 range trap): passes restarted=True when the
+    callback's signature takes it, the callback unchanged otherwise"""
+    if callback is None:
+        return None
+    import inspect
+    try:
+        ps = inspect.signature(callback).parameters
+    except (TypeError, ValueError):
+        return callback
+    if "restarted" in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values()):
+        return lambda **kw: callback(restarted=True, **kw)
+    return callback
+
+
 class Algorithm(nn.Module):
     @classmethod
     @abc.abstractmethod
@@ -98,6 +113,10 @@ class Algorithm(nn.Module):
     def solve(self, x0: Union[torch.Tensor, np.ndarray] = None, rhos: Union[float, Iterable[float]] = None,
               lams: Union[float, Iterable[float], dict] = None, max_iter: int = 24, pbar: bool = False,
               callback: Callable = None, return_full_states=False, **kwargs) -> torch.Tensor:
+        """Not thread-safe, like the reference's (module-global state in linop/comp_graph.py:201-202): a solve keeps per-solver flags
+        (``_x_only``, the fresh-state marker), the sub-batch chains set a per-process hint in the library (dpx_admm_iter_share) and
+        share one set of chain events per (host thread, device).  One solve at a time per process and solver; one process per GPU
+        (dprox.distributed) is the supported way to use several GPUs."""
         device = self.device
         if device.type != "cuda" and not be.host_mode():
             raise be.DpxError(f"solver lives on {device}: the MI355X backend has no CPU path; "
@@ -105,7 +124,7 @@ class Algorithm(nn.Module):
         x0, rhos, lams, max_iter = self.defaults(x0, rhos, lams, max_iter)
         # every kernel of the solve is issued on the current stream of the SOLVER's GPU (the C ABI takes a raw stream handle:
         # launching with another device current would run GPU-k pointers on GPU-0's stream)
-        def run():
+        def run(callback=callback):
             with be.device_guard(device), be.solve_scope("solve"):
                 xs, rs, ls = move(x0, rhos, lams, device=device)
                 state = self._initial_state(xs.contiguous(), **kwargs)
@@ -120,12 +139,14 @@ class Algorithm(nn.Module):
             state = run()
         except be.F16RangeError:
             # a split-f16 denoiser layer met an operand outside the binary16 range: that solve is invalid -- run it again from x0 on
-            # the split-bf16 arithmetic (the networks keep that mode; the callback sees the iterations of both runs)
+            # the split-bf16 arithmetic.  Side effects, stated: the networks keep that mode; the user's callback has already seen the
+            # iterations of the abandoned run and sees those of the second run too -- a callback that accepts a `restarted` keyword
+            # (or **kwargs) is told so with restarted=True on every call of the second run; the warning points at solve()'s caller.
             nets = [m for fn in list(self.psi_fns) + list(self.omega_fns) if isinstance(getattr(fn, "denoiser", None), torch.nn.Module)
                     for m in fn.denoiser.modules()]
-            if not be.f16_fallback(nets, "solve"):
+            if not be.f16_fallback(nets, "solve", stacklevel=4):
                 raise
-            state = run()
+            state = run(_restarted_callback(callback))
         return state if return_full_states else state[0]
 
     def _initial_state(self, x0, **kwargs):

@@ -90,6 +90,20 @@ def _psi_prox_code(fn):
     return None
 
 
+def plan_fingerprint(solver):
+    """everything mutable the pattern match of ``plan_admm`` reads, cheaply: the term lists (identity and type of every term), the
+    terms' beta / unroll / clamp / denoiser class, the linop at the root of each term and the x-update's kind.  Part of the plan
+    cache's key (``ADMM._plan_for``): a term swapped, re-weighted or re-configured after the first solve gets a new match instead
+    of a stale plan."""
+    ls = getattr(solver, "least_square", None)
+    terms = []
+    for fn in list(solver.psi_fns) + list(solver.omega_fns):
+        op = fn.linop
+        terms.append((id(fn), type(fn), fn.beta, getattr(fn, "unroll", None), getattr(fn, "clamp", None), type(getattr(fn, "denoiser", None)),
+                      id(op), type(op), getattr(op, "dim", None)))
+    return (len(solver.psi_fns), tuple(terms), id(ls), bool(getattr(ls, "freq_diagonalizable", False)))
+
+
 def plan_admm(solver, state):
     ls = getattr(solver, "least_square", None)
     if not isinstance(ls, least_squares) or not ls.freq_diagonalizable:

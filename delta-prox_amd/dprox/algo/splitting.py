@@ -70,8 +70,8 @@ class ADMM(Algorithm):
 
     def _plan_for(self, x):
         """the fused plan of this problem for an iterate like ``x`` (the pattern match depends on the problem graph and on the
-        iterate's shape / dtype only: done once per shape)"""
-        key = (tuple(x.shape), x.dtype) if isinstance(x, torch.Tensor) else None
+        iterate's shape / dtype: done once per shape and per configuration of the terms, fused.plan_fingerprint)"""
+        key = (tuple(x.shape), x.dtype, fused.plan_fingerprint(self)) if isinstance(x, torch.Tensor) else None
         hit = getattr(self, "_plan_cache", None)
         if key is not None and hit is not None and hit[0] == key:
             return hit[1]

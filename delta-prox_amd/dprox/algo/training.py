@@ -40,11 +40,12 @@ class TrainLoop:
 
     def __init__(self, model, lr=1e-4, weight_decay=1e-3, savedir="saved"):
         self.model, self.savedir = model, str(savedir)
-        params = [p for p in model.parameters() if p.requires_grad]
-        if not params:
+        if not any(p.requires_grad for p in model.parameters()):
             raise ValueError("train: the model has no trainable parameter (specialize(..., learned_params=True), or a denoiser "
                              "with requires_grad weights)")
-        self.optimizer = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+        # over ALL parameters like the reference (algo/primitives.py:150): frozen ones never get a gradient and are skipped by the
+        # step, and the optimizer state of a checkpoint keeps its group size whatever is frozen at resume time
+        self.optimizer = torch.optim.AdamW(list(model.parameters()), lr=lr, weight_decay=weight_decay)
         self.epoch, self.gstep, self.best_psnr, self.history = 0, 0, 0.0, []
         os.makedirs(self.savedir, exist_ok=True)
 

@@ -23,6 +23,17 @@ from ..linop import sum as lin_sum
 from .core import ProxFn
 
 
+def _bytes_hash(a):
+    """64-bit fingerprint of an array's bytes (xxh3: ~10 GB/s; crc32 + length where xxhash is missing)"""
+    mv = memoryview(a).cast("B") if a.size else b""
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(mv)
+    except ImportError:
+        import zlib
+        return zlib.crc32(mv)
+
+
 class sum_squares(ProxFn):
     """||K x - b||_2^2"""
     hip_kind = be.PROX_SUMSQ
@@ -30,9 +41,24 @@ class sum_squares(ProxFn):
     def __init__(self, linop, b=None, eps=1e-7):
         super().__init__(linop)
         self.eps = eps
-        if isinstance(b, np.ndarray):                      # converted once: a tensor's edits can be watched (version counter), an
-            b = torch.from_numpy(np.ascontiguousarray(b))   # array's cannot, and re-reading it on every use rebuilt every cache
+        # A NumPy observation is converted once -- re-reading it on every use, as the reference does (proxfn/base.py unwrap), rebuilt
+        # every cache -- but its in-place edits must not go unnoticed: a tensor's edits bump a version counter, an array's cannot be
+        # watched, so the array is kept and its bytes are fingerprinted once per solve (and on every use outside of a solve).
+        self._b_np, self._b_fp, self._b_fp_epoch = None, None, None
+        if isinstance(b, np.ndarray):
+            self._b_np = b
+            b = torch.from_numpy(np.ascontiguousarray(b))
         self._b = b
+
+    def _np_fingerprint(self):
+        ep = be.solve_epoch()
+        if ep is None or ep != self._b_fp_epoch or self._b_fp is None:
+            a = np.ascontiguousarray(self._b_np)
+            fp = (a.shape, str(a.dtype), _bytes_hash(a))
+            if fp != self._b_fp:                                        # first look, or edited since the last one: take the contents
+                self._b = torch.from_numpy(a)
+            self._b_fp, self._b_fp_epoch = fp, ep
+        return self._b_fp
 
     def _offset_key(self):
         k = super()._offset_key()
@@ -40,6 +66,8 @@ class sum_squares(ProxFn):
             return k
         # a tensor's in-place edits bump its version counter; anything else (a numpy array) cannot be watched: a key that never
         # compares equal makes every use re-read it, as the reference does
+        if self._b_np is not None:
+            return k + ((id(self._b_np), self._np_fingerprint()),)
         if isinstance(self._b, torch.Tensor):
             return k + ((id(self._b), self._b._version),)
         ver = getattr(self._b, "_version", None)           # a Placeholder counts its assignments (linop/leaf.py)

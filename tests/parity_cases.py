@@ -339,6 +339,41 @@ def case_cg(device, B):
     assert_close(cg(A, rhs, rtol=0.0, max_iters=10).cpu(), g[f"B{B}_x_10it"], TOL)
 
 
+def case_numpy_observation_edits(device):
+    """sum_squares(K, b) with a NumPy observation: the array is converted once and its caches (offset, data spectrum) are kept, but
+    an in-place edit of the array between two solves must be seen -- the reference re-reads b on every use (proxfn/base.py unwrap).
+    Also through a non-contiguous view (no shared memory with the converted tensor)."""
+    import synthetic
+    from dprox.contrib import masked_fft
+    gt, b, psf = synthetic.deconv_case(2, 1, 32, 32, seed=5, ksize=5, ksigma=1.5)
+    for view in (False, True):
+        store = np.zeros((2, 1, 32, 64), np.float32)
+        b_np = store[..., ::2] if view else np.ascontiguousarray(b.copy())
+        b_np[...] = b
+        x = dp.Variable()
+        fn = dp.sum_squares(dp.conv(x, psf), b_np)
+        s = dp.compile(fn + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device=device)
+        x0 = T(b, device)
+        out1 = s.solve(x0=x0, rhos=0.2, lams=0.01, max_iter=3).cpu().clone()
+        again = s.solve(x0=x0, rhos=0.2, lams=0.01, max_iter=3).cpu()
+        assert torch.equal(out1, again)
+        xr = dp.Variable()
+        ref1 = dp.compile(dp.sum_squares(dp.conv(xr, psf) - T(b, device)) + dp.norm1(dp.grad(xr, dim=0)) + dp.norm1(dp.grad(xr, dim=1)),
+                          method="admm", device=device).solve(x0=x0, rhos=0.2, lams=0.01, max_iter=3).cpu()
+        assert rel_l2(out1.numpy(), ref1.numpy()) <= 1e-6
+        b_np[...] = 0.5 * b                                   # in-place edit of the caller's array
+        out2 = s.solve(x0=x0, rhos=0.2, lams=0.01, max_iter=3).cpu()
+        xr = dp.Variable()
+        ref2 = dp.compile(dp.sum_squares(dp.conv(xr, psf) - T(0.5 * b, device)) + dp.norm1(dp.grad(xr, dim=0)) + dp.norm1(dp.grad(xr, dim=1)),
+                          method="admm", device=device).solve(x0=x0, rhos=0.2, lams=0.01, max_iter=3).cpu()
+        assert rel_l2(out2.numpy(), ref2.numpy()) <= 1e-6, (view, rel_l2(out2.numpy(), ref2.numpy()))
+        assert rel_l2(out2.numpy(), out1.numpy()) > 1e-2      # (the stale result would be bit-identical to out1)
+        # the offset itself outside of a solve follows the array at once
+        b_np[...] = 0.0
+        off = fn.offset
+        assert off is None or float(off.abs().max()) == 0.0
+
+
 CG_BRANCHES = (("default", {}),
                ("fused", dict(cg_fused_max_b=32, cg_split_update=0, cg_unfused=0)),
                ("fused + split update", dict(cg_fused_max_b=32, cg_split_update=1, cg_unfused=0)),

@@ -95,6 +95,10 @@ def test_cg(B):
     pc.case_cg(DEV, B)
 
 
+def test_numpy_observation_edited_in_place_is_seen():
+    pc.case_numpy_observation_edits(DEV)
+
+
 def test_cg_both_branches_of_the_fused_call():
     pc.case_cg_branches(DEV)
 
