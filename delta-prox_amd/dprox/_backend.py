@@ -15,7 +15,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPX_LIB selects another *HIP* build of the same library (kernel tuning experiments); never a non-HIP substitute
-LIB_PATH = os.environ.get("DPX_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdpx_hip.so")
+# Where the library lives: inside the package for an installed wheel (dprox/lib/, setup.py's build hook), next to the package in the
+# source tree (delta-prox_amd/lib/, __graft_entry__.build()).
+_IN_PKG = os.path.join(_HERE, "lib", "libdpx_hip.so")
+LIB_PATH = os.environ.get("DPX_LIB") or (_IN_PKG if os.path.exists(_IN_PKG) else os.path.join(os.path.dirname(_HERE), "lib", "libdpx_hip.so"))
 
 PROX_NORM1, PROX_NONNEG, PROX_SUMSQ, PROX_EXTERNAL = 0, 1, 2, 3
 LIN_IDENTITY, LIN_GRAD_H, LIN_GRAD_W = 0, 1, 2

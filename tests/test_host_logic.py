@@ -28,6 +28,65 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.query("dpx_spectrum_bytes", 1, 15, 21) == 2 * 15 * 11 * 8
 
 
+def test_tuning_registry_is_documented_and_round_trips():
+    """every knob of the library's registry is in include/dpx.h's table, and dpx_tune_set / dpx_tune_get round-trip"""
+    hdr = open(os.path.join(ROOT, "include", "dpx.h")).read()
+    lib = be.Library(be.LIB_PATH)
+    import ctypes
+    n = lib.query("dpx_tune_count")
+    names = [lib.query("dpx_tune_name", i).decode() for i in range(n)]
+    assert n >= 20 and lib.query("dpx_tune_name", n) is None
+    table = hdr[hdr.index("tuning knobs"):hdr.index("int dpx_tune_count")]
+    for name in names:
+        assert re.search(r"\b" + name + r"\b", table), f"knob {name} is not documented in include/dpx.h"
+        v = ctypes.c_int(-7)
+        lib.call("dpx_tune_get", name.encode(), ctypes.byref(v))
+        old = v.value
+        lib.call("dpx_tune_set", name.encode(), 5)
+        lib.call("dpx_tune_get", name.encode(), ctypes.byref(v))
+        assert v.value == 5
+        lib.call("dpx_tune_set", name.encode(), old)
+    assert lib.query("dpx_tune_set", b"no_such_knob", 1) < 0 and b"no_such_knob" in lib.cdll.dpx_last_error()
+    # no getenv outside the registry (and the collective library's path): a knob a test cannot reach in-process is a regression
+    csrc = os.path.join(ROOT, "delta-prox_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(csrc, f)).read()
+            hits = [ln for ln in src.splitlines() if "getenv(" in ln]
+            assert all("kKnobs[i].env" in ln or "DPX_RCCL_LIB" in ln for ln in hits), (f, hits)
+
+
+def test_wheel_builds_and_imports_without_path_edits(tmp_path):
+    """packaging (pyproject.toml + setup.py): `pip wheel` runs the HIP build hook, the wheel holds the package `dprox` with
+    dprox/lib/libdpx_hip.so inside, and a fresh interpreter imports it from the unpacked wheel alone (no sys.path edits, no repo)"""
+    import shutil
+    import subprocess
+    import sys
+    import zipfile
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    wh = tmp_path / "wh"
+    r = subprocess.run([sys.executable, "-m", "pip", "wheel", "--no-build-isolation", "--no-deps", "-q", "-w", str(wh), ROOT],
+                       capture_output=True, text=True, cwd=str(tmp_path), timeout=1500)
+    for junk in ("build", "UNKNOWN.egg-info", os.path.join("delta-prox_amd", "dprox_mi355x.egg-info")):
+        shutil.rmtree(os.path.join(ROOT, junk), ignore_errors=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    wheels = list(wh.glob("dprox_mi355x-*.whl"))
+    assert len(wheels) == 1, list(wh.iterdir())
+    site = tmp_path / "site"
+    with zipfile.ZipFile(wheels[0]) as z:
+        names = z.namelist()
+        z.extractall(site)
+    assert "dprox/lib/libdpx_hip.so" in names and "dprox/_backend.py" in names and not any(n.startswith(("oracle", "tests")) for n in names)
+    code = ("import dprox, dprox._backend as be; L = be.lib(); "
+            "assert L.path.endswith('dprox/lib/libdpx_hip.so') and '/site/' in L.path, L.path; "
+            "assert dprox.__file__.startswith(%r), dprox.__file__; print(L.query('dpx_version'))" % str(site))
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "DPX_LIB")}
+    env["PYTHONPATH"] = str(site)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=600)
+    assert r.returncode == 0 and int(r.stdout.strip()) >= 101, (r.stdout, r.stderr[-2000:])
+
+
 def test_to_torch_tensor_and_ndarray():
     a = np.zeros((5, 7, 3), np.float32)
     assert tuple(to_torch_tensor(a, batch=True).shape) == (1, 3, 5, 7)          # HWC -> NCHW
