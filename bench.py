@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--pmc", dest="pmc", action="store_true", default=None, help="measure roofline.traffic in this run: two rocprofv3 --pmc passes "
+                    "(FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of this same command as subprocesses (default at N = 1)")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="roofline.traffic from the committed profiles/ figure instead (labelled)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # (the counter passes' own invocation: the timed workload only)
     ap.add_argument("--chains", type=int, default=0, help="sub-batch chains of the two-kernel iteration (0 = the library's own choice, 1 = off: "
                     "every launch has the GPU to itself -- the setting the committed rocprofv3 kernel statistics are taken with)")
     return ap.parse_args()
@@ -129,6 +133,91 @@ def setup_profile(dp, be, b, psf, device):
             "note": "kernels of a cold solve other than the iteration's two: OTF / |OTF|^2 / denominator tables (k_psf2otf*, "
                     "k_denominator_pack), the fp64 data spectrum (k_twiddle_table_f64, k_rows_r2c_f64, k_cols_fwd_f64), initialize() "
                     "(v = K x0: k_grad, zeros) and the seed pass (k_seed_rows); torch's own fill / copy kernels are not in this list"}
+
+
+def pmc_traffic(kernel, timeout_s=150):
+    """HBM traffic per launch of `kernel`, measured NOW: two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE need separate passes:
+    3 + 2 of the 4 TCC slots; --pmc with --kernel-trace only, as the box's rules ask) of this same bench command -- one chain, no
+    companion legs, 10 steps -- as subprocesses; per launch: FETCH_SIZE [KiB] x 1024 x 2 (gfx950: wide coalesced reads are tallied at
+    half their bytes, MI355X_MICROARCH.md "HBM") + WRITE_SIZE [KiB] x 1024.  None (with the reason) if rocprofv3 is missing / fails."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="dpx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("DPX_CHAINS", None)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--no-pmc", "--no-cpu-baseline", "--no-extra-configs", "--steps", "10", "--warmup", "2", "--chains", "1"]
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                return None, f"rocprofv3 --pmc {ctr} pass exceeded {timeout_s} s"
+            if pr.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass failed ({pr.returncode}): {err.decode(errors='replace')[-300:]}"
+            got = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("dpx::", "").split("<")[0]
+                    if k == kernel and row["Counter_Name"] == ctr:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, f"no {ctr} rows for {kernel} in the counter CSV"
+            vals[ctr] = (sum(got) / len(got), len(got))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
+    return {"bytes": rd + wr, "read_bytes_corrected": rd, "write_bytes": wr, "launches_sampled": min(vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1])}, None
+
+
+def cache_sweep(dp, synthetic, device):
+    """HBM or Infinity Cache?  The two spectra handed between the two kernels of an iteration are 2 x 100 MB at B = 8 -- the 256 MB
+    Infinity Cache can hold them -- and FETCH_SIZE / WRITE_SIZE count fabric requests, cache hits included.  The same iteration at
+    B = 8 / 16 / 24 (hand-over 200 / 400 / 600 MB: beyond the cache from 16 on) in ps per pixel and iteration: the growth from 8 to 16
+    is what the cache contributes at B = 8; from 16 on every byte crosses the HBM interface."""
+    out = {}
+    for nb in (8, 16, 24):
+        rng = np.random.RandomState(77)
+        bb = torch.from_numpy(rng.rand(nb, C, H, W).astype(np.float32)).to(device)
+        x = dp.Variable()
+        s = dp.compile(dp.sum_squares(dp.conv(x, synthetic.point_spread_function(15, 5.0)) - bb) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)),
+                       method="admm", device=device)
+        t = {}
+        for n in (20, 120):
+            s.solve(x0=bb, rhos=RHO, lams=LAM, max_iter=n)
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s.solve(x0=bb, rhos=RHO, lams=LAM, max_iter=n)
+                torch.cuda.synchronize()
+                dtn = time.perf_counter() - t0
+                best = dtn if best is None else min(best, dtn)
+            t[n] = best
+        per_it = (t[120] - t[20]) / 100
+        npx = nb * C * H * W
+        out[f"B{nb}"] = {"ms_per_iter": per_it * 1e3, "ps_per_pixel": per_it * 1e12 / npx, "handover_MB": 2 * npx * 4 / 1e6,
+                         "frac_of_hbm_peak_on_36B": DESIGN_BYTES_PER_ELEM * npx / per_it / HBM_PEAK}
+        del s, bb
+        torch.cuda.empty_cache()
+    p8, p16 = out["B8"]["ps_per_pixel"], out["B16"]["ps_per_pixel"]
+    out["statement"] = (f"{p8:.2f} ps/pixel at B = 8 against {p16:.2f} at B = 16 and {out['B24']['ps_per_pixel']:.2f} at B = 24: "
+                        f"{100 * (p16 - p8) / p16:.0f} % of the B = 8 rate comes from spectrum hand-overs served by the Infinity Cache; the "
+                        "roofline fractions of this line are fractions of the 8 TB/s HBM peak on bytes that cross the L2 (fabric requests), "
+                        "not proven DRAM bytes -- `frac_of_hbm_peak_on_36B` at B = 16 / 24 is the cache-free figure")
+    return out
 
 
 def cpu_baseline(b_host, psf, n_iters=4, sample_b=2):
@@ -418,6 +507,16 @@ def main():
     solver, xvar, b, gt, psf = make_problem(dp, synthetic, rank, device)
     K, Wm = a.steps, a.warmup
 
+    if a.pmc_child:
+        # what the rocprofv3 counter passes of pmc_traffic() run: the headline workload's iterations as ONE chain (every launch covers the
+        # whole batch and has the GPU to itself), W warm-up + K steps, nothing else
+        solver.solve(x0=b, rhos=RHO, lams=LAM, max_iter=max(Wm, 1))
+        st = solver.initialize(b)
+        _, rs, ls, _ = solver.defaults(b, RHO, LAM, K)
+        solver.iters(st, rs.to(device), {k: v.to(device) for k, v in ls.items()}, K)
+        torch.cuda.synchronize()
+        return
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -585,10 +684,21 @@ def main():
     dom = max(rep, key=lambda k: rep[k][1])
     # HBM traffic of the dominant kernel from the PMC counters: rocprofv3 cannot be run from inside this process, so the
     # figure comes from the committed separate --pmc passes of this same command (tools/pmc_summary.py, profiles/)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_note, traffic_detail = None, None, None, None
     import glob
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    want_pmc = a.pmc if a.pmc is not None else (world == 1 and not under_profiler)
+    if want_pmc:
+        traffic_detail, why = pmc_traffic(dom)
+        if traffic_detail is not None:
+            traffic = traffic_detail["bytes"]
+            traffic_src = "measured by this command: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (--kernel-trace only) of the same workload as subprocesses"
+            traffic_note = ("per launch, one chain; FETCH_SIZE x 1024 x 2 (gfx950 tallies wide coalesced reads at half their bytes) + WRITE_SIZE x 1024; "
+                            "fabric requests incl. Infinity-Cache hits (see hbm_vs_infinity_cache)")
+        else:
+            traffic_note = f"the in-run counter passes failed ({why}); committed figure used"
     pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
-    if pmc_files:
+    if traffic is None and pmc_files:
         for name, e in json.load(open(pmc_files[-1])).items():
             if name.split("<")[0] == dom and "hbm_traffic_bytes" in e:
                 traffic = e["hbm_traffic_bytes"]
@@ -639,8 +749,10 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "frac_of_measured_copy": achieved / HBM_COPY, "traffic": traffic,
                      "traffic_source": traffic_src,
-                     "traffic_note": "NOT measured in this run: rocprofv3 cannot be attached from inside the process -- the figure is the "
-                                     "per-launch HBM traffic of this kernel from the committed separate --pmc passes of this same command",
+                     "traffic_note": traffic_note or "NOT measured in this run (--no-pmc / under a profiler / N > 1): the per-launch HBM traffic of this "
+                                                     "kernel from the committed separate --pmc passes of this same command",
+                     "traffic_detail": traffic_detail,
+                     "traffic_over_algorithmic": (traffic / dom_bytes) if traffic else None,
                      "algorithmic_bytes_per_launch": dom_bytes, "algorithmic_bytes_note": emit_note, "avg_launch_us": dom_avg_s * 1e6,
                      "measured_with": "one chain (DPX_CHAINS=1): each launch covers the whole batch and runs alone on the GPU; the timed legs "
                                       f"(`value`, `steady_state`) run {chains_used} sub-batch chain(s) whose launches overlap"},
@@ -673,6 +785,43 @@ def main():
         res["sharded"] = sharded
     if world == 1 and not a.no_extra_configs:
         res["configs"] = extra_configs(dp, synthetic, device)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train
+        tr = {}
+        for key, trainable in (("frozen_denoiser", False), ("trainable_denoiser", True)):
+            try:
+                tr[key] = bench_train.run(dp, synthetic, be, device, bs=2, size=768, iters=10, steps=3, trainable=trainable, kernels=True)
+            except Exception as e:                           # noqa: BLE001 (a companion leg must not take the headline line with it)
+                tr[key] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+        tr["reference_published"] = {"it_per_s": 1.49, "source": "notebooks/quickstart.ipynb:254-257 (train(model=doe_model, step_fn, 'BSD500', epochs=2): bs 2, "
+                                     "768 x 768 patches, ADMM unrolled x10, frozen ffdnet_color prior; GPU not stated)",
+                                     "ratio_frozen": (tr["frozen_denoiser"].get("steps_per_s", 0.0) / 1.49) if "steps_per_s" in tr["frozen_denoiser"] else None}
+        res["configs"]["train_unrolled_pnp"] = tr
+        res["roofline"]["hbm_vs_infinity_cache"] = cache_sweep(dp, synthetic, device)
+    # the figures a reader needs next to `roofline.frac`, inside the object the round records keep whole
+    cfg = res.get("configs", {})
+    kc = kernels.get("k_cols_p2")
+    res["roofline"]["companions"] = {
+        "headline_it_per_s": it_per_s, "headline_iteration_frac": res["roofline_iteration"]["frac"],
+        "steady_state_it_per_s": res["steady_state"]["it_per_s"], "steady_state_iteration_frac": res["steady_state"]["roofline_iteration_frac"],
+        "value_after_idle_gpu_it_per_s": res["value_after_idle_gpu"],
+        "after_idle_iteration_frac": (K / dt_idle) * DESIGN_BYTES_PER_ELEM * n_elem / HBM_PEAK,
+        "k_cols_p2": None if kc is None else {"avg_us": kc["avg_us"], "frac": kc["GBps"] * 1e9 / HBM_PEAK},
+        "parity_rel_l2": res.get("parity_rel_l2"),
+        "config3_frac_of_f16_pipe_over_3": cfg.get("config3", {}).get("roofline", {}).get("frac"),
+        "config3_it_per_s": cfg.get("config3", {}).get("it_per_s"),
+        "config4_shard4_ms_per_outer_iter": cfg.get("config4_shard4", {}).get("ms_per_outer_iter"),
+        "config4_shard4_frac": cfg.get("config4_shard4", {}).get("roofline", {}).get("frac"),
+        "config4_batch32_ms_per_outer_iter": cfg.get("config4_batch32", {}).get("ms_per_outer_iter"),
+        "config4_predicted_speedup_8_gpus": (cfg["config4_batch32"]["ms_per_outer_iter"] / cfg["config4_shard4"]["ms_per_outer_iter"])
+        if "config4_batch32" in cfg and "config4_shard4" in cfg else None,
+        "config5_f32_ms_per_step": cfg.get("config5_f32", {}).get("ms_per_step"),
+        "config5_bf16_ms_per_step": cfg.get("config5_bf16", {}).get("ms_per_step"),
+        "train_unrolled_pnp_steps_per_s": cfg.get("train_unrolled_pnp", {}).get("frozen_denoiser", {}).get("steps_per_s"),
+        "note": "iteration fractions: it/s x 36 B/element x 25 165 824 elements / 8 TB/s (wall clock, chains on); `frac` of this object: the dominant "
+                "kernel alone, one chain; after_idle: the identical K-step region after the GPU idled 0.5 s in front of its warm-up",
+    }
     # RCCL writes a version banner to the C stdout buffer, which would otherwise be flushed at exit BEHIND the JSON line: flush it
     # first, print the one line, then close stdout for everything that follows
     ctypes.CDLL(None).fflush(None)
