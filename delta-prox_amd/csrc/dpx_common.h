@@ -92,7 +92,7 @@ enum Tune {
   TUNE_CG_FUSED_MAX_B, TUNE_CG_SPLIT_UPDATE, TUNE_CG_UNFUSED, TUNE_CG_GRAM_BLOCKS, TUNE_PSF2OTF_DIRECT, TUNE_COMM_ALLGATHER_RING,
   TUNE_HQS_STREAM_DUALS, TUNE_PGD_BAND, TUNE_PGD_ROWS_PLAIN, TUNE_SEED_BAND, TUNE_SEED_ROWS_PLAIN, TUNE_ITER_W2048, TUNE_ITER_ROWS,
   TUNE_ITER_BAND, TUNE_ITER_R, TUNE_COLS_INPLACE, TUNE_CHAIN_LOCKSTEP, TUNE_DS_CT, TUNE_DS_RPB, TUNE_DS_ROW_THREADS,
-  TUNE_DS_COL_THREADS, TUNE_COLS_PERSIST_WG, TUNE_DEBUG_COLS, TUNE_COUNT
+  TUNE_DS_COL_THREADS, TUNE_COLS_PERSIST_WG, TUNE_DEBUG_COLS, TUNE_CG_ROWS_PER_WG, TUNE_CG_COLS_PER_WG, TUNE_CG_GRAM_SMALL, TUNE_COUNT
 };
 int tune(Tune k);
 
@@ -167,11 +167,77 @@ __device__ __forceinline__ float4 dpx_hist_load4(const float* plane, int bf16, l
 }
 
 // ---- complex arithmetic on float2 ---------------------------------------------------------------
+// gfx950 has packed-fp32 VOP3P instructions (v_pk_add / v_pk_mul / v_pk_fma_f32: one issue slot, both halves of a 64-bit register
+// pair) whose per-source op_sel / op_sel_hi (which half feeds the low / the high result) and neg_lo / neg_hi modifiers make a complex
+// product two instructions and a butterfly with a +-i rotation one -- hipcc finds the plain packed add / sub but builds every swapped
+// or half-negated operand with v_mov / v_pk_mov and falls back to scalar v_mul / v_fma for most products (k_cols_p2: 325 v_mov and
+// 420 scalar flops of 1870 vector instructions per wave).  DPX_PK_ASM = 1 writes these few primitives as VOP3P by hand; the C forms
+// below them are the same arithmetic in the same rounding order (product of the first components rounded, then one fma), used by the
+// host emulator and by -DDPX_PK_ASM=0 builds.
+#ifndef DPX_PK_ASM
+#ifdef DPX_EMULATED
+#define DPX_PK_ASM 0
+#else
+#define DPX_PK_ASM 1
+#endif
+#endif
+#if DPX_PK_ASM
+typedef float dpx_pk2 __attribute__((ext_vector_type(2)));
+#define DPX_PK(x) __builtin_bit_cast(dpx_pk2, x)
+#define DPX_F2(x) __builtin_bit_cast(float2, x)
+#endif
+// a * b:   t = (a.x b.x, a.y b.x);  (t.x - a.y b.y, t.y + a.x b.y)
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+#if DPX_PK_ASM
+  dpx_pk2 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(DPX_PK(a)), "v"(DPX_PK(b)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(DPX_PK(a)), "v"(DPX_PK(b)), "v"(t));
+  return DPX_F2(d);
+#else
+  return make_float2(fmaf(-a.y, b.y, a.x * b.x), fmaf(a.x, b.y, a.y * b.x));
+#endif
 }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {   // a * conj(b)
-  return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+// a * conj(b):   (t.x + a.y b.y, t.y - a.x b.y)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
+#if DPX_PK_ASM
+  dpx_pk2 t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(DPX_PK(a)), "v"(DPX_PK(b)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(DPX_PK(a)), "v"(DPX_PK(b)), "v"(t));
+  return DPX_F2(d);
+#else
+  return make_float2(fmaf(a.y, b.y, a.x * b.x), fmaf(-a.x, b.y, a.y * b.x));
+#endif
+}
+// a * (cr + i ci) with a compile-time constant held in a scalar register pair (rotations inside the register butterflies)
+__device__ __forceinline__ float2 cmul_const(float2 a, float cr, float ci) {
+#if DPX_PK_ASM
+  dpx_pk2 t, d;
+  const dpx_pk2 k = {cr, ci};
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(DPX_PK(a)), "s"(k));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(DPX_PK(a)), "s"(k), "v"(t));
+  return DPX_F2(d);
+#else
+  return make_float2(fmaf(-a.y, ci, a.x * cr), fmaf(a.x, ci, a.y * cr));
+#endif
+}
+// a + i b = (a.x - b.y, a.y + b.x)   and   a - i b = (a.x + b.y, a.y - b.x): one instruction each
+__device__ __forceinline__ float2 cadd_ib(float2 a, float2 b) {
+#if DPX_PK_ASM
+  dpx_pk2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(DPX_PK(a)), "v"(DPX_PK(b)));
+  return DPX_F2(d);
+#else
+  return make_float2(a.x - b.y, a.y + b.x);
+#endif
+}
+__device__ __forceinline__ float2 csub_ib(float2 a, float2 b) {
+#if DPX_PK_ASM
+  dpx_pk2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(DPX_PK(a)), "v"(DPX_PK(b)));
+  return DPX_F2(d);
+#else
+  return make_float2(a.x + b.y, a.y - b.x);
+#endif
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -181,6 +247,9 @@ __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2
 template <int DIR> __device__ __forceinline__ float2 cmul_i(float2 a) {
   return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
 }
+// a + w b  and  a - w b  with  w = -i (DIR < 0, forward) / +i (DIR > 0, inverse): the rotation folded into the butterfly
+template <int DIR> __device__ __forceinline__ float2 cadd_rot(float2 a, float2 b) { return DIR < 0 ? csub_ib(a, b) : cadd_ib(a, b); }
+template <int DIR> __device__ __forceinline__ float2 csub_rot(float2 a, float2 b) { return DIR < 0 ? cadd_ib(a, b) : csub_ib(a, b); }
 
 // ---- mixed-radix plan for one 1-D complex transform (passed by value to kernels) -----------
 struct Plan1D {

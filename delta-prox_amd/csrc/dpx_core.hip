@@ -161,6 +161,9 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"ds_col_threads", "DPX_DS_COL_THREADS", 0, nullptr},
     {"cols_persist_wg", "DPX_COLS_PERSIST_WG", 0, nullptr},
     {"debug_cols", "DPX_DEBUG_COLS", 0, nullptr},
+    {"cg_rows_per_wg", "DPX_CG_ROWS_PER_WG", 0, nullptr},
+    {"cg_cols_per_wg", "DPX_CG_COLS_PER_WG", 0, nullptr},
+    {"cg_gram_small", "DPX_CG_GRAM_SMALL", 0, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

@@ -386,6 +386,91 @@ __global__ void __launch_bounds__(256) k_gram_tile_test(float* __restrict__ r, f
   }
 }
 
+// The same launch for small batches (B <= 8, n_per_batch a multiple of 4): the slab kernel above pads every batch to 32 x 32 products
+// and runs 800 workgroups on a 4 x 320^2 residual (19.6 us per CG iteration of config 4's shard, most of it zero rows and the
+// finishing workgroup's 16 x 800 partial sums).  Here a thread holds the B values of four neighbouring elements (float4 per image),
+// accumulates the B (B + 1) / 2 distinct products in registers, and ~100 workgroups leave one partial per product: the same
+// interface (partial [B * B][nblk], finish + stop rule by the last workgroup to arrive), fixed summation order.
+template <int BT, bool UPDATE>
+__global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, float* __restrict__ partial, float* __restrict__ G, CgState S, long npb,
+                                                         int nblk, unsigned* __restrict__ counter, float init_rtol, float* __restrict__ x,
+                                                         const float* __restrict__ p, const float* __restrict__ Ap, int* __restrict__ host_flags) {
+  constexpr int NP = BT * (BT + 1) / 2;
+  __shared__ double rawd[64 * 65];                        // the test's matrix (cg_test_block)
+  __shared__ float red[4 * NP];
+  __shared__ int shf[3];
+  __shared__ float alpha_s[BT];
+  if (S.flags()[0]) return;                               // (uniform: the solve has converged, this launch ran ahead)
+  const int B = S.B, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if constexpr (UPDATE) {
+    if (tid < B) alpha_s[tid] = S.gamma()[tid] / S.pAp()[tid];
+    __syncthreads();
+  }
+  float acc[NP];
+#pragma unroll
+  for (int e = 0; e < NP; ++e) acc[e] = 0.f;
+  const long n4 = npb / 4;
+  for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+    float4 rv[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      rv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < B) {
+        const long at = (long)b * n4 + i;
+        rv[b] = ((const float4*)r)[at];
+        if constexpr (UPDATE) {
+          const float al = alpha_s[b];
+          const float4 pv = ((const float4*)p)[at], qv = ((const float4*)Ap)[at], xv = ((float4*)x)[at];
+          ((float4*)x)[at] = make_float4(fmaf(al, pv.x, xv.x), fmaf(al, pv.y, xv.y), fmaf(al, pv.z, xv.z), fmaf(al, pv.w, xv.w));
+          rv[b] = make_float4(fmaf(-al, qv.x, rv[b].x), fmaf(-al, qv.y, rv[b].y), fmaf(-al, qv.z, rv[b].z), fmaf(-al, qv.w, rv[b].w));
+          ((float4*)r)[at] = rv[b];
+        }
+      }
+    }
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < BT; ++a)
+#pragma unroll
+      for (int q = a; q < BT; ++q, ++e)
+        acc[e] = fmaf(rv[a].w, rv[q].w, fmaf(rv[a].z, rv[q].z, fmaf(rv[a].y, rv[q].y, fmaf(rv[a].x, rv[q].x, acc[e]))));
+  }
+#pragma unroll
+  for (int e = 0; e < NP; ++e) {
+    const float v = wave_sum(acc[e]);
+    if (lane == 0) red[wave * NP + e] = v;
+  }
+  __syncthreads();
+  if (tid < NP) {
+    const float v = ((red[tid] + red[NP + tid]) + red[2 * NP + tid]) + red[3 * NP + tid];
+    int a = 0, e0 = 0;                                   // pair index tid -> (a, q), a <= q
+    while (tid >= e0 + (BT - a)) { e0 += BT - a; ++a; }
+    const int q = a + (tid - e0);
+    if (a < B && q < B) {
+      dpx_st_agent(partial + ((long)a * B + q) * nblk + blockIdx.x, v);
+      if (q != a) dpx_st_agent(partial + ((long)q * B + a) * nblk + blockIdx.x, v);
+    }
+  }
+  if (!dpx_last_block(counter, (unsigned)nblk, &shf[2])) return;
+  for (int e = wave; e < B * B; e += 4) {
+    const float* pe = partial + (long)e * nblk;
+    float a0 = 0.f;
+    for (int i = lane; i < nblk; i += 64) a0 += dpx_ld_agent(pe + i);
+    const float v = wave_sum(a0);
+    if (lane == 0) G[e] = v;
+  }
+  __syncthreads();
+  cg_test_block(S, G, rawd, shf, init_rtol);
+  if (host_flags) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      host_flags[1] = S.flags()[1];
+      __threadfence_system();
+      host_flags[0] = S.flags()[0];
+      __threadfence_system();
+    }
+  }
+}
+
 static int gram_blocks(long npb) {
   long g = (npb + GR_CH - 1) / GR_CH;
   if (g > 1024) g = 1024;
@@ -791,6 +876,28 @@ int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, vo
     if (nblk > cap) nblk = cap;
   }
   if (env_blk > 0 && env_blk < nblk) nblk = env_blk;
+  const bool al16 = ((size_t)r % 16 == 0) && (!x || (((size_t)x % 16 == 0) && ((size_t)p % 16 == 0) && ((size_t)Ap % 16 == 0)));
+  if (B <= 8 && n_per_batch % 4 == 0 && al16 && tune(TUNE_CG_GRAM_SMALL) != 2) {
+    int nb = (int)((n_per_batch / 4 + 255) / 256);
+    nb = nb > 256 ? 256 : (nb < 1 ? 1 : nb);
+    if (env_blk > 0 && env_blk < nb) nb = env_blk;
+    const CgState S{(float*)state, B};
+#define DPX_GRAM_SMALL(BT)                                                                                                                       \
+  do {                                                                                                                                           \
+    if (x)                                                                                                                                       \
+      DPX_LAUNCH("k_gram_small_test_upd", (k_gram_small_test<BT, true>), dim3(nb), dim3(256), 0, s, r, (float*)ws, G, S, n_per_batch, nb, counter,  \
+                 init_rtol, x, p, Ap, host_flags);                                                                                               \
+    else                                                                                                                                         \
+      DPX_LAUNCH("k_gram_small_test", (k_gram_small_test<BT, false>), dim3(nb), dim3(256), 0, s, r, (float*)ws, G, S, n_per_batch, nb, counter,     \
+                 init_rtol, x, p, Ap, host_flags);                                                                                               \
+  } while (0)
+    if (B <= 1) DPX_GRAM_SMALL(1);
+    else if (B <= 2) DPX_GRAM_SMALL(2);
+    else if (B <= 4) DPX_GRAM_SMALL(4);
+    else DPX_GRAM_SMALL(8);
+#undef DPX_GRAM_SMALL
+    return launch_status("gram_test_fused");
+  }
   if (x)
     DPX_LAUNCH("k_gram_tile_test_upd", k_gram_tile_test<true>, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch,
                nblk, counter, init_rtol, x, p, Ap, host_flags);

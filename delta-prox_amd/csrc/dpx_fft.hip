@@ -864,12 +864,24 @@ int masked_normal_apply(const float* p, float* Ap, float2* z, const float* mask2
 
 // rows per row workgroup of the fused iteration: the largest divisor of H the LDS-resident transform holds (a workgroup's rows then
 // belong to one image: its <p, Ap> share is one number)
-static int fused_rpb(int H, int W) {
+// ... and, for a small batch, few enough rows that the launch has a workgroup for every CU: these launches are latency-bound (4 x 320^2:
+// 1.6 MB), and 128 workgroups of 10 rows each walk every Stockham pass twice (400 butterflies on 256 threads) on half the chip.
+static int fused_rpb(int B, int H, int W) {
   int r = rows_per_block(W);
-  while (r > 1 && H % r) --r;
+  const int knob = tune(TUNE_CG_ROWS_PER_WG);
+  if (knob > 0 && knob < r) r = knob;
+  while (r > 1 && (H % r || (knob <= 0 && (long)B * H / r < 256))) --r;
   return r;
 }
-size_t masked_normal_fused_ws_floats(int B, int H, int W) { return (size_t)B * (H / fused_rpb(H, W)) + 8; }
+static int fused_ct(int B, int H, int W) {
+  int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
+  CT = CT < 1 ? 1 : (CT > 16 ? 16 : CT);
+  const int knob = tune(TUNE_CG_COLS_PER_WG);
+  if (knob > 0) return knob < CT ? knob : CT;
+  while (CT > 4 && (long)B * ((W + CT - 1) / CT) < 256) --CT;      // (at least 4 columns = 32-byte pieces of a row)
+  return CT;
+}
+size_t masked_normal_fused_ws_floats(int B, int H, int W) { return (size_t)B * H + 8; }      // (one partial per workgroup; at most one workgroup per row)
 
 // The matvec of dpx_cg_masked_fft's fused iteration: the three launches above with the CG direction update in front (p = r + beta p
 // formed in the first kernel's load) and <p, Ap> behind (partial sums in the last kernel's store, finished by its last workgroup
@@ -877,10 +889,9 @@ size_t masked_normal_fused_ws_floats(int B, int H, int W) { return (size_t)B * (
 int masked_normal_apply_fused(float* p, const float* r, float* Ap, float2* z, const float* mask, int mask_images, const float* rho, float c,
                               float* state, float* dotws, unsigned* counter, int B, int H, int W, const void* table, hipStream_t s) {
   const Plan1D prow = make_plan(W), pcol = make_plan(H);
-  const int rpb = fused_rpb(H, W);
+  const int rpb = fused_rpb(B, H, W);
   const size_t shrow = (size_t)2 * rpb * (W + 1) * sizeof(float2);
-  int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
-  CT = CT < 1 ? 1 : (CT > 16 ? 16 : CT);
+  const int CT = fused_ct(B, H, W);
   const size_t shcol = (size_t)2 * CT * (H + 1) * sizeof(float2);
   const CgState S{state, B};
   const int* done = S.flags();

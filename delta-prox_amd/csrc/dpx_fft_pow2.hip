@@ -435,16 +435,48 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   constexpr bool TWG = DPX_COLS_TW_GLOBAL && (H >= 2048);
   const float2* twl = TWG ? twH : smem_p2 + COLS * S;
   float2 v[V];
+  // Input tile.  DMA_IN: by LDS-DMA, 16 bytes per lane (a wave instruction moves 16 rows x 64 bytes = 1 KB instead of 8 x 64), into
+  // the exchange buffer, each wave fetching exactly the rows its own lanes hold (piece j = rows t + T (2j + half), the table stage's
+  // lane map: value m of this lane lands at float2 index m * 64 + lane of the wave's image).  Piece j of wave w lands in column region j
+  // at slots [136 w, 136 w + 128) -- precisely the slots (17 t + m, t = 8 w .. 8 w + 7) this wave overwrites itself in the first pass,
+  // after it has read them (one wave's LDS operations execute in order): no other wave's stage is touched, no barrier is needed.
+  // Measured at 8x3x1024^2 (round 4, alternating runs on one box): k_cols_p2 72.3 us with it, 69.6 - 70.7 us without -- half the load
+  // instructions and no address arithmetic, but the tile crosses the LDS once more and the first pass waits for a full vmcnt(0): OFF.
+#ifndef DPX_COLS_DMA_IN
+#define DPX_COLS_DMA_IN 0
+#endif
+  constexpr bool DMA_IN = DPX_COLS_DMA_IN && DPX_COLS_PACK0 && !R3 && COLS == 8 && V == 16 && SPEC_TILE == 16 && !DBG;
+  if constexpr (DMA_IN) {
+    constexpr int RPW = 64 / COLS, LPR = COLS / 2;
+    const int lane_ = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane_ >> 5, li = lane_ & 31;
+    const float2* src = (const float2*)pin + (unsigned)((RPW * wv + li / LPR + T * half) * SPEC_TILE + (li % LPR) * 2) + sub_off;
+    float2* stg = smem_p2 + wv * (V * RPW + RPW);        // 17 * 8 slots per wave and column region
 #pragma unroll
-  for (int m = 0; m < V; ++m) v[m] = ld_stream<COLS_LD_NT>((const float2*)(pin + (off0 + step * hrow(m)) * 8u));
+    for (int j = 0; j < V / 2; ++j) dpx_glds16<COLS_LD_NT>(src + j * 2 * T * SPEC_TILE, stg + j * S);
+  } else {
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[m] = ld_stream<COLS_LD_NT>((const float2*)(pin + (off0 + step * hrow(m)) * 8u));
+  }
   const bool dc_lane = PACK && c == 0;               // the lanes carrying the packed (DC, Nyquist) column
+  float sidev[PACK ? V : 1];
   if (dc_lane) {                                      // (row spectra: both columns are real on entry)
     const float* sidef = (const float*)(spec_in + (size_t)P * H * Ws + (size_t)p * H + TMUL * t);
 #pragma unroll
-    for (int m = 0; m < V; ++m) v[m].y = sidef[2 * hrow(m)];
+    for (int m = 0; m < V; ++m) sidev[PACK ? m : 0] = sidef[2 * hrow(m)];
   }
   if constexpr (!TWG) {
     for (int i = tid; i < H; i += T * COLS) smem_p2[COLS * S + i] = twH[i];
+  }
+  if constexpr (DMA_IN) {
+    dpx_wait_vm<0>();                                 // this wave's pieces have landed (and its twiddle / side loads returned)
+    const float2* stg = smem_p2 + __builtin_amdgcn_readfirstlane(tid >> 6) * (V * (64 / COLS) + 64 / COLS) + (tid & 63);
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[m] = stg[(m >> 1) * S + (m & 1) * 64];
+  }
+  if (dc_lane) {
+#pragma unroll
+    for (int m = 0; m < V; ++m) v[m].y = sidev[PACK ? m : 0];
   }
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const char* add = (OP == OP_SOLVE && A.add) ? (const char*)(A.add + ubase) : nullptr;

@@ -53,11 +53,11 @@ template <int DIR> __device__ __forceinline__ void rdft2(float2& a, float2& b) {
 }
 template <int DIR> __device__ __forceinline__ void rdft4(float2& a0, float2& a1, float2& a2, float2& a3) {
   const float2 s0 = cadd(a0, a2), d0 = csub(a0, a2);
-  const float2 s1 = cadd(a1, a3), d1 = cmul_i<DIR>(csub(a1, a3));
+  const float2 s1 = cadd(a1, a3), e1 = csub(a1, a3);
   a0 = cadd(s0, s1);
   a2 = csub(s0, s1);
-  a1 = cadd(d0, d1);
-  a3 = csub(d0, d1);
+  a1 = cadd_rot<DIR>(d0, e1);          // d0 +- (-+i) e1: the rotation is the butterfly's operand selection
+  a3 = csub_rot<DIR>(d0, e1);
 }
 // multiply by exp(DIR * i * pi * q / 8), q = 1..7, constants folded
 template <int DIR, int Q> __device__ __forceinline__ float2 rot16(float2 a) {
@@ -65,16 +65,16 @@ template <int DIR, int Q> __device__ __forceinline__ float2 rot16(float2 a) {
   constexpr float cr = (Q == 1) ? c1 : (Q == 2) ? h : (Q == 3) ? s1 : (Q == 4) ? 0.f : (Q == 5) ? -s1 : (Q == 6) ? -h : -c1;
   constexpr float sr = (Q == 1) ? s1 : (Q == 2) ? h : (Q == 3) ? c1 : (Q == 4) ? 1.f : (Q == 5) ? c1 : (Q == 6) ? h : s1;
   constexpr float si = DIR < 0 ? -sr : sr;
-  return make_float2(a.x * cr - a.y * si, a.x * si + a.y * cr);
+  return cmul_const(a, cr, si);
 }
 template <int DIR> __device__ __forceinline__ void rdft8(float2 (&v)[8]) {
   rdft4<DIR>(v[0], v[2], v[4], v[6]);     // even samples -> E[0..3] in v[0],v[2],v[4],v[6]
   rdft4<DIR>(v[1], v[3], v[5], v[7]);     // odd samples  -> O[0..3] in v[1],v[3],v[5],v[7]
   const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-  const float2 o0 = v[1], o1 = rot16<DIR, 2>(v[3]), o2 = cmul_i<DIR>(v[5]), o3 = rot16<DIR, 6>(v[7]);
+  const float2 o0 = v[1], o1 = rot16<DIR, 2>(v[3]), o2 = v[5], o3 = rot16<DIR, 6>(v[7]);
   v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
   v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
-  v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+  v[2] = cadd_rot<DIR>(e2, o2); v[6] = csub_rot<DIR>(e2, o2);
   v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 template <int DIR> __device__ __forceinline__ void rdft16(float2 (&v)[16]) {
@@ -85,14 +85,18 @@ template <int DIR> __device__ __forceinline__ void rdft16(float2 (&v)[16]) {
   o[1] = rot16<DIR, 1>(o[1]);
   o[2] = rot16<DIR, 2>(o[2]);
   o[3] = rot16<DIR, 3>(o[3]);
-  o[4] = cmul_i<DIR>(o[4]);
   o[5] = rot16<DIR, 5>(o[5]);
   o[6] = rot16<DIR, 6>(o[6]);
   o[7] = rot16<DIR, 7>(o[7]);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    v[k] = cadd(e[k], o[k]);
-    v[k + 8] = csub(e[k], o[k]);
+    if (k == 4) {                        // o[4] carries the factor -+i: folded into the butterfly
+      v[k] = cadd_rot<DIR>(e[k], o[k]);
+      v[k + 8] = csub_rot<DIR>(e[k], o[k]);
+    } else {
+      v[k] = cadd(e[k], o[k]);
+      v[k + 8] = csub(e[k], o[k]);
+    }
   }
 }
 template <int R, int DIR> __device__ __forceinline__ void rdft(float2 (&v)[R]) {
@@ -204,11 +208,11 @@ __device__ __forceinline__ void fft_reg(float2 (&v)[N / T], float2* __restrict__
 // barriers as one power-of-two transform.  tw: exp(-2 pi i k / (3N * tws)) table, stride tws.
 template <int DIR> __device__ __forceinline__ void rdft3(float2& a0, float2& a1, float2& a2) {
   constexpr float h = 0.86602540378443864676f;
-  const float2 s = cadd(a1, a2), d = cmul_i<DIR>(cscale(csub(a1, a2), h));
+  const float2 s = cadd(a1, a2), d = cscale(csub(a1, a2), h);
   const float2 m = make_float2(fmaf(-0.5f, s.x, a0.x), fmaf(-0.5f, s.y, a0.y));
   a0 = cadd(a0, s);
-  a1 = cadd(m, d);
-  a2 = csub(m, d);
+  a1 = cadd_rot<DIR>(m, d);
+  a2 = csub_rot<DIR>(m, d);
 }
 template <int N, int T, int DIR, class Sync, class Hook = NoHook>
 __device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __restrict__ lds, int t, const float2* __restrict__ tw, int tws,

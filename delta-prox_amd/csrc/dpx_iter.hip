@@ -18,6 +18,14 @@
 #include <cstring>
 #include <type_traits>
 
+// The hand-written VOP3P complex primitives (dpx_common.h: DPX_PK_ASM) are OFF in this file: the same arithmetic in the same rounding
+// order from the C forms (bit-identical results).  Measured, round 4, alternating runs on one box at 8x3x1024^2: k_iter_rows_seq
+// 110.1 - 111.4 us with the asm forms (1850 vector instructions, 193 VGPRs) against 108.0 us without (2028, 224) -- this kernel sits on
+// the memory system's copy rate, and hipcc schedules the opaque asm pairs worse than its own code; the column kernel
+// (dpx_fft_pow2.hip) gains 2 - 3 us from them.
+#ifndef DPX_PK_ASM
+#define DPX_PK_ASM 0
+#endif
 #include "dpx_fft_reg.h"
 
 namespace dpx {

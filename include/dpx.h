@@ -78,6 +78,10 @@ int dpx_timing_report(char* buf, size_t cap);
  *   ds_col_threads                                                                        DPX_DS_COL_THREADS
  *   cols_persist_wg      workgroups per CU of the persistent column kernel (builds with   DPX_COLS_PERSIST_WG
  *                        DPX_COLS_PERSIST only)
+ *   cg_rows_per_wg,      rows / columns per workgroup of the fused CG matvec's transform      DPX_CG_ROWS_PER_WG,
+ *   cg_cols_per_wg       kernels (0 = enough workgroups to cover the chip's 256 CUs)             DPX_CG_COLS_PER_WG
+ *   cg_gram_small        fused CG, B <= 8: 1 = the register Gram kernel (default rule),          DPX_CG_GRAM_SMALL
+ *                        2 = the 32 x 32 slab kernel of larger batches
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */
