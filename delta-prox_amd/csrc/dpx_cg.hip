@@ -223,6 +223,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
     int* pin = nullptr;
     int* pin_dev = nullptr;     // the same memory as the device addresses it
     hipEvent_t ev[4];
+    int hint = -1;              // exit iteration of this thread's previous fused solve on this device (-1: none yet)
   };
   static thread_local Ring rings[DPX_CG_MAX_DEVICES];
   int devid = 0;
@@ -302,6 +303,19 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
         CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, nullptr, nullptr, nullptr, nullptr, s));
       } else {
         CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, it > 0 ? x : nullptr, p, Ap, pin_dev + (it & 3) * 4, s));
+        // Consecutive solves of one outer loop exit at the same iteration almost always (config 4: 2, 3, 3, 3, ...).  At the iteration the
+        // previous solve stopped at, look at THIS test's flag right away -- one host round trip, which the end of the solve pays
+        // anyway -- instead of finding out two iterations (seven empty launches) later.  A miss costs that one wait.
+        if (it == R.hint && it > 0 && !tune(TUNE_CG_NO_HINT)) {
+          CG_HIP(hipEventRecord(ev[it & 3], s));
+          CG_HIP(hipEventSynchronize(ev[it & 3]));
+          if (pin[(it & 3) * 4]) {
+            done = true;
+            done_it = pin[(it & 3) * 4 + 1];
+            last = -1;                                      // (nothing pending behind this point: the update below is not needed either)
+            break;
+          }
+        }
       }
       CG_TRY(dpx::masked_normal_apply_fused(p, r, Ap, z0, mask, mask_images, rho, n_identity, state, fdot, counters + 1, B, H, W, table, s));
       if (split_update) {
@@ -311,7 +325,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
       CG_HIP(hipEventRecord(ev[it & 3], s));
       last = it;
     }
-    if (!split_update && last >= 0) CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));     // the last iteration's update (a no-op once converged)
+    if (!split_update && last >= 0 && !done) CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));     // the last iteration's update (max_iters reached without convergence)
     if (!done && last >= 0) {
       // the iterations the loop did not look at yet, oldest first (a launch behind the converged one leaves its slot untouched)
       CG_HIP(hipEventSynchronize(ev[last & 3]));
@@ -321,6 +335,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
           break;
         }
     }
+    R.hint = done_it;
     const int st = launch_status("dpx_cg_masked_fft");
     return st != DPX_OK ? st : done_it;
   }

@@ -870,7 +870,7 @@ static int fused_rpb(int B, int H, int W) {
   int r = rows_per_block(W);
   const int knob = tune(TUNE_CG_ROWS_PER_WG);
   if (knob > 0 && knob < r) r = knob;
-  while (r > 1 && (H % r || (knob <= 0 && (long)B * H / r < 256))) --r;
+  while (r > 1 && (H % r || (knob <= 0 && (long)B * H / r < 320))) --r;      // (measured at 4 x 320^2: 10 / 5 / 4 / 2 rows: 0.757 / 0.721 / 0.706 / 0.720 ms per outer iteration)
   return r;
 }
 static int fused_ct(int B, int H, int W) {
@@ -878,7 +878,7 @@ static int fused_ct(int B, int H, int W) {
   CT = CT < 1 ? 1 : (CT > 16 ? 16 : CT);
   const int knob = tune(TUNE_CG_COLS_PER_WG);
   if (knob > 0) return knob < CT ? knob : CT;
-  while (CT > 4 && (long)B * ((W + CT - 1) / CT) < 256) --CT;      // (at least 4 columns = 32-byte pieces of a row)
+  while (CT > 4 && (long)B * ((W + CT - 1) / CT) < 320) --CT;      // (at least 4 columns = 32-byte pieces of a row; 11 / 8 / 5 / 4 columns: 0.737 / 0.720 / 0.714 / 0.706 ms)
   return CT;
 }
 size_t masked_normal_fused_ws_floats(int B, int H, int W) { return (size_t)B * H + 8; }      // (one partial per workgroup; at most one workgroup per row)

@@ -82,6 +82,8 @@ int dpx_timing_report(char* buf, size_t cap);
  *   cg_cols_per_wg       kernels (0 = enough workgroups to cover the chip's 256 CUs)             DPX_CG_COLS_PER_WG
  *   cg_gram_small        fused CG, B <= 8: 1 = the register Gram kernel (default rule),          DPX_CG_GRAM_SMALL
  *                        2 = the 32 x 32 slab kernel of larger batches
+ *   cg_no_hint           1 = the fused CG does not look at the stop flag early at the iteration   DPX_CG_NO_HINT
+ *                        the previous solve exited at (same result, seven more empty launches)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */

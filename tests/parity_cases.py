@@ -378,6 +378,7 @@ CG_BRANCHES = (("default", {}),
                ("fused", dict(cg_fused_max_b=32, cg_split_update=0, cg_unfused=0)),
                ("fused + split update", dict(cg_fused_max_b=32, cg_split_update=1, cg_unfused=0)),
                ("fused, slab Gram kernel", dict(cg_fused_max_b=32, cg_gram_small=2)),
+               ("fused, no exit-iteration hint", dict(cg_fused_max_b=32, cg_no_hint=1)),
                ("fused, 2 rows / 4 columns per workgroup", dict(cg_fused_max_b=32, cg_rows_per_wg=2, cg_cols_per_wg=4)),
                ("step by step", dict(cg_fused_max_b=0)),
                ("step by step (cg_unfused)", dict(cg_fused_max_b=32, cg_unfused=1)))
