@@ -26,7 +26,10 @@ namespace dpx {
 // image domain and bin (t + a T) + r M/3 in the frequency domain.  krow: the part of the frequency map that does not depend on t;
 // the bin M - k that the real-input (un)tangling pairs with bin k sits in lane (T - t) % T, register pne(m) (t != 0) / peq(m) (t == 0).
 template <int M, int T> struct RowMap {
-  static constexpr bool R3 = (M % 3 == 0);
+  // (M = 384 on T = 64 lanes: the one-wave 6 * 8 * 8 transform fft384_wave with the power-of-two register map -- the two-kernel
+  //  iteration's 768-wide rows; the staged kernels keep M = 384 on 16 lanes with the interleaved map)
+  static constexpr bool W384 = (M == 384 && T == 64);
+  static constexpr bool R3 = (M % 3 == 0) && !W384;
   static constexpr int V = M / T, VS = R3 ? V / 3 : V, N = R3 ? M / 3 : M;
   static constexpr int LDS_SLOTS = R3 ? 3 * LdsSeq<N>::SLOTS : LdsSeq<M>::SLOTS;
   __device__ static constexpr int krow(int m) { return R3 ? (m % VS) * T + (m / VS) * N : m * T; }
@@ -73,7 +76,8 @@ template <int M, int T> struct RowMap {
   // spectrum offset of bin krow(m) relative to the lane's bin t (column-tile-major: bin k of image row h at ((k >> 3) H + h) 8 + (k & 7))
   __device__ static constexpr size_t koff(int m, int H) { return (size_t)(krow(m) / SPEC_TILE) * H * SPEC_TILE; }
   template <int DIR> __device__ static __forceinline__ void fft(float2 (&v)[V], float2* lds, int t, const float2* __restrict__ twW) {
-    if constexpr (R3) fft_reg_x3<N, T, DIR>(v, lds, t, twW, 2, WaveSync());
+    if constexpr (W384) fft384_wave_tab<DIR>(v, lds, t, twW, 2, WaveSync());
+    else if constexpr (R3) fft_reg_x3<N, T, DIR>(v, lds, t, twW, 2, WaveSync());
     else fft_reg<M, T, DIR>(v, lds, t, twW, 2, WaveSync());
   }
   // Z (the transform of the row read as complex pairs) -> X (the row's half spectrum); returns the (real) Nyquist bin in lane t = 0
@@ -872,6 +876,7 @@ int seed_rows_pow2(const dpx_term* terms, int nterms, const float* rho, const fl
   switch (W) {
     case 256: launch_seed<128, 16>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;
     case 512: launch_seed<256, 32>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;
+    case 768: launch_seed<384, 64>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;
     default: launch_seed<512, 64>(S_, rho, spec, nrows, H, C, tw_rows(table), stream); break;
   }
   return launch_status("dpx_admm_seed_rows");

@@ -294,6 +294,80 @@ __device__ __forceinline__ void fft_reg_x3(float2 (&v)[3 * N / T], float2* __res
   }
 }
 
+// ---- length 384 = 6 * 8 * 8 on ONE wave (T = 64 lanes, 6 values per lane), natural order in and out -----------------------------------
+// v[m] = x[t + 64 m] on entry, X[t + 64 m] on exit -- the striding of the power-of-two transforms above, so the kernels that own
+// "pixel pairs t + m T" of a row (the streaming row kernels of the two-kernel iteration) take 768-wide rows unchanged: the reference's
+// own patch size is 768 x 768 (contrib/optic/utils.py:158-166).  Stockham passes of radix 6 (all 64 lanes), 8 and 8 (48 butterflies each:
+// lanes 48 .. 63 idle) and one redistribution read; every exchange is wave-local (sync = wave barrier).
+//   pass A: j = t < 64    in x[j + 64 m]              out[6 j + m]
+//   pass B: j < 48, k = j % 6: in[j + 48 m] W_48^{k m}  out[8 (j - k) + k + 6 m]
+//   pass C: j < 48:        in[j + 48 m] W_384^{j m}     out[j + 48 m]
+// twb[m - 1] = W_48^{(t % 6) m}, twc[m - 1] = W_384^{t m}, m = 1 .. 7 (lanes t < 48), forward-direction values.
+template <int DIR> __device__ __forceinline__ void rdft6(float2 (&v)[6]) {
+  float2 e0 = v[0], e1 = v[2], e2 = v[4], o0 = v[1], o1 = v[3], o2 = v[5];
+  rdft3<DIR>(e0, e1, e2);
+  rdft3<DIR>(o0, o1, o2);
+  constexpr float h = 0.86602540378443864676f, si = DIR < 0 ? -h : h;
+  o1 = cmul_const(o1, 0.5f, si);                       // W_6
+  o2 = cmul_const(o2, -0.5f, si);                      // W_6^2
+  v[0] = cadd(e0, o0); v[3] = csub(e0, o0);
+  v[1] = cadd(e1, o1); v[4] = csub(e1, o1);
+  v[2] = cadd(e2, o2); v[5] = csub(e2, o2);
+}
+struct Tw384 {
+  float2 b[7], c[7];
+  __device__ __forceinline__ void load(int t, const float2* __restrict__ tw, int tws) {      // tw[n tws] = exp(-2 pi i n / 384)
+    const int j = t < 48 ? t : 0, k = j % 6;
+#pragma unroll
+    for (int m = 1; m < 8; ++m) {
+      b[m - 1] = tw[(8 * k * m) * tws];
+      c[m - 1] = tw[(j * m) * tws];
+    }
+  }
+};
+template <int DIR, class Sync>
+__device__ __forceinline__ void fft384_wave(float2 (&v)[6], float2* __restrict__ lds, int t, const Tw384& W, Sync sync) {
+  rdft6<DIR>(v);
+#pragma unroll
+  for (int m = 0; m < 6; ++m) lds[lds_slot(6 * t + m)] = v[m];
+  sync();
+  float2 a[8];
+  const bool act = t < 48;
+  const int j = act ? t : 0, k = j % 6;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) a[m] = lds[lds_slot(j + 48 * m)];
+  sync();
+#pragma unroll
+  for (int m = 1; m < 8; ++m) a[m] = twmul<DIR>(a[m], W.b[m - 1]);
+  rdft8<DIR>(a);
+  if (act) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) lds[lds_slot(8 * (j - k) + k + 6 * m)] = a[m];
+  }
+  sync();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) a[m] = lds[lds_slot(j + 48 * m)];
+  sync();
+#pragma unroll
+  for (int m = 1; m < 8; ++m) a[m] = twmul<DIR>(a[m], W.c[m - 1]);
+  rdft8<DIR>(a);
+  if (act) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) lds[lds_slot(j + 48 * m)] = a[m];
+  }
+  sync();
+#pragma unroll
+  for (int m = 0; m < 6; ++m) v[m] = lds[lds_slot(t + 64 * m)];
+}
+
+// the same transform with its twiddles read from a table on the spot (kernels that transform one row per thread group)
+template <int DIR, class Sync>
+__device__ __forceinline__ void fft384_wave_tab(float2 (&v)[6], float2* __restrict__ lds, int t, const float2* __restrict__ tw, int tws, Sync sync) {
+  Tw384 W;
+  W.load(t, tw, tws);
+  fft384_wave<DIR>(v, lds, t, W, sync);
+}
+
 // The twiddles a thread needs depend only on its index t: kernels that transform many sequences with the same
 // thread mapping (one row after another) load them once into registers and reuse them for every transform.
 template <int N, int T, bool KEEPB = true> struct TwRegs {
@@ -318,9 +392,25 @@ template <int N, int T, bool KEEPB = true> struct TwRegs {
   }
 };
 
+// 384 points on one wave: the twiddle registers of fft384_wave behind the same interface (twb_ / bstride_ are accepted and unused)
+template <bool KEEPB> struct TwRegs<384, 64, KEEPB> {
+  Tw384 w;
+  const float2* twb_;
+  int bstride_;
+  __device__ __forceinline__ void load(int t, const float2* __restrict__ tw, int tws) {
+    twb_ = tw;
+    bstride_ = tws;
+    w.load(t, tw, tws);
+  }
+};
+
 // fft_reg with preloaded twiddles (same passes, same LDS image)
 template <int N, int T, int DIR, bool KEEPB, class Sync>
 __device__ __forceinline__ void fft_reg_tw(float2 (&v)[N / T], float2* __restrict__ lds, int t, const TwRegs<N, T, KEEPB>& W, Sync sync) {
+  if constexpr (N == 384 && T == 64) {
+    fft384_wave<DIR>(v, lds, t, W.w, sync);
+    return;
+  } else {
   constexpr int V = N / T;
   constexpr int RM = N / (V * V);
   using IX = LdsIdx<N, T>;
@@ -387,6 +477,7 @@ __device__ __forceinline__ void fft_reg_tw(float2 (&v)[N / T], float2* __restric
 #pragma unroll
   for (int m = 1; m < V; ++m) v[m] = twmul<DIR>(v[m], W.c[m - 1]);
   rdft<V, DIR>(v);
+  }
 }
 
 struct BlockSync {

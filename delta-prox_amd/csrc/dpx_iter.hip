@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       for (int m = 0; m < V; ++m) {
         const int k = t + m * T;
         Xk[m] = stX[stage_idx(k)];
-        Xm[m] = stX[stage_idx((M - k) & (M - 1))];
+        Xm[m] = stX[stage_idx((M - k) % M)];
       }
       const float xn = stN[g * T];
       dpx_wait_lds();
@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(256, 2) k_pgd_rows_seq(const float2* __restric
       for (int m = 0; m < V; ++m) {
         const int k = t + m * T;
         Xk[m] = stX[stage_idx(k)];
-        Xm[m] = stX[stage_idx((M - k) & (M - 1))];
+        Xm[m] = stX[stage_idx((M - k) % M)];
       }
       const float xn = stN[g * T];
       dpx_wait_lds();
@@ -882,6 +882,7 @@ bool pgd_rows_seq_pow2(const float2* sin, float2* sout, float* x, const float* k
     case 256: return launch_pgd_rows_seq<128, 16>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
     case 512: return launch_pgd_rows_seq<256, 32>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
     case 1024: return launch_pgd_rows_seq<512, 64>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
+    case 768: return launch_pgd_rows_seq<384, 64>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
     default: return false;
   }
 }
@@ -1069,6 +1070,7 @@ bool seed_rows_seq_pow2(const int* linops, int n, const float* rho, const float*
     case 256: return launch_seed_rows_seq<128, 16>(SO, rho, x0, spec, C, H, P, tw_rows(table), s);
     case 512: return launch_seed_rows_seq<256, 32>(SO, rho, x0, spec, C, H, P, tw_rows(table), s);
     case 1024: return launch_seed_rows_seq<512, 64>(SO, rho, x0, spec, C, H, P, tw_rows(table), s);
+    case 768: return launch_seed_rows_seq<384, 64>(SO, rho, x0, spec, C, H, P, tw_rows(table), s);
     default: return false;
   }
 }
@@ -1122,7 +1124,8 @@ extern "C" int dpx_admm_iter_config(int rows_mode, int bands_per_plane) {
 extern "C" int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms) {
   // (2048-wide planes: 16 values per thread spill in the row kernel -- 33 ps per pixel and iteration against 14 on the staged
   //  kernels, which the callers fall back to)
-  const bool wok = W == 256 || W == 512 || W == 1024 || (W == 2048 && tune(TUNE_ITER_W2048))     /* knob: keep the two-kernel iteration on 2048-wide planes */;     // (768 / 1536: 24 values per thread, staged kernels only)
+  // 768-wide rows: M = 384 = 6 * 8 * 8 on one wave per row (fft384_wave, 6 values per lane) in the streaming kernels; 1536: staged kernels only
+  const bool wok = W == 256 || W == 512 || W == 768 || W == 1024 || (W == 2048 && tune(TUNE_ITER_W2048))     /* knob: keep the two-kernel iteration on 2048-wide planes */;
   return pow2_path_available(H, W) && wok && H % 16 == 0 && terms_ok(terms, nterms);
 }
 
@@ -1205,10 +1208,10 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   // (small launches -- a few 256-wide planes -- are latency-bound: the ring-buffer kernel's row-parallel bands finish ~10 %
   //  sooner there than the streaming kernel's sequential ones; measured crossover between 256- and 512-wide planes)
   const bool tiny = W <= 256 && (long)P * H <= 4096 && !(mode && !strcmp(mode, "seq"));
-  if (!(mode && !strcmp(mode, "lockstep")) && W <= 1024 && !tiny) {
+  if ((!(mode && !strcmp(mode, "lockstep")) && W <= 1024 && !tiny) || W == 768) {      // (768-wide rows exist on the streaming kernel only)
     // as many bands per plane as keep every T-lane group of the launch resident at once (2 workgroups of 4 waves per
     // CU), rounded so that the groups fill whole workgroups; bands are >= 4 rows (halo = 2 extra inverse transforms)
-    const int T = W / 16, G = 64 / T, per_block = 4 * G;
+    const int T = W == 768 ? 64 : W / 16, G = 64 / T, per_block = 4 * G;
     int nb = (256 * 2 * 4 * G) / (P * dpx::g_chain_share);
     // ... rounded UP to a power of two (H is one): bands of equal length keep the waves of a workgroup in step, and ~1.5 rounds
     // of resident groups beat one round of unequal bands (8x3x1024^2: 128 bands of 8 rows 106 us, 85 bands of 12-13 rows 109 us,
@@ -1225,11 +1228,13 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
       switch (W) {
         case 256: launch_iter_rows_seq<128, 16>(sin, sout, TT, rho_next, x_out, emit_v, C, H, nb, P, tw, s); break;
         case 512: launch_iter_rows_seq<256, 32>(sin, sout, TT, rho_next, x_out, emit_v, C, H, nb, P, tw, s); break;
+        case 768: launch_iter_rows_seq<384, 64>(sin, sout, TT, rho_next, x_out, emit_v, C, H, nb, P, tw, s); break;
         default: launch_iter_rows_seq<512, 64>(sin, sout, TT, rho_next, x_out, emit_v, C, H, nb, P, tw, s); break;
       }
       return launch_status("dpx_admm_iter_rows");
     }
   }
+  DPX_REQUIRE(W != 768, "dpx_admm_iter_rows: no band partition of %d planes of %d rows for the 768-wide streaming kernel", P, H);
   const int r_env = tune(TUNE_ITER_R);   // tuning: rows per band of the ring-buffer kernel
   // (256-wide planes: 16 rows are in flight per workgroup, so a band of 8 rows + its 2 halo rows is ONE step of the kernel instead
   //  of two -- these launches are latency-bound: config 1 0.78 -> 0.62 ms per 20-iteration solve)

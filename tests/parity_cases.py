@@ -272,6 +272,43 @@ def case_other_plane_sizes(device, sizes=((384, 256), (1536, 256), (2048, 256), 
         assert_close(out.cpu(), ref, TOL, f"PGD x 3, {H}x{W}")
 
 
+def case_w768_two_kernel(device, H=256):
+    """768-wide rows on the two-kernel iteration (384 = 6 * 8 * 8 complex points per row on one wave, fft384_wave): ADMM, half-quadratic
+    splitting and ADMM_vxu with full states against the op-by-op iteration on the size-generic kernels, and the fresh-state /
+    touched-state seeds against each other.  (768 x 768 is the reference's own patch size, contrib/optic/utils.py:158-166.)"""
+    import synthetic
+    from dprox import _ops as ops
+    x0 = torch.zeros(1, 1, H, 768, device=device)
+    terms = ops.make_terms([dict(linop=1, prox=0, alpha=1.0, lam=None, v=x0, u=x0), dict(linop=2, prox=0, alpha=1.0, lam=None, v=x0, u=x0)])
+    assert ops.iter_supported(H, 768, terms, 2), "768-wide planes must be on the two-kernel iteration"
+    gt, b0, psf = synthetic.deconv_case(2, 1, H, 768, seed=3)
+    b = T(b0, device)
+    outs = {}
+    for fused in (True, False):
+        for method in ("admm", "hqs", "admm_vxu"):
+            x = dp.Variable()
+            fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
+            s = dp.compile(fns, method=method, device=device)
+            s.use_fused = fused
+            outs[(fused, method)] = s.solve(x0=b, rhos=0.2, lams=0.01, max_iter=4, return_full_states=True)
+            assert s.last_path == ("fused" if fused else "generic"), (method, s.last_path)
+    for method in ("admm", "hqs", "admm_vxu"):
+        a, c = outs[(True, method)], outs[(False, method)]
+        assert_close(a[0].cpu(), c[0].cpu(), TOL, f"768-wide {method}: x, two-kernel vs op by op")
+        for p, q in zip(a[1], c[1]):
+            close_on_scale(p.cpu().numpy(), q.cpu().numpy(), c[0].cpu().numpy(), 5e-5, f"768-wide {method}: v on the scale of x")
+    # a touched state takes the general seed (k_seed_rows), a fresh one the streaming seed: same iterate up to one transform's round-off
+    x = dp.Variable()
+    fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
+    s = dp.compile(fns, method="admm", device=device)
+    st = s.initialize(b.clone())
+    st[2][0].add_(0.0)                                       # (touching the state disables the fresh-state shortcut)
+    rh, lm = s.defaults(b, 0.2, 0.01, 3)[1:3]
+    touched = s.iters(st, rh.to(device), {k: v.to(device) for k, v in lm.items()}, 3)[0]
+    fresh = s.solve(x0=b, rhos=0.2, lams=0.01, max_iter=3)
+    assert_close(touched.cpu(), fresh.cpu(), 2e-6, "768-wide: general seed vs fresh-state seed")
+
+
 def case_unrolled_plane_sizes(device, shapes=((1, 3, 768, 1024), (1, 3, 768, 768))):
     """unrolled ADMM x 4 (forward on the two-kernel iteration / the staged kernels, hand-written backward stages) on the 3 * 2^k planes
     against float64 autograd through oracle.admm_f64: iterate and loss at 1e-5, gradients w.r.t. the rho / lambda schedules and

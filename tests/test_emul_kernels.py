@@ -50,6 +50,10 @@ def test_column_length_768():
     pc.case_h768(DEV, tiny=True)
 
 
+def test_768_wide_rows_on_the_two_kernel_iteration():
+    pc.case_w768_two_kernel(DEV)
+
+
 def test_other_plane_sizes():
     pc.case_other_plane_sizes(DEV, sizes=((384, 256), (256, 768)), channels=1)
 

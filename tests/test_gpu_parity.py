@@ -55,6 +55,10 @@ def test_column_length_768():
     pc.case_h768(DEV)
 
 
+def test_768_wide_rows_on_the_two_kernel_iteration():
+    pc.case_w768_two_kernel(DEV)
+
+
 def test_other_plane_sizes():
     pc.case_other_plane_sizes(DEV)
 
@@ -443,7 +447,7 @@ def test_reordered_algorithms_fused_vs_op_by_op(method, shape):
 
 
 
-@pytest.mark.parametrize("W", [256, 512, 1024])
+@pytest.mark.parametrize("W", [256, 512, 768, 1024])
 def test_streaming_row_kernel_wait_counts_stress(W):
     """Hardware-only (the host emulator replaces LDS-DMA by memcpy and s_waitcnt by a wave barrier): the streaming row kernel's
     hand-counted vmcnt waits under many band partitions and term sets, at T = 16 / 32 / 64 lanes per row.  A row's arithmetic
@@ -457,7 +461,7 @@ def test_streaming_row_kernel_wait_counts_stress(W):
     from dprox import _backend as be
     L = be.lib()
     rng = np.random.RandomState(W)
-    T_lanes = W // 16
+    T_lanes = 64 if W == 768 else W // 16                 # (768-wide rows: 384 = 6 * 8 * 8 complex points on one wave, 6 values per lane)
     per_block = 4 * (64 // T_lanes)
 
     def timing_names():
@@ -476,7 +480,7 @@ def test_streaming_row_kernel_wait_counts_stress(W):
             cands = [nb for nb in range(1, H // 4 + 1) if (P * nb) % per_block == 0]
             picks = sorted(set(int(c) for c in rng.choice(cands, size=min(4, len(cands)), replace=False)) | {cands[0], cands[-1]})
 
-            def run(rows_mode, bands):
+            def run(rows_mode, bands, fused=True):
                 L.call("dpx_admm_iter_config", rows_mode, bands)
                 x = dp.Variable()
                 fns = dp.sum_squares(dp.conv(x, psf) - bt)
@@ -489,6 +493,7 @@ def test_streaming_row_kernel_wait_counts_stress(W):
                 if "l1" in terms:
                     fns = fns + dp.norm1(x) * 0.5
                 s = dp.compile(fns, method="admm", device=DEV)
+                s.use_fused = fused
                 rhos = torch.linspace(0.4, 0.2, 4).repeat(B, 1) * torch.linspace(1.0, 1.5, B).view(B, 1)
                 L.call("dpx_timing_enable", 1)
                 timing_names()
@@ -496,7 +501,7 @@ def test_streaming_row_kernel_wait_counts_stress(W):
                 torch.cuda.synchronize()
                 names = timing_names()
                 L.call("dpx_timing_enable", 0)
-                assert s.last_path == "fused"
+                assert s.last_path == ("fused" if fused else "generic")
                 return [st[0]] + list(st[1]) + list(st[2]), names
 
             base, names = run(1, picks[0])
@@ -506,11 +511,18 @@ def test_streaming_row_kernel_wait_counts_stress(W):
                 assert "k_iter_rows_seq" in names
                 for a, c in zip(base, other):
                     assert torch.equal(a, c), (W, H, B, C, terms, picks[0], nb)
-            lock, names = run(2, 0)
-            assert "k_iter_rows" in names and "k_iter_rows_seq" not in names
+            if W == 768:                                   # (no lock-step kernel at this width: the op-by-op kernels are the independent reference)
+                lock, names = run(0, 0, fused=False)
+                assert "k_iter_rows_seq" not in names
+            else:
+                lock, names = run(2, 0)
+                assert "k_iter_rows" in names and "k_iter_rows_seq" not in names
             # (a single gradient term leaves a line of ~eps denominators in the x-update: round-off differences between two correct
             #  kernels are amplified there)
-            tol = 2e-4 if terms in ("h", "w") else 1e-5
+            tol = 2e-4 if terms in ("h", "w") else (3e-5 if W == 768 else 1e-5)      # (768: against the generic Stockham transforms)
+            if W == 768 and terms in ("h", "w"):
+                continue      # (the op-by-op path transforms the data term in fp32 every iteration: on that line of ~eps denominators the two
+                              #  correct paths sit 1e-2 apart, DESIGN.md section 4 -- the band-partition identity above is the test here)
             for a, c in zip(base, lock):
                 assert float((a - c).abs().max()) <= tol * max(float(c.abs().max()), 1.0), (W, H, B, C, terms, float((a - c).abs().max()))
     finally:
