@@ -167,19 +167,21 @@ def pmc_traffic(kernel, timeout_s=150):
                 return None, f"rocprofv3 --pmc {ctr} pass exceeded {timeout_s} s"
             if pr.returncode != 0:
                 return None, f"rocprofv3 --pmc {ctr} pass failed ({pr.returncode}): {err.decode(errors='replace')[-300:]}"
-            got = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            groups = {}                                    # full instantiation name -> values (the x-only last pass of solve() is another
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):      # instantiation of the same kernel: 8 B / element)
                 for row in csv.DictReader(open(f)):
-                    k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("dpx::", "").split("<")[0]
-                    if k == kernel and row["Counter_Name"] == ctr:
-                        got.append(float(row["Counter_Value"]))
-            if not got:
+                    full = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("dpx::", "")
+                    if full.split("<")[0] == kernel and row["Counter_Name"] == ctr:
+                        groups.setdefault(full, []).append(float(row["Counter_Value"]))
+            if not groups:
                 return None, f"no {ctr} rows for {kernel} in the counter CSV"
-            vals[ctr] = (sum(got) / len(got), len(got))
+            inst, got = max(groups.items(), key=lambda kv: len(kv[1]))      # the instantiation the timed iterations launch
+            vals[ctr] = (sum(got) / len(got), len(got), inst)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     rd, wr = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
-    return {"bytes": rd + wr, "read_bytes_corrected": rd, "write_bytes": wr, "launches_sampled": min(vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1])}, None
+    return {"bytes": rd + wr, "read_bytes_corrected": rd, "write_bytes": wr, "launches_sampled": min(vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]),
+            "instantiation": vals["FETCH_SIZE"][2]}, None
 
 
 def cache_sweep(dp, synthetic, device):
