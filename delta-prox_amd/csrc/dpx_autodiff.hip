@@ -462,6 +462,169 @@ __global__ void k_otf_grad(const float2* __restrict__ A, const float2* __restric
   }
 }
 
+// ---- the rhs stage of iteration `it` and the z stage of iteration `it - 1` in ONE pass (the unrolled backward loop runs them back to
+// back; W % 4 == 0).  Between them the staged form writes g_v_i, g_u_i (2 n planes) and reads them again; here a thread forms
+//     g_v_i = rho K_i g,   g_u_i = a_i - g_v_i,   g_d_i = J_i (g_v_i - g_u_i) + g_u_i      (a_i: the previous z stage's share, zb_gd)
+// for its four pixels and -- for the stencil adjoints -- for the pixel to their left / the four pixels above (recomputed from g, a_i,
+// v_i there: reads that mostly hit the cache), and leaves  g_x = sum_i K_i^T g_d_i,  a_i' = g_d_i  and the three reductions' partial
+// sums (d/d rho of iteration `it`: parts a and b as k_solve_rhs_bwd4; d/d lam_i of iteration `it - 1` as k_zupdate_bwd4).
+// 10 plane passes instead of 16, one launch instead of two.  a_in and a_out must be different buffers (neighbours read a_in).
+struct FusedBwdTerm {
+  int linop, prox;
+  float alpha;
+  const float* lam;       // [B], iteration it - 1
+  const float* v;         // saved prox output of iteration it - 1 (fp32 or bf16 history plane)
+  const float* a_in;      // the z stage's share of d/du from the previous backward step (nullable = 0)
+  float* a_out;           // g_d of this step
+};
+struct FusedBwdPack {
+  FusedBwdTerm t[DPX_MAX_TERMS];
+  int n;
+  int hist_bf16;
+};
+__device__ __forceinline__ void fb_gd4(const FusedBwdTerm& tm, const float (&kg)[4], long i, float lam, int hb, float (&gd)[4], float (&lt)[4]) {
+  const float4 a4 = tm.a_in ? *(const float4*)(tm.a_in + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 v4 = dpx_hist_load4(tm.v, hb, i);
+  const float aa[4] = {a4.x, a4.y, a4.z, a4.w}, va[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gu = aa[k] - kg[k], diff = kg[k] - gu, v = va[k];
+    float J, dl;
+    if (tm.prox == DPX_PROX_NORM1) {
+      J = v != 0.f ? 1.f : 0.f;
+      dl = v > 0.f ? -1.f : (v < 0.f ? 1.f : 0.f);
+    } else if (tm.prox == DPX_PROX_NONNEG) {
+      J = v > 0.f ? 1.f : 0.f;
+      dl = 0.f;
+    } else {
+      const float s = 1.f / (1.f + 2.f * lam);
+      J = s;
+      dl = -2.f * v * s;
+    }
+    lt[k] = diff * dl;
+    gd[k] = fmaf(J, diff, gu);
+  }
+}
+__device__ __forceinline__ float fb_gd1(const FusedBwdTerm& tm, float kg, long i, float lam, int hb) {
+  const float a = tm.a_in ? tm.a_in[i] : 0.f, v = dpx_hist_load(tm.v, hb, i);
+  const float gu = a - kg, diff = kg - gu;
+  float J;
+  if (tm.prox == DPX_PROX_NORM1) J = v != 0.f ? 1.f : 0.f;
+  else if (tm.prox == DPX_PROX_NONNEG) J = v > 0.f ? 1.f : 0.f;
+  else J = 1.f / (1.f + 2.f * lam);
+  return fmaf(J, diff, gu);
+}
+__global__ void __launch_bounds__(256) k_rhs_z_bwd4(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ rhs,
+                                                     const float* __restrict__ rho, FusedBwdPack T, float* __restrict__ gx,
+                                                     float* __restrict__ part_a, float* __restrict__ part_b, float* __restrict__ part_lam, int C,
+                                                     int H, int W) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y, hb = T.hist_bf16;
+  const long npb = (long)C * H * W, base = (long)b * npb;
+  const float r = rho[b];
+  float cI = 0.f;
+  int nW = 0, nH = 0;
+  for (int t = 0; t < T.n; ++t) {
+    if (T.t[t].linop == DPX_LIN_IDENTITY) cI += 1.f;
+    else if (T.t[t].linop == DPX_LIN_GRAD_W) ++nW;
+    else ++nH;
+  }
+  float acc_a = 0.f, acc_b = 0.f, lsum[DPX_MAX_TERMS];
+#pragma unroll
+  for (int t = 0; t < DPX_MAX_TERMS; ++t) lsum[t] = 0.f;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npb / 4; q += (long)gridDim.x * 256) {
+    const long p = q * 4;
+    const int w = (int)(p % W);
+    const long row = p / W;
+    const int h = (int)(row % H);
+    const long i = base + p, rowb = base + row * W;
+    const long up = (long)((h == 0 ? H - 1 : h - 1) - h) * W, dn = (long)((h + 1 == H ? 0 : h + 1) - h) * W;
+    const long il = rowb + (w == 0 ? W - 1 : w - 1), ir = rowb + (w + 4 == W ? 0 : w + 4);
+    const float4 g4 = *(const float4*)(g + i);
+    const float ga[4] = {g4.x, g4.y, g4.z, g4.w};
+    // ---- the two rho reductions of iteration `it` (k_solve_rhs_bwd4)
+    {
+      const float4 x4 = dpx_hist_load4(x, hb, i), r4 = dpx_hist_load4(rhs, hb, i);
+      const float xa[4] = {x4.x, x4.y, x4.z, x4.w}, ra[4] = {r4.x, r4.y, r4.z, r4.w};
+      float lx[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) lx[k] = cI * xa[k];
+      if (nW) {
+        const float xe[6] = {dpx_hist_load(x, hb, il), xa[0], xa[1], xa[2], xa[3], dpx_hist_load(x, hb, ir)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lx[k] += (float)nW * (2.f * xe[k + 1] - xe[k] - xe[k + 2]);
+      }
+      if (nH) {
+        const float4 xu = dpx_hist_load4(x, hb, i + up), xd = dpx_hist_load4(x, hb, i + dn);
+        const float xua[4] = {xu.x, xu.y, xu.z, xu.w}, xda[4] = {xd.x, xd.y, xd.z, xd.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lx[k] += (float)nH * (2.f * xa[k] - xua[k] - xda[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc_a = fmaf(ga[k], lx[k], acc_a);
+        acc_b = fmaf(ga[k], ra[k], acc_b);
+      }
+    }
+    // ---- g_v, g_u, g_d of every term at the own pixels and at the stencil neighbours; g_x = sum K^T g_d
+    const float gright = nW ? g[ir] : 0.f, gleft = nW ? g[il] : 0.f;
+    float gdn[4] = {0.f, 0.f, 0.f, 0.f}, gup[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nH) {
+      const float4 d4 = *(const float4*)(g + i + dn), u4 = *(const float4*)(g + i + up);
+      gdn[0] = d4.x; gdn[1] = d4.y; gdn[2] = d4.z; gdn[3] = d4.w;
+      gup[0] = u4.x; gup[1] = u4.y; gup[2] = u4.z; gup[3] = u4.w;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < DPX_MAX_TERMS; ++t) {
+      if (t < T.n) {
+        const FusedBwdTerm& tm = T.t[t];
+        const float lam = tm.lam ? tm.lam[b] * tm.alpha : 0.f;
+        float kg[4], gd[4], lt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (tm.linop == DPX_LIN_IDENTITY) kg[k] = ga[k];
+          else if (tm.linop == DPX_LIN_GRAD_W) kg[k] = (k < 3 ? ga[(k + 1) & 3] : gright) - ga[k];
+          else kg[k] = gdn[k] - ga[k];
+          kg[k] *= r;
+        }
+        fb_gd4(tm, kg, i, lam, hb, gd, lt);
+        lsum[t] += (lt[0] + lt[1]) + (lt[2] + lt[3]);
+        *(float4*)(tm.a_out + i) = make_float4(gd[0], gd[1], gd[2], gd[3]);
+        if (tm.linop == DPX_LIN_IDENTITY) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += gd[k];
+        } else if (tm.linop == DPX_LIN_GRAD_W) {           // adjoint: y[w-1] - y[w]; the left pixel's g_v = rho (g[w] - g[w-1])
+          const float left = fb_gd1(tm, r * (ga[0] - gleft), il, lam, hb);
+          acc[0] += left - gd[0];
+#pragma unroll
+          for (int k = 1; k < 4; ++k) acc[k] += gd[k - 1] - gd[k];
+        } else {                                            // grad_H adjoint: y[h-1] - y[h]; the row above has g_v = rho (g[h] - g[h-1])
+          float kgu[4], gdu[4], ltu[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) kgu[k] = r * (ga[k] - gup[k]);
+          fb_gd4(tm, kgu, i + up, lam, hb, gdu, ltu);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += gdu[k] - gd[k];
+        }
+      }
+    }
+    *(float4*)(gx + i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  const float sa = ad_block_sum(acc_a, sh);
+  __syncthreads();
+  const float sb = ad_block_sum(acc_b, sh);
+  if (threadIdx.x == 0) {
+    part_a[(long)b * gridDim.x + blockIdx.x] = -sa;
+    part_b[(long)b * gridDim.x + blockIdx.x] = sb;
+  }
+  for (int t = 0; t < T.n; ++t) {
+    __syncthreads();
+    const float s = ad_block_sum(lsum[t], sh);
+    if (threadIdx.x == 0) part_lam[((long)t * gridDim.y + b) * gridDim.x + blockIdx.x] = s * T.t[t].alpha;
+  }
+}
+
 static int ad_blocks(long npb) {
   long g = (npb + 256 * 8 - 1) / (256 * 8);
   return (int)(g > 512 ? 512 : (g < 1 ? 1 : g));
@@ -508,11 +671,26 @@ int solve_rhs_bwd_partials(const float* g, const float* x, const float* rhs, con
     DPX_LAUNCH("k_solve_rhs_bwd", k_solve_rhs_bwd, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, part_a, part_b, C, H, W);
   return launch_status("dpx_admm_unrolled_backward");
 }
+// glam == NULL: only the rho reductions; grho == NULL: only the lambda reductions
 int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
                 int C, int H, int W, hipStream_t s) {
-  DPX_LAUNCH("k_ad_finish_iter", k_ad_finish_iter, dim3(nterms * B + B), dim3(256), 0, s, part_lam, part_a, part_b, glam, grho, rho, nterms * B,
+  const int nB = glam ? nterms * B : 0, nR = grho ? B : 0;
+  if (nB + nR == 0) return DPX_OK;
+  DPX_LAUNCH("k_ad_finish_iter", k_ad_finish_iter, dim3(nB + nR), dim3(256), 0, s, part_lam, part_a, part_b, glam, grho, rho, nB,
              ad_blocks((long)C * H * W));
   return launch_status("dpx_admm_unrolled_backward");
+}
+// rhs stage of iteration `it` + z stage of iteration `it - 1` (k_rhs_z_bwd4); false: the planes do not fit it (W % 4)
+bool rhs_z_bwd_fused(const float* g, const float* x, const float* rhs, const float* rho, const dpx_bwd_term* terms, int nterms, const float* const* a_in,
+                     float* const* a_out, float* gx, float* part_a, float* part_b, float* part_lam, int hist_bf16, int B, int C, int H, int W,
+                     hipStream_t s) {
+  if (W % 4) return false;
+  FusedBwdPack T;
+  T.n = nterms;
+  T.hist_bf16 = hist_bf16;
+  for (int i = 0; i < nterms; ++i) T.t[i] = FusedBwdTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].v, a_in[i], a_out[i]};
+  DPX_LAUNCH("k_rhs_z_bwd", k_rhs_z_bwd4, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, gx, part_a, part_b, part_lam, C, H, W);
+  return true;
 }
 }  // namespace dpx
 

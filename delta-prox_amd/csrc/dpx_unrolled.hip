@@ -30,6 +30,9 @@ int finish_iter(const float* part_lam, const float* part_a, const float* part_b,
                 int C, int H, int W, hipStream_t s);
 int iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
                    float* rhs_out, int emit_bf16, int B, int C, int H, int W, const void* table, dpx_stream_t stream);   // dpx_iter.hip
+bool rhs_z_bwd_fused(const float* g, const float* x, const float* rhs, const float* rho, const dpx_bwd_term* terms, int nterms, const float* const* a_in,
+                     float* const* a_out, float* gx, float* part_a, float* part_b, float* part_lam, int hist_bf16, int B, int C, int H, int W,
+                     hipStream_t s);   // dpx_autodiff.hip
 int rhs_bwd_impl(const float* g, const float* rhs, const float* rho, const int* linops, int nterms, float* const* gv, float* const* gu,
                  const float* const* gu_add, float* grho, const float* grho_add, int hist_bf16, int B, int C, int H, int W, void* ws,
                  hipStream_t s);   // dpx_autodiff.hip
@@ -262,6 +265,78 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
   }
   bool off_started[DPX_MAX_TERMS] = {false, false, false, false};
   DPX_REQUIRE(n_off <= DPX_MAX_TERMS, "dpx_admm_unrolled_backward: at most %d offsets", DPX_MAX_TERMS);
+  // the offsets' share of one iteration: goff_k += K_k g_rhs
+  auto add_offsets = [&]() -> int {
+    for (int k = 0; k < n_off; ++k) {
+      if (!goff[k]) continue;
+      if (off_otf[k]) {
+        float* dst = off_started[k] ? tmp : goff[k];
+        DPX_TRY(dpx_fft_conv(grhs, dst, off_otf[k], 0, B, C, H, W, table, spectrum_ws, stream));
+        if (off_started[k]) {
+          const float* xs[2] = {goff[k], tmp};
+          DPX_TRY(dpx_lincomb(goff[k], 2, xs, one2, nullptr, B, (long)(px / B), stream));
+        }
+      } else {
+        const float* xs[2] = {grhs, goff[k]};
+        DPX_TRY(dpx_lincomb(goff[k], off_started[k] ? 2 : 1, xs, one2, nullptr, B, (long)(px / B), stream));
+      }
+      off_started[k] = true;
+    }
+    return DPX_OK;
+  };
+  // ---- the loop with the rhs stage of iteration `it` and the z stage of iteration `it - 1` as ONE pass (k_rhs_z_bwd4, W % 4 == 0):
+  //        z(T-1) | solve(T-1) | [rhs(T-1) + z(T-2)] | solve(T-2) | ... | [rhs(1) + z(0)] | solve(0) | rhs(0)
+  //      4 launches per iteration (3 of them the transform) + 1 finishing launch instead of 5 + 1, no g_v / g_u planes in between.
+  //      Knob unroll_bwd_staged = 1 keeps the staged loop below (A/B and tests).
+  if (W % 4 == 0 && !tune(TUNE_UNROLL_BWD_STAGED)) {
+    const hipStream_t st = (hipStream_t)stream;
+    float* abuf[2] = {gu_a, gu_b};
+    int cur = 0;
+    {
+      const int it = T - 1;
+      dpx_bwd_term bt[DPX_MAX_TERMS];
+      for (int i = 0; i < n; ++i)
+        bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, H_v(it, i), cur_gv[i], cur_gu[i], abuf[cur] + i * px};
+      DPX_TRY(zupdate_bwd_partials(gxz, bt, n, part_lam, hb, B, C, H, W, st));
+      DPX_TRY(finish_iter(part_lam, part_a, part_b, glam + (size_t)it * n * B, nullptr, rho_tab + (size_t)it * B, n, B, C, H, W, st));
+    }
+    const float* g = gxz;
+    if (gx) {
+      const float* xs[2] = {gx, gxz};
+      DPX_TRY(dpx_lincomb(gtot, 2, xs, one2, nullptr, B, (long)(px / B), stream));
+      g = gtot;
+    }
+    for (int it = T - 1; it >= 1; --it) {
+      const float* rho = rho_tab + (size_t)it * B;
+      DPX_TRY(dpx_fourier_apply_inv(g, grhs, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
+      DPX_TRY(add_offsets());
+      dpx_bwd_term bt[DPX_MAX_TERMS];
+      const float* ain[DPX_MAX_TERMS];
+      float* aout[DPX_MAX_TERMS];
+      for (int i = 0; i < n; ++i) {
+        bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)(it - 1) * B, H_v(it - 1, i), nullptr, nullptr, nullptr};
+        ain[i] = abuf[cur] + i * px;
+        aout[i] = abuf[cur ^ 1] + i * px;
+      }
+      if (!rhs_z_bwd_fused(grhs, H_x(it), H_rhs(it), rho, bt, n, ain, aout, gxz, part_a, part_b, part_lam, hb, B, C, H, W, st)) {
+        set_error("dpx_admm_unrolled_backward: fused stage refused a plane it was selected for");
+        return DPX_ERR_LAUNCH;
+      }
+      DPX_TRY(finish_iter(part_lam, part_a, part_b, glam + (size_t)(it - 1) * n * B, grho + (size_t)it * B, rho, n, B, C, H, W, st));
+      cur ^= 1;
+      g = gxz;
+    }
+    {
+      const float* rho = rho_tab;
+      DPX_TRY(dpx_fourier_apply_inv(g, grhs, dd, rho, eps, B, C, H, W, table, spectrum_ws, stream));
+      DPX_TRY(add_offsets());
+      const float* gua[DPX_MAX_TERMS];
+      for (int i = 0; i < n; ++i) gua[i] = abuf[cur] + (size_t)i * px;
+      DPX_TRY(solve_rhs_bwd_partials(grhs, H_x(0), H_rhs(0), rho, linops, n, gv0, gu0, gua, part_a, part_b, hb, B, C, H, W, st));
+      DPX_TRY(finish_iter(part_lam, part_a, part_b, nullptr, grho, rho, n, B, C, H, W, st));
+    }
+    return DPX_OK;
+  }
   for (int it = T - 1; it >= 0; --it) {
     const float* rho = rho_tab + (size_t)it * B;
     dpx_bwd_term bt[DPX_MAX_TERMS];

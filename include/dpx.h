@@ -84,6 +84,8 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        2 = the 32 x 32 slab kernel of larger batches
  *   cg_no_hint           1 = the fused CG does not look at the stop flag early at the iteration   DPX_CG_NO_HINT
  *                        the previous solve exited at (same result, seven more empty launches)
+ *   unroll_bwd_staged    1 = dpx_admm_unrolled_backward keeps the rhs stage and the z stage of      DPX_UNROLL_BWD_STAGED
+ *                        neighbouring iterations as two passes (same gradients up to round-off)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */

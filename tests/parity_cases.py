@@ -309,6 +309,44 @@ def case_w768_two_kernel(device, H=256):
     assert_close(touched.cpu(), fresh.cpu(), 2e-6, "768-wide: general seed vs fresh-state seed")
 
 
+def case_unrolled_bwd_fused_vs_staged(device, shape=(2, 3, 32, 48), K=4):
+    """the unrolled backward loop with the rhs stage of iteration t and the z stage of iteration t - 1 as one pass (k_rhs_z_bwd4, the
+    default) against the staged loop (knob unroll_bwd_staged): same loss, gradients w.r.t. the rho / lambda schedules, the observation
+    and x0 within fp32 round-off; three term sets (TV, TV + nonneg, nonneg + l1 on x), fp32 and bf16 history"""
+    import synthetic
+    from dprox import _backend as be
+    gt, b, psf = synthetic.deconv_case(*shape, seed=17, ksize=5, ksigma=1.2)
+    for terms in ("tv", "tv+nn", "nn+l1"):
+        for dtype in ("f32", "bf16"):
+            res = {}
+            for staged in (0, 1):
+                x = dp.Variable()
+                bt = T(b, device).clone().requires_grad_(True)
+                regs = []
+                if "tv" in terms:
+                    regs += [dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))]
+                if "nn" in terms:
+                    regs += [dp.nonneg(x)]
+                if "l1" in terms:
+                    regs += [dp.norm1(x) * 0.5]
+                fns = dp.sum_squares(dp.conv(x, psf) - bt)
+                for r in regs:
+                    fns = fns + r
+                solver = dp.specialize(dp.compile(fns, method="admm", device=device), method="unroll", device=device, max_iter=K, dtype=dtype)
+                rhos = torch.linspace(0.4, 0.2, K).requires_grad_(True)
+                lams = [torch.linspace(0.03, 0.01, K).requires_grad_(True) for _ in regs]
+                with be.tuned(unroll_bwd_staged=staged):
+                    xo = solver.solve(x0=T(b, device), rhos=rhos, lams=dict(zip(regs, lams)))
+                    loss = ((xo - T(gt, device)) ** 2).mean()
+                    loss.backward()
+                res[staged] = [float(loss.detach())] + [t.grad.detach().cpu().double().numpy() for t in [rhos] + lams + [bt]]
+            assert abs(res[0][0] - res[1][0]) <= 1e-7 * abs(res[1][0])
+            for k, (a, c) in enumerate(zip(res[0][1:], res[1][1:])):
+                e = rel_l2(a, c)
+                record(f"unrolled backward fused vs staged, {terms}, {dtype}, gradient {k}", e, 1e-5)
+                assert e <= 1e-5, (terms, dtype, k, e)
+
+
 def case_unrolled_plane_sizes(device, shapes=((1, 3, 768, 1024), (1, 3, 768, 768))):
     """unrolled ADMM x 4 (forward on the two-kernel iteration / the staged kernels, hand-written backward stages) on the 3 * 2^k planes
     against float64 autograd through oracle.admm_f64: iterate and loss at 1e-5, gradients w.r.t. the rho / lambda schedules and

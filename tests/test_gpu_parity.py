@@ -216,6 +216,10 @@ def test_mosaic_joint_demosaic_deconv():
     pc.case_mosaic_jd(DEV)
 
 
+def test_unrolled_backward_fused_stage_matches_the_staged_loop():
+    pc.case_unrolled_bwd_fused_vs_staged(DEV)
+
+
 def test_unrolled_gradients():
     pc.case_unrolled_grads(DEV)
 
