@@ -9,7 +9,7 @@
 //       (J and dprox/dlam are recovered from the saved OUTPUT v: soft-threshold passes where v != 0, nonneg where v > 0)
 //   x stage       g_rho = -<g_rhs, sum_i K_i^T K_i x>            (g_rhs = M g_x comes from dpx_fourier_apply_inv)
 //   rhs stage     g_v_i = rho K_i g, g_u_i = -g_v_i, g_rho = <g, rhs> / rho
-#include "dpx_common.h"
+#include "dpx_cg_dev.h"
 
 namespace dpx {
 
@@ -514,11 +514,15 @@ __device__ __forceinline__ float fb_gd1(const FusedBwdTerm& tm, float kg, long i
   else J = 1.f / (1.f + 2.f * lam);
   return fmaf(J, diff, gu);
 }
+// counter != NULL: the LAST workgroup to arrive also finishes the three reductions (what k_ad_finish_iter does in its own launch: the same
+// sums in the same order) -- glam[t B + b] (iteration it - 1) and grho[b] = sum part_a + (sum part_b) / rho_b (iteration it).
 __global__ void __launch_bounds__(256) k_rhs_z_bwd4(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ rhs,
                                                      const float* __restrict__ rho, FusedBwdPack T, float* __restrict__ gx,
                                                      float* __restrict__ part_a, float* __restrict__ part_b, float* __restrict__ part_lam, int C,
-                                                     int H, int W) {
+                                                     int H, int W, unsigned* __restrict__ counter, float* __restrict__ glam,
+                                                     float* __restrict__ grho) {
   __shared__ float sh[16];
+  __shared__ int shlast;
   const int b = blockIdx.y, hb = T.hist_bf16;
   const long npb = (long)C * H * W, base = (long)b * npb;
   const float r = rho[b];
@@ -615,13 +619,34 @@ __global__ void __launch_bounds__(256) k_rhs_z_bwd4(const float* __restrict__ g,
   __syncthreads();
   const float sb = ad_block_sum(acc_b, sh);
   if (threadIdx.x == 0) {
-    part_a[(long)b * gridDim.x + blockIdx.x] = -sa;
-    part_b[(long)b * gridDim.x + blockIdx.x] = sb;
+    dpx_st_agent(part_a + (long)b * gridDim.x + blockIdx.x, -sa);
+    dpx_st_agent(part_b + (long)b * gridDim.x + blockIdx.x, sb);
   }
   for (int t = 0; t < T.n; ++t) {
     __syncthreads();
     const float s = ad_block_sum(lsum[t], sh);
-    if (threadIdx.x == 0) part_lam[((long)t * gridDim.y + b) * gridDim.x + blockIdx.x] = s * T.t[t].alpha;
+    if (threadIdx.x == 0) dpx_st_agent(part_lam + ((long)t * gridDim.y + b) * gridDim.x + blockIdx.x, s * T.t[t].alpha);
+  }
+  if (!counter) return;
+  if (!dpx_last_block(counter, gridDim.x * gridDim.y, &shlast)) return;
+  const int nblk = gridDim.x, B = gridDim.y, nB = T.n * B;
+  for (int j = 0; j < nB + B; ++j) {
+    __syncthreads();
+    if (j < nB) {
+      float acc = 0.f;
+      for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += dpx_ld_agent(part_lam + (long)j * nblk + i);
+      acc = ad_block_sum(acc, sh);
+      if (threadIdx.x == 0) glam[j] = acc;
+    } else {
+      const int bb = j - nB;
+      float a = 0.f, c = 0.f;
+      for (int i = threadIdx.x; i < nblk; i += blockDim.x) a += dpx_ld_agent(part_a + (long)bb * nblk + i);
+      a = ad_block_sum(a, sh);
+      __syncthreads();
+      for (int i = threadIdx.x; i < nblk; i += blockDim.x) c += dpx_ld_agent(part_b + (long)bb * nblk + i);
+      c = ad_block_sum(c, sh);
+      if (threadIdx.x == 0) grho[bb] = a + c / rho[bb];
+    }
   }
 }
 
@@ -683,13 +708,14 @@ int finish_iter(const float* part_lam, const float* part_a, const float* part_b,
 // rhs stage of iteration `it` + z stage of iteration `it - 1` (k_rhs_z_bwd4); false: the planes do not fit it (W % 4)
 bool rhs_z_bwd_fused(const float* g, const float* x, const float* rhs, const float* rho, const dpx_bwd_term* terms, int nterms, const float* const* a_in,
                      float* const* a_out, float* gx, float* part_a, float* part_b, float* part_lam, int hist_bf16, int B, int C, int H, int W,
-                     hipStream_t s) {
+                     hipStream_t s, unsigned* counter, float* glam, float* grho) {
   if (W % 4) return false;
   FusedBwdPack T;
   T.n = nterms;
   T.hist_bf16 = hist_bf16;
   for (int i = 0; i < nterms; ++i) T.t[i] = FusedBwdTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].v, a_in[i], a_out[i]};
-  DPX_LAUNCH("k_rhs_z_bwd", k_rhs_z_bwd4, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, gx, part_a, part_b, part_lam, C, H, W);
+  DPX_LAUNCH("k_rhs_z_bwd", k_rhs_z_bwd4, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, gx, part_a, part_b, part_lam, C, H, W,
+             counter, glam, grho);
   return true;
 }
 }  // namespace dpx

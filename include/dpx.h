@@ -86,6 +86,8 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        the previous solve exited at (same result, seven more empty launches)
  *   unroll_bwd_staged    1 = dpx_admm_unrolled_backward keeps the rhs stage and the z stage of      DPX_UNROLL_BWD_STAGED
  *                        neighbouring iterations as two passes (same gradients up to round-off)
+ *   unroll_bwd_fold_finish  1 = the fused backward stage's last workgroup finishes the iteration's       DPX_UNROLL_BWD_FOLD_FINISH
+ *                        reductions instead of a finishing launch (slower: measured, kept for A/B)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */

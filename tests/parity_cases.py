@@ -272,7 +272,7 @@ def case_other_plane_sizes(device, sizes=((384, 256), (1536, 256), (2048, 256), 
         assert_close(out.cpu(), ref, TOL, f"PGD x 3, {H}x{W}")
 
 
-def case_w768_two_kernel(device, H=256):
+def case_w768_two_kernel(device, H=256, B=2):
     """768-wide rows on the two-kernel iteration (384 = 6 * 8 * 8 complex points per row on one wave, fft384_wave): ADMM, half-quadratic
     splitting and ADMM_vxu with full states against the op-by-op iteration on the size-generic kernels, and the fresh-state /
     touched-state seeds against each other.  (768 x 768 is the reference's own patch size, contrib/optic/utils.py:158-166.)"""
@@ -281,7 +281,7 @@ def case_w768_two_kernel(device, H=256):
     x0 = torch.zeros(1, 1, H, 768, device=device)
     terms = ops.make_terms([dict(linop=1, prox=0, alpha=1.0, lam=None, v=x0, u=x0), dict(linop=2, prox=0, alpha=1.0, lam=None, v=x0, u=x0)])
     assert ops.iter_supported(H, 768, terms, 2), "768-wide planes must be on the two-kernel iteration"
-    gt, b0, psf = synthetic.deconv_case(2, 1, H, 768, seed=3)
+    gt, b0, psf = synthetic.deconv_case(B, 1, H, 768, seed=3)
     b = T(b0, device)
     outs = {}
     for fused in (True, False):
@@ -319,7 +319,7 @@ def case_unrolled_bwd_fused_vs_staged(device, shape=(2, 3, 32, 48), K=4):
     for terms in ("tv", "tv+nn", "nn+l1"):
         for dtype in ("f32", "bf16"):
             res = {}
-            for staged in (0, 1):
+            for staged in (0, 1, 2):                           # 2: the fused stage with its reductions finished by its last workgroup
                 x = dp.Variable()
                 bt = T(b, device).clone().requires_grad_(True)
                 regs = []
@@ -335,16 +335,17 @@ def case_unrolled_bwd_fused_vs_staged(device, shape=(2, 3, 32, 48), K=4):
                 solver = dp.specialize(dp.compile(fns, method="admm", device=device), method="unroll", device=device, max_iter=K, dtype=dtype)
                 rhos = torch.linspace(0.4, 0.2, K).requires_grad_(True)
                 lams = [torch.linspace(0.03, 0.01, K).requires_grad_(True) for _ in regs]
-                with be.tuned(unroll_bwd_staged=staged):
+                with be.tuned(unroll_bwd_staged=int(staged == 1), unroll_bwd_fold_finish=int(staged == 2)):
                     xo = solver.solve(x0=T(b, device), rhos=rhos, lams=dict(zip(regs, lams)))
                     loss = ((xo - T(gt, device)) ** 2).mean()
                     loss.backward()
                 res[staged] = [float(loss.detach())] + [t.grad.detach().cpu().double().numpy() for t in [rhos] + lams + [bt]]
-            assert abs(res[0][0] - res[1][0]) <= 1e-7 * abs(res[1][0])
-            for k, (a, c) in enumerate(zip(res[0][1:], res[1][1:])):
-                e = rel_l2(a, c)
-                record(f"unrolled backward fused vs staged, {terms}, {dtype}, gradient {k}", e, 1e-5)
-                assert e <= 1e-5, (terms, dtype, k, e)
+            for other in (0, 2):
+                assert abs(res[other][0] - res[1][0]) <= 1e-7 * abs(res[1][0])
+                for k, (a, c) in enumerate(zip(res[other][1:], res[1][1:])):
+                    e = rel_l2(a, c)
+                    record(f"unrolled backward fused ({other}) vs staged, {terms}, {dtype}, gradient {k}", e, 1e-5)
+                    assert e <= 1e-5, (terms, dtype, k, other, e)
 
 
 def case_unrolled_plane_sizes(device, shapes=((1, 3, 768, 1024), (1, 3, 768, 768))):
@@ -459,7 +460,7 @@ CG_BRANCHES = (("default", {}),
                ("step by step (cg_unfused)", dict(cg_fused_max_b=32, cg_unfused=1)))
 
 
-def case_cg_branches(device):
+def case_cg_branches(device, quick=False):
     """G6 / G6b -- BOTH branches of dpx_cg_masked_fft (the fused 4-launch iteration and the step-by-step sequence, selected through
     dpx_tune_set / dpx_cg_config) against the real reference's cg() on batches of 1, 4, 12 and 20 systems: solution, exit iteration,
     the iterate after 10 fixed iterations.  By default B <= 8 runs fused and B > 8 step by step, so without the switches the two
@@ -468,12 +469,14 @@ def case_cg_branches(device):
     from dprox import _ops as ops
     assert {"cg_fused_max_b", "cg_split_update", "cg_unfused"} <= set(be.tune_names())
     g6, g6b = load_golden("g6_cg"), load_golden("g6b_cg_large_batches")
-    for B, g in ((1, g6), (4, g6), (12, g6b), (20, g6b)):
+    # (quick: the host emulator's share -- one batch on each side of the size rule, the branches that differ in kernels)
+    branches = [br for br in CG_BRANCHES if not quick or br[0] in ("default", "fused", "fused, slab Gram kernel", "step by step")]
+    for B, g in (((4, g6), (12, g6b)) if quick else ((1, g6), (4, g6), (12, g6b), (20, g6b))):
         mask, rhs = T(g[f"B{B}_mask"], device), T(g[f"B{B}_rhs"], device).contiguous()
         rho = T(g[f"B{B}_rho"], device) if f"B{B}_rho" in g else torch.full((B,), float(g["rho"]), device=device)
         n_ref = int(g[f"B{B}_iters"])
         outs = {}
-        for name, knobs in CG_BRANCHES:
+        for name, knobs in branches:
             with be.tuned(**knobs):
                 x, n = ops.cg_masked_fft(rhs, mask, rho, 1.0, 1e-6, 100)
                 x10, n10 = ops.cg_masked_fft(rhs, mask, rho, 1.0, 0.0, 10)

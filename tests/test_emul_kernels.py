@@ -51,7 +51,7 @@ def test_column_length_768():
 
 
 def test_768_wide_rows_on_the_two_kernel_iteration():
-    pc.case_w768_two_kernel(DEV)
+    pc.case_w768_two_kernel(DEV, B=1)
 
 
 def test_other_plane_sizes():
@@ -104,7 +104,7 @@ def test_numpy_observation_edited_in_place_is_seen():
 
 
 def test_cg_both_branches_of_the_fused_call():
-    pc.case_cg_branches(DEV)
+    pc.case_cg_branches(DEV, quick=True)
 
 
 def test_cg_masked_fft_odd_and_per_image_masks():
