@@ -152,8 +152,10 @@ __global__ void k_bx_pack_weights(const float* __restrict__ w, const float* __re
 
 // FFDNet input stage into the C8 layout: replicate-pad to even size, pixel-unshuffle(2) (channel = c*4 + dy*2 + dx), sigma map as
 // channel 4C, zero fill up to a multiple of 16 channels               (network_ffdnet.py:56-63)
+// p8 != 0: the "P8" form of the split-f16 operand planes -- a (pixel, 8-channel group) unit is [hi: 8 x binary16][lo: 8 x binary16], the
+// same 32 bytes as its eight fp32 values, already split (split2_f16): what the consuming layer's LDS-DMA lands IS its operand tile.
 __global__ void k_bx_pack_in(const float* __restrict__ x, const float* __restrict__ sigma, float* __restrict__ a, int B, int C, int H, int W,
-                             int H2, int W2, int G) {
+                             int H2, int W2, int G, int p8) {
   const long total = (long)B * G * H2 * W2 * 8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int j = (int)(i % 8);
@@ -172,7 +174,16 @@ __global__ void k_bx_pack_in(const float* __restrict__ x, const float* __restric
     } else if (ch == 4 * C) {
       v = sigma[b];
     }
-    a[i] = v;
+    if (p8) {
+      unsigned hw, lw;
+      split2_f16(v, hw, lw);
+      unsigned short* unit = (unsigned short*)a + (i - j) * 2;          // 32 bytes per unit
+      unit[j] = (unsigned short)(hw >> 16);
+      unit[8 + j] = (unsigned short)(lw >> 16);
+      if (fabsf(v) > 6.0e4f) atomicOr(&g_f16_overflow, 1u);
+    } else {
+      a[i] = v;
+    }
   }
 }
 
@@ -191,17 +202,22 @@ __global__ void k_bx_unpack_out(const float* __restrict__ o, float* __restrict__
 }
 
 // in / out: C8 fp32; Gin = input channel groups (even: chunks of 2), Gout = output groups actually stored.
-template <int MT, bool RELU, int MODE>
+// PRE / PSO (split-f16 only): the input arrives / the output leaves in the P8 form (k_bx_pack_in) -- the PRODUCING layer's epilogue
+// splits its fp32 results into the two binary16 planes (the same split2_f16 of the same fp32 values the consumer's split pass
+// performed: bit-identical operands), the consumer's LDS-DMA lands them directly as its operand tile (pieces ordered plane by plane),
+// two tiles alternating: no landing buffer, no split pass, one workgroup barrier less per 16-channel chunk.
+template <int MT, bool RELU, int MODE, bool PRE = false, bool PSO = false>
 // mask (nullable; C8, Gout groups): the stored value is zeroed where mask <= 0 -- the ReLU derivative of the backward-data pass
 // ([a_l > 0] from the saved forward activation), applied in the producing layer's epilogue.
 __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict__ in, float* __restrict__ out, const char* __restrict__ wpk, int Gin,
                                                         int Gout, int H, int W, int tiles_x, const float* __restrict__ mask) {
+  static_assert(MODE == 3 || (!PRE && !PSO), "pre-split operand planes exist for the split-f16 arithmetic only");
   constexpr int M32 = MT * 32, NPW = bx_planes(MODE), TAPB = bx_tap_bytes(MT, NPW), SLOTB = bx_slot_bytes(MT, NPW);
   constexpr int NPL = MODE == 1 ? 1 : (MODE == 3 ? 2 : 3);            // operand planes in use (the packed layouts always have room for three)
   HIP_DYNAMIC_SHARED(char, smem_bx)
   char* land = smem_bx;
-  char* tile = smem_bx + BX_LAND_BYTES;
-  char* ring = tile + BX_TILE_BYTES;
+  char* tile = PRE ? smem_bx : smem_bx + BX_LAND_BYTES;               // PRE: two tiles of two planes, [c & 1], BX_LAND_BYTES apart (the
+  char* ring = PRE ? smem_bx + 2 * BX_LAND_BYTES : tile + BX_TILE_BYTES;      // last DMA instruction of a tile is a whole KB: 768 bytes of slack)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
@@ -218,7 +234,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
 #pragma unroll
   for (int k = 0; k < BX_NPI; ++k) {
     const int q = k * 512 + tid;
-    const int u = q >> 1, half = q & 1;
+    const int u = PRE ? (q < BX_UNITS ? q : q - BX_UNITS) : q >> 1, half = PRE ? (q < BX_UNITS ? 0 : 1) : q & 1;      // PRE: plane by plane
     const int g = u / (BX_ROWS * BX_COLS), rem = u - g * (BX_ROWS * BX_COLS);
     const int row = rem / BX_COLS, col = rem - row * BX_COLS;
     const int yy = y0 + row - 1, xx = x0 + col - 1;
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
       if (k * 512 + wv * 64 < BX_PIECES) {                            // wave-uniform: whole 1 KB instructions
         const float* src = (poff[k] != ~0u && !(DPX_BX_DBG & 32)) ? cb + poff[k] : zero_block;
         if (DPX_BX_DBG & 64) src = inb + (tid & 63) * 4;
-        dpx_glds16(src, land + (k * 512 + wv * 64) * 16);
+        dpx_glds16(src, (PRE ? smem_bx + (c & 1) * BX_LAND_BYTES : land) + (k * 512 + wv * 64) * 16);
       }
     }
   };
@@ -268,7 +284,11 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
     if (!(DPX_BX_DBG & 16)) dpx_wait_vm<0>();
     DPX_LDS_BARRIER();                                                // landing buffer complete; everybody is done with the old tile
     }
-    for (int u = tid; u < ((DPX_BX_DBG & 2) ? 0 : BX_UNITS); u += 512) {
+    if constexpr (PRE) {
+      tile = smem_bx + (c & 1) * BX_LAND_BYTES;                       // landed as the operand planes themselves; the other tile is free:
+      if (c + 1 < chunks) issue_act(c + 1);                           // every wave has left chunk c - 1 (barrier above)
+    }
+    for (int u = tid; u < ((PRE || (DPX_BX_DBG & 2)) ? 0 : BX_UNITS); u += 512) {
       const float4 lo4 = *(const float4*)(land + u * 32), hi4 = *(const float4*)(land + u * 32 + 16);
       const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
       if constexpr (MODE == 3) {
@@ -298,7 +318,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
       if constexpr (MODE == 6)
         *(uint4*)(tile + 2 * BX_PLANE_BYTES + u * 16) = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
     }
-    if (!(DPX_BX_DBG & 4)) {
+    if (!PRE && !(DPX_BX_DBG & 4)) {
     DPX_LDS_BARRIER();                                                // tile ready, landing buffer free
     if (c + 1 < chunks) issue_act(c + 1);
     }
@@ -358,7 +378,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
       }
     }
   }
-  if (MODE == 3 && !(f16_max <= 6.0e4f)) atomicOr(&g_f16_overflow, 1u);        // (NaN counts)
+  if (MODE == 3 && !PSO && !(f16_max <= 6.0e4f)) atomicOr(&g_f16_overflow, 1u);        // (NaN counts; PSO: behind the epilogue, which splits the outputs)
   // ---- epilogue: bias, ReLU, C8 store.  D layout: col = lane & 31 (pixel), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) (cout) ----
   const int xx = x0 + n;
 #pragma unroll
@@ -383,6 +403,18 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
           v.w = fmaf(accx[mt][r][4 * q + 3], s, v.w);
         }
         if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if constexpr (PSO) {
+          if (cg < Gout && yy < H && xx < W) {
+            unsigned h0, l0, h1, l1;
+            split2_f16_pair(v.x, v.y, h0, l0);
+            split2_f16_pair(v.z, v.w, h1, l1);
+            f16_max = fmaxf(f16_max, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            char* unit = (char*)out + ((size_t)b * Gout * H * W + ((size_t)cg * H + yy) * W + xx) * 32;
+            *(uint2*)(unit + 8 * kg) = make_uint2(h0, h1);
+            *(uint2*)(unit + 16 + 8 * kg) = make_uint2(l0, l1);
+          }
+          continue;
+        }
         if (cg < Gout && yy < H && xx < W) {
           const size_t o = (size_t)b * Gout * H * W * 8 + (((size_t)cg * H + yy) * W + xx) * 8 + 4 * kg;
           if (mask) {                                                 // (kernel-uniform)
@@ -393,6 +425,39 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
         }
       }
     }
+  if (PSO && !(f16_max <= 6.0e4f)) atomicOr(&g_f16_overflow, 1u);
+}
+
+// split-f16 inference layers with pre-split operand planes in HBM (pre: input P8, pso: output P8)
+template <int MT>
+static void launch_bx_p8(bool relu, bool pre, bool pso, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W,
+                         hipStream_t s) {
+  const int tx = (W + BX_TW - 1) / BX_TW, ty = (H + BX_TH - 1) / BX_TH;
+  const size_t sh_pre = (size_t)2 * BX_LAND_BYTES + 2 * bx_slot_bytes(MT, 2), sh_std = (size_t)BX_LAND_BYTES + BX_TILE_BYTES + 2 * bx_slot_bytes(MT, 2);
+  const dim3 grid(tx * ty, B);
+#define DPX_BX_P8(R, PRE_, PSO_)                                                                                                             \
+  do {                                                                                                                                       \
+    const size_t sh = PRE_ ? sh_pre : sh_std;                                                                                                \
+    static bool attr = false;                                                                                                                \
+    if (!attr) {                                                                                                                             \
+      hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, R, 3, PRE_, PSO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);           \
+      attr = true;                                                                                                                           \
+    }                                                                                                                                        \
+    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, R, 3, PRE_, PSO_>), grid, dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx,            \
+               (const float*)nullptr);                                                                                                       \
+  } while (0)
+  if (pre && pso) { if (relu) DPX_BX_P8(true, true, true); else DPX_BX_P8(false, true, true); }
+  else if (pre) { if (relu) DPX_BX_P8(true, true, false); else DPX_BX_P8(false, true, false); }
+  else if (pso) { if (relu) DPX_BX_P8(true, false, true); else DPX_BX_P8(false, false, true); }
+#undef DPX_BX_P8
+}
+static void launch_bx_p8_mt(int mt, bool relu, bool pre, bool pso, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H,
+                            int W, hipStream_t s) {
+  switch (mt) {
+    case 1: launch_bx_p8<1>(relu, pre, pso, in, out, wpk, Gin, Gout, B, H, W, s); break;
+    case 2: launch_bx_p8<2>(relu, pre, pso, in, out, wpk, Gin, Gout, B, H, W, s); break;
+    default: launch_bx_p8<3>(relu, pre, pso, in, out, wpk, Gin, Gout, B, H, W, s); break;
+  }
 }
 
 template <int MT, int MODE>
@@ -529,7 +594,14 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
   float* bufA = a0 + px * 8 * G0;
   float* bufB = bufA + px * 8 * Gc;
   float* last = bufB + px * 8 * Gc;
-  DPX_LAUNCH("k_bx_pack_in", k_bx_pack_in, dim3(grid_for((long)(px * 8 * G0), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W, H2, W2, G0);
+  // split-f16 inference with the activations travelling between the layers as pre-split operand planes (P8, bit-identical results): knob
+  // ffdnet_presplit = 1, OFF by default.  Measured, round 4 (8x3x1024^2 colour / 32x1x320^2 gray, alternating runs on one box): 10.16 /
+  // 3.00 ms with it, 9.93 - 10.14 / 2.85 ms without -- no split pass, no landing buffer and one barrier less per chunk buy nothing
+  // (the kernel runs at the matrix pipe's power-limited rate), and two 8-byte stores per lane instead of one
+  // 16-byte store in the epilogue cost a little.
+  const bool p8 = mode == 3 && tune(TUNE_FFDNET_PRESPLIT) == 1;
+  DPX_LAUNCH("k_bx_pack_in", k_bx_pack_in, dim3(grid_for((long)(px * 8 * G0), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W, H2, W2, G0,
+             p8 ? 1 : 0);
   const char* wl = (const char*)packed;
   const float* cur = a0;
   int gin = G0;
@@ -538,7 +610,8 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
     const bool lastl = l == nb - 1;
     float* dst = lastl ? last : ((l & 1) ? bufB : bufA);
     const int gout = lastl ? GL : Gc;
-    if (mode == 1) launch_bx_mt<1>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    if (p8) launch_bx_p8_mt((cout + 31) / 32, !lastl, true, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    else if (mode == 1) launch_bx_mt<1>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     else if (mode == 3) launch_bx_mt<3>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     else launch_bx_mt<6>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     wl += bx_layer_bytes(cin, cout, bx_planes(mode));
@@ -573,7 +646,7 @@ extern "C" int dpx_ffdnet_forward_bf16_save(const float* x, float* y, const floa
   float* a0 = (float*)acts;
   float* hidden = a0 + px * 8 * G0;                                   // layer l's output (l < nb - 1) at hidden + l px 8 Gc
   float* last = hidden + (size_t)(nb - 1) * px * 8 * Gc;
-  DPX_LAUNCH("k_bx_pack_in", k_bx_pack_in, dim3(grid_for((long)(px * 8 * G0), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W, H2, W2, G0);
+  DPX_LAUNCH("k_bx_pack_in", k_bx_pack_in, dim3(grid_for((long)(px * 8 * G0), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W, H2, W2, G0, 0);
   const char* wl = (const char*)packed;
   const float* cur = a0;
   int gin = G0;

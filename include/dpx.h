@@ -88,6 +88,9 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        neighbouring iterations as two passes (same gradients up to round-off)
  *   unroll_bwd_fold_finish  1 = the fused backward stage's last workgroup finishes the iteration's       DPX_UNROLL_BWD_FOLD_FINISH
  *                        reductions instead of a finishing launch (slower: measured, kept for A/B)
+ *   ffdnet_presplit      split-f16 inference (dpx_ffdnet_forward_bf16, mode 3): 1 = activations       DPX_FFDNET_PRESPLIT
+ *                        travel between the layers as pre-split binary16 operand planes written by
+ *                        the producing layer (bit-identical results; measured +-0 .. -5 %: off)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */

@@ -41,6 +41,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return {x
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return {x, y}; }
 static inline int2 make_int2(int x, int y) { return {x, y}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;
