@@ -168,6 +168,7 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"unroll_bwd_staged", "DPX_UNROLL_BWD_STAGED", 0, nullptr},
     {"unroll_bwd_fold_finish", "DPX_UNROLL_BWD_FOLD_FINISH", 0, nullptr},
     {"ffdnet_presplit", "DPX_FFDNET_PRESPLIT", 0, nullptr},
+    {"generic_cols_ct", "DPX_GENERIC_COLS_CT", 0, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

@@ -812,6 +812,7 @@ int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, i
   int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
   if (CT < 1) CT = 1;
   if (CT > 16) CT = 16;
+  if (tune(TUNE_GENERIC_COLS_CT) > 0) CT = tune(TUNE_GENERIC_COLS_CT);      // knob: columns per workgroup of the size-generic column pass
   const size_t shcol = (size_t)2 * CT * (H + 1) * sizeof(float2);
   if (shcol > 160 * 1024) {
     set_error("column length %d too large for the LDS-resident generic FFT", H);
@@ -819,6 +820,11 @@ int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, i
   }
   const dim3 gcol((Ws + CT - 1) / CT, P);
   const float2* twH = tw_cols(table, W);
+  if (shcol > 60 * 1024) {
+    hipFuncSetAttribute((const void*)k_cols<OP_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
+    hipFuncSetAttribute((const void*)k_cols<OP_MULCONJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
+    hipFuncSetAttribute((const void*)k_cols<OP_SOLVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
+  }
   switch (op) {
     case OP_MUL: DPX_LAUNCH("k_cols", (k_cols<OP_MUL>), gcol, dim3(256), shcol, stream, spec, A, C, H, W, pcol, twH, CT); break;
     case OP_MULCONJ: DPX_LAUNCH("k_cols", (k_cols<OP_MULCONJ>), gcol, dim3(256), shcol, stream, spec, A, C, H, W, pcol, twH, CT); break;

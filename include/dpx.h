@@ -91,6 +91,8 @@ int dpx_timing_report(char* buf, size_t cap);
  *   ffdnet_presplit      split-f16 inference (dpx_ffdnet_forward_bf16, mode 3): 1 = activations       DPX_FFDNET_PRESPLIT
  *                        travel between the layers as pre-split binary16 operand planes written by
  *                        the producing layer (bit-identical results; measured +-0 .. -5 %: off)
+ *   generic_cols_ct      columns per workgroup of the size-generic column pass (planes off the     DPX_GENERIC_COLS_CT
+ *                        register-radix path; 0 = what 60 KB of LDS hold)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */
