@@ -272,7 +272,7 @@ def case_other_plane_sizes(device, sizes=((384, 256), (1536, 256), (2048, 256), 
         assert_close(out.cpu(), ref, TOL, f"PGD x 3, {H}x{W}")
 
 
-def case_w768_two_kernel(device, H=256, B=2):
+def case_w768_two_kernel(device, H=256, B=2, methods=("admm", "hqs", "admm_vxu")):
     """768-wide rows on the two-kernel iteration (384 = 6 * 8 * 8 complex points per row on one wave, fft384_wave): ADMM, half-quadratic
     splitting and ADMM_vxu with full states against the op-by-op iteration on the size-generic kernels, and the fresh-state /
     touched-state seeds against each other.  (768 x 768 is the reference's own patch size, contrib/optic/utils.py:158-166.)"""
@@ -285,14 +285,14 @@ def case_w768_two_kernel(device, H=256, B=2):
     b = T(b0, device)
     outs = {}
     for fused in (True, False):
-        for method in ("admm", "hqs", "admm_vxu"):
+        for method in methods:
             x = dp.Variable()
             fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
             s = dp.compile(fns, method=method, device=device)
             s.use_fused = fused
             outs[(fused, method)] = s.solve(x0=b, rhos=0.2, lams=0.01, max_iter=4, return_full_states=True)
             assert s.last_path == ("fused" if fused else "generic"), (method, s.last_path)
-    for method in ("admm", "hqs", "admm_vxu"):
+    for method in methods:
         a, c = outs[(True, method)], outs[(False, method)]
         assert_close(a[0].cpu(), c[0].cpu(), TOL, f"768-wide {method}: x, two-kernel vs op by op")
         for p, q in zip(a[1], c[1]):
@@ -479,11 +479,12 @@ def case_cg_branches(device, quick=False):
         for name, knobs in branches:
             with be.tuned(**knobs):
                 x, n = ops.cg_masked_fft(rhs, mask, rho, 1.0, 1e-6, 100)
-                x10, n10 = ops.cg_masked_fft(rhs, mask, rho, 1.0, 0.0, 10)
+                x10, n10 = (None, 10) if quick else ops.cg_masked_fft(rhs, mask, rho, 1.0, 0.0, 10)
             assert abs(n - n_ref) <= 1, (B, name, n, n_ref)
             assert n10 == 10, (B, name, n10)
             assert_close(x.cpu(), g[f"B{B}_x"], TOL, f"cg branch '{name}' B={B}")
-            assert_close(x10.cpu(), g[f"B{B}_x_10it"], TOL, f"cg branch '{name}' B={B}, 10 fixed iterations")
+            if x10 is not None:
+                assert_close(x10.cpu(), g[f"B{B}_x_10it"], TOL, f"cg branch '{name}' B={B}, 10 fixed iterations")
             outs[name] = (x.cpu().numpy(), n)
         # the branches run the same recurrences with differently ordered reductions: same exit iteration, solutions within round-off
         ns = {n for _, n in outs.values()}

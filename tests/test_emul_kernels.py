@@ -51,7 +51,7 @@ def test_column_length_768():
 
 
 def test_768_wide_rows_on_the_two_kernel_iteration():
-    pc.case_w768_two_kernel(DEV, B=1)
+    pc.case_w768_two_kernel(DEV, B=1, methods=("admm", "admm_vxu"))
 
 
 def test_other_plane_sizes():
