@@ -169,6 +169,7 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"unroll_bwd_fold_finish", "DPX_UNROLL_BWD_FOLD_FINISH", 0, nullptr},
     {"ffdnet_presplit", "DPX_FFDNET_PRESPLIT", 0, nullptr},
     {"generic_cols_ct", "DPX_GENERIC_COLS_CT", 0, nullptr},
+    {"cg_wave_fft", "DPX_CG_WAVE_FFT", 0, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

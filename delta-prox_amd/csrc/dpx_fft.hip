@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "dpx_cg_dev.h"
+#include "dpx_fft_reg.h"
 
 namespace dpx {
 
@@ -774,6 +775,162 @@ __global__ void k_crows_real_out(const float2* __restrict__ in, float* __restric
   }
 }
 
+// ---- the same three kernels for planes of 64 R1 x 64 R1 (R1 = 5: 320 x 320, the CS-MRI configuration; R1 = 6: 384 x 384) with every
+// 1-D transform on ONE wave's registers (fftR64_wave, dpx_fft_reg.h: radix R1 * 8 * 8, wave-local exchanges): a workgroup = 4 waves
+// = 4 rows / 4 columns; no workgroup barrier inside a transform, no index arithmetic of the size-generic Stockham passes, the
+// twiddles of a lane in 14 registers.  Same shifts, scale factors, mask handling, direction update and <p, Ap> hand-over as above.
+template <int R1>
+__global__ void __launch_bounds__(256) k_crows_real_in_w(float* __restrict__ in, float2* __restrict__ out, int nrows, const float2* __restrict__ twW,
+                                                         float scale, const float* __restrict__ dir_r, const float* __restrict__ beta,
+                                                         const int* __restrict__ done, int rows_per_image) {
+  constexpr int W = 64 * R1, hs = W / 2, S = LdsSeq<W>::SLOTS;
+  __shared__ float2 lds[4 * S];
+  if (done && done[0]) return;
+  const int tid = threadIdx.x, t = tid & 63, wv = tid >> 6;
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= nrows) return;                              // (wave-uniform)
+  TwR64<R1> tw;
+  tw.load(t, twW, 1);
+  const float bt = dir_r ? beta[row / rows_per_image] : 0.f;
+  float2 v[R1];
+#pragma unroll
+  for (int m = 0; m < R1; ++m) {
+    int src = t + 64 * m + hs;
+    if (src >= W) src -= W;
+    const size_t e = (size_t)row * W + src;
+    float x = in[e];
+    if (dir_r) {
+      x = fmaf(bt, x, dir_r[e]);
+      in[e] = x;
+    }
+    v[m] = make_float2(x, 0.f);
+  }
+  fftR64_wave<R1, -1>(v, lds + wv * S, t, tw, WaveSync());
+#pragma unroll
+  for (int m = 0; m < R1; ++m) {
+    int dst = t + 64 * m + hs;
+    if (dst >= W) dst -= W;
+    out[(size_t)row * W + dst] = cscale(v[m], scale);
+  }
+}
+
+template <int R1>
+__global__ void __launch_bounds__(256) k_ccols_mask_w(float2* __restrict__ data, const float* __restrict__ mask, int mask_images, int W,
+                                                      const float2* __restrict__ twH, int square, const int* __restrict__ done) {
+  constexpr int H = 64 * R1, hs = H / 2, S = LdsSeq<H>::SLOTS, ld = H + 1;
+  __shared__ float2 col[4 * ld];
+  __shared__ float2 lds[4 * S];
+  if (done && done[0]) return;
+  const int tid = threadIdx.x, t = tid & 63, wv = tid >> 6;
+  const int p = blockIdx.y, l0 = blockIdx.x * 4;
+  const int nseq = min(4, W - l0);
+  float2* base = data + (size_t)p * H * W;
+  const float* mk = mask + (mask_images == 1 ? (size_t)0 : (size_t)p * H * W);
+  for (int i = tid; i < H * nseq; i += 256) {            // the workgroup's columns, rows shifted to the transform's order
+    const int r = i / nseq, c = i - r * nseq;
+    int src = r + hs;
+    if (src >= H) src -= H;
+    col[c * ld + r] = base[(size_t)src * W + l0 + c];
+  }
+  __syncthreads();
+  if (wv < nseq) {
+    TwR64<R1> tw;
+    tw.load(t, twH, 1);
+    float2 v[R1];
+#pragma unroll
+    for (int m = 0; m < R1; ++m) v[m] = col[wv * ld + t + 64 * m];
+    fftR64_wave<R1, -1>(v, lds + wv * S, t, tw, WaveSync());
+    // bin k sits at centred row (k + hs) % H, which is where the inverse transform reads its input from: the shifts cancel, only the
+    // mask is indexed with the centred row
+#pragma unroll
+    for (int m = 0; m < R1; ++m) {
+      int row = t + 64 * m + hs;
+      if (row >= H) row -= H;
+      const float mv = mk[(size_t)row * W + l0 + wv];
+      v[m] = cscale(v[m], square ? mv * mv : mv);
+    }
+    WaveSync()();
+    fftR64_wave<R1, +1>(v, lds + wv * S, t, tw, WaveSync());
+#pragma unroll
+    for (int m = 0; m < R1; ++m) col[wv * ld + t + 64 * m] = v[m];
+  }
+  __syncthreads();
+  for (int i = tid; i < H * nseq; i += 256) {
+    const int k = i / nseq, c = i - k * nseq;
+    int dst = k + hs;
+    if (dst >= H) dst -= H;
+    base[(size_t)dst * W + l0 + c] = col[c * ld + k];
+  }
+}
+
+template <int R1>
+__global__ void __launch_bounds__(256) k_crows_real_out_w(const float2* __restrict__ in, float* __restrict__ out, const float* __restrict__ pin,
+                                                          const float* __restrict__ rho, float c, const int* __restrict__ done, int rows_per_image,
+                                                          int nrows, const float2* __restrict__ twW, float scale,
+                                                          float* __restrict__ dot_partial, unsigned* __restrict__ counter, float* __restrict__ pAp,
+                                                          int B) {
+  constexpr int W = 64 * R1, hs = W / 2, S = LdsSeq<W>::SLOTS;
+  __shared__ float2 lds[4 * S];
+  __shared__ float shred[4];
+  __shared__ int shlast;
+  if (done && done[0]) return;
+  const int tid = threadIdx.x, t = tid & 63, wv = tid >> 6;
+  const int row = blockIdx.x * 4 + wv;                   // (nrows is a multiple of 4: rows_per_image is)
+  TwR64<R1> tw;
+  tw.load(t, twW, 1);
+  float2 v[R1];
+#pragma unroll
+  for (int m = 0; m < R1; ++m) {
+    int src = t + 64 * m + hs;
+    if (src >= W) src -= W;
+    v[m] = in[(size_t)row * W + src];
+  }
+  fftR64_wave<R1, +1>(v, lds + wv * S, t, tw, WaveSync());
+  const float cr = c * rho[row / rows_per_image];
+  float dacc = 0.f;
+#pragma unroll
+  for (int m = 0; m < R1; ++m) {
+    int dst = t + 64 * m + hs;
+    if (dst >= W) dst -= W;
+    const size_t e = (size_t)row * W + dst;
+    const float pv = pin[e];
+    const float av = fmaf(cr, pv, v[m].x * scale);
+    out[e] = av;
+    dacc = fmaf(pv, av, dacc);
+  }
+  if (!dot_partial) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
+  if (t == 0) shred[wv] = dacc;
+  __syncthreads();
+  if (tid == 0) dpx_st_agent(dot_partial + blockIdx.x, ((shred[0] + shred[1]) + shred[2]) + shred[3]);
+  if (!dpx_last_block(counter, gridDim.x, &shlast)) return;
+  const int bpi = rows_per_image / 4;                    // workgroups per image
+  for (int bimg = wv; bimg < B; bimg += 4) {
+    float a = 0.f;
+    for (int i = t; i < bpi; i += 64) a += dpx_ld_agent(dot_partial + (size_t)bimg * bpi + i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (t == 0) pAp[bimg] = a;
+  }
+}
+
+// r / beta: the direction update in front (NULL: none); done_fwd / done_out: the converged flag the forward kernels / the last kernel
+// look at (NULL: none); square: `mask` holds the mask (1) or its square (0); dotws / counter / pAp: the <p, Ap> hand-over (NULL: none)
+template <int R1>
+static int masked_normal_apply_wave(float* p, const float* r, const float* beta, float* Ap, float2* z, const float* mask, int mask_images, int square,
+                                    const float* rho, float c, const int* done_fwd, const int* done_out, float* dotws, unsigned* counter, float* pAp,
+                                    int B, const void* table, hipStream_t s, const char* what) {
+  constexpr int N = 64 * R1;
+  const float scale = 1.0f / (float)N;                   // 1 / sqrt(H W)
+  const dim3 grow(B * N / 4), gcol(N / 4, B);
+  DPX_LAUNCH("k_crows_real_in", (k_crows_real_in_w<R1>), grow, dim3(256), 0, s, p, z, B * N, tw_rows(table), scale, r, beta, done_fwd, N);
+  DPX_LAUNCH("k_ccols_mask", (k_ccols_mask_w<R1>), gcol, dim3(256), 0, s, z, mask, mask_images, N, tw_cols(table, N), square, done_fwd);
+  DPX_LAUNCH("k_crows_real_out", (k_crows_real_out_w<R1>), grow, dim3(256), 0, s, (const float2*)z, Ap, (const float*)p, rho, c, done_out, N, B * N,
+             tw_rows(table), scale, dotws, counter, pAp, B);
+  return launch_status(what);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -848,6 +1005,15 @@ bool masked_normal_fits(int H, int W) {
 // z: one complex [B][H][W] scratch plane set.  Returns DPX_ERR_UNSUPPORTED for planes beyond the LDS-resident transform.
 int masked_normal_apply(const float* p, float* Ap, float2* z, const float* mask2, int mask_images, const float* rho, float c, const int* done,
                         int B, int H, int W, const void* table, hipStream_t s) {
+  if (H == W && tune(TUNE_CG_WAVE_FFT) != 2) {         // (as in the fused iteration below)
+    const char* what = "masked_normal_apply";
+    if (H == 320)
+      return masked_normal_apply_wave<5>((float*)p, nullptr, nullptr, Ap, z, mask2, mask_images, 0, rho, c, nullptr, done, nullptr, nullptr, nullptr, B,
+                                         table, s, what);
+    if (H == 384)
+      return masked_normal_apply_wave<6>((float*)p, nullptr, nullptr, Ap, z, mask2, mask_images, 0, rho, c, nullptr, done, nullptr, nullptr, nullptr, B,
+                                         table, s, what);
+  }
   const Plan1D prow = make_plan(W), pcol = make_plan(H);
   const int rpb = rows_per_block(W);
   const size_t shrow = (size_t)2 * rpb * (W + 1) * sizeof(float2);
@@ -894,6 +1060,15 @@ size_t masked_normal_fused_ws_floats(int B, int H, int W) { return (size_t)B * H
 // into the CG state).  `mask` is the mask itself (squared on the fly).  dotws: masked_normal_fused_ws_floats floats.
 int masked_normal_apply_fused(float* p, const float* r, float* Ap, float2* z, const float* mask, int mask_images, const float* rho, float c,
                               float* state, float* dotws, unsigned* counter, int B, int H, int W, const void* table, hipStream_t s) {
+  // 320 x 320 / 384 x 384 planes: every transform on one wave's registers (knob cg_wave_fft = 2 keeps the size-generic kernels)
+  if (H == W && tune(TUNE_CG_WAVE_FFT) != 2) {
+    const CgState S{state, B};
+    const char* what = "masked_normal_apply_fused";
+    if (H == 320)
+      return masked_normal_apply_wave<5>(p, r, S.beta(), Ap, z, mask, mask_images, 1, rho, c, S.flags(), S.flags(), dotws, counter, S.pAp(), B, table, s, what);
+    if (H == 384)
+      return masked_normal_apply_wave<6>(p, r, S.beta(), Ap, z, mask, mask_images, 1, rho, c, S.flags(), S.flags(), dotws, counter, S.pAp(), B, table, s, what);
+  }
   const Plan1D prow = make_plan(W), pcol = make_plan(H);
   const int rpb = fused_rpb(B, H, W);
   const size_t shrow = (size_t)2 * rpb * (W + 1) * sizeof(float2);

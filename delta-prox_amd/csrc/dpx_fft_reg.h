@@ -360,6 +360,73 @@ __device__ __forceinline__ void fft384_wave(float2 (&v)[6], float2* __restrict__
   for (int m = 0; m < 6; ++m) v[m] = lds[lds_slot(t + 64 * m)];
 }
 
+// ---- the same scheme for any length R1 * 64 (R1 = 5: 320 points, the plane size of the CS-MRI configuration; R1 = 6: 384) ------------
+// radix-5 butterfly (Winograd form: 5 real multiplications per component), natural order
+template <int DIR> __device__ __forceinline__ void rdft5(float2 (&v)[5]) {
+  constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;      // cos 72, cos 144 degrees
+  constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;       // sin 72, sin 144 degrees
+  const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+  const float2 m1 = make_float2(fmaf(c2, t2.x, fmaf(c1, t1.x, v[0].x)), fmaf(c2, t2.y, fmaf(c1, t1.y, v[0].y)));
+  const float2 m2 = make_float2(fmaf(c1, t2.x, fmaf(c2, t1.x, v[0].x)), fmaf(c1, t2.y, fmaf(c2, t1.y, v[0].y)));
+  const float2 q1 = make_float2(fmaf(s2, t4.x, s1 * t3.x), fmaf(s2, t4.y, s1 * t3.y));
+  const float2 q2 = make_float2(fmaf(-s1, t4.x, s2 * t3.x), fmaf(-s1, t4.y, s2 * t3.y));
+  v[0] = cadd(v[0], cadd(t1, t2));
+  v[1] = cadd_rot<DIR>(m1, q1);           // forward: m1 - i q1
+  v[4] = csub_rot<DIR>(m1, q1);
+  v[2] = cadd_rot<DIR>(m2, q2);
+  v[3] = csub_rot<DIR>(m2, q2);
+}
+template <int R1> struct TwR64 {
+  float2 b[7], c[7];
+  // tw[n tws] = exp(-2 pi i n / (64 R1));  b[m - 1] = W_{8 R1}^{(j % R1) m},  c[m - 1] = W_{64 R1}^{j m},  j = t < 8 R1
+  __device__ __forceinline__ void load(int t, const float2* __restrict__ tw, int tws) {
+    const int j = t < 8 * R1 ? t : 0, k = j % R1;
+#pragma unroll
+    for (int m = 1; m < 8; ++m) {
+      b[m - 1] = tw[(8 * k * m) * tws];
+      c[m - 1] = tw[(j * m) * tws];
+    }
+  }
+};
+// v[m] = x[t + 64 m] -> X[t + 64 m], m < R1; lds: LdsSeq<64 R1>::SLOTS float2 of this wave
+template <int R1, int DIR, class Sync>
+__device__ __forceinline__ void fftR64_wave(float2 (&v)[R1], float2* __restrict__ lds, int t, const TwR64<R1>& W, Sync sync) {
+  static_assert(R1 == 5 || R1 == 6, "first-pass radix 5 or 6");
+  constexpr int NB = 8 * R1;                           // radix-8 butterflies per pass
+  if constexpr (R1 == 5) rdft5<DIR>(v);
+  else rdft6<DIR>(v);
+#pragma unroll
+  for (int m = 0; m < R1; ++m) lds[lds_slot(R1 * t + m)] = v[m];
+  sync();
+  float2 a[8];
+  const bool act = t < NB;
+  const int j = act ? t : 0, k = j % R1;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) a[m] = lds[lds_slot(j + NB * m)];
+  sync();
+#pragma unroll
+  for (int m = 1; m < 8; ++m) a[m] = twmul<DIR>(a[m], W.b[m - 1]);
+  rdft8<DIR>(a);
+  if (act) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) lds[lds_slot(8 * (j - k) + k + R1 * m)] = a[m];
+  }
+  sync();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) a[m] = lds[lds_slot(j + NB * m)];
+  sync();
+#pragma unroll
+  for (int m = 1; m < 8; ++m) a[m] = twmul<DIR>(a[m], W.c[m - 1]);
+  rdft8<DIR>(a);
+  if (act) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) lds[lds_slot(j + NB * m)] = a[m];
+  }
+  sync();
+#pragma unroll
+  for (int m = 0; m < R1; ++m) v[m] = lds[lds_slot(t + 64 * m)];
+}
+
 // the same transform with its twiddles read from a table on the spot (kernels that transform one row per thread group)
 template <int DIR, class Sync>
 __device__ __forceinline__ void fft384_wave_tab(float2 (&v)[6], float2* __restrict__ lds, int t, const float2* __restrict__ tw, int tws, Sync sync) {

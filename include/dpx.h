@@ -93,6 +93,8 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        the producing layer (bit-identical results; measured +-0 .. -5 %: off)
  *   generic_cols_ct      columns per workgroup of the size-generic column pass (planes off the     DPX_GENERIC_COLS_CT
  *                        register-radix path; 0 = what 60 KB of LDS hold)
+ *   cg_wave_fft          fused CG on 320 x 320 / 384 x 384 planes: 2 = the size-generic transform        DPX_CG_WAVE_FFT
+ *                        kernels instead of the one-wave register transforms (same result to round-off)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */

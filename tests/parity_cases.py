@@ -505,6 +505,46 @@ def case_cg_branches(device, quick=False):
         L.call("dpx_cg_config", old[0], old[1], old[2])
 
 
+def case_cg_wave_fft(device, sizes=(320, 384), B=3, iters=6):
+    """the fused CG matvec on 320 x 320 and 384 x 384 planes -- every 1-D transform on one wave's registers (k_crows_real_in_w,
+    k_ccols_mask_w, k_crows_real_out_w: radix 5 / 6, 8, 8) -- against the size-generic kernels (knob cg_wave_fft = 2, themselves pinned
+    by G6 / G32) and against the oracle's dense-FFT CG: iterate after `iters` fixed iterations and the converged solve"""
+    import oracle.dprox_oracle as orc
+    from dprox import _backend as be
+    from dprox import _ops as ops
+    for N in sizes:
+        rng = np.random.RandomState(N)
+        mask = (rng.rand(1, N, N) < 0.3).astype(np.float32)
+        mask[:, N // 2 - 8:N // 2 + 8] = 1
+        rhs = rng.randn(B, N, N).astype(np.float32)
+        rho = (0.3 + rng.rand(B)).astype(np.float32)
+        mt, rt, rh = T(mask, device), T(rhs, device).contiguous(), T(rho, device)
+        out = {}
+        for name, knobs in (("wave", dict(cg_fused_max_b=32)), ("wave, step by step", dict(cg_fused_max_b=0)),
+                            ("generic", dict(cg_fused_max_b=32, cg_wave_fft=2))):
+            with be.tuned(**knobs):
+                xk, nk = ops.cg_masked_fft(rt, mt, rh, 1.0, 0.0, iters)
+                x, n = (xk, nk) if iters >= 100 else ops.cg_masked_fft(rt, mt, rh, 1.0, 1e-6, 100)
+            assert nk == iters
+            out[name] = (xk.cpu().numpy(), x.cpu().numpy(), n)
+        for name in ("wave", "wave, step by step"):
+            assert out[name][2] == out["generic"][2], (N, name, out[name][2], out["generic"][2])
+            for i, what in ((0, f"{iters} fixed iterations"), (1, "converged")):
+                e = rel_l2(out[name][i], out["generic"][i])
+                record(f"cg matvec, one-wave transforms ({name}) vs size-generic kernels, {N} x {N}, {what}", e, 2e-6)
+                assert e <= 2e-6, (N, name, what, e)
+        m2 = torch.from_numpy(mask) ** 2
+        rv = torch.from_numpy(rho).view(B, 1, 1)
+
+        def normal(p):          # Re F^-1 mask^2 F p + rho p with the centred orthonormal transform (contrib masked_fft: utils fft2 / ifft2)
+            f = torch.fft.fftshift(torch.fft.fft2(torch.fft.ifftshift(p, dim=(-2, -1)), norm="ortho"), dim=(-2, -1)) * m2
+            return torch.fft.fftshift(torch.fft.ifft2(torch.fft.ifftshift(f, dim=(-2, -1)), norm="ortho"), dim=(-2, -1)).real + rv * p
+
+        xo, no = orc.cg(normal, torch.from_numpy(rhs), rtol=1e-6, max_iters=100, return_iters=True)
+        assert abs(no - out["wave"][2]) <= 1, (N, no, out["wave"][2])
+        assert_close(out["wave"][1], xo.numpy(), TOL, f"cg with one-wave transforms vs oracle, {N} x {N}")
+
+
 def case_full_c4_batches(device, B):
     """G32b -- config 4 at the batch sizes of its 2-GPU and 1-GPU runs (16 and 32 x 1 x 320 x 320): LADMM with the CG x-update on the
     STEP-BY-STEP branch of dpx_cg_masked_fft (B > 8; what bench.py's config4_batch32 times), nonneg + gray FFDNet prior, 2 outer

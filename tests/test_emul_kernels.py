@@ -107,6 +107,10 @@ def test_cg_both_branches_of_the_fused_call():
     pc.case_cg_branches(DEV, quick=True)
 
 
+def test_cg_matvec_with_one_wave_transforms_320():
+    pc.case_cg_wave_fft(DEV, sizes=(320,), B=1, iters=3)
+
+
 def test_cg_masked_fft_odd_and_per_image_masks():
     pc.case_cg_masked_fft_shapes(DEV)
 
