@@ -696,14 +696,17 @@ int solve_rhs_bwd_partials(const float* g, const float* x, const float* rhs, con
     DPX_LAUNCH("k_solve_rhs_bwd", k_solve_rhs_bwd, dim3(ad_blocks((long)C * H * W), B), dim3(256), 0, s, g, x, rhs, rho, T, part_a, part_b, C, H, W);
   return launch_status("dpx_admm_unrolled_backward");
 }
-// glam == NULL: only the rho reductions; grho == NULL: only the lambda reductions
-int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
-                int C, int H, int W, hipStream_t s) {
+// glam == NULL: only the rho reductions; grho == NULL: only the lambda reductions; nblk: partial sums per row
+int finish_iter_n(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
+                  int nblk, hipStream_t s) {
   const int nB = glam ? nterms * B : 0, nR = grho ? B : 0;
   if (nB + nR == 0) return DPX_OK;
-  DPX_LAUNCH("k_ad_finish_iter", k_ad_finish_iter, dim3(nB + nR), dim3(256), 0, s, part_lam, part_a, part_b, glam, grho, rho, nB,
-             ad_blocks((long)C * H * W));
+  DPX_LAUNCH("k_ad_finish_iter", k_ad_finish_iter, dim3(nB + nR), dim3(256), 0, s, part_lam, part_a, part_b, glam, grho, rho, nB, nblk);
   return launch_status("dpx_admm_unrolled_backward");
+}
+int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
+                int C, int H, int W, hipStream_t s) {
+  return finish_iter_n(part_lam, part_a, part_b, glam, grho, rho, nterms, B, ad_blocks((long)C * H * W), s);
 }
 // rhs stage of iteration `it` + z stage of iteration `it - 1` (k_rhs_z_bwd4); false: the planes do not fit it (W % 4)
 bool rhs_z_bwd_fused(const float* g, const float* x, const float* rhs, const float* rho, const dpx_bwd_term* terms, int nterms, const float* const* a_in,

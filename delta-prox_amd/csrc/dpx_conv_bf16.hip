@@ -206,23 +206,30 @@ __global__ void k_bx_unpack_out(const float* __restrict__ o, float* __restrict__
 // splits its fp32 results into the two binary16 planes (the same split2_f16 of the same fp32 values the consumer's split pass
 // performed: bit-identical operands), the consumer's LDS-DMA lands them directly as its operand tile (pieces ordered plane by plane),
 // two tiles alternating: no landing buffer, no split pass, one workgroup barrier less per 16-channel chunk.
-template <int MT, bool RELU, int MODE, bool PRE = false, bool PSO = false>
+// TH: rows of the workgroup's tile (16: eight waves, one workgroup per CU; 8: four waves and half the LDS -- two workgroups per CU --
+// for launches whose 16-row tiles would leave CUs idle: 4 x 1 x 320 x 320 is 200 tiles of 16 rows on 256 CUs)
+template <int MT, bool RELU, int MODE, bool PRE = false, bool PSO = false, int TH = BX_TH>
 // mask (nullable; C8, Gout groups): the stored value is zeroed where mask <= 0 -- the ReLU derivative of the backward-data pass
 // ([a_l > 0] from the saved forward activation), applied in the producing layer's epilogue.
-__global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict__ in, float* __restrict__ out, const char* __restrict__ wpk, int Gin,
+__global__ void __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) k_conv3x3_bf16(const float* __restrict__ in, float* __restrict__ out, const char* __restrict__ wpk, int Gin,
                                                         int Gout, int H, int W, int tiles_x, const float* __restrict__ mask) {
   static_assert(MODE == 3 || (!PRE && !PSO), "pre-split operand planes exist for the split-f16 arithmetic only");
   constexpr int M32 = MT * 32, NPW = bx_planes(MODE), TAPB = bx_tap_bytes(MT, NPW), SLOTB = bx_slot_bytes(MT, NPW);
   constexpr int NPL = MODE == 1 ? 1 : (MODE == 3 ? 2 : 3);            // operand planes in use (the packed layouts always have room for three)
+  static_assert(TH == 16 || (TH == 8 && !PRE && !PSO), "tile rows");
+  // the tile geometry (TH = 16: the BX_* constants above)
+  constexpr int NWV = TH / 2, NT = NWV * 64, ROWS = TH + 2, UNITS = 2 * ROWS * BX_COLS, PIECES = 2 * UNITS;
+  constexpr int LAND_BYTES = ((PIECES + 63) / 64) * 1024, PLANE_BYTES = UNITS * 16, NPI = (PIECES + NT - 1) / NT;
+  constexpr int TILE_BYTES = (TH == 16 ? 3 : NPL) * PLANE_BYTES;
   HIP_DYNAMIC_SHARED(char, smem_bx)
   char* land = smem_bx;
-  char* tile = PRE ? smem_bx : smem_bx + BX_LAND_BYTES;               // PRE: two tiles of two planes, [c & 1], BX_LAND_BYTES apart (the
-  char* ring = PRE ? smem_bx + 2 * BX_LAND_BYTES : tile + BX_TILE_BYTES;      // last DMA instruction of a tile is a whole KB: 768 bytes of slack)
+  char* tile = PRE ? smem_bx : smem_bx + LAND_BYTES;               // PRE: two tiles of two planes, [c & 1], LAND_BYTES apart (the
+  char* ring = PRE ? smem_bx + 2 * LAND_BYTES : tile + TILE_BYTES;      // last DMA instruction of a tile is a whole KB: 768 bytes of slack)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int y0 = ty * BX_TH, x0 = tx * BX_TW;
+  const int y0 = ty * TH, x0 = tx * BX_TW;
   const int n = lane & 31, kg = lane >> 5;
   const int chunks = Gin / 2;
   const float* bias = (const float*)(wpk + (size_t)chunks * 3 * SLOTB);
@@ -230,26 +237,26 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
   const float* inb = in + (size_t)b * Gin * H * W * 8;
 
   // per-lane source offsets (floats, relative to the chunk's first group) of its DMA pieces; ~0u = outside the image
-  unsigned poff[BX_NPI];
+  unsigned poff[NPI];
 #pragma unroll
-  for (int k = 0; k < BX_NPI; ++k) {
-    const int q = k * 512 + tid;
-    const int u = PRE ? (q < BX_UNITS ? q : q - BX_UNITS) : q >> 1, half = PRE ? (q < BX_UNITS ? 0 : 1) : q & 1;      // PRE: plane by plane
-    const int g = u / (BX_ROWS * BX_COLS), rem = u - g * (BX_ROWS * BX_COLS);
+  for (int k = 0; k < NPI; ++k) {
+    const int q = k * NT + tid;
+    const int u = PRE ? (q < UNITS ? q : q - UNITS) : q >> 1, half = PRE ? (q < UNITS ? 0 : 1) : q & 1;      // PRE: plane by plane
+    const int g = u / (ROWS * BX_COLS), rem = u - g * (ROWS * BX_COLS);
     const int row = rem / BX_COLS, col = rem - row * BX_COLS;
     const int yy = y0 + row - 1, xx = x0 + col - 1;
-    const bool ok = q < BX_PIECES && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const bool ok = q < PIECES && yy >= 0 && yy < H && xx >= 0 && xx < W;
     poff[k] = ok ? (unsigned)(((size_t)g * H * W + (size_t)yy * W + xx) * 8 + half * 4) : ~0u;
   }
   auto issue_act = [&](int c) {
     if (DPX_BX_DBG & 8) return;
     const float* cb = inb + (size_t)(2 * c) * H * W * 8;
 #pragma unroll
-    for (int k = 0; k < BX_NPI; ++k) {
-      if (k * 512 + wv * 64 < BX_PIECES) {                            // wave-uniform: whole 1 KB instructions
+    for (int k = 0; k < NPI; ++k) {
+      if (k * NT + wv * 64 < PIECES) {                            // wave-uniform: whole 1 KB instructions
         const float* src = (poff[k] != ~0u && !(DPX_BX_DBG & 32)) ? cb + poff[k] : zero_block;
         if (DPX_BX_DBG & 64) src = inb + (tid & 63) * 4;
-        dpx_glds16(src, (PRE ? smem_bx + (c & 1) * BX_LAND_BYTES : land) + (k * 512 + wv * 64) * 16);
+        dpx_glds16(src, (PRE ? smem_bx + (c & 1) * LAND_BYTES : land) + (k * NT + wv * 64) * 16);
       }
     }
   };
@@ -257,7 +264,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
     if (DPX_BX_DBG & 8) return;
     const char* src = wpk + (size_t)slot_idx * SLOTB + lane * 16;
     char* dst = ring + (slot_idx & 1) * SLOTB;
-    for (int i = wv; i < SLOTB / 1024; i += 8) dpx_glds16(src + i * 1024, dst + i * 1024);
+    for (int i = wv; i < SLOTB / 1024; i += NWV) dpx_glds16(src + i * 1024, dst + i * 1024);
   };
 
   f32x16 acc[MT][2];
@@ -285,10 +292,10 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
     DPX_LDS_BARRIER();                                                // landing buffer complete; everybody is done with the old tile
     }
     if constexpr (PRE) {
-      tile = smem_bx + (c & 1) * BX_LAND_BYTES;                       // landed as the operand planes themselves; the other tile is free:
+      tile = smem_bx + (c & 1) * LAND_BYTES;                       // landed as the operand planes themselves; the other tile is free:
       if (c + 1 < chunks) issue_act(c + 1);                           // every wave has left chunk c - 1 (barrier above)
     }
-    for (int u = tid; u < ((PRE || (DPX_BX_DBG & 2)) ? 0 : BX_UNITS); u += 512) {
+    for (int u = tid; u < ((PRE || (DPX_BX_DBG & 2)) ? 0 : UNITS); u += NT) {
       const float4 lo4 = *(const float4*)(land + u * 32), hi4 = *(const float4*)(land + u * 32 + 16);
       const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
       if constexpr (MODE == 3) {
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) split2_f16_pair(v[2 * j], v[2 * j + 1], hw[j], lw[j]);
         *(uint4*)(tile + u * 16) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        *(uint4*)(tile + BX_PLANE_BYTES + u * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        *(uint4*)(tile + PLANE_BYTES + u * 16) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
         const float m8 = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
                                fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
         f16_max = fmaxf(f16_max, m8);
@@ -314,9 +321,9 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
       }
       *(uint4*)(tile + u * 16) = make_uint4(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7]));
       if constexpr (MODE != 1)
-        *(uint4*)(tile + BX_PLANE_BYTES + u * 16) = make_uint4(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7]));
+        *(uint4*)(tile + PLANE_BYTES + u * 16) = make_uint4(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7]));
       if constexpr (MODE == 6)
-        *(uint4*)(tile + 2 * BX_PLANE_BYTES + u * 16) = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
+        *(uint4*)(tile + 2 * PLANE_BYTES + u * 16) = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
     }
     if (!PRE && !(DPX_BX_DBG & 4)) {
     DPX_LDS_BARRIER();                                                // tile ready, landing buffer free
@@ -337,9 +344,9 @@ __global__ void __launch_bounds__(512, 1) k_conv3x3_bf16(const float* __restrict
         uint4 bf[2][NPL];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const int u = (DPX_BX_DBG & 1) ? (kg * BX_ROWS + 2 * wv + r) * BX_COLS + n : (kg * BX_ROWS + 2 * wv + r + dy) * BX_COLS + n + dx;
+          const int u = (DPX_BX_DBG & 1) ? (kg * ROWS + 2 * wv + r) * BX_COLS + n : (kg * ROWS + 2 * wv + r + dy) * BX_COLS + n + dx;
 #pragma unroll
-          for (int p = 0; p < NPL; ++p) bf[r][p] = *(const uint4*)(tile + p * BX_PLANE_BYTES + u * 16);
+          for (int p = 0; p < NPL; ++p) bf[r][p] = *(const uint4*)(tile + p * PLANE_BYTES + u * 16);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -460,21 +467,33 @@ static void launch_bx_p8_mt(int mt, bool relu, bool pre, bool pso, const float* 
   }
 }
 
-template <int MT, int MODE>
-static void launch_bx(bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s,
-                      const float* mask = nullptr) {
-  const int tx = (W + BX_TW - 1) / BX_TW, ty = (H + BX_TH - 1) / BX_TH;
-  const size_t sh = (size_t)BX_LAND_BYTES + BX_TILE_BYTES + 2 * bx_slot_bytes(MT, bx_planes(MODE));
+template <int MT, int MODE, int TH>
+static void launch_bx_th(bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s,
+                         const float* mask) {
+  constexpr int NPL = MODE == 1 ? 1 : (MODE == 3 ? 2 : 3), UNITS = 2 * (TH + 2) * BX_COLS;
+  const int tx = (W + BX_TW - 1) / BX_TW, ty = (H + TH - 1) / TH;
+  const size_t sh = (size_t)((2 * UNITS + 63) / 64) * 1024 + (size_t)(TH == 16 ? 3 : NPL) * UNITS * 16 + 2 * bx_slot_bytes(MT, bx_planes(MODE));
   static bool attr[2] = {false, false};
   if (!attr[relu]) {
-    if (relu) hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, true, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    else hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, false, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (relu) hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, true, MODE, false, false, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    else hipFuncSetAttribute((const void*)k_conv3x3_bf16<MT, false, MODE, false, false, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr[relu] = true;
   }
   if (relu)
-    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, true, MODE>), dim3(tx * ty, B), dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx, mask);
+    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, true, MODE, false, false, TH>), dim3(tx * ty, B), dim3(TH * 32), sh, s, in, out, wpk, Gin, Gout, H,
+               W, tx, mask);
   else
-    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, false, MODE>), dim3(tx * ty, B), dim3(512), sh, s, in, out, wpk, Gin, Gout, H, W, tx, mask);
+    DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, false, MODE, false, false, TH>), dim3(tx * ty, B), dim3(TH * 32), sh, s, in, out, wpk, Gin, Gout, H,
+               W, tx, mask);
+}
+// 8-row tiles when the 16-row tiling has fewer workgroups than 1.5 x the CUs (knob conv_tile_rows: 8 / 16 force one; 0 = this rule)
+template <int MT, int MODE>
+static void launch_bx(bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s,
+                      const float* mask = nullptr) {
+  const int knob = tune(TUNE_CONV_TILE_ROWS);
+  const long tiles16 = (long)((W + BX_TW - 1) / BX_TW) * ((H + 15) / 16) * B;
+  if (knob == 8 || (knob != 16 && tiles16 < 384)) launch_bx_th<MT, MODE, 8>(relu, in, out, wpk, Gin, Gout, B, H, W, s, mask);
+  else launch_bx_th<MT, MODE, 16>(relu, in, out, wpk, Gin, Gout, B, H, W, s, mask);
 }
 template <int MODE>
 static void launch_bx_mt(int mt, bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s,

@@ -170,6 +170,8 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"ffdnet_presplit", "DPX_FFDNET_PRESPLIT", 0, nullptr},
     {"generic_cols_ct", "DPX_GENERIC_COLS_CT", 0, nullptr},
     {"cg_wave_fft", "DPX_CG_WAVE_FFT", 0, nullptr},
+    {"conv_tile_rows", "DPX_CONV_TILE_ROWS", 0, nullptr},
+    {"unroll_bwd_band", "DPX_UNROLL_BWD_BAND", 0, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

@@ -893,6 +893,11 @@ int rows_r2c_pow2(const float* x, float2* spec, int P, int H, int W, const void*
   return launch_status("rows_r2c_pow2");
 }
 
+int rows_c2r_pow2(const float2* spec, float* y, int P, int H, int W, const void* table, hipStream_t stream) {
+  rows_dispatch(false, W, H, nullptr, (float2*)spec, y, P * H, tw_rows(table), 1.0f, stream);
+  return launch_status("rows_c2r_pow2");
+}
+
 int spectral_apply_pow2(const float* x, float* y, int op, const SpecArgs& A, int B, int C, int H, int W,
                         const void* table, void* ws, hipStream_t stream) {
   const int P = B * C, Ws = W / 2;

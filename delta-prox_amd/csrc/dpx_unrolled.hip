@@ -30,6 +30,15 @@ int finish_iter(const float* part_lam, const float* part_a, const float* part_b,
                 int C, int H, int W, hipStream_t s);
 int iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, int nterms, const float* rho_next, float* x_out, int emit_v,
                    float* rhs_out, int emit_bf16, int B, int C, int H, int W, const void* table, dpx_stream_t stream);   // dpx_iter.hip
+int finish_iter_n(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
+                  int nblk, hipStream_t s);
+int bwd_rows_slots(int C, int H, int W, int max_slots);   // dpx_bwd_rows.hip
+int bwd_rows_fused(const void* spec_in, void* spec_out, const float* x, const float* rhs, const float* rho, const dpx_bwd_term* terms, int nterms,
+                   const float* const* a_in, float* const* a_out, float* g_out, int g_acc, float* part_a, float* part_b, float* part_lam, int hist_bf16,
+                   int B, int C, int H, int W, const void* table, hipStream_t s);
+int cols_solve_pow2(const float2* spec_in, float2* spec_out, const SpecArgs& A, int P, int C, int H, int W, const void* table, hipStream_t stream);
+int rows_r2c_pow2(const float* x, float2* spec, int P, int H, int W, const void* table, hipStream_t stream);
+int rows_c2r_pow2(const float2* spec, float* y, int P, int H, int W, const void* table, hipStream_t stream);   // dpx_fft_pow2.hip
 bool rhs_z_bwd_fused(const float* g, const float* x, const float* rhs, const float* rho, const dpx_bwd_term* terms, int nterms, const float* const* a_in,
                      float* const* a_out, float* gx, float* part_a, float* part_b, float* part_lam, int hist_bf16, int B, int C, int H, int W,
                      hipStream_t s, unsigned* counter, float* glam, float* grho);   // dpx_autodiff.hip
@@ -284,11 +293,89 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
     }
     return DPX_OK;
   };
+  // ---- power-of-two planes: TWO launches per backward iteration (+ the finishing launch), the mirror image of the forward loop --
+  //        z(T-1) | rows | cols(T-1) | [rows^-1 + rhs(T-1) + z(T-2) + rows] | cols(T-2) | ... | cols(0) | rows^-1 | rhs(0)
+  //      g_rhs and g_x stay in the Fourier domain between the stages (k_bwd_rows, dpx_bwd_rows.hip).  The offsets' gradient
+  //      sum_t K g_rhs_t = K sum_t g_rhs_t is formed once at the end from the sum of the g_rhs images (emitted by the row kernel only
+  //      when an offset gradient is wanted).  Knob unroll_bwd_staged: 0 = this loop where it applies, 2 = the image-domain fused
+  //      stage below, 1 = the staged loop.
+  const int slots = (T > 1 && tune(TUNE_UNROLL_BWD_STAGED) == 0) ? bwd_rows_slots(C, H, W, ad_partial_blocks(C, H, W)) : 0;
+  if (slots > 0 && dpx_spectrum_bytes(B * C, H, W) > 0) {
+    const hipStream_t st = (hipStream_t)stream;
+    const int P = B * C;
+    float2* spec_a = (float2*)spectrum_ws;
+    float2* spec_b = (float2*)((char*)spectrum_ws + dpx_spectrum_bytes(P, H, W) / 2);
+    float* abuf[2] = {gu_a, gu_b};
+    int cur = 0;
+    bool want_off = false;
+    for (int k = 0; k < n_off; ++k) want_off = want_off || goff[k];
+    {
+      const int it = T - 1;
+      dpx_bwd_term bt[DPX_MAX_TERMS];
+      for (int i = 0; i < n; ++i)
+        bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, H_v(it, i), cur_gv[i], cur_gu[i], abuf[cur] + i * px};
+      DPX_TRY(zupdate_bwd_partials(gxz, bt, n, part_lam, hb, B, C, H, W, st));
+      DPX_TRY(finish_iter(part_lam, part_a, part_b, glam + (size_t)it * n * B, nullptr, rho_tab + (size_t)it * B, n, B, C, H, W, st));
+    }
+    const float* g = gxz;
+    if (gx) {
+      const float* xs[2] = {gx, gxz};
+      DPX_TRY(dpx_lincomb(gtot, 2, xs, one2, nullptr, B, (long)(px / B), stream));
+      g = gtot;
+    }
+    DPX_TRY(rows_r2c_pow2(g, spec_a, P, H, W, table, st));
+    SpecArgs sa{};
+    sa.dd = (const float2*)dd;
+    sa.eps = eps;
+    sa.eps_num = 0.f;
+    sa.scale = 1.0f / ((float)H * (float)W);
+    for (int it = T - 1; it >= 1; --it) {
+      const float* rho = rho_tab + (size_t)it * B;
+      sa.rho = rho;
+      DPX_TRY(cols_solve_pow2(spec_a, spec_b, sa, P, C, H, W, table, st));
+      dpx_bwd_term bt[DPX_MAX_TERMS];
+      const float* ain[DPX_MAX_TERMS];
+      float* aout[DPX_MAX_TERMS];
+      for (int i = 0; i < n; ++i) {
+        bt[i] = dpx_bwd_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)(it - 1) * B, H_v(it - 1, i), nullptr, nullptr, nullptr};
+        ain[i] = abuf[cur] + i * px;
+        aout[i] = abuf[cur ^ 1] + i * px;
+      }
+      DPX_TRY(bwd_rows_fused(spec_b, spec_a, H_x(it), H_rhs(it), rho, bt, n, ain, aout, want_off ? tmp : nullptr, it != T - 1, part_a, part_b, part_lam, hb,
+                             B, C, H, W, table, st));
+      DPX_TRY(finish_iter_n(part_lam, part_a, part_b, glam + (size_t)(it - 1) * n * B, grho + (size_t)it * B, rho, n, B, slots, st));
+      cur ^= 1;
+    }
+    {
+      const float* rho = rho_tab;
+      sa.rho = rho;
+      DPX_TRY(cols_solve_pow2(spec_a, spec_b, sa, P, C, H, W, table, st));
+      DPX_TRY(rows_c2r_pow2(spec_b, grhs, P, H, W, table, st));
+      if (want_off) {
+        const float* xs[2] = {grhs, tmp};
+        DPX_TRY(dpx_lincomb(tmp, 2, xs, one2, nullptr, B, (long)(px / B), stream));      // sum_t g_rhs_t
+        for (int k = 0; k < n_off; ++k) {
+          if (!goff[k]) continue;
+          if (off_otf[k]) {
+            DPX_TRY(dpx_fft_conv(tmp, goff[k], off_otf[k], 0, B, C, H, W, table, spectrum_ws, stream));
+          } else {
+            const float* one[1] = {tmp};
+            DPX_TRY(dpx_lincomb(goff[k], 1, one, one2, nullptr, B, (long)(px / B), stream));
+          }
+        }
+      }
+      const float* gua[DPX_MAX_TERMS];
+      for (int i = 0; i < n; ++i) gua[i] = abuf[cur] + (size_t)i * px;
+      DPX_TRY(solve_rhs_bwd_partials(grhs, H_x(0), H_rhs(0), rho, linops, n, gv0, gu0, gua, part_a, part_b, hb, B, C, H, W, st));
+      DPX_TRY(finish_iter(part_lam, part_a, part_b, nullptr, grho, rho, n, B, C, H, W, st));
+    }
+    return DPX_OK;
+  }
   // ---- the loop with the rhs stage of iteration `it` and the z stage of iteration `it - 1` as ONE pass (k_rhs_z_bwd4, W % 4 == 0):
   //        z(T-1) | solve(T-1) | [rhs(T-1) + z(T-2)] | solve(T-2) | ... | [rhs(1) + z(0)] | solve(0) | rhs(0)
   //      4 launches per iteration (3 of them the transform) + 1 finishing launch instead of 5 + 1, no g_v / g_u planes in between.
   //      Knob unroll_bwd_staged = 1 keeps the staged loop below (A/B and tests).
-  if (W % 4 == 0 && !tune(TUNE_UNROLL_BWD_STAGED)) {
+  if (W % 4 == 0 && tune(TUNE_UNROLL_BWD_STAGED) != 1) {
     const hipStream_t st = (hipStream_t)stream;
     float* abuf[2] = {gu_a, gu_b};
     int cur = 0;

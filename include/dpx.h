@@ -84,8 +84,11 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        2 = the 32 x 32 slab kernel of larger batches
  *   cg_no_hint           1 = the fused CG does not look at the stop flag early at the iteration   DPX_CG_NO_HINT
  *                        the previous solve exited at (same result, seven more empty launches)
- *   unroll_bwd_staged    1 = dpx_admm_unrolled_backward keeps the rhs stage and the z stage of      DPX_UNROLL_BWD_STAGED
+ *   unroll_bwd_staged    dpx_admm_unrolled_backward: 0 = the two-kernel backward iteration on          DPX_UNROLL_BWD_STAGED
+ *                        power-of-two planes (k_bwd_rows), else the image-domain fused stage; 2 = the
+ *                        image-domain fused stage everywhere; 1 = the rhs stage and the z stage of
  *                        neighbouring iterations as two passes (same gradients up to round-off)
+ *   unroll_bwd_band      rows per band of k_bwd_rows (0 = two lock-step rounds of a workgroup's rows)     DPX_UNROLL_BWD_BAND
  *   unroll_bwd_fold_finish  1 = the fused backward stage's last workgroup finishes the iteration's       DPX_UNROLL_BWD_FOLD_FINISH
  *                        reductions instead of a finishing launch (slower: measured, kept for A/B)
  *   ffdnet_presplit      split-f16 inference (dpx_ffdnet_forward_bf16, mode 3): 1 = activations       DPX_FFDNET_PRESPLIT
@@ -95,6 +98,8 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        register-radix path; 0 = what 60 KB of LDS hold)
  *   cg_wave_fft          fused CG on 320 x 320 / 384 x 384 planes: 2 = the size-generic transform        DPX_CG_WAVE_FFT
  *                        kernels instead of the one-wave register transforms (same result to round-off)
+ *   conv_tile_rows       split-arithmetic 3x3 layers: 8 / 16 = rows of a workgroup's tile (0: 8 when 16-row   DPX_CONV_TILE_ROWS
+ *                        tiles would give fewer than 384 workgroups, else 16); same results
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */

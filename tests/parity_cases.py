@@ -309,17 +309,26 @@ def case_w768_two_kernel(device, H=256, B=2, methods=("admm", "hqs", "admm_vxu")
     assert_close(touched.cpu(), fresh.cpu(), 2e-6, "768-wide: general seed vs fresh-state seed")
 
 
-def case_unrolled_bwd_fused_vs_staged(device, shape=(2, 3, 32, 48), K=4):
-    """the unrolled backward loop with the rhs stage of iteration t and the z stage of iteration t - 1 as one pass (k_rhs_z_bwd4, the
-    default) against the staged loop (knob unroll_bwd_staged): same loss, gradients w.r.t. the rho / lambda schedules, the observation
-    and x0 within fp32 round-off; three term sets (TV, TV + nonneg, nonneg + l1 on x), fp32 and bf16 history"""
+UNROLL_BWD_MODES = (("default", {}),                                            # two-kernel backward iteration on power-of-two planes, else the image-domain fused stage
+                    ("staged", dict(unroll_bwd_staged=1)),
+                    ("image-domain fused stage", dict(unroll_bwd_staged=2)),
+                    ("image-domain fused stage, reductions by its last workgroup", dict(unroll_bwd_staged=2, unroll_bwd_fold_finish=1)))
+
+
+def case_unrolled_bwd_fused_vs_staged(device, shape=(2, 3, 32, 48), K=4, term_sets=("tv", "tv+nn", "nn+l1"), dtypes=("f32", "bf16"), modes=UNROLL_BWD_MODES,
+                                      band=0):
+    """the unrolled backward loop in its fused forms -- on power-of-two planes two kernels per backward iteration (k_bwd_rows: inverse
+    row transform, rhs stage of iteration t + z stage of iteration t - 1, forward row transform; g_rhs / g_x stay in the Fourier domain),
+    elsewhere the two stages as one image-domain pass (k_rhs_z_bwd4) -- against the staged loop (knob unroll_bwd_staged): same loss,
+    gradients w.r.t. the rho / lambda schedules, the observation and x0 within fp32 round-off; three term sets (TV, TV + nonneg,
+    nonneg + l1 on x), fp32 and bf16 history"""
     import synthetic
     from dprox import _backend as be
     gt, b, psf = synthetic.deconv_case(*shape, seed=17, ksize=5, ksigma=1.2)
-    for terms in ("tv", "tv+nn", "nn+l1"):
-        for dtype in ("f32", "bf16"):
+    for terms in term_sets:
+        for dtype in dtypes:
             res = {}
-            for staged in (0, 1, 2):                           # 2: the fused stage with its reductions finished by its last workgroup
+            for name, knobs in modes:
                 x = dp.Variable()
                 bt = T(b, device).clone().requires_grad_(True)
                 regs = []
@@ -335,16 +344,19 @@ def case_unrolled_bwd_fused_vs_staged(device, shape=(2, 3, 32, 48), K=4):
                 solver = dp.specialize(dp.compile(fns, method="admm", device=device), method="unroll", device=device, max_iter=K, dtype=dtype)
                 rhos = torch.linspace(0.4, 0.2, K).requires_grad_(True)
                 lams = [torch.linspace(0.03, 0.01, K).requires_grad_(True) for _ in regs]
-                with be.tuned(unroll_bwd_staged=int(staged == 1), unroll_bwd_fold_finish=int(staged == 2)):
-                    xo = solver.solve(x0=T(b, device), rhos=rhos, lams=dict(zip(regs, lams)))
+                x0 = T(b, device).clone().requires_grad_(True)
+                with be.tuned(unroll_bwd_band=band, **knobs):
+                    xo = solver.solve(x0=x0, rhos=rhos, lams=dict(zip(regs, lams)))
                     loss = ((xo - T(gt, device)) ** 2).mean()
                     loss.backward()
-                res[staged] = [float(loss.detach())] + [t.grad.detach().cpu().double().numpy() for t in [rhos] + lams + [bt]]
-            for other in (0, 2):
-                assert abs(res[other][0] - res[1][0]) <= 1e-7 * abs(res[1][0])
-                for k, (a, c) in enumerate(zip(res[other][1:], res[1][1:])):
+                res[name] = [float(loss.detach())] + [t.grad.detach().cpu().double().numpy() for t in [rhos] + lams + [bt, x0]]
+            for other in res:
+                if other == "staged":
+                    continue
+                assert abs(res[other][0] - res["staged"][0]) <= 1e-7 * abs(res["staged"][0])
+                for k, (a, c) in enumerate(zip(res[other][1:], res["staged"][1:])):
                     e = rel_l2(a, c)
-                    record(f"unrolled backward fused ({other}) vs staged, {terms}, {dtype}, gradient {k}", e, 1e-5)
+                    record(f"unrolled backward, {other} vs staged, {shape[-2]} x {shape[-1]}, {terms}, {dtype}, gradient {k}", e, 1e-5)
                     assert e <= 1e-5, (terms, dtype, k, other, e)
 
 
@@ -794,10 +806,22 @@ def case_ffdnet(device, which=("odd", "even", "batch", "gray")):
                 with be.tuned(ffdnet_presplit=1):
                     pre = col.denoise(T(g["batch_sigma_x"], device), torch.tensor([0.05, 0.15], device=device))
                 assert torch.equal(pre, out), "pre-split activations must not change a bit"
+                if str(device) != "cpu":       # (a small image runs on 8-row tiles by default; the emulator has the 16-row geometry above)
+                    with be.tuned(conv_tile_rows=16):
+                        t16 = col.denoise(T(g["batch_sigma_x"], device), torch.tensor([0.05, 0.15], device=device))
+                    assert torch.equal(t16, out), "the workgroup's tile height must not change a bit"
         if "gray" in which:
             gray = _ffdnet("gray", device)
             out = gray.denoise(T(g["gray_x"], device), torch.tensor(0.1, device=device))
             assert_close(out.cpu(), g["gray_s0.1"], TOL, "gray FFDNet per band")
+            # 8-row and 16-row workgroup tiles of the split-arithmetic layers (launch geometry only): the same bits
+            from dprox import _backend as be
+            outs = []
+            for rows in (8, 16):
+                with be.tuned(conv_tile_rows=rows):
+                    outs.append(gray.denoise(T(g["gray_x"], device), torch.tensor(0.1, device=device)))
+            assert torch.equal(outs[0], outs[1]), "the workgroup's tile height must not change a bit"
+            assert_close(outs[0].cpu(), g["gray_s0.1"], TOL, "gray FFDNet per band, 8-row tiles")
 
 
 def case_admm_pnp(device):

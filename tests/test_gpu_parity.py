@@ -225,6 +225,12 @@ def test_unrolled_backward_fused_stage_matches_the_staged_loop():
     pc.case_unrolled_bwd_fused_vs_staged(DEV)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 256, 256), (3, 1, 512, 512), (1, 2, 256, 1024)])
+def test_unrolled_backward_two_kernel_iteration(shape):
+    pc.case_unrolled_bwd_fused_vs_staged(DEV, shape=shape, K=4)
+    pc.case_unrolled_bwd_fused_vs_staged(DEV, shape=shape, K=3, term_sets=("tv",), dtypes=("f32",), band=7)
+
+
 def test_unrolled_gradients():
     pc.case_unrolled_grads(DEV)
 
