@@ -430,6 +430,33 @@ __global__ void k_ad_finish_iter(const float* __restrict__ part_lam, const float
   }
 }
 
+// the same for ALL iterations of the two-kernel backward loop at once (blockIdx.y = stage k = 0 .. nst - 1, the stage of loop iteration
+// it = T - 1 - k): its partial sums sit at part + k * stride as [n B rows of lambda][B rows a][B rows b], nblk slots per row; it finishes
+// glam[(it - 1) n B + j] and grho[it B + b] with rho_tab[it B + b].  One launch behind the loop instead of one per iteration.
+__global__ void k_ad_finish_all(const float* __restrict__ part, long stride, float* __restrict__ glam, float* __restrict__ grho,
+                                const float* __restrict__ rho_tab, int nB, int B, int nblk, int T) {
+  __shared__ float sh[16];
+  const int j = blockIdx.x, it = T - 1 - (int)blockIdx.y;
+  const float* p = part + (long)blockIdx.y * stride;
+  if (j < nB) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += p[(long)j * nblk + i];
+    acc = ad_block_sum(acc, sh);
+    if (threadIdx.x == 0) glam[(long)(it - 1) * nB + j] = acc;
+  } else {
+    const int b = j - nB;
+    const float* pa = p + (long)nB * nblk;
+    const float* pb = pa + (long)B * nblk;
+    float a = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) a += pa[(long)b * nblk + i];
+    a = ad_block_sum(a, sh);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) c += pb[(long)b * nblk + i];
+    c = ad_block_sum(c, sh);
+    if (threadIdx.x == 0) grho[(long)it * B + b] = a + c / rho_tab[(long)it * B + b];
+  }
+}
+
 // Gradient of the Fourier-domain x-update w.r.t. the OTF of a convolutional data term (end-to-end optics: the PSF of conv_doe is
 // trained through the unrolled solver, reference README.md:93-116, linop/conv.py:81-156).  With X = (R + conj(O) Y + eps) / D,
 // D = |O|^2 + rho sum|G_i|^2 + eps, A = F(g_rhs) = F(g_x) / D, all transforms unnormalised:
@@ -702,6 +729,11 @@ int finish_iter_n(const float* part_lam, const float* part_a, const float* part_
   const int nB = glam ? nterms * B : 0, nR = grho ? B : 0;
   if (nB + nR == 0) return DPX_OK;
   DPX_LAUNCH("k_ad_finish_iter", k_ad_finish_iter, dim3(nB + nR), dim3(256), 0, s, part_lam, part_a, part_b, glam, grho, rho, nB, nblk);
+  return launch_status("dpx_admm_unrolled_backward");
+}
+int finish_all(const float* part, long stride, float* glam, float* grho, const float* rho_tab, int nterms, int B, int nblk, int T, int nst,
+               hipStream_t s) {
+  DPX_LAUNCH("k_ad_finish_all", k_ad_finish_all, dim3(nterms * B + B, nst), dim3(256), 0, s, part, stride, glam, grho, rho_tab, nterms * B, B, nblk, T);
   return launch_status("dpx_admm_unrolled_backward");
 }
 int finish_iter(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,

@@ -44,31 +44,40 @@ struct BwdRowTerms {
   int g_acc;              // ... stored (0) or added to what the plane holds (1: the sum over the iterations, for the offsets' gradient)
 };
 
-__device__ __forceinline__ float2 hist_pair(const float* plane, int bf16, size_t pair) {
-  if (bf16) {
+template <bool BF16> __device__ __forceinline__ float2 hist_pair(const float* plane, size_t pair) {
+  if constexpr (BF16) {
     const unsigned u = ((const unsigned*)plane)[pair];
     return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
   }
   return ((const float2*)plane)[pair];
 }
 
-// one component of the z stage: kg = g_v, a = the dual gradient's other share, v = saved prox output; returns g_d, adds to lt
-__device__ __forceinline__ float bwd_gd(int prox, float kg, float a, float v, float lam, float& lt) {
+// one component of the z stage: kg = g_v, a = the dual gradient's other share, v = saved prox output; returns g_d, adds to lt.
+// KIND: 1 soft threshold, 2 clipping at zero, 0 v / (1 + 2 lam) with sq = 1 / (1 + 2 lam) -- chosen once per term, outside the element loop
+template <int KIND> __device__ __forceinline__ float bwd_gd(float sq, float kg, float a, float v, float& lt) {
   const float gu = a - kg, diff = kg - gu;
   float J, dl;
-  if (prox == DPX_PROX_NORM1) {
+  if constexpr (KIND == 1) {
     J = v != 0.f ? 1.f : 0.f;
     dl = v > 0.f ? -1.f : (v < 0.f ? 1.f : 0.f);
-  } else if (prox == DPX_PROX_NONNEG) {
+  } else if constexpr (KIND == 2) {
     J = v > 0.f ? 1.f : 0.f;
     dl = 0.f;
   } else {
-    const float s = 1.f / (1.f + 2.f * lam);
-    J = s;
-    dl = -2.f * v * s;
+    J = sq;
+    dl = -2.f * v * sq;
   }
   lt = fmaf(diff, dl, lt);
   return fmaf(J, diff, gu);
+}
+template <int KIND, int V> __device__ __forceinline__ float bwd_gd_row(float sq, float rho, float2 (&w)[V], const float2 (&av)[V], const float2 (&vv)[V]) {
+  float lt = 0.f;
+#pragma unroll
+  for (int m = 0; m < V; ++m) {
+    w[m].x = bwd_gd<KIND>(sq, rho * w[m].x, av[m].x, vv[m].x, lt);
+    w[m].y = bwd_gd<KIND>(sq, rho * w[m].y, av[m].y, vv[m].y, lt);
+  }
+  return lt;
 }
 
 __device__ __forceinline__ float bwd_wave_sum(float v) {
@@ -79,7 +88,7 @@ __device__ __forceinline__ float bwd_wave_sum(float v) {
 
 // M = W / 2 pixel pairs per row, T lanes per row, SPB = 256 / T rows in flight per workgroup, NT terms.  Partial sums: one slot per
 // workgroup, [row][nblk] with nblk = C * bands workgroups per image (part_lam rows = term * B + image).
-template <int M, int T, int NT>
+template <int M, int T, int NT, bool HB>
 __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, BwdRowTerms TT,
                                                    const float* __restrict__ rho_b, float* __restrict__ part_a, float* __restrict__ part_b,
                                                    float* __restrict__ part_lam, int B, int C, int H, int R, int bands, int P,
@@ -95,7 +104,6 @@ __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ 
   const int pl = blockIdx.x / bands, band = blockIdx.x - pl * bands;
   const int r0 = band * R, Rb = min(R, H - r0);        // (the last band of a plane may be shorter)
   const int bi = pl / C, ci = pl - bi * C;
-  const int hb = TT.hist_bf16;
   const size_t plane_pairs = (size_t)pl * H * M;
   const float2* sin_main = spec_in + (size_t)pl * H * M;
   const float2* sin_side = spec_in + (size_t)P * H * M + (size_t)pl * H;
@@ -117,8 +125,6 @@ __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ 
   const int pair = lbase | ((T - t) & (T - 1));         // lane holding bin M-k for this lane's bin k
   const int lnext = lbase | ((t + 1) & (T - 1)), lprev = lbase | ((t + T - 1) & (T - 1));
 
-  TwRegs<M, T, false> twr;
-  twr.load(t, twW, 2);
 
   float acc_a = 0.f, acc_b = 0.f, lsum[NT];
 #pragma unroll
@@ -141,7 +147,6 @@ __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ 
     int h = r0 - 1 + q;                                 // circular rows: at most one wrap either way
     h = h < 0 ? h + H : (h >= H ? h - H : h);
     const int qz = q - 1;                               // row this sequence works on (g[qz] from LDS, g[qz + 1] own)
-    const bool z_live = qz >= 0 && qz <= Rb;
     const bool z_own = qz >= 1 && qz <= Rb;             // rows of this band (row qz = 0 is the halo above)
     int hz = r0 - 1 + qz;
     hz = hz < 0 ? hz + H : (hz >= H ? hz - H : hz);
@@ -163,15 +168,20 @@ __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ 
       }
     }
     WaveSync()();
-    fft_reg_tw<M, T, +1, false>(ga, myfft, t, twr, WaveSync());   // ga[m] = (g[2n], g[2n+1]), n = t + m*T
+    fft_reg<M, T, +1>(ga, myfft, t, twW, 2, WaveSync());   // ga[m] = (g[2n], g[2n+1]), n = t + m*T
     if (a_live) {
       float2* gr = gring + (q % RING) * M;
 #pragma unroll
       for (int m = 0; m < V; ++m) gr[t + m * T] = ga[m];
       if (TT.g_out && q >= 1 && q <= Rb) {
         float2* go = (float2*)TT.g_out + plane_pairs + (size_t)h * M;
+        if (TT.g_acc) {
 #pragma unroll
-        for (int m = 0; m < V; ++m) go[t + m * T] = TT.g_acc ? cadd(go[t + m * T], ga[m]) : ga[m];
+          for (int m = 0; m < V; ++m) go[t + m * T] = cadd(go[t + m * T], ga[m]);
+        } else {
+#pragma unroll
+          for (int m = 0; m < V; ++m) go[t + m * T] = ga[m];
+        }
       }
     }
     DPX_LDS_BARRIER();
@@ -205,10 +215,12 @@ __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ 
             lg.x += (float)nH * (2.f * gc[m].x - gp.x - ga[m].x);
             lg.y += (float)nH * (2.f * gc[m].y - gp.y - ga[m].y);
           }
-          const float2 xr = z_own ? hist_pair(TT.x, hb, rowz + t + m * T) : make_float2(0.f, 0.f);
-          const float2 rr = z_own ? hist_pair(TT.rhs, hb, rowz + t + m * T) : make_float2(0.f, 0.f);
-          acc_a = fmaf(lg.y, xr.y, fmaf(lg.x, xr.x, acc_a));                   // (rows outside the band contribute exact zeros)
-          acc_b = fmaf(gc[m].y, rr.y, fmaf(gc[m].x, rr.x, acc_b));
+          // (every row index is a valid row of the plane: the loads are unconditional, rows outside the band are left out by the selects)
+          const float2 xr = hist_pair<HB>(TT.x, rowz + t + m * T);
+          const float2 rr = hist_pair<HB>(TT.rhs, rowz + t + m * T);
+          const float pa = fmaf(lg.y, xr.y, lg.x * xr.x), pb = fmaf(gc[m].y, rr.y, gc[m].x * rr.x);
+          acc_a += z_own ? pa : 0.f;
+          acc_b += z_own ? pb : 0.f;
         }
       }
       __builtin_amdgcn_sched_barrier(0);                  // (keeps the terms' loads from being hoisted above: registers)
@@ -217,28 +229,37 @@ __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ 
       for (int i = 0; i < NT; ++i) {
         const BwdRowTerm tm = TT.t[i];
         const float lam = tm.lam ? tm.lam[bi] * tm.alpha : 0.f;
-        float2 w[V];
-        float lt = 0.f;
+        const float sq = 1.f / (1.f + 2.f * lam);
+        float2 av[V], vv[V], w[V];
 #pragma unroll
         for (int m = 0; m < V; ++m) {
-          float2 kg;
-          if (tm.linop == DPX_LIN_IDENTITY) {
-            kg = gc[m];
-          } else if (tm.linop == DPX_LIN_GRAD_H) {
-            kg = make_float2(ga[m].x - gc[m].x, ga[m].y - gc[m].y);
-          } else {                                      // grad_W: g[w+1] - g[w]; pixel 2n+2 is the neighbour lane's .x
+          av[m] = ((const float2*)tm.a_in)[rowz + t + m * T];
+          vv[m] = hist_pair<HB>(tm.v, rowz + t + m * T);
+        }
+        if (tm.linop == DPX_LIN_IDENTITY) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) w[m] = gc[m];
+        } else if (tm.linop == DPX_LIN_GRAD_H) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) w[m] = make_float2(ga[m].x - gc[m].x, ga[m].y - gc[m].y);
+        } else {                                        // grad_W: g[w+1] - g[w]; pixel 2n+2 is the neighbour lane's .x
+#pragma unroll
+          for (int m = 0; m < V; ++m) {
             const float nx_same = __shfl(gc[m].x, lnext);
             const float nx_wrap = __shfl(gc[(m + 1) % V].x, lbase);
             const float gr = (t == T - 1) ? nx_wrap : nx_same;
-            kg = make_float2(gc[m].y - gc[m].x, gr - gc[m].y);
+            w[m] = make_float2(gc[m].y - gc[m].x, gr - gc[m].y);
           }
-          const float2 av = (z_live && tm.a_in) ? ((const float2*)tm.a_in)[rowz + t + m * T] : make_float2(0.f, 0.f);
-          const float2 vv = z_live ? hist_pair(tm.v, hb, rowz + t + m * T) : make_float2(0.f, 0.f);
-          w[m].x = bwd_gd(tm.prox, rho * kg.x, av.x, vv.x, lam, lt);
-          w[m].y = bwd_gd(tm.prox, rho * kg.y, av.y, vv.y, lam, lt);
-          if (z_own) ((float2*)tm.a_out)[rowz + t + m * T] = w[m];
         }
-        if (z_own) lsum[i] += lt;
+        float lt;
+        if (tm.prox == DPX_PROX_NORM1) lt = bwd_gd_row<1, V>(sq, rho, w, av, vv);
+        else if (tm.prox == DPX_PROX_NONNEG) lt = bwd_gd_row<2, V>(sq, rho, w, av, vv);
+        else lt = bwd_gd_row<0, V>(sq, rho, w, av, vv);
+        lsum[i] += z_own ? lt : 0.f;
+        if (z_own) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) ((float2*)tm.a_out)[rowz + t + m * T] = w[m];
+        }
         if (tm.linop == DPX_LIN_IDENTITY) {
 #pragma unroll
           for (int m = 0; m < V; ++m) acc[m] = cadd(acc[m], w[m]);
@@ -251,11 +272,9 @@ __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ 
             acc[m] = make_float2(acc[m].x + (wl - w[m].x), acc[m].y + (w[m].x - w[m].y));
           }
         } else {                                          // grad_H: g_d goes to the ring, its adjoint is formed in phase C
-          if (z_live) {
-            float2* wr = wring + (qz % RING) * M;
+          float2* wr = wring + ((qz + RING) % RING) * M;  // (rows that are not live land in slots nobody reads before they are rewritten)
 #pragma unroll
-            for (int m = 0; m < V; ++m) wr[t + m * T] = w[m];
-          }
+          for (int m = 0; m < V; ++m) wr[t + m * T] = w[m];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -285,7 +304,7 @@ __global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ 
 #pragma unroll
       for (int m = 0; m < V; ++m) z[m] = acc[m];
       WaveSync()();
-      fft_reg_tw<M, T, -1, false>(z, myfft, t, twr, WaveSync());
+      fft_reg<M, T, -1>(z, myfft, t, twW, 2, WaveSync());
       float2* out = sout_main + (unsigned)hz * SPEC_TILE + tile_off;
 #pragma unroll
       for (int m = 0; m < V; ++m) {
@@ -339,18 +358,24 @@ static size_t bwd_rows_lds(int M, int T) {
   return (size_t)(SPB * S + 2 * (SPB + 2) * M) * sizeof(float2);
 }
 
-template <int M, int T, int NT>
-static void launch_bwd_rows_nt(const float2* sin, float2* sout, const BwdRowTerms& TT, const float* rho, float* part_a, float* part_b, float* part_lam,
+template <int M, int T, int NT, bool HB>
+static void launch_bwd_rows_hb(const float2* sin, float2* sout, const BwdRowTerms& TT, const float* rho, float* part_a, float* part_b, float* part_lam,
                                int B, int C, int H, int R, int bands, const float2* twW, hipStream_t s) {
   const size_t sh = bwd_rows_lds(M, T);
   static bool attr = false;
   if (!attr && sh > 48 * 1024) {
-    hipFuncSetAttribute((const void*)k_bwd_rows<M, T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipFuncSetAttribute((const void*)k_bwd_rows<M, T, NT, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     attr = true;
   }
   const int P = B * C;
-  DPX_LAUNCH("k_bwd_rows", (k_bwd_rows<M, T, NT>), dim3(P * bands), dim3(256), sh, s, sin, sout, TT, rho, part_a, part_b, part_lam, B, C, H, R, bands, P,
+  DPX_LAUNCH("k_bwd_rows", (k_bwd_rows<M, T, NT, HB>), dim3(P * bands), dim3(256), sh, s, sin, sout, TT, rho, part_a, part_b, part_lam, B, C, H, R, bands, P,
              twW);
+}
+template <int M, int T, int NT>
+static void launch_bwd_rows_nt(const float2* sin, float2* sout, const BwdRowTerms& TT, const float* rho, float* part_a, float* part_b, float* part_lam,
+                               int B, int C, int H, int R, int bands, const float2* twW, hipStream_t s) {
+  if (TT.hist_bf16) launch_bwd_rows_hb<M, T, NT, true>(sin, sout, TT, rho, part_a, part_b, part_lam, B, C, H, R, bands, twW, s);
+  else launch_bwd_rows_hb<M, T, NT, false>(sin, sout, TT, rho, part_a, part_b, part_lam, B, C, H, R, bands, twW, s);
 }
 template <int M, int T>
 static void launch_bwd_rows(const float2* sin, float2* sout, const BwdRowTerms& TT, const float* rho, float* part_a, float* part_b, float* part_lam,
@@ -393,6 +418,7 @@ int bwd_rows_fused(const void* spec_in, void* spec_out, const float* x, const fl
   TT.g_acc = g_acc;
   for (int i = 0; i < DPX_MAX_TERMS; ++i) TT.t[i] = BwdRowTerm{DPX_LIN_IDENTITY, DPX_PROX_NONNEG, 0.f, nullptr, nullptr, nullptr, nullptr};
   for (int i = 0; i < nterms; ++i) TT.t[i] = BwdRowTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].v, a_in[i], a_out[i]};
+  for (int i = 0; i < nterms; ++i) DPX_REQUIRE(a_in[i] && a_out[i] && terms[i].v, "dpx_admm_unrolled_backward: term %d lacks a plane of the row kernel", i);
   const int R = bwd_rows_band(H, W), bands = (H + R - 1) / R;
   const float2* tw = tw_rows(table);
   switch (W) {

@@ -32,6 +32,8 @@ int iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* terms, i
                    float* rhs_out, int emit_bf16, int B, int C, int H, int W, const void* table, dpx_stream_t stream);   // dpx_iter.hip
 int finish_iter_n(const float* part_lam, const float* part_a, const float* part_b, float* glam, float* grho, const float* rho, int nterms, int B,
                   int nblk, hipStream_t s);
+int finish_all(const float* part, long stride, float* glam, float* grho, const float* rho_tab, int nterms, int B, int nblk, int T, int nst,
+               hipStream_t s);
 int bwd_rows_slots(int C, int H, int W, int max_slots);   // dpx_bwd_rows.hip
 int bwd_rows_fused(const void* spec_in, void* spec_out, const float* x, const float* rhs, const float* rho, const dpx_bwd_term* terms, int nterms,
                    const float* const* a_in, float* const* a_out, float* g_out, int g_acc, float* part_a, float* part_b, float* part_lam, int hist_bf16,
@@ -329,9 +331,18 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
     sa.eps = eps;
     sa.eps_num = 0.f;
     sa.scale = 1.0f / ((float)H * (float)W);
+    // the iterations' partial sums side by side in the planes only the staged loop uses, finished by ONE launch behind the loop (a
+    // finishing launch per iteration is 9 of the loop's 27 launches); if they do not fit: one finishing launch per iteration
+    const long pstride = (long)(n + 2) * B * slots;
+    const bool all_at_once = (size_t)(T - 1) * pstride <= (size_t)2 * n * px;
     for (int it = T - 1; it >= 1; --it) {
       const float* rho = rho_tab + (size_t)it * B;
       sa.rho = rho;
+      if (all_at_once) {
+        part_lam = set[0] + (size_t)(T - 1 - it) * pstride;
+        part_a = part_lam + (size_t)n * B * slots;
+        part_b = part_a + (size_t)B * slots;
+      }
       DPX_TRY(cols_solve_pow2(spec_a, spec_b, sa, P, C, H, W, table, st));
       dpx_bwd_term bt[DPX_MAX_TERMS];
       const float* ain[DPX_MAX_TERMS];
@@ -343,8 +354,14 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
       }
       DPX_TRY(bwd_rows_fused(spec_b, spec_a, H_x(it), H_rhs(it), rho, bt, n, ain, aout, want_off ? tmp : nullptr, it != T - 1, part_a, part_b, part_lam, hb,
                              B, C, H, W, table, st));
-      DPX_TRY(finish_iter_n(part_lam, part_a, part_b, glam + (size_t)(it - 1) * n * B, grho + (size_t)it * B, rho, n, B, slots, st));
+      if (!all_at_once) DPX_TRY(finish_iter_n(part_lam, part_a, part_b, glam + (size_t)(it - 1) * n * B, grho + (size_t)it * B, rho, n, B, slots, st));
       cur ^= 1;
+    }
+    if (all_at_once) {
+      DPX_TRY(finish_all(set[0], pstride, glam, grho, rho_tab, n, B, slots, T, T - 1, st));
+      part_lam = rho_a + ((2 * B + 63) / 64) * 64;          // (the last stage below: the workspace's own partial-sum rows again)
+      part_a = part_lam + (size_t)DPX_MAX_TERMS * B * ad_partial_blocks(C, H, W);
+      part_b = part_a + (size_t)B * ad_partial_blocks(C, H, W);
     }
     {
       const float* rho = rho_tab;
