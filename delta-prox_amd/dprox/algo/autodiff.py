@@ -172,6 +172,23 @@ class DiffPlan:
         self.doe = list(doe)
 
 
+class _SchedRows(torch.autograd.Function):
+    """a [T'] schedule (T' >= T) as a contiguous [T, B] table: one copy kernel forward, one reduction backward (the chain of slice /
+    reshape / expand / contiguous nodes it replaces runs three kernels per table in the backward pass of a training step)"""
+
+    @staticmethod
+    def forward(ctx, v, T, B):
+        ctx.n = int(v.shape[0])
+        return v[:T].reshape(T, 1).expand(T, B).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g.sum(dim=1)
+        if ctx.n != gs.shape[0]:
+            gs = torch.cat([gs, gs.new_zeros(ctx.n - gs.shape[0])])
+        return gs, None, None
+
+
 def _sched_table(vals, T, B, dev):
     """0-d / [T] / [B,T] schedule -> [T,B] device tensor, differentiably, in ONE set of tiny torch ops per solve (row `it`
     is then a contiguous view: no per-iteration kernels)"""
@@ -180,7 +197,7 @@ def _sched_table(vals, T, B, dev):
     if v.ndim == 0:
         return v.reshape(1, 1).expand(T, B).contiguous()
     if v.ndim == 1:
-        return v[:T].reshape(T, 1).expand(T, B).contiguous()
+        return _SchedRows.apply(v, T, B) if v.requires_grad else v[:T].reshape(T, 1).expand(T, B).contiguous()
     return v[:, :T].t().expand(T, B).contiguous()
 
 

@@ -279,7 +279,7 @@ class FusedSplitCG:
             return state
         rho_tab = schedule_table(rhos, T, B, dev)
         lam_tab = []
-        for fn in psi:
+        for fn in (() if want_grad else psi):
             lt = schedule_table(lams[fn], T, B, dev)
             lam_tab.append(_sigma_table(fn, lt) if isinstance(fn, deep_prior) else lt)
         v = [t.contiguous() for t in v]
@@ -455,12 +455,13 @@ class FusedADMM:
             materialize_state(s, state)
             return state
 
-        rho_tab = schedule_table(rhos, T, B, dev)
-        _tr("rho table")
         raw_offs = [self._offset_autograd(fn, x0) for fn in s.omega_fns]
         trained_psfs = [cv.psf for cv in map(_omega_conv, s.omega_fns)
                         if isinstance(cv, conv_doe) and cv.circular and isinstance(cv.psf, torch.Tensor) and cv.psf.requires_grad]
         want_grad = dual and not vxu and autodiff.needs_grad(x0, rhos, lams, raw_offs, list(v) + list(u) + trained_psfs)
+        # (the differentiable path builds its own schedule tables as autograd nodes, autodiff.run: none are made here for it)
+        rho_tab = None if want_grad else schedule_table(rhos, T, B, dev)
+        _tr("rho table")
         # The two-kernel iteration starts from the row-transformed right-hand side rho_0 sum K_i^T (v_i - u_i): that pass needs
         # nothing but the state, so it is launched FIRST and the rest of the host-side preparation (schedule tables, data spectrum,
         # denominators, workspaces: ~0.1 ms) runs while the GPU is already busy instead of in front of it.
