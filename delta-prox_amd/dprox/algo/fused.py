@@ -279,7 +279,7 @@ class FusedSplitCG:
             return state
         rho_tab = schedule_table(rhos, T, B, dev)
         lam_tab = []
-        for fn in (() if want_grad else psi):
+        for fn in psi:
             lt = schedule_table(lams[fn], T, B, dev)
             lam_tab.append(_sigma_table(fn, lt) if isinstance(fn, deep_prior) else lt)
         v = [t.contiguous() for t in v]
@@ -498,7 +498,7 @@ class FusedADMM:
             materialize_state(s, state)
             s._fresh, fresh = None, False
         lam_tab = []
-        for fn in psi:
+        for fn in (() if want_grad else psi):
             lt = schedule_table(lams[fn], T, B, dev)
             lam_tab.append(_sigma_table(fn, lt) if isinstance(fn, deep_prior) else lt)     # deep priors: the table holds sigma
         # data spectrum F(sum_Omega K^T b): fp64 transform, kept in the Fourier domain, recomputed only when an
