@@ -752,6 +752,90 @@ extern "C" int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigm
   return launch_status("dpx_ffdnet_backward_bf16");
 }
 
+// ---- the same backward pass WITH the weight / bias gradients (deep_prior(trainable=True) on the split kernels) -------------------------
+// Forward and backward-data stay on the split kernels (C8 planes); the weight-gradient GEMM is the f32-input kernel of dpx_ffdnet.hip
+// (k_conv3x3_wgrad: fp32 products, fixed-order reduction), which reads planar [B][C][H][W] operands: the two operands of a layer --
+// the gradient w.r.t. its pre-activation output and its saved input -- are copied out of their C8 planes first (k_bx_c8_to_planar: two
+// plane passes per operand; 8 % of the weight-gradient kernel's own time at 2 x 96 x 384 x 384).
+namespace dpx {
+size_t ffd_wgrad_ws_floats(int nc, int in_nc);
+void ffd_launch_wgrad(const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Cin_a, int B, int H2, int W2, float* ws,
+                      hipStream_t s);   // dpx_ffdnet.hip
+}
+// C8 [B][G][H][W][8] -> planar [B][C][H][W] (C <= 8 G): a thread moves the 8 channels of one pixel
+__global__ void k_bx_c8_to_planar(const float* __restrict__ src, float* __restrict__ dst, int B, int G, int C, long hw) {
+  const long total = (long)B * G * hw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % hw;
+    const int g = (int)((i / hw) % G), b = (int)(i / (hw * G));
+    const float4 lo = *(const float4*)(src + i * 8), hi = *(const float4*)(src + i * 8 + 4);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (g * 8 + j < C) dst[((long)b * C + g * 8 + j) * hw + p] = v[j];
+  }
+}
+
+extern "C" size_t dpx_ffdnet_bf16_bwd_w_ws_bytes(int B, int in_nc, int nc, int H, int W) {
+  const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
+  const size_t gmax = (size_t)8 * groups16(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1);
+  return dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W) + (2 * px * gmax + ffd_wgrad_ws_floats(nc, in_nc)) * sizeof(float);
+}
+
+// gw[l] [cout_l][cin_l][9], gb[l] [cout_l] (entries may be NULL: that layer's gradients are not wanted); gx, gsigma may be NULL
+extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsigma, float* const* gw, float* const* gb, const void* packed_T,
+                                          const void* acts, int in_nc, int nc, int nb, int B, int H, int W, void* ws, dpx_stream_t stream) {
+  DPX_REQUIRE(gy && packed_T && acts && ws && gw && gb, "dpx_ffdnet_backward_bf16_w: null pointer");
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nb <= 64 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96,
+              "dpx_ffdnet_backward_bf16_w: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
+  hipStream_t s = (hipStream_t)stream;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const size_t px = (size_t)B * H2 * W2;
+  const long hw = (long)H2 * W2;
+  const int G0 = groups16(4 * in_nc + 1), Gc = groups16(nc), GL = groups16(4 * in_nc);
+  const float* a0 = (const float*)acts;
+  const float* hidden = a0 + px * 8 * G0;
+  float* g_last = (float*)ws;
+  float* gA = g_last + px * 8 * GL;
+  float* gB = gA + px * 8 * Gc;
+  float* g_a0 = gB + px * 8 * Gc;
+  float* planar_g = (float*)((char*)ws + dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W));
+  const size_t gmax = (size_t)8 * groups16(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1);
+  float* planar_a = planar_g + px * gmax;
+  float* wg_ws = planar_a + px * gmax;
+  DPX_LAUNCH("k_bx_pack_gout", k_bx_pack_gout, dim3(grid_for((long)(px * 8 * GL), 256, 8192)), dim3(256), 0, s, gy, g_last, B, in_nc, H, W, H2, W2, GL);
+  size_t off[64];
+  size_t o = 0;
+  for (int l = 0; l < nb; ++l) { off[l] = o; o += bx_layer_bytes(bx_cout(l, in_nc, nc, nb), bx_cin(l, in_nc, nc), 3); }
+  const float* cur = g_last;
+  int gin = GL;
+  const bool need_data = gx || gsigma;
+  for (int l = nb - 1; l >= 0; --l) {
+    const int cout_f = bx_cout(l, in_nc, nc, nb), cin_f = bx_cin(l, in_nc, nc);     // the FORWARD layer's channel counts
+    if (gw[l]) {
+      DPX_REQUIRE(gb[l], "dpx_ffdnet_backward_bf16_w: weight and bias gradients of layer %d come together", l);
+      // `cur`: the gradient w.r.t. forward layer l's pre-activation output (the ReLU mask was applied by backward layer l + 1's epilogue)
+      const float* a_l = (l == 0) ? a0 : hidden + (size_t)(l - 1) * px * 8 * Gc;
+      const int ga = (l == 0) ? G0 : Gc;
+      DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * gin * hw, 256, 8192)), dim3(256), 0, s, cur, planar_g, B, gin, cout_f, hw);
+      DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * ga * hw, 256, 8192)), dim3(256), 0, s, a_l, planar_a, B, ga, 8 * ga, hw);
+      ffd_launch_wgrad(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
+    }
+    if (l == 0 && !need_data) break;
+    float* dst = (l == 0) ? g_a0 : (((nb - 1 - l) & 1) ? gB : gA);
+    const int gout = (l == 0) ? G0 : Gc;
+    const float* mask = (l >= 1) ? hidden + (size_t)(l - 1) * px * 8 * Gc : nullptr;
+    launch_bx_mt<6>((cin_f + 31) / 32, false, cur, dst, (const char*)packed_T + off[l], gin, gout, B, H2, W2, s, mask);
+    cur = dst;
+    gin = gout;
+  }
+  if (gx)
+    DPX_LAUNCH("k_bx_unpack_gin", k_bx_unpack_gin, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, (const float*)g_a0, gx, B, in_nc, H,
+               W, H2, W2, G0);
+  if (gsigma) DPX_LAUNCH("k_bx_sigma_grad", k_bx_sigma_grad, dim3(B), dim3(256), 0, s, (const float*)g_a0, gsigma, in_nc, H2, W2, G0);
+  return launch_status("dpx_ffdnet_backward_bf16_w");
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // One plug-and-play ADMM iteration (config 3) without returning to the host language: algo/admm.py:49-59 with a deep_prior
 // z-update (proxfn/pnp/prior.py:73-86) --

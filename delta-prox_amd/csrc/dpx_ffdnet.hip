@@ -561,20 +561,38 @@ __global__ void __launch_bounds__(MT * 128) k_conv3x3_wgrad(const float* __restr
 }
 
 // gw[co0 + co][ci][tap] (co < CoN) = sum over the NG partial slices, in a fixed order
-__global__ void k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ gw, float* __restrict__ gb,
-                               int NG, int CoN, int co0, int Cin, int CoP, int CiP, int ntap) {
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ gw,
+                                                      float* __restrict__ gb, int NG, int CoN, int co0, int Cin, int CoP, int CiP, int ntap) {
+  __shared__ float shb[256];
   const long nw = (long)CoN * Cin * ntap;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + CoN; i += (long)gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    if (i < nw) {
-      const int t = (int)(i % ntap), ci = (int)((i / ntap) % Cin), co = (int)(i / ((long)ntap * Cin));
-      for (int g = 0; g < NG; ++g) acc += part[(((size_t)g * CoP + co) * CiP + ci) * ntap + t];
-      if (gw) gw[(long)co0 * Cin * ntap + i] = acc;
-    } else if (gb) {
-      const int co = (int)(i - nw);
-      for (int g = 0; g < NG; ++g) acc += part_b[((size_t)g * CoP + co) * 2] + part_b[((size_t)g * CoP + co) * 2 + 1];
-      gb[co0 + co] = acc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % ntap), ci = (int)((i / ntap) % Cin), co = (int)(i / ((long)ntap * Cin));
+    // eight interleaved running sums (slice g goes to sum g % 8), joined in a fixed order: the same bits run to run, eight loads in flight
+    const float* p0 = part + ((size_t)co * CiP + ci) * ntap + t;
+    const size_t gs = (size_t)CoP * CiP * ntap;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int g = 0;
+    for (; g + 8 <= NG; g += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a8[j] += p0[(size_t)(g + j) * gs];
     }
+    for (int j = 0; g < NG; ++g, ++j) a8[j] += p0[(size_t)g * gs];
+    if (gw) gw[(long)co0 * Cin * ntap + i] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  }
+  // the bias gradients: one workgroup per output channel, a thread per slice, a fixed tree over the threads (one thread walking the NG
+  // slices of a channel was the launch's critical path: 168 dependent round trips = 63 us behind a 15-us weight pass)
+  if (!gb) return;
+  for (int co = blockIdx.x; co < CoN; co += gridDim.x) {
+    float acc = 0.f;
+    for (int g = threadIdx.x; g < NG; g += 256) acc += part_b[((size_t)g * CoP + co) * 2] + part_b[((size_t)g * CoP + co) * 2 + 1];
+    __syncthreads();
+    shb[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) shb[threadIdx.x] += shb[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) gb[co0 + co] = shb[0];
   }
 }
 
@@ -625,6 +643,15 @@ static void launch_wgrad(const float* G, const float* A, float* gw, float* gb, i
                (const float*)part_b, gw, gb, NG, CoN, co0, Cin_w, CoP, CiP, ntap);
   }
 }
+
+// (for the split-arithmetic stack's training variant, dpx_conv_bf16.hip: the same weight-gradient kernels on planar copies of its C8 planes)
+namespace dpx {
+size_t ffd_wgrad_ws_floats(int nc, int in_nc) { return wgrad_ws_floats(nc, in_nc); }
+void ffd_launch_wgrad(const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Cin_a, int B, int H2, int W2, float* ws,
+                      hipStream_t s) {
+  launch_wgrad(G, A, gw, gb, Cout, Cin_w, Cin_a, B, H2, W2, ws, s);
+}
+}  // namespace dpx
 
 // ---- training variants: forward that keeps every layer's output, backward-data through the whole stack ----------------
 extern "C" size_t dpx_ffdnet_acts_bytes(int B, int in_nc, int nc, int nb, int H, int W) {

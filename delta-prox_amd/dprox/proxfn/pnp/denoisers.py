@@ -130,6 +130,9 @@ class FFDNet(RefKeyed):
         #               The default wherever the layer widths are multiples of 16;
         #   "bf16"   -- plain bf16 operands, fp32 accumulation (bf16 training / inference mode, ~3e-3 relative).
         self.compute_mode = os.environ.get("DPX_FFDNET_MODE", "f16x2" if nc % 16 == 0 else "f32")
+        # trainable weights: False = forward / backward-data on the split kernels as with frozen weights (weight gradients: the f32-input GEMM
+        # on planar copies of their planes); True = everything on the f32-input kernels (the round-3 path, A/B)
+        self.train_f32 = bool(os.environ.get("DPX_FFDNET_TRAIN_F32"))
         # what happens when a "f16x2" forward meets an operand outside the binary16 range (a checkpoint with a large dynamic range):
         # "bf16x3" -- the enclosing solve() / denoise() is re-run on the split-bf16 arithmetic and the network keeps that mode
         # (a RuntimeWarning says so); "raise" -- be.F16RangeError
@@ -238,10 +241,14 @@ class FFDNet(RefKeyed):
             sig_t = sig_t.to(device=x.device, dtype=torch.float32).reshape(-1)
             sig_t = sig_t.expand(B).contiguous() if sig_t.numel() == 1 else sig_t.contiguous()
             params = (self.weights + self.biases) if train_w else []
-            if not train_w and self.compute_mode in ("bf16x3", "f16x2") and self.nc % 16 == 0:
-                # frozen weights (unrolled plug-and-play training of schedules / upstream parameters): forward and backward-data on the
-                # split kernels -- fp32-accurate, 2 - 3x the f32-input matrix instruction; weight gradients stay on the f32-input path
-                return _FFDNetSplitFn.apply(self, x, sig_t)
+            if self.compute_mode in ("bf16x3", "f16x2") and self.nc % 16 == 0 and not (train_w and self.train_f32):
+                # forward and backward-data on the split kernels -- fp32-accurate, 2 - 3x the f32-input matrix instruction -- with frozen
+                # weights (unrolled plug-and-play training of schedules / upstream parameters) and with trainable ones (the weight-gradient
+                # GEMM is the f32-input kernel on planar copies of the split path's planes; `train_f32`: everything on the f32-input
+                # kernels, the round-3 path, for A/B)
+                self.last_train_path = "split"
+                return _FFDNetSplitFn.apply(self, x, sig_t, *params)
+            self.last_train_path = "f32"
             return _FFDNetFn.apply(self, x, sig_t, *params)
         sig = ops.as_batch_vec(sigma, B, x.device)
         L = be.lib()
@@ -267,7 +274,7 @@ class _FFDNetSplitFn(torch.autograd.Function):
     loss sit far below the binary16 range); a "f16x2" forward that meets an operand outside that range is caught by the range trap."""
 
     @staticmethod
-    def forward(ctx, net, x, sig):
+    def forward(ctx, net, x, sig, *params):
         B, C, H, W = x.shape
         L = be.lib()
         x = x.contiguous()
@@ -291,12 +298,23 @@ class _FFDNetSplitFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(gy) if ctx.needs_input_grad[1] else None
         gs = torch.empty(B, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[2] else None
+        nb = net.nb
+        need = ctx.needs_input_grad[3:]
+        if any(need):                                      # weights / biases were passed and are trained: fill their gradients
+            gws = [torch.empty_like(net.weights[i], dtype=torch.float32) if (need[i] or need[nb + i]) else None for i in range(nb)]
+            gbs = [torch.empty_like(net.biases[i], dtype=torch.float32) if gws[i] is not None else None for i in range(nb)]
+            pw = (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in gws])
+            pb = (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in gbs])
+            ws = ops.workspace("ffdnet_bf16_bwd_w", L.query("dpx_ffdnet_bf16_bwd_w_ws_bytes", B, net.in_nc, net.nc, H, W), gy.device)
+            L.call("dpx_ffdnet_backward_bf16_w", be.ptr(gy), be.ptr(gx), be.ptr(gs), pw, pb, be.ptr(net.packed_T_bf16()), be.ptr(acts), net.in_nc,
+                   net.nc, nb, B, H, W, be.ptr(ws), be.stream())
+            return (None, gx, gs, *gws, *gbs)
         if gx is None and gs is None:
-            return None, None, None
+            return (None, None, None) + (None,) * len(need)
         ws = ops.workspace("ffdnet_bf16_bwd", L.query("dpx_ffdnet_bf16_bwd_ws_bytes", B, net.in_nc, net.nc, H, W), gy.device)
         L.call("dpx_ffdnet_backward_bf16", be.ptr(gy), be.ptr(gx), be.ptr(gs), be.ptr(net.packed_T_bf16()), be.ptr(acts), net.in_nc, net.nc, net.nb,
                B, H, W, be.ptr(ws), be.stream())
-        return None, gx, gs
+        return (None, gx, gs) + (None,) * len(need)
 
 
 class _FFDNetFn(torch.autograd.Function):

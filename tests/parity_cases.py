@@ -1145,6 +1145,23 @@ def case_ffdnet_split_backward(device, tiny=False):
             assert_close(res[mode][0], res["f32"][0], TOL, f"split backward {shape} {mode}: forward")
             _assert_grad_close(res[mode][1], res["f32"][1], f"split backward {shape} {mode}: d/dx", tol=1e-5)
             _assert_grad_close(res[mode][2], res["f32"][2], f"split backward {shape} {mode}: d/dsigma", tol=1e-5)
+        # trainable weights: forward / backward-data on the split kernels + the f32-input weight-gradient GEMM on planar copies of their
+        # C8 planes (dpx_ffdnet_backward_bf16_w) against everything on the f32-input kernels (dpx_ffdnet_backward): every layer's dW, db
+        col.model.compute_mode = "f16x2"
+        col.requires_grad_(True)
+        wres = {}
+        for f32 in (True, False):
+            col.model.train_f32 = f32
+            col.zero_grad()
+            x = T(x0, device).requires_grad_(True)
+            y = col.denoise(x, T(s0, device))
+            assert ("Split" in y.grad_fn.name()) == (not f32)
+            (y * T(w0, device)).sum().backward()
+            wres[f32] = [p.grad.cpu().numpy() for p in col.model.weights + col.model.biases] + [x.grad.cpu().numpy()]
+        for k, (a_, b_) in enumerate(zip(wres[False], wres[True])):
+            _assert_grad_close(a_, b_, f"split training path {shape}: gradient {k} (weights, biases, d/dx)", tol=1e-5)
+        col.requires_grad_(False)
+        col.model.train_f32 = False
     col.model.compute_mode = "f16x2"
 
 
@@ -1155,10 +1172,17 @@ def case_ffdnet_weight_grads(device):
     col = _ffdnet("color", device)
     col.train()
     x = T(g["wg_x"], device)
-    (col.denoise(x, torch.tensor([0.05, 0.2], device=device)) * T(g["wg_w"], device)).sum().backward()
-    for li in (0, 5, 11):
-        _assert_grad_close(col.model.weights[li].grad.cpu(), g[f"wg_dw{li}"], f"dW layer {li}", tol=1e-4, flip_frac=0.02)
-        _assert_grad_close(col.model.biases[li].grad.cpu(), g[f"wg_db{li}"], f"db layer {li}", tol=1e-4, flip_frac=0.05)
+    # both arithmetic paths of a trainable stack: forward / backward-data on the split kernels + the f32-input weight-gradient GEMM on
+    # planar copies of their planes (the default), and everything on the f32-input kernels (train_f32)
+    for f32 in (True, False):
+        col.model.train_f32 = f32
+        col.zero_grad()
+        (col.denoise(x, torch.tensor([0.05, 0.2], device=device)) * T(g["wg_w"], device)).sum().backward()
+        tag = "f32-input kernels" if f32 else "split kernels"
+        for li in (0, 5, 11):
+            _assert_grad_close(col.model.weights[li].grad.cpu(), g[f"wg_dw{li}"], f"dW layer {li} ({tag})", tol=1e-4, flip_frac=0.02)
+            _assert_grad_close(col.model.biases[li].grad.cpu(), g[f"wg_db{li}"], f"db layer {li} ({tag})", tol=1e-4, flip_frac=0.05)
+    assert getattr(col.model, "compute_mode", "") not in ("bf16x3", "f16x2") or col.model.last_train_path == "split"
     # run-to-run determinism of the two-stage reduction
     g1 = col.model.weights[5].grad.clone()
     col.zero_grad()
