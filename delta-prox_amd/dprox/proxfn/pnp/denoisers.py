@@ -268,7 +268,8 @@ class FFDNet(RefKeyed):
 
 
 class _FFDNetSplitFn(torch.autograd.Function):
-    """FFDNet with frozen weights under autograd, on the split kernels: the forward pass keeps every layer's output (C8 layout),
+    """FFDNet under autograd on the split kernels (frozen weights, or -- parameters passed -- trainable ones: the weight / bias
+    gradients then come from dpx_ffdnet_backward_bf16_w): the forward pass keeps every layer's output (C8 layout),
     the backward pass is the same convolution kernel on flipped / transposed split weights with the ReLU masks in its epilogue
     (dpx_ffdnet_forward_bf16_save / dpx_ffdnet_backward_bf16).  The backward pass always runs split-bf16 (gradients of a mean
     loss sit far below the binary16 range); a "f16x2" forward that meets an operand outside that range is caught by the range trap."""
