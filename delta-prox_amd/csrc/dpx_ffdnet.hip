@@ -651,6 +651,11 @@ void ffd_launch_wgrad(const float* G, const float* A, float* gw, float* gb, int 
                       hipStream_t s) {
   launch_wgrad(G, A, gw, gb, Cout, Cin_w, Cin_a, B, H2, W2, ws, s);
 }
+void ffd_launch_wgrad_reduce(const float* part, const float* part_b, float* gw, float* gb, int NG, int CoN, int co0, int Cin, int CoP, int CiP,
+                             hipStream_t s) {
+  DPX_LAUNCH("k_wgrad_reduce", k_wgrad_reduce, dim3(grid_for((long)CoN * Cin * 9 + CoN, 256, 1024)), dim3(256), 0, s, part, part_b, gw, gb, NG, CoN, co0,
+             Cin, CoP, CiP, 9);
+}
 }  // namespace dpx
 
 // ---- training variants: forward that keeps every layer's output, backward-data through the whole stack ----------------

@@ -100,6 +100,8 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        kernels instead of the one-wave register transforms (same result to round-off)
  *   conv_tile_rows       split-arithmetic 3x3 layers: 8 / 16 = rows of a workgroup's tile (0: 8 when 16-row   DPX_CONV_TILE_ROWS
  *                        tiles would give fewer than 384 workgroups, else 16); same results
+ *   wgrad_f32            dpx_ffdnet_backward_bf16_w: 1 = the weight-gradient GEMM on the f32-input matrix        DPX_WGRAD_F32
+ *                        instruction (k_conv3x3_wgrad) instead of the split-bf16 one (k_wgrad_bf16x3)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */
