@@ -1120,7 +1120,7 @@ def case_ffdnet_split_backward(device, tiny=False):
     import synthetic
     from dprox.proxfn.pnp.denoisers import FFDNet, FFDNetColorDenoiser
     rng = np.random.RandomState(616)
-    shapes = ((2, 3, 17, 21),) if tiny else ((2, 3, 33, 47), (1, 3, 32, 40))
+    shapes = ((2, 3, 17, 21),) if tiny else ((2, 3, 33, 47), (1, 3, 32, 40), (1, 3, 74, 106))     # (37 x 53 after the unshuffle: partial and odd strips of the weight-gradient GEMM)
     for shape in shapes:
         if tiny:
             col = FFDNetColorDenoiser()
@@ -1150,16 +1150,21 @@ def case_ffdnet_split_backward(device, tiny=False):
         col.model.compute_mode = "f16x2"
         col.requires_grad_(True)
         wres = {}
-        for f32 in (True, False):
-            col.model.train_f32 = f32
+        from dprox import _backend as be
+        # (True: everything on the f32-input kernels; False: split kernels + the split-bf16 weight-gradient GEMM k_wgrad_bf16x3;
+        #  "gemm_f32": split kernels + the f32-input weight-gradient GEMM on the same planar copies, knob wgrad_f32)
+        for f32 in (True, False, "gemm_f32"):
+            col.model.train_f32 = f32 is True
             col.zero_grad()
             x = T(x0, device).requires_grad_(True)
-            y = col.denoise(x, T(s0, device))
-            assert ("Split" in y.grad_fn.name()) == (not f32)
-            (y * T(w0, device)).sum().backward()
+            with be.tuned(wgrad_f32=int(f32 == "gemm_f32")):
+                y = col.denoise(x, T(s0, device))
+                assert ("Split" in y.grad_fn.name()) == (f32 is not True)
+                (y * T(w0, device)).sum().backward()
             wres[f32] = [p.grad.cpu().numpy() for p in col.model.weights + col.model.biases] + [x.grad.cpu().numpy()]
-        for k, (a_, b_) in enumerate(zip(wres[False], wres[True])):
-            _assert_grad_close(a_, b_, f"split training path {shape}: gradient {k} (weights, biases, d/dx)", tol=1e-5)
+        for other in (False, "gemm_f32"):
+            for k, (a_, b_) in enumerate(zip(wres[other], wres[True])):
+                _assert_grad_close(a_, b_, f"split training path ({other}) {shape}: gradient {k} (weights, biases, d/dx)", tol=1e-5)
         col.requires_grad_(False)
         col.model.train_f32 = False
     col.model.compute_mode = "f16x2"
