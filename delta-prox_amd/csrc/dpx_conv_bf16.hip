@@ -486,13 +486,12 @@ static void launch_bx_th(bool relu, const float* in, float* out, const char* wpk
     DPX_LAUNCH("k_conv3x3_bf16", (k_conv3x3_bf16<MT, false, MODE, false, false, TH>), dim3(tx * ty, B), dim3(TH * 32), sh, s, in, out, wpk, Gin, Gout, H,
                W, tx, mask);
 }
-// 8-row tiles when the 16-row tiling has fewer workgroups than 1.5 x the CUs (knob conv_tile_rows: 8 / 16 force one; 0 = this rule)
+// knob conv_tile_rows = 8: 8-row tiles (two workgroups per CU) -- measured on the one launch shape they were made for (4 x 1 x 320 x 320:
+// 200 tiles of 16 rows on 256 CUs) they are 2 % SLOWER (a tile is bound by its CU's matrix pipe): off by default
 template <int MT, int MODE>
 static void launch_bx(bool relu, const float* in, float* out, const char* wpk, int Gin, int Gout, int B, int H, int W, hipStream_t s,
                       const float* mask = nullptr) {
-  const int knob = tune(TUNE_CONV_TILE_ROWS);
-  const long tiles16 = (long)((W + BX_TW - 1) / BX_TW) * ((H + 15) / 16) * B;
-  if (knob == 8 || (knob != 16 && tiles16 < 384)) launch_bx_th<MT, MODE, 8>(relu, in, out, wpk, Gin, Gout, B, H, W, s, mask);
+  if (tune(TUNE_CONV_TILE_ROWS) == 8) launch_bx_th<MT, MODE, 8>(relu, in, out, wpk, Gin, Gout, B, H, W, s, mask);
   else launch_bx_th<MT, MODE, 16>(relu, in, out, wpk, Gin, Gout, B, H, W, s, mask);
 }
 template <int MODE>

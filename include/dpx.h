@@ -98,8 +98,8 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        register-radix path; 0 = what 60 KB of LDS hold)
  *   cg_wave_fft          fused CG on 320 x 320 / 384 x 384 planes: 2 = the size-generic transform        DPX_CG_WAVE_FFT
  *                        kernels instead of the one-wave register transforms (same result to round-off)
- *   conv_tile_rows       split-arithmetic 3x3 layers: 8 / 16 = rows of a workgroup's tile (0: 8 when 16-row   DPX_CONV_TILE_ROWS
- *                        tiles would give fewer than 384 workgroups, else 16); same results
+ *   conv_tile_rows       split-arithmetic 3x3 layers: 8 = 8-row workgroup tiles (two workgroups per CU)      DPX_CONV_TILE_ROWS
+ *                        instead of 16-row ones; same results, measured 2 % slower where it could help: off
  *   wgrad_f32            dpx_ffdnet_backward_bf16_w: 1 = the weight-gradient GEMM on the f32-input matrix        DPX_WGRAD_F32
  *                        instruction (k_conv3x3_wgrad) instead of the split-bf16 one (k_wgrad_bf16x3)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS

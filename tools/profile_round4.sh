@@ -19,6 +19,10 @@ cp $(find $out/kt4 -name "*kernel_stats.csv" | head -1) $out/c4shard_kernel_stat
 rocprofv3 --kernel-trace --stats -d $out/kt5 -o kt --output-format csv -- python tools/bench_configs.py c5 > $out/c5.log 2>&1
 cp $(find $out/kt5 -name "*kernel_stats.csv" | head -1) $out/c5_kernel_stats.csv; rm -rf $out/kt5
 python tools/bench_train.py --kernels > $out/train_unrolled_pnp.log 2>&1
+python tools/bench_c5.py > $out/c5_steady_ab.log 2>&1
+python tools/bench_c5.py bf16 >> $out/c5_steady_ab.log 2>&1
+tools/c5_timeline.sh > /dev/null 2>&1; cp gpurun_out/c5tl/timeline.txt $out/c5_timeline.txt
+(python tools/bench_c4.py 4 32; DPX_CG_WAVE_FFT=2 python tools/bench_c4.py 4 32; DPX_CONV_TILE_ROWS=8 python tools/bench_c4.py 4) > $out/c4_ab.log 2>&1
 python tools/bench_shapes.py 8x3x1024x1024 8x3x768x1024 8x3x768x768 8x3x1024x768 1x3x768x1024 1x3x768x768 8x3x1000x1000 8x3x720x1280 > $out/plane_sizes.log 2>&1
 python tools/bench_methods.py > $out/bench_methods.log 2>&1
 python tools/prof_c4.py 4 > $out/c4shard_events.log 2>&1
