@@ -237,5 +237,5 @@ extern "C" int dpx_cg_config(int fused_max_b, int split_update, int unfused) {
   return DPX_OK;
 }
 
-extern "C" int dpx_version(void) { return 101; }
+extern "C" int dpx_version(void) { return 102; }
 extern "C" const char* dpx_last_error(void) { return dpx::g_err; }
