@@ -173,6 +173,7 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"conv_tile_rows", "DPX_CONV_TILE_ROWS", 0, nullptr},
     {"unroll_bwd_band", "DPX_UNROLL_BWD_BAND", 0, nullptr},
     {"wgrad_f32", "DPX_WGRAD_F32", 0, nullptr},
+    {"generic_interleaved", "DPX_GENERIC_INTERLEAVED", 1, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

@@ -415,6 +415,289 @@ __global__ void k_cols(float2* __restrict__ spec, SpecArgs A, int C, int H, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Size-generic transforms, second form (round 4): CT sequences INTERLEAVED in one LDS image, passes in place.
+//
+//   element n of sequence c lives at slot n * LD + c  (LD = CT + 1: the pad keeps strided butterfly outputs off one bank group)
+//
+// The kernels above give every sequence its own LDS line and ping-pong between two buffers: with 2 * (H + 1) * 8 bytes per column a
+// workgroup of the column pass holds 3 columns at H = 1000 -- 24-byte pieces of every 4 KB spectrum row, i.e. a third of each 64-byte
+// request used -- and every butterfly pays two integer divisions to find its sequence and position.  Here a workgroup of 512 threads
+// owns CT = 8 sequences (64-byte pieces, the column kernel of the power-of-two planes moves the same), a work item is (butterfly j,
+// sequence c) with c = item % CT, so the index arithmetic is shifts and one reciprocal multiply, the twiddles of a butterfly are
+// fetched once per 8 lanes (same address: broadcast), and a pass reads all its operands into registers, synchronises and writes them
+// back to the SAME buffer (at most 16 + R values per thread): half the LDS, two workgroups per CU up to H = 1100.
+// Same Stockham order, same butterflies, same table twiddles as stockham_pass: results are bit-identical to the first form's
+// (knob generic_interleaved = 0 keeps the first form; pinned in tests/parity_cases.py case_generic_interleaved).
+// Radices 2, 3, 4, 5, 7, 8, 11; lengths with another prime factor, or beyond 16 * 512 / CT elements per sequence, stay on the first form.
+// ---------------------------------------------------------------------------------------------
+constexpr int IL_NT = 512;        // threads per workgroup
+constexpr int IL_MAXE = 16;       // sequence elements per thread: N * CT <= IL_MAXE * IL_NT
+
+template <int R, int DIR> __device__ __forceinline__ void bfly_roots(float2 (&v)[R], const float2 (&w)[R]) {
+  if constexpr (R == 2) bfly2<DIR, float2>(v[0], v[1]);
+  else if constexpr (R == 4) bfly4<DIR, float2>(v);
+  else if constexpr (R == 8) bfly8<DIR, float2>(v);
+  else {                                                    // (bfly_odd with the roots of unity fetched once per pass)
+    float2 o[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      float2 acc = v[0];
+#pragma unroll
+      for (int m = 1; m < R; ++m) acc = gadd(acc, gmul(v[m], w[(q * m) % R]));
+      o[q] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = o[q];
+  }
+}
+
+template <int R, int DIR, int CT>
+__device__ __forceinline__ void il_pass(float2* __restrict__ a, int N, int Ns, const float2* __restrict__ tw, int tscale, int tid) {
+  constexpr int LD = CT + 1;
+  constexpr int NIT = (IL_MAXE + R - 1) / R;
+  DPX_OPAQUE(tid);      // (every pass derives its own index registers: hoisted out of the pass loop, those of all eight radices stay alive -- 256 VGPRs and spills)
+  const int nb = N / R, total = nb * CT;
+  const int twm = (N / (Ns * R)) * tscale, rstride = nb * tscale;
+  const float rcp_ns = 1.0f / (float)Ns;
+  float2 w[R];
+  if constexpr (R != 2 && R != 4 && R != 8) {
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      w[t] = tw[t * rstride];
+      if (DIR > 0) w[t].y = -w[t].y;
+    }
+  }
+  float2 v[NIT][R];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + it * IL_NT;
+    if (i < total) {
+      const int c = i % CT, j = i / CT;
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[it][m] = a[(j + m * nb) * LD + c];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + it * IL_NT;
+    if (i < total) {
+      const int c = i % CT, j = i / CT;
+      // k = j % Ns: j < 2^13 and q * Ns <= j, so (j + 0.5) / Ns is at least 0.5 / Ns >= q * 2^-13 away from an integer -- far above
+      // the product's rounding error (q * 2^-23)
+      const int k = j - Ns * (int)(((float)j + 0.5f) * rcp_ns);
+      if (Ns > 1) {
+#pragma unroll
+        for (int m = 1; m < R; ++m) {
+          float2 t = tw[k * m * twm];
+          if (DIR > 0) t.y = -t.y;
+          v[it][m] = gmul(v[it][m], t);
+        }
+      }
+      bfly_roots<R, DIR>(v[it], w);
+      const int j0 = (j - k) * R + k;
+#pragma unroll
+      for (int m = 0; m < R; ++m) a[(j0 + m * Ns) * LD + c] = v[it][m];
+    }
+  }
+  __syncthreads();
+}
+
+// in-place transform of the CT interleaved sequences; the caller synchronises in front, the last pass behind
+template <int DIR, int CT>
+__device__ __forceinline__ void fft_il(float2* __restrict__ a, const Plan1D& plan, const float2* __restrict__ tw, int tscale, int tid) {
+  const int N = plan.n;
+  int Ns = 1;
+  for (int f = 0; f < plan.nf; ++f) {
+    const int R = plan.radix[f];
+    switch (R) {
+      case 2: il_pass<2, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
+      case 3: il_pass<3, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
+      case 4: il_pass<4, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
+      case 5: il_pass<5, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
+      case 7: il_pass<7, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
+      case 8: il_pass<8, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
+      default: il_pass<11, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
+    }
+    Ns *= R;
+  }
+}
+
+// sequences per workgroup for a length (0: the length stays on the first form)
+static int il_seqs(const Plan1D& plan) {
+  for (int f = 0; f < plan.nf; ++f) {
+    const int r = plan.radix[f];
+    if (!(r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 11)) return 0;      // (radix 13 in this form: 169 VGPRs)
+  }
+  if (plan.n < 2) return 0;
+  if (plan.n * 8 <= IL_MAXE * IL_NT) return 8;
+  if (plan.n * 4 <= IL_MAXE * IL_NT) return 4;
+  return 0;
+}
+
+template <bool EVEN, int CT>
+__global__ void __launch_bounds__(IL_NT, 4) k_rows_r2c_il(const float* __restrict__ x, float2* __restrict__ spec, int W, int nrows, Plan1D plan,
+                                                       const float2* __restrict__ twW) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  constexpr int LD = CT + 1;
+  const int M = plan.n, Ws = (W + 1) / 2;
+  float2* a = smem;
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * CT;
+  const int nseq = min(CT, nrows - row0);
+#pragma unroll
+  for (int s = 0; s < CT; ++s) {
+    const float* xr = x + (size_t)(row0 + s) * W;
+    for (int n = tid; n < M; n += IL_NT) {
+      float2 v = make_float2(0.f, 0.f);
+      if (s < nseq) v = EVEN ? *(const float2*)(xr + 2 * n) : make_float2(xr[n], 0.f);
+      a[n * LD + s] = v;
+    }
+  }
+  __syncthreads();
+  fft_il<-1, CT>(a, plan, twW, EVEN ? 2 : 1, tid);
+#pragma unroll
+  for (int s = 0; s < CT; ++s) {
+    if (s >= nseq) break;
+    float2* out = spec + (size_t)(row0 + s) * Ws;
+    for (int k = tid; k < Ws; k += IL_NT) {
+      float2 X;
+      if (!EVEN) {
+        X = a[k * LD + s];
+      } else if (k == 0) {
+        const float2 z0 = a[s];
+        X = make_float2(z0.x + z0.y, z0.x - z0.y);               // (DC, Nyquist) packed
+      } else {
+        const float2 zk = a[k * LD + s], zm = cconj(a[(M - k) * LD + s]);
+        const float2 e = cscale(cadd(zk, zm), 0.5f);
+        const float2 d = cscale(csub(zk, zm), 0.5f);
+        const float2 o = make_float2(d.y, -d.x);                 // -i * d
+        X = cadd(e, cmul(o, twW[k]));
+      }
+      out[k] = X;
+    }
+  }
+}
+
+template <bool EVEN, int CT>
+__global__ void __launch_bounds__(IL_NT, 4) k_rows_c2r_il(const float2* __restrict__ spec, float* __restrict__ y, int W, int nrows, Plan1D plan,
+                                                       const float2* __restrict__ twW, float scale) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  constexpr int LD = CT + 1;
+  const int M = plan.n, Ws = (W + 1) / 2;
+  float2* a = smem;
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * CT;
+  const int nseq = min(CT, nrows - row0);
+  // half spectrum -> the transform's input, pair (k, M - k) by one thread (in place)
+#pragma unroll
+  for (int s = 0; s < CT; ++s) {
+    const float2* X = spec + (size_t)(row0 + s) * Ws;
+    if (EVEN) {
+      for (int k = tid; k <= M / 2; k += IL_NT) {
+        float2 p0 = make_float2(0.f, 0.f), p1 = p0;
+        const int k2 = M - k;
+        if (s < nseq) {
+          if (k == 0) {
+            const float2 x0 = X[0];
+            p0 = make_float2(x0.x + x0.y, x0.x - x0.y);
+          } else {
+            const float2 xa = X[k], xb = X[k2];
+            {
+              const float2 xm = cconj(xb);
+              const float2 e = cadd(xa, xm);
+              const float2 d = cmulc(csub(xa, xm), twW[k]);        // * w^{-k}
+              p0 = make_float2(e.x - d.y, e.y + d.x);              // e + i d
+            }
+            {
+              const float2 xm = cconj(xa);
+              const float2 e = cadd(xb, xm);
+              const float2 d = cmulc(csub(xb, xm), twW[k2]);
+              p1 = make_float2(e.x - d.y, e.y + d.x);
+            }
+          }
+        }
+        a[k * LD + s] = p0;
+        if (k != 0 && k2 != k) a[k2 * LD + s] = p1;
+      }
+    } else {
+      for (int k = tid; k < Ws; k += IL_NT) {
+        float2 v = make_float2(0.f, 0.f);
+        if (s < nseq) v = X[k];
+        a[k * LD + s] = v;
+        if (k > 0) a[(W - k) * LD + s] = cconj(v);
+      }
+    }
+  }
+  __syncthreads();
+  fft_il<+1, CT>(a, plan, twW, EVEN ? 2 : 1, tid);
+#pragma unroll
+  for (int s = 0; s < CT; ++s) {
+    if (s >= nseq) break;
+    float* yr = y + (size_t)(row0 + s) * W;
+    for (int n = tid; n < M; n += IL_NT) {
+      const float2 v = a[n * LD + s];
+      if (EVEN) *(float2*)(yr + 2 * n) = make_float2(v.x * scale, v.y * scale);
+      else yr[n] = v.x * scale;
+    }
+  }
+}
+
+// columns: forward c2c, operator, inverse c2c for CT adjacent columns of one plane (the arithmetic of k_cols)
+template <int OP, int CT>
+__global__ void __launch_bounds__(IL_NT, 4) k_cols_il(float2* __restrict__ spec, SpecArgs A, int C, int H, int W, Plan1D plan,
+                                                   const float2* __restrict__ twH) {
+  HIP_DYNAMIC_SHARED(float2, smem)
+  constexpr int LD = CT + 1;
+  const int Ws = (W + 1) / 2;
+  const bool packed = (W % 2 == 0);
+  float2* a = smem;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y, l0 = blockIdx.x * CT;
+  const int nseq = min(CT, Ws - l0);
+  const int ch = p % C, bi = p / C;
+  float2* base = spec + (size_t)p * H * Ws;
+  const int c = tid % CT;
+  const bool live = c < nseq;
+  for (int r = tid / CT; r < H; r += IL_NT / CT) a[r * LD + c] = live ? base[(size_t)r * Ws + l0 + c] : make_float2(0.f, 0.f);
+  __syncthreads();
+  fft_il<-1, CT>(a, plan, twH, 1, tid);
+  const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
+  const size_t tmain = (size_t)ch * H * Ws;
+  const size_t tside = (size_t)C * H * Ws + (size_t)ch * H;
+  const float2* add = (OP == OP_SOLVE && A.add) ? A.add + (size_t)p * H * Ws : nullptr;   // data spectrum F(K^T b), accumulated in the Fourier domain
+  const bool pk0 = packed && l0 + c == 0;
+  if (live)
+    for (int k = tid / CT; k < H; k += IL_NT / CT) {
+      float2 z = a[k * LD + c];
+      if (add) z = cadd(z, add[(size_t)k * Ws + l0 + c]);
+      if (!pk0) z = spec_op<OP>(z, A, tmain + (size_t)k * Ws + l0 + c, rho_b);
+      a[k * LD + c] = z;
+    }
+  if (packed && l0 == 0) {
+    // column 0 holds DC + i*Nyquist of real-valued columns: separate by Hermitian symmetry; the pair (k, H - k) by one thread, in place
+    __syncthreads();
+    for (int k = tid; k <= H / 2; k += IL_NT) {
+      const int k2 = (H - k) % H;
+      const float2 zk = a[k * LD], zm = cconj(a[k2 * LD]);
+      const float2 Ak = cscale(cadd(zk, zm), 0.5f);
+      const float2 d = cscale(csub(zk, zm), 0.5f);
+      const float2 Bk = make_float2(d.y, -d.x);                       // d / i
+      const float2 A1 = spec_op<OP>(Ak, A, tmain + (size_t)k * Ws, rho_b);
+      const float2 B1 = spec_op<OP>(Bk, A, tside + k, rho_b);
+      const float2 A2 = spec_op<OP>(cconj(Ak), A, tmain + (size_t)k2 * Ws, rho_b);
+      const float2 B2 = spec_op<OP>(cconj(Bk), A, tside + k2, rho_b);
+      a[k * LD] = make_float2(A1.x - B1.y, A1.y + B1.x);               // A' + i B'
+      a[k2 * LD] = make_float2(A2.x - B2.y, A2.y + B2.x);
+    }
+  }
+  __syncthreads();
+  fft_il<+1, CT>(a, plan, twH, 1, tid);
+  if (live)
+    for (int r = tid / CT; r < H; r += IL_NT / CT) base[(size_t)r * Ws + l0 + c] = a[r * LD + c];
+}
+
+// ---------------------------------------------------------------------------------------------
 // one-off fp64 forward transform of the data term:  spec = op(OTF) * F(b)   (packed fp32 half spectrum)
 // Accumulating F(K^T b) in the Fourier domain keeps the large, iteration-invariant part of the
 // right-hand side out of the per-iteration fp32 transforms (only the small increment
@@ -945,6 +1228,51 @@ static int rows_per_block(int M) {
   return r;
 }
 
+template <class K> static void il_lds_attr(K kernel, size_t sh) {
+  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+}
+template <bool EVEN, int CT>
+static void launch_rows_il_t(bool fwd, const float* x, float2* spec, float* y, int W, int nrows, const Plan1D& prow, const float2* twW, hipStream_t s) {
+  const size_t sh = (size_t)prow.n * (CT + 1) * sizeof(float2);
+  const dim3 grid((nrows + CT - 1) / CT);
+  if (fwd) {
+    il_lds_attr(k_rows_r2c_il<EVEN, CT>, sh);
+    DPX_LAUNCH("k_rows_r2c_il", (k_rows_r2c_il<EVEN, CT>), grid, dim3(IL_NT), sh, s, x, spec, W, nrows, prow, twW);
+  } else {
+    il_lds_attr(k_rows_c2r_il<EVEN, CT>, sh);
+    DPX_LAUNCH("k_rows_c2r_il", (k_rows_c2r_il<EVEN, CT>), grid, dim3(IL_NT), sh, s, (const float2*)spec, y, W, nrows, prow, twW, 1.0f);
+  }
+}
+static void launch_rows_il(bool fwd, bool even, int ct, const float* x, float2* spec, float* y, int W, int nrows, const Plan1D& prow,
+                           const float2* twW, hipStream_t s) {
+  if (ct == 8) {
+    if (even) launch_rows_il_t<true, 8>(fwd, x, spec, y, W, nrows, prow, twW, s);
+    else launch_rows_il_t<false, 8>(fwd, x, spec, y, W, nrows, prow, twW, s);
+  } else {
+    if (even) launch_rows_il_t<true, 4>(fwd, x, spec, y, W, nrows, prow, twW, s);
+    else launch_rows_il_t<false, 4>(fwd, x, spec, y, W, nrows, prow, twW, s);
+  }
+}
+template <int OP, int CT>
+static void launch_cols_il_t(float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH, hipStream_t s) {
+  const size_t sh = (size_t)H * (CT + 1) * sizeof(float2);
+  const dim3 grid((spec_cols(W) + CT - 1) / CT, P);
+  il_lds_attr(k_cols_il<OP, CT>, sh);
+  DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT>), grid, dim3(IL_NT), sh, s, spec, A, C, H, W, pcol, twH);
+}
+static void launch_cols_il(int op, int ct, float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH,
+                           hipStream_t s) {
+  if (ct == 8) {
+    if (op == OP_MUL) launch_cols_il_t<OP_MUL, 8>(spec, A, P, C, H, W, pcol, twH, s);
+    else if (op == OP_MULCONJ) launch_cols_il_t<OP_MULCONJ, 8>(spec, A, P, C, H, W, pcol, twH, s);
+    else launch_cols_il_t<OP_SOLVE, 8>(spec, A, P, C, H, W, pcol, twH, s);
+  } else {
+    if (op == OP_MUL) launch_cols_il_t<OP_MUL, 4>(spec, A, P, C, H, W, pcol, twH, s);
+    else if (op == OP_MULCONJ) launch_cols_il_t<OP_MULCONJ, 4>(spec, A, P, C, H, W, pcol, twH, s);
+    else launch_cols_il_t<OP_SOLVE, 4>(spec, A, P, C, H, W, pcol, twH, s);
+  }
+}
+
 int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, int C, int H, int W,
                    const void* table, void* ws, hipStream_t stream) {
   if (pow2_path_available(H, W)) return spectral_apply_pow2(x, y, op, A, B, C, H, W, table, ws, stream);
@@ -957,21 +1285,27 @@ int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, i
   const int rpb = rows_per_block(M);
   const size_t shrow = (size_t)2 * rpb * (M + 1) * sizeof(float2);
   const dim3 grow((nrows + rpb - 1) / rpb);
-  if (shrow > 160 * 1024) {
+  const int il = tune(TUNE_GENERIC_INTERLEAVED);          // 1 = rows and columns, 2 = rows only, 3 = columns only (A/B)
+  const int rct = (il == 1 || il == 2) ? il_seqs(prow) : 0, cct = (il == 1 || il == 3) ? il_seqs(pcol) : 0;
+  if (!rct && shrow > 160 * 1024) {
     set_error("row length %d too large for the LDS-resident generic FFT", W);
     return DPX_ERR_UNSUPPORTED;
   }
-  if (even)
+  // second form of the size-generic kernels (interleaved sequences, passes in place): knob generic_interleaved, default on
+  if (rct) {
+    launch_rows_il(true, even, rct, x, spec, y, W, nrows, prow, tw_rows(table), stream);
+  } else if (even)
     DPX_LAUNCH("k_rows_r2c", (k_rows_r2c<true>), grow, dim3(256), shrow, stream, x, spec, W, nrows, prow, tw_rows(table), rpb);
   else
     DPX_LAUNCH("k_rows_r2c", (k_rows_r2c<false>), grow, dim3(256), shrow, stream, x, spec, W, nrows, prow, tw_rows(table), rpb);
+  if (cct) launch_cols_il(op, cct, spec, A, P, C, H, W, pcol, tw_cols(table, W), stream);
 
   int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
   if (CT < 1) CT = 1;
   if (CT > 16) CT = 16;
   if (tune(TUNE_GENERIC_COLS_CT) > 0) CT = tune(TUNE_GENERIC_COLS_CT);      // knob: columns per workgroup of the size-generic column pass
   const size_t shcol = (size_t)2 * CT * (H + 1) * sizeof(float2);
-  if (shcol > 160 * 1024) {
+  if (!cct && shcol > 160 * 1024) {
     set_error("column length %d too large for the LDS-resident generic FFT", H);
     return DPX_ERR_UNSUPPORTED;
   }
@@ -982,12 +1316,14 @@ int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, i
     hipFuncSetAttribute((const void*)k_cols<OP_MULCONJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
     hipFuncSetAttribute((const void*)k_cols<OP_SOLVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shcol);
   }
-  switch (op) {
+  if (!cct) switch (op) {
     case OP_MUL: DPX_LAUNCH("k_cols", (k_cols<OP_MUL>), gcol, dim3(256), shcol, stream, spec, A, C, H, W, pcol, twH, CT); break;
     case OP_MULCONJ: DPX_LAUNCH("k_cols", (k_cols<OP_MULCONJ>), gcol, dim3(256), shcol, stream, spec, A, C, H, W, pcol, twH, CT); break;
     default: DPX_LAUNCH("k_cols", (k_cols<OP_SOLVE>), gcol, dim3(256), shcol, stream, spec, A, C, H, W, pcol, twH, CT); break;
   }
-  if (even)
+  if (rct)
+    launch_rows_il(false, even, rct, x, spec, y, W, nrows, prow, tw_rows(table), stream);
+  else if (even)
     DPX_LAUNCH("k_rows_c2r", (k_rows_c2r<true>), grow, dim3(256), shrow, stream, spec, y, W, nrows, prow, tw_rows(table), rpb, 1.0f);
   else
     DPX_LAUNCH("k_rows_c2r", (k_rows_c2r<false>), grow, dim3(256), shrow, stream, spec, y, W, nrows, prow, tw_rows(table), rpb, 1.0f);
