@@ -58,6 +58,8 @@ template <class CT> __device__ __forceinline__ CT mk(typename cx_traits<CT>::rea
   r.y = y;
   return r;
 }
+__device__ __forceinline__ float gfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double gfma(double a, double b, double c) { return fma(a, b, c); }
 template <class CT> __device__ __forceinline__ CT gmul(CT a, CT b) { return mk<CT>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 gmul(float2 a, float2 b) { return cmul(a, b); }
 template <class CT> __device__ __forceinline__ CT gadd(CT a, CT b) { return mk<CT>(a.x + b.x, a.y + b.y); }
@@ -115,7 +117,42 @@ template <int DIR, class CT> __device__ __forceinline__ void bfly8(CT (&v)[8]) {
   v[3] = gadd(e[3], t3);
   v[7] = gsub(e[3], t3);
 }
-// odd prime radix, O(R^2), roots of unity read from the transform's own table: W_R^t = tw[t * rstride]
+// odd radix on the half-size form: with a_k = v_k + v_{R-k}, b_k = v_k - v_{R-k} (k = 1 .. (R-1)/2)
+//   X_j, X_{R-j} = (v_0 + sum_k cos(2 pi j k / R) a_k)  -+ i (sum_k sin(2 pi j k / R) b_k)          (forward; inverse: +-)
+// -- (R-1)^2 / 2 real multiply-adds on complex operands instead of (R-1)^2 complex products (radix 5: 36 instead of 120 instructions;
+// the size-generic passes are co-limited by vector-instruction issue).  w[n] = exp(DIR * 2 pi i n / R), n = 0 .. R-1: cosines and sines
+// are the table's own values.  Explicit fma: both forms of the size-generic kernels (and the fp64 data-spectrum passes) share this
+// function and must round identically wherever it is inlined.
+template <int R, int DIR, class CT> __device__ __forceinline__ void bfly_odd_roots(CT (&v)[R], const CT (&w)[R]) {
+  typedef typename cx_traits<CT>::real RT;
+  constexpr int HR = (R - 1) / 2;
+  CT a[HR + 1], b[HR + 1];
+#pragma unroll
+  for (int k = 1; k <= HR; ++k) {
+    a[k] = gadd(v[k], v[R - k]);
+    b[k] = gsub(v[k], v[R - k]);
+  }
+  const CT v0 = v[0];
+  CT x0 = v0;
+#pragma unroll
+  for (int k = 1; k <= HR; ++k) x0 = gadd(x0, a[k]);
+  v[0] = x0;
+#pragma unroll
+  for (int j = 1; j <= HR; ++j) {
+    CT t = v0, u = mk<CT>((RT)0, (RT)0);
+#pragma unroll
+    for (int k = 1; k <= HR; ++k) {
+      const int n = (j * k) % R;
+      const RT c = w[n].x, sn = DIR > 0 ? w[n].y : -w[n].y;      // cos, sin of 2 pi n / R
+      t = mk<CT>(gfma(c, a[k].x, t.x), gfma(c, a[k].y, t.y));
+      u = mk<CT>(gfma(sn, b[k].x, u.x), gfma(sn, b[k].y, u.y));
+    }
+    const CT r = gmul_i<DIR>(u);                                  // -+ i u
+    v[j] = gadd(t, r);
+    v[R - j] = gsub(t, r);
+  }
+}
+// odd prime radix, roots of unity read from the transform's own table: W_R^t = tw[t * rstride]
 template <int R, int DIR, class CT> __device__ __forceinline__ void bfly_odd(CT (&v)[R], const Twid<CT>& tw, int rstride) {
   CT w[R];
 #pragma unroll
@@ -123,16 +160,7 @@ template <int R, int DIR, class CT> __device__ __forceinline__ void bfly_odd(CT 
     w[t] = tw.get((long long)t * rstride);
     if (DIR > 0) w[t].y = -w[t].y;
   }
-  CT o[R];
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    CT acc = v[0];
-#pragma unroll
-    for (int m = 1; m < R; ++m) acc = gadd(acc, gmul(v[m], w[(q * m) % R]));
-    o[q] = acc;
-  }
-#pragma unroll
-  for (int q = 0; q < R; ++q) v[q] = o[q];
+  bfly_odd_roots<R, DIR, CT>(v, w);
 }
 template <int R, int DIR, class CT> __device__ __forceinline__ void bfly(CT (&v)[R], const Twid<CT>& tw, int rstride) {
   if constexpr (R == 2) bfly2<DIR, CT>(v[0], v[1]);
@@ -350,6 +378,23 @@ __device__ __forceinline__ float2 spec_op(float2 z, const SpecArgs& A, size_t ti
   }
 }
 
+// the same operator with its table value fetched separately (k_cols_il requests a batch of them before the arithmetic)
+template <int OP> __device__ __forceinline__ float2 spec_table(const SpecArgs& A, size_t tix) {
+  if constexpr (OP == OP_SOLVE) return A.dd[tix];
+  else return A.otf[tix];
+}
+template <int OP> __device__ __forceinline__ float2 spec_op_t(float2 z, const SpecArgs& A, float2 tv, float rho_b) {
+  if constexpr (OP == OP_MUL) {
+    return cscale(cmul(z, tv), A.scale);
+  } else if constexpr (OP == OP_MULCONJ) {
+    return cscale(cmulc(z, tv), A.scale);
+  } else {
+    const float den = fmaf(rho_b, tv.y, tv.x) + A.eps;
+    const float inv = A.scale / den;
+    return make_float2((z.x + A.eps_num) * inv, z.y * inv);
+  }
+}
+
 // columns: forward c2c, operator, inverse c2c, for a tile of CT columns of one plane
 template <int OP>
 __global__ void k_cols(float2* __restrict__ spec, SpecArgs A, int C, int H, int W, Plan1D plan,
@@ -417,43 +462,48 @@ __global__ void k_cols(float2* __restrict__ spec, SpecArgs A, int C, int H, int 
 // ---------------------------------------------------------------------------------------------
 // Size-generic transforms, second form (round 4): CT sequences INTERLEAVED in one LDS image, passes in place.
 //
-//   element n of sequence c lives at slot n * LD + c  (LD = CT + 1: the pad keeps strided butterfly outputs off one bank group)
+//   element n of sequence c lives at slot n * LD + c  (LD = CT + 1: the pad keeps strided butterfly outputs off one bank group; CT = 1: LD = 1)
 //
 // The kernels above give every sequence its own LDS line and ping-pong between two buffers: with 2 * (H + 1) * 8 bytes per column a
 // workgroup of the column pass holds 3 columns at H = 1000 -- 24-byte pieces of every 4 KB spectrum row, i.e. a third of each 64-byte
-// request used -- and every butterfly pays two integer divisions to find its sequence and position.  Here a workgroup of 512 threads
-// owns CT = 8 sequences (64-byte pieces, the column kernel of the power-of-two planes moves the same), a work item is (butterfly j,
-// sequence c) with c = item % CT, so the index arithmetic is shifts and one reciprocal multiply, the twiddles of a butterfly are
-// fetched once per 8 lanes (same address: broadcast), and a pass reads all its operands into registers, synchronises and writes them
-// back to the SAME buffer (at most 16 + R values per thread): half the LDS, two workgroups per CU up to H = 1100.
+// request used -- and every butterfly pays two integer divisions to find its sequence and position.  Here
+//   * the COLUMN pass gives a workgroup of 512 threads CT = 8 columns (64-byte pieces, what the column kernel of the power-of-two planes
+//     moves); a work item is (butterfly j, column c) with c = item % CT, so the index arithmetic is shifts and one reciprocal multiply and
+//     the twiddles of a butterfly are fetched once per 8 lanes (same address: broadcast);
+//   * the ROW passes give every row to a ONE-WAVE workgroup (CT = 1, 64 threads): no workgroup barrier at all, ~20 independent waves per
+//     CU in different phases, so one wave's loads and stores overlap the others' passes (eight rows interleaved on 512 threads: 95 us per
+//     pass at 8 x 3 x 1000 x 1000, four on 256: 76, two on 128: 68, one on 64: 60);
+//   * a pass reads all its operands into registers, synchronises and writes them back to the SAME buffer (at most 16 + R values per
+//     thread): half the LDS, two column workgroups per CU up to H = 1100;
+//   * the pass twiddles are requested together with the operands in front of the barrier, and every loop of run-time length issues its
+//     global loads in batches (written one element at a time, each iteration waits for its own load);
+//   * odd radices use the half-size butterfly (bfly_odd_roots: 36 instead of 120 instructions at radix 5).
 // Same Stockham order, same butterflies, same table twiddles as stockham_pass: results are bit-identical to the first form's
 // (knob generic_interleaved = 0 keeps the first form; pinned in tests/parity_cases.py case_generic_interleaved).
 // Radices 2, 3, 4, 5, 7, 8, 11; lengths with another prime factor, or beyond 16 * 512 / CT elements per sequence, stay on the first form.
+// Measured (8 x 3 x 1000 x 1000, ADMM TV iteration): k_cols 363 -> 166 us, k_rows_r2c / c2r 165 / 155 -> 60 / 61 us, the iteration 0.91 ->
+// 0.52 ms.  Where the column pass's 166 us go (probes, same launch): load + operator + store without any pass 120 us (384 MB incl. the
+// denominators: 3.2 TB/s through 64-byte pieces at a 4008-byte stride), the passes alone 79 us; a wave-per-column form (no workgroup
+// barrier inside the passes) and a staggered start of the two workgroups of a CU were measured and change nothing.
 // ---------------------------------------------------------------------------------------------
 constexpr int IL_NT = 512;        // threads per workgroup
 constexpr int IL_MAXE = 16;       // sequence elements per thread: N * CT <= IL_MAXE * IL_NT
+constexpr int IL_UB = 8;          // global loads in flight per thread in the load / operator phases
+
+struct BlockSyncAll {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
 
 template <int R, int DIR> __device__ __forceinline__ void bfly_roots(float2 (&v)[R], const float2 (&w)[R]) {
   if constexpr (R == 2) bfly2<DIR, float2>(v[0], v[1]);
   else if constexpr (R == 4) bfly4<DIR, float2>(v);
   else if constexpr (R == 8) bfly8<DIR, float2>(v);
-  else {                                                    // (bfly_odd with the roots of unity fetched once per pass)
-    float2 o[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      float2 acc = v[0];
-#pragma unroll
-      for (int m = 1; m < R; ++m) acc = gadd(acc, gmul(v[m], w[(q * m) % R]));
-      o[q] = acc;
-    }
-#pragma unroll
-    for (int q = 0; q < R; ++q) v[q] = o[q];
-  }
+  else bfly_odd_roots<R, DIR, float2>(v, w);             // (bfly_odd with the roots of unity fetched once per pass)
 }
 
-template <int R, int DIR, int CT>
+template <int R, int DIR, int CT, int NT, class Sync = BlockSyncAll>
 __device__ __forceinline__ void il_pass(float2* __restrict__ a, int N, int Ns, const float2* __restrict__ tw, int tscale, int tid) {
-  constexpr int LD = CT + 1;
+  constexpr int LD = CT > 1 ? CT + 1 : 1;
   constexpr int NIT = (IL_MAXE + R - 1) / R;
   DPX_OPAQUE(tid);      // (every pass derives its own index registers: hoisted out of the pass loop, those of all eight radices stay alive -- 256 VGPRs and spills)
   const int nb = N / R, total = nb * CT;
@@ -467,20 +517,29 @@ __device__ __forceinline__ void il_pass(float2* __restrict__ a, int N, int Ns, c
       if (DIR > 0) w[t].y = -w[t].y;
     }
   }
-  float2 v[NIT][R];
+  // the pass twiddles W_{Ns R}^{k m} are requested together with the operands, in front of the barrier (their L1 / L2 latency hides
+  // behind it); radix 11 fetches them behind it (20 more registers than the 128 of four waves per SIMD hold)
+  constexpr bool EARLY = R <= 8;
+  constexpr int NTW = EARLY ? R - 1 : 1;
+  float2 v[NIT][R], pw[NIT][NTW];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int i = tid + it * IL_NT;
+    const int i = tid + it * NT;
     if (i < total) {
       const int c = i % CT, j = i / CT;
 #pragma unroll
       for (int m = 0; m < R; ++m) v[it][m] = a[(j + m * nb) * LD + c];
+      if (EARLY && Ns > 1) {
+        const int k = j - Ns * (int)(((float)j + 0.5f) * rcp_ns);
+#pragma unroll
+        for (int m = 1; m < R; ++m) pw[it][EARLY ? m - 1 : 0] = tw[k * m * twm];
+      }
     }
   }
-  __syncthreads();
+  Sync()();
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int i = tid + it * IL_NT;
+    const int i = tid + it * NT;
     if (i < total) {
       const int c = i % CT, j = i / CT;
       // k = j % Ns: j < 2^13 and q * Ns <= j, so (j + 0.5) / Ns is at least 0.5 / Ns >= q * 2^-13 away from an integer -- far above
@@ -489,7 +548,7 @@ __device__ __forceinline__ void il_pass(float2* __restrict__ a, int N, int Ns, c
       if (Ns > 1) {
 #pragma unroll
         for (int m = 1; m < R; ++m) {
-          float2 t = tw[k * m * twm];
+          float2 t = EARLY ? pw[it][EARLY ? m - 1 : 0] : tw[k * m * twm];
           if (DIR > 0) t.y = -t.y;
           v[it][m] = gmul(v[it][m], t);
         }
@@ -500,24 +559,24 @@ __device__ __forceinline__ void il_pass(float2* __restrict__ a, int N, int Ns, c
       for (int m = 0; m < R; ++m) a[(j0 + m * Ns) * LD + c] = v[it][m];
     }
   }
-  __syncthreads();
+  Sync()();
 }
 
 // in-place transform of the CT interleaved sequences; the caller synchronises in front, the last pass behind
-template <int DIR, int CT>
+template <int DIR, int CT, int NT, class Sync = BlockSyncAll>
 __device__ __forceinline__ void fft_il(float2* __restrict__ a, const Plan1D& plan, const float2* __restrict__ tw, int tscale, int tid) {
   const int N = plan.n;
   int Ns = 1;
   for (int f = 0; f < plan.nf; ++f) {
     const int R = plan.radix[f];
     switch (R) {
-      case 2: il_pass<2, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
-      case 3: il_pass<3, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
-      case 4: il_pass<4, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
-      case 5: il_pass<5, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
-      case 7: il_pass<7, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
-      case 8: il_pass<8, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
-      default: il_pass<11, DIR, CT>(a, N, Ns, tw, tscale, tid); break;
+      case 2: il_pass<2, DIR, CT, NT, Sync>(a, N, Ns, tw, tscale, tid); break;
+      case 3: il_pass<3, DIR, CT, NT, Sync>(a, N, Ns, tw, tscale, tid); break;
+      case 4: il_pass<4, DIR, CT, NT, Sync>(a, N, Ns, tw, tscale, tid); break;
+      case 5: il_pass<5, DIR, CT, NT, Sync>(a, N, Ns, tw, tscale, tid); break;
+      case 7: il_pass<7, DIR, CT, NT, Sync>(a, N, Ns, tw, tscale, tid); break;
+      case 8: il_pass<8, DIR, CT, NT, Sync>(a, N, Ns, tw, tscale, tid); break;
+      default: il_pass<11, DIR, CT, NT, Sync>(a, N, Ns, tw, tscale, tid); break;
     }
     Ns *= R;
   }
@@ -535,11 +594,14 @@ static int il_seqs(const Plan1D& plan) {
   return 0;
 }
 
-template <bool EVEN, int CT>
-__global__ void __launch_bounds__(IL_NT, 4) k_rows_r2c_il(const float* __restrict__ x, float2* __restrict__ spec, int W, int nrows, Plan1D plan,
+// (the loops of run-time length below issue their global loads in batches of UB: written one element at a time, each iteration waits for
+//  its own load -- M / NT dependent round trips per phase, which is what a one-wave workgroup's row kernel then consists of)
+template <bool EVEN, int CT, int NT>
+__global__ void __launch_bounds__(NT, 4) k_rows_r2c_il(const float* __restrict__ x, float2* __restrict__ spec, int W, int nrows, Plan1D plan,
                                                        const float2* __restrict__ twW) {
   HIP_DYNAMIC_SHARED(float2, smem)
-  constexpr int LD = CT + 1;
+  constexpr int LD = CT > 1 ? CT + 1 : 1;
+  constexpr int UB = CT >= 4 ? 2 : 8;
   const int M = plan.n, Ws = (W + 1) / 2;
   float2* a = smem;
   const int tid = threadIdx.x;
@@ -548,42 +610,65 @@ __global__ void __launch_bounds__(IL_NT, 4) k_rows_r2c_il(const float* __restric
 #pragma unroll
   for (int s = 0; s < CT; ++s) {
     const float* xr = x + (size_t)(row0 + s) * W;
-    for (int n = tid; n < M; n += IL_NT) {
-      float2 v = make_float2(0.f, 0.f);
-      if (s < nseq) v = EVEN ? *(const float2*)(xr + 2 * n) : make_float2(xr[n], 0.f);
-      a[n * LD + s] = v;
+    for (int n0 = tid; n0 < M; n0 += UB * NT) {
+      float2 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int n = n0 + u * NT;
+        v[u] = make_float2(0.f, 0.f);
+        if (s < nseq && n < M) v[u] = EVEN ? *(const float2*)(xr + 2 * n) : make_float2(xr[n], 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int n = n0 + u * NT;
+        if (n < M) a[n * LD + s] = v[u];
+      }
     }
   }
   __syncthreads();
-  fft_il<-1, CT>(a, plan, twW, EVEN ? 2 : 1, tid);
+  fft_il<-1, CT, NT>(a, plan, twW, EVEN ? 2 : 1, tid);
 #pragma unroll
   for (int s = 0; s < CT; ++s) {
     if (s >= nseq) break;
     float2* out = spec + (size_t)(row0 + s) * Ws;
-    for (int k = tid; k < Ws; k += IL_NT) {
-      float2 X;
-      if (!EVEN) {
-        X = a[k * LD + s];
-      } else if (k == 0) {
-        const float2 z0 = a[s];
-        X = make_float2(z0.x + z0.y, z0.x - z0.y);               // (DC, Nyquist) packed
-      } else {
-        const float2 zk = a[k * LD + s], zm = cconj(a[(M - k) * LD + s]);
-        const float2 e = cscale(cadd(zk, zm), 0.5f);
-        const float2 d = cscale(csub(zk, zm), 0.5f);
-        const float2 o = make_float2(d.y, -d.x);                 // -i * d
-        X = cadd(e, cmul(o, twW[k]));
+    for (int k0 = tid; k0 < Ws; k0 += UB * NT) {
+      float2 tw[UB];
+      if (EVEN) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k = k0 + u * NT;
+          tw[u] = k < Ws ? twW[k] : make_float2(0.f, 0.f);
+        }
       }
-      out[k] = X;
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int k = k0 + u * NT;
+        if (k >= Ws) continue;
+        float2 X;
+        if (!EVEN) {
+          X = a[k * LD + s];
+        } else if (k == 0) {
+          const float2 z0 = a[s];
+          X = make_float2(z0.x + z0.y, z0.x - z0.y);               // (DC, Nyquist) packed
+        } else {
+          const float2 zk = a[k * LD + s], zm = cconj(a[(M - k) * LD + s]);
+          const float2 e = cscale(cadd(zk, zm), 0.5f);
+          const float2 d = cscale(csub(zk, zm), 0.5f);
+          const float2 o = make_float2(d.y, -d.x);                 // -i * d
+          X = cadd(e, cmul(o, tw[u]));
+        }
+        out[k] = X;
+      }
     }
   }
 }
 
-template <bool EVEN, int CT>
-__global__ void __launch_bounds__(IL_NT, 4) k_rows_c2r_il(const float2* __restrict__ spec, float* __restrict__ y, int W, int nrows, Plan1D plan,
+template <bool EVEN, int CT, int NT>
+__global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict__ spec, float* __restrict__ y, int W, int nrows, Plan1D plan,
                                                        const float2* __restrict__ twW, float scale) {
   HIP_DYNAMIC_SHARED(float2, smem)
-  constexpr int LD = CT + 1;
+  constexpr int LD = CT > 1 ? CT + 1 : 1;
+  constexpr int UB = CT >= 4 ? 1 : 4;
   const int M = plan.n, Ws = (W + 1) / 2;
   float2* a = smem;
   const int tid = threadIdx.x;
@@ -594,48 +679,75 @@ __global__ void __launch_bounds__(IL_NT, 4) k_rows_c2r_il(const float2* __restri
   for (int s = 0; s < CT; ++s) {
     const float2* X = spec + (size_t)(row0 + s) * Ws;
     if (EVEN) {
-      for (int k = tid; k <= M / 2; k += IL_NT) {
-        float2 p0 = make_float2(0.f, 0.f), p1 = p0;
-        const int k2 = M - k;
-        if (s < nseq) {
-          if (k == 0) {
-            const float2 x0 = X[0];
-            p0 = make_float2(x0.x + x0.y, x0.x - x0.y);
-          } else {
-            const float2 xa = X[k], xb = X[k2];
-            {
-              const float2 xm = cconj(xb);
-              const float2 e = cadd(xa, xm);
-              const float2 d = cmulc(csub(xa, xm), twW[k]);        // * w^{-k}
-              p0 = make_float2(e.x - d.y, e.y + d.x);              // e + i d
-            }
-            {
-              const float2 xm = cconj(xa);
-              const float2 e = cadd(xb, xm);
-              const float2 d = cmulc(csub(xb, xm), twW[k2]);
-              p1 = make_float2(e.x - d.y, e.y + d.x);
+      for (int k0 = tid; k0 <= M / 2; k0 += UB * NT) {
+        float2 xa[UB], xb[UB], wa[UB], wb[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k = k0 + u * NT, k2 = M - k;
+          xa[u] = xb[u] = wa[u] = wb[u] = make_float2(0.f, 0.f);
+          if (s < nseq && k <= M / 2) {
+            xa[u] = X[k];
+            if (k != 0) {
+              xb[u] = X[k2];
+              wa[u] = twW[k];
+              wb[u] = twW[k2];
             }
           }
         }
-        a[k * LD + s] = p0;
-        if (k != 0 && k2 != k) a[k2 * LD + s] = p1;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k = k0 + u * NT, k2 = M - k;
+          if (k > M / 2) continue;
+          float2 p0 = make_float2(0.f, 0.f), p1 = p0;
+          if (s < nseq) {
+            if (k == 0) {
+              const float2 x0 = xa[u];
+              p0 = make_float2(x0.x + x0.y, x0.x - x0.y);
+            } else {
+              {
+                const float2 xm = cconj(xb[u]);
+                const float2 e = cadd(xa[u], xm);
+                const float2 d = cmulc(csub(xa[u], xm), wa[u]);        // * w^{-k}
+                p0 = make_float2(e.x - d.y, e.y + d.x);              // e + i d
+              }
+              {
+                const float2 xm = cconj(xa[u]);
+                const float2 e = cadd(xb[u], xm);
+                const float2 d = cmulc(csub(xb[u], xm), wb[u]);
+                p1 = make_float2(e.x - d.y, e.y + d.x);
+              }
+            }
+          }
+          a[k * LD + s] = p0;
+          if (k != 0 && k2 != k) a[k2 * LD + s] = p1;
+        }
       }
     } else {
-      for (int k = tid; k < Ws; k += IL_NT) {
-        float2 v = make_float2(0.f, 0.f);
-        if (s < nseq) v = X[k];
-        a[k * LD + s] = v;
-        if (k > 0) a[(W - k) * LD + s] = cconj(v);
+      for (int k0 = tid; k0 < Ws; k0 += UB * NT) {
+        float2 v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k = k0 + u * NT;
+          v[u] = make_float2(0.f, 0.f);
+          if (s < nseq && k < Ws) v[u] = X[k];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k = k0 + u * NT;
+          if (k >= Ws) continue;
+          a[k * LD + s] = v[u];
+          if (k > 0) a[(W - k) * LD + s] = cconj(v[u]);
+        }
       }
     }
   }
   __syncthreads();
-  fft_il<+1, CT>(a, plan, twW, EVEN ? 2 : 1, tid);
+  fft_il<+1, CT, NT>(a, plan, twW, EVEN ? 2 : 1, tid);
 #pragma unroll
   for (int s = 0; s < CT; ++s) {
     if (s >= nseq) break;
     float* yr = y + (size_t)(row0 + s) * W;
-    for (int n = tid; n < M; n += IL_NT) {
+    for (int n = tid; n < M; n += NT) {
       const float2 v = a[n * LD + s];
       if (EVEN) *(float2*)(yr + 2 * n) = make_float2(v.x * scale, v.y * scale);
       else yr[n] = v.x * scale;
@@ -644,11 +756,11 @@ __global__ void __launch_bounds__(IL_NT, 4) k_rows_c2r_il(const float2* __restri
 }
 
 // columns: forward c2c, operator, inverse c2c for CT adjacent columns of one plane (the arithmetic of k_cols)
-template <int OP, int CT>
-__global__ void __launch_bounds__(IL_NT, 4) k_cols_il(float2* __restrict__ spec, SpecArgs A, int C, int H, int W, Plan1D plan,
+template <int OP, int CT, int NT>
+__global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, SpecArgs A, int C, int H, int W, Plan1D plan,
                                                    const float2* __restrict__ twH) {
   HIP_DYNAMIC_SHARED(float2, smem)
-  constexpr int LD = CT + 1;
+  constexpr int LD = CT > 1 ? CT + 1 : 1;
   const int Ws = (W + 1) / 2;
   const bool packed = (W % 2 == 0);
   float2* a = smem;
@@ -659,25 +771,56 @@ __global__ void __launch_bounds__(IL_NT, 4) k_cols_il(float2* __restrict__ spec,
   float2* base = spec + (size_t)p * H * Ws;
   const int c = tid % CT;
   const bool live = c < nseq;
-  for (int r = tid / CT; r < H; r += IL_NT / CT) a[r * LD + c] = live ? base[(size_t)r * Ws + l0 + c] : make_float2(0.f, 0.f);
+  // (global loads in batches of IL_UB: a loop of run-time length keeps ONE load in flight per thread -- 16 dependent round trips per phase)
+  constexpr int RS = NT / CT;
+  for (int r0 = tid / CT; r0 < H; r0 += IL_UB * RS) {
+    float2 t[IL_UB];
+#pragma unroll
+    for (int u = 0; u < IL_UB; ++u) {
+      const int r = r0 + u * RS;
+      t[u] = (live && r < H) ? base[(size_t)r * Ws + l0 + c] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < IL_UB; ++u) {
+      const int r = r0 + u * RS;
+      if (r < H) a[r * LD + c] = t[u];
+    }
+  }
   __syncthreads();
-  fft_il<-1, CT>(a, plan, twH, 1, tid);
+  fft_il<-1, CT, NT>(a, plan, twH, 1, tid);
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const size_t tmain = (size_t)ch * H * Ws;
   const size_t tside = (size_t)C * H * Ws + (size_t)ch * H;
   const float2* add = (OP == OP_SOLVE && A.add) ? A.add + (size_t)p * H * Ws : nullptr;   // data spectrum F(K^T b), accumulated in the Fourier domain
   const bool pk0 = packed && l0 + c == 0;
   if (live)
-    for (int k = tid / CT; k < H; k += IL_NT / CT) {
-      float2 z = a[k * LD + c];
-      if (add) z = cadd(z, add[(size_t)k * Ws + l0 + c]);
-      if (!pk0) z = spec_op<OP>(z, A, tmain + (size_t)k * Ws + l0 + c, rho_b);
-      a[k * LD + c] = z;
+    for (int k0 = tid / CT; k0 < H; k0 += IL_UB * RS) {
+      float2 z[IL_UB], ad[IL_UB], tb[IL_UB];
+#pragma unroll
+      for (int u = 0; u < IL_UB; ++u) {
+        const int k = k0 + u * RS;
+        ad[u] = tb[u] = make_float2(0.f, 0.f);
+        if (k < H) {
+          if (add) ad[u] = add[(size_t)k * Ws + l0 + c];
+          if (!pk0) tb[u] = spec_table<OP>(A, tmain + (size_t)k * Ws + l0 + c);
+          z[u] = a[k * LD + c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < IL_UB; ++u) {
+        const int k = k0 + u * RS;
+        if (k < H) {
+          float2 zz = z[u];
+          if (add) zz = cadd(zz, ad[u]);
+          if (!pk0) zz = spec_op_t<OP>(zz, A, tb[u], rho_b);
+          a[k * LD + c] = zz;
+        }
+      }
     }
   if (packed && l0 == 0) {
     // column 0 holds DC + i*Nyquist of real-valued columns: separate by Hermitian symmetry; the pair (k, H - k) by one thread, in place
     __syncthreads();
-    for (int k = tid; k <= H / 2; k += IL_NT) {
+    for (int k = tid; k <= H / 2; k += NT) {
       const int k2 = (H - k) % H;
       const float2 zk = a[k * LD], zm = cconj(a[k2 * LD]);
       const float2 Ak = cscale(cadd(zk, zm), 0.5f);
@@ -692,9 +835,21 @@ __global__ void __launch_bounds__(IL_NT, 4) k_cols_il(float2* __restrict__ spec,
     }
   }
   __syncthreads();
-  fft_il<+1, CT>(a, plan, twH, 1, tid);
+  fft_il<+1, CT, NT>(a, plan, twH, 1, tid);
   if (live)
-    for (int r = tid / CT; r < H; r += IL_NT / CT) base[(size_t)r * Ws + l0 + c] = a[r * LD + c];
+    for (int r0 = tid / CT; r0 < H; r0 += IL_UB * RS) {
+      float2 t[IL_UB];
+#pragma unroll
+      for (int u = 0; u < IL_UB; ++u) {
+        const int r = r0 + u * RS;
+        if (r < H) t[u] = a[r * LD + c];
+      }
+#pragma unroll
+      for (int u = 0; u < IL_UB; ++u) {
+        const int r = r0 + u * RS;
+        if (r < H) base[(size_t)r * Ws + l0 + c] = t[u];
+      }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1231,46 +1386,51 @@ static int rows_per_block(int M) {
 template <class K> static void il_lds_attr(K kernel, size_t sh) {
   if (sh > 48 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
 }
-template <bool EVEN, int CT>
+template <bool EVEN, int CT, int NT>
 static void launch_rows_il_t(bool fwd, const float* x, float2* spec, float* y, int W, int nrows, const Plan1D& prow, const float2* twW, hipStream_t s) {
-  const size_t sh = (size_t)prow.n * (CT + 1) * sizeof(float2);
+  const size_t sh = (size_t)prow.n * (CT > 1 ? CT + 1 : 1) * sizeof(float2);
   const dim3 grid((nrows + CT - 1) / CT);
   if (fwd) {
-    il_lds_attr(k_rows_r2c_il<EVEN, CT>, sh);
-    DPX_LAUNCH("k_rows_r2c_il", (k_rows_r2c_il<EVEN, CT>), grid, dim3(IL_NT), sh, s, x, spec, W, nrows, prow, twW);
+    il_lds_attr(k_rows_r2c_il<EVEN, CT, NT>, sh);
+    DPX_LAUNCH("k_rows_r2c_il", (k_rows_r2c_il<EVEN, CT, NT>), grid, dim3(NT), sh, s, x, spec, W, nrows, prow, twW);
   } else {
-    il_lds_attr(k_rows_c2r_il<EVEN, CT>, sh);
-    DPX_LAUNCH("k_rows_c2r_il", (k_rows_c2r_il<EVEN, CT>), grid, dim3(IL_NT), sh, s, (const float2*)spec, y, W, nrows, prow, twW, 1.0f);
+    il_lds_attr(k_rows_c2r_il<EVEN, CT, NT>, sh);
+    DPX_LAUNCH("k_rows_c2r_il", (k_rows_c2r_il<EVEN, CT, NT>), grid, dim3(NT), sh, s, (const float2*)spec, y, W, nrows, prow, twW, 1.0f);
   }
 }
+// ct: 1 = one row per one-wave workgroup (row lengths up to 1024 complex points: the rule), 8 = eight rows interleaved on 512 threads (A/B),
+// 4 = four rows on 512 threads (lengths up to 2048)
 static void launch_rows_il(bool fwd, bool even, int ct, const float* x, float2* spec, float* y, int W, int nrows, const Plan1D& prow,
                            const float2* twW, hipStream_t s) {
-  if (ct == 8) {
-    if (even) launch_rows_il_t<true, 8>(fwd, x, spec, y, W, nrows, prow, twW, s);
-    else launch_rows_il_t<false, 8>(fwd, x, spec, y, W, nrows, prow, twW, s);
+  if (ct == 1) {
+    if (even) launch_rows_il_t<true, 1, 64>(fwd, x, spec, y, W, nrows, prow, twW, s);
+    else launch_rows_il_t<false, 1, 64>(fwd, x, spec, y, W, nrows, prow, twW, s);
+  } else if (ct == 8) {
+    if (even) launch_rows_il_t<true, 8, 512>(fwd, x, spec, y, W, nrows, prow, twW, s);
+    else launch_rows_il_t<false, 8, 512>(fwd, x, spec, y, W, nrows, prow, twW, s);
   } else {
-    if (even) launch_rows_il_t<true, 4>(fwd, x, spec, y, W, nrows, prow, twW, s);
-    else launch_rows_il_t<false, 4>(fwd, x, spec, y, W, nrows, prow, twW, s);
+    if (even) launch_rows_il_t<true, 4, 512>(fwd, x, spec, y, W, nrows, prow, twW, s);
+    else launch_rows_il_t<false, 4, 512>(fwd, x, spec, y, W, nrows, prow, twW, s);
   }
 }
-template <int OP, int CT>
+template <int OP, int CT, int NT>
 static void launch_cols_il_t(float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH, hipStream_t s) {
   const size_t sh = (size_t)H * (CT + 1) * sizeof(float2);
   const dim3 grid((spec_cols(W) + CT - 1) / CT, P);
-  il_lds_attr(k_cols_il<OP, CT>, sh);
-  DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT>), grid, dim3(IL_NT), sh, s, spec, A, C, H, W, pcol, twH);
+  il_lds_attr(k_cols_il<OP, CT, NT>, sh);
+  DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT, NT>), grid, dim3(NT), sh, s, spec, A, C, H, W, pcol, twH);
 }
+template <int CT, int NT>
+static void launch_cols_il_o(int op, float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH, hipStream_t s) {
+  if (op == OP_MUL) launch_cols_il_t<OP_MUL, CT, NT>(spec, A, P, C, H, W, pcol, twH, s);
+  else if (op == OP_MULCONJ) launch_cols_il_t<OP_MULCONJ, CT, NT>(spec, A, P, C, H, W, pcol, twH, s);
+  else launch_cols_il_t<OP_SOLVE, CT, NT>(spec, A, P, C, H, W, pcol, twH, s);
+}
+// ct: 8 = eight columns on 512 threads, 4 = four columns on 512 threads (column lengths above 1024)
 static void launch_cols_il(int op, int ct, float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH,
                            hipStream_t s) {
-  if (ct == 8) {
-    if (op == OP_MUL) launch_cols_il_t<OP_MUL, 8>(spec, A, P, C, H, W, pcol, twH, s);
-    else if (op == OP_MULCONJ) launch_cols_il_t<OP_MULCONJ, 8>(spec, A, P, C, H, W, pcol, twH, s);
-    else launch_cols_il_t<OP_SOLVE, 8>(spec, A, P, C, H, W, pcol, twH, s);
-  } else {
-    if (op == OP_MUL) launch_cols_il_t<OP_MUL, 4>(spec, A, P, C, H, W, pcol, twH, s);
-    else if (op == OP_MULCONJ) launch_cols_il_t<OP_MULCONJ, 4>(spec, A, P, C, H, W, pcol, twH, s);
-    else launch_cols_il_t<OP_SOLVE, 4>(spec, A, P, C, H, W, pcol, twH, s);
-  }
+  if (ct == 8) launch_cols_il_o<8, 512>(op, spec, A, P, C, H, W, pcol, twH, s);
+  else launch_cols_il_o<4, 512>(op, spec, A, P, C, H, W, pcol, twH, s);
 }
 
 int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, int C, int H, int W,
@@ -1285,8 +1445,10 @@ int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, i
   const int rpb = rows_per_block(M);
   const size_t shrow = (size_t)2 * rpb * (M + 1) * sizeof(float2);
   const dim3 grow((nrows + rpb - 1) / rpb);
-  const int il = tune(TUNE_GENERIC_INTERLEAVED);          // 1 = rows and columns, 2 = rows only, 3 = columns only (A/B)
-  const int rct = (il == 1 || il == 2) ? il_seqs(prow) : 0, cct = (il == 1 || il == 3) ? il_seqs(pcol) : 0;
+  const int il = tune(TUNE_GENERIC_INTERLEAVED);          // 1 = rows and columns, 2 = rows only, 3 = columns only, 4 = both, rows eight to a workgroup (A/B)
+  int rct = (il == 1 || il == 2 || il == 4) ? il_seqs(prow) : 0;
+  const int cct = (il == 1 || il == 3 || il == 4) ? il_seqs(pcol) : 0;
+  if (rct == 8 && il != 4) rct = 1;                      // a row per one-wave workgroup: no workgroup barrier, the waves of a CU drift apart
   if (!rct && shrow > 160 * 1024) {
     set_error("row length %d too large for the LDS-resident generic FFT", W);
     return DPX_ERR_UNSUPPORTED;

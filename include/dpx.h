@@ -102,9 +102,11 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        instead of 16-row ones; same results, measured 2 % slower where it could help: off
  *   wgrad_f32            dpx_ffdnet_backward_bf16_w: 1 = the weight-gradient GEMM on the f32-input matrix        DPX_WGRAD_F32
  *                        instruction (k_conv3x3_wgrad) instead of the split-bf16 one (k_wgrad_bf16x3)
- *   generic_interleaved  size-generic transforms (planes off the register-radix path): 1 = eight        DPX_GENERIC_INTERLEAVED
- *                        sequences interleaved in one LDS image, passes in place (k_rows_r2c_il / k_cols_il /
- *                        k_rows_c2r_il); 0 = one LDS line per sequence, two buffers (bit-identical results)
+ *   generic_interleaved  size-generic transforms (planes off the register-radix path): 1 = passes in place   DPX_GENERIC_INTERLEAVED
+ *                        on interleaved LDS images (k_cols_il: eight columns per workgroup; k_rows_r2c_il /
+ *                        k_rows_c2r_il: a row per one-wave workgroup); 0 = one LDS line per sequence, two buffers
+ *                        (k_rows_r2c / k_cols / k_rows_c2r); 2 / 3 = rows / columns only on the new form, 4 = rows
+ *                        eight to a 512-thread workgroup (A/B; all settings give bit-identical results)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */

@@ -273,12 +273,13 @@ def case_other_plane_sizes(device, sizes=((384, 256), (1536, 256), (2048, 256), 
 
 
 def case_generic_interleaved(device, sizes=((1, 3, 45, 35), (2, 1, 30, 44), (1, 1, 52, 26), (1, 3, 63, 28), (1, 1, 100, 120), (1, 1, 24, 34),
-                                             (1, 1, 1100, 24), (1, 1, 24, 2200)), oracle_sizes=((1, 3, 45, 35), (1, 1, 100, 120))):
-    """size-generic transforms, second form (k_rows_r2c_il / k_cols_il / k_rows_c2r_il: eight sequences interleaved in one LDS image, passes in
-    place) against the first form (knob generic_interleaved = 0: k_rows_r2c / k_cols / k_rows_c2r): same Stockham order, butterflies and table
-    twiddles, so convolution, adjoint and the ADMM iterate must be BIT-IDENTICAL -- odd and even widths, radices 2 / 3 / 4 / 5 / 7 / 8 / 11 / 13,
-    ragged last workgroups (135 rows, 18 columns), a 17-point row length that stays on the first form beside interleaved columns, and the
-    four-sequence workgroups of lengths above 1024 -- and against the oracle (the reference's restatement) on two of the sizes."""
+                                             (1, 1, 1100, 24), (1, 1, 24, 2200)), oracle_sizes=((1, 3, 45, 35), (1, 1, 100, 120)), forms=(1, 4)):
+    """size-generic transforms, second form (k_rows_r2c_il / k_rows_c2r_il: a row per one-wave workgroup, or eight rows interleaved on 512
+    threads with knob value 4; k_cols_il: eight columns interleaved in one LDS image; passes in place) against the first form (knob
+    generic_interleaved = 0: k_rows_r2c / k_cols / k_rows_c2r): same Stockham order, butterflies and table twiddles, so convolution, adjoint and
+    the ADMM iterate must be BIT-IDENTICAL -- odd and even widths, radices 2 / 3 / 4 / 5 / 7 / 8 / 11 (13 stays on the first form), ragged last
+    workgroups (135 rows, 18 columns), a 17-point row length that stays on the first form beside interleaved columns, and the four-sequence
+    workgroups of lengths above 1024 -- and against the oracle (the reference's restatement) on two of the sizes."""
     import oracle as O
     import synthetic
     from dprox import _backend as be
@@ -286,7 +287,7 @@ def case_generic_interleaved(device, sizes=((1, 3, 45, 35), (2, 1, 30, 44), (1, 
         gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=H + 3 * W)
         b, bt = T(b0, device), torch.from_numpy(b0)
         res = {}
-        for form in (1, 0):
+        for form in tuple(forms) + (0,):
             with be.tuned(generic_interleaved=form):
                 x = dp.Variable()
                 cv = dp.conv(x, psf).to(device)
@@ -294,8 +295,9 @@ def case_generic_interleaved(device, sizes=((1, 3, 45, 35), (2, 1, 30, 44), (1, 
                 x, fns, _ = tv_problem(b, psf)
                 out = dp.Problem(fns).solve(method="admm", device=device, x0=b, rhos=0.3, lams=0.01, max_iter=3).cpu()
                 res[form] = (fwd, adj, out)
-        for name, p, q in zip(("conv forward", "conv adjoint", "ADMM x 3"), res[1], res[0]):
-            assert torch.equal(p, q), f"{name} {B}x{C}x{H}x{W}: interleaved form differs from the first form by {float((p - q).abs().max())}"
+        for form in forms:
+            for name, p, q in zip(("conv forward", "conv adjoint", "ADMM x 3"), res[form], res[0]):
+                assert torch.equal(p, q), f"{name} {B}x{C}x{H}x{W}: form {form} differs from the first form by {float((p - q).abs().max())}"
         if (B, C, H, W) in oracle_sizes:
             lin = O.lin_conv(psf)
             assert_close(res[1][0], lin.fwd(bt), TOL, f"conv forward, {H}x{W} (interleaved generic transforms)")
