@@ -167,6 +167,129 @@ __global__ void k_rhs(float* __restrict__ rhs, const float* __restrict__ ktb, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// z / dual update of iteration t AND the right-hand side of iteration t + 1 in one pass (planes off the two-kernel iteration):
+//   d = K_i x + u_i ; v_i = prox_i(d) ; u_i' = d - v_i ;  rhs = ktb + rho' sum_i K_i^T (v_i - u_i')
+// k_zupdate + k_rhs move 12 planes (x, u_i in; v_i, u_i' out; v_i, u_i' in again; rhs out: two gradient terms), this pass 8: the
+// adjoint stencils need v - u' at the left / upper neighbour, which the thread RECOMPUTES from x and u there (cache hits: the
+// neighbour's own thread reads the same lines) instead of waiting for another thread's stores.  The incoming duals are therefore read
+// at neighbours while the outgoing ones are written: u must be double-buffered (terms[i].u_out != terms[i].u).  Same expressions in the
+// same order as the two kernels: bit-identical v, u', rhs.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void k_zupdate_rhs(const float* __restrict__ x, float* __restrict__ rhs, const float* __restrict__ ktb,
+                              const float* __restrict__ rho, TermPack T, int dual, int B, int C, int H, int W) {
+  const int Wv = W / VEC;
+  const long total = (long)B * C * H * Wv;
+  bool need_w = false, need_h = false;
+  for (int t = 0; t < T.n; ++t) {
+    need_w |= T.t[t].linop == DPX_LIN_GRAD_W;
+    need_h |= T.t[t].linop == DPX_LIN_GRAD_H;
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int wv = (int)(i % Wv);
+    const long row = i / Wv;                 // (b*C + c)*H + h
+    const int h = (int)(row % H);
+    const long plane = row / H;
+    const int b = (int)(plane / C);
+    const long off = row * W + (long)wv * VEC;
+    const long left = row * W + (wv == 0 ? W - 1 : wv * VEC - 1);                     // left neighbour of the group's first pixel
+    const long offu = (plane * H + (h == 0 ? H - 1 : h - 1)) * W + (long)wv * VEC;      // the group one row up
+    const float r = rho[b];
+    float xv[VEC + 1], xd[VEC], xu[VEC], xl = 0.f;
+    if constexpr (VEC == 4) {
+      const float4 q = *(const float4*)(x + off);
+      xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+    } else {
+      xv[0] = x[off];
+    }
+    if (need_w) {
+      xv[VEC] = x[row * W + ((wv + 1) * VEC) % W];
+      xl = x[left];
+    }
+    if (need_h) {
+      const long offd = (plane * H + (h + 1 == H ? 0 : h + 1)) * W + (long)wv * VEC;
+      if constexpr (VEC == 4) {
+        const float4 q = *(const float4*)(x + offd), p = *(const float4*)(x + offu);
+        xd[0] = q.x; xd[1] = q.y; xd[2] = q.z; xd[3] = q.w;
+        xu[0] = p.x; xu[1] = p.y; xu[2] = p.z; xu[3] = p.w;
+      } else {
+        xd[0] = x[offd];
+        xu[0] = x[offu];
+      }
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int t = 0; t < T.n; ++t) {
+      const dpx_term tm = T.t[t];
+      const float lam = tm.lam ? tm.lam[b] * tm.alpha : 0.f;
+      float uu[VEC], vv[VEC];
+      if constexpr (VEC == 4) {
+        const float4 q = *(const float4*)(tm.u + off);
+        uu[0] = q.x; uu[1] = q.y; uu[2] = q.z; uu[3] = q.w;
+      } else {
+        uu[0] = tm.u[off];
+      }
+      float y[VEC + 1];   // y[1..VEC] = v - u' at this pixel group, y[0] = left neighbour (as in k_rhs)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float kx;
+        if (tm.linop == DPX_LIN_IDENTITY) kx = xv[e];
+        else if (tm.linop == DPX_LIN_GRAD_W) kx = xv[e + 1] - xv[e];
+        else kx = xd[e] - xv[e];
+        const float d = kx + uu[e];
+        vv[e] = prox_eval(tm.prox, d, lam);
+        const float uin = uu[e];
+        uu[e] = d - vv[e];
+        y[e + 1] = vv[e] - (dual ? uu[e] : uin);            // (dual = 0: the duals are not advanced -- the next right-hand side sees the incoming ones)
+      }
+      if constexpr (VEC == 4) {
+        *(float4*)(tm.v + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        *(float4*)(tm.u_out + off) = make_float4(uu[0], uu[1], uu[2], uu[3]);
+      } else {
+        tm.v[off] = vv[0];
+        tm.u_out[off] = uu[0];
+      }
+      if (tm.linop == DPX_LIN_IDENTITY) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += y[e + 1];
+      } else if (tm.linop == DPX_LIN_GRAD_W) {
+        const float uin = tm.u[left];
+        const float d = (xv[0] - xl) + uin;                              // the left neighbour's own update, recomputed
+        const float vl = prox_eval(tm.prox, d, lam);
+        const float ul = d - vl;
+        y[0] = vl - (dual ? ul : uin);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += y[e] - y[e + 1];
+      } else {
+        float ua[VEC], yu[VEC];
+        if constexpr (VEC == 4) {
+          const float4 q = *(const float4*)(tm.u + offu);
+          ua[0] = q.x; ua[1] = q.y; ua[2] = q.z; ua[3] = q.w;
+        } else {
+          ua[0] = tm.u[offu];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = (xv[e] - xu[e]) + ua[e];                        // the upper neighbour's own update, recomputed
+          const float vu = prox_eval(tm.prox, d, lam);
+          const float un = d - vu;
+          yu[e] = vu - (dual ? un : ua[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += yu[e] - y[e + 1];
+      }
+    }
+    if constexpr (VEC == 4) {
+      float4 k = ktb ? *(const float4*)(ktb + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(rhs + off) = make_float4(fmaf(r, acc[0], k.x), fmaf(r, acc[1], k.y), fmaf(r, acc[2], k.z), fmaf(r, acc[3], k.w));
+    } else {
+      rhs[off] = fmaf(r, acc[0], ktb ? ktb[off] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // stand-alone stencil, prox, linear combination
 // ---------------------------------------------------------------------------------------------
 __global__ void k_grad(const float* __restrict__ x, float* __restrict__ y, int dim, int adjoint, long planes, int H, int W) {
@@ -541,6 +664,26 @@ extern "C" int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, cons
   else
     DPX_LAUNCH("k_rhs", (k_rhs<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, rho, T, B, C, H, W);
   return launch_status("dpx_admm_rhs");
+}
+
+extern "C" int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int nterms, float* rhs, const float* ktb, const float* rho_next,
+                                    int dual, int B, int C, int H, int W, dpx_stream_t stream) {
+  DPX_REQUIRE(x && rhs && rho_next && rhs != x && B > 0 && C > 0 && H > 0 && W > 0 && nterms > 0, "dpx_admm_zupdate_rhs: bad arguments");
+  TermPack T;
+  bool vec = (W % 4 == 0) && aligned16(x) && aligned16(rhs) && (!ktb || aligned16(ktb));
+  int rc = pack_terms(T, terms, nterms, "dpx_admm_zupdate_rhs", vec);
+  if (rc) return rc;
+  for (int i = 0; i < nterms; ++i)
+    DPX_REQUIRE(terms[i].prox != DPX_PROX_EXTERNAL && terms[i].u_out && terms[i].u_out != terms[i].u,
+                "dpx_admm_zupdate_rhs: term %d needs a closed-form prox and a double-buffered dual (u_out != u)", i);
+  const long n = (long)B * C * H * W;
+  if (vec)
+    DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<4>), dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T,
+               dual, B, C, H, W);
+  else
+    DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T, dual,
+               B, C, H, W);
+  return launch_status("dpx_admm_zupdate_rhs");
 }
 
 extern "C" int dpx_grad(const float* x, float* y, int dim, int adjoint, int B, int C, int H, int W, dpx_stream_t stream) {

@@ -758,14 +758,31 @@ __global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict_
 // columns: forward c2c, operator, inverse c2c for CT adjacent columns of one plane (the arithmetic of k_cols)
 template <int OP, int CT, int NT>
 __global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, SpecArgs A, int C, int H, int W, Plan1D plan,
-                                                   const float2* __restrict__ twH) {
+                                                   const float2* __restrict__ twH, int P) {
   HIP_DYNAMIC_SHARED(float2, smem)
   constexpr int LD = CT > 1 ? CT + 1 : 1;
   const int Ws = (W + 1) / 2;
   const bool packed = (W % 2 == 0);
   float2* a = smem;
   const int tid = threadIdx.x;
-  const int p = blockIdx.y, l0 = blockIdx.x * CT;
+  // workgroup -> (image, channel, column tile): the B images of one (channel, tile) -- they read the same 64 KB of denominators --
+  // take consecutive slots of ONE XCD (the hardware deals workgroup i to XCD i % 8), so that the table tile comes from that XCD's L2
+  // for all but the first of them; groups beyond the last full set of eight keep the plain order
+  const int ntile = (Ws + CT - 1) / CT, nb = P / C;
+  int p, tile;
+  {
+    const int ngroup = C * ntile, full = (ngroup / 8) * 8;
+    const int i = blockIdx.x, xcd = i % 8, slot = i / 8;
+    int g = (slot / nb) * 8 + xcd, bimg = slot % nb;
+    if (i >= full * nb) {
+      const int r = i - full * nb;
+      g = full + r / nb;
+      bimg = r % nb;
+    }
+    tile = g % ntile;
+    p = bimg * C + g / ntile;
+  }
+  const int l0 = tile * CT;
   const int nseq = min(CT, Ws - l0);
   const int ch = p % C, bi = p / C;
   float2* base = spec + (size_t)p * H * Ws;
@@ -1416,9 +1433,9 @@ static void launch_rows_il(bool fwd, bool even, int ct, const float* x, float2* 
 template <int OP, int CT, int NT>
 static void launch_cols_il_t(float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH, hipStream_t s) {
   const size_t sh = (size_t)H * (CT + 1) * sizeof(float2);
-  const dim3 grid((spec_cols(W) + CT - 1) / CT, P);
+  const dim3 grid(((spec_cols(W) + CT - 1) / CT) * P);
   il_lds_attr(k_cols_il<OP, CT, NT>, sh);
-  DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT, NT>), grid, dim3(NT), sh, s, spec, A, C, H, W, pcol, twH);
+  DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT, NT>), grid, dim3(NT), sh, s, spec, A, C, H, W, pcol, twH, P);
 }
 template <int CT, int NT>
 static void launch_cols_il_o(int op, float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH, hipStream_t s) {

@@ -566,6 +566,13 @@ def admm_zupdate(x, term_arr, nterms):
     be.lib().call("dpx_admm_zupdate", ptr(x), term_arr, nterms, B, C, H, W, be.stream())
 
 
+def admm_zupdate_rhs(x, term_arr, nterms, rhs, rho_next, dual=True, ktb=None):
+    """z / dual update of this iteration and the right-hand side of the next one in one pass (dpx_admm_zupdate_rhs: every term's dual is
+    double-buffered, u_out != u)"""
+    B, C, H, W = _shape4(x)
+    be.lib().call("dpx_admm_zupdate_rhs", ptr(x), term_arr, nterms, ptr(rhs), ptr(ktb), ptr(rho_next), int(bool(dual)), B, C, H, W, be.stream())
+
+
 # ----------------------------------------------------------------------------------------------
 # two-kernel fused iteration (power-of-two planes)
 # ----------------------------------------------------------------------------------------------

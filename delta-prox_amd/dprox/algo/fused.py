@@ -412,6 +412,8 @@ def sub_batch_chains(B, C, H, W):
 
 
 class FusedADMM:
+    merge_z_rhs = True      # staged iteration (planes off the two-kernel iteration): z / dual stage + next right-hand side as one pass
+
     def __init__(self, solver, codes):
         self.solver, self.codes = solver, codes
 
@@ -599,12 +601,28 @@ class FusedADMM:
             s.Kall.update_vars([x])
             return x, v, u
 
+        # closed-form proxes only: the z / dual stage of iteration t and the right-hand side of iteration t + 1 are ONE pass
+        # (dpx_admm_zupdate_rhs: 8 instead of 12 plane passes; it reads duals at neighbouring pixels, so the duals alternate between two
+        # sets of buffers -- half-quadratic splitting's are write-only scratch already)
+        merged = n > 0 and not ext and self.merge_z_rhs
+        if merged and dual:
+            u_alt = [torch.empty_like(t) for t in u]
+            for i in range(n):
+                terms[i].u_out = u_alt[i].data_ptr()
         for it in tqdm(range(T), disable=not pbar):
             for i in range(n):
                 terms[i].lam = lam_tab[i][it].data_ptr()
-            ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
+            if not merged or it == 0:
+                ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
             ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x, spec_add=FK)
-            ops.admm_zupdate(x, terms, n)
+            if merged and it + 1 < T:
+                ops.admm_zupdate_rhs(x, terms, n, rhs, rho_tab[it + 1], dual=dual)
+            else:
+                ops.admm_zupdate(x, terms, n)
+            if merged and dual:
+                for i in range(n):                                   # the duals just written become the next iteration's input
+                    u[i], u_alt[i] = u_alt[i], u[i]
+                    terms[i].u, terms[i].u_out = u[i].data_ptr(), u_alt[i].data_ptr()
             for i in ext:                                            # v_i holds d = x + u_i
                 d = v[i]
                 out = _denoise_split(psi[i], d, lam_tab[i][it])

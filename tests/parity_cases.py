@@ -306,6 +306,38 @@ def case_generic_interleaved(device, sizes=((1, 3, 45, 35), (2, 1, 30, 44), (1, 
             assert_close(res[1][2], ref, TOL, f"ADMM x 3, {H}x{W} (interleaved generic transforms)", maxabs_mult=4.0)
 
 
+def case_merged_z_rhs(device, shapes=((2, 3, 40, 52), (1, 1, 33, 47), (2, 1, 30, 44))):
+    """staged iteration on planes off the two-kernel iteration: the z / dual stage of iteration t and the right-hand side of iteration
+    t + 1 as ONE pass (dpx_admm_zupdate_rhs: neighbours' updates recomputed, duals double-buffered) against the two separate passes
+    (dpx_admm_zupdate, dpx_admm_rhs): the same expressions in the same order, so x, every v_i and every u_i must be BIT-IDENTICAL --
+    ADMM and half-quadratic splitting, identity / grad_H / grad_W terms, soft threshold / nonneg proxes, per-image rho schedules, widths
+    with and without 16-byte groups -- and the merged path against the op-by-op iteration to round-off."""
+    import synthetic
+    from dprox.algo import fused
+    for (B, C, H, W) in shapes:
+        gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=5 + H)
+        b = T(b0, device)
+        rhos = torch.linspace(0.5, 0.3, 5).repeat(B, 1) * torch.linspace(1.0, 1.4, B).view(B, 1)
+        for method in ("admm", "hqs"):
+            outs = {}
+            for mode in ("merged", "staged", "op-by-op"):
+                x = dp.Variable()
+                fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x) + dp.norm1(x) * 0.3
+                s = dp.compile(fns, method=method, device=device)
+                s.use_fused = mode != "op-by-op"
+                old = fused.FusedADMM.merge_z_rhs
+                fused.FusedADMM.merge_z_rhs = mode == "merged"
+                try:
+                    outs[mode] = s.solve(x0=b, rhos=rhos, lams=0.01, max_iter=5, return_full_states=True)
+                finally:
+                    fused.FusedADMM.merge_z_rhs = old
+                assert s.last_path == ("generic" if mode == "op-by-op" else "fused"), (mode, s.last_path)
+            flat = lambda st: [st[0]] + [t for part in st[1:] for t in (part if isinstance(part, (list, tuple)) else [part])]
+            for k, (p, q) in enumerate(zip(flat(outs["merged"]), flat(outs["staged"]))):
+                assert torch.equal(p, q), f"{method} {B}x{C}x{H}x{W}: state tensor {k} of the merged pass differs by {float((p - q).abs().max())}"
+            assert_close(outs["merged"][0].cpu(), outs["op-by-op"][0].cpu(), 2e-5, f"{method} {H}x{W}: merged z / rhs pass vs op by op")
+
+
 def case_w768_two_kernel(device, H=256, B=2, methods=("admm", "hqs", "admm_vxu")):
     """768-wide rows on the two-kernel iteration (384 = 6 * 8 * 8 complex points per row on one wave, fft384_wave): ADMM, half-quadratic
     splitting and ADMM_vxu with full states against the op-by-op iteration on the size-generic kernels, and the fresh-state /

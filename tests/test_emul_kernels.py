@@ -54,6 +54,10 @@ def test_768_wide_rows_on_the_two_kernel_iteration():
     pc.case_w768_two_kernel(DEV, B=1, methods=("admm", "admm_vxu"))
 
 
+def test_merged_z_rhs():
+    pc.case_merged_z_rhs(DEV)
+
+
 def test_generic_interleaved():
     pc.case_generic_interleaved(DEV, sizes=((1, 3, 45, 35), (2, 1, 30, 44), (1, 1, 52, 26), (1, 1, 63, 28), (1, 1, 24, 34), (1, 1, 1100, 24)),
                                 oracle_sizes=((1, 3, 45, 35),))

@@ -59,6 +59,10 @@ def test_768_wide_rows_on_the_two_kernel_iteration():
     pc.case_w768_two_kernel(DEV)
 
 
+def test_merged_z_rhs():
+    pc.case_merged_z_rhs(DEV)
+
+
 def test_generic_interleaved():
     pc.case_generic_interleaved(DEV)
 
