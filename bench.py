@@ -281,7 +281,8 @@ def extra_configs(dp, synthetic, device):
     other = {}
     for tag, shape, method in (("hqs_8x3x1024x1024", (B, C, H, W), "hqs"), ("admm_vxu_8x3x1024x1024", (B, C, H, W), "admm_vxu"),
                                ("pgd_8x3x1024x1024", (B, C, H, W), "pgd"),
-                               ("admm_8x3x768x1024", (B, C, 768, 1024), "admm"), ("admm_8x3x768x768", (B, C, 768, 768), "admm")):
+                               ("admm_8x3x768x1024", (B, C, 768, 1024), "admm"), ("admm_8x3x768x768", (B, C, 768, 768), "admm"),
+                               ("admm_8x3x1000x1000", (B, C, 1000, 1000), "admm")):
         gto, bo, psfo = synthetic.deconv_case(*shape, seed=2023)
         bo, x = torch.from_numpy(bo).to(device), dp.Variable()
         reg = dp.norm1(x) if method == "pgd" else dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
@@ -293,7 +294,7 @@ def extra_configs(dp, synthetic, device):
     other["note"] = ("hqs: the two-kernel ADMM iteration with DPX_TERM_NO_DUAL (no-dual row kernel, 20 B per pixel); admm_vxu: the same two kernels "
                      "with DPX_TERM_VXU (the planes carry q = u' - v); pgd: dpx_pgd_run (2 launches per iteration, 28 B per pixel); "
                      "768 x 1024 (the reference's example image): column length 3 x 256 on the register-radix path (fft_reg_x3), two-kernel "
-                     "iteration; 768 x 768: staged kernels (5 launches, 64 B per pixel).  hqs, admm_vxu, pgd and the 768 x 1024 ADMM run as two "
+                     "iteration; 768 x 768: two-kernel iteration, 384-point rows on one wave; 1000 x 1000: off the register-radix path -- size-generic in-place LDS transforms + merged z / rhs pass, 4 launches per iteration.  hqs, admm_vxu, pgd and the 768 x 1024 ADMM run as two "
                      "sub-batch chains on two streams like the headline (the staged kernels as one)")
     out["other_paths"] = other
     # ---- config 3: config 2's data term + deep_prior(FFDNet-colour, seeded weights), 30 iterations

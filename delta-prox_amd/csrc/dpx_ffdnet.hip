@@ -203,7 +203,8 @@ __device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[MT][NR], const float* _
 // not pay for 32 output rows.  Lane = (pixel or channel lane & 15, input channel lane >> 4 of the 4-group).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MT, bool RELU, bool MASKED = false, int NTAP = 9, bool RES = false, int DIL = 1, int NR = 2, bool M16 = false>
-__global__ void __launch_bounds__(256, 2) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
+// (MT = 3: 96 output channels x NR rows of fp32 accumulators per wave -- one wave per SIMD is what the register file holds; declared as such)
+__global__ void __launch_bounds__(256, (MT >= 3 ? 1 : 2)) k_conv3x3_mfma(const float* __restrict__ in, float* __restrict__ out,
                                                        const float* __restrict__ wpk, int Cin, int Cout, int H2, int W2, int tiles_x,
                                                        const float* __restrict__ mask, float slope) {
   // RELU epilogue: max(v, 0) + slope * min(v, 0) -- slope = 0: ReLU, 0.2: the U-Net's LeakyReLU (exact for either sign)

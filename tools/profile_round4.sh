@@ -23,7 +23,9 @@ python tools/bench_c5.py > $out/c5_steady_ab.log 2>&1
 python tools/bench_c5.py bf16 >> $out/c5_steady_ab.log 2>&1
 tools/c5_timeline.sh > /dev/null 2>&1; cp gpurun_out/c5tl/timeline.txt $out/c5_timeline.txt
 (python tools/bench_c4.py 4 32; DPX_CG_WAVE_FFT=2 python tools/bench_c4.py 4 32; DPX_CONV_TILE_ROWS=8 python tools/bench_c4.py 4) > $out/c4_ab.log 2>&1
-python tools/bench_shapes.py 8x3x1024x1024 8x3x768x1024 8x3x768x768 8x3x1024x768 1x3x768x1024 1x3x768x768 8x3x1000x1000 8x3x720x1280 > $out/plane_sizes.log 2>&1
+python tools/bench_shapes.py 8x3x1024x1024 8x3x768x1024 8x3x768x768 8x3x1024x768 1x3x768x1024 1x3x768x768 8x3x1000x1000 8x3x720x1280 8x3x640x640 8x3x500x500 4x3x1536x1536 8x3x1080x1920 > $out/plane_sizes.log 2>&1
+# planes off the register-radix path: per-kernel event times, second form of the size-generic transforms against the first, merged z / rhs pass
+for s in 8x3x1000x1000 8x3x720x1280 8x3x640x640; do python tools/prof_shape.py $s; DPX_GENERIC_INTERLEAVED=0 python tools/prof_shape.py $s; done > $out/generic_planes_kernels.log 2>&1
 python tools/bench_methods.py > $out/bench_methods.log 2>&1
 python tools/prof_c4.py 4 > $out/c4shard_events.log 2>&1
 head -6 $out/kernel_stats.csv; tail -c 400 $out/bench_steps20_warmup5.json; cat $out/plane_sizes.log
