@@ -484,7 +484,8 @@ __global__ void k_cols(float2* __restrict__ spec, SpecArgs A, int C, int H, int 
 // Measured (8 x 3 x 1000 x 1000, ADMM TV iteration): k_cols 363 -> 166 us, k_rows_r2c / c2r 165 / 155 -> 60 / 61 us, the iteration 0.91 ->
 // 0.52 ms.  Where the column pass's 166 us go (probes, same launch): load + operator + store without any pass 120 us (384 MB incl. the
 // denominators: 3.2 TB/s through 64-byte pieces at a 4008-byte stride), the passes alone 79 us; a wave-per-column form (no workgroup
-// barrier inside the passes) and a staggered start of the two workgroups of a CU were measured and change nothing.
+// barrier inside the passes) and a staggered start of the two workgroups of a CU were measured and change nothing; non-temporal
+// loads of the spectrum and data-spectrum values: 150 -> 166 us.
 // ---------------------------------------------------------------------------------------------
 constexpr int IL_NT = 512;        // threads per workgroup
 constexpr int IL_MAXE = 16;       // sequence elements per thread: N * CT <= IL_MAXE * IL_NT

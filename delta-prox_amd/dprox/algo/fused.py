@@ -556,8 +556,11 @@ class FusedADMM:
             for it in tqdm(range(T), disable=not pbar):
                 for i in range(n):
                     terms[i].lam = lam_tab[i][it].data_ptr()
-                ops.admm_zupdate(x, terms, n)
-                ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
+                if n > 0 and not ext and self.merge_z_rhs:           # v-update and right-hand side of the same iteration: one pass (the duals
+                    ops.admm_zupdate_rhs(x, terms, n, rhs, rho_tab[it], dual=False)      # it would write go to scratch: rhs from the incoming ones)
+                else:
+                    ops.admm_zupdate(x, terms, n)
+                    ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
                 ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x, spec_add=FK)
                 for i in range(n):
                     ops.lincomb([(1.0, u[i]), (-1.0, v[i]), (1.0, x)], out=u[i])

@@ -318,7 +318,7 @@ def case_merged_z_rhs(device, shapes=((2, 3, 40, 52), (1, 1, 33, 47), (2, 1, 30,
         gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=5 + H)
         b = T(b0, device)
         rhos = torch.linspace(0.5, 0.3, 5).repeat(B, 1) * torch.linspace(1.0, 1.4, B).view(B, 1)
-        for method in ("admm", "hqs"):
+        for method in ("admm", "hqs", "admm_vxu"):
             outs = {}
             for mode in ("merged", "staged", "op-by-op"):
                 x = dp.Variable()
@@ -336,6 +336,17 @@ def case_merged_z_rhs(device, shapes=((2, 3, 40, 52), (1, 1, 33, 47), (2, 1, 30,
             for k, (p, q) in enumerate(zip(flat(outs["merged"]), flat(outs["staged"]))):
                 assert torch.equal(p, q), f"{method} {B}x{C}x{H}x{W}: state tensor {k} of the merged pass differs by {float((p - q).abs().max())}"
             assert_close(outs["merged"][0].cpu(), outs["op-by-op"][0].cpu(), 2e-5, f"{method} {H}x{W}: merged z / rhs pass vs op by op")
+    # the entry refuses what it cannot do in one pass: a dual updated in place (its neighbours are read while it is written)
+    from dprox import _ops as ops, _backend as be
+    z = torch.zeros(1, 1, 8, 8, device=device)
+    v0, u0, rhs, rho = torch.zeros_like(z), torch.zeros_like(z), torch.zeros_like(z), torch.ones(1, device=device)
+    terms = ops.make_terms([dict(linop=1, prox=0, alpha=1.0, lam=rho, v=v0, u=u0)])
+    try:
+        ops.admm_zupdate_rhs(z, terms, 1, rhs, rho)
+    except be.DpxError as e:
+        assert "double-buffered" in str(e)
+    else:
+        raise AssertionError("dpx_admm_zupdate_rhs accepted an in-place dual")
 
 
 def case_w768_two_kernel(device, H=256, B=2, methods=("admm", "hqs", "admm_vxu")):
