@@ -169,7 +169,8 @@ __global__ void k_rhs(float* __restrict__ rhs, const float* __restrict__ ktb, co
 // ---------------------------------------------------------------------------------------------
 // z / dual update of iteration t AND the right-hand side of iteration t + 1 in one pass (planes off the two-kernel iteration):
 //   d = K_i x + u_i ; v_i = prox_i(d) ; u_i' = d - v_i ;  rhs = ktb + rho' sum_i K_i^T (v_i - u_i')
-// k_zupdate + k_rhs move 12 planes (x, u_i in; v_i, u_i' out; v_i, u_i' in again; rhs out: two gradient terms), this pass 8: the
+// k_zupdate + k_rhs move 12 planes (x, u_i in; v_i, u_i' out; v_i, u_i' in again; rhs out: two gradient terms), this pass 8 (6 without
+// the v stores, 4 with neither v nor dual stores: half-quadratic splitting): the
 // adjoint stencils need v - u' at the left / upper neighbour, which the thread RECOMPUTES from x and u there (cache hits: the
 // neighbour's own thread reads the same lines) instead of waiting for another thread's stores.  The incoming duals are therefore read
 // at neighbours while the outgoing ones are written: u must be double-buffered (terms[i].u_out != terms[i].u).  Same expressions in the
@@ -177,7 +178,7 @@ __global__ void k_rhs(float* __restrict__ rhs, const float* __restrict__ ktb, co
 // ---------------------------------------------------------------------------------------------
 template <int VEC>
 __global__ void k_zupdate_rhs(const float* __restrict__ x, float* __restrict__ rhs, const float* __restrict__ ktb,
-                              const float* __restrict__ rho, TermPack T, int dual, int B, int C, int H, int W) {
+                              const float* __restrict__ rho, TermPack T, int dual, int emit_v, int B, int C, int H, int W) {
   const int Wv = W / VEC;
   const long total = (long)B * C * H * Wv;
   bool need_w = false, need_h = false;
@@ -243,12 +244,14 @@ __global__ void k_zupdate_rhs(const float* __restrict__ x, float* __restrict__ r
         uu[e] = d - vv[e];
         y[e + 1] = vv[e] - (dual ? uu[e] : uin);            // (dual = 0: the duals are not advanced -- the next right-hand side sees the incoming ones)
       }
+      // (v is read by nobody inside the loop -- the next right-hand side is formed here -- and duals that are not advanced go nowhere:
+      //  emit_v = 0 / dual = 0 skip those stores; the caller's last z / dual stage, dpx_admm_zupdate, writes the final state)
       if constexpr (VEC == 4) {
-        *(float4*)(tm.v + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        *(float4*)(tm.u_out + off) = make_float4(uu[0], uu[1], uu[2], uu[3]);
+        if (emit_v) *(float4*)(tm.v + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (dual) *(float4*)(tm.u_out + off) = make_float4(uu[0], uu[1], uu[2], uu[3]);
       } else {
-        tm.v[off] = vv[0];
-        tm.u_out[off] = uu[0];
+        if (emit_v) tm.v[off] = vv[0];
+        if (dual) tm.u_out[off] = uu[0];
       }
       if (tm.linop == DPX_LIN_IDENTITY) {
 #pragma unroll
@@ -667,7 +670,7 @@ extern "C" int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, cons
 }
 
 extern "C" int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int nterms, float* rhs, const float* ktb, const float* rho_next,
-                                    int dual, int B, int C, int H, int W, dpx_stream_t stream) {
+                                    int dual, int emit_v, int B, int C, int H, int W, dpx_stream_t stream) {
   DPX_REQUIRE(x && rhs && rho_next && rhs != x && B > 0 && C > 0 && H > 0 && W > 0 && nterms > 0, "dpx_admm_zupdate_rhs: bad arguments");
   TermPack T;
   bool vec = (W % 4 == 0) && aligned16(x) && aligned16(rhs) && (!ktb || aligned16(ktb));
@@ -679,10 +682,10 @@ extern "C" int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int n
   const long n = (long)B * C * H * W;
   if (vec)
     DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<4>), dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T,
-               dual, B, C, H, W);
+               dual, emit_v, B, C, H, W);
   else
     DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T, dual,
-               B, C, H, W);
+               emit_v, B, C, H, W);
   return launch_status("dpx_admm_zupdate_rhs");
 }
 

@@ -130,7 +130,7 @@ SIGNATURES = {
     "dpx_fourier_apply_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dpx_admm_rhs": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_zupdate": (c_int, [c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dpx_admm_zupdate_rhs": (c_int, [c_void_p, POINTER(Term), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dpx_admm_zupdate_rhs": (c_int, [c_void_p, POINTER(Term), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dpx_admm_zupdate_bwd": (c_int, [c_void_p, POINTER(BwdTerm), c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_solve_rho_grad": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

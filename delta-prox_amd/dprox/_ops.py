@@ -566,11 +566,11 @@ def admm_zupdate(x, term_arr, nterms):
     be.lib().call("dpx_admm_zupdate", ptr(x), term_arr, nterms, B, C, H, W, be.stream())
 
 
-def admm_zupdate_rhs(x, term_arr, nterms, rhs, rho_next, dual=True, ktb=None):
+def admm_zupdate_rhs(x, term_arr, nterms, rhs, rho_next, dual=True, emit_v=True, ktb=None):
     """z / dual update of this iteration and the right-hand side of the next one in one pass (dpx_admm_zupdate_rhs: every term's dual is
-    double-buffered, u_out != u)"""
+    double-buffered, u_out != u; emit_v=False: v is not stored -- the loop's last stage must be admm_zupdate)"""
     B, C, H, W = _shape4(x)
-    be.lib().call("dpx_admm_zupdate_rhs", ptr(x), term_arr, nterms, ptr(rhs), ptr(ktb), ptr(rho_next), int(bool(dual)), B, C, H, W, be.stream())
+    be.lib().call("dpx_admm_zupdate_rhs", ptr(x), term_arr, nterms, ptr(rhs), ptr(ktb), ptr(rho_next), int(bool(dual)), int(bool(emit_v)), B, C, H, W, be.stream())
 
 
 # ----------------------------------------------------------------------------------------------

@@ -619,7 +619,7 @@ class FusedADMM:
                 ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
             ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x, spec_add=FK)
             if merged and it + 1 < T:
-                ops.admm_zupdate_rhs(x, terms, n, rhs, rho_tab[it + 1], dual=dual)
+                ops.admm_zupdate_rhs(x, terms, n, rhs, rho_tab[it + 1], dual=dual, emit_v=callback is not None)   # (v: only a callback looks at it before the last stage)
             else:
                 ops.admm_zupdate(x, terms, n)
             if merged and dual:

@@ -369,10 +369,11 @@ int dpx_admm_zupdate(const float* x, const dpx_term* terms, int nterms,
  * two gradient terms (the adjoint stencils recompute v - u' at the left / upper neighbour from x and u).  Closed-form proxes only;
  * every dual must be double-buffered (terms[i].u_out != terms[i].u); dual = 1: the right-hand side is formed from the updated duals
  * (ADMM: the caller swaps u / u_out), 0: from the incoming ones (half-quadratic splitting, algo/hqs.py: duals not advanced, u_out is
- * scratch).  Bit-identical v, u', rhs to the two calls
+ * scratch and is not written).  emit_v = 0: v_i is not stored either -- nothing inside the loop reads it (the next right-hand side is
+ * formed here); the caller's LAST z / dual stage is a dpx_admm_zupdate, which writes the final v_i, u_i.  Bit-identical v, u', rhs to the two calls
  * (algo/admm.py:49-59 -- the z / dual update -- followed by proxfn/sum_square.py:126-135 -- the next x-update's offset).           */
 int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int nterms, float* rhs, const float* ktb, const float* rho_next,
-                         int dual, int B, int C, int H, int W, dpx_stream_t stream);
+                         int dual, int emit_v, int B, int C, int H, int W, dpx_stream_t stream);
 
 /* ---- fused backward stages of the iteration (config 5, unrolled training; the reference uses PyTorch autograd through
  * the eager ops of algo/admm.py:49-59).  Per-image scalar gradients are reduced deterministically; `ws` has

@@ -336,6 +336,26 @@ def case_merged_z_rhs(device, shapes=((2, 3, 40, 52), (1, 1, 33, 47), (2, 1, 30,
             for k, (p, q) in enumerate(zip(flat(outs["merged"]), flat(outs["staged"]))):
                 assert torch.equal(p, q), f"{method} {B}x{C}x{H}x{W}: state tensor {k} of the merged pass differs by {float((p - q).abs().max())}"
             assert_close(outs["merged"][0].cpu(), outs["op-by-op"][0].cpu(), 2e-5, f"{method} {H}x{W}: merged z / rhs pass vs op by op")
+    # with a callback the merged pass stores v in every iteration (without one only the loop's last stage does): the states a callback sees
+    B, C, H, W = shapes[0]
+    gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=11)
+    b = T(b0, device)
+    seen = {}
+    for mode in ("merged", "staged"):
+        x = dp.Variable()
+        fns = dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
+        s = dp.compile(fns, method="admm", device=device)
+        log = seen[mode] = []
+        old = fused.FusedADMM.merge_z_rhs
+        fused.FusedADMM.merge_z_rhs = mode == "merged"
+        try:
+            s.solve(x0=b, rhos=0.3, lams=0.01, max_iter=4, callback=lambda iter, state, **kw: log.append([t.clone() for t in [state[0]] + list(state[1]) + list(state[2])]))
+        finally:
+            fused.FusedADMM.merge_z_rhs = old
+    assert len(seen["merged"]) == len(seen["staged"]) == 4
+    for it, (pa, qa) in enumerate(zip(seen["merged"], seen["staged"])):
+        for k, (p, q) in enumerate(zip(pa, qa)):
+            assert torch.equal(p, q), f"callback state {k} of iteration {it}: merged pass differs by {float((p - q).abs().max())}"
     # the entry refuses what it cannot do in one pass: a dual updated in place (its neighbours are read while it is written)
     from dprox import _ops as ops, _backend as be
     z = torch.zeros(1, 1, 8, 8, device=device)
