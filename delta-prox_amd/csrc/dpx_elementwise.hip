@@ -224,8 +224,12 @@ __global__ void k_zupdate_rhs(const float* __restrict__ x, float* __restrict__ r
     for (int t = 0; t < T.n; ++t) {
       const dpx_term tm = T.t[t];
       const float lam = tm.lam ? tm.lam[b] * tm.alpha : 0.f;
+      const bool nodual = tm.reserved & DPX_TERM_NO_DUAL;      // half-quadratic splitting: the incoming duals are zero and are not fetched
       float uu[VEC], vv[VEC];
-      if constexpr (VEC == 4) {
+      if (nodual) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) uu[e] = 0.f;
+      } else if constexpr (VEC == 4) {
         const float4 q = *(const float4*)(tm.u + off);
         uu[0] = q.x; uu[1] = q.y; uu[2] = q.z; uu[3] = q.w;
       } else {
@@ -257,7 +261,7 @@ __global__ void k_zupdate_rhs(const float* __restrict__ x, float* __restrict__ r
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] += y[e + 1];
       } else if (tm.linop == DPX_LIN_GRAD_W) {
-        const float uin = tm.u[left];
+        const float uin = nodual ? 0.f : tm.u[left];
         const float d = (xv[0] - xl) + uin;                              // the left neighbour's own update, recomputed
         const float vl = prox_eval(tm.prox, d, lam);
         const float ul = d - vl;
@@ -266,7 +270,10 @@ __global__ void k_zupdate_rhs(const float* __restrict__ x, float* __restrict__ r
         for (int e = 0; e < VEC; ++e) acc[e] += y[e] - y[e + 1];
       } else {
         float ua[VEC], yu[VEC];
-        if constexpr (VEC == 4) {
+        if (nodual) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) ua[e] = 0.f;
+        } else if constexpr (VEC == 4) {
           const float4 q = *(const float4*)(tm.u + offu);
           ua[0] = q.x; ua[1] = q.y; ua[2] = q.z; ua[3] = q.w;
         } else {
@@ -679,6 +686,8 @@ extern "C" int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int n
   for (int i = 0; i < nterms; ++i)
     DPX_REQUIRE(terms[i].prox != DPX_PROX_EXTERNAL && terms[i].u_out && terms[i].u_out != terms[i].u,
                 "dpx_admm_zupdate_rhs: term %d needs a closed-form prox and a double-buffered dual (u_out != u)", i);
+  for (int i = 0; i < nterms; ++i)
+    DPX_REQUIRE(!(terms[i].reserved & DPX_TERM_NO_DUAL) || !dual, "dpx_admm_zupdate_rhs: DPX_TERM_NO_DUAL (term %d) excludes dual = 1", i);
   const long n = (long)B * C * H * W;
   if (vec)
     DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<4>), dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T,

@@ -608,6 +608,9 @@ class FusedADMM:
         # (dpx_admm_zupdate_rhs: 8 instead of 12 plane passes; it reads duals at neighbouring pixels, so the duals alternate between two
         # sets of buffers -- half-quadratic splitting's are write-only scratch already)
         merged = n > 0 and not ext and self.merge_z_rhs
+        if merged and not dual:                                      # half-quadratic splitting: the duals are zero -- the merged pass need not fetch them
+            for i in range(n):
+                terms[i].reserved = be.TERM_NO_DUAL
         if merged and dual:
             u_alt = [torch.empty_like(t) for t in u]
             for i in range(n):

@@ -335,7 +335,7 @@ typedef struct dpx_term {
   int32_t linop;    /* DPX_LIN_* */
   int32_t prox;     /* DPX_PROX_* */
   float alpha;      /* lam multiplier (`alpha * fn`, proxfn/base.py:78-82) */
-  int32_t reserved; /* flags: DPX_TERM_NO_DUAL (dpx_admm_iter_rows / dpx_admm_run only; 0 elsewhere) */
+  int32_t reserved; /* flags: DPX_TERM_NO_DUAL (dpx_admm_iter_rows / dpx_admm_run / dpx_admm_zupdate_rhs; ignored elsewhere) */
   const float* lam; /* device [B] */
   float* v;         /* state v_i [B,C,H,W] */
   float* u;         /* state u_i [B,C,H,W] */
@@ -369,7 +369,7 @@ int dpx_admm_zupdate(const float* x, const dpx_term* terms, int nterms,
  * two gradient terms (the adjoint stencils recompute v - u' at the left / upper neighbour from x and u).  Closed-form proxes only;
  * every dual must be double-buffered (terms[i].u_out != terms[i].u); dual = 1: the right-hand side is formed from the updated duals
  * (ADMM: the caller swaps u / u_out), 0: from the incoming ones (half-quadratic splitting, algo/hqs.py: duals not advanced, u_out is
- * scratch and is not written).  emit_v = 0: v_i is not stored either -- nothing inside the loop reads it (the next right-hand side is
+ * scratch and is not written; with DPX_TERM_NO_DUAL on a term its incoming dual counts as zero and is not fetched).  emit_v = 0: v_i is not stored either -- nothing inside the loop reads it (the next right-hand side is
  * formed here); the caller's LAST z / dual stage is a dpx_admm_zupdate, which writes the final v_i, u_i.  Bit-identical v, u', rhs to the two calls
  * (algo/admm.py:49-59 -- the z / dual update -- followed by proxfn/sum_square.py:126-135 -- the next x-update's offset).           */
 int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int nterms, float* rhs, const float* ktb, const float* rho_next,

@@ -26,4 +26,4 @@ r = report(); L.call("dpx_timing_enable", 0)
 tot = sum(t for _, t in r.values())
 print(f"{B}x{C}x{H}x{W}: kernels {tot / 20:.4f} ms per iteration (20 iterations), path {s.last_path}")
 for k, (c, t) in sorted(r.items(), key=lambda kv: -kv[1][1]):
-    print(f"  {k:24s} x{c:4d}  avg {1e3 * t / c:8.1f} us  total {t:8.3f} ms  = {1e9 * t / c / (B * C * H * W) * 1e3:6.2f} ps/pixel")
+    print(f"  {k:24s} x{c:4d}  avg {1e3 * t / c:8.1f} us  total {t:8.3f} ms  = {1e9 * t / c / (B * C * H * W):6.2f} ps/pixel")
