@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Iterations/s of every compile() method on the config-2 problem (8x3x1024x1024 TV deconvolution), GPU only."""
+"""Iterations/s of every compile() method on the config-2 problem (8x3x1024x1024 TV deconvolution; another BxCxHxW as argument), GPU only."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "delta-prox_amd")]
@@ -7,7 +7,9 @@ import torch
 import dprox as dp
 import synthetic
 dev = torch.device("cuda")
-gt, b, psf = synthetic.deconv_case(8, 3, 1024, 1024, seed=2023)
+shape = tuple(int(v) for v in sys.argv[1].split("x")) if len(sys.argv) > 1 else (8, 3, 1024, 1024)
+gt, b, psf = synthetic.deconv_case(*shape, seed=2023)
+print("x".join(map(str, shape)))
 bt = torch.from_numpy(b).to(dev)
 for method in ("admm", "admm_vxu", "ladmm", "hqs", "pc", "pgd"):
     x = dp.Variable()
