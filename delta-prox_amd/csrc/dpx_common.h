@@ -303,6 +303,20 @@ struct SpecArgs {
 int spectral_apply(const float* x, float* y, int op, const SpecArgs& a, int B, int C, int H, int W,
                    const void* table, void* ws, hipStream_t stream);
 
+// Stencil passes: the hardware deals workgroup i to XCD i % 8, so neighbouring rows of a plane -- handled by neighbouring workgroups --
+// land in eight different L2s and every halo row crosses the fabric again (k_zupdate_rhs, 8 x 3 x 1000 x 1000, FETCH_SIZE: 582 MB for 288 MB
+// of operands = x thrice, u_0 twice).  xcd_block() renumbers the workgroups of a launch whose size is a multiple of 8 so that every XCD
+// walks ONE contiguous eighth of the data: vertical neighbours are then in flight on the same XCD at the same time and hit its L2.
+__device__ __forceinline__ unsigned xcd_block() {
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  return (nb & 7u) ? b : (b & 7u) * (nb >> 3) + (b >> 3);
+}
+static inline int grid_for8(long n, int block, int cap = 256 * 8) {      // grid_for, rounded up to a multiple of 8 (xcd_block)
+  long g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)((g + 7) & ~7L);
+}
 static inline int grid_for(long n, int block, int cap = 256 * 8) {
   long g = (n + block - 1) / block;
   if (g > cap) g = cap;

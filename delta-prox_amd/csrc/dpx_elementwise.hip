@@ -40,7 +40,7 @@ template <int VEC>
 __global__ void k_zupdate(const float* __restrict__ x, TermPack T, int B, int C, int H, int W) {
   const int Wv = W / VEC;
   const long total = (long)B * C * H * Wv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)xcd_block() * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int wv = (int)(i % Wv);
     const long row = i / Wv;                 // (b*C + c)*H + h
     const int h = (int)(row % H);
@@ -116,7 +116,7 @@ __global__ void k_rhs(float* __restrict__ rhs, const float* __restrict__ ktb, co
                       int B, int C, int H, int W) {
   const int Wv = W / VEC;
   const long total = (long)B * C * H * Wv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)xcd_block() * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int wv = (int)(i % Wv);
     const long row = i / Wv;
     const int h = (int)(row % H);
@@ -186,7 +186,7 @@ __global__ void k_zupdate_rhs(const float* __restrict__ x, float* __restrict__ r
     need_w |= T.t[t].linop == DPX_LIN_GRAD_W;
     need_h |= T.t[t].linop == DPX_LIN_GRAD_H;
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)xcd_block() * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int wv = (int)(i % Wv);
     const long row = i / Wv;                 // (b*C + c)*H + h
     const int h = (int)(row % H);
@@ -304,7 +304,7 @@ __global__ void k_zupdate_rhs(const float* __restrict__ x, float* __restrict__ r
 // ---------------------------------------------------------------------------------------------
 __global__ void k_grad(const float* __restrict__ x, float* __restrict__ y, int dim, int adjoint, long planes, int H, int W) {
   const long total = planes * H * W;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)xcd_block() * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int w = (int)(i % W);
     const long row = i / W;
     const int h = (int)(row % H);
@@ -655,9 +655,9 @@ extern "C" int dpx_admm_zupdate(const float* x, const dpx_term* terms, int nterm
   if (nterms == 0) return DPX_OK;
   const long n = (long)B * C * H * W;
   if (vec)
-    DPX_LAUNCH("k_zupdate", (k_zupdate<4>), dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, T, B, C, H, W);
+    DPX_LAUNCH("k_zupdate", (k_zupdate<4>), dim3(grid_for8(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, T, B, C, H, W);
   else
-    DPX_LAUNCH("k_zupdate", (k_zupdate<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, T, B, C, H, W);
+    DPX_LAUNCH("k_zupdate", (k_zupdate<1>), dim3(grid_for8(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, T, B, C, H, W);
   return launch_status("dpx_admm_zupdate");
 }
 
@@ -670,9 +670,9 @@ extern "C" int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, cons
   if (rc) return rc;
   const long n = (long)B * C * H * W;
   if (vec)
-    DPX_LAUNCH("k_rhs", (k_rhs<4>), dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, rho, T, B, C, H, W);
+    DPX_LAUNCH("k_rhs", (k_rhs<4>), dim3(grid_for8(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, rho, T, B, C, H, W);
   else
-    DPX_LAUNCH("k_rhs", (k_rhs<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, rho, T, B, C, H, W);
+    DPX_LAUNCH("k_rhs", (k_rhs<1>), dim3(grid_for8(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, rho, T, B, C, H, W);
   return launch_status("dpx_admm_rhs");
 }
 
@@ -690,10 +690,10 @@ extern "C" int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int n
     DPX_REQUIRE(!(terms[i].reserved & DPX_TERM_NO_DUAL) || !dual, "dpx_admm_zupdate_rhs: DPX_TERM_NO_DUAL (term %d) excludes dual = 1", i);
   const long n = (long)B * C * H * W;
   if (vec)
-    DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<4>), dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T,
+    DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<4>), dim3(grid_for8(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T,
                dual, emit_v, B, C, H, W);
   else
-    DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T, dual,
+    DPX_LAUNCH("k_zupdate_rhs", (k_zupdate_rhs<1>), dim3(grid_for8(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, rhs, ktb, rho_next, T, dual,
                emit_v, B, C, H, W);
   return launch_status("dpx_admm_zupdate_rhs");
 }
@@ -703,7 +703,7 @@ extern "C" int dpx_grad(const float* x, float* y, int dim, int adjoint, int B, i
   DPX_REQUIRE(dim == 0 || dim == 1, "dpx_grad: dim must be 0 (H) or 1 (W)");
   DPX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dpx_grad: bad shape");
   const long n = (long)B * C * H * W;
-  DPX_LAUNCH("k_grad", k_grad, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, dim, adjoint, (long)B * C, H, W);
+  DPX_LAUNCH("k_grad", k_grad, dim3(grid_for8(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, dim, adjoint, (long)B * C, H, W);
   return launch_status("dpx_grad");
 }
 

@@ -31,7 +31,7 @@ template <int MODE>
 __global__ void k_split_rhs(float* __restrict__ rhs, const float* __restrict__ ktb, const float* __restrict__ x, const float* __restrict__ rho,
                             SplitPack T, int B, int C, int H, int W) {
   const long total = (long)B * C * H * W;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)xcd_block() * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {      // (XCD-contiguous rows: dpx_common.h)
     const int w = (int)(i % W);
     long r = i / W;
     const int h = (int)(r % H);
@@ -79,7 +79,7 @@ __global__ void k_split_rhs(float* __restrict__ rhs, const float* __restrict__ k
 // Pock-Chambolle dual step, in place on z_i (terms[i].v):  z += r K_i xbar ;  z -= r prox_i(z, r * alpha)   with r = lam_i[b]
 __global__ void k_pc_dual(const float* __restrict__ xbar, SplitPack T, int B, int C, int H, int W) {
   const long total = (long)B * C * H * W;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)xcd_block() * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {      // (XCD-contiguous rows: dpx_common.h)
     const int w = (int)(i % W);
     long r = i / W;
     const int h = (int)(r % H);
@@ -125,9 +125,9 @@ extern "C" int dpx_split_rhs(float* rhs, const float* ktb, const float* x, const
   if (rc) return rc;
   const long n = (long)B * C * H * W;
   if (mode == 0)
-    DPX_LAUNCH("k_split_rhs", (k_split_rhs<0>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, x, rho, P, B, C, H, W);
+    DPX_LAUNCH("k_split_rhs", (k_split_rhs<0>), dim3(grid_for8(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, x, rho, P, B, C, H, W);
   else
-    DPX_LAUNCH("k_split_rhs", (k_split_rhs<1>), dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, x, rho, P, B, C, H, W);
+    DPX_LAUNCH("k_split_rhs", (k_split_rhs<1>), dim3(grid_for8(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, ktb, x, rho, P, B, C, H, W);
   return launch_status("dpx_split_rhs");
 }
 
@@ -137,6 +137,6 @@ extern "C" int dpx_pc_dual(const float* xbar, const dpx_term* terms, int nterms,
   const int rc = split_pack(P, terms, nterms, 0, "dpx_pc_dual");
   if (rc) return rc;
   for (int i = 0; i < nterms; ++i) DPX_REQUIRE(terms[i].prox >= DPX_PROX_NORM1 && terms[i].prox <= DPX_PROX_SUMSQ, "dpx_pc_dual: closed-form proxes only");
-  DPX_LAUNCH("k_pc_dual", k_pc_dual, dim3(grid_for((long)B * C * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream, xbar, P, B, C, H, W);
+  DPX_LAUNCH("k_pc_dual", k_pc_dual, dim3(grid_for8((long)B * C * H * W, 256, 8192)), dim3(256), 0, (hipStream_t)stream, xbar, P, B, C, H, W);
   return launch_status("dpx_pc_dual");
 }
