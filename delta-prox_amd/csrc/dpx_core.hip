@@ -150,7 +150,7 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"seed_band", "DPX_SEED_BAND", 0, nullptr},
     {"seed_rows_plain", "DPX_SEED_ROWS", 0, "plain"},
     {"iter_w2048", "DPX_ITER_W2048", 0, nullptr},
-    {"iter_rows", "DPX_ITER_ROWS", 0, "seq,lockstep"},
+    {"iter_rows", "DPX_ITER_ROWS", 0, "seq,lockstep,par"},
     {"iter_band", "DPX_ITER_BAND", 0, nullptr},
     {"iter_r", "DPX_ITER_R", 0, nullptr},
     {"cols_inplace", "DPX_COLS_INPLACE", 0, nullptr},
@@ -174,6 +174,9 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"unroll_bwd_band", "DPX_UNROLL_BWD_BAND", 0, nullptr},
     {"wgrad_f32", "DPX_WGRAD_F32", 0, nullptr},
     {"generic_interleaved", "DPX_GENERIC_INTERLEAVED", 1, nullptr},
+    {"iter_band_min_rows", "DPX_ITER_BAND_MIN_ROWS", 0, nullptr},
+    {"cols_wg", "DPX_COLS_WG_COLS", 0, nullptr},
+    {"iter_par_max_rows", "DPX_ITER_PAR_MAX_ROWS", 0, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

@@ -834,6 +834,11 @@ static void cols_dispatch(int H, const float2* spec, float2* spec_out, const Spe
       return;
     }
   }
+  if constexpr (OP == OP_SOLVE && COLS_WG == 8) {
+    // launches of a few planes: 4-column workgroups of 256 threads (one wave per SIMD, twice the workgroups); knob cols_wg
+    const int wgk = tune(TUNE_COLS_WG);
+    if (H == 1024 && wgk == 4) { launch_cols<1024, 64, 4, OP>(spec, spec_out, A, P, C, Ws, twH, s); return; }
+  }
   switch (H) {
     case 256: launch_cols<256, 32, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
     case 512: launch_cols<512, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;

@@ -27,40 +27,9 @@
 #define DPX_PK_ASM 0
 #endif
 #include "dpx_fft_reg.h"
+#include "dpx_iter_dev.h"
 
 namespace dpx {
-
-struct IterTerm {
-  int linop, prox;
-  float alpha;
-  const float* lam;
-  const float* u_in;
-  float* u_out;
-  float* v_out;
-};
-struct IterTerms {
-  IterTerm t[DPX_MAX_TERMS];
-  int n;
-  float dual;          // 1: ADMM.  0: half-quadratic splitting (DPX_TERM_NO_DUAL) -- the incoming duals count as zero and the right-hand side
-                       // sees v_i alone; applied as fma(dual, u, K x) / fma(-dual, u', v): the same instructions, and exact for dual = 1
-  int emit_bf16;       // x_out / v_out / rhs_out are bf16 planes (the bf16 history of the unrolled forward pass) instead of fp32
-  int vxu;             // 1: ADMM in the order v, x, u (DPX_TERM_VXU, algo/admm.py:103-120) -- the stream in `u` carries q = u' - v (u' = -u):
-                       // t = q + x, d = K x + t, v = prox(d), q' = t - v goes out, the next right-hand side sees v - t
-  int u_live;          // 0: the incoming duals are all zero (DPX_TERM_U_ZERO, first iteration after ADMM.initialize) -- the streaming kernel then
-                       // fetches every u row from row 0 of plane 0 (cache hits) instead of streaming the planes from HBM, the lock-step
-                       // kernel does not load them at all
-  float* rhs_out;      // nullable: the next x-update's right-hand-side increment rho' sum K_i^T (v_i - u_i) as an image (the unrolled
-                       // forward pass keeps it for the backward pass); like x_out / v_out an emit store, never counted in the waits
-};
-
-__device__ __forceinline__ float prox1(int kind, float d, float lam) {
-  if (kind == DPX_PROX_NORM1) {
-    const float m = fmaxf(fabsf(d) - lam, 0.f);
-    return d > 0.f ? m : (d < 0.f ? -m : 0.f * m);
-  }
-  if (kind == DPX_PROX_NONNEG) return fmaxf(d, 0.f);
-  return d / (1.f + 2.f * lam);
-}
 
 // M = W/2 complex points per row, T threads per row, SPB = 256/T rows in flight per workgroup, NT terms.
 // Global loads are issued one phase ahead of their use (u rows at the top of phase A, the next spectrum row at
@@ -328,19 +297,7 @@ static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& T
 // next: 2 x 100 MB at 8x3x1024^2, which the 256 MB Infinity Cache can hold); the dual variables come back a whole iteration
 // later and the data spectrum is re-read once per iteration -- streaming those past the caches (`nt`) leaves the cache to the
 // spectra.  Measured (12-variant matrix, gpurun_out/ab3.log): all plain 4692 it/s, this setting 5147 it/s.
-#ifndef DPX_R_LDX
-#define DPX_R_LDX 0
-#endif
-#ifndef DPX_R_LDU
-#define DPX_R_LDU 1
-#endif
-#ifndef DPX_R_STU
-#define DPX_R_STU 2
-#endif
-#ifndef DPX_R_STX
-#define DPX_R_STX 1       // the spectrum handed to the next kernel: write-through (`sc1`), nothing left dirty at the kernel boundary (+0.5 ... 1 %)
-#endif
-constexpr int R_LDX = DPX_R_LDX, R_LDU = DPX_R_LDU, R_STU = DPX_R_STU, R_STX = DPX_R_STX;
+// (DPX_R_LDX / _LDU / _STU / _STX and the constants R_LDX ... R_STX: dpx_iter_dev.h)
 // DUAL = false: half-quadratic splitting (TT.dual == 0, DPX_TERM_NO_DUAL) -- the duals are neither fetched nor stored (the general
 // kernel streams 16 of its 24 B per element for planes nobody reads: 36 -> 20 B per element and iteration with the column kernel);
 // every wait count below is the general one with the dual streams' operations taken out (NU = 0 terms with a dual).
@@ -554,8 +511,7 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
         }
         float2 v[V];
         if (tm.prox == DPX_PROX_NORM1) {
-#pragma unroll
-          for (int m = 0; m < V; ++m) v[m] = make_float2(prox1(DPX_PROX_NORM1, d[m].x, lam), prox1(DPX_PROX_NORM1, d[m].y, lam));
+          soft_threshold_pairs<V>(d, v, lam);
         } else if (tm.prox == DPX_PROX_NONNEG) {
 #pragma unroll
           for (int m = 0; m < V; ++m) v[m] = make_float2(fmaxf(d[m].x, 0.f), fmaxf(d[m].y, 0.f));
@@ -1113,7 +1069,7 @@ extern "C" int dpx_admm_iter_share(int chains) {
   return DPX_OK;
 }
 extern "C" int dpx_admm_iter_config(int rows_mode, int bands_per_plane) {
-  DPX_REQUIRE(rows_mode >= 0 && rows_mode <= 2 && bands_per_plane >= 0, "dpx_admm_iter_config: bad arguments");
+  DPX_REQUIRE(rows_mode >= 0 && rows_mode <= 3 && bands_per_plane >= 0, "dpx_admm_iter_config: bad arguments");
   g_rows_mode = rows_mode;
   g_rows_band = bands_per_plane;
   dpx::g_rows_mode_pgd = rows_mode;                      // (dpx_pgd_run's row pass follows the same switch: 2 = the plain kernel)
@@ -1202,8 +1158,12 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   // Streaming kernel (one T-lane group per band): bands as long as possible while still >= ~2 waves per SIMD-pair
   // of the chip; DPX_ITER_ROWS=lockstep keeps the ring-buffer kernel (A/B timing), DPX_ITER_BAND overrides the number of bands per plane.
   const int mode_knob = tune(TUNE_ITER_ROWS), band_env0 = tune(TUNE_ITER_BAND);
-  const char* mode_env = mode_knob == 1 ? "seq" : (mode_knob == 2 ? "lockstep" : nullptr);
-  const char* mode = g_rows_mode > 0 ? (g_rows_mode == 1 ? "seq" : "lockstep") : (g_rows_mode == 0 ? nullptr : mode_env);
+  const char* mode_env = mode_knob == 1 ? "seq" : (mode_knob == 2 ? "lockstep" : (mode_knob == 3 ? "par" : nullptr));
+  const char* mode = g_rows_mode > 0 ? (g_rows_mode == 1 ? "seq" : (g_rows_mode == 2 ? "lockstep" : "par")) : (g_rows_mode == 0 ? nullptr : mode_env);
+  // launches of a few planes: the rows of a band side by side (dpx_iter_par.hip; bit-identical to the streaming kernel)
+  if (!mode || !strcmp(mode, "par")) {
+    if (launch_iter_rows_par(sin, sout, TT, rho_next, x_out, emit_v, C, H, W, P, tw, s, mode != nullptr)) return launch_status("dpx_admm_iter_rows");
+  }
   const int band_env = g_rows_band >= 0 ? g_rows_band : band_env0;
   // (small launches -- a few 256-wide planes -- are latency-bound: the ring-buffer kernel's row-parallel bands finish ~10 %
   //  sooner there than the streaming kernel's sequential ones; measured crossover between 256- and 512-wide planes)
@@ -1222,7 +1182,10 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
       nb = p2;
     }
     if (band_env) nb = band_env;
-    if (nb > H / 4) nb = H / 4;
+    // shortest band: 4 rows (halo = 2 extra inverse transforms per band); knob iter_band_min_rows
+    const int min_rows_knob = tune(TUNE_ITER_BAND_MIN_ROWS);
+    const int min_rows = min_rows_knob > 0 ? min_rows_knob : 4;
+    if (nb > H / min_rows) nb = H / min_rows;
     while (nb > 1 && (P * nb) % per_block) --nb;
     if (nb >= 1 && (P * nb) % per_block == 0) {
       switch (W) {

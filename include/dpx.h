@@ -67,8 +67,12 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        row kernel (bit-identical across band counts)
  *   pgd_rows_plain,      1 = the plain (non-streaming) row kernels                        DPX_PGD_ROWS=plain,
  *   seed_rows_plain                                                                       DPX_SEED_ROWS=plain
- *   iter_rows            1 = streaming row kernel, 2 = lock-step ring-buffer kernel       DPX_ITER_ROWS=seq|lockstep
- *                        (dpx_admm_iter_config overrides)
+ *   iter_rows            1 = streaming row kernel, 2 = lock-step ring-buffer kernel,      DPX_ITER_ROWS=seq|lockstep|par
+ *                        3 = row-parallel kernel (k_iter_rows_par: the rows of a band side by
+ *                        side in one 16-wave workgroup; 256 / 512 / 1024-wide rows)
+ *                        (dpx_admm_iter_config overrides); 1 and 3 are bit-identical
+ *   iter_par_max_rows    launches of at most this many rows (planes x H) take the row-parallel      DPX_ITER_PAR_MAX_ROWS
+ *                        kernel (0 = the library's rule, 8192; < 0 = never)
  *   iter_band, iter_r    bands per plane (streaming) / rows per band (lock-step)          DPX_ITER_BAND, DPX_ITER_R
  *   iter_w2048           1 = keep 2048-wide planes on the two-kernel iteration            DPX_ITER_W2048
  *   cols_inplace         1 = column pass in place                                         DPX_COLS_INPLACE
@@ -107,6 +111,12 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        k_rows_c2r_il: a row per one-wave workgroup); 0 = one LDS line per sequence, two buffers
  *                        (k_rows_r2c / k_cols / k_rows_c2r); 2 / 3 = rows / columns only on the new form, 4 = rows
  *                        eight to a 512-thread workgroup (A/B; all settings give bit-identical results)
+ *   iter_band_min_rows   shortest band (rows) the streaming row kernel of the two-kernel iteration may     DPX_ITER_BAND_MIN_ROWS
+ *                        use when few planes must fill the chip (0 = the library's rule: 4 rows, 2 for launches
+ *                        of fewer than 8 planes of 1024-wide rows; bit-identical across band counts)
+ *   cols_wg              columns per workgroup of k_cols_p2 on 1024-row planes: 8 (512 threads), 4 (256      DPX_COLS_WG_COLS
+ *                        threads, twice the workgroups: launches of a few planes), 0 = by the number of
+ *                        planes (bit-identical)
  *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
  *                        tools/ only)
  */
@@ -482,7 +492,8 @@ int dpx_admm_iter_rows(const void* spec_in, void* spec_out, const dpx_term* term
 int dpx_split_rhs(float* rhs, const float* ktb, const float* x, const float* rho, const dpx_term* terms, int nterms, int mode,
                   int B, int C, int H, int W, dpx_stream_t stream);
 int dpx_pc_dual(const float* xbar, const dpx_term* terms, int nterms, int B, int C, int H, int W, dpx_stream_t stream);
-/* test / tuning hook: rows_mode 0 automatic, 1 streaming row kernel, 2 lock-step row kernel; bands_per_plane 0 = automatic */
+/* test / tuning hook: rows_mode 0 automatic, 1 streaming row kernel, 2 lock-step row kernel, 3 row-parallel kernel (launches of a few
+ * planes; bit-identical to 1); bands_per_plane 0 = automatic */
 int dpx_admm_iter_config(int rows_mode, int bands_per_plane);
 /* tuning hint: the following dpx_admm_* calls are one of `chains` sub-batch chains of a solve that run concurrently on separate
  * streams (the images of a batch never exchange data, algo/admm.py:49-59 acts per image): band lengths are chosen for the planes

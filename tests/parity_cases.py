@@ -1825,6 +1825,57 @@ def case_sub_batch_chains(device, shapes=((4, 1, 256, 256),), iters=13, methods=
             os.environ["DPX_CHAINS"] = old
 
 
+def case_row_parallel_kernel(device, shapes=((1, 2, 256, 256),), iters=5, methods=("admm", "hqs", "admm_vxu"), nterms_list=(2, 3, 4), hfirst=(True, False)):
+    """The row-parallel kernel of launches with few planes (k_iter_rows_par, dpx_iter_par.hip: the rows of a band transformed side by
+    side in one 16-wave workgroup, stencil neighbours through LDS) against the streaming band walker (k_iter_rows_seq): BIT-identical
+    full states, x-only results and callback runs -- ADMM, half-quadratic splitting (no-dual instantiation) and the v, x, u order; two
+    to four terms, the grad_H term first or behind the others (the accumulation order of the K^T terms is the streaming kernel's:
+    terms behind grad_H wait for phase C), per-image rho schedules, ragged bands (H not a multiple of the workgroup's own rows)."""
+    import synthetic
+    from dprox import _backend as be
+    L = be.lib()
+    try:
+        for (B, C, H, W) in shapes:
+            gt, b0, psf = synthetic.deconv_case(B, C, H, W, seed=61 + W + B)
+            b = T(b0, device)
+            rhos = torch.linspace(0.5, 0.2, iters)[None, :] * torch.linspace(1.0, 1.3, B)[:, None]
+            for method in methods:
+                for nterms in nterms_list:
+                    for hf in hfirst:
+                        def run(mode, kind):
+                            L.call("dpx_admm_iter_config", mode, 0)
+                            x = dp.Variable()
+                            gh, gw = dp.norm1(dp.grad(x, dim=0)), dp.norm1(dp.grad(x, dim=1))
+                            fns = dp.sum_squares(dp.conv(x, psf) - b) + (gh + gw if hf else gw + gh)
+                            if nterms >= 3:
+                                fns = fns + dp.nonneg(x)
+                            if nterms >= 4:
+                                fns = fns + dp.norm1(x) * 0.5
+                            if not hf and nterms >= 3:        # grad_H last: every other term in front of it
+                                fns = dp.sum_squares(dp.conv(x, psf) - b) + gw + dp.nonneg(x) + (dp.norm1(x) * 0.5 + gh if nterms >= 4 else gh)
+                            s = dp.compile(fns, method=method, device=device)
+                            kw = dict(x0=b, rhos=rhos, lams=0.01, max_iter=iters)
+                            if kind == "full":
+                                st = s.solve(return_full_states=True, **kw)
+                                out = [st[0]] + list(st[1]) + (list(st[2]) if len(st) > 2 else [])
+                            elif kind == "x":
+                                out = [s.solve(**kw)]
+                            else:
+                                seen = []
+                                s.solve(callback=lambda **k: seen.append(k["state"][0].clone()), **kw)
+                                out = seen
+                            assert s.last_path == "fused"
+                            return out
+                        for kind in ("full", "x", "callback"):
+                            seq, par = run(1, kind), run(3, kind)
+                            assert len(seq) == len(par)
+                            for a, c in zip(seq, par):
+                                assert torch.equal(a, c), ("row-parallel kernel differs from the streaming kernel", (B, C, H, W), method, nterms, hf, kind,
+                                                           float((a - c).abs().max()))
+    finally:
+        L.call("dpx_admm_iter_config", 0, 0)
+
+
 def case_hqs_nodual_kernel(device, shapes=((1, 2, 256, 256),), iters=4, nterms_list=(1, 2, 3, 4)):
     """Half-quadratic splitting on the streaming row kernel's no-dual variant (k_iter_rows_seq<..., DUAL = false>: the duals are
     neither fetched nor stored, its wait counts are the general kernel's minus the dual streams) against the lock-step ring-buffer

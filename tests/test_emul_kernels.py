@@ -264,3 +264,7 @@ def test_leaky_conv_layer_vs_torch():
     ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
     got = ops.conv2d_leaky(x, blob, 32, 0.2)
     assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_row_parallel_kernel_is_bit_identical_to_the_streaming_kernel():
+    pc.case_row_parallel_kernel(DEV, shapes=((1, 2, 256, 256),), iters=3, methods=("admm", "hqs", "admm_vxu"), nterms_list=(2, 4), hfirst=(True, False))

@@ -584,3 +584,7 @@ def test_chain_streams_are_probed_for_overlap_and_missing_ones_fall_back():
     finally:
         fused._concurrent_side_streams = real
     assert torch.equal(ref, one)
+
+
+def test_row_parallel_kernel_is_bit_identical_to_the_streaming_kernel():
+    pc.case_row_parallel_kernel(DEV, shapes=((1, 2, 256, 256), (2, 1, 512, 512), (1, 3, 1024, 1024), (3, 1, 384, 1024)))
