@@ -149,7 +149,6 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"pgd_rows_plain", "DPX_PGD_ROWS", 0, "plain"},
     {"seed_band", "DPX_SEED_BAND", 0, nullptr},
     {"seed_rows_plain", "DPX_SEED_ROWS", 0, "plain"},
-    {"iter_w2048", "DPX_ITER_W2048", 0, nullptr},
     {"iter_rows", "DPX_ITER_ROWS", 0, "seq,lockstep,par"},
     {"iter_band", "DPX_ITER_BAND", 0, nullptr},
     {"iter_r", "DPX_ITER_R", 0, nullptr},

@@ -395,6 +395,19 @@ constexpr int COLS_LD_NT = DPX_COLS_LD_NT, COLS_ADD_NT = DPX_COLS_ADD_NT, COLS_S
 // ones, and the three extra ran alone in a fourth round: 75.7 -> 68.9 us without them.
 // The workgroup's work; PACK = its column c == 0 is the plane's packed (DC, Nyquist) column.  Two instantiations per kernel so that
 // the packed variant's extra live values (and spills) stay out of the register allocation of the other 63 workgroups in 64.
+// Tuning aid (variant builds with -DDPX_PAR_TRACE only, tools/par_trace.py): 100 MHz real-time stamps of every wave of the first 256 workgroups
+#ifdef DPX_PAR_TRACE
+__device__ unsigned long long dpx_cols_trace_buf[256 * 16 * 10];
+#define DPX_CSTAMP(i)                                                                                                       \
+  do {                                                                                                                      \
+    if ((threadIdx.x & 63) == 0 && bid < 256) dpx_cols_trace_buf[(bid * 16 + (threadIdx.x >> 6)) * 10 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" int dpx_dbg_cols_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpx_cols_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+#else
+#define DPX_CSTAMP(i) ((void)0)
+#endif
 template <int H, int T, int COLS, int OP, int DBG, bool PACK>
 __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, const SpecArgs& A, int C, int Ws, int P,
                                           const float2* __restrict__ twH, int bid, int nmain, bool is_side, int p, int j, unsigned sub_off) {
@@ -408,6 +421,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   auto hrow = [](int m) { return R3 ? 3 * (m % VS) * T + m / VS : m * T; };
   auto krow = [](int m) { return R3 ? (m % VS) * T + (m / VS) * (H / 3) : m * T; };
   HIP_DYNAMIC_SHARED(float2, smem_p2)
+  DPX_CSTAMP(0);
   const int tid = threadIdx.x, c = tid % COLS, t = tid / COLS;
   // uniform (scalar) bases + 32-bit per-thread element offsets: one address VGPR per access
   size_t ubase;                                       // element offset of the tile's plane / of the side array
@@ -469,6 +483,25 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
 #pragma unroll
     for (int m = 0; m < V; ++m) sidev[PACK ? m : 0] = sidef[2 * hrow(m)];
   }
+  // DPX_COLS_PACK_EARLY: the packed column's Nyquist denominators are requested with the tile (V floats per lane of the packed
+  // column's instantiation, alive through the forward transform) instead of behind the operator, where their memory round trip
+  // made the launch's three packed workgroups its last to finish (1 x 3 x 1024^2: 17.0 us against 13.6 for the others)
+#ifndef DPX_COLS_PACK_EARLY
+#define DPX_COLS_PACK_EARLY 1
+#endif
+  constexpr bool PACK_EARLY = DPX_COLS_PACK_EARLY && PACK && OP == OP_SOLVE;
+  float dnb_early[PACK_EARLY ? V : 1];
+  if constexpr (PACK_EARLY) {
+    if (dc_lane) {
+      const float rb = A.rho ? A.rho[p / C] : 0.f;
+      const float2* tsd0 = A.dd + (unsigned)C * H * Ws + (unsigned)(p % C) * H + t;
+#pragma unroll
+      for (int m = 0; m < V; ++m) {
+        const float2 db = tsd0[krow(m)];
+        dnb_early[m] = fmaf(rb, db.y, db.x) + A.eps;
+      }
+    }
+  }
   if constexpr (!TWG) {
     for (int i = tid; i < H; i += T * COLS) smem_p2[COLS * S + i] = twH[i];
   }
@@ -508,6 +541,7 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float2* tstage = smem_p2 + wave * (64 * V);
   auto fetch_table = [&]() {
+    DPX_CSTAMP(8);
     if (DMA_TABLE && !is_side) {
       DPX_LDS_BARRIER();                                // every wave has read its last-pass inputs
       // piece j: rows T*(2j + half) + RPW*wave + li/LPR (half = lane / 32, li = lane % 32), columns 2*(li % LPR), +1
@@ -533,11 +567,17 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
         for (int m = 0; m < V; ++m) av[m] = ld_stream<COLS_ADD_NT>((const float2*)(add + (offa + step * krow(m)) * 8u));
       }
     }
+    DPX_CSTAMP(9);
   };
+#ifdef DPX_PAR_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DPX_CSTAMP(1);
+#endif
   if (!(DBG & 1)) {
     if constexpr (R3) fft_reg_x3<H / 3, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
     else fft_reg<H, T, -1>(v, lds, t, twl, 1, BlockSync(), fetch_table);
   }
+  DPX_CSTAMP(2);
   __builtin_amdgcn_sched_barrier(0);
 #ifdef DPX_COLS_PRIO
   __builtin_amdgcn_s_setprio(DPX_COLS_PRIO);          // experiment: workgroups past their forward transform go first
@@ -628,8 +668,12 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
       const float2* tsd = A.dd + (unsigned)C * H * Ws + (unsigned)(p % C) * H + ts;
 #pragma unroll
       for (int m = 0; m < V; ++m) {
-        const float2 db = tsd[krow(m)];
-        dnb[m] = fmaf(rho_b, db.y, db.x) + A.eps;
+        if constexpr (PACK_EARLY) {
+          dnb[m] = dnb_early[m];
+        } else {
+          const float2 db = tsd[krow(m)];
+          dnb[m] = fmaf(rho_b, db.y, db.x) + A.eps;
+        }
       }
 #pragma unroll
       for (int m = 0; m < V; ++m) {
@@ -651,11 +695,14 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  DPX_CSTAMP(3);
   DPX_LDS_BARRIER();
+  DPX_CSTAMP(4);
   if (!(DBG & 1)) {
     if constexpr (R3) fft_reg_x3<H / 3, T, +1>(v, lds, t, twl, 1, BlockSync());
     else fft_reg<H, T, +1>(v, lds, t, twl, 1, BlockSync());
   }
+  DPX_CSTAMP(5);
   unsigned off1 = off0;
   DPX_OPAQUE(off1);       // do not keep the load offsets alive for the stores
 #pragma unroll
@@ -667,6 +714,11 @@ __device__ __forceinline__ void cols_body(const float2* __restrict__ spec_in, fl
 #pragma unroll
     for (int m = 0; m < V; ++m) st_stream<COLS_ST>(so + hrow(m), make_float2(v[m].y, 0.f));
   }
+  DPX_CSTAMP(6);
+#ifdef DPX_PAR_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DPX_CSTAMP(7);
+#endif
 }
 
 

@@ -381,6 +381,12 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   constexpr int NX_STEADY_NS = (NU * (D + V)) > 63 ? 63 : (NU * (D + V));
   constexpr int NU_LAST_NS = (NU * V) > 63 ? 63 : (NU * V);
   constexpr int NU_STEADY_NS = (NU * V + D + 1) > 63 ? 63 : (NU * V + D + 1);
+  // LATE_U (three and four terms): the dual rows are read from the staging area term by term inside the update loop instead of all
+  // at once in front of it (NT x V register pairs less alive through the loop: no scratch for ADMM with TV + nonneg / + norm1), so the
+  // next dual rows are requested BEHIND the loop -- the dual stores and v emits of a step then sit in FRONT of that request and drop
+  // out of the count of operations issued after it
+  constexpr bool LATE_U = DUAL && NT >= 3;
+  constexpr int NU_LAST_L = V, NU_STEADY_L = V + D + 1, NU_LAST_NS_L = 0, NU_STEADY_NS_L = D + 1;
   const bool has_spec = rho_next != nullptr;
   // An emitting pass (the last one of a call; every one under a callback) also stores x (V per row, phase A, behind issue_x) and v
   // (NT V per row, phase B, behind issue_u).  With bands of equal length every steady-state wait has them behind the awaited DMA
@@ -392,9 +398,9 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   const bool xonly = !DUAL && emit_v == 2;
   const int qfirst = xonly ? 1 : 0, qlast = xonly ? Rmax : Rmax + 1;
   const int emode = (x_out && rrem == 0) ? ((emit_v && !xonly) ? 2 : 1) : 0;
-  auto wait_emit = [&](auto nbase, auto with_x) {
-    constexpr int N0 = decltype(nbase)::value, WX = decltype(with_x)::value;
-    constexpr int N1 = (N0 + WX * EX) > 63 ? 63 : (N0 + WX * EX), N2 = (N0 + WX * EX + EV) > 63 ? 63 : (N0 + WX * EX + EV);
+  auto wait_emit = [&](auto nbase, auto with_x, auto with_v) {
+    constexpr int N0 = decltype(nbase)::value, WX = decltype(with_x)::value, WV = decltype(with_v)::value;
+    constexpr int N1 = (N0 + WX * EX) > 63 ? 63 : (N0 + WX * EX), N2 = (N0 + WX * EX + WV * EV) > 63 ? 63 : (N0 + WX * EX + WV * EV);
     if (emode == 2) dpx_wait_vm<N2>();
     else if (emode == 1) dpx_wait_vm<N1>();
     else dpx_wait_vm<N0>();
@@ -409,8 +415,8 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
   for (int q = qfirst; q <= qlast; ++q) {
     // ---------------- phase A: inverse row transform of row q ----------------
     if (q >= 3) {
-      if (has_spec) wait_emit(std::integral_constant<int, NX_STEADY>(), std::integral_constant<int, 1>());
-      else wait_emit(std::integral_constant<int, NX_STEADY_NS>(), std::integral_constant<int, 1>());
+      if (has_spec) wait_emit(std::integral_constant<int, NX_STEADY>(), std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+      else wait_emit(std::integral_constant<int, NX_STEADY_NS>(), std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
     }
     else if (q == 1) dpx_wait_vm<0>();
     else dpx_wait_vm<NU * D>();
@@ -455,22 +461,34 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       const float dualf = DUAL ? TT.dual : 0.f;
       if constexpr (DUAL) {
         if (q >= 3) {
-          if (has_spec) {
-            if (q <= Rmax) wait_emit(std::integral_constant<int, NU_STEADY>(), std::integral_constant<int, 1>());
-            else wait_emit(std::integral_constant<int, NU_LAST>(), std::integral_constant<int, 0>());      // (row Rmax + 1 is a halo row: no x store in its phase A)
+          using I0 = std::integral_constant<int, 0>;
+          using I1 = std::integral_constant<int, 1>;
+          if constexpr (LATE_U) {                       // (the v emits of the previous step sit in front of the awaited request)
+            if (has_spec) {
+              if (q <= Rmax) wait_emit(std::integral_constant<int, NU_STEADY_L>(), I1(), I0());
+              else wait_emit(std::integral_constant<int, NU_LAST_L>(), I0(), I0());
+            } else {
+              if (q <= Rmax) wait_emit(std::integral_constant<int, NU_STEADY_NS_L>(), I1(), I0());
+              else wait_emit(std::integral_constant<int, NU_LAST_NS_L>(), I0(), I0());
+            }
+          } else if (has_spec) {
+            if (q <= Rmax) wait_emit(std::integral_constant<int, NU_STEADY>(), I1(), I1());
+            else wait_emit(std::integral_constant<int, NU_LAST>(), I0(), I1());      // (row Rmax + 1 is a halo row: no x store in its phase A)
           } else {
-            if (q <= Rmax) wait_emit(std::integral_constant<int, NU_STEADY_NS>(), std::integral_constant<int, 1>());
-            else wait_emit(std::integral_constant<int, NU_LAST_NS>(), std::integral_constant<int, 0>());
+            if (q <= Rmax) wait_emit(std::integral_constant<int, NU_STEADY_NS>(), I1(), I1());
+            else wait_emit(std::integral_constant<int, NU_LAST_NS>(), I0(), I1());
           }
         } else {
           dpx_wait_vm<D + 1>();
         }
+        if constexpr (!LATE_U) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+          for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int m = 0; m < V; ++m) ureg[n][m] = stU[n * STG + stage_idx(t + m * T)];
-        dpx_wait_lds();
-        if (qz < Rmax) issue_u(rowof(qz + 1));
+            for (int m = 0; m < V; ++m) ureg[n][m] = stU[n * STG + stage_idx(t + m * T)];
+          dpx_wait_lds();
+          if (qz < Rmax) issue_u(rowof(qz + 1));
+        }
       } else {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -484,6 +502,10 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
       for (int n = 0; n < NT; ++n) {
         const IterTerm tm = TT.t[n];
         const float lam = lamv[n];
+        if constexpr (LATE_U) {
+#pragma unroll
+          for (int m = 0; m < V; ++m) ureg[n][m] = stU[n * STG + stage_idx(t + m * T)];
+        }
         // d = K x + u   (the operator / prox codes are wave-uniform: one branch per term, not per element)
         float2 d[V];
         if (tm.linop == DPX_LIN_IDENTITY) {
@@ -562,6 +584,10 @@ __global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restri
             wprev[m] = w[m];
           }
         }
+      }
+      if constexpr (LATE_U) {
+        dpx_wait_lds();                                 // (the loop's reads of the staging area have returned)
+        if (qz < Rmax) issue_u(rowof(qz + 1));
       }
       // ---------------- phase C: right-hand-side increment of row qz and its forward row transform ----------------
       if (own && rho_next) {
@@ -1060,9 +1086,41 @@ static int terms_ok(const dpx_term* terms, int nterms) {
 // run-time overrides of the row-kernel choice (tests / tuning): rows_mode 0 = automatic, 1 = streaming kernel, 2 = lock-step
 // ring-buffer kernel; bands_per_plane 0 = automatic.  The environment variables DPX_ITER_ROWS / DPX_ITER_BAND set the defaults.
 static int g_rows_mode = -1, g_rows_band = -1;
-namespace dpx { int g_rows_mode_pgd = 0, g_rows_band_pgd = 0, g_chain_share = 1; }
+namespace dpx { int g_rows_mode_pgd = 0, g_rows_band_pgd = 0, g_chain_share = 1; int iter_seq_bands(int P, int H, int W, int forced); }
 // Sub-batches of one solve running as independent chains on separate streams (dprox/algo/fused.py) share the GPU: the row kernels size
 // their bands for `chains` x the planes of one call.  A tuning hint only -- results do not depend on the band partition.
+// Bands per plane of the streaming row kernel (k_iter_rows_seq) for a launch of P planes of H x W: as many as keep every T-lane group
+// of the launch resident at once (2 workgroups of 4 waves per CU, times the chains that share the GPU), rounded UP to a power of two
+// (H is one: bands of equal length keep the waves of a workgroup in step, and ~1.5 rounds of resident groups beat one round of
+// unequal bands -- 8x3x1024^2: 128 bands of 8 rows 106 us, 85 bands of 12-13 rows 109 us, 96 / 102 / 136 bands 127-133 us), at least
+// `iter_band_min_rows` (4) rows long, and such that the groups fill whole workgroups.  A partition always exists: if no count below
+// the rule's fills whole workgroups (P odd and large), the smallest count that does is taken (per_block / gcd(P, per_block) <= 16).
+int dpx::iter_seq_bands(int P, int H, int W, int forced) {
+  const int T = W == 768 ? 64 : W / 16, G = 64 / T, per_block = 4 * G;
+  int nb = (256 * 2 * 4 * G) / (P * dpx::g_chain_share);
+  {
+    int p2 = 1;
+    while (p2 < nb) p2 <<= 1;
+    nb = p2;
+  }
+  if (forced) nb = forced;
+  const int min_rows_knob = tune(TUNE_ITER_BAND_MIN_ROWS);
+  const int min_rows = min_rows_knob > 0 ? min_rows_knob : 4;
+  if (nb > H / min_rows) nb = H / min_rows;
+  if (nb < 1) nb = 1;
+  while (nb > 1 && (P * nb) % per_block) --nb;
+  if ((P * nb) % per_block) {
+    int a = P, b = per_block;
+    while (b) { const int r = a % b; a = b; b = r; }
+    nb = per_block / a;
+  }
+  return nb;
+}
+
+extern "C" int dpx_admm_iter_bands(int planes, int H, int W) {
+  if (planes < 1 || H < 16 || !(W == 256 || W == 512 || W == 768 || W == 1024)) return 0;
+  return dpx::iter_seq_bands(planes, H, W, g_rows_band > 0 ? g_rows_band : tune(TUNE_ITER_BAND));
+}
 extern "C" int dpx_admm_iter_share(int chains) {
   DPX_REQUIRE(chains >= 1 && chains <= 16, "dpx_admm_iter_share: chains must be in [1, 16]");
   dpx::g_chain_share = chains;
@@ -1078,10 +1136,10 @@ extern "C" int dpx_admm_iter_config(int rows_mode, int bands_per_plane) {
 }
 
 extern "C" int dpx_admm_iter_supported(int H, int W, const dpx_term* terms, int nterms) {
-  // (2048-wide planes: 16 values per thread spill in the row kernel -- 33 ps per pixel and iteration against 14 on the staged
-  //  kernels, which the callers fall back to)
+  // (2048-wide planes: 16 values per thread spilled 121 - 279 registers in the lock-step row kernel -- 33 ps per pixel and iteration
+  //  against 14 on the staged kernels, which the callers use; the instantiation is gone since round 5)
   // 768-wide rows: M = 384 = 6 * 8 * 8 on one wave per row (fft384_wave, 6 values per lane) in the streaming kernels; 1536: staged kernels only
-  const bool wok = W == 256 || W == 512 || W == 768 || W == 1024 || (W == 2048 && tune(TUNE_ITER_W2048))     /* knob: keep the two-kernel iteration on 2048-wide planes */;
+  const bool wok = W == 256 || W == 512 || W == 768 || W == 1024;
   return pow2_path_available(H, W) && wok && H % 16 == 0 && terms_ok(terms, nterms);
 }
 
@@ -1169,24 +1227,8 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   //  sooner there than the streaming kernel's sequential ones; measured crossover between 256- and 512-wide planes)
   const bool tiny = W <= 256 && (long)P * H <= 4096 && !(mode && !strcmp(mode, "seq"));
   if ((!(mode && !strcmp(mode, "lockstep")) && W <= 1024 && !tiny) || W == 768) {      // (768-wide rows exist on the streaming kernel only)
-    // as many bands per plane as keep every T-lane group of the launch resident at once (2 workgroups of 4 waves per
-    // CU), rounded so that the groups fill whole workgroups; bands are >= 4 rows (halo = 2 extra inverse transforms)
     const int T = W == 768 ? 64 : W / 16, G = 64 / T, per_block = 4 * G;
-    int nb = (256 * 2 * 4 * G) / (P * dpx::g_chain_share);
-    // ... rounded UP to a power of two (H is one): bands of equal length keep the waves of a workgroup in step, and ~1.5 rounds
-    // of resident groups beat one round of unequal bands (8x3x1024^2: 128 bands of 8 rows 106 us, 85 bands of 12-13 rows 109 us,
-    // 96 / 102 / 136 bands 127-133 us)
-    {
-      int p2 = 1;
-      while (p2 < nb) p2 <<= 1;
-      nb = p2;
-    }
-    if (band_env) nb = band_env;
-    // shortest band: 4 rows (halo = 2 extra inverse transforms per band); knob iter_band_min_rows
-    const int min_rows_knob = tune(TUNE_ITER_BAND_MIN_ROWS);
-    const int min_rows = min_rows_knob > 0 ? min_rows_knob : 4;
-    if (nb > H / min_rows) nb = H / min_rows;
-    while (nb > 1 && (P * nb) % per_block) --nb;
+    const int nb = dpx::iter_seq_bands(P, H, W, band_env);
     if (nb >= 1 && (P * nb) % per_block == 0) {
       switch (W) {
         case 256: launch_iter_rows_seq<128, 16>(sin, sout, TT, rho_next, x_out, emit_v, C, H, nb, P, tw, s); break;
@@ -1205,8 +1247,7 @@ int dpx::iter_rows_impl(const void* spec_in, void* spec_out, const dpx_term* ter
   switch (W) {
     case 256: launch_iter_rows<128, 16>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
     case 512: launch_iter_rows<256, 32>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
-    case 1024: launch_iter_rows<512, 64>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
-    default: launch_iter_rows<1024, 64>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
+    default: launch_iter_rows<512, 64>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, tw, s); break;
   }
   return launch_status("dpx_admm_iter_rows");
 }

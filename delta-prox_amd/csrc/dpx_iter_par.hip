@@ -25,12 +25,29 @@
 #endif
 #include "dpx_iter_dev.h"
 
+// Tuning aid (tools/build_variant.sh par_trace -DDPX_PAR_TRACE; never in the shipped library): every wave of the first 256 workgroups
+// stamps the 100 MHz real-time counter at the phase boundaries; tools/par_trace.py reads the stamps of the last launch.
+#ifdef DPX_PAR_TRACE
+__device__ unsigned long long dpx_par_trace_buf[256 * 16 * 10];
+#define DPX_STAMP(i)                                                                                                       \
+  do {                                                                                                                     \
+    if (lane == 0 && blockIdx.x < 256) dpx_par_trace_buf[(blockIdx.x * 16 + wave) * 10 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" int dpx_dbg_par_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpx_par_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+#else
+#define DPX_STAMP(i) ((void)0)
+#endif
+
 namespace dpx {
 
 template <int M, int T, int NT, bool DUAL, bool VXU, int NW>
-__global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
-                                                             const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
-                                                             int C, int H, int bands, int P, const float2* __restrict__ twW) {
+__global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __restrict__ spec_in, float2* __restrict__ spec_out,
+                                                             const float2* __restrict__ twW, const float* __restrict__ rho_next,
+                                                             float* __restrict__ x_out, int emit_v, int C, int H, int bands, int P, IterTerms TT) {
+  // (argument order: the pointers and sizes the first loads need come first -- the leading 16 dwords of the kernel arguments are
+  //  preloaded into scalar registers at wave launch, -mllvm -amdgpu-kernarg-preload-count=16 -- the by-value term table last)
   constexpr int V = M / T, G = 64 / T, S = LdsSeq<M>::SLOTS, D = V / 2, RM = M / (V * V);
   constexpr int STG = 64 * V;                           // float2 per staged row set of one wave (G rows of M)
   constexpr int PERWAVE = G * S + STG + 32;
@@ -47,12 +64,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
   float2* myfft = wl + g * S;                           // inverse transform's scratch; then this row's w (grad_H term) for the row below
   float2* stX = wl + G * S;                             // DMA staging of the spectrum rows; then x of this wave's rows; then forward scratch
   float* stN = (float*)(stX + STG);
-  for (int i = tid; i < M; i += 64 * NW) twl[i] = twW[i];
-  if (tid < 64) twb[tid] = twW[(tid * (M / (V * RM)) * 2) % (2 * M)];
-  TwRegs<M, T, false> twr;
-  twr.load(t, twW, 2);
-  twr.twb_ = twb;
-  twr.bstride_ = 1;
+  DPX_STAMP(0);
+  static_assert(M <= 64 * NW, "one untangling twiddle per thread");
 
   // xonly (emit_v == 2, no-dual instantiation only): the last pass of a solve() that hands back x alone -- inverse transforms and x stores
   const bool xonly = !DUAL && emit_v == 2;
@@ -89,12 +102,27 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
   const int pair = lbase | ((T - t) & (T - 1));
   auto stage_idx = [&](int e) { return ((e >> 1) / T) * 128 + g * 2 * T + ((e >> 1) % T) * 2 + (e & 1); };
 
+  // ONE memory round trip in front of phase A: the spectrum row by LDS-DMA first (older than every load the compiler counts, so its
+  // waits cover it), then all twiddle loads back to back, the LDS copies behind them
   if (wave_live) {
 #pragma unroll
     for (int i = 0; i < D; ++i) dpx_glds16<R_LDX>(spec_in + xoff + (unsigned)h * SPEC_TILE + xstep * i, stX + i * 128);
     dpx_glds4<R_LDX>(spec_in + noff + h, stN);
   }
+  const float2 tw_a = twW[tid < M ? tid : 0];
+  const float2 tw_b = twW[((tid & 63) * (M / (V * RM)) * 2) % (2 * M)];
+  TwRegs<M, T, false> twr;
+  twr.load(t, twW, 2);
+  twr.twb_ = twb;
+  twr.bstride_ = 1;
+#ifdef DPX_PAR_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DPX_STAMP(9);
+#endif
+  if (tid < M) twl[tid] = tw_a;
+  if (tid < 64) twb[tid] = tw_b;
   __syncthreads();                                      // the twiddle copies
+  DPX_STAMP(1);
   // ---------------- phase A: inverse row transform of row q ----------------
   float2 xa[V];
   float2 ureg[NT][V];
@@ -106,6 +134,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
   const bool own = xonly ? a_live : (q >= 1 && q <= R);
   if (wave_live) {
     dpx_wait_vm<0>();
+    DPX_STAMP(2);
     {
       float2 Xk[V], Xm[V];
 #pragma unroll
@@ -142,6 +171,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
     }
     WaveSync()();
     fft_reg_tw<M, T, +1, false>(xa, myfft, t, twr, WaveSync());   // xa[m] = (x[2n], x[2n+1]), n = t + m*T
+    DPX_STAMP(3);
     if (x_out && own) {
       const size_t xo = (size_t)pl * H * M + (size_t)h * M + t;
 #pragma unroll
@@ -155,6 +185,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
   }
   if (xonly) return;
   DPX_LDS_BARRIER();
+  DPX_STAMP(4);
   // ---------------- phase B: z / dual update of row q (x[q] = xa, x[q + 1] from the neighbour) ----------------
   float2 acc[V], cpost[NT][V], wown[V];
 #pragma unroll
@@ -265,7 +296,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
       }
     }
   }
+  DPX_STAMP(5);
   DPX_LDS_BARRIER();
+  DPX_STAMP(6);
   // ---------------- phase C: right-hand-side increment of row q and its forward row transform ----------------
   const bool wave_own = wave * G <= R && wave * G + G - 1 >= 1;      // wave-uniform: some group of this wave owns a row of the band
   if (wave_own && rho_next) {
@@ -296,6 +329,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
     float2* fwd = stX + g * S;                          // (the x exchange buffer: read by the row above before the barrier)
     WaveSync()();
     fft_reg_tw<M, T, -1, false>(z, fwd, t, twr, WaveSync());
+    DPX_STAMP(7);
     float2* out = spec_out + tile_off + hz * SPEC_TILE;
 #pragma unroll
     for (int m = 0; m < V; ++m) {
@@ -314,6 +348,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
       }
       if (own) st_stream<R_STX>(out + tile_step * m, Xo);
     }
+    DPX_STAMP(8);
   }
 }
 
@@ -331,7 +366,7 @@ static void launch_par_d(const float2* sin, float2* sout, const IterTerms& TT, c
   const int rows = xonly ? RW : RW - 2;                 // own rows per workgroup
   const int bands = (H + rows - 1) / rows;
   DPX_LAUNCH(VXU ? "k_iter_rows_par_vxu" : (DUAL ? "k_iter_rows_par" : "k_iter_rows_par_nodual"), (k_iter_rows_par<M, T, NT, DUAL, VXU, NW>),
-             dim3(P * bands), dim3(64 * NW), sh, s, sin, sout, TT, rho_next, x_out, emit_v, C, H, bands, P, twW);
+             dim3(P * bands), dim3(64 * NW), sh, s, sin, sout, twW, rho_next, x_out, emit_v, C, H, bands, P, TT);
 }
 template <int M, int T, int NT>
 static void launch_par_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v, int C, int H, int P,

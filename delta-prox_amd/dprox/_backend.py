@@ -140,6 +140,7 @@ SIGNATURES = {
     "dpx_pc_dual": (c_int, [c_void_p, POINTER(Term), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_iter_config": (c_int, [c_int, c_int]),
     "dpx_admm_iter_share": (c_int, [c_int]),
+    "dpx_admm_iter_bands": (c_int, [c_int, c_int, c_int]),
     "dpx_admm_iter_supported": (c_int, [c_int, c_int, POINTER(Term), c_int]),
     "dpx_admm_seed_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_admm_seed_rows_fresh": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -92,15 +92,21 @@ def _psi_prox_code(fn):
 
 def plan_fingerprint(solver):
     """everything mutable the pattern match of ``plan_admm`` reads, cheaply: the term lists (identity and type of every term), the
-    terms' beta / unroll / clamp / denoiser class, the linop at the root of each term and the x-update's kind.  Part of the plan
+    terms' beta / unroll / clamp / x8 / sqrt, the denoiser's class AND identity, the linop at the root of each term (with the version of
+    its tables where it has any: a kernel swapped in place) and the x-update's kind.  Part of the plan
     cache's key (``ADMM._plan_for``): a term swapped, re-weighted or re-configured after the first solve gets a new match instead
     of a stale plan."""
     ls = getattr(solver, "least_square", None)
     terms = []
     for fn in list(solver.psi_fns) + list(solver.omega_fns):
         op = fn.linop
-        terms.append((id(fn), type(fn), fn.beta, getattr(fn, "unroll", None), getattr(fn, "clamp", None), type(getattr(fn, "denoiser", None)),
-                      id(op), type(op), getattr(op, "dim", None)))
+        beta = fn.beta
+        if isinstance(beta, torch.Tensor):                  # (a tensor-valued weight: compared by value, never by `==` on tensors)
+            beta = tuple(float(t) for t in beta.detach().reshape(-1).cpu())
+        den = getattr(fn, "denoiser", None)
+        terms.append((id(fn), type(fn), beta, getattr(fn, "unroll", None), getattr(fn, "clamp", None), type(den), id(den),
+                      getattr(fn, "x8", None), getattr(fn, "sqrt", None), id(op), type(op), getattr(op, "dim", None),
+                      getattr(op, "tables_version", lambda: None)()))
     return (len(solver.psi_fns), tuple(terms), id(ls), bool(getattr(ls, "freq_diagonalizable", False)))
 
 
@@ -611,6 +617,7 @@ class FusedADMM:
         if merged and not dual:                                      # half-quadratic splitting: the duals are zero -- the merged pass need not fetch them
             for i in range(n):
                 terms[i].reserved = be.TERM_NO_DUAL
+        u_given = list(u)                                            # the caller's dual tensors
         if merged and dual:
             u_alt = [torch.empty_like(t) for t in u]
             for i in range(n):
@@ -639,6 +646,14 @@ class FusedADMM:
             if callback is not None:
                 s._notify_all_op_current_step(it)
                 callback(iter=it, state=(x, v, u) if dual else (x, v), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+        if merged and dual:
+            # the duals alternated between the caller's tensors and u_alt: after an odd number of iterations the current ones sit in
+            # u_alt -- they go back into the tensors that came in, so that a caller holding on to its state's duals sees this call's
+            # result there (as with the in-place dual update of the un-merged stages), and the returned state IS those tensors
+            for i in range(n):
+                if u[i] is not u_given[i]:
+                    u_given[i].copy_(u[i])
+                    u[i] = u_given[i]
         s.Kall.update_vars([x])
         return (x, v, u) if dual else (x, v)
 

@@ -74,7 +74,6 @@ int dpx_timing_report(char* buf, size_t cap);
  *   iter_par_max_rows    launches of at most this many rows (planes x H) take the row-parallel      DPX_ITER_PAR_MAX_ROWS
  *                        kernel (0 = the library's rule, 8192; < 0 = never)
  *   iter_band, iter_r    bands per plane (streaming) / rows per band (lock-step)          DPX_ITER_BAND, DPX_ITER_R
- *   iter_w2048           1 = keep 2048-wide planes on the two-kernel iteration            DPX_ITER_W2048
  *   cols_inplace         1 = column pass in place                                         DPX_COLS_INPLACE
  *   chain_lockstep       1 = sub-batch chains' column passes ordered by events            DPX_CHAIN_LOCKSTEP
  *   ds_ct, ds_rpb,       geometry of the one-off fp64 data-spectrum pass                  DPX_DS_CT, DPX_DS_RPB,
@@ -495,6 +494,9 @@ int dpx_pc_dual(const float* xbar, const dpx_term* terms, int nterms, int B, int
 /* test / tuning hook: rows_mode 0 automatic, 1 streaming row kernel, 2 lock-step row kernel, 3 row-parallel kernel (launches of a few
  * planes; bit-identical to 1); bands_per_plane 0 = automatic */
 int dpx_admm_iter_config(int rows_mode, int bands_per_plane);
+/* query: bands per plane the streaming row kernel would walk for a launch of `planes` planes of H x W (> 0; the groups of
+ * planes x bands always fill whole workgroups -- a partition exists for every plane count), 0 = W is not a row length of that kernel */
+int dpx_admm_iter_bands(int planes, int H, int W);
 /* tuning hint: the following dpx_admm_* calls are one of `chains` sub-batch chains of a solve that run concurrently on separate
  * streams (the images of a batch never exchange data, algo/admm.py:49-59 acts per image): band lengths are chosen for the planes
  * of all chains together.  1 = a call has the GPU to itself (default).  Results never depend on it.                          */

@@ -1296,10 +1296,62 @@ def g36_hqs_pow2():
     save("g36_hqs_pow2", **out)
 
 
+def g37_generic_planes():
+    """The plane sizes bench.py times off the register-radix path, at their full size: 8 x 3 x 1000 x 1000 (`other_paths.admm_8x3x1000x1000`:
+    the XCD renumbering of the stencil passes and the 8-column interleave only see full grids at this size) and 2 x 3 x 720 x 1280, ADMM
+    TV-deconvolution, rho 0.1, lam 0.005, 6 iterations: full state packed like G30 (samples + per-image float64 sums / norms), and the
+    float64 iterate of the reference itself (linop/conv.py:31-41 is size-agnostic; algo/admm.py:49-59)."""
+    for tag, shape, seed in (("1000", (8, 3, 1000, 1000), 3701), ("720x1280", (2, 3, 720, 1280), 3702)):
+        gt, b, psf = synthetic.deconv_case(*shape, seed=seed)
+        x = dp.Variable()
+        st = dp.Problem(_tv_problem(x, T(b), psf)).solve(method="admm", device="cpu", x0=T(b), rhos=0.1, lams=0.005, max_iter=6, return_full_states=True)
+        out = {"seed": seed, "shape": np.array(shape)}
+        _pack(out, "x", st[0], 8)
+        for i in range(2):
+            _pack(out, f"v{i}", st[1][i], 16)
+            _pack(out, f"u{i}", st[2][i], 16)
+        lam6 = np.full(6, 0.005, np.float32)
+        x64o, _, _ = admm_f64(b, psf, [("grad0", "norm1", 1.0), ("grad1", "norm1", 1.0)], np.full(6, 0.1, np.float32), [lam6, lam6], 6)
+        x64 = ref_f64_admm(b, psf, 6)
+        f64_pin(out, "x_f64", x64, x64o)
+        _pack(out, "x_f64", x64, 8)
+        out["psnr"] = np.array([10 * np.log10(1.0 / np.mean((st[0][i].numpy() - gt[i]) ** 2)) for i in range(shape[0])])
+        save("g37_generic_" + tag, **out)
+
+
+def g38_full_c3_batch8():
+    """config 3 as BASELINE.json states it -- the batch of 8 x 3 x 1024 x 1024, ADMM with the FFDNet-colour prior (seeded weights) on the
+    log_descent(35, 5, 30) schedule -- at both ends of the schedule: its first 3 steps from x0 = b (as G31, but the whole batch: the
+    launch geometry bench.py times) and its LAST 3 steps (rho, sigma at their smallest: the best-conditioned x-updates and the weakest
+    denoising) started from x0 = b as well (27 FFDNet passes over 8 images to get there on the reference's CPU path are out of reach; the
+    kernels see the schedule's values, not its history).  x, v, u packed; float64 iterates of the reference itself."""
+    gt, b, psf = synthetic.deconv_case(8, 3, 1024, 1024, seed=2308)
+    rhos30, sig30 = log_descent(35, 5, 30)
+    out = {"seed": 2308}
+    for tag, sl in (("first", slice(0, 3)), ("last", slice(27, 30))):
+        rhos, sigmas = rhos30[sl].clone(), sig30[sl].clone()
+        x = dp.Variable()
+        prior = dp.deep_prior(x, denoiser=ColorDen(7))
+        fns = dp.sum_squares(dp.conv(x, psf) - T(b)) + prior
+        with torch.no_grad():
+            st = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams={prior: sigmas}, max_iter=3, return_full_states=True)
+        out[tag + "_rhos"], out[tag + "_sigmas"] = rhos, sigmas
+        _pack(out, tag + "_x", st[0], 8)
+        _pack(out, tag + "_v0", st[1][0], 8)
+        _pack(out, tag + "_u0", st[2][0], 8)
+        st64 = ref_f64_admm(b, psf, 3, rhos=rhos, lams=sigmas, dims=(), prior=ColorDen(7), full=True)
+        _pack(out, tag + "_x_f64", st64[0], 8)
+        _pack(out, tag + "_v0_f64", st64[1][0], 8)
+        print(f"   g38 {tag}: reference fp32 vs its float64 run: x {float((st[0].double() - st64[0]).norm() / st64[0].norm()):.2e}, "
+              f"v {float((st[1][0].double() - st64[1][0]).norm() / st64[1][0].norm()):.2e}")
+    save("g38_full_c3_batch8", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g6b_cg_large_batches, g7_ladmm_cg, g8_ffdnet, g8b_ffdnet_wide_range,
                g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
-               g30_full_c2, g30b_full_c2_batch8, g31_full_c3, g32_full_c4, g32b_full_c4_batches, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2):
+               g30_full_c2, g30b_full_c2_batch8, g31_full_c3, g32_full_c4, g32b_full_c4_batches, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2,
+               g37_generic_planes, g38_full_c3_batch8):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -245,7 +245,8 @@ def case_h768(device, tiny=False):
 def case_other_plane_sizes(device, sizes=((384, 256), (1536, 256), (2048, 256), (256, 768), (768, 768), (512, 1536)), channels=None):
     """the other plane sizes of the register-radix path (3 * 2^k rows / columns: fft_reg_x3; 2048 rows on 4-column workgroups)
     against the oracle (the fp32 CPU restatement of the reference, pinned by the fixtures): convolution, adjoint, the ADMM
-    iteration (two kernels, or the staged kernels for 768- and 1536-wide planes) and the fused proximal-gradient call"""
+    iteration (two kernels -- 768-wide rows on one wave per row, fft384_wave -- or the staged kernels for 1536- and 2048-wide planes) and
+    the fused proximal-gradient call"""
     import oracle as O
     import synthetic
     from dprox import _ops as ops
@@ -2125,6 +2126,74 @@ def case_full_c2_batch8(device):
     assert e_l2 <= TOL and e_sum <= TOL, (e_l2, e_sum)
     psnr = [float(10 * np.log10(1.0 / np.mean((out[i].cpu().numpy() - gt[i]) ** 2))) for i in range(8)]
     assert np.allclose(psnr, g["psnr"], atol=1e-3), (psnr, g["psnr"])
+
+
+def case_generic_planes_full_size(device, tags=("1000", "720x1280")):
+    """G37 -- the plane sizes bench.py times off the register-radix path AT THEIR FULL SIZE: 8 x 3 x 1000 x 1000 and 2 x 3 x 720 x 1280, 6 ADMM
+    iterations, full state against the real reference's run (the small generic cases stop at 100 x 120: the XCD renumbering of the stencil
+    passes, the 8-column interleave of k_cols_il and the merged z / rhs pass only see full grids here).  x at 1e-5 against the reference
+    and at least as close to the reference's own float64 iterate as the reference's float32 output is."""
+    import synthetic
+    for tag in tags:
+        g = load_golden("g37_generic_" + tag)
+        shape = tuple(int(v) for v in g["shape"])
+        gt, b, psf = synthetic.deconv_case(*shape, seed=int(g["seed"]))
+        bt = T(b, device)
+        x, fns, _ = tv_problem(bt, psf)
+        s = dp.compile(fns, method="admm", device=device)
+        st = s.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=6, return_full_states=True)
+        assert s.last_path == "fused"
+        _check_packed(g, "x", st[0], 8, TOL, what=f"generic {tag} ")
+        for i in range(2):
+            _check_packed(g, f"v{i}", st[1][i], 16, TOL, scale_key="x", what=f"generic {tag} ", scale_sub=2)
+            _check_packed(g, f"u{i}", st[2][i], 16, TOL, scale_key="x", what=f"generic {tag} ", scale_sub=2)
+        out = s.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=6)               # (x only: the loop's last stage without the state stores)
+        _check_packed(g, "x", out, 8, TOL, what=f"generic {tag} (x only) ")
+        ref_err = rel_l2(g["x"], g["x_f64"])
+        got_err = rel_l2(out[..., ::8, ::8].cpu().numpy(), g["x_f64"])
+        record(f"generic {tag}: x vs the reference's float64 iterate (reference's own distance: {ref_err:.2e})", got_err, ref_err + TOL)
+        assert got_err <= ref_err + TOL, (tag, got_err, ref_err)
+        psnr = [10 * np.log10(1.0 / np.mean((out[i].cpu().numpy() - gt[i]) ** 2)) for i in range(shape[0])]
+        assert np.allclose(psnr, g["psnr"], atol=2e-3), (psnr, g["psnr"])
+        del s, st, out, bt
+        if str(device) != "cpu":
+            torch.cuda.empty_cache()
+
+
+def case_full_c3_batch8(device):
+    """G38 -- config 3 as BASELINE.json states it (8 x 3 x 1024 x 1024, FFDNet-colour plug-and-play ADMM, log_descent(35, 5, 30)): the first 3
+    and the last 3 steps of the 30-step schedule on the whole batch, against the real reference and its own float64 run (criterion as
+    for G31 / G9: at least as close to the float64 iterate as the reference is, + the 1e-5 budget)."""
+    import synthetic
+    g = load_golden("g38_full_c3_batch8")
+    gt, b, psf = synthetic.deconv_case(8, 3, 1024, 1024, seed=int(g["seed"]))
+    bt = T(b, device)
+    rhos30, sig30 = dp.log_descent(35, 5, 30)
+    samp = lambda t: t[..., ::8, ::8].cpu().numpy()
+    for tag, sl in (("first", slice(0, 3)), ("last", slice(27, 30))):
+        assert np.allclose(rhos30[sl].numpy(), g[tag + "_rhos"], rtol=1e-6) and np.allclose(sig30[sl].numpy(), g[tag + "_sigmas"], rtol=1e-6)
+        x = dp.Variable()
+        prior = dp.deep_prior(x, denoiser=_ffdnet("color", device))
+        fns = dp.sum_squares(dp.conv(x, psf) - bt) + prior
+        with torch.no_grad():
+            s = dp.compile(fns, method="admm", device=device)
+            st = s.solve(x0=bt, rhos=rhos30[sl].clone(), lams={prior: sig30[sl].clone()}, max_iter=3, return_full_states=True)
+        assert s.last_path == "fused"
+        for key, got in (("x", samp(st[0])), ("v0", samp(st[1][0]))):
+            ref_err = rel_l2(g[f"{tag}_{key}"], g[f"{tag}_{key}_f64"])
+            got_err = rel_l2(got, g[f"{tag}_{key}_f64"])
+            r = rel_l2(got, g[f"{tag}_{key}"])
+            record(f"c3 batch 8, {tag} 3 steps: {key} vs the reference's float64 iterate (reference's own distance: {ref_err:.2e})", got_err, ref_err + TOL)
+            record(f"c3 batch 8, {tag} 3 steps: {key} vs the reference (both fp32)", r, 2 * ref_err + TOL)
+            assert got_err <= ref_err + TOL, (tag, key, got_err, ref_err)
+            assert r <= 2 * ref_err + TOL, (tag, key, r, ref_err)
+        d = st[1][0].double().reshape(8, -1).norm(dim=1).cpu().numpy()
+        e = float(np.max(np.abs(d - g[tag + "_v0_f64_l2"]) / g[tag + "_v0_f64_l2"]))
+        record(f"c3 batch 8, {tag} 3 steps: v per-image L2 norm vs float64", e, 1e-4)
+        assert e <= 1e-4, (tag, e)
+        del s, st
+        if str(device) != "cpu":
+            torch.cuda.empty_cache()
 
 
 def case_full_c3(device):

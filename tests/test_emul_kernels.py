@@ -267,4 +267,5 @@ def test_leaky_conv_layer_vs_torch():
 
 
 def test_row_parallel_kernel_is_bit_identical_to_the_streaming_kernel():
-    pc.case_row_parallel_kernel(DEV, shapes=((1, 2, 256, 256),), iters=3, methods=("admm", "hqs", "admm_vxu"), nterms_list=(2, 4), hfirst=(True, False))
+    pc.case_row_parallel_kernel(DEV, shapes=((1, 2, 256, 256),), iters=2, methods=("admm", "hqs"), nterms_list=(3,), hfirst=(True, False))
+    pc.case_row_parallel_kernel(DEV, shapes=((1, 1, 256, 256),), iters=2, methods=("admm_vxu",), nterms_list=(2,), hfirst=(True,))

@@ -588,3 +588,11 @@ def test_chain_streams_are_probed_for_overlap_and_missing_ones_fall_back():
 
 def test_row_parallel_kernel_is_bit_identical_to_the_streaming_kernel():
     pc.case_row_parallel_kernel(DEV, shapes=((1, 2, 256, 256), (2, 1, 512, 512), (1, 3, 1024, 1024), (3, 1, 384, 1024)))
+
+
+def test_g37_bench_only_plane_sizes_at_full_size():
+    pc.case_generic_planes_full_size(DEV)
+
+
+def test_g38_config3_whole_batch_both_ends_of_the_schedule():
+    pc.case_full_c3_batch8(DEV)

@@ -28,6 +28,25 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.query("dpx_spectrum_bytes", 1, 15, 21) == 2 * 15 * 11 * 8
 
 
+def test_streaming_row_kernel_always_has_a_band_partition():
+    """dpx_admm_iter_supported answers for a plane size without knowing the plane count, so the streaming row kernel (the only row
+    kernel of 768-wide planes) must find a band partition for EVERY count: planes x bands fill whole workgroups of 4 waves, bands are
+    at least one row long -- also for odd and large plane counts and with sub-batch chains sharing the GPU (round-4 advisor finding:
+    P x share > 1024 with P not a multiple of 4 had no partition and the solve raised)."""
+    lib = be.Library(be.LIB_PATH)
+    for W, per_block in ((768, 4), (1024, 4), (512, 8), (256, 16)):
+        for share in (1, 2, 3):
+            lib.call("dpx_admm_iter_share", share)
+            try:
+                for H in (256, 768, 1024):
+                    for P in list(range(1, 70)) + [255, 257, 1023, 1025, 1027, 2049, 4097]:
+                        nb = lib.query("dpx_admm_iter_bands", P, H, W)
+                        assert nb >= 1 and nb <= H and (P * nb) % per_block == 0, (W, share, H, P, nb)
+            finally:
+                lib.call("dpx_admm_iter_share", 1)
+    assert lib.query("dpx_admm_iter_bands", 3, 1024, 1000) == 0
+
+
 def test_tuning_registry_is_documented_and_round_trips():
     """every knob of the library's registry is in include/dpx.h's table, and dpx_tune_set / dpx_tune_get round-trip"""
     hdr = open(os.path.join(ROOT, "include", "dpx.h")).read()
