@@ -766,22 +766,29 @@ __global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, Sp
   const bool packed = (W % 2 == 0);
   float2* a = smem;
   const int tid = threadIdx.x;
-  // workgroup -> (image, channel, column tile): the B images of one (channel, tile) -- they read the same 64 KB of denominators --
-  // take consecutive slots of ONE XCD (the hardware deals workgroup i to XCD i % 8), so that the table tile comes from that XCD's L2
-  // for all but the first of them; groups beyond the last full set of eight keep the plain order
+  // workgroup -> (image, channel, column tile).  The hardware deals workgroup i to XCD i % 8; the work is dealt so that ONE XCD takes
+  //   * the B images of a (channel, tile) in consecutive slots -- they read the same 64 KB of denominators: from that XCD's L2 for all
+  //     but the first -- and
+  //   * IL_KB = 8 ADJACENT tiles (64 columns: 512 bytes of every spectrum row) one behind the other: a tile's 64-byte pieces start at
+  //     32 r mod 128 in row r (a row is 8 Ws bytes, no multiple of the 128-byte line), so each piece shares lines with its neighbours;
+  //     with the neighbours behind eight different L2s every line crossed the fabric twice or more (FETCH_SIZE: 2.5 x the
+  //     algorithmic read at 8 x 3 x 1000 x 1000) -- behind one L2 the second toucher hits.
+  // unit u = (channel, block of IL_KB tiles) -> XCD u % 8; a launch is 8 x the longest XCD list, the padding workgroups leave at once.
+  constexpr int IL_KB = 8;
   const int ntile = (Ws + CT - 1) / CT, nb = P / C;
   int p, tile;
   {
-    const int ngroup = C * ntile, full = (ngroup / 8) * 8;
-    const int i = blockIdx.x, xcd = i % 8, slot = i / 8;
-    int g = (slot / nb) * 8 + xcd, bimg = slot % nb;
-    if (i >= full * nb) {
-      const int r = i - full * nb;
-      g = full + r / nb;
-      bimg = r % nb;
+    const int nblk = (ntile + IL_KB - 1) / IL_KB, U = C * nblk;
+    int u = blockIdx.x % 8, item = blockIdx.x / 8, cnt = 0;
+    for (; u < U; u += 8) {
+      const int tb = u % nblk;
+      cnt = min(IL_KB, ntile - tb * IL_KB) * nb;
+      if (item < cnt) break;
+      item -= cnt;
     }
-    tile = g % ntile;
-    p = bimg * C + g / ntile;
+    if (u >= U) return;
+    tile = (u % nblk) * IL_KB + item / nb;
+    p = (item % nb) * C + u / nblk;
   }
   const int l0 = tile * CT;
   const int nseq = min(CT, Ws - l0);
@@ -1434,7 +1441,15 @@ static void launch_rows_il(bool fwd, bool even, int ct, const float* x, float2* 
 template <int OP, int CT, int NT>
 static void launch_cols_il_t(float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH, hipStream_t s) {
   const size_t sh = (size_t)H * (CT + 1) * sizeof(float2);
-  const dim3 grid(((spec_cols(W) + CT - 1) / CT) * P);
+  // 8 x the longest per-XCD work list (k_cols_il: unit u = (channel, block of 8 adjacent tiles) -> XCD u % 8)
+  const int ntile = (spec_cols(W) + CT - 1) / CT, nblk = (ntile + 7) / 8, U = C * nblk, nb = P / C;
+  int longest = 0;
+  for (int x = 0; x < 8; ++x) {
+    int n = 0;
+    for (int u = x; u < U; u += 8) n += ((u % nblk) * 8 + 8 <= ntile ? 8 : ntile - (u % nblk) * 8) * nb;
+    longest = n > longest ? n : longest;
+  }
+  const dim3 grid(8 * longest);
   il_lds_attr(k_cols_il<OP, CT, NT>, sh);
   DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT, NT>), grid, dim3(NT), sh, s, spec, A, C, H, W, pcol, twH, P);
 }

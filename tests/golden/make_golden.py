@@ -1336,12 +1336,12 @@ def g38_full_c3_batch8():
         with torch.no_grad():
             st = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams={prior: sigmas}, max_iter=3, return_full_states=True)
         out[tag + "_rhos"], out[tag + "_sigmas"] = rhos, sigmas
-        _pack(out, tag + "_x", st[0], 8)
-        _pack(out, tag + "_v0", st[1][0], 8)
-        _pack(out, tag + "_u0", st[2][0], 8)
+        _pack(out, tag + "_x", st[0], 16)
+        _pack(out, tag + "_v0", st[1][0], 16)
+        _pack(out, tag + "_u0", st[2][0], 16)
         st64 = ref_f64_admm(b, psf, 3, rhos=rhos, lams=sigmas, dims=(), prior=ColorDen(7), full=True)
-        _pack(out, tag + "_x_f64", st64[0], 8)
-        _pack(out, tag + "_v0_f64", st64[1][0], 8)
+        _pack(out, tag + "_x_f64", st64[0], 16)
+        _pack(out, tag + "_v0_f64", st64[1][0], 16)
         print(f"   g38 {tag}: reference fp32 vs its float64 run: x {float((st[0].double() - st64[0]).norm() / st64[0].norm()):.2e}, "
               f"v {float((st[1][0].double() - st64[1][0]).norm() / st64[1][0].norm()):.2e}")
     save("g38_full_c3_batch8", **out)

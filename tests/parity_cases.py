@@ -2169,7 +2169,7 @@ def case_full_c3_batch8(device):
     gt, b, psf = synthetic.deconv_case(8, 3, 1024, 1024, seed=int(g["seed"]))
     bt = T(b, device)
     rhos30, sig30 = dp.log_descent(35, 5, 30)
-    samp = lambda t: t[..., ::8, ::8].cpu().numpy()
+    samp = lambda t: t[..., ::16, ::16].cpu().numpy()
     for tag, sl in (("first", slice(0, 3)), ("last", slice(27, 30))):
         assert np.allclose(rhos30[sl].numpy(), g[tag + "_rhos"], rtol=1e-6) and np.allclose(sig30[sl].numpy(), g[tag + "_sigmas"], rtol=1e-6)
         x = dp.Variable()
