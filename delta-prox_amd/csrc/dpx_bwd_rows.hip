@@ -23,68 +23,9 @@
 #define DPX_PK_ASM 0                                    // (as in dpx_iter.hip)
 #endif
 #include "dpx_fft_reg.h"
+#include "dpx_bwd_dev.h"
 
 namespace dpx {
-
-struct BwdRowTerm {
-  int linop, prox;
-  float alpha;
-  const float* lam;       // [B], iteration t - 1
-  const float* v;         // saved prox output of iteration t - 1 (fp32 or bf16 history plane)
-  const float* a_in;      // the z stage's share of d/du from the previous backward step (nullable = 0)
-  float* a_out;           // g_d of this step
-};
-struct BwdRowTerms {
-  BwdRowTerm t[DPX_MAX_TERMS];
-  int n;
-  int hist_bf16;
-  const float* x;         // history planes of iteration t
-  const float* rhs;
-  float* g_out;           // nullable: g_rhs as an image ...
-  int g_acc;              // ... stored (0) or added to what the plane holds (1: the sum over the iterations, for the offsets' gradient)
-};
-
-template <bool BF16> __device__ __forceinline__ float2 hist_pair(const float* plane, size_t pair) {
-  if constexpr (BF16) {
-    const unsigned u = ((const unsigned*)plane)[pair];
-    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
-  }
-  return ((const float2*)plane)[pair];
-}
-
-// one component of the z stage: kg = g_v, a = the dual gradient's other share, v = saved prox output; returns g_d, adds to lt.
-// KIND: 1 soft threshold, 2 clipping at zero, 0 v / (1 + 2 lam) with sq = 1 / (1 + 2 lam) -- chosen once per term, outside the element loop
-template <int KIND> __device__ __forceinline__ float bwd_gd(float sq, float kg, float a, float v, float& lt) {
-  const float gu = a - kg, diff = kg - gu;
-  float J, dl;
-  if constexpr (KIND == 1) {
-    J = v != 0.f ? 1.f : 0.f;
-    dl = v > 0.f ? -1.f : (v < 0.f ? 1.f : 0.f);
-  } else if constexpr (KIND == 2) {
-    J = v > 0.f ? 1.f : 0.f;
-    dl = 0.f;
-  } else {
-    J = sq;
-    dl = -2.f * v * sq;
-  }
-  lt = fmaf(diff, dl, lt);
-  return fmaf(J, diff, gu);
-}
-template <int KIND, int V> __device__ __forceinline__ float bwd_gd_row(float sq, float rho, float2 (&w)[V], const float2 (&av)[V], const float2 (&vv)[V]) {
-  float lt = 0.f;
-#pragma unroll
-  for (int m = 0; m < V; ++m) {
-    w[m].x = bwd_gd<KIND>(sq, rho * w[m].x, av[m].x, vv[m].x, lt);
-    w[m].y = bwd_gd<KIND>(sq, rho * w[m].y, av[m].y, vv[m].y, lt);
-  }
-  return lt;
-}
-
-__device__ __forceinline__ float bwd_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 
 // M = W / 2 pixel pairs per row, T lanes per row, SPB = 256 / T rows in flight per workgroup, NT terms.  Partial sums: one slot per
 // workgroup, [row][nblk] with nblk = C * bands workgroups per image (part_lam rows = term * B + image).
@@ -398,9 +339,10 @@ static int bwd_rows_band(int H, int W) {
 }
 
 // workgroups (= partial-sum slots) per image of the launch below; 0: planes this kernel does not take
-int bwd_rows_slots(int C, int H, int W, int max_slots) {
+int bwd_rows_slots(int B, int C, int H, int W, int max_slots) {
   if (!(W == 256 || W == 512 || W == 1024) || !pow2_path_available(H, W) || H % 16) return 0;
-  const int R = bwd_rows_band(H, W), bands = (H + R - 1) / R;
+  const int own = bwd_rows_par_own(B * C, H, W);       // > 0: the row-parallel kernel (dpx_bwd_rows_par.hip) takes the launch
+  const int R = own ? own : bwd_rows_band(H, W), bands = (H + R - 1) / R;
   return C * bands <= max_slots ? C * bands : 0;
 }
 
@@ -419,8 +361,10 @@ int bwd_rows_fused(const void* spec_in, void* spec_out, const float* x, const fl
   for (int i = 0; i < DPX_MAX_TERMS; ++i) TT.t[i] = BwdRowTerm{DPX_LIN_IDENTITY, DPX_PROX_NONNEG, 0.f, nullptr, nullptr, nullptr, nullptr};
   for (int i = 0; i < nterms; ++i) TT.t[i] = BwdRowTerm{terms[i].linop, terms[i].prox, terms[i].alpha, terms[i].lam, terms[i].v, a_in[i], a_out[i]};
   for (int i = 0; i < nterms; ++i) DPX_REQUIRE(a_in[i] && a_out[i] && terms[i].v, "dpx_admm_unrolled_backward: term %d lacks a plane of the row kernel", i);
-  const int R = bwd_rows_band(H, W), bands = (H + R - 1) / R;
   const float2* tw = tw_rows(table);
+  if (const int own = bwd_rows_par_own(B * C, H, W))
+    return bwd_rows_par_launch((const float2*)spec_in, (float2*)spec_out, TT, rho, part_a, part_b, part_lam, B, C, H, W, (H + own - 1) / own, tw, s);
+  const int R = bwd_rows_band(H, W), bands = (H + R - 1) / R;
   switch (W) {
     case 256: launch_bwd_rows<128, 16>((const float2*)spec_in, (float2*)spec_out, TT, rho, part_a, part_b, part_lam, B, C, H, R, bands, tw, s); break;
     case 512: launch_bwd_rows<256, 32>((const float2*)spec_in, (float2*)spec_out, TT, rho, part_a, part_b, part_lam, B, C, H, R, bands, tw, s); break;

@@ -34,7 +34,7 @@ int finish_iter_n(const float* part_lam, const float* part_a, const float* part_
                   int nblk, hipStream_t s);
 int finish_all(const float* part, long stride, float* glam, float* grho, const float* rho_tab, int nterms, int B, int nblk, int T, int nst,
                hipStream_t s);
-int bwd_rows_slots(int C, int H, int W, int max_slots);   // dpx_bwd_rows.hip
+int bwd_rows_slots(int B, int C, int H, int W, int max_slots);   // dpx_bwd_rows.hip
 int bwd_rows_fused(const void* spec_in, void* spec_out, const float* x, const float* rhs, const float* rho, const dpx_bwd_term* terms, int nterms,
                    const float* const* a_in, float* const* a_out, float* g_out, int g_acc, float* part_a, float* part_b, float* part_lam, int hist_bf16,
                    int B, int C, int H, int W, const void* table, hipStream_t s);
@@ -301,7 +301,7 @@ static int unrolled_backward_impl(const float* hist, const unsigned short* hist1
   //      sum_t K g_rhs_t = K sum_t g_rhs_t is formed once at the end from the sum of the g_rhs images (emitted by the row kernel only
   //      when an offset gradient is wanted).  Knob unroll_bwd_staged: 0 = this loop where it applies, 2 = the image-domain fused
   //      stage below, 1 = the staged loop.
-  const int slots = (T > 1 && tune(TUNE_UNROLL_BWD_STAGED) == 0) ? bwd_rows_slots(C, H, W, ad_partial_blocks(C, H, W)) : 0;
+  const int slots = (T > 1 && tune(TUNE_UNROLL_BWD_STAGED) == 0) ? bwd_rows_slots(B, C, H, W, ad_partial_blocks(C, H, W)) : 0;
   if (slots > 0 && dpx_spectrum_bytes(B * C, H, W) > 0) {
     const hipStream_t st = (hipStream_t)stream;
     const int P = B * C;

@@ -92,6 +92,9 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        image-domain fused stage everywhere; 1 = the rhs stage and the z stage of
  *                        neighbouring iterations as two passes (same gradients up to round-off)
  *   unroll_bwd_band      rows per band of k_bwd_rows (0 = two lock-step rounds of a workgroup's rows)     DPX_UNROLL_BWD_BAND
+ *   unroll_bwd_par_max_rows  backward launches of at most this many rows (planes x H) take the row-parallel kernel    DPX_UNROLL_BWD_PAR_MAX_ROWS
+ *                        (k_bwd_rows_par: the rows of a band side by side in one 16-wave workgroup; 0 = the library's
+ *                        rule, 12288; < 0 = never: the lock-step bands of k_bwd_rows); gradients equal to round-off
  *   unroll_bwd_fold_finish  1 = the fused backward stage's last workgroup finishes the iteration's       DPX_UNROLL_BWD_FOLD_FINISH
  *                        reductions instead of a finishing launch (slower: measured, kept for A/B)
  *   ffdnet_presplit      split-f16 inference (dpx_ffdnet_forward_bf16, mode 3): 1 = activations       DPX_FFDNET_PRESPLIT
