@@ -24,9 +24,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
                                                             int B, int C, int H, int bands, int P, BwdRowTerms TT) {
   constexpr int V = M / T, G = 64 / T, S = LdsSeq<M>::SLOTS, D = V / 2, RM = M / (V * V);
   constexpr int STG = 64 * V, PERWAVE = G * S + STG + 32, RW = NW * G;
-  static_assert(V == 8 && STG + 32 == G * S && M <= 64 * NW, "row-parallel geometry");
+  static_assert(V == 8 && STG + 32 == G * S, "row-parallel geometry");
   HIP_DYNAMIC_SHARED(float2, smem_bp)
-  __shared__ float red[NW * (2 + DPX_MAX_TERMS)];
+  __shared__ double red[NW * (2 + DPX_MAX_TERMS)];
   float2* twl = smem_bp;
   float2* twb = smem_bp + M;
   float2* waves = twb + 64;
@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
     for (int i = 0; i < D; ++i) dpx_glds16<0>(spec_in + xoff + (unsigned)h * SPEC_TILE + xstep * i, stX + i * 128);
     dpx_glds4<0>(spec_in + noff + h, stN);
   }
+  for (int i = tid + 64 * NW; i < M; i += 64 * NW) twl[i] = twW[i];      // (M > 64 NW: the eight-wave build at 1024-wide rows)
   const float2 tw_a = twW[tid < M ? tid : 0];
   const float2 tw_b = twW[((tid & 63) * (M / (V * RM)) * 2) % (2 * M)];
   TwRegs<M, T, false> twr;
@@ -133,20 +134,18 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
   }
   DPX_LDS_BARRIER();
   // ---------------- phase B: the two stages on row q (g[q] = ga; g[q - 1], g[q + 1] from the neighbours) ----------------
-  float2 acc[V], wown[V];
+  float2 acc[V];
 #pragma unroll
-  for (int m = 0; m < V; ++m) acc[m] = wown[m] = make_float2(0.f, 0.f);
-  float acc_a = 0.f, acc_b = 0.f, lsum[NT];
+  for (int m = 0; m < V; ++m) acc[m] = make_float2(0.f, 0.f);
+  // the partial sums of d/d rho_t are signed products that cancel to ~1e-5 of their magnitude: summed in double inside the workgroup
+  // (a dozen additions per lane and row), one rounding per slot
+  double acc_a = 0.0, acc_b = 0.0;
+  float lsum[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) lsum[i] = 0.f;
   if (wave_live) {
-    float2 gn[V];                                       // g[q + 1]
-    {
-      const int qn = (q + 1 < RW) ? q + 1 : q;
-      const float2* gb = waves + (qn / G) * PERWAVE + G * S + (qn % G) * M + t;
-#pragma unroll
-      for (int m = 0; m < V; ++m) gn[m] = gb[m * T];
-    }
+    const int qn = (q + 1 < RW) ? q + 1 : q;
+    const float2* gnb = waves + (qn / G) * PERWAVE + G * S + (qn % G) * M + t;      // g[q + 1] (read where it is used: registers)
     // -- the two rho reductions of iteration t over the band's own rows: <g, rhs> and <g, L x> = <L g, x>, L = sum_i K_i^T K_i
     {
       const int qp = q >= 1 ? q - 1 : 0;
@@ -162,15 +161,15 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
           lg.y += (float)nW * (2.f * ga[m].y - ga[m].x - right);
         }
         if (nH) {
-          const float2 gp = gpb[m * T];
-          lg.x += (float)nH * (2.f * ga[m].x - gp.x - gn[m].x);
-          lg.y += (float)nH * (2.f * ga[m].y - gp.y - gn[m].y);
+          const float2 gp = gpb[m * T], gn = gnb[m * T];
+          lg.x += (float)nH * (2.f * ga[m].x - gp.x - gn.x);
+          lg.y += (float)nH * (2.f * ga[m].y - gp.y - gn.y);
         }
         const float2 xr = hist_pair<HB>(TT.x, rowz + t + m * T);
         const float2 rr = hist_pair<HB>(TT.rhs, rowz + t + m * T);
         const float pa = fmaf(lg.y, xr.y, lg.x * xr.x), pb = fmaf(ga[m].y, rr.y, ga[m].x * rr.x);
-        acc_a += own ? pa : 0.f;
-        acc_b += own ? pb : 0.f;
+        acc_a += own ? (double)pa : 0.0;
+        acc_b += own ? (double)pb : 0.0;
       }
     }
     __builtin_amdgcn_sched_barrier(0);                  // (keeps the terms' loads from being hoisted above: registers)
@@ -191,7 +190,10 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
         for (int m = 0; m < V; ++m) w[m] = ga[m];
       } else if (tm.linop == DPX_LIN_GRAD_H) {
 #pragma unroll
-        for (int m = 0; m < V; ++m) w[m] = make_float2(gn[m].x - ga[m].x, gn[m].y - ga[m].y);
+        for (int m = 0; m < V; ++m) {
+          const float2 gn = gnb[m * T];
+          w[m] = make_float2(gn.x - ga[m].x, gn.y - ga[m].y);
+        }
       } else {                                          // grad_W: g[w+1] - g[w]; pixel 2n+2 is the neighbour lane's .x
 #pragma unroll
         for (int m = 0; m < V; ++m) {
@@ -222,13 +224,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
           acc[m] = make_float2(acc[m].x + (wlft - w[m].x), acc[m].y + (w[m].x - w[m].y));
         }
       } else {                                          // grad_H: g_d goes to the row below through LDS, its adjoint is formed in phase C
+        float2* wb = myfft + t;                         // (every live group writes: its own copy is read back in phase C)
 #pragma unroll
-        for (int m = 0; m < V; ++m) wown[m] = w[m];
-        if (z_live) {
-          float2* wb = myfft + t;
-#pragma unroll
-          for (int m = 0; m < V; ++m) wb[m * T] = w[m];
-        }
+        for (int m = 0; m < V; ++m) wb[m * T] = w[m];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -242,8 +240,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
       const float2* wb = waves + (qp / G) * PERWAVE + (qp % G) * S + t;
 #pragma unroll
       for (int m = 0; m < V; ++m) {
-        const float2 up = wb[m * T];
-        acc[m] = make_float2(acc[m].x + (up.x - wown[m].x), acc[m].y + (up.y - wown[m].y));
+        const float2 up = wb[m * T], cu = myfft[t + m * T];
+        acc[m] = make_float2(acc[m].x + (up.x - cu.x), acc[m].y + (up.y - cu.y));
       }
     }
     float2* fwd = stX + g * S;
@@ -270,11 +268,16 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
   }
   // ---- the workgroup's partial sums, one slot each (the finishing launch adds the slots of an image in index order) ----
   {
-    float vals[2 + NT];
-    vals[0] = bwd_wave_sum(acc_a);
-    vals[1] = bwd_wave_sum(acc_b);
+    auto wave_sum_d = [](double v) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) vals[2 + i] = bwd_wave_sum(lsum[i]);
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      return v;
+    };
+    double vals[2 + NT];
+    vals[0] = wave_sum_d(acc_a);
+    vals[1] = wave_sum_d(acc_b);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) vals[2 + i] = wave_sum_d((double)lsum[i]);
     if (lane == 0) {
 #pragma unroll
       for (int e = 0; e < 2 + NT; ++e) red[wave * (2 + DPX_MAX_TERMS) + e] = vals[e];
@@ -282,9 +285,10 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
     __syncthreads();
     if (tid < 2 + NT) {
       constexpr int W4 = 2 + DPX_MAX_TERMS;
-      float sum = 0.f;
+      double sumd = 0.0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) sum += red[w * W4 + tid];
+      for (int w = 0; w < NW; ++w) sumd += red[w * W4 + tid];
+      const float sum = (float)sumd;
       const int nblk = C * bands;
       const long slot = (long)ci * bands + band;
       if (tid == 0) part_a[(long)bi * nblk + slot] = -sum;
@@ -294,7 +298,10 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
   }
 }
 
-constexpr int BWD_PAR_NW = 16;
+#ifndef DPX_BWD_PAR_NW
+#define DPX_BWD_PAR_NW 8           // waves per workgroup: 8 = 256 registers per lane (16: 128, 29 - 56 of them spilled -- config 5 1.207 ms per step against 1.072; lock-step bands 1.086)
+#endif
+constexpr int BWD_PAR_NW = DPX_BWD_PAR_NW;
 
 template <int M, int T, int NT, bool HB>
 static void launch_bp_hb(const float2* sin, float2* sout, const BwdRowTerms& TT, const float* rho, float* part_a, float* part_b, float* part_lam,

@@ -407,7 +407,9 @@ def case_w768_two_kernel(device, H=256, B=2, methods=("admm", "hqs", "admm_vxu")
     assert_close(touched.cpu(), fresh.cpu(), 2e-6, "768-wide: general seed vs fresh-state seed")
 
 
-UNROLL_BWD_MODES = (("default", {}),                                            # two-kernel backward iteration on power-of-two planes, else the image-domain fused stage
+UNROLL_BWD_MODES = (("default", {}),                                            # two-kernel backward iteration on power-of-two planes (small launches: the row-parallel
+                                                                                # kernel k_bwd_rows_par), else the image-domain fused stage
+                    ("lock-step bands", dict(unroll_bwd_par_max_rows=-1)),          # two-kernel backward iteration on k_bwd_rows whatever the launch size
                     ("staged", dict(unroll_bwd_staged=1)),
                     ("image-domain fused stage", dict(unroll_bwd_staged=2)),
                     ("image-domain fused stage, reductions by its last workgroup", dict(unroll_bwd_staged=2, unroll_bwd_fold_finish=1)))

@@ -33,7 +33,9 @@ def run(n):
     t2 = time.perf_counter()
     return (t2 - t0) / n * 1e3, (t1 - t0) / n * 1e3
 for rnd in range(3):
-    for name, knobs in (("two-kernel backward", {}), ("image-domain fused stage", dict(unroll_bwd_staged=2)), ("staged", dict(unroll_bwd_staged=1))):
+    for name, knobs in (("two-kernel backward", {}), ("... lock-step bands (k_bwd_rows)", dict(unroll_bwd_par_max_rows=-1)),
+                        ("... forward on the streaming kernel too", dict(unroll_bwd_par_max_rows=-1, iter_par_max_rows=-1)),
+                        ("image-domain fused stage", dict(unroll_bwd_staged=2)), ("staged", dict(unroll_bwd_staged=1))):
         with be.tuned(**knobs):
             w, h = run(40)
-        print(f"{dtype} {name:28s} {w:.3f} ms per step (host issue {h:.3f} ms)")
+        print(f"{dtype} {name:42s} {w:.3f} ms per step (host issue {h:.3f} ms)")
