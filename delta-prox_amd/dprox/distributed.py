@@ -16,6 +16,12 @@ dprox/algo/base.py:118).
 
 Caveat kept from the reference: the CG stop rule couples the images of a batch (linalg/solve/solver_cg.py:103-104),
 so CG-based solves are reproducible per shard, not across different shardings.
+
+REQUIREMENT -- one process per GPU, one solve at a time per process.  ``solve()`` is not re-entrant (as the reference's is not:
+module-level state in linop/comp_graph.py:201-202): the x-only flag of a solve (algo/driver.py), the sub-batch chains' share of
+the GPU (``dpx_admm_iter_share``) and the tuning registry are per-process state.  Launch as ``bench.py`` is launched
+(``torch.distributed.run --nproc-per-node N``: RANK / LOCAL_RANK from the environment, ``torch.cuda.set_device(LOCAL_RANK)``);
+several solver threads inside one process, or one process driving several GPUs, are not supported.
 """
 import ctypes
 from typing import Callable, Dict, List, Optional, Tuple
