@@ -17,6 +17,12 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """the oracle tests first: behind the emulator's tests (fibers + torch's thread pool in one process) the same CPU FFTs run 30 x slower
+    (test_g5_admm_tv_config1: 1.9 s alone, 65 s at the end of the suite)"""
+    items.sort(key=lambda it: 0 if "test_oracle_golden" in it.nodeid else 1)
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}

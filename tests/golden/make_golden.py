@@ -1347,11 +1347,54 @@ def g38_full_c3_batch8():
     save("g38_full_c3_batch8", **out)
 
 
+def g39_train_unrolled_pnp():
+    """The training workload bench.py times (`train_unrolled_pnp`; the reference's one published throughput figure, notebooks/quickstart.ipynb:
+    254-257) at ITS size: 2 RGB patches of 768 x 768, ADMM unrolled 10 times on sum_squares(conv_doe(x, PSF), b) + deep_prior(ffdnet_color, frozen
+    seeded weights), log_descent(49, 7.65, 10) schedules, MSE loss -- forward and the reference's autograd w.r.t. the PSF (through the solver's
+    data term AND through the simulated observation b = conv_doe(gt, PSF) + noise), rho_t and sigma_t (algo/specialization/unroll.py:21-58,
+    linop/conv.py:59-156).  Inputs as tools/bench_train.py builds them (seed 2024)."""
+    from dprox.linop.conv import conv_doe
+    bs, size, iters, k = 2, 768, 10, 15
+    rng = np.random.RandomState(2024)
+    gt = synthetic.synth_detail(rng, bs, 3, size, size)
+    psf0 = synthetic.point_spread_function(k, 5.0)
+    full = np.zeros((1, 3, size, size), np.float32)
+    full[:, :, :k, :k] = psf0[:, :, 0]
+    full = np.roll(full, (size // 2 - k // 2, size // 2 - k // 2), axis=(-2, -1))
+    noise = (rng.randn(bs, 3, size, size) * 7.65 / 255).astype(np.float32)
+    rhos0, sig0 = log_descent(49, 7.65, iters, sigma=7.65 / 255)
+    psf = T(full).clone()
+    psf = psf / psf.sum(dim=(-2, -1), keepdim=True)
+    rhos = rhos0.float().clone().requires_grad_(True)
+    lams = sig0.float().clone().requires_grad_(True)            # sigma_t^2; the solver gets the square root
+    xv, P, Bv = dp.Variable(), dp.Placeholder(), dp.Placeholder()
+    reg = dp.deep_prior(xv, denoiser=ColorDen(7))
+    op = conv_doe(xv, P, circular=True)
+    solver = dp.compile(dp.sum_squares(op, Bv) + reg, method="admm", device="cpu")
+    solver = dp.specialize(solver, method="unroll", device="cpu", max_iter=iters)
+    blur = conv_doe(dp.Variable(), P, circular=True)
+    P.value = psf
+    inp = blur.forward(T(gt)) + T(noise)
+    Bv.value = inp
+    pred = solver.solve(x0=inp.detach(), rhos=rhos, lams={reg: lams.sqrt()})
+    loss = ((pred - T(gt)) ** 2).mean()
+    loss.backward()
+    g_psf = op.psf.grad + blur.psf.grad          # (the reference wraps the Placeholder's value in one nn.Parameter per operator)
+    out = {"seed": 2024, "loss": loss.detach().double(), "g_rhos": rhos.grad, "g_lams": lams.grad, "rhos": rhos0.float(), "lams": sig0.float()}
+    _pack(out, "pred", pred.detach(), 8)
+    _pack(out, "inp", inp.detach(), 8)
+    out["g_psf"] = g_psf[..., size // 2 - 16:size // 2 + 16, size // 2 - 16:size // 2 + 16].clone()      # the 32 x 32 window around the PSF's support
+    out["g_psf_l2"] = g_psf.double().norm()
+    out["g_psf_sum"] = g_psf.double().sum(dim=(-2, -1))
+    print("g39:", float(loss), rhos.grad, lams.grad, float(g_psf.norm()))
+    save("g39_train_unrolled_pnp", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g6b_cg_large_batches, g7_ladmm_cg, g8_ffdnet, g8b_ffdnet_wide_range,
                g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
                g30_full_c2, g30b_full_c2_batch8, g31_full_c3, g32_full_c4, g32b_full_c4_batches, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2,
-               g37_generic_planes, g38_full_c3_batch8):
+               g37_generic_planes, g38_full_c3_batch8, g39_train_unrolled_pnp):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -560,6 +560,40 @@ def case_numpy_observation_edits(device):
         b_np[...] = 0.0
         off = fn.offset
         assert off is None or float(off.abs().max()) == 0.0
+        # an explicit replacement (sum_squares.set_b: array or tensor) takes every dependent cache with it
+        fn.set_b(np.ascontiguousarray(0.25 * b))
+        out3 = s.solve(x0=x0, rhos=0.2, lams=0.01, max_iter=3).cpu()
+        xr = dp.Variable()
+        ref3 = dp.compile(dp.sum_squares(dp.conv(xr, psf) - T(0.25 * b, device)) + dp.norm1(dp.grad(xr, dim=0)) + dp.norm1(dp.grad(xr, dim=1)),
+                          method="admm", device=device).solve(x0=x0, rhos=0.2, lams=0.01, max_iter=3).cpu()
+        assert rel_l2(out3.numpy(), ref3.numpy()) <= 1e-6, (view, rel_l2(out3.numpy(), ref3.numpy()))
+        fn.set_b(T(b, device))
+        out4 = s.solve(x0=x0, rhos=0.2, lams=0.01, max_iter=3).cpu()
+        assert rel_l2(out4.numpy(), ref1.numpy()) <= 1e-6
+
+
+def case_merged_loop_keeps_the_callers_duals(device, shape=(1, 2, 30, 44)):
+    """The merged z / rhs loop of the size-generic path double-buffers the duals; after an ODD number of iterations the current duals sit in
+    the loop's second set of buffers -- they are copied back, so the tensors of the state that went into iters() hold the result (as with the
+    in-place dual update of the un-merged stages) and ARE the returned state (round-4 advisor finding)."""
+    import synthetic
+    gt, b0, psf = synthetic.deconv_case(*shape, seed=3, ksize=5, ksigma=1.2)
+    b = T(b0, device)
+    for iters in (3, 4):
+        x = dp.Variable()
+        s = dp.compile(dp.sum_squares(dp.conv(x, psf) - b) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device=device)
+        _, rhos, lams, _ = s.defaults(b, 0.3, 0.01, iters)
+        rd, ld = rhos.to(device), {k: v.to(device) for k, v in lams.items()}
+        st = s.initialize(b)
+        st[2][0].add_(0.0)
+        held = [t for t in st[2]]                              # the caller keeps its state's dual tensors
+        out = s.iters(st, rd, ld, iters)
+        assert s.last_path == "fused"
+        for a, c in zip(held, out[2]):
+            assert a is c or torch.equal(a, c), ("the caller's dual tensors hold stale values after an odd number of iterations", iters)
+        ref = s.solve(x0=b, rhos=0.3, lams=0.01, max_iter=iters, return_full_states=True)
+        for a, c in zip(held, ref[2]):
+            assert rel_l2(a.cpu().numpy(), c.cpu().numpy()) <= 2e-6, iters
 
 
 CG_BRANCHES = (("default", {}),
@@ -1538,6 +1572,56 @@ def case_doe_psf_grad(device):
             r = rel_l2(got.detach().cpu().numpy(), g[f"{tag}_{name}"])
             record(f"doe {tag} {name} vs the reference's autograd", r, 1e-4)
             assert r <= 1e-4, (tag, name, r)
+
+
+def case_train_unrolled_pnp_full_size(device, tol_pred=1e-5, tol_grad=1e-4):
+    """G39 -- the training workload `bench.py` times (`train_unrolled_pnp`: the reference's published throughput figure) at its own size: 2 x 3 x
+    768 x 768, ADMM unrolled x 10 on a conv_doe data term + frozen FFDNet-colour prior, MSE loss; the first step's forward result, loss and the
+    gradients w.r.t. the PSF (through the data term and through the simulated observation), rho_t and sigma_t^2 against the reference's
+    autograd.  Bars: 1e-5 on the forward result and the loss, 1e-4 on the gradients (measured on the MI355X: prediction 2.3e-6, loss 8e-8,
+    d/d rho_t 4e-8, d/d sigma_t^2 3.7e-6, d/d PSF 2.5e-7; profiles/r5_parity_achieved_gpu.json)."""
+    import synthetic
+    g = load_golden("g39_train_unrolled_pnp")
+    bs, size, iters, k = 2, 768, 10, 15
+    rng = np.random.RandomState(int(g["seed"]))
+    gt = T(synthetic.synth_detail(rng, bs, 3, size, size), device)
+    psf0 = synthetic.point_spread_function(k, 5.0)
+    full = np.zeros((1, 3, size, size), np.float32)
+    full[:, :, :k, :k] = psf0[:, :, 0]
+    full = np.roll(full, (size // 2 - k // 2, size // 2 - k // 2), axis=(-2, -1))
+    noise = T((rng.randn(bs, 3, size, size) * 7.65 / 255).astype(np.float32), device)
+    psf = T(full, device).clone()
+    psf = (psf / psf.sum(dim=(-2, -1), keepdim=True)).detach().requires_grad_(True)
+    rhos = T(g["rhos"], device).clone().requires_grad_(True)
+    lams = T(g["lams"], device).clone().requires_grad_(True)
+    x, P, Bv = dp.Variable(), dp.Placeholder(), dp.Placeholder()
+    reg = dp.deep_prior(x, denoiser=_ffdnet("color", device))
+    solver = dp.compile(dp.sum_squares(dp.conv_doe(x, P, circular=True), Bv) + reg, method="admm", device=device)
+    solver = dp.specialize(solver, method="unroll", device=device, max_iter=iters)
+    blur = dp.conv_doe(dp.Variable(), P, circular=True).to(device)
+    P.value = psf
+    inp = blur.forward(gt) + noise
+    Bv.value = inp
+    pred = solver.solve(x0=inp.detach(), rhos=rhos, lams={reg: lams.sqrt()})
+    loss = ((pred - gt) ** 2).mean()
+    loss.backward()
+    _check_packed(g, "inp", inp.detach(), 8, TOL, what="train step: observation ")
+    r = rel_l2(pred.detach()[..., ::8, ::8].cpu().numpy(), g["pred"])
+    record("train step 2 x 3 x 768^2: prediction samples vs the reference", r, tol_pred)
+    assert r <= tol_pred, r
+    lv, lr = float(loss.detach().double()), float(g["loss"])
+    record("train step 2 x 3 x 768^2: loss", abs(lv - lr) / abs(lr), tol_pred)
+    assert abs(lv - lr) <= tol_pred * abs(lr), (lv, lr)
+    h0 = size // 2 - 16
+    for name, got, ref in (("d/d rho_t", rhos.grad, g["g_rhos"]), ("d/d sigma_t^2", lams.grad, g["g_lams"]),
+                           ("d/d PSF (32 x 32 window around its support)", psf.grad[..., h0:h0 + 32, h0:h0 + 32], g["g_psf"])):
+        assert got is not None, name
+        e = rel_l2(got.detach().cpu().numpy(), ref)
+        record(f"train step 2 x 3 x 768^2: {name} vs the reference's autograd", e, tol_grad)
+        assert e <= tol_grad, (name, e)
+    e = abs(float(psf.grad.double().norm()) - float(g["g_psf_l2"])) / float(g["g_psf_l2"])
+    record("train step 2 x 3 x 768^2: |d/d PSF|_2 over the whole plane", e, tol_grad)
+    assert e <= tol_grad, e
 
 
 def case_linop_autograd(device):

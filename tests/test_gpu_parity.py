@@ -596,3 +596,11 @@ def test_g37_bench_only_plane_sizes_at_full_size():
 
 def test_g38_config3_whole_batch_both_ends_of_the_schedule():
     pc.case_full_c3_batch8(DEV)
+
+
+def test_merged_loop_keeps_the_callers_duals():
+    pc.case_merged_loop_keeps_the_callers_duals(DEV)
+
+
+def test_g39_training_workload_at_bench_size():
+    pc.case_train_unrolled_pnp_full_size(DEV)
