@@ -398,6 +398,8 @@ bool launch_iter_rows_par(const float2* sin, float2* sout, const IterTerms& TT, 
     const int knob = tune(TUNE_ITER_PAR_MAX_ROWS);
     const long max_rows = knob > 0 ? knob : (knob < 0 ? 0 : 8192);
     if ((long)P * H > max_rows) return false;
+    // (a few 256-wide planes -- config 1 -- stay on the lock-step kernel's 8-row bands: 0.580 ms per 20-iteration solve against 0.606 here)
+    if (W <= 256 && (long)P * H <= 4096 && knob == 0) return false;
   }
   switch (W) {
     case 256: launch_par<128, 16>(sin, sout, TT, rho_next, x_out, emit_v, C, H, P, twW, s); break;

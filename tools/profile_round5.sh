@@ -25,6 +25,8 @@ cp $(find $out/kt5 -name "*kernel_stats.csv" | head -1) $out/c5_kernel_stats.csv
 python tools/bench_shapes.py 8x3x1024x1024 8x3x768x1024 8x3x768x768 8x3x1024x768 1x3x1024x1024 1x3x768x1024 1x3x768x768 8x3x1000x1000 8x3x720x1280 8x3x640x640 8x3x500x500 4x3x1536x1536 4x3x2048x2048 8x3x1080x1920 > $out/plane_sizes.log 2>&1
 for s in 8x3x1000x1000 8x3x720x1280; do python tools/prof_shape.py $s; done > $out/generic_planes_kernels.log 2>&1
 python tools/bench_methods.py > $out/bench_methods.log 2>&1
+(python tools/bench_c5.py; python tools/bench_c5.py bf16) > $out/c5_steady_ab.log 2>&1
+DPX_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra-configs > $out/bench_forced_dist_path.json 2>> $out/bench.err
 # matrix-core evidence for the committed convolution kernels
 tools/profile_ffdnet_r3.sh $tag > $out/ffdnet_modes.log 2>&1; cp gpurun_out/ffd_$tag/ffdnet_pmc.json $out/ffdnet_pmc.json; cp gpurun_out/ffd_$tag/kernel_stats.csv $out/ffdnet_kernel_stats.csv
 python -m pytest tests -m gpu -q > $out/gputests.log 2>&1; cp gpurun_out/parity_achieved_gpu.json $out/parity_achieved_gpu.json
