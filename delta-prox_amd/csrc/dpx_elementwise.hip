@@ -676,6 +676,49 @@ extern "C" int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, cons
   return launch_status("dpx_admm_rhs");
 }
 
+// rhs = rho_b sum_i K_i^T K_i x0: dpx_admm_rhs for a state that comes straight from ADMM.initialize (algo/admm.py:61-67: v_i = K_i x0, u_i = 0)
+// without that state -- the same differences in the same order (K^T (K x0 - 0) for grad: (x[h] - x[h-1]) - (x[h+1] - x[h]), circular)
+__global__ void k_rhs_fresh(float* __restrict__ rhs, const float* __restrict__ x0, const float* __restrict__ rho, int nI, int nH, int nW, int B, int C,
+                            int H, int W) {
+  const long total = (long)B * C * H * W;
+  for (long i = (long)xcd_block() * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long row = i / W;
+    const int h = (int)(row % H);
+    const long plane = row / H;
+    const float* p = x0 + plane * H * W;
+    const float c = p[(long)h * W + w];
+    float acc = 0.f;
+    for (int k = 0; k < nI; ++k) acc += c;
+    if (nH) {
+      const float up = p[(long)(h ? h - 1 : H - 1) * W + w], dn = p[(long)(h + 1 < H ? h + 1 : 0) * W + w];
+      const float t = (c - up) - (dn - c);
+      for (int k = 0; k < nH; ++k) acc += t;
+    }
+    if (nW) {
+      const float lf = p[(long)h * W + (w ? w - 1 : W - 1)], rt = p[(long)h * W + (w + 1 < W ? w + 1 : 0)];
+      const float t = (c - lf) - (rt - c);
+      for (int k = 0; k < nW; ++k) acc += t;
+    }
+    rhs[i] = rho[plane / C] * acc;
+  }
+}
+extern "C" int dpx_admm_rhs_fresh(float* rhs, const float* x0, const float* rho, const int* linops, int nterms, int B, int C, int H, int W,
+                                  dpx_stream_t stream) {
+  DPX_REQUIRE(rhs && x0 && rho && linops && rhs != x0 && nterms >= 1 && nterms <= DPX_MAX_TERMS && B > 0 && C > 0 && H > 0 && W > 0,
+              "dpx_admm_rhs_fresh: bad arguments");
+  int nI = 0, nH = 0, nW = 0;
+  for (int i = 0; i < nterms; ++i) {
+    DPX_REQUIRE(linops[i] >= DPX_LIN_IDENTITY && linops[i] <= DPX_LIN_GRAD_W, "dpx_admm_rhs_fresh: term %d: operator %d", i, linops[i]);
+    nI += linops[i] == DPX_LIN_IDENTITY;
+    nH += linops[i] == DPX_LIN_GRAD_H;
+    nW += linops[i] == DPX_LIN_GRAD_W;
+  }
+  const long n = (long)B * C * H * W;
+  DPX_LAUNCH("k_rhs_fresh", k_rhs_fresh, dim3(grid_for8(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, rhs, x0, rho, nI, nH, nW, B, C, H, W);
+  return launch_status("dpx_admm_rhs_fresh");
+}
+
 extern "C" int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int nterms, float* rhs, const float* ktb, const float* rho_next,
                                     int dual, int emit_v, int B, int C, int H, int W, dpx_stream_t stream) {
   DPX_REQUIRE(x && rhs && rho_next && rhs != x && B > 0 && C > 0 && H > 0 && W > 0 && nterms > 0, "dpx_admm_zupdate_rhs: bad arguments");

@@ -86,7 +86,7 @@ extern "C" size_t dpx_admm_unrolled_hist_bytes(int nterms, int T, int B, int C, 
 extern "C" int dpx_admm_unrolled_forward(float* hist, const float* const* v0, const float* const* u0, const int* linops, const int* proxes,
                                          const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
                                          const void* spec_add, const void* dd, float eps, int B, int C, int H, int W, const void* table,
-                                         void* spectrum_ws, dpx_stream_t stream) {
+                                         void* spectrum_ws, const float* fresh_x0, dpx_stream_t stream) {
   DPX_REQUIRE(hist && v0 && u0 && linops && proxes && alphas && rho_tab && lam_tabs && dd && table && spectrum_ws,
               "dpx_admm_unrolled_forward: null pointer");
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && T >= 1 && B > 0 && C > 0 && H > 0 && W > 0, "dpx_admm_unrolled_forward: bad sizes");
@@ -101,14 +101,18 @@ extern "C" int dpx_admm_unrolled_forward(float* hist, const float* const* v0, co
       char* spec_b = spec_a + dpx_spectrum_bytes(B * C, H, W) / 2;
       dpx_term rt[DPX_MAX_TERMS];
       for (int i = 0; i < nterms; ++i) rt[i] = dpx_term{linops[i], proxes[i], 1.0f, 0, nullptr, (float*)v0[i], (float*)u0[i], nullptr};
-      DPX_TRY(dpx_admm_rhs(h.rhs(0), nullptr, rho_tab, rt, nterms, B, C, H, W, stream));
+      // fresh_x0: the state is ADMM.initialize(x0) untouched (v_i = K_i x0, u_i = 0) and need not exist -- the first right-hand side is formed
+      // from x0 and the first iteration does not stream the (zero) duals (DPX_TERM_U_ZERO: row 0 of plane 0 of every image of u0[i] is zero)
+      if (fresh_x0) DPX_TRY(dpx_admm_rhs_fresh(h.rhs(0), fresh_x0, rho_tab, linops, nterms, B, C, H, W, stream));
+      else DPX_TRY(dpx_admm_rhs(h.rhs(0), nullptr, rho_tab, rt, nterms, B, C, H, W, stream));
       DPX_TRY(dpx_rfft_rows(h.rhs(0), spec_a, B, C, H, W, table, stream));
       for (int it = 0; it < T; ++it) {
         const float* rho = rho_tab + (size_t)it * B;
         DPX_TRY(dpx_admm_iter_cols(spec_a, spec_b, spec_add, dd, rho, eps, B, C, H, W, table, stream));
         dpx_term zt[DPX_MAX_TERMS];
         for (int i = 0; i < nterms; ++i)
-          zt[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, h.v(it, i), it ? h.u(it - 1, i) : (float*)u0[i], h.u(it, i)};
+          zt[i] = dpx_term{linops[i], proxes[i], alphas[i], (it == 0 && fresh_x0) ? DPX_TERM_U_ZERO : 0, lam_tabs[i] + (size_t)it * B, h.v(it, i),
+                           it ? h.u(it - 1, i) : (float*)u0[i], h.u(it, i)};
         const bool last = it == T - 1;
         DPX_TRY(iter_rows_impl(spec_b, last ? nullptr : spec_a, zt, nterms, last ? nullptr : rho_tab + (size_t)(it + 1) * B, h.x(it), 1,
                                last ? nullptr : h.rhs(it + 1), 0, B, C, H, W, table, stream));
@@ -116,6 +120,7 @@ extern "C" int dpx_admm_unrolled_forward(float* hist, const float* const* v0, co
       return DPX_OK;
     }
   }
+  DPX_REQUIRE(!fresh_x0, "dpx_admm_unrolled_forward: fresh_x0 needs the two-kernel iteration (plane %d x %d is not on it): pass the initial state", H, W);
   for (int it = 0; it < T; ++it) {
     dpx_term rt[DPX_MAX_TERMS], zt[DPX_MAX_TERMS];
     for (int i = 0; i < nterms; ++i) {
@@ -146,7 +151,7 @@ extern "C" int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float
                                               const float* const* v0, const float* const* u0, const int* linops, const int* proxes,
                                               const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
                                               const void* spec_add, const void* dd, float eps, int B, int C, int H, int W,
-                                              const void* table, void* spectrum_ws, dpx_stream_t stream) {
+                                              const void* table, void* spectrum_ws, const float* fresh_x0, dpx_stream_t stream) {
   DPX_REQUIRE(hist_bf16 && work && x_out && v_out && u_out && v0 && u0 && linops && proxes && alphas && rho_tab && lam_tabs && dd && table &&
                   spectrum_ws, "dpx_admm_unrolled_forward_bf16: null pointer");
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && T >= 1 && B > 0 && C > 0 && H > 0 && W > 0, "dpx_admm_unrolled_forward_bf16: bad sizes");
@@ -171,7 +176,8 @@ extern "C" int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float
       char* spec_b = spec_a + dpx_spectrum_bytes(B * C, H, W) / 2;
       dpx_term rt[DPX_MAX_TERMS];
       for (int i = 0; i < n; ++i) rt[i] = dpx_term{linops[i], proxes[i], 1.0f, 0, nullptr, (float*)v0[i], (float*)u0[i], nullptr};
-      DPX_TRY(dpx_admm_rhs(rhs_w, nullptr, rho_tab, rt, n, B, C, H, W, stream));
+      if (fresh_x0) DPX_TRY(dpx_admm_rhs_fresh(rhs_w, fresh_x0, rho_tab, linops, n, B, C, H, W, stream));      // (see dpx_admm_unrolled_forward)
+      else DPX_TRY(dpx_admm_rhs(rhs_w, nullptr, rho_tab, rt, n, B, C, H, W, stream));
       DPX_TRY(dpx_rfft_rows(rhs_w, spec_a, B, C, H, W, table, stream));
       PlanePack P;
       P.n = 1;
@@ -184,7 +190,7 @@ extern "C" int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float
           float* pu = it ? uw((it - 1) & 1, i) : (float*)u0[i];
           float* nv = last ? v_out[i] : (float*)(slot(it) + (size_t)(2 + i) * px);
           float* nu = last ? u_out[i] : uw(it & 1, i);
-          zt[i] = dpx_term{linops[i], proxes[i], alphas[i], 0, lam_tabs[i] + (size_t)it * B, nv, pu, nu};
+          zt[i] = dpx_term{linops[i], proxes[i], alphas[i], (it == 0 && fresh_x0) ? DPX_TERM_U_ZERO : 0, lam_tabs[i] + (size_t)it * B, nv, pu, nu};
         }
         DPX_TRY(dpx_admm_iter_cols(spec_a, spec_b, spec_add, dd, rho_tab + (size_t)it * B, eps, B, C, H, W, table, stream));
         DPX_TRY(iter_rows_impl(spec_b, last ? nullptr : spec_a, zt, n, last ? nullptr : rho_tab + (size_t)(it + 1) * B,

@@ -157,7 +157,8 @@ SIGNATURES = {
     "dpx_admm_unrolled_hist_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "dpx_admm_unrolled_forward": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_float), c_int,
                                           c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p,
-                                          c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p]),
+    "dpx_admm_rhs_fresh": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_admm_unrolled_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dpx_admm_unrolled_backward": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p,
                                            c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float),
@@ -167,7 +168,7 @@ SIGNATURES = {
     "dpx_admm_unrolled_work_bytes_bf16": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dpx_admm_unrolled_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                                POINTER(c_int), POINTER(c_int), POINTER(c_float), c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p,
-                                               c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                               c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpx_admm_unrolled_bwd_ws_bytes_bf16": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dpx_admm_unrolled_backward_bf16": (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_void_p,
                                            c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float),

@@ -233,6 +233,10 @@ class _UnrolledClosed(torch.autograd.Function):
         rho_tab = rho_tab.contiguous()
         lam_tabs = [t.contiguous() for t in lam_tabs]
         lin, prx, alp, dd, table, sws = _UnrolledClosed._common(plan, dev, shape)
+        # the state is ADMM.initialize(x0) untouched and was never computed (fused.lazy_initial_state): the C side forms the first right-hand
+        # side from x0 itself (two stencil passes, two zero fills and their copies less per training step)
+        fresh_x0 = getattr(plan, "fresh_x0", None)
+        plan.fresh_x0 = None
         vp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in v])
         up = (ctypes.c_void_p * n)(*[t.data_ptr() for t in u])
         lp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in lam_tabs])
@@ -245,14 +249,14 @@ class _UnrolledClosed(torch.autograd.Function):
             u_out = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(n)]
             L.call("dpx_admm_unrolled_forward_bf16", be.ptr(hist), be.ptr(work), be.ptr(x_out), (ctypes.c_void_p * n)(*[t.data_ptr() for t in v_out]),
                    (ctypes.c_void_p * n)(*[t.data_ptr() for t in u_out]), vp, up, lin, prx, alp, n, be.ptr(rho_tab), lp, T, be.ptr(plan.FK), be.ptr(dd),
-                   ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.stream())
+                   ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.ptr(fresh_x0), be.stream())
             ctx.plan, ctx.T, ctx.n_off, ctx.shape = plan, T, len(offs), shape
             ctx.save_for_backward(rho_tab, *lam_tabs)
             ctx.hist = hist
             return (x_out, *v_out, *u_out)
         hist = torch.empty((T, 2 + 2 * n) + shape, dtype=torch.float32, device=dev)
         be.lib().call("dpx_admm_unrolled_forward", be.ptr(hist), vp, up, lin, prx, alp, n, be.ptr(rho_tab), lp, T, be.ptr(plan.FK), be.ptr(dd),
-                      ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.stream())
+                      ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.ptr(fresh_x0), be.stream())
         ctx.plan, ctx.T, ctx.n_off, ctx.shape = plan, T, len(offs), shape
         ctx.save_for_backward(rho_tab, *lam_tabs)
         ctx.hist = hist

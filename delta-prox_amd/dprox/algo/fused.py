@@ -482,7 +482,11 @@ class FusedADMM:
                 chains = 1
         fresh = dual and not vxu and fresh_state(s, state)
         lazy = fresh and getattr(s, "_fresh_lazy", False)
-        if lazy and (want_grad or T <= 0 or len(psi) == 0):     # (a path that reads the split variables)
+        # the differentiable path may keep a lazy state when nothing is differentiated THROUGH the state and the whole loop is one C call on
+        # the two-kernel iteration (autodiff._UnrolledClosed): the C side then forms the first right-hand side from x0 (dpx_admm_rhs_fresh)
+        grad_fresh = (lazy and want_grad and T > 0 and len(psi) > 0 and not x0.requires_grad and not trained_psfs
+                      and all(pc != be.PROX_EXTERNAL for _, pc in self.codes) and not os.environ.get("DPX_UNROLL_CHAIN"))
+        if lazy and not grad_fresh and (want_grad or T <= 0 or len(psi) == 0):     # (a path that reads the split variables)
             materialize_state(s, state)
             lazy = False
         s._fresh = None                                        # (the state is about to be advanced in place)
@@ -501,7 +505,7 @@ class FusedADMM:
         _tr("seeds issued")
         if not isinstance(seeded, dict):
             chains = 1
-        if lazy and seeded is None:                           # (cannot happen for a state lazy_initial_state handed out; kept as a guard)
+        if lazy and seeded is None and not grad_fresh:         # (cannot happen for a state lazy_initial_state handed out; kept as a guard)
             s._fresh, s._fresh_lazy = (x0, list(v), list(u), [t._version for t in [x0] + list(v) + list(u)]), True
             materialize_state(s, state)
             s._fresh, fresh = None, False
@@ -533,6 +537,12 @@ class FusedADMM:
             plan = autodiff.DiffPlan(self.codes, psi, (t0, c0, t1, c1), FK, otfs, ls_eps(ls), hist_bf16=getattr(s, "unroll_dtype", "f32") == "bf16",
                                      doe=doe)
             diff_offs = [o if o is not None else torch.zeros((), device=dev) for o in raw_offs]
+            if grad_fresh and not doe:
+                plan.fresh_x0 = x0
+            elif grad_fresh:                                       # (a trained PSF: the stage-by-stage path reads the state)
+                s._fresh, s._fresh_lazy = (x0, list(v), list(u), [t._version for t in [x0] + list(v) + list(u)]), True
+                materialize_state(s, state)
+                s._fresh = None
             x, v, u = autodiff.run(plan, (x0, v, u), rhos, {fn: lams[fn] for fn in psi}, T, diff_offs)
             s.Kall.update_vars([x.detach()])
             return x, v, u

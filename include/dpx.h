@@ -370,6 +370,10 @@ typedef struct dpx_term {
 
 /* rhs = ktb + sum_i rho_b * K_i^T (v_i - u_i)   -- proxfn/sum_square.py:126-135 with
  * b_i = v_i - u_i from algo/admm.py:51.  ktb = sum over Omega of K^T offset (constant per solve). */
+/* the same right-hand side for a state straight from ADMM.initialize (v_i = K_i x0, u_i = 0; algo/admm.py:61-67) WITHOUT that state:
+ * rhs = rho_b sum_i K_i^T K_i x0, the same differences in the same order; linops[i] in {identity, grad_H, grad_W}                          */
+int dpx_admm_rhs_fresh(float* rhs, const float* x0, const float* rho, const int* linops, int nterms, int B, int C, int H, int W,
+                       dpx_stream_t stream);
 int dpx_admm_rhs(float* rhs, const float* ktb, const float* rho, const dpx_term* terms, int nterms,
                  int B, int C, int H, int W, dpx_stream_t stream);
 
@@ -425,12 +429,15 @@ int dpx_otf_grad(const void* A, const void* X, const void* Y, const void* O, voi
  * forward's outputs are its last iteration's x / v_i / u_i planes.  rho_tab [T][B], lam_tabs[i] [T][B] (device).
  * backward: gx / gv_in[i] / gu_in[i] = gradients w.r.t. the final x, v_i, u_i (NULL = 0); out: gv0[i], gu0[i] (initial split /
  * dual variables), grho [T][B], glam [T][n][B], goff[k] = gradient w.r.t. the k-th Omega offset (off_otf[k]: its OTF table,
- * NULL = identity; goff[k] NULL = not wanted).                                                                       */
+ * NULL = identity; goff[k] NULL = not wanted).
+ * fresh_x0 (nullable; planes on the two-kernel iteration only): the initial state is ADMM.initialize(fresh_x0) untouched (algo/admm.py:61-67:
+ * v_i = K_i x0, u_i = 0) and need not have been computed -- the first right-hand side is formed from x0 (dpx_admm_rhs_fresh), the first
+ * iteration does not stream the zero duals; v0[i] are not dereferenced, u0[i] must hold zeros in row 0 of plane 0 of every image.       */
 size_t dpx_admm_unrolled_hist_bytes(int nterms, int T, int B, int C, int H, int W);
 int dpx_admm_unrolled_forward(float* hist, const float* const* v0, const float* const* u0, const int* linops, const int* proxes,
                               const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
                               const void* spec_add, const void* dd, float eps, int B, int C, int H, int W, const void* table,
-                              void* spectrum_ws, dpx_stream_t stream);
+                              void* spectrum_ws, const float* fresh_x0, dpx_stream_t stream);
 size_t dpx_admm_unrolled_bwd_ws_bytes(int nterms, int B, int C, int H, int W);
 int dpx_admm_unrolled_backward(const float* hist, const float* gx, const float* const* gv_in, const float* const* gu_in,
                                float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
@@ -448,7 +455,7 @@ int dpx_admm_unrolled_forward_bf16(void* hist_bf16, void* work, float* x_out, fl
                                    const float* const* v0, const float* const* u0, const int* linops, const int* proxes,
                                    const float* alphas, int nterms, const float* rho_tab, const float* const* lam_tabs, int T,
                                    const void* spec_add, const void* dd, float eps, int B, int C, int H, int W, const void* table,
-                                   void* spectrum_ws, dpx_stream_t stream);
+                                   void* spectrum_ws, const float* fresh_x0, dpx_stream_t stream);
 size_t dpx_admm_unrolled_bwd_ws_bytes_bf16(int nterms, int B, int C, int H, int W);
 int dpx_admm_unrolled_backward_bf16(const void* hist_bf16, const float* gx, const float* const* gv_in, const float* const* gu_in,
                                     float* const* gv0, float* const* gu0, float* grho, float* glam, float* const* goff,
