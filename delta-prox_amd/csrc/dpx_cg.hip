@@ -12,6 +12,7 @@
 // LDL^T factorisation in float64 on one wavefront (B <= 64; pivots >= 0), no eigen-solver needed.  Once the test succeeds
 // the state's `done` flag is set and every later control kernel of the solve returns immediately (the iterate is frozen at
 // exactly the reference's exit point; `n_done` = the iteration index the reference prints in "Converged at CG Iter").
+#include <chrono>
 #include <cstdlib>
 
 #include "dpx_cg_dev.h"
@@ -126,7 +127,7 @@ int masked_normal_apply_fused(float* p, const float* r, float* Ap, float2* z, co
                               float* state, float* dotws, unsigned* counter, int B, int H, int W, const void* table, hipStream_t s);
 size_t masked_normal_fused_ws_floats(int B, int H, int W);
 int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, float* x, const float* p,
-                    const float* Ap, int* host_flags, hipStream_t s);   // dpx_elementwise.hip
+                    const float* Ap, int* host_flags, int host_tag, hipStream_t s);   // dpx_elementwise.hip
 }
 
 extern "C" size_t dpx_cg_state_bytes(int B) { return B > 0 ? (size_t)(5 * B + 4) * sizeof(float) : 0; }
@@ -197,6 +198,24 @@ extern "C" size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_image
          (dpx::masked_normal_fused_ws_floats(B, H, W) + 8) * sizeof(float);
 }
 
+// Spin until the device has stored `tag` at *slot (host-coherent memory, written by the finishing workgroup of a launch already in the
+// stream, together with the word next to it: one 8-byte store).  Looks at the stream now and then: a stream that has drained or failed without the tag, or ten
+// seconds without it, end the wait with false.
+static bool wait_for_tag(volatile int* slot, int tag, hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long spins = 1;; ++spins) {
+    if (__atomic_load_n((const int*)slot, __ATOMIC_ACQUIRE) == tag) return true;
+    if ((spins & 0xfffffu) == 0) {                       // about every few milliseconds
+      const hipError_t q = hipStreamQuery(s);
+      if (q != hipErrorNotReady) return q == hipSuccess && __atomic_load_n((const int*)slot, __ATOMIC_ACQUIRE) == tag;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return false;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
+
 extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol,
                                  int max_iters, int B, int H, int W, const void* table, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(x && b && mask && rho && table && ws && B >= 1 && B <= 64 && H > 0 && W > 0 && max_iters >= 0 && (mask_images == 1 || mask_images == B),
@@ -224,6 +243,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
     int* pin_dev = nullptr;     // the same memory as the device addresses it
     hipEvent_t ev[4];
     int hint = -1;              // exit iteration of this thread's previous fused solve on this device (-1: none yet)
+    unsigned seq = 0;           // solves issued by this thread on this device: the high bits of the tags the test kernels store
   };
   static thread_local Ring rings[DPX_CG_MAX_DEVICES];
   int devid = 0;
@@ -234,7 +254,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   Ring& R = rings[devid];
   if (!R.pin) {
     int* pnew = nullptr;
-    if (hipHostMalloc((void**)&pnew, 4 * 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&pnew, 4 * 4 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
       set_error("dpx_cg_masked_fft: hipHostMalloc failed");
       return DPX_ERR_LAUNCH;
     }
@@ -289,31 +309,74 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
     float* fdot = (float*)((char*)dotws + dpx_bdot_ws_bytes(B, n));
     unsigned* counters = (unsigned*)(fdot + dpx::masked_normal_fused_ws_floats(B, H, W));
     DPX_LAUNCH("k_cgm_start", k_cgm_start, dim3(grid_for((long)B * n, 256, 1024)), dim3(256), 0, s, x, r, p, b, (long)B * n, flags, counters);
+    // How the host learns that the test of iteration j has run: the finishing workgroup of that launch stores (done | n_done << 1, tag_j) as one 8-byte word into slot
+    // j & 3 of a host-coherent ring, and the host spins on the tag -- slots in order, so that a launch
+    // that found the solve converged already (and stores nothing) is never waited for.  No event, no marker packet between the launches
+    // (an event per iteration left ~5.5 us of idle stream in front of every test kernel: knob cg_event_wait = 1 is that form).
+    const bool poll = !split_update && tune(TUNE_CG_EVENT_WAIT) == 0;
+    const unsigned seq = ++R.seq;
+    auto tag_of = [&](int j) { return (int)((((seq & 0x1fffffu) << 10) | (unsigned)((j & 1023) + 1)) & 0x7fffffffu); };
+    // (a slot the test kernel stored: low word = done | n_done << 1, high word = tag; a slot copied from the device flags -- the
+    //  split_update form -- : (done, n_done, ...) as they are)
+    auto slot_done = [&](int j) { return split_update ? pin[(j & 3) * 4] != 0 : (pin[(j & 3) * 4] & 1) != 0; };
+    auto slot_it = [&](int j) { return split_update ? pin[(j & 3) * 4 + 1] : pin[(j & 3) * 4] >> 1; };
+    int inspected = 0;                                       // slots of iterations [0, inspected) have been looked at
+    auto inspect = [&](int upto) -> int {                    // 1: converged (done / done_it set), 0: not yet, < 0: error
+      for (; inspected <= upto; ++inspected) {
+        volatile int* sl = pin + (inspected & 3) * 4;
+        if (!wait_for_tag(sl + 1, tag_of(inspected), s)) {
+          set_error("dpx_cg_masked_fft: the stop test of iteration %d never reported (stream failed or timed out)", inspected);
+          return DPX_ERR_LAUNCH;
+        }
+        if (sl[0] & 1) {
+          done = true;
+          done_it = sl[0] >> 1;
+          return 1;
+        }
+      }
+      return 0;
+    };
     for (int it = 0; it < n_it; ++it) {
       if (it >= LAG) {
-        CG_HIP(hipEventSynchronize(ev[(it - LAG) & 3]));
-        if (pin[((it - LAG) & 3) * 4]) {
-          done = true;
-          done_it = pin[((it - LAG) & 3) * 4 + 1];
-          break;
+        if (poll) {
+          const int rc = inspect(it - LAG);
+          if (rc < 0) return rc;
+          if (rc) break;
+        } else {
+          CG_HIP(hipEventSynchronize(ev[(it - LAG) & 3]));
+          if (slot_done(it - LAG)) {
+            done = true;
+            done_it = slot_it(it - LAG);
+            break;
+          }
         }
       }
       // 4 launches: [x / r update of the previous iteration + Gram pass + stop rule, flags to the pinned slot] + the operator's three
       if (split_update) {
-        CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, nullptr, nullptr, nullptr, nullptr, s));
+        CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, nullptr, nullptr, nullptr, nullptr, 0, s));
       } else {
-        CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, it > 0 ? x : nullptr, p, Ap, pin_dev + (it & 3) * 4, s));
+        CG_TRY(dpx::gram_test_fused(r, gram, state, B, n, dotws, counters, it == 0 ? rtol : -1.f, it > 0 ? x : nullptr, p, Ap, pin_dev + (it & 3) * 4,
+                                    tag_of(it), s));
         // Consecutive solves of one outer loop exit at the same iteration almost always (config 4: 2, 3, 3, 3, ...).  At the iteration the
         // previous solve stopped at, look at THIS test's flag right away -- one host round trip, which the end of the solve pays
         // anyway -- instead of finding out two iterations (seven empty launches) later.  A miss costs that one wait.
         if (it == R.hint && it > 0 && !tune(TUNE_CG_NO_HINT)) {
-          CG_HIP(hipEventRecord(ev[it & 3], s));
-          CG_HIP(hipEventSynchronize(ev[it & 3]));
-          if (pin[(it & 3) * 4]) {
-            done = true;
-            done_it = pin[(it & 3) * 4 + 1];
-            last = -1;                                      // (nothing pending behind this point: the update below is not needed either)
-            break;
+          if (poll) {
+            const int rc = inspect(it);
+            if (rc < 0) return rc;
+            if (rc) {
+              last = -1;                                    // (nothing pending behind this point: the update below is not needed either)
+              break;
+            }
+          } else {
+            CG_HIP(hipEventRecord(ev[it & 3], s));
+            CG_HIP(hipEventSynchronize(ev[it & 3]));
+            if (slot_done(it)) {
+              done = true;
+              done_it = slot_it(it);
+              last = -1;
+              break;
+            }
           }
         }
       }
@@ -322,18 +385,23 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
         CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));
         CG_HIP(hipMemcpyAsync(pin + (it & 3) * 4, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
       }
-      CG_HIP(hipEventRecord(ev[it & 3], s));
+      if (!poll) CG_HIP(hipEventRecord(ev[it & 3], s));
       last = it;
     }
     if (!split_update && last >= 0 && !done) CG_TRY(dpx_cg_update(x, r, p, Ap, state, B, n, stream));     // the last iteration's update (max_iters reached without convergence)
     if (!done && last >= 0) {
       // the iterations the loop did not look at yet, oldest first (a launch behind the converged one leaves its slot untouched)
-      CG_HIP(hipEventSynchronize(ev[last & 3]));
-      for (int j = (last - LAG + 1 > 0 ? last - LAG + 1 : 0); j <= last; ++j)
-        if (pin[(j & 3) * 4]) {
-          done_it = pin[(j & 3) * 4 + 1];
-          break;
-        }
+      if (poll) {
+        const int rc = inspect(last);
+        if (rc < 0) return rc;
+      } else {
+        CG_HIP(hipEventSynchronize(ev[last & 3]));
+        for (int j = (last - LAG + 1 > 0 ? last - LAG + 1 : 0); j <= last; ++j)
+          if (slot_done(j)) {
+            done_it = slot_it(j);
+            break;
+          }
+      }
     }
     R.hint = done_it;
     const int st = launch_status("dpx_cg_masked_fft");

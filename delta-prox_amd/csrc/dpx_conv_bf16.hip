@@ -1083,6 +1083,39 @@ extern "C" int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, in
   return dpx_lincomb(terms[ext].u, 2, xs, cf, nullptr, B, (long)C * H * W, stream);     // u = d - v
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One plug-and-play iteration whose x-update is the masked-Fourier CG solve (config 4: ADMM / LinearizedADMM on compressed-sensing MRI,
+// algo/admm.py:49-59 / 78-100 with least_squares.solve_cg, proxfn/sum_square.py:158-197) without returning to the host language:
+//   rhs = Ktb + rho sum_i (v_i - u_i)  ->  x = dpx_cg_masked_fft(rhs)  ->  closed-form terms: v_i, u_i;  the prior's term `ext`:
+//   d = x + u (left in terms[ext].v by the z stage), v = FFDNet(d, sigma), u = d - v.
+// Between the CG solve's last look at its stop flag and the denoiser's first launch the host runs this function's few lines instead of
+// the host language's operator layers (44 us of idle stream per iteration of the 4 x 1 x 320^2 shard, profiles/r5_c4_timeline.txt).
+// Single-channel images (C = 1: the fused CG's planes).  Returns the CG exit iteration (>= 0) or a negative status.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int dpx_admm_cg_pnp_iter(float* x, float* rhs, const float* ktb, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
+                                    const float* sigma, const float* mask, int mask_images, float n_identity, float rtol, int max_iters,
+                                    const void* packed, int in_nc, int nc, int nb, int mode, int B, int H, int W, const void* table, void* cg_ws,
+                                    void* ffd_ws, dpx_stream_t stream) {
+  DPX_REQUIRE(x && rhs && terms && v_new && rho && sigma && mask && packed && table && cg_ws && ffd_ws, "dpx_admm_cg_pnp_iter: null pointer");
+  DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && ext >= 0 && ext < nterms && terms[ext].linop == DPX_LIN_IDENTITY,
+              "dpx_admm_cg_pnp_iter: the prior must be a term on x itself");
+  DPX_REQUIRE(in_nc == 1, "dpx_admm_cg_pnp_iter: a %d-channel network on single-channel images", in_nc);
+  int rc = dpx_admm_rhs(rhs, ktb, rho, terms, nterms, B, 1, H, W, stream);
+  if (rc) return rc;
+  const int n_cg = dpx_cg_masked_fft(x, rhs, mask, mask_images, rho, n_identity, rtol, max_iters, B, H, W, table, cg_ws, stream);
+  if (n_cg < 0) return n_cg;
+  rc = dpx_admm_zupdate(x, terms, nterms, B, 1, H, W, stream);
+  if (rc) return rc;
+  const float* d = terms[ext].v;
+  if (mode == 0) rc = dpx_ffdnet_forward(d, v_new, sigma, packed, in_nc, nc, nb, B, H, W, ffd_ws, stream);
+  else rc = dpx_ffdnet_forward_bf16(d, v_new, sigma, packed, in_nc, nc, nb, mode, B, H, W, ffd_ws, stream);
+  if (rc) return rc;
+  const float* xs[2] = {d, v_new};
+  const float cf[2] = {1.f, -1.f};
+  rc = dpx_lincomb(terms[ext].u, 2, xs, cf, nullptr, B, (long)H * W, stream);     // u = d - v
+  return rc ? rc : n_cg;
+}
+
 // 1 if a split-f16 layer (mode 3) has met an operand outside the binary16 range since the last reset (results of that call are then
 // invalid: rerun in mode 6).  Synchronises the device.
 extern "C" int dpx_ffdnet_f16_overflow(int reset) {

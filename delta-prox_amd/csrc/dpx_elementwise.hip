@@ -470,11 +470,12 @@ __global__ void __launch_bounds__(256) k_gram_tile(const float* __restrict__ r, 
 // (cg_test_block) -- k_gram_tile -> k_dot_finish -> k_cg_test in one launch.  B <= 32.
 // UPDATE: + the x / r update of the previous iteration in the slab load (k_cg_update folded in: alpha_b = gamma_b / <p_b, A p_b> from the
 // state the previous launches left).  host_flags (nullable): a host-mapped copy of (done, n_done) written by the finishing workgroup --
-// the host polls it behind an event instead of copying the flags back with a transfer per iteration.
+// the host polls it instead of copying the flags back with a transfer per iteration: one 8-byte word, low half = done | n_done << 1, high
+// half = host_tag, which tells the host that THIS launch's test has run (dpx_cg_masked_fft spins on it: no event, no marker packet).
 template <bool UPDATE>
 __global__ void __launch_bounds__(256) k_gram_tile_test(float* __restrict__ r, float* __restrict__ partial, float* __restrict__ G, CgState S,
                                                         long npb, int nblk, unsigned* __restrict__ counter, float init_rtol, float* __restrict__ x,
-                                                        const float* __restrict__ p, const float* __restrict__ Ap, int* __restrict__ host_flags) {
+                                                        const float* __restrict__ p, const float* __restrict__ Ap, int* __restrict__ host_flags, int host_tag) {
   __shared__ double rawd[64 * 65];                        // the slabs' staging (28.8 KB), then the test's matrix (33.3 KB)
   char* raw = (char*)rawd;
   __shared__ int shf[3];
@@ -511,10 +512,10 @@ __global__ void __launch_bounds__(256) k_gram_tile_test(float* __restrict__ r, f
   if (host_flags) {
     __syncthreads();
     if (threadIdx.x == 0) {
-      host_flags[1] = S.flags()[1];
-      __threadfence_system();
-      host_flags[0] = S.flags()[0];
-      __threadfence_system();
+      // (done, n_done, tag) in ONE 8-byte store the host reads in one piece: nothing else travels through memory with it (the iterate is
+      //  consumed by later launches of this stream), so no system-scope fence -- each one writes the L2's dirty lines back -- is needed
+      const unsigned long long word = ((unsigned long long)(unsigned)host_tag << 32) | (unsigned)((S.flags()[1] << 1) | (S.flags()[0] ? 1 : 0));
+      __hip_atomic_store((unsigned long long*)host_flags, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -527,7 +528,7 @@ __global__ void __launch_bounds__(256) k_gram_tile_test(float* __restrict__ r, f
 template <int BT, bool UPDATE>
 __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, float* __restrict__ partial, float* __restrict__ G, CgState S, long npb,
                                                          int nblk, unsigned* __restrict__ counter, float init_rtol, float* __restrict__ x,
-                                                         const float* __restrict__ p, const float* __restrict__ Ap, int* __restrict__ host_flags) {
+                                                         const float* __restrict__ p, const float* __restrict__ Ap, int* __restrict__ host_flags, int host_tag) {
   constexpr int NP = BT * (BT + 1) / 2;
   __shared__ double rawd[64 * 65];                        // the test's matrix (cg_test_block)
   __shared__ float red[4 * NP];
@@ -596,10 +597,10 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
   if (host_flags) {
     __syncthreads();
     if (threadIdx.x == 0) {
-      host_flags[1] = S.flags()[1];
-      __threadfence_system();
-      host_flags[0] = S.flags()[0];
-      __threadfence_system();
+      // (done, n_done, tag) in ONE 8-byte store the host reads in one piece: nothing else travels through memory with it (the iterate is
+      //  consumed by later launches of this stream), so no system-scope fence -- each one writes the L2's dirty lines back -- is needed
+      const unsigned long long word = ((unsigned long long)(unsigned)host_tag << 32) | (unsigned)((S.flags()[1] << 1) | (S.flags()[0] ? 1 : 0));
+      __hip_atomic_store((unsigned long long*)host_flags, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -1064,7 +1065,7 @@ namespace dpx {
 // Gram pass + finish + stop rule in one launch (dpx_cg_masked_fft's fused iteration, B <= 32); ws: B * B * gram_blocks floats
 // x / p / Ap non-null: the pending update x += alpha p, r -= alpha A p of the previous iteration is applied on the way (r is written)
 int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, float* x, const float* p,
-                    const float* Ap, int* host_flags, hipStream_t s) {
+                    const float* Ap, int* host_flags, int host_tag, hipStream_t s) {
   const int env_blk = tune(TUNE_CG_GRAM_BLOCKS);      // tuning
   int nblk = gram_blocks(n_per_batch);
   // the finishing workgroup adds up B * B * nblk partial products: for larger batches fewer, longer slab walks (B = 32: 64 workgroups)
@@ -1084,10 +1085,10 @@ int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, vo
   do {                                                                                                                                           \
     if (x)                                                                                                                                       \
       DPX_LAUNCH("k_gram_small_test_upd", (k_gram_small_test<BT, true>), dim3(nb), dim3(256), 0, s, r, (float*)ws, G, S, n_per_batch, nb, counter,  \
-                 init_rtol, x, p, Ap, host_flags);                                                                                               \
+                 init_rtol, x, p, Ap, host_flags, host_tag);                                                                                               \
     else                                                                                                                                         \
       DPX_LAUNCH("k_gram_small_test", (k_gram_small_test<BT, false>), dim3(nb), dim3(256), 0, s, r, (float*)ws, G, S, n_per_batch, nb, counter,     \
-                 init_rtol, x, p, Ap, host_flags);                                                                                               \
+                 init_rtol, x, p, Ap, host_flags, host_tag);                                                                                               \
   } while (0)
     if (B <= 1) DPX_GRAM_SMALL(1);
     else if (B <= 2) DPX_GRAM_SMALL(2);
@@ -1098,10 +1099,10 @@ int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, vo
   }
   if (x)
     DPX_LAUNCH("k_gram_tile_test_upd", k_gram_tile_test<true>, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch,
-               nblk, counter, init_rtol, x, p, Ap, host_flags);
+               nblk, counter, init_rtol, x, p, Ap, host_flags, host_tag);
   else
     DPX_LAUNCH("k_gram_tile_test", k_gram_tile_test<false>, dim3(nblk), dim3(256), 0, s, r, (float*)ws, G, CgState{(float*)state, B}, n_per_batch,
-               nblk, counter, init_rtol, x, p, Ap, host_flags);
+               nblk, counter, init_rtol, x, p, Ap, host_flags, host_tag);
   return launch_status("gram_test_fused");
 }
 }  // namespace dpx

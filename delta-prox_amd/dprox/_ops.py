@@ -561,6 +561,43 @@ def admm_pnp_iter(x, rhs, term_arr, nterms, ext, v_new, rho, sigma, spec_add, dd
            ptr(spectrum_ws(B * C, H, W, x.device)), ptr(ws), be.stream())
 
 
+class CgPnpIter:
+    """One plug-and-play iteration with the masked-Fourier CG x-update in one C call (dpx_admm_cg_pnp_iter), set up once per run: everything
+    that does not change between iterations (workspaces, packed weights, the table, the mask) is resolved here, the per-iteration call
+    passes pointers only.  `net`: the gray FFDNet of term `ext`; x: [B, 1, H, W]."""
+
+    def __init__(self, x, rhs, ktb, term_arr, nterms, ext, mask, n_identity, rtol, max_iters, net):
+        B, C, H, W = _shape4(x)
+        assert C == 1 and net.in_nc == 1
+        L = be.lib()
+        self.L = L
+        self.mode = {"f32": 0, "bf16x3": 6, "bf16": 1, "f16x2": 3}[net.compute_mode]
+        mask = mask.to(device=x.device, dtype=torch.float32).contiguous()
+        mimg = B if mask.numel() == x.numel() else 1
+        assert mask.numel() == mimg * H * W
+        if self.mode == 0:
+            packed = net.packed()
+            ffd_ws = workspace("ffdnet", L.query("dpx_ffdnet_ws_bytes", B, net.in_nc, net.nc, H, W), x.device)
+        else:
+            packed = net.packed_bf16(self.mode)
+            ffd_ws = workspace("ffdnet_bf16", L.query("dpx_ffdnet_bf16_ws_bytes", B, net.in_nc, net.nc, H, W), x.device)
+        cg_ws = workspace("cg_masked_fft", L.query("dpx_cg_masked_fft_ws_bytes", B, H, W, mimg), x.device)
+        self.keep = (mask, packed, ffd_ws, cg_ws, ktb, rhs, fft_table(H, W, x.device))
+        self.fixed = (ptr(mask), mimg, c_float(n_identity), c_float(rtol), int(max_iters), ptr(packed), net.in_nc, net.nc, net.nb, self.mode, B, H, W,
+                      ptr(self.keep[6]), ptr(cg_ws), ptr(ffd_ws))
+        self.head = (ptr(rhs), ptr(ktb), term_arr, nterms, int(ext))
+
+    def __call__(self, x, v_new, rho, sigma):
+        """x (written), v_new (receives the denoised image); returns the CG exit iteration"""
+        if self.mode == 3:
+            be.note_f16_launch()
+        L = self.L
+        n = L.query("dpx_admm_cg_pnp_iter", ptr(x), *self.head, ptr(v_new), ptr(rho), ptr(sigma), *self.fixed, be.stream())
+        if n < 0:
+            raise be.DpxError(f"dpx_admm_cg_pnp_iter failed ({n}): {L.cdll.dpx_last_error().decode()}")
+        return int(n)
+
+
 def admm_zupdate(x, term_arr, nterms):
     B, C, H, W = _shape4(x)
     be.lib().call("dpx_admm_zupdate", ptr(x), term_arr, nterms, B, C, H, W, be.stream())

@@ -301,6 +301,32 @@ class FusedSplitCG:
         ktb = ls.quad_rhs()
         if ktb is not None and ktb.shape != x0.shape:
             ktb = ktb.expand_as(x0).contiguous()
+        # one gray FFDNet prior on single-channel images behind the masked-Fourier CG (config 4): the whole iteration is ONE C call
+        # (dpx_admm_cg_pnp_iter) -- the host language's layers between the CG solve's stop flag and the denoiser's first launch were 44 us of
+        # idle stream per iteration of a 4 x 1 x 320^2 shard.  DPX_SPLIT_CG_STAGED=1: the stage-by-stage loop below (A/B, tests).
+        cfg = ls.linear_solve_config
+        sysm = ls._masked_fft_system(False) if (cfg.solver_type == "cg" and not cfg.verbose) else None
+        one_call = (len(ext) == 1 and C == 1 and isinstance(psi[ext[0]].denoiser, FFDNetDenoiser) and psi[ext[0]].denoiser.model.in_nc == 1
+                    and not torch.is_grad_enabled() and sysm is not None and B <= 64 and not be.host_mode_skip_fast_cg()
+                    and ls._masked_fft_fits(sysm[0], x0) and not os.environ.get("DPX_SPLIT_CG_STAGED"))
+        s.last_split_cg_loop = "one call" if one_call else "staged"     # (tests / tools: which loop the last solve took)
+        if one_call:
+            e = ext[0]
+            x = torch.empty_like(x0)
+            v_new = torch.empty_like(x0)
+            step = ops.CgPnpIter(x, rhs, ktb, terms, n, e, sysm[0], sysm[1], cfg.rtol, cfg.max_iters, psi[e].denoiser.model)
+            for it in tqdm(range(T), disable=not pbar):
+                for i in range(n):
+                    terms[i].lam = lam_tab[i][it].data_ptr()
+                ls.cg_iters.append(step(x, v_new, rho_tab[it], lam_tab[e][it]))
+                v[e], v_new = v_new, v[e]                            # the denoised image becomes v; its old buffer is the next target
+                terms[e].v = v[e].data_ptr()
+                var.value = x
+                if callback is not None:
+                    s._notify_all_op_current_step(it)
+                    callback(iter=it, state=(x, v, u), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+            s.Kall.update_vars([x])
+            return x, v, u
         for it in tqdm(range(T), disable=not pbar):
             for i in range(n):
                 terms[i].lam = lam_tab[i][it].data_ptr()

@@ -235,7 +235,9 @@ class FFDNet(RefKeyed):
         be.require(x, what="FFDNet input")
         B, C, H, W = x.shape
         assert C == self.in_nc, f"FFDNet built for {self.in_nc} channels, got {C}"
-        train_w = any(p.requires_grad for p in self.parameters())
+        # (inference inside torch.no_grad() -- every plug-and-play iteration -- must not pay for a walk over the 30 parameters: the host is
+        #  the critical path between the x-update and the first convolution launch of config 4's shard)
+        train_w = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if torch.is_grad_enabled() and (train_w or x.requires_grad or (isinstance(sigma, torch.Tensor) and sigma.requires_grad)):
             sig_t = sigma if isinstance(sigma, torch.Tensor) else torch.as_tensor(sigma, dtype=torch.float32)
             sig_t = sig_t.to(device=x.device, dtype=torch.float32).reshape(-1)

@@ -87,6 +87,9 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        2 = the 32 x 32 slab kernel of larger batches
  *   cg_no_hint           1 = the fused CG does not look at the stop flag early at the iteration   DPX_CG_NO_HINT
  *                        the previous solve exited at (same result, seven more empty launches)
+ *   cg_event_wait        1 = the fused CG waits for its stop flag behind a HIP event per iteration       DPX_CG_EVENT_WAIT
+ *                        (rounds 2 - 4; a marker packet, ~5 us of idle stream each) instead of spinning
+ *                        on the tag the test kernel stores into host-coherent memory (same result)
  *   unroll_bwd_staged    dpx_admm_unrolled_backward: 0 = the two-kernel backward iteration on          DPX_UNROLL_BWD_STAGED
  *                        power-of-two planes (k_bwd_rows), else the image-domain fused stage; 2 = the
  *                        image-domain fused stage everywhere; 1 = the rhs stage and the z stage of
@@ -599,6 +602,16 @@ int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsigma, float*
 int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
                       const float* sigma, const void* spec_add, const void* dd, float eps, const void* packed, int in_nc, int nc, int nb,
                       int mode, int B, int C, int H, int W, const void* table, void* spectrum_ws, void* ffd_ws, dpx_stream_t stream);
+
+/* ... and with the masked-Fourier CG x-update in place of the Fourier solve (config 4: algo/admm.py:49-59 / 78-100 over
+ * least_squares.solve_cg, proxfn/sum_square.py:158-197): rhs = ktb + rho sum_i (v_i - u_i) (ktb: K^T b of the data term, nullable),
+ * x = dpx_cg_masked_fft(rhs) (mask / mask_images / n_identity / rtol / max_iters / cg_ws as there), z / dual stage of the closed-form
+ * terms, denoiser on d = x + u, u = d - v.  Single-channel images [B, 1, H, W], a gray network (in_nc = 1), sigma [B].  Returns the CG
+ * exit iteration (>= 0) or a negative status.                                                                                      */
+int dpx_admm_cg_pnp_iter(float* x, float* rhs, const float* ktb, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
+                         const float* sigma, const float* mask, int mask_images, float n_identity, float rtol, int max_iters,
+                         const void* packed, int in_nc, int nc, int nb, int mode, int B, int H, int W, const void* table, void* cg_ws,
+                         void* ffd_ws, dpx_stream_t stream);
 
 /* Generic convolution layers on the same MFMA kernel (residual U-Net denoisers behind deep_prior: DRUNet,
  * dprox/proxfn/pnp/denoisers/models/network_unet.py:67-117, basicblock.py).  NCHW fp32, stride 1.

@@ -46,6 +46,8 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
 typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
+#define hipErrorNotReady 600
+static inline hipError_t hipStreamQuery(hipStream_t) { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emul"; }
@@ -283,6 +285,10 @@ typedef int hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return 0; }
 #define hipEventDisableTiming 2
 #define hipHostMallocDefault 0
+#define hipHostMallocMapped 2
+#define hipHostMallocCoherent 0x40000000
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
 #define hipMemcpyDeviceToHost 2
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = 0; return 0; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, int) { *p = malloc(n); return *p ? 0 : 1; }

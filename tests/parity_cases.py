@@ -601,6 +601,8 @@ CG_BRANCHES = (("default", {}),
                ("fused + split update", dict(cg_fused_max_b=32, cg_split_update=1, cg_unfused=0)),
                ("fused, slab Gram kernel", dict(cg_fused_max_b=32, cg_gram_small=2)),
                ("fused, no exit-iteration hint", dict(cg_fused_max_b=32, cg_no_hint=1)),
+               ("fused, stop flag behind an event", dict(cg_fused_max_b=32, cg_event_wait=1)),
+               ("fused, stop flag behind an event, no hint", dict(cg_fused_max_b=32, cg_event_wait=1, cg_no_hint=1)),
                ("fused, 2 rows / 4 columns per workgroup", dict(cg_fused_max_b=32, cg_rows_per_wg=2, cg_cols_per_wg=4)),
                ("step by step", dict(cg_fused_max_b=0)),
                ("step by step (cg_unfused)", dict(cg_fused_max_b=32, cg_unfused=1)))
@@ -616,7 +618,7 @@ def case_cg_branches(device, quick=False):
     assert {"cg_fused_max_b", "cg_split_update", "cg_unfused"} <= set(be.tune_names())
     g6, g6b = load_golden("g6_cg"), load_golden("g6b_cg_large_batches")
     # (quick: the host emulator's share -- one batch on each side of the size rule, the branches that differ in kernels)
-    branches = [br for br in CG_BRANCHES if not quick or br[0] in ("default", "fused", "fused, slab Gram kernel", "step by step")]
+    branches = [br for br in CG_BRANCHES if not quick or br[0] in ("default", "fused", "fused, slab Gram kernel", "fused, stop flag behind an event", "step by step")]
     for B, g in (((4, g6), (12, g6b)) if quick else ((1, g6), (4, g6), (12, g6b), (20, g6b))):
         mask, rhs = T(g[f"B{B}_mask"], device), T(g[f"B{B}_rhs"], device).contiguous()
         rho = T(g[f"B{B}_rho"], device) if f"B{B}_rho" in g else torch.full((B,), float(g["rho"]), device=device)
@@ -1052,6 +1054,29 @@ def case_ladmm_cg(device):
     with torch.no_grad():
         x_native = dp.Problem(fns2, linear_solve_config=cfg).solve(method="ladmm", device=device, x0=x0, rhos=0.5, lams=0.03, max_iter=5)
     assert_close(x_native.cpu(), g["x"], TOL, "ladmm x with contrib.masked_fft")
+    # the whole iteration in one C call (dpx_admm_cg_pnp_iter) against the stage-by-stage loop: the same launches, the same bits, the
+    # same CG exit iterations -- and both are what the two solves above went through
+    import os
+    outs = {}
+    for staged in (False, True):
+        os.environ.pop("DPX_SPLIT_CG_STAGED", None)
+        if staged:
+            os.environ["DPX_SPLIT_CG_STAGED"] = "1"
+        try:
+            x3 = dp.Variable()
+            ls_fns = dp.sum_squares(masked_fft(x3, mask), y) + dp.nonneg(x3) + dp.deep_prior(x3, denoiser=_ffdnet("gray", device))
+            solver = dp.compile(ls_fns, method="ladmm", device=device, linear_solve_config=cfg)
+            with torch.no_grad():
+                st3 = solver.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=5, return_full_states=True)
+        finally:
+            os.environ.pop("DPX_SPLIT_CG_STAGED", None)
+        loop = getattr(solver, "last_split_cg_loop", None)
+        outs[staged] = (st3, list(solver.least_square.cg_iters), loop)
+    (sa, na, la), (sb, nb_, lb) = outs[False], outs[True]
+    assert (la, lb) == ("one call", "staged"), (la, lb)
+    assert na == nb_ and len(na) == 5, (na, nb_)
+    assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1][1], sb[1][1]) and torch.equal(sa[2][1], sb[2][1]) and torch.equal(sa[2][0], sb[2][0])
+    assert_close(sa[0].cpu(), g["x"], TOL, "ladmm x, one call per iteration")
 
 
 def case_unrolled_grads(device):
