@@ -216,10 +216,42 @@ static bool wait_for_tag(volatile int* slot, int tag, hipStream_t s) {
   }
 }
 
+namespace dpx {
+// the fused branch (B <= cg_fused_max_b, not cg_unfused) takes this batch: its start state (r = b, x = p = 0, flags and arrival counters
+// cleared -- k_cgm_start) can then be written by the producer of b itself (dpx_admm_cg_pnp_iter's tail pass) through cg_masked_fft_start_ptrs
+bool cg_masked_fft_is_fused(int B) {
+  const int fused_max_b = tune(TUNE_CG_FUSED_MAX_B);
+  return B <= (fused_max_b > 32 ? 32 : fused_max_b) && tune(TUNE_CG_UNFUSED) == 0;
+}
+CgStartPtrs cg_masked_fft_start_ptrs(void* ws, int B, int H, int W, int mask_images) {
+  const size_t n = (size_t)H * W;
+  float* w = (float*)ws;
+  float* r = w;
+  float* p = r + (size_t)B * n;
+  float* Ap = p + (size_t)B * n;
+  float2* z0 = (float2*)(Ap + (size_t)B * n + (((size_t)3 * B * n) & 1));
+  float2* z1 = z0 + (size_t)B * n;
+  float* mask2 = (float*)(z1 + (size_t)B * n);
+  float* state = mask2 + (size_t)mask_images * n;
+  float* gram = state + 5 * B + 4;
+  float* dotws = gram + (((size_t)B * B + 63) / 64) * 64;
+  float* fdot = (float*)((char*)dotws + dpx_bdot_ws_bytes(B, (long)n));
+  unsigned* counters = (unsigned*)(fdot + dpx::masked_normal_fused_ws_floats(B, H, W));
+  return CgStartPtrs{r, p, (int*)(state + 5 * B), counters};
+}
+}  // namespace dpx
+
 extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol,
                                  int max_iters, int B, int H, int W, const void* table, void* ws, dpx_stream_t stream) {
-  DPX_REQUIRE(x && b && mask && rho && table && ws && B >= 1 && B <= 64 && H > 0 && W > 0 && max_iters >= 0 && (mask_images == 1 || mask_images == B),
+  return dpx::cg_masked_fft_run(x, b, mask, mask_images, rho, n_identity, rtol, max_iters, B, H, W, table, ws, false, nullptr, stream);
+}
+
+// started: the start state is in place already (see cg_masked_fft_start_ptrs; b is not looked at); fused branch only
+int dpx::cg_masked_fft_run(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol, int max_iters,
+                           int B, int H, int W, const void* table, void* ws, bool started, CgSpeculate* spec, dpx_stream_t stream) {
+  DPX_REQUIRE(x && (b || started) && mask && rho && table && ws && B >= 1 && B <= 64 && H > 0 && W > 0 && max_iters >= 0 && (mask_images == 1 || mask_images == B),
               "dpx_cg_masked_fft: bad arguments (B = %d must be 1..64)", B);
+  DPX_REQUIRE(!started || cg_masked_fft_is_fused(B), "dpx_cg_masked_fft: a pre-started solve needs the fused branch (B = %d)", B);
   hipStream_t s = (hipStream_t)stream;
   const long n = (long)H * W;
   float* w = (float*)ws;
@@ -308,7 +340,8 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
   if (B <= (fused_max_b > 32 ? 32 : fused_max_b) && !unfused) {
     float* fdot = (float*)((char*)dotws + dpx_bdot_ws_bytes(B, n));
     unsigned* counters = (unsigned*)(fdot + dpx::masked_normal_fused_ws_floats(B, H, W));
-    DPX_LAUNCH("k_cgm_start", k_cgm_start, dim3(grid_for((long)B * n, 256, 1024)), dim3(256), 0, s, x, r, p, b, (long)B * n, flags, counters);
+    if (!started)
+      DPX_LAUNCH("k_cgm_start", k_cgm_start, dim3(grid_for((long)B * n, 256, 1024)), dim3(256), 0, s, x, r, p, b, (long)B * n, flags, counters);
     // How the host learns that the test of iteration j has run: the finishing workgroup of that launch stores (done | n_done << 1, tag_j) as one 8-byte word into slot
     // j & 3 of a host-coherent ring, and the host spins on the tag -- slots in order, so that a launch
     // that found the solve converged already (and stores nothing) is never waited for.  No event, no marker packet between the launches
@@ -361,11 +394,17 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
         // previous solve stopped at, look at THIS test's flag right away -- one host round trip, which the end of the solve pays
         // anyway -- instead of finding out two iterations (seven empty launches) later.  A miss costs that one wait.
         if (it == R.hint && it > 0 && !tune(TUNE_CG_NO_HINT)) {
+          if (spec && poll && !spec->launched) {            // the caller's next stage, predicated on this test's verdict (CgSpeculate; the
+                                                            //  in-order look at the slots below is what makes `valid` exact)
+            spec->launched = true;
+            CG_TRY(spec->launch(spec->ctx, flags, stream));
+          }
           if (poll) {
             const int rc = inspect(it);
             if (rc < 0) return rc;
             if (rc) {
               last = -1;                                    // (nothing pending behind this point: the update below is not needed either)
+              if (spec) spec->valid = spec->launched;        // (done now or earlier: the flag was set when the predicated launch ran)
               break;
             }
           } else {
@@ -375,6 +414,7 @@ extern "C" int dpx_cg_masked_fft(float* x, const float* b, const float* mask, in
               done = true;
               done_it = slot_it(it);
               last = -1;
+              if (spec) spec->valid = spec->launched;
               break;
             }
           }

@@ -87,12 +87,33 @@ namespace dpx {
 void set_error(const char* fmt, ...);
 int launch_status(const char* what);   // hipGetLastError() -> DPX_OK / DPX_ERR_LAUNCH
 
+// ---- dpx_cg_masked_fft's start state, for a producer of the right-hand side that writes it itself (dpx_cg.hip) -------------
+struct CgStartPtrs {
+  float* r;             // residual (= b at the start), [B][H W]
+  float* p;             // direction (= 0 at the start)
+  int* flags;           // 4 control words: (0, -1, 0, 0) at the start
+  unsigned* counters;   // two arrival counters: 0 at the start
+};
+bool cg_masked_fft_is_fused(int B);
+CgStartPtrs cg_masked_fft_start_ptrs(void* ws, int B, int H, int W, int mask_images);
+// Work that follows the solve, issued BEFORE the host has seen the stop flag: at the iteration the previous solve of this thread exited at, right
+// behind that iteration's stop test, `launch` is called once with the device address of the solve's `done` word -- what it launches must do
+// nothing unless *done_flag != 0.  valid: the solve ended exactly there (the launch ran for real); otherwise the caller issues that work again,
+// unconditionally, behind the solve.
+struct CgSpeculate {
+  int (*launch)(void* ctx, const int* done_flag, dpx_stream_t stream);
+  void* ctx;
+  bool launched = false, valid = false;
+};
+int cg_masked_fft_run(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol, int max_iters,
+                      int B, int H, int W, const void* table, void* ws, bool started, CgSpeculate* spec, dpx_stream_t stream);
+
 // ---- tuning knobs (dpx_tune_set / dpx_tune_get of the C ABI; dpx_core.hip holds the table, include/dpx.h documents it) ----------
 enum Tune {
   TUNE_CG_FUSED_MAX_B, TUNE_CG_SPLIT_UPDATE, TUNE_CG_UNFUSED, TUNE_CG_GRAM_BLOCKS, TUNE_PSF2OTF_DIRECT, TUNE_COMM_ALLGATHER_RING,
   TUNE_HQS_STREAM_DUALS, TUNE_PGD_BAND, TUNE_PGD_ROWS_PLAIN, TUNE_SEED_BAND, TUNE_SEED_ROWS_PLAIN, TUNE_ITER_ROWS,
   TUNE_ITER_BAND, TUNE_ITER_R, TUNE_COLS_INPLACE, TUNE_CHAIN_LOCKSTEP, TUNE_DS_CT, TUNE_DS_RPB, TUNE_DS_ROW_THREADS,
-  TUNE_DS_COL_THREADS, TUNE_COLS_PERSIST_WG, TUNE_DEBUG_COLS, TUNE_CG_ROWS_PER_WG, TUNE_CG_COLS_PER_WG, TUNE_CG_GRAM_SMALL, TUNE_CG_NO_HINT, TUNE_UNROLL_BWD_STAGED, TUNE_UNROLL_BWD_FOLD_FINISH, TUNE_FFDNET_PRESPLIT, TUNE_GENERIC_COLS_CT, TUNE_CG_WAVE_FFT, TUNE_CONV_TILE_ROWS, TUNE_UNROLL_BWD_BAND, TUNE_WGRAD_F32, TUNE_GENERIC_INTERLEAVED, TUNE_ITER_BAND_MIN_ROWS, TUNE_COLS_WG, TUNE_ITER_PAR_MAX_ROWS, TUNE_UNROLL_BWD_PAR_MAX_ROWS, TUNE_CG_EVENT_WAIT, TUNE_COUNT
+  TUNE_DS_COL_THREADS, TUNE_COLS_PERSIST_WG, TUNE_DEBUG_COLS, TUNE_CG_ROWS_PER_WG, TUNE_CG_COLS_PER_WG, TUNE_CG_GRAM_SMALL, TUNE_CG_NO_HINT, TUNE_UNROLL_BWD_STAGED, TUNE_UNROLL_BWD_FOLD_FINISH, TUNE_FFDNET_PRESPLIT, TUNE_GENERIC_COLS_CT, TUNE_CG_WAVE_FFT, TUNE_CONV_TILE_ROWS, TUNE_UNROLL_BWD_BAND, TUNE_WGRAD_F32, TUNE_GENERIC_INTERLEAVED, TUNE_ITER_BAND_MIN_ROWS, TUNE_COLS_WG, TUNE_ITER_PAR_MAX_ROWS, TUNE_UNROLL_BWD_PAR_MAX_ROWS, TUNE_CG_EVENT_WAIT, TUNE_PNP_CG_NO_FOLD, TUNE_COUNT
 };
 int tune(Tune k);
 

@@ -598,8 +598,124 @@ extern "C" size_t dpx_ffdnet_bf16_ws_bytes(int B, int in_nc, int nc, int H, int 
   return (px * 8 * groups16(4 * in_nc + 1) + 2 * px * 8 * groups16(nc) + px * 8 * groups16(4 * in_nc)) * sizeof(float);
 }
 
+// What dpx_admm_cg_pnp_iter runs in front of the first layer instead of k_zupdate + k_bx_pack_in (identity terms, even H and W: every pixel is one
+// slot of the packed tensor): d_i = x + u_i, closed-form terms v_i = prox_i(d_i), u_i = d_i - v_i, the prior's term v = d -- k_zupdate's
+// arithmetic -- and d of the prior's term pixel-unshuffled with the sigma plane into the first layer's C8 input.  pred (nullable): the CG's
+// `done` word -- launched ahead of the host's look at it (CgSpeculate), the pass does nothing unless the solve has converged.
+struct PnpHead {
+  const float* x;
+  const float* sigma;
+  float* a;
+  const int* pred;
+  int nterms, ext;
+  float* v[DPX_MAX_TERMS];
+  float* u[DPX_MAX_TERMS];
+  const float* lam[DPX_MAX_TERMS];
+  float alpha[DPX_MAX_TERMS];
+  int prox[DPX_MAX_TERMS];
+};
+__device__ __forceinline__ float pnp_prox(int kind, float d, float lam) {      // (prox_eval of dpx_elementwise.hip)
+  switch (kind) {
+    case DPX_PROX_NORM1: {
+      const float m = fmaxf(fabsf(d) - lam, 0.f);
+      return d > 0.f ? m : (d < 0.f ? -m : 0.f * m);
+    }
+    case DPX_PROX_NONNEG: return fmaxf(d, 0.f);
+    case DPX_PROX_SUMSQ: return d / (1.f + 2.f * lam);
+    default: return d;
+  }
+}
+__global__ void k_pnp_head(PnpHead Q, int B, int C, int H, int W, int H2, int W2, int G) {
+  if (Q.pred && Q.pred[0] == 0) return;
+  const long total = (long)B * G * H2 * W2 * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    long r = i / 8;
+    const int x2 = (int)(r % W2);
+    r /= W2;
+    const int y2 = (int)(r % H2);
+    r /= H2;
+    const int g = (int)(r % G), b = (int)(r / G);
+    const int ch = g * 8 + j;
+    float out = 0.f;
+    if (ch < 4 * C) {
+      const int c = ch >> 2, yy = 2 * y2 + ((ch >> 1) & 1), xx = 2 * x2 + (ch & 1);
+      const long off = (((long)b * C + c) * H + yy) * W + xx;
+      const float xv = Q.x[off];
+      for (int t = 0; t < Q.nterms; ++t) {
+        const float d = xv + Q.u[t][off];
+        if (t == Q.ext) {
+          Q.v[t][off] = d;
+          out = d;
+        } else {
+          const float lam = Q.lam[t] ? Q.lam[t][b] * Q.alpha[t] : 0.f;
+          const float vv = pnp_prox(Q.prox[t], d, lam);
+          Q.v[t][off] = vv;
+          Q.u[t][off] = d - vv;
+        }
+      }
+    } else if (ch == 4 * C) {
+      out = Q.sigma[b];
+    }
+    Q.a[i] = out;
+  }
+}
+
+// What dpx_admm_cg_pnp_iter hangs behind the last layer instead of k_bx_unpack_out (identity terms only: every Psi term acts on x itself):
+//   v_new = PixelShuffle(last layer), u_ext = d - v_new (d = terms[ext].v), and -- rho_next non-null -- the NEXT iteration's right-hand side
+//   ktb + rho_next sum_i (v_i - u_i) written straight into the CG's start state (r = rhs, x_next = p = 0, flags / counters cleared):
+//   k_bx_unpack_out + k_lincomb + k_rhs + k_cgm_start as one launch, the same arithmetic in the same order.
+struct PnpTail {
+  float* v_new;
+  float* u_ext;
+  const float* d;
+  const float* ktb;        // nullable
+  const float* rho_next;   // nullable: no next right-hand side
+  float* x_next;
+  dpx::CgStartPtrs cg;
+  int nterms, ext;
+  const float* v[DPX_MAX_TERMS];
+  const float* u[DPX_MAX_TERMS];
+};
+__global__ void k_pnp_tail(const float* __restrict__ o, PnpTail Q, int B, int C, int H, int W, int H2, int W2, int G) {
+  const long total = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    long r = i / W;
+    const int yy = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    const int ch = c * 4 + (yy & 1) * 2 + (xx & 1);
+    const float vn = o[((((long)b * G + (ch >> 3)) * H2 + (yy >> 1)) * W2 + (xx >> 1)) * 8 + (ch & 7)];
+    const float ue = Q.d[i] - vn;
+    Q.v_new[i] = vn;
+    Q.u_ext[i] = ue;
+    if (Q.rho_next) {
+      float acc = 0.f;
+      for (int t = 0; t < Q.nterms; ++t) acc += (t == Q.ext) ? vn - ue : Q.v[t][i] - Q.u[t][i];
+      Q.cg.r[i] = fmaf(Q.rho_next[b], acc, Q.ktb ? Q.ktb[i] : 0.f);
+      Q.cg.p[i] = 0.f;
+      Q.x_next[i] = 0.f;
+    }
+  }
+  if (Q.rho_next && blockIdx.x == 0 && threadIdx.x == 0) {
+    Q.cg.flags[0] = 0;
+    Q.cg.flags[1] = -1;
+    Q.cg.flags[2] = 0;
+    Q.cg.flags[3] = 0;
+    Q.cg.counters[0] = 0u;
+    Q.cg.counters[1] = 0u;
+  }
+}
+
+static int ffdnet_forward_bf16_impl(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode, int B, int H,
+                                    int W, void* ws, dpx_stream_t stream, const PnpTail* tail, bool packed_in = false);
 extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode,
                                        int B, int H, int W, void* ws, dpx_stream_t stream) {
+  return ffdnet_forward_bf16_impl(x, y, sigma, packed, in_nc, nc, nb, mode, B, H, W, ws, stream, nullptr);
+}
+static int ffdnet_forward_bf16_impl(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode, int B, int H,
+                                    int W, void* ws, dpx_stream_t stream, const PnpTail* tail, bool packed_in) {
   DPX_REQUIRE(x && y && sigma && packed && ws, "dpx_ffdnet_forward_bf16: null pointer");
   DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 && (mode == 6 || mode == 1 || mode == 3),
               "dpx_ffdnet_forward_bf16: unsupported configuration (in_nc=%d nc=%d nb=%d mode=%d)", in_nc, nc, nb, mode);
@@ -618,8 +734,9 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
   // (the kernel runs at the matrix pipe's power-limited rate), and two 8-byte stores per lane instead of one
   // 16-byte store in the epilogue cost a little.
   const bool p8 = mode == 3 && tune(TUNE_FFDNET_PRESPLIT) == 1;
-  DPX_LAUNCH("k_bx_pack_in", k_bx_pack_in, dim3(grid_for((long)(px * 8 * G0), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W, H2, W2, G0,
-             p8 ? 1 : 0);
+  if (!packed_in)              // (packed_in: k_pnp_head has filled a0 -- plain C8, never with ffdnet_presplit)
+    DPX_LAUNCH("k_bx_pack_in", k_bx_pack_in, dim3(grid_for((long)(px * 8 * G0), 256, 8192)), dim3(256), 0, s, x, sigma, a0, B, in_nc, H, W, H2, W2, G0,
+               p8 ? 1 : 0);
   const char* wl = (const char*)packed;
   const float* cur = a0;
   int gin = G0;
@@ -636,8 +753,12 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
     cur = dst;
     gin = gout;
   }
-  DPX_LAUNCH("k_bx_unpack_out", k_bx_unpack_out, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, last, y, B, in_nc, H, W, H2,
-             W2, GL);
+  if (tail)
+    DPX_LAUNCH("k_pnp_tail", k_pnp_tail, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, (const float*)last, *tail, B, in_nc, H, W,
+               H2, W2, GL);
+  else
+    DPX_LAUNCH("k_bx_unpack_out", k_bx_unpack_out, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, last, y, B, in_nc, H, W, H2,
+               W2, GL);
   return launch_status("dpx_ffdnet_forward_bf16");
 }
 
@@ -1095,18 +1216,84 @@ extern "C" int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, in
 extern "C" int dpx_admm_cg_pnp_iter(float* x, float* rhs, const float* ktb, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
                                     const float* sigma, const float* mask, int mask_images, float n_identity, float rtol, int max_iters,
                                     const void* packed, int in_nc, int nc, int nb, int mode, int B, int H, int W, const void* table, void* cg_ws,
-                                    void* ffd_ws, dpx_stream_t stream) {
+                                    void* ffd_ws, const float* rho_next, float* x_next, int rhs_ready, dpx_stream_t stream) {
   DPX_REQUIRE(x && rhs && terms && v_new && rho && sigma && mask && packed && table && cg_ws && ffd_ws, "dpx_admm_cg_pnp_iter: null pointer");
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && ext >= 0 && ext < nterms && terms[ext].linop == DPX_LIN_IDENTITY,
               "dpx_admm_cg_pnp_iter: the prior must be a term on x itself");
   DPX_REQUIRE(in_nc == 1, "dpx_admm_cg_pnp_iter: a %d-channel network on single-channel images", in_nc);
-  int rc = dpx_admm_rhs(rhs, ktb, rho, terms, nterms, B, 1, H, W, stream);
-  if (rc) return rc;
-  const int n_cg = dpx_cg_masked_fft(x, rhs, mask, mask_images, rho, n_identity, rtol, max_iters, B, H, W, table, cg_ws, stream);
+  // the folded tail (and with it a prepared next right-hand side) needs the split kernels' C8 output, identity terms and the fused CG branch
+  bool fold = mode != 0 && dpx::cg_masked_fft_is_fused(B) && tune(TUNE_PNP_CG_NO_FOLD) == 0;
+  for (int t = 0; t < nterms; ++t) fold = fold && terms[t].linop == DPX_LIN_IDENTITY && terms[t].v && terms[t].u && !terms[t].u_out;
+  DPX_REQUIRE(!rhs_ready || fold, "dpx_admm_cg_pnp_iter: rhs_ready without the folded tail (see dpx_admm_cg_pnp_iter_folds)");
+  DPX_REQUIRE(!rho_next || (x_next && x_next != x), "dpx_admm_cg_pnp_iter: rho_next needs a second iterate buffer");
+  int rc;
+  if (!rhs_ready) {
+    rc = dpx_admm_rhs(rhs, ktb, rho, terms, nterms, B, 1, H, W, stream);
+    if (rc) return rc;
+  }
+  // the folded head (z / dual stage + the first layer's input as one pass) additionally needs even planes and the plain C8 input
+  const bool fold_head = fold && H % 2 == 0 && W % 2 == 0 && !(mode == 3 && tune(TUNE_FFDNET_PRESPLIT) == 1);
+  struct HeadCtx {
+    PnpHead Q;
+    int B, H, W, G0;
+  } hc;
+  if (fold_head) {
+    hc.B = B; hc.H = H; hc.W = W; hc.G0 = groups16(4 * in_nc + 1);
+    hc.Q.x = x; hc.Q.sigma = sigma; hc.Q.a = (float*)ffd_ws; hc.Q.pred = nullptr; hc.Q.nterms = nterms; hc.Q.ext = ext;
+    for (int t = 0; t < DPX_MAX_TERMS; ++t) {
+      const bool on = t < nterms;
+      hc.Q.v[t] = on ? terms[t].v : nullptr;
+      hc.Q.u[t] = on ? terms[t].u : nullptr;
+      hc.Q.lam[t] = on ? terms[t].lam : nullptr;
+      hc.Q.alpha[t] = on ? terms[t].alpha : 0.f;
+      hc.Q.prox[t] = on ? terms[t].prox : 0;
+    }
+  }
+  auto launch_head = +[](void* ctx, const int* pred, dpx_stream_t st) -> int {
+    HeadCtx& h = *(HeadCtx*)ctx;
+    PnpHead Q = h.Q;
+    Q.pred = pred;
+    const int H2 = h.H / 2, W2 = h.W / 2;
+    DPX_LAUNCH("k_pnp_head", k_pnp_head, dim3(grid_for((long)h.B * h.G0 * H2 * W2 * 8, 256, 8192)), dim3(256), 0, (hipStream_t)st, Q, h.B, 1, h.H, h.W, H2, W2,
+               h.G0);
+    return launch_status("dpx_admm_cg_pnp_iter");
+  };
+  // (the head goes into the stream right behind the stop test of the iteration the previous solve ended at, predicated on that test: the
+  //  host's look at the flag and its next launches overlap with it instead of leaving the stream idle -- knob pnp_cg_no_fold = 2: off)
+  dpx::CgSpeculate spec{launch_head, &hc};
+  const bool speculate = fold_head && tune(TUNE_PNP_CG_NO_FOLD) != 2;
+  const int n_cg = dpx::cg_masked_fft_run(x, rhs, mask, mask_images, rho, n_identity, rtol, max_iters, B, H, W, table, cg_ws, rhs_ready != 0,
+                                          speculate ? &spec : nullptr, stream);
   if (n_cg < 0) return n_cg;
-  rc = dpx_admm_zupdate(x, terms, nterms, B, 1, H, W, stream);
-  if (rc) return rc;
+  if (fold_head) {
+    if (!spec.valid) {
+      rc = launch_head(&hc, nullptr, stream);
+      if (rc) return rc;
+    }
+  } else {
+    rc = dpx_admm_zupdate(x, terms, nterms, B, 1, H, W, stream);
+    if (rc) return rc;
+  }
   const float* d = terms[ext].v;
+  if (fold) {
+    PnpTail Q;
+    Q.v_new = v_new;
+    Q.u_ext = terms[ext].u;
+    Q.d = d;
+    Q.ktb = ktb;
+    Q.rho_next = rho_next;
+    Q.x_next = x_next;
+    Q.cg = dpx::cg_masked_fft_start_ptrs(cg_ws, B, H, W, mask_images);
+    Q.nterms = nterms;
+    Q.ext = ext;
+    for (int t = 0; t < DPX_MAX_TERMS; ++t) {
+      Q.v[t] = t < nterms ? terms[t].v : nullptr;
+      Q.u[t] = t < nterms ? terms[t].u : nullptr;
+    }
+    rc = ffdnet_forward_bf16_impl(d, v_new, sigma, packed, in_nc, nc, nb, mode, B, H, W, ffd_ws, stream, &Q, fold_head);
+    return rc ? rc : n_cg;
+  }
+  DPX_REQUIRE(!rho_next, "dpx_admm_cg_pnp_iter: rho_next without the folded tail (see dpx_admm_cg_pnp_iter_folds)");
   if (mode == 0) rc = dpx_ffdnet_forward(d, v_new, sigma, packed, in_nc, nc, nb, B, H, W, ffd_ws, stream);
   else rc = dpx_ffdnet_forward_bf16(d, v_new, sigma, packed, in_nc, nc, nb, mode, B, H, W, ffd_ws, stream);
   if (rc) return rc;
@@ -1114,6 +1301,10 @@ extern "C" int dpx_admm_cg_pnp_iter(float* x, float* rhs, const float* ktb, cons
   const float cf[2] = {1.f, -1.f};
   rc = dpx_lincomb(terms[ext].u, 2, xs, cf, nullptr, B, (long)H * W, stream);     // u = d - v
   return rc ? rc : n_cg;
+}
+// 1 when dpx_admm_cg_pnp_iter would fold its tail for this (mode, B) -- only then may a caller pass rho_next / rhs_ready
+extern "C" int dpx_admm_cg_pnp_iter_folds(int mode, int B) {
+  return mode != 0 && dpx::cg_masked_fft_is_fused(B) && tune(TUNE_PNP_CG_NO_FOLD) == 0 ? 1 : 0;
 }
 
 // 1 if a split-f16 layer (mode 3) has met an operand outside the binary16 range since the last reset (results of that call are then

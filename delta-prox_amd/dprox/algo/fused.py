@@ -315,10 +315,15 @@ class FusedSplitCG:
             x = torch.empty_like(x0)
             v_new = torch.empty_like(x0)
             step = ops.CgPnpIter(x, rhs, ktb, terms, n, e, sysm[0], sysm[1], cfg.rtol, cfg.max_iters, psi[e].denoiser.model)
+            xs = (x, torch.empty_like(x0)) if step.folds else (x, x)  # (folded tail: iteration t + 1's iterate is zeroed while x_t is still the result)
             for it in tqdm(range(T), disable=not pbar):
                 for i in range(n):
                     terms[i].lam = lam_tab[i][it].data_ptr()
-                ls.cg_iters.append(step(x, v_new, rho_tab[it], lam_tab[e][it]))
+                x = xs[it & 1]
+                if step.folds and it + 1 < T:
+                    ls.cg_iters.append(step(x, v_new, rho_tab[it], lam_tab[e][it], rho_tab[it + 1], xs[(it + 1) & 1]))
+                else:
+                    ls.cg_iters.append(step(x, v_new, rho_tab[it], lam_tab[e][it]))
                 v[e], v_new = v_new, v[e]                            # the denoised image becomes v; its old buffer is the next target
                 terms[e].v = v[e].data_ptr()
                 var.value = x

@@ -90,6 +90,10 @@ int dpx_timing_report(char* buf, size_t cap);
  *   cg_event_wait        1 = the fused CG waits for its stop flag behind a HIP event per iteration       DPX_CG_EVENT_WAIT
  *                        (rounds 2 - 4; a marker packet, ~5 us of idle stream each) instead of spinning
  *                        on the tag the test kernel stores into host-coherent memory (same result)
+ *   pnp_cg_no_fold       1 = dpx_admm_cg_pnp_iter keeps k_zupdate + k_bx_pack_in and k_bx_unpack_out, k_lincomb,  DPX_PNP_CG_NO_FOLD
+ *                        k_rhs, k_cgm_start as six launches instead of its head and tail passes (same bits;
+ *                        dpx_admm_cg_pnp_iter_folds = 0); 2 = folded, but the head pass is not issued ahead of the
+ *                        host's look at the CG's stop flag
  *   unroll_bwd_staged    dpx_admm_unrolled_backward: 0 = the two-kernel backward iteration on          DPX_UNROLL_BWD_STAGED
  *                        power-of-two planes (k_bwd_rows), else the image-domain fused stage; 2 = the
  *                        image-domain fused stage everywhere; 1 = the rhs stage and the z stage of
@@ -607,11 +611,17 @@ int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, int nterms, i
  * least_squares.solve_cg, proxfn/sum_square.py:158-197): rhs = ktb + rho sum_i (v_i - u_i) (ktb: K^T b of the data term, nullable),
  * x = dpx_cg_masked_fft(rhs) (mask / mask_images / n_identity / rtol / max_iters / cg_ws as there), z / dual stage of the closed-form
  * terms, denoiser on d = x + u, u = d - v.  Single-channel images [B, 1, H, W], a gray network (in_nc = 1), sigma [B].  Returns the CG
- * exit iteration (>= 0) or a negative status.                                                                                      */
+ * exit iteration (>= 0) or a negative status.
+ * Folded head / tail (dpx_admm_cg_pnp_iter_folds(mode, B) = 1: split kernels, fused CG branch, every term on x itself): the z / dual stage
+ * and the first layer's input are one pass (even H, W), issued right behind the stop test of the CG iteration the previous solve ended at
+ * and predicated on that test, so that the host's look at the flag overlaps with it; the pass behind the last layer also forms u and -- rho_next non-null -- the NEXT iteration's right-hand side, written straight into the CG's start state with
+ * x_next (the next call's x, another buffer than this call's) zeroed; that next call passes rhs_ready = 1 and skips its rhs stage.  With
+ * rho_next = NULL and rhs_ready = 0 every call stands alone.                                                                        */
 int dpx_admm_cg_pnp_iter(float* x, float* rhs, const float* ktb, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
                          const float* sigma, const float* mask, int mask_images, float n_identity, float rtol, int max_iters,
                          const void* packed, int in_nc, int nc, int nb, int mode, int B, int H, int W, const void* table, void* cg_ws,
-                         void* ffd_ws, dpx_stream_t stream);
+                         void* ffd_ws, const float* rho_next, float* x_next, int rhs_ready, dpx_stream_t stream);
+int dpx_admm_cg_pnp_iter_folds(int mode, int B);
 
 /* Generic convolution layers on the same MFMA kernel (residual U-Net denoisers behind deep_prior: DRUNet,
  * dprox/proxfn/pnp/denoisers/models/network_unet.py:67-117, basicblock.py).  NCHW fp32, stride 1.

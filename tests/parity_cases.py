@@ -1054,11 +1054,15 @@ def case_ladmm_cg(device):
     with torch.no_grad():
         x_native = dp.Problem(fns2, linear_solve_config=cfg).solve(method="ladmm", device=device, x0=x0, rhos=0.5, lams=0.03, max_iter=5)
     assert_close(x_native.cpu(), g["x"], TOL, "ladmm x with contrib.masked_fft")
-    # the whole iteration in one C call (dpx_admm_cg_pnp_iter) against the stage-by-stage loop: the same launches, the same bits, the
-    # same CG exit iterations -- and both are what the two solves above went through
+    # the whole iteration in one C call (dpx_admm_cg_pnp_iter) -- with its folded passes (k_pnp_head: z / dual stage + the first layer's
+    # input, issued ahead of the host's look at the CG's stop flag; k_pnp_tail: unpack + dual + the next right-hand side + the CG's start
+    # state) and without -- against the stage-by-stage loop: the same arithmetic, the same bits, the
+    # same CG exit iterations
     import os
+    from dprox import _backend as be
     outs = {}
-    for staged in (False, True):
+    for name, staged, knobs in (("one call, folded tail", False, {}), ("one call, folded, head not issued early", False, dict(pnp_cg_no_fold=2)),
+                                ("one call", False, dict(pnp_cg_no_fold=1)), ("staged", True, {})):
         os.environ.pop("DPX_SPLIT_CG_STAGED", None)
         if staged:
             os.environ["DPX_SPLIT_CG_STAGED"] = "1"
@@ -1066,17 +1070,22 @@ def case_ladmm_cg(device):
             x3 = dp.Variable()
             ls_fns = dp.sum_squares(masked_fft(x3, mask), y) + dp.nonneg(x3) + dp.deep_prior(x3, denoiser=_ffdnet("gray", device))
             solver = dp.compile(ls_fns, method="ladmm", device=device, linear_solve_config=cfg)
-            with torch.no_grad():
-                st3 = solver.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=5, return_full_states=True)
+            seen = []
+            with torch.no_grad(), be.tuned(**knobs):
+                st3 = solver.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=5, return_full_states=True,
+                                   callback=lambda iter, state, **kw: seen.append(state[0].clone()))
         finally:
             os.environ.pop("DPX_SPLIT_CG_STAGED", None)
-        loop = getattr(solver, "last_split_cg_loop", None)
-        outs[staged] = (st3, list(solver.least_square.cg_iters), loop)
-    (sa, na, la), (sb, nb_, lb) = outs[False], outs[True]
-    assert (la, lb) == ("one call", "staged"), (la, lb)
-    assert na == nb_ and len(na) == 5, (na, nb_)
-    assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1][1], sb[1][1]) and torch.equal(sa[2][1], sb[2][1]) and torch.equal(sa[2][0], sb[2][0])
-    assert_close(sa[0].cpu(), g["x"], TOL, "ladmm x, one call per iteration")
+        outs[name] = (st3, list(solver.least_square.cg_iters), getattr(solver, "last_split_cg_loop", None), seen)
+    assert [outs[k][2] for k in outs] == ["one call", "one call", "one call", "staged"], [outs[k][2] for k in outs]
+    sb, nb_, _, seen_b = outs["staged"]
+    assert len(nb_) == 5 and len(seen_b) == 5
+    for name in ("one call, folded tail", "one call, folded, head not issued early", "one call"):
+        sa, na, _, seen_a = outs[name]
+        assert na == nb_, (name, na, nb_)
+        assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1][1], sb[1][1]) and torch.equal(sa[2][1], sb[2][1]) and torch.equal(sa[2][0], sb[2][0]), name
+        assert all(torch.equal(p, q) for p, q in zip(seen_a, seen_b)), name        # (the iterates a callback sees, every iteration)
+    assert_close(outs["one call, folded tail"][0][0].cpu(), g["x"], TOL, "ladmm x, one call per iteration")
 
 
 def case_unrolled_grads(device):

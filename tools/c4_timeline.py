@@ -3,7 +3,7 @@
 last two outer iterations with their durations and the gaps in front of them.  usage: c4_timeline.py <kernel_trace.csv>"""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "k_rhs<" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "k_pnp_tail" in r["Kernel_Name"] or "k_bx_unpack_out" in r["Kernel_Name"]]
 a, b = starts[-3], starts[-1]
 sel = rows[a:b]
 t0 = int(sel[0]["Start_Timestamp"])
