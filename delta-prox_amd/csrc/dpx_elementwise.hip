@@ -534,18 +534,23 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
   __shared__ float red[4 * NP];
   __shared__ int shf[3];
   __shared__ float alpha_s[BT];
-  if (S.flags()[0]) return;                               // (uniform: the solve has converged, this launch ran ahead)
+  // (the solve's `done` word and the step lengths are requested together with the first elements: one memory round trip at the head of the
+  //  launch instead of three -- flag, then gamma / <p, Ap> behind a barrier, then the data; the flag is looked at before the first store)
+  const int dn = S.flags()[0];
   const int B = S.B, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float alpha_r[BT];
   if constexpr (UPDATE) {
-    if (tid < B) alpha_s[tid] = S.gamma()[tid] / S.pAp()[tid];
-    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < BT; ++b) alpha_r[b] = b < B ? S.gamma()[b] / S.pAp()[b] : 0.f;
   }
+  (void)alpha_s;
   float acc[NP];
 #pragma unroll
   for (int e = 0; e < NP; ++e) acc[e] = 0.f;
   const long n4 = npb / 4;
+  bool checked = false;
   for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
-    float4 rv[BT];
+    float4 rv[BT], pvs[UPDATE ? BT : 1], qvs[UPDATE ? BT : 1], xvs[UPDATE ? BT : 1];
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
       rv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -553,8 +558,23 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
         const long at = (long)b * n4 + i;
         rv[b] = ((const float4*)r)[at];
         if constexpr (UPDATE) {
-          const float al = alpha_s[b];
-          const float4 pv = ((const float4*)p)[at], qv = ((const float4*)Ap)[at], xv = ((float4*)x)[at];
+          pvs[b] = ((const float4*)p)[at];
+          qvs[b] = ((const float4*)Ap)[at];
+          xvs[b] = ((float4*)x)[at];
+        }
+      }
+    }
+    if (!checked) {                                       // (uniform: the solve has converged, this launch ran ahead)
+      if (dn) return;
+      checked = true;
+    }
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      if (b < B) {
+        const long at = (long)b * n4 + i;
+        if constexpr (UPDATE) {
+          const float al = alpha_r[b];
+          const float4 pv = pvs[b], qv = qvs[b], xv = xvs[b];
           ((float4*)x)[at] = make_float4(fmaf(al, pv.x, xv.x), fmaf(al, pv.y, xv.y), fmaf(al, pv.z, xv.z), fmaf(al, pv.w, xv.w));
           rv[b] = make_float4(fmaf(-al, qv.x, rv[b].x), fmaf(-al, qv.y, rv[b].y), fmaf(-al, qv.z, rv[b].z), fmaf(-al, qv.w, rv[b].w));
           ((float4*)r)[at] = rv[b];
@@ -568,6 +588,7 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
       for (int q = a; q < BT; ++q, ++e)
         acc[e] = fmaf(rv[a].w, rv[q].w, fmaf(rv[a].z, rv[q].z, fmaf(rv[a].y, rv[q].y, fmaf(rv[a].x, rv[q].x, acc[e]))));
   }
+  if (dn) return;                                         // (threads without an element of their own)
 #pragma unroll
   for (int e = 0; e < NP; ++e) {
     const float v = wave_sum(acc[e]);

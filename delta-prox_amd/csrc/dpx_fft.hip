@@ -1248,22 +1248,34 @@ __global__ void __launch_bounds__(256) k_crows_real_in_w(float* __restrict__ in,
                                                          const int* __restrict__ done, int rows_per_image) {
   constexpr int W = 64 * R1, hs = W / 2, S = LdsSeq<W>::SLOTS;
   __shared__ float2 lds[4 * S];
-  if (done && done[0]) return;
+  // (the solve's `done` word is looked at AFTER this launch's loads have been issued and before its first store: one memory round trip at
+  //  the head of the launch instead of two -- these launches are a few microseconds long)
+  const int dn = done ? done[0] : 0;
   const int tid = threadIdx.x, t = tid & 63, wv = tid >> 6;
   const int row = blockIdx.x * 4 + wv;
   if (row >= nrows) return;                              // (wave-uniform)
   TwR64<R1> tw;
   tw.load(t, twW, 1);
   const float bt = dir_r ? beta[row / rows_per_image] : 0.f;
+  float xin[R1], rin[R1];
+#pragma unroll
+  for (int m = 0; m < R1; ++m) {
+    int src = t + 64 * m + hs;
+    if (src >= W) src -= W;
+    const size_t e = (size_t)row * W + src;
+    xin[m] = in[e];
+    rin[m] = dir_r ? dir_r[e] : 0.f;
+  }
+  if (dn) return;
   float2 v[R1];
 #pragma unroll
   for (int m = 0; m < R1; ++m) {
     int src = t + 64 * m + hs;
     if (src >= W) src -= W;
     const size_t e = (size_t)row * W + src;
-    float x = in[e];
+    float x = xin[m];
     if (dir_r) {
-      x = fmaf(bt, x, dir_r[e]);
+      x = fmaf(bt, x, rin[m]);
       in[e] = x;
     }
     v[m] = make_float2(x, 0.f);
@@ -1283,7 +1295,7 @@ __global__ void __launch_bounds__(256) k_ccols_mask_w(float2* __restrict__ data,
   constexpr int H = 64 * R1, hs = H / 2, S = LdsSeq<H>::SLOTS, ld = H + 1;
   __shared__ float2 col[4 * ld];
   __shared__ float2 lds[4 * S];
-  if (done && done[0]) return;
+  const int dn = done ? done[0] : 0;                     // (looked at behind the loads, see k_crows_real_in_w)
   const int tid = threadIdx.x, t = tid & 63, wv = tid >> 6;
   const int p = blockIdx.y, l0 = blockIdx.x * 4;
   const int nseq = min(4, W - l0);
@@ -1295,6 +1307,7 @@ __global__ void __launch_bounds__(256) k_ccols_mask_w(float2* __restrict__ data,
     if (src >= H) src -= H;
     col[c * ld + r] = base[(size_t)src * W + l0 + c];
   }
+  if (dn) return;                                        // (uniform over the launch)
   __syncthreads();
   if (wv < nseq) {
     TwR64<R1> tw;
@@ -1336,27 +1349,30 @@ __global__ void __launch_bounds__(256) k_crows_real_out_w(const float2* __restri
   __shared__ float2 lds[4 * S];
   __shared__ float shred[4];
   __shared__ int shlast;
-  if (done && done[0]) return;
+  const int dn = done ? done[0] : 0;                     // (looked at behind the loads, see k_crows_real_in_w)
   const int tid = threadIdx.x, t = tid & 63, wv = tid >> 6;
   const int row = blockIdx.x * 4 + wv;                   // (nrows is a multiple of 4: rows_per_image is)
   TwR64<R1> tw;
   tw.load(t, twW, 1);
   float2 v[R1];
+  float pvs[R1];
 #pragma unroll
   for (int m = 0; m < R1; ++m) {
     int src = t + 64 * m + hs;
     if (src >= W) src -= W;
     v[m] = in[(size_t)row * W + src];
+    pvs[m] = pin[(size_t)row * W + src];                 // (the direction at the output position t + 64 m + hs of this lane: the same index)
   }
-  fftR64_wave<R1, +1>(v, lds + wv * S, t, tw, WaveSync());
   const float cr = c * rho[row / rows_per_image];
+  if (dn) return;
+  fftR64_wave<R1, +1>(v, lds + wv * S, t, tw, WaveSync());
   float dacc = 0.f;
 #pragma unroll
   for (int m = 0; m < R1; ++m) {
     int dst = t + 64 * m + hs;
     if (dst >= W) dst -= W;
     const size_t e = (size_t)row * W + dst;
-    const float pv = pin[e];
+    const float pv = pvs[m];
     const float av = fmaf(cr, pv, v[m].x * scale);
     out[e] = av;
     dacc = fmaf(pv, av, dacc);

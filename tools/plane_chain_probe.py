@@ -16,15 +16,19 @@ for shp in shapes:
     x = dp.Variable()
     s = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device="cuda")
 
+    issue = {}
+
     def wall(n):
         best = None
         for _ in range(4):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             s.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=n)
+            t1 = time.perf_counter()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
+            if best is None or dt < best:
+                best, issue[n] = dt, t1 - t0          # (issue: until solve() returned -- every launch handed to the runtime)
         return best
 
     ref = None
@@ -34,5 +38,5 @@ for shp in shapes:
         ref = out if ref is None else ref
         s.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=60)
         per_it = (wall(100) - wall(20)) / 80
-        print(f"{shp}: {chains} chain(s)  {per_it * 1e6:7.2f} us/it   bit-identical {bool(torch.equal(out, ref))}", flush=True)
+        print(f"{shp}: {chains} chain(s)  {per_it * 1e6:7.2f} us/it   (host issue {(issue[100] - issue[20]) / 80 * 1e6:6.2f} us/it)   bit-identical {bool(torch.equal(out, ref))}", flush=True)
     os.environ.pop("DPX_CHAINS", None)

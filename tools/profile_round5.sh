@@ -22,6 +22,9 @@ rocprofv3 --kernel-trace --stats -d $out/kt4 -o kt --output-format csv -- python
 cp $(find $out/kt4 -name "*kernel_stats.csv" | head -1) $out/c4shard_kernel_stats.csv; rm -rf $out/kt4
 rocprofv3 --kernel-trace --stats -d $out/kt5 -o kt --output-format csv -- python tools/bench_configs.py c5 > $out/c5.log 2>&1
 cp $(find $out/kt5 -name "*kernel_stats.csv" | head -1) $out/c5_kernel_stats.csv; rm -rf $out/kt5
+# config 4's shard under the A/B switches of its loop (tag polling / events, one call / staged, folded head and tail) + the timeline of the default
+bash tools/c4_ab.sh > $out/c4_loop_ab.log 2>&1; cp gpurun_out/c4b/timeline.txt $out/c4_timeline.txt
+python tools/plane_chain_probe.py 2>&1 | grep -v amdgpu.ids > $out/plane_chain_probe.log
 python tools/bench_shapes.py 8x3x1024x1024 8x3x768x1024 8x3x768x768 8x3x1024x768 1x3x1024x1024 1x3x768x1024 1x3x768x768 8x3x1000x1000 8x3x720x1280 8x3x640x640 8x3x500x500 4x3x1536x1536 4x3x2048x2048 8x3x1080x1920 > $out/plane_sizes.log 2>&1
 for s in 8x3x1000x1000 8x3x720x1280; do python tools/prof_shape.py $s; done > $out/generic_planes_kernels.log 2>&1
 python tools/bench_methods.py > $out/bench_methods.log 2>&1
