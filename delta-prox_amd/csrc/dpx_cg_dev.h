@@ -75,8 +75,15 @@ __device__ __forceinline__ bool dpx_last_block(unsigned* counter, unsigned nbloc
 __device__ __forceinline__ void cg_test_block(CgState S, const float* __restrict__ G, double* M, int* sh, float init_rtol) {
   const int B = S.B, t = threadIdx.x, nthr = blockDim.x;
   int* fl = S.flags();
-  if (fl[0]) return;                                        // converged earlier: the solve is frozen (uniform)
-  if (init_rtol >= 0.f && fl[2] == 0) {
+  // (everything the test needs from the state is requested at once -- the two control words, the tolerances, gamma of the previous
+  //  iteration: one memory round trip in front of the factorisation instead of three or four; this block is the tail of a launch that is
+  //  a few microseconds long)
+  const int f0 = fl[0], f2 = fl[2];
+  const float gprev = t < B ? S.gamma_prev()[t] : 1.f;
+  float tau2 = INFINITY;
+  for (int i = 0; i < B; ++i) tau2 = fminf(tau2, S.tol2()[i]);
+  if (f0) return;                                           // converged earlier: the solve is frozen (uniform)
+  if (init_rtol >= 0.f && f2 == 0) {
     if (t < B) {
       const float nb = sqrtf(fmaxf(G[t * B + t], 0.f));
       const float tl = init_rtol * nb;
@@ -87,9 +94,9 @@ __device__ __forceinline__ void cg_test_block(CgState S, const float* __restrict
       S.pAp()[t] = 1.f;
     }
     __syncthreads();
+    tau2 = INFINITY;                                        // (the tolerances just written, not what was there before)
+    for (int i = 0; i < B; ++i) tau2 = fminf(tau2, S.tol2()[i]);
   }
-  float tau2 = INFINITY;
-  for (int i = 0; i < B; ++i) tau2 = fminf(tau2, S.tol2()[i]);
   for (int e = t; e < B * B; e += nthr) {
     const int i = e / B, j = e - i * B;
     const double g = 0.5 * ((double)G[i * B + j] + (double)G[j * B + i]);
@@ -129,19 +136,19 @@ __device__ __forceinline__ void cg_test_block(CgState S, const float* __restrict
   if (sh[0]) {
     if (t == 0) {
       fl[0] = 1;
-      fl[1] = fl[2];
+      fl[1] = f2;
     }
     return;
   }
-  const bool first = fl[2] == 0;
+  const bool first = f2 == 0;
   __syncthreads();
   if (t < B) {
     const float g = G[t * B + t];                           // gamma_i = <r_i, r_i>
-    S.beta()[t] = first ? 0.f : g / S.gamma_prev()[t];      // beta = gamma / gamma_1   (solver_cg.py:112)
+    S.beta()[t] = first ? 0.f : g / gprev;                  // beta = gamma / gamma_1   (solver_cg.py:112)
     S.gamma()[t] = g;
     S.gamma_prev()[t] = g;
   }
-  if (t == 0) fl[2] += 1;
+  if (t == 0) fl[2] = f2 + 1;
 }
 
 }  // namespace dpx

@@ -520,6 +520,23 @@ __global__ void __launch_bounds__(256) k_gram_tile_test(float* __restrict__ r, f
   }
 }
 
+// Tuning aid (tools/build_variant.sh par_trace -DDPX_PAR_TRACE; never in the shipped library): thread 0 of every workgroup of the small Gram /
+// stop-test launch stamps the 100 MHz real-time counter at its phase boundaries; tools/gram_trace.py reads the stamps of the last launch.
+#ifdef DPX_PAR_TRACE
+__device__ unsigned long long dpx_gram_trace_buf[256 * 8];
+#define DPX_GSTAMP(i)                                                                                             \
+  do {                                                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 256) dpx_gram_trace_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+}  // namespace dpx
+extern "C" int dpx_dbg_gram_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpx::dpx_gram_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+namespace dpx {
+#else
+#define DPX_GSTAMP(i) ((void)0)
+#endif
+
 // The same launch for small batches (B <= 8, n_per_batch a multiple of 4): the slab kernel above pads every batch to 32 x 32 products
 // and runs 800 workgroups on a 4 x 320^2 residual (19.6 us per CG iteration of config 4's shard, most of it zero rows and the
 // finishing workgroup's 16 x 800 partial sums).  Here a thread holds the B values of four neighbouring elements (float4 per image),
@@ -534,8 +551,10 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
   __shared__ float red[4 * NP];
   __shared__ int shf[3];
   __shared__ float alpha_s[BT];
+  __shared__ float Gs[BT * BT];
   // (the solve's `done` word and the step lengths are requested together with the first elements: one memory round trip at the head of the
   //  launch instead of three -- flag, then gamma / <p, Ap> behind a barrier, then the data; the flag is looked at before the first store)
+  DPX_GSTAMP(0);
   const int dn = S.flags()[0];
   const int B = S.B, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float alpha_r[BT];
@@ -567,6 +586,7 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
     if (!checked) {                                       // (uniform: the solve has converged, this launch ran ahead)
       if (dn) return;
       checked = true;
+      DPX_GSTAMP(1);
     }
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
@@ -589,6 +609,7 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
         acc[e] = fmaf(rv[a].w, rv[q].w, fmaf(rv[a].z, rv[q].z, fmaf(rv[a].y, rv[q].y, fmaf(rv[a].x, rv[q].x, acc[e]))));
   }
   if (dn) return;                                         // (threads without an element of their own)
+  DPX_GSTAMP(2);
 #pragma unroll
   for (int e = 0; e < NP; ++e) {
     const float v = wave_sum(acc[e]);
@@ -605,16 +626,48 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
       if (q != a) dpx_st_agent(partial + ((long)q * B + a) * nblk + blockIdx.x, v);
     }
   }
+  DPX_GSTAMP(3);
   if (!dpx_last_block(counter, (unsigned)nblk, &shf[2])) return;
-  for (int e = wave; e < B * B; e += 4) {
-    const float* pe = partial + (long)e * nblk;
+  DPX_GSTAMP(4);
+  // the slabs' partial products added up: one wave per distinct product (a <= q; the mirrored entry holds the same partials), every wave's
+  // loads requested before the first sum (one memory round trip for the finishing workgroup instead of one per product), the same
+  // additions in the same order as ever; the finished matrix stays in shared memory for the test (and goes to G for whoever looks)
+  constexpr int EPW = (NP + 3) / 4;
+  float ldv[EPW][4];
+#pragma unroll
+  for (int k = 0; k < EPW; ++k) {
+    const int e = wave + 4 * k;
+    int a = 0, e0 = 0;
+    while (e < NP && e >= e0 + (BT - a)) { e0 += BT - a; ++a; }
+    const int q = a + (e - e0);
+    const bool on = e < NP && q < B;
+    const float* pe = partial + ((long)a * B + q) * nblk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ldv[k][j] = (on && lane + 64 * j < nblk) ? dpx_ld_agent(pe + lane + 64 * j) : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < EPW; ++k) {
+    const int e = wave + 4 * k;
+    int a = 0, e0 = 0;
+    while (e < NP && e >= e0 + (BT - a)) { e0 += BT - a; ++a; }
+    const int q = a + (e - e0);
+    if (e >= NP || q >= B) continue;
     float a0 = 0.f;
-    for (int i = lane; i < nblk; i += 64) a0 += dpx_ld_agent(pe + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + 64 * j < nblk) a0 += ldv[k][j];
     const float v = wave_sum(a0);
-    if (lane == 0) G[e] = v;
+    if (lane == 0) {
+      Gs[a * B + q] = v;
+      Gs[q * B + a] = v;
+      G[a * B + q] = v;
+      G[q * B + a] = v;
+    }
   }
   __syncthreads();
-  cg_test_block(S, G, rawd, shf, init_rtol);
+  DPX_GSTAMP(5);
+  cg_test_block(S, Gs, rawd, shf, init_rtol);
+  DPX_GSTAMP(6);
   if (host_flags) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -624,6 +677,7 @@ __global__ void __launch_bounds__(256) k_gram_small_test(float* __restrict__ r, 
       __hip_atomic_store((unsigned long long*)host_flags, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  DPX_GSTAMP(7);
 }
 
 static int gram_blocks(long npb) {
