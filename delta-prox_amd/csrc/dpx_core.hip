@@ -179,6 +179,7 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"unroll_bwd_par_max_rows", "DPX_UNROLL_BWD_PAR_MAX_ROWS", 0, nullptr},
     {"cg_event_wait", "DPX_CG_EVENT_WAIT", 0, nullptr},
     {"pnp_cg_no_fold", "DPX_PNP_CG_NO_FOLD", 0, nullptr},
+    {"il_tw_lds", "DPX_IL_TW_LDS", 1, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

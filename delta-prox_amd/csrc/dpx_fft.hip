@@ -597,7 +597,8 @@ static int il_seqs(const Plan1D& plan) {
 
 // (the loops of run-time length below issue their global loads in batches of UB: written one element at a time, each iteration waits for
 //  its own load -- M / NT dependent round trips per phase, which is what a one-wave workgroup's row kernel then consists of)
-template <bool EVEN, int CT, int NT>
+// TWL (both row kernels, as in k_cols_il): the M twiddles of the transform in shared memory behind the rows
+template <bool EVEN, int CT, int NT, bool TWL>
 __global__ void __launch_bounds__(NT, 4) k_rows_r2c_il(const float* __restrict__ x, float2* __restrict__ spec, int W, int nrows, Plan1D plan,
                                                        const float2* __restrict__ twW) {
   HIP_DYNAMIC_SHARED(float2, smem)
@@ -606,6 +607,14 @@ __global__ void __launch_bounds__(NT, 4) k_rows_r2c_il(const float* __restrict__
   const int M = plan.n, Ws = (W + 1) / 2;
   float2* a = smem;
   const int tid = threadIdx.x;
+  const float2* twp = twW;
+  int tsc = EVEN ? 2 : 1;
+  if constexpr (TWL) {
+    float2* tl = smem + (size_t)M * LD;
+    for (int i = tid; i < M; i += NT) tl[i] = twW[i * tsc];
+    twp = tl;
+    tsc = 1;
+  }
   const int row0 = blockIdx.x * CT;
   const int nseq = min(CT, nrows - row0);
 #pragma unroll
@@ -627,7 +636,7 @@ __global__ void __launch_bounds__(NT, 4) k_rows_r2c_il(const float* __restrict__
     }
   }
   __syncthreads();
-  fft_il<-1, CT, NT>(a, plan, twW, EVEN ? 2 : 1, tid);
+  fft_il<-1, CT, NT>(a, plan, twp, tsc, tid);
 #pragma unroll
   for (int s = 0; s < CT; ++s) {
     if (s >= nseq) break;
@@ -664,7 +673,7 @@ __global__ void __launch_bounds__(NT, 4) k_rows_r2c_il(const float* __restrict__
   }
 }
 
-template <bool EVEN, int CT, int NT>
+template <bool EVEN, int CT, int NT, bool TWL>
 __global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict__ spec, float* __restrict__ y, int W, int nrows, Plan1D plan,
                                                        const float2* __restrict__ twW, float scale) {
   HIP_DYNAMIC_SHARED(float2, smem)
@@ -673,6 +682,14 @@ __global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict_
   const int M = plan.n, Ws = (W + 1) / 2;
   float2* a = smem;
   const int tid = threadIdx.x;
+  const float2* twp = twW;
+  int tsc = EVEN ? 2 : 1;
+  if constexpr (TWL) {
+    float2* tl = smem + (size_t)M * LD;
+    for (int i = tid; i < M; i += NT) tl[i] = twW[i * tsc];
+    twp = tl;
+    tsc = 1;
+  }
   const int row0 = blockIdx.x * CT;
   const int nseq = min(CT, nrows - row0);
   // half spectrum -> the transform's input, pair (k, M - k) by one thread (in place)
@@ -743,7 +760,7 @@ __global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict_
     }
   }
   __syncthreads();
-  fft_il<+1, CT, NT>(a, plan, twW, EVEN ? 2 : 1, tid);
+  fft_il<+1, CT, NT>(a, plan, twp, tsc, tid);
 #pragma unroll
   for (int s = 0; s < CT; ++s) {
     if (s >= nseq) break;
@@ -756,8 +773,29 @@ __global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict_
   }
 }
 
+// Tuning aid (tools/build_variant.sh par_trace -DDPX_PAR_TRACE; never in the shipped library): thread 0 of the first 2048 workgroups of k_cols_il
+// stamps the 100 MHz real-time counter at the phase boundaries; tools/il_trace.py reads the stamps of the last launch.
+#ifdef DPX_PAR_TRACE
+__device__ unsigned long long dpx_il_trace_buf[2048 * 8];
+#define DPX_ILSTAMP(i)                                                                                             \
+  do {                                                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) dpx_il_trace_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+}  // namespace dpx
+extern "C" int dpx_dbg_il_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpx::dpx_il_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+namespace dpx {
+#else
+#define DPX_ILSTAMP(i) ((void)0)
+#endif
+
 // columns: forward c2c, operator, inverse c2c for CT adjacent columns of one plane (the arithmetic of k_cols)
-template <int OP, int CT, int NT>
+// TWL: the H twiddles of the column length sit in shared memory behind the tile (copied with the tile's loads): a pass of the size-generic
+// transform gathers R - 1 of them per butterfly -- from the global table that is 14 scattered 8-byte loads per thread and pass, each lane of a
+// wave in another cache line, and the CU's vector L1 looks lines up one at a time: the in-kernel timeline (tools/il_trace.py) had the four
+// forward passes of a 1000-point column tile at 15 - 17 us of a workgroup's 42 - 47.
+template <int OP, int CT, int NT, bool TWL>
 __global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, SpecArgs A, int C, int H, int W, Plan1D plan,
                                                    const float2* __restrict__ twH, int P) {
   HIP_DYNAMIC_SHARED(float2, smem)
@@ -787,6 +825,7 @@ __global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, Sp
       item -= cnt;
     }
     if (u >= U) return;
+    DPX_ILSTAMP(0);
     tile = (u % nblk) * IL_KB + item / nb;
     p = (item % nb) * C + u / nblk;
   }
@@ -811,8 +850,16 @@ __global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, Sp
       if (r < H) a[r * LD + c] = t[u];
     }
   }
+  const float2* twp = twH;
+  if constexpr (TWL) {
+    float2* tl = smem + (size_t)H * LD;
+    for (int i = tid; i < H; i += NT) tl[i] = twH[i];
+    twp = tl;
+  }
   __syncthreads();
-  fft_il<-1, CT, NT>(a, plan, twH, 1, tid);
+  DPX_ILSTAMP(1);
+  fft_il<-1, CT, NT>(a, plan, twp, 1, tid);
+  DPX_ILSTAMP(2);
   const float rho_b = (OP == OP_SOLVE && A.rho) ? A.rho[bi] : 0.f;
   const size_t tmain = (size_t)ch * H * Ws;
   const size_t tside = (size_t)C * H * Ws + (size_t)ch * H;
@@ -860,7 +907,9 @@ __global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, Sp
     }
   }
   __syncthreads();
-  fft_il<+1, CT, NT>(a, plan, twH, 1, tid);
+  DPX_ILSTAMP(3);
+  fft_il<+1, CT, NT>(a, plan, twp, 1, tid);
+  DPX_ILSTAMP(4);
   if (live)
     for (int r0 = tid / CT; r0 < H; r0 += IL_UB * RS) {
       float2 t[IL_UB];
@@ -875,9 +924,9 @@ __global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, Sp
         if (r < H) base[(size_t)r * Ws + l0 + c] = t[u];
       }
     }
+  DPX_ILSTAMP(5);
 }
 
-// ---------------------------------------------------------------------------------------------
 // one-off fp64 forward transform of the data term:  spec = op(OTF) * F(b)   (packed fp32 half spectrum)
 // Accumulating F(K^T b) in the Fourier domain keeps the large, iteration-invariant part of the
 // right-hand side out of the per-iteration fp32 transforms (only the small increment
@@ -1431,12 +1480,14 @@ template <bool EVEN, int CT, int NT>
 static void launch_rows_il_t(bool fwd, const float* x, float2* spec, float* y, int W, int nrows, const Plan1D& prow, const float2* twW, hipStream_t s) {
   const size_t sh = (size_t)prow.n * (CT > 1 ? CT + 1 : 1) * sizeof(float2);
   const dim3 grid((nrows + CT - 1) / CT);
+  // (TWL = false: measured on the one-wave row workgroups, the table copy halves the workgroups a CU holds and costs more than the gathers it
+  //  saves -- 8 x 3 x 1000 x 1000: 62.9 -> 68.5 us, 1080 x 1920: 113 -> 170 us; the instantiation stays for A/B builds)
   if (fwd) {
-    il_lds_attr(k_rows_r2c_il<EVEN, CT, NT>, sh);
-    DPX_LAUNCH("k_rows_r2c_il", (k_rows_r2c_il<EVEN, CT, NT>), grid, dim3(NT), sh, s, x, spec, W, nrows, prow, twW);
+    il_lds_attr(k_rows_r2c_il<EVEN, CT, NT, false>, sh);
+    DPX_LAUNCH("k_rows_r2c_il", (k_rows_r2c_il<EVEN, CT, NT, false>), grid, dim3(NT), sh, s, x, spec, W, nrows, prow, twW);
   } else {
-    il_lds_attr(k_rows_c2r_il<EVEN, CT, NT>, sh);
-    DPX_LAUNCH("k_rows_c2r_il", (k_rows_c2r_il<EVEN, CT, NT>), grid, dim3(NT), sh, s, (const float2*)spec, y, W, nrows, prow, twW, 1.0f);
+    il_lds_attr(k_rows_c2r_il<EVEN, CT, NT, false>, sh);
+    DPX_LAUNCH("k_rows_c2r_il", (k_rows_c2r_il<EVEN, CT, NT, false>), grid, dim3(NT), sh, s, (const float2*)spec, y, W, nrows, prow, twW, 1.0f);
   }
 }
 // ct: 1 = one row per one-wave workgroup (row lengths up to 1024 complex points: the rule), 8 = eight rows interleaved on 512 threads (A/B),
@@ -1466,8 +1517,15 @@ static void launch_cols_il_t(float2* spec, const SpecArgs& A, int P, int C, int 
     longest = n > longest ? n : longest;
   }
   const dim3 grid(8 * longest);
-  il_lds_attr(k_cols_il<OP, CT, NT>, sh);
-  DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT, NT>), grid, dim3(NT), sh, s, spec, A, C, H, W, pcol, twH, P);
+  // the twiddle table in shared memory when the workgroups per CU stay what they are without it (knob il_tw_lds = 0: never)
+  const size_t sh_tw = sh + (size_t)H * sizeof(float2), lds_cu = 160 * 1024;
+  if (tune(TUNE_IL_TW_LDS) != 0 && sh_tw <= lds_cu && lds_cu / sh_tw >= (lds_cu / sh > 2 ? 2 : lds_cu / sh)) {
+    il_lds_attr(k_cols_il<OP, CT, NT, true>, sh_tw);
+    DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT, NT, true>), grid, dim3(NT), sh_tw, s, spec, A, C, H, W, pcol, twH, P);
+    return;
+  }
+  il_lds_attr(k_cols_il<OP, CT, NT, false>, sh);
+  DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT, NT, false>), grid, dim3(NT), sh, s, spec, A, C, H, W, pcol, twH, P);
 }
 template <int CT, int NT>
 static void launch_cols_il_o(int op, float2* spec, const SpecArgs& A, int P, int C, int H, int W, const Plan1D& pcol, const float2* twH, hipStream_t s) {

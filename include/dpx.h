@@ -94,6 +94,9 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        k_rhs, k_cgm_start as six launches instead of its head and tail passes (same bits;
  *                        dpx_admm_cg_pnp_iter_folds = 0); 2 = folded, but the head pass is not issued ahead of the
  *                        host's look at the CG's stop flag
+ *   il_tw_lds            size-generic column / row transforms (planes off the power-of-two path): 1 = a pass     DPX_IL_TW_LDS
+ *                        gathers its twiddles from a copy of the table in shared memory (default, where the
+ *                        copy does not cost a workgroup per CU), 0 = from the global table (same values)
  *   unroll_bwd_staged    dpx_admm_unrolled_backward: 0 = the two-kernel backward iteration on          DPX_UNROLL_BWD_STAGED
  *                        power-of-two planes (k_bwd_rows), else the image-domain fused stage; 2 = the
  *                        image-domain fused stage everywhere; 1 = the rhs stage and the z stage of
