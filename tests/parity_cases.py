@@ -1088,6 +1088,56 @@ def case_ladmm_cg(device):
     assert_close(outs["one call, folded tail"][0][0].cpu(), g["x"], TOL, "ladmm x, one call per iteration")
 
 
+def case_split_cg_loop_forms(device, B=2, H=48, W=48, iters=4):
+    """The four forms of the plug-and-play loop with a CG x-update (FusedSplitCG.run: one C call per iteration with folded head / tail passes
+    and the head issued ahead of the host's look at the CG's stop flag; the same without issuing it early; one C call, nothing folded; the
+    stage-by-stage loop) on a small CS-MRI problem with a 3-layer gray FFDNet: same iterates in every iteration (what a callback sees), same
+    final state, same CG exit iterations -- bit for bit.  (The staged form against the reference: fixtures G7 / G32.)"""
+    import os
+    import synthetic
+    from dprox import _backend as be
+    from dprox.contrib import masked_fft
+    from dprox.linalg import LinearSolveConfig
+    from dprox.proxfn.pnp.denoisers import FFDNet, FFDNetDenoiser
+    from dprox.utils import ifft2
+    gt, mask, y = synthetic.csmri_case(B, H, W, seed=5, center=8)
+    mask_d, y_d = T(mask, device), torch.from_numpy(y).to(device)
+    x0 = ifft2(y_d).real.contiguous()
+    cfg = LinearSolveConfig(rtol=1e-6, max_iters=100)
+    outs = {}
+    forms = (("one call, folded", False, {}), ("one call, folded, head not issued early", False, dict(pnp_cg_no_fold=2)),
+             ("one call", False, dict(pnp_cg_no_fold=1)), ("staged", True, {}))
+    for name, staged, knobs in forms:
+        os.environ.pop("DPX_SPLIT_CG_STAGED", None)
+        if staged:
+            os.environ["DPX_SPLIT_CG_STAGED"] = "1"
+        try:
+            x = dp.Variable()
+            den = FFDNetDenoiser()
+            den.model = FFDNet(in_nc=1, out_nc=1, nc=16, nb=3, act_mode="R").load_layers(synthetic.ffdnet_weights(3, 1, 1, 16, 3))   # (a small stand-in: the emulator's share)
+            fns = dp.sum_squares(masked_fft(x, mask_d), y_d) + dp.nonneg(x) + dp.deep_prior(x, denoiser=den)
+            solver = dp.compile(fns, method="ladmm", device=device, linear_solve_config=cfg)
+            seen = []
+            with torch.no_grad(), be.tuned(**knobs):
+                st = solver.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=iters, return_full_states=True,
+                                  callback=lambda iter, state, **kw: seen.append(state[0].clone()))
+        finally:
+            os.environ.pop("DPX_SPLIT_CG_STAGED", None)
+        outs[name] = (st, list(solver.least_square.cg_iters), getattr(solver, "last_split_cg_loop", None), seen, solver.last_path)
+    assert [outs[k][2] for k, _, _ in forms] == ["one call", "one call", "one call", "staged"], [outs[k][2] for k, _, _ in forms]
+    assert all(outs[k][4] == "fused-cg" for k in outs)
+    sb, nb_, _, seen_b, _ = outs["staged"]
+    assert len(nb_) == iters and len(seen_b) == iters and all(n > 0 for n in nb_), nb_
+    assert bool(torch.isfinite(sb[0]).all()) and float(sb[0].abs().max()) > 0
+    for name, _, _ in forms[:3]:
+        sa, na, _, seen_a, _ = outs[name]
+        assert na == nb_, (name, na, nb_)
+        assert torch.equal(sa[0], sb[0]), name
+        for i in range(2):
+            assert torch.equal(sa[1][i], sb[1][i]) and torch.equal(sa[2][i], sb[2][i]), (name, i)
+        assert all(torch.equal(p, q) for p, q in zip(seen_a, seen_b)), name
+
+
 def case_unrolled_grads(device):
     """G11 (config 5 at fixture size): loss and gradients of 3 unrolled ADMM iterations w.r.t. the rho / lambda schedules,
     the observation b and x0 -- hand-written backward stages vs the reference's PyTorch autograd.

@@ -153,6 +153,10 @@ def test_other_algorithms():
     pc.case_other_algorithms(DEV)
 
 
+def test_plug_and_play_cg_loop_forms_are_bit_identical():
+    pc.case_split_cg_loop_forms(DEV)
+
+
 def test_csmri_custom_admm():
     pc.case_csmri(DEV, solve=False)          # the 4-iteration solve with the 15-layer gray FFDNet runs on the GPU only
 

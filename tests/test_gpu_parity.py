@@ -193,6 +193,11 @@ def test_ladmm_cg():
     pc.case_ladmm_cg(DEV)
 
 
+def test_plug_and_play_cg_loop_forms_are_bit_identical():
+    pc.case_split_cg_loop_forms(DEV)
+    pc.case_split_cg_loop_forms(DEV, B=4, H=320, W=320, iters=6)          # (config 4's shard: the one-wave transforms of the fused CG)
+
+
 def test_other_algorithms():
     pc.case_other_algorithms(DEV)
 
