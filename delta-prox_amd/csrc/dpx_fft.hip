@@ -1481,7 +1481,8 @@ static void launch_rows_il_t(bool fwd, const float* x, float2* spec, float* y, i
   const size_t sh = (size_t)prow.n * (CT > 1 ? CT + 1 : 1) * sizeof(float2);
   const dim3 grid((nrows + CT - 1) / CT);
   // (TWL = false: measured on the one-wave row workgroups, the table copy halves the workgroups a CU holds and costs more than the gathers it
-  //  saves -- 8 x 3 x 1000 x 1000: 62.9 -> 68.5 us, 1080 x 1920: 113 -> 170 us; the instantiation stays for A/B builds)
+  //  saves -- 8 x 3 x 1000 x 1000: 62.9 -> 68.5 us, 1080 x 1920: 113 -> 170 us; four one-wave rows per workgroup around ONE shared copy were measured too: 64.7 -> 71 us;
+  //  the instantiation stays for A/B builds)
   if (fwd) {
     il_lds_attr(k_rows_r2c_il<EVEN, CT, NT, false>, sh);
     DPX_LAUNCH("k_rows_r2c_il", (k_rows_r2c_il<EVEN, CT, NT, false>), grid, dim3(NT), sh, s, x, spec, W, nrows, prow, twW);
