@@ -199,8 +199,9 @@ extern "C" size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_image
 }
 
 // Spin until the device has stored `tag` at *slot (host-coherent memory, written by the finishing workgroup of a launch already in the
-// stream, together with the word next to it: one 8-byte store).  Looks at the stream now and then: a stream that has drained or failed without the tag, or ten
-// seconds without it, end the wait with false.
+// stream, together with the word next to it: one 8-byte store).  Looks at the stream now and then: once it has drained every store of its
+// kernels is visible whatever the platform does with device stores to pinned memory in mid-kernel, so the answer is final -- the tag, or false (also for a
+// failed stream, and after a minute without either).
 static bool wait_for_tag(volatile int* slot, int tag, hipStream_t s) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned long spins = 1;; ++spins) {
@@ -208,7 +209,7 @@ static bool wait_for_tag(volatile int* slot, int tag, hipStream_t s) {
     if ((spins & 0xfffffu) == 0) {                       // about every few milliseconds
       const hipError_t q = hipStreamQuery(s);
       if (q != hipErrorNotReady) return q == hipSuccess && __atomic_load_n((const int*)slot, __ATOMIC_ACQUIRE) == tag;
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return false;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return false;
     }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
