@@ -320,7 +320,7 @@ class FusedSplitCG:
                 for i in range(n):
                     terms[i].lam = lam_tab[i][it].data_ptr()
                 x = xs[it & 1]
-                if step.folds and it + 1 < T:
+                if step.folds and it + 1 < T and callback is None:     # (a callback may solve something else in between: the prepared CG state lives in a shared workspace)
                     ls.cg_iters.append(step(x, v_new, rho_tab[it], lam_tab[e][it], rho_tab[it + 1], xs[(it + 1) & 1]))
                 else:
                     ls.cg_iters.append(step(x, v_new, rho_tab[it], lam_tab[e][it]))

@@ -1119,11 +1119,18 @@ def case_split_cg_loop_forms(device, B=2, H=48, W=48, iters=4):
             solver = dp.compile(fns, method="ladmm", device=device, linear_solve_config=cfg)
             seen = []
             with torch.no_grad(), be.tuned(**knobs):
-                st = solver.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=iters, return_full_states=True,
-                                  callback=lambda iter, state, **kw: seen.append(state[0].clone()))
+                # without a callback (the folded tail also prepares the next iteration's right-hand side and CG start state) ...
+                st = solver.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=iters, return_full_states=True)
+                n_plain = list(solver.least_square.cg_iters)
+                solver.least_square.cg_iters.clear()
+                # ... and with one (every call of the loop stands alone; the iterates a callback sees)
+                st_cb = solver.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=iters, return_full_states=True,
+                                     callback=lambda iter, state, **kw: seen.append(state[0].clone()))
         finally:
             os.environ.pop("DPX_SPLIT_CG_STAGED", None)
-        outs[name] = (st, list(solver.least_square.cg_iters), getattr(solver, "last_split_cg_loop", None), seen, solver.last_path)
+        assert list(solver.least_square.cg_iters) == n_plain, (name, n_plain, list(solver.least_square.cg_iters))
+        assert torch.equal(st[0], st_cb[0]) and all(torch.equal(p, q) for i in (1, 2) for p, q in zip(st[i], st_cb[i])), name
+        outs[name] = (st, n_plain, getattr(solver, "last_split_cg_loop", None), seen, solver.last_path)
     assert [outs[k][2] for k, _, _ in forms] == ["one call", "one call", "one call", "staged"], [outs[k][2] for k, _, _ in forms]
     assert all(outs[k][4] == "fused-cg" for k in outs)
     sb, nb_, _, seen_b, _ = outs["staged"]
