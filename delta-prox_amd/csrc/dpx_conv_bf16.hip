@@ -17,6 +17,7 @@
 // [plane][k-group][row][col][8];  weights arrive by LDS-DMA in slots of 3 taps, pre-split at pack time, ring of 2 slots, one
 // workgroup barrier per slot.  LDS: 39 + 57 + 54 KB (MT = 3): one workgroup per CU, two waves per SIMD.
 #include "dpx_common.h"
+#include "dpx_prox_dev.h"
 
 // Tuning probes (wrong results by design; DESIGN.md section 3 has what they measured): 1 tap-independent fragment reads,
 // 2 no split pass, 4 no DMA / waits / barriers, 8 no DMA (barriers stay), 16 DMA never waited for,
@@ -614,17 +615,6 @@ struct PnpHead {
   float alpha[DPX_MAX_TERMS];
   int prox[DPX_MAX_TERMS];
 };
-__device__ __forceinline__ float pnp_prox(int kind, float d, float lam) {      // (prox_eval of dpx_elementwise.hip)
-  switch (kind) {
-    case DPX_PROX_NORM1: {
-      const float m = fmaxf(fabsf(d) - lam, 0.f);
-      return d > 0.f ? m : (d < 0.f ? -m : 0.f * m);
-    }
-    case DPX_PROX_NONNEG: return fmaxf(d, 0.f);
-    case DPX_PROX_SUMSQ: return d / (1.f + 2.f * lam);
-    default: return d;
-  }
-}
 __global__ void k_pnp_head(PnpHead Q, int B, int C, int H, int W, int H2, int W2, int G) {
   if (Q.pred && Q.pred[0] == 0) return;
   const long total = (long)B * G * H2 * W2 * 8;
@@ -649,7 +639,7 @@ __global__ void k_pnp_head(PnpHead Q, int B, int C, int H, int W, int H2, int W2
           out = d;
         } else {
           const float lam = Q.lam[t] ? Q.lam[t][b] * Q.alpha[t] : 0.f;
-          const float vv = pnp_prox(Q.prox[t], d, lam);
+          const float vv = prox_eval(Q.prox[t], d, lam);
           Q.v[t][off] = vv;
           Q.u[t][off] = d - vv;
         }

@@ -13,25 +13,10 @@
 #include <cstdlib>
 
 #include "dpx_cg_dev.h"
+#include "dpx_prox_dev.h"
 
 namespace dpx {
 
-__device__ __forceinline__ float prox_eval(int kind, float d, float lam) {
-  switch (kind) {
-    case DPX_PROX_NORM1: {                                   // sign(d) * max(|d| - lam, 0)
-      const float m = fmaxf(fabsf(d) - lam, 0.f);
-      return d > 0.f ? m : (d < 0.f ? -m : 0.f * m);
-    }
-    case DPX_PROX_NONNEG: return fmaxf(d, 0.f);
-    case DPX_PROX_SUMSQ: return d / (1.f + 2.f * lam);
-    default: return d;
-  }
-}
-
-struct TermPack {
-  dpx_term t[DPX_MAX_TERMS];
-  int n;
-};
 
 // ---------------------------------------------------------------------------------------------
 // z / dual update.  One thread = 4 consecutive pixels of a row (VEC=4) or one pixel (VEC=1).
