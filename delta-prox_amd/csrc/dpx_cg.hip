@@ -349,6 +349,7 @@ int dpx::cg_masked_fft_run(float* x, const float* b, const float* mask, int mask
     // (an event per iteration left ~5.5 us of idle stream in front of every test kernel: knob cg_event_wait = 1 is that form).
     const bool poll = !split_update && tune(TUNE_CG_EVENT_WAIT) == 0;
     const unsigned seq = ++R.seq;
+    const int hint = (spec && spec->hint >= 0) ? spec->hint : R.hint;      // (a caller that knows better: the same solve of the previous run)
     auto tag_of = [&](int j) { return (int)((((seq & 0x1fffffu) << 10) | (unsigned)((j & 1023) + 1)) & 0x7fffffffu); };
     // (a slot the test kernel stored: low word = done | n_done << 1, high word = tag; a slot copied from the device flags -- the
     //  split_update form -- : (done, n_done, ...) as they are)
@@ -394,7 +395,7 @@ int dpx::cg_masked_fft_run(float* x, const float* b, const float* mask, int mask
         // Consecutive solves of one outer loop exit at the same iteration almost always (config 4: 2, 3, 3, 3, ...).  At the iteration the
         // previous solve stopped at, look at THIS test's flag right away -- one host round trip, which the end of the solve pays
         // anyway -- instead of finding out two iterations (seven empty launches) later.  A miss costs that one wait.
-        if (it == R.hint && it > 0 && !tune(TUNE_CG_NO_HINT)) {
+        if (it == hint && it > 0 && !tune(TUNE_CG_NO_HINT)) {
           if (spec && poll && !spec->launched) {            // the caller's next stage, predicated on this test's verdict (CgSpeculate; the
                                                             //  in-order look at the slots below is what makes `valid` exact)
             spec->launched = true;

@@ -104,6 +104,7 @@ struct CgSpeculate {
   int (*launch)(void* ctx, const int* done_flag, dpx_stream_t stream);
   void* ctx;
   bool launched = false, valid = false;
+  int hint = -1;        // >= 0: the iteration this solve is expected to end at (instead of the thread's previous solve's)
 };
 int cg_masked_fft_run(float* x, const float* b, const float* mask, int mask_images, const float* rho, float n_identity, float rtol, int max_iters,
                       int B, int H, int W, const void* table, void* ws, bool started, CgSpeculate* spec, dpx_stream_t stream);

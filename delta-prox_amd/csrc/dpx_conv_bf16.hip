@@ -1206,7 +1206,7 @@ extern "C" int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, in
 extern "C" int dpx_admm_cg_pnp_iter(float* x, float* rhs, const float* ktb, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
                                     const float* sigma, const float* mask, int mask_images, float n_identity, float rtol, int max_iters,
                                     const void* packed, int in_nc, int nc, int nb, int mode, int B, int H, int W, const void* table, void* cg_ws,
-                                    void* ffd_ws, const float* rho_next, float* x_next, int rhs_ready, dpx_stream_t stream) {
+                                    void* ffd_ws, const float* rho_next, float* x_next, int rhs_ready, int cg_hint, dpx_stream_t stream) {
   DPX_REQUIRE(x && rhs && terms && v_new && rho && sigma && mask && packed && table && cg_ws && ffd_ws, "dpx_admm_cg_pnp_iter: null pointer");
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS && ext >= 0 && ext < nterms && terms[ext].linop == DPX_LIN_IDENTITY,
               "dpx_admm_cg_pnp_iter: the prior must be a term on x itself");
@@ -1251,6 +1251,7 @@ extern "C" int dpx_admm_cg_pnp_iter(float* x, float* rhs, const float* ktb, cons
   // (the head goes into the stream right behind the stop test of the iteration the previous solve ended at, predicated on that test: the
   //  host's look at the flag and its next launches overlap with it instead of leaving the stream idle -- knob pnp_cg_no_fold = 2: off)
   dpx::CgSpeculate spec{launch_head, &hc};
+  spec.hint = cg_hint;
   const bool speculate = fold_head && tune(TUNE_PNP_CG_NO_FOLD) != 2;
   const int n_cg = dpx::cg_masked_fft_run(x, rhs, mask, mask_images, rho, n_identity, rtol, max_iters, B, H, W, table, cg_ws, rhs_ready != 0,
                                           speculate ? &spec : nullptr, stream);

@@ -199,7 +199,7 @@ SIGNATURES = {
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpx_admm_cg_pnp_iter": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                      c_float, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_int, c_void_p]),
+                                     c_void_p, c_int, c_int, c_void_p]),
     "dpx_admm_cg_pnp_iter_folds": (c_int, [c_int, c_int]),
     "dpx_conv_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
     "dpx_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -589,7 +589,7 @@ class CgPnpIter:
         self.folds = bool(L.query("dpx_admm_cg_pnp_iter_folds", self.mode, B))
         self.ready = False        # the previous call prepared this call's right-hand side
 
-    def __call__(self, x, v_new, rho, sigma, rho_next=None, x_next=None):
+    def __call__(self, x, v_new, rho, sigma, rho_next=None, x_next=None, cg_hint=-1):
         """x (written), v_new (receives the denoised image); returns the CG exit iteration.  rho_next / x_next (self.folds only): the pass
         behind the denoiser also prepares the next call's right-hand side and CG start state (x_next zeroed: the next call's x) -- the next
         call then skips its rhs stage by itself"""
@@ -598,7 +598,7 @@ class CgPnpIter:
         L = self.L
         ready, self.ready = self.ready, rho_next is not None
         n = L.query("dpx_admm_cg_pnp_iter", ptr(x), *self.head, ptr(v_new), ptr(rho), ptr(sigma), *self.fixed, ptr(rho_next), ptr(x_next), int(ready),
-                    be.stream())
+                    int(cg_hint), be.stream())
         if n < 0:
             raise be.DpxError(f"dpx_admm_cg_pnp_iter failed ({n}): {L.cdll.dpx_last_error().decode()}")
         return int(n)

@@ -315,15 +315,20 @@ class FusedSplitCG:
             x = torch.empty_like(x0)
             v_new = torch.empty_like(x0)
             step = ops.CgPnpIter(x, rhs, ktb, terms, n, e, sysm[0], sysm[1], cfg.rtol, cfg.max_iters, psi[e].denoiser.model)
+            hist, run_hist = list(getattr(s, "_cg_exit_hist", ())), []
+            s._cg_exit_hist = run_hist
             xs = (x, torch.empty_like(x0)) if step.folds else (x, x)  # (folded tail: iteration t + 1's iterate is zeroed while x_t is still the result)
             for it in tqdm(range(T), disable=not pbar):
                 for i in range(n):
                     terms[i].lam = lam_tab[i][it].data_ptr()
                 x = xs[it & 1]
+                hint = hist[it] if it < len(hist) else -1            # (where the same solve of this solver's previous run ended)
                 if step.folds and it + 1 < T and callback is None:     # (a callback may solve something else in between: the prepared CG state lives in a shared workspace)
-                    ls.cg_iters.append(step(x, v_new, rho_tab[it], lam_tab[e][it], rho_tab[it + 1], xs[(it + 1) & 1]))
+                    n_cg = step(x, v_new, rho_tab[it], lam_tab[e][it], rho_tab[it + 1], xs[(it + 1) & 1], cg_hint=hint)
                 else:
-                    ls.cg_iters.append(step(x, v_new, rho_tab[it], lam_tab[e][it]))
+                    n_cg = step(x, v_new, rho_tab[it], lam_tab[e][it], cg_hint=hint)
+                ls.cg_iters.append(n_cg)
+                run_hist.append(n_cg)
                 v[e], v_new = v_new, v[e]                            # the denoised image becomes v; its old buffer is the next target
                 terms[e].v = v[e].data_ptr()
                 var.value = x

@@ -640,11 +640,12 @@ int dpx_admm_pnp_iter(float* x, float* rhs, const dpx_term* terms, int nterms, i
  * and the first layer's input are one pass (even H, W), issued right behind the stop test of the CG iteration the previous solve ended at
  * and predicated on that test, so that the host's look at the flag overlaps with it; the pass behind the last layer also forms u and -- rho_next non-null -- the NEXT iteration's right-hand side, written straight into the CG's start state with
  * x_next (the next call's x, another buffer than this call's) zeroed; that next call passes rhs_ready = 1 and skips its rhs stage.  With
- * rho_next = NULL and rhs_ready = 0 every call stands alone.                                                                        */
+ * rho_next = NULL and rhs_ready = 0 every call stands alone.  cg_hint (>= 0; -1: none): the CG iteration this call's solve is expected to end at
+ * -- where the head pass is issued early; without it the exit iteration of the thread's previous solve serves (results never depend on it).                                                                        */
 int dpx_admm_cg_pnp_iter(float* x, float* rhs, const float* ktb, const dpx_term* terms, int nterms, int ext, float* v_new, const float* rho,
                          const float* sigma, const float* mask, int mask_images, float n_identity, float rtol, int max_iters,
                          const void* packed, int in_nc, int nc, int nb, int mode, int B, int H, int W, const void* table, void* cg_ws,
-                         void* ffd_ws, const float* rho_next, float* x_next, int rhs_ready, dpx_stream_t stream);
+                         void* ffd_ws, const float* rho_next, float* x_next, int rhs_ready, int cg_hint, dpx_stream_t stream);
 int dpx_admm_cg_pnp_iter_folds(int mode, int B);
 
 /* Generic convolution layers on the same MFMA kernel (residual U-Net denoisers behind deep_prior: DRUNet,
