@@ -564,6 +564,21 @@ __device__ __forceinline__ void il_pass(float2* __restrict__ a, int N, int Ns, c
   Sync()();
 }
 
+// Tuning aid (-DDPX_PAR_TRACE builds only): phase stamps of k_rows_c2r_il's one-wave workgroups (tools/ilrow_trace.py)
+#ifdef DPX_PAR_TRACE
+__device__ unsigned long long dpx_ilrow_trace_buf[4096 * 8];
+#define DPX_ROWSTAMP(i)                                                                                             \
+  do {                                                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) dpx_ilrow_trace_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+}  // namespace dpx
+extern "C" int dpx_dbg_ilrow_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpx::dpx_ilrow_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+namespace dpx {
+#else
+#define DPX_ROWSTAMP(i) ((void)0)
+#endif
 // in-place transform of the CT interleaved sequences; the caller synchronises in front, the last pass behind
 template <int DIR, int CT, int NT, class Sync = BlockSyncAll>
 __device__ __forceinline__ void fft_il(float2* __restrict__ a, const Plan1D& plan, const float2* __restrict__ tw, int tscale, int tid) {
@@ -581,6 +596,9 @@ __device__ __forceinline__ void fft_il(float2* __restrict__ a, const Plan1D& pla
       default: il_pass<11, DIR, CT, NT, Sync>(a, N, Ns, tw, tscale, tid); break;
     }
     Ns *= R;
+#ifdef DPX_PAR_TRACE
+    if (NT == 64 && DIR > 0 && f < 4) DPX_ROWSTAMP(2 + f);
+#endif
   }
 }
 
@@ -596,6 +614,10 @@ static int il_seqs(const Plan1D& plan) {
   return 0;
 }
 
+// Where a one-wave row transform's time goes (tools/ilrow_trace.py, 8 x 3 x 1000 x 1000: 500 complex points, passes 4 x 5 x 5 x 5; a workgroup lives 12 us,
+// 16 of them per CU): row loaded + untangled 2.6 us, first pass 1.5, the three passes with twiddles 2.0 each, row stored 1.5 -- with four waves per SIMD in the same
+// kind of pass that is the passes' ~450 vector instructions per wave (60 % of them integer / move) sharing the SIMD, i.e. instruction-bound like k_cols_il.  Compile-time
+// lengths and strides (a 1000-point instantiation of the column passes: measured) take 4 % off, not more: not adopted.
 // (the loops of run-time length below issue their global loads in batches of UB: written one element at a time, each iteration waits for
 //  its own load -- M / NT dependent round trips per phase, which is what a one-wave workgroup's row kernel then consists of)
 // TWL (both row kernels, as in k_cols_il): the M twiddles of the transform in shared memory behind the rows
@@ -691,6 +713,7 @@ __global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict_
     twp = tl;
     tsc = 1;
   }
+  DPX_ROWSTAMP(0);
   const int row0 = blockIdx.x * CT;
   const int nseq = min(CT, nrows - row0);
   // half spectrum -> the transform's input, pair (k, M - k) by one thread (in place)
@@ -761,7 +784,9 @@ __global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict_
     }
   }
   __syncthreads();
+  DPX_ROWSTAMP(1);
   fft_il<+1, CT, NT>(a, plan, twp, tsc, tid);
+  DPX_ROWSTAMP(6);
 #pragma unroll
   for (int s = 0; s < CT; ++s) {
     if (s >= nseq) break;
@@ -772,6 +797,7 @@ __global__ void __launch_bounds__(NT, 4) k_rows_c2r_il(const float2* __restrict_
       else yr[n] = v.x * scale;
     }
   }
+  DPX_ROWSTAMP(7);
 }
 
 // Tuning aid (tools/build_variant.sh par_trace -DDPX_PAR_TRACE; never in the shipped library): thread 0 of the first 2048 workgroups of k_cols_il
