@@ -37,3 +37,4 @@ with torch.no_grad():
         s.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=10)
     torch.cuda.synchronize(); pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
