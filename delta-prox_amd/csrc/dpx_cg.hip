@@ -224,21 +224,32 @@ bool cg_masked_fft_is_fused(int B) {
   const int fused_max_b = tune(TUNE_CG_FUSED_MAX_B);
   return B <= (fused_max_b > 32 ? 32 : fused_max_b) && tune(TUNE_CG_UNFUSED) == 0;
 }
-CgStartPtrs cg_masked_fft_start_ptrs(void* ws, int B, int H, int W, int mask_images) {
+// the one place that knows how dpx_cg_masked_fft carves up its workspace (dpx_cg_masked_fft_ws_bytes)
+struct CgWsLayout {
+  float *r, *p, *Ap;
+  float2 *z0, *z1;
+  float *mask2, *state, *gram, *dotws, *fdot;
+  unsigned* counters;
+};
+static CgWsLayout cg_ws_layout(void* ws, int B, int H, int W, int mask_images) {
   const size_t n = (size_t)H * W;
-  float* w = (float*)ws;
-  float* r = w;
-  float* p = r + (size_t)B * n;
-  float* Ap = p + (size_t)B * n;
-  float2* z0 = (float2*)(Ap + (size_t)B * n + (((size_t)3 * B * n) & 1));
-  float2* z1 = z0 + (size_t)B * n;
-  float* mask2 = (float*)(z1 + (size_t)B * n);
-  float* state = mask2 + (size_t)mask_images * n;
-  float* gram = state + 5 * B + 4;
-  float* dotws = gram + (((size_t)B * B + 63) / 64) * 64;
-  float* fdot = (float*)((char*)dotws + dpx_bdot_ws_bytes(B, (long)n));
-  unsigned* counters = (unsigned*)(fdot + dpx::masked_normal_fused_ws_floats(B, H, W));
-  return CgStartPtrs{r, p, (int*)(state + 5 * B), counters};
+  CgWsLayout L;
+  L.r = (float*)ws;
+  L.p = L.r + (size_t)B * n;
+  L.Ap = L.p + (size_t)B * n;
+  L.z0 = (float2*)(L.Ap + (size_t)B * n + (((size_t)3 * B * n) & 1));      // (8-byte aligned also when 3 B n is odd; the slack is in ws_bytes)
+  L.z1 = L.z0 + (size_t)B * n;
+  L.mask2 = (float*)(L.z1 + (size_t)B * n);
+  L.state = L.mask2 + (size_t)mask_images * n;
+  L.gram = L.state + 5 * B + 4;
+  L.dotws = L.gram + (((size_t)B * B + 63) / 64) * 64;
+  L.fdot = (float*)((char*)L.dotws + dpx_bdot_ws_bytes(B, (long)n));                           // (fused branch)
+  L.counters = (unsigned*)(L.fdot + dpx::masked_normal_fused_ws_floats(B, H, W));
+  return L;
+}
+CgStartPtrs cg_masked_fft_start_ptrs(void* ws, int B, int H, int W, int mask_images) {
+  const CgWsLayout L = cg_ws_layout(ws, B, H, W, mask_images);
+  return CgStartPtrs{L.r, L.p, (int*)(L.state + 5 * B), L.counters};
 }
 }  // namespace dpx
 
@@ -255,16 +266,9 @@ int dpx::cg_masked_fft_run(float* x, const float* b, const float* mask, int mask
   DPX_REQUIRE(!started || cg_masked_fft_is_fused(B), "dpx_cg_masked_fft: a pre-started solve needs the fused branch (B = %d)", B);
   hipStream_t s = (hipStream_t)stream;
   const long n = (long)H * W;
-  float* w = (float*)ws;
-  float* r = w;
-  float* p = r + (size_t)B * n;
-  float* Ap = p + (size_t)B * n;
-  float2* z0 = (float2*)(Ap + (size_t)B * n + (((size_t)3 * B * n) & 1));      // (8-byte aligned also when 3 B n is odd; the slack is in ws_bytes)
-  float2* z1 = z0 + (size_t)B * n;
-  float* mask2 = (float*)(z1 + (size_t)B * n);
-  float* state = mask2 + (size_t)mask_images * n;
-  float* gram = state + 5 * B + 4;
-  float* dotws = gram + (((size_t)B * B + 63) / 64) * 64;
+  const CgWsLayout WL = cg_ws_layout(ws, B, H, W, mask_images);
+  float *r = WL.r, *p = WL.p, *Ap = WL.Ap, *mask2 = WL.mask2, *state = WL.state, *gram = WL.gram, *dotws = WL.dotws;
+  float2 *z0 = WL.z0, *z1 = WL.z1;
   int* flags = (int*)(state + 5 * B);
   float* pAp = state + 3 * B;
 
@@ -339,8 +343,8 @@ int dpx::cg_masked_fft_run(float* x, const float* b, const float* mask, int mask
   //  against 2.25 / 4.08 on the step-by-step sequence -- the Gram pass with its finish in one workgroup stops paying beyond 8)
   const int fused_max_b = tune(TUNE_CG_FUSED_MAX_B);
   if (B <= (fused_max_b > 32 ? 32 : fused_max_b) && !unfused) {
-    float* fdot = (float*)((char*)dotws + dpx_bdot_ws_bytes(B, n));
-    unsigned* counters = (unsigned*)(fdot + dpx::masked_normal_fused_ws_floats(B, H, W));
+    float* fdot = WL.fdot;
+    unsigned* counters = WL.counters;
     if (!started)
       DPX_LAUNCH("k_cgm_start", k_cgm_start, dim3(grid_for((long)B * n, 256, 1024)), dim3(256), 0, s, x, r, p, b, (long)B * n, flags, counters);
     // How the host learns that the test of iteration j has run: the finishing workgroup of that launch stores (done | n_done << 1, tag_j) as one 8-byte word into slot
