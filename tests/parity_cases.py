@@ -1123,7 +1123,7 @@ def case_generic_fused_rows(device, shapes=((2, 3, 30, 36), (1, 2, 18, 20), (1, 
                 assert all(torch.equal(p, q) for p, q in zip(sa, sb)), (method, (B, C, H, W), "iterates seen by the callback")
 
 
-def case_split_cg_loop_forms(device, B=2, H=48, W=48, iters=4):
+def case_split_cg_loop_forms(device, B=2, H=48, W=48, iters=4, compute_mode=None):
     """The four forms of the plug-and-play loop with a CG x-update (FusedSplitCG.run: one C call per iteration with folded head / tail passes
     and the head issued ahead of the host's look at the CG's stop flag; the same without issuing it early; one C call, nothing folded; the
     stage-by-stage loop) on a small CS-MRI problem with a 3-layer gray FFDNet: same iterates in every iteration (what a callback sees), same
@@ -1150,6 +1150,8 @@ def case_split_cg_loop_forms(device, B=2, H=48, W=48, iters=4):
             x = dp.Variable()
             den = FFDNetDenoiser()
             den.model = FFDNet(in_nc=1, out_nc=1, nc=16, nb=3, act_mode="R").load_layers(synthetic.ffdnet_weights(3, 1, 1, 16, 3))   # (a small stand-in: the emulator's share)
+            if compute_mode:
+                den.model.compute_mode = compute_mode                # ("f32": the one-call loop without the folded passes -- the f32-input kernels' layout)
             fns = dp.sum_squares(masked_fft(x, mask_d), y_d) + dp.nonneg(x) + dp.deep_prior(x, denoiser=den)
             solver = dp.compile(fns, method="ladmm", device=device, linear_solve_config=cfg)
             seen = []

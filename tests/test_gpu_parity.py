@@ -201,6 +201,8 @@ def test_generic_planes_fused_row_pass_is_bit_identical_to_the_four_launch_itera
 def test_plug_and_play_cg_loop_forms_are_bit_identical():
     pc.case_split_cg_loop_forms(DEV)
     pc.case_split_cg_loop_forms(DEV, B=4, H=320, W=320, iters=6)          # (config 4's shard: the one-wave transforms of the fused CG)
+    for mode in ("bf16x3", "f32"):
+        pc.case_split_cg_loop_forms(DEV, compute_mode=mode)
 
 
 def test_other_algorithms():
