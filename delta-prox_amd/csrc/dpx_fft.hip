@@ -532,9 +532,14 @@ __device__ __forceinline__ void il_pass(float2* __restrict__ a, int N, int Ns, c
 #pragma unroll
       for (int m = 0; m < R; ++m) v[it][m] = a[(j + m * nb) * LD + c];
       if (EARLY && Ns > 1) {
-        const int k = j - Ns * (int)(((float)j + 0.5f) * rcp_ns);
+        const int k = j - __mul24(Ns, (int)(((float)j + 0.5f) * rcp_ns));
+        const int kt = __mul24(k, twm);                       // (the index of W^{k m}: m kt by additions; index products fit 24 bits -- a full 32-bit multiply costs four additions)
+        int idx = kt;
 #pragma unroll
-        for (int m = 1; m < R; ++m) pw[it][EARLY ? m - 1 : 0] = tw[k * m * twm];
+        for (int m = 1; m < R; ++m) {
+          pw[it][EARLY ? m - 1 : 0] = tw[idx];
+          idx += kt;
+        }
       }
     }
   }
@@ -546,17 +551,18 @@ __device__ __forceinline__ void il_pass(float2* __restrict__ a, int N, int Ns, c
       const int c = i % CT, j = i / CT;
       // k = j % Ns: j < 2^13 and q * Ns <= j, so (j + 0.5) / Ns is at least 0.5 / Ns >= q * 2^-13 away from an integer -- far above
       // the product's rounding error (q * 2^-23)
-      const int k = j - Ns * (int)(((float)j + 0.5f) * rcp_ns);
+      const int k = j - __mul24(Ns, (int)(((float)j + 0.5f) * rcp_ns));
       if (Ns > 1) {
+        const int kt = __mul24(k, twm);
 #pragma unroll
         for (int m = 1; m < R; ++m) {
-          float2 t = EARLY ? pw[it][EARLY ? m - 1 : 0] : tw[k * m * twm];
+          float2 t = EARLY ? pw[it][EARLY ? m - 1 : 0] : tw[m * kt];
           if (DIR > 0) t.y = -t.y;
           v[it][m] = gmul(v[it][m], t);
         }
       }
       bfly_roots<R, DIR>(v[it], w);
-      const int j0 = (j - k) * R + k;
+      const int j0 = __mul24(j - k, R) + k;
 #pragma unroll
       for (int m = 0; m < R; ++m) a[(j0 + m * Ns) * LD + c] = v[it][m];
     }

@@ -275,6 +275,7 @@ static inline float __frcp_rn(float a) { return 1.0f / a; }
 // ---- misc runtime shims ---------------------------------------------------------------------------
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+static inline int __mul24(int a, int b) { return a * b; }
 template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
 
