@@ -621,9 +621,10 @@ static int il_seqs(const Plan1D& plan) {
 }
 
 // Where a one-wave row transform's time goes (tools/ilrow_trace.py, 8 x 3 x 1000 x 1000: 500 complex points, passes 4 x 5 x 5 x 5; a workgroup lives 12 us,
-// 16 of them per CU): row loaded + untangled 2.6 us, first pass 1.5, the three passes with twiddles 2.0 each, row stored 1.5 -- with four waves per SIMD in the same
-// kind of pass that is the passes' ~450 vector instructions per wave (60 % of them integer / move) sharing the SIMD, i.e. instruction-bound like k_cols_il.  Compile-time
-// lengths and strides (a 1000-point instantiation of the column passes: measured) take 4 % off, not more: not adopted.
+// 16 of them per CU): row loaded + untangled 2.6 us, first pass 1.5, the three passes with twiddles 2.0 each, row stored 1.5.  A pass is ~450 vector
+// instructions per wave (60 % of them integer / move), but it is not issue-bound: 12 % fewer issue cycles (twiddle indices by additions, 24-bit index
+// products) bought 1 - 4 %, compile-time lengths and strides 4 % on the column passes (not adopted) -- a pass is a chain of shared-memory round trips, a
+// twiddle gather and two barriers, and the waves of a CU walk it in step.
 // (the loops of run-time length below issue their global loads in batches of UB: written one element at a time, each iteration waits for
 //  its own load -- M / NT dependent round trips per phase, which is what a one-wave workgroup's row kernel then consists of)
 // TWL (both row kernels, as in k_cols_il): the M twiddles of the transform in shared memory behind the rows
