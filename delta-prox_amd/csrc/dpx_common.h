@@ -39,6 +39,8 @@
 #include <cstring>
 template <int NT = 0> __device__ inline void dpx_glds16(const void* g, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, g, 16); }
 template <int NT = 0> __device__ inline void dpx_glds4(const void* g, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 4, g, 4); }
+// (wave-uniform 64-bit base + per-lane 32-bit byte offset)
+__device__ inline void dpx_glds16_s(const void* sbase, unsigned voff, void* lds_wave_base) { std::memcpy((char*)lds_wave_base + (threadIdx.x & 63) * 16, (const char*)sbase + voff, 16); }
 template <int N> __device__ inline void dpx_wait_vm() { __builtin_amdgcn_wave_barrier(); }
 __device__ inline void dpx_wait_lds() { __builtin_amdgcn_wave_barrier(); }
 #else
@@ -64,6 +66,16 @@ template <int NT = 0> __device__ __forceinline__ void dpx_glds4(const void* g, v
   else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+// the same with a wave-uniform 64-bit base in scalar registers and a per-lane 32-bit byte offset: one address register per lane instead of two
+__device__ __forceinline__ void dpx_glds16_s(const void* sbase, unsigned voff, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  const unsigned long long b = (unsigned long long)(size_t)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sb), "s"(dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void dpx_wait_vm() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");

@@ -569,26 +569,51 @@ static int groups16(int c) { return 2 * ((c + 15) / 16); }           // channel 
 
 }  // namespace dpx
 
+#include "dpx_conv_wino_dev.h"
+
+namespace dpx {
+// mode 4 ("split-f16 Winograd"): the first layer (13 -> nc channels: one 16-channel chunk) and layers of more than 64 output channels (their
+// 192 accumulators leave the Winograd kernel's pipeline no registers) stay on the direct split-f16 kernel, every other layer runs as F(2x2, 3x3)
+static bool bx_layer_is_wino(int mode, int l, int cout) { return mode == 4 && l >= 1 && cout <= 64; }
+static size_t bx_layer_bytes_mode(int mode, int l, int in_nc, int nc, int nb) {
+  const int cin = bx_cin(l, in_nc, nc), cout = bx_cout(l, in_nc, nc, nb);
+  return bx_layer_is_wino(mode, l, cout) ? wn_layer_bytes(cin, cout) : bx_layer_bytes(cin, cout, bx_planes(mode == 4 ? 3 : mode));
+}
+}  // namespace dpx
+
 using namespace dpx;
 
-// mode: 6 = split-bf16 (fp32-accurate), 3 = split-f16 (fp32-accurate for |operands| < 6e4, half the matrix work), 1 = plain bf16 operands
+// mode: 6 = split-bf16 (fp32-accurate), 3 = split-f16 (fp32-accurate for |operands| < 6e4, half the matrix work), 1 = plain bf16 operands,
+// 4 = split-f16 with the layers behind the first one as Winograd F(2x2, 3x3) (dpx_conv_wino_dev.h: 2.25 x fewer matrix instructions)
 extern "C" size_t dpx_ffdnet_bf16_packed_bytes(int in_nc, int nc, int nb) {
-  size_t n = 0;
-  for (int l = 0; l < nb; ++l) n += bx_layer_bytes(bx_cin(l, in_nc, nc), bx_cout(l, in_nc, nc, nb));
-  return n + 1024;
+  size_t n = 0, n4 = 0;
+  for (int l = 0; l < nb; ++l) {
+    n += bx_layer_bytes(bx_cin(l, in_nc, nc), bx_cout(l, in_nc, nc, nb));
+    n4 += bx_layer_bytes_mode(4, l, in_nc, nc, nb);
+  }
+  return (n > n4 ? n : n4) + 1024;                                   // (the last KB: scratch of the packing kernels)
 }
 
 extern "C" int dpx_ffdnet_bf16_pack(void* packed, const float* const* w, const float* const* b, int in_nc, int nc, int nb, int mode,
                                     dpx_stream_t stream) {
-  DPX_REQUIRE(packed && w && b && in_nc > 0 && nc > 0 && nb >= 2 && (mode == 6 || mode == 1 || mode == 3), "dpx_ffdnet_bf16_pack: bad arguments");
+  DPX_REQUIRE(packed && w && b && in_nc > 0 && nc > 0 && nb >= 2 && (mode == 6 || mode == 1 || mode == 3 || mode == 4), "dpx_ffdnet_bf16_pack: bad arguments");
   DPX_REQUIRE(nc <= 96 && nc % 16 == 0 && 4 * in_nc <= 96, "dpx_ffdnet_bf16_pack: layers of 16..96 channels (multiples of 16), got %d", nc);
+  DPX_REQUIRE(nb <= 64, "dpx_ffdnet_bf16_pack: at most 64 layers");
   char* dst = (char*)packed;
+  unsigned* umax = (unsigned*)((char*)packed + dpx_ffdnet_bf16_packed_bytes(in_nc, nc, nb) - 1024);       // one word per layer
+  if (mode == 4 && hipMemsetAsync(umax, 0, 64 * sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return DPX_ERR_LAUNCH;
   for (int l = 0; l < nb; ++l) {
     const int cin = bx_cin(l, in_nc, nc), cout = bx_cout(l, in_nc, nc, nb);
     DPX_REQUIRE(w[l] && b[l], "dpx_ffdnet_bf16_pack: layer %d has null weights", l);
-    const size_t n = bx_layer_bytes(cin, cout, bx_planes(mode));
-    DPX_LAUNCH("k_bx_pack_weights", k_bx_pack_weights, dim3(grid_for((long)(n / 2), 256, 2048)), dim3(256), 0, (hipStream_t)stream, w[l], b[l],
-               (unsigned short*)dst, cin, cout, mode, 0);
+    const size_t n = bx_layer_bytes_mode(mode, l, in_nc, nc, nb);
+    if (bx_layer_is_wino(mode, l, cout)) {
+      DPX_LAUNCH("k_wn_umax", k_wn_umax, dim3(grid_for((long)cin * cout * 16, 256, 256)), dim3(256), 0, (hipStream_t)stream, w[l], cin * cout, umax + l);
+      DPX_LAUNCH("k_wn_pack_weights", k_wn_pack_weights, dim3(grid_for((long)(n / 2), 256, 2048)), dim3(256), 0, (hipStream_t)stream, w[l], b[l],
+                 (unsigned short*)dst, cin, cout, (const unsigned*)(umax + l));
+    } else {
+      DPX_LAUNCH("k_bx_pack_weights", k_bx_pack_weights, dim3(grid_for((long)(n / 2), 256, 2048)), dim3(256), 0, (hipStream_t)stream, w[l], b[l],
+                 (unsigned short*)dst, cin, cout, mode == 4 ? 3 : mode, 0);
+    }
     dst += n;
   }
   return launch_status("dpx_ffdnet_bf16_pack");
@@ -707,7 +732,8 @@ extern "C" int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* si
 static int ffdnet_forward_bf16_impl(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode, int B, int H,
                                     int W, void* ws, dpx_stream_t stream, const PnpTail* tail, bool packed_in) {
   DPX_REQUIRE(x && y && sigma && packed && ws, "dpx_ffdnet_forward_bf16: null pointer");
-  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 && (mode == 6 || mode == 1 || mode == 3),
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 &&
+                  (mode == 6 || mode == 1 || mode == 3 || mode == 4),
               "dpx_ffdnet_forward_bf16: unsupported configuration (in_nc=%d nc=%d nb=%d mode=%d)", in_nc, nc, nb, mode);
   hipStream_t s = (hipStream_t)stream;
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
@@ -736,10 +762,11 @@ static int ffdnet_forward_bf16_impl(const float* x, float* y, const float* sigma
     float* dst = lastl ? last : ((l & 1) ? bufB : bufA);
     const int gout = lastl ? GL : Gc;
     if (p8) launch_bx_p8_mt((cout + 31) / 32, !lastl, true, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    else if (bx_layer_is_wino(mode, l, cout)) launch_wino_mt((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     else if (mode == 1) launch_bx_mt<1>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
-    else if (mode == 3) launch_bx_mt<3>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
+    else if (mode == 3 || mode == 4) launch_bx_mt<3>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
     else launch_bx_mt<6>((cout + 31) / 32, !lastl, cur, dst, wl, gin, gout, B, H2, W2, s);
-    wl += bx_layer_bytes(cin, cout, bx_planes(mode));
+    wl += bx_layer_bytes_mode(mode, l, in_nc, nc, nb);
     cur = dst;
     gin = gout;
   }

@@ -266,7 +266,10 @@ def host_mode():
     return _host_pointers
 
 
-# ---- range trap of the split-f16 denoiser arithmetic (FFDNet.compute_mode = "f16x2") -------------------------------------------
+# ---- range trap of the split-f16 denoiser arithmetic (FFDNet.compute_mode = "f16x2" / "f16x2w") -----------------------------------
+# FFDNet.compute_mode -> `mode` of the C ABI (dpx_ffdnet_forward_bf16, dpx_admm_pnp_iter, dpx_admm_cg_pnp_iter)
+FFDNET_MODES = {"f32": 0, "bf16x3": 6, "bf16": 1, "f16x2": 3, "f16x2w": 4}
+F16_MODES = ("f16x2", "f16x2w")                    # the modes whose operands must stay inside the binary16 range
 _f16_pending = False
 _solve_depth = 0
 _solve_epoch = 0
@@ -300,7 +303,7 @@ def f16_fallback(modules, where, stacklevel=3):
     for good and the caller re-runs; returns False when there is nothing to switch (or a network asks to raise instead:
     ``model.f16_fallback = 'raise'``), in which case the caller re-raises."""
     import warnings
-    nets = [m for m in modules if getattr(m, "compute_mode", None) == "f16x2"]
+    nets = [m for m in modules if getattr(m, "compute_mode", None) in F16_MODES]
     if not nets or any(getattr(m, "f16_fallback", "bf16x3") == "raise" for m in nets):
         return False
     for m in nets:

@@ -546,8 +546,8 @@ def admm_pnp_iter(x, rhs, term_arr, nterms, ext, v_new, rho, sigma, spec_add, dd
     """one plug-and-play ADMM iteration in one C call (dpx_admm_pnp_iter); `net`: the FFDNet module of term `ext`"""
     B, C, H, W = _shape4(x)
     L = be.lib()
-    mode = {"f32": 0, "bf16x3": 6, "bf16": 1, "f16x2": 3}[net.compute_mode]
-    if mode == 3:
+    mode = be.FFDNET_MODES[net.compute_mode]
+    if mode in (3, 4):
         be.note_f16_launch()
     Bn = B if net.in_nc == C else B * C
     if mode == 0:
@@ -571,7 +571,7 @@ class CgPnpIter:
         assert C == 1 and net.in_nc == 1
         L = be.lib()
         self.L = L
-        self.mode = {"f32": 0, "bf16x3": 6, "bf16": 1, "f16x2": 3}[net.compute_mode]
+        self.mode = be.FFDNET_MODES[net.compute_mode]
         mask = mask.to(device=x.device, dtype=torch.float32).contiguous()
         mimg = B if mask.numel() == x.numel() else 1
         assert mask.numel() == mimg * H * W
@@ -593,7 +593,7 @@ class CgPnpIter:
         """x (written), v_new (receives the denoised image); returns the CG exit iteration.  rho_next / x_next (self.folds only): the pass
         behind the denoiser also prepares the next call's right-hand side and CG start state (x_next zeroed: the next call's x) -- the next
         call then skips its rhs stage by itself"""
-        if self.mode == 3:
+        if self.mode in (3, 4):
             be.note_f16_launch()
         L = self.L
         ready, self.ready = self.ready, rho_next is not None

@@ -128,6 +128,10 @@ class FFDNet(RefKeyed):
         #               matrix work of "bf16x3"; 1e-7 from float64 on this stack, like fp32 itself).  Operands must stay inside the
         #               binary16 range (|x| < 6e4) -- a solve / denoise() call that met one that did not raises (be.check_f16_range).
         #               The default wherever the layer widths are multiples of 16;
+        #   "f16x2w" -- "f16x2" with every layer behind the first one as Winograd F(2x2, 3x3): 16 instead of 36 matrix products per 2 x 2
+        #               outputs (dpx_conv_wino_dev.h; the transformed weights are computed in float64, the transforms are fp32 additions);
+        #               the same range rule (the trap watches the transformed inputs: |x| < 1.5e4 is always safe).  Under autograd the
+        #               forward pass runs as "f16x2";
         #   "bf16"   -- plain bf16 operands, fp32 accumulation (bf16 training / inference mode, ~3e-3 relative).
         self.compute_mode = os.environ.get("DPX_FFDNET_MODE", "f16x2" if nc % 16 == 0 else "f32")
         # trainable weights: False = forward / backward-data on the split kernels as with frozen weights (weight gradients: the f32-input GEMM
@@ -243,7 +247,7 @@ class FFDNet(RefKeyed):
             sig_t = sig_t.to(device=x.device, dtype=torch.float32).reshape(-1)
             sig_t = sig_t.expand(B).contiguous() if sig_t.numel() == 1 else sig_t.contiguous()
             params = (self.weights + self.biases) if train_w else []
-            if self.compute_mode in ("bf16x3", "f16x2") and self.nc % 16 == 0 and not (train_w and self.train_f32):
+            if self.compute_mode in ("bf16x3", "f16x2", "f16x2w") and self.nc % 16 == 0 and not (train_w and self.train_f32):
                 # forward and backward-data on the split kernels -- fp32-accurate, 2 - 3x the f32-input matrix instruction -- with frozen
                 # weights (unrolled plug-and-play training of schedules / upstream parameters) and with trainable ones (the weight-gradient
                 # GEMM is the f32-input kernel on planar copies of the split path's planes; `train_f32`: everything on the f32-input
@@ -255,9 +259,9 @@ class FFDNet(RefKeyed):
         sig = ops.as_batch_vec(sigma, B, x.device)
         L = be.lib()
         y = torch.empty_like(x)
-        if self.compute_mode in ("bf16x3", "bf16", "f16x2"):
-            mode = {"bf16x3": 6, "bf16": 1, "f16x2": 3}[self.compute_mode]
-            if mode == 3:
+        if self.compute_mode in ("bf16x3", "bf16", "f16x2", "f16x2w"):
+            mode = be.FFDNET_MODES[self.compute_mode]
+            if mode in (3, 4):
                 be.note_f16_launch()
             ws = ops.workspace("ffdnet_bf16", L.query("dpx_ffdnet_bf16_ws_bytes", B, self.in_nc, self.nc, H, W), x.device)
             L.call("dpx_ffdnet_forward_bf16", be.ptr(x), be.ptr(y), be.ptr(sig), be.ptr(self.packed_bf16(mode)), self.in_nc, self.nc,
@@ -282,7 +286,7 @@ class _FFDNetSplitFn(torch.autograd.Function):
         L = be.lib()
         x = x.contiguous()
         y = torch.empty_like(x)
-        mode = {"bf16x3": 6, "f16x2": 3}[net.compute_mode]
+        mode = {"bf16x3": 6, "f16x2": 3, "f16x2w": 3}[net.compute_mode]
         if mode == 3:
             be.note_f16_launch()
         acts = torch.empty(L.query("dpx_ffdnet_bf16_acts_bytes", B, net.in_nc, net.nc, net.nb, H, W), dtype=torch.uint8, device=x.device)

@@ -122,7 +122,7 @@ def T64(a):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)))
 
 
-def ref_f64_admm(b, psf, K, rhos=0.1, lams=0.005, dims=(0, 1), prior=None, extra=None, full=False):
+def ref_f64_admm(b, psf, K, rhos=0.1, lams=0.005, dims=(0, 1), prior=None, extra=None, full=False, callback=None):
     """ADMM on  sum_squares(conv(x, psf) - b) + [TV terms along `dims`] + [deep_prior(denoiser=prior)] + [extra(x)]  run by the REFERENCE in
     float64 (reference_in_float64): returns x, or the full state with full=True."""
     with reference_in_float64():
@@ -142,7 +142,8 @@ def ref_f64_admm(b, psf, K, rhos=0.1, lams=0.005, dims=(0, 1), prior=None, extra
             lam_arg = dict(lam_arg)
             lam_arg[ef] = 0.0
         with torch.no_grad():
-            out = dp.Problem(fns).solve(method="admm", device="cpu", x0=b64.clone(), rhos=rhos, lams=lam_arg, max_iter=K, return_full_states=full)
+            out = dp.Problem(fns).solve(method="admm", device="cpu", x0=b64.clone(), rhos=rhos, lams=lam_arg, max_iter=K, return_full_states=full,
+                                        callback=callback)
     assert (out[0] if full else out).dtype == torch.float64
     return out
 
@@ -1347,6 +1348,122 @@ def g38_full_c3_batch8():
     save("g38_full_c3_batch8", **out)
 
 
+def g38b_full_c3_trajectory():
+    """config 3 as bench.py times it -- 8 x 3 x 1024 x 1024, ADMM with the FFDNet-colour prior (seeded weights), ALL 30 steps of the
+    log_descent(35, 5, 30) schedule in ONE solve from x0 = b -- with x and v sampled at iterations 10, 20 and 30 from the reference and
+    from the reference's own float64 run of the same 30 steps (algo/admm.py:49-59, proxfn/pnp/prior.py:42-89, algo/tune/dpir.py:13-39).
+    G38 covers the two ends of the schedule from a fresh start; this fixture covers the path in between."""
+    gt, b, psf = synthetic.deconv_case(8, 3, 1024, 1024, seed=2308)
+    rhos, sigmas = log_descent(35, 5, 30)
+    out = {"seed": 2308, "rhos": rhos, "sigmas": sigmas}
+
+    def recorder(suffix):
+        def cb(iter, state, rho, lam):
+            if iter + 1 in (10, 20, 30):
+                _pack(out, f"it{iter + 1}_x{suffix}", state[0], 16)
+                _pack(out, f"it{iter + 1}_v0{suffix}", state[1][0], 16)
+                _pack(out, f"it{iter + 1}_u0{suffix}", state[2][0], 16)
+                print(f"   g38b{suffix}: iteration {iter + 1} recorded", flush=True)
+        return cb
+
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=ColorDen(7))
+    fns = dp.sum_squares(dp.conv(x, psf) - T(b)) + prior
+    with torch.no_grad():
+        xo = dp.Problem(fns).solve(method="admm", device="cpu", x0=T(b), rhos=rhos, lams={prior: sigmas}, max_iter=30, callback=recorder(""))
+    out["psnr"] = np.array([10 * np.log10(1.0 / np.mean((xo[i].numpy() - gt[i]) ** 2)) for i in range(8)])
+    x64 = ref_f64_admm(b, psf, 30, rhos=rhos, lams=sigmas, dims=(), prior=ColorDen(7), callback=recorder("_f64"))
+    for it in (10, 20, 30):
+        for k in ("x", "v0", "u0"):
+            out[f"it{it}_{k}_f64"] = out[f"it{it}_{k}_f64"].float()     # (samples kept in fp32; sums / norms stay float64)
+    print(f"   g38b: reference fp32 vs its float64 run after 30 steps: x {float((xo.double() - x64).norm() / x64.norm()):.2e}")
+    out["ref_err_x30"] = np.float64(float((xo.double() - x64).norm() / x64.norm()))
+    save("g38b_full_c3_trajectory", **out)
+
+
+def g32c_full_c4_trajectory():
+    """config 4, one GPU's shard, at the length bench.py times: 4 x 1 x 320 x 320 CS-MRI, LADMM with the CG x-update (rtol 1e-6, <= 100
+    iterations), 10 outer iterations -- the final state and ALL TEN CG exit counts of the reference's own loop
+    (linalg/solve/solver_cg.py:99-129, algo/admm.py:78-100); inputs as G32."""
+    import dprox.linalg.solve.solver_cg as scg
+    import dprox.proxfn.sum_square as ssq
+    gt, mask, y = synthetic.csmri_case(4, 320, 320, seed=2304, center=32)
+    mask, y = T(mask), T(y)
+    x = dp.Variable()
+    fns = dp.sum_squares(MaskedFFT(x, mask), y) + dp.nonneg(x) + dp.deep_prior(x, denoiser=GrayDen(seed=11))
+    x0 = ifft2(y).real.float()
+    calls = {"bdot": 0}
+    counts = []
+    orig_bdot, orig_ls = scg.bdot, ssq.linear_solve
+
+    def bdot(*a, **k):
+        calls["bdot"] += 1
+        return orig_bdot(*a, **k)
+
+    def linear_solve(*a, **k):
+        n0 = calls["bdot"]
+        r = orig_ls(*a, **k)
+        counts.append((calls["bdot"] - n0) // 2)
+        return r
+
+    out = {"seed": 2304}
+
+    def cb(iter, state, rho, lam):
+        if iter + 1 == 5:
+            _pack(out, "it5_x", state[0], 4)
+
+    scg.bdot, ssq.linear_solve = bdot, linear_solve
+    try:
+        with torch.no_grad():
+            st = dp.Problem(fns, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100)).solve(
+                method="ladmm", device="cpu", x0=x0, rhos=0.5, lams=0.03, max_iter=10, return_full_states=True, callback=cb)
+    finally:
+        scg.bdot, ssq.linear_solve = orig_bdot, orig_ls
+    out["cg_iters"] = np.array(counts)
+    print("config-4 shard, 10 outer iterations: CG exit counts", counts)
+    _pack(out, "x", st[0], 4)
+    for i in range(2):
+        _pack(out, f"v{i}", st[1][i], 4)
+        _pack(out, f"u{i}", st[2][i], 4)
+    # The yardstick: the reference itself in float64 (reference_in_float64) running the SAME CG iteration counts -- every linear_solve call gets
+    # max_iters = the fp32 run's exit count and rtol = 0, so that the two runs differ by float32 round-off alone.  Ten outer iterations of a
+    # truncated-CG x-update and a seeded (non-contractive) denoiser amplify that round-off: the reference's own float32 iterate is `ref_err` away
+    # from this float64 one (1e-4 class), which is what a second float32 implementation has to be measured against.
+    fixed = list(counts)
+    k = {"i": 0}
+
+    def linear_solve_fixed(A, b, config=None, *a, **kw):
+        cfg = LinearSolveConfig(rtol=0.0, max_iters=int(fixed[k["i"]]))
+        k["i"] += 1
+        return orig_ls(A, b, cfg, *a, **kw)
+
+    def cb64(iter, state, rho, lam):
+        if iter + 1 == 5:
+            _pack(out, "it5_x_f64", state[0], 4)
+
+    ssq.linear_solve = linear_solve_fixed
+    try:
+        with reference_in_float64(), torch.no_grad():
+            x64 = dp.Variable()
+            y64 = y.to(torch.complex128)
+            fns64 = dp.sum_squares(MaskedFFT(x64, mask.double()), y64) + dp.nonneg(x64) + dp.deep_prior(x64, denoiser=GrayDen(seed=11).double())
+            st64 = dp.Problem(fns64, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100)).solve(
+                method="ladmm", device="cpu", x0=ifft2(y64).real, rhos=0.5, lams=0.03, max_iter=10, return_full_states=True, callback=cb64)
+    finally:
+        ssq.linear_solve = orig_ls
+    assert st64[0].dtype == torch.float64 and k["i"] == 10
+    _pack(out, "x_f64", st64[0], 4)
+    for i in range(2):
+        _pack(out, f"v{i}_f64", st64[1][i], 4)
+        _pack(out, f"u{i}_f64", st64[2][i], 4)
+    for kk in list(out):
+        if kk.endswith("_f64") and out[kk].dtype == torch.float64:
+            out[kk] = out[kk].float()                      # (samples kept in fp32; sums / norms stay float64)
+    print(f"   g32c: reference fp32 vs its float64 run (same CG counts) after 10 outer iterations: x {float((st[0].double() - st64[0]).norm() / st64[0].norm()):.2e}, "
+          f"after 5: {float((out['it5_x'].double() - out['it5_x_f64'].double()).norm() / out['it5_x_f64'].double().norm()):.2e}")
+    save("g32c_full_c4_trajectory", **out)
+
+
 def g39_train_unrolled_pnp():
     """The training workload bench.py times (`train_unrolled_pnp`; the reference's one published throughput figure, notebooks/quickstart.ipynb:
     254-257) at ITS size: 2 RGB patches of 768 x 768, ADMM unrolled 10 times on sum_squares(conv_doe(x, PSF), b) + deep_prior(ffdnet_color, frozen
@@ -1395,6 +1512,7 @@ if __name__ == "__main__":
     for fn in (g1_linops, g2_psf2otf, g3_prox, g4_solve_direct, g5_admm_tv, g6_cg, g6b_cg_large_batches, g7_ladmm_cg, g8_ffdnet, g8b_ffdnet_wide_range,
                g9_admm_pnp, g10_pgd, g11_unrolled_grads, g12_log_descent, g13_known_answers, g14_other_algorithms, g15_csmri, g16_ffdnet_grads, g17_mosaic_jd, g18_sisr, g19_conv_doe, g20_drunet, g21_x8_augment, g22_unet, g23_pnp_scaled_sqrt, g24_linear_solve_grad, g25_doe_psf_grad,
                g30_full_c2, g30b_full_c2_batch8, g31_full_c3, g32_full_c4, g32b_full_c4_batches, g33_full_c5, g34_pgd_pow2, g35_h768, g36_hqs_pow2,
-               g37_generic_planes, g38_full_c3_batch8, g39_train_unrolled_pnp):
+               g37_generic_planes, g38_full_c3_batch8, g38b_full_c3_trajectory, g32c_full_c4_trajectory,
+               g39_train_unrolled_pnp):
         if not only or any(fn.__name__.startswith(o) for o in only):
             fn()

@@ -888,6 +888,48 @@ def case_ffdnet_f16_split(device, tiny=False):
     col.model.compute_mode = "f16x2"
 
 
+def case_ffdnet_winograd(device, tiny=False):
+    """compute_mode "f16x2w": the layers behind the first one (up to 64 output channels) as Winograd F(2x2, 3x3) on the split-f16 matrix
+    instruction (dpx_conv_wino_dev.h; network_ffdnet.py:54-68, basicblock.py:61-98).  Gray FFDNet (64 channels: every middle layer and the last
+    one) and the colour one's last layer against the reference's fp32 outputs (G8) at the same 1e-5 as the other modes; networks of 16 and 64
+    channels on planes of several workgroup tiles (persistent workgroups: more tiles than workgroups), odd sizes, against the f32-input mode;
+    the range trap.  tiny: the small networks only (the SIMT emulator)."""
+    import synthetic
+    from dprox import _backend as be
+    from dprox.proxfn.pnp.denoisers import FFDNet, FFDNetColorDenoiser
+    rng = np.random.RandomState(31)
+    shapes = ((16, 3, (2, 3, 20, 28)), (64, 3, (2, 3, 40, 72))) if tiny else ((16, 3, (2, 3, 20, 28)), (64, 4, (3, 3, 135, 210)), (64, 4, (1, 3, 512, 640)))
+    with torch.no_grad():
+        for nc, nb, shape in shapes:
+            col = FFDNetColorDenoiser()
+            col.model = FFDNet(in_nc=3, out_nc=3, nc=nc, nb=nb, act_mode="R").load_layers(synthetic.ffdnet_weights(5, 3, 3, nc, nb))
+            col = col.to(device)
+            x = T(rng.rand(*shape).astype(np.float32), device)
+            sig = torch.tensor(0.05, device=device)
+            col.model.compute_mode = "f32"
+            ref = col.denoise(x, sig).cpu()
+            col.model.compute_mode = "f16x2w"
+            out = col.denoise(x, sig)
+            assert_close(out.cpu(), ref, TOL, f"FFDNet Winograd layers, {nc} channels, {shape} vs the f32 mode")
+            assert torch.equal(col.denoise(x, sig), out), "run-to-run"
+        # the range trap sees the transformed inputs
+        col.model.f16_fallback = "raise"
+        with pytest.raises(be.F16RangeError, match="binary16"):
+            col.denoise((x * 3.0e5).contiguous(), sig)
+        if tiny:
+            return
+        g = load_golden("g8_ffdnet")
+        gray = _ffdnet("gray", device)
+        gray.model.compute_mode = "f16x2w"
+        out = gray.denoise(T(g["gray_x"], device), torch.tensor(0.1, device=device))
+        assert_close(out.cpu(), g["gray_s0.1"], TOL, "gray FFDNet per band, Winograd layers")
+        color = _ffdnet("color", device)
+        color.model.compute_mode = "f16x2w"
+        for tag in ("odd", "even"):
+            out = color.denoise(T(g[f"{tag}_x"], device), torch.tensor(0.02, device=device))
+            assert_close(out.cpu(), g[f"{tag}_s0.02"], TOL, f"colour FFDNet {tag}, last layer Winograd")
+
+
 def case_ffdnet_wide_range(device):
     """G8b: a checkpoint with a large dynamic range (He-normal x 8: activations ~8x per layer, out of binary16 range after a few
     layers).  denoise() on the default split-f16 arithmetic trips the range trap, is re-run on split-bf16 automatically and matches
@@ -2408,6 +2450,87 @@ def case_full_c3_batch8(device):
         del s, st
         if str(device) != "cpu":
             torch.cuda.empty_cache()
+
+
+def case_full_c3_trajectory(device):
+    """G38b -- config 3 at the length bench.py times: 8 x 3 x 1024 x 1024, FFDNet-colour plug-and-play ADMM, ALL 30 steps of log_descent(35, 5, 30)
+    in one solve from x0 = b, x and v after 10, 20 and 30 iterations against the real reference and the reference's own float64 run of the same
+    30 steps (criterion as G38 / G31 / G9: at least as close to the float64 iterate as the reference is, + the 1e-5 budget; and within the sum
+    of the two fp32 distances of the reference).  Three solves of 10 / 20 / 30 iterations on the path bench.py times (no callback)."""
+    import synthetic
+    g = load_golden("g38b_full_c3_trajectory")
+    gt, b, psf = synthetic.deconv_case(8, 3, 1024, 1024, seed=int(g["seed"]))
+    bt = T(b, device)
+    rhos30, sig30 = dp.log_descent(35, 5, 30)
+    assert np.allclose(rhos30.numpy(), g["rhos"], rtol=1e-6) and np.allclose(sig30.numpy(), g["sigmas"], rtol=1e-6)
+    samp = lambda t: t[..., ::16, ::16].cpu().numpy()
+    x = dp.Variable()
+    prior = dp.deep_prior(x, denoiser=_ffdnet("color", device))
+    fns = dp.sum_squares(dp.conv(x, psf) - bt) + prior
+    with torch.no_grad():
+        s = dp.compile(fns, method="admm", device=device)
+        for it in (10, 20, 30):
+            st = s.solve(x0=bt, rhos=rhos30[:it].clone(), lams={prior: sig30[:it].clone()}, max_iter=it, return_full_states=True)
+            assert s.last_path == "fused"
+            for key, got in (("x", samp(st[0])), ("v0", samp(st[1][0]))):
+                ref_err = rel_l2(g[f"it{it}_{key}"], g[f"it{it}_{key}_f64"])
+                got_err = rel_l2(got, g[f"it{it}_{key}_f64"])
+                r = rel_l2(got, g[f"it{it}_{key}"])
+                record(f"c3 batch 8, 30-step solve, iteration {it}: {key} vs the reference's float64 iterate (reference's own distance: {ref_err:.2e})", got_err,
+                       ref_err + TOL)
+                record(f"c3 batch 8, 30-step solve, iteration {it}: {key} vs the reference (both fp32)", r, 2 * ref_err + TOL)
+                assert got_err <= ref_err + TOL, (it, key, got_err, ref_err)
+                assert r <= 2 * ref_err + TOL, (it, key, r, ref_err)
+            d = st[1][0].double().reshape(8, -1).norm(dim=1).cpu().numpy()
+            e = float(np.max(np.abs(d - g[f"it{it}_v0_f64_l2"]) / g[f"it{it}_v0_f64_l2"]))
+            record(f"c3 batch 8, 30-step solve, iteration {it}: v per-image L2 norm vs float64", e, 1e-4)
+            assert e <= 1e-4, (it, e)
+        psnr = [10 * np.log10(1.0 / np.mean((st[0][i].cpu().numpy() - gt[i]) ** 2)) for i in range(8)]
+        assert np.allclose(psnr, g["psnr"], atol=5e-3), (psnr, g["psnr"])
+
+
+def case_full_c4_trajectory(device):
+    """G32c -- one GPU's shard of config 4 at the length bench.py times: 4 x 1 x 320 x 320, LADMM, CG x-update (rtol 1e-6, <= 100), nonneg + gray
+    FFDNet prior, 10 outer iterations: the final state, x after 5 iterations (a second solve), and ALL TEN CG exit counts EQUAL to the reference's
+    (linalg/solve/solver_cg.py:99-129)."""
+    import synthetic
+    from dprox.contrib import masked_fft
+    from dprox.linalg import LinearSolveConfig
+    from dprox.utils import ifft2
+    g = load_golden("g32c_full_c4_trajectory")
+    gt, mask, y = synthetic.csmri_case(4, 320, 320, seed=int(g["seed"]), center=32)
+    mask, y = T(mask, device), T(y, device)
+    x = dp.Variable()
+    fns = dp.sum_squares(masked_fft(x, mask), y) + dp.nonneg(x) + dp.deep_prior(x, denoiser=_ffdnet("gray", device))
+    x0 = ifft2(y).real.float().contiguous()
+    with torch.no_grad():
+        s = dp.compile(fns, method="ladmm", device=device, linear_solve_config=LinearSolveConfig(rtol=1e-6, max_iters=100))
+        st = s.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=10, return_full_states=True)
+        its = [int(v) for v in s.least_square.cg_iters[-10:]]
+        assert its == [int(v) for v in g["cg_iters"]], (its, list(g["cg_iters"]))
+        x5 = s.solve(x0=x0, rhos=0.5, lams=0.03, max_iter=5)
+    # Ten outer iterations of a truncated-CG x-update and a seeded denoiser amplify float32 round-off: the reference's own float32 x is `ref_err`
+    # away from its float64 run with the SAME CG iteration counts (3.4e-5 on the stored ::4 lattice -- where the centred-FFT images happen to be
+    # 4x smaller than their rms --, 3.8e-6 over the full tensor).  Criterion as for config 3: at least as close to the float64 iterate as the
+    # reference is (+ the 1e-5 budget), within the sum of the two distances of the reference, and per-image norms / sums of the FULL tensors at 1e-5.
+    samp = lambda t: t[..., ::4, ::4].cpu().numpy()
+    for key, got in (("x", samp(st[0])), ("it5_x", samp(x5)), ("v0", samp(st[1][0])), ("u0", samp(st[2][0])), ("v1", samp(st[1][1])), ("u1", samp(st[2][1]))):
+        scale = np.linalg.norm(g["x_f64"].astype(np.float64).ravel())                 # (split variables on the iterate's scale)
+        f64 = g[key + "_f64"].astype(np.float64)
+        ref_err = float(np.linalg.norm((g[key] - f64).ravel()) / scale)
+        got_err = float(np.linalg.norm((got - f64).ravel()) / scale)
+        r = float(np.linalg.norm((got.astype(np.float64) - g[key]).ravel()) / scale)
+        record(f"c4, 10 outer iterations: {key} vs the reference's float64 run, same CG counts (reference's own distance: {ref_err:.2e})", got_err, ref_err + TOL)
+        record(f"c4, 10 outer iterations: {key} vs the reference (both fp32)", r, 2 * ref_err + TOL)
+        assert got_err <= ref_err + TOL, (key, got_err, ref_err)
+        assert r <= 2 * ref_err + TOL, (key, r, ref_err)
+    for key, t in (("x", st[0]), ("it5_x", x5)):
+        d = t.double().reshape(4, -1)
+        e_l2 = float(np.max(np.abs(d.norm(dim=1).cpu().numpy() - g[key + "_l2"]) / g[key + "_l2"]))
+        e_sum = float(np.max(np.abs(d.sum(1).cpu().numpy() - g[key + "_sum"]) / (g[key + "_l2"] * np.sqrt(d.shape[1]))))
+        record(f"c4, 10 outer iterations: {key} per-image L2 norm (full tensor)", e_l2, TOL)
+        record(f"c4, 10 outer iterations: {key} per-image sum / (sqrt(n) L2) (full tensor)", e_sum, TOL)
+        assert e_l2 <= TOL and e_sum <= TOL, (key, e_l2, e_sum)
 
 
 def case_full_c3(device):

@@ -141,6 +141,10 @@ def test_ffdnet_split_f16_and_its_range_trap():
     pc.case_ffdnet_f16_split(DEV, tiny=True)
 
 
+def test_ffdnet_winograd_layers():
+    pc.case_ffdnet_winograd(DEV, tiny=True)
+
+
 def test_linear_solve_implicit_backward():
     pc.case_linear_solve_grad(DEV)
 

@@ -160,6 +160,11 @@ def test_ffdnet_split_f16_and_its_range_trap():
 
 
 @pytest.mark.gpu
+def test_ffdnet_winograd_layers():
+    pc.case_ffdnet_winograd(DEV)
+
+
+@pytest.mark.gpu
 def test_ffdnet_split_backward():
     pc.case_ffdnet_split_backward(DEV)
 
@@ -298,6 +303,10 @@ def test_full_size_config3_pnp():
 
 def test_full_size_config4_shard_ladmm_cg():
     pc.case_full_c4(DEV)
+
+
+def test_g32c_config4_shard_ten_outer_iterations_all_cg_exit_counts():
+    pc.case_full_c4_trajectory(DEV)
 
 
 @pytest.mark.parametrize("B", [16, 32])
@@ -608,6 +617,10 @@ def test_g37_bench_only_plane_sizes_at_full_size():
 
 def test_g38_config3_whole_batch_both_ends_of_the_schedule():
     pc.case_full_c3_batch8(DEV)
+
+
+def test_g38b_config3_whole_batch_the_30_step_solve_bench_times():
+    pc.case_full_c3_trajectory(DEV)
 
 
 def test_merged_loop_keeps_the_callers_duals():
