@@ -29,8 +29,9 @@ namespace dpx {
 
 // M = W / 2 pixel pairs per row, T lanes per row, SPB = 256 / T rows in flight per workgroup, NT terms.  Partial sums: one slot per
 // workgroup, [row][nblk] with nblk = C * bands workgroups per image (part_lam rows = term * B + image).
+// (three or four terms, and two with an fp32 history: one wave per SIMD -- up to 512 registers -- instead of 2 - 28 spilled ones; tools/spill_check.py)
 template <int M, int T, int NT, bool HB>
-__global__ void __launch_bounds__(256, 2) k_bwd_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, BwdRowTerms TT,
+__global__ void __launch_bounds__(256, (NT >= 3 || (NT == 2 && !HB)) ? 1 : 2) k_bwd_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, BwdRowTerms TT,
                                                    const float* __restrict__ rho_b, float* __restrict__ part_a, float* __restrict__ part_b,
                                                    float* __restrict__ part_lam, int B, int C, int H, int R, int bands, int P,
                                                    const float2* __restrict__ twW) {

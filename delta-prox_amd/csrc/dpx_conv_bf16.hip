@@ -237,25 +237,36 @@ __global__ void __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) k_conv3x3_bf16(cons
   const float* zero_block = bias + M32;                               // 64 zero bytes behind the bias
   const float* inb = in + (size_t)b * Gin * H * W * 8;
 
-  // per-lane source offsets (floats, relative to the chunk's first group) of its DMA pieces; ~0u = outside the image
-  unsigned poff[NPI];
-#pragma unroll
-  for (int k = 0; k < NPI; ++k) {
-    const int q = k * NT + tid;
+  // per-lane source offset (floats, relative to the chunk's first group) of DMA piece k; ~0u = outside the image.  MT = 3 (192 accumulators)
+  // recomputes it for every chunk (~20 integer instructions per piece against 162 matrix instructions per chunk) instead of keeping NPI registers
+  // -- with them the split-f16 forms spilled 4 - 6 registers; the smaller forms keep the table.
+  constexpr bool POFF_TABLE = MT < 3;
+  auto piece_off = [&](int k, int tid_) {
+    const int q = k * NT + tid_;
     const int u = PRE ? (q < UNITS ? q : q - UNITS) : q >> 1, half = PRE ? (q < UNITS ? 0 : 1) : q & 1;      // PRE: plane by plane
     const int g = u / (ROWS * BX_COLS), rem = u - g * (ROWS * BX_COLS);
     const int row = rem / BX_COLS, col = rem - row * BX_COLS;
     const int yy = y0 + row - 1, xx = x0 + col - 1;
     const bool ok = q < PIECES && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    poff[k] = ok ? (unsigned)(((size_t)g * H * W + (size_t)yy * W + xx) * 8 + half * 4) : ~0u;
+    return ok ? (unsigned)(((size_t)g * H * W + (size_t)yy * W + xx) * 8 + half * 4) : ~0u;
+  };
+  unsigned poff[POFF_TABLE ? NPI : 1];
+  if constexpr (POFF_TABLE) {
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) poff[k] = piece_off(k, tid);
   }
   auto issue_act = [&](int c) {
     if (DPX_BX_DBG & 8) return;
     const float* cb = inb + (size_t)(2 * c) * H * W * 8;
+    int tid_c = tid;
+    if constexpr (!POFF_TABLE) DPX_OPAQUE(tid_c);                     // (per chunk: the offsets must not be hoisted out of the chunk loop)
 #pragma unroll
     for (int k = 0; k < NPI; ++k) {
       if (k * NT + wv * 64 < PIECES) {                            // wave-uniform: whole 1 KB instructions
-        const float* src = (poff[k] != ~0u && !(DPX_BX_DBG & 32)) ? cb + poff[k] : zero_block;
+        unsigned po;
+        if constexpr (POFF_TABLE) po = poff[k];
+        else po = piece_off(k, tid_c);
+        const float* src = (po != ~0u && !(DPX_BX_DBG & 32)) ? cb + po : zero_block;
         if (DPX_BX_DBG & 64) src = inb + (tid & 63) * 4;
         dpx_glds16(src, (PRE ? smem_bx + (c & 1) * LAND_BYTES : land) + (k * NT + wv * 64) * 16);
       }

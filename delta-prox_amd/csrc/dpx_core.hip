@@ -180,7 +180,6 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"cg_event_wait", "DPX_CG_EVENT_WAIT", 0, nullptr},
     {"pnp_cg_no_fold", "DPX_PNP_CG_NO_FOLD", 0, nullptr},
     {"il_tw_lds", "DPX_IL_TW_LDS", 1, nullptr},
-    {"generic_fused_rows", "DPX_GENERIC_FUSED_ROWS", 0, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

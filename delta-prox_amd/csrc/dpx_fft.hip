@@ -962,220 +962,6 @@ __global__ void __launch_bounds__(NT, 4) k_cols_il(float2* __restrict__ spec, Sp
 }
 
 // ---------------------------------------------------------------------------------------------
-// The row pass of an ADMM iteration on planes OFF the power-of-two path as ONE launch (even W): inverse row transforms of a band of
-// spectrum rows, the z / dual stage of iteration t and the right-hand side of iteration t + 1, forward row transforms -- what
-// k_rows_c2r_il -> k_zupdate_rhs -> k_rows_r2c_il do with x and the right-hand side going through memory in between (16 of that sequence's
-// 40 bytes per pixel, and two launches).  A workgroup = NWV one-wave row transforms: the R = NWV - 2 rows of its band and one halo row on
-// either side (x of the row above and below feeds the vertical stencil and the recomputed neighbour updates, exactly as in k_zupdate_rhs);
-// the rows of x sit in shared memory as (x[2n], x[2n + 1]) pairs, the finished right-hand-side rows in a second set of slots that only
-// their own wave touches.  The same expressions in the same order as the three kernels: bit-identical spectra, duals, v and x.
-// spec_in != spec_out (halo rows are read from spec_in while neighbours store theirs).
-// ---------------------------------------------------------------------------------------------
-template <int NWV>
-__global__ void __launch_bounds__(64 * NWV, NWV == 16 ? 4 : 2)
-    k_iter_rows_il(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, float* __restrict__ x_out, const float* __restrict__ ktb,
-                   const float* __restrict__ rho, TermPack T, int dual, int emit_v, int C, int H, int W, int bands, Plan1D plan,
-                   const float2* __restrict__ twW) {
-  HIP_DYNAMIC_SHARED(float2, smem)
-  constexpr int RMAX = NWV - 2;
-  const int M = plan.n, Ws = W / 2;
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int pl = blockIdx.x / bands, bb = blockIdx.x - pl * bands;
-  const int r0 = bb * RMAX;
-  const int R = min(RMAX, H - r0);                        // rows of this band
-  int h = r0 - 1 + q;
-  h = h < 0 ? h + H : (h >= H ? h - H : h);
-  const bool live = q <= R + 1, own = q >= 1 && q <= R;
-  float2* a = smem + (size_t)q * M;                       // this wave's row of x (pairs)
-  float2* rs = smem + (size_t)NWV * M + (size_t)(q > 0 ? q - 1 : 0) * M;      // this wave's right-hand-side row (own rows only)
-  // ---- phase A: spectrum row h -> x row (k_rows_c2r_il, EVEN, one sequence on one wave) ------------------------------------
-  if (live) {
-    const float2* X = spec_in + ((size_t)pl * H + h) * Ws;
-    constexpr int UB = 4;
-    for (int k0 = lane; k0 <= M / 2; k0 += UB * 64) {
-      float2 xa[UB], xb[UB], wa[UB], wb[UB];
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int k = k0 + u * 64, k2 = M - k;
-        xa[u] = xb[u] = wa[u] = wb[u] = make_float2(0.f, 0.f);
-        if (k <= M / 2) {
-          xa[u] = X[k];
-          if (k != 0) {
-            xb[u] = X[k2];
-            wa[u] = twW[k];
-            wb[u] = twW[k2];
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int k = k0 + u * 64, k2 = M - k;
-        if (k > M / 2) continue;
-        float2 p0, p1 = make_float2(0.f, 0.f);
-        if (k == 0) {
-          const float2 x0 = xa[u];
-          p0 = make_float2(x0.x + x0.y, x0.x - x0.y);
-        } else {
-          {
-            const float2 xm = cconj(xb[u]);
-            const float2 e = cadd(xa[u], xm);
-            const float2 d = cmulc(csub(xa[u], xm), wa[u]);        // * w^{-k}
-            p0 = make_float2(e.x - d.y, e.y + d.x);              // e + i d
-          }
-          {
-            const float2 xm = cconj(xa[u]);
-            const float2 e = cadd(xb[u], xm);
-            const float2 d = cmulc(csub(xb[u], xm), wb[u]);
-            p1 = make_float2(e.x - d.y, e.y + d.x);
-          }
-        }
-        a[k] = p0;
-        if (k != 0 && k2 != k) a[k2] = p1;
-      }
-    }
-    WaveSync()();
-    fft_il<+1, 1, 64, WaveSync>(a, plan, twW, 2, lane);
-    if (x_out && own) {
-      float* yr = x_out + ((size_t)pl * H + h) * W;
-      for (int n = lane; n < M; n += 64) {
-        const float2 v = a[n];
-        *(float2*)(yr + 2 * n) = make_float2(v.x * 1.0f, v.y * 1.0f);
-      }
-    }
-  }
-  __syncthreads();
-  if (!own) return;
-  // ---- phase B: z / dual stage + next right-hand side of row h (k_zupdate_rhs on pixel pairs; x from the three rows in shared memory) ----
-  {
-    const float* xs = (const float*)a;
-    const float* xsd = (const float*)(smem + (size_t)(q + 1) * M);
-    const float* xsu = (const float*)(smem + (size_t)(q - 1) * M);
-    const int b = pl / C;
-    const size_t row = (size_t)pl * H + h;
-    const size_t rowu = (size_t)pl * H + (h == 0 ? H - 1 : h - 1);
-    const float r = rho[b];
-    bool need_w = false, need_h = false;
-    for (int t = 0; t < T.n; ++t) {
-      need_w |= T.t[t].linop == DPX_LIN_GRAD_W;
-      need_h |= T.t[t].linop == DPX_LIN_GRAD_H;
-    }
-    for (int n = lane; n < M; n += 64) {
-      const size_t off = row * W + 2 * (size_t)n;
-      const size_t left = row * W + (n == 0 ? W - 1 : 2 * n - 1);
-      const size_t offu = rowu * W + 2 * (size_t)n;
-      float xv[3], xd[2] = {0.f, 0.f}, xu[2] = {0.f, 0.f}, xl = 0.f;
-      xv[0] = xs[2 * n];
-      xv[1] = xs[2 * n + 1];
-      xv[2] = 0.f;
-      if (need_w) {
-        xv[2] = xs[(2 * n + 2) % W];
-        xl = xs[n == 0 ? W - 1 : 2 * n - 1];
-      }
-      if (need_h) {
-        xd[0] = xsd[2 * n];
-        xd[1] = xsd[2 * n + 1];
-        xu[0] = xsu[2 * n];
-        xu[1] = xsu[2 * n + 1];
-      }
-      float acc[2] = {0.f, 0.f};
-      for (int t = 0; t < T.n; ++t) {
-        const dpx_term tm = T.t[t];
-        const float lam = tm.lam ? tm.lam[b] * tm.alpha : 0.f;
-        const bool nodual = tm.reserved & DPX_TERM_NO_DUAL;
-        float uu[2], vv[2];
-        if (nodual) {
-          uu[0] = uu[1] = 0.f;
-        } else {
-          const float2 qv = *(const float2*)(tm.u + off);
-          uu[0] = qv.x;
-          uu[1] = qv.y;
-        }
-        float y[3];                                          // y[1..2] = v - u' at this pixel pair, y[0] = left neighbour
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          float kx;
-          if (tm.linop == DPX_LIN_IDENTITY) kx = xv[e];
-          else if (tm.linop == DPX_LIN_GRAD_W) kx = xv[e + 1] - xv[e];
-          else kx = xd[e] - xv[e];
-          const float d = kx + uu[e];
-          vv[e] = prox_eval(tm.prox, d, lam);
-          const float uin = uu[e];
-          uu[e] = d - vv[e];
-          y[e + 1] = vv[e] - (dual ? uu[e] : uin);
-        }
-        if (emit_v) *(float2*)(tm.v + off) = make_float2(vv[0], vv[1]);
-        if (dual) *(float2*)(tm.u_out + off) = make_float2(uu[0], uu[1]);
-        if (tm.linop == DPX_LIN_IDENTITY) {
-#pragma unroll
-          for (int e = 0; e < 2; ++e) acc[e] += y[e + 1];
-        } else if (tm.linop == DPX_LIN_GRAD_W) {
-          const float uin = nodual ? 0.f : tm.u[left];
-          const float d = (xv[0] - xl) + uin;                 // the left neighbour's own update, recomputed
-          const float vl = prox_eval(tm.prox, d, lam);
-          const float ul = d - vl;
-          y[0] = vl - (dual ? ul : uin);
-#pragma unroll
-          for (int e = 0; e < 2; ++e) acc[e] += y[e] - y[e + 1];
-        } else {
-          float ua[2], yu[2];
-          if (nodual) {
-            ua[0] = ua[1] = 0.f;
-          } else {
-            const float2 qv = *(const float2*)(tm.u + offu);
-            ua[0] = qv.x;
-            ua[1] = qv.y;
-          }
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float d = (xv[e] - xu[e]) + ua[e];            // the upper neighbour's own update, recomputed
-            const float vu = prox_eval(tm.prox, d, lam);
-            const float un = d - vu;
-            yu[e] = vu - (dual ? un : ua[e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 2; ++e) acc[e] += yu[e] - y[e + 1];
-        }
-      }
-      float2 kk = make_float2(0.f, 0.f);
-      if (ktb) kk = *(const float2*)(ktb + off);
-      rs[n] = make_float2(fmaf(r, acc[0], kk.x), fmaf(r, acc[1], kk.y));
-    }
-  }
-  // ---- phase C: right-hand-side row -> spectrum row (k_rows_r2c_il, EVEN, one sequence on one wave) ----------------------------
-  WaveSync()();
-  fft_il<-1, 1, 64, WaveSync>(rs, plan, twW, 2, lane);
-  {
-    constexpr int UB = 8;
-    float2* out = spec_out + ((size_t)pl * H + h) * Ws;
-    for (int k0 = lane; k0 < Ws; k0 += UB * 64) {
-      float2 tw[UB];
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int k = k0 + u * 64;
-        tw[u] = k < Ws ? twW[k] : make_float2(0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int k = k0 + u * 64;
-        if (k >= Ws) continue;
-        float2 X;
-        if (k == 0) {
-          const float2 z0 = rs[0];
-          X = make_float2(z0.x + z0.y, z0.x - z0.y);               // (DC, Nyquist) packed
-        } else {
-          const float2 zk = rs[k], zm = cconj(rs[M - k]);
-          const float2 e = cscale(cadd(zk, zm), 0.5f);
-          const float2 d = cscale(csub(zk, zm), 0.5f);
-          const float2 o = make_float2(d.y, -d.x);                 // -i * d
-          X = cadd(e, cmul(o, tw[u]));
-        }
-        out[k] = X;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // one-off fp64 forward transform of the data term:  spec = op(OTF) * F(b)   (packed fp32 half spectrum)
 // Accumulating F(K^T b) in the Fourier domain keeps the large, iteration-invariant part of the
 // right-hand side out of the per-iteration fp32 transforms (only the small increment
@@ -2050,94 +1836,6 @@ extern "C" int dpx_fourier_solve(const float* rhs, float* x, const void* spec_ad
   a.eps_num = eps;
   a.scale = 1.0f / ((float)H * (float)W);
   return spectral_apply(rhs, x, OP_SOLVE, a, B, C, H, W, table, ws, (hipStream_t)stream);
-}
-
-// ---- the size-generic Fourier solve in stages, for a caller that keeps the spectrum between iterations (dpx_admm_generic_rows) -------------
-// ws: the dpx_spectrum_bytes workspace = two spectrum buffers; `half` selects the one the stages work on.
-//   stages & 1: row transforms rhs -> spectrum;  & 2: the column pass (in place: forward, solve with the data spectrum, inverse);
-//   & 4: row transforms spectrum -> x.  The interleaved kernels only (dpx_admm_generic_rows_supported).
-namespace dpx {
-static bool generic_rows_plan(int H, int W, Plan1D& prow, Plan1D& pcol, int& cct, int& nwv) {
-  if (W % 2 != 0 || W < 4 || H < 3 || pow2_path_available(H, W) || tune(TUNE_GENERIC_INTERLEAVED) != 1) return false;
-  prow = make_plan(W / 2);
-  pcol = make_plan(H);
-  if (il_seqs(prow) != 8) return false;                   // (rows: one sequence per wave, lengths up to 1024 complex points)
-  cct = il_seqs(pcol);
-  if (!cct) return false;
-  const size_t row = (size_t)(W / 2) * sizeof(float2);
-  nwv = (size_t)(2 * 16 - 2) * row <= 120 * 1024 && H >= 28 ? 16 : 8;
-  return (size_t)(2 * nwv - 2) * row <= 150 * 1024;
-}
-}  // namespace dpx
-extern "C" int dpx_admm_generic_rows_supported(int H, int W) {
-  Plan1D a, b;
-  int cct = 0, nwv = 0;
-  return tune(TUNE_GENERIC_FUSED_ROWS) != 0 && H > 0 && W > 0 && dpx::generic_rows_plan(H, W, a, b, cct, nwv) ? 1 : 0;
-}
-extern "C" int dpx_fourier_solve_stages(const float* rhs, float* x, const void* spec_add, const void* dd, const float* rho, float eps, int B, int C,
-                                        int H, int W, const void* table, void* ws, int stages, int half, dpx_stream_t stream) {
-  DPX_REQUIRE(table && ws && B > 0 && C > 0 && H > 0 && W > 0 && (half == 0 || half == 1) && stages > 0 && stages < 8, "dpx_fourier_solve_stages: bad arguments");
-  DPX_REQUIRE((!(stages & 1) || rhs) && (!(stages & 4) || x) && (!(stages & 2) || (rho && dd)), "dpx_fourier_solve_stages: null pointer");
-  Plan1D prow, pcol;
-  int cct = 0, nwv = 0;
-  if (!dpx::generic_rows_plan(H, W, prow, pcol, cct, nwv)) {
-    set_error("dpx_fourier_solve_stages: %d x %d planes are not on the interleaved size-generic kernels", H, W);
-    return DPX_ERR_UNSUPPORTED;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  const int P = B * C;
-  float2* spec = (float2*)ws + (size_t)half * P * H * spec_cols(W);
-  if (stages & 1) launch_rows_il(true, true, 1, rhs, spec, nullptr, W, P * H, prow, tw_rows(table), s);
-  if (stages & 2) {
-    SpecArgs a{};
-    a.add = (const float2*)spec_add;
-    a.dd = (const float2*)dd;
-    a.rho = rho;
-    a.eps = eps;
-    a.eps_num = eps;
-    a.scale = 1.0f / ((float)H * (float)W);
-    launch_cols_il(OP_SOLVE, cct, spec, a, P, C, H, W, pcol, tw_cols(table, W), s);
-  }
-  if (stages & 4) launch_rows_il(false, true, 1, nullptr, spec, x, W, P * H, prow, tw_rows(table), s);
-  return launch_status("dpx_fourier_solve_stages");
-}
-// The fused row pass (k_iter_rows_il): spectrum buffer `half_in` of ws -> the other one; terms / rho_next / dual / emit_v as dpx_admm_zupdate_rhs,
-// x_out (nullable) receives x of this iteration.
-extern "C" int dpx_admm_generic_rows(void* ws, int half_in, const dpx_term* terms, int nterms, const float* rho_next, int dual, int emit_v, float* x_out,
-                                     int B, int C, int H, int W, const void* table, dpx_stream_t stream) {
-  DPX_REQUIRE(ws && terms && rho_next && table && nterms >= 1 && nterms <= DPX_MAX_TERMS && B > 0 && C > 0 && (half_in == 0 || half_in == 1),
-              "dpx_admm_generic_rows: bad arguments");
-  Plan1D prow, pcol;
-  int cct = 0, nwv = 0;
-  if (!dpx::generic_rows_plan(H, W, prow, pcol, cct, nwv)) {
-    set_error("dpx_admm_generic_rows: %d x %d planes are not on the interleaved size-generic kernels", H, W);
-    return DPX_ERR_UNSUPPORTED;
-  }
-  TermPack T;
-  T.n = nterms;
-  for (int i = 0; i < nterms; ++i) {
-    T.t[i] = terms[i];
-    DPX_REQUIRE(terms[i].v && (terms[i].u || (terms[i].reserved & DPX_TERM_NO_DUAL)) && (!dual || (terms[i].u_out && terms[i].u_out != terms[i].u)),
-                "dpx_admm_generic_rows: term %d: the duals must be double-buffered", i);
-    DPX_REQUIRE(terms[i].prox != DPX_PROX_EXTERNAL, "dpx_admm_generic_rows: term %d: closed-form proxes only", i);
-  }
-  const int P = B * C;
-  const size_t one = (size_t)P * H * spec_cols(W);
-  const float2* sin = (const float2*)ws + (size_t)half_in * one;
-  float2* sout = (float2*)ws + (size_t)(1 - half_in) * one;
-  const size_t sh = (size_t)(2 * nwv - 2) * (W / 2) * sizeof(float2);
-  const int bands = (H + nwv - 3) / (nwv - 2);
-  hipStream_t s = (hipStream_t)stream;
-  if (nwv == 16) {
-    il_lds_attr(k_iter_rows_il<16>, sh);
-    DPX_LAUNCH("k_iter_rows_il", k_iter_rows_il<16>, dim3(P * bands), dim3(1024), sh, s, sin, sout, x_out, (const float*)nullptr, rho_next, T, dual, emit_v, C, H, W,
-               bands, prow, tw_rows(table));
-  } else {
-    il_lds_attr(k_iter_rows_il<8>, sh);
-    DPX_LAUNCH("k_iter_rows_il", k_iter_rows_il<8>, dim3(P * bands), dim3(512), sh, s, sin, sout, x_out, (const float*)nullptr, rho_next, T, dual, emit_v, C, H, W,
-               bands, prow, tw_rows(table));
-  }
-  return launch_status("dpx_admm_generic_rows");
 }
 
 extern "C" int dpx_fourier_apply_inv(const float* g, float* out, const void* dd, const float* rho, float eps, int B, int C, int H, int W,

@@ -34,8 +34,9 @@ namespace dpx {
 // M = W/2 complex points per row, T threads per row, SPB = 256/T rows in flight per workgroup, NT terms.
 // Global loads are issued one phase ahead of their use (u rows at the top of phase A, the next spectrum row at
 // the top of phase C) so that the transforms cover the HBM latency; 2 workgroups (8 waves) share a CU.
+// (1024-wide rows with three or four terms: one wave per SIMD -- 512 registers -- instead of 14 / 28 spilled ones; tools/spill_check.py)
 template <int M, int T, int NT>
-__global__ void __launch_bounds__(256, 2) k_iter_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
+__global__ void __launch_bounds__(256, (M == 512 && NT >= 3) ? 1 : 2) k_iter_rows(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
                                                     const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
                                                     int C, int H, int R, int P, const float2* __restrict__ twW) {
   constexpr int V = M / T, SPB = 256 / T, S = LdsSeq<M>::SLOTS, RING = SPB + 1;
@@ -303,8 +304,10 @@ static void launch_iter_rows(const float2* sin, float2* sout, const IterTerms& T
 // every wait count below is the general one with the dual streams' operations taken out (NU = 0 terms with a dual).
 // VXU = true (DUAL only): the update order v, x, u (see IterTerms::vxu) -- two more additions per element and term, its own instantiation
 // so that the headline kernel's instruction stream stays as it is.
+// (four terms -- their staging areas leave room for one workgroup per CU anyway -- and the 512-wide v, x, u form with three: one wave per SIMD,
+//  i.e. up to 512 registers, instead of 2 - 22 spilled ones; tools/spill_check.py)
 template <int M, int T, int NT, bool DUAL, bool VXU = false>
-__global__ void __launch_bounds__(256, 2) k_iter_rows_seq(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
+__global__ void __launch_bounds__(256, (NT >= 4 || (NT == 3 && VXU && M == 256)) ? 1 : 2) k_iter_rows_seq(const float2* __restrict__ spec_in, float2* __restrict__ spec_out, IterTerms TT,
                                                         const float* __restrict__ rho_next, float* __restrict__ x_out, int emit_v,
                                                         int C, int H, int bands, int P, const float2* __restrict__ twW) {
   constexpr int V = M / T, G = 64 / T, S = LdsSeq<M>::SLOTS, D = V / 2, RM = M / (V * V);

@@ -355,7 +355,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_iter_rows_par(const float2* __re
 template <int M, int T, int NT, bool DUAL, bool VXU>
 static void launch_par_d(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v, int C, int H, int P,
                          const float2* twW, hipStream_t s) {
-  constexpr int NW = 16, G = 64 / T, S = M + M / 16, V = M / T, RW = NW * G;
+  // 16 waves (128 registers each) for the one- and two-term forms; three or four terms and the v, x, u order keep more rows of duals / split
+  // variables in registers: 8 waves of 256 registers (no scratch in any instantiation: tools/spill_check.py)
+  constexpr int NW = (NT >= 3 || VXU) ? 8 : 16, G = 64 / T, S = M + M / 16, V = M / T, RW = NW * G;
   const size_t sh = (size_t)(M + 64 + NW * (G * S + 64 * V + 32)) * sizeof(float2);
   static bool attr = false;
   if (!attr) {

@@ -85,11 +85,6 @@ SIGNATURES = {
     "dpx_denominator_pack": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dpx_fourier_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "dpx_admm_generic_rows_supported": (c_int, [c_int, c_int]),
-    "dpx_fourier_solve_stages": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                         c_int, c_int, c_void_p]),
-    "dpx_admm_generic_rows": (c_int, [c_void_p, c_int, POINTER(Term), c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                      c_void_p]),
     "dpx_cfft2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_lincomb": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_float), POINTER(c_void_p), c_int, c_long, c_void_p]),

@@ -616,27 +616,6 @@ def admm_zupdate_rhs(x, term_arr, nterms, rhs, rho_next, dual=True, emit_v=True,
     be.lib().call("dpx_admm_zupdate_rhs", ptr(x), term_arr, nterms, ptr(rhs), ptr(ktb), ptr(rho_next), int(bool(dual)), int(bool(emit_v)), B, C, H, W, be.stream())
 
 
-def generic_rows_supported(H, W):
-    """planes off the power-of-two path whose iteration runs as columns + ONE fused row pass (dpx_admm_generic_rows)"""
-    return bool(be.lib().query("dpx_admm_generic_rows_supported", int(H), int(W)))
-
-
-def fourier_solve_stages(rhs, x, spec_add, dd, rho, eps, shape, ws, stages, half, device):
-    """dpx_fourier_solve_stages on the private two-buffer spectrum workspace `ws` (stages: 1 rows in, 2 columns, 4 rows out)"""
-    B, C, H, W = shape
-    be.lib().call("dpx_fourier_solve_stages", ptr(rhs), ptr(x), ptr(spec_add), ptr(dd), ptr(rho), c_float(eps), B, C, H, W,
-                  ptr(fft_table(H, W, device)), ptr(ws), int(stages), int(half), be.stream())
-
-
-def admm_generic_rows(ws, half_in, term_arr, nterms, rho_next, dual, emit_v, x_out, shape, device):
-    B, C, H, W = shape
-    be.lib().call("dpx_admm_generic_rows", ptr(ws), int(half_in), term_arr, nterms, ptr(rho_next), int(bool(dual)), int(bool(emit_v)), ptr(x_out),
-                  B, C, H, W, ptr(fft_table(H, W, device)), be.stream())
-
-
-# ----------------------------------------------------------------------------------------------
-# two-kernel fused iteration (power-of-two planes)
-# ----------------------------------------------------------------------------------------------
 def iter_supported(H, W, term_arr, nterms):
     return bool(be.lib().query("dpx_admm_iter_supported", H, W, term_arr, nterms))
 

@@ -668,37 +668,16 @@ class FusedADMM:
             u_alt = [torch.empty_like(t) for t in u]
             for i in range(n):
                 terms[i].u_out = u_alt[i].data_ptr()
-        # planes off the power-of-two path (even W): the spectrum stays between the iterations -- column pass + ONE fused row pass per
-        # iteration (dpx_admm_generic_rows: inverse row transforms, z / dual stage, next right-hand side, forward row transforms) instead of
-        # four launches with x and the right-hand side going through memory; x (and v) leave the chip when a callback looks
-        gen = merged and (x.is_cuda or be.host_mode()) and ops.generic_rows_supported(H, W)
-        s.last_generic_rows = gen                                   # (tests / tools: the last solve's loop form)
-        if gen:
-            gws = ops._bytes(be.lib().query("dpx_spectrum_bytes", B * C, H, W), dev)     # (private: two spectrum buffers that live across the iterations)
-            gdd = ops.denominator(t0, c0, t1, c1, C, H, W, dev)
-            half, shape4 = 0, (B, C, H, W)
         for it in tqdm(range(T), disable=not pbar):
             for i in range(n):
                 terms[i].lam = lam_tab[i][it].data_ptr()
-            if gen:
-                if it == 0:
-                    ops.admm_rhs(rhs, None, rho_tab[0], terms, n)
-                    ops.fourier_solve_stages(rhs, None, None, None, None, ls_eps(ls), shape4, gws, 1, half, dev)
-                if it + 1 < T:
-                    ops.fourier_solve_stages(None, None, FK, gdd, rho_tab[it], ls_eps(ls), shape4, gws, 2, half, dev)
-                    ops.admm_generic_rows(gws, half, terms, n, rho_tab[it + 1], dual, callback is not None, x if callback is not None else None, shape4, dev)
-                    half ^= 1
-                else:
-                    ops.fourier_solve_stages(None, x, FK, gdd, rho_tab[it], ls_eps(ls), shape4, gws, 2 | 4, half, dev)
-                    ops.admm_zupdate(x, terms, n)
+            if not merged or it == 0:
+                ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
+            ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x, spec_add=FK)
+            if merged and it + 1 < T:
+                ops.admm_zupdate_rhs(x, terms, n, rhs, rho_tab[it + 1], dual=dual, emit_v=callback is not None)   # (v: only a callback looks at it before the last stage)
             else:
-                if not merged or it == 0:
-                    ops.admm_rhs(rhs, None, rho_tab[it], terms, n)
-                ops.fourier_solve(rhs, t0, t1, c0, c1, rho_tab[it], ls_eps(ls), out=x, spec_add=FK)
-                if merged and it + 1 < T:
-                    ops.admm_zupdate_rhs(x, terms, n, rhs, rho_tab[it + 1], dual=dual, emit_v=callback is not None)   # (v: only a callback looks at it before the last stage)
-                else:
-                    ops.admm_zupdate(x, terms, n)
+                ops.admm_zupdate(x, terms, n)
             if merged and dual:
                 for i in range(n):                                   # the duals just written become the next iteration's input
                     u[i], u_alt[i] = u_alt[i], u[i]

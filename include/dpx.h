@@ -97,11 +97,6 @@ int dpx_timing_report(char* buf, size_t cap);
  *   il_tw_lds            size-generic column / row transforms (planes off the power-of-two path): 1 = a pass     DPX_IL_TW_LDS
  *                        gathers its twiddles from a copy of the table in shared memory (default, where the
  *                        copy does not cost a workgroup per CU), 0 = from the global table (same values)
- *   generic_fused_rows   1 = planes off the power-of-two path (even W) run columns + ONE fused row pass             DPX_GENERIC_FUSED_ROWS
- *                        (dpx_admm_generic_rows) instead of the four-launch iteration.  OFF by default: bit-identical
- *                        but measured slower (8 x 3 x 1000 x 1000: 341 us against the 244 us of the three launches it
- *                        replaces -- a wave walks inverse transform, stencil stage and forward transform of its row one
- *                        after the other, 16 waves per CU with nothing to overlap them)
  *   unroll_bwd_staged    dpx_admm_unrolled_backward: 0 = the two-kernel backward iteration on          DPX_UNROLL_BWD_STAGED
  *                        power-of-two planes (k_bwd_rows), else the image-domain fused stage; 2 = the
  *                        image-domain fused stage everywhere; 1 = the rhs stage and the z stage of
@@ -405,22 +400,6 @@ int dpx_admm_zupdate(const float* x, const dpx_term* terms, int nterms,
  * (algo/admm.py:49-59 -- the z / dual update -- followed by proxfn/sum_square.py:126-135 -- the next x-update's offset).           */
 int dpx_admm_zupdate_rhs(const float* x, const dpx_term* terms, int nterms, float* rhs, const float* ktb, const float* rho_next,
                          int dual, int emit_v, int B, int C, int H, int W, dpx_stream_t stream);
-
-/* The same solve in stages, for a loop that keeps the spectrum between iterations on planes off the power-of-two path (even W, the
- * interleaved size-generic kernels: dpx_admm_generic_rows_supported).  ws: a dpx_spectrum_bytes workspace = two spectrum buffers, `half`
- * (0 / 1) the one worked on.  stages & 1: row transforms rhs -> spectrum; & 2: the column pass in place (forward, the solve with the data
- * spectrum, inverse); & 4: row transforms spectrum -> x.  1 | 2 | 4 on one buffer = dpx_fourier_solve.
- * dpx_admm_generic_rows: the row pass of an ADMM iteration as ONE launch -- inverse row transforms of spectrum buffer half_in, the z / dual
- * stage of this iteration and the right-hand side of the next one (dpx_admm_zupdate_rhs's arithmetic and arguments; ktb = NULL: the data
- * term lives in the Fourier domain), forward row transforms into the OTHER buffer; x_out (nullable) receives this iteration's x.  A loop:
- *   stages 1 on buffer 0;  repeat { stage 2 on h; dpx_admm_generic_rows(h -> 1 - h); h = 1 - h };  stage 2 | 4 on h; dpx_admm_zupdate.
- * Bit-identical to dpx_fourier_solve + dpx_admm_zupdate_rhs per iteration (reference: algo/admm.py:49-59).  A/B form behind knob
- * generic_fused_rows (off by default: measured slower than the launches it replaces, see the knob's entry).                               */
-int dpx_admm_generic_rows_supported(int H, int W);
-int dpx_fourier_solve_stages(const float* rhs, float* x, const void* spec_add, const void* dd, const float* rho, float eps, int B, int C, int H,
-                             int W, const void* table, void* ws, int stages, int half, dpx_stream_t stream);
-int dpx_admm_generic_rows(void* ws, int half_in, const dpx_term* terms, int nterms, const float* rho_next, int dual, int emit_v, float* x_out,
-                          int B, int C, int H, int W, const void* table, dpx_stream_t stream);
 
 /* ---- fused backward stages of the iteration (config 5, unrolled training; the reference uses PyTorch autograd through
  * the eager ops of algo/admm.py:49-59).  Per-image scalar gradients are reduced deterministically; `ws` has

@@ -1130,41 +1130,6 @@ def case_ladmm_cg(device):
     assert_close(outs["one call, folded tail"][0][0].cpu(), g["x"], TOL, "ladmm x, one call per iteration")
 
 
-def case_generic_fused_rows(device, shapes=((2, 3, 30, 36), (1, 2, 18, 20), (1, 1, 45, 50)), iters=4):
-    """Planes off the power-of-two path (even W): the iteration as column pass + ONE fused row pass (dpx_admm_generic_rows / k_iter_rows_il:
-    inverse row transforms, z / dual stage, next right-hand side, forward row transforms of a band with its halo rows) against the four-launch
-    iteration it replaces (knob generic_fused_rows = 0, the default -- the fused pass is correct but was measured slower; the four launches
-    against the reference: G37 and the generic-size fixtures) -- x, every v_i and u_i, with and without a callback (x and v leave the chip only
-    when one looks), ADMM and half-quadratic splitting: bit for bit."""
-    import synthetic
-    from dprox import _backend as be
-    for (B, C, H, W) in shapes:
-        gt, b, psf = synthetic.deconv_case(B, C, H, W, seed=3)
-        bt = T(b, device)
-        for method in ("admm", "hqs"):
-            res = {}
-            for fused in (1, 0):
-                x = dp.Variable()
-                fns = dp.sum_squares(dp.conv(x, psf) - bt) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)) + dp.nonneg(x)
-                solver = dp.compile(fns, method=method, device=device)
-                seen = []
-                with be.tuned(generic_fused_rows=fused):
-                    st = solver.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=iters, return_full_states=True)
-                    st_cb = solver.solve(x0=bt, rhos=0.1, lams=0.005, max_iter=iters, return_full_states=True,
-                                         callback=lambda iter, state, **kw: seen.append([state[0].clone()] + [t.clone() for t in state[1]]))
-                used = getattr(solver, "last_generic_rows", None)
-                res[fused] = (st, st_cb, seen, used, solver.last_path)
-            assert res[1][4] == "fused" and res[0][4] == "fused", (method, res[1][4], res[0][4])
-            assert res[1][3] is True and res[0][3] is False, (method, (B, C, H, W), res[1][3], res[0][3])
-            flat = lambda st: [st[0]] + [t for part in st[1:] for t in part]
-            for k in (0, 1):
-                for p, q in zip(flat(res[1][k]), flat(res[0][k])):
-                    assert torch.equal(p, q), (method, (B, C, H, W), "callback" if k else "no callback")
-            assert len(res[1][2]) == iters
-            for sa, sb in zip(res[1][2], res[0][2]):
-                assert all(torch.equal(p, q) for p, q in zip(sa, sb)), (method, (B, C, H, W), "iterates seen by the callback")
-
-
 def case_split_cg_loop_forms(device, B=2, H=48, W=48, iters=4, compute_mode=None):
     """The four forms of the plug-and-play loop with a CG x-update (FusedSplitCG.run: one C call per iteration with folded head / tail passes
     and the head issued ahead of the host's look at the CG's stop flag; the same without issuing it early; one C call, nothing folded; the

@@ -157,10 +157,6 @@ def test_other_algorithms():
     pc.case_other_algorithms(DEV)
 
 
-def test_generic_planes_fused_row_pass_is_bit_identical_to_the_four_launch_iteration():
-    pc.case_generic_fused_rows(DEV)
-
-
 def test_plug_and_play_cg_loop_forms_are_bit_identical():
     pc.case_split_cg_loop_forms(DEV, B=1, H=32, W=32, iters=3)          # (the emulator's share; the GPU suite runs 2 x 48 x 48 and config 4's shard)
 

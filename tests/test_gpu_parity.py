@@ -198,11 +198,6 @@ def test_ladmm_cg():
     pc.case_ladmm_cg(DEV)
 
 
-def test_generic_planes_fused_row_pass_is_bit_identical_to_the_four_launch_iteration():
-    pc.case_generic_fused_rows(DEV)
-    pc.case_generic_fused_rows(DEV, shapes=((2, 3, 1000, 1000), (1, 3, 720, 1280), (1, 1, 1080, 1920), (2, 1, 500, 640)), iters=3)
-
-
 def test_plug_and_play_cg_loop_forms_are_bit_identical():
     pc.case_split_cg_loop_forms(DEV)
     pc.case_split_cg_loop_forms(DEV, B=4, H=320, W=320, iters=6)          # (config 4's shard: the one-wave transforms of the fused CG)
