@@ -209,6 +209,15 @@ __global__ void k_bx_unpack_out(const float* __restrict__ o, float* __restrict__
 // two tiles alternating: no landing buffer, no split pass, one workgroup barrier less per 16-channel chunk.
 // TH: rows of the workgroup's tile (16: eight waves, one workgroup per CU; 8: four waves and half the LDS -- two workgroups per CU --
 // for launches whose 16-row tiles would leave CUs idle: 4 x 1 x 320 x 320 is 200 tiles of 16 rows on 256 CUs)
+#ifdef DPX_WN_TRACE
+__device__ unsigned long long dpx_bx_trace_buf[8 * 64];
+#define DPX_BX_STAMP(i)                                                                                                                         \
+  do {                                                                                                                                         \
+    if (MT == 3 && MODE == 3 && Gin > 2 && (tid & 63) == 0 && blockIdx.x == 300 && blockIdx.y == 0 && (i) < 64) dpx_bx_trace_buf[(tid >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define DPX_BX_STAMP(i) ((void)0)
+#endif
 template <int MT, bool RELU, int MODE, bool PRE = false, bool PSO = false, int TH = BX_TH>
 // mask (nullable; C8, Gout groups): the stored value is zeroed where mask <= 0 -- the ReLU derivative of the backward-data pass
 // ([a_l > 0] from the saved forward activation), applied in the producing layer's epilogue.
@@ -227,6 +236,7 @@ __global__ void __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) k_conv3x3_bf16(cons
   char* tile = PRE ? smem_bx : smem_bx + LAND_BYTES;               // PRE: two tiles of two planes, [c & 1], LAND_BYTES apart (the
   char* ring = PRE ? smem_bx + 2 * LAND_BYTES : tile + TILE_BYTES;      // last DMA instruction of a tile is a whole KB: 768 bytes of slack)
   const int tid = threadIdx.x, lane = tid & 63;
+  DPX_BX_STAMP(0);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -299,10 +309,13 @@ __global__ void __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) k_conv3x3_bf16(cons
   }
   for (int c = 0; c < chunks; ++c) {
     // ---- the chunk's activations: landed -> split into bf16 planes ------------------------------------------------------
+    DPX_BX_STAMP(1 + c * 8);
     if (!(DPX_BX_DBG & 4)) {
     if (!(DPX_BX_DBG & 16)) dpx_wait_vm<0>();
+    DPX_BX_STAMP(2 + c * 8);
     DPX_LDS_BARRIER();                                                // landing buffer complete; everybody is done with the old tile
     }
+    DPX_BX_STAMP(3 + c * 8);
     if constexpr (PRE) {
       tile = smem_bx + (c & 1) * LAND_BYTES;                       // landed as the operand planes themselves; the other tile is free:
       if (c + 1 < chunks) issue_act(c + 1);                           // every wave has left chunk c - 1 (barrier above)
@@ -337,10 +350,12 @@ __global__ void __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) k_conv3x3_bf16(cons
       if constexpr (MODE == 6)
         *(uint4*)(tile + 2 * PLANE_BYTES + u * 16) = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
     }
+    DPX_BX_STAMP(4 + c * 8);
     if (!PRE && !(DPX_BX_DBG & 4)) {
     DPX_LDS_BARRIER();                                                // tile ready, landing buffer free
     if (c + 1 < chunks) issue_act(c + 1);
     }
+    DPX_BX_STAMP(5 + c * 8);
     // ---- three slots of three taps ----------------------------------------------------------------------------------------
     for (int tg = 0; tg < 3; ++tg) {
       const int s = c * 3 + tg;
@@ -349,6 +364,7 @@ __global__ void __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) k_conv3x3_bf16(cons
         DPX_LDS_BARRIER();                                            // slot s landed; slot s - 1 no longer read by anybody
       }
       if (s + 1 < nslots && !(DPX_BX_DBG & 4)) issue_w(s + 1);
+      DPX_BX_STAMP(6 + tg + c * 8);
       const char* wslot = ring + (s & 1) * SLOTB;
 #pragma unroll
       for (int t3 = 0; t3 < 3; ++t3) {
@@ -397,6 +413,7 @@ __global__ void __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) k_conv3x3_bf16(cons
       }
     }
   }
+  DPX_BX_STAMP(49);
   if (MODE == 3 && !PSO && !(f16_max <= 6.0e4f)) atomicOr(&g_f16_overflow, 1u);        // (NaN counts; PSO: behind the epilogue, which splits the outputs)
   // ---- epilogue: bias, ReLU, C8 store.  D layout: col = lane & 31 (pixel), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) (cout) ----
   const int xx = x0 + n;
@@ -445,6 +462,11 @@ __global__ void __launch_bounds__(TH * 32, TH == 16 ? 1 : 2) k_conv3x3_bf16(cons
       }
     }
   if (PSO && !(f16_max <= 6.0e4f)) atomicOr(&g_f16_overflow, 1u);
+  DPX_BX_STAMP(50);
+#ifdef DPX_WN_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DPX_BX_STAMP(51);
+#endif
 }
 
 // split-f16 inference layers with pre-split operand planes in HBM (pre: input P8, pso: output P8)
@@ -581,6 +603,11 @@ static int groups16(int c) { return 2 * ((c + 15) / 16); }           // channel 
 }  // namespace dpx
 
 #include "dpx_conv_wino_dev.h"
+#ifdef DPX_WN_TRACE
+extern "C" int dpx_dbg_bx_trace(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(dpx::dpx_bx_trace_buf), sizeof(unsigned long long) * (n < 512 ? n : 512)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 namespace dpx {
 // mode 4 ("split-f16 Winograd"): the first layer (13 -> nc channels: one 16-channel chunk) and layers of more than 64 output channels (their
