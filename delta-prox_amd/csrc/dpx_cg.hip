@@ -13,6 +13,7 @@
 // the state's `done` flag is set and every later control kernel of the solve returns immediately (the iterate is frozen at
 // exactly the reference's exit point; `n_done` = the iteration index the reference prints in "Converged at CG Iter").
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 
 #include "dpx_cg_dev.h"
@@ -199,20 +200,35 @@ extern "C" size_t dpx_cg_masked_fft_ws_bytes(int B, int H, int W, int mask_image
 }
 
 // Spin until the device has stored `tag` at *slot (host-coherent memory, written by the finishing workgroup of a launch already in the
-// stream, together with the word next to it: one 8-byte store).  Looks at the stream now and then: once it has drained every store of its
-// kernels is visible whatever the platform does with device stores to pinned memory in mid-kernel, so the answer is final -- the tag, or false (also for a
-// failed stream, and after a minute without either).
+// stream, together with the word next to it: one 8-byte store).  Once a millisecond (by the clock, not by a spin count) it looks at the stream:
+// a drained stream makes every store of its kernels visible whatever the platform does with device stores to pinned memory in mid-kernel, so
+// the answer is then final -- the tag, or false (also for a failed stream).  The one-minute limit guards against a store that never comes
+// although the stream drains normally -- it only runs while the stream reports work in flight AFTER the tag's own launch could have run, i.e.
+// it is restarted whenever the stream makes progress the host can see: a stream with minutes of earlier work in front of the solve is waited for.
 static bool wait_for_tag(volatile int* slot, int tag, hipStream_t s) {
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned long spins = 1;; ++spins) {
+  using clock = std::chrono::steady_clock;
+  auto t_query = clock::now(), t_limit = t_query;
+  for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n((const int*)slot, __ATOMIC_ACQUIRE) == tag) return true;
-    if ((spins & 0xfffffu) == 0) {                       // about every few milliseconds
-      const hipError_t q = hipStreamQuery(s);
-      if (q != hipErrorNotReady) return q == hipSuccess && __atomic_load_n((const int*)slot, __ATOMIC_ACQUIRE) == tag;
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return false;
+    if ((spins & 0x3ffu) == 0) {                         // (the clock itself is read every 1024 spins: tens of microseconds)
+      const auto now = clock::now();
+      if (now - t_query >= std::chrono::milliseconds(1)) {
+        t_query = now;
+        const hipError_t q = hipStreamQuery(s);
+        if (q != hipErrorNotReady) return q == hipSuccess && __atomic_load_n((const int*)slot, __ATOMIC_ACQUIRE) == tag;
+        if (now - t_limit > std::chrono::seconds(60)) {
+          // a minute of "not ready": fall back to the blocking wait instead of failing a solve that merely queued behind a long job
+          if (hipStreamSynchronize(s) != hipSuccess) return false;
+          return __atomic_load_n((const int*)slot, __ATOMIC_ACQUIRE) == tag;
+        }
+      }
     }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
 #endif
   }
 }
@@ -329,7 +345,8 @@ int dpx::cg_masked_fft_run(float* x, const float* b, const float* mask, int mask
     if (rc_ != DPX_OK) return rc_;   \
   } while (0)
   const int n_it = max_iters < (int)((long)B * n) ? max_iters : (int)((long)B * n);
-  const int LAG = 2;
+  constexpr int LAG = 2;
+  static_assert(LAG < 4, "the four-slot ring of stop-test results and the 1024-iteration tag wrap are safe only while fewer than 4 tests are in flight");
   int done_it = n_it;
   bool done = false;
   int last = -1;

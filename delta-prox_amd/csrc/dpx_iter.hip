@@ -1115,7 +1115,10 @@ int dpx::iter_seq_bands(int P, int H, int W, int forced) {
   if ((P * nb) % per_block) {
     int a = P, b = per_block;
     while (b) { const int r = a % b; a = b; b = r; }
-    nb = per_block / a;
+    const int last_resort = per_block / a;
+    // (bands shorter than the rule's minimum -- one or two rows at H = 32 -- are not what the streaming kernel's tests walk: planes other than
+    //  768-wide ones then stay on the lock-step kernel, which the caller falls back to when the count returned here fills no whole workgroups)
+    if (W == 768 || H / last_resort >= min_rows) nb = last_resort;
   }
   return nb;
 }

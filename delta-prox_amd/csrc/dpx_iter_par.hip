@@ -359,10 +359,12 @@ static void launch_par_d(const float2* sin, float2* sout, const IterTerms& TT, c
   // variables in registers: 8 waves of 256 registers (no scratch in any instantiation: tools/spill_check.py)
   constexpr int NW = (NT >= 3 || VXU) ? 8 : 16, G = 64 / T, S = M + M / 16, V = M / T, RW = NW * G;
   const size_t sh = (size_t)(M + 64 + NW * (G * S + 64 * V + 32)) * sizeof(float2);
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr = 0;                   // one bit per device: the 140 KB opt-in is a per-device function attribute
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr >> (dev & 63) & 1ull)) {
     hipFuncSetAttribute((const void*)k_iter_rows_par<M, T, NT, DUAL, VXU, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    attr = true;
+    attr |= 1ull << (dev & 63);
   }
   const bool xonly = !DUAL && emit_v == 2;
   const int rows = xonly ? RW : RW - 2;                 // own rows per workgroup

@@ -101,8 +101,8 @@ def plan_fingerprint(solver):
     for fn in list(solver.psi_fns) + list(solver.omega_fns):
         op = fn.linop
         beta = fn.beta
-        if isinstance(beta, torch.Tensor):                  # (a tensor-valued weight: compared by value, never by `==` on tensors)
-            beta = tuple(float(t) for t in beta.detach().reshape(-1).cpu())
+        if isinstance(beta, torch.Tensor):                  # (a tensor-valued weight: by identity and version -- no device read-back on the
+            beta = ("tensor", id(beta), beta._version)      #  plan-cache lookup of every solve; never `==` on tensors)
         den = getattr(fn, "denoiser", None)
         terms.append((id(fn), type(fn), beta, getattr(fn, "unroll", None), getattr(fn, "clamp", None), type(den), id(den),
                       getattr(fn, "x8", None), getattr(fn, "sqrt", None), id(op), type(op), getattr(op, "dim", None),
@@ -314,7 +314,9 @@ class FusedSplitCG:
             e = ext[0]
             x = torch.empty_like(x0)
             v_new = torch.empty_like(x0)
-            step = ops.CgPnpIter(x, rhs, ktb, terms, n, e, sysm[0], sysm[1], cfg.rtol, cfg.max_iters, psi[e].denoiser.model)
+            net = psi[e].denoiser.model
+            net_key = lambda: (net._weights_version(), net.compute_mode)
+            step, step_key = ops.CgPnpIter(x, rhs, ktb, terms, n, e, sysm[0], sysm[1], cfg.rtol, cfg.max_iters, net), net_key()
             hist, run_hist = list(getattr(s, "_cg_exit_hist", ())), []
             s._cg_exit_hist = run_hist
             xs = (x, torch.empty_like(x0)) if step.folds else (x, x)  # (folded tail: iteration t + 1's iterate is zeroed while x_t is still the result)
@@ -335,6 +337,8 @@ class FusedSplitCG:
                 if callback is not None:
                     s._notify_all_op_current_step(it)
                     callback(iter=it, state=(x, v, u), rho=rhos[..., it], lam={k: val[..., it] for k, val in lams.items()})
+                    if net_key() != step_key:                        # the callback touched the denoiser (weights / arithmetic mode): resolve the
+                        step, step_key = ops.CgPnpIter(xs[0], rhs, ktb, terms, n, e, sysm[0], sysm[1], cfg.rtol, cfg.max_iters, net), net_key()   # packed weights again
             s.Kall.update_vars([x])
             return x, v, u
         for it in tqdm(range(T), disable=not pbar):

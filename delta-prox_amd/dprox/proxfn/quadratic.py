@@ -54,9 +54,10 @@ class sum_squares(ProxFn):
         self._b = b
 
     def set_b(self, b):
-        """Replace the observation explicitly (array or tensor): every dependent cache (offset, K^T b, data spectrum) follows, and a
-        NumPy array handed over this way is fingerprinted here, once.  An in-place edit of a NumPy observation made INSIDE a solve (e.g.
-        by a callback) is only seen at the next solve -- the bytes are looked at once per outermost solve; call this to force it."""
+        """Replace the observation explicitly (array or tensor): every dependent cache (offset, K^T b, data spectrum) follows -- the call itself
+        invalidates them (a counter in the cache key), whatever `id(b)` and version counters say.  A NumPy array's bytes are fingerprinted lazily, at
+        its next use.  An in-place edit of a NumPy observation made INSIDE a solve (e.g. by a callback) is only seen at the next solve -- the bytes
+        are looked at once per outermost solve; call this to force it."""
         self._b_np, self._b_fp, self._b_fp_epoch = None, None, None
         if isinstance(b, np.ndarray):
             self._b_np = b
@@ -75,7 +76,7 @@ class sum_squares(ProxFn):
         return self._b_fp
 
     def _offset_key(self):
-        k = super()._offset_key()
+        k = super()._offset_key() + (getattr(self, "_set_b_count", 0),)
         if self._b is None:
             return k
         # a tensor's in-place edits bump its version counter; anything else (a numpy array) cannot be watched: a key that never

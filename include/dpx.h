@@ -572,6 +572,11 @@ int dpx_ffdnet_forward(const float* x, float* y, const float* sigma, const void*
  * mode); mode = 3: split-f16 -- x = hi + lo / 2^11 with two binary16 terms, three products on v_mfma_f32_32x32x16_f16 (half the
  * matrix work of mode 6, 1e-7 from float64 on the FFDNet stack), valid while every operand stays inside the binary16 range:
  * dpx_ffdnet_f16_overflow(reset) returns 1 if a mode-3 layer has met |x| > 6e4 since the last reset (synchronises the device).
+ * mode = 4: mode 3 with every layer behind the first one that has at most 64 output channels as Winograd F(2x2, 3x3) on the same split-f16
+ * arithmetic (k_conv3x3_wino: 16 instead of 36 products per 2 x 2 outputs; transformed weights computed in float64 at pack time, the
+ * transforms are fp32 additions; the range trap watches the transformed inputs, |x| < 1.5e4 is always safe).  As accurate as mode 3 on
+ * the FFDNet stacks (2e-7 from the f32-input path) and measured SLOWER than it on gfx950: opt-in.  The packed blob
+ * of a mode is only valid for that mode; dpx_ffdnet_bf16_packed_bytes covers every mode.
  * Activations travel between the layers as fp32 in the channel-group layout [B][C/8][H][W][8].  nc: multiple of 16.           */
 int dpx_ffdnet_f16_overflow(int reset);
 size_t dpx_ffdnet_bf16_packed_bytes(int in_nc, int nc, int nb);

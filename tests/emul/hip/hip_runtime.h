@@ -296,6 +296,7 @@ static inline hipError_t hipHostMalloc(void** p, size_t n, int) { *p = malloc(n)
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }

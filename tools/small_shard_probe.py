@@ -20,7 +20,11 @@ if not settings:
 gt, b, psf = synthetic.deconv_case(B, C, H, W, seed=1)
 bt = torch.from_numpy(b).cuda()
 x = dp.Variable()
-s = dp.compile(dp.sum_squares(dp.conv(x, psf) - bt) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1)), method="admm", device="cuda")
+fns = dp.sum_squares(dp.conv(x, psf) - bt) + dp.norm1(dp.grad(x, dim=0)) + dp.norm1(dp.grad(x, dim=1))
+if "nonneg" in sys.argv:                                  # TV + nonneg: three terms (the 8-wave forms of the row-parallel kernel)
+    fns = fns + dp.nonneg(x)
+    print("objective: TV + nonneg (three terms)")
+s = dp.compile(fns, method="admm", device="cuda")
 L = be.lib()
 
 
