@@ -123,10 +123,9 @@ int cg_masked_fft_run(float* x, const float* b, const float* mask, int mask_imag
 
 // ---- tuning knobs (dpx_tune_set / dpx_tune_get of the C ABI; dpx_core.hip holds the table, include/dpx.h documents it) ----------
 enum Tune {
-  TUNE_CG_FUSED_MAX_B, TUNE_CG_SPLIT_UPDATE, TUNE_CG_UNFUSED, TUNE_CG_GRAM_BLOCKS, TUNE_PSF2OTF_DIRECT, TUNE_COMM_ALLGATHER_RING,
-  TUNE_HQS_STREAM_DUALS, TUNE_PGD_BAND, TUNE_PGD_ROWS_PLAIN, TUNE_SEED_BAND, TUNE_SEED_ROWS_PLAIN, TUNE_ITER_ROWS,
-  TUNE_ITER_BAND, TUNE_ITER_R, TUNE_COLS_INPLACE, TUNE_CHAIN_LOCKSTEP, TUNE_DS_CT, TUNE_DS_RPB, TUNE_DS_ROW_THREADS,
-  TUNE_DS_COL_THREADS, TUNE_COLS_PERSIST_WG, TUNE_DEBUG_COLS, TUNE_CG_ROWS_PER_WG, TUNE_CG_COLS_PER_WG, TUNE_CG_GRAM_SMALL, TUNE_CG_NO_HINT, TUNE_UNROLL_BWD_STAGED, TUNE_UNROLL_BWD_FOLD_FINISH, TUNE_FFDNET_PRESPLIT, TUNE_GENERIC_COLS_CT, TUNE_CG_WAVE_FFT, TUNE_CONV_TILE_ROWS, TUNE_UNROLL_BWD_BAND, TUNE_WGRAD_F32, TUNE_GENERIC_INTERLEAVED, TUNE_ITER_BAND_MIN_ROWS, TUNE_COLS_WG, TUNE_ITER_PAR_MAX_ROWS, TUNE_UNROLL_BWD_PAR_MAX_ROWS, TUNE_CG_EVENT_WAIT, TUNE_PNP_CG_NO_FOLD, TUNE_IL_TW_LDS, TUNE_COUNT
+  TUNE_CG_FUSED_MAX_B, TUNE_CG_SPLIT_UPDATE, TUNE_CG_UNFUSED, TUNE_COMM_ALLGATHER_RING, TUNE_ITER_ROWS,
+  TUNE_ITER_BAND, TUNE_ITER_R, TUNE_DS_RPB, TUNE_DS_ROW_THREADS,
+  TUNE_DS_COL_THREADS, TUNE_CG_ROWS_PER_WG, TUNE_CG_COLS_PER_WG, TUNE_CG_GRAM_SMALL, TUNE_CG_NO_HINT, TUNE_UNROLL_BWD_STAGED, TUNE_UNROLL_BWD_FOLD_FINISH, TUNE_FFDNET_PRESPLIT, TUNE_CG_WAVE_FFT, TUNE_CONV_TILE_ROWS, TUNE_UNROLL_BWD_BAND, TUNE_WGRAD_F32, TUNE_GENERIC_INTERLEAVED, TUNE_ITER_BAND_MIN_ROWS, TUNE_ITER_PAR_MAX_ROWS, TUNE_UNROLL_BWD_PAR_MAX_ROWS, TUNE_CG_EVENT_WAIT, TUNE_PNP_CG_NO_FOLD, TUNE_COUNT
 };
 int tune(Tune k);
 

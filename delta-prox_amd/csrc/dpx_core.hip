@@ -141,25 +141,13 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"cg_fused_max_b", "DPX_CG_FUSED_MAX_B", 8, nullptr},
     {"cg_split_update", "DPX_CG_SPLIT_UPDATE", 0, nullptr},
     {"cg_unfused", "DPX_CG_UNFUSED", 0, nullptr},
-    {"cg_gram_blocks", "DPX_CGF_GRAM_BLOCKS", 0, nullptr},
-    {"psf2otf_direct", "DPX_PSF2OTF_DIRECT", 0, nullptr},
     {"comm_allgather_ring", "DPX_COMM_ALLGATHER", 0, "ring"},
-    {"hqs_stream_duals", "DPX_HQS_STREAM_DUALS", 0, nullptr},
-    {"pgd_band", "DPX_PGD_BAND", 0, nullptr},
-    {"pgd_rows_plain", "DPX_PGD_ROWS", 0, "plain"},
-    {"seed_band", "DPX_SEED_BAND", 0, nullptr},
-    {"seed_rows_plain", "DPX_SEED_ROWS", 0, "plain"},
     {"iter_rows", "DPX_ITER_ROWS", 0, "seq,lockstep,par"},
     {"iter_band", "DPX_ITER_BAND", 0, nullptr},
     {"iter_r", "DPX_ITER_R", 0, nullptr},
-    {"cols_inplace", "DPX_COLS_INPLACE", 0, nullptr},
-    {"chain_lockstep", "DPX_CHAIN_LOCKSTEP", 0, nullptr},
-    {"ds_ct", "DPX_DS_CT", 0, nullptr},
     {"ds_rpb", "DPX_DS_RPB", 0, nullptr},
     {"ds_row_threads", "DPX_DS_ROW_THREADS", 0, nullptr},
     {"ds_col_threads", "DPX_DS_COL_THREADS", 0, nullptr},
-    {"cols_persist_wg", "DPX_COLS_PERSIST_WG", 0, nullptr},
-    {"debug_cols", "DPX_DEBUG_COLS", 0, nullptr},
     {"cg_rows_per_wg", "DPX_CG_ROWS_PER_WG", 0, nullptr},
     {"cg_cols_per_wg", "DPX_CG_COLS_PER_WG", 0, nullptr},
     {"cg_gram_small", "DPX_CG_GRAM_SMALL", 0, nullptr},
@@ -167,19 +155,16 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"unroll_bwd_staged", "DPX_UNROLL_BWD_STAGED", 0, nullptr},
     {"unroll_bwd_fold_finish", "DPX_UNROLL_BWD_FOLD_FINISH", 0, nullptr},
     {"ffdnet_presplit", "DPX_FFDNET_PRESPLIT", 0, nullptr},
-    {"generic_cols_ct", "DPX_GENERIC_COLS_CT", 0, nullptr},
     {"cg_wave_fft", "DPX_CG_WAVE_FFT", 0, nullptr},
     {"conv_tile_rows", "DPX_CONV_TILE_ROWS", 0, nullptr},
     {"unroll_bwd_band", "DPX_UNROLL_BWD_BAND", 0, nullptr},
     {"wgrad_f32", "DPX_WGRAD_F32", 0, nullptr},
     {"generic_interleaved", "DPX_GENERIC_INTERLEAVED", 1, nullptr},
     {"iter_band_min_rows", "DPX_ITER_BAND_MIN_ROWS", 0, nullptr},
-    {"cols_wg", "DPX_COLS_WG_COLS", 0, nullptr},
     {"iter_par_max_rows", "DPX_ITER_PAR_MAX_ROWS", 0, nullptr},
     {"unroll_bwd_par_max_rows", "DPX_UNROLL_BWD_PAR_MAX_ROWS", 0, nullptr},
     {"cg_event_wait", "DPX_CG_EVENT_WAIT", 0, nullptr},
     {"pnp_cg_no_fold", "DPX_PNP_CG_NO_FOLD", 0, nullptr},
-    {"il_tw_lds", "DPX_IL_TW_LDS", 1, nullptr},
 };
 std::atomic<int> g_knob[TUNE_COUNT];
 std::once_flag g_knob_once;

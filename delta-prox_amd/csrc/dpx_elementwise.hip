@@ -1126,7 +1126,7 @@ namespace dpx {
 // x / p / Ap non-null: the pending update x += alpha p, r -= alpha A p of the previous iteration is applied on the way (r is written)
 int gram_test_fused(float* r, float* G, void* state, int B, long n_per_batch, void* ws, unsigned* counter, float init_rtol, float* x, const float* p,
                     const float* Ap, int* host_flags, int host_tag, hipStream_t s) {
-  const int env_blk = tune(TUNE_CG_GRAM_BLOCKS);      // tuning
+  const int env_blk = 0;                              // (0 = by size)
   int nblk = gram_blocks(n_per_batch);
   // the finishing workgroup adds up B * B * nblk partial products: for larger batches fewer, longer slab walks (B = 32: 64 workgroups)
   if (B > 8) {

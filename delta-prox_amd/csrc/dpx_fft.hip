@@ -1555,7 +1555,7 @@ static void launch_cols_il_t(float2* spec, const SpecArgs& A, int P, int C, int 
   const dim3 grid(8 * longest);
   // the twiddle table in shared memory when the workgroups per CU stay what they are without it (knob il_tw_lds = 0: never)
   const size_t sh_tw = sh + (size_t)H * sizeof(float2), lds_cu = 160 * 1024;
-  if (tune(TUNE_IL_TW_LDS) != 0 && sh_tw <= lds_cu && lds_cu / sh_tw >= (lds_cu / sh > 2 ? 2 : lds_cu / sh)) {
+  if (sh_tw <= lds_cu && lds_cu / sh_tw >= (lds_cu / sh > 2 ? 2 : lds_cu / sh)) {
     il_lds_attr(k_cols_il<OP, CT, NT, true>, sh_tw);
     DPX_LAUNCH("k_cols_il", (k_cols_il<OP, CT, NT, true>), grid, dim3(NT), sh_tw, s, spec, A, C, H, W, pcol, twH, P);
     return;
@@ -1608,7 +1608,6 @@ int spectral_apply(const float* x, float* y, int op, const SpecArgs& A, int B, i
   int CT = (int)(60 * 1024 / (2 * (size_t)(H + 1) * sizeof(float2)));
   if (CT < 1) CT = 1;
   if (CT > 16) CT = 16;
-  if (tune(TUNE_GENERIC_COLS_CT) > 0) CT = tune(TUNE_GENERIC_COLS_CT);      // knob: columns per workgroup of the size-generic column pass
   const size_t shcol = (size_t)2 * CT * (H + 1) * sizeof(float2);
   if (!cct && shcol > 160 * 1024) {
     set_error("column length %d too large for the LDS-resident generic FFT", H);
@@ -1767,7 +1766,7 @@ static size_t ds_ld(int n) { return (size_t)n + n / 8 + 1; }      // padded LDS 
 static int ds_ct(int H) {
   // two columns per workgroup (256 threads, two workgroups per CU: one loads while the other transforms) beat four (512 threads, one per
   // CU) at 8x3x1024^2: column pass 234 vs 267 us, row pass 164 vs 156 us (64-byte instead of 128-byte pieces); DPX_DS_CT=4 forces four
-  const int env = tune(TUNE_DS_CT);
+  const int env = 0;
   if (env == 4 && 4 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024) return 4;
   return 2 * 2 * ds_ld(H) * sizeof(double2) <= 160 * 1024 ? 2 : 0;
 }

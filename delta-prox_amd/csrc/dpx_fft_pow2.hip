@@ -783,29 +783,6 @@ __global__ void __launch_bounds__(T* COLS, DPX_COLS_WPE) k_cols_p2(const float2*
 
 // Tuning probe (DPX_DEBUG_COLS=4, wrong results by design): the column kernel's HBM traffic with 16-byte accesses and
 // no arithmetic -- the ceiling a wide-access version of k_cols_p2 could reach at the same occupancy.
-template <int H, int T, int COLS>
-__global__ void __launch_bounds__(T* COLS, 4) k_cols_probe_wide(const float4* __restrict__ spec_in, float4* __restrict__ spec_out,
-                                                                const float4* __restrict__ add, int n_tiles) {
-  HIP_DYNAMIC_SHARED(float2, smem_probe)
-  constexpr int V = H / T;
-  const size_t base = (size_t)blockIdx.x * (H * COLS / 2);      // float4 units per tile
-  if (blockIdx.x >= n_tiles) return;
-  const int tid = threadIdx.x;
-  float4 v[V / 2], a[V / 2];
-#pragma unroll
-  for (int m = 0; m < V / 2; ++m) v[m] = spec_in[base + tid + m * (T * COLS)];
-  if (tid == 100000) smem_probe[0] = make_float2(v[0].x, 0.f);
-  __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
-#pragma unroll
-  for (int m = 0; m < V / 2; ++m) a[m] = add[base + tid + m * (T * COLS)];
-#pragma unroll
-  for (int m = 0; m < V / 2; ++m) v[m] = make_float4(v[m].x + a[m].x, v[m].y + a[m].y, v[m].z + a[m].z, v[m].w + a[m].w);
-  __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();
-#pragma unroll
-  for (int m = 0; m < V / 2; ++m) spec_out[base + tid + m * (T * COLS)] = v[m];
-}
 
 // ---------------------------------------------------------------------------------------------
 // host dispatch
@@ -856,8 +833,7 @@ static void launch_cols(const float2* spec, float2* spec_out, const SpecArgs& A,
   int grid = total_blocks;
 #if DPX_COLS_PERSIST
   {
-    const int per_cu_env = tune(TUNE_COLS_PERSIST_WG);
-    const int cap = 256 * (per_cu_env ? per_cu_env : DPX_COLS_PERSIST);
+    const int cap = 256 * DPX_COLS_PERSIST;
     if (grid > cap) grid = cap;
   }
 #endif
@@ -871,26 +847,8 @@ constexpr int COLS_WG = DPX_COLS_WG;   // columns per workgroup of the column ke
 
 template <int OP>
 static void cols_dispatch(int H, const float2* spec, float2* spec_out, const SpecArgs& A, int P, int C, int Ws, const float2* twH, hipStream_t s) {
-  if (H == 1024 && OP == OP_SOLVE) {
-    const int dbg = tune(TUNE_DEBUG_COLS);
-    if (dbg == 1) { launch_cols<1024, 64, COLS_WG, OP, 1>(spec, spec_out, A, P, C, Ws, twH, s); return; }
-    if (dbg == 2) { launch_cols<1024, 64, COLS_WG, OP, 2>(spec, spec_out, A, P, C, Ws, twH, s); return; }
-    if (dbg == 3) { launch_cols<1024, 64, COLS_WG, OP, 3>(spec, spec_out, A, P, C, Ws, twH, s); return; }
-    if (dbg == 4) {
-      const size_t sh = (size_t)(COLS_WG * 1092 + 1024) * sizeof(float2);
-      static bool once = false;
-      if (!once) { hipFuncSetAttribute((const void*)k_cols_probe_wide<1024, 64, COLS_WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); once = true; }
-      const int nt = P * (Ws / COLS_WG);
-      DPX_LAUNCH("k_cols_p2", (k_cols_probe_wide<1024, 64, COLS_WG>), dim3(nt), dim3(512), sh, s, (const float4*)spec, (float4*)spec_out,
-                 (const float4*)A.add, nt);
-      return;
-    }
-  }
-  if constexpr (OP == OP_SOLVE && COLS_WG == 8) {
-    // launches of a few planes: 4-column workgroups of 256 threads (one wave per SIMD, twice the workgroups); knob cols_wg
-    const int wgk = tune(TUNE_COLS_WG);
-    if (H == 1024 && wgk == 4) { launch_cols<1024, 64, 4, OP>(spec, spec_out, A, P, C, Ws, twH, s); return; }
-  }
+  // (measured and removed -- round 5: 4-column workgroups for launches of a few planes, 16.9 -> 22.8 us; the transform-free / wide-access
+  //  probe forms of this kernel behind the debug knob: DESIGN.md section 3)
   switch (H) {
     case 256: launch_cols<256, 32, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;
     case 512: launch_cols<512, 64, COLS_WG, OP>(spec, spec_out, A, P, C, Ws, twH, s); break;

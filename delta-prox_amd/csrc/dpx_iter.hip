@@ -649,7 +649,7 @@ static void launch_iter_rows_seq_d(const float2* sin, float2* sout, const IterTe
 template <int M, int T, int NT>
 static void launch_iter_rows_seq_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v,
                                     int C, int H, int R, int P, const float2* twW, hipStream_t s) {
-  const bool keep_dual = tune(TUNE_HQS_STREAM_DUALS) != 0;      // (A/B: half-quadratic splitting on the general kernel)
+  const bool keep_dual = false;                                 // (half-quadratic splitting on the general kernel: bit-identical, 36 instead of 20 B per pixel)
   // emit_v == 2 (x only: the last pass of a solve() that returns x alone) runs on the no-dual instantiation whatever the solver
   if (emit_v == 2 && x_out && !rho_next) launch_iter_rows_seq_d<M, T, NT, false>(sin, sout, TT, rho_next, x_out, 2, C, H, R, P, twW, s);
   else if (TT.vxu) launch_iter_rows_seq_d<M, T, NT, true, true>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, R, P, twW, s);
@@ -838,7 +838,7 @@ static bool launch_pgd_rows_seq(const float2* sin, float2* sout, float* x, const
   int p2 = 1;
   while (p2 < nb) p2 <<= 1;
   nb = 2 * p2;
-  const int band_env = tune(TUNE_PGD_BAND);
+  const int band_env = 0;
   if (band_env) nb = band_env;
   if (g_rows_band_pgd > 0) nb = g_rows_band_pgd;
   if (nb > H) nb = H;
@@ -861,7 +861,7 @@ static bool launch_pgd_rows_seq(const float2* sin, float2* sout, float* x, const
 // false: the plane / batch does not fit the streaming kernel (the caller keeps k_pgd_rows)
 bool pgd_rows_seq_pow2(const float2* sin, float2* sout, float* x, const float* ktb, const float* rho, const float* lam, float alpha, int prox, int P,
                        int C, int H, int W, const void* table, hipStream_t s) {
-  const bool plain = tune(TUNE_PGD_ROWS_PLAIN) != 0;      // (A/B and tests)
+  const bool plain = false;                               // (the plain row kernel serves the planes the streaming one has no partition for)
   if (plain || g_rows_mode_pgd == 2) return false;
   switch (W) {
     case 256: return launch_pgd_rows_seq<128, 16>(sin, sout, x, ktb, rho, lam, alpha, prox, C, H, P, tw_rows(table), s);
@@ -1029,7 +1029,7 @@ static bool launch_seed_rows_seq(const SeedOps& SO, const float* rho, const floa
   int nb = (256 * 2 * 4 * G) / (P * g_chain_share), p2 = 1;
   while (p2 < nb) p2 <<= 1;
   nb = p2;
-  const int band_env = tune(TUNE_SEED_BAND);
+  const int band_env = 0;
   if (band_env) nb = band_env;
   if (nb > H / 4) nb = H / 4;
   const int per_block = 4 * G;
@@ -1046,7 +1046,7 @@ static bool launch_seed_rows_seq(const SeedOps& SO, const float* rho, const floa
 // false: the plane / batch does not fit the streaming kernel (the caller keeps k_seed_rows<FRESH>)
 bool seed_rows_seq_pow2(const int* linops, int n, const float* rho, const float* x0, float2* spec, int P, int C, int H, int W, const void* table,
                         hipStream_t s) {
-  const bool plain = tune(TUNE_SEED_ROWS_PLAIN) != 0;      // (A/B and tests)
+  const bool plain = false;
   if (plain || g_rows_mode_pgd == 2) return false;                 // (dpx_admm_iter_config: 2 = the plain kernels)
   SeedOps SO{};
   SO.n = n;
@@ -1274,7 +1274,7 @@ extern "C" int dpx_admm_run(void* spec_a, void* spec_b, const void* spec_add, co
   DPX_REQUIRE(nterms >= 1 && nterms <= DPX_MAX_TERMS, "dpx_admm_run: nterms");
   for (int i = 0; i < nterms; ++i) cur[i] = terms[i];
   int parity = 0;
-  const bool cols_inplace = tune(TUNE_COLS_INPLACE) != 0;    // tuning experiment
+  const bool cols_inplace = false;                           // (column pass in place: a round-2 experiment, no gain)
   for (int k = 0; k < n_iters; ++k) {
     const int it = it0 + k;
     const bool last_of_solve = (it == total_iters - 1);
@@ -1384,7 +1384,7 @@ extern "C" int dpx_admm_run_chains(const dpx_chain* chains, int nchains, const v
   ChainEvents* Ep = chain_events("dpx_admm_run_chains");
   if (!Ep) return DPX_ERR_LAUNCH;
   ChainEvents& E = *Ep;
-  const bool lockstep = tune(TUNE_CHAIN_LOCKSTEP) != 0;
+  const bool lockstep = false;                          // (chains in lock step: measured slower, round 3; the ordered form below stays for reference runs)
   const bool ordered = lockstep && nchains > 1;
   dpx_term cur[DPX_MAX_CHAINS][DPX_MAX_TERMS];
   for (int c = 0; c < nchains; ++c)

@@ -375,7 +375,7 @@ static void launch_par_d(const float2* sin, float2* sout, const IterTerms& TT, c
 template <int M, int T, int NT>
 static void launch_par_nt(const float2* sin, float2* sout, const IterTerms& TT, const float* rho_next, float* x_out, int emit_v, int C, int H, int P,
                           const float2* twW, hipStream_t s) {
-  const bool keep_dual = tune(TUNE_HQS_STREAM_DUALS) != 0;
+  const bool keep_dual = false;
   // (the same choice of instantiation as launch_iter_rows_seq_nt, dpx_iter.hip)
   if (emit_v == 2 && x_out && !rho_next) launch_par_d<M, T, NT, false, false>(sin, sout, TT, rho_next, x_out, 2, C, H, P, twW, s);
   else if (TT.vxu) launch_par_d<M, T, NT, true, true>(sin, sout, TT, rho_next, x_out, emit_v ? 1 : 0, C, H, P, twW, s);

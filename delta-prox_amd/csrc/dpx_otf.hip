@@ -254,7 +254,7 @@ extern "C" int dpx_psf2otf(const double* psf, int kh, int kw, int kc, int C, int
               H, W, C, kh, kw, kc);   // psf2otf.py:53-54
   const long total = (long)table_elems(C, H, W);
   const size_t sh = ((size_t)kc * kh * PT_L + (size_t)PT_K * kh + (size_t)PT_L * kw) * sizeof(double2);
-  const bool direct = tune(TUNE_PSF2OTF_DIRECT) != 0;      // (A/B: the entry-by-entry kernel)
+  const bool direct = false;                               // (the entry-by-entry kernel serves kernels whose tile does not fit 64 KB of LDS)
   if (sh <= 64 * 1024 && !direct) {
     const int Wl = (W % 2 == 0) ? W / 2 + 1 : (W + 1) / 2;
     const long blocks = (long)C * ((H + PT_K - 1) / PT_K) * ((Wl + PT_L - 1) / PT_L);

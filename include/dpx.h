@@ -58,15 +58,7 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        (0 = always step by step; at most 32)
  *   cg_split_update      1 = fused CG with its own x / r update launch + flag copy        DPX_CG_SPLIT_UPDATE
  *   cg_unfused           1 = always the step-by-step CG sequence                          DPX_CG_UNFUSED
- *   cg_gram_blocks       workgroups of the fused Gram pass (0 = by size)                  DPX_CGF_GRAM_BLOCKS
- *   psf2otf_direct       1 = entry-by-entry dpx_psf2otf kernel (same sums, same order)    DPX_PSF2OTF_DIRECT
  *   comm_allgather_ring  1 = ncclAllGather instead of world-1 direct sends                DPX_COMM_ALLGATHER=ring
- *   hqs_stream_duals     1 = half-quadratic splitting on the general row kernel           DPX_HQS_STREAM_DUALS
- *                        (bit-identical)
- *   pgd_band, seed_band  bands per plane of dpx_pgd_run's / the seed pass's streaming      DPX_PGD_BAND, DPX_SEED_BAND
- *                        row kernel (bit-identical across band counts)
- *   pgd_rows_plain,      1 = the plain (non-streaming) row kernels                        DPX_PGD_ROWS=plain,
- *   seed_rows_plain                                                                       DPX_SEED_ROWS=plain
  *   iter_rows            1 = streaming row kernel, 2 = lock-step ring-buffer kernel,      DPX_ITER_ROWS=seq|lockstep|par
  *                        3 = row-parallel kernel (k_iter_rows_par: the rows of a band side by
  *                        side in one 16-wave workgroup; 256 / 512 / 1024-wide rows)
@@ -74,13 +66,9 @@ int dpx_timing_report(char* buf, size_t cap);
  *   iter_par_max_rows    launches of at most this many rows (planes x H) take the row-parallel      DPX_ITER_PAR_MAX_ROWS
  *                        kernel (0 = the library's rule, 8192; < 0 = never)
  *   iter_band, iter_r    bands per plane (streaming) / rows per band (lock-step)          DPX_ITER_BAND, DPX_ITER_R
- *   cols_inplace         1 = column pass in place                                         DPX_COLS_INPLACE
- *   chain_lockstep       1 = sub-batch chains' column passes ordered by events            DPX_CHAIN_LOCKSTEP
- *   ds_ct, ds_rpb,       geometry of the one-off fp64 data-spectrum pass                  DPX_DS_CT, DPX_DS_RPB,
+ *   ds_rpb,              geometry of the one-off fp64 data-spectrum pass                  DPX_DS_RPB,
  *   ds_row_threads,                                                                       DPX_DS_ROW_THREADS,
  *   ds_col_threads                                                                        DPX_DS_COL_THREADS
- *   cols_persist_wg      workgroups per CU of the persistent column kernel (builds with   DPX_COLS_PERSIST_WG
- *                        DPX_COLS_PERSIST only)
  *   cg_rows_per_wg,      rows / columns per workgroup of the fused CG matvec's transform      DPX_CG_ROWS_PER_WG,
  *   cg_cols_per_wg       kernels (0 = enough workgroups to cover the chip's 256 CUs)             DPX_CG_COLS_PER_WG
  *   cg_gram_small        fused CG, B <= 8: 1 = the register Gram kernel (default rule),          DPX_CG_GRAM_SMALL
@@ -94,9 +82,6 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        k_rhs, k_cgm_start as six launches instead of its head and tail passes (same bits;
  *                        dpx_admm_cg_pnp_iter_folds = 0); 2 = folded, but the head pass is not issued ahead of the
  *                        host's look at the CG's stop flag
- *   il_tw_lds            size-generic column / row transforms (planes off the power-of-two path): 1 = a pass     DPX_IL_TW_LDS
- *                        gathers its twiddles from a copy of the table in shared memory (default, where the
- *                        copy does not cost a workgroup per CU), 0 = from the global table (same values)
  *   unroll_bwd_staged    dpx_admm_unrolled_backward: 0 = the two-kernel backward iteration on          DPX_UNROLL_BWD_STAGED
  *                        power-of-two planes (k_bwd_rows), else the image-domain fused stage; 2 = the
  *                        image-domain fused stage everywhere; 1 = the rhs stage and the z stage of
@@ -110,8 +95,6 @@ int dpx_timing_report(char* buf, size_t cap);
  *   ffdnet_presplit      split-f16 inference (dpx_ffdnet_forward_bf16, mode 3): 1 = activations       DPX_FFDNET_PRESPLIT
  *                        travel between the layers as pre-split binary16 operand planes written by
  *                        the producing layer (bit-identical results; measured +-0 .. -5 %: off)
- *   generic_cols_ct      columns per workgroup of the size-generic column pass (planes off the     DPX_GENERIC_COLS_CT
- *                        register-radix path; 0 = what 60 KB of LDS hold)
  *   cg_wave_fft          fused CG on 320 x 320 / 384 x 384 planes: 2 = the size-generic transform        DPX_CG_WAVE_FFT
  *                        kernels instead of the one-wave register transforms (same result to round-off)
  *   conv_tile_rows       split-arithmetic 3x3 layers: 8 = 8-row workgroup tiles (two workgroups per CU)      DPX_CONV_TILE_ROWS
@@ -126,16 +109,12 @@ int dpx_timing_report(char* buf, size_t cap);
  *   iter_band_min_rows   shortest band (rows) the streaming row kernel of the two-kernel iteration may     DPX_ITER_BAND_MIN_ROWS
  *                        use when few planes must fill the chip (0 = the library's rule: 4 rows, 2 for launches
  *                        of fewer than 8 planes of 1024-wide rows; bit-identical across band counts)
- *   cols_wg              columns per workgroup of k_cols_p2 on 1024-row planes: 8 (512 threads), 4 (256      DPX_COLS_WG_COLS
- *                        threads, twice the workgroups: launches of a few planes), 0 = by the number of
- *                        planes (bit-identical)
- *   debug_cols           1..4 = timing probes of k_cols_p2 (WRONG RESULTS by design;      DPX_DEBUG_COLS
- *                        tools/ only)
  */
 int dpx_tune_count(void);
 const char* dpx_tune_name(int i);                       /* NULL beyond dpx_tune_count() */
 int dpx_tune_set(const char* name, int value);          /* DPX_ERR_ARG for a name the registry does not hold */
 int dpx_tune_get(const char* name, int* value);
+
 /* The CG solver's three switches as one typed call (cg_fused_max_b <= 32, cg_split_update, cg_unfused); a negative argument
  * leaves that switch unchanged.  Both branches of dpx_cg_masked_fft -- fused (B <= fused_max_b) and step by step -- compute the
  * reference's cg() (linalg/solve/solver_cg.py:56-136) with the same stop rule and exit iteration.                            */

@@ -16,7 +16,7 @@ B, C, H, W = (int(v) for v in shape.split("x"))
 settings = [a for a in sys.argv[1:] if "=" in a or a == "default"]
 if not settings:
     settings = ["default", "iter_band=64", "iter_band=128", "iter_band=256", "iter_band=512,iter_band_min_rows=2", "iter_band=1024,iter_band_min_rows=1",
-                "iter_rows=2,iter_r=2", "iter_rows=2,iter_r=6", "iter_rows=2,iter_r=16", "cols_wg=4", "cols_wg=4,iter_band=512,iter_band_min_rows=2"]
+                "iter_rows=2,iter_r=2", "iter_rows=2,iter_r=6", "iter_rows=2,iter_r=16"]
 gt, b, psf = synthetic.deconv_case(B, C, H, W, seed=1)
 bt = torch.from_numpy(b).cuda()
 x = dp.Variable()

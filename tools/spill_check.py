@@ -3,7 +3,7 @@
 
 Reads the per-kernel resource remarks hipcc prints with -Rpass-analysis=kernel-resource-usage -- __graft_entry__.build() keeps them next to every
 object file (delta-prox_amd/build/*.o.resources.txt) -- and fails (exit status 1) if a kernel that is not a probe reports ScratchSize > 0.
-Probe kernels (wrong results by design, reachable through a debug knob only): k_cols_p2<..., DBG != 0>, k_cols_probe_*.
+Probe kernels (wrong results by design) would be exempt -- k_cols_p2<..., DBG != 0>, k_cols_probe_* -- none is instantiated any more.
 
     python tools/spill_check.py [-v]        (tools/spill_check.sh is the same call; tests/test_host_logic.py runs it)
 """
