@@ -17,8 +17,13 @@
 
 namespace dpx {
 
+// Registers (round 6): at most 128 per lane in every instantiation (94 - 120 used), i.e. TWO 8-wave workgroups per CU.  Round 5's build used 158 -
+// 192 and ran one workgroup per CU -- config 5's twelve 512-row planes are 444 workgroups: two rounds, 38.8 us per launch against the forward
+// kernel's 21.4.  What brought it down, without touching the arithmetic: the two double-precision rho sums are reduced over the wave and parked in the
+// workgroup's slot array right behind their loop instead of living through the term loop (this alone: 137 -> 96), the history and incoming-adjoint
+// values are loaded two values at a time, and the forward transform's twiddle registers are loaded again in front of phase C.
 template <int M, int T, int NT, bool HB, int NW>
-__global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __restrict__ spec_in, float2* __restrict__ spec_out,
+__global__ void __launch_bounds__(64 * NW, 4) k_bwd_rows_par(const float2* __restrict__ spec_in, float2* __restrict__ spec_out,
                                                             const float2* __restrict__ twW, const float* __restrict__ rho_b,
                                                             float* __restrict__ part_a, float* __restrict__ part_b, float* __restrict__ part_lam,
                                                             int B, int C, int H, int bands, int P, BwdRowTerms TT) {
@@ -66,9 +71,6 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
   const unsigned xoff = (unsigned)pl * H * M + (e0 / SPEC_TILE) * H * SPEC_TILE + (e0 % SPEC_TILE);
   const unsigned xstep = (unsigned)(2 * T / SPEC_TILE) * H * SPEC_TILE;
   const unsigned noff = (unsigned)P * H * M + (unsigned)pl * H;
-  const unsigned tile_off = (unsigned)pl * H * M + (unsigned)((t % SPEC_TILE) + (t / SPEC_TILE) * H * SPEC_TILE);
-  const unsigned tile_step = (unsigned)((T / SPEC_TILE) * H * SPEC_TILE);
-  const int pair = lbase | ((T - t) & (T - 1));
   const int lnext = lbase | ((t + 1) & (T - 1)), lprev = lbase | ((t + T - 1) & (T - 1));
   auto stage_idx = [&](int e) { return ((e >> 1) / T) * 128 + g * 2 * T + ((e >> 1) % T) * 2 + (e & 1); };
 
@@ -150,26 +152,49 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
     {
       const int qp = q >= 1 ? q - 1 : 0;
       const float2* gpb = waves + (qp / G) * PERWAVE + G * S + (qp % G) * M + t;
+      constexpr int QS = 2;                   // values per batch of history loads (fp32 history: one -- 128 registers)
 #pragma unroll
-      for (int m = 0; m < V; ++m) {
-        float2 lg = make_float2(cI * ga[m].x, cI * ga[m].y);
-        if (nW) {
-          const float r_same = __shfl(ga[m].x, lnext), r_wrap = __shfl(ga[(m + 1) % V].x, lbase);
-          const float l_same = __shfl(ga[m].y, lprev), l_wrap = __shfl(ga[(m + V - 1) % V].y, lbase | (T - 1));
-          const float right = (t == T - 1) ? r_wrap : r_same, left = (t == 0) ? l_wrap : l_same;
-          lg.x += (float)nW * (2.f * ga[m].x - left - ga[m].y);
-          lg.y += (float)nW * (2.f * ga[m].y - ga[m].x - right);
+      for (int m0 = 0; m0 < V; m0 += QS) {
+        float2 xr[QS], rr[QS];
+#pragma unroll
+        for (int k = 0; k < QS; ++k) {
+          xr[k] = hist_pair<HB>(TT.x, rowz + t + (m0 + k) * T);
+          rr[k] = hist_pair<HB>(TT.rhs, rowz + t + (m0 + k) * T);
         }
-        if (nH) {
-          const float2 gp = gpb[m * T], gn = gnb[m * T];
-          lg.x += (float)nH * (2.f * ga[m].x - gp.x - gn.x);
-          lg.y += (float)nH * (2.f * ga[m].y - gp.y - gn.y);
+#pragma unroll
+        for (int k = 0; k < QS; ++k) {
+          const int m = m0 + k;
+          float2 lg = make_float2(cI * ga[m].x, cI * ga[m].y);
+          if (nW) {
+            const float r_same = __shfl(ga[m].x, lnext), r_wrap = __shfl(ga[(m + 1) % V].x, lbase);
+            const float l_same = __shfl(ga[m].y, lprev), l_wrap = __shfl(ga[(m + V - 1) % V].y, lbase | (T - 1));
+            const float right = (t == T - 1) ? r_wrap : r_same, left = (t == 0) ? l_wrap : l_same;
+            lg.x += (float)nW * (2.f * ga[m].x - left - ga[m].y);
+            lg.y += (float)nW * (2.f * ga[m].y - ga[m].x - right);
+          }
+          if (nH) {
+            const float2 gp = gpb[m * T], gn = gnb[m * T];
+            lg.x += (float)nH * (2.f * ga[m].x - gp.x - gn.x);
+            lg.y += (float)nH * (2.f * ga[m].y - gp.y - gn.y);
+          }
+          const float pa = fmaf(lg.y, xr[k].y, lg.x * xr[k].x), pb = fmaf(ga[m].y, rr[k].y, ga[m].x * rr[k].x);
+          acc_a += own ? (double)pa : 0.0;
+          acc_b += own ? (double)pb : 0.0;
         }
-        const float2 xr = hist_pair<HB>(TT.x, rowz + t + m * T);
-        const float2 rr = hist_pair<HB>(TT.rhs, rowz + t + m * T);
-        const float pa = fmaf(lg.y, xr.y, lg.x * xr.x), pb = fmaf(ga[m].y, rr.y, ga[m].x * rr.x);
-        acc_a += own ? (double)pa : 0.0;
-        acc_b += own ? (double)pb : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // (the two double sums leave the registers here: reduced over the wave and parked in the workgroup's slot array)
+    {
+      double va = acc_a, vb = acc_b;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        va += __shfl_xor(va, o);
+        vb += __shfl_xor(vb, o);
+      }
+      if (lane == 0) {
+        red[wave * (2 + DPX_MAX_TERMS) + 0] = va;
+        red[wave * (2 + DPX_MAX_TERMS) + 1] = vb;
       }
     }
     __builtin_amdgcn_sched_barrier(0);                  // (keeps the terms' loads from being hoisted above: registers)
@@ -179,12 +204,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
       const BwdRowTerm tm = TT.t[i];
       const float lam = tm.lam ? tm.lam[bi] * tm.alpha : 0.f;
       const float sq = 1.f / (1.f + 2.f * lam);
-      float2 av[V], vv[V], w[V];
-#pragma unroll
-      for (int m = 0; m < V; ++m) {
-        av[m] = ((const float2*)tm.a_in)[rowz + t + m * T];
-        vv[m] = hist_pair<HB>(tm.v, rowz + t + m * T);
-      }
+      float2 w[V];
       if (tm.linop == DPX_LIN_IDENTITY) {
 #pragma unroll
         for (int m = 0; m < V; ++m) w[m] = ga[m];
@@ -203,10 +223,34 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
           w[m] = make_float2(ga[m].y - ga[m].x, gr - ga[m].y);
         }
       }
-      float lt;
-      if (tm.prox == DPX_PROX_NORM1) lt = bwd_gd_row<1, V>(sq, rho, w, av, vv);
-      else if (tm.prox == DPX_PROX_NONNEG) lt = bwd_gd_row<2, V>(sq, rho, w, av, vv);
-      else lt = bwd_gd_row<0, V>(sq, rho, w, av, vv);
+      // the prox stage in quarters of the row's values: a quarter's incoming adjoint and history values in registers at a time (the sum `lt`
+      // runs over m = 0 .. V - 1 in order, as bwd_gd_row does)
+      float lt = 0.f;
+      constexpr int QP = 2;
+#pragma unroll
+      for (int m0 = 0; m0 < V; m0 += QP) {
+        float2 av[QP], vv[QP];
+#pragma unroll
+        for (int k = 0; k < QP; ++k) {
+          av[k] = ((const float2*)tm.a_in)[rowz + t + (m0 + k) * T];
+          vv[k] = hist_pair<HB>(tm.v, rowz + t + (m0 + k) * T);
+        }
+#pragma unroll
+        for (int k = 0; k < QP; ++k) {
+          const int m = m0 + k;
+          if (tm.prox == DPX_PROX_NORM1) {
+            w[m].x = bwd_gd<1>(sq, rho * w[m].x, av[k].x, vv[k].x, lt);
+            w[m].y = bwd_gd<1>(sq, rho * w[m].y, av[k].y, vv[k].y, lt);
+          } else if (tm.prox == DPX_PROX_NONNEG) {
+            w[m].x = bwd_gd<2>(sq, rho * w[m].x, av[k].x, vv[k].x, lt);
+            w[m].y = bwd_gd<2>(sq, rho * w[m].y, av[k].y, vv[k].y, lt);
+          } else {
+            w[m].x = bwd_gd<0>(sq, rho * w[m].x, av[k].x, vv[k].x, lt);
+            w[m].y = bwd_gd<0>(sq, rho * w[m].y, av[k].y, vv[k].y, lt);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       lsum[i] += own ? lt : 0.f;
       if (own) {
 #pragma unroll
@@ -245,12 +289,21 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
       }
     }
     float2* fwd = stX + g * S;
+    int t_c = t;
+    DPX_OPAQUE(t_c);                                    // (phase A's twiddle registers are not carried through phase B: loaded again, 14 L2 hits)
+    TwRegs<M, T, false> twc;
+    twc.load(t_c, twW, 2);
+    twc.twb_ = twb;
+    twc.bstride_ = 1;
     WaveSync()();
-    fft_reg_tw<M, T, -1, false>(acc, fwd, t, twr, WaveSync());
-    float2* out = spec_out + tile_off + (unsigned)h * SPEC_TILE;
+    fft_reg_tw<M, T, -1, false>(acc, fwd, t, twc, WaveSync());
+    const unsigned tile_off_c = (unsigned)pl * H * M + (unsigned)((t_c % SPEC_TILE) + (t_c / SPEC_TILE) * H * SPEC_TILE);
+    const unsigned tile_step_c = (unsigned)((T / SPEC_TILE) * H * SPEC_TILE);
+    const int pair_c = lbase | ((T - t_c) & (T - 1));
+    float2* out = spec_out + tile_off_c + (unsigned)h * SPEC_TILE;
 #pragma unroll
     for (int m = 0; m < V; ++m) {
-      const float2 got = make_float2(__shfl(acc[V - 1 - m].x, pair), __shfl(acc[V - 1 - m].y, pair));
+      const float2 got = make_float2(__shfl(acc[V - 1 - m].x, pair_c), __shfl(acc[V - 1 - m].y, pair_c));
       const float2 zm = cconj(t == 0 ? acc[(V - m) % V] : got);
       const int k = t + m * T;
       const float2 zk = acc[m];
@@ -263,7 +316,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
         const float2 d = cscale(csub(zk, zm), 0.5f);
         Xo = cadd(e, cmul(make_float2(d.y, -d.x), twl[k]));
       }
-      if (own) out[tile_step * m] = Xo;
+      if (own) out[tile_step_c * m] = Xo;
     }
   }
   // ---- the workgroup's partial sums, one slot each (the finishing launch adds the slots of an image in index order) ----
@@ -274,13 +327,12 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
       return v;
     };
     double vals[2 + NT];
-    vals[0] = wave_sum_d(acc_a);
-    vals[1] = wave_sum_d(acc_b);
 #pragma unroll
     for (int i = 0; i < NT; ++i) vals[2 + i] = wave_sum_d((double)lsum[i]);
     if (lane == 0) {
+      if (!wave_live) red[wave * (2 + DPX_MAX_TERMS) + 0] = red[wave * (2 + DPX_MAX_TERMS) + 1] = 0.0;     // (idle waves: their two slots were not written above)
 #pragma unroll
-      for (int e = 0; e < 2 + NT; ++e) red[wave * (2 + DPX_MAX_TERMS) + e] = vals[e];
+      for (int e = 2; e < 2 + NT; ++e) red[wave * (2 + DPX_MAX_TERMS) + e] = vals[e];
     }
     __syncthreads();
     if (tid < 2 + NT) {
@@ -299,7 +351,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_bwd_rows_par(const float2* __res
 }
 
 #ifndef DPX_BWD_PAR_NW
-#define DPX_BWD_PAR_NW 8           // waves per workgroup: 8 = 256 registers per lane (16: 128, 29 - 56 of them spilled -- config 5 1.207 ms per step against 1.072; lock-step bands 1.086)
+#define DPX_BWD_PAR_NW 8           // waves per workgroup (two workgroups per CU; 16: one)
 #endif
 constexpr int BWD_PAR_NW = DPX_BWD_PAR_NW;
 
