@@ -540,8 +540,45 @@ static void launch_bx_mt(int mt, bool relu, const float* in, float* out, const c
 
 // ---- backward-data of the FFDNet stack on the split kernels: adjoints of the input / output stages in the C8 layout ----------------
 // adjoint of k_bx_unpack_out (PixelShuffle + crop): g_last[b][ch][y2][x2] = gy[b][c][2 y2 + dy][2 x2 + dx] inside the image, else 0
-__global__ void k_bx_pack_gout(const float* __restrict__ gy, float* __restrict__ g, int B, int C, int H, int W, int H2, int W2, int G) {
+// ---- the gradient scale of a split-f16 backward pass ------------------------------------------------------------------------------
+// Gradients of a mean loss sit at 1e-7, far below binary16's normal range, and the backward pass is linear in them: the incoming gradient
+// is multiplied by a power of two that brings max |gy| into [8, 16) (k_bx_absmax leaves the bits of max |gy| in a word, every consumer
+// derives the same factor from it), and gx, d/dsigma, dW, db are multiplied by its inverse -- exact, with 2^12 of headroom upwards for
+// what twelve transposed layers do to the magnitude (an operand beyond 6e4 trips dpx_ffdnet_f16_overflow as in the forward pass;
+// operands below 2^-14 keep an ABSOLUTE error of 2^-35 through the scaled low part).
+__global__ void __launch_bounds__(256) k_bx_absmax(const float* __restrict__ x, long n, unsigned* __restrict__ amax_bits) {
+  __shared__ float sh[4];
+  float m = 0.f;
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  for (; i + 3 < n; i += (long)gridDim.x * 1024) {
+    const float4 v = *(const float4*)(x + i);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (; i < n; ++i) m = fmaxf(m, fabsf(x[i]));                         // (the tail: at most three elements of one thread)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]))));   // (non-negative floats order like their bits)
+}
+// 2^(BX_GS - e) with 2^(e-1) <= max |gy| < 2^e, i.e. max |gy| lands in [2^(BX_GS-1), 2^BX_GS); 1 when there is no word (split-bf16 passes), for a
+// zero / denormal-sized gradient, and for inf / NaN (the range trap's case)
+constexpr int BX_GS = 4;
+__device__ __forceinline__ float bx_grad_scale(const unsigned* amax_bits) {
+  if (!amax_bits) return 1.f;
+  const int ex = (int)(*amax_bits >> 23);
+  return (ex < 8 || ex >= 255) ? 1.f : __uint_as_float((unsigned)(253 + BX_GS - ex) << 23);
+}
+__device__ __forceinline__ float bx_grad_unscale(const unsigned* amax_bits) {
+  if (!amax_bits) return 1.f;
+  const int ex = (int)(*amax_bits >> 23);
+  return (ex < 8 || ex >= 255) ? 1.f : __uint_as_float((unsigned)(ex + 1 - BX_GS) << 23);
+}
+
+__global__ void k_bx_pack_gout(const float* __restrict__ gy, float* __restrict__ g, int B, int C, int H, int W, int H2, int W2, int G,
+                               const unsigned* __restrict__ amax_bits) {
   const long total = (long)B * G * H2 * W2 * 8;
+  const float sc = bx_grad_scale(amax_bits);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int j = (int)(i % 8);
     long r = i / 8;
@@ -554,14 +591,16 @@ __global__ void k_bx_pack_gout(const float* __restrict__ gy, float* __restrict__
     float v = 0.f;
     if (ch < 4 * C) {
       const int c = ch >> 2, yy = 2 * y2 + ((ch >> 1) & 1), xx = 2 * x2 + (ch & 1);
-      if (yy < H && xx < W) v = gy[(((long)b * C + c) * H + yy) * W + xx];
+      if (yy < H && xx < W) v = gy[(((long)b * C + c) * H + yy) * W + xx] * sc;
     }
     g[i] = v;
   }
 }
 // adjoint of k_bx_pack_in's image part (replicate-pad to even size + pixel-unshuffle): the padded row / column folds onto the last one
-__global__ void k_bx_unpack_gin(const float* __restrict__ ga, float* __restrict__ gx, int B, int C, int H, int W, int H2, int W2, int G) {
+__global__ void k_bx_unpack_gin(const float* __restrict__ ga, float* __restrict__ gx, int B, int C, int H, int W, int H2, int W2, int G,
+                                const unsigned* __restrict__ amax_bits) {
   const long total = (long)B * C * H * W;
+  const float us = bx_grad_unscale(amax_bits);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int xx = (int)(i % W);
     long r = i / W;
@@ -577,23 +616,41 @@ __global__ void k_bx_unpack_gin(const float* __restrict__ ga, float* __restrict_
     if (fy) v += at(yy + 1, xx);
     if (fx) v += at(yy, xx + 1);
     if (fy && fx) v += at(yy + 1, xx + 1);
-    gx[i] = v;
+    gx[i] = v * us;
   }
 }
-// d / d sigma_b = sum over the sigma-map channel (4 C) of g_a0: one workgroup per image, fixed summation order
-__global__ void __launch_bounds__(256) k_bx_sigma_grad(const float* __restrict__ ga, float* __restrict__ gs, int C, int H2, int W2, int G) {
+// d / d sigma_b = sum over the sigma-map channel (4 C) of g_a0, in a fixed order: BX_SG_SLICES workgroups per image leave the sums of their
+// contiguous slices, one workgroup per image adds those up (one workgroup per image walking the whole plane took 147 us at 2 x 384 x 384)
+constexpr int BX_SG_SLICES = 64;
+__global__ void __launch_bounds__(256) k_bx_sigma_grad(const float* __restrict__ ga, float* __restrict__ part, int C, int H2, int W2, int G) {
   __shared__ float sh[256];
-  const int b = blockIdx.x, ch = 4 * C;
+  const int b = blockIdx.y, ch = 4 * C;
   const float* base = ga + (((long)b * G + (ch >> 3)) * H2 * W2) * 8 + (ch & 7);
+  const long hw = (long)H2 * W2, i0 = hw * blockIdx.x / BX_SG_SLICES, i1 = hw * (blockIdx.x + 1) / BX_SG_SLICES;
   float acc = 0.f;
-  for (long i = threadIdx.x; i < (long)H2 * W2; i += 256) acc += base[i * 8];
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) acc += base[i * 8];
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) gs[b] = sh[0];
+  if (threadIdx.x == 0) part[b * BX_SG_SLICES + blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(BX_SG_SLICES) k_bx_sigma_grad_finish(const float* __restrict__ part, float* __restrict__ gs,
+                                                                     const unsigned* __restrict__ amax_bits) {
+  float v = part[blockIdx.x * BX_SG_SLICES + threadIdx.x];
+#pragma unroll
+  for (int o = BX_SG_SLICES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (threadIdx.x == 0) gs[blockIdx.x] = v * bx_grad_unscale(amax_bits);
+}
+// the tail of the backward workspaces: [0] the bits of max |gy| (split-f16 passes), from byte 256 on the sigma gradient's partial sums
+static size_t bx_bwd_tail_bytes(int B) { return 256 + (size_t)B * BX_SG_SLICES * sizeof(float); }
+static void launch_bx_sigma_grad(const float* g_a0, float* gsigma, char* tail, const unsigned* amax_bits, int B, int in_nc, int H2, int W2, int G0,
+                                 hipStream_t s) {
+  float* part = (float*)(tail + 256);
+  DPX_LAUNCH("k_bx_sigma_grad", k_bx_sigma_grad, dim3(BX_SG_SLICES, B), dim3(256), 0, s, g_a0, part, in_nc, H2, W2, G0);
+  DPX_LAUNCH("k_bx_sigma_grad_finish", k_bx_sigma_grad_finish, dim3(B), dim3(BX_SG_SLICES), 0, s, (const float*)part, gsigma, amax_bits);
 }
 
 static int bx_cin(int l, int in_nc, int nc) { return l == 0 ? 4 * in_nc + 1 : nc; }
@@ -866,17 +923,18 @@ extern "C" size_t dpx_ffdnet_bf16_packed_transposed_bytes(int in_nc, int nc, int
   return n + 1024;
 }
 
-// packed_T: the nb backward-data layers in FORWARD order (layer l: bx_cout(l) -> bx_cin(l) channels), split-bf16 planes, zero bias
-extern "C" int dpx_ffdnet_bf16_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream) {
-  DPX_REQUIRE(packed_T && w && in_nc > 0 && nc > 0 && nb >= 2, "dpx_ffdnet_bf16_pack_transposed: bad arguments");
+// packed_T: the nb backward-data layers in FORWARD order (layer l: bx_cout(l) -> bx_cin(l) channels), zero bias; mode 6: split-bf16 planes,
+// mode 3: split-f16 planes (a weight beyond the binary16 range trips dpx_ffdnet_f16_overflow)
+extern "C" int dpx_ffdnet_bf16_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, int mode, dpx_stream_t stream) {
+  DPX_REQUIRE(packed_T && w && in_nc > 0 && nc > 0 && nb >= 2 && (mode == 6 || mode == 3), "dpx_ffdnet_bf16_pack_transposed: bad arguments");
   DPX_REQUIRE(nc <= 96 && nc % 16 == 0 && 4 * in_nc <= 96, "dpx_ffdnet_bf16_pack_transposed: layers of 16..96 channels (multiples of 16), got %d", nc);
   char* dst = (char*)packed_T;
   for (int l = 0; l < nb; ++l) {
     const int cin_t = bx_cout(l, in_nc, nc, nb), cout_t = bx_cin(l, in_nc, nc);
     DPX_REQUIRE(w[l], "dpx_ffdnet_bf16_pack_transposed: layer %d has null weights", l);
-    const size_t n = bx_layer_bytes(cin_t, cout_t, 3);
+    const size_t n = bx_layer_bytes(cin_t, cout_t, bx_planes(mode));
     DPX_LAUNCH("k_bx_pack_weights", k_bx_pack_weights, dim3(grid_for((long)(n / 2), 256, 2048)), dim3(256), 0, (hipStream_t)stream, w[l],
-               (const float*)nullptr, (unsigned short*)dst, cin_t, cout_t, 6, 1);
+               (const float*)nullptr, (unsigned short*)dst, cin_t, cout_t, mode, 1);
     dst += n;
   }
   return launch_status("dpx_ffdnet_bf16_pack_transposed");
@@ -884,15 +942,39 @@ extern "C" int dpx_ffdnet_bf16_pack_transposed(void* packed_T, const float* cons
 
 extern "C" size_t dpx_ffdnet_bf16_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W) {
   const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
-  return (px * 8 * groups16(4 * in_nc) + 2 * px * 8 * groups16(nc) + px * 8 * groups16(4 * in_nc + 1)) * sizeof(float);
+  return (px * 8 * groups16(4 * in_nc) + 2 * px * 8 * groups16(nc) + px * 8 * groups16(4 * in_nc + 1)) * sizeof(float) + bx_bwd_tail_bytes(B);
+}
+// the planes of a backward workspace (everything in front of its tail)
+static size_t bx_bwd_plane_bytes(int B, int in_nc, int nc, int H, int W) { return dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W) - bx_bwd_tail_bytes(B); }
+// the backward-data layer of forward layer l; mode 3: in the split-f16 arithmetic (its operands -- the scaled gradients -- are watched by the range trap)
+static void launch_bx_bwd_layer(int mode, int mt, const float* cur, float* dst, const char* wpk, int gin, int gout, int B, int H2, int W2, hipStream_t s,
+                                const float* mask) {
+  if (mode == 3) launch_bx_mt<3>(mt, false, cur, dst, wpk, gin, gout, B, H2, W2, s, mask);
+  else launch_bx_mt<6>(mt, false, cur, dst, wpk, gin, gout, B, H2, W2, s, mask);
+}
+// the first launches of a backward pass: mode 3 -- the bits of max |gy| into the workspace tail's first word; then the scaled gradient in the C8 layout
+static const unsigned* launch_bx_pack_gout(int mode, const float* gy, float* g_last, char* tail, int B, int in_nc, int H, int W, int H2, int W2, int GL,
+                                           hipStream_t s) {
+  unsigned* amax_bits = nullptr;
+  if (mode == 3) {
+    amax_bits = (unsigned*)tail;
+    hipMemsetAsync(amax_bits, 0, sizeof(unsigned), s);
+    const long n = (long)B * in_nc * H * W;
+    DPX_LAUNCH("k_bx_absmax", k_bx_absmax, dim3(grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0, s, gy, n, amax_bits);
+  }
+  const size_t px = (size_t)B * H2 * W2;
+  DPX_LAUNCH("k_bx_pack_gout", k_bx_pack_gout, dim3(grid_for((long)(px * 8 * GL), 256, 8192)), dim3(256), 0, s, gy, g_last, B, in_nc, H, W, H2, W2, GL,
+             (const unsigned*)amax_bits);
+  return amax_bits;
 }
 
-// gx, gsigma: either may be NULL.  acts: dpx_ffdnet_forward_bf16_save's buffer.
+// gx, gsigma: either may be NULL.  acts: dpx_ffdnet_forward_bf16_save's buffer.  mode: the arithmetic packed_T was packed for (6: split-bf16,
+// any range; 3: split-f16 on gradients scaled by a power of two, half the matrix work -- dpx_ffdnet_f16_overflow says afterwards whether it held).
 extern "C" int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigma, const void* packed_T, const void* acts, int in_nc, int nc, int nb,
-                                        int B, int H, int W, void* ws, dpx_stream_t stream) {
+                                        int mode, int B, int H, int W, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(gy && packed_T && acts && ws && (gx || gsigma), "dpx_ffdnet_backward_bf16: null pointer");
-  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96,
-              "dpx_ffdnet_backward_bf16: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 && (mode == 6 || mode == 3),
+              "dpx_ffdnet_backward_bf16: unsupported configuration (in_nc=%d nc=%d nb=%d mode=%d)", in_nc, nc, nb, mode);
   hipStream_t s = (hipStream_t)stream;
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const size_t px = (size_t)B * H2 * W2;
@@ -902,11 +984,12 @@ extern "C" int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigm
   float* gA = g_last + px * 8 * GL;
   float* gB = gA + px * 8 * Gc;
   float* g_a0 = gB + px * 8 * Gc;
-  DPX_LAUNCH("k_bx_pack_gout", k_bx_pack_gout, dim3(grid_for((long)(px * 8 * GL), 256, 8192)), dim3(256), 0, s, gy, g_last, B, in_nc, H, W, H2, W2, GL);
+  char* tail = (char*)ws + bx_bwd_plane_bytes(B, in_nc, nc, H, W);
+  const unsigned* amax_bits = launch_bx_pack_gout(mode, gy, g_last, tail, B, in_nc, H, W, H2, W2, GL, s);
   size_t off[64];
   DPX_REQUIRE(nb <= 64, "dpx_ffdnet_backward_bf16: at most 64 layers");
   size_t o = 0;
-  for (int l = 0; l < nb; ++l) { off[l] = o; o += bx_layer_bytes(bx_cout(l, in_nc, nc, nb), bx_cin(l, in_nc, nc), 3); }
+  for (int l = 0; l < nb; ++l) { off[l] = o; o += bx_layer_bytes(bx_cout(l, in_nc, nc, nb), bx_cin(l, in_nc, nc), bx_planes(mode)); }
   const float* cur = g_last;
   int gin = GL;
   for (int l = nb - 1; l >= 0; --l) {
@@ -916,14 +999,14 @@ extern "C" int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigm
     // the output of backward layer l is the gradient w.r.t. a_l, the (post-ReLU) output of forward layer l - 1: stored already
     // multiplied by [a_l > 0], ready to be the next layer's plain input
     const float* mask = (l >= 1) ? hidden + (size_t)(l - 1) * px * 8 * Gc : nullptr;
-    launch_bx_mt<6>((cout_t + 31) / 32, false, cur, dst, (const char*)packed_T + off[l], gin, gout, B, H2, W2, s, mask);
+    launch_bx_bwd_layer(mode, (cout_t + 31) / 32, cur, dst, (const char*)packed_T + off[l], gin, gout, B, H2, W2, s, mask);
     cur = dst;
     gin = gout;
   }
   if (gx)
     DPX_LAUNCH("k_bx_unpack_gin", k_bx_unpack_gin, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, (const float*)g_a0, gx, B, in_nc, H,
-               W, H2, W2, G0);
-  if (gsigma) DPX_LAUNCH("k_bx_sigma_grad", k_bx_sigma_grad, dim3(B), dim3(256), 0, s, (const float*)g_a0, gsigma, in_nc, H2, W2, G0);
+               W, H2, W2, G0, amax_bits);
+  if (gsigma) launch_bx_sigma_grad(g_a0, gsigma, tail, amax_bits, B, in_nc, H2, W2, G0, s);
   return launch_status("dpx_ffdnet_backward_bf16");
 }
 
@@ -938,8 +1021,11 @@ void ffd_launch_wgrad(const float* G, const float* A, float* gw, float* gb, int 
                       hipStream_t s);   // dpx_ffdnet.hip
 }
 // C8 [B][G][H][W][8] -> planar [B][C][H][W] (C <= 8 G): a thread moves the 8 channels of one pixel
-__global__ void k_bx_c8_to_planar(const float* __restrict__ src, float* __restrict__ dst, int B, int G, int C, long hw) {
+// amax_bits (nullable): the gradient planes of a split-f16 backward pass leave multiplied by the inverse of their scale
+__global__ void k_bx_c8_to_planar(const float* __restrict__ src, float* __restrict__ dst, int B, int G, int C, long hw,
+                                  const unsigned* __restrict__ amax_bits) {
   const long total = (long)B * G * hw;
+  const float us = bx_grad_unscale(amax_bits);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long p = i % hw;
     const int g = (int)((i / hw) % G), b = (int)(i / (hw * G));
@@ -947,7 +1033,7 @@ __global__ void k_bx_c8_to_planar(const float* __restrict__ src, float* __restri
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (g * 8 + j < C) dst[((long)b * C + g * 8 + j) * hw + p] = v[j];
+      if (g * 8 + j < C) dst[((long)b * C + g * 8 + j) * hw + p] = v[j] * us;
   }
 }
 
@@ -1170,10 +1256,10 @@ extern "C" size_t dpx_ffdnet_bf16_bwd_w_ws_bytes(int B, int in_nc, int nc, int H
 
 // gw[l] [cout_l][cin_l][9], gb[l] [cout_l] (entries may be NULL: that layer's gradients are not wanted); gx, gsigma may be NULL
 extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsigma, float* const* gw, float* const* gb, const void* packed_T,
-                                          const void* acts, int in_nc, int nc, int nb, int B, int H, int W, void* ws, dpx_stream_t stream) {
+                                          const void* acts, int in_nc, int nc, int nb, int mode, int B, int H, int W, void* ws, dpx_stream_t stream) {
   DPX_REQUIRE(gy && packed_T && acts && ws && gw && gb, "dpx_ffdnet_backward_bf16_w: null pointer");
-  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nb <= 64 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96,
-              "dpx_ffdnet_backward_bf16_w: unsupported configuration (in_nc=%d nc=%d nb=%d)", in_nc, nc, nb);
+  DPX_REQUIRE(B > 0 && H > 0 && W > 0 && in_nc > 0 && nb >= 2 && nb <= 64 && nc % 16 == 0 && nc <= 96 && 4 * in_nc <= 96 && (mode == 6 || mode == 3),
+              "dpx_ffdnet_backward_bf16_w: unsupported configuration (in_nc=%d nc=%d nb=%d mode=%d)", in_nc, nc, nb, mode);
   hipStream_t s = (hipStream_t)stream;
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   const size_t px = (size_t)B * H2 * W2;
@@ -1187,14 +1273,15 @@ extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsi
   float* g_a0 = gB + px * 8 * Gc;
   // (the planar copies sit 16 floats behind / 48 floats in front of their neighbours: k_wgrad_bf16x3 reads up to 1 float in front of and
   //  24 floats behind a plane set with unconditional loads)
+  char* tail = (char*)ws + bx_bwd_plane_bytes(B, in_nc, nc, H, W);
   float* planar_g = (float*)((char*)ws + dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W)) + 16;
   const size_t gmax = (size_t)8 * groups16(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1);
   float* planar_a = planar_g + px * gmax + 64;
   float* wg_ws = planar_a + px * gmax + 48;
-  DPX_LAUNCH("k_bx_pack_gout", k_bx_pack_gout, dim3(grid_for((long)(px * 8 * GL), 256, 8192)), dim3(256), 0, s, gy, g_last, B, in_nc, H, W, H2, W2, GL);
+  const unsigned* amax_bits = launch_bx_pack_gout(mode, gy, g_last, tail, B, in_nc, H, W, H2, W2, GL, s);
   size_t off[64];
   size_t o = 0;
-  for (int l = 0; l < nb; ++l) { off[l] = o; o += bx_layer_bytes(bx_cout(l, in_nc, nc, nb), bx_cin(l, in_nc, nc), 3); }
+  for (int l = 0; l < nb; ++l) { off[l] = o; o += bx_layer_bytes(bx_cout(l, in_nc, nc, nb), bx_cin(l, in_nc, nc), bx_planes(mode)); }
   const float* cur = g_last;
   int gin = GL;
   const bool need_data = gx || gsigma;
@@ -1205,8 +1292,10 @@ extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsi
       // `cur`: the gradient w.r.t. forward layer l's pre-activation output (the ReLU mask was applied by backward layer l + 1's epilogue)
       const float* a_l = (l == 0) ? a0 : hidden + (size_t)(l - 1) * px * 8 * Gc;
       const int ga = (l == 0) ? G0 : Gc;
-      DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * gin * hw, 256, 8192)), dim3(256), 0, s, cur, planar_g, B, gin, cout_f, hw);
-      DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * ga * hw, 256, 8192)), dim3(256), 0, s, a_l, planar_a, B, ga, 8 * ga, hw);
+      DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * gin * hw, 256, 8192)), dim3(256), 0, s, cur, planar_g, B, gin, cout_f, hw,
+                 amax_bits);
+      DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * ga * hw, 256, 8192)), dim3(256), 0, s, a_l, planar_a, B, ga, 8 * ga, hw,
+                 (const unsigned*)nullptr);
       // knob wgrad_f32 = 1: the f32-input GEMM (k_conv3x3_wgrad) instead of the split-bf16 one
       if (tune(TUNE_WGRAD_F32)) ffd_launch_wgrad(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
       else launch_wgrad_bf16x3(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
@@ -1215,14 +1304,14 @@ extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsi
     float* dst = (l == 0) ? g_a0 : (((nb - 1 - l) & 1) ? gB : gA);
     const int gout = (l == 0) ? G0 : Gc;
     const float* mask = (l >= 1) ? hidden + (size_t)(l - 1) * px * 8 * Gc : nullptr;
-    launch_bx_mt<6>((cin_f + 31) / 32, false, cur, dst, (const char*)packed_T + off[l], gin, gout, B, H2, W2, s, mask);
+    launch_bx_bwd_layer(mode, (cin_f + 31) / 32, cur, dst, (const char*)packed_T + off[l], gin, gout, B, H2, W2, s, mask);
     cur = dst;
     gin = gout;
   }
   if (gx)
     DPX_LAUNCH("k_bx_unpack_gin", k_bx_unpack_gin, dim3(grid_for((long)B * in_nc * H * W, 256, 8192)), dim3(256), 0, s, (const float*)g_a0, gx, B, in_nc, H,
-               W, H2, W2, G0);
-  if (gsigma) DPX_LAUNCH("k_bx_sigma_grad", k_bx_sigma_grad, dim3(B), dim3(256), 0, s, (const float*)g_a0, gsigma, in_nc, H2, W2, G0);
+               W, H2, W2, G0, amax_bits);
+  if (gsigma) launch_bx_sigma_grad(g_a0, gsigma, tail, amax_bits, B, in_nc, H2, W2, G0, s);
   return launch_status("dpx_ffdnet_backward_bf16_w");
 }
 

@@ -184,12 +184,13 @@ SIGNATURES = {
     "dpx_ffdnet_bf16_acts_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "dpx_ffdnet_forward_bf16_save": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dpx_ffdnet_bf16_packed_transposed_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "dpx_ffdnet_bf16_pack_transposed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dpx_ffdnet_bf16_pack_transposed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dpx_ffdnet_bf16_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "dpx_ffdnet_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dpx_ffdnet_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                 c_void_p]),
     "dpx_ffdnet_bf16_bwd_w_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dpx_ffdnet_backward_bf16_w": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                           c_void_p, c_void_p]),
+                                           c_int, c_void_p, c_void_p]),
     "dpx_admm_pnp_iter": (c_int, [c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dpx_admm_cg_pnp_iter": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
@@ -306,6 +307,33 @@ def f16_fallback(modules, where, stacklevel=3):
     warnings.warn(f"{where}: an operand left the binary16 range of the split-f16 FFDNet arithmetic; re-running on split-bf16 "
                   "(compute_mode = 'bf16x3', any range, ~1.4x slower) -- the network keeps that mode", RuntimeWarning, stacklevel=stacklevel)
     return True
+
+
+_bwd_f16_nets = []                                  # networks whose split-f16 backward pass launched in the autograd pass in progress
+
+
+def note_f16_backward(net):
+    """A split-f16 backward pass of ``net`` (dpx_ffdnet_backward_bf16[_w], mode 3) has been launched inside the running autograd pass: when
+    that pass ends the range trap is read ONCE (one synchronisation per backward pass, none per layer); if a scaled gradient left the
+    binary16 range the gradients are invalid -- the networks concerned fall back to the split-bf16 backward arithmetic for good and
+    F16RangeError comes out of ``loss.backward()`` (dp.train's loop repeats the step; anybody else's loop should)."""
+    import torch
+    if not _bwd_f16_nets:
+        torch.autograd.Variable._execution_engine.queue_callback(_check_f16_backward)
+    if not any(m is net for m in _bwd_f16_nets):
+        _bwd_f16_nets.append(net)
+
+
+def _check_f16_backward():
+    nets = list(_bwd_f16_nets)
+    del _bwd_f16_nets[:]
+    if lib().query("dpx_ffdnet_f16_overflow", 1):
+        for m in nets:
+            m.backward_mode = "bf16x3"
+        raise F16RangeError("backward: an operand (a gradient scaled to max |g| in [8, 16), a weight, or an activation of a forward pass not "
+                            "checked since) left the binary16 range in the split-f16 arithmetic of the FFDNet layers -- the gradients of this "
+                            "backward pass are invalid.  The network's backward pass now runs split-bf16 (`backward_mode = 'bf16x3'`): repeat "
+                            "the step")
 
 
 class solve_scope:

@@ -11,9 +11,12 @@ iterations -- is the solver's own HIP path (algo/autodiff.py); this module only 
 import json
 import math
 import os
+import warnings
 
 import torch
 import torch.nn.functional as F
+
+from .. import _backend as be
 
 
 def _batches(dataset, bs, shuffle, generator):
@@ -77,8 +80,15 @@ class TrainLoop:
     def run_epoch(self, step_fn, batches):
         tot_l, tot_p, n = 0.0, 0.0, 0
         for batch in batches:
-            gt, _inp, pred = step_fn(batch)
-            lv, pv = self.step(gt, pred)
+            for attempt in (0, 1):
+                gt, _inp, pred = step_fn(batch)
+                try:
+                    lv, pv = self.step(gt, pred)
+                    break
+                except be.F16RangeError as e:             # a split-f16 backward pass left the binary16 range: the networks concerned
+                    if attempt:                            # have fallen back to split-bf16 (be.note_f16_backward) -- the step is repeated
+                        raise
+                    warnings.warn(f"{e} -- repeating the step", RuntimeWarning, stacklevel=2)
             tot_l, tot_p, n = tot_l + lv, tot_p + pv, n + 1
         rec = {"epoch": self.epoch, "loss": tot_l / max(n, 1), "psnr": tot_p / max(n, 1), "steps": n}
         self.history.append(rec)

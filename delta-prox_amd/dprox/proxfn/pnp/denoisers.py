@@ -141,6 +141,11 @@ class FFDNet(RefKeyed):
         # "bf16x3" -- the enclosing solve() / denoise() is re-run on the split-bf16 arithmetic and the network keeps that mode
         # (a RuntimeWarning says so); "raise" -- be.F16RangeError
         self.f16_fallback = os.environ.get("DPX_F16_FALLBACK", "bf16x3")
+        # arithmetic of the backward pass on the split kernels (autograd through the network): "auto" -- split-f16 on gradients scaled by a
+        # power of two (dpx_ffdnet_backward_bf16, mode 3: half the matrix work) when the forward pass runs split-f16, else split-bf16;
+        # "f16x2" / "bf16x3" force one.  A scaled gradient that leaves the binary16 range on its way through the stack (2^12 of headroom)
+        # makes that backward pass raise be.F16RangeError and the network fall back to "bf16x3" (be.note_f16_backward)
+        self.backward_mode = os.environ.get("DPX_FFDNET_BWD_MODE", "auto")
         self._packed_bf16 = None
 
     @property
@@ -206,16 +211,26 @@ class FFDNet(RefKeyed):
             self._packed_T = (key, blob)
         return self._packed_T[1]
 
-    def packed_T_bf16(self):
-        """the backward-data layers' weights for the split kernels (dpx_ffdnet_bf16_pack_transposed), cached per weight version"""
+    def backward_mode_id(self):
+        """`mode` of dpx_ffdnet_backward_bf16[_w] for this network's next backward pass: 3 (split-f16, scaled gradients) or 6 (split-bf16)"""
+        bm = self.backward_mode
+        if bm == "auto":
+            bm = "f16x2" if self.compute_mode in be.F16_MODES else "bf16x3"
+        if bm not in ("f16x2", "bf16x3"):
+            raise ValueError(f"FFDNet.backward_mode: 'auto', 'f16x2' or 'bf16x3', got {self.backward_mode!r}")
+        return 3 if bm == "f16x2" else 6
+
+    def packed_T_bf16(self, mode=6):
+        """the backward-data layers' weights for the split kernels (dpx_ffdnet_bf16_pack_transposed; mode 6: split-bf16 planes, 3: split-f16),
+        cached per weight version and mode"""
         dev = self.weights[0].device
-        key = (self._weights_version(), str(dev))
+        key = (self._weights_version(), str(dev), mode)
         if getattr(self, "_packed_T_bf16", None) is None or self._packed_T_bf16[0] != key:
             L = be.lib()
             blob = torch.empty(L.query("dpx_ffdnet_bf16_packed_transposed_bytes", self.in_nc, self.nc, self.nb), dtype=torch.uint8, device=dev)
             ws = [w.detach().float().contiguous() for w in self.weights]
             pw = (ctypes.c_void_p * self.nb)(*[w.data_ptr() for w in ws])
-            L.call("dpx_ffdnet_bf16_pack_transposed", be.ptr(blob), pw, self.in_nc, self.nc, self.nb, be.stream())
+            L.call("dpx_ffdnet_bf16_pack_transposed", be.ptr(blob), pw, self.in_nc, self.nc, self.nb, mode, be.stream())
             self._packed_T_bf16 = (key, blob)
         return self._packed_T_bf16[1]
 
@@ -277,8 +292,9 @@ class _FFDNetSplitFn(torch.autograd.Function):
     """FFDNet under autograd on the split kernels (frozen weights, or -- parameters passed -- trainable ones: the weight / bias
     gradients then come from dpx_ffdnet_backward_bf16_w): the forward pass keeps every layer's output (C8 layout),
     the backward pass is the same convolution kernel on flipped / transposed split weights with the ReLU masks in its epilogue
-    (dpx_ffdnet_forward_bf16_save / dpx_ffdnet_backward_bf16).  The backward pass always runs split-bf16 (gradients of a mean
-    loss sit far below the binary16 range); a "f16x2" forward that meets an operand outside that range is caught by the range trap."""
+    (dpx_ffdnet_forward_bf16_save / dpx_ffdnet_backward_bf16).  The backward pass runs in `net.backward_mode`: split-bf16, or -- with a
+    split-f16 forward -- split-f16 on gradients scaled by a power of two (gradients of a mean loss sit far below the binary16 range; the
+    pass is linear in them); an operand outside the binary16 range is caught by the range trap in either direction."""
 
     @staticmethod
     def forward(ctx, net, x, sig, *params):
@@ -307,20 +323,23 @@ class _FFDNetSplitFn(torch.autograd.Function):
         gs = torch.empty(B, dtype=torch.float32, device=gy.device) if ctx.needs_input_grad[2] else None
         nb = net.nb
         need = ctx.needs_input_grad[3:]
+        bmode = net.backward_mode_id()
+        if bmode == 3 and (any(need) or gx is not None or gs is not None):
+            be.note_f16_backward(net)                      # (checked once, when this backward pass of the autograd engine ends)
         if any(need):                                      # weights / biases were passed and are trained: fill their gradients
             gws = [torch.empty_like(net.weights[i], dtype=torch.float32) if (need[i] or need[nb + i]) else None for i in range(nb)]
             gbs = [torch.empty_like(net.biases[i], dtype=torch.float32) if gws[i] is not None else None for i in range(nb)]
             pw = (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in gws])
             pb = (ctypes.c_void_p * nb)(*[None if t is None else t.data_ptr() for t in gbs])
             ws = ops.workspace("ffdnet_bf16_bwd_w", L.query("dpx_ffdnet_bf16_bwd_w_ws_bytes", B, net.in_nc, net.nc, H, W), gy.device)
-            L.call("dpx_ffdnet_backward_bf16_w", be.ptr(gy), be.ptr(gx), be.ptr(gs), pw, pb, be.ptr(net.packed_T_bf16()), be.ptr(acts), net.in_nc,
-                   net.nc, nb, B, H, W, be.ptr(ws), be.stream())
+            L.call("dpx_ffdnet_backward_bf16_w", be.ptr(gy), be.ptr(gx), be.ptr(gs), pw, pb, be.ptr(net.packed_T_bf16(bmode)), be.ptr(acts), net.in_nc,
+                   net.nc, nb, bmode, B, H, W, be.ptr(ws), be.stream())
             return (None, gx, gs, *gws, *gbs)
         if gx is None and gs is None:
             return (None, None, None) + (None,) * len(need)
         ws = ops.workspace("ffdnet_bf16_bwd", L.query("dpx_ffdnet_bf16_bwd_ws_bytes", B, net.in_nc, net.nc, H, W), gy.device)
-        L.call("dpx_ffdnet_backward_bf16", be.ptr(gy), be.ptr(gx), be.ptr(gs), be.ptr(net.packed_T_bf16()), be.ptr(acts), net.in_nc, net.nc, net.nb,
-               B, H, W, be.ptr(ws), be.stream())
+        L.call("dpx_ffdnet_backward_bf16", be.ptr(gy), be.ptr(gx), be.ptr(gs), be.ptr(net.packed_T_bf16(bmode)), be.ptr(acts), net.in_nc, net.nc, net.nb,
+               bmode, B, H, W, be.ptr(ws), be.stream())
         return (None, gx, gs) + (None,) * len(need)
 
 

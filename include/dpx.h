@@ -567,24 +567,26 @@ int dpx_ffdnet_forward_bf16(const float* x, float* y, const float* sigma, const 
 /* Reverse mode of the same stack on the split kernels, frozen weights (gradients w.r.t. the image and sigma; the reference lets
  * autograd differentiate network_ffdnet.py:54-68): a forward pass that keeps every layer's output in `acts`
  * (dpx_ffdnet_bf16_acts_bytes; mode 6 or 3), the backward-data layers' weights (dpx_ffdnet_bf16_pack_transposed: flipped /
- * transposed, split-bf16 planes, no bias; dpx_ffdnet_bf16_packed_transposed_bytes) and the backward pass -- the same kernel on
- * those weights with the ReLU masks [a_l > 0] in its epilogue, always in split-bf16 (gradients may be far below the binary16
- * range).  gx / gsigma: either may be NULL.                                                                                    */
+ * transposed, split planes of `mode`, no bias; dpx_ffdnet_bf16_packed_transposed_bytes) and the backward pass -- the same kernel on
+ * those weights with the ReLU masks [a_l > 0] in its epilogue.  Its `mode` (the one packed_T was packed for): 6 = split-bf16, any
+ * range; 3 = split-f16 (half the matrix work) on gradients multiplied by a power of two that brings max |gy| into [8, 16) -- gx,
+ * d/dsigma (and dW, db below) leave multiplied by its inverse, exact; an operand that leaves the binary16 range on the way sets
+ * dpx_ffdnet_f16_overflow (the results are then invalid: run mode 6).  gx / gsigma: either may be NULL.                         */
 size_t dpx_ffdnet_bf16_acts_bytes(int B, int in_nc, int nc, int nb, int H, int W);
 int dpx_ffdnet_forward_bf16_save(const float* x, float* y, const float* sigma, const void* packed, int in_nc, int nc, int nb, int mode,
                                  int B, int H, int W, void* acts, dpx_stream_t stream);
 size_t dpx_ffdnet_bf16_packed_transposed_bytes(int in_nc, int nc, int nb);
-int dpx_ffdnet_bf16_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, dpx_stream_t stream);
+int dpx_ffdnet_bf16_pack_transposed(void* packed_T, const float* const* w, int in_nc, int nc, int nb, int mode, dpx_stream_t stream);
 size_t dpx_ffdnet_bf16_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W);
 int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigma, const void* packed_T, const void* acts, int in_nc, int nc, int nb,
-                             int B, int H, int W, void* ws, dpx_stream_t stream);
+                             int mode, int B, int H, int W, void* ws, dpx_stream_t stream);
 /* ... and with the weight / bias gradients (deep_prior(..., trainable=True), reference proxfn/pnp/prior.py:52-60: the denoiser's
  * parameters join the optimiser): forward and backward-data as above on the split kernels, the weight-gradient GEMM of every layer on
  * the f32-input kernel of dpx_ffdnet_backward, fed planar copies of the layer's two C8 operands.  gw[l]: [cout_l][cin_l][9] (cin_0 =
  * 4 in_nc + 1), gb[l]: [cout_l]; gw[l] == NULL skips layer l; gx / gsigma may be NULL.                                       */
 size_t dpx_ffdnet_bf16_bwd_w_ws_bytes(int B, int in_nc, int nc, int H, int W);
 int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsigma, float* const* gw, float* const* gb, const void* packed_T,
-                               const void* acts, int in_nc, int nc, int nb, int B, int H, int W, void* ws, dpx_stream_t stream);
+                               const void* acts, int in_nc, int nc, int nb, int mode, int B, int H, int W, void* ws, dpx_stream_t stream);
 
 /* One plug-and-play ADMM iteration in one call (algo/admm.py:49-59 with deep_prior(FFDNet) as term `ext`): rhs stage, Fourier
  * solve with the fp64 data spectrum, z / dual stage of the closed-form terms, denoiser (mode 0: f32-input MFMA, packed by

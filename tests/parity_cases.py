@@ -1412,6 +1412,18 @@ def case_ffdnet_split_backward(device, tiny=False):
             assert_close(res[mode][0], res["f32"][0], TOL, f"split backward {shape} {mode}: forward")
             _assert_grad_close(res[mode][1], res["f32"][1], f"split backward {shape} {mode}: d/dx", tol=1e-5)
             _assert_grad_close(res[mode][2], res["f32"][2], f"split backward {shape} {mode}: d/dsigma", tol=1e-5)
+        # the split-f16 backward pass scales the incoming gradient by a power of two (max |gy| -> [8, 16)) and the results back: gradients of
+        # the size a mean loss produces (1e-9 of the above, far below binary16's range) and huge ones come out as the same numbers times
+        # that factor; the arithmetic of the two passes can also be chosen apart (a split-bf16 forward with a split-f16 backward and v.v.)
+        assert col.model.backward_mode == "auto" and col.model.backward_mode_id() == 3
+        for fwd, bwd, factor in (("f16x2", "auto", 1e-9), ("f16x2", "auto", 3e7), ("bf16x3", "f16x2", 1e-9), ("f16x2", "bf16x3", 1.0)):
+            col.model.compute_mode, col.model.backward_mode = fwd, bwd
+            x = T(x0, device).requires_grad_(True)
+            sig = T(s0, device).requires_grad_(True)
+            (col.denoise(x, sig) * T(w0, device)).sum().mul(factor).backward()
+            _assert_grad_close(x.grad.cpu().numpy() / np.float32(factor), res["f32"][1], f"split backward {shape} {fwd}/{bwd} x {factor}: d/dx", tol=1e-5)
+            _assert_grad_close(sig.grad.cpu().numpy() / np.float32(factor), res["f32"][2], f"split backward {shape} {fwd}/{bwd} x {factor}: d/dsigma", tol=1e-5)
+        col.model.compute_mode, col.model.backward_mode = "f16x2", "auto"
         # trainable weights: forward / backward-data on the split kernels + the f32-input weight-gradient GEMM on planar copies of their
         # C8 planes (dpx_ffdnet_backward_bf16_w) against everything on the f32-input kernels (dpx_ffdnet_backward): every layer's dW, db
         col.model.compute_mode = "f16x2"
@@ -1435,6 +1447,31 @@ def case_ffdnet_split_backward(device, tiny=False):
         col.requires_grad_(False)
         col.model.train_f32 = False
     col.model.compute_mode = "f16x2"
+    # the range trap of the backward pass: weights that multiply a gradient by far more than the 2^12 of headroom (the forward pass on the
+    # split-bf16 arithmetic, which has fp32's range) -- loss.backward() raises, the network's backward pass falls back to split-bf16, and
+    # the repeated pass is right
+    from dprox import _backend as be
+    net = FFDNet(in_nc=3, out_nc=3, nc=16, nb=3, act_mode="R").load_layers(
+        [(w * 600.0, b) for w, b in synthetic.ffdnet_weights(5, 3, 3, 16, 3)]).to(device)
+    net.requires_grad_(False)
+    net.compute_mode, net.backward_mode = "bf16x3", "f16x2"
+    x0 = rng.rand(1, 3, 12, 16).astype(np.float32)
+    w0 = rng.randn(1, 3, 12, 16).astype(np.float32)
+    x = T(x0, device).requires_grad_(True)
+    try:
+        (net(x, T(np.float32([0.05]), device)) * T(w0, device)).sum().backward()
+        raise AssertionError("a split-f16 backward pass whose gradients grow by 1e8 must trip the range trap")
+    except be.F16RangeError:
+        pass
+    assert net.backward_mode == "bf16x3"
+    x = T(x0, device).requires_grad_(True)
+    (net(x, T(np.float32([0.05]), device)) * T(w0, device)).sum().backward()
+    g_split = x.grad.cpu().numpy()
+    net.compute_mode = "f32"
+    x = T(x0, device).requires_grad_(True)
+    (net(x, T(np.float32([0.05]), device)) * T(w0, device)).sum().backward()
+    assert np.isfinite(g_split).all()
+    _assert_grad_close(g_split, x.grad.cpu().numpy(), "split backward after the range trap's fallback: d/dx", tol=1e-5)
 
 
 def case_ffdnet_weight_grads(device):
