@@ -18,6 +18,7 @@
 // workgroup barrier per slot.  LDS: 39 + 57 + 54 KB (MT = 3): one workgroup per CU, two waves per SIMD.
 #include "dpx_common.h"
 #include "dpx_prox_dev.h"
+#include "dpx_mma_dev.h"
 
 // Tuning probes (wrong results by design; DESIGN.md section 3 has what they measured): 1 tap-independent fragment reads,
 // 2 no split pass, 4 no DMA / waits / barriers, 8 no DMA (barriers stay), 16 DMA never waited for,
@@ -27,7 +28,13 @@
 #endif
 namespace dpx {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ unsigned g_f16_overflow = 0u;                              // set by any split-f16 layer that met |x| > 6e4 (NaN counts)
+// (for the kernels of other translation units -- dpx_wgrad_c8.hip -- which receive the word's address as an argument)
+unsigned* f16_overflow_flag() {
+  static unsigned* p = nullptr;
+  if (!p) hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_f16_overflow));
+  return p;
+}
 
 constexpr int BX_TW = 32, BX_TH = 16, BX_ROWS = BX_TH + 2, BX_COLS = BX_TW + 2;
 constexpr int BX_UNITS = 2 * BX_ROWS * BX_COLS;                      // (k-group, row, col) units of 8 channels: 1224
@@ -46,70 +53,6 @@ static inline size_t bx_layer_bytes(int cin, int cout, int NPW = 3) {
   const int chunks = (cin + 15) / 16, MT = (cout + 31) / 32;
   return (size_t)chunks * 3 * bx_slot_bytes(MT, NPW) + (size_t)MT * 32 * 4 + 64;
 }
-
-// exact three-way split by truncation; every part is returned as fp32 bits whose low 16 bits are zero
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-  h = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(h);
-  m = __float_as_uint(r1) & 0xffff0000u;
-  l = __float_as_uint(r1 - __uint_as_float(m)) & 0xffff0000u;
-}
-__device__ __forceinline__ unsigned pack_hi16(unsigned lo_elem, unsigned hi_elem) { return (hi_elem & 0xffff0000u) | (lo_elem >> 16); }
-// round-to-nearest-even bf16 (MODE = 1, plain bf16 operands), as fp32 bits with a zero low half
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
-}
-
-// MODE = 3 ("split-f16"): x = hi + lo / 2048 with hi = half(x) (11 significant bits, round to nearest) and lo = half((x - hi) * 2048)
-// (the next 11 bits, scaled by 2^11 so that it stays in the normal range of binary16).  Three products  wh ah | wh al | wl ah
-// (dropped: wl al <= 2^-22 |w a|); the two cross terms go to their own accumulator, which enters the result times 2^-11.
-// Measured on the FFDNet stack against float64: 9.7e-8 (the f32-input instruction: 1.1e-7, split-bf16: 5.8e-8).  Operands must stay
-// below the binary16 range (6.5e4): the split pass counts the values that do not (dpx_ffdnet_f16_overflow).
-// Both parts as fp32-style words whose upper 16 bits hold the binary16 pattern (so that pack_hi16 packs them like the bf16 parts).
-constexpr float F16_LO_SCALE = 2048.f;
-__device__ unsigned g_f16_overflow = 0u;                              // set by any split-f16 layer that met |x| > 6e4
-__device__ __forceinline__ unsigned f16_word(float x) {
-  const _Float16 h = (_Float16)x;
-  unsigned short b;
-  __builtin_memcpy(&b, &h, 2);
-  return (unsigned)b << 16;
-}
-__device__ __forceinline__ float f16_word_value(unsigned w) {
-  const unsigned short b = (unsigned short)(w >> 16);
-  _Float16 h;
-  __builtin_memcpy(&h, &b, 2);
-  return (float)h;
-}
-__device__ __forceinline__ void split2_f16(float x, unsigned& h, unsigned& l) {
-  h = f16_word(x);
-  l = f16_word((x - f16_word_value(h)) * F16_LO_SCALE);
-}
-// two neighbouring elements at once, as the packed dwords of the operand tile (element 0 in the low half): packed conversions
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2_f16_pair(float a, float b, unsigned& hw, unsigned& lw) {
-  const f32x2_t x = {a, b};
-  const f16x2_t h = __builtin_convertvector(x, f16x2_t);
-  const f32x2_t r = (x - __builtin_convertvector(h, f32x2_t)) * F16_LO_SCALE;
-  const f16x2_t l = __builtin_convertvector(r, f16x2_t);
-  __builtin_memcpy(&hw, &h, 4);
-  __builtin_memcpy(&lw, &l, 4);
-}
-
-#ifdef DPX_EMULATED
-__device__ inline f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) { return emul_mfma_32x32x16_bf16(a, b, c); }
-__device__ inline f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) { return emul_mfma_32x32x16_f16(a, b, c); }
-#else
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 mfma_f16(uint4 a, uint4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-}
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 mfma_bf16(uint4 a, uint4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-#endif
 
 // w [cout][cin][9] fp32, b [cout] (nullable) -> packed layer.  mode 6: three exact planes; mode 1: plane 0 = RNE bf16, others 0.
 // tr: the backward-data layer of w -- (cin, cout) are ITS channel counts (the forward layer's cout, cin), the tensor is the forward
@@ -594,6 +537,7 @@ __global__ void k_bx_pack_gout(const float* __restrict__ gy, float* __restrict__
       if (yy < H && xx < W) v = gy[(((long)b * C + c) * H + yy) * W + xx] * sc;
     }
     g[i] = v;
+    if (i == 0 && amax_bits) ((float*)amax_bits)[1] = bx_grad_unscale(amax_bits);       // (the weight-gradient reduction's factor: word 1 of the tail)
   }
 }
 // adjoint of k_bx_pack_in's image part (replicate-pad to even size + pixel-unshuffle): the padded row / column folds onto the last one
@@ -1211,7 +1155,10 @@ __global__ void __launch_bounds__(CW * 64, 1) k_wgrad_bf16x3(const float* __rest
 
 namespace dpx {
 void ffd_launch_wgrad_reduce(const float* part, const float* part_b, float* gw, float* gb, int NG, int CoN, int co0, int Cin, int CoP, int CiP,
-                             hipStream_t s);   // dpx_ffdnet.hip
+                             const float* mul, hipStream_t s);   // dpx_ffdnet.hip
+size_t wgrad_c8_ws_floats(int cout_max, int cin_max);                // dpx_wgrad_c8.hip
+void launch_wgrad_c8(int mode, const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Gg, int Ga, int B, int H, int W,
+                     float* ws, const float* mul, hipStream_t s);
 }
 static size_t wgb_ws_floats(int nc, int in_nc) {
   const int cop = ((nc > 4 * in_nc ? nc : 4 * in_nc) + 31) / 32 * 32, cip = ((nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1) + 31) / 32 * 32;
@@ -1244,13 +1191,15 @@ static void launch_wgrad_bf16x3(const float* G, const float* A, float* gw, float
   }
 #undef DPX_WGB
   NG *= CW;                                               // (partial slices)
-  ffd_launch_wgrad_reduce(part, part_b, gw, gb, NG, Cout, 0, Cin_w, CoP, CiP, s);
+  ffd_launch_wgrad_reduce(part, part_b, gw, gb, NG, Cout, 0, Cin_w, CoP, CiP, nullptr, s);
 }
 
 extern "C" size_t dpx_ffdnet_bf16_bwd_w_ws_bytes(int B, int in_nc, int nc, int H, int W) {
   const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
   const size_t gmax = (size_t)8 * groups16(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1);
-  const size_t wg = ffd_wgrad_ws_floats(nc, in_nc) > wgb_ws_floats(nc, in_nc) ? ffd_wgrad_ws_floats(nc, in_nc) : wgb_ws_floats(nc, in_nc);
+  size_t wg = ffd_wgrad_ws_floats(nc, in_nc) > wgb_ws_floats(nc, in_nc) ? ffd_wgrad_ws_floats(nc, in_nc) : wgb_ws_floats(nc, in_nc);
+  const size_t wc = wgrad_c8_ws_floats(nc > 4 * in_nc ? nc : 4 * in_nc, nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1);
+  if (wc > wg) wg = wc;
   return dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W) + (2 * (px * gmax + 64) + wg) * sizeof(float);       // (+ 64: the planar copies' guard floats)
 }
 
@@ -1262,6 +1211,7 @@ extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsi
               "dpx_ffdnet_backward_bf16_w: unsupported configuration (in_nc=%d nc=%d nb=%d mode=%d)", in_nc, nc, nb, mode);
   hipStream_t s = (hipStream_t)stream;
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  DPX_REQUIRE((size_t)12 * H2 * W2 * 32 < ((size_t)1 << 32), "dpx_ffdnet_backward_bf16_w: plane %dx%d too large", H, W);
   const size_t px = (size_t)B * H2 * W2;
   const long hw = (long)H2 * W2;
   const int G0 = groups16(4 * in_nc + 1), Gc = groups16(nc), GL = groups16(4 * in_nc);
@@ -1292,13 +1242,18 @@ extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsi
       // `cur`: the gradient w.r.t. forward layer l's pre-activation output (the ReLU mask was applied by backward layer l + 1's epilogue)
       const float* a_l = (l == 0) ? a0 : hidden + (size_t)(l - 1) * px * 8 * Gc;
       const int ga = (l == 0) ? G0 : Gc;
-      DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * gin * hw, 256, 8192)), dim3(256), 0, s, cur, planar_g, B, gin, cout_f, hw,
-                 amax_bits);
-      DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * ga * hw, 256, 8192)), dim3(256), 0, s, a_l, planar_a, B, ga, 8 * ga, hw,
-                 (const unsigned*)nullptr);
-      // knob wgrad_f32 = 1: the f32-input GEMM (k_conv3x3_wgrad) instead of the split-bf16 one
-      if (tune(TUNE_WGRAD_F32)) ffd_launch_wgrad(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
-      else launch_wgrad_bf16x3(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
+      // knob wgrad_f32 = 0: k_wgrad_c8 on the C8 planes themselves, in the arithmetic of this backward pass; 1 / 2: planar copies of the two
+      // operands and the f32-input GEMM (k_conv3x3_wgrad) / round 4's split-bf16 kernel (k_wgrad_bf16x3) on them
+      if (tune(TUNE_WGRAD_F32) == 0) {
+        launch_wgrad_c8(mode, cur, a_l, gw[l], gb[l], cout_f, cin_f, gin, ga, B, H2, W2, wg_ws, amax_bits ? (const float*)amax_bits + 1 : nullptr, s);
+      } else {
+        DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * gin * hw, 256, 8192)), dim3(256), 0, s, cur, planar_g, B, gin, cout_f, hw,
+                   amax_bits);
+        DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * ga * hw, 256, 8192)), dim3(256), 0, s, a_l, planar_a, B, ga, 8 * ga, hw,
+                   (const unsigned*)nullptr);
+        if (tune(TUNE_WGRAD_F32) == 1) ffd_launch_wgrad(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
+        else launch_wgrad_bf16x3(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
+      }
     }
     if (l == 0 && !need_data) break;
     float* dst = (l == 0) ? g_a0 : (((nb - 1 - l) & 1) ? gB : gA);

@@ -562,9 +562,12 @@ __global__ void __launch_bounds__(MT * 128) k_conv3x3_wgrad(const float* __restr
 }
 
 // gw[co0 + co][ci][tap] (co < CoN) = sum over the NG partial slices, in a fixed order
+// mul (device, nullable): every sum leaves multiplied by *mul (the inverse gradient scale of a split-f16 backward pass: a power of two)
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, const float* __restrict__ part_b, float* __restrict__ gw,
-                                                      float* __restrict__ gb, int NG, int CoN, int co0, int Cin, int CoP, int CiP, int ntap) {
+                                                      float* __restrict__ gb, int NG, int CoN, int co0, int Cin, int CoP, int CiP, int ntap,
+                                                      const float* __restrict__ mul) {
   __shared__ float shb[256];
+  const float ms = mul ? *mul : 1.f;
   const long nw = (long)CoN * Cin * ntap;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i % ntap), ci = (int)((i / ntap) % Cin), co = (int)(i / ((long)ntap * Cin));
@@ -578,7 +581,7 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
       for (int j = 0; j < 8; ++j) a8[j] += p0[(size_t)(g + j) * gs];
     }
     for (int j = 0; g < NG; ++g, ++j) a8[j] += p0[(size_t)g * gs];
-    if (gw) gw[(long)co0 * Cin * ntap + i] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    if (gw) gw[(long)co0 * Cin * ntap + i] = (((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]))) * ms;
   }
   // the bias gradients: one workgroup per output channel, a thread per slice, a fixed tree over the threads (one thread walking the NG
   // slices of a channel was the launch's critical path: 168 dependent round trips = 63 us behind a 15-us weight pass)
@@ -593,7 +596,7 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
       if ((int)threadIdx.x < w) shb[threadIdx.x] += shb[threadIdx.x + w];
       __syncthreads();
     }
-    if (threadIdx.x == 0) gb[co0 + co] = shb[0];
+    if (threadIdx.x == 0) gb[co0 + co] = shb[0] * ms;
   }
 }
 
@@ -641,7 +644,7 @@ static void launch_wgrad(const float* G, const float* A, float* gw, float* gb, i
     else if (dil == 3) launch_wgrad_mt<9, 3>(MT, grid, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty);
     else launch_wgrad_mt<9, 4>(MT, grid, s, G, A, part, part_b, Cout, co0, Cin_a, B, H2, W2, tx, ty);
     DPX_LAUNCH("k_wgrad_reduce", k_wgrad_reduce, dim3(grid_for((long)CoN * Cin_w * ntap + CoN, 256, 1024)), dim3(256), 0, s, (const float*)part,
-               (const float*)part_b, gw, gb, NG, CoN, co0, Cin_w, CoP, CiP, ntap);
+               (const float*)part_b, gw, gb, NG, CoN, co0, Cin_w, CoP, CiP, ntap, (const float*)nullptr);
   }
 }
 
@@ -653,9 +656,9 @@ void ffd_launch_wgrad(const float* G, const float* A, float* gw, float* gb, int 
   launch_wgrad(G, A, gw, gb, Cout, Cin_w, Cin_a, B, H2, W2, ws, s);
 }
 void ffd_launch_wgrad_reduce(const float* part, const float* part_b, float* gw, float* gb, int NG, int CoN, int co0, int Cin, int CoP, int CiP,
-                             hipStream_t s) {
+                             const float* mul, hipStream_t s) {
   DPX_LAUNCH("k_wgrad_reduce", k_wgrad_reduce, dim3(grid_for((long)CoN * Cin * 9 + CoN, 256, 1024)), dim3(256), 0, s, part, part_b, gw, gb, NG, CoN, co0,
-             Cin, CoP, CiP, 9);
+             Cin, CoP, CiP, 9, mul);
 }
 }  // namespace dpx
 

@@ -189,6 +189,9 @@ SIGNATURES = {
     "dpx_ffdnet_backward_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                  c_void_p]),
     "dpx_ffdnet_bf16_bwd_w_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dpx_conv3x3_wgrad_c8_ws_bytes": (c_size_t, [c_int, c_int]),
+    "dpx_conv3x3_wgrad_c8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                     c_void_p]),
     "dpx_ffdnet_backward_bf16_w": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_int, c_void_p, c_void_p]),
     "dpx_admm_pnp_iter": (c_int, [c_void_p, c_void_p, POINTER(Term), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,

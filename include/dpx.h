@@ -585,6 +585,15 @@ int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigma, const vo
  * the f32-input kernel of dpx_ffdnet_backward, fed planar copies of the layer's two C8 operands.  gw[l]: [cout_l][cin_l][9] (cin_0 =
  * 4 in_nc + 1), gb[l]: [cout_l]; gw[l] == NULL skips layer l; gx / gsigma may be NULL.                                       */
 size_t dpx_ffdnet_bf16_bwd_w_ws_bytes(int B, int in_nc, int nc, int H, int W);
+/* The weight-gradient kernel of that pass on its own: dW[co][ci][dy][dx] = sum_{b,y,x} g[b][co][y][x] a[b][ci][y+dy-1][x+dx-1] (zero outside
+ * the image), db[co] = sum g -- what autograd forms for a 3x3 convolution of network_ffdnet.py:54-68 -- from the C8 planes
+ * [B][groups][H][W][8] of the layer's output gradient g and input a, K = pixels on the 16-bit matrix instruction at fp32 accuracy
+ * (mode 6: split-bf16, any range; 3: split-f16, |g|, |a| < 6e4 -- dpx_ffdnet_f16_overflow -- and g scaled towards 1 .. 16 by the caller).
+ * cout <= 8 g_groups, cin <= 8 a_groups, both <= 96, in blocks of 32: equal counts, or one side a single block.  gw [cout][cin][9],
+ * gb [cout]; mul (device, nullable): both leave multiplied by *mul.  Partial sums per workgroup + fixed-order reduction: bit-reproducible. */
+size_t dpx_conv3x3_wgrad_c8_ws_bytes(int cout, int cin);
+int dpx_conv3x3_wgrad_c8(const float* g, const float* a, float* gw, float* gb, int cout, int cin, int g_groups, int a_groups, int mode,
+                         const float* mul, int B, int H, int W, void* ws, dpx_stream_t stream);
 int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsigma, float* const* gw, float* const* gb, const void* packed_T,
                                const void* acts, int in_nc, int nc, int nb, int mode, int B, int H, int W, void* ws, dpx_stream_t stream);
 

@@ -58,6 +58,7 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, h
 #define HIP_SYMBOL(x) (&(x))
 static inline hipError_t hipMemcpyFromSymbol(void* d, const void* sym, size_t n) { memcpy(d, sym, n); return 0; }
 static inline hipError_t hipMemcpyToSymbol(void* sym, const void* s, size_t n) { memcpy(sym, s, n); return 0; }
+static inline hipError_t hipGetSymbolAddress(void** p, const void* sym) { *p = (void*)sym; return 0; }
 
 namespace emul {
 struct Idx { unsigned x, y, z; };

@@ -1430,22 +1430,27 @@ def case_ffdnet_split_backward(device, tiny=False):
         col.requires_grad_(True)
         wres = {}
         from dprox import _backend as be
-        # (True: everything on the f32-input kernels; False: split kernels + the split-bf16 weight-gradient GEMM k_wgrad_bf16x3;
-        #  "gemm_f32": split kernels + the f32-input weight-gradient GEMM on the same planar copies, knob wgrad_f32)
-        for f32 in (True, False, "gemm_f32"):
+        # (True: everything on the f32-input kernels; False: split kernels + the weight-gradient kernel on their C8 planes, k_wgrad_c8, in the
+        #  backward pass's arithmetic -- split-f16 on scaled gradients; "c8_bf16x3": the same with a split-bf16 backward pass;
+        #  "gemm_f32" / "planar_bf16x3": planar copies of the operands + the f32-input GEMM / round 4's split-bf16 kernel, knob wgrad_f32 = 1 / 2)
+        knob = {True: 0, False: 0, "c8_bf16x3": 0, "gemm_f32": 1, "planar_bf16x3": 2}
+        for f32 in (True, False, "c8_bf16x3", "gemm_f32", "planar_bf16x3"):
             col.model.train_f32 = f32 is True
+            col.model.backward_mode = "bf16x3" if f32 in ("c8_bf16x3", "planar_bf16x3") else "auto"
             col.zero_grad()
             x = T(x0, device).requires_grad_(True)
-            with be.tuned(wgrad_f32=int(f32 == "gemm_f32")):
+            with be.tuned(wgrad_f32=knob[f32]):
                 y = col.denoise(x, T(s0, device))
                 assert ("Split" in y.grad_fn.name()) == (f32 is not True)
-                (y * T(w0, device)).sum().backward()
-            wres[f32] = [p.grad.cpu().numpy() for p in col.model.weights + col.model.biases] + [x.grad.cpu().numpy()]
-        for other in (False, "gemm_f32"):
+                (y * T(w0, device)).sum().mul(1.0 if f32 is True else 1e-6).backward()       # (a mean loss's magnitudes on the split paths)
+            sc = np.float32(1.0 if f32 is True else 1e-6)
+            wres[f32] = [p.grad.cpu().numpy() / sc for p in col.model.weights + col.model.biases] + [x.grad.cpu().numpy() / sc]
+        for other in (False, "c8_bf16x3", "gemm_f32", "planar_bf16x3"):
             for k, (a_, b_) in enumerate(zip(wres[other], wres[True])):
                 _assert_grad_close(a_, b_, f"split training path ({other}) {shape}: gradient {k} (weights, biases, d/dx)", tol=1e-5)
         col.requires_grad_(False)
         col.model.train_f32 = False
+        col.model.backward_mode = "auto"
     col.model.compute_mode = "f16x2"
     # the range trap of the backward pass: weights that multiply a gradient by far more than the 2^12 of headroom (the forward pass on the
     # split-bf16 arithmetic, which has fp32's range) -- loss.backward() raises, the network's backward pass falls back to split-bf16, and
@@ -1472,6 +1477,60 @@ def case_ffdnet_split_backward(device, tiny=False):
     (net(x, T(np.float32([0.05]), device)) * T(w0, device)).sum().backward()
     assert np.isfinite(g_split).all()
     _assert_grad_close(g_split, x.grad.cpu().numpy(), "split backward after the range trap's fallback: d/dx", tol=1e-5)
+
+
+def case_wgrad_c8(device, tiny=False):
+    """dpx_conv3x3_wgrad_c8 (k_wgrad_c8: the weight-gradient GEMM on the C8 planes, K = pixels) against the float64 sums it stands for
+    (what autograd forms for a 3x3 convolution of network_ffdnet.py:54-68), both arithmetic modes, every instantiated channel-block shape,
+    planes with partial / several column strips and fewer rows than a workgroup's share; the `mul` factor; bit-identical repeats."""
+    import ctypes
+    from dprox import _backend as be
+    L = be.lib()
+    rng = np.random.RandomState(4242)
+    #         cout cin  (first layer, hidden, last layer of the colour and gray stacks; small widths)
+    shapes = ((96, 96), (96, 13), (12, 96), (64, 64), (64, 5), (4, 64), (16, 16), (16, 64), (48, 16))
+    planes = ((2, 9, 11), (1, 37, 70), (3, 5, 33))
+    if tiny:
+        shapes, planes = ((96, 96), (64, 64), (16, 13)), ((1, 4, 35),)
+    g16 = lambda c: 2 * ((c + 15) // 16)                       # channel groups of 8, whole 16-channel chunks (the split kernels' C8 planes)
+    for cout, cin in shapes:
+        for B, H, W in planes:
+            Gg, Ga = g16(cout), g16(cin)
+            g = np.zeros((B, Gg * 8, H, W), np.float32)
+            a = np.zeros((B, Ga * 8, H, W), np.float32)
+            g[:, :cout] = rng.randn(B, cout, H, W) * 3.0
+            a[:, :cin] = np.maximum(rng.randn(B, cin, H, W), 0) * 0.7      # (post-ReLU activations)
+            c8 = lambda t: np.ascontiguousarray(t.reshape(B, -1, 8, H, W).transpose(0, 1, 3, 4, 2))
+            ap = np.pad(a.astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1)))
+            ref_w = np.zeros((cout, cin, 3, 3))
+            for dy in range(3):
+                for dx in range(3):
+                    ref_w[:, :, dy, dx] = np.einsum("bohw,bihw->oi", g[:, :cout].astype(np.float64), ap[:, :cin, dy:dy + H, dx:dx + W])
+            ref_b = g[:, :cout].astype(np.float64).sum(axis=(0, 2, 3))
+            gt, at = T(c8(g), device), T(c8(a), device)
+            ws = torch.empty(L.query("dpx_conv3x3_wgrad_c8_ws_bytes", cout, cin), dtype=torch.uint8, device=device)
+            mul = T(np.float32([0.25]), device)
+            for mode in (3, 6):
+                outs = []
+                for rep in range(2):
+                    gw = torch.full((cout, cin, 3, 3), float("nan"), device=device)
+                    gb = torch.full((cout,), float("nan"), device=device)
+                    L.call("dpx_conv3x3_wgrad_c8", be.ptr(gt), be.ptr(at), be.ptr(gw), be.ptr(gb), cout, cin, Gg, Ga, mode,
+                           be.ptr(mul) if rep else None, B, H, W, be.ptr(ws), be.stream())
+                    outs.append((gw.cpu().numpy().astype(np.float64) * (4.0 if rep else 1.0), gb.cpu().numpy().astype(np.float64) * (4.0 if rep else 1.0)))
+                what = f"wgrad_c8 {cout}<-{cin} {B}x{H}x{W} mode {mode}"
+                assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), what + ": `mul` = 2^-2 must only scale"
+                assert_close(outs[0][0], ref_w, 2e-6, what + ": dW")
+                assert_close(outs[0][1], ref_b, 2e-6, what + ": db")
+    if not tiny:
+        assert L.query("dpx_ffdnet_f16_overflow", 1) == 0
+        big = T(np.full((1, 2, 4, 8, 8), 7.0e4, np.float32), device)          # an operand beyond the binary16 range trips the trap (mode 3 only)
+        gw, gb = torch.empty(16, 16, 3, 3, device=device), torch.empty(16, device=device)
+        ws = torch.empty(L.query("dpx_conv3x3_wgrad_c8_ws_bytes", 16, 16), dtype=torch.uint8, device=device)
+        L.call("dpx_conv3x3_wgrad_c8", be.ptr(big), be.ptr(big), be.ptr(gw), be.ptr(gb), 16, 16, 2, 2, 6, None, 1, 4, 8, be.ptr(ws), be.stream())
+        assert L.query("dpx_ffdnet_f16_overflow", 1) == 0
+        L.call("dpx_conv3x3_wgrad_c8", be.ptr(big), be.ptr(big), be.ptr(gw), be.ptr(gb), 16, 16, 2, 2, 3, None, 1, 4, 8, be.ptr(ws), be.stream())
+        assert L.query("dpx_ffdnet_f16_overflow", 1) == 1
 
 
 def case_ffdnet_weight_grads(device):

@@ -218,6 +218,10 @@ def test_ffdnet_weight_gradients():
     pc.case_ffdnet_weight_grads(DEV)
 
 
+def test_wgrad_c8_kernel():
+    pc.case_wgrad_c8(DEV, tiny=True)
+
+
 def test_ffdnet_split_backward():
     pc.case_ffdnet_split_backward(DEV, tiny=True)
 

@@ -165,6 +165,11 @@ def test_ffdnet_winograd_layers():
 
 
 @pytest.mark.gpu
+def test_wgrad_c8_kernel():
+    pc.case_wgrad_c8(DEV)
+
+
+@pytest.mark.gpu
 def test_ffdnet_split_backward():
     pc.case_ffdnet_split_backward(DEV)
 
