@@ -31,12 +31,12 @@
 namespace dpx {
 
 // Tuning aid (tools/build_variant_one.sh wc_trace dpx_wgrad_c8 -DDPX_WC_TRACE; never in the shipped library): the waves of workgroup 40 stamp the shader
-// clock along their steps 8 .. 11; tools/wgrad_trace.py prints the timeline of the last launch.
+// clock along their jobs 8 .. 11; tools/wgrad_trace.py prints the timeline of the last launch.
 #ifdef DPX_WC_TRACE
 __device__ unsigned long long dpx_wc_trace_buf[8 * 64];
 #define DPX_WC_STAMP(i)                                                                                                                       \
   do {                                                                                                                                       \
-    const long st_ = c - c_begin - 8;                                                                                                        \
+    const long st_ = c - 8;                                                                                                        \
     if (MT == 3 && NT == 3 && lane == 0 && blockIdx.x == 40 && st_ >= 0 && st_ < 4) dpx_wc_trace_buf[wv * 64 + st_ * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
@@ -44,18 +44,21 @@ __device__ unsigned long long dpx_wc_trace_buf[8 * 64];
 #endif
 
 constexpr int WC_WT = 32;                                  // pixels of a gradient row per step (two matrix K-steps of 16)
-constexpr int WC_ROWB = 80;                                // bytes between the channels of a plane row: 40 x 16 bit (A uses 34, G 32)
 constexpr int WC_NW = 8;                                   // waves per workgroup
 
 template <int MT, int NT, int MODE>
 struct WcGeom {
   static constexpr int NPL = MODE == 3 ? 2 : 3, CoP = MT * 32, CiP = NT * 32;
-  static constexpr int GP = NPL * CoP * WC_ROWB, AP = NPL * CiP * WC_ROWB;                 // G planes; one slot of the A ring
-  static constexpr int OFF_A = GP, OFF_RG = OFF_A + 3 * AP, OFF_RA = OFF_RG + (CoP / 8) * 1024, OFF_RE = OFF_RA + (CiP / 8) * 1024;
-  static constexpr int OFF_BS = OFF_RE + 1024;                                              // the bias gradient's running sums: 8 floats per pair-thread of G
+  // bytes between the channels of a plane row (34 pixels of the input row, 32 of the gradient row, 16 bit each): 80 = 20 dwords, conflict-free
+  // 16-byte reads; the three-plane arithmetic takes 72 (a few two-way conflicts) so that its six plane sets still fit the CU's 160 KB
+  static constexpr int ROWB = MODE == 3 ? 80 : 72;
+  static constexpr int GP = NPL * CoP * ROWB, AP = NPL * CiP * ROWB;                         // one set of G planes; one slot of the A ring
+  static constexpr int OFF_A = 2 * GP, OFF_RG = OFF_A + 4 * AP, OFF_RA = OFF_RG + (CoP / 8) * 1024, OFF_RE = OFF_RA + (CiP / 8) * 1024;
+  static constexpr int OFF_BS = OFF_RE + WC_NW * 256;                                       // the bias gradient's running sums: 8 floats per pixel pair of a G group row
   static constexpr int LDS_BYTES = OFF_BS + (CoP / 8) * 16 * 32;
   static constexpr int NTRIP = 3 * NT * MT, BASE = NTRIP / WC_NW, REM = NTRIP % WC_NW;    // whole (mt, nt, dy) triples per wave; left-over triples
   static constexpr int NEX = (3 * REM + WC_NW - 1) / WC_NW, NACC = 3 * BASE + NEX;          // left-over single tiles per wave; accumulators per wave
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 typedef _Float16 wc_f16x2 __attribute__((ext_vector_type(2)));
@@ -79,62 +82,25 @@ __device__ __forceinline__ uint4 wc_shift(const unsigned (&p)[5]) {
 }
 
 // G: C8 [B][Gg][H][W][8] (the gradient w.r.t. the layer's pre-activation output), A: C8 [B][Ga][H][W][8] (the layer's input);
-// part: [gridDim.x][MT NT 9 tiles][1024] (the accumulators' layout, see the epilogue), part_b: [gridDim.x][MT 32][2].  Channels beyond 8 Gg / 8 Ga count as zero.
+// part: [gridDim.x][MT NT 9 tiles][1024] (the accumulators' layout, see the epilogue), part_b: [gridDim.x][MT 32][2].  Channels beyond 8 Gg / 8 Ga
+// count as zero.
 template <int MT, int NT, int MODE>
 __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restrict__ G, const float* __restrict__ A, float* __restrict__ part,
                                                             float* __restrict__ part_b, int Gg, int Ga, int B, int H, int W, int nstrips, long nchunks,
                                                             unsigned* __restrict__ f16_flag) {
   typedef WcGeom<MT, NT, MODE> GM;
-  constexpr int NPL = GM::NPL, CoP = GM::CoP, CiP = GM::CiP, BASE = GM::BASE, REM = GM::REM, NEX = GM::NEX, NACC = GM::NACC;
+  constexpr int NPL = GM::NPL, CoP = GM::CoP, CiP = GM::CiP, BASE = GM::BASE, REM = GM::REM, NEX = GM::NEX, NACC = GM::NACC, ROWB = GM::ROWB;
   HIP_DYNAMIC_SHARED(char, smem_wc)
-  char* const gpl = smem_wc;                                // G planes [plane][co][40 px]
-  char* const apl = smem_wc + GM::OFF_A;                    // A ring: 3 slots of [plane][ci][40 px]; stored pixel s <-> image column x0 + s - 1
-  char* const raw_g = smem_wc + GM::OFF_RG;                 // landing areas (fp32, C8 order): [group][32 px][8]
-  char* const raw_a = smem_wc + GM::OFF_RA;
-  char* const raw_e = smem_wc + GM::OFF_RE;                 // the input row's two outer pixels: [group][left, right][8]
+  char* const gpl = smem_wc;                                // two sets of G planes [plane][co][pixels]
+  char* const apl = smem_wc + GM::OFF_A;                    // A ring: 4 slots of [plane][ci][pixels]; stored pixel s <-> image column x0 + s - 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, kg = lane >> 5;
+  const bool early = wv < 4;                                // (waves w and w + 4 share a SIMD: one stages while the other multiplies)
 
-  // ---- the planes of channels no group covers (and the pad pixels) stay zero
+  // ---- the planes of channels no group covers (and the pad pixels) stay zero; the bias sums start at zero
   for (int i = tid * 16; i < GM::OFF_RG; i += WC_NW * 64 * 16) *(uint4*)(smem_wc + i) = make_uint4(0u, 0u, 0u, 0u);
-
-  // ---- a thread's item of the split pass: a pixel pair of one 8-channel group of the gradient row (16 pairs per group) or of the input
-  // row (17 pairs: stored pixels 0 .. 33).  Recomputed from the thread index in front of every split pass (a dozen integer instructions
-  // against five registers held across the matrix phase, whose 176 accumulators leave none to spare).
-  const int n_gi = Gg * 16, n_ai = Ga * 17;
-  struct Item {
-    bool g_item, a_item;
-    int g, pp, src0, src1, dst_off;                         // group, pair; the pair's two pixels in the landing areas; its dwords' offset in a plane
-  };
-  auto item_of = [&](int tid_) {
-    Item it;
-    it.g_item = tid_ < n_gi;
-    it.a_item = !it.g_item && tid_ - n_gi < n_ai;
-    if (it.g_item) {
-      it.g = tid_ >> 4;
-      it.pp = tid_ & 15;
-      it.src0 = GM::OFF_RG + (it.g * 32 + 2 * it.pp) * 32;
-      it.src1 = it.src0 + 32;
-    } else {
-      const int a = it.a_item ? tid_ - n_gi : 0;
-      it.g = a / 17;
-      it.pp = a - it.g * 17;
-      const int s0 = 2 * it.pp, s1 = s0 + 1;               // stored pixels; s = 0: the left outer pixel, s = 33: the right one, else main pixel s - 1
-      it.src0 = s0 == 0 ? GM::OFF_RE + (it.g * 2) * 32 : GM::OFF_RA + (it.g * 32 + s0 - 1) * 32;
-      it.src1 = s1 == 33 ? GM::OFF_RE + (it.g * 2 + 1) * 32 : GM::OFF_RA + (it.g * 32 + s1 - 1) * 32;
-    }
-    it.dst_off = (it.g * 8) * WC_ROWB + it.pp * 4;
-    return it;
-  };
-  const bool g_item = tid < n_gi;
-  float f16_max = 0.f;
-  // the bias gradient's running sums live in LDS (a private 32-byte slot per pair-thread of G: 8 registers less across the matrix phase)
-  float* const bslot = (float*)(smem_wc + GM::OFF_BS + (g_item ? tid : 0) * 32);
-  if (g_item) {
-    *(float4*)bslot = make_float4(0.f, 0.f, 0.f, 0.f);
-    *(float4*)(bslot + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  for (int i = tid * 16; i < GM::LDS_BYTES - GM::OFF_BS; i += WC_NW * 64 * 16) *(uint4*)(smem_wc + GM::OFF_BS + i) = make_uint4(0u, 0u, 0u, 0u);
 
   // ---- this wave's tiles: triples t = wv BASE + i (i < BASE; BASE == MT: the MT output blocks of ONE (nt, dy) -- one read and one set of
   // shifts of the input operand serve all of them) and left-over tiles j = wv + 8 e of the triples 8 BASE ..; t = (nt 3 + dy) MT + mt
@@ -149,8 +115,8 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
   for (int i = 0; i < BASE; ++i) {
     int mt, nt;
     decode(wv * BASE + i, mt, nt, tr_dy[i]);
-    tr_g[i] = mt * 32 * WC_ROWB;
-    tr_a[i] = nt * 32 * WC_ROWB;
+    tr_g[i] = mt * 32 * ROWB;
+    tr_a[i] = nt * 32 * ROWB;
   }
   int ex_g[NEX > 0 ? NEX : 1], ex_a[NEX > 0 ? NEX : 1], ex_dy[NEX > 0 ? NEX : 1], ex_dx[NEX > 0 ? NEX : 1];   // ex_dx < 0: no such tile
 #pragma unroll
@@ -161,107 +127,161 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
     int mt, nt;
     decode(WC_NW * BASE + jj / 3, mt, nt, ex_dy[e]);
     ex_dx[e] = on ? jj - (jj / 3) * 3 : -1;
-    ex_g[e] = mt * 32 * WC_ROWB;
-    ex_a[e] = nt * 32 * WC_ROWB;
+    ex_g[e] = mt * 32 * ROWB;
+    ex_a[e] = nt * 32 * ROWB;
   }
-  const int lane_off = n * WC_ROWB + kg * 16;              // this lane's channel row and its 8 (+ 2) pixels of a 16-pixel K-step
+  const int lane_off = n * ROWB + kg * 16;                  // this lane's channel row and its 8 (+ 2) pixels of a 16-pixel K-step
 
   f32x16 acc[NACC];
 #pragma unroll
   for (int u = 0; u < NACC; ++u)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
+  float f16_max = 0.f;
 
-  // ---- the walk: chunk c = (b nstrips + xs) H + y, down a strip
+  // ---- the walk.  Real steps c = (b nstrips + xs) H + y go down a strip: step y stages the gradient row y and the input row y + 1 and multiplies
+  // against the input rows y - 1, y, y + 1.  In front of a workgroup's first step and of every strip's first row come two staging-only jobs
+  // (the input rows y - 1 and y), so that the pipeline below never needs a special case: job J stages ONE input row into ring slot J & 3 (and,
+  // if real, one gradient row into plane set J & 1) and a real job reads the slots J - 2, J - 1, J.
+  struct Job {
+    int b, xs, ya, yg;                                      // image, strip, input row (-1 .. H: outside = zeros), gradient row (< 0: none)
+    bool real, valid;
+  };
   const long c_begin = nchunks * blockIdx.x / gridDim.x, c_end = nchunks * (blockIdx.x + 1) / gridDim.x;
-  int y = (int)(c_begin % H), xs = (int)((c_begin / H) % nstrips), b = (int)(c_begin / ((long)H * nstrips));
-  const size_t plane8 = (size_t)H * W * 8;
-
-  // LDS-DMA of one step's rows into the landing areas: whole 1 KB group rows (32 pixels x 32 bytes), dealt to the waves; pixels / rows outside
-  // the image are fetched from the clamped position and zeroed by the split pass
-  auto issue = [&](bool with_g, int b_, int xs_, int yg, int ya) {
-    const int x0 = xs_ * WC_WT;
-    const int px = lane >> 1, half = lane & 1;
-    const int xc = min(x0 + px, W - 1);
-    const unsigned voff = (unsigned)((xc * 8 + half * 4) * 4);
-    const int yac = min(max(ya, 0), H - 1);
-    const int n_i = (with_g ? Gg : 0) + Ga + 1;
-    for (int k = wv; k < ((DPX_WC_DBG & 8) ? 0 : n_i); k += WC_NW) {
-      const int ka = with_g ? k - Gg : k;
-      if (ka < 0) {
-        dpx_glds16_s(G + ((size_t)b_ * Gg + k) * plane8 + (size_t)yg * W * 8, voff, raw_g + k * 1024);
-      } else if (ka < Ga) {
-        dpx_glds16_s(A + ((size_t)b_ * Ga + ka) * plane8 + (size_t)yac * W * 8, voff, raw_a + ka * 1024);
-      } else {
-        const int g = min(lane >> 2, Ga - 1), e = (lane >> 1) & 1;
-        const int x = e ? min(x0 + WC_WT, W - 1) : max(x0 - 1, 0);
-        dpx_glds16_s(A + (size_t)b_ * Ga * plane8, (unsigned)((((size_t)g * H + yac) * W + x) * 32 + half * 16), raw_e);
+  int it_y = (int)(c_begin % H), it_xs = (int)((c_begin / H) % nstrips), it_b = (int)(c_begin / ((long)H * nstrips)), it_warm = 2;
+  long it_left = c_end - c_begin;
+  auto next_job = [&]() {
+    Job j;
+    j.b = it_b;
+    j.xs = it_xs;
+    j.valid = it_left > 0;
+    j.real = false;
+    j.yg = -1;
+    j.ya = 0;
+    if (!j.valid) return j;
+    if (it_warm == 2) {
+      j.ya = it_y - 1;
+      it_warm = 1;
+    } else if (it_warm == 1) {
+      j.ya = it_y;
+      it_warm = 0;
+    } else {
+      j.ya = it_y + 1;
+      j.yg = it_y;
+      j.real = true;
+      --it_left;
+      if (++it_y == H) {
+        it_y = 0;
+        it_warm = 2;
+        if (++it_xs == nstrips) {
+          it_xs = 0;
+          ++it_b;
+        }
       }
     }
+    return j;
   };
 
-  // the split pass of one landed row: fp32 pixel pair x 8 channels -> one dword per channel and plane
-  auto split_item = [&](const Item& it, char* planes, int plane_bytes, bool ok0, bool ok1, bool is_g) {
-    const float4 p0a = *(const float4*)(smem_wc + it.src0), p0b = *(const float4*)(smem_wc + it.src0 + 16);
-    const float4 p1a = *(const float4*)(smem_wc + it.src1), p1b = *(const float4*)(smem_wc + it.src1 + 16);
-    const float v0[8] = {p0a.x, p0a.y, p0a.z, p0a.w, p0b.x, p0b.y, p0b.z, p0b.w};
-    const float v1[8] = {p1a.x, p1a.y, p1a.z, p1a.w, p1b.x, p1b.y, p1b.z, p1b.w};
+  // ---- staging, wave by wave: wave w owns the group rows k = w, w + 8, w + 16 of a job (k < Gg: group k of the gradient row, then the groups
+  // of the input row) -- it fetches them (LDS-DMA, 1 KB = 32 pixels x 8 channels each; the input row's two outer pixels of its groups by one
+  // more instruction), and it alone reads them back: no workgroup barrier between a fetch and its split pass.  Pixels / rows outside the image
+  // are fetched from the clamped position and zeroed by the split pass.
+  const size_t plane8 = (size_t)H * W * 8;
+  auto issue = [&](const Job& jb) {
+    if (DPX_WC_DBG & 8) return;
+    const int x0 = jb.xs * WC_WT;
+    const int xc = min(x0 + (lane >> 1), W - 1);
+    const unsigned voff = (unsigned)((xc * 8 + (lane & 1) * 4) * 4);
+    const int yac = min(max(jb.ya, 0), H - 1);
+    bool any_a = false;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int k = wv + WC_NW * j;
+      if (k < Gg) {
+        if (jb.yg >= 0) dpx_glds16_s(G + ((size_t)jb.b * Gg + k) * plane8 + (size_t)jb.yg * W * 8, voff, smem_wc + GM::OFF_RG + k * 1024);
+      } else if (k < Gg + Ga) {
+        any_a = true;
+        dpx_glds16_s(A + ((size_t)jb.b * Ga + (k - Gg)) * plane8 + (size_t)yac * W * 8, voff, smem_wc + GM::OFF_RA + (k - Gg) * 1024);
+      }
+    }
+    if (any_a && lane < 16) {                               // lanes 4 j .. 4 j + 3: [left, right] outer pixel of piece j's group, two halves each
+      const int kk = wv + WC_NW * (lane >> 2), ka = min(max(kk - Gg, 0), Ga - 1);
+      const int x = (lane & 2) ? min(x0 + WC_WT, W - 1) : max(x0 - 1, 0);
+      const unsigned vo = (((unsigned)ka * (unsigned)H + (unsigned)yac) * (unsigned)W + (unsigned)x) * 32u + (lane & 1) * 16u;
+      dpx_glds16_s(A + (size_t)jb.b * Ga * plane8, vo, smem_wc + GM::OFF_RE + wv * 256);
+    }
+  };
+  // the split pass of this wave's landed group rows: lane = (piece j, pixel pair pp); fp32 pixel pair x 8 channels -> one dword per channel and plane
+  auto split_own = [&](const Job& jb, int J) {
+    if (DPX_WC_DBG & 2) return;
+    int lane_c = lane;
+    DPX_OPAQUE(lane_c);                                     // (the item geometry is recomputed per pass: a dozen integer instructions against registers
+    const int j = lane_c / 17, pp = lane_c - j * 17;        //  held across the matrix phase, whose 176 accumulators leave none to spare)
+    const int k = wv + WC_NW * j;
+    const bool is_g = k < Gg, is_a = !is_g && k < Gg + Ga;
+    if (!((is_g && pp < 16 && jb.yg >= 0) || is_a)) return;
+    const int x0 = jb.xs * WC_WT;
+    int src0, src1, dst;
+    bool ok0, ok1;
     if (is_g) {
-      float4 ba = *(const float4*)bslot, bb = *(const float4*)(bslot + 4);
-      ba.x += (ok0 ? v0[0] : 0.f) + (ok1 ? v1[0] : 0.f);
-      ba.y += (ok0 ? v0[1] : 0.f) + (ok1 ? v1[1] : 0.f);
-      ba.z += (ok0 ? v0[2] : 0.f) + (ok1 ? v1[2] : 0.f);
-      ba.w += (ok0 ? v0[3] : 0.f) + (ok1 ? v1[3] : 0.f);
-      bb.x += (ok0 ? v0[4] : 0.f) + (ok1 ? v1[4] : 0.f);
-      bb.y += (ok0 ? v0[5] : 0.f) + (ok1 ? v1[5] : 0.f);
-      bb.z += (ok0 ? v0[6] : 0.f) + (ok1 ? v1[6] : 0.f);
-      bb.w += (ok0 ? v0[7] : 0.f) + (ok1 ? v1[7] : 0.f);
-      *(float4*)bslot = ba;
-      *(float4*)(bslot + 4) = bb;
+      src0 = GM::OFF_RG + k * 1024 + pp * 64;
+      src1 = src0 + 32;
+      dst = (J & 1) * GM::GP + (k * 8) * ROWB + pp * 4;
+      const int xg = x0 + 2 * pp;
+      ok0 = xg < W;
+      ok1 = xg + 1 < W;
+    } else {
+      const int ka = k - Gg, main = GM::OFF_RA + ka * 1024, edge = GM::OFF_RE + wv * 256 + j * 64;
+      src0 = pp == 0 ? edge : main + (2 * pp - 1) * 32;    // stored pixels 2 pp, 2 pp + 1; s = 0: the left outer pixel, s = 33: the right one, else main pixel s - 1
+      src1 = pp == 16 ? edge + 32 : main + (2 * pp) * 32;
+      dst = GM::OFF_A + (J & 3) * GM::AP + (ka * 8) * ROWB + pp * 4;
+      const int xa = x0 + 2 * pp - 1;
+      const bool row_ok = jb.ya >= 0 && jb.ya < H;
+      ok0 = row_ok && xa >= 0 && xa < W;
+      ok1 = row_ok && xa + 1 < W;
+    }
+    const int plane_bytes = (is_g ? CoP : CiP) * ROWB;
+    const float4 p0a = *(const float4*)(smem_wc + src0), p0b = *(const float4*)(smem_wc + src0 + 16);
+    const float4 p1a = *(const float4*)(smem_wc + src1), p1b = *(const float4*)(smem_wc + src1 + 16);
+    float v0[8] = {p0a.x, p0a.y, p0a.z, p0a.w, p0b.x, p0b.y, p0b.z, p0b.w};
+    float v1[8] = {p1a.x, p1a.y, p1a.z, p1a.w, p1b.x, p1b.y, p1b.z, p1b.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v0[c] = ok0 ? v0[c] : 0.f;
+      v1[c] = ok1 ? v1[c] : 0.f;
+    }
+    if (is_g) {                                             // the bias gradient's running sums: a private 32-byte slot per (group, pixel pair)
+      float* bs = (float*)(smem_wc + GM::OFF_BS + (k * 16 + pp) * 32);
+      float4 ba = *(const float4*)bs, bb = *(const float4*)(bs + 4);
+      ba.x += v0[0] + v1[0];
+      ba.y += v0[1] + v1[1];
+      ba.z += v0[2] + v1[2];
+      ba.w += v0[3] + v1[3];
+      bb.x += v0[4] + v1[4];
+      bb.y += v0[5] + v1[5];
+      bb.z += v0[6] + v1[6];
+      bb.w += v0[7] + v1[7];
+      *(float4*)bs = ba;
+      *(float4*)(bs + 4) = bb;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float a0 = ok0 ? v0[j] : 0.f, a1 = ok1 ? v1[j] : 0.f;
-      char* d = planes + it.dst_off + j * WC_ROWB;
+    for (int c = 0; c < 8; ++c) {
+      char* d = smem_wc + dst + c * ROWB;
       if constexpr (MODE == 3) {
         unsigned hw, lw;
-        split2_f16_pair(a0, a1, hw, lw);
+        split2_f16_pair(v0[c], v1[c], hw, lw);
         *(unsigned*)d = hw;
         *(unsigned*)(d + plane_bytes) = lw;
-        f16_max = fmaxf(f16_max, fmaxf(fabsf(a0), fabsf(a1)));
+        f16_max = fmaxf(f16_max, fmaxf(fabsf(v0[c]), fabsf(v1[c])));
       } else {
         unsigned h0, m0, l0, h1, m1, l1;
-        split3(a0, h0, m0, l0);
-        split3(a1, h1, m1, l1);
+        split3(v0[c], h0, m0, l0);
+        split3(v1[c], h1, m1, l1);
         *(unsigned*)d = pack_hi16(h0, h1);
         *(unsigned*)(d + plane_bytes) = pack_hi16(m0, m1);
         *(unsigned*)(d + 2 * plane_bytes) = pack_hi16(l0, l1);
       }
     }
-  };
-  auto split_a = [&](const Item& it, int xs_, int ya, int slot) {
-    if (!it.a_item) return;
-    const int x0 = xs_ * WC_WT, xa = x0 + 2 * it.pp - 1;    // image column of stored pixel 2 pp
-    const bool row_ok = ya >= 0 && ya < H;
-    split_item(it, apl + slot * GM::AP, CiP * WC_ROWB, row_ok && xa >= 0 && xa < W, row_ok && xa + 1 < W, false);
-  };
-  auto split_g = [&](const Item& it, int xs_) {
-    if (!it.g_item) return;
-    const int xg = xs_ * WC_WT + 2 * it.pp;
-    split_item(it, gpl, CoP * WC_ROWB, xg < W, xg + 1 < W, true);
-  };
-  auto my_item = [&]() {
-    int tid_c = tid;
-    DPX_OPAQUE(tid_c);                                      // (per split pass: the geometry must not be hoisted out of the walk)
-    return item_of(tid_c);
-  };
-  // an input row on its own (the two rows above a strip's first step)
-  auto stage_row = [&](int b_, int xs_, int ya, int slot) {
-    issue(false, b_, xs_, 0, ya);
-    dpx_wait_vm<0>();
-    DPX_LDS_BARRIER();
-    split_a(my_item(), xs_, ya, slot);
-    DPX_LDS_BARRIER();
   };
 
   // one tile: the three (six) products of its K-step
@@ -279,15 +299,22 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
       d = mfma_bf16(gq[0], aq[0], d);
     }
   };
-  auto load_g = [&](int goff, int ks, uint4 (&gq)[3]) {
-    const char* p = gpl + goff + lane_off + ks * 32;
+  auto read16 = [&](const char* p) {                       // 16 bytes of a plane row (rows 72 bytes apart are 8 modulo 16: two 8-byte reads)
+    if constexpr (ROWB % 16 == 0) return *(const uint4*)p;
+    else {
+      const uint2 v = *(const uint2*)p, w = *(const uint2*)(p + 8);
+      return make_uint4(v.x, v.y, w.x, w.y);
+    }
+  };
+  auto load_g = [&](const char* gset, int goff, int ks, uint4 (&gq)[3]) {
+    const char* p = gset + goff + lane_off + ks * 32;
     if constexpr (MODE == 3) {
-      gq[0] = *(const uint4*)p;
+      gq[0] = read16(p);
       gq[1] = wc_scale8(gq[0], 0.015625f);
-      gq[2] = wc_scale8(*(const uint4*)(p + CoP * WC_ROWB), 0.015625f);
+      gq[2] = wc_scale8(read16(p + CoP * ROWB), 0.015625f);
     } else {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) gq[q] = *(const uint4*)(p + q * CoP * WC_ROWB);
+      for (int q = 0; q < 3; ++q) gq[q] = read16(p + q * CoP * ROWB);
     }
   };
   // ten pixels per plane of the lane's input channel; MODE 3: [ah, ah 2^-5, al' 2^-5]
@@ -296,12 +323,12 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
     unsigned raw[NPL][5];
 #pragma unroll
     for (int q = 0; q < NPL; ++q) {
-      const uint4 v = *(const uint4*)(p + q * CiP * WC_ROWB);
+      const uint4 v = read16(p + q * CiP * ROWB);
       raw[q][0] = v.x;
       raw[q][1] = v.y;
       raw[q][2] = v.z;
       raw[q][3] = v.w;
-      raw[q][4] = *(const unsigned*)(p + q * CiP * WC_ROWB + 16);
+      raw[q][4] = *(const unsigned*)(p + q * CiP * ROWB + 16);
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -321,43 +348,11 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
 #pragma unroll
     for (int q = 0; q < 3; ++q) aq[q] = wc_shift<DX>(ar[q]);
   };
-
-  int s0 = 0, s1 = 1, s2 = 2;                               // ring slots of the input rows y - 1, y, y + 1
-  bool fresh = true;
-  for (long c = c_begin; c < c_end; ++c) {
-    if (fresh) {                                            // the first step of this workgroup / of a strip: rows y - 1 and y come on their own
-      stage_row(b, xs, y - 1, s0);
-      stage_row(b, xs, y, s1);
-      issue(true, b, xs, y, y + 1);
-    }
-    DPX_WC_STAMP(0);
-    dpx_wait_vm<0>();
-    DPX_WC_STAMP(1);
-    DPX_LDS_BARRIER();                                      // this step's rows have landed; everybody is done with the previous step's planes
-    DPX_WC_STAMP(2);
-    if (!(DPX_WC_DBG & 2)) {
-      const Item it = my_item();
-      split_g(it, xs);
-      split_a(it, xs, y + 1, s2);
-    }
-    DPX_WC_STAMP(3);
-    DPX_LDS_BARRIER();                                      // planes ready, landing areas free
-    DPX_WC_STAMP(4);
-    const int r0 = s0, r1 = s1, r2 = s2;
+  // the matrix phase of real job J: input rows y - 1, y, y + 1 in ring slots J - 2, J - 1, J; gradient row in plane set J & 1
+  auto matrix_phase = [&](int J) {
+    const char* gset = gpl + (J & 1) * GM::GP;
+    const int r0 = (J - 2) & 3, r1 = (J - 1) & 3, r2 = J & 3;
     auto slot_of = [&](int dy) { return dy == 0 ? r0 : (dy == 1 ? r1 : r2); };   // (selects: an indexed array would live in scratch memory)
-    // the next step's position; its rows travel under this step's matrix instructions
-    int yn = y + 1, xn = xs, bn = b;
-    fresh = false;
-    if (yn == H) {
-      yn = 0;
-      fresh = true;
-      if (++xn == nstrips) {
-        xn = 0;
-        ++bn;
-      }
-    }
-    if (c + 1 < c_end && !fresh) issue(true, bn, xn, yn, yn + 1);
-    DPX_WC_STAMP(5);
 #pragma unroll
     for (int ks = 0; ks < ((DPX_WC_DBG & 1) ? 0 : 2); ++ks) {
       if constexpr (BASE == MT && MT > 1) {
@@ -370,7 +365,7 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
 #pragma unroll
         for (int i = 0; i < BASE; ++i) {
           uint4 gq[3];
-          load_g(tr_g[i], ks, gq);
+          load_g(gset, tr_g[i], ks, gq);
           tile_mma(acc[3 * i + 0], gq, a0);
           tile_mma(acc[3 * i + 1], gq, a1);
           tile_mma(acc[3 * i + 2], gq, a2);
@@ -381,7 +376,7 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
           unsigned ar[3][5];
           uint4 gq[3], aq[3];
           load_a(tr_a[i], slot_of(tr_dy[i]), ks, ar);
-          load_g(tr_g[i], ks, gq);
+          load_g(gset, tr_g[i], ks, gq);
           shifted(std::integral_constant<int, 0>{}, ar, aq);
           tile_mma(acc[3 * i + 0], gq, aq);
           shifted(std::integral_constant<int, 1>{}, ar, aq);
@@ -396,7 +391,7 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
           unsigned ar[3][5];
           uint4 gq[3], aq[3];
           load_a(ex_a[e], slot_of(ex_dy[e]), ks, ar);
-          load_g(ex_g[e], ks, gq);
+          load_g(gset, ex_g[e], ks, gq);
           if (ex_dx[e] == 0) shifted(std::integral_constant<int, 0>{}, ar, aq);
           else if (ex_dx[e] == 1) shifted(std::integral_constant<int, 1>{}, ar, aq);
           else shifted(std::integral_constant<int, 2>{}, ar, aq);
@@ -404,14 +399,40 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
         }
       }
     }
-    DPX_WC_STAMP(6);
-    y = yn;
-    xs = xn;
-    b = bn;
-    const int t = s0;
-    s0 = s1;
-    s1 = s2;
-    s2 = t;
+  };
+
+  // ---- the pipeline: while job J multiplies, job J + 1 is split and job J + 2 travels.  Per SIMD one wave stages first and multiplies afterwards,
+  // the other the other way round: the matrix pipe has work while a wave converts or waits for an LDS-DMA issue slot.  One barrier per job.
+  Job j0 = next_job(), j1 = next_job(), j2 = next_job();
+  issue(j0);
+  dpx_wait_vm<0>();
+  DPX_LDS_BARRIER();                                        // (the zero fill above is complete)
+  split_own(j0, 0);
+  dpx_wait_lds();
+  if (j1.valid) issue(j1);
+  DPX_LDS_BARRIER();
+  auto stage_next = [&](int J) {
+    if (j1.valid) {
+      dpx_wait_vm<0>();                                     // this wave's rows of job J + 1 have landed
+      split_own(j1, J + 1);
+    }
+    dpx_wait_lds();                                         // ... and have been read: their landing areas take job J + 2
+    if (j2.valid) issue(j2);
+  };
+  for (int J = 0; j0.valid; ++J) {
+    const long c = J;
+    DPX_WC_STAMP(0);
+    if (early) stage_next(J);
+    DPX_WC_STAMP(1);
+    if (j0.real) matrix_phase(J);
+    DPX_WC_STAMP(2);
+    if (!early) stage_next(J);
+    DPX_WC_STAMP(3);
+    DPX_LDS_BARRIER();
+    DPX_WC_STAMP(4);
+    j0 = j1;
+    j1 = j2;
+    j2 = next_job();
   }
   if (MODE == 3 && !(f16_max <= 6.0e4f)) atomicOr(f16_flag, 1u);        // (NaN counts: dpx_ffdnet_f16_overflow)
 
@@ -437,21 +458,15 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
       decode(WC_NW * BASE + (wv + WC_NW * e) / 3, mt, nt, dy);
       store_tile(acc[3 * BASE + e], mt, nt, dy * 3 + ex_dx[e]);
     }
-  // bias gradient: the 16 pair-threads of a group are 16 neighbouring lanes
-  if (tid < ((n_gi + 63) & ~63)) {
-    const float4 ba = *(const float4*)bslot, bb = *(const float4*)(bslot + 4);
-    const float bs[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+  // bias gradient of channel tid: its group's 16 pair sums, in a fixed order
+  if (tid < Gg * 8) {
+    const float* bs = (const float*)(smem_wc + GM::OFF_BS) + (tid >> 3) * 16 * 8 + (tid & 7);
+    float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = g_item ? bs[j] : 0.f;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (g_item && (tid & 15) == 0) {
-        float* pb = part_b + ((size_t)blockIdx.x * CoP + (tid >> 4) * 8 + j) * 2;
-        pb[0] = v;
-        pb[1] = 0.f;
-      }
-    }
+    for (int pp = 0; pp < 16; ++pp) v += bs[pp * 8];
+    float* pb = part_b + ((size_t)blockIdx.x * CoP + tid) * 2;
+    pb[0] = v;
+    pb[1] = 0.f;
   }
 }
 
