@@ -51,7 +51,7 @@ struct WcGeom {
   static constexpr int NPL = MODE == 3 ? 2 : 3, CoP = MT * 32, CiP = NT * 32;
   // bytes between the channels of a plane row (34 pixels of the input row, 32 of the gradient row, 16 bit each): 80 = 20 dwords, conflict-free
   // 16-byte reads; the three-plane arithmetic takes 72 (a few two-way conflicts) so that its six plane sets still fit the CU's 160 KB
-  static constexpr int ROWB = MODE == 3 ? 80 : 72;
+  static constexpr int ROWB = NPL == 2 ? 80 : 72;
   static constexpr int GP = NPL * CoP * ROWB, AP = NPL * CiP * ROWB;                         // one set of G planes; one slot of the A ring
   static constexpr int OFF_A = 2 * GP, OFF_RG = OFF_A + 4 * AP, OFF_RA = OFF_RG + (CoP / 8) * 1024, OFF_RE = OFF_RA + (CiP / 8) * 1024;
   static constexpr int OFF_BS = OFF_RE + WC_NW * 256;                                       // the bias gradient's running sums: 8 floats per pixel pair of a G group row
@@ -96,7 +96,6 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, kg = lane >> 5;
-  const bool early = wv < 4;                                // (waves w and w + 4 share a SIMD: one stages while the other multiplies)
 
   // ---- the planes of channels no group covers (and the pad pixels) stay zero; the bias sums start at zero
   for (int i = tid * 16; i < GM::OFF_RG; i += WC_NW * 64 * 16) *(uint4*)(smem_wc + i) = make_uint4(0u, 0u, 0u, 0u);
@@ -187,29 +186,33 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
   // more instruction), and it alone reads them back: no workgroup barrier between a fetch and its split pass.  Pixels / rows outside the image
   // are fetched from the clamped position and zeroed by the split pass.
   const size_t plane8 = (size_t)H * W * 8;
-  auto issue = [&](const Job& jb) {
-    if (DPX_WC_DBG & 8) return;
+  // piece p of this wave's share of job jb: p = 0 .. 2 the group rows k = wv + 8 p, p = 3 the outer pixels of its input groups
+  auto issue_piece = [&](const Job& jb, int p) {
+    if ((DPX_WC_DBG & 8) || !jb.valid) return;
+    char* const rawb = smem_wc;
     const int x0 = jb.xs * WC_WT;
-    const int xc = min(x0 + (lane >> 1), W - 1);
-    const unsigned voff = (unsigned)((xc * 8 + (lane & 1) * 4) * 4);
     const int yac = min(max(jb.ya, 0), H - 1);
-    bool any_a = false;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int k = wv + WC_NW * j;
+    if (p < 3) {
+      const int k = wv + WC_NW * p;
+      const int xc = min(x0 + (lane >> 1), W - 1);
+      const unsigned voff = (unsigned)((xc * 8 + (lane & 1) * 4) * 4);
       if (k < Gg) {
-        if (jb.yg >= 0) dpx_glds16_s(G + ((size_t)jb.b * Gg + k) * plane8 + (size_t)jb.yg * W * 8, voff, smem_wc + GM::OFF_RG + k * 1024);
+        if (jb.yg >= 0) dpx_glds16_s(G + ((size_t)jb.b * Gg + k) * plane8 + (size_t)jb.yg * W * 8, voff, rawb + GM::OFF_RG + k * 1024);
       } else if (k < Gg + Ga) {
-        any_a = true;
-        dpx_glds16_s(A + ((size_t)jb.b * Ga + (k - Gg)) * plane8 + (size_t)yac * W * 8, voff, smem_wc + GM::OFF_RA + (k - Gg) * 1024);
+        dpx_glds16_s(A + ((size_t)jb.b * Ga + (k - Gg)) * plane8 + (size_t)yac * W * 8, voff, rawb + GM::OFF_RA + (k - Gg) * 1024);
+      }
+    } else if (wv + 2 * WC_NW >= Gg && wv < Gg + Ga) {      // (one of k = wv, wv + 8, wv + 16 is an input group)
+      if (lane < 16) {                                      // lanes 4 j .. 4 j + 3: [left, right] outer pixel of piece j's group, two halves each
+        const int kk = wv + WC_NW * (lane >> 2), ka = min(max(kk - Gg, 0), Ga - 1);
+        const int x = (lane & 2) ? min(x0 + WC_WT, W - 1) : max(x0 - 1, 0);
+        const unsigned vo = (((unsigned)ka * (unsigned)H + (unsigned)yac) * (unsigned)W + (unsigned)x) * 32u + (lane & 1) * 16u;
+        dpx_glds16_s(A + (size_t)jb.b * Ga * plane8, vo, rawb + GM::OFF_RE + wv * 256);
       }
     }
-    if (any_a && lane < 16) {                               // lanes 4 j .. 4 j + 3: [left, right] outer pixel of piece j's group, two halves each
-      const int kk = wv + WC_NW * (lane >> 2), ka = min(max(kk - Gg, 0), Ga - 1);
-      const int x = (lane & 2) ? min(x0 + WC_WT, W - 1) : max(x0 - 1, 0);
-      const unsigned vo = (((unsigned)ka * (unsigned)H + (unsigned)yac) * (unsigned)W + (unsigned)x) * 32u + (lane & 1) * 16u;
-      dpx_glds16_s(A + (size_t)jb.b * Ga * plane8, vo, smem_wc + GM::OFF_RE + wv * 256);
-    }
+  };
+  auto issue = [&](const Job& jb) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) issue_piece(jb, p);
   };
   // the split pass of this wave's landed group rows: lane = (piece j, pixel pair pp); fp32 pixel pair x 8 channels -> one dword per channel and plane
   auto split_own = [&](const Job& jb, int J) {
@@ -221,6 +224,7 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
     const bool is_g = k < Gg, is_a = !is_g && k < Gg + Ga;
     if (!((is_g && pp < 16 && jb.yg >= 0) || is_a)) return;
     const int x0 = jb.xs * WC_WT;
+    const char* const rawb = smem_wc;
     int src0, src1, dst;
     bool ok0, ok1;
     if (is_g) {
@@ -241,8 +245,8 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
       ok1 = row_ok && xa + 1 < W;
     }
     const int plane_bytes = (is_g ? CoP : CiP) * ROWB;
-    const float4 p0a = *(const float4*)(smem_wc + src0), p0b = *(const float4*)(smem_wc + src0 + 16);
-    const float4 p1a = *(const float4*)(smem_wc + src1), p1b = *(const float4*)(smem_wc + src1 + 16);
+    const float4 p0a = *(const float4*)(rawb + src0), p0b = *(const float4*)(rawb + src0 + 16);
+    const float4 p1a = *(const float4*)(rawb + src1), p1b = *(const float4*)(rawb + src1 + 16);
     float v0[8] = {p0a.x, p0a.y, p0a.z, p0a.w, p0b.x, p0b.y, p0b.z, p0b.w};
     float v1[8] = {p1a.x, p1a.y, p1a.z, p1a.w, p1b.x, p1b.y, p1b.z, p1b.w};
 #pragma unroll
@@ -401,35 +405,35 @@ __global__ void __launch_bounds__(WC_NW * 64, 1) k_wgrad_c8(const float* __restr
     }
   };
 
-  // ---- the pipeline: while job J multiplies, job J + 1 is split and job J + 2 travels.  Per SIMD one wave stages first and multiplies afterwards,
-  // the other the other way round: the matrix pipe has work while a wave converts or waits for an LDS-DMA issue slot.  One barrier per job.
+  // ---- the pipeline: job J + 1 is split and job J + 2 sent for, then job J multiplies.  One barrier per job.  Measured per job at 96 -> 96
+  // channels (tools/wgrad_trace.py; shader cycles): split pass ~2000, the LDS-DMA issue of the 25 pieces ~1300 (the CU takes ~50 cycles per KB beside
+  // matrix work), matrix phase ~4800 for 3936 cycles of matrix instructions per SIMD, barrier skew ~900.  Measured and dropped (193 - 210 us per
+  // launch, all of them: the three parts do not overlap, whatever the order): one wave of a SIMD staging while the other multiplies (a wave on
+  // its own keeps the matrix pipe 41 % busy, two together 80 %), the LDS-DMA pieces issued between the tiles of the matrix phase (it grows by
+  // what the issue took), two sets of landing areas with the LDS-DMA issued in front of the split pass, the cross terms' scaled operands kept
+  // as third planes instead of the packed multiplications per use.
   Job j0 = next_job(), j1 = next_job(), j2 = next_job();
   issue(j0);
   dpx_wait_vm<0>();
   DPX_LDS_BARRIER();                                        // (the zero fill above is complete)
   split_own(j0, 0);
   dpx_wait_lds();
-  if (j1.valid) issue(j1);
+  issue(j1);
   DPX_LDS_BARRIER();
-  auto stage_next = [&](int J) {
+  for (int J = 0; j0.valid; ++J) {
+    const long c = J;
+    DPX_WC_STAMP(0);
     if (j1.valid) {
       dpx_wait_vm<0>();                                     // this wave's rows of job J + 1 have landed
       split_own(j1, J + 1);
     }
     dpx_wait_lds();                                         // ... and have been read: their landing areas take job J + 2
-    if (j2.valid) issue(j2);
-  };
-  for (int J = 0; j0.valid; ++J) {
-    const long c = J;
-    DPX_WC_STAMP(0);
-    if (early) stage_next(J);
+    issue(j2);
     DPX_WC_STAMP(1);
     if (j0.real) matrix_phase(J);
     DPX_WC_STAMP(2);
-    if (!early) stage_next(J);
-    DPX_WC_STAMP(3);
     DPX_LDS_BARRIER();
-    DPX_WC_STAMP(4);
+    DPX_WC_STAMP(3);
     j0 = j1;
     j1 = j2;
     j2 = next_job();
