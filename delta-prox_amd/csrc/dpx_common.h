@@ -125,7 +125,7 @@ int cg_masked_fft_run(float* x, const float* b, const float* mask, int mask_imag
 enum Tune {
   TUNE_CG_FUSED_MAX_B, TUNE_CG_SPLIT_UPDATE, TUNE_CG_UNFUSED, TUNE_COMM_ALLGATHER_RING, TUNE_ITER_ROWS,
   TUNE_ITER_BAND, TUNE_ITER_R, TUNE_DS_RPB, TUNE_DS_ROW_THREADS,
-  TUNE_DS_COL_THREADS, TUNE_CG_ROWS_PER_WG, TUNE_CG_COLS_PER_WG, TUNE_CG_GRAM_SMALL, TUNE_CG_NO_HINT, TUNE_UNROLL_BWD_STAGED, TUNE_UNROLL_BWD_FOLD_FINISH, TUNE_FFDNET_PRESPLIT, TUNE_CG_WAVE_FFT, TUNE_CONV_TILE_ROWS, TUNE_UNROLL_BWD_BAND, TUNE_WGRAD_F32, TUNE_GENERIC_INTERLEAVED, TUNE_ITER_BAND_MIN_ROWS, TUNE_ITER_PAR_MAX_ROWS, TUNE_UNROLL_BWD_PAR_MAX_ROWS, TUNE_CG_EVENT_WAIT, TUNE_PNP_CG_NO_FOLD, TUNE_COUNT
+  TUNE_DS_COL_THREADS, TUNE_CG_ROWS_PER_WG, TUNE_CG_COLS_PER_WG, TUNE_CG_GRAM_SMALL, TUNE_CG_NO_HINT, TUNE_UNROLL_BWD_STAGED, TUNE_UNROLL_BWD_FOLD_FINISH, TUNE_FFDNET_PRESPLIT, TUNE_CG_WAVE_FFT, TUNE_CONV_TILE_ROWS, TUNE_UNROLL_BWD_BAND, TUNE_GENERIC_INTERLEAVED, TUNE_ITER_BAND_MIN_ROWS, TUNE_ITER_PAR_MAX_ROWS, TUNE_UNROLL_BWD_PAR_MAX_ROWS, TUNE_CG_EVENT_WAIT, TUNE_PNP_CG_NO_FOLD, TUNE_COUNT
 };
 int tune(Tune k);
 

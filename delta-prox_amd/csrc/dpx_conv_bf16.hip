@@ -955,252 +955,18 @@ extern "C" int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigm
 }
 
 // ---- the same backward pass WITH the weight / bias gradients (deep_prior(trainable=True) on the split kernels) -------------------------
-// Forward and backward-data stay on the split kernels (C8 planes); the weight-gradient GEMM is the f32-input kernel of dpx_ffdnet.hip
-// (k_conv3x3_wgrad: fp32 products, fixed-order reduction), which reads planar [B][C][H][W] operands: the two operands of a layer --
-// the gradient w.r.t. its pre-activation output and its saved input -- are copied out of their C8 planes first (k_bx_c8_to_planar: two
-// plane passes per operand; 8 % of the weight-gradient kernel's own time at 2 x 96 x 384 x 384).
+// Forward and backward-data stay on the split kernels (C8 planes); the weight-gradient GEMM of a layer reads the same planes -- the gradient
+// w.r.t. its pre-activation output and its saved input -- in the arithmetic of the backward pass (k_wgrad_c8, dpx_wgrad_c8.hip).  (Round 4 fed
+// planar copies of both operands to a register kernel, k_wgrad_bf16x3: 338 us per 96 -> 96 layer at 2 x 384 x 384 against 157 now.)
 namespace dpx {
-size_t ffd_wgrad_ws_floats(int nc, int in_nc);
-void ffd_launch_wgrad(const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Cin_a, int B, int H2, int W2, float* ws,
-                      hipStream_t s);   // dpx_ffdnet.hip
-}
-// C8 [B][G][H][W][8] -> planar [B][C][H][W] (C <= 8 G): a thread moves the 8 channels of one pixel
-// amax_bits (nullable): the gradient planes of a split-f16 backward pass leave multiplied by the inverse of their scale
-__global__ void k_bx_c8_to_planar(const float* __restrict__ src, float* __restrict__ dst, int B, int G, int C, long hw,
-                                  const unsigned* __restrict__ amax_bits) {
-  const long total = (long)B * G * hw;
-  const float us = bx_grad_unscale(amax_bits);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long p = i % hw;
-    const int g = (int)((i / hw) % G), b = (int)(i / (hw * G));
-    const float4 lo = *(const float4*)(src + i * 8), hi = *(const float4*)(src + i * 8 + 4);
-    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (g * 8 + j < C) dst[((long)b * C + g * 8 + j) * hw + p] = v[j] * us;
-  }
-}
-
-// ---- the weight-gradient GEMM on the 16-bit matrix instruction at fp32 accuracy (split-bf16: six products, as MODE = 6 above) -----------
-//   dW[co][ci][tap] = sum_{b, y, x} G[b][co][y][x] * A[b][ci][y + dy][x + dx]   (zero outside the image),  K = pixels.
-// Both operands are planar here, i.e. K-contiguous for a fixed channel -- what v_mfma_f32_32x32x16_bf16 wants: an operand lane holds 8
-// consecutive K of one row / column.  A wave owns one 32 x 32 (co, ci) tile for all 9 taps (9 accumulators: 144 registers, hence two
-// waves per SIMD; a workgroup is one wave -- a nine-wave workgroup of all tiles would put three waves on one SIMD) and walks a contiguous
-// range of 16-pixel chunks: per chunk it loads 8 pixels of its co row of G and 10 pixels (8 + the two neighbours) of its ci row of A for the
-// rows y - 1, y, y + 1, splits them into three exact bf16 parts in registers, packs the three horizontal shifts, and issues 9 x 6
-// matrix instructions.  No LDS, no barrier.  Partial sums per workgroup, finished by k_wgrad_reduce in a fixed order (the
-// f32-input kernel's hand-over: bit-reproducible run to run).
-constexpr int WGB_NG = 256;                               // workgroups = partial slices (one per CU)
-typedef float wgb_f4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef float wgb_f2 __attribute__((ext_vector_type(2), aligned(4)));
-
-__device__ __forceinline__ uint4 wgb_pack8(const unsigned (&e)[10], int s) {      // elements s .. s + 7 (fp32 words whose low halves are zero)
-  return make_uint4(pack_hi16(e[s], e[s + 1]), pack_hi16(e[s + 2], e[s + 3]), pack_hi16(e[s + 4], e[s + 5]), pack_hi16(e[s + 6], e[s + 7]));
-}
-
-// elements s .. s + 7 of ten packed 16-bit elements (five dwords, element 0 in the low half of p[0]); s = 0, 1, 2
-__device__ __forceinline__ uint4 wgb_shift(const unsigned* p, int s) {
-  if (s == 0) return make_uint4(p[0], p[1], p[2], p[3]);
-  if (s == 2) return make_uint4(p[1], p[2], p[3], p[4]);
-  return make_uint4((p[0] >> 16) | (p[1] << 16), (p[1] >> 16) | (p[2] << 16), (p[2] >> 16) | (p[3] << 16), (p[3] >> 16) | (p[4] << 16));   // (v_alignbit)
-}
-
-// G and A must be readable 16 floats in front of and 32 floats behind their planes (the staging buffers of dpx_ffdnet_backward_bf16_w are
-// padded for it): every load of the loop is an unconditional vector load, pixels outside the image are zeroed by selects -- the
-// bounds-checked element loads of a first version compiled to ~80 branches per step.
-template <int MT, int CW>
-__global__ void __launch_bounds__(CW * 64, 1) k_wgrad_bf16x3(const float* __restrict__ G, const float* __restrict__ A, float* __restrict__ part,
-                                                             float* __restrict__ part_b, int Cout, int Cin_a, int B, int H, int W, int ncx,
-                                                             long nchunks) {
-  constexpr int CoP = MT * 32;
-  const int CiP = (gridDim.y / MT) * 32;
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int mt = blockIdx.y % MT, nt = blockIdx.y / MT;   // (a workgroup: ONE (co, ci) tile; its CW waves walk CW neighbouring column strips)
-  const int n = lane & 31, kg = lane >> 5;
-  const int co = mt * 32 + n, ci = nt * 32 + n;
-  const bool co_ok = co < Cout, ci_ok = ci < Cin_a;
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  float bsum = 0.f;
-  const long c_begin = nchunks * blockIdx.x / gridDim.x, c_end = nchunks * (blockIdx.x + 1) / gridDim.x;
-  // chunk c = ((b ncx + cxg) H + y): the walk goes DOWN a 16-pixel column strip, so the split operands of the input rows y, y + 1 of one
-  // step are the rows y - 1, y of the next: one new input row per step instead of three (a third of the loads and of the split work)
-  int y = (int)(c_begin % H);
-  int cxg = (int)((c_begin / H) % ncx), b = (int)(c_begin / ((long)H * ncx));
-  const long plane = (long)H * W;
-  unsigned rows[3][15];                                   // [row y - 1 + r][plane * 5 + k]: the row's ten pixels xg - 1 .. xg + 8, split, packed in pairs
-  struct Raw {                                            // a step's loads: 8 pixels of the gradient row, 10 of the input row y + 1
-    wgb_f4 g0, g1, a0, a1;
-    wgb_f2 a2;
-  };
-  struct Pos {
-    int xg, nvalid, gvalid;                               // first pixel of this lane's 8; how many of xg - 1 .. xg + 8 / of xg .. xg + 7 lie left of the right edge
-    const float* abase;
-    const float* grow;
-  };
-  auto position = [&](int b_, int cxg_, int y_) {
-    const int cx = cxg_ * CW + wv;
-    const bool strip_ok = cx * 16 < W;                    // (the last group of strips may reach beyond the image: zeros all the way)
-    Pos P;
-    P.xg = strip_ok ? cx * 16 + 8 * kg : 8 * kg;
-    P.nvalid = (strip_ok && ci_ok) ? W - P.xg + 1 : 0;
-    P.gvalid = (strip_ok && co_ok) ? W - P.xg : 0;
-    P.abase = A + ((long)b_ * Cin_a + (ci_ok ? ci : 0)) * plane;
-    P.grow = G + (((long)b_ * Cout + (co_ok ? co : 0)) * H + y_) * W + P.xg;
-    return P;
-  };
-  auto row_ptr = [&](const Pos& P, int yy) { return P.abase + (long)((yy >= 0 && yy < H) ? yy : 0) * W + P.xg - 1; };
-  auto issue = [&](const Pos& P, int y_) {
-    Raw R;
-    const float* ar = row_ptr(P, y_ + 1);
-    R.g0 = *(const wgb_f4*)P.grow;
-    R.g1 = *(const wgb_f4*)(P.grow + 4);
-    R.a0 = *(const wgb_f4*)ar;
-    R.a1 = *(const wgb_f4*)(ar + 4);
-    R.a2 = *(const wgb_f2*)(ar + 8);
-    return R;
-  };
-  // ten pixels of an input row (zeros outside the image) -> three planes of packed pairs
-  auto split_row = [&](const Pos& P, int yy, wgb_f4 q0, wgb_f4 q1, wgb_f2 q2, unsigned (&dst)[15]) {
-    const bool row_ok = yy >= 0 && yy < H;
-    const float v[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
-    unsigned h[10], m[10], l[10];
-#pragma unroll
-    for (int j = 0; j < 10; ++j) split3((row_ok && j < P.nvalid && (j > 0 || P.xg > 0)) ? v[j] : 0.f, h[j], m[j], l[j]);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      dst[k] = pack_hi16(h[2 * k], h[2 * k + 1]);
-      dst[5 + k] = pack_hi16(m[2 * k], m[2 * k + 1]);
-      dst[10 + k] = pack_hi16(l[2 * k], l[2 * k + 1]);
-    }
-  };
-  auto load_row_now = [&](const Pos& P, int yy, unsigned (&dst)[15]) {
-    const float* ar = row_ptr(P, yy);
-    split_row(P, yy, *(const wgb_f4*)ar, *(const wgb_f4*)(ar + 4), *(const wgb_f2*)(ar + 8), dst);
-  };
-  bool fresh = true;
-  Pos P = position(b, cxg, y);
-  Raw R = issue(P, y);                                    // (the loop keeps ONE step of loads in flight: issued behind the split pass of the
-  for (long c = c_begin; c < c_end; ++c) {                //  step before, they travel while its 54 matrix instructions run)
-    if (fresh || y == 0) {                                // (the start of this workgroup's range / of a column strip)
-      load_row_now(P, y - 1, rows[0]);
-      load_row_now(P, y, rows[1]);
-      fresh = false;
-    }
-    split_row(P, y + 1, R.a0, R.a1, R.a2, rows[2]);
-    // ---- this lane's 8 pixels of its output channel's gradient row, split
-    uint4 gf[3];
-    {
-      const float v[8] = {R.g0.x, R.g0.y, R.g0.z, R.g0.w, R.g1.x, R.g1.y, R.g1.z, R.g1.w};
-      unsigned h[10], m[10], l[10];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = j < P.gvalid ? v[j] : 0.f;
-        split3(x, h[j], m[j], l[j]);
-        bsum += x;
-      }
-      gf[0] = wgb_pack8(h, 0);
-      gf[1] = wgb_pack8(m, 0);
-      gf[2] = wgb_pack8(l, 0);
-    }
-    // ---- the next step's position and loads
-    if (++y == H) {
-      y = 0;
-      if (++cxg == ncx) {
-        cxg = 0;
-        ++b;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 1 < c_end) {
-      P = position(b, cxg, y);
-      R = issue(P, y);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // six products per tap, small terms first and the leading product last (as the forward layers' MODE = 6).  (Measured: interleaving
-    // the taps so that an accumulator is not written by consecutive matrix instructions changes nothing.)
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const uint4 ah = wgb_shift(rows[dy], dx), am = wgb_shift(rows[dy] + 5, dx), al = wgb_shift(rows[dy] + 10, dx);   // (the horizontal shift dx - 1)
-        f32x16& d = acc[dy * 3 + dx];
-        d = mfma_bf16(gf[1], am, d);
-        d = mfma_bf16(gf[2], ah, d);
-        d = mfma_bf16(gf[0], al, d);
-        d = mfma_bf16(gf[1], ah, d);
-        d = mfma_bf16(gf[0], am, d);
-        d = mfma_bf16(gf[0], ah, d);
-      }
-#pragma unroll
-    for (int k = 0; k < 15; ++k) {
-      rows[0][k] = rows[1][k];
-      rows[1][k] = rows[2][k];
-    }
-  }
-  // ---- the wave's partial sums (one slice per wave): D layout col = lane & 31 (ci), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) (co)
-  float* dst = part + ((size_t)blockIdx.x * CW + wv) * CoP * CiP * 9;
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * kg;
-      dst[((size_t)(mt * 32 + row) * CiP + nt * 32 + n) * 9 + t] = acc[t][i];
-    }
-  if (nt == 0) part_b[(((size_t)blockIdx.x * CW + wv) * CoP + mt * 32 + n) * 2 + kg] = bsum;
-}
-
-namespace dpx {
-void ffd_launch_wgrad_reduce(const float* part, const float* part_b, float* gw, float* gb, int NG, int CoN, int co0, int Cin, int CoP, int CiP,
-                             const float* mul, hipStream_t s);   // dpx_ffdnet.hip
 size_t wgrad_c8_ws_floats(int cout_max, int cin_max);                // dpx_wgrad_c8.hip
 void launch_wgrad_c8(int mode, const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Gg, int Ga, int B, int H, int W,
                      float* ws, const float* mul, hipStream_t s);
 }
-static size_t wgb_ws_floats(int nc, int in_nc) {
-  const int cop = ((nc > 4 * in_nc ? nc : 4 * in_nc) + 31) / 32 * 32, cip = ((nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1) + 31) / 32 * 32;
-  return (size_t)WGB_NG * cop * cip * 9 + (size_t)WGB_NG * cop * 2;
-}
-// G: [B][Cout][H][W], A: [B][Cin_a][H][W] (planar), gw: [Cout][Cin_w][9], gb: [Cout]; Cout, Cin_w <= 96
-static void launch_wgrad_bf16x3(const float* G, const float* A, float* gw, float* gb, int Cout, int Cin_w, int Cin_a, int B, int H, int W, float* ws,
-                                hipStream_t s) {
-  const int MT = (Cout + 31) / 32, NT = (Cin_w + 31) / 32, CoP = MT * 32, CiP = NT * 32;
-  // a workgroup = CW waves on CW neighbouring 16-pixel column strips of one tile: with CW = 2 the two waves use both halves of every
-  // 128-byte line of their rows while it is in the CU's L1 (the walk goes down the strip: alone, a wave uses 64 bytes of each line it
-  // makes the L2 deliver -- and the kernel is bound by exactly that traffic).  2048 waves in all: eight per CU, two per SIMD.
-  constexpr int CW = 2;
-  const int ncx = ((W + 15) / 16 + CW - 1) / CW;
-  const long nchunks = (long)B * H * ncx;
-  int NG = 2048 / (MT * NT * CW);
-  if (NG * CW > WGB_NG) NG = WGB_NG / CW;
-  if ((long)NG > nchunks) NG = (int)nchunks;
-  float* part = ws;
-  float* part_b = ws + (size_t)NG * CW * CoP * CiP * 9;
-  const dim3 grid(NG, MT * NT), blk(64 * CW);
-#define DPX_WGB(M_, C_) DPX_LAUNCH("k_wgrad_bf16x3", (k_wgrad_bf16x3<M_, C_>), grid, blk, 0, s, G, A, part, part_b, Cout, Cin_a, B, H, W, ncx, nchunks)
-  switch (MT * 4 + CW) {
-    case 5: DPX_WGB(1, 1); break;
-    case 6: DPX_WGB(1, 2); break;
-    case 9: DPX_WGB(2, 1); break;
-    case 10: DPX_WGB(2, 2); break;
-    case 13: DPX_WGB(3, 1); break;
-    default: DPX_WGB(3, 2); break;
-  }
-#undef DPX_WGB
-  NG *= CW;                                               // (partial slices)
-  ffd_launch_wgrad_reduce(part, part_b, gw, gb, NG, Cout, 0, Cin_w, CoP, CiP, nullptr, s);
-}
 
 extern "C" size_t dpx_ffdnet_bf16_bwd_w_ws_bytes(int B, int in_nc, int nc, int H, int W) {
-  const size_t H2 = (H + 1) / 2, W2 = (W + 1) / 2, px = (size_t)B * H2 * W2;
-  const size_t gmax = (size_t)8 * groups16(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1);
-  size_t wg = ffd_wgrad_ws_floats(nc, in_nc) > wgb_ws_floats(nc, in_nc) ? ffd_wgrad_ws_floats(nc, in_nc) : wgb_ws_floats(nc, in_nc);
-  const size_t wc = wgrad_c8_ws_floats(nc > 4 * in_nc ? nc : 4 * in_nc, nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1);
-  if (wc > wg) wg = wc;
-  return dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W) + (2 * (px * gmax + 64) + wg) * sizeof(float);       // (+ 64: the planar copies' guard floats)
+  return dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W) +
+         wgrad_c8_ws_floats(nc > 4 * in_nc ? nc : 4 * in_nc, nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1) * sizeof(float);
 }
 
 // gw[l] [cout_l][cin_l][9], gb[l] [cout_l] (entries may be NULL: that layer's gradients are not wanted); gx, gsigma may be NULL
@@ -1213,7 +979,6 @@ extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsi
   const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
   DPX_REQUIRE((size_t)12 * H2 * W2 * 32 < ((size_t)1 << 32), "dpx_ffdnet_backward_bf16_w: plane %dx%d too large", H, W);
   const size_t px = (size_t)B * H2 * W2;
-  const long hw = (long)H2 * W2;
   const int G0 = groups16(4 * in_nc + 1), Gc = groups16(nc), GL = groups16(4 * in_nc);
   const float* a0 = (const float*)acts;
   const float* hidden = a0 + px * 8 * G0;
@@ -1221,13 +986,8 @@ extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsi
   float* gA = g_last + px * 8 * GL;
   float* gB = gA + px * 8 * Gc;
   float* g_a0 = gB + px * 8 * Gc;
-  // (the planar copies sit 16 floats behind / 48 floats in front of their neighbours: k_wgrad_bf16x3 reads up to 1 float in front of and
-  //  24 floats behind a plane set with unconditional loads)
   char* tail = (char*)ws + bx_bwd_plane_bytes(B, in_nc, nc, H, W);
-  float* planar_g = (float*)((char*)ws + dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W)) + 16;
-  const size_t gmax = (size_t)8 * groups16(nc > 4 * in_nc + 1 ? nc : 4 * in_nc + 1);
-  float* planar_a = planar_g + px * gmax + 64;
-  float* wg_ws = planar_a + px * gmax + 48;
+  float* wg_ws = (float*)((char*)ws + dpx_ffdnet_bf16_bwd_ws_bytes(B, in_nc, nc, H, W));
   const unsigned* amax_bits = launch_bx_pack_gout(mode, gy, g_last, tail, B, in_nc, H, W, H2, W2, GL, s);
   size_t off[64];
   size_t o = 0;
@@ -1242,18 +1002,8 @@ extern "C" int dpx_ffdnet_backward_bf16_w(const float* gy, float* gx, float* gsi
       // `cur`: the gradient w.r.t. forward layer l's pre-activation output (the ReLU mask was applied by backward layer l + 1's epilogue)
       const float* a_l = (l == 0) ? a0 : hidden + (size_t)(l - 1) * px * 8 * Gc;
       const int ga = (l == 0) ? G0 : Gc;
-      // knob wgrad_f32 = 0: k_wgrad_c8 on the C8 planes themselves, in the arithmetic of this backward pass; 1 / 2: planar copies of the two
-      // operands and the f32-input GEMM (k_conv3x3_wgrad) / round 4's split-bf16 kernel (k_wgrad_bf16x3) on them
-      if (tune(TUNE_WGRAD_F32) == 0) {
-        launch_wgrad_c8(mode, cur, a_l, gw[l], gb[l], cout_f, cin_f, gin, ga, B, H2, W2, wg_ws, amax_bits ? (const float*)amax_bits + 1 : nullptr, s);
-      } else {
-        DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * gin * hw, 256, 8192)), dim3(256), 0, s, cur, planar_g, B, gin, cout_f, hw,
-                   amax_bits);
-        DPX_LAUNCH("k_bx_c8_to_planar", k_bx_c8_to_planar, dim3(grid_for((long)B * ga * hw, 256, 8192)), dim3(256), 0, s, a_l, planar_a, B, ga, 8 * ga, hw,
-                   (const unsigned*)nullptr);
-        if (tune(TUNE_WGRAD_F32) == 1) ffd_launch_wgrad(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
-        else launch_wgrad_bf16x3(planar_g, planar_a, gw[l], gb[l], cout_f, cin_f, 8 * ga, B, H2, W2, wg_ws, s);
-      }
+      // (the sums leave multiplied by the inverse gradient scale of a split-f16 pass: word 1 of the tail)
+      launch_wgrad_c8(mode, cur, a_l, gw[l], gb[l], cout_f, cin_f, gin, ga, B, H2, W2, wg_ws, amax_bits ? (const float*)amax_bits + 1 : nullptr, s);
     }
     if (l == 0 && !need_data) break;
     float* dst = (l == 0) ? g_a0 : (((nb - 1 - l) & 1) ? gB : gA);

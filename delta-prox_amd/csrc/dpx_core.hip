@@ -158,7 +158,6 @@ const KnobDef kKnobs[TUNE_COUNT] = {
     {"cg_wave_fft", "DPX_CG_WAVE_FFT", 0, nullptr},
     {"conv_tile_rows", "DPX_CONV_TILE_ROWS", 0, nullptr},
     {"unroll_bwd_band", "DPX_UNROLL_BWD_BAND", 0, nullptr},
-    {"wgrad_f32", "DPX_WGRAD_F32", 0, nullptr},
     {"generic_interleaved", "DPX_GENERIC_INTERLEAVED", 1, nullptr},
     {"iter_band_min_rows", "DPX_ITER_BAND_MIN_ROWS", 0, nullptr},
     {"iter_par_max_rows", "DPX_ITER_PAR_MAX_ROWS", 0, nullptr},

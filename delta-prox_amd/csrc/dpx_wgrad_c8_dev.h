@@ -1,25 +1,29 @@
-// Weight / bias gradients of a 3x3 layer straight from the C8 planes the split kernels read and write (included by dpx_conv_bf16.hip).
+// Weight / bias gradients of a 3x3 layer straight from the C8 planes the split kernels read and write (instantiated by dpx_wgrad_c8.hip).
 //
 //   dW[co][ci][dy][dx] = sum_{b, y, x} G[b][co][y][x] * A[b][ci][y + dy - 1][x + dx - 1]   (zero outside the image),   db[co] = sum G[b][co][y][x]
 //
 // a GEMM whose K axis is the PIXELS: v_mfma_f32_32x32x16_{f16,bf16} wants, per lane, 8 consecutive K of ONE channel, and the C8 layout
 // [B][C/8][H][W][8] keeps 8 CHANNELS of one pixel together.  Round 4's kernel (k_wgrad_bf16x3) therefore read planar copies of both
 // operands (k_bx_c8_to_planar: two extra plane passes per layer), every wave split its own operands (each element of G was split by three
-// waves, each of A by three), and it ran one wave per SIMD at 48 % of its roofline.  Here:
+// waves, each of A by three), and it ran one wave per SIMD at 48 % of its roofline: 268 + 70 us per 96 -> 96 layer at 2 x 384 x 384.  Here:
 //   * a workgroup (8 waves, one per CU, persistent) owns ALL MT x NT x 9 accumulator tiles of the layer -- 81 tiles of 32 x 32 at 96 -> 96
-//     channels, 10 - 11 per wave -- and walks DOWN 32-pixel column strips (K = 32 pixels per step); every element of G and A is fetched
-//     once per workgroup (LDS-DMA of whole 1 KB group rows, nothing through registers), split ONCE, and transposed on its way into the
-//     operand planes: a thread takes a pixel PAIR of one 8-channel group and writes one dword (two pixels of one channel) per channel and
-//     plane -- planes [plane][channel][40 pixels] of 16-bit elements, 80 bytes between channels (conflict-free 16-byte reads);
-//   * the operand of tap (dy, dx) is the input row y + dy - 1 (a ring of three rows in LDS: one new row per step) read at pixels + dx:
-//     ten pixels per lane, the three horizontal shifts by v_alignbit;
+//     channels, 10 - 11 per wave, 176 accumulator registers -- and walks DOWN 32-pixel column strips (K = 32 pixels per step);
+//   * every element of G and A is fetched once per workgroup by LDS-DMA (whole 1 KB group rows: 32 pixels x 8 channels, nothing through
+//     registers), split ONCE, and transposed on its way into the operand planes: a lane takes a pixel PAIR of one 8-channel group and
+//     writes one dword (two pixels of one channel) per channel and plane -- planes [plane][channel][pixels] of 16-bit elements, 80 bytes
+//     between channels (conflict-free 16-byte reads).  The group rows of a step are dealt to the waves, and a wave splits what it fetched
+//     itself: no barrier between a fetch and its split pass, one workgroup barrier per step;
+//   * the operand of tap (dy, dx) is the input row y + dy - 1 (a ring of four rows in LDS: one new row per step) read at pixels + dx:
+//     ten pixels per lane, the three horizontal shifts by v_alignbit, shared by the three output blocks a wave owns;
 //   * MODE 3 (the split-f16 backward pass: G arrives scaled, dpx_conv_bf16.hip "gradient scale"): g = gh + gl' / 2^11, a = ah + al' / 2^11,
 //     three products into ONE accumulator -- gh ah + (gh 2^-6)(al' 2^-5) + (gl' 2^-6)(ah 2^-5): the cross terms' factor 2^-11 is spread over
 //     both operands by packed multiplications (exact above the subnormal range; below it the error is 2^-25 absolute on a term that is
-//     2^-11 of the product).  MODE 6: three exact bf16 planes each, six products (any range).
-//   * partial sums per workgroup, finished by k_wgrad_reduce in a fixed order (bit-reproducible run to run).
+//     2^-11 of the product).  MODE 6: three exact bf16 planes each, six products (any range);
+//   * partial sums per workgroup in the accumulators' own layout (1 KB per store instruction), finished by k_wgrad_c8_reduce in a fixed order
+//     (bit-reproducible run to run).
 // Tiles are dealt to the waves as whole (mt, nt, dy) triples (three dx taps share the operand reads) plus single left-over tiles, so that the
-// two waves of every SIMD carry 20 or 21 of the 81 tiles.
+// two waves of every SIMD carry 20 or 21 of the 81 tiles.  Measured (MI355X, 2 x 96 x 384 x 384): 141 us per launch inside the training step
+// (197 us on random data, whose matrix instructions draw more power: 248 TFLOP/s fp32-equivalent), split-bf16 266 us; DESIGN.md section 8.
 #pragma once
 
 // Tuning probes (wrong results by design; tools/build_variant.sh <name> -DDPX_WC_DBG=<bits>): 1 no matrix phase, 2 no split pass, 4 no partial-sum

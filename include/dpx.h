@@ -99,8 +99,6 @@ int dpx_timing_report(char* buf, size_t cap);
  *                        kernels instead of the one-wave register transforms (same result to round-off)
  *   conv_tile_rows       split-arithmetic 3x3 layers: 8 = 8-row workgroup tiles (two workgroups per CU)      DPX_CONV_TILE_ROWS
  *                        instead of 16-row ones; same results, measured 2 % slower where it could help: off
- *   wgrad_f32            dpx_ffdnet_backward_bf16_w: 1 = the weight-gradient GEMM on the f32-input matrix        DPX_WGRAD_F32
- *                        instruction (k_conv3x3_wgrad) instead of the split-bf16 one (k_wgrad_bf16x3)
  *   generic_interleaved  size-generic transforms (planes off the register-radix path): 1 = passes in place   DPX_GENERIC_INTERLEAVED
  *                        on interleaved LDS images (k_cols_il: eight columns per workgroup; k_rows_r2c_il /
  *                        k_rows_c2r_il: a row per one-wave workgroup); 0 = one LDS line per sequence, two buffers
@@ -581,9 +579,9 @@ size_t dpx_ffdnet_bf16_bwd_ws_bytes(int B, int in_nc, int nc, int H, int W);
 int dpx_ffdnet_backward_bf16(const float* gy, float* gx, float* gsigma, const void* packed_T, const void* acts, int in_nc, int nc, int nb,
                              int mode, int B, int H, int W, void* ws, dpx_stream_t stream);
 /* ... and with the weight / bias gradients (deep_prior(..., trainable=True), reference proxfn/pnp/prior.py:52-60: the denoiser's
- * parameters join the optimiser): forward and backward-data as above on the split kernels, the weight-gradient GEMM of every layer on
- * the f32-input kernel of dpx_ffdnet_backward, fed planar copies of the layer's two C8 operands.  gw[l]: [cout_l][cin_l][9] (cin_0 =
- * 4 in_nc + 1), gb[l]: [cout_l]; gw[l] == NULL skips layer l; gx / gsigma may be NULL.                                       */
+ * parameters join the optimiser): forward and backward-data as above on the split kernels, the weight-gradient GEMM of every layer from
+ * the same C8 planes in the pass's arithmetic (dpx_conv3x3_wgrad_c8 below).  gw[l]: [cout_l][cin_l][9] (cin_0 = 4 in_nc + 1),
+ * gb[l]: [cout_l]; gw[l] == NULL skips layer l; gx / gsigma may be NULL.                                                      */
 size_t dpx_ffdnet_bf16_bwd_w_ws_bytes(int B, int in_nc, int nc, int H, int W);
 /* The weight-gradient kernel of that pass on its own: dW[co][ci][dy][dx] = sum_{b,y,x} g[b][co][y][x] a[b][ci][y+dy-1][x+dx-1] (zero outside
  * the image), db[co] = sum g -- what autograd forms for a 3x3 convolution of network_ffdnet.py:54-68 -- from the C8 planes

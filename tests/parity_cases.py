@@ -1431,21 +1431,18 @@ def case_ffdnet_split_backward(device, tiny=False):
         wres = {}
         from dprox import _backend as be
         # (True: everything on the f32-input kernels; False: split kernels + the weight-gradient kernel on their C8 planes, k_wgrad_c8, in the
-        #  backward pass's arithmetic -- split-f16 on scaled gradients; "c8_bf16x3": the same with a split-bf16 backward pass;
-        #  "gemm_f32" / "planar_bf16x3": planar copies of the operands + the f32-input GEMM / round 4's split-bf16 kernel, knob wgrad_f32 = 1 / 2)
-        knob = {True: 0, False: 0, "c8_bf16x3": 0, "gemm_f32": 1, "planar_bf16x3": 2}
-        for f32 in (True, False, "c8_bf16x3", "gemm_f32", "planar_bf16x3"):
+        #  backward pass's arithmetic -- split-f16 on scaled gradients; "c8_bf16x3": the same with a split-bf16 backward pass)
+        for f32 in (True, False, "c8_bf16x3"):
             col.model.train_f32 = f32 is True
-            col.model.backward_mode = "bf16x3" if f32 in ("c8_bf16x3", "planar_bf16x3") else "auto"
+            col.model.backward_mode = "bf16x3" if f32 == "c8_bf16x3" else "auto"
             col.zero_grad()
             x = T(x0, device).requires_grad_(True)
-            with be.tuned(wgrad_f32=knob[f32]):
-                y = col.denoise(x, T(s0, device))
-                assert ("Split" in y.grad_fn.name()) == (f32 is not True)
-                (y * T(w0, device)).sum().mul(1.0 if f32 is True else 1e-6).backward()       # (a mean loss's magnitudes on the split paths)
+            y = col.denoise(x, T(s0, device))
+            assert ("Split" in y.grad_fn.name()) == (f32 is not True)
+            (y * T(w0, device)).sum().mul(1.0 if f32 is True else 1e-6).backward()       # (a mean loss's magnitudes on the split paths)
             sc = np.float32(1.0 if f32 is True else 1e-6)
             wres[f32] = [p.grad.cpu().numpy() / sc for p in col.model.weights + col.model.biases] + [x.grad.cpu().numpy() / sc]
-        for other in (False, "c8_bf16x3", "gemm_f32", "planar_bf16x3"):
+        for other in (False, "c8_bf16x3"):
             for k, (a_, b_) in enumerate(zip(wres[other], wres[True])):
                 _assert_grad_close(a_, b_, f"split training path ({other}) {shape}: gradient {k} (weights, biases, d/dx)", tol=1e-5)
         col.requires_grad_(False)
