@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU box, variant library built with -DDPX_WC_TRACE (tools/build_variant_one.sh wc_trace dpx_wgrad_c8 -DDPX_WC_TRACE; run with DPX_LIB=...):
-shader-clock timeline of k_wgrad_c8<3, 3, mode> -- the eight waves of workgroup 40 along four steps.  python tools/wgrad_trace.py [mode]"""
+shader-clock timeline of k_wgrad_c8<3, 3, mode> -- the eight waves of workgroup 40 along four jobs (a job = one 32-pixel step of the walk).  python tools/wgrad_trace.py [mode]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "delta-prox_amd")]
@@ -16,7 +16,7 @@ gw, gb = torch.empty(C, C, 3, 3, device="cuda"), torch.empty(C, device="cuda")
 ws = torch.empty(L.query("dpx_conv3x3_wgrad_c8_ws_bytes", C, C), dtype=torch.uint8, device="cuda")
 cdll = L.cdll
 cdll.dpx_dbg_wc_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
-names = ["top", "own DMA landed", "barrier 1", "split done", "barrier 2", "next rows issued", "matrix phase done"]
+names = ["top", "split pass + LDS-DMA issue done", "matrix phase done", "barrier passed"]
 for rep in range(3):
     L.call("dpx_conv3x3_wgrad_c8", be.ptr(g), be.ptr(a), be.ptr(gw), be.ptr(gb), C, C, G, G, mode, None, B, H, W, be.ptr(ws), be.stream())
     torch.cuda.synchronize()
@@ -24,7 +24,7 @@ for rep in range(3):
     assert cdll.dpx_dbg_wc_trace(buf, 512) == 0
     t = np.frombuffer(buf, dtype=np.uint64).reshape(8, 64).astype(np.float64)
     t0 = t[:, 0].min()
-    print(f"run {rep} (mode {mode}): shader-clock cycles (100 MHz counter x ?) since the first wave reached step 8; columns: waves 0..7")
+    print(f"run {rep} (mode {mode}): shader-clock cycles since the first wave reached job 8 of workgroup 40; columns: waves 0..7")
     for st in range(4):
         for i, nm in enumerate(names):
-            print(f"  step {8 + st} {nm:20s} " + " ".join(f"{int(v - t0):7d}" for v in t[:, st * 8 + i]))
+            print(f"  job {8 + st} {nm:32s} " + " ".join(f"{int(v - t0):7d}" for v in t[:, st * 8 + i]))
