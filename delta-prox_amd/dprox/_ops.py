@@ -37,6 +37,17 @@ def fft_table(H, W, device):
     return t
 
 
+_zero_scalars = {}
+
+
+def zero_scalar(device):
+    """a cached 0-d zero on ``device`` (a stand-in for an absent offset in the differentiable path: never written)"""
+    key = str(device)
+    if key not in _zero_scalars:
+        _zero_scalars[key] = torch.zeros((), device=device)
+    return _zero_scalars[key]
+
+
 def workspace(tag, nbytes, device):
     key = (str(device), tag)
     w = _workspaces.get(key)

@@ -230,6 +230,14 @@ class _UnrolledClosed(torch.autograd.Function):
         u = [t.contiguous() for t in u]
         shape, dev = tuple(v[0].shape), v[0].device
         B, C, H, W = shape
+        # schedules handed over as they are -- [T'] vectors (run() does that when every one of them is): their [T, B] tables are ONE copy
+        # kernel here and their gradients two reductions in backward (a table per schedule through _SchedRows: three copies, three reductions
+        # and two more copies when the strided rows become .grad -- in a 1-ms training step)
+        ctx.sched_len = None
+        if rho_tab.ndim == 1:
+            ctx.sched_len = [int(t.shape[0]) for t in (rho_tab, *lam_tabs)]
+            tabs = torch.cat([t[:T].reshape(1, T, 1).expand(1, T, B) for t in (rho_tab, *lam_tabs)])
+            rho_tab, lam_tabs = tabs[0], [tabs[1 + i] for i in range(n)]
         rho_tab = rho_tab.contiguous()
         lam_tabs = [t.contiguous() for t in lam_tabs]
         lin, prx, alp, dd, table, sws = _UnrolledClosed._common(plan, dev, shape)
@@ -292,6 +300,10 @@ class _UnrolledClosed(torch.autograd.Function):
         L.call("dpx_admm_unrolled_backward_bf16" if bf16 else "dpx_admm_unrolled_backward", be.ptr(hist), be.ptr(gxp), gvi, gui, (ctypes.c_void_p * n)(*[t.data_ptr() for t in gv0]),
                (ctypes.c_void_p * n)(*[t.data_ptr() for t in gu0]), be.ptr(g_rho), be.ptr(g_lam), gop, otf, n_off, lin, prx, alp, n,
                be.ptr(rho_tab), lp, T, be.ptr(dd), ctypes.c_float(plan.eps), B, C, H, W, be.ptr(table), be.ptr(sws), be.ptr(ws), be.stream())
+        if ctx.sched_len is not None:                     # [T'] schedules: sum over the images (two reductions; the terms' rows come out contiguous:
+            g_r, g_l = g_rho.sum(dim=1), g_lam.permute(1, 0, 2).sum(dim=2)        # no copy when they become .grad), zero beyond the T iterations run
+            pad = lambda g, m: g if m == T else torch.cat([g, g.new_zeros(m - T)])
+            return (None, None, pad(g_r, ctx.sched_len[0]), *[pad(g_l[i], ctx.sched_len[1 + i]) for i in range(n)], *gv0, *gu0, *g_off)
         return (None, None, g_rho, *[g_lam[:, i] for i in range(n)], *gv0, *gu0, *g_off)
 
 
@@ -308,10 +320,17 @@ def run(plan: DiffPlan, state, rhos, lams, max_iter, diff_offsets):
         v = [_LinApply.apply(lc, x) if (t.grad_fn is None and not t.requires_grad) else t for (lc, _), t in zip(codes, v)]
     closed = tuple(i for i, (_, pc) in enumerate(codes) if pc != be.PROX_EXTERNAL)
     ext = [i for i, (_, pc) in enumerate(codes) if pc == be.PROX_EXTERNAL]
+    doe_otfs = [o for o, _ in plan.doe]
+    one_node = not ext and n > 0 and max_iter > 0 and not doe_otfs and not os.environ.get("DPX_UNROLL_CHAIN")
+    if one_node:
+        # [T'] schedules on the device go to the node as they are (its own single copy / single reduction, see _UnrolledClosed.forward)
+        sched = [rhos] + [lams[fn] for fn in plan.psi]
+        if all(isinstance(t, torch.Tensor) and t.ndim == 1 and t.shape[0] >= max_iter and t.device == dev and t.dtype == torch.float32 for t in sched):
+            out = _UnrolledClosed.apply(plan, max_iter, *sched, *v, *u, *diff_offsets)
+            return out[0], list(out[1:1 + n]), list(out[1 + n:1 + 2 * n])
     rho_tab = _sched_table(rhos, max_iter, B, dev)
     lam_tabs = [_sched_table(lams[fn], max_iter, B, dev) for fn in plan.psi]
-    doe_otfs = [o for o, _ in plan.doe]
-    if not ext and n > 0 and max_iter > 0 and not doe_otfs and not os.environ.get("DPX_UNROLL_CHAIN"):
+    if one_node:
         out = _UnrolledClosed.apply(plan, max_iter, rho_tab, *lam_tabs, *v, *u, *diff_offsets)
         return out[0], list(out[1:1 + n]), list(out[1 + n:1 + 2 * n])
     for it in range(max_iter):

@@ -150,9 +150,9 @@ def lazy_initial_state(solver, x0, plan):
         return None
     n = len(plan.codes)
     v = [torch.empty_like(x0) for _ in range(n)]
-    u = [torch.empty_like(x0) for _ in range(n)]
-    for t in u:
-        t[:, 0, 0, :].zero_()                                  # (row 0 of plane 0 of every IMAGE: sub-batch chains start at any of them)
+    U = torch.empty((n,) + tuple(x0.shape), dtype=x0.dtype, device=x0.device)
+    U[:, :, 0, 0, :].zero_()                                   # (row 0 of plane 0 of every IMAGE: sub-batch chains start at any of them; one
+    u = list(U.unbind(0))                                      #  fill for all terms -- a training step of 1 ms counts its 4-us launches)
     solver._fresh = (x0, v, u, [t._version for t in [x0] + v + u])
     solver._fresh_lazy = True
     return x0, v, u
@@ -576,7 +576,7 @@ class FusedADMM:
                     doe.append((autodiff._FullOtf.apply(P), Yhat))
             plan = autodiff.DiffPlan(self.codes, psi, (t0, c0, t1, c1), FK, otfs, ls_eps(ls), hist_bf16=getattr(s, "unroll_dtype", "f32") == "bf16",
                                      doe=doe)
-            diff_offs = [o if o is not None else torch.zeros((), device=dev) for o in raw_offs]
+            diff_offs = [o if o is not None else ops.zero_scalar(dev) for o in raw_offs]
             if grad_fresh and not doe:
                 plan.fresh_x0 = x0
             elif grad_fresh:                                       # (a trained PSF: the stage-by-stage path reads the state)
