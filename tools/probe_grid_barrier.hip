@@ -58,6 +58,39 @@ __global__ void k_barrier2(unsigned* base, int iters, int work, float* sink) {
   }
   if (acc == 1.2345f) sink[0] = acc;
 }
+// the leanest form: ONE release fence in front of a relaxed arrive, a relaxed spin (no cache invalidation per poll), ONE acquire fence behind it;
+// per-XCD counters + a top counter as above.  dirty != nullptr: every workgroup also writes 48 KB of its own between barriers (a phase of a
+// 3-plane iteration leaves ~12 MB of dirty lines in the L2s that the release has to write back)
+__global__ void k_barrier3(unsigned* base, int iters, int work, float* sink, float* dirty) {
+  unsigned* top = base;
+  unsigned* gen = base + 32;
+  unsigned* mine = base + 64 + 32 * (blockIdx.x & 7);
+  const unsigned per_xcd = (gridDim.x >> 3) + ((blockIdx.x & 7) < (gridDim.x & 7) ? 1u : 0u);
+  float acc = threadIdx.x;
+  for (int i = 0; i < iters; ++i) {
+    for (int w = 0; w < work; ++w) acc = acc * 1.0001f + 0.5f;
+    if (dirty)
+      for (int k = threadIdx.x; k < 12288; k += blockDim.x) dirty[(size_t)blockIdx.x * 12288 + k] = acc + i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned g = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      bool spin = true;
+      if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == per_xcd - 1) {
+        __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 7) {
+          __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          spin = false;
+        }
+      }
+      if (spin) while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g) {}
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+  if (acc == 1.2345f) sink[0] = acc;
+}
 __global__ void k_empty(float* sink, int work) {
   float acc = threadIdx.x;
   for (int w = 0; w < work; ++w) acc = acc * 1.0001f + 0.5f;
@@ -106,6 +139,26 @@ int main() {
         if (rep) printf("two-level grid barrier (one counter per XCD + a top counter), %3d workgroups x 512 threads: %6.2f us per barrier\n", grid, ms * 1e3 / 2000);
       }
     }
+  }
+  {
+    unsigned* b3;
+    float* dirty;
+    CK(hipMalloc(&b3, 4096));
+    CK(hipMalloc(&dirty, (size_t)256 * 12288 * 4));
+    for (int grid : {192, 256})
+      for (int d = 0; d < 2; ++d)
+        for (int rep = 0; rep < 2; ++rep) {
+          CK(hipMemset(b3, 0, 4096));
+          CK(hipEventRecord(e0));
+          hipLaunchKernelGGL(k_barrier3, dim3(grid), dim3(512), 0, 0, b3, 2000, 64, sink, d ? dirty : (float*)nullptr);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep)
+            printf("two-level grid barrier, relaxed atomics + one release / one acquire fence%s, %3d workgroups x 512 threads: %6.2f us per barrier\n",
+                   d ? ", 48 KB written per workgroup in between" : "", grid, ms * 1e3 / 2000);
+        }
   }
   for (int grid : {192, 256}) {
     const int n = 2000;
