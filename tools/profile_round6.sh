@@ -34,6 +34,9 @@ DPX_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 LOCAL_RANK
 python tools/bench_wino.py 8 > $out/wino_vs_direct.log 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probe_grid_barrier.hip -o /tmp/probe_grid_barrier.bin && /tmp/probe_grid_barrier.bin > $out/grid_barrier_probe.log 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probe_wino_prereq.hip -o /tmp/probe_wino_prereq.bin && /tmp/probe_wino_prereq.bin > $out/wino_prereq_probe.log 2>&1
+# round 6: training through the FFDNet prior (split-f16 backward pass, k_wgrad_c8) and the weight-gradient kernel on its own
+python tools/bench_train.py --kernels > $out/train_final.json 2>&1
+(python tools/bench_wgrad.py; python tools/bench_wgrad.py 4 64 320 320; python tools/bench_wgrad.py 2 16 384 384) 2>&1 | grep mode > $out/wgrad_bench.txt
 # matrix-core evidence for the committed convolution kernels
 tools/profile_ffdnet_r3.sh $tag > $out/ffdnet_modes.log 2>&1; cp gpurun_out/ffd_$tag/ffdnet_pmc.json $out/ffdnet_pmc.json; cp gpurun_out/ffd_$tag/kernel_stats.csv $out/ffdnet_kernel_stats.csv
 python -m pytest tests -m gpu -q > $out/gputests.log 2>&1; cp gpurun_out/parity_achieved_gpu.json $out/parity_achieved_gpu.json
