@@ -60,10 +60,12 @@ template <int MT, int NT, int MODE>
 static void launch_wc(const float* G, const float* A, float* part, float* part_b, int Gg, int Ga, int B, int H, int W, int nstrips, long nchunks,
                       int NG, hipStream_t s) {
   typedef WcGeom<MT, NT, MODE> GM;
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr = 0;                   // one bit per device: the opt-in beyond 64 KB is a per-device function attribute
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!(attr >> (dev & 63) & 1ull)) {
     hipFuncSetAttribute((const void*)k_wgrad_c8<MT, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, GM::LDS_BYTES);
-    attr = true;
+    attr |= 1ull << (dev & 63);
   }
   DPX_LAUNCH("k_wgrad_c8", (k_wgrad_c8<MT, NT, MODE>), dim3(NG), dim3(WC_NW * 64), GM::LDS_BYTES, s, G, A, part, part_b, Gg, Ga, B, H, W, nstrips,
              nchunks, f16_overflow_flag());
