@@ -240,6 +240,36 @@ def test_denoiser_state_dicts_follow_the_nn_module_protocol():
         assert torch.equal(solver.psi_fns[0].denoiser.model.weights[3].cpu(), a.ffd.model.weights[3])
 
 
+def test_train_loop_repeats_a_step_whose_split_f16_backward_left_the_range(tmp_path):
+    """dp.train's epoch loop: a backward pass that trips the range trap of the split-f16 FFDNet arithmetic raises F16RangeError out of
+    loss.backward() (be.note_f16_backward: the networks concerned have fallen back to split-bf16 by then) -- the batch is run again, once;
+    a second failure is not swallowed"""
+    from dprox.algo.training import TrainLoop
+    m = torch.nn.Linear(4, 4)
+    loop = TrainLoop(m, savedir=str(tmp_path))
+    x = torch.randn(3, 4)
+    calls = {"step_fn": 0, "fail": 1}
+    real_step = loop.step
+
+    def step_fn(batch):
+        calls["step_fn"] += 1
+        return batch, batch, m(batch)
+
+    def flaky_step(gt, pred):
+        if calls["fail"] > 0:
+            calls["fail"] -= 1
+            raise be.F16RangeError("backward: test")
+        return real_step(gt, pred)
+
+    loop.step = flaky_step
+    with pytest.warns(RuntimeWarning, match="repeating the step"):
+        rec = loop.run_epoch(step_fn, [x, x])
+    assert calls["step_fn"] == 3 and rec["steps"] == 2 and loop.gstep == 2
+    calls["fail"] = 2
+    with pytest.raises(be.F16RangeError), pytest.warns(RuntimeWarning):
+        loop.run_epoch(step_fn, [x])
+
+
 def test_product_does_not_import_the_oracle():
     import subprocess
     import sys
